@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference).
+
+Runs only in the build container (the reference does not travel to the GPU box).  The
+fixtures are data: seeded inputs, the reference's weights for small-width nets and the
+reference's outputs/losses/gradients/updated parameters.  While generating, every oracle
+function is checked against the reference (the oracle is pinned twice: here at generation
+time, and by tests/test_oracle_golden.py from the committed vectors).
+
+    PYTHONDONTWRITEBYTECODE=1 python3 oracle/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("NIRGAN_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, HERE)
+
+from model import networks as ref_networks                              # noqa: E402
+from model.generator_inject import define_G_inject as ref_define_G_inject  # noqa: E402
+from utils.remote_sensing_indices import RemoteSensingIndices as RefRS  # noqa: E402
+import nirgan_oracle as O                                               # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(4)
+
+
+def synth(B, H, W, seed):
+    """SURVEY 8(d) synthetic tiles: rgb = 0.02+0.58U, nir = 0.05+0.75U, embeds ~ N(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    rgb = 0.02 + 0.58 * torch.rand(B, 3, H, W, generator=g)
+    nir = 0.05 + 0.75 * torch.rand(B, 1, H, W, generator=g)
+    emb = torch.randn(B, 256, generator=g)
+    return rgb, nir, emb
+
+
+def sd(net):
+    return {k: v.detach().clone() for k, v in net.state_dict().items()}
+
+
+def npd(prefix, d):
+    return {prefix + k: v.detach().numpy() for k, v in d.items()}
+
+
+def close(a, b, tol=1e-6, what=""):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= tol * max(ref, 1e-30) + 1e-30, f"oracle != reference for {what}: err {err} ref {ref}"
+
+
+def ref_train_batch(netG, netD, rgb, nir, lam_gan=1.0, lam_l1=100.0, lam_rs=0.0, rs_w=None, padding=0,
+                    embeds=None):
+    """The reference's per-batch sequence with its own modules and torch.optim.Adam.
+
+    Order and formulas from model/pix2pix.py:165-257, :485-492 (cannot be imported: Lightning).
+    """
+    crit = ref_networks.GANLoss("lsgan")
+    l1 = torch.nn.L1Loss()
+    optD = torch.optim.Adam(netD.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    optG = torch.optim.Adam(netG.parameters(), lr=2e-4, betas=(0.5, 0.999))
+
+    def fwd(x):
+        if padding:
+            x = torch.nn.functional.pad(x, (padding,) * 4, mode="reflect")
+        y = netG(x) if embeds is None else netG(x, embeds)
+        if padding:
+            y = y[..., padding:-padding, padding:-padding]
+        return y
+
+    res = {}
+    # optimizer_idx 0
+    pred = fwd(rgb)
+    res["pred"] = pred.detach().clone()
+    pf = netD(torch.cat((rgb, pred), 1).detach())
+    pr = netD(torch.cat((rgb, nir), 1))
+    res["d_fake"], res["d_real"] = pf.detach().clone(), pr.detach().clone()
+    lf, lr_ = crit(pf, False), crit(pr, True)
+    loss_d = lf + lr_
+    optD.zero_grad()
+    optG.zero_grad()
+    loss_d.backward()
+    res["loss_D"], res["loss_D_fake"], res["loss_D_real"] = loss_d.detach(), lf.detach(), lr_.detach()
+    res["grads_D"] = {k: p.grad.detach().clone() for k, p in netD.named_parameters()}
+    assert all(p.grad is None or p.grad.abs().max() == 0 for p in netG.parameters())
+    optD.step()
+    res["params_D_after"] = sd(netD)
+    # optimizer_idx 1 (Lightning toggle_optimizer: D params frozen)
+    for p in netD.parameters():
+        p.requires_grad_(False)
+    pred = fwd(rgb)
+    pf = netD(torch.cat((rgb, pred), 1))
+    res["d_fake_gstep"] = pf.detach().clone()
+    l_gan = crit(pf, True)
+    l_l1 = l1(pred, nir)
+    loss_g = l_gan * lam_gan + l_l1 * lam_l1
+    res["loss_G_gan"], res["loss_G_l1"] = l_gan.detach(), l_l1.detach()
+    if lam_rs > 0:
+        l_rs = RefRS(mode="loss", criterion="l1").get_and_weight_losses(rgb, nir, pred, loss_config=rs_w)
+        res["loss_G_rs"] = l_rs.detach()
+        loss_g = loss_g + l_rs * lam_rs
+    optG.zero_grad()
+    loss_g.backward()
+    res["loss_G"] = loss_g.detach()
+    res["grads_G"] = {k: p.grad.detach().clone() for k, p in netG.named_parameters()}
+    optG.step()
+    res["params_G_after"] = sd(netG)
+    for p in netD.parameters():
+        p.requires_grad_(True)
+    return res
+
+
+def check_trainer(pG0, pD0, n_blocks, rgb, nir, res, **kw):
+    embeds = kw.pop("embeds", None)
+    tr = O.OracleTrainer(pG0, pD0, n_blocks, **kw)
+    out = tr.step(rgb, nir, embeds)
+    close(out["loss_D"], res["loss_D"], what="loss_D")
+    close(out["loss_G"], res["loss_G"], what="loss_G")
+    for k, v in res["grads_D"].items():
+        close(tr.last["grads_D"][k], v, 1e-5, "grad D " + k)
+    shadow = O.shadowed_bias_keys("G", n_blocks)
+    for k, v in res["grads_G"].items():
+        if k in shadow:
+            continue
+        close(tr.last["grads_G"][k], v, 1e-5, "grad G " + k)
+    for k, v in res["params_D_after"].items():
+        if k in O.shadowed_bias_keys("D"):
+            continue
+        close(tr.pD[k], v, 1e-6, "param D " + k)
+    for k, v in res["params_G_after"].items():
+        if k in shadow:
+            continue
+        close(tr.pG[k], v, 1e-6, "param G " + k)
+
+
+# ---------------------------------------------------------------- F1: small-width whole nets
+def f1(n_blocks, name, lam_rs=0.0, padding=0, H=32):
+    torch.manual_seed(0)
+    netG = ref_networks.define_G(3, 1, 8, f"resnet_{n_blocks}blocks", "instance", False, "normal", 0.02)
+    netD = ref_networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
+    pG0, pD0 = sd(netG), sd(netD)
+    rgb, nir, _ = synth(2, H, H, 1234)
+    rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333,
+            "lambda_savi": 0.0, "lambda_msavi": 0.0, "lambda_gndvi": 0.0}
+    res = ref_train_batch(netG, netD, rgb, nir, lam_rs=lam_rs, rs_w=rs_w, padding=padding)
+    # oracle cross-check
+    close(O.px_forward(pG0, rgb, n_blocks, padding), res["pred"], what="G forward")
+    close(O.discriminator_forward(pD0, torch.cat((rgb, res["pred"]), 1)), res["d_fake"], what="D fake")
+    close(O.discriminator_forward(pD0, torch.cat((rgb, nir), 1)), res["d_real"], what="D real")
+    check_trainer(pG0, pD0, n_blocks, rgb, nir, res, padding=padding, lambda_rs=lam_rs, rs_weights=rs_w)
+    arrs = {"rgb": rgb.numpy(), "nir": nir.numpy(), "n_blocks": np.int32(n_blocks),
+            "padding": np.int32(padding), "lambda_rs": np.float32(lam_rs)}
+    arrs.update(npd("G0/", pG0))
+    arrs.update(npd("D0/", pD0))
+    for k in ("pred", "d_fake", "d_real", "d_fake_gstep", "loss_D", "loss_D_fake", "loss_D_real", "loss_G",
+              "loss_G_gan", "loss_G_l1", "loss_G_rs"):
+        if k in res:
+            arrs[k] = res[k].numpy()
+    arrs.update(npd("gD/", res["grads_D"]))
+    arrs.update(npd("gG/", res["grads_G"]))
+    arrs.update(npd("D1/", res["params_D_after"]))
+    arrs.update(npd("G1/", res["params_G_after"]))
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name, "loss_D", float(res["loss_D"]), "loss_G", float(res["loss_G"]))
+
+
+# ---------------------------------------------------------------- inject generator
+def ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def f_inject(name):
+    cfg = ns(base_configs=ns(input_nc=3, output_nc=1, ngf=8, netG="resnet_9blocks", norm="instance",
+                             no_dropout=True, init_type="normal", init_gain=0.02),
+             satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
+                        scaling_param=True, scaling_param_init=0.01))
+    torch.manual_seed(0)
+    netG = ref_define_G_inject(cfg)
+    # fc (256 -> 16384) is 4.2 M values: too large for a fixture.  Replace it by a seeded draw that the
+    # tests regenerate (torch CPU generator, same torch build on the GPU box) and store its checksum.
+    g = torch.Generator().manual_seed(4321)
+    with torch.no_grad():
+        netG.fc.weight.copy_(torch.randn(16384, 256, generator=g) * 0.02)
+        netG.fc.bias.copy_(torch.randn(16384, generator=g) * 0.02)
+        netG.scale_param.fill_(0.5)   # large enough that the modulation is visible at 1e-3
+    netD = ref_networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
+    pG0, pD0 = sd(netG), sd(netD)
+    rgb, nir, emb = synth(2, 40, 40, 99)      # non-square-friendly size: inject map is 20x20
+    res = ref_train_batch(netG, netD, rgb, nir, embeds=emb)
+    close(O.generator_inject_forward(pG0, rgb, emb, 9), res["pred"], what="inject forward")
+    check_trainer(pG0, pD0, 9, rgb, nir, res, embeds=emb)
+    arrs = {"rgb": rgb.numpy(), "nir": nir.numpy(), "embeds": emb.numpy(), "fc_seed": np.int64(4321),
+            "fc_weight_sum": pG0["fc.weight"].double().sum().numpy(),
+            "fc_weight_abs": pG0["fc.weight"].double().abs().sum().numpy()}
+    arrs.update(npd("G0/", {k: v for k, v in pG0.items() if not k.startswith("fc.")}))
+    arrs.update(npd("D0/", pD0))
+    for k in ("pred", "loss_D", "loss_G", "loss_G_gan", "loss_G_l1"):
+        arrs[k] = res[k].numpy()
+    gG = res["grads_G"]
+    arrs["g_scale_param"] = gG["scale_param"].numpy()
+    arrs["g_fc_bias"] = gG["fc.bias"].numpy()
+    arrs["g_fc_weight_rows0_8"] = gG["fc.weight"][:8].numpy()
+    arrs["g_fc_weight_sum"] = gG["fc.weight"].double().sum().numpy()
+    arrs["g_fc_weight_abs"] = gG["fc.weight"].double().abs().sum().numpy()
+    arrs.update(npd("gG/", {k: v for k, v in gG.items() if not k.startswith("fc.")}))
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name, "loss_G", float(res["loss_G"]), "dscale", float(gG["scale_param"]))
+
+
+# ---------------------------------------------------------------- F3: loss known-answer tests
+def f3(name):
+    g = torch.Generator().manual_seed(7)
+    pred_d = torch.randn(2, 1, 30, 30, generator=g)
+    crit = ref_networks.GANLoss("lsgan")
+    arrs = {"pred_d": pred_d.numpy()}
+    for real in (True, False):
+        t = crit.get_target_tensor(pred_d, real)
+        assert t.stride() == (0, 0, 0, 0)
+        tag = "real" if real else "fake"
+        arrs["mask_" + tag] = t.contiguous().numpy()
+        p = pred_d.clone().requires_grad_(True)
+        l = crit(p, real)
+        l.backward()
+        arrs["lsgan_" + tag] = l.detach().numpy()
+        arrs["lsgan_grad_" + tag] = p.grad.numpy()
+        close(O.lsgan_loss(pred_d, real), l, what="lsgan")
+        assert torch.equal(O.gan_target_tensor(pred_d, real), t)
+    rgb = 0.05 + 0.95 * torch.rand(2, 3, 64, 64, generator=g)
+    nir = 0.01 + 0.99 * torch.rand(2, 1, 64, 64, generator=g)
+    pred = 0.01 + 0.99 * torch.rand(2, 1, 64, 64, generator=g)
+    arrs.update({"rgb": rgb.numpy(), "nir": nir.numpy(), "pred": pred.numpy()})
+    p = pred.clone().requires_grad_(True)
+    l = torch.nn.L1Loss()(p, nir)
+    l.backward()
+    arrs["l1"], arrs["l1_grad"] = l.detach().numpy(), p.grad.numpy()
+    w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333,
+         "lambda_savi": 0.0, "lambda_msavi": 0.0, "lambda_gndvi": 0.0}
+    for crit_name in ("l1", "l2"):
+        rs = RefRS(mode="loss", criterion=crit_name)
+        p = pred.clone().requires_grad_(True)
+        l = rs.get_and_weight_losses(rgb, nir, p, loss_config=w)
+        l.backward()
+        arrs[f"rs_{crit_name}"], arrs[f"rs_{crit_name}_grad"] = l.detach().numpy(), p.grad.numpy()
+        close(O.rs_weighted_loss(rgb, nir, pred, w, crit_name), l, what="rs " + crit_name)
+        d = rs.get_and_weight_losses(rgb, nir, pred, mode="logging_dict")
+        od = O.rs_logging_dict(rgb, nir, pred, crit_name)
+        for k, v in d.items():
+            arrs[f"rslog_{crit_name}/{k}"] = v.numpy()
+            close(od[k], v, what=k)
+    # default loss_config (None) path
+    l = RefRS().get_and_weight_losses(rgb, nir, pred)
+    arrs["rs_default"] = l.numpy()
+    close(O.rs_weighted_loss(rgb, nir, pred), l, what="rs default")
+    # index mode
+    rsi = RefRS(mode="index")
+    oi = O.rs_index_pairs(rgb, nir, pred, "index")
+    for nm, fn in (("ndvi", rsi.ndvi_calculation), ("ndwi", rsi.ndwi_calculation), ("evi", rsi.evi_calculation),
+                   ("gndvi", rsi.gndvi_calculation), ("savi", rsi.savi_calculation), ("msavi", rsi.msavi_calculation)):
+        a, b = fn(rgb, nir, pred)
+        close(oi[nm][0], a, what=nm)
+        close(oi[nm][1], b, what=nm)
+        arrs[f"index_{nm}_pred"] = b.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name)
+
+
+# ---------------------------------------------------------------- F5: full-size checksums
+def f5(name):
+    arrs = {}
+    for nb in (6, 9):
+        torch.manual_seed(0)
+        netG = ref_networks.define_G(3, 1, 64, f"resnet_{nb}blocks", "instance", False, "normal", 0.02)
+        rgb, _, _ = synth(1, 256, 256, 1234)
+        with torch.no_grad():
+            y = netG(rgb)
+            close(O.generator_forward(sd(netG), rgb, nb), y, what=f"full G{nb}")
+        gi = torch.Generator().manual_seed(5)
+        idx = torch.randint(0, 256 * 256, (64,), generator=gi)
+        arrs[f"g{nb}_stats"] = np.array([y.mean(), y.std(), y.min(), y.max()], dtype=np.float64)
+        arrs[f"g{nb}_idx"] = idx.numpy()
+        arrs[f"g{nb}_samples"] = y.flatten()[idx].numpy()
+        arrs[f"g{nb}_nparams"] = np.int64(sum(p.numel() for p in netG.parameters()))
+        arrs[f"g{nb}_wsum"] = np.float64(sum(p.detach().double().sum() for p in netG.parameters()))
+    torch.manual_seed(0)
+    netD = ref_networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
+    x = torch.cat(synth(1, 256, 256, 1234)[:2], 1)
+    with torch.no_grad():
+        y = netD(x)
+        close(O.discriminator_forward(sd(netD), x), y, what="full D")
+    arrs["d_out"] = y.numpy()
+    arrs["d_nparams"] = np.int64(sum(p.numel() for p in netD.parameters()))
+    arrs["d_wsum"] = np.float64(sum(p.detach().double().sum() for p in netD.parameters()))
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name)
+
+
+if __name__ == "__main__":
+    f1(6, "f1_g6_d.npz")
+    f1(9, "f1_g9_rs_pad.npz", lam_rs=1.0, padding=10, H=40)
+    f_inject("f1_inject.npz")
+    f3("f3_losses.npz")
+    f5("f5_fullsize.npz")

@@ -1,0 +1,346 @@
+"""CPU oracle for the NIR-GAN Pix2Pix hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (plain PyTorch fp32 functional ops) of the reference's
+RGB->NIR Pix2Pix train/inference path.  It is the checker the HIP path is compared with;
+it is never the thing measured or shipped.  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import it.  The product path
+(``nir-gan_amd/``) never imports anything under ``oracle/``.
+
+Parity pin: the reference has no tests or golden vectors of its own, so
+this oracle is pinned by outputs of the reference itself: ``oracle/make_golden.py`` imports
+``/root/reference/model/networks.py``, ``model/generator_inject.py`` and
+``utils/remote_sensing_indices.py`` in the build container, runs them on seeded inputs and
+commits inputs + expected outputs under ``tests/golden/``; ``tests/test_oracle_golden.py``
+checks every function here against those vectors.  Parts of the path that live in
+``model/pix2pix.py`` (not importable: needs pytorch_lightning/omegaconf/wandb/kornia) are
+restated from the source text and are "parity unpinned" beyond the fixtures of the
+functions they call; they are marked [text] below.
+
+Parameters are plain dicts keyed by the reference's ``state_dict`` names
+(``model.1.weight`` ...), tensors in the reference's layouts (Conv2d ``Cout,Cin,kh,kw``,
+ConvTranspose2d ``Cin,Cout,kh,kw``, Linear ``out,in``).
+
+All ``file:line`` citations are relative to the reference repository root.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+IN_EPS = 1e-5  # torch.nn.InstanceNorm2d default eps (model/networks.py:30)
+
+
+# --------------------------------------------------------------------------------------
+# key layout of the reference Sequential (model/networks.py:341-374, 559-580)
+# --------------------------------------------------------------------------------------
+def generator_keys(n_blocks: int) -> dict:
+    """Indices of the parametrised entries of ResnetGenerator.model (networks.py:341-370)."""
+    first = 1                      # [0] ReflectionPad2d(3) [1] Conv7x7 [2] IN [3] ReLU
+    down = [4, 7]                  # Conv3x3 s2, IN, ReLU  (x2)
+    blocks = list(range(10, 10 + n_blocks))
+    up0 = 10 + n_blocks            # ConvT, IN, ReLU (x2)
+    up = [up0, up0 + 3]
+    last = up0 + 7                 # ReflectionPad2d(3) at up0+6, Conv7x7 at up0+7, Tanh
+    return {"first": first, "down": down, "blocks": blocks, "up": up, "last": last}
+
+
+DISC_CONV_IDX = [0, 2, 5, 8, 11]   # NLayerDiscriminator(n_layers=3) (networks.py:559-580)
+
+
+def _inorm(x: torch.Tensor) -> torch.Tensor:
+    # InstanceNorm2d(affine=False, track_running_stats=False): networks.py:30
+    return F.instance_norm(x, eps=IN_EPS)
+
+
+# --------------------------------------------------------------------------------------
+# generator (model/networks.py:316-374, ResnetBlock :377-434)
+# --------------------------------------------------------------------------------------
+def generator_trunk_head(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model[:6] of the reference: pad3, conv7, IN, ReLU, conv3 s2, IN (generator_inject.py:107)."""
+    x = F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), p["model.1.weight"], p["model.1.bias"])
+    x = F.relu(_inorm(x))
+    x = F.conv2d(x, p["model.4.weight"], p["model.4.bias"], stride=2, padding=1)
+    return _inorm(x)
+
+
+def generator_trunk_tail(p: Params, x: torch.Tensor, n_blocks: int) -> torch.Tensor:
+    """model[6:] of the reference: ReLU, conv3 s2, IN, ReLU, blocks, 2x convT, pad3, conv7, tanh."""
+    k = generator_keys(n_blocks)
+    x = F.relu(x)
+    x = F.conv2d(x, p["model.7.weight"], p["model.7.bias"], stride=2, padding=1)
+    x = F.relu(_inorm(x))
+    for i in k["blocks"]:          # ResnetBlock.forward: out = x + conv_block(x) (networks.py:430-434)
+        h = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"),
+                     p[f"model.{i}.conv_block.1.weight"], p[f"model.{i}.conv_block.1.bias"])
+        h = F.relu(_inorm(h))
+        h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"),
+                     p[f"model.{i}.conv_block.5.weight"], p[f"model.{i}.conv_block.5.bias"])
+        x = x + _inorm(h)
+    for i in k["up"]:              # ConvTranspose2d k3 s2 p1 op1 (networks.py:360-363)
+        x = F.conv_transpose2d(x, p[f"model.{i}.weight"], p[f"model.{i}.bias"],
+                               stride=2, padding=1, output_padding=1)
+        x = F.relu(_inorm(x))
+    i = k["last"]
+    x = F.conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), p[f"model.{i}.weight"], p[f"model.{i}.bias"])
+    return torch.tanh(x)
+
+
+def generator_forward(p: Params, x: torch.Tensor, n_blocks: int) -> torch.Tensor:
+    """ResnetGenerator.forward (networks.py:372-374)."""
+    return generator_trunk_tail(p, generator_trunk_head(p, x), n_blocks)
+
+
+def inject_modulation(p: Params, x: torch.Tensor, embeds: torch.Tensor, style: str = "multiply",
+                      use_scale: bool = True) -> torch.Tensor:
+    """The SatCLIP injection of ResnetGenerator_inject.forward (generator_inject.py:110-127).
+
+    x: B x C x H x W (post-IN, pre-ReLU).  embeds: B x 256.
+    """
+    e = F.linear(embeds, p["fc.weight"], p["fc.bias"])            # :110
+    e = e.view(-1, 1, 128, 128)                                  # :113
+    # NB the reference passes size=(x.shape[-1], x.shape[-2]) i.e. (W, H)            # :116
+    e = F.interpolate(e, size=(x.shape[-1], x.shape[-2]), mode="bilinear", align_corners=False)
+    e = e.repeat(1, x.shape[-3], 1, 1)                            # :119
+    if style == "add":                                            # :122-123
+        return x + p["scale_param"] * e
+    if style == "multiply" and use_scale:                         # :124-125
+        return x * (1 + p["scale_param"] * e)
+    if style == "multiply":                                       # :126-127
+        return x * e
+    raise NotImplementedError(style)
+
+
+def generator_inject_forward(p: Params, x: torch.Tensor, embeds: torch.Tensor, n_blocks: int = 9,
+                             style: str = "multiply", use_scale: bool = True,
+                             post_correction: bool = False) -> torch.Tensor:
+    """ResnetGenerator_inject.forward (generator_inject.py:105-135)."""
+    h = generator_trunk_head(p, x)
+    h = inject_modulation(p, h, embeds, style, use_scale)
+    out = generator_trunk_tail(p, h, n_blocks)
+    if post_correction:                                           # :133-134
+        out = out * p["post_correction_param"]
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# discriminator (model/networks.py:539-584)
+# --------------------------------------------------------------------------------------
+def discriminator_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """NLayerDiscriminator(n_layers=3).forward: 70x70 PatchGAN, no sigmoid."""
+    x = F.leaky_relu(F.conv2d(x, p["model.0.weight"], p["model.0.bias"], stride=2, padding=1), 0.2)
+    for i, s in ((2, 2), (5, 2), (8, 1)):
+        x = F.conv2d(x, p[f"model.{i}.weight"], p[f"model.{i}.bias"], stride=s, padding=1)
+        x = F.leaky_relu(_inorm(x), 0.2)
+    return F.conv2d(x, p["model.11.weight"], p["model.11.bias"], stride=1, padding=1)
+
+
+# --------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------
+def gan_target_tensor(pred: torch.Tensor, target_is_real: bool,
+                      real_label: float = 1.0, fake_label: float = 0.0) -> torch.Tensor:
+    """GANLoss.get_target_tensor (networks.py:241-256): 0-dim fp32 label expanded to pred's shape."""
+    lab = torch.tensor(real_label if target_is_real else fake_label, dtype=torch.float32)
+    return lab.expand_as(pred)
+
+
+def lsgan_loss(pred: torch.Tensor, target_is_real: bool) -> torch.Tensor:
+    """GANLoss('lsgan').__call__ (networks.py:258-276): MSELoss, mean over all elements."""
+    return F.mse_loss(pred, gan_target_tensor(pred, target_is_real))
+
+
+def l1_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """torch.nn.L1Loss() (pix2pix.py:60, used :222)."""
+    return F.l1_loss(pred, target)
+
+
+def _crit(name: str):
+    if name == "l1":
+        return F.l1_loss
+    if name == "l2":
+        return F.mse_loss
+    raise NotImplementedError(name)
+
+
+def rs_index_pairs(rgb, nir, pred, mode: str = "loss") -> dict:
+    """All six spectral indices for (nir, pred) (remote_sensing_indices.py:84-319).
+
+    mode 'loss' uses the reference's epsilons (ndvi/ndwi/evi only); 'index' none.
+    """
+    eps = 1e-6 if mode == "loss" else 0.0
+    red, green, blue = rgb[:, 0:1], rgb[:, 1:2], rgb[:, 2:3]
+    out = {}
+    out["ndvi"] = ((nir - red) / (nir + red + eps), (pred - red) / (pred + red + eps))           # :109-111
+    out["ndwi"] = ((nir - green) / (nir + green + eps), (pred - green) / (pred + green + eps))   # :148-151
+    nd, ndp = (nir - red) / (nir + red), (pred - red) / (pred + red)                             # :186-187
+    out["gndvi"] = ((nir - green) / (nd + green), (pred - green) / (ndp + green))                # :190-191
+    out["savi"] = (1.5 * (nir - red) / (nir + red + 0.5), 1.5 * (pred - red) / (pred + red + 0.5))  # :226-227
+    out["msavi"] = ((2 * nir + 1 - torch.sqrt((2 * nir + 1) ** 2 - 8 * (nir - red))) / 2,
+                    (2 * pred + 1 - torch.sqrt((2 * pred + 1) ** 2 - 8 * (pred - red))) / 2)     # :263-264
+    l, c1, c2, g = 1, 6, 7.5, 2.5                                                                # :295
+    if mode == "loss":
+        den = (nir + c1) * (red - c2) * (blue + l) + 1e-6                                        # :304-305
+        denp = (pred + c1) * (red - c2) * (blue + l) + 1e-6
+    else:
+        den = (nir + c1) * (red - c2) * (blue + l)                                               # :313-314
+        denp = (pred + c1) * (red - c2) * (blue + l)
+    out["evi"] = (g * ((nir - red) / den), g * ((pred - red) / denp))
+    return out
+
+
+RS_ORDER = ["ndvi", "ndwi", "gndvi", "savi", "msavi", "evi"]   # dict order of loss_fns (:45-52)
+RS_DEFAULT = {"lambda_ndvi": 0.333, "lambda_ndwi": 0.333, "lambda_evi": 0.333,
+              "lambda_savi": 0.0, "lambda_msavi": 0.0, "lambda_gndvi": 0.0}   # :37-43
+
+
+def rs_weighted_loss(rgb, nir, pred, loss_config: Optional[dict] = None, criterion: str = "l1"):
+    """RemoteSensingIndices('loss', criterion).get_and_weight_losses(mode='loss') (:23-61)."""
+    cfg = RS_DEFAULT if loss_config is None else loss_config
+    crit = _crit(criterion)
+    idx = rs_index_pairs(rgb, nir, pred, "loss")
+    total = 0.0
+    for name in RS_ORDER:
+        w = cfg.get("lambda_" + name, 0.0)
+        if w > 0.0:
+            a, b = idx[name]
+            total = total + w * crit(a, b)
+    return total
+
+
+def rs_logging_dict(rgb, nir, pred, criterion: str = "l1") -> dict:
+    """get_and_weight_losses(mode='logging_dict') (:63-68)."""
+    crit = _crit(criterion)
+    idx = rs_index_pairs(rgb, nir, pred, "loss")
+    return {f"indices_loss/{n}_error": crit(*idx[n]) for n in RS_ORDER}
+
+
+# --------------------------------------------------------------------------------------
+# Px2Px_PL orchestration  [text: model/pix2pix.py is not importable here]
+# --------------------------------------------------------------------------------------
+def px_forward(pG: Params, rgb: torch.Tensor, n_blocks: int, padding: int = 0,
+               embeds: Optional[torch.Tensor] = None, inject_cfg: Optional[dict] = None) -> torch.Tensor:
+    """Px2Px_PL.forward (pix2pix.py:88-110): reflect-pad -> netG -> crop."""
+    x = rgb
+    if padding:
+        x = F.pad(x, (padding,) * 4, mode="reflect")                      # :91-93
+    if embeds is None:
+        y = generator_forward(pG, x, n_blocks)                            # :97
+    else:
+        c = inject_cfg or {}
+        y = generator_inject_forward(pG, x, embeds, n_blocks, c.get("style", "multiply"),
+                                     c.get("use_scale", True), c.get("post_correction", False))  # :102
+    if padding:
+        y = y[..., padding:-padding, padding:-padding]                    # :107-108
+    return y
+
+
+def d_step_loss(pD: Params, rgb, nir, pred) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """optimizer_idx 0 (pix2pix.py:195-212): loss_D = MSE(D(fake.detach()),0) + MSE(D(real),1), no 0.5."""
+    pred_fake = discriminator_forward(pD, torch.cat((rgb, pred), 1).detach())
+    loss_fake = lsgan_loss(pred_fake, False)
+    pred_real = discriminator_forward(pD, torch.cat((rgb, nir), 1))
+    loss_real = lsgan_loss(pred_real, True)
+    return loss_fake + loss_real, loss_fake, loss_real
+
+
+def g_step_loss(pD: Params, rgb, nir, pred, lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0,
+                rs_weights: Optional[dict] = None, rs_criterion: str = "l1") -> Tuple[torch.Tensor, dict]:
+    """optimizer_idx 1 (pix2pix.py:215-257)."""
+    pred_fake = discriminator_forward(pD, torch.cat((rgb, pred), 1))
+    l_gan = lsgan_loss(pred_fake, True)                                   # :220
+    l_l1 = l1_loss(pred, nir)                                             # :222
+    loss = l_gan * lambda_gan + l_l1 * lambda_l1                          # :226-229
+    parts = {"gan": l_gan, "l1": l_l1}
+    if lambda_rs > 0.0:                                                   # :246-251
+        l_rs = rs_weighted_loss(rgb, nir, pred, rs_weights, rs_criterion)
+        loss = loss + l_rs * lambda_rs
+        parts["rs"] = l_rs
+    return loss, parts
+
+
+def adam_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int,
+              lr=2e-4, b1=0.5, b2=0.999, eps=1e-8) -> None:
+    """torch.optim.Adam single-tensor update (pix2pix.py:486-487; torch defaults eps=1e-8, wd=0).
+
+    In place on p, m, v; ``step`` is the 1-based step count AFTER increment.
+    """
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+class OracleTrainer:
+    """One batch of the reference's two-optimizer loop, restated on CPU.  [text]
+
+    Order (pix2pix.py:165-257, :485-492 and Lightning 1.9 multi-optimizer loop):
+    optimizer 0 = D: G forward, loss_D, backward (grads of D only: fake is detached), Adam(D);
+    optimizer 1 = G: G forward again, D frozen (toggle_optimizer), loss_G, backward, Adam(G).
+    """
+
+    def __init__(self, pG: Params, pD: Params, n_blocks: int, padding: int = 0,
+                 lr=2e-4, beta1=0.5, lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0,
+                 rs_weights: Optional[dict] = None, rs_criterion="l1", inject_cfg: Optional[dict] = None):
+        self.pG = {k: v.detach().clone().requires_grad_(True) for k, v in pG.items()}
+        self.pD = {k: v.detach().clone().requires_grad_(True) for k, v in pD.items()}
+        self.n_blocks, self.padding = n_blocks, padding
+        self.lr, self.beta1 = lr, beta1
+        self.lam = (lambda_gan, lambda_l1, lambda_rs)
+        self.rs_weights, self.rs_criterion = rs_weights, rs_criterion
+        self.inject_cfg = inject_cfg
+        self.state = {id(t): (torch.zeros_like(t), torch.zeros_like(t)) for t in
+                      list(self.pG.values()) + list(self.pD.values())}
+        self.step_count = 0
+        self.last = {}
+
+    def _adam(self, params: Params, grads: dict):
+        for k, t in params.items():
+            g = grads[k]
+            if g is None:
+                continue
+            m, v = self.state[id(t)]
+            with torch.no_grad():
+                adam_step(t, g, m, v, self.step_count, self.lr, self.beta1)
+
+    def step(self, rgb, nir, embeds=None) -> dict:
+        self.step_count += 1
+        lg, l1w, lrs = self.lam
+        # ---- optimizer_idx 0: discriminator
+        pred = px_forward(self.pG, rgb, self.n_blocks, self.padding, embeds, self.inject_cfg)
+        loss_d, lf, lr_ = d_step_loss(self.pD, rgb, nir, pred)
+        gD = torch.autograd.grad(loss_d, list(self.pD.values()))
+        gD = dict(zip(self.pD.keys(), gD))
+        self._adam(self.pD, gD)
+        # ---- optimizer_idx 1: generator (D frozen, already updated)
+        pred = px_forward(self.pG, rgb, self.n_blocks, self.padding, embeds, self.inject_cfg)
+        pD_frozen = {k: v.detach() for k, v in self.pD.items()}
+        loss_g, parts = g_step_loss(pD_frozen, rgb, nir, pred, lg, l1w, lrs, self.rs_weights, self.rs_criterion)
+        gG = torch.autograd.grad(loss_g, list(self.pG.values()), allow_unused=True)
+        gG = dict(zip(self.pG.keys(), gG))
+        self._adam(self.pG, gG)
+        self.last = {"pred": pred.detach(), "grads_D": gD, "grads_G": gG}
+        out = {"loss_D": loss_d.detach(), "loss_D_fake": lf.detach(), "loss_D_real": lr_.detach(),
+               "loss_G": loss_g.detach()}
+        out.update({"loss_G_" + k: v.detach() for k, v in parts.items()})
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# weight construction in the reference's RNG order (networks.py:68-117)
+# --------------------------------------------------------------------------------------
+def shadowed_bias_keys(net: str, n_blocks: int = 6) -> set:
+    """Biases that feed an InstanceNorm directly (mathematically dead; SURVEY section 7 hard parts)."""
+    if net == "D":
+        return {"model.2.bias", "model.5.bias", "model.8.bias"}
+    k = generator_keys(n_blocks)
+    keys = {f"model.{k['first']}.bias"} | {f"model.{i}.bias" for i in k["down"] + k["up"]}
+    for i in k["blocks"]:
+        keys |= {f"model.{i}.conv_block.1.bias", f"model.{i}.conv_block.5.bias"}
+    return keys
