@@ -1,0 +1,275 @@
+/*
+ * nirgan_hip.h -- C ABI of libnirgan_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary for the NIR-GAN Pix2Pix hot path.  The reference implements the path
+ * with stock torch.nn layers (Python only, no FFI of its own); the entry points below are
+ * what a binding of that path binds instead.  Each one cites the reference call site(s) it
+ * replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the library never
+ *     allocates, frees or retains device memory;
+ *   - `stream` is a hipStream_t passed as void*; every launch goes to that stream, no hidden
+ *     synchronisation, safe for hipGraph capture;
+ *   - activations are fp32 "NHWC with halo": [B][Hp][Wp][cs] floats, cs % 4 == 0, base 16-byte
+ *     aligned.  Convolutions are *valid* convolutions over such buffers; the producer of a
+ *     buffer writes the halo (reflect copies, or zeros that are set once at allocation);
+ *   - weights are consumed in a packed layout [N][ntaps*run] (K contiguous) produced by
+ *     nirgan_pack_rows from the reference layouts (Conv2d Cout,Cin,kh,kw; ConvTranspose2d
+ *     Cin,Cout,kh,kw; Linear out,in) through an int32 index map;
+ *   - every function returns 0 on success, a negative code on error (message from
+ *     nirgan_last_error()); descriptors are validated (alignment, extents) before launch.
+ */
+#ifndef NIRGAN_HIP_H
+#define NIRGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIRGAN_MAX_TAPS 16
+
+#define NIRGAN_OK 0
+#define NIRGAN_ERR_ARG (-1)      /* invalid descriptor / argument */
+#define NIRGAN_ERR_LAUNCH (-2)   /* HIP launch error */
+
+#define NIRGAN_ACT_NONE 0
+#define NIRGAN_ACT_RELU 1
+#define NIRGAN_ACT_LRELU 2
+#define NIRGAN_ACT_TANH 3
+
+#define NIRGAN_BORDER_KEEP 0     /* halo untouched (zero halo set once by the owner) */
+#define NIRGAN_BORDER_REFLECT 1  /* halo = reflection of the interior (nn.ReflectionPad2d) */
+
+int nirgan_version(void);
+const char* nirgan_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the MFMA pipe (v_mfma_f32_32x32x2_f32, exact fp32).
+ *   out[b][oh*out_stride+out_oh][ow*out_stride+out_ow][n] (+bias[n]) =
+ *       sum_{t<ntaps} sum_{c<run} in[b][oh*in_stride+in_oh+tap_dh[t]][ow*in_stride+in_ow+tap_dw[t]][c] * w[n][t*run+c]
+ * `run` floats are read contiguously from the tap's pixel (run may span several pixels:
+ * run = kw*cs packs a kernel row).  One descriptor covers: forward of Conv2d (stride 1/2),
+ * data-gradient of Conv2d (flipped weights; stride-2 as 4 sub-pixel phases), forward and
+ * data-gradient of ConvTranspose2d (4 phases / strided), the 1x1 "tap-plane" products of the
+ * single-output-channel 7x7 / 4x4 layers, and nn.Linear.
+ * Replaces: nn.Conv2d / nn.ConvTranspose2d forward+backward at model/networks.py:342,349,
+ * 360-363,367,405-427,559,566,574,579; nn.Linear at model/generator_inject.py:90,110.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* in;  int64_t in_elems;   /* input buffer and its size in floats */
+    int in_hp, in_wp, in_cs;              /* halo'd height, width, floats per pixel */
+    int run;                              /* contiguous floats per tap (multiple of 4) */
+    int in_stride, in_oh, in_ow;          /* input step per output pixel, origin */
+    int ntaps;
+    int tap_dh[NIRGAN_MAX_TAPS], tap_dw[NIRGAN_MAX_TAPS];
+    const float* w;   int64_t w_elems;    /* packed weights [N][ntaps*run] */
+    const float* bias;                    /* [N] or NULL */
+    float* out;       int64_t out_elems;
+    int out_hp, out_wp, out_cs;
+    int out_stride, out_oh, out_ow;
+    int B, OH, OW, N;
+    const float* zero_page;               /* >= 64 zero bytes, 16-byte aligned */
+} nirgan_conv_desc;
+
+int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Implicit-GEMM weight gradient (MFMA, split over pixels into deterministic slabs).
+ *   slab[s][n][t*run+c] = sum_{m in split s}
+ *       p[b][oh+p_oh][ow+p_ow][n] * q[b][oh*q_stride+q_oh+tap_dh[t]][ow*q_stride+q_ow+tap_dw[t]][c]
+ * with m = (b,oh,ow) over B*OH*OW.  Conv2d: p = dY (n = cout), q = X (c = cin).
+ * ConvTranspose2d: p = X (n = cin), q = dY (c = cout).  nirgan_reduce_rows then sums the
+ * slabs into the reference-layout gradient.  Replaces autograd's weight gradient of the same
+ * layers as nirgan_conv_igemm.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* p;   int64_t p_elems;
+    int p_hp, p_wp, p_cs, p_oh, p_ow;
+    const float* q;   int64_t q_elems;
+    int q_hp, q_wp, q_cs, q_stride, q_oh, q_ow;
+    int run, ntaps;
+    int tap_dh[NIRGAN_MAX_TAPS], tap_dw[NIRGAN_MAX_TAPS];
+    int B, OH, OW, N;                     /* N: rows of the gradient; round_up(N,4) <= p_cs */
+    float* slabs;     int64_t slab_elems; /* [nsplit][N][ntaps*run] */
+    int nsplit, rows_per_split;           /* rows_per_split % 32 == 0, nsplit*rows_per_split >= B*OH*OW */
+    const float* zero_page;
+} nirgan_wgrad_desc;
+
+int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream);
+
+/* dst[n*dst_row_stride + map[k]] (= | +=) sum_s slabs[s][n][k]  for map[k] >= 0 */
+int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,
+                       float* dst, int64_t dst_elems, int dst_row_stride, int accumulate, void* stream);
+
+/* dst[n][k] = map[k] >= 0 ? src[n*src_row_stride + map[k]] : 0   (weight packing) */
+int nirgan_pack_rows(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,
+                     float* dst, int N, int K, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * InstanceNorm2d(affine=False, eps) + activation + residual + halo write, forward.
+ *   z = norm ? (y - mean_bc) * rstd_bc : y ;  a = act(z) + residual ;  out interior = a,
+ *   reflect halo of width o_pad written when border == NIRGAN_BORDER_REFLECT.
+ * Biased variance over H*W per (b,c); mean/rstd saved for backward.
+ * Replaces: nn.InstanceNorm2d + nn.ReLU / nn.LeakyReLU(0.2) / residual add / the
+ * nn.ReflectionPad2d of the next layer, model/networks.py:30,343-344,350-351,364-365,
+ * 405-433,559,567-568,575-576.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* y;                       /* [B][H][W][C] dense */
+    int B, H, W, C;
+    int norm; float eps;
+    float* mean; float* rstd;             /* [B][C] */
+    int act; float slope;
+    const float* residual; int r_hp, r_wp, r_pad;   /* optional [B][r_hp][r_wp][C], interior at r_pad */
+    float* out; int o_hp, o_wp, o_pad; int border;
+    float* ws; int64_t ws_elems;          /* >= B * nchunk * 2 * C floats, see nirgan_instnorm_ws_elems */
+} nirgan_in_fwd_desc;
+
+int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C);
+int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Backward of the same block.  Incoming gradient g_a = gather(g) (+ g2):
+ *   g is a halo'd buffer [B][g_hp][g_wp][C]; g_fold = 1 folds a reflect halo of width g_pad
+ *   back onto the interior (adjoint of ReflectionPad2d), g_fold = 0 reads the interior only;
+ *   g2 is an optional dense [B][H][W][C] term (skip connection).
+ *   g_z = g_a * act'(a);  dy = norm ? rstd*(g_z - mean(g_z) - z*mean(g_z*z)) : g_z.
+ * dy is written to the interior (d_pad) of a zero-halo buffer that feeds the data- and
+ * weight-gradient GEMMs; gsum_out (optional, dense) receives g_a; dbias (optional, [C])
+ * accumulates sum dy.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* g; int g_hp, g_wp, g_pad, g_fold;
+    const float* g2;
+    const float* a; int a_hp, a_wp, a_pad;   /* activated output (mask source); may be NULL when act == NONE */
+    int act; float slope;
+    const float* y; const float* mean; const float* rstd; int norm;
+    int B, H, W, C;
+    float* dy; int d_hp, d_wp, d_pad;
+    float* gsum_out;
+    float* dbias;
+    float* ws; int64_t ws_elems;
+} nirgan_in_bwd_desc;
+
+int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Layout / halo helpers at the NCHW boundary.
+ * ------------------------------------------------------------------------------------- */
+/* dst[b][hh][ww][c0+c] = src[b][c][rh(hh)][rw(ww)], c < Cs.  pad_mode REFLECT: the halo of
+ * width pad1+pad2 is the composition reflect(pad1) then reflect(pad2) (Px2Px_PL.forward's
+ * F.pad(...,'reflect') model/pix2pix.py:91-93 followed by ReflectionPad2d(3) networks.py:341).
+ * pad_mode KEEP: only the interior (offset pad1+pad2) is written (torch.cat + zero padding,
+ * model/pix2pix.py:197,202,216 + networks.py:559). */
+int nirgan_nchw_to_halo(const float* src, int B, int Cs, int H, int W,
+                        float* dst, int dst_cs, int c0, int pad1, int pad2, int pad_mode, void* stream);
+
+/* Single-output-channel convolution tail: out[b][oh][ow] = act(bias + sum_t Q[b][oh+tap_dh[t]][ow+tap_dw[t]][t])
+ * restricted to the crop window (crop pixels removed on every side); dst is NCHW [B][1][OH-2crop][OW-2crop].
+ * With the 1x1 tap-plane product this is Conv2d(C,1,k) (+Tanh, + crop of pix2pix.py:107-108):
+ * model/networks.py:367-368, :579. */
+typedef struct {
+    const float* q; int q_hp, q_wp, q_cs;
+    int ntaps; int tap_dh[64], tap_dw[64];
+    const float* bias;                    /* 1 float on device, or NULL */
+    int act;
+    int B, OH, OW, crop;
+    float* dst;                           /* [B][OH-2crop][OW-2crop] */
+} nirgan_tap_gather_desc;
+int nirgan_tap_gather(const nirgan_tap_gather_desc* d, void* stream);
+
+/* Adjoint: dq[b][hh][ww][t] = dz[b][hh-tap_dh[t]][ww-tap_dw[t]], dz = dout*act'(out) inside
+ * the crop window and 0 elsewhere; channels t >= ntaps of dq are zeroed; dbias (optional)
+ * accumulates sum dz. */
+typedef struct {
+    const float* dout; const float* out;  /* [B][OH-2crop][OW-2crop] each; out may be NULL when act == NONE */
+    int act;
+    int B, OH, OW, crop;
+    int ntaps; int tap_dh[64], tap_dw[64];
+    float* dq; int q_hp, q_wp, q_cs;
+    float* dbias;
+} nirgan_tap_scatter_desc;
+int nirgan_tap_scatter(const nirgan_tap_scatter_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Losses (forward value + gradient in one pass).
+ * ------------------------------------------------------------------------------------- */
+/* LSGAN: loss_out[0] += weight * mean((pred - target)^2); grad = weight * 2 (pred-target)/n.
+ * GANLoss('lsgan') with MSELoss, model/networks.py:233,258-276. */
+int nirgan_lsgan(const float* pred, int64_t n, float target, float weight,
+                 float* loss_out, float* grad, void* stream);
+
+/* L1 + spectral-index losses on NCHW tiles (rgb [B][3][H][W], nir/pred [B][1][H][W]).
+ *   sums[0..6] += sum|pred-nir|, then the per-index sums of criterion(idx(nir), idx(pred))
+ *   for ndvi, ndwi, gndvi, savi, msavi, evi (all divided by n by the caller);
+ *   grad_pred = extra_scale*extra[...][extra_c] + w_l1*sign(pred-nir)/n + sum_i w_i * d crit_i / d pred
+ * criterion 0 = l1, 1 = l2.  torch.nn.L1Loss model/pix2pix.py:60,222;
+ * RemoteSensingIndices utils/remote_sensing_indices.py:23-71,84-319. */
+typedef struct {
+    const float* rgb; const float* nir; const float* pred;
+    int B, H, W;
+    float w_l1, w_ndvi, w_ndwi, w_gndvi, w_savi, w_msavi, w_evi;  /* already multiplied by lambda_rs */
+    int criterion;
+    int log_all;                          /* 1: evaluate all six indices (logging_dict); 0: only those with weight != 0 */
+    const float* extra; int extra_cs, extra_c; float extra_scale;  /* optional NHWC gradient term */
+    float* sums;                          /* 7 floats, accumulated */
+    float* grad_pred;                     /* [B][1][H][W] or NULL (forward only) */
+} nirgan_pix_loss_desc;
+int nirgan_pix_loss(const nirgan_pix_loss_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Adam (torch.optim.Adam, amsgrad=False, weight_decay=0) on a flat fp32 range.
+ * model/pix2pix.py:486-487.  `step` is the 1-based count after increment.
+ * ------------------------------------------------------------------------------------- */
+int nirgan_adam(float* p, const float* g, float* m, float* v, int64_t n,
+                float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * SatCLIP injection (model/generator_inject.py:110-127).
+ * ------------------------------------------------------------------------------------- */
+/* F.interpolate(e.view(B,1,S,S), size=(OH,OW), mode='bilinear', align_corners=False) */
+int nirgan_bilinear_fwd(const float* src, int B, int SH, int SW, float* dst, int OH, int OW, void* stream);
+int nirgan_bilinear_bwd(const float* ddst, int B, int OH, int OW, float* dsrc, int SH, int SW, void* stream);
+
+/* a = relu(z * (1 + s*e)) ('multiply') or relu(z + s*e) ('add'); z dense [B][H][W][C], e [B][H][W],
+ * a written to the interior of a halo'd buffer. */
+typedef struct {
+    const float* z; const float* e; const float* scale;   /* scale: 1 float on device */
+    int style;                                            /* 0 multiply, 1 add */
+    int B, H, W, C;
+    float* out; int o_hp, o_wp, o_pad;
+} nirgan_inject_fwd_desc;
+int nirgan_inject_fwd(const nirgan_inject_fwd_desc* d, void* stream);
+
+/* backward: g (dense, wrt a) -> dz (dense), de [B][H][W], dscale (1 float, accumulated) */
+typedef struct {
+    const float* g; const float* a; int a_hp, a_wp, a_pad;
+    const float* z; const float* e; const float* scale;
+    int style;
+    int B, H, W, C;
+    float* dz; float* de; float* dscale;
+} nirgan_inject_bwd_desc;
+int nirgan_inject_bwd(const nirgan_inject_bwd_desc* d, void* stream);
+
+/* column sums: out[c] (+)= sum_r x[r][c]  (bias gradients of Linear) */
+int nirgan_colsum(const float* x, int64_t rows, int cols, float* out, int accumulate, void* stream);
+
+/* misc stream-ordered helpers */
+int nirgan_fill(float* dst, int64_t n, float value, void* stream);
+int nirgan_axpy(float* y, const float* x, int64_t n, float alpha, void* stream);   /* y += alpha*x */
+
+/* run a pre-built list of descriptors back to back (one host call per phase) */
+#define NIRGAN_OP_CONV 1
+#define NIRGAN_OP_WGRAD 2
+#define NIRGAN_OP_IN_FWD 3
+#define NIRGAN_OP_IN_BWD 4
+typedef struct { int op; const void* desc; } nirgan_plan_entry;
+int nirgan_run_plan(const nirgan_plan_entry* entries, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIRGAN_HIP_H */

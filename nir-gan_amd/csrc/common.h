@@ -1,0 +1,62 @@
+// Shared host/device helpers for libnirgan_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/nirgan_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NG_GLOBAL __attribute__((address_space(1)))
+#define NG_LDS __attribute__((address_space(3)))
+
+void nirgan_set_error(const char* fmt, ...);
+
+#define NG_REQUIRE(cond, ...)                      \
+    do {                                           \
+        if (!(cond)) {                             \
+            nirgan_set_error(__VA_ARGS__);         \
+            return NIRGAN_ERR_ARG;                 \
+        }                                          \
+    } while (0)
+
+static inline int nirgan_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        nirgan_set_error("%s: %s", what, hipGetErrorString(e));
+        return NIRGAN_ERR_LAUNCH;
+    }
+    return NIRGAN_OK;
+}
+
+static inline bool ng_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// bijective XCD-aware remap of a 1-D block id: consecutive logical ids land on one XCD
+// (blocks b and b+8 share an XCD under round-robin dispatch; speed only, never correctness).
+__device__ __forceinline__ int ng_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// 16-byte async global -> LDS copy: LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void ng_glds16(const float* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const NG_GLOBAL void*)src, (NG_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+// reflect index into [0, n) (nn.ReflectionPad2d semantics, pad < n)
+__host__ __device__ __forceinline__ int ng_reflect(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__device__ __forceinline__ float ng_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

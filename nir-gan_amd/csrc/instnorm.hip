@@ -1,0 +1,334 @@
+// InstanceNorm2d(affine=False) + activation + residual + halo write, forward and backward,
+// on dense NHWC fp32.  HBM-bound: lanes run along C (float4 per lane, fully coalesced rows),
+// pixel chunks spread over the grid, per-(b,c) sums combined through a small partial buffer
+// in a fixed order (deterministic).  Sums are taken about a per-channel shift (the value at
+// pixel 0) so that E[x^2]-E[x]^2 does not cancel.
+#include "common.h"
+
+namespace {
+
+__host__ __device__ inline int in_nrg(int C) {
+    const int q4 = C / 4;
+    return q4 >= 256 ? 1 : 256 / q4;
+}
+
+inline int in_nchunk(int B, int HW, int C) {
+    const int nrg = in_nrg(C);
+    int want = 2048 / B;
+    if (want < 1) want = 1;
+    int cap = HW / (nrg * 8);
+    if (cap < 1) cap = 1;
+    return want < cap ? want : cap;
+}
+
+// padded-buffer coordinates that hold a copy of interior coordinate h under a reflect halo
+// of width P (P < H): the interior itself plus its mirror images.  Returns the count (<= 3).
+__device__ __forceinline__ int halo_images(int h, int H, int P, int* out) {
+    int n = 0;
+    out[n++] = h + P;
+    if (h >= 1 && h <= P) out[n++] = P - h;
+    if (h >= H - 1 - P && h <= H - 2) out[n++] = P + 2 * (H - 1) - h;
+    return n;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// block-level sum over the row groups of two float4 accumulators; result valid for tid < q4
+__device__ __forceinline__ void rg_reduce2(f32x4& s1, f32x4& s2, f32x4* lds, int tid, int q4, int nrg) {
+    lds[tid] = s1;
+    lds[256 + tid] = s2;
+    __syncthreads();
+    if (tid < q4) {
+        f32x4 a = lds[tid], b = lds[256 + tid];
+        for (int r = 1; r < nrg; ++r) {
+            a += lds[r * q4 + tid];
+            b += lds[256 + r * q4 + tid];
+        }
+        s1 = a;
+        s2 = b;
+    }
+    __syncthreads();
+}
+
+struct InFwd {
+    const float* y; int HW, W, H, C;
+    int norm; float eps;
+    float* mean; float* rstd;
+    int act; float slope;
+    const float* residual; int r_row, r_img, r_org;
+    float* out; int o_row, o_img, o_pad, border;
+    float* ws; int nchunk, ppc;
+};
+
+__global__ __launch_bounds__(256) void in_stats_kernel(const InFwd p) {
+    __shared__ f32x4 lds[512];
+    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
+    const int q4 = p.C / 4, nrg = in_nrg(p.C);
+    const int q = tid % q4, rg = tid / q4;
+    const float* yb = p.y + size_t(b) * p.HW * p.C;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (rg < nrg) {
+        const f32x4 k = ld4(yb + q * 4);
+        const int start = chunk * p.ppc;
+        int end = start + p.ppc;
+        end = end < p.HW ? end : p.HW;
+        for (int pix = start + rg; pix < end; pix += nrg) {
+            const f32x4 v = ld4(yb + size_t(pix) * p.C + q * 4) - k;
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    rg_reduce2(s1, s2, lds, tid, q4, nrg);
+    if (tid < q4) {
+        float* w = p.ws + (size_t(b) * p.nchunk + chunk) * 2 * p.C;
+        st4(w + tid * 4, s1);
+        st4(w + p.C + tid * 4, s2);
+    }
+}
+
+__device__ __forceinline__ f32x4 act4(f32x4 z, int act, float slope) {
+    if (act == NIRGAN_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = z[i] > 0.f ? z[i] : 0.f;
+    } else if (act == NIRGAN_ACT_LRELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = z[i] > 0.f ? z[i] : z[i] * slope;
+    }
+    return z;
+}
+
+__global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
+    __shared__ f32x4 s_mean[256], s_rstd[256];
+    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
+    const int q4 = p.C / 4, nrg = in_nrg(p.C);
+    const int q = tid % q4, rg = tid / q4;
+    const float* yb = p.y + size_t(b) * p.HW * p.C;
+    if (tid < q4) {
+        f32x4 mean = {0, 0, 0, 0}, rstd = {1, 1, 1, 1};
+        if (p.norm) {
+            f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+            const float* w = p.ws + size_t(b) * p.nchunk * 2 * p.C;
+            for (int c = 0; c < p.nchunk; ++c) {
+                s1 += ld4(w + size_t(c) * 2 * p.C + tid * 4);
+                s2 += ld4(w + size_t(c) * 2 * p.C + p.C + tid * 4);
+            }
+            const float inv = 1.f / float(p.HW);
+            const f32x4 k = ld4(yb + tid * 4);
+            const f32x4 m = s1 * inv;
+            f32x4 var = s2 * inv - m * m;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                var[i] = var[i] > 0.f ? var[i] : 0.f;
+                rstd[i] = 1.f / sqrtf(var[i] + p.eps);
+            }
+            mean = k + m;
+            if (chunk == 0) {
+                st4(p.mean + size_t(b) * p.C + tid * 4, mean);
+                st4(p.rstd + size_t(b) * p.C + tid * 4, rstd);
+            }
+        }
+        s_mean[tid] = mean;
+        s_rstd[tid] = rstd;
+    }
+    __syncthreads();
+    if (rg >= nrg) return;
+    const f32x4 mean = s_mean[q], rstd = s_rstd[q];
+    const int start = chunk * p.ppc;
+    int end = start + p.ppc;
+    end = end < p.HW ? end : p.HW;
+    float* ob = p.out + size_t(b) * p.o_img;
+    const float* rb = p.residual ? p.residual + size_t(b) * p.r_img + p.r_org : nullptr;
+    for (int pix = start + rg; pix < end; pix += nrg) {
+        const int h = pix / p.W, w = pix - h * p.W;
+        f32x4 v = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
+        v = act4(v, p.act, p.slope);
+        if (rb) v += ld4(rb + size_t(h) * p.r_row + size_t(w) * p.C + q * 4);
+        if (p.border == NIRGAN_BORDER_REFLECT && p.o_pad > 0) {
+            int hs[3], wsx[3];
+            const int nh = halo_images(h, p.H, p.o_pad, hs), nw = halo_images(w, p.W, p.o_pad, wsx);
+            for (int i = 0; i < nh; ++i)
+                for (int j = 0; j < nw; ++j) st4(ob + size_t(hs[i]) * p.o_row + size_t(wsx[j]) * p.C + q * 4, v);
+        } else {
+            st4(ob + size_t(h + p.o_pad) * p.o_row + size_t(w + p.o_pad) * p.C + q * 4, v);
+        }
+    }
+}
+
+struct InBwd {
+    const float* g; int g_row, g_img, g_pad, g_fold;
+    const float* g2;
+    const float* a; int a_row, a_img, a_org;
+    int act; float slope;
+    const float* y; const float* mean; const float* rstd; int norm;
+    int HW, W, H, C;
+    float* dy; int d_row, d_img, d_org;
+    float* gsum_out;
+    float* dbias;
+    float* ws; int nchunk, ppc;
+};
+
+__global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
+    __shared__ f32x4 lds[512];
+    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
+    const int q4 = p.C / 4, nrg = in_nrg(p.C);
+    const int q = tid % q4, rg = tid / q4;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (rg < nrg) {
+        f32x4 mean = {0, 0, 0, 0}, rstd = {1, 1, 1, 1};
+        if (p.norm) {
+            mean = ld4(p.mean + size_t(b) * p.C + q * 4);
+            rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
+        }
+        const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
+        const float* g2b = p.g2 ? p.g2 + size_t(b) * p.HW * p.C : nullptr;
+        const float* ab = p.a ? p.a + size_t(b) * p.a_img + p.a_org : nullptr;
+        const float* yb = p.y ? p.y + size_t(b) * p.HW * p.C : nullptr;
+        float* db = p.dy + size_t(b) * p.d_img + p.d_org;
+        const int start = chunk * p.ppc;
+        int end = start + p.ppc;
+        end = end < p.HW ? end : p.HW;
+        for (int pix = start + rg; pix < end; pix += nrg) {
+            const int h = pix / p.W, w = pix - h * p.W;
+            f32x4 ga = {0, 0, 0, 0};
+            if (gb) {
+                if (p.g_fold) {
+                    int hs[3], wsx[3];
+                    const int nh = halo_images(h, p.H, p.g_pad, hs), nw = halo_images(w, p.W, p.g_pad, wsx);
+                    for (int i = 0; i < nh; ++i)
+                        for (int j = 0; j < nw; ++j) ga += ld4(gb + size_t(hs[i]) * p.g_row + size_t(wsx[j]) * p.C + q * 4);
+                } else {
+                    ga = ld4(gb + size_t(h + p.g_pad) * p.g_row + size_t(w + p.g_pad) * p.C + q * 4);
+                }
+            }
+            if (g2b) ga += ld4(g2b + size_t(pix) * p.C + q * 4);
+            if (p.gsum_out) st4(p.gsum_out + (size_t(b) * p.HW + pix) * p.C + q * 4, ga);
+            f32x4 gz = ga;
+            if (p.act == NIRGAN_ACT_RELU || p.act == NIRGAN_ACT_LRELU) {
+                const f32x4 av = ld4(ab + size_t(h) * p.a_row + size_t(w) * p.C + q * 4);
+                const float neg = p.act == NIRGAN_ACT_RELU ? 0.f : p.slope;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gz[i] = av[i] > 0.f ? gz[i] : gz[i] * neg;
+            }
+            st4(db + size_t(h) * p.d_row + size_t(w) * p.C + q * 4, gz);
+            s1 += gz;
+            if (p.norm) {
+                const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
+                s2 += gz * z;
+            }
+        }
+    }
+    rg_reduce2(s1, s2, lds, tid, q4, nrg);
+    if (tid < q4) {
+        if (p.norm) {
+            float* w = p.ws + (size_t(b) * p.nchunk + chunk) * 2 * p.C;
+            st4(w + tid * 4, s1);
+            st4(w + p.C + tid * 4, s2);
+        } else if (p.dbias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(p.dbias + tid * 4 + i, s1[i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p) {
+    __shared__ f32x4 lds[512];
+    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
+    const int q4 = p.C / 4, nrg = in_nrg(p.C);
+    const int q = tid % q4, rg = tid / q4;
+    if (tid < q4) {
+        f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+        const float* w = p.ws + size_t(b) * p.nchunk * 2 * p.C;
+        for (int c = 0; c < p.nchunk; ++c) {
+            s1 += ld4(w + size_t(c) * 2 * p.C + tid * 4);
+            s2 += ld4(w + size_t(c) * 2 * p.C + p.C + tid * 4);
+        }
+        const float inv = 1.f / float(p.HW);
+        lds[tid] = s1 * inv;
+        lds[256 + tid] = s2 * inv;
+    }
+    __syncthreads();
+    f32x4 sd = {0, 0, 0, 0}, dummy = {0, 0, 0, 0};
+    if (rg < nrg) {
+        const f32x4 m1 = lds[q], m2 = lds[256 + q];
+        const f32x4 mean = ld4(p.mean + size_t(b) * p.C + q * 4);
+        const f32x4 rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
+        const float* yb = p.y + size_t(b) * p.HW * p.C;
+        float* db = p.dy + size_t(b) * p.d_img + p.d_org;
+        const int start = chunk * p.ppc;
+        int end = start + p.ppc;
+        end = end < p.HW ? end : p.HW;
+        for (int pix = start + rg; pix < end; pix += nrg) {
+            const int h = pix / p.W, w = pix - h * p.W;
+            float* dp = db + size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
+            const f32x4 gz = ld4(dp);
+            const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
+            const f32x4 d = rstd * (gz - m1 - z * m2);
+            st4(dp, d);
+            sd += d;
+        }
+    }
+    if (p.dbias) {
+        __syncthreads();
+        rg_reduce2(sd, dummy, lds, tid, q4, nrg);
+        if (tid < q4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) atomicAdd(p.dbias + tid * 4 + i, sd[i]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return int64_t(B) * in_nchunk(B, H * W, C) * 2 * C;
+}
+
+extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
+    NG_REQUIRE(d && d->y && d->out, "instnorm_fwd: null pointer");
+    NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C >= 4 && d->C % 4 == 0 && d->C <= 1024, "instnorm_fwd: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
+    NG_REQUIRE(ng_aligned16(d->y) && ng_aligned16(d->out) && ng_aligned16(d->residual), "instnorm_fwd: pointers must be 16-byte aligned");
+    NG_REQUIRE(d->o_pad >= 0 && d->o_hp == d->H + 2 * d->o_pad && d->o_wp == d->W + 2 * d->o_pad, "instnorm_fwd: output halo geometry mismatch");
+    NG_REQUIRE(d->border != NIRGAN_BORDER_REFLECT || (d->o_pad < d->H && d->o_pad < d->W), "instnorm_fwd: reflect halo wider than the image");
+    NG_REQUIRE(!d->residual || (d->r_hp == d->H + 2 * d->r_pad && d->r_wp == d->W + 2 * d->r_pad), "instnorm_fwd: residual geometry mismatch");
+    InFwd p;
+    p.y = d->y; p.H = d->H; p.W = d->W; p.HW = d->H * d->W; p.C = d->C;
+    p.norm = d->norm; p.eps = d->eps; p.mean = d->mean; p.rstd = d->rstd; p.act = d->act; p.slope = d->slope;
+    p.residual = d->residual; p.r_row = d->r_wp * d->C; p.r_img = d->r_hp * p.r_row; p.r_org = d->r_pad * p.r_row + d->r_pad * d->C;
+    p.out = d->out; p.o_row = d->o_wp * d->C; p.o_img = d->o_hp * p.o_row; p.o_pad = d->o_pad; p.border = d->border;
+    p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C); p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->norm) {
+        NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
+        hipLaunchKernelGGL(in_stats_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+    }
+    hipLaunchKernelGGL(in_apply_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+    return nirgan_check_launch("instnorm_fwd");
+}
+
+extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
+    NG_REQUIRE(d && d->dy && (d->g || d->g2), "instnorm_bwd: null pointer");
+    NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C >= 4 && d->C % 4 == 0 && d->C <= 1024, "instnorm_bwd: bad shape");
+    NG_REQUIRE(!d->g || (d->g_hp == d->H + 2 * d->g_pad && d->g_wp == d->W + 2 * d->g_pad), "instnorm_bwd: g geometry mismatch");
+    NG_REQUIRE(!d->g_fold || (d->g_pad < d->H && d->g_pad < d->W), "instnorm_bwd: fold halo wider than the image");
+    NG_REQUIRE(d->d_hp == d->H + 2 * d->d_pad && d->d_wp == d->W + 2 * d->d_pad, "instnorm_bwd: dy geometry mismatch");
+    const bool masked = d->act == NIRGAN_ACT_RELU || d->act == NIRGAN_ACT_LRELU;
+    NG_REQUIRE(!masked || (d->a && d->a_hp == d->H + 2 * d->a_pad && d->a_wp == d->W + 2 * d->a_pad), "instnorm_bwd: activation mask source missing or mismatched");
+    NG_REQUIRE(!d->norm || (d->y && d->mean && d->rstd && d->ws), "instnorm_bwd: y/mean/rstd/ws required when norm");
+    InBwd p;
+    p.g = d->g; p.g_row = d->g_wp * d->C; p.g_img = d->g_hp * p.g_row; p.g_pad = d->g_pad; p.g_fold = d->g_fold;
+    p.g2 = d->g2;
+    p.a = d->a; p.a_row = d->a_wp * d->C; p.a_img = d->a_hp * p.a_row; p.a_org = d->a_pad * p.a_row + d->a_pad * d->C;
+    p.act = d->act; p.slope = d->slope;
+    p.y = d->y; p.mean = d->mean; p.rstd = d->rstd; p.norm = d->norm;
+    p.H = d->H; p.W = d->W; p.HW = d->H * d->W; p.C = d->C;
+    p.dy = d->dy; p.d_row = d->d_wp * d->C; p.d_img = d->d_hp * p.d_row; p.d_org = d->d_pad * p.d_row + d->d_pad * d->C;
+    p.gsum_out = d->gsum_out; p.dbias = d->dbias;
+    p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C); p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
+    NG_REQUIRE(!d->norm || d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C, "instnorm_bwd: ws too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+    if (d->norm) hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+    return nirgan_check_launch("instnorm_bwd");
+}

@@ -1,0 +1,168 @@
+// NCHW boundary <-> halo'd NHWC, and the tap-plane gather/scatter of the single-output-channel
+// convolutions (7x7 64->1 + tanh of the generator, 4x4 512->1 of the PatchGAN).  HBM-bound.
+#include "common.h"
+
+namespace {
+
+__global__ void nchw_to_halo_kernel(const float* __restrict__ src, int B, int Cs, int H, int W,
+                                    float* __restrict__ dst, int cs, int c0, int pad1, int pad2, int reflect) {
+    const int P = pad1 + pad2;
+    const int Hp = H + 2 * P, Wp = W + 2 * P;
+    const int64_t total = int64_t(B) * Hp * Wp;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int ww = int(i % Wp);
+        const int hh = int((i / Wp) % Hp);
+        const int b = int(i / (int64_t(Wp) * Hp));
+        int h = hh - P, w = ww - P;
+        if (reflect) {
+            // ReflectionPad2d(pad2) applied to F.pad(x, pad1, 'reflect'): undo pad2 first, then pad1
+            h = ng_reflect(hh - pad2, H + 2 * pad1) - pad1;
+            w = ng_reflect(ww - pad2, W + 2 * pad1) - pad1;
+            h = ng_reflect(h, H);
+            w = ng_reflect(w, W);
+        } else if (h < 0 || h >= H || w < 0 || w >= W) {
+            continue;
+        }
+        float* d = dst + i * cs + c0;
+        for (int c = 0; c < Cs; ++c) d[c] = src[((int64_t(b) * Cs + c) * H + h) * W + w];
+    }
+}
+
+struct GatherP {
+    const float* q; int q_row, q_img, q_cs;
+    int ntaps; int off[64];
+    const float* bias; int act;
+    int B, OH, OW, crop;
+    float* dst;
+};
+
+__global__ void tap_gather_kernel(const GatherP p) {
+    const int H2 = p.OH - 2 * p.crop, W2 = p.OW - 2 * p.crop;
+    const int64_t total = int64_t(p.B) * H2 * W2;
+    const float bv = p.bias ? p.bias[0] : 0.f;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int w = int(i % W2), h = int((i / W2) % H2), b = int(i / (int64_t(W2) * H2));
+        const float* base = p.q + int64_t(b) * p.q_img + int64_t(h + p.crop) * p.q_row + int64_t(w + p.crop) * p.q_cs;
+        float s = 0.f;
+        for (int t = 0; t < p.ntaps; ++t) s += base[p.off[t] + t];
+        s += bv;
+        if (p.act == NIRGAN_ACT_TANH) s = tanhf(s);
+        p.dst[i] = s;
+    }
+}
+
+struct ScatterP {
+    const float* dout; const float* out; int act;
+    int B, OH, OW, crop;
+    int ntaps; int dh[64], dw[64];
+    float* dq; int q_hp, q_wp, q_cs;
+    float* dbias;
+};
+
+// one thread per (pixel of dq, group of 4 taps): dq[b][hh][ww][t] = dz[hh-dh_t][ww-dw_t]
+__global__ void tap_scatter_kernel(const ScatterP p) {
+    const int H2 = p.OH - 2 * p.crop, W2 = p.OW - 2 * p.crop;
+    const int q4 = p.q_cs / 4;
+    const int64_t total = int64_t(p.B) * p.q_hp * p.q_wp * q4;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
+        const int tq = int(i % q4);
+        const int64_t pix = i / q4;
+        const int ww = int(pix % p.q_wp), hh = int((pix / p.q_wp) % p.q_hp), b = int(pix / (int64_t(p.q_wp) * p.q_hp));
+        f32x4 v = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = tq * 4 + k;
+            if (t < p.ntaps) {
+                const int h = hh - p.dh[t] - p.crop, w = ww - p.dw[t] - p.crop;
+                if (h >= 0 && h < H2 && w >= 0 && w < W2) {
+                    const int64_t o = (int64_t(b) * H2 + h) * W2 + w;
+                    float g = p.dout[o];
+                    if (p.act == NIRGAN_ACT_TANH) {
+                        const float y = p.out[o];
+                        g *= 1.f - y * y;
+                    }
+                    v[k] = g;
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(p.dq + pix * p.q_cs + tq * 4) = v;
+    }
+}
+
+__global__ void tap_dbias_kernel(const float* __restrict__ dout, const float* __restrict__ out, int act, int64_t n, float* dbias) {
+    float s = 0.f;
+    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+        float g = dout[i];
+        if (act == NIRGAN_ACT_TANH) {
+            const float y = out[i];
+            g *= 1.f - y * y;
+        }
+        s += g;
+    }
+    s = ng_wave_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dbias, part[0] + part[1] + part[2] + part[3]);
+}
+
+inline int grid_for(int64_t total) {
+    const int64_t g = (total + 255) / 256;
+    return int(g < 8192 ? (g < 1 ? 1 : g) : 8192);
+}
+
+}  // namespace
+
+extern "C" int nirgan_nchw_to_halo(const float* src, int B, int Cs, int H, int W, float* dst, int dst_cs, int c0,
+                                   int pad1, int pad2, int pad_mode, void* stream) {
+    NG_REQUIRE(src && dst && B > 0 && Cs > 0 && H > 0 && W > 0, "nchw_to_halo: bad arguments");
+    NG_REQUIRE(c0 >= 0 && c0 + Cs <= dst_cs && pad1 >= 0 && pad2 >= 0, "nchw_to_halo: channel window / pads out of range");
+    NG_REQUIRE(pad_mode != NIRGAN_BORDER_REFLECT || (pad1 < H && pad1 < W && pad2 < H + 2 * pad1 && pad2 < W + 2 * pad1), "nchw_to_halo: reflect pad wider than the image");
+    const int P = pad1 + pad2;
+    const int64_t total = int64_t(B) * (H + 2 * P) * (W + 2 * P);
+    hipLaunchKernelGGL(nchw_to_halo_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       src, B, Cs, H, W, dst, dst_cs, c0, pad1, pad2, pad_mode == NIRGAN_BORDER_REFLECT ? 1 : 0);
+    return nirgan_check_launch("nchw_to_halo");
+}
+
+extern "C" int nirgan_tap_gather(const nirgan_tap_gather_desc* d, void* stream) {
+    NG_REQUIRE(d && d->q && d->dst, "tap_gather: null pointer");
+    NG_REQUIRE(d->ntaps >= 1 && d->ntaps <= 64 && d->ntaps <= d->q_cs, "tap_gather: ntaps out of range");
+    NG_REQUIRE(d->B > 0 && d->crop >= 0 && d->OH > 2 * d->crop && d->OW > 2 * d->crop, "tap_gather: bad shape");
+    GatherP p;
+    p.q = d->q; p.q_cs = d->q_cs; p.q_row = d->q_wp * d->q_cs; p.q_img = d->q_hp * p.q_row;
+    p.ntaps = d->ntaps;
+    for (int t = 0; t < 64; ++t) {
+        p.off[t] = 0;
+        if (t < d->ntaps) {
+            NG_REQUIRE(d->tap_dh[t] >= 0 && d->OH - 1 + d->tap_dh[t] < d->q_hp && d->tap_dw[t] >= 0 && d->OW - 1 + d->tap_dw[t] < d->q_wp, "tap_gather: tap %d out of range", t);
+            p.off[t] = d->tap_dh[t] * p.q_row + d->tap_dw[t] * d->q_cs;
+        }
+    }
+    p.bias = d->bias; p.act = d->act; p.B = d->B; p.OH = d->OH; p.OW = d->OW; p.crop = d->crop; p.dst = d->dst;
+    const int64_t total = int64_t(d->B) * (d->OH - 2 * d->crop) * (d->OW - 2 * d->crop);
+    hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("tap_gather");
+}
+
+extern "C" int nirgan_tap_scatter(const nirgan_tap_scatter_desc* d, void* stream) {
+    NG_REQUIRE(d && d->dout && d->dq, "tap_scatter: null pointer");
+    NG_REQUIRE(d->act != NIRGAN_ACT_TANH || d->out, "tap_scatter: out required for tanh");
+    NG_REQUIRE(d->ntaps >= 1 && d->ntaps <= 64 && d->ntaps <= d->q_cs && d->q_cs % 4 == 0, "tap_scatter: ntaps/q_cs out of range");
+    NG_REQUIRE(d->B > 0 && d->crop >= 0 && d->OH > 2 * d->crop && d->OW > 2 * d->crop, "tap_scatter: bad shape");
+    NG_REQUIRE(ng_aligned16(d->dq), "tap_scatter: dq must be 16-byte aligned");
+    ScatterP p;
+    p.dout = d->dout; p.out = d->out; p.act = d->act; p.B = d->B; p.OH = d->OH; p.OW = d->OW; p.crop = d->crop;
+    p.ntaps = d->ntaps;
+    for (int t = 0; t < 64; ++t) { p.dh[t] = t < d->ntaps ? d->tap_dh[t] : 0; p.dw[t] = t < d->ntaps ? d->tap_dw[t] : 0; }
+    p.dq = d->dq; p.q_hp = d->q_hp; p.q_wp = d->q_wp; p.q_cs = d->q_cs; p.dbias = d->dbias;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = int64_t(d->B) * d->q_hp * d->q_wp * (d->q_cs / 4);
+    hipLaunchKernelGGL(tap_scatter_kernel, dim3(grid_for(total)), dim3(256), 0, st, p);
+    if (d->dbias) {
+        const int64_t n = int64_t(d->B) * (d->OH - 2 * d->crop) * (d->OW - 2 * d->crop);
+        const int g = grid_for(n) < 256 ? grid_for(n) : 256;
+        hipLaunchKernelGGL(tap_dbias_kernel, dim3(g), dim3(256), 0, st, d->dout, d->out, d->act, n, d->dbias);
+    }
+    return nirgan_check_launch("tap_scatter");
+}

@@ -1,0 +1,199 @@
+"""MI355X-native counterpart of the reference's ``model/pix2pix.py`` (class ``Px2Px_PL``).
+
+Same constructor argument (the YAML config tree), attributes (``netG, netD, criterionGAN,
+criterionL1, rs_losses, satclip, config, opt``) and methods (``forward, predict_step,
+training_step, extract_batch, configure_optimizers``; reference model/pix2pix.py:17-492).
+It subclasses ``pytorch_lightning.LightningModule`` when Lightning is importable (so the
+reference's train.py drives it unchanged) and ``torch.nn.Module`` otherwise; in both cases
+``train_batch(batch)`` runs the whole two-optimizer batch on the fused HIP trainer.
+
+Out of scope here (validation/plot/wandb branches): validation_step's image
+logging, calculate_metrics, the SatCLIP location encoder itself -- ``coords`` may carry the
+precomputed B x 256 embeddings (as the reference's own smoke test does, pix2pix.py:509-526).
+"""
+from __future__ import annotations
+
+import torch
+from torch.optim.lr_scheduler import ReduceLROnPlateau
+
+try:  # Lightning is optional: the reference pins 1.9 (requirements.txt:18)
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+    _HAVE_PL = True
+except Exception:  # pragma: no cover - depends on the environment
+    _Base = torch.nn.Module
+    _HAVE_PL = False
+
+from model import networks
+from nirgan_hip import functional as HF
+from nirgan_hip.optim import HipAdam
+from nirgan_hip.trainer import Pix2PixTrainer
+
+
+class HipL1Loss(torch.nn.Module):
+    """torch.nn.L1Loss() for (prediction, target) NIR tiles on the fused HIP pixel-loss pass."""
+
+    def forward(self, pred, target):
+        B, _, H, W = pred.shape
+        rgb = torch.zeros(B, 3, H, W, dtype=torch.float32, device=pred.device)
+        return HF.PixLossFn.apply(rgb, target, pred, (1.0, 0, 0, 0, 0, 0, 0), 0)
+
+
+class Px2Px_PL(_Base):
+    def __init__(self, opt):
+        super(Px2Px_PL, self).__init__()
+        self.opt = opt.base_configs
+        self.config = opt
+        self.isTrain = self.opt.isTrain
+        sat = self.config.satclip
+        use_sat = bool(sat.use_satclip)
+        if use_sat and sat.satclip_style == "concat":
+            raise NotImplementedError("SatCLIP 'concat' style is not on the MI355X path; use 'inject'")
+        elif use_sat and sat.satclip_style == "inject":
+            print(f"Creating SatCLIP Injection Generator with injection style: '{sat.satclip_inject_style}'.")
+            from model.generator_inject import define_G_inject
+            self.netG = define_G_inject(self.config)
+        else:
+            print("Creating Standard Pix2Pix Generator.")
+            self.netG = networks.define_G(self.opt.input_nc, self.opt.output_nc, self.opt.ngf, self.opt.netG, self.opt.norm,
+                                          not self.opt.no_dropout, self.opt.init_type, self.opt.init_gain)
+        self.netD = networks.define_D(self.opt.input_nc + self.opt.output_nc, self.opt.ndf, self.opt.netD,
+                                      self.opt.n_layers_D, self.opt.norm, self.opt.init_type, self.opt.init_gain)
+        self.criterionGAN = networks.GANLoss(self.opt.gan_mode)
+        self.criterionL1 = HipL1Loss()
+        if self.opt.lambda_rs_losses > 0.0:
+            from utils.remote_sensing_indices import RemoteSensingIndices
+            self.rs_losses = RemoteSensingIndices(mode="loss", criterion=self.opt.rs_losses_criterium)
+        if getattr(self.opt, "lambda_ssim", 0.0) > 0.0 or getattr(self.opt, "lambda_hist", 0.0) > 0.0:
+            raise NotImplementedError("lambda_ssim / lambda_hist > 0 are not on the MI355X path (0.0 in every shipped config)")
+        self.satclip = use_sat
+        self.satclip_model = None     # the location encoder is outside this path; coords may carry embeddings
+        self._fused = None
+        self.logged = {}
+
+    # ------------------------------------------------------------------ pad -> netG -> crop
+    def forward(self, input, embeds=None, use_padding=True):
+        pad = int(self.config.Data.padding_amount) if self.config.Data.padding else 0
+        self.netG.data_pad = pad           # reflect pad + crop are folded into the first / last kernel
+        if not self.satclip:
+            return self.netG(input)
+        if self.config.satclip.satclip_style == "inject":
+            return self.netG(input, embeds)
+        raise NotImplementedError("SatClip Style not recognized")
+
+    @torch.no_grad()
+    def predict_step(self, rgb, coords=None):
+        assert self.training == False, "Model is in training mode, set to eval mode before predicting"
+        if self.satclip == False:
+            batch = {"rgb": rgb, "nir": torch.Tensor([0])}
+            rgb, _ = self.extract_batch(batch)
+            return self.forward(rgb)
+        if self.config.satclip.satclip_style == "inject":
+            batch = {"rgb": rgb, "nir": torch.Tensor([0]), "coords": coords}
+            rgb, _, embeds = self.extract_batch(batch)
+            return self.forward(rgb, embeds)
+        raise NotImplementedError("SatClip Style not recognized, choose 'concat' or 'inject'")
+
+    def _log(self, name, value):
+        if _HAVE_PL and getattr(self, "_trainer", None) is not None:
+            self.log(name, value)
+        else:
+            self.logged[name] = value.detach() if torch.is_tensor(value) else value
+
+    def training_step(self, batch, batch_idx, optimizer_idx):
+        assert self.training == True, "Model is in eval mode, set to training mode before training"
+        embeds = None
+        if self.satclip == False:
+            rgb, nir = self.extract_batch(batch)
+        else:
+            rgb, nir, embeds = self.extract_batch(batch)
+        pred = self.forward(rgb, embeds) if embeds is not None else self.forward(rgb)
+        if optimizer_idx == 0:
+            fake_AB = torch.cat((rgb, pred), 1)
+            pred_fake = self.netD(fake_AB.detach())
+            loss_D_fake = self.criterionGAN(pred_fake, False)
+            real_AB = torch.cat((rgb, nir), 1)
+            pred_real = self.netD(real_AB)
+            loss_D_real = self.criterionGAN(pred_real, True)
+            loss_D = (loss_D_fake + loss_D_real)
+            self._log("model_loss/discriminator_real", loss_D_real)
+            self._log("model_loss/discriminator_fake", loss_D_fake)
+            self._log("model_loss/discriminator_loss", loss_D)
+            return loss_D
+        if optimizer_idx == 1:
+            fake_AB = torch.cat((rgb, pred), 1)
+            pred_fake = self.netD(fake_AB)
+            loss_G_GAN = self.criterionGAN(pred_fake, True)
+            self._log("model_loss/generator_GAN_loss", loss_G_GAN)
+            loss_G_L1 = self.criterionL1(pred, nir)
+            self._log("model_loss/generator_L1", loss_G_L1)
+            loss_G = loss_G_GAN * self.opt.lambda_GAN + loss_G_L1 * self.opt.lambda_L1
+            if self.opt.lambda_rs_losses > 0.0:
+                losses_rs_indices = self.rs_losses.get_and_weight_losses(rgb, nir, pred,
+                                                                         loss_config=dict(self.opt.internal_rs_loss_weights))
+                self._log("model_loss/indices_loss_weighted", losses_rs_indices)
+                loss_G = loss_G + losses_rs_indices * self.opt.lambda_rs_losses
+            self._log("model_loss/generator_total_loss", loss_G)
+            return loss_G
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """Scalar part of the reference's validation (val/L1); image/plot logging is out of scope."""
+        embeds = None
+        if self.satclip == False:
+            rgb, nir = self.extract_batch(batch)
+        else:
+            rgb, nir, embeds = self.extract_batch(batch)
+        pred = self.forward(rgb, embeds) if embeds is not None else self.forward(rgb)
+        l1 = self.criterionL1(pred, nir)
+        self._log("val/L1", l1)
+        return l1
+
+    def extract_batch(self, batch):
+        rgb = batch["rgb"]
+        nir = batch["nir"]
+        if not self.satclip:
+            return rgb, nir
+        coords = batch["coords"]
+        if self.config.satclip.satclip_style == "inject":
+            return rgb, nir, self.satclip_get_inject(coords)
+        raise NotImplementedError("SatClip Style not recognized, choose 'concat' or 'inject'")
+
+    def satclip_get_inject(self, coords):
+        if coords is not None and coords.dim() == 2 and coords.shape[-1] == 256:
+            return coords.float()            # precomputed SatCLIP embeddings
+        raise NotImplementedError("the SatCLIP location encoder is outside the MI355X path: pass B x 256 embeddings as 'coords'")
+
+    def configure_optimizers(self):
+        optim_g = HipAdam(self.netG.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999), net=self.netG)
+        optim_d = HipAdam(self.netD.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999), net=self.netD)
+        sched_g = ReduceLROnPlateau(optim_g, mode='min', patience=self.config.Schedulers.patience_g)
+        sched_d = ReduceLROnPlateau(optim_d, mode='min', patience=self.config.Schedulers.patience_d)
+        return ([optim_d, optim_g],
+                [{'scheduler': sched_d, 'monitor': self.config.Schedulers.metric, 'interval': 'epoch'},
+                 {'scheduler': sched_g, 'monitor': self.config.Schedulers.metric, 'interval': 'epoch'}])
+
+    # ------------------------------------------------------------------ fused fast path
+    def fused_trainer(self, reducer=None) -> Pix2PixTrainer:
+        if self._fused is None:
+            sat = self.config.satclip
+            inject = None
+            if self.satclip:
+                inject = {"style": sat.satclip_inject_style, "use_scale": bool(sat.scaling_param),
+                          "post_correction": bool(sat.post_correction)}
+            pad = int(self.config.Data.padding_amount) if self.config.Data.padding else 0
+            self._fused = Pix2PixTrainer(
+                self.netG, self.netD, n_blocks=self.netG.n_blocks, lr=self.opt.lr, beta1=self.opt.beta1,
+                lambda_gan=self.opt.lambda_GAN, lambda_l1=self.opt.lambda_L1, lambda_rs=self.opt.lambda_rs_losses,
+                rs_weights=dict(self.opt.internal_rs_loss_weights), rs_criterion=self.opt.rs_losses_criterium,
+                padding=pad, inject=inject, reducer=reducer)
+        return self._fused
+
+    def train_batch(self, batch):
+        """Both optimizer passes of one batch (D then G) on the fused HIP trainer; returns a lazy loss view."""
+        assert self.training == True, "Model is in eval mode, set to training mode before training"
+        if self.satclip:
+            rgb, nir, embeds = self.extract_batch(batch)
+        else:
+            (rgb, nir), embeds = self.extract_batch(batch), None
+        return self.fused_trainer().step(rgb, nir, embeds)

@@ -1,0 +1,432 @@
+"""Launch plans for the generator and the PatchGAN on libnirgan_hip.
+
+An engine owns, for one (batch, tile size) shape, every device buffer of a network (halo'd
+NHWC activations, saved statistics, gradient scratch, packed weights, split-K slabs) and the
+pre-built descriptor lists ("plans") for forward and backward.  Running a plan is a tight
+loop of C-ABI calls on the current HIP stream: no allocation, no synchronisation.  Buffers
+are sized for residency (288 GB HBM3E): nothing is recomputed or re-laid-out between forward
+and backward.
+
+Reference structure being reproduced: ResnetGenerator / ResnetBlock (model/networks.py:316-434),
+ResnetGenerator_inject.forward (model/generator_inject.py:105-135), NLayerDiscriminator
+(model/networks.py:539-584), Px2Px_PL.forward's pad/crop (model/pix2pix.py:88-110).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import geometry as G
+from . import lib as L
+
+IN_EPS = 1e-5
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Ctx:
+    """Device context of an engine: allocator, zero page, stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda" and not L.is_emulated():
+            raise RuntimeError("nirgan_hip runs on MI355X (cuda device) only; there is no CPU path")
+        self.zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)
+        self.keep: list = []
+        self.bytes = 0
+
+    def zeros(self, *shape) -> torch.Tensor:
+        t = torch.zeros(*shape, dtype=torch.float32, device=self.device)
+        self.bytes += t.numel() * 4
+        return t
+
+    def i32(self, arr: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.device)
+        self.keep.append(t)
+        return t
+
+    def stream(self):
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return None
+
+
+class Halo:
+    """[B][H+2p][W+2p][C] fp32 buffer; the interior starts at (p, p)."""
+
+    def __init__(self, ctx: Ctx, B, H, W, C, pad=0, tensor: Optional[torch.Tensor] = None):
+        self.B, self.H, self.W, self.C, self.pad = B, H, W, C, pad
+        self.hp, self.wp = H + 2 * pad, W + 2 * pad
+        self.t = tensor if tensor is not None else ctx.zeros(B, self.hp, self.wp, C)
+        assert self.t.numel() == B * self.hp * self.wp * C
+        ctx.keep.append(self.t)          # descriptors hold raw pointers: the context owns every buffer
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    @property
+    def elems(self):
+        return self.t.numel()
+
+    def interior(self) -> torch.Tensor:
+        p = self.pad
+        return self.t[:, p:p + self.H, p:p + self.W, :]
+
+
+class Plan:
+    def __init__(self, ctx: Ctx):
+        self.ctx = ctx
+        self.ops: list = []
+
+    def add(self, name: str, *args):
+        self.ops.append((name, args))
+
+    def extend(self, other: "Plan"):
+        self.ops.extend(other.ops)
+
+    def run(self):
+        be = L.backend()
+        st = self.ctx.stream()
+        for name, args in self.ops:
+            rc = getattr(be, name)(*args, st)
+            if rc != 0:
+                L.check(rc, name)
+
+
+def _set_taps(desc, dh, dw):
+    assert len(dh) == len(dw) <= L.MAX_TAPS
+    desc.ntaps = len(dh)
+    for i, (a, b) in enumerate(zip(dh, dw)):
+        desc.tap_dh[i] = a
+        desc.tap_dw[i] = b
+
+
+class Weights:
+    """Packed copies of one parameter tensor, refreshed by a pack plan."""
+
+    def __init__(self, ctx: Ctx):
+        self.ctx = ctx
+        self.cache: Dict[tuple, torch.Tensor] = {}
+
+    def packed(self, plan: Plan, param: torch.Tensor, spec: G.PackSpec, rows_alloc: Optional[int] = None) -> torch.Tensor:
+        key = (param.data_ptr(), spec.key)
+        if key in self.cache:
+            return self.cache[key]
+        rows = max(spec.N, rows_alloc or 0)
+        buf = self.ctx.zeros(rows, spec.K)
+        imap = self.ctx.i32(spec.index_map)
+        plan.add("nirgan_pack_rows", param.data_ptr(), param.numel(), spec.row_stride, imap.data_ptr(),
+                 buf.data_ptr(), spec.N, spec.K)
+        self.cache[key] = buf
+        return buf
+
+
+# ---------------------------------------------------------------------------------------------
+# descriptor emitters
+# ---------------------------------------------------------------------------------------------
+def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bias, out: Halo, *, N, OH, OW,
+              in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None):
+    d = L.ConvDesc()
+    d.inp, d.in_elems = inp.ptr, inp.elems
+    d.in_hp, d.in_wp, d.in_cs = (in_hw or (inp.hp, inp.wp)) + (inp.C,)
+    d.run, d.in_stride, d.in_oh, d.in_ow = taps.run, in_stride, in_oh, in_ow
+    _set_taps(d, taps.dh, taps.dw)
+    d.w, d.w_elems, d.bias = w.data_ptr(), w.numel(), _ptr(bias)
+    d.out, d.out_elems = out.ptr, out.elems
+    d.out_hp, d.out_wp, d.out_cs = out.hp, out.wp, out.C
+    d.out_stride, d.out_oh, d.out_ow = out_stride, out_oh, out_ow
+    d.B, d.OH, d.OW, d.N = inp.B, OH, OW, N
+    d.zero_page = ctx.zero_page.data_ptr()
+    ctx.keep.append(d)
+    plan.add("nirgan_conv_igemm", C.byref(d))
+    return d
+
+
+def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.PackSpec, grad: torch.Tensor, *,
+               N, OH, OW, p_oh, p_ow, q_stride=1, q_oh=0, q_ow=0, accumulate=False, slabs_pool=None):
+    K = taps.n * taps.run
+    assert K == spec.K, (K, spec.K)
+    tiles = (-(-N // 128) if N > 64 else 1) * (-(-K // 128))
+    M = p.B * OH * OW
+    nsplit, rows = G.wgrad_split(M, tiles)
+    need = nsplit * N * K
+    slabs = slabs_pool.get(need) if slabs_pool is not None else ctx.zeros(need)
+    d = L.WgradDesc()
+    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = p.ptr, p.elems, p.hp, p.wp, p.C, p_oh, p_ow
+    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = q.ptr, q.elems, q.hp, q.wp, q.C
+    d.q_stride, d.q_oh, d.q_ow = q_stride, q_oh, q_ow
+    d.run = taps.run
+    _set_taps(d, taps.dh, taps.dw)
+    d.B, d.OH, d.OW, d.N = p.B, OH, OW, N
+    d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
+    d.zero_page = ctx.zero_page.data_ptr()
+    ctx.keep.append(d)
+    imap = ctx.i32(spec.index_map)
+    plan.add("nirgan_wgrad_igemm", C.byref(d))
+    plan.add("nirgan_reduce_rows", slabs.data_ptr(), nsplit, N, K, imap.data_ptr(), grad.data_ptr(), grad.numel(),
+             spec.row_stride, 1 if accumulate else 0)
+    return d
+
+
+class SlabPool:
+    """Scratch shared by the weight-gradient launches of an engine (they run serially on one stream)."""
+
+    DEFAULT = 20 * 1024 * 1024   # floats; covers ~1024 blocks x 128x128 partial tiles
+
+    def __init__(self, ctx: Ctx):
+        self.ctx, self.buf = ctx, None
+
+    def get(self, n: int) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < n:
+            floor = 0 if (self.buf is not None or L.is_emulated()) else self.DEFAULT
+            self.buf = self.ctx.zeros(max(n, floor))
+            self.ctx.keep.append(self.buf)
+        return self.buf
+
+
+def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.ACT_NONE, slope=0.2, residual: Optional[Halo] = None,
+                border=L.BORDER_KEEP, stats=None, ws=None):
+    assert y.pad == 0 and out.H == y.H and out.W == y.W and out.C == y.C
+    d = L.InFwdDesc()
+    d.y, d.B, d.H, d.W, d.C = y.ptr, y.B, y.H, y.W, y.C
+    d.norm, d.eps = (1 if norm else 0), IN_EPS
+    if norm:
+        d.mean, d.rstd = stats[0].data_ptr(), stats[1].data_ptr()
+        d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
+    d.act, d.slope = act, slope
+    if residual is not None:
+        d.residual, d.r_hp, d.r_wp, d.r_pad = residual.ptr, residual.hp, residual.wp, residual.pad
+    d.out, d.o_hp, d.o_wp, d.o_pad, d.border = out.ptr, out.hp, out.wp, out.pad, border
+    ctx.keep.append(d)
+    plan.add("nirgan_instnorm_fwd", C.byref(d))
+    return d
+
+
+def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Optional[Halo] = None, a: Optional[Halo] = None,
+                act=L.ACT_NONE, slope=0.2, y: Optional[Halo] = None, stats=None, norm=True, dy: Halo, gsum: Optional[Halo] = None,
+                dbias: Optional[torch.Tensor] = None, ws=None, shape=None):
+    B, H, W, Cc = shape
+    d = L.InBwdDesc()
+    if g is not None:
+        assert g.H == H and g.W == W and g.C == Cc
+        d.g, d.g_hp, d.g_wp, d.g_pad, d.g_fold = g.ptr, g.hp, g.wp, g.pad, (1 if g_fold else 0)
+    if g2 is not None:
+        assert g2.pad == 0
+        d.g2 = g2.ptr
+    if a is not None:
+        d.a, d.a_hp, d.a_wp, d.a_pad = a.ptr, a.hp, a.wp, a.pad
+    d.act, d.slope = act, slope
+    d.norm = 1 if norm else 0
+    if norm:
+        d.y, d.mean, d.rstd = y.ptr, stats[0].data_ptr(), stats[1].data_ptr()
+        d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
+    d.B, d.H, d.W, d.C = B, H, W, Cc
+    d.dy, d.d_hp, d.d_wp, d.d_pad = dy.ptr, dy.hp, dy.wp, dy.pad
+    if gsum is not None:
+        d.gsum_out = gsum.ptr
+    if dbias is not None:
+        d.dbias = dbias.data_ptr()
+    ctx.keep.append(d)
+    plan.add("nirgan_instnorm_bwd", C.byref(d))
+    return d
+
+
+class _Scratch:
+    """Workspace for instance-norm partial sums, sized for the largest user."""
+
+    def __init__(self, ctx: Ctx):
+        self.ctx, self.n = ctx, 0
+        self.t: Optional[torch.Tensor] = None
+
+    def want(self, B, H, W, Cc):
+        self.n = max(self.n, int(L.backend().nirgan_instnorm_ws_elems(B, H, W, Cc)))
+
+    def get(self) -> torch.Tensor:
+        if self.t is None or self.t.numel() < self.n:
+            self.t = self.ctx.zeros(max(self.n, 4))
+        return self.t
+
+
+# ---------------------------------------------------------------------------------------------
+# layer bundles: each keeps its buffers and emits forward / backward ops
+# ---------------------------------------------------------------------------------------------
+class ConvIN:
+    """conv (Conv2d / ConvTranspose2d / row-packed first conv) -> [InstanceNorm] -> act -> halo'd output.
+
+    kind: 'conv' (Conv2d k,s,p over an NHWC halo buffer), 'rowpacked' (Conv2d over a 4-channel
+    buffer, one tap per kernel row), 'convT' (ConvTranspose2d k3 s2 p1 op1).
+    """
+
+    def __init__(self, eng, name, kind, inp: Halo, weight, bias, *, k, s, p, cout, norm=True, act=L.ACT_RELU,
+                 out_pad=0, out_border=L.BORDER_KEEP, residual: Optional[Halo] = None, cin_real=None, keep_z=False):
+        self.eng, self.name, self.kind = eng, name, kind
+        self.inp, self.weight, self.bias = inp, weight, bias
+        self.k, self.s, self.p, self.cout = k, s, p, cout
+        self.norm, self.act, self.residual = norm, act, residual
+        self.cin = inp.C if kind != "rowpacked" else cin_real
+        ctx = eng.ctx
+        if kind == "convT":
+            self.OH, self.OW = inp.H * 2, inp.W * 2
+        else:
+            self.OH, self.OW = G.conv_out(inp.H, k, s, p), G.conv_out(inp.W, k, s, p)
+        assert inp.pad >= (p if kind != "convT" else 1), (name, inp.pad, p)
+        B = inp.B
+        self.y = Halo(ctx, B, self.OH, self.OW, cout, 0)
+        self.out = Halo(ctx, B, self.OH, self.OW, cout, out_pad)
+        self.out_border = out_border
+        self.stats = (ctx.zeros(B, cout), ctx.zeros(B, cout)) if norm else None
+        eng.scratch.want(B, self.OH, self.OW, cout)
+        self.keep_z = keep_z   # inject: `out` holds z (no act); the modulation produces the activated tensor
+
+    # ---- forward
+    def emit_fwd(self, plan: Plan, pack: Plan):
+        eng, ctx, inp = self.eng, self.eng.ctx, self.inp
+        k, s, p = self.k, self.s, self.p
+        if self.kind == "conv":
+            taps = G.conv_fwd_taps(k, inp.C)
+            w = eng.weights.packed(pack, self.weight, G.conv_fwd_pack(self.cout, inp.C, k))
+            emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
+                      in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
+        elif self.kind == "rowpacked":
+            taps = G.conv_rowpacked_taps(k, inp.C)
+            w = eng.weights.packed(pack, self.weight, G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C))
+            emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
+                      in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
+        else:  # convT: 4 sub-pixel phases over the zero-halo-1 input
+            for ph in G.convT_fwd_phases(inp.H, inp.W, k, p):
+                taps = G.Taps(ph.dh, ph.dw, inp.C)
+                w = eng.weights.packed(pack, self.weight, G.convT_fwd_pack(inp.C, self.cout, k, ph.taps_hw))
+                emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=ph.n_h, OW=ph.n_w,
+                          in_oh=ph.in_oh + inp.pad - 1, in_ow=ph.in_ow + inp.pad - 1,
+                          out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow)
+        emit_in_fwd(plan, ctx, self.y, self.out, norm=self.norm, act=(L.ACT_NONE if self.keep_z else self.act),
+                    residual=self.residual, border=self.out_border, stats=self.stats, ws=eng.scratch.get())
+
+    # ---- backward: g (+g2) is the gradient wrt `out`; produces dy (zero halo) then weight / data gradients
+    def alloc_bwd(self, need_dgrad: bool):
+        ctx, k = self.eng.ctx, self.k
+        if self.kind == "convT":
+            zpad = 1
+        elif self.s == 1:
+            zpad = k - 1 if need_dgrad else 0
+        else:
+            zpad = 1 if need_dgrad else 0
+        self.dy = Halo(ctx, self.inp.B, self.OH, self.OW, self.cout, zpad)
+
+    def emit_bwd(self, plan: Plan, pack: Plan, *, g: Optional[Halo], g_fold=False, g2: Optional[Halo] = None,
+                 gsum: Optional[Halo] = None, gw: Optional[torch.Tensor], gb: Optional[torch.Tensor], dgrad_out: Optional[Halo],
+                 mask: Optional[Halo] = None, act=None):
+        eng, ctx, inp = self.eng, self.eng.ctx, self.inp
+        k, s, p = self.k, self.s, self.p
+        act = self.act if act is None else act
+        emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, a=(mask if mask is not None else self.out), act=act,
+                    y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum, dbias=gb, ws=eng.scratch.get(),
+                    shape=(inp.B, self.OH, self.OW, self.cout))
+        dy = self.dy
+        # weight gradient (skipped when the parameters are frozen: gw is None)
+        if gw is None:
+            pass
+        elif self.kind == "conv":
+            emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
+                       N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
+                       q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs)
+        elif self.kind == "rowpacked":
+            emit_wgrad(plan, ctx, dy, inp, G.conv_rowpacked_taps(k, inp.C), G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C), gw,
+                       N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
+                       q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs)
+        else:  # convT: rows = input channels, gathered side = dY with stride 2
+            emit_wgrad(plan, ctx, inp, dy, G.convT_dgrad_taps(k, self.cout), G.convT_dgrad_pack(inp.C, self.cout, k), gw,
+                       N=inp.C, OH=inp.H, OW=inp.W, p_oh=inp.pad, p_ow=inp.pad, q_stride=2,
+                       q_oh=dy.pad - p, q_ow=dy.pad - p, slabs_pool=eng.slabs)
+        # data gradient
+        if dgrad_out is None:
+            return
+        if self.kind == "conv" and s == 1:
+            # full correlation: gradient wrt the halo'd input (size H+2p), folded / cropped by the consumer
+            assert dgrad_out.H == inp.H and dgrad_out.pad == p and dy.pad == k - 1
+            taps = G.conv_dgrad_s1_taps(k, self.cout)
+            hw = [(kh, kw) for kh in range(k) for kw in range(k)]
+            w = eng.weights.packed(pack, self.weight, G.conv_dgrad_pack(self.cout, inp.C, k, hw))
+            emit_conv(plan, ctx, dy, taps, w, None, dgrad_out, N=inp.C, OH=dgrad_out.hp, OW=dgrad_out.wp)
+        elif self.kind in ("conv", "rowpacked") and s == 2:
+            assert dgrad_out.H == inp.H and dy.pad == 1
+            cin_buf = inp.C
+            for ph in G.conv_dgrad_s2_phases(inp.H, inp.W, k, p):
+                if self.kind == "conv":
+                    spec = G.conv_dgrad_pack(self.cout, inp.C, k, ph.taps_hw)
+                else:
+                    spec = G.conv_dgrad_pack(self.cout, self.cin, k, ph.taps_hw)
+                    cin_buf = self.cin
+                w = eng.weights.packed(pack, self.weight, spec)
+                emit_conv(plan, ctx, dy, G.Taps(ph.dh, ph.dw, self.cout), w, None, dgrad_out, N=cin_buf,
+                          OH=ph.n_h, OW=ph.n_w, in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2,
+                          out_oh=ph.out_oh + dgrad_out.pad, out_ow=ph.out_ow + dgrad_out.pad)
+        elif self.kind == "convT":
+            assert dgrad_out.H == inp.H and dy.pad == 1
+            w = eng.weights.packed(pack, self.weight, G.convT_dgrad_pack(inp.C, self.cout, k))
+            emit_conv(plan, ctx, dy, G.convT_dgrad_taps(k, self.cout), w, None, dgrad_out, N=inp.C, OH=inp.H, OW=inp.W,
+                      in_stride=2, in_oh=dy.pad - p, in_ow=dy.pad - p, out_oh=dgrad_out.pad, out_ow=dgrad_out.pad)
+        else:
+            raise NotImplementedError(self.kind)
+
+
+class TapPlaneConv:
+    """Conv2d(C, 1, k, padding=p) (+bias, +tanh, +crop) as a 1x1 product into k*k tap planes
+    followed by a shifted gather-sum (model/networks.py:367-368 and :579)."""
+
+    def __init__(self, eng, name, inp: Halo, weight, bias, *, k, p, act=L.ACT_NONE, crop=0):
+        self.eng, self.name, self.inp, self.weight, self.bias = eng, name, inp, weight, bias
+        self.k, self.p, self.act, self.crop = k, p, act, crop
+        assert inp.pad == p
+        ctx = eng.ctx
+        self.nt = k * k
+        self.qcs = -(-self.nt // 4) * 4
+        self.OH, self.OW = inp.hp - k + 1, inp.wp - k + 1
+        self.q = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
+        self.whole_in = Halo(ctx, inp.B, inp.hp, inp.wp, inp.C, 0, tensor=inp.t)     # same memory, halo as image
+        self.dst = ctx.zeros(inp.B, 1, self.OH - 2 * crop, self.OW - 2 * crop)
+
+    def emit_fwd(self, plan: Plan, pack: Plan):
+        eng, ctx = self.eng, self.eng.ctx
+        w = eng.weights.packed(pack, self.weight, G.tapplane_fwd_pack(self.inp.C, self.k), rows_alloc=self.qcs)
+        emit_conv(plan, ctx, self.whole_in, G.Taps([0], [0], self.inp.C), w, None, self.q, N=self.qcs,
+                  OH=self.inp.hp, OW=self.inp.wp)
+        d = L.TapGatherDesc()
+        d.q, d.q_hp, d.q_wp, d.q_cs, d.ntaps = self.q.ptr, self.q.hp, self.q.wp, self.qcs, self.nt
+        for t in range(self.nt):
+            d.tap_dh[t], d.tap_dw[t] = t // self.k, t % self.k
+        d.bias, d.act = _ptr(self.bias), self.act
+        d.B, d.OH, d.OW, d.crop, d.dst = self.inp.B, self.OH, self.OW, self.crop, self.dst.data_ptr()
+        ctx.keep.append(d)
+        plan.add("nirgan_tap_gather", C.byref(d))
+
+    def alloc_bwd(self):
+        ctx, inp = self.eng.ctx, self.inp
+        self.dq = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
+        self.gin = Halo(ctx, inp.B, inp.H, inp.W, inp.C, inp.pad)     # gradient wrt the halo'd input
+        self.gin_whole = Halo(ctx, inp.B, inp.hp, inp.wp, inp.C, 0, tensor=self.gin.t)
+        self.dout = ctx.zeros(inp.B, 1, self.OH - 2 * self.crop, self.OW - 2 * self.crop)
+
+    def emit_bwd(self, plan: Plan, pack: Plan, gw: Optional[torch.Tensor], gb: Optional[torch.Tensor]):
+        eng, ctx, inp = self.eng, self.eng.ctx, self.inp
+        d = L.TapScatterDesc()
+        d.dout, d.out, d.act = self.dout.data_ptr(), self.dst.data_ptr(), self.act
+        d.B, d.OH, d.OW, d.crop, d.ntaps = inp.B, self.OH, self.OW, self.crop, self.nt
+        for t in range(self.nt):
+            d.tap_dh[t], d.tap_dw[t] = t // self.k, t % self.k
+        d.dq, d.q_hp, d.q_wp, d.q_cs = self.dq.ptr, self.dq.hp, self.dq.wp, self.qcs
+        d.dbias = _ptr(gb)
+        ctx.keep.append(d)
+        self.scatter_desc = d
+        plan.add("nirgan_tap_scatter", C.byref(d))
+        if gw is not None:
+            emit_wgrad(plan, ctx, self.dq, self.whole_in, G.Taps([0], [0], inp.C), G.tapplane_fwd_pack(inp.C, self.k), gw,
+                       N=self.nt, OH=inp.hp, OW=inp.wp, p_oh=0, p_ow=0, slabs_pool=eng.slabs)
+        w = eng.weights.packed(pack, self.weight, G.tapplane_dgrad_pack(inp.C, self.k, self.qcs))
+        emit_conv(plan, ctx, self.dq, G.Taps([0], [0], self.qcs), w, None, self.gin_whole, N=inp.C, OH=inp.hp, OW=inp.wp)

@@ -1,0 +1,79 @@
+"""Flat parameter / gradient / Adam-state storage for one network.
+
+All parameters of a network live in ONE fp32 device buffer (each tensor starts on a 16-byte
+boundary), gradients in a second one of the same layout.  The nn.Parameter objects of the
+module alias slices of it, so ``state_dict()`` keeps the reference's keys and layouts
+(model/networks.py Sequential indices), Adam is a single streaming kernel over the range
+(nirgan_adam) and data parallelism is a single RCCL all-reduce per network per step.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import lib as L
+
+
+class FlatParams:
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        self.names: List[str] = []
+        self.slices: Dict[str, Tuple[int, int, torch.Size]] = {}
+        self.flat = self.grad = self.m = self.v = None
+        self.step_count = 0
+        self.version = 0            # bumped whenever parameter VALUES change through this object
+        self._bind()
+
+    def _bind(self):
+        named = list(self.module.named_parameters())
+        assert named, "module has no parameters"
+        dev = named[0][1].device
+        off = 0
+        self.names, self.slices = [], {}
+        for n, p in named:
+            assert p.dtype == torch.float32 and p.device == dev
+            self.names.append(n)
+            self.slices[n] = (off, p.numel(), p.shape)
+            off += -(-p.numel() // 4) * 4
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = self.v = None
+        with torch.no_grad():
+            for n, p in named:
+                o, k, shp = self.slices[n]
+                view = self.flat[o:o + k].view(shp)
+                view.copy_(p.data)
+                p.data = view
+        self._ptr0 = named[0][1].data_ptr()
+        self.device = dev
+        self.version += 1
+
+    def ensure(self) -> bool:
+        """Re-bind when the module was moved / re-materialised (e.g. ``.to(device)``). True if rebuilt."""
+        p0 = next(self.module.parameters())
+        if p0.data_ptr() != self._ptr0 or p0.device != self.device:
+            self._bind()
+            return True
+        return False
+
+    def param_views(self) -> Dict[str, torch.Tensor]:
+        return {n: self.flat[o:o + k].view(s) for n, (o, k, s) in self.slices.items()}
+
+    def grad_views(self) -> Dict[str, torch.Tensor]:
+        return {n: self.grad[o:o + k].view(s) for n, (o, k, s) in self.slices.items()}
+
+    def values_version(self) -> int:
+        """Changes whenever any parameter was modified in place (torch version counters) or re-bound."""
+        return self.version * 1000003 + sum(p._version for p in self.module.parameters())
+
+    def adam_step(self, lr: float, beta1: float, beta2: float = 0.999, eps: float = 1e-8, stream=None):
+        """torch.optim.Adam(lr, betas=(beta1, 0.999)) on the whole network (model/pix2pix.py:486-487)."""
+        if self.m is None:
+            self.m = torch.zeros_like(self.flat)
+            self.v = torch.zeros_like(self.flat)
+        self.step_count += 1
+        L.call("nirgan_adam", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+               self.total, lr, beta1, beta2, eps, self.step_count, stream)
+        self.version += 1

@@ -146,6 +146,11 @@ def f1(n_blocks, name, lam_rs=0.0, padding=0, H=32):
     torch.manual_seed(0)
     netG = ref_networks.define_G(3, 1, 8, f"resnet_{n_blocks}blocks", "instance", False, "normal", 0.02)
     netD = ref_networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
+    if lam_rs > 0:
+        # the spectral indices are singular where pred + band ~ 0 and pred comes out of tanh in (-1, 1):
+        # a positive output bias keeps pred in (0.5, 1) so that the whole-step vectors are well conditioned
+        with torch.no_grad():
+            list(netG.parameters())[-1].fill_(1.5)
     pG0, pD0 = sd(netG), sd(netD)
     rgb, nir, _ = synth(2, H, H, 1234)
     rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333,
@@ -193,7 +198,7 @@ def f_inject(name):
         netG.scale_param.fill_(0.5)   # large enough that the modulation is visible at 1e-3
     netD = ref_networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
     pG0, pD0 = sd(netG), sd(netD)
-    rgb, nir, emb = synth(2, 40, 40, 99)      # non-square-friendly size: inject map is 20x20
+    rgb, nir, emb = synth(2, 40, 40, 100)     # inject map is 20x20 (seed chosen so that no ReLU input is within 1e-6 of 0)
     res = ref_train_batch(netG, netD, rgb, nir, embeds=emb)
     close(O.generator_inject_forward(pG0, rgb, emb, 9), res["pred"], what="inject forward")
     check_trainer(pG0, pD0, 9, rgb, nir, res, embeds=emb)
@@ -304,7 +309,7 @@ def f5(name):
 
 if __name__ == "__main__":
     f1(6, "f1_g6_d.npz")
-    f1(9, "f1_g9_rs_pad.npz", lam_rs=1.0, padding=10, H=40)
+    f1(9, "f1_g9_rs_pad.npz", lam_rs=1.0, padding=10, H=44)
     f_inject("f1_inject.npz")
     f3("f3_losses.npz")
     f5("f5_fullsize.npz")

@@ -1,0 +1,435 @@
+"""numpy emulator of the libnirgan_hip C ABI -- TEST INFRASTRUCTURE ONLY.
+
+Implements every entry point of include/nirgan_hip.h on HOST pointers with the documented
+semantics (halo'd NHWC buffers, tap lists, split slabs ...).  Installed through the
+``nirgan_hip.lib.set_backend`` test seam so that the host logic (descriptor geometry, buffer
+plumbing, plan ordering, flat parameters, trainer, data parallel reducer) can be exercised
+against the oracle WITHOUT a GPU.  It is never used by the product path, smoke() or bench.py.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def arr(ptr, n, dtype=np.float32):
+    if ptr is None or ptr == 0:
+        return None
+    if hasattr(ptr, "value"):
+        ptr = ptr.value
+    ct = C.c_float if dtype == np.float32 else C.c_int32
+    return np.ctypeslib.as_array((ct * int(n)).from_address(int(ptr)))
+
+
+def obj(ref):
+    return ref._obj if hasattr(ref, "_obj") else ref
+
+
+def _in_nchunk(B, HW, Cc):
+    q4 = Cc // 4
+    nrg = 1 if q4 >= 256 else 256 // q4
+    want = max(1, 2048 // B)
+    cap = max(1, HW // (nrg * 8))
+    return min(want, cap)
+
+
+def halo_images(h, H, P):
+    out = [h + P]
+    if 1 <= h <= P:
+        out.append(P - h)
+    if H - 1 - P <= h <= H - 2:
+        out.append(P + 2 * (H - 1) - h)
+    return out
+
+
+def reflect(i, n):
+    i = np.abs(i)
+    return np.where(i >= n, 2 * (n - 1) - i, i)
+
+
+class EmuBackend:
+    is_emulator = True
+
+    def __init__(self):
+        self.err = b""
+        self.calls = []
+
+    # ------------------------------------------------------------------ housekeeping
+    def nirgan_version(self):
+        return 100
+
+    def nirgan_last_error(self):
+        return self.err
+
+    def _fail(self, msg):
+        self.err = msg.encode()
+        return -1
+
+    # ------------------------------------------------------------------ conv
+    def nirgan_conv_igemm(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("conv")
+        if d.run % 4 or d.in_cs % 4:
+            return self._fail("conv: run/in_cs not multiple of 4")
+        K = d.ntaps * d.run
+        inp = arr(d.inp, d.in_elems)
+        w = arr(d.w, d.w_elems)[: d.N * K].reshape(d.N, K)
+        out = arr(d.out, d.out_elems)
+        bias = arr(d.bias, d.N)
+        in_row, out_row = d.in_wp * d.in_cs, d.out_wp * d.out_cs
+        in_img, out_img = d.in_hp * in_row, d.out_hp * out_row
+        oh, ow = np.arange(d.OH)[:, None], np.arange(d.OW)[None, :]
+        base = (oh * d.in_stride + d.in_oh) * in_row + (ow * d.in_stride + d.in_ow) * d.in_cs
+        obase = (oh * d.out_stride + d.out_oh) * out_row + (ow * d.out_stride + d.out_ow) * d.out_cs
+        rr = np.arange(d.run)
+        for t in range(d.ntaps):
+            r0, r1 = (d.OH - 1) * d.in_stride + d.in_oh + d.tap_dh[t], d.in_oh + d.tap_dh[t]
+            if min(r0, r1) < 0 or max(r0, r1) >= d.in_hp:
+                return self._fail("conv: input rows out of range")
+            c0 = d.in_ow + d.tap_dw[t]
+            c1 = (d.OW - 1) * d.in_stride + d.in_ow + d.tap_dw[t]
+            if c0 < 0 or c1 * d.in_cs + d.run > d.in_wp * d.in_cs:
+                return self._fail("conv: input cols out of range")
+        if d.N > d.out_cs or (d.OH - 1) * d.out_stride + d.out_oh >= d.out_hp or (d.OW - 1) * d.out_stride + d.out_ow >= d.out_wp:
+            return self._fail("conv: output out of range")
+        for b in range(d.B):
+            acc = np.zeros((d.OH, d.OW, d.N), dtype=np.float64)
+            for t in range(d.ntaps):
+                off = (d.tap_dh[t] * d.in_wp + d.tap_dw[t]) * d.in_cs
+                A = inp[b * in_img + base[..., None] + off + rr]
+                acc += A.astype(np.float64) @ w[:, t * d.run:(t + 1) * d.run].T.astype(np.float64)
+            if bias is not None:
+                acc += bias
+            idx = b * out_img + obase[..., None] + np.arange(d.N)
+            out[idx] = acc.astype(np.float32)
+        return 0
+
+    def nirgan_wgrad_igemm(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("wgrad")
+        K = d.ntaps * d.run
+        if d.rows_per_split % 32 or d.nsplit * d.rows_per_split < d.B * d.OH * d.OW:
+            return self._fail("wgrad: bad split")
+        if ((d.N + 3) & ~3) > d.p_cs:
+            return self._fail("wgrad: N exceeds p_cs")
+        p, q = arr(d.p, d.p_elems), arr(d.q, d.q_elems)
+        slabs = arr(d.slabs, d.slab_elems)[: d.nsplit * d.N * K].reshape(d.nsplit, d.N, K)
+        p_row, q_row = d.p_wp * d.p_cs, d.q_wp * d.q_cs
+        oh, ow = np.arange(d.OH)[:, None], np.arange(d.OW)[None, :]
+        pbase = (oh + d.p_oh) * p_row + (ow + d.p_ow) * d.p_cs
+        qbase = (oh * d.q_stride + d.q_oh) * q_row + (ow * d.q_stride + d.q_ow) * d.q_cs
+        for t in range(d.ntaps):
+            r0, r1 = d.q_oh + d.tap_dh[t], (d.OH - 1) * d.q_stride + d.q_oh + d.tap_dh[t]
+            c0, c1 = d.q_ow + d.tap_dw[t], (d.OW - 1) * d.q_stride + d.q_ow + d.tap_dw[t]
+            if r0 < 0 or r1 >= d.q_hp or c0 < 0 or c1 * d.q_cs + d.run > d.q_wp * d.q_cs:
+                return self._fail("wgrad: q window out of range")
+        if d.OH - 1 + d.p_oh >= d.p_hp or d.OW - 1 + d.p_ow >= d.p_wp:
+            return self._fail("wgrad: p window out of range")
+        P_all, Q_all = [], []
+        for b in range(d.B):
+            P_all.append(p[b * d.p_hp * p_row + pbase[..., None] + np.arange(d.N)].reshape(-1, d.N))
+            qs = []
+            for t in range(d.ntaps):
+                off = (d.tap_dh[t] * d.q_wp + d.tap_dw[t]) * d.q_cs
+                qs.append(q[b * d.q_hp * q_row + qbase[..., None] + off + np.arange(d.run)].reshape(-1, d.run))
+            Q_all.append(np.concatenate(qs, axis=1))
+        P_all, Q_all = np.concatenate(P_all).astype(np.float64), np.concatenate(Q_all).astype(np.float64)
+        M = P_all.shape[0]
+        for s in range(d.nsplit):
+            a, e = s * d.rows_per_split, min((s + 1) * d.rows_per_split, M)
+            slabs[s] = (P_all[a:e].T @ Q_all[a:e]).astype(np.float32) if e > a else 0.0
+        return 0
+
+    def nirgan_reduce_rows(self, slabs, nsplit, N, K, imap, dst, dst_elems, stride, accumulate, stream=None):
+        self.calls.append("reduce")
+        s = arr(slabs, nsplit * N * K).reshape(nsplit, N, K).sum(0)
+        m = arr(imap, K, np.int32)
+        o = arr(dst, dst_elems)
+        ok = m >= 0
+        idx = (np.arange(N)[:, None] * stride + m[None, :])[:, ok]
+        if idx.max() >= dst_elems:
+            return self._fail("reduce_rows: index out of range")
+        if accumulate:
+            o[idx] += s[:, ok]
+        else:
+            o[idx] = s[:, ok]
+        return 0
+
+    def nirgan_pack_rows(self, src, src_elems, stride, imap, dst, N, K, stream=None):
+        self.calls.append("pack")
+        s, m, o = arr(src, src_elems), arr(imap, K, np.int32), arr(dst, N * K).reshape(N, K)
+        ok = m >= 0
+        idx = np.arange(N)[:, None] * stride + np.where(ok, m, 0)[None, :]
+        if idx.max() >= src_elems:
+            return self._fail("pack_rows: index out of range")
+        o[:] = np.where(ok[None, :], s[idx], 0.0)
+        return 0
+
+    # ------------------------------------------------------------------ instance norm
+    def nirgan_instnorm_ws_elems(self, B, H, W, Cc):
+        return B * _in_nchunk(B, H * W, Cc) * 2 * Cc
+
+    @staticmethod
+    def _act(z, act, slope):
+        if act == 1:
+            return np.maximum(z, 0)
+        if act == 2:
+            return np.where(z > 0, z, z * slope)
+        return z
+
+    def nirgan_instnorm_fwd(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("in_fwd")
+        B, H, W, Cc = d.B, d.H, d.W, d.C
+        if d.o_hp != H + 2 * d.o_pad or d.o_wp != W + 2 * d.o_pad:
+            return self._fail("in_fwd: geometry")
+        y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float64)
+        if d.norm:
+            if d.ws_elems < self.nirgan_instnorm_ws_elems(B, H, W, Cc):
+                return self._fail("in_fwd: ws too small")
+            mean = y.mean(1)
+            var = y.var(1)
+            rstd = 1.0 / np.sqrt(var + d.eps)
+            arr(d.mean, B * Cc).reshape(B, Cc)[:] = mean
+            arr(d.rstd, B * Cc).reshape(B, Cc)[:] = rstd
+            z = (y - mean[:, None]) * rstd[:, None]
+        else:
+            z = y
+        a = self._act(z, d.act, d.slope).reshape(B, H, W, Cc)
+        if d.residual:
+            r = arr(d.residual, B * d.r_hp * d.r_wp * Cc).reshape(B, d.r_hp, d.r_wp, Cc)
+            a = a + r[:, d.r_pad:d.r_pad + H, d.r_pad:d.r_pad + W]
+        out = arr(d.out, B * d.o_hp * d.o_wp * Cc).reshape(B, d.o_hp, d.o_wp, Cc)
+        P = d.o_pad
+        out[:, P:P + H, P:P + W] = a
+        if d.border == 1 and P > 0:
+            hh = reflect(np.arange(d.o_hp) - P, H)
+            ww = reflect(np.arange(d.o_wp) - P, W)
+            out[:] = a[:, hh][:, :, ww]
+        return 0
+
+    def nirgan_instnorm_bwd(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("in_bwd")
+        B, H, W, Cc = d.B, d.H, d.W, d.C
+        ga = np.zeros((B, H, W, Cc), dtype=np.float64)
+        if d.g:
+            if d.g_hp != H + 2 * d.g_pad or d.g_wp != W + 2 * d.g_pad:
+                return self._fail("in_bwd: g geometry")
+            g = arr(d.g, B * d.g_hp * d.g_wp * Cc).reshape(B, d.g_hp, d.g_wp, Cc).astype(np.float64)
+            P = d.g_pad
+            if d.g_fold:
+                hh = reflect(np.arange(d.g_hp) - P, H)
+                ww = reflect(np.arange(d.g_wp) - P, W)
+                tmp = np.zeros((B, H, d.g_wp, Cc))
+                np.add.at(tmp, (slice(None), hh), g)
+                tmp2 = np.zeros((B, H, W, Cc))
+                np.add.at(tmp2, (slice(None), slice(None), ww), tmp)
+                ga += tmp2
+            else:
+                ga += g[:, P:P + H, P:P + W]
+        if d.g2:
+            ga += arr(d.g2, B * H * W * Cc).reshape(B, H, W, Cc)
+        if d.gsum_out:
+            arr(d.gsum_out, B * H * W * Cc).reshape(B, H, W, Cc)[:] = ga
+        gz = ga
+        if d.act in (1, 2):
+            a = arr(d.a, B * d.a_hp * d.a_wp * Cc).reshape(B, d.a_hp, d.a_wp, Cc)[:, d.a_pad:d.a_pad + H, d.a_pad:d.a_pad + W]
+            gz = np.where(a > 0, ga, ga * (0.0 if d.act == 1 else d.slope))
+        if d.norm:
+            y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float64)
+            mean = arr(d.mean, B * Cc).reshape(B, 1, Cc)
+            rstd = arr(d.rstd, B * Cc).reshape(B, 1, Cc)
+            z = (y - mean) * rstd
+            gzf = gz.reshape(B, H * W, Cc)
+            dy = rstd * (gzf - gzf.mean(1, keepdims=True) - z * (gzf * z).mean(1, keepdims=True))
+            dy = dy.reshape(B, H, W, Cc)
+        else:
+            dy = gz
+        o = arr(d.dy, B * d.d_hp * d.d_wp * Cc).reshape(B, d.d_hp, d.d_wp, Cc)
+        o[:, d.d_pad:d.d_pad + H, d.d_pad:d.d_pad + W] = dy
+        if d.dbias:
+            arr(d.dbias, Cc)[:] += dy.sum((0, 1, 2))
+        return 0
+
+    # ------------------------------------------------------------------ layout
+    def nirgan_nchw_to_halo(self, src, B, Cs, H, W, dst, cs, c0, pad1, pad2, mode, stream=None):
+        self.calls.append("nchw_to_halo")
+        P = pad1 + pad2
+        Hp, Wp = H + 2 * P, W + 2 * P
+        s = arr(src, B * Cs * H * W).reshape(B, Cs, H, W)
+        o = arr(dst, B * Hp * Wp * cs).reshape(B, Hp, Wp, cs)
+        if mode == 1:
+            hh = reflect(reflect(np.arange(Hp) - pad2, H + 2 * pad1) - pad1, H)
+            ww = reflect(reflect(np.arange(Wp) - pad2, W + 2 * pad1) - pad1, W)
+            o[..., c0:c0 + Cs] = s[:, :, hh][:, :, :, ww].transpose(0, 2, 3, 1)
+        else:
+            o[:, P:P + H, P:P + W, c0:c0 + Cs] = s.transpose(0, 2, 3, 1)
+        return 0
+
+    def nirgan_tap_gather(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("tap_gather")
+        q = arr(d.q, d.B * d.q_hp * d.q_wp * d.q_cs).reshape(d.B, d.q_hp, d.q_wp, d.q_cs)
+        acc = np.zeros((d.B, d.OH, d.OW), dtype=np.float64)
+        for t in range(d.ntaps):
+            acc += q[:, d.tap_dh[t]:d.tap_dh[t] + d.OH, d.tap_dw[t]:d.tap_dw[t] + d.OW, t]
+        if d.bias:
+            acc += arr(d.bias, 1)[0]
+        if d.act == 3:
+            acc = np.tanh(acc)
+        c = d.crop
+        arr(d.dst, d.B * (d.OH - 2 * c) * (d.OW - 2 * c)).reshape(d.B, d.OH - 2 * c, d.OW - 2 * c)[:] = acc[:, c:d.OH - c, c:d.OW - c]
+        return 0
+
+    def nirgan_tap_scatter(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("tap_scatter")
+        c = d.crop
+        H2, W2 = d.OH - 2 * c, d.OW - 2 * c
+        dz = arr(d.dout, d.B * H2 * W2).reshape(d.B, H2, W2).astype(np.float64)
+        if d.act == 3:
+            y = arr(d.out, d.B * H2 * W2).reshape(d.B, H2, W2)
+            dz = dz * (1 - y.astype(np.float64) ** 2)
+        full = np.zeros((d.B, d.OH, d.OW))
+        full[:, c:c + H2, c:c + W2] = dz
+        dq = arr(d.dq, d.B * d.q_hp * d.q_wp * d.q_cs).reshape(d.B, d.q_hp, d.q_wp, d.q_cs)
+        dq[:] = 0
+        for t in range(d.ntaps):
+            dq[:, d.tap_dh[t]:d.tap_dh[t] + d.OH, d.tap_dw[t]:d.tap_dw[t] + d.OW, t] = full
+        if d.dbias:
+            arr(d.dbias, 1)[0] += dz.sum()
+        return 0
+
+    # ------------------------------------------------------------------ losses
+    def nirgan_lsgan(self, pred, n, target, weight, loss_out, grad, stream=None):
+        self.calls.append("lsgan")
+        p = arr(pred, n).astype(np.float64)
+        arr(loss_out, 1)[0] += weight * np.mean((p - target) ** 2)
+        if grad:
+            arr(grad, n)[:] = weight * 2 * (p - target) / n
+        return 0
+
+    def nirgan_pix_loss(self, ref, stream=None):
+        with torch.enable_grad():
+            return self._pix_loss(obj(ref))
+
+    def _pix_loss(self, d):
+        self.calls.append("pix_loss")
+        B, H, W = d.B, d.H, d.W
+        n = B * H * W
+        # fp32 like the kernel: the indices are singular where pred + band ~ 0 (pred comes out of tanh)
+        rgb = torch.from_numpy(arr(d.rgb, 3 * n).reshape(B, 3, H, W).copy())
+        x = torch.from_numpy(arr(d.nir, n).reshape(B, 1, H, W).copy())
+        y = torch.from_numpy(arr(d.pred, n).reshape(B, 1, H, W).copy()).requires_grad_(True)
+        R, Gc, Bl = rgb[:, 0:1], rgb[:, 1:2], rgb[:, 2:3]
+        w = [d.w_l1, d.w_ndvi, d.w_ndwi, d.w_gndvi, d.w_savi, d.w_msavi, d.w_evi]
+        crit = (lambda a, b: (a - b).abs().sum()) if d.criterion == 0 else (lambda a, b: ((a - b) ** 2).sum())
+
+        def idx(k, v):
+            if k == 1:
+                return (v - R) / (v + R + 1e-6)
+            if k == 2:
+                return (v - Gc) / (v + Gc + 1e-6)
+            if k == 3:
+                return (v - Gc) / ((v - R) / (v + R) + Gc)
+            if k == 4:
+                return 1.5 * (v - R) / (v + R + 0.5)
+            if k == 5:
+                return (2 * v + 1 - torch.sqrt((2 * v + 1) ** 2 - 8 * (v - R))) / 2
+            return 2.5 * ((v - R) / ((v + 6) * (R - 7.5) * (Bl + 1) + 1e-6))
+
+        sums = arr(d.sums, 7)
+        total = 0.0
+        s0 = (y - x).abs().sum()
+        sums[0] += float(s0.detach())
+        total = total + w[0] * s0
+        for k in range(1, 7):
+            if d.log_all or w[k] != 0:
+                sk = crit(idx(k, x), idx(k, y))
+                sums[k] += float(sk.detach())
+                if w[k] != 0:
+                    total = total + w[k] * sk
+        if d.grad_pred:
+            (total / n).backward()
+            g = y.grad.numpy().reshape(-1).copy()
+            if d.extra:
+                g += d.extra_scale * arr(d.extra, n * d.extra_cs)[d.extra_c::d.extra_cs]
+            arr(d.grad_pred, n)[:] = g
+        return 0
+
+    # ------------------------------------------------------------------ elementwise
+    def nirgan_adam(self, p, g, m, v, n, lr, b1, b2, eps, step, stream=None):
+        self.calls.append("adam")
+        P, G_, M, V = arr(p, n), arr(g, n), arr(m, n), arr(v, n)
+        M[:] = M * np.float32(b1) + np.float32(1 - b1) * G_
+        V[:] = V * np.float32(b2) + np.float32(1 - b2) * G_ * G_
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        P[:] -= np.float32(lr / bc1) * (M / (np.sqrt(V) / np.float32(np.sqrt(bc2)) + np.float32(eps)))
+        return 0
+
+    def nirgan_bilinear_fwd(self, src, B, SH, SW, dst, OH, OW, stream=None):
+        self.calls.append("bilinear_fwd")
+        s = torch.from_numpy(arr(src, B * SH * SW).reshape(B, 1, SH, SW).copy())
+        o = F.interpolate(s, size=(OH, OW), mode="bilinear", align_corners=False)
+        arr(dst, B * OH * OW)[:] = o.reshape(-1).numpy()
+        return 0
+
+    def nirgan_bilinear_bwd(self, ddst, B, OH, OW, dsrc, SH, SW, stream=None):
+        self.calls.append("bilinear_bwd")
+        with torch.enable_grad():
+            s = torch.zeros(B, 1, SH, SW, requires_grad=True)
+            o = F.interpolate(s, size=(OH, OW), mode="bilinear", align_corners=False)
+            o.backward(torch.from_numpy(arr(ddst, B * OH * OW).reshape(B, 1, OH, OW).copy()))
+        arr(dsrc, B * SH * SW)[:] = s.grad.reshape(-1).numpy()
+        return 0
+
+    def nirgan_inject_fwd(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("inject_fwd")
+        B, H, W, Cc = d.B, d.H, d.W, d.C
+        z = arr(d.z, B * H * W * Cc).reshape(B, H, W, Cc)
+        e = arr(d.e, B * H * W).reshape(B, H, W, 1)
+        s = arr(d.scale, 1)[0] if d.scale else 1.0
+        v = z * (1 + s * e) if d.style == 0 else z + s * e
+        o = arr(d.out, B * d.o_hp * d.o_wp * Cc).reshape(B, d.o_hp, d.o_wp, Cc)
+        o[:, d.o_pad:d.o_pad + H, d.o_pad:d.o_pad + W] = np.maximum(v, 0)
+        return 0
+
+    def nirgan_inject_bwd(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("inject_bwd")
+        B, H, W, Cc = d.B, d.H, d.W, d.C
+        g = arr(d.g, B * H * W * Cc).reshape(B, H, W, Cc).astype(np.float64)
+        a = arr(d.a, B * d.a_hp * d.a_wp * Cc).reshape(B, d.a_hp, d.a_wp, Cc)[:, d.a_pad:d.a_pad + H, d.a_pad:d.a_pad + W]
+        z = arr(d.z, B * H * W * Cc).reshape(B, H, W, Cc).astype(np.float64)
+        e = arr(d.e, B * H * W).reshape(B, H, W, 1).astype(np.float64)
+        s = float(arr(d.scale, 1)[0]) if d.scale else 1.0
+        gm = np.where(a > 0, g, 0.0)
+        if d.style == 0:
+            dz, de, ds = gm * (1 + s * e), (gm * z * s).sum(-1), (gm * z * e).sum()
+        else:
+            dz, de, ds = gm, (gm * s).sum(-1), (gm * e).sum()
+        arr(d.dz, B * H * W * Cc).reshape(B, H, W, Cc)[:] = dz
+        arr(d.de, B * H * W).reshape(B, H, W)[:] = de
+        if d.dscale:
+            arr(d.dscale, 1)[0] += ds
+        return 0
+
+    def nirgan_colsum(self, x, rows, cols, out, accumulate, stream=None):
+        s = arr(x, rows * cols).reshape(rows, cols).sum(0)
+        o = arr(out, cols)
+        o[:] = o + s if accumulate else s
+        return 0
+
+    def nirgan_fill(self, dst, n, value, stream=None):
+        arr(dst, n)[:] = value
+        return 0
+
+    def nirgan_axpy(self, y, x, n, alpha, stream=None):
+        arr(y, n)[:] += alpha * arr(x, n)
+        return 0
+
+    def nirgan_run_plan(self, entries, n, stream=None):
+        return self._fail("run_plan is not emulated")

@@ -1,0 +1,302 @@
+"""Host logic (descriptor geometry, halo plumbing, plan order, flat parameters, fused trainer,
+autograd bridges) against the golden vectors of the reference, with the C ABI served by the
+numpy emulator of tests/emu_backend.py.  No GPU, no HIP code runs here: these tests pin the
+*host side*; the kernels themselves are pinned by the -m gpu tests through the same ABI."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import nirgan_oracle as O
+from emu_backend import EmuBackend
+from nirgan_hip import lib as L
+
+torch.set_num_threads(4)
+
+
+@pytest.fixture()
+def emu():
+    be = EmuBackend()
+    L.set_backend(be)
+    yield be
+    L.set_backend(None)
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+def sub(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in z.items() if k.startswith(prefix)}
+
+
+def close(a, b, tol, what=""):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= tol * max(ref, 1e-20), f"{what}: err {err:.3e} ref {ref:.3e}"
+
+
+def adam_close(p_new, p_ref, grad, p_old, what, lr=2e-4):
+    """First Adam step: p1 = p0 - lr*g/(|g| + eps').  Exact given OUR gradient (pins the Adam kernel);
+    against the reference's p1 only where |g| >> eps (elsewhere the step is a sign flip of rounding noise)."""
+    p_new, p_ref, grad = (torch.as_tensor(t).float().cpu() for t in (p_new, p_ref, grad))
+    p_old = torch.as_tensor(p_old).float().clone()
+    m, v = torch.zeros_like(p_old), torch.zeros_like(p_old)
+    O.adam_step(p_old, grad, m, v, 1, lr=lr, b1=0.5)
+    close(p_new, p_old, 1e-6, what + " (adam kernel)")
+    live = grad.abs() > 1e-6 * grad.abs().max().clamp_min(1e-30)
+    err = ((p_new - p_ref).abs() * live).max().item()
+    assert err <= 0.02 * lr, f"{what}: {err:.3e}"
+
+
+def make_nets(z, n_blocks, ngf=8):
+    from model import networks
+    netG = networks.define_G(3, 1, ngf, f"resnet_{n_blocks}blocks", "instance", False, "normal", 0.02)
+    netD = networks.define_D(4, ngf, "basic", 3, "instance", "normal", 0.02)
+    netG.load_state_dict(sub(z, "G0/"))
+    netD.load_state_dict(sub(z, "D0/"))
+    return netG, netD
+
+
+def test_state_dict_keys_and_rng_parity(golden_dir):
+    """Same keys/layouts as the reference and the same weights for the same seed (networks.py:68-117)."""
+    from model import networks
+    z = load(golden_dir, "f5_fullsize.npz")
+    for nb in (6, 9):
+        torch.manual_seed(0)
+        net = networks.define_G(3, 1, 64, f"resnet_{nb}blocks", "instance", False, "normal", 0.02)
+        assert sum(p.numel() for p in net.parameters()) == int(z[f"g{nb}_nparams"])
+        wsum = float(sum(p.detach().double().sum() for p in net.parameters()))
+        assert abs(wsum - float(z[f"g{nb}_wsum"])) < 1e-9
+    torch.manual_seed(0)
+    netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
+    assert sum(p.numel() for p in netD.parameters()) == int(z["d_nparams"])
+    assert abs(float(sum(p.detach().double().sum() for p in netD.parameters())) - float(z["d_wsum"])) < 1e-9
+    g = load(golden_dir, "f1_g6_d.npz")
+    torch.manual_seed(0)
+    small = networks.define_G(3, 1, 8, "resnet_6blocks", "instance", False, "normal", 0.02)
+    sd = small.state_dict()
+    ref = sub(g, "G0/")
+    assert list(sd.keys()) == list(ref.keys())
+    for k in sd:
+        assert torch.equal(sd[k], ref[k]), k
+
+
+def test_reference_error_conventions():
+    from model import networks
+    from utils.remote_sensing_indices import RemoteSensingIndices
+    with pytest.raises(NotImplementedError):
+        networks.define_G(3, 1, 8, "resnet_3blocks", "instance")
+    with pytest.raises(NotImplementedError):
+        networks.define_D(4, 8, "fancy", 3, "instance")
+    with pytest.raises(NotImplementedError):
+        networks.get_norm_layer("layer")
+    with pytest.raises(NotImplementedError):
+        networks.GANLoss("hinge")
+    with pytest.raises(NotImplementedError):
+        RemoteSensingIndices(mode="loss", criterion="huber")
+    with pytest.raises(AssertionError):
+        RemoteSensingIndices(mode="train")
+
+
+def test_no_cpu_fallback():
+    """Without the test seam a CPU tensor must be refused loudly."""
+    from model import networks
+    net = networks.define_G(3, 1, 8, "resnet_6blocks", "instance")
+    with pytest.raises(RuntimeError):
+        net(torch.rand(1, 3, 32, 32))
+
+
+@pytest.mark.parametrize("name", ["f1_g6_d.npz", "f1_g9_rs_pad.npz"])
+def test_fused_trainer_matches_reference(emu, golden_dir, name):
+    from nirgan_hip.trainer import Pix2PixTrainer
+    z = load(golden_dir, name)
+    nb, pad, lam_rs = int(z["n_blocks"]), int(z["padding"]), float(z["lambda_rs"])
+    netG, netD = make_nets(z, nb)
+    rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333, "lambda_savi": 0.0,
+            "lambda_msavi": 0.0, "lambda_gndvi": 0.0}
+    tr = Pix2PixTrainer(netG, netD, n_blocks=nb, lambda_rs=lam_rs, rs_weights=rs_w, padding=pad)
+    rgb, nir = torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])
+    view = tr.step(rgb, nir)
+    out = view.as_dict()
+    close(tr.G.pred, z["pred"], 2e-5, "pred")
+    close(out["loss_D"], z["loss_D"], 1e-5, "loss_D")
+    close(out["loss_G"], z["loss_G"], 1e-5, "loss_G")
+    gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
+    for k, v in sub(z, "gD/").items():
+        if k not in O.shadowed_bias_keys("D"):
+            close(gD[k], v, 2e-4, "gD " + k)
+    shadow = O.shadowed_bias_keys("G", nb)
+    for k, v in sub(z, "gG/").items():
+        if k not in shadow:
+            close(gG[k], v, 2e-4, "gG " + k)
+    pD, pG = dict(netD.named_parameters()), dict(netG.named_parameters())
+    for k, v in sub(z, "D1/").items():
+        if k not in O.shadowed_bias_keys("D"):
+            adam_close(pD[k], v, gD[k], z["D0/" + k], "D1 " + k)
+    for k, v in sub(z, "G1/").items():
+        if k not in shadow:
+            adam_close(pG[k], v, gG[k], z["G0/" + k], "G1 " + k)
+    # a second step runs on the same buffers (halo invariants hold, weights re-packed)
+    ref = O.OracleTrainer(sub(z, "G0/"), sub(z, "D0/"), nb, padding=pad, lambda_rs=lam_rs, rs_weights=rs_w)
+    ref.step(rgb, nir)
+    o2 = ref.step(rgb, nir)
+    v2 = tr.step(rgb, nir).as_dict()
+    close(v2["loss_D"], o2["loss_D"], 1e-4, "loss_D step 2")
+    close(v2["loss_G"], o2["loss_G"], 1e-4, "loss_G step 2")
+
+
+def regen_fc(z):
+    g = torch.Generator().manual_seed(int(z["fc_seed"]))
+    return torch.randn(16384, 256, generator=g) * 0.02, torch.randn(16384, generator=g) * 0.02
+
+
+def inject_config():
+    ns = types.SimpleNamespace
+    return ns(base_configs=ns(input_nc=3, output_nc=1, ngf=8, netG="resnet_9blocks", norm="instance", no_dropout=True,
+                              init_type="normal", init_gain=0.02),
+              satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
+                         scaling_param=True, scaling_param_init=0.01))
+
+
+def test_inject_generator_trainer(emu, golden_dir, capsys):
+    from model import networks
+    from model.generator_inject import define_G_inject
+    from nirgan_hip.trainer import Pix2PixTrainer
+    z = load(golden_dir, "f1_inject.npz")
+    netG = define_G_inject(inject_config())
+    sd = sub(z, "G0/")
+    sd["fc.weight"], sd["fc.bias"] = regen_fc(z)
+    netG.load_state_dict(sd)
+    netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
+    netD.load_state_dict(sub(z, "D0/"))
+    rgb, nir, emb = (torch.from_numpy(z[k]) for k in ("rgb", "nir", "embeds"))
+    tr = Pix2PixTrainer(netG, netD, n_blocks=9, inject={"style": "multiply", "use_scale": True})
+    out = tr.step(rgb, nir, emb).as_dict()
+    close(tr.G.pred, z["pred"], 2e-5, "pred")
+    close(out["loss_G"], z["loss_G"], 1e-5, "loss_G")
+    g = tr.flatG.grad_views()
+    close(g["scale_param"], z["g_scale_param"], 2e-4, "dscale")
+    close(g["fc.bias"], z["g_fc_bias"], 2e-4, "dfc.bias")
+    close(g["fc.weight"][:8], z["g_fc_weight_rows0_8"], 2e-4, "dfc.weight")
+    shadow = O.shadowed_bias_keys("G", 9)
+    for k, v in sub(z, "gG/").items():
+        if k not in shadow:
+            close(g[k], v, 2e-4, "gG " + k)
+
+
+def test_autograd_bridges_follow_the_reference_loop(emu, golden_dir):
+    """training_step-style use: modules + losses + any optimizer, as Lightning drives the reference."""
+    from model import networks
+    from model.pix2pix import HipL1Loss
+    from nirgan_hip.optim import HipAdam
+    z = load(golden_dir, "f1_g6_d.npz")
+    netG, netD = make_nets(z, 6)
+    crit, l1 = networks.GANLoss("lsgan"), HipL1Loss()
+    optD = HipAdam(netD.parameters(), lr=2e-4, betas=(0.5, 0.999), net=netD)
+    optG = HipAdam(netG.parameters(), lr=2e-4, betas=(0.5, 0.999), net=netG)
+    rgb, nir = torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])
+    pred = netG(rgb)
+    close(pred, z["pred"], 2e-5, "pred")
+    loss_d = crit(netD(torch.cat((rgb, pred), 1).detach()), False) + crit(netD(torch.cat((rgb, nir), 1)), True)
+    close(loss_d, z["loss_D"], 1e-5, "loss_D")
+    optD.zero_grad()
+    loss_d.backward()
+    for k, p in netD.named_parameters():
+        if k not in O.shadowed_bias_keys("D"):
+            close(p.grad, z["gD/" + k], 2e-4, "gD " + k)
+    assert all(p.grad is None for p in netG.parameters())
+    optD.step()
+    for p in netD.parameters():
+        p.requires_grad_(False)
+    pred = netG(rgb)
+    loss_g = crit(netD(torch.cat((rgb, pred), 1)), True) * 1.0 + l1(pred, nir) * 100.0
+    close(loss_g, z["loss_G"], 1e-5, "loss_G")
+    optG.zero_grad()
+    loss_g.backward()
+    shadow = O.shadowed_bias_keys("G", 6)
+    for k, p in netG.named_parameters():
+        if k not in shadow:
+            close(p.grad, z["gG/" + k], 2e-4, "gG " + k)
+    optG.step()
+    for k, p in netG.named_parameters():
+        if k not in shadow:
+            close(p, z["G1/" + k], 1e-5, "G1 " + k)
+    # label mask: bit exact, stride-0 expansion of the 0-dim buffer (networks.py:241-256)
+    f3 = load(golden_dir, "f3_losses.npz")
+    pd_ = torch.from_numpy(f3["pred_d"])
+    for real, tag in ((True, "real"), (False, "fake")):
+        t = crit.get_target_tensor(pd_, real)
+        assert t.stride() == (0, 0, 0, 0)
+        assert t.contiguous().numpy().tobytes() == f3["mask_" + tag].tobytes()
+
+
+def test_rs_indices_module(emu, golden_dir):
+    from utils.remote_sensing_indices import RemoteSensingIndices
+    z = load(golden_dir, "f3_losses.npz")
+    rgb, nir, pred = (torch.from_numpy(z[k]) for k in ("rgb", "nir", "pred"))
+    w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333, "lambda_savi": 0.0, "lambda_msavi": 0.0,
+         "lambda_gndvi": 0.0}
+    for c in ("l1", "l2"):
+        rs = RemoteSensingIndices(mode="loss", criterion=c)
+        p = pred.clone().requires_grad_(True)
+        l = rs.get_and_weight_losses(rgb, nir, p, loss_config=w)
+        l.backward()
+        close(l.detach(), z["rs_" + c], 1e-5, "rs " + c)
+        close(p.grad, z[f"rs_{c}_grad"], 1e-4, "rs grad " + c)
+        d = rs.get_and_weight_losses(rgb, nir, pred, mode="logging_dict")
+        for k, v in d.items():
+            close(v, z[f"rslog_{c}/{k}"], 1e-5, k)
+    close(RemoteSensingIndices().get_and_weight_losses(rgb, nir, pred), z["rs_default"], 1e-5, "default")
+    with pytest.raises(NotImplementedError):
+        RemoteSensingIndices().get_and_weight_losses(rgb, nir, pred, mode="nope")
+    idx = RemoteSensingIndices(mode="index")
+    for n in ("ndvi", "ndwi", "evi", "gndvi", "savi", "msavi"):
+        _, b = getattr(idx, n + "_calculation")(rgb, nir, pred)
+        close(b, z[f"index_{n}_pred"], 1e-5, n)
+
+
+def test_px2px_pl_surface(emu, golden_dir):
+    """configs[0]: the shipped YAML keys, 6-block override, plumbing of Px2Px_PL (losses finite, keys, one step)."""
+    from model.pix2pix import Px2Px_PL
+    from utils.config import to_attr
+    cfg = to_attr({
+        "base_configs": {"isTrain": True, "input_nc": 3, "output_nc": 1, "ngf": 8, "ndf": 8, "netD": "basic",
+                         "netG": "resnet_6blocks", "norm": "instance", "no_dropout": True, "init_type": "normal",
+                         "init_gain": 0.02, "n_layers_D": 3, "gan_mode": "lsgan", "lr": 0.0002, "beta1": 0.5,
+                         "lambda_GAN": 1.0, "lambda_L1": 100.0, "lambda_ssim": 0.0, "lambda_hist": 0.0,
+                         "lambda_rs_losses": 0.0, "rs_losses_criterium": "l1",
+                         "internal_rs_loss_weights": {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333}},
+        "satclip": {"use_satclip": False},
+        "Schedulers": {"metric": "val/L1", "patience_g": 25, "patience_d": 25},
+        "Data": {"padding": True, "padding_amount": 10}})
+    m = Px2Px_PL(cfg)
+    for attr in ("netG", "netD", "criterionGAN", "criterionL1", "satclip", "config", "opt"):
+        assert hasattr(m, attr)
+    keys = list(m.state_dict().keys())
+    assert "netG.model.1.weight" in keys and "netD.model.11.bias" in keys and "criterionGAN.real_label" in keys
+    g = torch.Generator().manual_seed(3)
+    batch = {"rgb": 0.02 + 0.58 * torch.rand(2, 3, 40, 40, generator=g), "nir": 0.05 + 0.75 * torch.rand(2, 1, 40, 40, generator=g)}
+    m.train()
+    l0 = m.training_step(batch, 0, 0)
+    l1 = m.training_step(batch, 0, 1)
+    assert torch.isfinite(l0) and torch.isfinite(l1)
+    (od, og), scheds = m.configure_optimizers()
+    assert len(scheds) == 2 and scheds[0]["monitor"] == "val/L1"
+    out = m.train_batch(batch).as_dict()
+    assert abs(out["loss_D"] - float(l0.detach())) < 1e-4 * abs(float(l0.detach()))
+    # loss_G of the fused batch is taken against the UPDATED discriminator (optimizer 0 stepped first)
+    assert np.isfinite(out["loss_G"]) and abs(out["loss_G_l1"] * 100.0 - float(l1.detach())) < 2.0
+    m.eval()
+    with pytest.raises(AssertionError):
+        m.training_step(batch, 0, 0)
+    p = m.predict_step(batch["rgb"])
+    assert p.shape == (2, 1, 40, 40)
+    m.train()
+    with pytest.raises(AssertionError):
+        m.predict_step(batch["rgb"])
