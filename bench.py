@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Throughput of the NIR-GAN Pix2Pix train step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one batch of the reference's loop (model/pix2pix.py:165-257): generator forward,
+PatchGAN forward on fake+real, both backward passes, both Adam steps -- on synthetic random
+tiles already resident in HBM.  Workload = BASELINE.json configs[1]: 6-block
+ResnetGenerator + 3-layer PatchGAN, bs=16 256x256 per GPU, GAN + L1 loss, fp32 (exact-fp32
+MFMA).  N > 1: one process per GPU (torchrun), tile batches sharded data-parallel, flat
+gradients all-reduced with RCCL; per-GPU work is fixed ("weak").
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the 128-wide
+implicit-GEMM convolution, conv_igemm_kernel<128>): algorithmic FLOPs of its launches
+(2*M*N*K from the descriptors) / their duration, bracketed by HIP events on the launch
+stream inside the timed steps.  `cpu_baseline` times the CPU oracle (a port, on a bounded
+sample) on rank 0 at N = 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nir-gan_amd"))
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synth(B, H, W, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    rgb = 0.02 + 0.58 * torch.rand(B, 3, H, W, generator=g)
+    nir = 0.05 + 0.75 * torch.rand(B, 1, H, W, generator=g)
+    return rgb.to(device), nir.to(device)
+
+
+def conv_probe_flops(trainer):
+    """Algorithmic FLOPs of one step's conv_igemm_kernel<128> launches, and a hook that brackets them."""
+    from nirgan_hip import lib as L
+    total, count = 0.0, 0
+    plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_frozen]
+    for pl in plans:
+        idx = []
+        for i, (name, args) in enumerate(pl.ops):
+            if name == "nirgan_conv_igemm":
+                d = args[0]._obj
+                if d.N > 64:
+                    total += 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run
+                    count += 1
+                    idx.append(i)
+        pl.probe_idx = set(idx)
+        pl.probe_events = []
+    return total, count, plans
+
+
+def host_cores() -> int:
+    """CPU share of this process (affinity mask / cgroup quota), not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(n_blocks, size, bs=4, steps=2):
+    """The CPU oracle (port of the reference's step) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nirgan_oracle as O
+    from model import networks
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    netG = networks.define_G(3, 1, 64, f"resnet_{n_blocks}blocks", "instance", False, "normal", 0.02)
+    netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
+    tr = O.OracleTrainer(netG.state_dict(), netD.state_dict(), n_blocks)
+    rgb, nir = synth(bs, size, size, 1234, "cpu")
+    tr.step(rgb, nir)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(rgb, nir)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": bs / dt, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (plain PyTorch CPU fp32) train step, {n_blocks}-block, bs={bs}, {size}x{size}, 1 warm-up + {steps} timed steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bs", type=int, default=16, help="tiles per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--blocks", type=int, default=6)
+    ap.add_argument("--padding", type=int, default=0, help="Data.padding_amount (YAML default 10); 0 = BASELINE.md headline case")
+    ap.add_argument("--lambda-rs", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    reducer = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+        from nirgan_hip.parallel import GradReducer
+        reducer = GradReducer()
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    torch.manual_seed(0)
+    netG = networks.define_G(3, 1, 64, f"resnet_{a.blocks}blocks", "instance", False, "normal", 0.02).to(dev)
+    netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)
+    rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333}
+    tr = Pix2PixTrainer(netG, netD, n_blocks=a.blocks, padding=a.padding, lambda_rs=a.lambda_rs, rs_weights=rs_w, reducer=reducer)
+    rgb, nir = synth(a.bs, a.size, a.size, 1234 + rank, dev)
+
+    for _ in range(max(a.warmup, 1)):
+        tr.step(rgb, nir)
+    flops, nlaunch, plans = conv_probe_flops(tr)
+    if a.no_probe:
+        for pl in plans:
+            pl.probe_idx = None
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step(rgb, nir)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = tr.step(rgb, nir).as_dict()
+    assert all(v == v and abs(v) < 1e30 for v in losses.values()), f"non-finite losses {losses}"
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = a.bs * world * a.steps / dt
+        roof = None
+        if not a.no_probe:
+            ev_ms, n_ev = 0.0, 0
+            for pl in plans:
+                for s, e in pl.probe_events:
+                    ev_ms += s.elapsed_time(e)
+                    n_ev += 1
+            per_launch_flop = flops / max(nlaunch, 1)
+            avg_ms = ev_ms / max(n_ev, 1)
+            ach = per_launch_flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_igemm_kernel<128>", "launches_per_step": nlaunch,
+                    "avg_launch_ms": round(avg_ms, 5), "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
+                    "share_of_step_time": round(ev_ms / max(n_ev, 1) * nlaunch / ms, 3)}
+        gflop_tile = {(6, 0): 257.0, (6, 10): 290.5, (9, 0): 344.0, (9, 10): 391.6}.get((a.blocks, a.padding))
+        out = {"metric": "256x256 RGB tiles/sec (G+D fwd+bwd+step)", "value": round(value, 3), "unit": "tiles/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"configs[1]: {a.blocks}-block ResnetGenerator + 3-layer PatchGAN, bs={a.bs}/GPU, "
+                                      f"{a.size}x{a.size}, GAN+L1" + (f"+RS(l={a.lambda_rs})" if a.lambda_rs else "")
+                                      + f", padding={a.padding}, fp32 MFMA",
+                          "global_batch": a.bs * world, "parallelism": f"dp{world}"},
+               "roofline": roof}
+        if gflop_tile:
+            out["step_tflops_algorithmic"] = round(gflop_tile * value / 1e3, 2)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.blocks, a.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,8 @@ class Plan:
     def __init__(self, ctx: Ctx):
         self.ctx = ctx
         self.ops: list = []
+        self.probe_idx = None        # bench.py: indices of ops to bracket with HIP events on the launch stream
+        self.probe_events: list = []
 
     def add(self, name: str, *args):
         self.ops.append((name, args))
@@ -93,8 +95,23 @@ class Plan:
     def run(self):
         be = L.backend()
         st = self.ctx.stream()
+        if self.probe_idx:
+            return self._run_probed(be, st)
         for name, args in self.ops:
             rc = getattr(be, name)(*args, st)
+            if rc != 0:
+                L.check(rc, name)
+
+    def _run_probed(self, be, st):
+        for i, (name, args) in enumerate(self.ops):
+            if i in self.probe_idx:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = getattr(be, name)(*args, st)
+                e.record()
+                self.probe_events.append((s, e))
+            else:
+                rc = getattr(be, name)(*args, st)
             if rc != 0:
                 L.check(rc, name)
 
@@ -157,6 +174,7 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     nsplit, rows = G.wgrad_split(M, tiles)
     need = nsplit * N * K
     slabs = slabs_pool.get(need) if slabs_pool is not None else ctx.zeros(need)
+    ctx.keep.append(slabs)
     d = L.WgradDesc()
     d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = p.ptr, p.elems, p.hp, p.wp, p.C, p_oh, p_ow
     d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = q.ptr, q.elems, q.hp, q.wp, q.C
@@ -326,7 +344,9 @@ class ConvIN:
         k, s, p = self.k, self.s, self.p
         act = self.act if act is None else act
         emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, a=(mask if mask is not None else self.out), act=act,
-                    y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum, dbias=gb, ws=eng.scratch.get(),
+                    y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
+                    dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
+                    ws=eng.scratch.get(),
                     shape=(inp.B, self.OH, self.OW, self.cout))
         dy = self.dy
         # weight gradient (skipped when the parameters are frozen: gw is None)

@@ -146,7 +146,7 @@ def gan_target_tensor(pred: torch.Tensor, target_is_real: bool,
                       real_label: float = 1.0, fake_label: float = 0.0) -> torch.Tensor:
     """GANLoss.get_target_tensor (networks.py:241-256): 0-dim fp32 label expanded to pred's shape."""
     lab = torch.tensor(real_label if target_is_real else fake_label, dtype=torch.float32)
-    return lab.expand_as(pred)
+    return lab.to(pred.dtype).expand_as(pred)      # fp32 in the reference; the cast only serves fp64 diagnostics
 
 
 def lsgan_loss(pred: torch.Tensor, target_is_real: bool) -> torch.Tensor:

@@ -15,7 +15,25 @@ for p in (PKG, ORACLE, ROOT):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def host_cores() -> int:
+    """CPU share of this container (affinity mask / cgroup quota), not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(host_cores())
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

@@ -1,0 +1,301 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point is run on device buffers and
+compared with the numpy restatement of the same descriptor (tests/emu_backend.py, test
+infrastructure) on host copies.  fp32 MFMA results are exact-fp32 FMA chains in a different
+order than the fp64 restatement: tolerance 1e-5 relative to the output's max-abs (1e-4 for
+the long reductions of the weight gradient), far inside the 1e-3 the path is specified to.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from emu_backend import EmuBackend
+from nirgan_hip import geometry as G
+from nirgan_hip import lib as L
+from nirgan_hip.engine import Ctx, Halo, Plan, emit_conv, emit_in_bwd, emit_in_fwd, emit_wgrad
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, tol, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what + ": non-finite"
+    err, ref = (a - b).abs().max().item(), b.abs().max().item()
+    assert err <= tol * max(ref, 1e-20), f"{what}: err {err:.3e} ref {ref:.3e}"
+
+
+class Twin:
+    """The same buffers on the device and on the host; descriptors are emitted against either."""
+
+    def __init__(self):
+        self.gctx = Ctx(DEV)
+        self.emu = EmuBackend()
+        L.set_backend(self.emu)
+        try:
+            self.cctx = Ctx("cpu")
+        finally:
+            L.set_backend(None)
+        self.pairs = []
+
+    def halo(self, B, H, W, Cc, pad, gen=None, fill_halo=True):
+        g = Halo(self.gctx, B, H, W, Cc, pad)
+        c = Halo(self.cctx, B, H, W, Cc, pad)
+        if gen is not None:
+            data = torch.randn(c.t.shape, generator=gen)
+            if not fill_halo and pad:
+                m = torch.zeros_like(data)
+                m[:, pad:pad + H, pad:pad + W] = 1
+                data = data * m
+            c.t.copy_(data)
+            g.t.copy_(data)
+        self.pairs.append((g.t, c.t))
+        return g, c
+
+    def tensor(self, *shape, gen=None, scale=1.0):
+        c = torch.zeros(*shape)
+        if gen is not None:
+            c.copy_(torch.randn(*shape, generator=gen) * scale)
+        g = c.to(DEV)
+        self.pairs.append((g, c))
+        return g, c
+
+    def run(self, gplan: Plan, cplan: Plan):
+        gplan.run()
+        torch.cuda.synchronize()
+        L.set_backend(self.emu)
+        try:
+            cplan.run()
+        finally:
+            L.set_backend(None)
+
+
+CONV_CASES = [
+    # name, B, H, W, Cin, Cout, k, s, p
+    ("res3x3_256", 2, 9, 11, 256, 256, 3, 1, 1),
+    ("down3x3_s2", 2, 16, 12, 64, 128, 3, 2, 1),
+    ("d4x4_s2", 1, 18, 18, 128, 256, 4, 2, 1),
+    ("d4x4_s1_512", 1, 8, 9, 256, 512, 4, 1, 1),
+    ("small_c8_n16", 3, 10, 10, 8, 16, 3, 1, 1),
+    ("n64_tail", 1, 13, 7, 32, 64, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_forward_wgrad_dgrad(case):
+    _, B, H, W, Cin, Cout, k, s, p = case
+    gen = torch.Generator().manual_seed(11)
+    tw = Twin()
+    OH, OW = G.conv_out(H, k, s, p), G.conv_out(W, k, s, p)
+    xg, xc = tw.halo(B, H, W, Cin, p, gen)
+    wg, wc = tw.tensor(Cout, Cin, k, k, gen=gen, scale=0.05)
+    bg, bc = tw.tensor(Cout, gen=gen)
+    spec = G.conv_fwd_pack(Cout, Cin, k)
+    taps = G.conv_fwd_taps(k, Cin)
+    zpad = k - 1 if s == 1 else 1
+    outs = []
+    for ctx, x, w, b in ((tw.gctx, xg, wg, bg), (tw.cctx, xc, wc, bc)):
+        plan = Plan(ctx)
+        wp = ctx.zeros(spec.N, spec.K)
+        imap = ctx.i32(spec.index_map)
+        plan.add("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, imap.data_ptr(), wp.data_ptr(), spec.N, spec.K)
+        y = Halo(ctx, B, OH, OW, Cout, 0)
+        emit_conv(plan, ctx, x, taps, wp, b, y, N=Cout, OH=OH, OW=OW, in_stride=s, in_oh=0, in_ow=0)
+        # weight gradient with dY := y (any dense tensor does) in a zero-halo buffer
+        dy = Halo(ctx, B, OH, OW, Cout, zpad)
+        gw = ctx.zeros(Cout, Cin, k, k)
+        plan2 = Plan(ctx)
+        emit_wgrad(plan2, ctx, dy, x, taps, spec, gw, N=Cout, OH=OH, OW=OW, p_oh=zpad, p_ow=zpad, q_stride=s)
+        # data gradient
+        if s == 1:
+            gx = Halo(ctx, B, H, W, Cin, p)
+            hw = [(kh, kw) for kh in range(k) for kw in range(k)]
+            dspec = G.conv_dgrad_pack(Cout, Cin, k, hw)
+            wd = ctx.zeros(dspec.N, dspec.K)
+            im2 = ctx.i32(dspec.index_map)
+            plan2.add("nirgan_pack_rows", w.data_ptr(), w.numel(), dspec.row_stride, im2.data_ptr(), wd.data_ptr(), dspec.N, dspec.K)
+            emit_conv(plan2, ctx, dy, G.conv_dgrad_s1_taps(k, Cout), wd, None, gx, N=Cin, OH=gx.hp, OW=gx.wp)
+        else:
+            gx = Halo(ctx, B, H, W, Cin, 0)
+            for ph in G.conv_dgrad_s2_phases(H, W, k, p):
+                dspec = G.conv_dgrad_pack(Cout, Cin, k, ph.taps_hw)
+                wd = ctx.zeros(dspec.N, dspec.K)
+                ctx.keep.append(wd)
+                im2 = ctx.i32(dspec.index_map)
+                plan2.add("nirgan_pack_rows", w.data_ptr(), w.numel(), dspec.row_stride, im2.data_ptr(), wd.data_ptr(), dspec.N, dspec.K)
+                emit_conv(plan2, ctx, dy, G.Taps(ph.dh, ph.dw, Cout), wd, None, gx, N=Cin, OH=ph.n_h, OW=ph.n_w,
+                          in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow)
+        outs.append((plan, plan2, y, dy, gw, gx))
+    (gp, gp2, gy, gdy, ggw, ggx), (cp, cp2, cy, cdy, cgw, cgx) = outs
+    tw.run(gp, cp)
+    close(gy.t, cy.t, 1e-5, "conv fwd")
+    # also against torch's own convolution (the reference's nn.Conv2d arithmetic)
+    ref = torch.nn.functional.conv2d(xc.t.permute(0, 3, 1, 2), wc, bc, stride=s)
+    close(gy.t.permute(0, 3, 1, 2), ref, 1e-4, "conv fwd vs torch")
+    cdy.interior().copy_(cy.t)
+    gdy.interior().copy_(cy.t.to(DEV))
+    tw.run(gp2, cp2)
+    close(ggw, cgw, 1e-4, "wgrad")
+    close(ggx.t, cgx.t, 1e-5, "dgrad")
+
+
+def test_convT_phases_match_torch():
+    gen = torch.Generator().manual_seed(3)
+    B, H, W, Cin, Cout, k = 2, 7, 6, 128, 64, 3
+    tw = Twin()
+    xg, xc = tw.halo(B, H, W, Cin, 1, gen, fill_halo=False)
+    wg, wc = tw.tensor(Cin, Cout, k, k, gen=gen, scale=0.05)
+    ctx = tw.gctx
+    y = Halo(ctx, B, 2 * H, 2 * W, Cout, 0)
+    plan = Plan(ctx)
+    for ph in G.convT_fwd_phases(H, W, k, 1):
+        spec = G.convT_fwd_pack(Cin, Cout, k, ph.taps_hw)
+        wp = ctx.zeros(spec.N, spec.K)
+        ctx.keep.append(wp)
+        plan.add("nirgan_pack_rows", wg.data_ptr(), wg.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), wp.data_ptr(), spec.N, spec.K)
+        emit_conv(plan, ctx, xg, G.Taps(ph.dh, ph.dw, Cin), wp, None, y, N=Cout, OH=ph.n_h, OW=ph.n_w,
+                  in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow)
+    plan.run()
+    ref = torch.nn.functional.conv_transpose2d(xc.interior().permute(0, 3, 1, 2), wc, None, stride=2, padding=1, output_padding=1)
+    close(y.t.permute(0, 3, 1, 2), ref, 1e-5, "convT fwd")
+
+
+def test_rowpacked_first_conv():
+    """7x7, 3 -> 64 over a 4-channel NHWC buffer with one tap per kernel row (run = 28)."""
+    gen = torch.Generator().manual_seed(5)
+    B, H, W, k = 2, 20, 24, 7
+    tw = Twin()
+    xg, xc = tw.halo(B, H, W, 4, 3, gen)
+    xg.t[..., 3] = 0
+    xc.t[..., 3] = 0
+    wg, wc = tw.tensor(64, 3, k, k, gen=gen, scale=0.05)
+    ctx = tw.gctx
+    spec = G.conv_rowpacked_pack(64, 3, k, 4)
+    wp = ctx.zeros(spec.N, spec.K)
+    y = Halo(ctx, B, H, W, 64, 0)
+    plan = Plan(ctx)
+    plan.add("nirgan_pack_rows", wg.data_ptr(), wg.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), wp.data_ptr(), spec.N, spec.K)
+    emit_conv(plan, ctx, xg, G.conv_rowpacked_taps(k, 4), wp, None, y, N=64, OH=H, OW=W)
+    plan.run()
+    ref = torch.nn.functional.conv2d(xc.t[..., :3].permute(0, 3, 1, 2), wc)
+    close(y.t.permute(0, 3, 1, 2), ref, 1e-5, "rowpacked conv")
+
+
+@pytest.mark.parametrize("shape", [(2, 17, 13, 64), (3, 31, 31, 512), (1, 64, 64, 256), (2, 6, 6, 8)])
+def test_instnorm_forward_backward(shape):
+    B, H, W, Cc = shape
+    gen = torch.Generator().manual_seed(9)
+    tw = Twin()
+    res = []
+    for border, act, use_res in ((L.BORDER_REFLECT, L.ACT_RELU, False), (L.BORDER_KEEP, L.ACT_LRELU, False),
+                                 (L.BORDER_REFLECT, L.ACT_NONE, True)):
+        yg, yc = tw.halo(B, H, W, Cc, 0, gen)
+        yc.t.add_(0.7)      # a mean far from zero exercises the shifted-sum variance
+        yg.t.copy_(yc.t)
+        rg, rc = tw.halo(B, H, W, Cc, 1, gen)
+        gg, gc = tw.halo(B, H, W, Cc, 1, gen)          # incoming gradient wrt the halo'd output (to fold)
+        g2g, g2c = tw.halo(B, H, W, Cc, 0, gen)
+        for ctx, y, r, g, g2 in ((tw.gctx, yg, rg, gg, g2g), (tw.cctx, yc, rc, gc, g2c)):
+            be = tw.emu if ctx is tw.cctx else None
+            n = int((be or L.backend()).nirgan_instnorm_ws_elems(B, H, W, Cc))
+            ws = ctx.zeros(n)
+            out = Halo(ctx, B, H, W, Cc, 1)
+            stats = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
+            plan = Plan(ctx)
+            emit_in_fwd(plan, ctx, y, out, norm=True, act=act, residual=r if use_res else None, border=border, stats=stats, ws=ws)
+            dy = Halo(ctx, B, H, W, Cc, 2)
+            gsum = Halo(ctx, B, H, W, Cc, 0)
+            dbias = ctx.zeros(Cc)
+            emit_in_bwd(plan, ctx, g=g, g_fold=(border == L.BORDER_REFLECT), g2=g2, a=out, act=act, y=y, stats=stats,
+                        norm=True, dy=dy, gsum=gsum, dbias=dbias, ws=ws, shape=(B, H, W, Cc))
+            res.append((plan, out, stats, dy, gsum, dbias))
+        (gp, go, gs, gdy, ggs, gdb), (cp, co, cs, cdy, cgs, cdb) = res[-2:]
+        tw.run(gp, cp)
+        close(go.t, co.t, 1e-5, "in fwd")
+        close(gs[0], cs[0], 1e-5, "mean")
+        close(gs[1], cs[1], 1e-5, "rstd")
+        close(ggs.t, cgs.t, 1e-5, "gsum")
+        close(gdy.t, cdy.t, 2e-5, "in bwd")
+        # torch's instance_norm on the same data
+        ref = torch.nn.functional.instance_norm(yc.t.permute(0, 3, 1, 2), eps=1e-5)
+        if act == L.ACT_NONE and use_res:
+            ref = ref + rc.interior().permute(0, 3, 1, 2)
+            close(go.interior().permute(0, 3, 1, 2), ref, 1e-5, "in fwd vs torch")
+
+
+def test_layout_tap_and_loss_kernels(golden_dir):
+    import os
+    gen = torch.Generator().manual_seed(21)
+    emu = EmuBackend()
+    be = L.backend()
+    st = torch.cuda.current_stream().cuda_stream
+    # nchw -> halo, composite reflect (data padding 10 then conv padding 3)
+    src = torch.rand(2, 3, 24, 20, generator=gen)
+    gsrc = src.to(DEV)
+    P = 13
+    gd = torch.zeros(2, 24 + 2 * P, 20 + 2 * P, 4, device=DEV)
+    L.check(be.nirgan_nchw_to_halo(gsrc.data_ptr(), 2, 3, 24, 20, gd.data_ptr(), 4, 0, 10, 3, L.BORDER_REFLECT, st))
+    ref = torch.nn.functional.pad(torch.nn.functional.pad(src, (10,) * 4, mode="reflect"), (3,) * 4, mode="reflect")
+    close(gd[..., :3].permute(0, 3, 1, 2), ref, 0, "composite reflect")
+    # lsgan + pixel losses against the golden known answers of the reference
+    z = np.load(os.path.join(golden_dir, "f3_losses.npz"))
+    pd_ = torch.from_numpy(z["pred_d"]).to(DEV)
+    for real, tag in ((True, "real"), (False, "fake")):
+        loss = torch.zeros(1, device=DEV)
+        grad = torch.empty_like(pd_)
+        L.check(be.nirgan_lsgan(pd_.data_ptr(), pd_.numel(), 1.0 if real else 0.0, 1.0, loss.data_ptr(), grad.data_ptr(), st))
+        close(loss[0], torch.from_numpy(z["lsgan_" + tag]), 1e-5, "lsgan")
+        close(grad, torch.from_numpy(z["lsgan_grad_" + tag]), 1e-5, "lsgan grad")
+    from utils.remote_sensing_indices import RemoteSensingIndices
+    rgb, nir, pred = (torch.from_numpy(z[k]).to(DEV) for k in ("rgb", "nir", "pred"))
+    w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333}
+    for c in ("l1", "l2"):
+        p = pred.clone().requires_grad_(True)
+        l = RemoteSensingIndices("loss", c).get_and_weight_losses(rgb, nir, p, loss_config=w)
+        l.backward()
+        close(l, torch.from_numpy(z["rs_" + c]), 1e-5, "rs " + c)
+        close(p.grad, torch.from_numpy(z[f"rs_{c}_grad"]), 1e-4, "rs grad " + c)
+        for k, v in RemoteSensingIndices("loss", c).get_and_weight_losses(rgb, nir, pred, mode="logging_dict").items():
+            close(v, torch.from_numpy(z[f"rslog_{c}/{k}"]), 2e-5, k)
+    from model.pix2pix import HipL1Loss
+    p = pred.clone().requires_grad_(True)
+    l = HipL1Loss()(p, nir)
+    l.backward()
+    close(l, torch.from_numpy(z["l1"]), 1e-5, "l1")
+    close(p.grad, torch.from_numpy(z["l1_grad"]), 1e-6, "l1 grad")
+
+
+def test_adam_kernel_matches_torch_optimizer():
+    torch.manual_seed(3)
+    n = 100003
+    p = torch.randn(n + 1)[:n].contiguous()
+    q = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([q], lr=2e-4, betas=(0.5, 0.999))
+    gp, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(1, 5):
+        g = torch.randn(n) * (10.0 ** (step - 3))
+        q.grad = g.clone()
+        opt.step()
+        gg = g.to(DEV)
+        L.call("nirgan_adam", gp.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), n, 2e-4, 0.5, 0.999, 1e-8, step, st)
+        close(gp, q.detach(), 1e-6, f"adam step {step}")
+
+
+def test_bilinear_and_inject_match_torch():
+    gen = torch.Generator().manual_seed(8)
+    B, S, O_ = 2, 128, 69
+    src = torch.randn(B, 1, S, S, generator=gen)
+    st = torch.cuda.current_stream().cuda_stream
+    gs, gd = src.to(DEV), torch.zeros(B, O_, O_, device=DEV)
+    L.call("nirgan_bilinear_fwd", gs.data_ptr(), B, S, S, gd.data_ptr(), O_, O_, st)
+    s2 = src.clone().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(s2, size=(O_, O_), mode="bilinear", align_corners=False)
+    close(gd, ref[:, 0], 1e-6, "bilinear fwd")
+    dd = torch.randn(B, O_, O_, generator=gen)
+    ref.backward(dd[:, None])
+    gds = torch.zeros(B, S, S, device=DEV)
+    L.call("nirgan_bilinear_bwd", dd.to(DEV).data_ptr(), B, O_, O_, gds.data_ptr(), S, S, st)
+    close(gds, s2.grad[:, 0], 1e-5, "bilinear bwd")
