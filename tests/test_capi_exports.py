@@ -1,0 +1,51 @@
+"""The C-ABI library loads and exports every symbol include/nirgan_hip.h declares (no compute calls: no GPU here)."""
+import os
+import re
+
+from nirgan_hip import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "nirgan_hip.h")).read()
+    declared = set(re.findall(r"\b(nirgan_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
+    L.check_exports()
+    assert L.backend().nirgan_version() >= 100
+    assert L.backend().nirgan_last_error() is not None
+
+
+def test_descriptor_validation_rejects_bad_arguments_without_launching():
+    """Argument errors come back as codes + message before any kernel launch (safe without a GPU)."""
+    d = L.ConvDesc()
+    rc = L.backend().nirgan_conv_igemm(d, None)
+    assert rc == -1 and b"null" in L.backend().nirgan_last_error()
+    w = L.WgradDesc()
+    assert L.backend().nirgan_wgrad_igemm(w, None) == -1
+    assert L.backend().nirgan_instnorm_ws_elems(2, 64, 64, 256) > 0
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """ctypes mirrors have exactly the C layout: sizeof and the offset of the last field, computed by gcc."""
+    import ctypes as C
+    import subprocess
+    pairs = [("nirgan_conv_desc", L.ConvDesc, "zero_page"), ("nirgan_wgrad_desc", L.WgradDesc, "zero_page"),
+             ("nirgan_in_fwd_desc", L.InFwdDesc, "ws_elems"), ("nirgan_in_bwd_desc", L.InBwdDesc, "ws_elems"),
+             ("nirgan_tap_gather_desc", L.TapGatherDesc, "dst"), ("nirgan_tap_scatter_desc", L.TapScatterDesc, "dbias"),
+             ("nirgan_pix_loss_desc", L.PixLossDesc, "grad_pred"), ("nirgan_inject_fwd_desc", L.InjectFwdDesc, "o_pad"),
+             ("nirgan_inject_bwd_desc", L.InjectBwdDesc, "dscale"), ("nirgan_plan_entry", L.PlanEntry, "desc")]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "nirgan_hip.h"\nint main(void){\n'
+    for cname, _, last in pairs:
+        src += f'printf("%zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));\n'
+    src += "return 0;}\n"
+    c = tmp_path / "layout.c"
+    c.write_text(src)
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for (cname, ct, last), line in zip(pairs, lines):
+        size, off = (int(x) for x in line.split())
+        assert C.sizeof(ct) == size, cname
+        assert getattr(ct, ct._fields_[-1][0]).offset == off, cname
