@@ -100,6 +100,11 @@ typedef struct {
 
 int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream);
 
+/* Horizontally fused launch of a data-gradient convolution and the weight gradient of the same layer (both
+ * read the same dY): one grid holds the tiles of both, so the partly filled last round of one problem is
+ * filled by the other.  Semantics = nirgan_conv_igemm(c) followed by nirgan_wgrad_igemm(w). */
+int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wgrad_desc* w, void* stream);
+
 /* dst[n*dst_row_stride + map[k]] (= | +=) sum_s slabs[s][n][k]  for map[k] >= 0 */
 int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,
                        float* dst, int64_t dst_elems, int dst_row_stride, int accumulate, void* stream);

@@ -1,0 +1,422 @@
+// Tile bodies of the two implicit-GEMM kernels (device functions shared by the stand-alone
+// kernels and the horizontally fused data-gradient + weight-gradient launch), plus the
+// descriptor -> kernel-parameter translation with validation.
+#pragma once
+#include "common.h"
+
+namespace ng {
+
+struct ConvParams {
+    const float* in;
+    const float* w;
+    const float* bias;
+    float* out;
+    const float* zero;
+    int in_row, in_img, in_cs, run, in_stride, in_org;
+    int ntaps;
+    int tap_off[NIRGAN_MAX_TAPS];
+    int K;
+    int out_cs, out_row, out_img, out_stride, out_org;
+    int OW, OHW, M, N;
+    int mtiles, ntiles;
+};
+
+
+template <int BN>
+__device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* smem) {
+    constexpr int BM = 128;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NT = BN / 64;   // 32-column MFMA tiles per wave
+    constexpr int BI = BN / 32;   // B loader instructions per wave (8 rows each)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int id = ng_xcd_remap(block_id, p.mtiles * p.ntiles);
+    const int n0 = (id % p.ntiles) * BN, m0 = (id / p.ntiles) * BM;
+
+    // ---------------- loader state: each lane owns one 16-byte chunk of 4 A rows and BI B rows
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    int a_base[4], a_col[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + lrow;
+        const int lc = lchunk ^ ((row >> 1) & 7);
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        const int b = m / p.OHW, r = m - b * p.OHW;
+        const int oh = r / p.OW, ow = r - oh * p.OW;
+        a_col[i] = lc * 4;
+        a_base[i] = b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + lc * 4;
+    }
+    int b_base[BI], b_col[BI];
+    bool b_ok[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int row = (wave * BI + i) * 8 + lrow;
+        const int lc = lchunk ^ ((row >> 1) & 7);
+        const int n = n0 + row;
+        b_ok[i] = n < p.N;
+        b_col[i] = lc * 4;
+        b_base[i] = (b_ok[i] ? n : 0) * p.K + lc * 4;
+    }
+
+    auto issue = [&](int stage, int t, int c0) {
+        char* sA = smem + stage * STAGE;
+        char* sB = sA + A_BYTES;
+        const int toff = p.tap_off[t] + c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* src = (c0 + a_col[i] < p.run) ? p.in + (a_base[i] + toff) : p.zero;
+            ng_glds16(src, sA + (wave * 4 + i) * 1024);
+        }
+        const int woff = t * p.run + c0;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const float* src = (b_ok[i] && c0 + b_col[i] < p.run) ? p.w + (b_base[i] + woff) : p.zero;
+            ng_glds16(src, sB + (wave * BI + i) * 1024);
+        }
+    };
+
+    // ---------------- compute state
+    const int wr = wave >> 1, wc = wave & 1;
+    const int half = lane >> 5;
+    int a_off[2], a_key[2], b_off[NT], b_key[NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = wr * 64 + mt * 32 + (lane & 31);
+        a_off[mt] = row * 128;
+        a_key[mt] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int row = wc * (BN / 2) + nt * 32 + (lane & 31);
+        b_off[nt] = row * 128;
+        b_key[nt] = (row >> 1) & 7;
+    }
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // fragments of group g+1 are read from LDS before the 16 MFMAs of group g are issued (register double
+    // buffer), so the LDS latency sits under 1024 MFMA cycles instead of in front of them
+    auto compute = [&](int stage) {
+        const char* sA = smem + stage * STAGE;
+        const char* sB = sA + A_BYTES;
+        f32x4 a[2][2], b[2][NT];
+        auto load = [&](int g, int slot) {
+            const int chunk = 2 * g + half;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                a[slot][mt] = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + ((chunk ^ a_key[mt]) << 4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                b[slot][nt] = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + ((chunk ^ b_key[nt]) << 4));
+        };
+        load(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) load(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this group's MFMAs
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][mt][j], b[g & 1][nt][j], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    // ---------------- main loop: K-steps enumerate (tap, 32-float slice of the run)
+    const int csteps = (p.run + 31) >> 5;
+    const int nk = p.ntaps * csteps;
+    int t = 0, c0 = 0;
+    issue(0, 0, 0);
+    for (int s = 0; s < nk; ++s) {
+        int c1 = c0 + 32, t1 = t;
+        if (c1 >= p.run) { c1 = 0; t1 = t + 1; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nk) issue((s + 1) & 1, t1, c1);
+        compute(s & 1);
+        t = t1; c0 = c1;
+    }
+
+    // ---------------- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + wc * (BN / 2) + nt * 32 + (lane & 31);
+            const bool col_ok = col < p.N;
+            const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < p.M && col_ok) {
+                    const int b = m / p.OHW, rr = m - b * p.OHW;
+                    const int oh = rr / p.OW, ow = rr - oh * p.OW;
+                    const int off = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + col;
+                    p.out[off] = acc[mt][nt][r] + bv;
+                }
+            }
+        }
+    }
+}
+
+
+struct WgradParams {
+    const float* p;
+    const float* q;
+    float* slabs;
+    const float* zero;
+    int p_row, p_img, p_cs, p_org;
+    int q_row, q_img, q_cs, q_stride, q_org;
+    int run, ntaps;
+    int tap_off[NIRGAN_MAX_TAPS];
+    int K, OW, OH, OHW, M, N;
+    int rows_per_split, nsplit, ntiles_n, ntiles_k;
+};
+
+
+template <int TN>
+__device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block_id, char* smem) {
+    constexpr int P_BYTES = 32 * TN * 4;
+    constexpr int Q_BYTES = 32 * 128 * 4;
+    constexpr int STAGE = P_BYTES + Q_BYTES;
+    constexpr int LPR = TN / 4;          // lanes per P row
+    constexpr int RPI = 64 / LPR;        // P rows per wave-instruction
+    constexpr int PI = TN / 32;          // P instructions per wave
+    constexpr int EA = TN / 64;          // n-interleave: floats per lane per P fragment read
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.ntiles_n * p.ntiles_k;
+    const int id = ng_xcd_remap(block_id, tiles * p.nsplit);
+    const int split = id / tiles, tile = id - split * tiles;
+    const int n0 = (tile % p.ntiles_n) * TN, j0 = (tile / p.ntiles_n) * 128;
+    const int mstart = split * p.rows_per_split;
+    int mend = mstart + p.rows_per_split;
+    mend = mend < p.M ? mend : p.M;
+    const int nk = mend > mstart ? (mend - mstart + 31) >> 5 : 0;
+
+    // ---------------- loader state
+    const int p_lrow = lane / LPR, p_chunk = lane % LPR;
+    const bool p_ok = n0 + p_chunk * 4 < p.N;
+    const int p_n = p_ok ? n0 + p_chunk * 4 : 0;
+    const int q_lrow = lane >> 5, q_chunk = lane & 31;
+    const int q_j = j0 + q_chunk * 4;
+    const bool q_ok = q_j < p.K;
+    int q_add = 0;
+    if (q_ok) {
+        const int t = q_j / p.run;
+        q_add = p.tap_off[t] + (q_j - t * p.run);
+    }
+
+    // pixel coordinates of this lane's rows, advanced by 32 pixels per step without integer division
+    struct Pix { int b, oh, ow; };
+    auto decompose = [&](int m) {
+        Pix x;
+        x.b = m / p.OHW;
+        const int r = m - x.b * p.OHW;
+        x.oh = r / p.OW;
+        x.ow = r - x.oh * p.OW;
+        return x;
+    };
+    auto advance = [&](Pix& x) {
+        x.ow += 32;
+        while (x.ow >= p.OW) { x.ow -= p.OW; ++x.oh; }
+        while (x.oh >= p.OH) { x.oh -= p.OH; ++x.b; }
+    };
+    Pix pp[PI], qp[4];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) pp[i] = decompose(mstart + (wave * PI + i) * RPI + p_lrow);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qp[i] = decompose(mstart + (wave * 4 + i) * 2 + q_lrow);
+
+    auto issue = [&](int stage, int mb) {
+        char* sP = smem + stage * STAGE;
+        char* sQ = sP + P_BYTES;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int ins = wave * PI + i;
+            const int m = mb + ins * RPI + p_lrow;
+            const float* src = p.p + (pp[i].b * p.p_img + pp[i].oh * p.p_row + pp[i].ow * p.p_cs + p.p_org + p_n);
+            src = (p_ok && m < mend) ? src : p.zero;
+            ng_glds16(src, sP + ins * 1024);
+            advance(pp[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ins = wave * 4 + i;
+            const int m = mb + ins * 2 + q_lrow;
+            const float* src = p.q + (qp[i].b * p.q_img + qp[i].oh * p.q_stride * p.q_row + qp[i].ow * p.q_stride * p.q_cs + p.q_org + q_add);
+            src = (q_ok && m < p.M) ? src : (q_ok ? p.q + (p.q_org + q_add) : p.zero);
+            ng_glds16(src, sQ + ins * 1024);
+            advance(qp[i]);
+        }
+    };
+
+    // ---------------- compute state
+    const int wr = wave >> 1, wc = wave & 1;
+    const int half = lane >> 5;
+    const int a_off = half * (TN * 4) + (wr * (TN / 2) + EA * (lane & 31)) * 4;
+    const int b_off = half * 512 + (wc * 64 + 2 * (lane & 31)) * 4;
+    f32x16 acc[EA][2];
+#pragma unroll
+    for (int e = 0; e < EA; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+
+    // 4 pixel-pair steps per group: the 8 fragment reads of group g+1 are issued before the 16 MFMAs of group g
+    auto compute = [&](int stage) {
+        const char* sP = smem + stage * STAGE;
+        const char* sQ = sP + P_BYTES;
+        float a[2][4][EA];
+        f32x2 b[2][4];
+        auto load = [&](int g, int slot) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = 4 * g + i;
+                if constexpr (EA == 2) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(sP + a_off + kk * (2 * TN * 4));
+                    a[slot][i][0] = v[0]; a[slot][i][1] = v[1];
+                } else {
+                    a[slot][i][0] = *reinterpret_cast<const float*>(sP + a_off + kk * (2 * TN * 4));
+                }
+                b[slot][i] = *reinterpret_cast<const f32x2*>(sQ + b_off + kk * 1024);
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) load(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this group's MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < EA; ++e) {
+                    acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][0], acc[e][0], 0, 0, 0);
+                    acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][1], acc[e][1], 0, 0, 0);
+                }
+        }
+    };
+
+    if (nk > 0) issue(0, mstart);
+    for (int s = 0; s < nk; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nk) issue((s + 1) & 1, mstart + (s + 1) * 32);
+        compute(s & 1);
+    }
+
+    // ---------------- store the partial tile: row i = (r&3)+8*(r>>2)+4*half, col = lane&31
+    const int jj = j0 + wc * 64 + 2 * (lane & 31);
+    if (jj < p.K) {
+        float* slab = p.slabs + size_t(split) * p.N * p.K;
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int n = n0 + wr * (TN / 2) + EA * i + e;
+                if (n < p.N) {
+                    f32x2 v;
+                    v[0] = acc[e][0][r];
+                    v[1] = acc[e][1][r];
+                    *reinterpret_cast<f32x2*>(slab + size_t(n) * p.K + jj) = v;
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------- host: descriptor -> parameters
+inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
+    NG_REQUIRE(d != nullptr, "conv: null descriptor");
+    NG_REQUIRE(d->in && d->w && d->out && d->zero_page, "conv: null pointer");
+    NG_REQUIRE(ng_aligned16(d->in) && ng_aligned16(d->w) && ng_aligned16(d->zero_page), "conv: in/w/zero_page must be 16-byte aligned");
+    NG_REQUIRE(d->B > 0 && d->OH > 0 && d->OW > 0 && d->N > 0, "conv: empty problem B=%d OH=%d OW=%d N=%d", d->B, d->OH, d->OW, d->N);
+    NG_REQUIRE(d->ntaps >= 1 && d->ntaps <= NIRGAN_MAX_TAPS, "conv: ntaps=%d out of range", d->ntaps);
+    NG_REQUIRE(d->run > 0 && d->run % 4 == 0 && d->in_cs > 0 && d->in_cs % 4 == 0, "conv: run=%d and in_cs=%d must be positive multiples of 4", d->run, d->in_cs);
+    NG_REQUIRE(d->in_stride >= 1 && d->out_stride >= 1, "conv: strides must be >= 1");
+    NG_REQUIRE(d->in_elems < (int64_t(1) << 31) && d->out_elems < (int64_t(1) << 31) && d->w_elems < (int64_t(1) << 31), "conv: buffers must be < 2^31 floats");
+    NG_REQUIRE(d->in_elems >= int64_t(d->B) * d->in_hp * d->in_wp * d->in_cs, "conv: in_elems too small");
+    NG_REQUIRE(d->out_elems >= int64_t(d->B) * d->out_hp * d->out_wp * d->out_cs, "conv: out_elems too small");
+    NG_REQUIRE(d->w_elems >= int64_t(d->N) * d->ntaps * d->run, "conv: w_elems too small");
+    NG_REQUIRE(d->N <= d->out_cs, "conv: N=%d exceeds out_cs=%d", d->N, d->out_cs);
+    int dh0 = d->tap_dh[0], dh1 = d->tap_dh[0], dw0 = d->tap_dw[0], dw1 = d->tap_dw[0];
+    for (int t = 1; t < d->ntaps; ++t) {
+        dh0 = d->tap_dh[t] < dh0 ? d->tap_dh[t] : dh0; dh1 = d->tap_dh[t] > dh1 ? d->tap_dh[t] : dh1;
+        dw0 = d->tap_dw[t] < dw0 ? d->tap_dw[t] : dw0; dw1 = d->tap_dw[t] > dw1 ? d->tap_dw[t] : dw1;
+    }
+    NG_REQUIRE(d->in_oh + dh0 >= 0 && (d->OH - 1) * d->in_stride + d->in_oh + dh1 < d->in_hp, "conv: input rows out of range");
+    NG_REQUIRE(d->in_ow + dw0 >= 0 && int64_t((d->OW - 1) * d->in_stride + d->in_ow + dw1) * d->in_cs + d->run <= int64_t(d->in_wp) * d->in_cs, "conv: input columns out of range");
+    NG_REQUIRE(d->out_oh >= 0 && (d->OH - 1) * d->out_stride + d->out_oh < d->out_hp && d->out_ow >= 0 && (d->OW - 1) * d->out_stride + d->out_ow < d->out_wp, "conv: output window out of range");
+
+    p.in = d->in; p.w = d->w; p.bias = d->bias; p.out = d->out; p.zero = d->zero_page;
+    p.in_cs = d->in_cs; p.in_row = d->in_wp * d->in_cs; p.in_img = d->in_hp * p.in_row;
+    p.run = d->run; p.in_stride = d->in_stride; p.in_org = d->in_oh * p.in_row + d->in_ow * d->in_cs;
+    p.ntaps = d->ntaps;
+    for (int t = 0; t < NIRGAN_MAX_TAPS; ++t) p.tap_off[t] = t < d->ntaps ? d->tap_dh[t] * p.in_row + d->tap_dw[t] * d->in_cs : 0;
+    p.K = d->ntaps * d->run;
+    p.out_cs = d->out_cs; p.out_row = d->out_wp * d->out_cs; p.out_img = d->out_hp * p.out_row;
+    p.out_stride = d->out_stride; p.out_org = d->out_oh * p.out_row + d->out_ow * d->out_cs;
+    p.OW = d->OW; p.OHW = d->OH * d->OW;
+    const int64_t M = int64_t(d->B) * p.OHW;
+    NG_REQUIRE(M < (int64_t(1) << 31), "conv: too many output pixels");
+    p.M = int(M); p.N = d->N;
+    p.mtiles = (p.M + 127) / 128;
+    p.ntiles = d->N > 64 ? (d->N + 127) / 128 : 1;
+    return NIRGAN_OK;
+}
+
+inline int build_wgrad_params(const nirgan_wgrad_desc* d, WgradParams& p) {
+    NG_REQUIRE(d != nullptr, "wgrad_igemm: null descriptor");
+    NG_REQUIRE(d->p && d->q && d->slabs && d->zero_page, "wgrad_igemm: null pointer");
+    NG_REQUIRE(ng_aligned16(d->p) && ng_aligned16(d->q) && ng_aligned16(d->slabs) && ng_aligned16(d->zero_page), "wgrad_igemm: pointers must be 16-byte aligned");
+    NG_REQUIRE(d->B > 0 && d->OH > 0 && d->OW > 0 && d->N > 0, "wgrad_igemm: empty problem");
+    NG_REQUIRE(d->p_cs % 4 == 0 && d->q_cs % 4 == 0 && d->run % 4 == 0 && d->run > 0, "wgrad_igemm: p_cs, q_cs, run must be multiples of 4");
+    NG_REQUIRE(d->ntaps >= 1 && d->ntaps <= NIRGAN_MAX_TAPS, "wgrad_igemm: ntaps=%d out of range", d->ntaps);
+    NG_REQUIRE(d->q_stride >= 1, "wgrad_igemm: q_stride must be >= 1");
+    NG_REQUIRE(d->p_elems < (int64_t(1) << 31) && d->q_elems < (int64_t(1) << 31), "wgrad_igemm: buffers must be < 2^31 floats");
+    NG_REQUIRE(d->p_elems >= int64_t(d->B) * d->p_hp * d->p_wp * d->p_cs, "wgrad_igemm: p_elems too small");
+    NG_REQUIRE(d->q_elems >= int64_t(d->B) * d->q_hp * d->q_wp * d->q_cs, "wgrad_igemm: q_elems too small");
+    NG_REQUIRE(((d->N + 3) & ~3) <= d->p_cs, "wgrad_igemm: N (rounded up to 4) exceeds p_cs");
+    NG_REQUIRE(d->p_oh >= 0 && d->OH - 1 + d->p_oh < d->p_hp && d->p_ow >= 0 && d->OW - 1 + d->p_ow < d->p_wp, "wgrad_igemm: p window out of range");
+    int dh0 = d->tap_dh[0], dh1 = d->tap_dh[0], dw0 = d->tap_dw[0], dw1 = d->tap_dw[0];
+    for (int t = 1; t < d->ntaps; ++t) {
+        dh0 = d->tap_dh[t] < dh0 ? d->tap_dh[t] : dh0; dh1 = d->tap_dh[t] > dh1 ? d->tap_dh[t] : dh1;
+        dw0 = d->tap_dw[t] < dw0 ? d->tap_dw[t] : dw0; dw1 = d->tap_dw[t] > dw1 ? d->tap_dw[t] : dw1;
+    }
+    NG_REQUIRE(d->q_oh + dh0 >= 0 && (d->OH - 1) * d->q_stride + d->q_oh + dh1 < d->q_hp, "wgrad_igemm: q rows out of range");
+    NG_REQUIRE(d->q_ow + dw0 >= 0 && int64_t((d->OW - 1) * d->q_stride + d->q_ow + dw1) * d->q_cs + d->run <= int64_t(d->q_wp) * d->q_cs, "wgrad_igemm: q columns out of range");
+    const int64_t M = int64_t(d->B) * d->OH * d->OW;
+    NG_REQUIRE(M < (int64_t(1) << 31), "wgrad_igemm: too many pixels");
+    NG_REQUIRE(d->nsplit >= 1 && d->rows_per_split > 0 && d->rows_per_split % 32 == 0 && int64_t(d->nsplit) * d->rows_per_split >= M, "wgrad_igemm: bad split (nsplit=%d rows=%d M=%lld)", d->nsplit, d->rows_per_split, (long long)M);
+    const int K = d->ntaps * d->run;
+    NG_REQUIRE(d->slab_elems >= int64_t(d->nsplit) * d->N * K, "wgrad_igemm: slab_elems too small");
+
+    p.p = d->p; p.q = d->q; p.slabs = d->slabs; p.zero = d->zero_page;
+    p.p_cs = d->p_cs; p.p_row = d->p_wp * d->p_cs; p.p_img = d->p_hp * p.p_row; p.p_org = d->p_oh * p.p_row + d->p_ow * d->p_cs;
+    p.q_cs = d->q_cs; p.q_row = d->q_wp * d->q_cs; p.q_img = d->q_hp * p.q_row; p.q_stride = d->q_stride;
+    p.q_org = d->q_oh * p.q_row + d->q_ow * d->q_cs;
+    p.run = d->run; p.ntaps = d->ntaps;
+    for (int t = 0; t < NIRGAN_MAX_TAPS; ++t) p.tap_off[t] = t < d->ntaps ? d->tap_dh[t] * p.q_row + d->tap_dw[t] * d->q_cs : 0;
+    p.K = K; p.OW = d->OW; p.OH = d->OH; p.OHW = d->OH * d->OW; p.M = int(M); p.N = d->N;
+    p.rows_per_split = d->rows_per_split; p.nsplit = d->nsplit;
+    p.ntiles_k = (K + 127) / 128;
+    p.ntiles_n = d->N > 64 ? (d->N + 127) / 128 : 1;
+    return NIRGAN_OK;
+}
+
+}  // namespace ng

@@ -83,7 +83,7 @@ class Plan:
     def __init__(self, ctx: Ctx):
         self.ctx = ctx
         self.ops: list = []
-        self.probe_idx = None        # bench.py: indices of ops to bracket with HIP events on the launch stream
+        self.probe_idx = None        # bench.py: {op index: kernel label} to bracket with HIP events on the launch stream
         self.probe_events: list = []
 
     def add(self, name: str, *args):
@@ -109,7 +109,7 @@ class Plan:
                 s.record()
                 rc = getattr(be, name)(*args, st)
                 e.record()
-                self.probe_events.append((s, e))
+                self.probe_events.append((self.probe_idx[i], s, e))
             else:
                 rc = getattr(be, name)(*args, st)
             if rc != 0:
@@ -161,17 +161,25 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.B, d.OH, d.OW, d.N = inp.B, OH, OW, N
     d.zero_page = ctx.zero_page.data_ptr()
     ctx.keep.append(d)
-    plan.add("nirgan_conv_igemm", C.byref(d))
+    if plan is not None:
+        plan.add("nirgan_conv_igemm", C.byref(d))
     return d
 
 
 def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.PackSpec, grad: torch.Tensor, *,
-               N, OH, OW, p_oh, p_ow, q_stride=1, q_oh=0, q_ow=0, accumulate=False, slabs_pool=None):
+               N, OH, OW, p_oh, p_ow, q_stride=1, q_oh=0, q_ow=0, accumulate=False, slabs_pool=None, pair_with=None):
+    """pair_with: a ConvDesc (built with plan=None) launched in the same grid (nirgan_conv_wgrad_pair)."""
     K = taps.n * taps.run
     assert K == spec.K, (K, spec.K)
     tiles = (-(-N // 128) if N > 64 else 1) * (-(-K // 128))
     M = p.B * OH * OW
-    nsplit, rows = G.wgrad_split(M, tiles)
+    target = 1024
+    if pair_with is not None:
+        c = pair_with
+        conv_blocks = -(-(c.B * c.OH * c.OW) // 128) * (-(-c.N // 128) if c.N > 64 else 1)
+        total = 512 * max(1, round((conv_blocks + 1024) / 512))
+        target = max(total - conv_blocks, 512)
+    nsplit, rows = G.wgrad_split(M, tiles, target)
     need = nsplit * N * K
     slabs = slabs_pool.get(need) if slabs_pool is not None else ctx.zeros(need)
     ctx.keep.append(slabs)
@@ -186,7 +194,10 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     d.zero_page = ctx.zero_page.data_ptr()
     ctx.keep.append(d)
     imap = ctx.i32(spec.index_map)
-    plan.add("nirgan_wgrad_igemm", C.byref(d))
+    if pair_with is not None:
+        plan.add("nirgan_conv_wgrad_pair", C.byref(pair_with), C.byref(d))
+    else:
+        plan.add("nirgan_wgrad_igemm", C.byref(d))
     plan.add("nirgan_reduce_rows", slabs.data_ptr(), nsplit, N, K, imap.data_ptr(), grad.data_ptr(), grad.numel(),
              spec.row_stride, 1 if accumulate else 0)
     return d
@@ -349,6 +360,17 @@ class ConvIN:
                     ws=eng.scratch.get(),
                     shape=(inp.B, self.OH, self.OW, self.cout))
         dy = self.dy
+        # stride-1 convolutions that need both gradients: one fused launch (data-gradient tiles + weight-gradient tiles)
+        if self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None:
+            assert dgrad_out.H == inp.H and dgrad_out.pad == p and dy.pad == k - 1
+            hw = [(kh, kw) for kh in range(k) for kw in range(k)]
+            wd = eng.weights.packed(pack, self.weight, G.conv_dgrad_pack(self.cout, inp.C, k, hw))
+            cdesc = emit_conv(None, ctx, dy, G.conv_dgrad_s1_taps(k, self.cout), wd, None, dgrad_out, N=inp.C,
+                              OH=dgrad_out.hp, OW=dgrad_out.wp)
+            emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
+                       N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
+                       q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_with=cdesc)
+            return
         # weight gradient (skipped when the parameters are frozen: gw is None)
         if gw is None:
             pass

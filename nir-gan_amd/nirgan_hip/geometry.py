@@ -186,8 +186,11 @@ def linear_pack(nout: int, nin: int) -> PackSpec:
 
 
 def wgrad_split(M: int, tiles: int, target_blocks: int = 1024) -> Tuple[int, int]:
-    """(nsplit, rows_per_split): enough blocks to fill 256 CUs x 2, rows a multiple of 32."""
-    want = max(1, -(-target_blocks // max(tiles, 1)))
+    """(nsplit, rows_per_split) for the weight-gradient GEMM.
+
+    256 CUs x 2 resident blocks = 512 slots: tiles*nsplit is kept AT OR BELOW a whole number of rounds
+    (<= target_blocks) so that no nearly-empty trailing round appears; rows are a multiple of 32."""
+    want = max(1, target_blocks // max(tiles, 1))
     rows = max(32, -(-M // want))
     rows = -(-rows // 32) * 32
     nsplit = -(-M // rows)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Per-op timing of one train step (GPU box): every C-ABI call of every plan is bracketed by HIP events on the
+launch stream; MFMA ops are annotated with their algorithmic FLOPs (2*M*N*K) and block counts."""
+import os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nir-gan_amd"))
+import torch
+from model import networks
+from nirgan_hip.trainer import Pix2PixTrainer
+
+bs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+pad = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+dev = "cuda:0"
+torch.manual_seed(0)
+netG = networks.define_G(3, 1, 64, f"resnet_{nb}blocks", "instance", False, "normal", 0.02).to(dev)
+netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)
+tr = Pix2PixTrainer(netG, netD, n_blocks=nb, padding=pad)
+g = torch.Generator().manual_seed(1)
+rgb = (0.02 + 0.58 * torch.rand(bs, 3, 256, 256, generator=g)).to(dev)
+nir = (0.05 + 0.75 * torch.rand(bs, 1, 256, 256, generator=g)).to(dev)
+for _ in range(3):
+    tr.step(rgb, nir)
+plans = {"G.fwd": tr.G.fwd, "G.bwd": tr.G.bwd, "D2.fwd": tr.D2.fwd, "D2.bwd": tr.D2.bwd, "D1.fwd": tr.D1.fwd, "D1.bwdF": tr.D1.bwd_frozen,
+         "G.pack": tr.G.pack_fwd, "G.packb": tr.G.pack_bwd}
+
+
+def describe(name, args):
+    if name == "nirgan_conv_igemm":
+        d = args[0]._obj
+        M = d.B * d.OH * d.OW
+        blocks = -(-M // 128) * (-(-d.N // 128) if d.N > 64 else 1)
+        return f"conv M={M} N={d.N} K={d.ntaps}x{d.run} s{d.in_stride}/{d.out_stride} blk={blocks}", 2.0 * M * d.N * d.ntaps * d.run
+    if name == "nirgan_wgrad_igemm":
+        w = args[0]._obj
+        M = w.B * w.OH * w.OW
+        K = w.ntaps * w.run
+        blocks = (-(-w.N // 128) if w.N > 64 else 1) * (-(-K // 128)) * w.nsplit
+        return f"wgrad M={M} N={w.N} K={K} split={w.nsplit} blk={blocks}", 2.0 * M * w.N * K
+    if name == "nirgan_conv_wgrad_pair":
+        c, w = args[0]._obj, args[1]._obj
+        Mc, Mw = c.B * c.OH * c.OW, w.B * w.OH * w.OW
+        cb = -(-Mc // 128) * (-(-c.N // 128))
+        wb = (-(-w.N // 128)) * (-(-(w.ntaps * w.run) // 128)) * w.nsplit
+        return f"pair Mc={Mc} N={c.N} K={c.ntaps*c.run} | Mw={Mw} split={w.nsplit} blk={cb}+{wb}", 2.0 * Mc * c.N * c.ntaps * c.run + 2.0 * Mw * w.N * w.ntaps * w.run
+    if name in ("nirgan_instnorm_fwd", "nirgan_instnorm_bwd"):
+        d = args[0]._obj
+        return f"{name[7:]} B={d.B} {d.H}x{d.W}x{d.C}", 0.0
+    return name[7:], 0.0
+
+
+for pl in plans.values():
+    pl.probe_idx = {i: i for i in range(len(pl.ops))}
+    pl.probe_events = []
+tr.G._packed_version = tr.G._packed_bwd_version = -1   # force the pack plans once
+tr.step(rgb, nir)
+torch.cuda.synchronize()
+rows = []
+for pname, pl in plans.items():
+    for i, s, e in pl.probe_events:
+        name, args = pl.ops[i]
+        desc, fl = describe(name, args)
+        rows.append((s.elapsed_time(e), pname, desc, fl))
+    pl.probe_idx = None
+tot = sum(r[0] for r in rows)
+print(f"bs={bs} blocks={nb} pad={pad}: sum of bracketed op times {tot:.2f} ms, {len(rows)} ops")
+agg = collections.OrderedDict()
+for ms, pname, desc, fl in rows:
+    k = desc
+    a = agg.setdefault(k, [0.0, 0, 0.0])
+    a[0] += ms; a[1] += 1; a[2] += fl
+for k, (ms, n, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+    tf = f"{fl / (ms * 1e-3) / 1e12:7.1f} TF/s" if fl else ""
+    print(f"{ms:8.3f} ms  x{n:<3d} {ms / n * 1e3:9.1f} us  {tf:14s} {k}")

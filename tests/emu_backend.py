@@ -141,6 +141,10 @@ class EmuBackend:
             slabs[s] = (P_all[a:e].T @ Q_all[a:e]).astype(np.float32) if e > a else 0.0
         return 0
 
+    def nirgan_conv_wgrad_pair(self, cref, wref, stream=None):
+        rc = self.nirgan_conv_igemm(cref)
+        return rc if rc else self.nirgan_wgrad_igemm(wref)
+
     def nirgan_reduce_rows(self, slabs, nsplit, N, K, imap, dst, dst_elems, stride, accumulate, stream=None):
         self.calls.append("reduce")
         s = arr(slabs, nsplit * N * K).reshape(nsplit, N, K).sum(0)
