@@ -42,7 +42,7 @@ def mfma_probes(trainer):
 
     conv_igemm_kernel<128>: 2*M*N*K per launch.  conv_wgrad_pair_kernel (data-gradient tiles + weight-gradient
     tiles of one layer in one grid): the sum of both problems' 2*M*N*K."""
-    plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_frozen]
+    plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0]}
     for pl in plans:
         pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}

@@ -172,6 +172,18 @@ int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream);
 int nirgan_nchw_to_halo(const float* src, int B, int Cs, int H, int W,
                         float* dst, int dst_cs, int c0, int pad1, int pad2, int pad_mode, void* stream);
 
+/* Data gradient of a Conv2d wrt ONE input channel (the generator step only needs dD/dpred, channel 3 of
+ * cat(rgb, pred): model/pix2pix.py:216-221 through networks.py:559):
+ *   out[b][h][w] = sum_{kh,kw,co} dY[b][(h+pad-kh)/stride][(w+pad-kw)/stride][co] * W[co][channel][kh][kw]
+ * dY is a halo'd NHWC buffer [B][OH+2dy_pad][OW+2dy_pad][C]; W is in the reference layout [C][cin][k][k]. */
+typedef struct {
+    const float* dy; int dy_hp, dy_wp, dy_pad, C;
+    const float* w; int cin, k, stride, pad, channel;
+    int B, H, W;
+    float* out;                           /* [B][H][W] */
+} nirgan_chan_dgrad_desc;
+int nirgan_conv_channel_dgrad(const nirgan_chan_dgrad_desc* d, void* stream);
+
 /* Single-output-channel convolution tail: out[b][oh][ow] = act(bias + sum_t Q[b][oh+tap_dh[t]][ow+tap_dw[t]][t])
  * restricted to the crop window (crop pixels removed on every side); dst is NCHW [B][1][OH-2crop][OW-2crop].
  * With the 1x1 tap-plane product this is Conv2d(C,1,k) (+Tanh, + crop of pix2pix.py:107-108):

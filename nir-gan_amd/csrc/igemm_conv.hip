@@ -18,8 +18,9 @@ namespace {
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ng::ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    ng::conv_tile<BN>(p, blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) char st0[(128 + BN) * 128];
+    __shared__ __attribute__((aligned(16))) char st1[(128 + BN) * 128];
+    ng::conv_tile<BN>(p, blockIdx.x, st0, st1);
 }
 
 }  // namespace
@@ -30,11 +31,9 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->N > 64) {
-        static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess; }();
-        (void)once;
-        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(p.mtiles * p.ntiles), dim3(256), 65536, st, p);
+        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(p.mtiles * p.ntiles), dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(p.mtiles), dim3(256), 49152, st, p);
+        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(p.mtiles), dim3(256), 0, st, p);
     }
     return nirgan_check_launch("conv_igemm");
 }

@@ -23,7 +23,7 @@ struct ConvParams {
 
 
 template <int BN>
-__device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* smem) {
+__device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* st0, char* st1) {
     constexpr int BM = 128;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
@@ -62,8 +62,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         b_base[i] = (b_ok[i] ? n : 0) * p.K + lc * 4;
     }
 
-    auto issue = [&](int stage, int t, int c0) {
-        char* sA = smem + stage * STAGE;
+    auto issue = [&](char* sA, int t, int c0) {
         char* sB = sA + A_BYTES;
         const int toff = p.tap_off[t] + c0;
 #pragma unroll
@@ -105,8 +104,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 
     // fragments of group g+1 are read from LDS before the 16 MFMAs of group g are issued (register double
     // buffer), so the LDS latency sits under 1024 MFMA cycles instead of in front of them
-    auto compute = [&](int stage) {
-        const char* sA = smem + stage * STAGE;
+    auto compute = [&](const char* sA) {
         const char* sB = sA + A_BYTES;
         f32x4 a[2][2], b[2][NT];
         auto load = [&](int g, int slot) {
@@ -122,7 +120,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g + 1 < 4) load(g + 1, (g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this group's MFMAs
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -137,39 +134,88 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     const int csteps = (p.run + 31) >> 5;
     const int nk = p.ntaps * csteps;
     int t = 0, c0 = 0;
-    issue(0, 0, 0);
-    for (int s = 0; s < nk; ++s) {
-        int c1 = c0 + 32, t1 = t;
-        if (c1 >= p.run) { c1 = 0; t1 = t + 1; }
+    // steady state: the LDS-DMA of step s+1 and its address arithmetic are issued BETWEEN the MFMAs of step s.
+    // The two stages are distinct LDS objects and the loop is unrolled by two, so the compiler knows the DMA
+    // writes do not alias the fragment reads and can interleave them; the sched_group_barrier sequence asks for
+    // fragment reads first, then quads of MFMAs with one load's arithmetic + issue in the shadow of each quad.
+    auto hints = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
+#pragma unroll
+            for (int q = 0; q < 2 * NT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (g < 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x006, 14, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+            }
+        }
+    };
+    auto next = [&](int& tt, int& cc) {
+        cc += 32;
+        if (cc >= p.run) { cc = 0; ++tt; }
+    };
+    issue(st0, 0, 0);
+    int s = 0;
+    for (; s + 2 < nk; s += 2) {
+        next(t, c0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < nk) issue((s + 1) & 1, t1, c1);
-        compute(s & 1);
-        t = t1; c0 = c1;
+        issue(st1, t, c0);
+        compute(st0);
+        hints();
+        next(t, c0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue(st0, t, c0);
+        compute(st1);
+        hints();
+    }
+    // tail: one or two steps left, stage parity is even at s
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nk) {
+        next(t, c0);
+        issue(st1, t, c0);
+        compute(st0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        compute(st1);
+    } else {
+        compute(st0);
     }
 
-    // ---------------- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---------------- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // One pixel decomposition per 32-row MFMA tile; the 16 rows of a lane are reached by small increments
+    // (no per-row integer division).
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+        const int mbase = m0 + wr * 64 + mt * 32 + 4 * half;
+        int mb_c = mbase < p.M ? mbase : p.M - 1;
+        const int b0 = mb_c / p.OHW, r0 = mb_c - b0 * p.OHW;
+        const int oh0 = r0 / p.OW, ow0 = r0 - oh0 * p.OW;
+        const int OH = p.OHW / p.OW;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = n0 + wc * (BN / 2) + nt * 32 + (lane & 31);
-            const bool col_ok = col < p.N;
-            const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int delta = (r & 3) + 8 * (r >> 2);
+            const int m = mbase + delta;
+            int b = b0, oh = oh0, ow = ow0 + delta;
+            while (ow >= p.OW) { ow -= p.OW; ++oh; }
+            while (oh >= OH) { oh -= OH; ++b; }
+            const int off = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < p.M && col_ok) {
-                    const int b = m / p.OHW, rr = m - b * p.OHW;
-                    const int oh = rr / p.OW, ow = rr - oh * p.OW;
-                    const int off = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + col;
-                    p.out[off] = acc[mt][nt][r] + bv;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = n0 + wc * (BN / 2) + nt * 32 + (lane & 31);
+                if (m < p.M && col < p.N) {
+                    const float bv = p.bias != nullptr ? p.bias[col] : 0.f;
+                    p.out[off + col] = acc[mt][nt][r] + bv;
                 }
             }
         }
     }
 }
-
 
 struct WgradParams {
     const float* p;
@@ -186,7 +232,7 @@ struct WgradParams {
 
 
 template <int TN>
-__device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block_id, char* smem) {
+__device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block_id, char* st0, char* st1) {
     constexpr int P_BYTES = 32 * TN * 4;
     constexpr int Q_BYTES = 32 * 128 * 4;
     constexpr int STAGE = P_BYTES + Q_BYTES;
@@ -240,8 +286,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
 #pragma unroll
     for (int i = 0; i < 4; ++i) qp[i] = decompose(mstart + (wave * 4 + i) * 2 + q_lrow);
 
-    auto issue = [&](int stage, int mb) {
-        char* sP = smem + stage * STAGE;
+    auto issue = [&](char* sP, int mb) {
         char* sQ = sP + P_BYTES;
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
@@ -277,8 +322,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
             for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
 
     // 4 pixel-pair steps per group: the 8 fragment reads of group g+1 are issued before the 16 MFMAs of group g
-    auto compute = [&](int stage) {
-        const char* sP = smem + stage * STAGE;
+    auto compute = [&](const char* sP) {
         const char* sQ = sP + P_BYTES;
         float a[2][4][EA];
         f32x2 b[2][4];
@@ -299,7 +343,6 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g + 1 < 4) load(g + 1, (g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this group's MFMAs
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -310,12 +353,49 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
         }
     };
 
-    if (nk > 0) issue(0, mstart);
-    for (int s = 0; s < nk; ++s) {
+    // same structure as conv_tile: two distinct LDS stage objects, loop unrolled by two, the LDS-DMA of the next
+    // 32 pixels issued between the MFMAs of the current ones
+    auto hints = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int q = 0; q < 2 * EA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (g < 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x006, 16, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+            }
+        }
+    };
+    if (nk > 0) {
+        issue(st0, mstart);
+        int s = 0;
+        for (; s + 2 < nk; s += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue(st1, mstart + (s + 1) * 32);
+            compute(st0);
+            hints();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue(st0, mstart + (s + 2) * 32);
+            compute(st1);
+            hints();
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < nk) issue((s + 1) & 1, mstart + (s + 1) * 32);
-        compute(s & 1);
+        if (s + 1 < nk) {
+            issue(st1, mstart + (s + 1) * 32);
+            compute(st0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(st1);
+        } else {
+            compute(st0);
+        }
     }
 
     // ---------------- store the partial tile: row i = (r&3)+8*(r>>2)+4*half, col = lane&31

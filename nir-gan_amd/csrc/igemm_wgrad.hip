@@ -16,49 +16,73 @@ namespace {
 
 template <int TN>
 __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const ng::WgradParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    ng::wgrad_tile<TN>(p, blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) char st0[32 * (TN + 128) * 4];
+    __shared__ __attribute__((aligned(16))) char st1[32 * (TN + 128) * 4];
+    ng::wgrad_tile<TN>(p, blockIdx.x, st0, st1);
 }
 
 // horizontally fused launch: the data-gradient tiles of a stride-1 convolution followed by the tiles of its
 // weight gradient (both consume the same dY).  One grid: the weight-gradient blocks fill the partly empty
 // last round of the data-gradient, and the other way round.
 __global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const ng::ConvParams cp, const ng::WgradParams wp, const int conv_blocks) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ __attribute__((aligned(16))) char st0[32768];
+    __shared__ __attribute__((aligned(16))) char st1[32768];
     if (int(blockIdx.x) < conv_blocks)
-        ng::conv_tile<128>(cp, blockIdx.x, smem);
+        ng::conv_tile<128>(cp, blockIdx.x, st0, st1);
     else
-        ng::wgrad_tile<128>(wp, int(blockIdx.x) - conv_blocks, smem);
+        ng::wgrad_tile<128>(wp, int(blockIdx.x) - conv_blocks, st0, st1);
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ slabs, int nsplit, int N, int K,
-                                   const int32_t* __restrict__ map, float* __restrict__ dst,
-                                   int64_t dst_elems, int dst_row_stride, int accumulate) {
-    const int64_t total = int64_t(N) * K;
-    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
-        const int n = int(i / K), k = int(i - int64_t(n) * K);
-        const int mk = map[k];
+// grid (K/256, N): 64 lanes x float4 cover 256 consecutive k of one row; the 4 waves of the block take the
+// splits sp = wave, wave+4, ... (independent loads in flight) and are combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ slabs, int nsplit, int N, int K,
+                                                          const int32_t* __restrict__ map, float* __restrict__ dst,
+                                                          int64_t dst_elems, int dst_row_stride, int accumulate) {
+    __shared__ f32x4 part[4][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k4 = (blockIdx.x * 64 + lane) * 4;
+    const int n = blockIdx.y;
+    const size_t total = size_t(N) * K;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (k4 < K) {
+        const float* src = slabs + size_t(n) * K + k4;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        int sp = grp;
+        for (; sp + 4 < nsplit; sp += 8) {
+            s += *reinterpret_cast<const f32x4*>(src + sp * total);
+            s1 += *reinterpret_cast<const f32x4*>(src + (sp + 4) * total);
+        }
+        if (sp < nsplit) s += *reinterpret_cast<const f32x4*>(src + sp * total);
+        s += s1;
+    }
+    part[grp][lane] = s;
+    __syncthreads();
+    if (grp != 0 || k4 >= K) return;
+    s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int mk = map[k4 + j];
         if (mk < 0) continue;
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += slabs[int64_t(sp) * total + i];
         const int64_t o = int64_t(n) * dst_row_stride + mk;
-        if (o < dst_elems) dst[o] = accumulate ? dst[o] + s : s;
+        if (o < dst_elems) dst[o] = accumulate ? dst[o] + s[j] : s[j];
     }
 }
 
-__global__ void pack_rows_kernel(const float* __restrict__ src, int64_t src_elems, int src_row_stride,
-                                 const int32_t* __restrict__ map, float* __restrict__ dst, int N, int K) {
-    const int64_t total = int64_t(N) * K;
-    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
-        const int n = int(i / K), k = int(i - int64_t(n) * K);
-        const int mk = map[k];
-        float v = 0.f;
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, int64_t src_elems, int src_row_stride,
+                                                        const int32_t* __restrict__ map, float* __restrict__ dst, int N, int K) {
+    const int k4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int n = blockIdx.y;
+    if (k4 >= K) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int mk = map[k4 + j];
         if (mk >= 0) {
             const int64_t o = int64_t(n) * src_row_stride + mk;
-            if (o < src_elems) v = src[o];
+            if (o < src_elems) v[j] = src[o];
         }
-        dst[i] = v;
     }
+    *reinterpret_cast<f32x4*>(dst + size_t(n) * K + k4) = v;
 }
 
 }  // namespace
@@ -70,11 +94,9 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->N > 64) {
-        static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_igemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess; }();
-        (void)once;
-        hipLaunchKernelGGL(wgrad_igemm_kernel<128>, dim3(p.ntiles_n * p.ntiles_k * p.nsplit), dim3(256), 65536, st, p);
+        hipLaunchKernelGGL(wgrad_igemm_kernel<128>, dim3(p.ntiles_n * p.ntiles_k * p.nsplit), dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL(wgrad_igemm_kernel<64>, dim3(p.ntiles_k * p.nsplit), dim3(256), 49152, st, p);
+        hipLaunchKernelGGL(wgrad_igemm_kernel<64>, dim3(p.ntiles_k * p.nsplit), dim3(256), 0, st, p);
     }
     return nirgan_check_launch("wgrad_igemm");
 }
@@ -90,30 +112,26 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
         rc = nirgan_conv_igemm(c, stream);
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
-    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess; }();
-    (void)once;
     const int conv_blocks = cp.mtiles * cp.ntiles;
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit;
-    hipLaunchKernelGGL(conv_wgrad_pair_kernel, dim3(conv_blocks + wgrad_blocks), dim3(256), 65536, static_cast<hipStream_t>(stream), cp, wp, conv_blocks);
+    hipLaunchKernelGGL(conv_wgrad_pair_kernel, dim3(conv_blocks + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cp, wp, conv_blocks);
     return nirgan_check_launch("conv_wgrad_pair");
 }
 
 extern "C" int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,
                                   float* dst, int64_t dst_elems, int dst_row_stride, int accumulate, void* stream) {
-    NG_REQUIRE(slabs && map && dst && nsplit >= 1 && N > 0 && K > 0, "reduce_rows: bad arguments");
-    const int64_t total = int64_t(N) * K;
-    const int grid = int((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+    NG_REQUIRE(slabs && map && dst && nsplit >= 1 && N > 0 && K > 0 && K % 4 == 0 && N <= 65535, "reduce_rows: bad arguments");
+    NG_REQUIRE(ng_aligned16(slabs), "reduce_rows: slabs must be 16-byte aligned");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((K + 255) / 256, N), dim3(256), 0, static_cast<hipStream_t>(stream),
                        slabs, nsplit, N, K, map, dst, dst_elems, dst_row_stride, accumulate);
     return nirgan_check_launch("reduce_rows");
 }
 
 extern "C" int nirgan_pack_rows(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,
                                 float* dst, int N, int K, void* stream) {
-    NG_REQUIRE(src && map && dst && N > 0 && K > 0, "pack_rows: bad arguments");
-    const int64_t total = int64_t(N) * K;
-    const int grid = int((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+    NG_REQUIRE(src && map && dst && N > 0 && K > 0 && K % 4 == 0 && N <= 65535, "pack_rows: bad arguments");
+    NG_REQUIRE(ng_aligned16(dst), "pack_rows: dst must be 16-byte aligned");
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((K + 1023) / 1024, N), dim3(256), 0, static_cast<hipStream_t>(stream),
                        src, src_elems, src_row_stride, map, dst, N, K);
     return nirgan_check_launch("pack_rows");
 }

@@ -106,6 +106,59 @@ __global__ void tap_dbias_kernel(const float* __restrict__ dout, const float* __
     if (threadIdx.x == 0) atomicAdd(dbias, part[0] + part[1] + part[2] + part[3]);
 }
 
+struct ChanDgradP {
+    const float* dy; int dy_row, dy_img, dy_pad, C, OH, OW;
+    const float* w; int cin, k, stride, pad, channel;
+    int B, H, W;
+    float* out;
+};
+
+// out[b][h][w] = sum_{kh,kw,co} dY[b][(h+p-kh)/s][(w+p-kw)/s][co] * W[co][c][kh][kw] over taps with integral indices.
+// 16 lanes (float4 each) cover the channels of one pixel, a wave handles 4 pixels; the k*k*C weights of the
+// selected input channel are staged once per block in LDS.
+__global__ __launch_bounds__(256) void chan_dgrad_kernel(const ChanDgradP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wsel = reinterpret_cast<float*>(smem_raw);        // [k*k][C]
+    const int kk = p.k * p.k;
+    for (int i = threadIdx.x; i < kk * p.C; i += 256) {
+        const int t = i / p.C, co = i - t * p.C;
+        wsel[i] = p.w[(size_t(co) * p.cin + p.channel) * kk + t];
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;          // 16 pixels per block iteration
+    const int64_t npix = int64_t(p.B) * p.H * p.W;
+    const int q4 = p.C / 4;
+    for (int64_t base = int64_t(blockIdx.x) * 16; base < npix; base += int64_t(gridDim.x) * 16) {
+        const int64_t pix = base + grp;
+        float acc = 0.f;
+        if (pix < npix) {
+            const int w = int(pix % p.W), h = int((pix / p.W) % p.H), b = int(pix / (int64_t(p.W) * p.H));
+            for (int kh = 0; kh < p.k; ++kh) {
+                const int nh = h + p.pad - kh;
+                if (nh % p.stride) continue;
+                const int oh = nh / p.stride;
+                if (nh < 0 || oh >= p.OH) continue;
+                for (int kw = 0; kw < p.k; ++kw) {
+                    const int nw = w + p.pad - kw;
+                    if (nw % p.stride) continue;
+                    const int ow = nw / p.stride;
+                    if (nw < 0 || ow >= p.OW) continue;
+                    const float* d = p.dy + size_t(b) * p.dy_img + size_t(oh + p.dy_pad) * p.dy_row + size_t(ow + p.dy_pad) * p.C;
+                    const float* ws = wsel + (kh * p.k + kw) * p.C;
+                    for (int q = sub; q < q4; q += 16) {
+                        const f32x4 dv = *reinterpret_cast<const f32x4*>(d + q * 4);
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + q * 4);
+                        acc += dv[0] * wv[0] + dv[1] * wv[1] + dv[2] * wv[2] + dv[3] * wv[3];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (sub == 0 && pix < npix) p.out[pix] = acc;
+    }
+}
+
 inline int grid_for(int64_t total) {
     const int64_t g = (total + 255) / 256;
     return int(g < 8192 ? (g < 1 ? 1 : g) : 8192);
@@ -165,4 +218,24 @@ extern "C" int nirgan_tap_scatter(const nirgan_tap_scatter_desc* d, void* stream
         hipLaunchKernelGGL(tap_dbias_kernel, dim3(g), dim3(256), 0, st, d->dout, d->out, d->act, n, d->dbias);
     }
     return nirgan_check_launch("tap_scatter");
+}
+
+extern "C" int nirgan_conv_channel_dgrad(const nirgan_chan_dgrad_desc* d, void* stream) {
+    NG_REQUIRE(d && d->dy && d->w && d->out, "conv_channel_dgrad: null pointer");
+    NG_REQUIRE(d->C >= 4 && d->C % 4 == 0 && d->k >= 1 && d->k <= 7 && d->stride >= 1 && d->pad >= 0, "conv_channel_dgrad: bad layer");
+    NG_REQUIRE(d->channel >= 0 && d->channel < d->cin && d->B > 0 && d->H > 0 && d->W > 0 && d->dy_pad >= 0, "conv_channel_dgrad: bad shape");
+    NG_REQUIRE(ng_aligned16(d->dy), "conv_channel_dgrad: dy must be 16-byte aligned");
+    const int OH = (d->H + 2 * d->pad - d->k) / d->stride + 1, OW = (d->W + 2 * d->pad - d->k) / d->stride + 1;
+    NG_REQUIRE(d->dy_hp == OH + 2 * d->dy_pad && d->dy_wp == OW + 2 * d->dy_pad, "conv_channel_dgrad: dY geometry mismatch");
+    const size_t lds = size_t(d->k) * d->k * d->C * 4;
+    NG_REQUIRE(lds <= 65536, "conv_channel_dgrad: weights do not fit LDS");
+    ChanDgradP p;
+    p.dy = d->dy; p.C = d->C; p.dy_row = d->dy_wp * d->C; p.dy_img = d->dy_hp * p.dy_row; p.dy_pad = d->dy_pad; p.OH = OH; p.OW = OW;
+    p.w = d->w; p.cin = d->cin; p.k = d->k; p.stride = d->stride; p.pad = d->pad; p.channel = d->channel;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.out = d->out;
+    const int64_t npix = int64_t(d->B) * d->H * d->W;
+    int64_t g = (npix + 15) / 16;
+    g = g < 4096 ? g : 4096;
+    hipLaunchKernelGGL(chan_dgrad_kernel, dim3(int(g)), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("conv_channel_dgrad");
 }

@@ -58,6 +58,12 @@ class InBwdDesc(C.Structure):
                 ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64)]
 
 
+class ChanDgradDesc(C.Structure):
+    _fields_ = [("dy", fp), ("dy_hp", i32), ("dy_wp", i32), ("dy_pad", i32), ("C", i32),
+                ("w", fp), ("cin", i32), ("k", i32), ("stride", i32), ("pad", i32), ("channel", i32),
+                ("B", i32), ("H", i32), ("W", i32), ("out", fp)]
+
+
 class TapGatherDesc(C.Structure):
     _fields_ = [("q", fp), ("q_hp", i32), ("q_wp", i32), ("q_cs", i32), ("ntaps", i32),
                 ("tap_dh", i32 * 64), ("tap_dw", i32 * 64), ("bias", fp), ("act", i32),
@@ -106,6 +112,7 @@ PROTOTYPES = {
     "nirgan_instnorm_fwd": (i32, [C.POINTER(InFwdDesc), fp]),
     "nirgan_instnorm_bwd": (i32, [C.POINTER(InBwdDesc), fp]),
     "nirgan_nchw_to_halo": (i32, [fp, i32, i32, i32, i32, fp, i32, i32, i32, i32, i32, fp]),
+    "nirgan_conv_channel_dgrad": (i32, [C.POINTER(ChanDgradDesc), fp]),
     "nirgan_tap_gather": (i32, [C.POINTER(TapGatherDesc), fp]),
     "nirgan_tap_scatter": (i32, [C.POINTER(TapScatterDesc), fp]),
     "nirgan_lsgan": (i32, [fp, i64, f32, f32, fp, fp, fp]),

@@ -188,11 +188,10 @@ class GeneratorEngine(_Engine):
             layer.alloc_bwd(need_dgrad=False)
         for layer in [self.L2, self.L3, self.U1, self.U2] + [c for _, c1, c2 in self.blocks for c in (c1, c2)]:
             layer.alloc_bwd(need_dgrad=True)
-        # bias gradients are accumulated with atomics: zero them first
-        bias_keys = [k for k in gr if k.endswith(".bias") and k.startswith("model.")]
-        for k in bias_keys:
-            b.add("nirgan_fill", gr[k].data_ptr(), gr[k].numel(), 0.0)
+        # the only live generator bias (last conv) is accumulated with atomics: zero it first.  Biases in front
+        # of an InstanceNorm have gradient exactly 0 and are never written (their flat-gradient slots stay 0).
         il = lay["last"]
+        b.add("nirgan_fill", GW(il, "bias").data_ptr(), 1, 0.0)
         self.last.emit_bwd(b, pk, GW(il), GW(il, "bias"))
         i0, i1 = lay["up"]
         g_u1 = Halo(ctx, B, self.U1.OH, self.U1.OW, self.U1.cout, 0)
@@ -287,19 +286,30 @@ class DiscriminatorEngine(_Engine):
         self.g2 = Halo(ctx, B, self.C2.OH, self.C2.OW, self.C2.cout, 0)
         self.g1 = Halo(ctx, B, self.C1.OH, self.C1.OW, self.C1.cout, 0)
         self.gx4 = Halo(ctx, B, self.H, self.W, 4, 0)
-        self.bwd_frozen = Plan(ctx)       # data-gradient only (generator step: D's parameters are frozen)
-        for plan, frozen in ((b, False), (self.bwd_frozen, True)):
+        self.gpred = ctx.zeros(B, self.H, self.W)
+        self.bwd_frozen = Plan(ctx)       # parameters frozen: gradient wrt the whole 4-channel input (autograd bridge)
+        self.bwd_pred = Plan(ctx)         # parameters frozen: gradient wrt channel 3 (pred) only (fused generator step)
+        for plan, mode in ((b, "train"), (self.bwd_frozen, "input"), (self.bwd_pred, "pred")):
+            frozen = mode != "train"
+
             def GW(i, what="weight"):
                 return None if frozen else gr[f"model.{i}.{what}"]
-            if not frozen:
-                for k in gr:
-                    if k.endswith(".bias"):
-                        plan.add("nirgan_fill", gr[k].data_ptr(), gr[k].numel(), 0.0)
+            if not frozen:   # live biases (first and last conv) accumulate with atomics
+                for k in ("model.0.bias", "model.11.bias"):
+                    plan.add("nirgan_fill", gr[k].data_ptr(), gr[k].numel(), 0.0)
             self.C5.emit_bwd(plan, pk, GW(11), GW(11, "bias"))
             self.C4.emit_bwd(plan, pk, g=self.C5.gin, g_fold=False, gw=GW(8), gb=GW(8, "bias"), dgrad_out=self.g3p)
             self.C3.emit_bwd(plan, pk, g=self.g3p, g_fold=False, gw=GW(5), gb=GW(5, "bias"), dgrad_out=self.g2)
             self.C2.emit_bwd(plan, pk, g=self.g2, gw=GW(2), gb=GW(2, "bias"), dgrad_out=self.g1)
-            self.C1.emit_bwd(plan, pk, g=self.g1, gw=GW(0), gb=GW(0, "bias"), dgrad_out=self.gx4 if frozen else None)
+            self.C1.emit_bwd(plan, pk, g=self.g1, gw=GW(0), gb=GW(0, "bias"), dgrad_out=self.gx4 if mode == "input" else None)
+            if mode == "pred":
+                d = L.ChanDgradDesc()
+                dy, w = self.C1.dy, self.params["model.0.weight"]
+                d.dy, d.dy_hp, d.dy_wp, d.dy_pad, d.C = dy.ptr, dy.hp, dy.wp, dy.pad, dy.C
+                d.w, d.cin, d.k, d.stride, d.pad, d.channel = w.data_ptr(), 4, 4, 2, 1, 3
+                d.B, d.H, d.W, d.out = B, self.H, self.W, self.gpred.data_ptr()
+                ctx.keep.append(d)
+                plan.add("nirgan_conv_channel_dgrad", C.byref(d))
 
     def input_plan(self, parts) -> Plan:
         """parts: list of (NCHW tensor [nb, Cs, H, W], b0, c0) written straight into the halo'd input
@@ -325,9 +335,17 @@ class DiscriminatorEngine(_Engine):
         self.fwd.run()
         return self.out
 
-    def backward(self, dout: Optional[torch.Tensor], frozen: bool = False, version: int = 0) -> Optional[torch.Tensor]:
+    def backward(self, dout: Optional[torch.Tensor], frozen: bool = False, version: int = 0, pred_only: bool = False) -> Optional[torch.Tensor]:
+        """frozen=False: parameter gradients.  frozen=True: gradient wrt the input ([B][H][W][4]), or wrt its
+        channel 3 only ([B][H][W]) when pred_only."""
         self.refresh_weights(version, backward=True)
         if dout is not None:
             self.dout.copy_(dout)
-        (self.bwd_frozen if frozen else self.bwd).run()
-        return self.gx4.t if frozen else None
+        if not frozen:
+            self.bwd.run()
+            return None
+        if pred_only:
+            self.bwd_pred.run()
+            return self.gpred
+        self.bwd_frozen.run()
+        return self.gx4.t

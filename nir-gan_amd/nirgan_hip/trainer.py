@@ -70,7 +70,7 @@ class Pix2PixTrainer:
             w = float(self.rs_weights.get("lambda_" + k, 0.0)) if self.lambda_rs > 0.0 else 0.0
             setattr(d, "w_" + k, self.lambda_rs * w if w > 0.0 else 0.0)
         d.criterion, d.log_all = self.rs_criterion, 0
-        d.extra, d.extra_cs, d.extra_c, d.extra_scale = self.D1.gx4.ptr, 4, 3, 1.0
+        d.extra, d.extra_cs, d.extra_c, d.extra_scale = self.D1.gpred.data_ptr(), 1, 0, 1.0
         d.sums, d.grad_pred = self.losses.data_ptr() + 3 * 4, self.G.dpred.data_ptr()
         self._pix = d
 
@@ -100,7 +100,7 @@ class Pix2PixTrainer:
         # ---- optimizer 1: generator against the updated, frozen discriminator
         D1.forward(parts=[(self.rgb, 0, 0), (pred, 0, 3)], version=self.flatD.version)
         L.check(be.nirgan_lsgan(D1.out.data_ptr(), npatch, 1.0, self.lambda_gan, lp + 8, D1.dout.data_ptr(), st), "lsgan")
-        D1.backward(None, frozen=True, version=self.flatD.version)
+        D1.backward(None, frozen=True, version=self.flatD.version, pred_only=True)
         L.check(be.nirgan_pix_loss(C.byref(self._pix), st), "pix_loss")
         G.backward(None, version=self.flatG.version)
         if self.reducer is not None:

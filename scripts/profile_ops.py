@@ -21,7 +21,7 @@ rgb = (0.02 + 0.58 * torch.rand(bs, 3, 256, 256, generator=g)).to(dev)
 nir = (0.05 + 0.75 * torch.rand(bs, 1, 256, 256, generator=g)).to(dev)
 for _ in range(3):
     tr.step(rgb, nir)
-plans = {"G.fwd": tr.G.fwd, "G.bwd": tr.G.bwd, "D2.fwd": tr.D2.fwd, "D2.bwd": tr.D2.bwd, "D1.fwd": tr.D1.fwd, "D1.bwdF": tr.D1.bwd_frozen,
+plans = {"G.fwd": tr.G.fwd, "G.bwd": tr.G.bwd, "D2.fwd": tr.D2.fwd, "D2.bwd": tr.D2.bwd, "D1.fwd": tr.D1.fwd, "D1.bwdP": tr.D1.bwd_pred,
          "G.pack": tr.G.pack_fwd, "G.packb": tr.G.pack_bwd}
 
 

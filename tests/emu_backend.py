@@ -272,6 +272,22 @@ class EmuBackend:
             o[:, P:P + H, P:P + W, c0:c0 + Cs] = s.transpose(0, 2, 3, 1)
         return 0
 
+    def nirgan_conv_channel_dgrad(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("chan_dgrad")
+        OH, OW = (d.H + 2 * d.pad - d.k) // d.stride + 1, (d.W + 2 * d.pad - d.k) // d.stride + 1
+        if d.dy_hp != OH + 2 * d.dy_pad or d.dy_wp != OW + 2 * d.dy_pad:
+            return self._fail("chan_dgrad: geometry")
+        dy = arr(d.dy, d.B * d.dy_hp * d.dy_wp * d.C).reshape(d.B, d.dy_hp, d.dy_wp, d.C)
+        dy = dy[:, d.dy_pad:d.dy_pad + OH, d.dy_pad:d.dy_pad + OW].transpose(0, 3, 1, 2)
+        w = arr(d.w, d.C * d.cin * d.k * d.k).reshape(d.C, d.cin, d.k, d.k)[:, d.channel:d.channel + 1]
+        x = torch.zeros(d.B, 1, d.H, d.W, requires_grad=True)
+        with torch.enable_grad():
+            y = F.conv2d(x, torch.from_numpy(w.copy()), stride=d.stride, padding=d.pad)
+            y.backward(torch.from_numpy(np.ascontiguousarray(dy)))
+        arr(d.out, d.B * d.H * d.W)[:] = x.grad.reshape(-1).numpy()
+        return 0
+
     def nirgan_tap_gather(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("tap_gather")

@@ -299,3 +299,25 @@ def test_bilinear_and_inject_match_torch():
     gds = torch.zeros(B, S, S, device=DEV)
     L.call("nirgan_bilinear_bwd", dd.to(DEV).data_ptr(), B, O_, O_, gds.data_ptr(), S, S, st)
     close(gds, s2.grad[:, 0], 1e-5, "bilinear bwd")
+
+
+def test_channel_dgrad_matches_torch():
+    """dD/dpred only: data gradient of Conv2d(4, 64, 4, stride 2, padding 1) wrt input channel 3."""
+    gen = torch.Generator().manual_seed(13)
+    B, H, W, Cout = 2, 20, 24, 64
+    OH, OW = H // 2, W // 2
+    w = torch.randn(Cout, 4, 4, 4, generator=gen) * 0.1
+    dy = torch.randn(B, Cout, OH, OW, generator=gen)
+    x = torch.zeros(B, 4, H, W, requires_grad=True)
+    torch.nn.functional.conv2d(x, w, stride=2, padding=1).backward(dy)
+    ctx = Ctx(DEV)
+    z = Halo(ctx, B, OH, OW, Cout, 1)
+    z.interior().copy_(dy.permute(0, 2, 3, 1).to(DEV))
+    wg = w.to(DEV)
+    out = ctx.zeros(B, H, W)
+    d = L.ChanDgradDesc()
+    d.dy, d.dy_hp, d.dy_wp, d.dy_pad, d.C = z.ptr, z.hp, z.wp, 1, Cout
+    d.w, d.cin, d.k, d.stride, d.pad, d.channel = wg.data_ptr(), 4, 4, 2, 1, 3
+    d.B, d.H, d.W, d.out = B, H, W, out.data_ptr()
+    L.call("nirgan_conv_channel_dgrad", C.byref(d), torch.cuda.current_stream().cuda_stream)
+    close(out, x.grad[:, 3], 1e-5, "channel dgrad")
