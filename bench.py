@@ -186,6 +186,17 @@ def main():
                               "launches_per_step": nlaunch, "avg_launch_ms": round(avg_ms, 5),
                               "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
                               "share_of_step_time": round(avg_ms * nlaunch / ms, 3)})
+            # HBM traffic per launch from the PMC passes recorded under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+            # corrected as MI355X_MICROARCH.md prescribes); only valid for the workload it was measured on
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            except Exception:
+                pmc = {}
+            for r in roofs:
+                ent = pmc.get(r["kernel"])
+                if ent and a.bs == 16 and a.size == 256 and a.blocks == 6 and a.padding == 0:
+                    r["traffic"] = ent["hbm_bytes_per_launch_corrected"]
+                    r["traffic_unit"] = "bytes/launch (PMC, res-block layer)"
             roofs.sort(key=lambda r: -r["share_of_step_time"])
             roof = roofs[0] if roofs else None
             roof_other = roofs[1:] or None
