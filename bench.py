@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=6)
     ap.add_argument("--padding", type=int, default=0, help="Data.padding_amount (YAML default 10); 0 = BASELINE.md headline case")
     ap.add_argument("--lambda-rs", type=float, default=0.0)
+    ap.add_argument("--inject", action="store_true", help="SatCLIP-inject generator (configs[3]): 9 blocks, fc 256->128x128, multiply")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     a = ap.parse_args()
@@ -132,11 +133,28 @@ def main():
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
     torch.manual_seed(0)
-    netG = networks.define_G(3, 1, 64, f"resnet_{a.blocks}blocks", "instance", False, "normal", 0.02).to(dev)
+    inject, embeds = None, None
+    if a.inject:
+        import types
+        from model.generator_inject import define_G_inject
+        ns = types.SimpleNamespace
+        a.blocks = 9
+        cfg = ns(base_configs=ns(input_nc=3, output_nc=1, ngf=64, netG="resnet_9blocks", norm="instance", no_dropout=True,
+                                 init_type="normal", init_gain=0.02),
+                 satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
+                            scaling_param=True, scaling_param_init=0.01))
+        netG = define_G_inject(cfg).to(dev)
+        inject = {"style": "multiply", "use_scale": True}
+        embeds = torch.randn(a.bs, 256, generator=torch.Generator().manual_seed(99 + rank)).to(dev)
+    else:
+        netG = networks.define_G(3, 1, 64, f"resnet_{a.blocks}blocks", "instance", False, "normal", 0.02).to(dev)
     netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)
     rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333}
-    tr = Pix2PixTrainer(netG, netD, n_blocks=a.blocks, padding=a.padding, lambda_rs=a.lambda_rs, rs_weights=rs_w, reducer=reducer)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=a.blocks, padding=a.padding, lambda_rs=a.lambda_rs, rs_weights=rs_w,
+                        inject=inject, reducer=reducer)
     rgb, nir = synth(a.bs, a.size, a.size, 1234 + rank, dev)
+    _step = tr.step
+    tr.step = lambda r, n: _step(r, n, embeds)
 
     for _ in range(max(a.warmup, 1)):
         tr.step(rgb, nir)
@@ -206,7 +224,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"configs[1]: {a.blocks}-block ResnetGenerator + 3-layer PatchGAN, bs={a.bs}/GPU, "
                                       f"{a.size}x{a.size}, GAN+L1" + (f"+RS(l={a.lambda_rs})" if a.lambda_rs else "")
-                                      + f", padding={a.padding}, fp32 MFMA",
+                                      + (", SatCLIP inject" if a.inject else "") + f", padding={a.padding}, fp32 MFMA",
                           "global_batch": a.bs * world, "parallelism": f"dp{world}"},
                "roofline": roof}
         if roof_other:

@@ -45,13 +45,14 @@ class ResnetGenerator_inject(_HipNet):
         self.model = nn.Sequential(*model)
 
     def _make_engine(self, key):
-        B, H, W, pad = key
+        B, H, W, pad, need_bwd = key
         f = self._flat()
         cfg = {"style": self.inject_style, "use_scale": bool(self.scaling_param), "post_correction": bool(self.post_correction)}
-        return GeneratorEngine(f.param_views(), f.grad_views(), self.n_blocks, B, H, W, data_pad=pad, inject=cfg)
+        return GeneratorEngine(f.param_views(), f.grad_views(), self.n_blocks, B, H, W, data_pad=pad, inject=cfg,
+                               need_backward=need_bwd)
 
     def forward(self, input, embeds):
-        return HF.GeneratorFn.apply(self, input, embeds, *self.parameters())
+        return HF.GeneratorFn.apply(self, torch.is_grad_enabled(), input, embeds, *self.parameters())
 
 
 def define_G_inject(config):

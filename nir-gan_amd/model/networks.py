@@ -187,12 +187,12 @@ class ResnetGenerator(_HipNet):
         self.model = nn.Sequential(*_resnet_sequence(input_nc, output_nc, ngf, norm_layer, use_dropout, n_blocks, padding_type))
 
     def _make_engine(self, key):
-        B, H, W, pad = key
+        B, H, W, pad, need_bwd = key
         f = self._flat()
-        return GeneratorEngine(f.param_views(), f.grad_views(), self.n_blocks, B, H, W, data_pad=pad)
+        return GeneratorEngine(f.param_views(), f.grad_views(), self.n_blocks, B, H, W, data_pad=pad, need_backward=need_bwd)
 
     def forward(self, input):
-        return HF.GeneratorFn.apply(self, input, None, *self.parameters())
+        return HF.GeneratorFn.apply(self, torch.is_grad_enabled(), input, None, *self.parameters())
 
 
 class NLayerDiscriminator(_HipNet):
@@ -219,12 +219,12 @@ class NLayerDiscriminator(_HipNet):
         self.model = nn.Sequential(*sequence)
 
     def _make_engine(self, key):
-        B, H, W = key
+        B, H, W, need_bwd = key
         f = self._flat()
-        return DiscriminatorEngine(f.param_views(), f.grad_views(), B, H, W)
+        return DiscriminatorEngine(f.param_views(), f.grad_views(), B, H, W, need_backward=need_bwd)
 
     def forward(self, input):
-        return HF.DiscriminatorFn.apply(self, input, *self.parameters())
+        return HF.DiscriminatorFn.apply(self, torch.is_grad_enabled(), input, *self.parameters())
 
 
 def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02, gpu_ids=[]):

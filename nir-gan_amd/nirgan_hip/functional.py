@@ -58,11 +58,12 @@ class EnginePool:
 
 class GeneratorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, rgb, embeds, *params):
+    def forward(ctx, net, grad_mode, rgb, embeds, *params):
         _require_device(rgb, "generator")
         B, _, H, W = rgb.shape
-        need_bwd = any(ctx.needs_input_grad[3:])
-        lease = net._pool().lease((B, H, W, net.data_pad))
+        need_bwd = grad_mode and any(ctx.needs_input_grad[4:])
+        # inference (no_grad / frozen generator): a forward-only engine without backward buffers
+        lease = net._pool().lease((B, H, W, net.data_pad, need_bwd))
         eng = lease.eng
         ver = net._flat().values_version()
         pred = eng.forward(rgb.detach().contiguous().float(), None if embeds is None else embeds.detach().contiguous().float(), version=ver)
@@ -82,17 +83,17 @@ class GeneratorFn(torch.autograd.Function):
         g = flat.grad.clone()
         grads = tuple(g[o:o + k].view(s) for (o, k, s) in (flat.slices[n] for n in flat.names))
         lease.release()
-        return (None, None, None) + grads
+        return (None, None, None, None) + grads
 
 
 class DiscriminatorFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, x, *params):
+    def forward(ctx, net, grad_mode, x, *params):
         _require_device(x, "discriminator")
         B, _, H, W = x.shape
-        need_w = any(ctx.needs_input_grad[2:])
-        need_x = ctx.needs_input_grad[1]
-        lease = net._pool().lease((B, H, W))
+        need_w = grad_mode and any(ctx.needs_input_grad[3:])
+        need_x = grad_mode and ctx.needs_input_grad[2]
+        lease = net._pool().lease((B, H, W, need_w or need_x))
         eng = lease.eng
         ver = net._flat().values_version()
         out = eng.forward(x.detach().contiguous().float(), version=ver).clone()
@@ -118,7 +119,7 @@ class DiscriminatorFn(torch.autograd.Function):
             gx4 = eng.backward(dout, frozen=True, version=ctx.ver)
             gx = gx4.permute(0, 3, 1, 2).contiguous()
         lease.release()
-        return (None, gx) + grads
+        return (None, None, gx) + grads
 
 
 class LsganFn(torch.autograd.Function):

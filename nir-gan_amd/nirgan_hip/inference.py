@@ -1,0 +1,42 @@
+"""Inference helpers around the generator forward.
+
+The reference's create_synthetic_dataset.py (:100-118) runs ``model(hr)`` under no_grad on whole tiles,
+then post-processes on the CPU and stores fp16 ``.npz`` files (:49-52, :117).  ``predict_tiled`` adds
+what large scenes need on the GPU side: the scene is cut into tiles that overlap by twice the model's
+reflect padding trick (model/pix2pix.py:91-93,107-108 hides tile-edge artefacts with pad-10 / crop); the
+overlap is discarded, so every output pixel comes from a tile interior.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+
+@torch.no_grad()
+def predict_tiled(model, rgb: torch.Tensor, tile: int = 512, margin: int = 16, batch: int = 8, embeds=None) -> torch.Tensor:
+    """rgb: B x 3 x H x W (any H, W >= 4) -> B x 1 x H x W.  ``tile`` is the network input size (multiple of 4);
+    ``margin`` pixels on every side of a tile are context only."""
+    assert tile % 4 == 0 and 0 <= margin < tile // 2
+    B, _, H, W = rgb.shape
+    core = tile - 2 * margin
+    ph, pw = (-H) % core, (-W) % core
+    x = torch.nn.functional.pad(rgb, (margin, margin + pw, margin, margin + ph), mode="reflect")
+    out = torch.empty(B, 1, H + ph, W + pw, dtype=rgb.dtype, device=rgb.device)
+    coords = [(b, i, j) for b in range(B) for i in range(0, H + ph, core) for j in range(0, W + pw, core)]
+    for k in range(0, len(coords), batch):
+        chunk = coords[k:k + batch]
+        tiles = torch.stack([x[b, :, i:i + tile, j:j + tile] for b, i, j in chunk])
+        e = None if embeds is None else torch.stack([embeds[b] for b, _, _ in chunk])
+        pred = model(tiles) if e is None else model(tiles, e)
+        for (b, i, j), p in zip(chunk, pred):
+            out[b, :, i:i + core, j:j + core] = p[:, margin:margin + core, margin:margin + core]
+    return out[:, :, :H, :W]
+
+
+def save_nir_npz(pred_nir: torch.Tensor, out_path: str, name: str) -> str:
+    """fp16 compressed .npz with key 'nir', as create_synthetic_dataset.py:49-52,115-118 writes it."""
+    fn = os.path.join(out_path, f"{name}")
+    np.savez_compressed(fn, nir=pred_nir.detach().to(torch.float16).cpu().numpy())
+    return fn if fn.endswith(".npz") else fn + ".npz"

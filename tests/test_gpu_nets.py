@@ -263,3 +263,64 @@ def test_batch16_properties():
     # gradient of the batch mean = mean of per-half gradients (what the RCCL all-reduce relies on)
     g_full = tr.flatG.grad.clone()
     assert torch.isfinite(g_full).all()
+
+
+def test_data_parallel_equivalence_on_device():
+    """What the RCCL all-reduce relies on: mean of the per-shard gradients == gradient of the whole batch
+    (InstanceNorm is per sample, losses are means).  Two shards of 2 tiles vs one batch of 4, 6-block ngf 64, 128x128."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    rgb, nir = synth(4, 128, 128, 11)
+    grads = []
+    for shard in (slice(0, 4), slice(0, 2), slice(2, 4)):
+        torch.manual_seed(0)
+        netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
+        netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+        tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0)        # lr 0: D stays put, so the G gradients are comparable too
+        tr.step(rgb[shard].to(DEV), nir[shard].to(DEV))
+        grads.append((tr.flatD.grad.clone(), tr.flatG.grad.clone()))
+    (gD, gG), (gD0, gG0), (gD1, gG1) = grads
+    for full, a, b, name in ((gD, gD0, gD1, "D"), (gG, gG0, gG1, "G")):
+        mean = 0.5 * (a + b)
+        err = (mean - full).norm().item() / full.norm().item()
+        assert err < 1e-4, (name, err)
+
+
+def test_training_is_stable_over_many_steps():
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    torch.manual_seed(0)
+    netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
+    netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6)
+    rgb, nir = synth(2, 128, 128, 5)
+    rgb, nir = rgb.to(DEV), nir.to(DEV)
+    first = tr.step(rgb, nir).as_dict()
+    for _ in range(40):
+        last = tr.step(rgb, nir)
+    last = last.as_dict()
+    assert all(np.isfinite(v) for v in last.values()), last
+    assert last["loss_G_l1"] < 0.7 * first["loss_G_l1"], (first, last)      # overfits a fixed batch
+    assert all(torch.isfinite(p).all() for p in list(netG.parameters()) + list(netD.parameters()))
+
+
+def test_inference_engines_and_tiling():
+    """no_grad forward uses forward-only engines (create_synthetic_dataset.py:106-107) and equals the training-mode output."""
+    from model import networks
+    from nirgan_hip.inference import predict_tiled
+    torch.manual_seed(0)
+    netG = networks.define_G(3, 1, 64, "resnet_9blocks", "instance", False, "normal", 0.02).to(DEV)
+    rgb, _ = synth(2, 256, 256, 3)
+    rgb = rgb.to(DEV)
+    netG.data_pad = 10
+    with torch.no_grad():
+        p0 = netG(rgb)
+    p1 = netG(rgb)
+    assert p1.requires_grad and not p0.requires_grad
+    assert torch.equal(p0, p1.detach())
+    engines = [e for lst in netG._pool().free.values() for e in lst]
+    assert any(len(e.bwd.ops) == 0 for e in engines)
+    netG.data_pad = 0
+    big = torch.cat([rgb, rgb.flip(-1)], -1)[:, :, :200, :300]
+    out = predict_tiled(netG, big, tile=128, margin=16)
+    assert out.shape == (2, 1, 200, 300) and torch.isfinite(out).all()
