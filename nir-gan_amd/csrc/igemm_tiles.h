@@ -4,6 +4,35 @@
 #pragma once
 #include "common.h"
 
+// In-kernel stamps for the diagnostic build only (scripts/diag/conv_stamp.hip defines NG_DIAG); no stamp
+// executes in the product build.
+#ifdef NG_DIAG
+__device__ __forceinline__ unsigned long long ng_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define NG_DIAG_DECL unsigned long long ng_t0 = ng_stamp(), ng_a = ng_t0, ng_wait = 0, ng_body = 0, ng_b = 0;
+#define NG_WAIT_BEGIN ng_a = ng_stamp();
+#define NG_WAIT_END ng_b = ng_stamp(); ng_wait += ng_b - ng_a; ng_a = ng_b;
+#define NG_BODY_END ng_b = ng_stamp(); ng_body += ng_b - ng_a; ng_a = ng_b;
+#define NG_DIAG_STORE(dbg, blk)                                                                          \
+    if ((threadIdx.x & 63) == 0 && (dbg) != nullptr) {                                                     \
+        unsigned long long* o = (dbg) + (size_t(blk) * 4 + (threadIdx.x >> 6)) * 6;                         \
+        const unsigned long long te = ng_stamp();                                                           \
+        o[0] = ng_t0; o[1] = ng_loop_end; o[2] = te; o[3] = ng_wait; o[4] = ng_body;                        \
+        o[5] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                                        \
+    }
+#else
+#define NG_DIAG_DECL
+#define NG_WAIT_BEGIN
+#define NG_WAIT_END
+#define NG_BODY_END
+#define NG_DIAG_STORE(dbg, blk)
+#endif
+
 namespace ng {
 
 struct ConvParams {
@@ -19,6 +48,7 @@ struct ConvParams {
     int out_cs, out_row, out_img, out_stride, out_org;
     int OW, OHW, M, N;
     int mtiles, ntiles;
+    unsigned long long* dbg;   // diagnostic build only
 };
 
 
@@ -157,21 +187,28 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         cc += 32;
         if (cc >= p.run) { cc = 0; ++tt; }
     };
+    NG_DIAG_DECL
     issue(st0, 0, 0);
     int s = 0;
     for (; s + 2 < nk; s += 2) {
         next(t, c0);
+        NG_WAIT_BEGIN
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        NG_WAIT_END
         issue(st1, t, c0);
         compute(st0);
         hints();
+        NG_BODY_END
         next(t, c0);
+        NG_WAIT_BEGIN
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        NG_WAIT_END
         issue(st0, t, c0);
         compute(st1);
         hints();
+        NG_BODY_END
     }
     // tail: one or two steps left, stage parity is even at s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -187,34 +224,66 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         compute(st0);
     }
 
-    // ---------------- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // One pixel decomposition per 32-row MFMA tile; the 16 rows of a lane are reached by small increments
-    // (no per-row integer division).
+#ifdef NG_DIAG
+    const unsigned long long ng_loop_end = ng_stamp();
+#endif
+    // ---------------- epilogue: the accumulators go through LDS (the two stage buffers are free now: rows 0-63
+    // of the tile in st0, rows 64-127 in st1) so that every output pixel row is written with 16 bytes per lane in
+    // whole 128-B lines.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    __syncthreads();                                   // all fragment reads of the last step are done
+    {
+        float* half_base = reinterpret_cast<float*>(wr == 0 ? st0 : st1);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int mbase = m0 + wr * 64 + mt * 32 + 4 * half;
-        int mb_c = mbase < p.M ? mbase : p.M - 1;
-        const int b0 = mb_c / p.OHW, r0 = mb_c - b0 * p.OHW;
-        const int oh0 = r0 / p.OW, ow0 = r0 - oh0 * p.OW;
-        const int OH = p.OHW / p.OW;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int delta = (r & 3) + 8 * (r >> 2);
-            const int m = mbase + delta;
-            int b = b0, oh = oh0, ow = ow0 + delta;
-            while (ow >= p.OW) { ow -= p.OW; ++oh; }
-            while (oh >= OH) { oh -= OH; ++b; }
-            const int off = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org;
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int col = n0 + wc * (BN / 2) + nt * 32 + (lane & 31);
-                if (m < p.M && col < p.N) {
-                    const float bv = p.bias != nullptr ? p.bias[col] : 0.f;
-                    p.out[off + col] = acc[mt][nt][r] + bv;
+                const int col = wc * (BN / 2) + nt * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row_l = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    half_base[row_l * BN + col] = acc[mt][nt][r];
                 }
             }
+    }
+    __syncthreads();
+    {
+        constexpr int LPR = BN / 4;            // lanes per output row (float4 each)
+        constexpr int RPP = 256 / LPR;         // rows per pass
+        const int chunk = tid % LPR, row0 = tid / LPR;
+        const int n = n0 + chunk * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = n + j < p.N ? p.bias[n + j] : 0.f;
+        }
+        int m = m0 + row0;
+        const int mc = m < p.M ? m : p.M - 1;
+        int b = mc / p.OHW;
+        const int r0 = mc - b * p.OHW;
+        int oh = r0 / p.OW, ow = r0 - oh * p.OW;
+        const int OH = p.OHW / p.OW;
+#pragma unroll 4
+        for (int row = row0; row < BM; row += RPP) {
+            if (m < p.M && n < p.N) {
+                const float* src = reinterpret_cast<const float*>(row < 64 ? st0 : st1) + (row & 63) * BN + chunk * 4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                v += bv;
+                float* dst = p.out + (b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n);
+                if (n + 4 <= p.N) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.N) dst[j] = v[j];
+                }
+            }
+            m += RPP;
+            ow += RPP;
+            while (ow >= p.OW) { ow -= p.OW; ++oh; }
+            while (oh >= OH) { oh -= OH; ++b; }
         }
     }
+    NG_DIAG_STORE(p.dbg, block_id)
 }
 
 struct WgradParams {
@@ -398,33 +467,46 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
         }
     }
 
-    // ---------------- store the partial tile: row i = (r&3)+8*(r>>2)+4*half, col = lane&31
-    const int jj = j0 + wc * 64 + 2 * (lane & 31);
-    if (jj < p.K) {
-        float* slab = p.slabs + size_t(split) * p.N * p.K;
+    // ---------------- store the partial tile through LDS (rows = n, 128 columns J): whole 512-B slab rows,
+    // 16 bytes per lane.  Accumulator layout: row i = (r&3)+8*(r>>2)+4*half -> n = base + EA*i + e, col = lane&31.
+    __syncthreads();
+    {
+        float* half_base = reinterpret_cast<float*>(wr == 0 ? st0 : st1);
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
+        for (int e = 0; e < EA; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int n = n0 + wr * (TN / 2) + EA * i + e;
+                f32x2 v;
+                v[0] = acc[e][0][r];
+                v[1] = acc[e][1][r];
+                *reinterpret_cast<f32x2*>(half_base + (EA * i + e) * 128 + wc * 64 + 2 * (lane & 31)) = v;
+            }
+    }
+    __syncthreads();
+    {
+        float* slab = p.slabs + size_t(split) * p.N * p.K;
+        const int chunk = tid & 31, row0 = tid >> 5;
+        const int jj = j0 + chunk * 4;
+        if (jj < p.K) {
+#pragma unroll 4
+            for (int row = row0; row < TN; row += 8) {
+                const int n = n0 + row;
                 if (n < p.N) {
-                    f32x2 v;
-                    v[0] = acc[e][0][r];
-                    v[1] = acc[e][1][r];
-                    *reinterpret_cast<f32x2*>(slab + size_t(n) * p.K + jj) = v;
+                    const float* src = reinterpret_cast<const float*>(row < TN / 2 ? st0 : st1) + (row % (TN / 2)) * 128 + chunk * 4;
+                    *reinterpret_cast<f32x4*>(slab + size_t(n) * p.K + jj) = *reinterpret_cast<const f32x4*>(src);
                 }
             }
         }
     }
 }
 
-
 // ---------------------------------------------------------------- host: descriptor -> parameters
 inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     NG_REQUIRE(d != nullptr, "conv: null descriptor");
     NG_REQUIRE(d->in && d->w && d->out && d->zero_page, "conv: null pointer");
-    NG_REQUIRE(ng_aligned16(d->in) && ng_aligned16(d->w) && ng_aligned16(d->zero_page), "conv: in/w/zero_page must be 16-byte aligned");
+    NG_REQUIRE(ng_aligned16(d->in) && ng_aligned16(d->w) && ng_aligned16(d->zero_page) && ng_aligned16(d->out), "conv: in/w/out/zero_page must be 16-byte aligned");
+    NG_REQUIRE(d->out_cs % 4 == 0 || d->N < 4, "conv: out_cs must be a multiple of 4");
     NG_REQUIRE(d->B > 0 && d->OH > 0 && d->OW > 0 && d->N > 0, "conv: empty problem B=%d OH=%d OW=%d N=%d", d->B, d->OH, d->OW, d->N);
     NG_REQUIRE(d->ntaps >= 1 && d->ntaps <= NIRGAN_MAX_TAPS, "conv: ntaps=%d out of range", d->ntaps);
     NG_REQUIRE(d->run > 0 && d->run % 4 == 0 && d->in_cs > 0 && d->in_cs % 4 == 0, "conv: run=%d and in_cs=%d must be positive multiples of 4", d->run, d->in_cs);
@@ -457,6 +539,7 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.M = int(M); p.N = d->N;
     p.mtiles = (p.M + 127) / 128;
     p.ntiles = d->N > 64 ? (d->N + 127) / 128 : 1;
+    p.dbg = nullptr;
     return NIRGAN_OK;
 }
 
