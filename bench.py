@@ -43,7 +43,7 @@ def mfma_probes(trainer):
     conv_igemm_kernel<128>: 2*M*N*K per launch.  conv_wgrad_pair_kernel (data-gradient tiles + weight-gradient
     tiles of one layer in one grid): the sum of both problems' 2*M*N*K."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
-    kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0]}
+    kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0]}
     for pl in plans:
         pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}
         for i, (name, args) in enumerate(pl.ops):
@@ -52,6 +52,13 @@ def mfma_probes(trainer):
                 if d.N > 64:
                     k = "conv_igemm_kernel<128>"
                     kinds[k][0] += 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run
+                    kinds[k][1] += 1
+                    pl.probe_idx[i] = k
+            elif name == "nirgan_conv_igemm_group":
+                ds = [args[0][j].contents for j in range(args[1])]
+                if ds[0].N > 64:
+                    k = "conv_group_kernel<128>"
+                    kinds[k][0] += sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds)
                     kinds[k][1] += 1
                     pl.probe_idx[i] = k
             elif name == "nirgan_conv_wgrad_pair":

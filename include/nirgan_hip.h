@@ -100,6 +100,10 @@ typedef struct {
 
 int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream);
 
+/* Up to 4 independent descriptors of the same tile width (all N <= 64 or all N > 64) in one launch: the four
+ * sub-pixel phases of a stride-2 data gradient or of a ConvTranspose2d forward (model/networks.py:349,360-363). */
+int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int n, void* stream);
+
 /* Horizontally fused launch of a data-gradient convolution and the weight gradient of the same layer (both
  * read the same dY): one grid holds the tiles of both, so the partly filled last round of one problem is
  * filled by the other.  Semantics = nirgan_conv_igemm(c) followed by nirgan_wgrad_igemm(w). */

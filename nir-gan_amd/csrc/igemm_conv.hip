@@ -23,6 +23,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ng::ConvParams
     ng::conv_tile<BN>(p, blockIdx.x, st0, st1);
 }
 
+// up to 4 independent problems (the sub-pixel phases of a stride-2 data gradient / transposed convolution) in ONE
+// grid: the phases are small (a quarter of the layer each), one launch fills the chip instead of four partial ones
+struct ConvGroup {
+    ng::ConvParams p[4];
+    int first[5];        // first block id of each problem; first[n] = total
+    int n;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_group_kernel(const ConvGroup g) {
+    __shared__ __attribute__((aligned(16))) char st0[(128 + BN) * 128];
+    __shared__ __attribute__((aligned(16))) char st1[(128 + BN) * 128];
+    const int bid = blockIdx.x;
+    int k = 0;
+    if (bid >= g.first[1]) k = 1;
+    if (bid >= g.first[2]) k = 2;
+    if (bid >= g.first[3]) k = 3;
+    if (k == 0) ng::conv_tile<BN>(g.p[0], bid, st0, st1);
+    else if (k == 1) ng::conv_tile<BN>(g.p[1], bid - g.first[1], st0, st1);
+    else if (k == 2) ng::conv_tile<BN>(g.p[2], bid - g.first[2], st0, st1);
+    else ng::conv_tile<BN>(g.p[3], bid - g.first[3], st0, st1);
+}
+
 }  // namespace
 
 extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
@@ -36,4 +59,28 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
         hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(p.mtiles), dim3(256), 0, st, p);
     }
     return nirgan_check_launch("conv_igemm");
+}
+
+extern "C" int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int n, void* stream) {
+    NG_REQUIRE(descs != nullptr && n >= 1 && n <= 4, "conv_igemm_group: 1..4 descriptors");
+    ConvGroup g;
+    int total = 0;
+    bool wide = false;
+    for (int i = 0; i < n; ++i) {
+        NG_REQUIRE(descs[i] != nullptr, "conv_igemm_group: null descriptor %d", i);
+        const int rc = ng::build_conv_params(descs[i], g.p[i]);
+        if (rc != NIRGAN_OK) return rc;
+        const bool w = descs[i]->N > 64;
+        NG_REQUIRE(i == 0 || w == wide, "conv_igemm_group: all problems must use the same tile width (N <= 64 or N > 64)");
+        wide = w;
+        g.first[i] = total;
+        total += g.p[i].mtiles * g.p[i].ntiles;
+    }
+    for (int i = n; i < 4; ++i) { g.p[i] = g.p[0]; g.first[i] = 0x7fffffff; }
+    g.first[4] = total;
+    g.n = n;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (wide) hipLaunchKernelGGL(conv_group_kernel<128>, dim3(total), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(conv_group_kernel<64>, dim3(total), dim3(256), 0, st, g);
+    return nirgan_check_launch("conv_igemm_group");
 }

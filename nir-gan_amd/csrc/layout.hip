@@ -29,26 +29,45 @@ __global__ void nchw_to_halo_kernel(const float* __restrict__ src, int B, int Cs
 }
 
 struct GatherP {
-    const float* q; int q_row, q_img, q_cs;
-    int ntaps; int off[64];
+    const float* q; int q_row, q_img, q_cs, q_hp, q_wp;
+    int ntaps; int dh[64], dw[64]; int kh, kw;
     const float* bias; int act;
     int B, OH, OW, crop;
     float* dst;
 };
 
-__global__ void tap_gather_kernel(const GatherP p) {
+// Block = 8 x 32 outputs.  The (8+kh-1) x (32+kw-1) window of tap-plane records is staged in LDS with coalesced
+// 16-byte loads (records are q_cs contiguous floats) at an ODD float stride per record, so that the 49 (16) reads of
+// a thread -- record (y+kh, x+kw), plane kh*k+kw -- are bank-conflict free across the 32 x-neighbours.
+__global__ __launch_bounds__(256) void tap_gather_kernel(const GatherP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
     const int H2 = p.OH - 2 * p.crop, W2 = p.OW - 2 * p.crop;
-    const int64_t total = int64_t(p.B) * H2 * W2;
-    const float bv = p.bias ? p.bias[0] : 0.f;
-    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
-        const int w = int(i % W2), h = int((i / W2) % H2), b = int(i / (int64_t(W2) * H2));
-        const float* base = p.q + int64_t(b) * p.q_img + int64_t(h + p.crop) * p.q_row + int64_t(w + p.crop) * p.q_cs;
-        float s = 0.f;
-        for (int t = 0; t < p.ntaps; ++t) s += base[p.off[t] + t];
-        s += bv;
-        if (p.act == NIRGAN_ACT_TANH) s = tanhf(s);
-        p.dst[i] = s;
+    const int tiles_x = (W2 + 31) / 32, tiles_y = (H2 + 7) / 8;
+    const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+    const int ty0 = (tile / tiles_x) * 8, tx0 = (tile % tiles_x) * 32;
+    const int q4 = p.q_cs / 4, stride = p.q_cs | 1;
+    const int rh = 8 + p.kh - 1, rw = 32 + p.kw - 1;
+    // window origin in q coordinates: output (y, x) reads q rows y+crop+dh, cols x+crop+dw (dh, dw >= 0)
+    const float* qb = p.q + int64_t(b) * p.q_img;
+    for (int i = threadIdx.x; i < rh * rw * q4; i += 256) {
+        const int c = i % q4, px = i / q4;
+        const int wy = px / rw, wx = px - wy * rw;
+        int gy = ty0 + p.crop + wy, gx = tx0 + p.crop + wx;
+        gy = gy < p.q_hp ? gy : p.q_hp - 1;          // clamped rows/cols are only read by masked-off outputs
+        gx = gx < p.q_wp ? gx : p.q_wp - 1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(qb + int64_t(gy) * p.q_row + int64_t(gx) * p.q_cs + c * 4);
+        float* d = lds + px * stride + c * 4;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x >= W2 || y >= H2) return;
+    float s = p.bias ? p.bias[0] : 0.f;
+    for (int t = 0; t < p.ntaps; ++t) s += lds[((ly + p.dh[t]) * rw + lx + p.dw[t]) * stride + t];
+    if (p.act == NIRGAN_ACT_TANH) s = tanhf(s);
+    p.dst[(int64_t(b) * H2 + y) * W2 + x] = s;
 }
 
 struct ScatterP {
@@ -180,21 +199,31 @@ extern "C" int nirgan_nchw_to_halo(const float* src, int B, int Cs, int H, int W
 
 extern "C" int nirgan_tap_gather(const nirgan_tap_gather_desc* d, void* stream) {
     NG_REQUIRE(d && d->q && d->dst, "tap_gather: null pointer");
-    NG_REQUIRE(d->ntaps >= 1 && d->ntaps <= 64 && d->ntaps <= d->q_cs, "tap_gather: ntaps out of range");
+    NG_REQUIRE(d->ntaps >= 1 && d->ntaps <= 64 && d->ntaps <= d->q_cs && d->q_cs % 4 == 0, "tap_gather: ntaps/q_cs out of range");
     NG_REQUIRE(d->B > 0 && d->crop >= 0 && d->OH > 2 * d->crop && d->OW > 2 * d->crop, "tap_gather: bad shape");
+    NG_REQUIRE(ng_aligned16(d->q), "tap_gather: q must be 16-byte aligned");
     GatherP p;
-    p.q = d->q; p.q_cs = d->q_cs; p.q_row = d->q_wp * d->q_cs; p.q_img = d->q_hp * p.q_row;
+    p.q = d->q; p.q_cs = d->q_cs; p.q_row = d->q_wp * d->q_cs; p.q_img = d->q_hp * p.q_row; p.q_hp = d->q_hp; p.q_wp = d->q_wp;
     p.ntaps = d->ntaps;
+    int kh = 1, kw = 1;
     for (int t = 0; t < 64; ++t) {
-        p.off[t] = 0;
+        p.dh[t] = p.dw[t] = 0;
         if (t < d->ntaps) {
             NG_REQUIRE(d->tap_dh[t] >= 0 && d->OH - 1 + d->tap_dh[t] < d->q_hp && d->tap_dw[t] >= 0 && d->OW - 1 + d->tap_dw[t] < d->q_wp, "tap_gather: tap %d out of range", t);
-            p.off[t] = d->tap_dh[t] * p.q_row + d->tap_dw[t] * d->q_cs;
+            p.dh[t] = d->tap_dh[t]; p.dw[t] = d->tap_dw[t];
+            kh = d->tap_dh[t] + 1 > kh ? d->tap_dh[t] + 1 : kh;
+            kw = d->tap_dw[t] + 1 > kw ? d->tap_dw[t] + 1 : kw;
         }
     }
+    p.kh = kh; p.kw = kw;
     p.bias = d->bias; p.act = d->act; p.B = d->B; p.OH = d->OH; p.OW = d->OW; p.crop = d->crop; p.dst = d->dst;
-    const int64_t total = int64_t(d->B) * (d->OH - 2 * d->crop) * (d->OW - 2 * d->crop);
-    hipLaunchKernelGGL(tap_gather_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    const int H2 = d->OH - 2 * d->crop, W2 = d->OW - 2 * d->crop;
+    const size_t lds = size_t(8 + kh - 1) * (32 + kw - 1) * (d->q_cs | 1) * 4;
+    NG_REQUIRE(lds <= 160 * 1024, "tap_gather: window does not fit LDS");
+    static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(tap_gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+    (void)once;
+    const int grid = d->B * ((W2 + 31) / 32) * ((H2 + 7) / 8);
+    hipLaunchKernelGGL(tap_gather_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("tap_gather");
 }
 

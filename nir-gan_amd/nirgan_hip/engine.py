@@ -203,6 +203,15 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     return d
 
 
+def emit_conv_group(plan: Plan, ctx: Ctx, descs: list):
+    """One launch for up to 4 conv descriptors (sub-pixel phases)."""
+    for i in range(0, len(descs), 4):
+        grp = descs[i:i + 4]
+        arr = (C.POINTER(L.ConvDesc) * len(grp))(*[C.pointer(d) for d in grp])
+        ctx.keep.append(arr)
+        plan.add("nirgan_conv_igemm_group", arr, len(grp))
+
+
 class SlabPool:
     """Scratch shared by the weight-gradient launches of an engine (they run serially on one stream)."""
 
@@ -327,13 +336,15 @@ class ConvIN:
             w = eng.weights.packed(pack, self.weight, G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C))
             emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
                       in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
-        else:  # convT: 4 sub-pixel phases over the zero-halo-1 input
+        else:  # convT: 4 sub-pixel phases over the zero-halo-1 input, one launch
+            descs = []
             for ph in G.convT_fwd_phases(inp.H, inp.W, k, p):
                 taps = G.Taps(ph.dh, ph.dw, inp.C)
                 w = eng.weights.packed(pack, self.weight, G.convT_fwd_pack(inp.C, self.cout, k, ph.taps_hw))
-                emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=ph.n_h, OW=ph.n_w,
-                          in_oh=ph.in_oh + inp.pad - 1, in_ow=ph.in_ow + inp.pad - 1,
-                          out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow)
+                descs.append(emit_conv(None, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=ph.n_h, OW=ph.n_w,
+                                       in_oh=ph.in_oh + inp.pad - 1, in_ow=ph.in_ow + inp.pad - 1,
+                                       out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow))
+            emit_conv_group(plan, ctx, descs)
         emit_in_fwd(plan, ctx, self.y, self.out, norm=self.norm, act=(L.ACT_NONE if self.keep_z else self.act),
                     residual=self.residual, border=self.out_border, stats=self.stats, ws=eng.scratch.get())
 
@@ -399,6 +410,7 @@ class ConvIN:
         elif self.kind in ("conv", "rowpacked") and s == 2:
             assert dgrad_out.H == inp.H and dy.pad == 1
             cin_buf = inp.C
+            descs = []
             for ph in G.conv_dgrad_s2_phases(inp.H, inp.W, k, p):
                 if self.kind == "conv":
                     spec = G.conv_dgrad_pack(self.cout, inp.C, k, ph.taps_hw)
@@ -406,9 +418,10 @@ class ConvIN:
                     spec = G.conv_dgrad_pack(self.cout, self.cin, k, ph.taps_hw)
                     cin_buf = self.cin
                 w = eng.weights.packed(pack, self.weight, spec)
-                emit_conv(plan, ctx, dy, G.Taps(ph.dh, ph.dw, self.cout), w, None, dgrad_out, N=cin_buf,
-                          OH=ph.n_h, OW=ph.n_w, in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2,
-                          out_oh=ph.out_oh + dgrad_out.pad, out_ow=ph.out_ow + dgrad_out.pad)
+                descs.append(emit_conv(None, ctx, dy, G.Taps(ph.dh, ph.dw, self.cout), w, None, dgrad_out, N=cin_buf,
+                                       OH=ph.n_h, OW=ph.n_w, in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2,
+                                       out_oh=ph.out_oh + dgrad_out.pad, out_ow=ph.out_ow + dgrad_out.pad))
+            emit_conv_group(plan, ctx, descs)
         elif self.kind == "convT":
             assert dgrad_out.H == inp.H and dy.pad == 1
             w = eng.weights.packed(pack, self.weight, G.convT_dgrad_pack(inp.C, self.cout, k))

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "nirgan_last_error": (C.c_char_p, []),
     "nirgan_conv_igemm": (i32, [C.POINTER(ConvDesc), fp]),
     "nirgan_wgrad_igemm": (i32, [C.POINTER(WgradDesc), fp]),
+    "nirgan_conv_igemm_group": (i32, [C.POINTER(C.POINTER(ConvDesc)), i32, fp]),
     "nirgan_conv_wgrad_pair": (i32, [C.POINTER(ConvDesc), C.POINTER(WgradDesc), fp]),
     "nirgan_reduce_rows": (i32, [fp, i32, i32, i32, fp, fp, i64, i32, i32, fp]),
     "nirgan_pack_rows": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),

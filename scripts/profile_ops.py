@@ -31,6 +31,12 @@ def describe(name, args):
         M = d.B * d.OH * d.OW
         blocks = -(-M // 128) * (-(-d.N // 128) if d.N > 64 else 1)
         return f"conv M={M} N={d.N} K={d.ntaps}x{d.run} s{d.in_stride}/{d.out_stride} blk={blocks}", 2.0 * M * d.N * d.ntaps * d.run
+    if name == "nirgan_conv_igemm_group":
+        ds = [args[0][i].contents for i in range(args[1])]
+        fl = sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds)
+        blk = sum(-(-(d.B * d.OH * d.OW) // 128) * (-(-d.N // 128) if d.N > 64 else 1) for d in ds)
+        d = ds[0]
+        return f"group x{len(ds)} M={d.B * d.OH * d.OW} N={d.N} K={d.ntaps}x{d.run} s{d.in_stride}/{d.out_stride} blk={blk}", fl
     if name == "nirgan_wgrad_igemm":
         w = args[0]._obj
         M = w.B * w.OH * w.OW

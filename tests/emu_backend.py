@@ -141,6 +141,13 @@ class EmuBackend:
             slabs[s] = (P_all[a:e].T @ Q_all[a:e]).astype(np.float32) if e > a else 0.0
         return 0
 
+    def nirgan_conv_igemm_group(self, descs, n, stream=None):
+        for i in range(n):
+            rc = self.nirgan_conv_igemm(descs[i].contents)
+            if rc:
+                return rc
+        return 0
+
     def nirgan_conv_wgrad_pair(self, cref, wref, stream=None):
         rc = self.nirgan_conv_igemm(cref)
         return rc if rc else self.nirgan_wgrad_igemm(wref)
