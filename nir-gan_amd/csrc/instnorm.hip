@@ -14,7 +14,7 @@ __host__ __device__ inline int in_nrg(int C) {
 
 inline int in_nchunk(int B, int HW, int C) {
     const int nrg = in_nrg(C);
-    int want = 2048 / B;
+    int want = 1024 / B;
     if (want < 1) want = 1;
     int cap = HW / (nrg * 8);
     if (cap < 1) cap = 1;
@@ -87,6 +87,31 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InFwd p) {
     }
 }
 
+// one thread per (b, 4 channels): combine the chunk partials in chunk order (deterministic) -> mean, rstd
+__global__ __launch_bounds__(256) void in_finalize_kernel(const InFwd p, int B) {
+    const int q4 = p.C / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * q4) return;
+    const int b = i / q4, q = i - b * q4;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    const float* w = p.ws + size_t(b) * p.nchunk * 2 * p.C;
+    for (int c = 0; c < p.nchunk; ++c) {
+        s1 += ld4(w + size_t(c) * 2 * p.C + q * 4);
+        s2 += ld4(w + size_t(c) * 2 * p.C + p.C + q * 4);
+    }
+    const float inv = 1.f / float(p.HW);
+    const f32x4 k = ld4(p.y + size_t(b) * p.HW * p.C + q * 4);
+    const f32x4 m = s1 * inv;
+    f32x4 var = s2 * inv - m * m, rstd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        var[j] = var[j] > 0.f ? var[j] : 0.f;
+        rstd[j] = 1.f / sqrtf(var[j] + p.eps);
+    }
+    st4(p.mean + size_t(b) * p.C + q * 4, k + m);
+    st4(p.rstd + size_t(b) * p.C + q * 4, rstd);
+}
+
 __device__ __forceinline__ f32x4 act4(f32x4 z, int act, float slope) {
     if (act == NIRGAN_ACT_RELU) {
 #pragma unroll
@@ -99,41 +124,16 @@ __device__ __forceinline__ f32x4 act4(f32x4 z, int act, float slope) {
 }
 
 __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
-    __shared__ f32x4 s_mean[256], s_rstd[256];
     const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
     const int q4 = p.C / 4, nrg = in_nrg(p.C);
     const int q = tid % q4, rg = tid / q4;
-    const float* yb = p.y + size_t(b) * p.HW * p.C;
-    if (tid < q4) {
-        f32x4 mean = {0, 0, 0, 0}, rstd = {1, 1, 1, 1};
-        if (p.norm) {
-            f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-            const float* w = p.ws + size_t(b) * p.nchunk * 2 * p.C;
-            for (int c = 0; c < p.nchunk; ++c) {
-                s1 += ld4(w + size_t(c) * 2 * p.C + tid * 4);
-                s2 += ld4(w + size_t(c) * 2 * p.C + p.C + tid * 4);
-            }
-            const float inv = 1.f / float(p.HW);
-            const f32x4 k = ld4(yb + tid * 4);
-            const f32x4 m = s1 * inv;
-            f32x4 var = s2 * inv - m * m;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                var[i] = var[i] > 0.f ? var[i] : 0.f;
-                rstd[i] = 1.f / sqrtf(var[i] + p.eps);
-            }
-            mean = k + m;
-            if (chunk == 0) {
-                st4(p.mean + size_t(b) * p.C + tid * 4, mean);
-                st4(p.rstd + size_t(b) * p.C + tid * 4, rstd);
-            }
-        }
-        s_mean[tid] = mean;
-        s_rstd[tid] = rstd;
-    }
-    __syncthreads();
     if (rg >= nrg) return;
-    const f32x4 mean = s_mean[q], rstd = s_rstd[q];
+    const float* yb = p.y + size_t(b) * p.HW * p.C;
+    f32x4 mean = {0, 0, 0, 0}, rstd = {1, 1, 1, 1};
+    if (p.norm) {
+        mean = ld4(p.mean + size_t(b) * p.C + q * 4);
+        rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
+    }
     const int start = chunk * p.ppc;
     int end = start + p.ppc;
     end = end < p.HW ? end : p.HW;
@@ -231,50 +231,44 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
     }
 }
 
-__global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p) {
-    __shared__ f32x4 lds[512];
+// one thread per (b, 4 channels): mean(g_z), mean(g_z * z) from the chunk partials, stored behind them in ws
+__global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const InBwd p, int B) {
+    const int q4 = p.C / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * q4) return;
+    const int b = i / q4, q = i - b * q4;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    const float* w = p.ws + size_t(b) * p.nchunk * 2 * p.C;
+    for (int c = 0; c < p.nchunk; ++c) {
+        s1 += ld4(w + size_t(c) * 2 * p.C + q * 4);
+        s2 += ld4(w + size_t(c) * 2 * p.C + p.C + q * 4);
+    }
+    const float inv = 1.f / float(p.HW);
+    float* m = p.ws + size_t(B) * p.nchunk * 2 * p.C + size_t(b) * 2 * p.C;
+    st4(m + q * 4, s1 * inv);
+    st4(m + p.C + q * 4, s2 * inv);
+}
+
+__global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B) {
     const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
     const int q4 = p.C / 4, nrg = in_nrg(p.C);
     const int q = tid % q4, rg = tid / q4;
-    if (tid < q4) {
-        f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-        const float* w = p.ws + size_t(b) * p.nchunk * 2 * p.C;
-        for (int c = 0; c < p.nchunk; ++c) {
-            s1 += ld4(w + size_t(c) * 2 * p.C + tid * 4);
-            s2 += ld4(w + size_t(c) * 2 * p.C + p.C + tid * 4);
-        }
-        const float inv = 1.f / float(p.HW);
-        lds[tid] = s1 * inv;
-        lds[256 + tid] = s2 * inv;
-    }
-    __syncthreads();
-    f32x4 sd = {0, 0, 0, 0}, dummy = {0, 0, 0, 0};
-    if (rg < nrg) {
-        const f32x4 m1 = lds[q], m2 = lds[256 + q];
-        const f32x4 mean = ld4(p.mean + size_t(b) * p.C + q * 4);
-        const f32x4 rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
-        const float* yb = p.y + size_t(b) * p.HW * p.C;
-        float* db = p.dy + size_t(b) * p.d_img + p.d_org;
-        const int start = chunk * p.ppc;
-        int end = start + p.ppc;
-        end = end < p.HW ? end : p.HW;
-        for (int pix = start + rg; pix < end; pix += nrg) {
-            const int h = pix / p.W, w = pix - h * p.W;
-            float* dp = db + size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
-            const f32x4 gz = ld4(dp);
-            const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
-            const f32x4 d = rstd * (gz - m1 - z * m2);
-            st4(dp, d);
-            sd += d;
-        }
-    }
-    if (p.dbias) {
-        __syncthreads();
-        rg_reduce2(sd, dummy, lds, tid, q4, nrg);
-        if (tid < q4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(p.dbias + tid * 4 + i, sd[i]);
-        }
+    if (rg >= nrg) return;
+    const float* mm = p.ws + size_t(B) * p.nchunk * 2 * p.C + size_t(b) * 2 * p.C;
+    const f32x4 m1 = ld4(mm + q * 4), m2 = ld4(mm + p.C + q * 4);
+    const f32x4 mean = ld4(p.mean + size_t(b) * p.C + q * 4);
+    const f32x4 rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
+    const float* yb = p.y + size_t(b) * p.HW * p.C;
+    float* db = p.dy + size_t(b) * p.d_img + p.d_org;
+    const int start = chunk * p.ppc;
+    int end = start + p.ppc;
+    end = end < p.HW ? end : p.HW;
+    for (int pix = start + rg; pix < end; pix += nrg) {
+        const int h = pix / p.W, w = pix - h * p.W;
+        float* dp = db + size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
+        const f32x4 gz = ld4(dp);
+        const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
+        st4(dp, rstd * (gz - m1 - z * m2));
     }
 }
 
@@ -282,7 +276,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p) {
 
 extern "C" int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    return int64_t(B) * in_nchunk(B, H * W, C) * 2 * C;
+    return int64_t(B) * in_nchunk(B, H * W, C) * 2 * C + int64_t(B) * 2 * C;
 }
 
 extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
@@ -302,6 +296,7 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
     if (d->norm) {
         NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
         hipLaunchKernelGGL(in_stats_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(in_finalize_kernel, dim3((d->B * (d->C / 4) + 255) / 256), dim3(256), 0, st, p, d->B);
     }
     hipLaunchKernelGGL(in_apply_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     return nirgan_check_launch("instnorm_fwd");
@@ -326,9 +321,12 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     p.dy = d->dy; p.d_row = d->d_wp * d->C; p.d_img = d->d_hp * p.d_row; p.d_org = d->d_pad * p.d_row + d->d_pad * d->C;
     p.gsum_out = d->gsum_out; p.dbias = d->dbias;
     p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C); p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
-    NG_REQUIRE(!d->norm || d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C, "instnorm_bwd: ws too small");
+    NG_REQUIRE(!d->norm || d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C + int64_t(d->B) * 2 * d->C, "instnorm_bwd: ws too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
-    if (d->norm) hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+    if (d->norm) {
+        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((d->B * (d->C / 4) + 255) / 256), dim3(256), 0, st, p, d->B);
+        hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p, d->B);
+    }
     return nirgan_check_launch("instnorm_bwd");
 }

@@ -29,7 +29,7 @@ def obj(ref):
 def _in_nchunk(B, HW, Cc):
     q4 = Cc // 4
     nrg = 1 if q4 >= 256 else 256 // q4
-    want = max(1, 2048 // B)
+    want = max(1, 1024 // B)
     cap = max(1, HW // (nrg * 8))
     return min(want, cap)
 
@@ -179,7 +179,7 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ instance norm
     def nirgan_instnorm_ws_elems(self, B, H, W, Cc):
-        return B * _in_nchunk(B, H * W, Cc) * 2 * Cc
+        return B * _in_nchunk(B, H * W, Cc) * 2 * Cc + B * 2 * Cc
 
     @staticmethod
     def _act(z, act, slope):
