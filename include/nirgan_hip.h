@@ -72,6 +72,10 @@ typedef struct {
     int out_stride, out_oh, out_ow;
     int B, OH, OW, N;
     const float* zero_page;               /* >= 64 zero bytes, 16-byte aligned */
+    /* optional split-K for problems with few output tiles (< 1 tile per CU slot): the K-steps are divided over
+     * `ksplit` blocks per tile, partial tiles go to split_ws [ksplit][B*OH*OW][N] and are summed (fixed order,
+     * + bias) into `out` by a second small launch.  ksplit <= 1: off. */
+    int ksplit; float* split_ws; int64_t split_ws_elems;
 } nirgan_conv_desc;
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
@@ -116,6 +120,11 @@ int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32
 /* dst[n][k] = map[k] >= 0 ? src[n*src_row_stride + map[k]] : 0   (weight packing) */
 int nirgan_pack_rows(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,
                      float* dst, int N, int K, void* stream);
+
+/* All weight packs of a step in one launch.  jobs_device: njobs x 8 int64 in DEVICE memory:
+ * {src, dst, map, src_elems, N, K, src_row_stride, first_block}; job j owns blocks
+ * [first_block_j, first_block_j + N_j * ceil(K_j / 1024)); total_blocks = their sum. */
+int nirgan_pack_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False, eps) + activation + residual + halo write, forward.

@@ -23,6 +23,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ng::ConvParams
     ng::conv_tile<BN>(p, blockIdx.x, st0, st1);
 }
 
+// split-K second stage: out(m, n) = bias[n] + sum_s ws[s][m][n], written with the descriptor's output geometry
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ng::ConvParams p) {
+    const int n4 = p.N / 4;
+    const long long total = (long long)p.M * n4;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = int(i / n4), q = int(i - (long long)m * n4);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < p.ksplit; ++k) s += *reinterpret_cast<const f32x4*>(p.split_ws + ((size_t(k) * p.M + m) * p.N + q * 4));
+        if (p.bias != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += p.bias[q * 4 + j];
+        }
+        const int b = m / p.OHW, r = m - b * p.OHW;
+        const int oh = r / p.OW, ow = r - oh * p.OW;
+        *reinterpret_cast<f32x4*>(p.out + (b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + q * 4)) = s;
+    }
+}
+
 // up to 4 independent problems (the sub-pixel phases of a stride-2 data gradient / transposed convolution) in ONE
 // grid: the phases are small (a quarter of the layer each), one launch fills the chip instead of four partial ones
 struct ConvGroup {
@@ -54,9 +72,14 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->N > 64) {
-        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(p.mtiles * p.ntiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(p.mtiles * p.ntiles * p.ksplit), dim3(256), 0, st, p);
     } else {
-        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(p.mtiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3(p.mtiles * p.ksplit), dim3(256), 0, st, p);
+    }
+    if (p.ksplit > 1) {
+        const long long total = (long long)p.M * (p.N / 4);
+        const int grid = int((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p);
     }
     return nirgan_check_launch("conv_igemm");
 }
@@ -70,6 +93,7 @@ extern "C" int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int
         NG_REQUIRE(descs[i] != nullptr, "conv_igemm_group: null descriptor %d", i);
         const int rc = ng::build_conv_params(descs[i], g.p[i]);
         if (rc != NIRGAN_OK) return rc;
+        NG_REQUIRE(descs[i]->ksplit <= 1, "conv_igemm_group: split-K descriptors are not groupable");
         const bool w = descs[i]->N > 64;
         NG_REQUIRE(i == 0 || w == wide, "conv_igemm_group: all problems must use the same tile width (N <= 64 or N > 64)");
         wide = w;

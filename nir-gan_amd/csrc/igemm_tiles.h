@@ -48,6 +48,8 @@ struct ConvParams {
     int out_cs, out_row, out_img, out_stride, out_org;
     int OW, OHW, M, N;
     int mtiles, ntiles;
+    int ksplit;                // > 1: the K-steps are divided over ksplit blocks per tile, partial tiles go to split_ws
+    float* split_ws;           // [ksplit][M][N] dense
     unsigned long long* dbg;   // diagnostic build only
 };
 
@@ -63,7 +65,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int id = ng_xcd_remap(block_id, p.mtiles * p.ntiles);
+    const int tiles = p.mtiles * p.ntiles;
+    const int rid = ng_xcd_remap(block_id, tiles * p.ksplit);
+    const int ksp = rid / tiles, id = rid - ksp * tiles;
     const int n0 = (id % p.ntiles) * BN, m0 = (id / p.ntiles) * BM;
 
     // ---------------- loader state: each lane owns one 16-byte chunk of 4 A rows and BI B rows
@@ -162,8 +166,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 
     // ---------------- main loop: K-steps enumerate (tap, 32-float slice of the run)
     const int csteps = (p.run + 31) >> 5;
-    const int nk = p.ntaps * csteps;
-    int t = 0, c0 = 0;
+    const int nk_all = p.ntaps * csteps;
+    const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+    const int ks0 = ksp * per;
+    const int nk = (ks0 + per < nk_all ? per : nk_all - ks0);      // > 0: the host never over-splits
+    int t = ks0 / csteps, c0 = (ks0 - t * csteps) * 32;
     // steady state: the LDS-DMA of step s+1 and its address arithmetic are issued BETWEEN the MFMAs of step s.
     // The two stages are distinct LDS objects and the loop is unrolled by two, so the compiler knows the DMA
     // writes do not alias the fragment reads and can interleave them; the sched_group_barrier sequence asks for
@@ -188,7 +195,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         if (cc >= p.run) { cc = 0; ++tt; }
     };
     NG_DIAG_DECL
-    issue(st0, 0, 0);
+    issue(st0, t, c0);
     int s = 0;
     for (; s + 2 < nk; s += 2) {
         next(t, c0);
@@ -252,7 +259,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         const int chunk = tid % LPR, row0 = tid / LPR;
         const int n = n0 + chunk * 4;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr) {
+        const bool to_ws = p.ksplit > 1;
+        if (p.bias != nullptr && !to_ws) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = n + j < p.N ? p.bias[n + j] : 0.f;
         }
@@ -268,7 +276,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                 const float* src = reinterpret_cast<const float*>(row < 64 ? st0 : st1) + (row & 63) * BN + chunk * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(src);
                 v += bv;
-                float* dst = p.out + (b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n);
+                float* dst = to_ws ? p.split_ws + ((size_t(ksp) * p.M + m) * p.N + n)
+                                   : p.out + (b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n);
                 if (n + 4 <= p.N) {
                     *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
@@ -540,6 +549,18 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.mtiles = (p.M + 127) / 128;
     p.ntiles = d->N > 64 ? (d->N + 127) / 128 : 1;
     p.dbg = nullptr;
+    p.ksplit = 1;
+    p.split_ws = nullptr;
+    if (d->ksplit > 1) {
+        const int nk = d->ntaps * ((d->run + 31) / 32);
+        NG_REQUIRE(d->split_ws != nullptr && ng_aligned16(d->split_ws), "conv: split_ws missing or misaligned");
+        NG_REQUIRE(d->N % 4 == 0, "conv: split-K needs N %% 4 == 0");
+        NG_REQUIRE(d->split_ws_elems >= int64_t(d->ksplit) * M * d->N, "conv: split_ws too small");
+        const int per = (nk + d->ksplit - 1) / d->ksplit;
+        NG_REQUIRE(per * (d->ksplit - 1) < nk, "conv: ksplit=%d too large for %d K-steps", d->ksplit, nk);
+        p.ksplit = d->ksplit;
+        p.split_ws = d->split_ws;
+    }
     return NIRGAN_OK;
 }
 

@@ -85,6 +85,35 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     *reinterpret_cast<f32x4*>(dst + size_t(n) * K + k4) = v;
 }
 
+// all weight packs of a plan in one launch: jobs live in device memory (8 x int64 each):
+// src, dst, map, src_elems, N, K, src_row_stride, first_block
+__global__ __launch_bounds__(256) void pack_rows_batch_kernel(const long long* __restrict__ jobs, int njobs) {
+    int j = 0;
+    for (int i = 1; i < njobs; ++i)
+        if (int(blockIdx.x) >= int(jobs[i * 8 + 7])) j = i;
+    const long long* J = jobs + j * 8;
+    const float* src = reinterpret_cast<const float*>(J[0]);
+    float* dst = reinterpret_cast<float*>(J[1]);
+    const int32_t* map = reinterpret_cast<const int32_t*>(J[2]);
+    const long long src_elems = J[3];
+    const int K = int(J[5]), stride = int(J[6]);
+    const int kblocks = (K + 1023) / 1024;
+    const int local = int(blockIdx.x) - int(J[7]);
+    const int n = local / kblocks, kb = local - n * kblocks;
+    const int k4 = (kb * 256 + threadIdx.x) * 4;
+    if (k4 >= K) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int mk = map[k4 + q];
+        if (mk >= 0) {
+            const long long o = (long long)n * stride + mk;
+            if (o < src_elems) v[q] = src[o];
+        }
+    }
+    *reinterpret_cast<f32x4*>(dst + size_t(n) * K + k4) = v;
+}
+
 }  // namespace
 
 
@@ -108,7 +137,7 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     if (rc != NIRGAN_OK) return rc;
     rc = ng::build_wgrad_params(w, wp);
     if (rc != NIRGAN_OK) return rc;
-    if (c->N <= 64 || w->N <= 64) {      // narrow variants: two ordinary launches
+    if (c->N <= 64 || w->N <= 64 || c->ksplit > 1) {      // narrow or split-K variants: two ordinary launches
         rc = nirgan_conv_igemm(c, stream);
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
@@ -134,4 +163,11 @@ extern "C" int nirgan_pack_rows(const float* src, int64_t src_elems, int src_row
     hipLaunchKernelGGL(pack_rows_kernel, dim3((K + 1023) / 1024, N), dim3(256), 0, static_cast<hipStream_t>(stream),
                        src, src_elems, src_row_stride, map, dst, N, K);
     return nirgan_check_launch("pack_rows");
+}
+
+extern "C" int nirgan_pack_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream) {
+    NG_REQUIRE(jobs_device && njobs >= 1 && njobs <= 256 && total_blocks >= 1, "pack_rows_batch: bad arguments");
+    hipLaunchKernelGGL(pack_rows_batch_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(jobs_device), njobs);
+    return nirgan_check_launch("pack_rows_batch");
 }

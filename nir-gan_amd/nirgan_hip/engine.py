@@ -92,6 +92,20 @@ class Plan:
     def extend(self, other: "Plan"):
         self.ops.extend(other.ops)
 
+    def fuse_packs(self):
+        """Replace the nirgan_pack_rows ops of this plan by ONE nirgan_pack_rows_batch launch (job table in device memory)."""
+        packs = [a for n, a in self.ops if n == "nirgan_pack_rows"]
+        if len(packs) < 2 or len(packs) > 256:
+            return
+        rows, first = [], 0
+        for src, src_elems, stride, imap, dst, N, K in packs:
+            rows.append([src, dst, imap, src_elems, N, K, stride, first])
+            first += N * ((K + 1023) // 1024)
+        table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
+        self.ctx.keep.append(table)
+        self.ops = [(n, a) for n, a in self.ops if n != "nirgan_pack_rows"]
+        self.ops.append(("nirgan_pack_rows_batch", (table.data_ptr(), len(rows), first)))
+
     def run(self):
         be = L.backend()
         st = self.ctx.stream()
@@ -147,8 +161,29 @@ class Weights:
 # ---------------------------------------------------------------------------------------------
 # descriptor emitters
 # ---------------------------------------------------------------------------------------------
+class SplitPool:
+    """Workspace for split-K partial tiles, shared by the launches of a context (they run serially)."""
+
+    def __init__(self, ctx: "Ctx"):
+        self.ctx, self.buf = ctx, None
+
+    def get(self, n: int) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < n:
+            self.buf = self.ctx.zeros(n)
+            self.ctx.keep.append(self.buf)
+        return self.buf
+
+
+def choose_ksplit(tiles: int, nk: int) -> int:
+    """Few output tiles (< ~0.8 per CU slot) and a long K loop: divide K so that ~512-1024 blocks exist."""
+    if tiles >= 400 or nk < 32:
+        return 1
+    k = max(1, min(8, 1024 // max(tiles, 1), nk // 16))
+    return k if k > 1 else 1
+
+
 def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bias, out: Halo, *, N, OH, OW,
-              in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None):
+              in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None, allow_split=True):
     d = L.ConvDesc()
     d.inp, d.in_elems = inp.ptr, inp.elems
     d.in_hp, d.in_wp, d.in_cs = (in_hw or (inp.hp, inp.wp)) + (inp.C,)
@@ -162,6 +197,14 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.zero_page = ctx.zero_page.data_ptr()
     ctx.keep.append(d)
     if plan is not None:
+        M = inp.B * OH * OW
+        tiles = -(-M // 128) * (-(-N // 128) if N > 64 else 1)
+        ks = choose_ksplit(tiles, taps.n * (-(-taps.run // 32))) if (allow_split and N % 4 == 0) else 1
+        if ks > 1:
+            if not hasattr(ctx, "split_pool"):
+                ctx.split_pool = SplitPool(ctx)
+            ws = ctx.split_pool.get(ks * M * N)
+            d.ksplit, d.split_ws, d.split_ws_elems = ks, ws.data_ptr(), ws.numel()
         plan.add("nirgan_conv_igemm", C.byref(d))
     return d
 

@@ -37,6 +37,10 @@ class _Engine:
 
     def refresh_weights(self, version: int, backward: bool = False):
         """Re-pack weights when the parameters changed (version = optimizer step counter)."""
+        if not getattr(self, "_packs_fused", False):
+            self.pack_fwd.fuse_packs()
+            self.pack_bwd.fuse_packs()
+            self._packs_fused = True
         if self._packed_version != version:
             self.pack_fwd.run()
             self._packed_version = version

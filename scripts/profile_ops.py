@@ -30,7 +30,7 @@ def describe(name, args):
         d = args[0]._obj
         M = d.B * d.OH * d.OW
         blocks = -(-M // 128) * (-(-d.N // 128) if d.N > 64 else 1)
-        return f"conv M={M} N={d.N} K={d.ntaps}x{d.run} s{d.in_stride}/{d.out_stride} blk={blocks}", 2.0 * M * d.N * d.ntaps * d.run
+        return f"conv M={M} N={d.N} K={d.ntaps}x{d.run} s{d.in_stride}/{d.out_stride} blk={blocks}" + (f" ksplit={d.ksplit}" if d.ksplit > 1 else ""), 2.0 * M * d.N * d.ntaps * d.run
     if name == "nirgan_conv_igemm_group":
         ds = [args[0][i].contents for i in range(args[1])]
         fl = sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds)

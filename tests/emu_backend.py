@@ -177,6 +177,18 @@ class EmuBackend:
         o[:] = np.where(ok[None, :], s[idx], 0.0)
         return 0
 
+    def nirgan_pack_rows_batch(self, jobs, njobs, total_blocks, stream=None):
+        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 8)).from_address(int(jobs))).reshape(njobs, 8)
+        blocks = 0
+        for src, dst, imap, src_elems, N, K, stride, first in J:
+            if first != blocks:
+                return self._fail("pack_rows_batch: first_block mismatch")
+            rc = self.nirgan_pack_rows(int(src), int(src_elems), int(stride), int(imap), int(dst), int(N), int(K))
+            if rc:
+                return rc
+            blocks += int(N) * ((int(K) + 1023) // 1024)
+        return 0 if blocks == total_blocks else self._fail("pack_rows_batch: total_blocks mismatch")
+
     # ------------------------------------------------------------------ instance norm
     def nirgan_instnorm_ws_elems(self, B, H, W, Cc):
         return B * _in_nchunk(B, H * W, Cc) * 2 * Cc + B * 2 * Cc

@@ -321,3 +321,29 @@ def test_channel_dgrad_matches_torch():
     d.B, d.H, d.W, d.out = B, H, W, out.data_ptr()
     L.call("nirgan_conv_channel_dgrad", C.byref(d), torch.cuda.current_stream().cuda_stream)
     close(out, x.grad[:, 3], 1e-5, "channel dgrad")
+
+
+def test_conv_split_k_matches_plain():
+    """Few output tiles + long K: the split-K path (partial tiles + fixed-order reduce) equals the plain launch."""
+    gen = torch.Generator().manual_seed(17)
+    B, H, W, Cin, Cout, k = 2, 12, 12, 256, 256, 4
+    ctx = Ctx(DEV)
+    x = Halo(ctx, B, H, W, Cin, 1)
+    x.t.copy_(torch.randn(x.t.shape, generator=gen))
+    w = (torch.randn(Cout, Cin, k, k, generator=gen) * 0.05).to(DEV)
+    bias = torch.randn(Cout, generator=gen).to(DEV)
+    spec = G.conv_fwd_pack(Cout, Cin, k)
+    wp = ctx.zeros(spec.N, spec.K)
+    L.call("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), wp.data_ptr(), spec.N, spec.K, None)
+    OH = G.conv_out(H, k, 1, 1)
+    outs = []
+    for split in (False, True):
+        y = Halo(ctx, B, OH, OH, Cout, 1)
+        plan = Plan(ctx)
+        d = emit_conv(plan, ctx, x, G.conv_fwd_taps(k, Cin), wp, bias, y, N=Cout, OH=OH, OW=OH, out_oh=1, out_ow=1, allow_split=split)
+        assert (d.ksplit > 1) == split
+        plan.run()
+        outs.append(y.t.clone())
+    close(outs[1], outs[0], 1e-5, "split-K conv")
+    ref = torch.nn.functional.conv2d(x.t.permute(0, 3, 1, 2).cpu(), w.cpu(), bias.cpu())
+    close(outs[1][:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref, 1e-4, "split-K conv vs torch")
