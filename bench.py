@@ -130,7 +130,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     reducer = None
-    if world > 1:
+    if world > 1 or os.environ.get("NIRGAN_FORCE_DIST") == "1":     # the env var exercises RCCL on a single GPU (tests)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         from nirgan_hip.parallel import GradReducer
@@ -171,7 +171,7 @@ def main():
             pl.probe_idx = None
 
     def barrier():
-        if world > 1:
+        if reducer is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -181,7 +181,7 @@ def main():
         tr.step(rgb, nir)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if reducer is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -241,7 +241,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if reducer is not None:
         torch.distributed.destroy_process_group()
 
 

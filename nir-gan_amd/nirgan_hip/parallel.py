@@ -24,10 +24,9 @@ class GradReducer:
         self.rank = dist.get_rank(group)
 
     def all_reduce_mean(self, flat_grad: torch.Tensor) -> None:
-        if self.world == 1:
-            return
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-        flat_grad.mul_(1.0 / self.world)
+        if self.world > 1:
+            flat_grad.mul_(1.0 / self.world)
 
     def broadcast_params(self, flat_params: torch.Tensor, src: int = 0) -> None:
         """Make every rank start from rank ``src``'s weights (DDP does this at wrap time)."""
