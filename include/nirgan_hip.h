@@ -154,7 +154,7 @@ int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream);
  *   g is a halo'd buffer [B][g_hp][g_wp][C]; g_fold = 1 folds a reflect halo of width g_pad
  *   back onto the interior (adjoint of ReflectionPad2d), g_fold = 0 reads the interior only;
  *   g2 is an optional dense [B][H][W][C] term (skip connection).
- *   g_z = g_a * act'(a);  dy = norm ? rstd*(g_z - mean(g_z) - z*mean(g_z*z)) : g_z.
+ *   g_z = g_a * act'(z), z = norm ? (y - mean)*rstd : y;  dy = norm ? rstd*(g_z - mean(g_z) - z*mean(g_z*z)) : g_z.
  * dy is written to the interior (d_pad) of a zero-halo buffer that feeds the data- and
  * weight-gradient GEMMs; gsum_out (optional, dense) receives g_a; dbias (optional, [C])
  * accumulates sum dy.
@@ -162,7 +162,7 @@ int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream);
 typedef struct {
     const float* g; int g_hp, g_wp, g_pad, g_fold;
     const float* g2;
-    const float* a; int a_hp, a_wp, a_pad;   /* activated output (mask source); may be NULL when act == NONE */
+    const float* a; int a_hp, a_wp, a_pad;   /* unused (kept for ABI stability): the mask is the sign of z recomputed from y */
     int act; float slope;
     const float* y; const float* mean; const float* rstd; int norm;
     int B, H, W, C;

@@ -182,7 +182,6 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
         }
         const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
         const float* g2b = p.g2 ? p.g2 + size_t(b) * p.HW * p.C : nullptr;
-        const float* ab = p.a ? p.a + size_t(b) * p.a_img + p.a_org : nullptr;
         const float* yb = p.y ? p.y + size_t(b) * p.HW * p.C : nullptr;
         float* db = p.dy + size_t(b) * p.d_img + p.d_org;
         const int start = chunk * p.ppc;
@@ -203,19 +202,20 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
             }
             if (g2b) ga += ld4(g2b + size_t(pix) * p.C + q * 4);
             if (p.gsum_out) st4(p.gsum_out + (size_t(b) * p.HW + pix) * p.C + q * 4, ga);
+            // z = (y - mean) * rstd is recomputed exactly as the forward computed it: its sign is the activation
+            // mask (ReLU / LeakyReLU), so the activated tensor does not have to be read back
+            f32x4 z = {0, 0, 0, 0};
+            const bool masked = p.act == NIRGAN_ACT_RELU || p.act == NIRGAN_ACT_LRELU;
+            if (p.norm || masked) z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
             f32x4 gz = ga;
-            if (p.act == NIRGAN_ACT_RELU || p.act == NIRGAN_ACT_LRELU) {
-                const f32x4 av = ld4(ab + size_t(h) * p.a_row + size_t(w) * p.C + q * 4);
+            if (masked) {
                 const float neg = p.act == NIRGAN_ACT_RELU ? 0.f : p.slope;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gz[i] = av[i] > 0.f ? gz[i] : gz[i] * neg;
+                for (int i = 0; i < 4; ++i) gz[i] = z[i] > 0.f ? gz[i] : gz[i] * neg;
             }
             st4(db + size_t(h) * p.d_row + size_t(w) * p.C + q * 4, gz);
             s1 += gz;
-            if (p.norm) {
-                const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
-                s2 += gz * z;
-            }
+            if (p.norm) s2 += gz * z;
         }
     }
     rg_reduce2(s1, s2, lds, tid, q4, nrg);
@@ -309,8 +309,8 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     NG_REQUIRE(!d->g_fold || (d->g_pad < d->H && d->g_pad < d->W), "instnorm_bwd: fold halo wider than the image");
     NG_REQUIRE(d->d_hp == d->H + 2 * d->d_pad && d->d_wp == d->W + 2 * d->d_pad, "instnorm_bwd: dy geometry mismatch");
     const bool masked = d->act == NIRGAN_ACT_RELU || d->act == NIRGAN_ACT_LRELU;
-    NG_REQUIRE(!masked || (d->a && d->a_hp == d->H + 2 * d->a_pad && d->a_wp == d->W + 2 * d->a_pad), "instnorm_bwd: activation mask source missing or mismatched");
-    NG_REQUIRE(!d->norm || (d->y && d->mean && d->rstd && d->ws), "instnorm_bwd: y/mean/rstd/ws required when norm");
+    NG_REQUIRE(!(masked || d->norm) || d->y, "instnorm_bwd: y (pre-activation input of the block) required for the mask / statistics");
+    NG_REQUIRE(!d->norm || (d->mean && d->rstd && d->ws), "instnorm_bwd: mean/rstd/ws required when norm");
     InBwd p;
     p.g = d->g; p.g_row = d->g_wp * d->C; p.g_img = d->g_hp * p.g_row; p.g_pad = d->g_pad; p.g_fold = d->g_fold;
     p.g2 = d->g2;

@@ -304,8 +304,10 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
         d.a, d.a_hp, d.a_wp, d.a_pad = a.ptr, a.hp, a.wp, a.pad
     d.act, d.slope = act, slope
     d.norm = 1 if norm else 0
+    if y is not None:
+        d.y = y.ptr
     if norm:
-        d.y, d.mean, d.rstd = y.ptr, stats[0].data_ptr(), stats[1].data_ptr()
+        d.mean, d.rstd = stats[0].data_ptr(), stats[1].data_ptr()
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     d.B, d.H, d.W, d.C = B, H, W, Cc
     d.dy, d.d_hp, d.d_wp, d.d_pad = dy.ptr, dy.hp, dy.wp, dy.pad

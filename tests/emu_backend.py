@@ -256,17 +256,22 @@ class EmuBackend:
             ga += arr(d.g2, B * H * W * Cc).reshape(B, H, W, Cc)
         if d.gsum_out:
             arr(d.gsum_out, B * H * W * Cc).reshape(B, H, W, Cc)[:] = ga
+        z = None
+        if d.norm or d.act in (1, 2):
+            y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float32)
+            if d.norm:
+                mean = arr(d.mean, B * Cc).reshape(B, 1, Cc)
+                rstd = arr(d.rstd, B * Cc).reshape(B, 1, Cc)
+                z = ((y - mean) * rstd)            # fp32, as the kernel (and the forward) computes it
+            else:
+                z = y
         gz = ga
         if d.act in (1, 2):
-            a = arr(d.a, B * d.a_hp * d.a_wp * Cc).reshape(B, d.a_hp, d.a_wp, Cc)[:, d.a_pad:d.a_pad + H, d.a_pad:d.a_pad + W]
-            gz = np.where(a > 0, ga, ga * (0.0 if d.act == 1 else d.slope))
+            gz = np.where(z.reshape(B, H, W, Cc) > 0, ga, ga * (0.0 if d.act == 1 else d.slope))
         if d.norm:
-            y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float64)
-            mean = arr(d.mean, B * Cc).reshape(B, 1, Cc)
-            rstd = arr(d.rstd, B * Cc).reshape(B, 1, Cc)
-            z = (y - mean) * rstd
+            zz = z.astype(np.float64)
             gzf = gz.reshape(B, H * W, Cc)
-            dy = rstd * (gzf - gzf.mean(1, keepdims=True) - z * (gzf * z).mean(1, keepdims=True))
+            dy = rstd * (gzf - gzf.mean(1, keepdims=True) - zz * (gzf * zz).mean(1, keepdims=True))
             dy = dy.reshape(B, H, W, Cc)
         else:
             dy = gz
