@@ -28,6 +28,9 @@ sys.path.insert(0, os.path.join(ROOT, "nir-gan_amd"))
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (v_mfma_f32_32x32x16_bf16); never the 2:1-sparsity headline
+# peak the ALGORITHMIC flops are priced against, per operand precision (bf16x3 issues three bf16 products per product)
+PEAKS = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0}
 
 
 def synth(B, H, W, seed, device):
@@ -119,6 +122,12 @@ def main():
     ap.add_argument("--padding", type=int, default=0, help="Data.padding_amount (YAML default 10); 0 = BASELINE.md headline case")
     ap.add_argument("--lambda-rs", type=float, default=0.0)
     ap.add_argument("--inject", action="store_true", help="SatCLIP-inject generator (configs[3]): 9 blocks, fc 256->128x128, multiply")
+    ap.add_argument("--precision", choices=["fp32", "bf16", "bf16x3"], default="fp32",
+                    help="operand precision of the MFMA contractions; fp32 is the BASELINE.json configs[1] headline, "
+                         "bf16 is configs[4]'s 'bf16 MFMA' (fp32 accumulate, fp32 master weights, everything else fp32)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="configs[4]: every rank-step draws one resolution bucket (4*bs @128, bs @256, bs/4 @512: equal tile "
+                         "area); value is reported in 256x256-equivalent tiles/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     a = ap.parse_args()
@@ -158,13 +167,35 @@ def main():
     netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)
     rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333}
     tr = Pix2PixTrainer(netG, netD, n_blocks=a.blocks, padding=a.padding, lambda_rs=a.lambda_rs, rs_weights=rs_w,
-                        inject=inject, reducer=reducer)
+                        inject=inject, reducer=reducer, precision=a.precision)
     rgb, nir = synth(a.bs, a.size, a.size, 1234 + rank, dev)
     _step = tr.step
     tr.step = lambda r, n: _step(r, n, embeds)
+    buckets, bucket_ms = None, None
+    if a.mixed:
+        assert not a.inject and a.bs % 4 == 0, "--mixed: plain generator, bs % 4 == 0"
+        buckets = [(4 * a.bs, 128), (a.bs, 256), (a.bs // 4, 512)]
+        data = [synth(b, sz, sz, 1234 + 17 * i + rank, dev) for i, (b, sz) in enumerate(buckets)]
+        bucket_ms = [[] for _ in buckets]
+        counter = [rank]                   # ranks start on different buckets
 
-    for _ in range(max(a.warmup, 1)):
+        def mixed_step(_r, _n, timed=False):
+            i = counter[0] % len(buckets)
+            counter[0] += 1
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            out = _step(data[i][0], data[i][1], None)
+            if timed:
+                e1.record()
+                bucket_ms[i].append((e0, e1))
+            return out
+        tr.step = mixed_step
+
+    for _ in range(max(a.warmup, 3 if a.mixed else 1)):
         tr.step(rgb, nir)
+    if a.mixed:
+        tr._prepare(a.bs, 256, 256)        # the probes bracket the 256x256 bucket's launches
     kinds, plans = mfma_probes(tr)
     if a.no_probe:
         for pl in plans:
@@ -178,7 +209,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        tr.step(rgb, nir)
+        if a.mixed:
+            tr.step(rgb, nir, True)
+        else:
+            tr.step(rgb, nir)
     barrier()
     dt = time.perf_counter() - t0
     if reducer is not None:
@@ -206,8 +240,8 @@ def main():
                 per_launch_flop = flops / nlaunch
                 avg_ms = ev_ms / n_ev
                 ach = per_launch_flop / (avg_ms * 1e-3) / 1e12
-                roofs.append({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "kernel": k,
+                roofs.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAKS[a.precision], 1), "unit": "TFLOP/s",
+                              "frac": round(ach / PEAKS[a.precision], 4), "traffic": None, "kernel": k,
                               "launches_per_step": nlaunch, "avg_launch_ms": round(avg_ms, 5),
                               "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
                               "share_of_step_time": round(avg_ms * nlaunch / ms, 3)})
@@ -219,24 +253,35 @@ def main():
                 pmc = {}
             for r in roofs:
                 ent = pmc.get(r["kernel"])
-                if ent and a.bs == 16 and a.size == 256 and a.blocks == 6 and a.padding == 0:
+                if ent and a.bs == 16 and a.size == 256 and a.blocks == 6 and a.padding == 0 and a.precision == "fp32" and not a.mixed:
                     r["traffic"] = ent["hbm_bytes_per_launch_corrected"]
                     r["traffic_unit"] = "bytes/launch (PMC, res-block layer)"
             roofs.sort(key=lambda r: -r["share_of_step_time"])
             roof = roofs[0] if roofs else None
             roof_other = roofs[1:] or None
         gflop_tile = {(6, 0): 257.0, (6, 10): 290.5, (9, 0): 344.0, (9, 10): 391.6}.get((a.blocks, a.padding))
+        dtype = {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate", "bf16x3": "f32 as 2 bf16 terms (3 products), f32 accumulate"}[a.precision]
+        mfma = {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA (fp32 accumulate/master)", "bf16x3": "bf16x3 split-fp32 MFMA"}[a.precision]
+        if a.mixed:
+            workload = (f"configs[4]: mixed-resolution buckets {[f'{b}@{sz}' for b, sz in buckets]} per GPU (one bucket per rank-step, "
+                        f"equal tile area), {a.blocks}-block ResnetGenerator + PatchGAN, GAN+L1"
+                        + (f"+RS(l={a.lambda_rs})" if a.lambda_rs else "") + f", padding={a.padding}, {mfma}; value in 256x256-equivalent tiles/s")
+        else:
+            workload = (f"configs[1]: {a.blocks}-block ResnetGenerator + 3-layer PatchGAN, bs={a.bs}/GPU, "
+                        f"{a.size}x{a.size}, GAN+L1" + (f"+RS(l={a.lambda_rs})" if a.lambda_rs else "")
+                        + (", SatCLIP inject" if a.inject else "") + f", padding={a.padding}, {mfma}")
         out = {"metric": "256x256 RGB tiles/sec (G+D fwd+bwd+step)", "value": round(value, 3), "unit": "tiles/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"configs[1]: {a.blocks}-block ResnetGenerator + 3-layer PatchGAN, bs={a.bs}/GPU, "
-                                      f"{a.size}x{a.size}, GAN+L1" + (f"+RS(l={a.lambda_rs})" if a.lambda_rs else "")
-                                      + (", SatCLIP inject" if a.inject else "") + f", padding={a.padding}, fp32 MFMA",
-                          "global_batch": a.bs * world, "parallelism": f"dp{world}"},
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": {"workload": workload, "global_batch": a.bs * world, "parallelism": f"dp{world}"},
                "roofline": roof}
+        if a.mixed:
+            out["buckets_rank0"] = [{"tiles": b, "size": sz, "steps": len(ev),
+                                     "raw_tiles_per_s": round(b * len(ev) / (sum(x.elapsed_time(y) for x, y in ev) * 1e-3), 2) if ev else None}
+                                    for (b, sz), ev in zip(buckets, bucket_ms)]
         if roof_other:
             out["roofline_other"] = roof_other
-        if gflop_tile:
+        if gflop_tile and not a.mixed and a.size == 256:
             out["step_tflops_algorithmic"] = round(gflop_tile * value / 1e3, 2)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.size)

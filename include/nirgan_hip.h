@@ -76,6 +76,11 @@ typedef struct {
      * `ksplit` blocks per tile, partial tiles go to split_ws [ksplit][B*OH*OW][N] and are summed (fixed order,
      * + bias) into `out` by a second small launch.  ksplit <= 1: off. */
     int ksplit; float* split_ws; int64_t split_ws_elems;
+    /* operand precision of the contraction: 0 = fp32 (default; the parity path), 1 = both operands rounded to bf16
+     * (round-to-nearest-even) as they enter the matrix pipe, fp32 accumulate (BASELINE.json configs[4] "bf16 MFMA"),
+     * 2 = fp32 operands split into two bf16 terms each, three bf16 products per fp32 product (error <= ~2^-16 relative
+     * per product), fp32 accumulate.  Buffers stay fp32 in every mode. */
+    int precision;
 } nirgan_conv_desc;
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
@@ -100,6 +105,7 @@ typedef struct {
     float* slabs;     int64_t slab_elems; /* [nsplit][N][ntaps*run] */
     int nsplit, rows_per_split;           /* rows_per_split % 32 == 0, nsplit*rows_per_split >= B*OH*OW */
     const float* zero_page;
+    int precision;                        /* as in nirgan_conv_desc */
 } nirgan_wgrad_desc;
 
 int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream);

@@ -35,6 +35,28 @@ __device__ __forceinline__ unsigned long long ng_stamp() {
 
 namespace ng {
 
+// Operand precision of the contraction (descriptor field `precision`):
+//   0  fp32 operands, v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain)
+//   1  operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as they leave LDS, v_mfma_f32_32x32x16_bf16, fp32 accumulate
+//   2  fp32 operands split x = hi + mid (two bf16 terms) and contracted as hi*hi + hi*mid + mid*hi on the bf16 pipe
+//      (relative error of a product <= ~2^-16), fp32 accumulate
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 ng_bf16_round(const f32x8 v) { return __builtin_convertvector(v, bf16x8); }
+__device__ __forceinline__ f32x8 ng_bf16_widen(const bf16x8 v) { return __builtin_convertvector(v, f32x8); }
+
+template <int PREC>
+__device__ __forceinline__ void ng_mfma_bf16(const f32x8 a, const f32x8 b, f32x16& acc) {
+    const bf16x8 ah = ng_bf16_round(a), bh = ng_bf16_round(b);
+    if constexpr (PREC == 2) {
+        const bf16x8 am = ng_bf16_round(a - ng_bf16_widen(ah)), bm = ng_bf16_round(b - ng_bf16_widen(bh));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 struct ConvParams {
     const float* in;
     const float* w;
@@ -51,10 +73,11 @@ struct ConvParams {
     int ksplit;                // > 1: the K-steps are divided over ksplit blocks per tile, partial tiles go to split_ws
     float* split_ws;           // [ksplit][M][N] dense
     unsigned long long* dbg;   // diagnostic build only
+    int prec;                  // 0 fp32, 1 bf16 operands, 2 bf16x3 split (host-side dispatch only)
 };
 
 
-template <int BN>
+template <int BN, int PREC>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* st0, char* st1) {
     constexpr int BM = 128;
     constexpr int A_BYTES = BM * 128;
@@ -140,27 +163,62 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     // buffer), so the LDS latency sits under 1024 MFMA cycles instead of in front of them
     auto compute = [&](const char* sA) {
         const char* sB = sA + A_BYTES;
-        f32x4 a[2][2], b[2][NT];
-        auto load = [&](int g, int slot) {
-            const int chunk = 2 * g + half;
+        if constexpr (PREC == 0) {
+            f32x4 a[2][2], b[2][NT];
+            auto load = [&](int g, int slot) {
+                const int chunk = 2 * g + half;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                a[slot][mt] = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + ((chunk ^ a_key[mt]) << 4));
+                for (int mt = 0; mt < 2; ++mt)
+                    a[slot][mt] = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + ((chunk ^ a_key[mt]) << 4));
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                b[slot][nt] = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + ((chunk ^ b_key[nt]) << 4));
-        };
-        load(0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+                    b[slot][nt] = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + ((chunk ^ b_key[nt]) << 4));
+            };
+            load(0, 0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g + 1 < 4) load(g + 1, (g + 1) & 1);
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) load(g + 1, (g + 1) & 1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][mt][j], b[g & 1][nt][j], acc[mt][nt], 0, 0, 0);
+            }
+        } else {
+            // bf16 pipe: one MFMA contracts 16 k = the chunks 4h..4h+3 of the 32-float slice; lanes 0-31 hold the 8 k of
+            // chunks 4h, 4h+1 of their row, lanes 32-63 those of chunks 4h+2, 4h+3 (same assignment for A and B)
+            f32x8 a[2][2], b[2][NT];
+            auto load = [&](int h, int slot) {
+                const int c0 = 4 * h + 2 * half;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + ((c0 ^ a_key[mt]) << 4));
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + (((c0 + 1) ^ a_key[mt]) << 4));
+                    a[slot][mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + ((c0 ^ b_key[nt]) << 4));
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + (((c0 + 1) ^ b_key[nt]) << 4));
+                    b[slot][nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+            // PREC 1 prefetches the second half's fragments under the first half's MFMAs; the split variant needs the
+            // registers for the hi/mid terms and reads each half just before use
+            constexpr bool PF = PREC == 1;
+            load(0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int slot = PF ? (h & 1) : 0;
+                if (PF && h + 1 < 2) load(h + 1, (h + 1) & 1);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][mt][j], b[g & 1][nt][j], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) ng_mfma_bf16<PREC>(a[slot][mt], b[slot][nt], acc[mt][nt]);
+                if (!PF && h + 1 < 2) load(h + 1, 0);
+            }
         }
     };
 
@@ -176,6 +234,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     // writes do not alias the fragment reads and can interleave them; the sched_group_barrier sequence asks for
     // fragment reads first, then quads of MFMAs with one load's arithmetic + issue in the shadow of each quad.
     auto hints = [&]() {
+        if constexpr (PREC != 0) return;
         __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -306,10 +365,11 @@ struct WgradParams {
     int tap_off[NIRGAN_MAX_TAPS];
     int K, OW, OH, OHW, M, N;
     int rows_per_split, nsplit, ntiles_n, ntiles_k;
+    int prec;
 };
 
 
-template <int TN>
+template <int TN, int PREC>
 __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block_id, char* st0, char* st1) {
     constexpr int P_BYTES = 32 * TN * 4;
     constexpr int Q_BYTES = 32 * 128 * 4;
@@ -402,38 +462,72 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
     // 4 pixel-pair steps per group: the 8 fragment reads of group g+1 are issued before the 16 MFMAs of group g
     auto compute = [&](const char* sP) {
         const char* sQ = sP + P_BYTES;
-        float a[2][4][EA];
-        f32x2 b[2][4];
-        auto load = [&](int g, int slot) {
+        if constexpr (PREC == 0) {
+            float a[2][4][EA];
+            f32x2 b[2][4];
+            auto load = [&](int g, int slot) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kk = 4 * g + i;
-                if constexpr (EA == 2) {
-                    const f32x2 v = *reinterpret_cast<const f32x2*>(sP + a_off + kk * (2 * TN * 4));
-                    a[slot][i][0] = v[0]; a[slot][i][1] = v[1];
-                } else {
-                    a[slot][i][0] = *reinterpret_cast<const float*>(sP + a_off + kk * (2 * TN * 4));
+                for (int i = 0; i < 4; ++i) {
+                    const int kk = 4 * g + i;
+                    if constexpr (EA == 2) {
+                        const f32x2 v = *reinterpret_cast<const f32x2*>(sP + a_off + kk * (2 * TN * 4));
+                        a[slot][i][0] = v[0]; a[slot][i][1] = v[1];
+                    } else {
+                        a[slot][i][0] = *reinterpret_cast<const float*>(sP + a_off + kk * (2 * TN * 4));
+                    }
+                    b[slot][i] = *reinterpret_cast<const f32x2*>(sQ + b_off + kk * 1024);
                 }
-                b[slot][i] = *reinterpret_cast<const f32x2*>(sQ + b_off + kk * 1024);
+            };
+            load(0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g + 1 < 4) load(g + 1, (g + 1) & 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < EA; ++e) {
+                        acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][0], acc[e][0], 0, 0, 0);
+                        acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][1], acc[e][1], 0, 0, 0);
+                    }
             }
-        };
-        load(0, 0);
+        } else {
+            // bf16 pipe: one MFMA contracts the 16 pixels 16q..16q+15; lanes 0-31 hold the even ones, lanes 32-63 the odd
+            // ones of their n (A) / J (B) column -- the same per-lane addresses as the fp32 path, 8 pixel pairs at a time
+            f32x8 a[2][EA], b[2][2];
+            auto load = [&](int q, int slot) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g + 1 < 4) load(g + 1, (g + 1) & 1);
+                for (int i = 0; i < 8; ++i) {
+                    const int kk = 8 * q + i;
+                    if constexpr (EA == 2) {
+                        const f32x2 v = *reinterpret_cast<const f32x2*>(sP + a_off + kk * (2 * TN * 4));
+                        a[slot][0][i] = v[0]; a[slot][1][i] = v[1];
+                    } else {
+                        a[slot][0][i] = *reinterpret_cast<const float*>(sP + a_off + kk * (2 * TN * 4));
+                    }
+                    const f32x2 w = *reinterpret_cast<const f32x2*>(sQ + b_off + kk * 1024);
+                    b[slot][0][i] = w[0]; b[slot][1][i] = w[1];
+                }
+            };
+            constexpr bool PF = PREC == 1;
+            load(0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int q = 0; q < 2; ++q) {
+                const int slot = PF ? (q & 1) : 0;
+                if (PF && q + 1 < 2) load(q + 1, (q + 1) & 1);
 #pragma unroll
                 for (int e = 0; e < EA; ++e) {
-                    acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][0], acc[e][0], 0, 0, 0);
-                    acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][1], acc[e][1], 0, 0, 0);
+                    ng_mfma_bf16<PREC>(a[slot][e], b[slot][0], acc[e][0]);
+                    ng_mfma_bf16<PREC>(a[slot][e], b[slot][1], acc[e][1]);
                 }
+                if (!PF && q + 1 < 2) load(q + 1, 0);
+            }
         }
     };
 
     // same structure as conv_tile: two distinct LDS stage objects, loop unrolled by two, the LDS-DMA of the next
     // 32 pixels issued between the MFMAs of the current ones
     auto hints = [&]() {
+        if constexpr (PREC != 0) return;
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -548,6 +642,8 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.M = int(M); p.N = d->N;
     p.mtiles = (p.M + 127) / 128;
     p.ntiles = d->N > 64 ? (d->N + 127) / 128 : 1;
+    NG_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv: precision=%d (0 fp32, 1 bf16, 2 bf16x3)", d->precision);
+    p.prec = d->precision;
     p.dbg = nullptr;
     p.ksplit = 1;
     p.split_ws = nullptr;
@@ -600,6 +696,8 @@ inline int build_wgrad_params(const nirgan_wgrad_desc* d, WgradParams& p) {
     p.rows_per_split = d->rows_per_split; p.nsplit = d->nsplit;
     p.ntiles_k = (K + 127) / 128;
     p.ntiles_n = d->N > 64 ? (d->N + 127) / 128 : 1;
+    NG_REQUIRE(d->precision >= 0 && d->precision <= 2, "wgrad_igemm: precision=%d (0 fp32, 1 bf16, 2 bf16x3)", d->precision);
+    p.prec = d->precision;
     return NIRGAN_OK;
 }
 

@@ -14,23 +14,24 @@
 
 namespace {
 
-template <int TN>
+template <int TN, int PREC = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const ng::WgradParams p) {
     __shared__ __attribute__((aligned(16))) char st0[32 * (TN + 128) * 4];
     __shared__ __attribute__((aligned(16))) char st1[32 * (TN + 128) * 4];
-    ng::wgrad_tile<TN>(p, blockIdx.x, st0, st1);
+    ng::wgrad_tile<TN, PREC>(p, blockIdx.x, st0, st1);
 }
 
 // horizontally fused launch: the data-gradient tiles of a stride-1 convolution followed by the tiles of its
 // weight gradient (both consume the same dY).  One grid: the weight-gradient blocks fill the partly empty
 // last round of the data-gradient, and the other way round.
+template <int PREC = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const ng::ConvParams cp, const ng::WgradParams wp, const int conv_blocks) {
     __shared__ __attribute__((aligned(16))) char st0[32768];
     __shared__ __attribute__((aligned(16))) char st1[32768];
     if (int(blockIdx.x) < conv_blocks)
-        ng::conv_tile<128>(cp, blockIdx.x, st0, st1);
+        ng::conv_tile<128, PREC>(cp, blockIdx.x, st0, st1);
     else
-        ng::wgrad_tile<128>(wp, int(blockIdx.x) - conv_blocks, st0, st1);
+        ng::wgrad_tile<128, PREC>(wp, int(blockIdx.x) - conv_blocks, st0, st1);
 }
 
 // grid (K/256, N): 64 lanes x float4 cover 256 consecutive k of one row; the 4 waves of the block take the
@@ -122,11 +123,14 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     const int rc = ng::build_wgrad_params(d, p);
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(p.ntiles_n * p.ntiles_k * p.nsplit);
+#define NG_LAUNCH_WGRAD(TN, PREC) hipLaunchKernelGGL((wgrad_igemm_kernel<TN, PREC>), grid, dim3(256), 0, st, p)
     if (d->N > 64) {
-        hipLaunchKernelGGL(wgrad_igemm_kernel<128>, dim3(p.ntiles_n * p.ntiles_k * p.nsplit), dim3(256), 0, st, p);
+        if (p.prec == 0) NG_LAUNCH_WGRAD(128, 0); else if (p.prec == 1) NG_LAUNCH_WGRAD(128, 1); else NG_LAUNCH_WGRAD(128, 2);
     } else {
-        hipLaunchKernelGGL(wgrad_igemm_kernel<64>, dim3(p.ntiles_k * p.nsplit), dim3(256), 0, st, p);
+        if (p.prec == 0) NG_LAUNCH_WGRAD(64, 0); else if (p.prec == 1) NG_LAUNCH_WGRAD(64, 1); else NG_LAUNCH_WGRAD(64, 2);
     }
+#undef NG_LAUNCH_WGRAD
     return nirgan_check_launch("wgrad_igemm");
 }
 
@@ -143,7 +147,12 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     }
     const int conv_blocks = cp.mtiles * cp.ntiles;
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit;
-    hipLaunchKernelGGL(conv_wgrad_pair_kernel, dim3(conv_blocks + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), cp, wp, conv_blocks);
+    NG_REQUIRE(cp.prec == wp.prec, "conv_wgrad_pair: both halves must use the same precision");
+    const dim3 grid(conv_blocks + wgrad_blocks);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cp.prec == 0) hipLaunchKernelGGL(conv_wgrad_pair_kernel<0>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
+    else if (cp.prec == 1) hipLaunchKernelGGL(conv_wgrad_pair_kernel<1>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
+    else hipLaunchKernelGGL(conv_wgrad_pair_kernel<2>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
     return nirgan_check_launch("conv_wgrad_pair");
 }
 

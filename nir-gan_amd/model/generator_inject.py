@@ -49,7 +49,7 @@ class ResnetGenerator_inject(_HipNet):
         f = self._flat()
         cfg = {"style": self.inject_style, "use_scale": bool(self.scaling_param), "post_correction": bool(self.post_correction)}
         return GeneratorEngine(f.param_views(), f.grad_views(), self.n_blocks, B, H, W, data_pad=pad, inject=cfg,
-                               need_backward=need_bwd)
+                               need_backward=need_bwd, precision=getattr(self, "precision", "fp32"))
 
     def forward(self, input, embeds):
         return HF.GeneratorFn.apply(self, torch.is_grad_enabled(), input, embeds, *self.parameters())

@@ -133,6 +133,19 @@ class _HipNet(nn.Module):
             f.ensure()
         return f
 
+    @property
+    def precision(self) -> str:
+        """Operand precision of the MFMA contractions: 'fp32' (default, the reference's arithmetic), 'bf16', 'bf16x3'
+        (nirgan_hip/engine.py::precision_code).  Not part of the reference's API; assigning rebuilds the engines."""
+        return self.__dict__.get("_precision", "fp32")
+
+    @precision.setter
+    def precision(self, value: str):
+        from nirgan_hip.engine import precision_code
+        precision_code(value)
+        self.__dict__["_precision"] = value
+        self.__dict__["_pool_obj"] = None
+
     def _pool(self) -> HF.EnginePool:
         p = self.__dict__.get("_pool_obj")
         if p is None:
@@ -189,7 +202,8 @@ class ResnetGenerator(_HipNet):
     def _make_engine(self, key):
         B, H, W, pad, need_bwd = key
         f = self._flat()
-        return GeneratorEngine(f.param_views(), f.grad_views(), self.n_blocks, B, H, W, data_pad=pad, need_backward=need_bwd)
+        return GeneratorEngine(f.param_views(), f.grad_views(), self.n_blocks, B, H, W, data_pad=pad, need_backward=need_bwd,
+                               precision=getattr(self, "precision", "fp32"))
 
     def forward(self, input):
         return HF.GeneratorFn.apply(self, torch.is_grad_enabled(), input, None, *self.parameters())
@@ -221,7 +235,8 @@ class NLayerDiscriminator(_HipNet):
     def _make_engine(self, key):
         B, H, W, need_bwd = key
         f = self._flat()
-        return DiscriminatorEngine(f.param_views(), f.grad_views(), B, H, W, need_backward=need_bwd)
+        return DiscriminatorEngine(f.param_views(), f.grad_views(), B, H, W, need_backward=need_bwd,
+                                   precision=getattr(self, "precision", "fp32"))
 
     def forward(self, input):
         return HF.DiscriminatorFn.apply(self, torch.is_grad_enabled(), input, *self.parameters())

@@ -29,11 +29,25 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-class Ctx:
-    """Device context of an engine: allocator, zero page, stream."""
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 
-    def __init__(self, device):
+
+def precision_code(precision) -> int:
+    """'fp32' (default, the parity path) | 'bf16' (operands rounded to bf16 on the matrix pipe, fp32 accumulate) |
+    'bf16x3' (fp32 operands as two bf16 terms, three bf16 products)."""
+    if precision in PRECISIONS.values():
+        return int(precision)
+    if precision not in PRECISIONS:
+        raise NotImplementedError(f"precision [{precision}] is not implemented ('fp32', 'bf16', 'bf16x3')")
+    return PRECISIONS[precision]
+
+
+class Ctx:
+    """Device context of an engine: allocator, zero page, stream, operand precision of the contractions."""
+
+    def __init__(self, device, precision="fp32"):
         self.device = torch.device(device)
+        self.precision = precision_code(precision)
         if self.device.type != "cuda" and not L.is_emulated():
             raise RuntimeError("nirgan_hip runs on MI355X (cuda device) only; there is no CPU path")
         self.zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)
@@ -195,6 +209,7 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.out_stride, d.out_oh, d.out_ow = out_stride, out_oh, out_ow
     d.B, d.OH, d.OW, d.N = inp.B, OH, OW, N
     d.zero_page = ctx.zero_page.data_ptr()
+    d.precision = ctx.precision
     ctx.keep.append(d)
     if plan is not None:
         M = inp.B * OH * OW
@@ -235,6 +250,7 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     d.B, d.OH, d.OW, d.N = p.B, OH, OW, N
     d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
     d.zero_page = ctx.zero_page.data_ptr()
+    d.precision = ctx.precision
     ctx.keep.append(d)
     imap = ctx.i32(spec.index_map)
     if pair_with is not None:

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("out", fp), ("out_elems", i64), ("out_hp", i32), ("out_wp", i32), ("out_cs", i32),
                 ("out_stride", i32), ("out_oh", i32), ("out_ow", i32),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32), ("zero_page", fp),
-                ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64)]
+                ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -39,7 +39,8 @@ class WgradDesc(C.Structure):
                 ("q_oh", i32), ("q_ow", i32), ("run", i32), ("ntaps", i32),
                 ("tap_dh", i32 * MAX_TAPS), ("tap_dw", i32 * MAX_TAPS),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32),
-                ("slabs", fp), ("slab_elems", i64), ("nsplit", i32), ("rows_per_split", i32), ("zero_page", fp)]
+                ("slabs", fp), ("slab_elems", i64), ("nsplit", i32), ("rows_per_split", i32), ("zero_page", fp),
+                ("precision", i32)]
 
 
 class InFwdDesc(C.Structure):

@@ -25,8 +25,8 @@ def generator_layout(n_blocks: int) -> dict:
 
 
 class _Engine:
-    def __init__(self, device):
-        self.ctx = Ctx(device)
+    def __init__(self, device, precision="fp32"):
+        self.ctx = Ctx(device, precision)
         self.weights = Weights(self.ctx)
         self.slabs = SlabPool(self.ctx)
         self.scratch = _Scratch(self.ctx)
@@ -53,9 +53,10 @@ class GeneratorEngine(_Engine):
     """ResnetGenerator(input_nc=3, output_nc=1, ngf, n_blocks, InstanceNorm, reflect padding)."""
 
     def __init__(self, params: Dict[str, torch.Tensor], grads: Optional[Dict[str, torch.Tensor]], n_blocks: int,
-                 B: int, H: int, W: int, data_pad: int = 0, inject: Optional[dict] = None, need_backward: bool = True):
+                 B: int, H: int, W: int, data_pad: int = 0, inject: Optional[dict] = None, need_backward: bool = True,
+                 precision="fp32"):
         dev = params["model.1.weight"].device
-        super().__init__(dev)
+        super().__init__(dev, precision)
         ctx = self.ctx
         self.params, self.grads = params, grads
         self.n_blocks, self.B, self.H, self.W, self.data_pad = n_blocks, B, H, W, data_pad
@@ -251,9 +252,9 @@ class DiscriminatorEngine(_Engine):
     """NLayerDiscriminator(input_nc=4, ndf, n_layers=3, InstanceNorm): 70x70 PatchGAN."""
 
     def __init__(self, params: Dict[str, torch.Tensor], grads: Optional[Dict[str, torch.Tensor]], B: int, H: int, W: int,
-                 need_backward: bool = True):
+                 need_backward: bool = True, precision="fp32"):
         dev = params["model.0.weight"].device
-        super().__init__(dev)
+        super().__init__(dev, precision)
         ctx = self.ctx
         self.params, self.grads, self.B, self.H, self.W = params, grads, B, H, W
         ndf, in_nc = params["model.0.weight"].shape[0], params["model.0.weight"].shape[1]

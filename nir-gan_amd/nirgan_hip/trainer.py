@@ -27,10 +27,38 @@ from .nets import DiscriminatorEngine, GeneratorEngine
 RS_KEYS = ["ndvi", "ndwi", "gndvi", "savi", "msavi", "evi"]
 
 
+class _ShapeState:
+    """Engines, staging tensors and descriptors of one (B, H, W): built once per resolution bucket and kept
+    (configs[4] draws 128/256/512 tiles step by step; 288 GB of HBM hold all buckets side by side)."""
+
+    def __init__(self, tr: "Pix2PixTrainer", B, H, W):
+        dev = tr.flatG.flat.device
+        gp, gg = tr.flatG.param_views(), tr.flatG.grad_views()
+        dp, dg = tr.flatD.param_views(), tr.flatD.grad_views()
+        self.G = GeneratorEngine(gp, gg, tr.n_blocks, B, H, W, data_pad=tr.padding, inject=tr.inject, precision=tr.precision)
+        self.D2 = DiscriminatorEngine(dp, dg, 2 * B, H, W, precision=tr.precision)
+        self.D1 = DiscriminatorEngine(dp, dg, B, H, W, precision=tr.precision)
+        self.rgb = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
+        self.nir = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
+        self.n_patch = self.D1.B * self.D1.out[0].numel()
+        # pixel-loss descriptor (static pointers)
+        d = L.PixLossDesc()
+        d.rgb, d.nir, d.pred = self.rgb.data_ptr(), self.nir.data_ptr(), self.G.pred.data_ptr()
+        d.B, d.H, d.W = B, H, W
+        d.w_l1 = tr.lambda_l1
+        for k in RS_KEYS:
+            w = float(tr.rs_weights.get("lambda_" + k, 0.0)) if tr.lambda_rs > 0.0 else 0.0
+            setattr(d, "w_" + k, tr.lambda_rs * w if w > 0.0 else 0.0)
+        d.criterion, d.log_all = tr.rs_criterion, 0
+        d.extra, d.extra_cs, d.extra_c, d.extra_scale = self.D1.gpred.data_ptr(), 1, 0, 1.0
+        d.sums, d.grad_pred = tr.losses.data_ptr() + 3 * 4, self.G.dpred.data_ptr()
+        self.pix = d
+
+
 class Pix2PixTrainer:
     def __init__(self, netG: torch.nn.Module, netD: torch.nn.Module, *, n_blocks: int, lr=2e-4, beta1=0.5,
                  lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0, rs_weights: Optional[Dict[str, float]] = None,
-                 rs_criterion="l1", padding=0, inject: Optional[dict] = None, reducer=None):
+                 rs_criterion="l1", padding=0, inject: Optional[dict] = None, reducer=None, precision="fp32"):
         self.netG, self.netD = netG, netD
         self.flatG = netG._flat() if hasattr(netG, "_flat") else FlatParams(netG)
         self.flatD = netD._flat() if hasattr(netD, "_flat") else FlatParams(netD)
@@ -42,37 +70,26 @@ class Pix2PixTrainer:
             raise NotImplementedError(f"Criterion '{rs_criterion}' not implemented. 'l1' or 'l2' are supported.")
         self.rs_criterion = 0 if rs_criterion == "l1" else 1
         self.reducer = reducer            # parallel.GradReducer or None
+        self.precision = precision        # 'fp32' | 'bf16' | 'bf16x3' (engine.precision_code)
+        self._states: Dict[tuple, _ShapeState] = {}
         self._shape = None
+        self.losses = None
         self.steps = 0
 
     # ------------------------------------------------------------------ engines for one shape
     def _prepare(self, B, H, W):
         rebuilt = self.flatG.ensure() | self.flatD.ensure()
-        if self._shape == (B, H, W) and not rebuilt:
-            return
-        dev = self.flatG.flat.device
-        self.G = GeneratorEngine(self.flatG.param_views(), self.flatG.grad_views(), self.n_blocks, B, H, W,
-                                 data_pad=self.padding, inject=self.inject)
-        self.D2 = DiscriminatorEngine(self.flatD.param_views(), self.flatD.grad_views(), 2 * B, H, W)
-        self.D1 = DiscriminatorEngine(self.flatD.param_views(), self.flatD.grad_views(), B, H, W)
-        self.rgb = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
-        self.nir = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
-        self.losses = torch.zeros(16, dtype=torch.float32, device=dev)   # 0 D_fake 1 D_real 2 G_gan 3.. pix sums[7]
+        if rebuilt:
+            self._states.clear()          # the flat ranges moved: every descriptor holds stale pointers
+        if self.losses is None or rebuilt:
+            # 0 D_fake 1 D_real 2 G_gan 3.. pix sums[7]
+            self.losses = torch.zeros(16, dtype=torch.float32, device=self.flatG.flat.device)
+        st = self._states.get((B, H, W))
+        if st is None:
+            st = self._states[(B, H, W)] = _ShapeState(self, B, H, W)
         self._shape = (B, H, W)
-        nD = self.D1.out[0].numel()
-        self._n_patch = self.D1.B * nD
-        # pixel-loss descriptor (static pointers)
-        d = L.PixLossDesc()
-        d.rgb, d.nir, d.pred = self.rgb.data_ptr(), self.nir.data_ptr(), self.G.pred.data_ptr()
-        d.B, d.H, d.W = B, H, W
-        d.w_l1 = self.lambda_l1
-        for k in RS_KEYS:
-            w = float(self.rs_weights.get("lambda_" + k, 0.0)) if self.lambda_rs > 0.0 else 0.0
-            setattr(d, "w_" + k, self.lambda_rs * w if w > 0.0 else 0.0)
-        d.criterion, d.log_all = self.rs_criterion, 0
-        d.extra, d.extra_cs, d.extra_c, d.extra_scale = self.D1.gpred.data_ptr(), 1, 0, 1.0
-        d.sums, d.grad_pred = self.losses.data_ptr() + 3 * 4, self.G.dpred.data_ptr()
-        self._pix = d
+        self.G, self.D2, self.D1, self.rgb, self.nir = st.G, st.D2, st.D1, st.rgb, st.nir
+        self._n_patch, self._pix = st.n_patch, st.pix
 
     # ------------------------------------------------------------------ one batch
     def step(self, rgb: torch.Tensor, nir: torch.Tensor, embeds: Optional[torch.Tensor] = None) -> "LossView":

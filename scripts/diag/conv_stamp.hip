@@ -10,7 +10,7 @@ void nirgan_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfp
 __global__ __launch_bounds__(256, 2) void k(const ng::ConvParams p) {
     __shared__ __attribute__((aligned(16))) char st0[32768];
     __shared__ __attribute__((aligned(16))) char st1[32768];
-    ng::conv_tile<128>(p, blockIdx.x, st0, st1);
+    ng::conv_tile<128, 0>(p, blockIdx.x, st0, st1);
 }
 
 int main() {

@@ -11,11 +11,12 @@ from nirgan_hip.trainer import Pix2PixTrainer
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 pad = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+prec = sys.argv[4] if len(sys.argv) > 4 else "fp32"
 dev = "cuda:0"
 torch.manual_seed(0)
 netG = networks.define_G(3, 1, 64, f"resnet_{nb}blocks", "instance", False, "normal", 0.02).to(dev)
 netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)
-tr = Pix2PixTrainer(netG, netD, n_blocks=nb, padding=pad)
+tr = Pix2PixTrainer(netG, netD, n_blocks=nb, padding=pad, precision=prec)
 g = torch.Generator().manual_seed(1)
 rgb = (0.02 + 0.58 * torch.rand(bs, 3, 256, 256, generator=g)).to(dev)
 nir = (0.05 + 0.75 * torch.rand(bs, 1, 256, 256, generator=g)).to(dev)
@@ -69,7 +70,7 @@ for pname, pl in plans.items():
         rows.append((s.elapsed_time(e), pname, desc, fl))
     pl.probe_idx = None
 tot = sum(r[0] for r in rows)
-print(f"bs={bs} blocks={nb} pad={pad}: sum of bracketed op times {tot:.2f} ms, {len(rows)} ops")
+print(f"bs={bs} blocks={nb} pad={pad} precision={prec}: sum of bracketed op times {tot:.2f} ms, {len(rows)} ops")
 agg = collections.OrderedDict()
 for ms, pname, desc, fl in rows:
     k = desc

@@ -22,6 +22,25 @@ def arr(ptr, n, dtype=np.float32):
     return np.ctypeslib.as_array((ct * int(n)).from_address(int(ptr)))
 
 
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest-even bf16 -> fp32 (what v_cvt_pk_bf16_f32 does), finite inputs."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = (u + (0x7FFF + ((u >> 16) & 1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
+def contract(A: np.ndarray, B: np.ndarray, precision: int) -> np.ndarray:
+    """A @ B with the operand treatment of the descriptor's `precision` (accumulation in float64 here)."""
+    if precision == 0:
+        return A.astype(np.float64) @ B.astype(np.float64)
+    ah, bh = bf16_round(A), bf16_round(B)
+    if precision == 1:
+        return ah.astype(np.float64) @ bh.astype(np.float64)
+    am, bm = bf16_round(A - ah), bf16_round(B - bh)
+    ah, bh, am, bm = (v.astype(np.float64) for v in (ah, bh, am, bm))
+    return ah @ bh + ah @ bm + am @ bh
+
+
 def obj(ref):
     return ref._obj if hasattr(ref, "_obj") else ref
 
@@ -98,7 +117,7 @@ class EmuBackend:
             for t in range(d.ntaps):
                 off = (d.tap_dh[t] * d.in_wp + d.tap_dw[t]) * d.in_cs
                 A = inp[b * in_img + base[..., None] + off + rr]
-                acc += A.astype(np.float64) @ w[:, t * d.run:(t + 1) * d.run].T.astype(np.float64)
+                acc += contract(A.reshape(-1, d.run), np.ascontiguousarray(w[:, t * d.run:(t + 1) * d.run].T), d.precision).reshape(d.OH, d.OW, d.N)
             if bias is not None:
                 acc += bias
             idx = b * out_img + obase[..., None] + np.arange(d.N)
@@ -134,11 +153,11 @@ class EmuBackend:
                 off = (d.tap_dh[t] * d.q_wp + d.tap_dw[t]) * d.q_cs
                 qs.append(q[b * d.q_hp * q_row + qbase[..., None] + off + np.arange(d.run)].reshape(-1, d.run))
             Q_all.append(np.concatenate(qs, axis=1))
-        P_all, Q_all = np.concatenate(P_all).astype(np.float64), np.concatenate(Q_all).astype(np.float64)
+        P_all, Q_all = np.concatenate(P_all), np.concatenate(Q_all)
         M = P_all.shape[0]
         for s in range(d.nsplit):
             a, e = s * d.rows_per_split, min((s + 1) * d.rows_per_split, M)
-            slabs[s] = (P_all[a:e].T @ Q_all[a:e]).astype(np.float32) if e > a else 0.0
+            slabs[s] = contract(np.ascontiguousarray(P_all[a:e].T), Q_all[a:e], d.precision).astype(np.float32) if e > a else 0.0
         return 0
 
     def nirgan_conv_igemm_group(self, descs, n, stream=None):

@@ -30,12 +30,12 @@ def close(a, b, tol, what=""):
 class Twin:
     """The same buffers on the device and on the host; descriptors are emitted against either."""
 
-    def __init__(self):
-        self.gctx = Ctx(DEV)
+    def __init__(self, precision="fp32"):
+        self.gctx = Ctx(DEV, precision)
         self.emu = EmuBackend()
         L.set_backend(self.emu)
         try:
-            self.cctx = Ctx("cpu")
+            self.cctx = Ctx("cpu", precision)
         finally:
             L.set_backend(None)
         self.pairs = []
@@ -72,68 +72,28 @@ class Twin:
             L.set_backend(None)
 
 
-CONV_CASES = [
-    # name, B, H, W, Cin, Cout, k, s, p
-    ("res3x3_256", 2, 9, 11, 256, 256, 3, 1, 1),
-    ("down3x3_s2", 2, 16, 12, 64, 128, 3, 2, 1),
-    ("d4x4_s2", 1, 18, 18, 128, 256, 4, 2, 1),
-    ("d4x4_s1_512", 1, 8, 9, 256, 512, 4, 1, 1),
-    ("small_c8_n16", 3, 10, 10, 8, 16, 3, 1, 1),
-    ("n64_tail", 1, 13, 7, 32, 64, 3, 1, 1),
-]
+from conv_cases import CONV_CASES, build_conv_case
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_forward_wgrad_dgrad(case):
+def test_conv_forward_wgrad_dgrad(case, precision):
+    """Device kernels against the numpy restatement of the same descriptors, in every operand precision: products of
+    bf16 values are exact in fp32, so the bf16 modes differ from the restatement only by summation order, like fp32."""
     _, B, H, W, Cin, Cout, k, s, p = case
     gen = torch.Generator().manual_seed(11)
-    tw = Twin()
-    OH, OW = G.conv_out(H, k, s, p), G.conv_out(W, k, s, p)
+    tw = Twin(precision)
     xg, xc = tw.halo(B, H, W, Cin, p, gen)
     wg, wc = tw.tensor(Cout, Cin, k, k, gen=gen, scale=0.05)
     bg, bc = tw.tensor(Cout, gen=gen)
-    spec = G.conv_fwd_pack(Cout, Cin, k)
-    taps = G.conv_fwd_taps(k, Cin)
-    zpad = k - 1 if s == 1 else 1
-    outs = []
-    for ctx, x, w, b in ((tw.gctx, xg, wg, bg), (tw.cctx, xc, wc, bc)):
-        plan = Plan(ctx)
-        wp = ctx.zeros(spec.N, spec.K)
-        imap = ctx.i32(spec.index_map)
-        plan.add("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, imap.data_ptr(), wp.data_ptr(), spec.N, spec.K)
-        y = Halo(ctx, B, OH, OW, Cout, 0)
-        emit_conv(plan, ctx, x, taps, wp, b, y, N=Cout, OH=OH, OW=OW, in_stride=s, in_oh=0, in_ow=0)
-        # weight gradient with dY := y (any dense tensor does) in a zero-halo buffer
-        dy = Halo(ctx, B, OH, OW, Cout, zpad)
-        gw = ctx.zeros(Cout, Cin, k, k)
-        plan2 = Plan(ctx)
-        emit_wgrad(plan2, ctx, dy, x, taps, spec, gw, N=Cout, OH=OH, OW=OW, p_oh=zpad, p_ow=zpad, q_stride=s)
-        # data gradient
-        if s == 1:
-            gx = Halo(ctx, B, H, W, Cin, p)
-            hw = [(kh, kw) for kh in range(k) for kw in range(k)]
-            dspec = G.conv_dgrad_pack(Cout, Cin, k, hw)
-            wd = ctx.zeros(dspec.N, dspec.K)
-            im2 = ctx.i32(dspec.index_map)
-            plan2.add("nirgan_pack_rows", w.data_ptr(), w.numel(), dspec.row_stride, im2.data_ptr(), wd.data_ptr(), dspec.N, dspec.K)
-            emit_conv(plan2, ctx, dy, G.conv_dgrad_s1_taps(k, Cout), wd, None, gx, N=Cin, OH=gx.hp, OW=gx.wp)
-        else:
-            gx = Halo(ctx, B, H, W, Cin, 0)
-            for ph in G.conv_dgrad_s2_phases(H, W, k, p):
-                dspec = G.conv_dgrad_pack(Cout, Cin, k, ph.taps_hw)
-                wd = ctx.zeros(dspec.N, dspec.K)
-                ctx.keep.append(wd)
-                im2 = ctx.i32(dspec.index_map)
-                plan2.add("nirgan_pack_rows", w.data_ptr(), w.numel(), dspec.row_stride, im2.data_ptr(), wd.data_ptr(), dspec.N, dspec.K)
-                emit_conv(plan2, ctx, dy, G.Taps(ph.dh, ph.dw, Cout), wd, None, gx, N=Cin, OH=ph.n_h, OW=ph.n_w,
-                          in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow)
-        outs.append((plan, plan2, y, dy, gw, gx))
-    (gp, gp2, gy, gdy, ggw, ggx), (cp, cp2, cy, cdy, cgw, cgx) = outs
+    (gp, gp2, gy, gdy, ggw, ggx) = build_conv_case(tw.gctx, xg, wg, bg, case)
+    (cp, cp2, cy, cdy, cgw, cgx) = build_conv_case(tw.cctx, xc, wc, bc, case)
     tw.run(gp, cp)
     close(gy.t, cy.t, 1e-5, "conv fwd")
-    # also against torch's own convolution (the reference's nn.Conv2d arithmetic)
-    ref = torch.nn.functional.conv2d(xc.t.permute(0, 3, 1, 2), wc, bc, stride=s)
-    close(gy.t.permute(0, 3, 1, 2), ref, 1e-4, "conv fwd vs torch")
+    if precision != "bf16":
+        # also against torch's own convolution (the reference's nn.Conv2d arithmetic)
+        ref = torch.nn.functional.conv2d(xc.t.permute(0, 3, 1, 2), wc, bc, stride=s)
+        close(gy.t.permute(0, 3, 1, 2), ref, 1e-4, "conv fwd vs torch")
     cdy.interior().copy_(cy.t)
     gdy.interior().copy_(cy.t.to(DEV))
     tw.run(gp2, cp2)

@@ -324,3 +324,83 @@ def test_inference_engines_and_tiling():
     big = torch.cat([rgb, rgb.flip(-1)], -1)[:, :, :200, :300]
     out = predict_tiled(netG, big, tile=128, margin=16)
     assert out.shape == (2, 1, 200, 300) and torch.isfinite(out).all()
+
+
+# ---------------------------------------------------------------------------------- operand precision modes
+def test_bf16x3_split_mode_keeps_fp32_parity(golden_dir):
+    """precision='bf16x3' on the device against the fp32 golden vectors of the reference: same 1e-3 bar as fp32."""
+    from nirgan_hip.trainer import Pix2PixTrainer
+    z = load(golden_dir, "f1_g6_d.npz")
+    netG, netD = make_nets(z, 6)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6, precision="bf16x3")
+    out = tr.step(torch.from_numpy(z["rgb"]).to(DEV), torch.from_numpy(z["nir"]).to(DEV)).as_dict()
+    close(tr.G.pred, z["pred"], 1e-3, "pred")
+    for k in ("loss_D", "loss_G", "loss_G_gan", "loss_G_l1"):
+        close(out[k], z[k], 1e-3, k)
+    gD = tr.flatD.grad_views()
+    for k, v in sub(z, "gD/").items():
+        if k not in O.shadowed_bias_keys("D"):
+            grad_close(gD[k], v, "gD " + k, l2=2e-3, mx=2e-2)
+
+
+def test_bf16_mode_small_net_against_bf16_restatement(golden_dir):
+    """precision='bf16' end to end on the device: inside the bf16 noise band around the oracle's bf16 restatement (the
+    per-contraction rule is checked exactly in test_gpu_kernels / test_bf16_contraction_backward_rule)."""
+    from nirgan_hip.trainer import Pix2PixTrainer
+    z = load(golden_dir, "f1_g6_d.npz")
+    netG, netD = make_nets(z, 6)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6, precision="bf16")
+    rgb, nir = torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])
+    out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
+    with O.operand_precision("bf16"):
+        ref = O.OracleTrainer(sub(z, "G0/"), sub(z, "D0/"), 6)
+        o = ref.step(rgb, nir)
+    noise = (ref.last["pred"] - torch.from_numpy(z["pred"])).abs().max().item()
+    assert noise > 1e-3
+    assert (tr.G.pred.cpu().reshape(-1) - ref.last["pred"].reshape(-1)).abs().max().item() < 0.5 * noise
+    close(out["loss_D"], o["loss_D"], 1e-2, "loss_D")
+    close(out["loss_G"], o["loss_G"], 1e-2, "loss_G")
+
+
+def test_precision_modes_fullsize_forward():
+    """ngf = 64, 256x256: bf16x3 reproduces the fp32 engine to 1e-4; bf16 sits within 5e-2 of it (and is not identical)."""
+    from model import networks
+    torch.manual_seed(0)
+    net = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
+    rgb, _ = synth(2, 256, 256, 7)
+    outs = {}
+    for prec in ("fp32", "bf16x3", "bf16"):
+        net.precision = prec
+        with torch.no_grad():
+            outs[prec] = net(rgb.to(DEV)).cpu()
+    ref = outs["fp32"]
+    assert (outs["bf16x3"] - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    d = (outs["bf16"] - ref).abs().max().item()
+    assert 1e-5 < d <= 5e-2 * ref.abs().max().item(), d
+
+
+def test_mixed_resolution_buckets_on_device():
+    """configs[4]: one trainer, three resolution buckets, engines kept per bucket; alternating buckets gives the same
+    losses as dedicated trainers on the same sequence."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+
+    def nets():
+        torch.manual_seed(0)
+        return (networks.define_G(3, 1, 16, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV),
+                networks.define_D(4, 16, "basic", 3, "instance", "normal", 0.02).to(DEV))
+    buckets = [(8, 64), (2, 128), (1, 256)]
+    data = [tuple(t.to(DEV) for t in synth(b, s, s, 40 + i)) for i, (b, s) in enumerate(buckets)]
+    g, d = nets()
+    tr = Pix2PixTrainer(g, d, n_blocks=6)
+    seq = [0, 1, 2, 0, 1, 2]
+    got = [tr.step(*data[i]).as_dict() for i in seq]
+    assert len(tr._states) == 3
+    # oracle on the same sequence (small nets: a second or two)
+    g, d = nets()
+    ref = O.OracleTrainer({k: v.cpu() for k, v in g.state_dict().items()}, {k: v.cpu() for k, v in d.state_dict().items()}, 6)
+    for n, i in enumerate(seq):
+        o = ref.step(data[i][0].cpu(), data[i][1].cpu())
+        tol = 1e-3 if n < 3 else 5e-3
+        close(got[n]["loss_D"], o["loss_D"], tol, f"loss_D step {n}")
+        close(got[n]["loss_G"], o["loss_G"], tol, f"loss_G step {n}")
