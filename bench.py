@@ -10,11 +10,16 @@ ResnetGenerator + 3-layer PatchGAN, bs=16 256x256 per GPU, GAN + L1 loss, fp32 (
 MFMA).  N > 1: one process per GPU (torchrun), tile batches sharded data-parallel, flat
 gradients all-reduced with RCCL; per-GPU work is fixed ("weak").
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the 128-wide
-implicit-GEMM convolution, conv_igemm_kernel<128>): algorithmic FLOPs of its launches
-(2*M*N*K from the descriptors) / their duration, bracketed by HIP events on the launch
-stream inside the timed steps.  `cpu_baseline` times the CPU oracle (a port, on a bounded
-sample) on rank 0 at N = 1.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel by share of step time
+(conv_wgrad_pair_kernel: data-gradient + weight-gradient tiles of one layer in one grid;
+`roofline_other` lists conv_igemm_kernel<128> and conv_group_kernel<128>): algorithmic FLOPs
+of its launches (2*M*N*K from the descriptors) / their duration, bracketed by HIP events on
+the launch stream inside the timed steps.  `cpu_baseline` times the CPU oracle (a port, on a
+bounded sample) on rank 0 at N = 1.
+
+Other workloads (not the headline): --blocks 9 --lambda-rs 1 --bs 32 (configs[2]); --inject
+--size 512 --padding 10 --bs 8 (configs[3]); --mixed --precision bf16 --blocks 9 --lambda-rs 1
+(configs[4]: resolution buckets, bf16 MFMA); --precision bf16x3 (split-fp32 on the bf16 pipe).
 """
 import argparse
 import json

@@ -263,6 +263,28 @@ int nirgan_pix_loss(const nirgan_pix_loss_desc* d, void* stream);
 int nirgan_adam(float* p, const float* g, float* m, float* v, int64_t n,
                 float lr, float beta1, float beta2, float eps, int step, void* stream);
 
+/* -------------------------------------------------------------------------------------
+ * Image-quality metrics of the train / validation loop, one pass on the device instead of the
+ * reference's `.cpu()` round trip every 10th batch (model/pix2pix.py:183-186, :281):
+ * utils/calculate_metrics.py:5-36 = F.l1_loss, F.mse_loss, kornia.metrics.psnr(pred, target, 1.0),
+ * kornia.metrics.ssim(pred, target, window_size=5, max_val=1.).mean(); utils/losses.py:11-30 ssim_loss (window 11).
+ * means[0] = mean |pred - target|, means[1] = mean (pred - target)^2, means[2] = mean of the SSIM map
+ * (Gaussian window `window` x `window`, sigma, reflect border, output size = input size:
+ *   ssim = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2) + eps), C1 = (0.01 max_val)^2, C2 = (0.03 max_val)^2);
+ * PSNR = 10 log10(max_val^2 / means[1]) is left to the caller.  pred/target: `planes` = B*C dense H x W images.
+ * ws: nirgan_image_metrics_ws_elems(planes, H, W) floats.  Deterministic (fixed-order partial sums).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* pred; const float* target;
+    int planes, H, W;
+    int window; float sigma, max_val, eps;   /* kornia: sigma 1.5, eps 1e-12; window odd, <= 11, H, W > window/2 */
+    float* ws; int64_t ws_elems;
+    float* means;                            /* 3 floats on device */
+} nirgan_metrics_desc;
+
+int64_t nirgan_image_metrics_ws_elems(int planes, int H, int W);
+int nirgan_image_metrics(const nirgan_metrics_desc* d, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).
  * ------------------------------------------------------------------------------------- */

@@ -7,9 +7,11 @@ It subclasses ``pytorch_lightning.LightningModule`` when Lightning is importable
 reference's train.py drives it unchanged) and ``torch.nn.Module`` otherwise; in both cases
 ``train_batch(batch)`` runs the whole two-optimizer batch on the fused HIP trainer.
 
-Out of scope here (validation/plot/wandb branches): validation_step's image
-logging, calculate_metrics, the SatCLIP location encoder itself -- ``coords`` may carry the
-precomputed B x 256 embeddings (as the reference's own smoke test does, pix2pix.py:509-526).
+The train / validation image metrics (calculate_metrics: L1, L2, PSNR, SSIM) are one fused device pass
+(utils/calculate_metrics.py -> nirgan_image_metrics) instead of the reference's ``.cpu()`` round trip.
+Out of scope here (plot/wandb branches): validation_step's image logging, the SatCLIP location
+encoder itself -- ``coords`` may carry the precomputed B x 256 embeddings (as the reference's own smoke test
+does, pix2pix.py:509-526).
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ from model import networks
 from nirgan_hip import functional as HF
 from nirgan_hip.optim import HipAdam
 from nirgan_hip.trainer import Pix2PixTrainer
+from utils.calculate_metrics import calculate_metrics
 
 
 class HipL1Loss(torch.nn.Module):
@@ -108,6 +111,14 @@ class Px2Px_PL(_Base):
         else:
             rgb, nir, embeds = self.extract_batch(batch)
         pred = self.forward(rgb, embeds) if embeds is not None else self.forward(rgb)
+        # train metrics every 10th batch on the first optimizer pass (pix2pix.py:181-191), computed on the device
+        if optimizer_idx == 0 and batch_idx % 10 == 0 and self._wants_metrics():
+            for k, v in calculate_metrics(pred=pred, target=nir, phase="train").items():
+                self._log(k, v)
+            if hasattr(self.netG, "scale_param"):
+                self._log("scale_param", self.netG.scale_param.item())
+            if hasattr(self.netG, "post_correction_param"):
+                self._log("post_correction_param", self.netG.post_correction_param.item())
         if optimizer_idx == 0:
             fake_AB = torch.cat((rgb, pred), 1)
             pred_fake = self.netD(fake_AB.detach())
@@ -138,16 +149,43 @@ class Px2Px_PL(_Base):
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx):
-        """Scalar part of the reference's validation (val/L1); image/plot logging is out of scope."""
+        """Scalar part of the reference's validation (pix2pix.py:259-315): val/L1, val/L2, val/PSNR, val/SSIM (the
+        ReduceLROnPlateau monitor is val/L1, :488-492), prediction/input statistics and the six index errors; the
+        image/plot/wandb logging is out of scope."""
         embeds = None
         if self.satclip == False:
             rgb, nir = self.extract_batch(batch)
         else:
             rgb, nir, embeds = self.extract_batch(batch)
-        pred = self.forward(rgb, embeds) if embeds is not None else self.forward(rgb)
-        l1 = self.criterionL1(pred, nir)
-        self._log("val/L1", l1)
-        return l1
+        nir_pred = self.predict_step(rgb, embeds) if embeds is not None else self.predict_step(rgb)
+        rgb = rgb[:, :3, :, :]
+        metrics = calculate_metrics(pred=nir_pred, target=nir, phase="val")
+        for k, v in metrics.items():
+            self._log(k, v)
+        if self._wants_metrics() and batch_idx < self._num_val_images():
+            if getattr(getattr(self.config.custom_configs, "Logging", None), "log_input_stats", False):
+                self._log("val_stats/min_pred", torch.min(nir_pred).item())
+                self._log("val_stats/max_pred", torch.max(nir_pred).item())
+                self._log("val_stats/mean_pred", torch.mean(nir_pred).item())
+                self._log("val_stats/min_input", torch.min(nir).item())
+                self._log("val_stats/max_input", torch.max(nir).item())
+                self._log("val_stats/mean_input", torch.mean(nir).item())
+            if self.opt.lambda_rs_losses > 0.0:
+                for k, v in self.rs_losses.get_and_weight_losses(rgb, nir, nir_pred, mode="logging_dict").items():
+                    self._log(k, v)
+        return metrics["val/L1"]
+
+    def _wants_metrics(self) -> bool:
+        """The reference logs only when a logger with an experiment is attached (pix2pix.py:182, :280); without
+        Lightning the values go to ``self.logged``."""
+        if _HAVE_PL:
+            lg = getattr(self, "logger", None)
+            return bool(lg) and hasattr(lg, "experiment")
+        return True
+
+    def _num_val_images(self) -> int:
+        lg = getattr(getattr(self.config, "custom_configs", None), "Logging", None)
+        return int(getattr(lg, "num_val_images", 0)) if lg is not None else 0
 
     def extract_batch(self, batch):
         rgb = batch["rgb"]

@@ -97,6 +97,12 @@ class InjectBwdDesc(C.Structure):
                 ("dz", fp), ("de", fp), ("dscale", fp)]
 
 
+class MetricsDesc(C.Structure):
+    _fields_ = [("pred", fp), ("target", fp), ("planes", i32), ("H", i32), ("W", i32),
+                ("window", i32), ("sigma", f32), ("max_val", f32), ("eps", f32),
+                ("ws", fp), ("ws_elems", i64), ("means", fp)]
+
+
 class PlanEntry(C.Structure):
     _fields_ = [("op", i32), ("desc", fp)]
 
@@ -112,6 +118,8 @@ PROTOTYPES = {
     "nirgan_reduce_rows": (i32, [fp, i32, i32, i32, fp, fp, i64, i32, i32, fp]),
     "nirgan_pack_rows": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_batch": (i32, [fp, i32, i32, fp]),
+    "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),
+    "nirgan_image_metrics": (i32, [C.POINTER(MetricsDesc), fp]),
     "nirgan_instnorm_ws_elems": (i64, [i32, i32, i32, i32]),
     "nirgan_instnorm_fwd": (i32, [C.POINTER(InFwdDesc), fp]),
     "nirgan_instnorm_bwd": (i32, [C.POINTER(InBwdDesc), fp]),

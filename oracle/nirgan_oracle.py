@@ -292,6 +292,40 @@ def rs_logging_dict(rgb, nir, pred, criterion: str = "l1") -> dict:
 
 
 # --------------------------------------------------------------------------------------
+# train / validation metrics: utils/calculate_metrics.py:5-36.  kornia==0.7.3 (requirements.txt:9)
+# is NOT installed here and not vendored under /root/reference: its published algorithm is restated --
+# kornia.metrics.ssim(img1, img2, window_size, max_val=1.0, eps=1e-12, padding='same'): 1-D Gaussian
+# exp(-x^2 / (2*1.5^2)) normalised to sum 1, applied separably with border_type='reflect'; C1 = (0.01*max_val)^2,
+# C2 = (0.03*max_val)^2; ssim = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2) + eps);
+# kornia.metrics.psnr = 10 log10(max_val^2 / mse).  PARITY UNPINNED against kornia itself; pinned by known answers
+# (tests/test_oracle_golden.py::test_metric_known_answers).
+# --------------------------------------------------------------------------------------
+def ssim_map(a: torch.Tensor, b: torch.Tensor, window_size: int = 5, max_val: float = 1.0, eps: float = 1e-12) -> torch.Tensor:
+    r = window_size // 2
+    x = torch.arange(window_size, dtype=a.dtype) - r
+    k = torch.exp(-x * x / (2.0 * 1.5 ** 2))
+    k = k / k.sum()
+    C = a.shape[1]
+    kh, kw = k.view(1, 1, -1, 1).repeat(C, 1, 1, 1), k.view(1, 1, 1, -1).repeat(C, 1, 1, 1)
+
+    def filt(t):
+        t = F.pad(t, (r, r, r, r), mode="reflect")
+        return F.conv2d(F.conv2d(t, kw, groups=C), kh, groups=C)
+    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
+    mu1, mu2 = filt(a), filt(b)
+    s1, s2, s12 = filt(a * a) - mu1 * mu1, filt(b * b) - mu2 * mu2, filt(a * b) - mu1 * mu2
+    return ((2.0 * mu1 * mu2 + c1) * (2.0 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2) + eps)
+
+
+def calculate_metrics(pred: torch.Tensor, target: torch.Tensor, phase: str = "train") -> dict:
+    """utils/calculate_metrics.py:5-36."""
+    l2 = F.mse_loss(pred, target).item()
+    return {phase + "/L1": F.l1_loss(pred, target).item(), phase + "/L2": l2,
+            phase + "/PSNR": 10.0 * math.log10(1.0 / l2) if l2 > 0 else float("inf"),
+            phase + "/SSIM": ssim_map(pred, target, 5, 1.0).mean().item()}
+
+
+# --------------------------------------------------------------------------------------
 # Px2Px_PL orchestration  [text: model/pix2pix.py is not importable here]
 # --------------------------------------------------------------------------------------
 def px_forward(pG: Params, rgb: torch.Tensor, n_blocks: int, padding: int = 0,

@@ -208,6 +208,36 @@ class EmuBackend:
             blocks += int(N) * ((int(K) + 1023) // 1024)
         return 0 if blocks == total_blocks else self._fail("pack_rows_batch: total_blocks mismatch")
 
+    # ------------------------------------------------------------------ image metrics
+    def nirgan_image_metrics_ws_elems(self, planes, H, W):
+        return planes * ((H + 31) // 32) * ((W + 31) // 32) * 3
+
+    def nirgan_image_metrics(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("metrics")
+        r = d.window // 2
+        if d.window % 2 == 0 or d.window > 11 or d.H <= r or d.W <= r:
+            return self._fail("image_metrics: bad window")
+        if d.ws_elems < self.nirgan_image_metrics_ws_elems(d.planes, d.H, d.W):
+            return self._fail("image_metrics: workspace too small")
+        n = d.planes * d.H * d.W
+        a = torch.from_numpy(arr(d.pred, n).reshape(d.planes, 1, d.H, d.W).astype(np.float64))
+        b = torch.from_numpy(arr(d.target, n).reshape(d.planes, 1, d.H, d.W).astype(np.float64))
+        x = torch.arange(d.window, dtype=torch.float64) - r
+        k = torch.exp(-x * x / (2.0 * d.sigma ** 2))
+        k = (k / k.sum())
+        k2 = (k[:, None] * k[None, :])[None, None]
+
+        def filt(t):
+            return F.conv2d(F.pad(t, (r, r, r, r), mode="reflect"), k2)
+        c1, c2 = (0.01 * d.max_val) ** 2, (0.03 * d.max_val) ** 2
+        mu1, mu2 = filt(a), filt(b)
+        s1, s2, s12 = filt(a * a) - mu1 * mu1, filt(b * b) - mu2 * mu2, filt(a * b) - mu1 * mu2
+        ssim = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2) + d.eps)
+        out = arr(d.means, 3)
+        out[0], out[1], out[2] = (a - b).abs().mean().item(), ((a - b) ** 2).mean().item(), ssim.mean().item()
+        return 0
+
     # ------------------------------------------------------------------ instance norm
     def nirgan_instnorm_ws_elems(self, B, H, W, Cc):
         return B * _in_nchunk(B, H * W, Cc) * 2 * Cc + B * 2 * Cc

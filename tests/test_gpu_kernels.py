@@ -307,3 +307,24 @@ def test_conv_split_k_matches_plain():
     close(outs[1], outs[0], 1e-5, "split-K conv")
     ref = torch.nn.functional.conv2d(x.t.permute(0, 3, 1, 2).cpu(), w.cpu(), bias.cpu())
     close(outs[1][:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref, 1e-4, "split-K conv vs torch")
+
+
+@pytest.mark.parametrize("shape,window", [((2, 1, 256, 256), 5), ((3, 1, 40, 50), 5), ((1, 2, 64, 33), 11), ((1, 1, 8, 8), 5),
+                                          ((1, 1, 70, 6), 11)])
+def test_image_metrics_kernel(shape, window):
+    """nirgan_image_metrics against the oracle's restatement of utils/calculate_metrics.py (L1, L2, SSIM mean)."""
+    import nirgan_oracle as O
+    from utils.calculate_metrics import calculate_metrics, image_metrics_device
+    g = torch.Generator().manual_seed(5)
+    pred = torch.rand(*shape, generator=g)
+    target = (pred + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    got = image_metrics_device(pred.to(DEV), target.to(DEV), window_size=window).cpu()
+    d = pred.double() - target.double()
+    ref = torch.tensor([d.abs().mean(), (d * d).mean(), O.ssim_map(pred.double(), target.double(), window).mean()])
+    close(got, ref.float(), 2e-5, "metrics")
+    again = image_metrics_device(pred.to(DEV), target.to(DEV), window_size=window).cpu()
+    assert torch.equal(got, again)          # fixed-order partial sums: bitwise reproducible
+    if window == 5:
+        m, r = calculate_metrics(pred.to(DEV), target.to(DEV), "train"), O.calculate_metrics(pred, target, "train")
+        for k in r:
+            close(torch.tensor(m[k]), torch.tensor(r[k]), 1e-4, k)

@@ -297,9 +297,22 @@ def test_px2px_pl_surface(emu, golden_dir):
         m.training_step(batch, 0, 0)
     p = m.predict_step(batch["rgb"])
     assert p.shape == (2, 1, 40, 40)
+    # validation scalars (pix2pix.py:259-283): the four image metrics, computed by the fused device pass
+    m.logged.clear()
+    v = m.validation_step(batch, 0)
+    ref = O.calculate_metrics(p, batch["nir"], "val")
+    for k in ("val/L1", "val/L2", "val/PSNR", "val/SSIM"):
+        assert abs(float(m.logged[k]) - ref[k]) <= 1e-4 * abs(ref[k]), k
+    assert abs(v - ref["val/L1"]) <= 1e-4 * ref["val/L1"]
     m.train()
     with pytest.raises(AssertionError):
         m.predict_step(batch["rgb"])
+    m.logged.clear()
+    m.training_step(batch, 10, 0)                      # every 10th batch, first optimizer pass (pix2pix.py:181-185)
+    assert "train/SSIM" in m.logged and "train/PSNR" in m.logged
+    m.logged.clear()
+    m.training_step(batch, 11, 0)
+    assert "train/SSIM" not in m.logged
 
 
 # ---------------------------------------------------------------------------------- operand precision modes
@@ -436,3 +449,26 @@ def test_mixed_resolution_buckets_share_one_trainer(emu, golden_dir):
         close(out["loss_D"], o["loss_D"], tol, f"loss_D step {i}")
         close(out["loss_G"], o["loss_G"], tol, f"loss_G step {i}")
     assert len(tr._states) == 2
+
+
+def test_calculate_metrics_surface(emu):
+    """utils.calculate_metrics.calculate_metrics keeps the reference's signature/keys (utils/calculate_metrics.py:5-36)
+    and agrees with the oracle's restatement; ssim_loss is value-only."""
+    from utils.calculate_metrics import calculate_metrics, image_metrics_device
+    from utils.losses import emd_loss, ssim_loss
+    g = torch.Generator().manual_seed(2)
+    pred = torch.rand(2, 1, 40, 50, generator=g)
+    target = (pred + 0.05 * torch.randn(2, 1, 40, 50, generator=g)).clamp(0, 1)
+    got, ref = calculate_metrics(pred, target, phase="val"), O.calculate_metrics(pred, target, "val")
+    assert list(got) == ["val/L1", "val/L2", "val/PSNR", "val/SSIM"]
+    for k in ref:
+        close(got[k], ref[k], 1e-5, k)
+    close(ssim_loss(pred, target), 1.0 - O.ssim_map(pred, target, 11).mean(), 1e-5, "ssim_loss")
+    with pytest.raises(NotImplementedError):
+        ssim_loss(pred.clone().requires_grad_(True), target)
+    with pytest.raises(NotImplementedError):
+        emd_loss(pred, target)
+    with pytest.raises(ValueError):
+        image_metrics_device(pred, target[:, :, :-1])
+    with pytest.raises(RuntimeError):
+        image_metrics_device(pred[:, :, :2, :2], target[:, :, :2, :2])      # smaller than the window radius
