@@ -285,6 +285,30 @@ typedef struct {
 int64_t nirgan_image_metrics_ws_elems(int planes, int H, int W);
 int nirgan_image_metrics(const nirgan_metrics_desc* d, void* stream);
 
+/* -------------------------------------------------------------------------------------
+ * SatCLIP location encoder, fp64 like the reference (model/satclip/load_lightweight.py:29,
+ * satclip_wrapper.py:30-35; called from model/pix2pix.py:481-484 once per batch):
+ * positional_encoding/spherical_harmonics.py:26-42 + spherical_harmonics_closed_form.py:8-40 (real spherical
+ * harmonics of degree < L at phi = deg2rad(lon + 180), theta = deg2rad(lat + 90); feature (l, m) at index l*l+l+m),
+ * then SirenNet (location_encoder.py:73-151): x <- sin(w0_i * (W_i x + b_i)) for every layer with w0_i != 0,
+ * x <- W_i x + b_i where w0_i == 0 (the last layer's Identity).  Evaluation mode (dropout off), forward only.
+ * sh_norm[l*l+l+m] = [sqrt 2 if m != 0] * sqrt((2l+1)(l-|m|)!/(4 pi (l+|m|)!)) is supplied by the host.
+ * weights[i]: [dims[i+1]][dims[i]] row-major (nn.Linear layout), biases[i] may be NULL; all device pointers,
+ * the pointer tables themselves live on the host.  features (optional): [B][L*L] copy of the harmonics.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const double* lonlat; int B;             /* [B][2] = (lon, lat) in degrees */
+    int L; const double* sh_norm;            /* legendre_polys; [L*L] on device */
+    int nlayers;                             /* linear layers incl. the last one, <= 8 */
+    const double* const* weights; const double* const* biases;
+    const int* dims;                         /* host: nlayers+1 widths, dims[0] = L*L, each <= 2048 */
+    const double* w0;                        /* host: nlayers sine frequencies (30, 1, ..., 0) */
+    double* out;                             /* [B][dims[nlayers]] */
+    double* features;                        /* optional */
+} nirgan_locenc_desc;
+
+int nirgan_location_encoder(const nirgan_locenc_desc* d, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).
  * ------------------------------------------------------------------------------------- */

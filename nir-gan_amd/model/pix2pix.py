@@ -70,7 +70,10 @@ class Px2Px_PL(_Base):
         if getattr(self.opt, "lambda_ssim", 0.0) > 0.0 or getattr(self.opt, "lambda_hist", 0.0) > 0.0:
             raise NotImplementedError("lambda_ssim / lambda_hist > 0 are not on the MI355X path (0.0 in every shipped config)")
         self.satclip = use_sat
-        self.satclip_model = None     # the location encoder is outside this path; coords may carry embeddings
+        # frozen SatCLIP location encoder (pix2pix.py:69-80): built from the checkpoint when it is there (no network
+        # here: the file must be local); without it ``coords`` must already carry the B x 256 embeddings
+        self.satclip_model = None
+        self._satclip_path = getattr(sat, "satclip_path", None) or "model/satclip/satclip-resnet50-l10.ckpt"
         self._fused = None
         self.logged = {}
 
@@ -198,9 +201,21 @@ class Px2Px_PL(_Base):
         raise NotImplementedError("SatClip Style not recognized, choose 'concat' or 'inject'")
 
     def satclip_get_inject(self, coords):
+        """pix2pix.py:481-484: lon/lat -> embeddings with the frozen location encoder (one fused fp64 HIP launch).
+        B x 256 inputs are taken as precomputed embeddings (the reference's own smoke test feeds those, :509-526)."""
         if coords is not None and coords.dim() == 2 and coords.shape[-1] == 256:
-            return coords.float()            # precomputed SatCLIP embeddings
-        raise NotImplementedError("the SatCLIP location encoder is outside the MI355X path: pass B x 256 embeddings as 'coords'")
+            return coords.float()
+        if coords is None or coords.dim() != 2 or coords.shape[-1] != 2:
+            raise ValueError("coords must be B x 2 (lon, lat) or B x 256 precomputed SatCLIP embeddings")
+        if self.satclip_model is None:
+            import os
+            if not os.path.exists(self._satclip_path):
+                raise FileNotFoundError(f"SatCLIP checkpoint '{self._satclip_path}' not found (config.satclip.satclip_path); "
+                                        "pass B x 256 embeddings as 'coords' or provide the checkpoint")
+            from model.satclip.satclip_wrapper import SatClIP_wrapper
+            self.satclip_model = SatClIP_wrapper(self._satclip_path, device=coords.device).eval()
+        with torch.no_grad():
+            return self.satclip_model.predict(coords.double()).float()
 
     def configure_optimizers(self):
         optim_g = HipAdam(self.netG.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999), net=self.netG)

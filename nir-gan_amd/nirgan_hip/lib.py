@@ -103,6 +103,12 @@ class MetricsDesc(C.Structure):
                 ("ws", fp), ("ws_elems", i64), ("means", fp)]
 
 
+class LocEncDesc(C.Structure):
+    _fields_ = [("lonlat", fp), ("B", i32), ("L", i32), ("sh_norm", fp), ("nlayers", i32),
+                ("weights", C.POINTER(fp)), ("biases", C.POINTER(fp)), ("dims", C.POINTER(i32)),
+                ("w0", C.POINTER(C.c_double)), ("out", fp), ("features", fp)]
+
+
 class PlanEntry(C.Structure):
     _fields_ = [("op", i32), ("desc", fp)]
 
@@ -118,6 +124,7 @@ PROTOTYPES = {
     "nirgan_reduce_rows": (i32, [fp, i32, i32, i32, fp, fp, i64, i32, i32, fp]),
     "nirgan_pack_rows": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_batch": (i32, [fp, i32, i32, fp]),
+    "nirgan_location_encoder": (i32, [C.POINTER(LocEncDesc), fp]),
     "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),
     "nirgan_image_metrics": (i32, [C.POINTER(MetricsDesc), fp]),
     "nirgan_instnorm_ws_elems": (i64, [i32, i32, i32, i32]),

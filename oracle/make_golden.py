@@ -307,9 +307,62 @@ def f5(name):
     print("wrote", name)
 
 
+def f6(name):
+    """SatCLIP harmonics: the reference's closed-form SH (model/satclip/positional_encoding/spherical_harmonics_closed_form.py,
+    a self-contained file: math + torch) driven exactly as SphericalHarmonics.forward drives it
+    (positional_encoding/spherical_harmonics.py:26-42; that module itself is not importable: its sibling
+    spherical_harmonics_ylm.py is missing from the reference tree).  The Siren part of the fixture is the oracle's own
+    output for seeded weights (text restatement, not pinned by the reference)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_sh_closed_form", os.path.join(REF, "model", "satclip", "positional_encoding", "spherical_harmonics_closed_form.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(77)
+    lon = torch.rand(12, generator=g, dtype=torch.float64) * 360 - 180
+    lat = torch.rand(12, generator=g, dtype=torch.float64) * 180 - 90
+    lonlat = torch.stack((lon, lat), dim=-1)
+    lonlat[0] = torch.tensor([0.0, 0.0], dtype=torch.float64)
+    lonlat[1] = torch.tensor([-180.0, 89.5], dtype=torch.float64)
+    lonlat[2] = torch.tensor([179.99, -89.5], dtype=torch.float64)
+    arrs = {"lonlat": lonlat.numpy()}
+    for L in (10, 16):
+        phi, theta = torch.deg2rad(lonlat[:, 0] + 180), torch.deg2rad(lonlat[:, 1] + 90)
+        Y = []
+        for l in range(L):
+            for m in range(-l, l + 1):
+                y = mod.SH(m, l, phi, theta)
+                if isinstance(y, float):
+                    y = y * torch.ones_like(phi)
+                Y.append(y)
+        Y = torch.stack(Y, dim=-1)
+        mine = O.spherical_harmonics(lonlat, L)
+        close(mine, Y, 1e-13, f"spherical harmonics L={L}")
+        arrs[f"Y{L}"] = Y.numpy()
+    # Siren (oracle's restatement) on seeded weights: 100 -> 64 -> 64 -> 32
+    g = torch.Generator().manual_seed(78)
+    p = {}
+    dims = [(64, 100), (64, 64)]
+    for i, (o, n) in enumerate(dims):
+        std = (1 / n) if i == 0 else (np.sqrt(6 / n) / 1.0)
+        p[f"nnet.layers.{i}.weight"] = (torch.rand(o, n, generator=g, dtype=torch.float64) * 2 - 1) * std
+        p[f"nnet.layers.{i}.bias"] = (torch.rand(o, generator=g, dtype=torch.float64) * 2 - 1) * std
+    std = np.sqrt(6 / 64)
+    p["nnet.last_layer.weight"] = (torch.rand(32, 64, generator=g, dtype=torch.float64) * 2 - 1) * std
+    p["nnet.last_layer.bias"] = (torch.rand(32, generator=g, dtype=torch.float64) * 2 - 1) * std
+    arrs.update({"siren/" + k: v.numpy() for k, v in p.items()})
+    arrs["siren_out"] = O.location_encoder_forward(p, lonlat, 10, 2).numpy()
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "f6":       # add the location-encoder fixture without touching the others
+        f6("f6_locenc.npz")
+        sys.exit(0)
     f1(6, "f1_g6_d.npz")
     f1(9, "f1_g9_rs_pad.npz", lam_rs=1.0, padding=10, H=44)
     f_inject("f1_inject.npz")
     f3("f3_losses.npz")
     f5("f5_fullsize.npz")
+    f6("f6_locenc.npz")

@@ -326,6 +326,67 @@ def calculate_metrics(pred: torch.Tensor, target: torch.Tensor, phase: str = "tr
 
 
 # --------------------------------------------------------------------------------------
+# SatCLIP location encoder, fp64 (load_lightweight.py:29).
+#   spherical_harmonics: positional_encoding/spherical_harmonics.py:26-42 with the closed-form SH of
+#     spherical_harmonics_closed_form.py:8-40 -- PINNED: oracle/make_golden.py imports that file and commits
+#     tests/golden/f6_locenc.npz.  The 'analytic' variant (spherical_harmonics_ylm.py) is missing from the reference
+#     tree; it tabulates the same functions.
+#   siren_forward: location_encoder.py:73-151 restated from the text -- the module is NOT importable
+#     (model/satclip/__init__.py pulls pytorch_lightning; positional_encoding/__init__.py needs the missing ylm file):
+#     parity UNPINNED for the MLP part; it is three F.linear + sin calls.
+# --------------------------------------------------------------------------------------
+def _assoc_legendre(l: int, m: int, x: torch.Tensor) -> torch.Tensor:
+    pmm = torch.ones_like(x)
+    if m > 0:
+        somx2 = torch.sqrt((1 - x) * (1 + x))
+        fact = 1.0
+        for _ in range(1, m + 1):
+            pmm = pmm * (-fact) * somx2
+            fact += 2.0
+    if l == m:
+        return pmm
+    pmmp1 = x * (2.0 * m + 1.0) * pmm
+    if l == m + 1:
+        return pmmp1
+    pll = torch.zeros_like(x)
+    for ll in range(m + 2, l + 1):
+        pll = ((2.0 * ll - 1.0) * x * pmmp1 - (ll + m - 1.0) * pmm) / (ll - m)
+        pmm, pmmp1 = pmmp1, pll
+    return pll
+
+
+def spherical_harmonics(lonlat: torch.Tensor, legendre_polys: int = 10) -> torch.Tensor:
+    lon, lat = lonlat[:, 0], lonlat[:, 1]
+    phi, theta = torch.deg2rad(lon + 180), torch.deg2rad(lat + 90)
+    ct = torch.cos(theta)
+    Y = []
+    for l in range(legendre_polys):
+        for m in range(-l, l + 1):
+            am = abs(m)
+            k = math.sqrt((2.0 * l + 1.0) * math.factorial(l - am) / (4 * math.pi * math.factorial(l + am)))
+            if m == 0:
+                y = k * _assoc_legendre(l, 0, ct)
+            elif m > 0:
+                y = math.sqrt(2.0) * k * torch.cos(m * phi) * _assoc_legendre(l, m, ct)
+            else:
+                y = math.sqrt(2.0) * k * torch.sin(-m * phi) * _assoc_legendre(l, am, ct)
+            Y.append(y)
+    return torch.stack(Y, dim=-1)
+
+
+def siren_forward(p: Params, x: torch.Tensor, num_layers: int, w0: float = 1.0, w0_initial: float = 30.0) -> torch.Tensor:
+    """SirenNet.forward in eval mode (dropout off): keys nnet.layers.{i}.weight/bias, nnet.last_layer.weight/bias."""
+    for i in range(num_layers):
+        x = torch.sin((w0_initial if i == 0 else w0) * F.linear(x, p[f"nnet.layers.{i}.weight"], p.get(f"nnet.layers.{i}.bias")))
+    return F.linear(x, p["nnet.last_layer.weight"], p.get("nnet.last_layer.bias"))
+
+
+def location_encoder_forward(p: Params, lonlat: torch.Tensor, legendre_polys: int, num_layers: int) -> torch.Tensor:
+    """LocationEncoder.forward (location_encoder.py:267-274) on fp64 lon/lat."""
+    return siren_forward(p, spherical_harmonics(lonlat.double(), legendre_polys), num_layers)
+
+
+# --------------------------------------------------------------------------------------
 # Px2Px_PL orchestration  [text: model/pix2pix.py is not importable here]
 # --------------------------------------------------------------------------------------
 def px_forward(pG: Params, rgb: torch.Tensor, n_blocks: int, padding: int = 0,

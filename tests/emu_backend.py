@@ -18,7 +18,7 @@ def arr(ptr, n, dtype=np.float32):
         return None
     if hasattr(ptr, "value"):
         ptr = ptr.value
-    ct = C.c_float if dtype == np.float32 else C.c_int32
+    ct = {np.float32: C.c_float, np.float64: C.c_double}.get(dtype, C.c_int32)
     return np.ctypeslib.as_array((ct * int(n)).from_address(int(ptr)))
 
 
@@ -207,6 +207,50 @@ class EmuBackend:
                 return rc
             blocks += int(N) * ((int(K) + 1023) // 1024)
         return 0 if blocks == total_blocks else self._fail("pack_rows_batch: total_blocks mismatch")
+
+    # ------------------------------------------------------------------ SatCLIP location encoder
+    def nirgan_location_encoder(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("locenc")
+        nf = d.L * d.L
+        if d.dims[0] != nf or d.nlayers < 1 or d.nlayers > 8:
+            return self._fail("location_encoder: bad layer table")
+        ll = arr(d.lonlat, d.B * 2, np.float64).reshape(d.B, 2)
+        K = arr(d.sh_norm, nf, np.float64)
+        phi, theta = np.deg2rad(ll[:, 0] + 180.0), np.deg2rad(ll[:, 1] + 90.0)
+        x = np.cos(theta)
+        Y = np.zeros((d.B, nf))
+        for l in range(d.L):
+            for m in range(-l, l + 1):
+                am = abs(m)
+                pmm = np.ones_like(x)
+                if am > 0:
+                    somx2, fact = np.sqrt((1 - x) * (1 + x)), 1.0
+                    for _ in range(am):
+                        pmm = pmm * (-fact) * somx2
+                        fact += 2.0
+                if l == am:
+                    P = pmm
+                else:
+                    pmmp1 = x * (2.0 * am + 1.0) * pmm
+                    P = pmmp1
+                    for q in range(am + 2, l + 1):
+                        P = ((2.0 * q - 1.0) * x * pmmp1 - (q + am - 1.0) * pmm) / (q - am)
+                        pmm, pmmp1 = pmmp1, P
+                f = l * l + l + m
+                Y[:, f] = K[f] * P if m == 0 else (K[f] * np.cos(m * phi) * P if m > 0 else K[f] * np.sin(am * phi) * P)
+        if d.features:
+            arr(d.features, d.B * nf, np.float64)[:] = Y.reshape(-1)
+        h = Y
+        for i in range(d.nlayers):
+            W = arr(d.weights[i], d.dims[i + 1] * d.dims[i], np.float64).reshape(d.dims[i + 1], d.dims[i])
+            h = h @ W.T
+            if d.biases[i]:
+                h = h + arr(d.biases[i], d.dims[i + 1], np.float64)
+            if d.w0[i] != 0.0:
+                h = np.sin(d.w0[i] * h)
+        arr(d.out, d.B * d.dims[d.nlayers], np.float64)[:] = h.reshape(-1)
+        return 0
 
     # ------------------------------------------------------------------ image metrics
     def nirgan_image_metrics_ws_elems(self, planes, H, W):

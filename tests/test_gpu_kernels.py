@@ -328,3 +328,24 @@ def test_image_metrics_kernel(shape, window):
         m, r = calculate_metrics(pred.to(DEV), target.to(DEV), "train"), O.calculate_metrics(pred, target, "train")
         for k in r:
             close(torch.tensor(m[k]), torch.tensor(r[k]), 1e-4, k)
+
+
+def test_location_encoder_kernel(golden_dir, tmp_path):
+    """nirgan_location_encoder (fp64) against the reference's closed-form harmonics (fixture f6) and the oracle's
+    Siren restatement; a SatCLIP-sized encoder (L = 10 -> 512 -> 512 -> 256, B = 32) against the oracle."""
+    import os
+    import nirgan_oracle as O
+    from model.satclip.location_encoder import LocationEncoder, SphericalHarmonics, get_neural_network, get_positional_encoding
+    z = np.load(os.path.join(golden_dir, "f6_locenc.npz"))
+    lonlat = torch.from_numpy(z["lonlat"]).to(DEV)
+    for L_ in (10, 16):
+        close(SphericalHarmonics(L_).to(DEV)(lonlat).cpu().float(), torch.from_numpy(z[f"Y{L_}"]).float(), 1e-6, "harmonics")
+        assert (SphericalHarmonics(L_).to(DEV)(lonlat).cpu() - torch.from_numpy(z[f"Y{L_}"])).abs().max().item() < 1e-12
+    torch.manual_seed(4)
+    enc = LocationEncoder(get_positional_encoding("sphericalharmonics", 10, "analytic"), get_neural_network("siren", 100, 256, 512, 2)).double().eval().to(DEV)
+    g = torch.Generator().manual_seed(9)
+    ll = torch.stack((torch.rand(32, generator=g, dtype=torch.float64) * 360 - 180, torch.rand(32, generator=g, dtype=torch.float64) * 180 - 90), -1)
+    got = enc(ll.to(DEV)).cpu()
+    p = {"nnet." + k: v.detach().cpu() for k, v in enc.nnet.state_dict().items()}
+    ref = O.location_encoder_forward(p, ll, 10, 2)
+    assert got.dtype == torch.float64 and (got - ref).abs().max().item() < 1e-11 * max(ref.abs().max().item(), 1.0)

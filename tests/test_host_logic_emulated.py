@@ -472,3 +472,48 @@ def test_calculate_metrics_surface(emu):
         image_metrics_device(pred, target[:, :, :-1])
     with pytest.raises(RuntimeError):
         image_metrics_device(pred[:, :, :2, :2], target[:, :, :2, :2])      # smaller than the window radius
+
+
+def _locenc_checkpoint(z):
+    hp = {"le_type": "sphericalharmonics", "legendre_polys": 10, "harmonics_calculation": "analytic", "min_radius": 1,
+          "max_radius": 360, "frequency_num": 10, "pe_type": "siren", "embed_dim": 32, "capacity": 64, "num_hidden_layers": 2}
+    sd = {"model.location." + k: v for k, v in sub(z, "siren/").items()}
+    sd["model.visual.conv1.weight"] = torch.zeros(1)            # the rest of SatCLIP is ignored by the loader
+    return {"hyper_parameters": hp, "state_dict": sd}
+
+
+def test_satclip_location_encoder_surface(emu, golden_dir, tmp_path):
+    """model.satclip.{location_encoder, load_lightweight, satclip_wrapper}: the reference's names, parameter keys and
+    checkpoint format (load_lightweight.py:5-35, satclip_wrapper.py:8-35); harmonics against the reference's own
+    closed-form values (fixture f6), the whole encoder against the oracle."""
+    from model.satclip.location_encoder import (LocationEncoder, SphericalHarmonics, get_neural_network,
+                                                get_positional_encoding)
+    from model.satclip.load_lightweight import get_satclip_loc_encoder
+    from model.satclip.satclip_wrapper import SatClIP_wrapper
+    z = load(golden_dir, "f6_locenc.npz")
+    lonlat = torch.from_numpy(z["lonlat"])
+    for L_ in (10, 16):
+        close(SphericalHarmonics(L_)(lonlat), z[f"Y{L_}"], 1e-12, f"harmonics L={L_}")
+    net = get_neural_network("siren", 100, 32, 64, 2)
+    assert sorted(net.state_dict()) == sorted(k[len("nnet."):] for k in sub(z, "siren/"))
+    assert float(net.layers[0].weight.detach().abs().max()) <= 1 / 100 and net.layers[0].activation.w0 == 30.0
+    path = tmp_path / "satclip.ckpt"
+    torch.save(_locenc_checkpoint(z), path)
+    enc = get_satclip_loc_encoder(str(path), "cpu")
+    assert isinstance(enc, LocationEncoder) and not enc.training and enc.nnet.last_layer.weight.dtype == torch.float64
+    out = enc(lonlat)
+    assert out.dtype == torch.float64
+    close(out, z["siren_out"], 1e-12, "encoder vs oracle")
+    emb = SatClIP_wrapper(str(path), device="cpu").predict(lonlat.float())
+    assert emb.dtype == torch.float32 and emb.shape == (lonlat.shape[0], 32) and not emb.requires_grad
+    close(emb, O.location_encoder_forward(sub(z, "siren/"), lonlat.float().double(), 10, 2).float(), 1e-6, "wrapper")
+    with pytest.raises(NotImplementedError):
+        get_positional_encoding("grid")
+    with pytest.raises(NotImplementedError):
+        get_neural_network("fcnet", 100)
+    with pytest.raises(ValueError):
+        get_positional_encoding("nope")
+    with pytest.raises(NotImplementedError):
+        enc.train()(lonlat)
+    with pytest.raises(ValueError):
+        enc.eval()(lonlat[:, :1])
