@@ -309,6 +309,24 @@ typedef struct {
 
 int nirgan_location_encoder(const nirgan_locenc_desc* d, void* stream);
 
+/* -------------------------------------------------------------------------------------
+ * Histogram matching of predicted tiles to a reference band: create_synthetic_dataset.py:34-47
+ * `match_histograms(img_np, ref_np, channel_axis=None)` per tile (scikit-image, float path
+ * `_match_cumulative_cdf`): out = interp(cumsum(src_counts)/n, cumsum(tmpl_counts)/n, tmpl_values)[src_lookup]
+ * with (values, counts) = unique(...) of each plane.  image/reference/out: [B][N] dense planes of equal size
+ * (the script resizes the reference to the tile first).  ws: nirgan_hist_match_ws_bytes(B, N) bytes, 8-byte aligned.
+ * Finite inputs (no NaN); -0.0 and +0.0 are one value, as in numpy.  Deterministic.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* image; const float* reference;
+    int B, N;
+    void* ws; int64_t ws_bytes;
+    float* out;
+} nirgan_hist_match_desc;
+
+int64_t nirgan_hist_match_ws_bytes(int B, int N);
+int nirgan_hist_match(const nirgan_hist_match_desc* d, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).
  * ------------------------------------------------------------------------------------- */

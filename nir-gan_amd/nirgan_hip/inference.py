@@ -40,3 +40,35 @@ def save_nir_npz(pred_nir: torch.Tensor, out_path: str, name: str) -> str:
     fn = os.path.join(out_path, f"{name}")
     np.savez_compressed(fn, nir=pred_nir.detach().to(torch.float16).cpu().numpy())
     return fn if fn.endswith(".npz") else fn + ".npz"
+
+
+@torch.no_grad()
+def histogram_match(image: torch.Tensor, reference: torch.Tensor) -> torch.Tensor:
+    """create_synthetic_dataset.py:34-47 on the device: ``reference`` ([B, 1, h, w], e.g. the Sentinel-2 NIR band) is
+    resized to the tile with F.interpolate(mode='bilinear', align_corners=False) semantics (nirgan_bilinear_fwd), then
+    every tile of ``image`` ([B, 1, H, W]) is matched to its reference plane (skimage.exposure.match_histograms,
+    channel_axis=None -> nirgan_hist_match).  Returns [B, 1, H, W] like the reference's helper; stays on the GPU."""
+    import ctypes as C
+    from . import lib as L
+    if image.dim() != 4 or reference.dim() != 4 or image.shape[:2] != reference.shape[:2] or image.shape[1] != 1:
+        raise ValueError(f"image/reference must be [B, 1, H, W] / [B, 1, h, w], got {tuple(image.shape)} and {tuple(reference.shape)}")
+    if image.device != reference.device or (image.device.type != "cuda" and not L.is_emulated()):
+        raise RuntimeError("nirgan_hip runs on MI355X (cuda device) only; there is no CPU path")
+    dev = image.device
+    be = L.backend()
+    st = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+    img = image.detach().to(torch.float32).contiguous()
+    ref = reference.detach().to(torch.float32).contiguous()
+    B, _, H, W = img.shape
+    if ref.shape[-2:] != (H, W):
+        up = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+        L.check(be.nirgan_bilinear_fwd(ref.data_ptr(), B, ref.shape[-2], ref.shape[-1], up.data_ptr(), H, W, st), "bilinear")
+        ref = up
+    N = H * W
+    ws = torch.empty(int(be.nirgan_hist_match_ws_bytes(B, N)) // 8, dtype=torch.int64, device=dev)
+    out = torch.empty_like(img)
+    d = L.HistMatchDesc()
+    d.image, d.reference, d.B, d.N = img.data_ptr(), ref.data_ptr(), B, N
+    d.ws, d.ws_bytes, d.out = ws.data_ptr(), ws.numel() * 8, out.data_ptr()
+    L.check(be.nirgan_hist_match(C.byref(d), st), "hist_match")
+    return out

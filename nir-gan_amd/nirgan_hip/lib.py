@@ -109,6 +109,10 @@ class LocEncDesc(C.Structure):
                 ("w0", C.POINTER(C.c_double)), ("out", fp), ("features", fp)]
 
 
+class HistMatchDesc(C.Structure):
+    _fields_ = [("image", fp), ("reference", fp), ("B", i32), ("N", i32), ("ws", fp), ("ws_bytes", i64), ("out", fp)]
+
+
 class PlanEntry(C.Structure):
     _fields_ = [("op", i32), ("desc", fp)]
 
@@ -125,6 +129,8 @@ PROTOTYPES = {
     "nirgan_pack_rows": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_location_encoder": (i32, [C.POINTER(LocEncDesc), fp]),
+    "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),
+    "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),
     "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),
     "nirgan_image_metrics": (i32, [C.POINTER(MetricsDesc), fp]),
     "nirgan_instnorm_ws_elems": (i64, [i32, i32, i32, i32]),

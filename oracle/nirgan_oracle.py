@@ -387,6 +387,32 @@ def location_encoder_forward(p: Params, lonlat: torch.Tensor, legendre_polys: in
 
 
 # --------------------------------------------------------------------------------------
+# Histogram matching: create_synthetic_dataset.py:34-47.  scikit-image is NOT installed here and not
+# vendored under /root/reference (the reference pins no version for it): the published float path of
+# skimage.exposure.match_histograms(image, reference, channel_axis=None) -- _match_cumulative_cdf -- is restated with
+# numpy.  PARITY UNPINNED against scikit-image itself; pinned by known answers (tests/test_oracle_golden.py).
+# --------------------------------------------------------------------------------------
+def match_histograms_plane(source, template):
+    import numpy as np
+    src_values, src_lookup, src_counts = np.unique(source.reshape(-1), return_inverse=True, return_counts=True)
+    tmpl_values, tmpl_counts = np.unique(template.reshape(-1), return_counts=True)
+    src_quantiles = np.cumsum(src_counts) / source.size
+    tmpl_quantiles = np.cumsum(tmpl_counts) / template.size
+    interp_a_values = np.interp(src_quantiles, tmpl_quantiles, tmpl_values)
+    return interp_a_values[src_lookup].reshape(source.shape).astype(source.dtype, copy=False)
+
+
+def histogram_match(image: torch.Tensor, reference: torch.Tensor) -> torch.Tensor:
+    """create_synthetic_dataset.py:34-47: resize the reference to the tile (bilinear), match each tile; [B, 1, H, W]."""
+    reference = F.interpolate(reference, size=image.shape[-2:], mode="bilinear", align_corners=False)
+    matched = []
+    for img, ref in zip(image, reference):
+        m = match_histograms_plane(img.squeeze().cpu().numpy(), ref.squeeze().cpu().numpy())
+        matched.append(torch.from_numpy(m).unsqueeze(0))
+    return torch.stack(matched, dim=0)
+
+
+# --------------------------------------------------------------------------------------
 # Px2Px_PL orchestration  [text: model/pix2pix.py is not importable here]
 # --------------------------------------------------------------------------------------
 def px_forward(pG: Params, rgb: torch.Tensor, n_blocks: int, padding: int = 0,

@@ -252,6 +252,28 @@ class EmuBackend:
         arr(d.out, d.B * d.dims[d.nlayers], np.float64)[:] = h.reshape(-1)
         return 0
 
+    # ------------------------------------------------------------------ histogram matching
+    def nirgan_hist_match_ws_bytes(self, B, N):
+        P = 2048
+        while P < N:
+            P *= 2
+        return B * P * 12
+
+    def nirgan_hist_match(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("hist_match")
+        if d.ws_bytes < self.nirgan_hist_match_ws_bytes(d.B, d.N):
+            return self._fail("hist_match: workspace too small")
+        img = arr(d.image, d.B * d.N).reshape(d.B, d.N)
+        tmp = arr(d.reference, d.B * d.N).reshape(d.B, d.N)
+        out = arr(d.out, d.B * d.N).reshape(d.B, d.N)
+        for b in range(d.B):
+            sv, lookup, sc = np.unique(img[b], return_inverse=True, return_counts=True)
+            tv, tc = np.unique(tmp[b], return_counts=True)
+            vals = np.interp(np.cumsum(sc) / d.N, np.cumsum(tc) / d.N, tv)
+            out[b] = vals[lookup].astype(np.float32)
+        return 0
+
     # ------------------------------------------------------------------ image metrics
     def nirgan_image_metrics_ws_elems(self, planes, H, W):
         return planes * ((H + 31) // 32) * ((W + 31) // 32) * 3

@@ -349,3 +349,29 @@ def test_location_encoder_kernel(golden_dir, tmp_path):
     p = {"nnet." + k: v.detach().cpu() for k, v in enc.nnet.state_dict().items()}
     ref = O.location_encoder_forward(p, ll, 10, 2)
     assert got.dtype == torch.float64 and (got - ref).abs().max().item() < 1e-11 * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("shape,ties", [((2, 1, 64, 64), False), ((1, 1, 256, 256), False), ((1, 1, 50, 70), False),
+                                        ((2, 1, 64, 64), True), ((1, 1, 4, 4), True), ((1, 1, 512, 512), True)])
+def test_histogram_match_kernel(shape, ties):
+    """nirgan_hist_match (bitonic sort + quantile interpolation on the device) against the numpy restatement of
+    skimage.exposure.match_histograms; sizes below / at / above one LDS chunk, non-powers of two, heavy ties."""
+    import nirgan_oracle as O
+    from nirgan_hip.inference import histogram_match
+    g = torch.Generator().manual_seed(13)
+    img = torch.randn(*shape, generator=g)
+    ref = torch.rand(*shape, generator=g) * 2 - 0.5
+    if ties:
+        img, ref = (img * 4).round() / 4, (ref * 16).round() / 16
+        img[0, 0, 0, 0], img[0, 0, 0, 1] = 0.0, -0.0
+    got = histogram_match(img.to(DEV), ref.to(DEV)).cpu()
+    want = O.histogram_match(img, ref)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1.0)
+    if not ties:
+        assert torch.equal(got.flatten().sort().values, ref.flatten().sort().values)      # a permutation of the template
+    # the script's case: low-resolution reference resized on the device first
+    small = ref[..., ::4, ::4].contiguous() if shape[-1] >= 16 else ref
+    got = histogram_match(img.to(DEV), small.to(DEV)).cpu()
+    want = O.histogram_match(img, small)
+    assert (got - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1.0)

@@ -75,3 +75,21 @@ def test_predict_tiled_shapes_and_single_tile_identity(emu, capsys):
     big = 0.02 + 0.58 * torch.rand(2, 3, 50, 37, generator=g)
     out = predict_tiled(model, big, tile=32, margin=4, batch=3)
     assert out.shape == (2, 1, 50, 37) and torch.isfinite(out).all()
+
+
+def test_histogram_match_helper(emu):
+    """nirgan_hip.inference.histogram_match = the helper of create_synthetic_dataset.py:34-47 (resize + per-tile matching)."""
+    import nirgan_oracle as O
+    from nirgan_hip.inference import histogram_match
+    g = torch.Generator().manual_seed(3)
+    pred = torch.rand(2, 1, 24, 28, generator=g)
+    s2 = torch.rand(2, 1, 6, 7, generator=g) * 0.5 + 0.2
+    got = histogram_match(pred, s2)
+    ref = O.histogram_match(pred, s2)
+    assert got.shape == (2, 1, 24, 28)
+    assert (got - ref).abs().max().item() <= 1e-6
+    q = (pred * 8).round() / 8                                  # heavy ties on both sides
+    r = (torch.rand(2, 1, 24, 28, generator=g) * 4).round() / 4
+    assert (histogram_match(q, r) - O.histogram_match(q, r)).abs().max().item() <= 1e-6
+    with pytest.raises(ValueError):
+        histogram_match(pred[:, 0], s2)
