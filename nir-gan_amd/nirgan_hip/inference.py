@@ -43,6 +43,18 @@ def save_nir_npz(pred_nir: torch.Tensor, out_path: str, name: str) -> str:
 
 
 @torch.no_grad()
+def resize_bilinear(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """F.interpolate(x, size=(H, W), mode='bilinear', align_corners=False) for [B, 1, h, w] on the device."""
+    from . import lib as L
+    dev = x.device
+    st = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+    x = x.detach().to(torch.float32).contiguous()
+    up = torch.empty(x.shape[0], 1, H, W, dtype=torch.float32, device=dev)
+    L.check(L.backend().nirgan_bilinear_fwd(x.data_ptr(), x.shape[0], x.shape[-2], x.shape[-1], up.data_ptr(), H, W, st), "bilinear")
+    return up
+
+
+@torch.no_grad()
 def histogram_match(image: torch.Tensor, reference: torch.Tensor) -> torch.Tensor:
     """create_synthetic_dataset.py:34-47 on the device: ``reference`` ([B, 1, h, w], e.g. the Sentinel-2 NIR band) is
     resized to the tile with F.interpolate(mode='bilinear', align_corners=False) semantics (nirgan_bilinear_fwd), then
@@ -61,9 +73,7 @@ def histogram_match(image: torch.Tensor, reference: torch.Tensor) -> torch.Tenso
     ref = reference.detach().to(torch.float32).contiguous()
     B, _, H, W = img.shape
     if ref.shape[-2:] != (H, W):
-        up = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
-        L.check(be.nirgan_bilinear_fwd(ref.data_ptr(), B, ref.shape[-2], ref.shape[-1], up.data_ptr(), H, W, st), "bilinear")
-        ref = up
+        ref = resize_bilinear(ref, H, W)
     N = H * W
     ws = torch.empty(int(be.nirgan_hist_match_ws_bytes(B, N)) // 8, dtype=torch.int64, device=dev)
     out = torch.empty_like(img)

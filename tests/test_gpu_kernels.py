@@ -368,10 +368,17 @@ def test_histogram_match_kernel(shape, ties):
     want = O.histogram_match(img, ref)
     assert got.shape == want.shape
     assert (got - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1.0)
-    if not ties:
-        assert torch.equal(got.flatten().sort().values, ref.flatten().sort().values)      # a permutation of the template
-    # the script's case: low-resolution reference resized on the device first
-    small = ref[..., ::4, ::4].contiguous() if shape[-1] >= 16 else ref
-    got = histogram_match(img.to(DEV), small.to(DEV)).cpu()
-    want = O.histogram_match(img, small)
-    assert (got - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1.0)
+    if not ties and all(t[b].unique().numel() == t[b].numel() for t in (img, ref) for b in range(shape[0])):
+        assert torch.equal(got.flatten().sort().values, ref.flatten().sort().values)      # no ties at all: a permutation of the template
+    # the script's case: low-resolution reference resized on the device first.  Matching is discontinuous in the
+    # template's ties (a run of equal values interpolates, values one ulp apart do not), and an upsampled image is full
+    # of ties, so the comparison is teacher-forced on the device's own resize; the resize itself is within 1e-6 of torch's
+    if shape[-1] >= 16:
+        from nirgan_hip.inference import resize_bilinear
+        small = ref[..., ::4, ::4].contiguous()
+        up = resize_bilinear(small.to(DEV), shape[-2], shape[-1]).cpu()
+        want_up = torch.nn.functional.interpolate(small, size=shape[-2:], mode="bilinear", align_corners=False)
+        assert (up - want_up).abs().max().item() <= 1e-6 * max(want_up.abs().max().item(), 1.0)
+        got = histogram_match(img.to(DEV), small.to(DEV)).cpu()
+        want = O.histogram_match(img, up)
+        assert (got - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1.0)
