@@ -33,6 +33,15 @@ from nirgan_hip.trainer import Pix2PixTrainer
 from utils.calculate_metrics import calculate_metrics
 
 
+def _cfg(node, name, default=None):
+    """Optional config entry: OmegaConf nodes, namespaces and attribute-dicts signal absence differently."""
+    try:
+        v = getattr(node, name)
+    except (AttributeError, KeyError):
+        return default
+    return default if v is None else v
+
+
 class HipL1Loss(torch.nn.Module):
     """torch.nn.L1Loss() for (prediction, target) NIR tiles on the fused HIP pixel-loss pass."""
 
@@ -67,13 +76,13 @@ class Px2Px_PL(_Base):
         if self.opt.lambda_rs_losses > 0.0:
             from utils.remote_sensing_indices import RemoteSensingIndices
             self.rs_losses = RemoteSensingIndices(mode="loss", criterion=self.opt.rs_losses_criterium)
-        if getattr(self.opt, "lambda_ssim", 0.0) > 0.0 or getattr(self.opt, "lambda_hist", 0.0) > 0.0:
+        if _cfg(self.opt, "lambda_ssim", 0.0) > 0.0 or _cfg(self.opt, "lambda_hist", 0.0) > 0.0:
             raise NotImplementedError("lambda_ssim / lambda_hist > 0 are not on the MI355X path (0.0 in every shipped config)")
         self.satclip = use_sat
         # frozen SatCLIP location encoder (pix2pix.py:69-80): built from the checkpoint when it is there (no network
         # here: the file must be local); without it ``coords`` must already carry the B x 256 embeddings
         self.satclip_model = None
-        self._satclip_path = getattr(sat, "satclip_path", None) or "model/satclip/satclip-resnet50-l10.ckpt"
+        self._satclip_path = _cfg(sat, "satclip_path") or "model/satclip/satclip-resnet50-l10.ckpt"
         self._fused = None
         self.logged = {}
 
@@ -166,7 +175,7 @@ class Px2Px_PL(_Base):
         for k, v in metrics.items():
             self._log(k, v)
         if self._wants_metrics() and batch_idx < self._num_val_images():
-            if getattr(getattr(self.config.custom_configs, "Logging", None), "log_input_stats", False):
+            if _cfg(_cfg(_cfg(self.config, "custom_configs"), "Logging"), "log_input_stats", False):
                 self._log("val_stats/min_pred", torch.min(nir_pred).item())
                 self._log("val_stats/max_pred", torch.max(nir_pred).item())
                 self._log("val_stats/mean_pred", torch.mean(nir_pred).item())
@@ -187,8 +196,7 @@ class Px2Px_PL(_Base):
         return True
 
     def _num_val_images(self) -> int:
-        lg = getattr(getattr(self.config, "custom_configs", None), "Logging", None)
-        return int(getattr(lg, "num_val_images", 0)) if lg is not None else 0
+        return int(_cfg(_cfg(_cfg(self.config, "custom_configs"), "Logging"), "num_val_images", 0))
 
     def extract_batch(self, batch):
         rgb = batch["rgb"]

@@ -64,6 +64,7 @@ class Pix2PixTrainer:
         self.flatD = netD._flat() if hasattr(netD, "_flat") else FlatParams(netD)
         self.n_blocks, self.padding, self.inject = n_blocks, padding, inject
         self.lr, self.beta1 = lr, beta1
+        self.lr_d, self.lr_g = None, None   # per-network overrides (ReduceLROnPlateau steps them separately); None = self.lr
         self.lambda_gan, self.lambda_l1, self.lambda_rs = float(lambda_gan), float(lambda_l1), float(lambda_rs)
         self.rs_weights = rs_weights or {}
         if rs_criterion not in ("l1", "l2"):
@@ -113,7 +114,7 @@ class Pix2PixTrainer:
         D2.backward(None, frozen=False, version=self.flatD.version)
         if self.reducer is not None:
             self.reducer.all_reduce_mean(self.flatD.grad)
-        self.flatD.adam_step(self.lr, self.beta1, stream=st)
+        self.flatD.adam_step(self.lr if self.lr_d is None else self.lr_d, self.beta1, stream=st)
         # ---- optimizer 1: generator against the updated, frozen discriminator
         D1.forward(parts=[(self.rgb, 0, 0), (pred, 0, 3)], version=self.flatD.version)
         L.check(be.nirgan_lsgan(D1.out.data_ptr(), npatch, 1.0, self.lambda_gan, lp + 8, D1.dout.data_ptr(), st), "lsgan")
@@ -122,7 +123,7 @@ class Pix2PixTrainer:
         G.backward(None, version=self.flatG.version)
         if self.reducer is not None:
             self.reducer.all_reduce_mean(self.flatG.grad)
-        self.flatG.adam_step(self.lr, self.beta1, stream=st)
+        self.flatG.adam_step(self.lr if self.lr_g is None else self.lr_g, self.beta1, stream=st)
         self.steps += 1
         return LossView(self, B * H * W)
 
