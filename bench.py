@@ -202,6 +202,28 @@ def main():
     if a.mixed:
         tr._prepare(a.bs, 256, 256)        # the probes bracket the 256x256 bucket's launches
     kinds, plans = mfma_probes(tr)
+    # generator-forward MFMA utilisation (second half of BASELINE.json's metric): HIP events around the generator's
+    # forward plan inside the timed steps (the launch stream is torch's current stream)
+    gen_fwd_events, gen_bwd_events = [], []
+    if not a.no_probe:
+        for eng in ([st.G for st in tr._states.values()] if a.mixed else [tr.G]):
+            def timed_forward(*args, _orig=eng.forward, _hw=(eng.Hg, eng.Wg), _b=eng.B, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = _orig(*args, **kw)
+                e1.record()
+                gen_fwd_events.append((e0, e1, _b * _hw[0] * _hw[1]))
+                return out
+            eng.forward = timed_forward
+
+            def timed_backward(*args, _orig=eng.backward, _hw=(eng.Hg, eng.Wg), _b=eng.B, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = _orig(*args, **kw)
+                e1.record()
+                gen_bwd_events.append((e0, e1, _b * _hw[0] * _hw[1]))
+                return out
+            eng.backward = timed_backward
     if a.no_probe:
         for pl in plans:
             pl.probe_idx = None
@@ -286,6 +308,25 @@ def main():
                                     for (b, sz), ev in zip(buckets, bucket_ms)]
         if roof_other:
             out["roofline_other"] = roof_other
+        if gen_fwd_events:
+            # generator forward = 69.29 (6-block) / 98.28 (9-block) GFLOP per 256x256 generator input
+            g256 = {6: 69.29, 9: 98.28}[a.blocks]          # per 65536 generator-input pixels (padded size counted below)
+            t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gen_fwd_events)
+            px = sum(n for _, _, n in gen_fwd_events)
+            tf = g256 * (px / 65536.0) / t_ms          # GFLOP / ms = TFLOP/s
+            out["gen_fwd"] = {"ms_per_call": round(t_ms / len(gen_fwd_events), 3), "tflops_algorithmic": round(tf, 2),
+                              "mfma_util": round(tf / PEAKS[a.precision], 4), "peak": round(PEAKS[a.precision], 1),
+                              "note": "generator forward incl. its instance-norm / layout kernels; algorithmic conv FLOPs / elapsed / dense MFMA peak"}
+        if gen_fwd_events and gen_bwd_events:
+            # backward = data + weight gradients of every conv except the first layer's data gradient: 2g - g1,
+            # g1 = 7x7x3x64 MACs per pixel (SURVEY 8d formula)
+            g1 = 2.0 * 49 * 3 * 64 * 65536 / 1e9
+            gfb = 3.0 * {6: 69.29, 9: 98.28}[a.blocks] - g1
+            t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gen_fwd_events + gen_bwd_events)
+            px = sum(n for _, _, n in gen_fwd_events)
+            tf = gfb * (px / 65536.0) / t_ms
+            out["gen_fwd_bwd"] = {"ms_per_step": round(t_ms / len(gen_fwd_events), 3), "tflops_algorithmic": round(tf, 2),
+                                  "mfma_util": round(tf / PEAKS[a.precision], 4)}
         if gflop_tile and not a.mixed and a.size == 256:
             out["step_tflops_algorithmic"] = round(gflop_tile * value / 1e3, 2)
         if world == 1 and not a.no_cpu_baseline:

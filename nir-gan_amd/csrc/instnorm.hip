@@ -87,18 +87,32 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InFwd p) {
     }
 }
 
-// one thread per (b, 4 channels): combine the chunk partials in chunk order (deterministic) -> mean, rstd
-__global__ __launch_bounds__(256) void in_finalize_kernel(const InFwd p, int B) {
-    const int q4 = p.C / 4;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * q4) return;
-    const int b = i / q4, q = i - b * q4;
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-    const float* w = p.ws + size_t(b) * p.nchunk * 2 * p.C;
-    for (int c = 0; c < p.nchunk; ++c) {
-        s1 += ld4(w + size_t(c) * 2 * p.C + q * 4);
-        s2 += ld4(w + size_t(c) * 2 * p.C + p.C + q * 4);
+// sum of the chunk partials of sample b (blockIdx.x): row group rg adds chunks rg, rg+nrg, ... (independent loads, 8 in
+// flight), the groups are combined through LDS in group order -- a fixed order, so the result is reproducible.
+// Result valid for tid < q4.  (One thread per channel quad walking all chunks serially cost ~17 us of pure latency.)
+__device__ __forceinline__ void chunk_sums(const float* w, int nchunk, int C, int tid, f32x4* lds, f32x4& s1, f32x4& s2) {
+    const int q4 = C / 4, nrg = in_nrg(C);
+    const int q = tid % q4, rg = tid / q4;
+    s1 = f32x4{0, 0, 0, 0};
+    s2 = f32x4{0, 0, 0, 0};
+    if (rg < nrg) {
+#pragma unroll 8
+        for (int c = rg; c < nchunk; c += nrg) {
+            s1 += ld4(w + size_t(c) * 2 * C + q * 4);
+            s2 += ld4(w + size_t(c) * 2 * C + C + q * 4);
+        }
     }
+    rg_reduce2(s1, s2, lds, tid, q4, nrg);
+}
+
+// one block per sample: chunk partials -> mean, rstd
+__global__ __launch_bounds__(256) void in_finalize_kernel(const InFwd p, int B) {
+    __shared__ f32x4 lds[512];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    f32x4 s1, s2;
+    chunk_sums(p.ws + size_t(b) * p.nchunk * 2 * p.C, p.nchunk, p.C, tid, lds, s1, s2);
+    if (tid >= p.C / 4) return;
+    const int q = tid;
     const float inv = 1.f / float(p.HW);
     const f32x4 k = ld4(p.y + size_t(b) * p.HW * p.C + q * 4);
     const f32x4 m = s1 * inv;
@@ -231,22 +245,17 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
     }
 }
 
-// one thread per (b, 4 channels): mean(g_z), mean(g_z * z) from the chunk partials, stored behind them in ws
+// one block per sample: mean(g_z), mean(g_z * z) from the chunk partials, stored behind them in ws
 __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const InBwd p, int B) {
-    const int q4 = p.C / 4;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * q4) return;
-    const int b = i / q4, q = i - b * q4;
-    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
-    const float* w = p.ws + size_t(b) * p.nchunk * 2 * p.C;
-    for (int c = 0; c < p.nchunk; ++c) {
-        s1 += ld4(w + size_t(c) * 2 * p.C + q * 4);
-        s2 += ld4(w + size_t(c) * 2 * p.C + p.C + q * 4);
-    }
+    __shared__ f32x4 lds[512];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    f32x4 s1, s2;
+    chunk_sums(p.ws + size_t(b) * p.nchunk * 2 * p.C, p.nchunk, p.C, tid, lds, s1, s2);
+    if (tid >= p.C / 4) return;
     const float inv = 1.f / float(p.HW);
     float* m = p.ws + size_t(B) * p.nchunk * 2 * p.C + size_t(b) * 2 * p.C;
-    st4(m + q * 4, s1 * inv);
-    st4(m + p.C + q * 4, s2 * inv);
+    st4(m + tid * 4, s1 * inv);
+    st4(m + p.C + tid * 4, s2 * inv);
 }
 
 __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B) {
@@ -296,7 +305,7 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
     if (d->norm) {
         NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
         hipLaunchKernelGGL(in_stats_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(in_finalize_kernel, dim3((d->B * (d->C / 4) + 255) / 256), dim3(256), 0, st, p, d->B);
+        hipLaunchKernelGGL(in_finalize_kernel, dim3(d->B), dim3(256), 0, st, p, d->B);
     }
     hipLaunchKernelGGL(in_apply_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     return nirgan_check_launch("instnorm_fwd");
@@ -325,7 +334,7 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     if (d->norm) {
-        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3((d->B * (d->C / 4) + 255) / 256), dim3(256), 0, st, p, d->B);
+        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(d->B), dim3(256), 0, st, p, d->B);
         hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p, d->B);
     }
     return nirgan_check_launch("instnorm_bwd");
