@@ -25,6 +25,15 @@ def test_descriptor_validation_rejects_bad_arguments_without_launching():
     w = L.WgradDesc()
     assert L.backend().nirgan_wgrad_igemm(w, None) == -1
     assert L.backend().nirgan_instnorm_ws_elems(2, 64, 64, 256) > 0
+    be = L.backend()
+    assert be.nirgan_image_metrics(L.MetricsDesc(), None) == -1 and b"image_metrics" in be.nirgan_last_error()
+    assert be.nirgan_image_metrics_ws_elems(2, 256, 256) == 2 * 8 * 8 * 3
+    assert be.nirgan_location_encoder(L.LocEncDesc(), None) == -1 and b"location_encoder" in be.nirgan_last_error()
+    assert be.nirgan_hist_match(L.HistMatchDesc(), None) == -1 and b"hist_match" in be.nirgan_last_error()
+    assert be.nirgan_hist_match_ws_bytes(2, 65536) == 2 * 65536 * 12 and be.nirgan_hist_match_ws_bytes(1, 1000) == 2048 * 12
+    d = L.ConvDesc()
+    d.precision = 7
+    assert be.nirgan_conv_igemm(d, None) == -1
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -286,13 +286,16 @@ def test_data_parallel_equivalence_on_device():
         assert err < 1e-4, (name, err)
 
 
-def test_training_is_stable_over_many_steps():
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+def test_training_is_stable_over_many_steps(precision):
+    """41 optimizer steps on a fixed batch: finite everywhere and the L1 term drops (in every operand precision: the bf16
+    modes keep fp32 master weights, accumulation, normalisation and Adam)."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
     torch.manual_seed(0)
     netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
     netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
-    tr = Pix2PixTrainer(netG, netD, n_blocks=6)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6, precision=precision)
     rgb, nir = synth(2, 128, 128, 5)
     rgb, nir = rgb.to(DEV), nir.to(DEV)
     first = tr.step(rgb, nir).as_dict()
