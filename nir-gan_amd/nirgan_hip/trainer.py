@@ -11,7 +11,8 @@ two-optimizer schedule, configure_optimizers :485-492):
 Differences from the reference that do not change results: the generator forward runs once
 (its parameters do not change between the two optimizer passes, so the second forward would
 reproduce ``pred`` bit for bit); the fake and real PatchGAN passes of the D step run as one
-batch of 2B (InstanceNorm is per sample); torch.cat never materialises.
+batch of 2B (InstanceNorm is per sample); torch.cat never materialises.  Optionally
+(``micro_batches=2``) the batch is cut into parts that run concurrently on separate HIP streams.
 """
 from __future__ import annotations
 
@@ -27,38 +28,79 @@ from .nets import DiscriminatorEngine, GeneratorEngine
 RS_KEYS = ["ndvi", "ndwi", "gndvi", "savi", "msavi", "evi"]
 
 
-class _ShapeState:
-    """Engines, staging tensors and descriptors of one (B, H, W): built once per resolution bucket and kept
-    (configs[4] draws 128/256/512 tiles step by step; 288 GB of HBM hold all buckets side by side)."""
+class _Micro:
+    """Engines, staging tensors and descriptors of one micro-batch [lo, hi) of one (B, H, W)."""
 
-    def __init__(self, tr: "Pix2PixTrainer", B, H, W):
+    def __init__(self, tr: "Pix2PixTrainer", lo, hi, H, W, gradG, gradD, scale):
         dev = tr.flatG.flat.device
-        gp, gg = tr.flatG.param_views(), tr.flatG.grad_views()
-        dp, dg = tr.flatD.param_views(), tr.flatD.grad_views()
-        self.G = GeneratorEngine(gp, gg, tr.n_blocks, B, H, W, data_pad=tr.padding, inject=tr.inject, precision=tr.precision)
-        self.D2 = DiscriminatorEngine(dp, dg, 2 * B, H, W, precision=tr.precision)
-        self.D1 = DiscriminatorEngine(dp, dg, B, H, W, precision=tr.precision)
+        B = hi - lo
+        self.lo, self.hi, self.B, self.scale = lo, hi, B, scale
+        gp, dp = tr.flatG.param_views(), tr.flatD.param_views()
+        self.G = GeneratorEngine(gp, gradG, tr.n_blocks, B, H, W, data_pad=tr.padding, inject=tr.inject, precision=tr.precision)
+        self.D2 = DiscriminatorEngine(dp, gradD, 2 * B, H, W, precision=tr.precision)
+        self.D1 = DiscriminatorEngine(dp, gradD, B, H, W, precision=tr.precision)
         self.rgb = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
         self.nir = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
         self.n_patch = self.D1.B * self.D1.out[0].numel()
-        # pixel-loss descriptor (static pointers)
+        # pixel-loss descriptor (static pointers); `scale` = this micro-batch's share of the batch mean
         d = L.PixLossDesc()
         d.rgb, d.nir, d.pred = self.rgb.data_ptr(), self.nir.data_ptr(), self.G.pred.data_ptr()
         d.B, d.H, d.W = B, H, W
-        d.w_l1 = tr.lambda_l1
+        d.w_l1 = tr.lambda_l1 * scale
         for k in RS_KEYS:
             w = float(tr.rs_weights.get("lambda_" + k, 0.0)) if tr.lambda_rs > 0.0 else 0.0
-            setattr(d, "w_" + k, tr.lambda_rs * w if w > 0.0 else 0.0)
+            setattr(d, "w_" + k, tr.lambda_rs * w * scale if w > 0.0 else 0.0)
         d.criterion, d.log_all = tr.rs_criterion, 0
         d.extra, d.extra_cs, d.extra_c, d.extra_scale = self.D1.gpred.data_ptr(), 1, 0, 1.0
         d.sums, d.grad_pred = tr.losses.data_ptr() + 3 * 4, self.G.dpred.data_ptr()
         self.pix = d
 
 
+class _ShapeState:
+    """Everything one (B, H, W) needs, built once per resolution bucket and kept (configs[4] draws 128/256/512 tiles
+    step by step; 288 GB of HBM hold all buckets side by side).  With micro-batches the batch is cut into equal
+    parts that run on separate HIP streams: instance norm is per sample and every loss is a mean, so the sum of the
+    parts' gradients (each scaled by its share) is the batch gradient; the HBM-bound kernels of one part run under
+    the matrix-pipe kernels of the other."""
+
+    def __init__(self, tr: "Pix2PixTrainer", B, H, W):
+        n = tr._micro_count(B, H, W)
+        self.n = n
+        per = B // n
+        self.extraG = [torch.zeros_like(tr.flatG.grad) for _ in range(n - 1)]
+        self.extraD = [torch.zeros_like(tr.flatD.grad) for _ in range(n - 1)]
+
+        def views(flat, buf):
+            return {k: buf[o:o + cnt].view(shp) for k, (o, cnt, shp) in flat.slices.items()}
+        self.micros = []
+        for i in range(n):
+            gG = tr.flatG.grad_views() if i == 0 else views(tr.flatG, self.extraG[i - 1])
+            gD = tr.flatD.grad_views() if i == 0 else views(tr.flatD, self.extraD[i - 1])
+            self.micros.append(_Micro(tr, i * per, (i + 1) * per, H, W, gG, gD, 1.0 / n))
+        dev = tr.flatG.flat.device
+        self.streams = [None] + [torch.cuda.Stream(dev) if dev.type == "cuda" else None for _ in range(n - 1)]
+
+
+class _on_stream:
+    """`with torch.cuda.stream(s)` that is a no-op for the launch stream itself (s is None) and on the CPU test seam."""
+
+    def __init__(self, s):
+        self.cm = torch.cuda.stream(s) if s is not None else None
+
+    def __enter__(self):
+        if self.cm is not None:
+            self.cm.__enter__()
+
+    def __exit__(self, *exc):
+        if self.cm is not None:
+            self.cm.__exit__(*exc)
+
+
 class Pix2PixTrainer:
     def __init__(self, netG: torch.nn.Module, netD: torch.nn.Module, *, n_blocks: int, lr=2e-4, beta1=0.5,
                  lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0, rs_weights: Optional[Dict[str, float]] = None,
-                 rs_criterion="l1", padding=0, inject: Optional[dict] = None, reducer=None, precision="fp32"):
+                 rs_criterion="l1", padding=0, inject: Optional[dict] = None, reducer=None, precision="fp32",
+                 micro_batches: int = 1):
         self.netG, self.netD = netG, netD
         self.flatG = netG._flat() if hasattr(netG, "_flat") else FlatParams(netG)
         self.flatD = netD._flat() if hasattr(netD, "_flat") else FlatParams(netD)
@@ -72,10 +114,19 @@ class Pix2PixTrainer:
         self.rs_criterion = 0 if rs_criterion == "l1" else 1
         self.reducer = reducer            # parallel.GradReducer or None
         self.precision = precision        # 'fp32' | 'bf16' | 'bf16x3' (engine.precision_code)
+        if int(micro_batches) < 1:
+            raise ValueError("micro_batches must be >= 1")
+        self.micro_batches = int(micro_batches)   # parts of the batch run on separate HIP streams (1 = off)
         self._states: Dict[tuple, _ShapeState] = {}
         self._shape = None
         self.losses = None
         self.steps = 0
+
+    def _micro_count(self, B, H, W) -> int:
+        n = self.micro_batches
+        while n > 1 and B % n:
+            n -= 1
+        return n
 
     # ------------------------------------------------------------------ engines for one shape
     def _prepare(self, B, H, W):
@@ -89,38 +140,76 @@ class Pix2PixTrainer:
         if st is None:
             st = self._states[(B, H, W)] = _ShapeState(self, B, H, W)
         self._shape = (B, H, W)
-        self.G, self.D2, self.D1, self.rgb, self.nir = st.G, st.D2, st.D1, st.rgb, st.nir
-        self._n_patch, self._pix = st.n_patch, st.pix
+        self._state = st
+        m0 = st.micros[0]                 # single-part view (tests, probes): the first micro-batch's engines
+        self.G, self.D2, self.D1, self.rgb, self.nir = m0.G, m0.D2, m0.D1, m0.rgb, m0.nir
+
+    @property
+    def pred(self) -> torch.Tensor:
+        """The step's generator output for the whole batch (B x 1 x H x W)."""
+        ms = self._state.micros
+        return ms[0].G.pred if len(ms) == 1 else torch.cat([m.G.pred for m in ms], 0)
+
+    # ------------------------------------------------------------------ the two optimizer passes of one micro-batch
+    def _d_pass(self, m: _Micro, embeds):
+        be, st = L.backend(), m.G.ctx.stream()
+        lp = self.losses.data_ptr()
+        B, npatch = m.B, m.n_patch
+        pred = m.G.forward(m.rgb, embeds, version=self.flatG.version)              # generator forward (once)
+        m.D2.forward(parts=[(m.rgb, 0, 0), (pred, 0, 3), (m.rgb, B, 0), (m.nir, B, 3)], version=self.flatD.version)
+        out, dout = m.D2.out.data_ptr(), m.D2.dout.data_ptr()
+        L.check(be.nirgan_lsgan(out, npatch, 0.0, m.scale, lp, dout, st), "lsgan")
+        L.check(be.nirgan_lsgan(out + npatch * 4, npatch, 1.0, m.scale, lp + 4, dout + npatch * 4, st), "lsgan")
+        m.D2.backward(None, frozen=False, version=self.flatD.version)
+
+    def _g_pass(self, m: _Micro):
+        be, st = L.backend(), m.G.ctx.stream()
+        lp = self.losses.data_ptr()
+        m.D1.forward(parts=[(m.rgb, 0, 0), (m.G.pred, 0, 3)], version=self.flatD.version)
+        L.check(be.nirgan_lsgan(m.D1.out.data_ptr(), m.n_patch, 1.0, self.lambda_gan * m.scale, lp + 8, m.D1.dout.data_ptr(), st), "lsgan")
+        m.D1.backward(None, frozen=True, version=self.flatD.version, pred_only=True)
+        L.check(be.nirgan_pix_loss(C.byref(m.pix), st), "pix_loss")
+        m.G.backward(None, version=self.flatG.version)
+
+    def _fork(self, state: _ShapeState):
+        for s in state.streams[1:]:
+            if s is not None:
+                s.wait_stream(torch.cuda.current_stream(s.device))
+
+    def _join(self, state: _ShapeState, flat: FlatParams, extras):
+        """Wait for the side streams, then add their gradient parts into the network's flat gradient (fixed order)."""
+        for s in state.streams[1:]:
+            if s is not None:
+                torch.cuda.current_stream(s.device).wait_stream(s)
+        st = self.G.ctx.stream()
+        for buf in extras:
+            L.call("nirgan_axpy", flat.grad.data_ptr(), buf.data_ptr(), flat.total, 1.0, st)
 
     # ------------------------------------------------------------------ one batch
     def step(self, rgb: torch.Tensor, nir: torch.Tensor, embeds: Optional[torch.Tensor] = None) -> "LossView":
         B, _, H, W = rgb.shape
         self._prepare(B, H, W)
+        state = self._state
         st = self.G.ctx.stream()
-        be = L.backend()
-        self.rgb.copy_(rgb)
-        self.nir.copy_(nir)
-        G, D2, D1 = self.G, self.D2, self.D1
-        npatch = self._n_patch
-        lp = self.losses.data_ptr()
-        L.check(be.nirgan_fill(lp, 16, 0.0, st), "fill")
-        # ---- generator forward (once)
-        pred = G.forward(self.rgb, embeds, version=self.flatG.version)
-        # ---- optimizer 0: discriminator on [fake ; real]
-        D2.forward(parts=[(self.rgb, 0, 0), (pred, 0, 3), (self.rgb, B, 0), (self.nir, B, 3)], version=self.flatD.version)
-        out, dout = D2.out.data_ptr(), D2.dout.data_ptr()
-        L.check(be.nirgan_lsgan(out, npatch, 0.0, 1.0, lp, dout, st), "lsgan")
-        L.check(be.nirgan_lsgan(out + npatch * 4, npatch, 1.0, 1.0, lp + 4, dout + npatch * 4, st), "lsgan")
-        D2.backward(None, frozen=False, version=self.flatD.version)
+        for m in state.micros:
+            m.rgb.copy_(rgb[m.lo:m.hi])
+            m.nir.copy_(nir[m.lo:m.hi])
+        L.check(L.backend().nirgan_fill(self.losses.data_ptr(), 16, 0.0, st), "fill")
+        # ---- optimizer 0: generator forward + discriminator on [fake ; real], per micro-batch
+        self._fork(state)
+        for m, s in zip(state.micros, state.streams):
+            with _on_stream(s):
+                self._d_pass(m, None if embeds is None else embeds[m.lo:m.hi])
+        self._join(state, self.flatD, state.extraD)
         if self.reducer is not None:
             self.reducer.all_reduce_mean(self.flatD.grad)
         self.flatD.adam_step(self.lr if self.lr_d is None else self.lr_d, self.beta1, stream=st)
         # ---- optimizer 1: generator against the updated, frozen discriminator
-        D1.forward(parts=[(self.rgb, 0, 0), (pred, 0, 3)], version=self.flatD.version)
-        L.check(be.nirgan_lsgan(D1.out.data_ptr(), npatch, 1.0, self.lambda_gan, lp + 8, D1.dout.data_ptr(), st), "lsgan")
-        D1.backward(None, frozen=True, version=self.flatD.version, pred_only=True)
-        L.check(be.nirgan_pix_loss(C.byref(self._pix), st), "pix_loss")
-        G.backward(None, version=self.flatG.version)
+        self._fork(state)
+        for m, s in zip(state.micros, state.streams):
+            with _on_stream(s):
+                self._g_pass(m)
+        self._join(state, self.flatG, state.extraG)
         if self.reducer is not None:
             self.reducer.all_reduce_mean(self.flatG.grad)
         self.flatG.adam_step(self.lr if self.lr_g is None else self.lr_g, self.beta1, stream=st)

@@ -408,3 +408,36 @@ def test_mixed_resolution_buckets_on_device():
         tol = 1e-3 if n < 3 else 5e-3
         close(got[n]["loss_D"], o["loss_D"], tol, f"loss_D step {n}")
         close(got[n]["loss_G"], o["loss_G"], tol, f"loss_G step {n}")
+
+
+def test_micro_batches_on_two_streams_match_the_single_stream_step():
+    """ngf = 64, bs 4 @128: the two-part step on two HIP streams gives the single-part step's losses and gradients
+    (fp32 summation order of the weight gradients differs: 1e-4), over two consecutive steps (stream joins before each
+    Adam step, re-packed weights after)."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+
+    def run(micro):
+        torch.manual_seed(0)
+        g = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
+        d = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+        tr = Pix2PixTrainer(g, d, n_blocks=6, micro_batches=micro)   # RS indices are singular at random init (tanh output): not here
+        rgb, nir = synth(4, 128, 128, 21)
+        outs = []
+        for _ in range(2):
+            o = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
+            torch.cuda.synchronize()
+            outs.append((o, tr.flatG.grad.clone(), tr.flatD.grad.clone(), tr.pred.clone()))
+        return tr, outs
+    tr1, a = run(1)
+    tr2, b = run(2)
+    assert tr2._state.n == 2 and tr2._state.streams[1] is not None
+    for (o1, gG1, gD1, p1), (o2, gG2, gD2, p2) in zip(a[:1], b[:1]):
+        close(p2, p1, 1e-5, "pred")
+        for k in o1:
+            close(torch.tensor(o2[k]), torch.tensor(o1[k]), 1e-4, k)
+        assert ((gD2 - gD1).norm() / gD1.norm()).item() < 1e-4
+        assert ((gG2 - gG1).norm() / gG1.norm()).item() < 1e-3
+    # second step: trajectories have separated by Adam's amplification of rounding noise only
+    for k in a[1][0]:
+        close(torch.tensor(b[1][0][k]), torch.tensor(a[1][0][k]), 5e-3, "step 2 " + k)

@@ -563,3 +563,31 @@ def test_lightning_free_fit_loop(emu, tmp_path):
     missing = m2.load_state_dict(sd, strict=False)
     assert not missing.missing_keys
     assert torch.equal(m2.netG.model[1].weight.detach(), m.netG.model[1].weight.detach().cpu())
+
+
+def test_micro_batched_step_equals_the_whole_batch(emu, golden_dir):
+    """micro_batches=2: the batch runs as two parts (separate HIP streams on the device) whose scaled gradients are summed
+    before each Adam step -- same golden vectors as the single-part step (instance norm is per sample, losses are means)."""
+    from nirgan_hip.trainer import Pix2PixTrainer
+    z = load(golden_dir, "f1_g9_rs_pad.npz")
+    nb, pad, lam_rs = int(z["n_blocks"]), int(z["padding"]), float(z["lambda_rs"])
+    netG, netD = make_nets(z, nb)
+    rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333}
+    tr = Pix2PixTrainer(netG, netD, n_blocks=nb, lambda_rs=lam_rs, rs_weights=rs_w, padding=pad, micro_batches=2)
+    out = tr.step(torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])).as_dict()
+    assert tr._state.n == 2 and tr._state.micros[0].B == 1
+    close(tr.pred, z["pred"], 2e-5, "pred")
+    close(out["loss_D"], z["loss_D"], 1e-5, "loss_D")
+    close(out["loss_G"], z["loss_G"], 1e-5, "loss_G")
+    gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
+    for k, v in sub(z, "gD/").items():
+        if k not in O.shadowed_bias_keys("D"):
+            close(gD[k], v, 2e-4, "gD " + k)
+    shadow = O.shadowed_bias_keys("G", nb)
+    for k, v in sub(z, "gG/").items():
+        if k not in shadow:
+            close(gG[k], v, 2e-4, "gG " + k)
+    # an odd batch falls back to fewer parts
+    tr3 = Pix2PixTrainer(*make_nets(z, nb), n_blocks=nb, micro_batches=2)
+    tr3.step(torch.rand(3, 3, 32, 32) * 0.5 + 0.1, torch.rand(3, 1, 32, 32) * 0.5 + 0.1)
+    assert tr3._state.n == 1
