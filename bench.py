@@ -276,17 +276,22 @@ def main():
                               "launches_per_step": nlaunch, "avg_launch_ms": round(avg_ms, 5),
                               "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
                               "share_of_step_time": round(avg_ms * nlaunch / ms, 3)})
-            # HBM traffic per launch from the PMC passes recorded under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-            # corrected as MI355X_MICROARCH.md prescribes); only valid for the workload it was measured on
+            # HBM traffic per launch from the PMC passes recorded under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # separate passes over this same bench command, FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes; mean over
+            # the kernel's launches in a step); only valid for the workload it was measured on
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_summary.json")))
             except Exception:
                 pmc = {}
             for r in roofs:
-                ent = pmc.get(r["kernel"])
-                if ent and a.bs == 16 and a.size == 256 and a.blocks == 6 and a.padding == 0 and a.precision == "fp32" and not a.mixed:
-                    r["traffic"] = ent["hbm_bytes_per_launch_corrected"]
-                    r["traffic_unit"] = "bytes/launch (PMC, res-block layer)"
+                ent = next((v for k, v in pmc.items() if k.split("<")[0] == r["kernel"].split("<")[0]
+                            and ("<" not in r["kernel"] or k.startswith(r["kernel"][:-1] + ","))), None)
+                if ent and a.bs == 16 and a.size == 256 and a.blocks == 6 and a.padding == 0 and a.precision == "fp32" \
+                        and not a.mixed and a.micro == 1 and "hbm_read_bytes_per_launch_corrected" in ent:
+                    r["traffic"] = int(ent["hbm_read_bytes_per_launch_corrected"] + ent.get("hbm_write_bytes_per_launch", 0.0))
+                    r["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, mean over the kernel's launches)"
+                    if "mfma_busy_fraction_of_active_cycles" in ent:
+                        r["pmc_mfma_busy"] = round(ent["mfma_busy_fraction_of_active_cycles"], 4)
             roofs.sort(key=lambda r: -r["share_of_step_time"])
             roof = roofs[0] if roofs else None
             roof_other = roofs[1:] or None

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter CSVs per kernel: python3 scripts/pmc_summary.py <dir> [<dir> ...] > profiles/...json
+Each <dir> holds one pass (*_counter_collection.csv).  Output: per kernel name, launches and the per-launch mean of
+every counter found; FETCH_SIZE is reported raw (KB) and x2-corrected in bytes as MI355X_MICROARCH.md prescribes."""
+import csv, glob, json, os, sys, collections
+
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for d in sys.argv[1:]:
+    for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            name = r.get("Kernel_Name") or r.get("Kernel Name") or ""
+            cn, cv = r.get("Counter_Name"), r.get("Counter_Value")
+            if not cn:
+                continue
+            a = acc[name][cn]
+            a[0] += float(cv)
+            a[1] += 1
+out = {}
+for name, cs in acc.items():
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    short = short.split("(")[0].strip()
+    e = {"launches": max(v[1] for v in cs.values())}
+    for cn, (s, n) in cs.items():
+        e[cn + "_per_launch"] = s / n
+    if "FETCH_SIZE" in cs:
+        e["hbm_read_bytes_per_launch_corrected"] = 2.0 * 1024.0 * cs["FETCH_SIZE"][0] / cs["FETCH_SIZE"][1]
+    if "WRITE_SIZE" in cs:
+        e["hbm_write_bytes_per_launch"] = 1024.0 * cs["WRITE_SIZE"][0] / cs["WRITE_SIZE"][1]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "GRBM_GUI_ACTIVE" in cs:
+        # MFMA-busy cycles are summed over the 4 SIMDs of 256 CUs; GRBM_GUI_ACTIVE over the 8 XCDs
+        busy = cs["SQ_VALU_MFMA_BUSY_CYCLES"][0] / cs["SQ_VALU_MFMA_BUSY_CYCLES"][1]
+        act = cs["GRBM_GUI_ACTIVE"][0] / cs["GRBM_GUI_ACTIVE"][1]
+        e["mfma_busy_fraction_of_active_cycles"] = busy / (1024.0 * act / 8.0)
+    out[short] = e
+json.dump(out, sys.stdout, indent=1, sort_keys=True)
