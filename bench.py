@@ -95,7 +95,7 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(n_blocks, size, bs=4, steps=2):
+def cpu_baseline(n_blocks, size, bs=4, steps=8):
     """The CPU oracle (port of the reference's step) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nirgan_oracle as O
