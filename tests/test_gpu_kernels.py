@@ -382,3 +382,61 @@ def test_histogram_match_kernel(shape, ties):
         got = histogram_match(img.to(DEV), small.to(DEV)).cpu()
         want = O.histogram_match(img, up)
         assert (got - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_fullsize_adjoint_and_linearity_identities(precision):
+    """Size-independent properties at the benchmark size (bs 16, 64x64x256 residual-block layer; no oracle needed):
+    <conv(x; W), dY> = <x, dgrad(dY; W)> = <W, wgrad(x, dY)> (the three kernels are one bilinear form), and
+    conv(a x1 + b x2) = a conv(x1) + b conv(x2).  Dot products are taken in float64 on the device."""
+    case = ("res_full", 16, 64, 64, 256, 256, 3, 1, 1)
+    _, B, H, W, Cin, Cout, k, s, p = case
+    ctx = Ctx(DEV, precision)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = Halo(ctx, B, H, W, Cin, p)
+    x.t.copy_(torch.randn(x.t.shape, generator=g, device=DEV))            # halo included: the ring of the data gradient counts
+    w = torch.randn(Cout, Cin, k, k, generator=g, device=DEV) * 0.05
+    b = torch.zeros(Cout, device=DEV)
+    plan, plan2, y, dy, gw, gx = build_conv_case(ctx, x, w, b, case)
+    plan.run()
+    y1 = y.t.clone()
+    dyv = torch.randn(y.t.shape, generator=g, device=DEV)
+    dy.interior().copy_(dyv)
+    plan2.run()
+    torch.cuda.synchronize()
+    dot = lambda a, c: (a.double() * c.double()).sum().item()              # noqa: E731
+    lhs = dot(y1, dyv)
+    tol = 1e-5 if precision == "fp32" else 2e-4
+    assert abs(dot(x.t, gx.t) - lhs) <= tol * abs(lhs), ("data gradient is not the adjoint", dot(x.t, gx.t), lhs)
+    assert abs(dot(w, gw) - lhs) <= tol * abs(lhs), ("weight gradient is not the adjoint", dot(w, gw), lhs)
+    # linearity in x
+    x2 = torch.randn(x.t.shape, generator=g, device=DEV)
+    x1 = x.t.clone()
+    x.t.copy_(x2)
+    plan.run()
+    y2 = y.t.clone()
+    x.t.copy_(0.75 * x1 - 1.5 * x2)
+    plan.run()
+    err = (y.t - (0.75 * y1 - 1.5 * y2)).abs().max().item()
+    assert err <= (1e-5 if precision == "fp32" else 2e-4) * y1.abs().max().item(), err
+
+
+def test_fullsize_postprocess_properties():
+    """512x512 planes: histogram matching is idempotent and maps onto the template's values; SSIM(x, x) = 1, symmetric."""
+    from nirgan_hip.inference import histogram_match
+    from utils.calculate_metrics import image_metrics_device
+    g = torch.Generator(device=DEV).manual_seed(9)
+    a = torch.randn(2, 1, 512, 512, generator=g, device=DEV)
+    b = torch.rand(2, 1, 512, 512, generator=g, device=DEV)
+    m = histogram_match(a, b)
+    assert torch.equal(histogram_match(m, b), m)
+    assert torch.equal(histogram_match(b, b), b)
+    for i in range(2):
+        if b[i].unique().numel() == b[i].numel() and a[i].unique().numel() == a[i].numel():
+            assert torch.equal(m[i].flatten().sort().values, b[i].flatten().sort().values)
+    order_a = a.flatten(1).argsort(dim=1, stable=True)
+    assert bool(m.flatten(1).gather(1, order_a).diff(dim=1).ge(0).all()), "matching must be monotone in the source value"
+    s_xx = image_metrics_device(b, b)
+    assert s_xx[0].item() == 0.0 and s_xx[1].item() == 0.0 and abs(s_xx[2].item() - 1.0) < 1e-6
+    c = (b + 0.05 * torch.randn(b.shape, generator=g, device=DEV)).clamp(0, 1)
+    assert abs(image_metrics_device(b, c)[2].item() - image_metrics_device(c, b)[2].item()) < 1e-6
