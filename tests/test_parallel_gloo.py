@@ -39,7 +39,7 @@ def _batch():
     return 0.02 + 0.58 * torch.rand(4, 3, 32, 32, generator=g), 0.05 + 0.75 * torch.rand(4, 1, 32, 32, generator=g)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, micro):
     _setup_path()
     torch.set_num_threads(2)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -49,7 +49,7 @@ def _worker(rank, world, port, out_dir):
     z = np.load(os.path.join(ROOT, "tests", "golden", "f1_g6_d.npz"))
     netG, netD = _build(z)
     red = GradReducer()
-    tr = Pix2PixTrainer(netG, netD, n_blocks=6, reducer=red)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6, reducer=red, micro_batches=micro)
     rgb, nir = _batch()
     out = tr.step(shard_batch(rgb, rank, world), shard_batch(nir, rank, world)).as_dict()
     torch.save({"gD": tr.flatD.grad.clone(), "gG": tr.flatG.grad.clone(), "pD": tr.flatD.flat.clone(),
@@ -58,10 +58,12 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_single_process(tmp_path):
+@pytest.mark.parametrize("micro", [1, 2])
+def test_two_rank_gradients_equal_single_process(tmp_path, micro):
+    """micro = 2: every rank additionally cuts its shard into two parts whose gradients are summed before the all-reduce."""
     _setup_path()
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * micro
+    mp.spawn(_worker, args=(2, port, str(tmp_path), micro), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in (0, 1))
     # both ranks hold identical reduced gradients and identical updated parameters
     for k in ("gD", "gG", "pD", "pG"):
