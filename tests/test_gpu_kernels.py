@@ -440,3 +440,39 @@ def test_fullsize_postprocess_properties():
     assert s_xx[0].item() == 0.0 and s_xx[1].item() == 0.0 and abs(s_xx[2].item() - 1.0) < 1e-6
     c = (b + 0.05 * torch.randn(b.shape, generator=g, device=DEV)).clamp(0, 1)
     assert abs(image_metrics_device(b, c)[2].item() - image_metrics_device(c, b)[2].item()) < 1e-6
+
+
+def test_conv_random_shapes_fuzz():
+    """40 random layer shapes (channels 4..160 in multiples of 4, odd sizes, stride 1/2, every operand
+    precision; k in {1,3,4}) through forward, weight gradient and data gradient: device vs the numpy restatement of the descriptors."""
+    import random
+    rnd = random.Random(1234)
+    for it in range(40):
+        k = rnd.choice([1, 3, 3, 4])          # 7x7 layers run row-packed / as tap planes (their own tests): <= 16 taps here
+        s = rnd.choice([1, 1, 2]) if k in (3, 4) else 1
+        p = rnd.choice([0, 1]) if k == 1 else (k - 1) // 2 if k != 4 else 1
+        p = 0 if k == 1 else p
+        Cin, Cout = 4 * rnd.randint(1, 40), 4 * rnd.randint(1, 40)
+        B = rnd.randint(1, 3)
+        H, W = rnd.randint(max(k, 5), 23), rnd.randint(max(k, 5), 23)
+        if s == 2 and k == 3:
+            H, W = H & ~1, W & ~1          # the engines use 3x3 stride 2 on even sizes only (down-sampling of 4k tiles)
+        if s == 2 and k == 4:
+            H, W = H & ~1, W & ~1
+        H, W = max(H, 6), max(W, 6)
+        precision = rnd.choice(["fp32", "bf16", "bf16x3"])
+        case = (f"fuzz{it}", B, H, W, Cin, Cout, k, s, p)
+        gen = torch.Generator().manual_seed(100 + it)
+        tw = Twin(precision)
+        xg, xc = tw.halo(B, H, W, Cin, p, gen)
+        wg, wc = tw.tensor(Cout, Cin, k, k, gen=gen, scale=0.1)
+        bg, bc = tw.tensor(Cout, gen=gen)
+        gp, gp2, gy, gdy, ggw, ggx = build_conv_case(tw.gctx, xg, wg, bg, case)
+        cp, cp2, cy, cdy, cgw, cgx = build_conv_case(tw.cctx, xc, wc, bc, case)
+        tw.run(gp, cp)
+        close(gy.t, cy.t, 2e-5, f"{case} {precision} fwd")
+        cdy.interior().copy_(cy.t)
+        gdy.interior().copy_(cy.t.to(DEV))
+        tw.run(gp2, cp2)
+        close(ggw, cgw, 1e-4, f"{case} {precision} wgrad")
+        close(ggx.t, cgx.t, 2e-5, f"{case} {precision} dgrad")
