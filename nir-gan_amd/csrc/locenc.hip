@@ -1,7 +1,7 @@
 // SatCLIP location encoder: lon/lat -> real spherical harmonics (L*L features, closed form) ->
 // SirenNet -> embedding, all in fp64 like the reference (model/satclip/load_lightweight.py:29 `.double()`,
 // satclip_wrapper.py:33).  B is the tile batch (8-32 coordinates): a latency kernel, one workgroup per
-// coordinate, activations in LDS, one wave per output row of each linear layer with a wave-shuffle reduction.
+// coordinate (16 waves), activations in LDS, two output rows of a linear layer per wave and pass, wave-shuffle reductions.
 //
 // Harmonics follow positional_encoding/spherical_harmonics.py:26-42 and spherical_harmonics_closed_form.py:8-40:
 //   phi = deg2rad(lon + 180), theta = deg2rad(lat + 90), feature (l, m), m = -l..l, l = 0..L-1 at index l*l + l + m:
@@ -55,7 +55,7 @@ __device__ double assoc_legendre(int l, int m, double x) {
     return pll;
 }
 
-__global__ __launch_bounds__(256) void locenc_kernel(const LocEncP p) {
+__global__ __launch_bounds__(1024) void locenc_kernel(const LocEncP p) {
     __shared__ double buf[2][MAX_WIDTH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bi = blockIdx.x;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void locenc_kernel(const LocEncP p) {
     const double phi = (lon + 180.0) * d2r, theta = (lat + 90.0) * d2r;
     const double ct = cos(theta);
     const int nf = p.L * p.L;
-    for (int f = tid; f < nf; f += 256) {
+    for (int f = tid; f < nf; f += 1024) {
         int l = int(sqrt(double(f)));
         while (l * l > f) --l;
         while ((l + 1) * (l + 1) <= f) ++l;
@@ -84,16 +84,27 @@ __global__ __launch_bounds__(256) void locenc_kernel(const LocEncP p) {
         const int din = p.din[li], dout = p.dout[li];
         const double* W = p.w[li];
         const bool last = li == p.nlayers - 1;
-        for (int j = wave; j < dout; j += 4) {
-            const double* row = W + size_t(j) * din;
-            double s = 0.0;
-            for (int k = lane; k < din; k += 64) s += row[k] * buf[cur][k];
-            s = wave_sum_f64(s);
-            if (lane == 0) {
-                if (p.b[li]) s += p.b[li][j];
+        // 16 waves, two output rows per wave and pass: the weight rows stream from L2, so the loop is latency-bound and
+        // wants many independent loads in flight (4 waves x 1 row measured 412 us for 32 coordinates)
+        for (int j = wave * 2; j < dout; j += 32) {
+            const bool two = j + 1 < dout;
+            const double* row0 = W + size_t(j) * din;
+            const double* row1 = W + size_t(two ? j + 1 : j) * din;
+            double s0 = 0.0, s1 = 0.0;
+            for (int k = lane; k < din; k += 64) {
+                const double xv = buf[cur][k];
+                s0 += row0[k] * xv;
+                s1 += row1[k] * xv;
+            }
+            s0 = wave_sum_f64(s0);
+            s1 = wave_sum_f64(s1);
+            if (lane < 2 && (lane == 0 || two)) {
+                const int jj = j + lane;
+                double s = lane == 0 ? s0 : s1;
+                if (p.b[li]) s += p.b[li][jj];
                 if (p.w0[li] != 0.0) s = sin(p.w0[li] * s);
-                if (last) p.out[size_t(bi) * dout + j] = s;
-                else buf[cur ^ 1][j] = s;
+                if (last) p.out[size_t(bi) * dout + jj] = s;
+                else buf[cur ^ 1][jj] = s;
             }
         }
         __syncthreads();
@@ -118,6 +129,6 @@ extern "C" int nirgan_location_encoder(const nirgan_locenc_desc* d, void* stream
                    "location_encoder: layer %d is %d -> %d (width <= %d)", i, d->dims[i], d->dims[i + 1], MAX_WIDTH);
         p.w[i] = d->weights[i]; p.b[i] = d->biases[i]; p.din[i] = d->dims[i]; p.dout[i] = d->dims[i + 1]; p.w0[i] = d->w0[i];
     }
-    hipLaunchKernelGGL(locenc_kernel, dim3(d->B), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(locenc_kernel, dim3(d->B), dim3(1024), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("location_encoder");
 }
