@@ -155,21 +155,21 @@ class Pix2PixTrainer:
         be, st = L.backend(), m.G.ctx.stream()
         lp = self.losses.data_ptr()
         B, npatch = m.B, m.n_patch
-        pred = m.G.forward(m.rgb, embeds, version=self.flatG.version)              # generator forward (once)
-        m.D2.forward(parts=[(m.rgb, 0, 0), (pred, 0, 3), (m.rgb, B, 0), (m.nir, B, 3)], version=self.flatD.version)
+        pred = m.G.forward(m.rgb, embeds, version=self.flatG.values_version())              # generator forward (once)
+        m.D2.forward(parts=[(m.rgb, 0, 0), (pred, 0, 3), (m.rgb, B, 0), (m.nir, B, 3)], version=self.flatD.values_version())
         out, dout = m.D2.out.data_ptr(), m.D2.dout.data_ptr()
         L.check(be.nirgan_lsgan(out, npatch, 0.0, m.scale, lp, dout, st), "lsgan")
         L.check(be.nirgan_lsgan(out + npatch * 4, npatch, 1.0, m.scale, lp + 4, dout + npatch * 4, st), "lsgan")
-        m.D2.backward(None, frozen=False, version=self.flatD.version)
+        m.D2.backward(None, frozen=False, version=self.flatD.values_version())
 
     def _g_pass(self, m: _Micro):
         be, st = L.backend(), m.G.ctx.stream()
         lp = self.losses.data_ptr()
-        m.D1.forward(parts=[(m.rgb, 0, 0), (m.G.pred, 0, 3)], version=self.flatD.version)
+        m.D1.forward(parts=[(m.rgb, 0, 0), (m.G.pred, 0, 3)], version=self.flatD.values_version())
         L.check(be.nirgan_lsgan(m.D1.out.data_ptr(), m.n_patch, 1.0, self.lambda_gan * m.scale, lp + 8, m.D1.dout.data_ptr(), st), "lsgan")
-        m.D1.backward(None, frozen=True, version=self.flatD.version, pred_only=True)
+        m.D1.backward(None, frozen=True, version=self.flatD.values_version(), pred_only=True)
         L.check(be.nirgan_pix_loss(C.byref(m.pix), st), "pix_loss")
-        m.G.backward(None, version=self.flatG.version)
+        m.G.backward(None, version=self.flatG.values_version())
 
     def _fork(self, state: _ShapeState):
         for s in state.streams[1:]:

@@ -591,3 +591,27 @@ def test_micro_batched_step_equals_the_whole_batch(emu, golden_dir):
     tr3 = Pix2PixTrainer(*make_nets(z, nb), n_blocks=nb, micro_batches=2)
     tr3.step(torch.rand(3, 3, 32, 32) * 0.5 + 0.1, torch.rand(3, 1, 32, 32) * 0.5 + 0.1)
     assert tr3._state.n == 1
+
+
+def test_fused_trainer_sees_external_weight_changes(emu, golden_dir):
+    """Weights changed behind the trainer's back (load_state_dict / in-place surgery between steps) are re-packed: the next
+    step equals a fresh trainer's first step on the modified weights."""
+    from nirgan_hip.trainer import Pix2PixTrainer
+    z = load(golden_dir, "f1_g6_d.npz")
+    rgb, nir = torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])
+    netG, netD = make_nets(z, 6)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0)      # lr 0: the steps themselves leave the weights alone
+    tr.step(rgb, nir)
+    with torch.no_grad():
+        netG.model[1].weight.mul_(1.5)
+        sd = netD.state_dict()
+        sd["model.11.weight"] = sd["model.11.weight"] * 0.5
+        netD.load_state_dict(sd)
+    after = tr.step(rgb, nir).as_dict()
+    g2, d2 = make_nets(z, 6)
+    g2.load_state_dict(netG.state_dict())
+    d2.load_state_dict(netD.state_dict())
+    fresh = Pix2PixTrainer(g2, d2, n_blocks=6, lr=0.0).step(rgb, nir).as_dict()
+    for k in ("loss_D", "loss_G", "loss_G_l1"):
+        close(after[k], fresh[k], 1e-6, k)
+    assert abs(after["loss_G"] - float(z["loss_G"])) > 1e-3 * abs(float(z["loss_G"]))      # and it did change something
