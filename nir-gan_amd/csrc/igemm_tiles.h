@@ -73,12 +73,17 @@ struct ConvParams {
     int ksplit;                // > 1: the K-steps are divided over ksplit blocks per tile, partial tiles go to split_ws
     float* split_ws;           // [ksplit][M][N] dense
     unsigned long long* dbg;   // diagnostic build only
+    int w_bf16;                // packed weights stored as bf16 (bf16 operand mode only)
     int prec;                  // 0 fp32, 1 bf16 operands, 2 bf16x3 split (host-side dispatch only)
 };
 
 
-template <int BN, int PREC>
+// WB16 (bf16 mode only): the packed weights are STORED as bf16 (rounded once by the pack kernel instead of at every
+// fragment read -- same values): B rows are 64 B per K-step, one ds_read_b128 is one MFMA operand, 25 % fewer bytes and
+// LDS-DMA pieces per K-step.  64-byte rows: a wave-instruction lands 16 rows, the chunk swizzle is chunk ^ ((row>>2)&3).
+template <int BN, int PREC, bool WB16 = false>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* st0, char* st1) {
+    static_assert(!WB16 || PREC == 1, "bf16-stored weights are consumed by the bf16 operand mode only");
     constexpr int BM = 128;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
@@ -107,16 +112,26 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         a_col[i] = lc * 4;
         a_base[i] = b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + lc * 4;
     }
-    int b_base[BI], b_col[BI];
-    bool b_ok[BI];
+    constexpr int BIW = WB16 ? BN / 64 : BI;     // B loader instructions per wave (16 rows of 64 B each when WB16)
+    int b_base[BIW], b_col[BIW];
+    bool b_ok[BIW];
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-        const int row = (wave * BI + i) * 8 + lrow;
-        const int lc = lchunk ^ ((row >> 1) & 7);
-        const int n = n0 + row;
-        b_ok[i] = n < p.N;
-        b_col[i] = lc * 4;
-        b_base[i] = (b_ok[i] ? n : 0) * p.K + lc * 4;
+    for (int i = 0; i < BIW; ++i) {
+        if constexpr (WB16) {
+            const int row = (wave * BIW + i) * 16 + (lane >> 2);
+            const int lc = (lane & 3) ^ ((row >> 2) & 3);
+            const int n = n0 + row;
+            b_ok[i] = n < p.N;
+            b_col[i] = lc * 8;                                   // in bf16 elements
+            b_base[i] = (b_ok[i] ? n : 0) * p.K + lc * 8;
+        } else {
+            const int row = (wave * BI + i) * 8 + lrow;
+            const int lc = lchunk ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            b_ok[i] = n < p.N;
+            b_col[i] = lc * 4;
+            b_base[i] = (b_ok[i] ? n : 0) * p.K + lc * 4;
+        }
     }
 
     auto issue = [&](char* sA, int t, int c0) {
@@ -129,9 +144,16 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         }
         const int woff = t * p.run + c0;
 #pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const float* src = (b_ok[i] && c0 + b_col[i] < p.run) ? p.w + (b_base[i] + woff) : p.zero;
-            ng_glds16(src, sB + (wave * BI + i) * 1024);
+        for (int i = 0; i < BIW; ++i) {
+            const bool ok = b_ok[i] && c0 + b_col[i] < p.run;
+            if constexpr (WB16) {
+                const unsigned short* w16 = reinterpret_cast<const unsigned short*>(p.w);
+                const float* src = ok ? reinterpret_cast<const float*>(w16 + (b_base[i] + woff)) : p.zero;
+                ng_glds16(src, sB + (wave * BIW + i) * 1024);
+            } else {
+                const float* src = ok ? p.w + (b_base[i] + woff) : p.zero;
+                ng_glds16(src, sB + (wave * BI + i) * 1024);
+            }
         }
     };
 
@@ -148,8 +170,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int row = wc * (BN / 2) + nt * 32 + (lane & 31);
-        b_off[nt] = row * 128;
-        b_key[nt] = (row >> 1) & 7;
+        b_off[nt] = row * (WB16 ? 64 : 128);
+        b_key[nt] = WB16 ? (row >> 2) & 3 : (row >> 1) & 7;
     }
     f32x16 acc[2][NT];
 #pragma unroll
@@ -190,6 +212,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
             // bf16 pipe: one MFMA contracts 16 k = the chunks 4h..4h+3 of the 32-float slice; lanes 0-31 hold the 8 k of
             // chunks 4h, 4h+1 of their row, lanes 32-63 those of chunks 4h+2, 4h+3 (same assignment for A and B)
             f32x8 a[2][2], b[2][NT];
+            bf16x8 bw[2][NT];
             auto load = [&](int h, int slot) {
                 const int c0 = 4 * h + 2 * half;
 #pragma unroll
@@ -200,9 +223,14 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + ((c0 ^ b_key[nt]) << 4));
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + (((c0 + 1) ^ b_key[nt]) << 4));
-                    b[slot][nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if constexpr (WB16) {
+                        // 64-byte rows of bf16: 16-byte chunk 2h + half holds exactly this lane's 8 k
+                        bw[slot][nt] = *reinterpret_cast<const bf16x8*>(sB + b_off[nt] + (((2 * h + half) ^ b_key[nt]) << 4));
+                    } else {
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + ((c0 ^ b_key[nt]) << 4));
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(sB + b_off[nt] + (((c0 + 1) ^ b_key[nt]) << 4));
+                        b[slot][nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
                 }
             };
             // PREC 1 prefetches the second half's fragments under the first half's MFMAs; the split variant needs the
@@ -216,7 +244,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) ng_mfma_bf16<PREC>(a[slot][mt], b[slot][nt], acc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (WB16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ng_bf16_round(a[slot][mt]), bw[slot][nt], acc[mt][nt], 0, 0, 0);
+                        else ng_mfma_bf16<PREC>(a[slot][mt], b[slot][nt], acc[mt][nt]);
+                    }
                 if (!PF && h + 1 < 2) load(h + 1, 0);
             }
         }
@@ -657,6 +688,8 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.ntiles = d->N > 64 ? (d->N + 127) / 128 : 1;
     NG_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv: precision=%d (0 fp32, 1 bf16, 2 bf16x3)", d->precision);
     p.prec = d->precision;
+    p.w_bf16 = d->w_bf16 ? 1 : 0;
+    NG_REQUIRE(!p.w_bf16 || (d->precision == 1 && d->run % 8 == 0), "conv: bf16-stored weights need precision 1 and run %% 8 == 0 (run=%d)", d->run);
     p.dbg = nullptr;
     p.ksplit = 1;
     p.split_ws = nullptr;

@@ -24,12 +24,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const ng::WgradPara
 // horizontally fused launch: the data-gradient tiles of a stride-1 convolution followed by the tiles of its
 // weight gradient (both consume the same dY).  One grid: the weight-gradient blocks fill the partly empty
 // last round of the data-gradient, and the other way round.
-template <int PREC = 0>
+template <int PREC = 0, bool WB16 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const ng::ConvParams cp, const ng::WgradParams wp, const int conv_blocks) {
     __shared__ __attribute__((aligned(16))) char st0[32768];
     __shared__ __attribute__((aligned(16))) char st1[32768];
     if (int(blockIdx.x) < conv_blocks)
-        ng::conv_tile<128, PREC>(cp, blockIdx.x, st0, st1);
+        ng::conv_tile<128, PREC, WB16>(cp, blockIdx.x, st0, st1);
     else
         ng::wgrad_tile<128, PREC>(wp, int(blockIdx.x) - conv_blocks, st0, st1);
 }
@@ -69,8 +69,17 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+// four packed values to their destination: fp32, or bf16 (round to nearest even: what the bf16 operand mode would do at every
+// fragment read -- done once here when the weights are stored as bf16)
+__device__ __forceinline__ void pack_store(float* dst, size_t elem, f32x4 v, int bf16) {
+    if (bf16) *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(dst) + elem) = __builtin_convertvector(v, bf16x4_t);
+    else *reinterpret_cast<f32x4*>(dst + elem) = v;
+}
+
 __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, int64_t src_elems, int src_row_stride,
-                                                        const int32_t* __restrict__ map, float* __restrict__ dst, int N, int K) {
+                                                        const int32_t* __restrict__ map, float* __restrict__ dst, int N, int K, int bf16) {
     const int k4 = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int n = blockIdx.y;
     if (k4 >= K) return;
@@ -83,11 +92,11 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
             if (o < src_elems) v[j] = src[o];
         }
     }
-    *reinterpret_cast<f32x4*>(dst + size_t(n) * K + k4) = v;
+    pack_store(dst, size_t(n) * K + k4, v, bf16);
 }
 
 // all weight packs of a plan in one launch: jobs live in device memory (8 x int64 each):
-// src, dst, map, src_elems, N, K, src_row_stride, first_block
+// src, dst, map, src_elems, N, K, src_row_stride | (bf16 destination << 32), first_block
 __global__ __launch_bounds__(256) void pack_rows_batch_kernel(const long long* __restrict__ jobs, int njobs) {
     int j = 0;
     for (int i = 1; i < njobs; ++i)
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(256) void pack_rows_batch_kernel(const long long* _
     float* dst = reinterpret_cast<float*>(J[1]);
     const int32_t* map = reinterpret_cast<const int32_t*>(J[2]);
     const long long src_elems = J[3];
-    const int K = int(J[5]), stride = int(J[6]);
+    const int K = int(J[5]), stride = int(J[6] & 0xffffffffll), bf16 = int(J[6] >> 32);
     const int kblocks = (K + 1023) / 1024;
     const int local = int(blockIdx.x) - int(J[7]);
     const int n = local / kblocks, kb = local - n * kblocks;
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256) void pack_rows_batch_kernel(const long long* _
             if (o < src_elems) v[q] = src[o];
         }
     }
-    *reinterpret_cast<f32x4*>(dst + size_t(n) * K + k4) = v;
+    pack_store(dst, size_t(n) * K + k4, v, bf16);
 }
 
 }  // namespace
@@ -151,6 +160,7 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     const dim3 grid(conv_blocks + wgrad_blocks);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (cp.prec == 0) hipLaunchKernelGGL(conv_wgrad_pair_kernel<0>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
+    else if (cp.prec == 1 && cp.w_bf16) hipLaunchKernelGGL((conv_wgrad_pair_kernel<1, true>), grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else if (cp.prec == 1) hipLaunchKernelGGL(conv_wgrad_pair_kernel<1>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else hipLaunchKernelGGL(conv_wgrad_pair_kernel<2>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
     return nirgan_check_launch("conv_wgrad_pair");
@@ -165,13 +175,24 @@ extern "C" int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, 
     return nirgan_check_launch("reduce_rows");
 }
 
-extern "C" int nirgan_pack_rows(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,
-                                float* dst, int N, int K, void* stream) {
+static int pack_rows_impl(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,
+                          float* dst, int N, int K, int bf16, void* stream) {
     NG_REQUIRE(src && map && dst && N > 0 && K > 0 && K % 4 == 0 && N <= 65535, "pack_rows: bad arguments");
     NG_REQUIRE(ng_aligned16(dst), "pack_rows: dst must be 16-byte aligned");
+    NG_REQUIRE(!bf16 || K % 8 == 0, "pack_rows: bf16 rows need K %% 8 == 0 (16-byte aligned rows)");
     hipLaunchKernelGGL(pack_rows_kernel, dim3((K + 1023) / 1024, N), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       src, src_elems, src_row_stride, map, dst, N, K);
+                       src, src_elems, src_row_stride, map, dst, N, K, bf16);
     return nirgan_check_launch("pack_rows");
+}
+
+extern "C" int nirgan_pack_rows(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,
+                                float* dst, int N, int K, void* stream) {
+    return pack_rows_impl(src, src_elems, src_row_stride, map, dst, N, K, 0, stream);
+}
+
+extern "C" int nirgan_pack_rows_bf16(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,
+                                     void* dst_bf16, int N, int K, void* stream) {
+    return pack_rows_impl(src, src_elems, src_row_stride, map, static_cast<float*>(dst_bf16), N, K, 1, stream);
 }
 
 extern "C" int nirgan_pack_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream) {

@@ -108,16 +108,16 @@ class Plan:
 
     def fuse_packs(self):
         """Replace the nirgan_pack_rows ops of this plan by ONE nirgan_pack_rows_batch launch (job table in device memory)."""
-        packs = [a for n, a in self.ops if n == "nirgan_pack_rows"]
+        packs = [(a, n == "nirgan_pack_rows_bf16") for n, a in self.ops if n in ("nirgan_pack_rows", "nirgan_pack_rows_bf16")]
         if len(packs) < 2 or len(packs) > 256:
             return
         rows, first = [], 0
-        for src, src_elems, stride, imap, dst, N, K in packs:
-            rows.append([src, dst, imap, src_elems, N, K, stride, first])
+        for (src, src_elems, stride, imap, dst, N, K), bf16 in packs:
+            rows.append([src, dst, imap, src_elems, N, K, stride | ((1 << 32) if bf16 else 0), first])
             first += N * ((K + 1023) // 1024)
         table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
         self.ctx.keep.append(table)
-        self.ops = [(n, a) for n, a in self.ops if n != "nirgan_pack_rows"]
+        self.ops = [(n, a) for n, a in self.ops if n not in ("nirgan_pack_rows", "nirgan_pack_rows_bf16")]
         self.ops.append(("nirgan_pack_rows_batch", (table.data_ptr(), len(rows), first)))
 
     def run(self):
@@ -164,10 +164,19 @@ class Weights:
         if key in self.cache:
             return self.cache[key]
         rows = max(spec.N, rows_alloc or 0)
-        buf = self.ctx.zeros(rows, spec.K)
         imap = self.ctx.i32(spec.index_map)
-        plan.add("nirgan_pack_rows", param.data_ptr(), param.numel(), spec.row_stride, imap.data_ptr(),
-                 buf.data_ptr(), spec.N, spec.K)
+        # bf16 operand mode: the packed copy is STORED as bf16 (rounded once here instead of at every fragment read) when
+        # its rows stay 16-byte aligned; consumers recognise it by the tensor's dtype (emit_conv)
+        if self.ctx.precision == 1 and spec.run > 0 and spec.run % 8 == 0 and spec.K % 8 == 0:
+            buf = torch.zeros(rows, spec.K, dtype=torch.bfloat16, device=self.ctx.device)
+            self.ctx.bytes += buf.numel() * 2
+            plan.add("nirgan_pack_rows_bf16", param.data_ptr(), param.numel(), spec.row_stride, imap.data_ptr(),
+                     buf.data_ptr(), spec.N, spec.K)
+        else:
+            buf = self.ctx.zeros(rows, spec.K)
+            plan.add("nirgan_pack_rows", param.data_ptr(), param.numel(), spec.row_stride, imap.data_ptr(),
+                     buf.data_ptr(), spec.N, spec.K)
+        self.ctx.keep.append(buf)
         self.cache[key] = buf
         return buf
 
@@ -204,6 +213,9 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.run, d.in_stride, d.in_oh, d.in_ow = taps.run, in_stride, in_oh, in_ow
     _set_taps(d, taps.dh, taps.dw)
     d.w, d.w_elems, d.bias = w.data_ptr(), w.numel(), _ptr(bias)
+    d.w_bf16 = 1 if w.dtype == torch.bfloat16 else 0
+    if d.w_bf16 and taps.run % 8:
+        raise ValueError(f"bf16-stored weights need run % 8 == 0 (run={taps.run})")
     d.out, d.out_elems = out.ptr, out.elems
     d.out_hp, d.out_wp, d.out_cs = out.hp, out.wp, out.C
     d.out_stride, d.out_oh, d.out_ow = out_stride, out_oh, out_ow

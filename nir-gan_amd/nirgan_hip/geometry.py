@@ -24,6 +24,7 @@ class PackSpec:
     row_stride: int
     index_map: np.ndarray            # int32 [K]
     key: tuple = ()
+    run: int = 0                     # contiguous floats per tap the consuming contraction reads (0: unknown)
 
 
 @dataclass
@@ -50,7 +51,7 @@ def conv_fwd_pack(cout: int, cin: int, k: int) -> PackSpec:
     """packed[co][(kh*k+kw)*cin + ci] = W[co][ci][kh][kw]; also the wgrad reduce map."""
     t = np.arange(k * k)[:, None]
     ci = np.arange(cin)[None, :]
-    return PackSpec(cout, k * k * cin, cin * k * k, (ci * (k * k) + t).astype(np.int32).reshape(-1), ("cf", cout, cin, k))
+    return PackSpec(cout, k * k * cin, cin * k * k, (ci * (k * k) + t).astype(np.int32).reshape(-1), ("cf", cout, cin, k), cin)
 
 
 def conv_rowpacked_taps(k: int, cs: int) -> Taps:
@@ -65,7 +66,7 @@ def conv_rowpacked_pack(cout: int, cin: int, k: int, cs: int) -> PackSpec:
         for kw in range(k):
             for c in range(cin):
                 idx[kh, kw, c] = c * k * k + kh * k + kw
-    return PackSpec(cout, k * k * cs, cin * k * k, idx.reshape(-1), ("cr", cout, cin, k, cs))
+    return PackSpec(cout, k * k * cs, cin * k * k, idx.reshape(-1), ("cr", cout, cin, k, cs), k * cs)
 
 
 def conv_dgrad_s1_taps(k: int, cout: int) -> Taps:
@@ -78,7 +79,7 @@ def conv_dgrad_pack(cout: int, cin: int, k: int, taps_hw: List[Tuple[int, int]])
     idx = np.empty((len(taps_hw), cout), dtype=np.int32)
     for t, (kh, kw) in enumerate(taps_hw):
         idx[t, :] = np.arange(cout) * (cin * k * k) + kh * k + kw
-    return PackSpec(cin, len(taps_hw) * cout, k * k, idx.reshape(-1), ("cd", cout, cin, k, tuple(taps_hw)))
+    return PackSpec(cin, len(taps_hw) * cout, k * k, idx.reshape(-1), ("cd", cout, cin, k, tuple(taps_hw)), cout)
 
 
 @dataclass
@@ -153,7 +154,7 @@ def convT_fwd_pack(cin: int, cout: int, k: int, taps_hw: List[Tuple[int, int]]) 
     idx = np.empty((len(taps_hw), cin), dtype=np.int32)
     for t, (kh, kw) in enumerate(taps_hw):
         idx[t, :] = np.arange(cin) * (cout * k * k) + kh * k + kw
-    return PackSpec(cout, len(taps_hw) * cin, k * k, idx.reshape(-1), ("tf", cin, cout, k, tuple(taps_hw)))
+    return PackSpec(cout, len(taps_hw) * cin, k * k, idx.reshape(-1), ("tf", cin, cout, k, tuple(taps_hw)), cin)
 
 
 def convT_dgrad_taps(k: int, cout: int) -> Taps:
@@ -165,24 +166,24 @@ def convT_dgrad_pack(cin: int, cout: int, k: int) -> PackSpec:
     """packed[ci][(kh*k+kw)*cout + co] = W[ci][co][kh][kw]; also the convT wgrad reduce map."""
     t = np.arange(k * k)[:, None]
     co = np.arange(cout)[None, :]
-    return PackSpec(cin, k * k * cout, cout * k * k, (co * (k * k) + t).astype(np.int32).reshape(-1), ("td", cin, cout, k))
+    return PackSpec(cin, k * k * cout, cout * k * k, (co * (k * k) + t).astype(np.int32).reshape(-1), ("td", cin, cout, k), cout)
 
 
 # ------------------------------------------------------------------ Conv2d(C, 1, k): tap planes
 def tapplane_fwd_pack(cin: int, k: int) -> PackSpec:
     """packed[t][ci] = W[0][ci][kh][kw], t = kh*k+kw; also the wgrad reduce map."""
-    return PackSpec(k * k, cin, 1, (np.arange(cin) * (k * k)).astype(np.int32), ("pf", cin, k))
+    return PackSpec(k * k, cin, 1, (np.arange(cin) * (k * k)).astype(np.int32), ("pf", cin, k), cin)
 
 
 def tapplane_dgrad_pack(cin: int, k: int, qcs: int) -> PackSpec:
     """packed[ci][t] = W[0][ci][t] for t < k*k, 0 for the padding planes."""
     idx = np.full(qcs, -1, dtype=np.int32)
     idx[:k * k] = np.arange(k * k)
-    return PackSpec(cin, qcs, k * k, idx, ("pd", cin, k, qcs))
+    return PackSpec(cin, qcs, k * k, idx, ("pd", cin, k, qcs), qcs)
 
 
 def linear_pack(nout: int, nin: int) -> PackSpec:
-    return PackSpec(nout, nin, nin, np.arange(nin, dtype=np.int32), ("ln", nout, nin))
+    return PackSpec(nout, nin, nin, np.arange(nin, dtype=np.int32), ("ln", nout, nin), nin)
 
 
 def wgrad_split(M: int, tiles: int, target_blocks: int = 1024) -> Tuple[int, int]:

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("out", fp), ("out_elems", i64), ("out_hp", i32), ("out_wp", i32), ("out_cs", i32),
                 ("out_stride", i32), ("out_oh", i32), ("out_ow", i32),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32), ("zero_page", fp),
-                ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32)]
+                ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32), ("w_bf16", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -127,6 +127,7 @@ PROTOTYPES = {
     "nirgan_conv_wgrad_pair": (i32, [C.POINTER(ConvDesc), C.POINTER(WgradDesc), fp]),
     "nirgan_reduce_rows": (i32, [fp, i32, i32, i32, fp, fp, i64, i32, i32, fp]),
     "nirgan_pack_rows": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
+    "nirgan_pack_rows_bf16": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_location_encoder": (i32, [C.POINTER(LocEncDesc), fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),

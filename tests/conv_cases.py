@@ -14,6 +14,20 @@ CONV_CASES = [
 ]
 
 
+def _packed(ctx, plan, w, spec):
+    """Packed copy of w as the engines keep it: bf16-stored in the bf16 operand mode when the rows stay 16-byte aligned."""
+    import torch
+    imap = ctx.i32(spec.index_map)
+    if ctx.precision == 1 and spec.run % 8 == 0 and spec.K % 8 == 0:
+        buf = torch.zeros(spec.N, spec.K, dtype=torch.bfloat16, device=ctx.device)
+        plan.add("nirgan_pack_rows_bf16", w.data_ptr(), w.numel(), spec.row_stride, imap.data_ptr(), buf.data_ptr(), spec.N, spec.K)
+    else:
+        buf = ctx.zeros(spec.N, spec.K)
+        plan.add("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, imap.data_ptr(), buf.data_ptr(), spec.N, spec.K)
+    ctx.keep.append(buf)
+    return buf
+
+
 def build_conv_case(ctx, x, w, b, case):
     """x: input Halo (pad p), w: torch-layout weight, b: bias.  Returns (forward plan, backward plan, y, dy, gw, gx);
     the caller fills dy's interior between the two plans."""
@@ -23,10 +37,7 @@ def build_conv_case(ctx, x, w, b, case):
     taps = G.conv_fwd_taps(k, Cin)
     zpad = k - 1 if s == 1 else 1
     plan = Plan(ctx)
-    wp = ctx.zeros(spec.N, spec.K)
-    ctx.keep.append(wp)
-    imap = ctx.i32(spec.index_map)
-    plan.add("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, imap.data_ptr(), wp.data_ptr(), spec.N, spec.K)
+    wp = _packed(ctx, plan, w, spec)
     y = Halo(ctx, B, OH, OW, Cout, 0)
     emit_conv(plan, ctx, x, taps, wp, b, y, N=Cout, OH=OH, OW=OW, in_stride=s, in_oh=0, in_ow=0)
     # weight gradient with dY in a zero-halo buffer
@@ -40,19 +51,13 @@ def build_conv_case(ctx, x, w, b, case):
         gx = Halo(ctx, B, H, W, Cin, p)
         hw = [(kh, kw) for kh in range(k) for kw in range(k)]
         dspec = G.conv_dgrad_pack(Cout, Cin, k, hw)
-        wd = ctx.zeros(dspec.N, dspec.K)
-        ctx.keep.append(wd)
-        im2 = ctx.i32(dspec.index_map)
-        plan2.add("nirgan_pack_rows", w.data_ptr(), w.numel(), dspec.row_stride, im2.data_ptr(), wd.data_ptr(), dspec.N, dspec.K)
+        wd = _packed(ctx, plan2, w, dspec)
         emit_conv(plan2, ctx, dy, G.conv_dgrad_s1_taps(k, Cout), wd, None, gx, N=Cin, OH=gx.hp, OW=gx.wp)
     else:
         gx = Halo(ctx, B, H, W, Cin, 0)
         for ph in G.conv_dgrad_s2_phases(H, W, k, p):
             dspec = G.conv_dgrad_pack(Cout, Cin, k, ph.taps_hw)
-            wd = ctx.zeros(dspec.N, dspec.K)
-            ctx.keep.append(wd)
-            im2 = ctx.i32(dspec.index_map)
-            plan2.add("nirgan_pack_rows", w.data_ptr(), w.numel(), dspec.row_stride, im2.data_ptr(), wd.data_ptr(), dspec.N, dspec.K)
+            wd = _packed(ctx, plan2, w, dspec)
             emit_conv(plan2, ctx, dy, G.Taps(ph.dh, ph.dw, Cout), wd, None, gx, N=Cin, OH=ph.n_h, OW=ph.n_w,
                       in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow)
     return plan, plan2, y, dy, gw, gx

@@ -93,7 +93,11 @@ class EmuBackend:
             return self._fail("conv: run/in_cs not multiple of 4")
         K = d.ntaps * d.run
         inp = arr(d.inp, d.in_elems)
-        w = arr(d.w, d.w_elems)[: d.N * K].reshape(d.N, K)
+        if d.w_bf16:
+            w16 = np.ctypeslib.as_array((C.c_uint16 * int(d.w_elems)).from_address(int(d.w)))[: d.N * K]
+            w = (w16.astype(np.uint32) << 16).view(np.float32).reshape(d.N, K)
+        else:
+            w = arr(d.w, d.w_elems)[: d.N * K].reshape(d.N, K)
         out = arr(d.out, d.out_elems)
         bias = arr(d.bias, d.N)
         in_row, out_row = d.in_wp * d.in_cs, d.out_wp * d.out_cs
@@ -186,8 +190,19 @@ class EmuBackend:
             o[idx] = s[:, ok]
         return 0
 
-    def nirgan_pack_rows(self, src, src_elems, stride, imap, dst, N, K, stream=None):
+    def nirgan_pack_rows_bf16(self, src, src_elems, stride, imap, dst, N, K, stream=None):
+        return self.nirgan_pack_rows(src, src_elems, stride, imap, dst, N, K, bf16=True)
+
+    def nirgan_pack_rows(self, src, src_elems, stride, imap, dst, N, K, stream=None, bf16=False):
         self.calls.append("pack")
+        if bf16:
+            tmp = np.zeros((N, K), dtype=np.float32)
+            rc = self.nirgan_pack_rows(src, src_elems, stride, imap, tmp.ctypes.data, N, K)
+            if rc:
+                return rc
+            o16 = np.ctypeslib.as_array((C.c_uint16 * (N * K)).from_address(int(dst if not hasattr(dst, "value") else dst.value)))
+            o16[:] = (bf16_round(tmp).view(np.uint32) >> 16).astype(np.uint16).reshape(-1)
+            return 0
         s, m, o = arr(src, src_elems), arr(imap, K, np.int32), arr(dst, N * K).reshape(N, K)
         ok = m >= 0
         idx = np.arange(N)[:, None] * stride + np.where(ok, m, 0)[None, :]
@@ -202,7 +217,8 @@ class EmuBackend:
         for src, dst, imap, src_elems, N, K, stride, first in J:
             if first != blocks:
                 return self._fail("pack_rows_batch: first_block mismatch")
-            rc = self.nirgan_pack_rows(int(src), int(src_elems), int(stride), int(imap), int(dst), int(N), int(K))
+            rc = self.nirgan_pack_rows(int(src), int(src_elems), int(stride) & 0xffffffff, int(imap), int(dst), int(N), int(K),
+                                       bf16=bool(int(stride) >> 32))
             if rc:
                 return rc
             blocks += int(N) * ((int(K) + 1023) // 1024)
