@@ -85,6 +85,10 @@ typedef struct {
      * elements).  Only with precision == 1 and run % 8 == 0: the weights are rounded once when packed instead of at every
      * fragment read -- identical values, 25 % fewer operand bytes per K-step. */
     int w_bf16;
+    /* 1: `in` points to bf16 values (a producer's out_bf16 / dy_bf16 twin: same halo'd geometry, in_elems counts bf16
+     * elements).  Only together with w_bf16 (precision 1, run % 8 == 0, in_cs % 8 == 0): both operands are then read as
+     * stored, half the bytes and LDS-DMA pieces per K-step, no conversion in the K loop. */
+    int in_bf16;
 } nirgan_conv_desc;
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
@@ -157,6 +161,8 @@ typedef struct {
     const float* residual; int r_hp, r_wp, r_pad;   /* optional [B][r_hp][r_wp][C], interior at r_pad */
     float* out; int o_hp, o_wp, o_pad; int border;
     float* ws; int64_t ws_elems;          /* >= B * nchunk * 2 * C floats, see nirgan_instnorm_ws_elems */
+    void* out_bf16;                       /* optional twin of `out` (same geometry, bf16 elements): every store is mirrored, rounded
+                                           * to nearest even -- the operand the bf16 mode's convolutions read (in_bf16) */
 } nirgan_in_fwd_desc;
 
 int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C);
@@ -183,6 +189,7 @@ typedef struct {
     float* gsum_out;
     float* dbias;
     float* ws; int64_t ws_elems;
+    void* dy_bf16;                        /* optional twin of `dy` (same geometry, bf16), as out_bf16 */
 } nirgan_in_bwd_desc;
 
 int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream);

@@ -16,11 +16,11 @@
 
 namespace {
 
-template <int BN, int PREC = 0, bool WB16 = false>
+template <int BN, int PREC = 0, bool WB16 = false, bool AB16 = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ng::ConvParams p) {
     __shared__ __attribute__((aligned(16))) char st0[(128 + BN) * 128];
     __shared__ __attribute__((aligned(16))) char st1[(128 + BN) * 128];
-    ng::conv_tile<BN, PREC, WB16>(p, blockIdx.x, st0, st1);
+    ng::conv_tile<BN, PREC, WB16, AB16>(p, blockIdx.x, st0, st1);
 }
 
 // split-K second stage: out(m, n) = bias[n] + sum_s ws[s][m][n], written with the descriptor's output geometry
@@ -49,7 +49,7 @@ struct ConvGroup {
     int n;
 };
 
-template <int BN, int PREC = 0, bool WB16 = false>
+template <int BN, int PREC = 0, bool WB16 = false, bool AB16 = false>
 __global__ __launch_bounds__(256, 2) void conv_group_kernel(const ConvGroup g) {
     __shared__ __attribute__((aligned(16))) char st0[(128 + BN) * 128];
     __shared__ __attribute__((aligned(16))) char st1[(128 + BN) * 128];
@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256, 2) void conv_group_kernel(const ConvGroup g) {
     if (bid >= g.first[1]) k = 1;
     if (bid >= g.first[2]) k = 2;
     if (bid >= g.first[3]) k = 3;
-    if (k == 0) ng::conv_tile<BN, PREC, WB16>(g.p[0], bid, st0, st1);
-    else if (k == 1) ng::conv_tile<BN, PREC, WB16>(g.p[1], bid - g.first[1], st0, st1);
-    else if (k == 2) ng::conv_tile<BN, PREC, WB16>(g.p[2], bid - g.first[2], st0, st1);
-    else ng::conv_tile<BN, PREC, WB16>(g.p[3], bid - g.first[3], st0, st1);
+    if (k == 0) ng::conv_tile<BN, PREC, WB16, AB16>(g.p[0], bid, st0, st1);
+    else if (k == 1) ng::conv_tile<BN, PREC, WB16, AB16>(g.p[1], bid - g.first[1], st0, st1);
+    else if (k == 2) ng::conv_tile<BN, PREC, WB16, AB16>(g.p[2], bid - g.first[2], st0, st1);
+    else ng::conv_tile<BN, PREC, WB16, AB16>(g.p[3], bid - g.first[3], st0, st1);
 }
 
 }  // namespace
@@ -75,11 +75,13 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
 #define NG_LAUNCH_CONV(BN, PREC) hipLaunchKernelGGL((conv_igemm_kernel<BN, PREC>), grid, dim3(256), 0, st, p)
     if (d->N > 64) {
         if (p.prec == 0) NG_LAUNCH_CONV(128, 0);
+        else if (p.prec == 1 && p.in_bf16) hipLaunchKernelGGL((conv_igemm_kernel<128, 1, true, true>), grid, dim3(256), 0, st, p);
         else if (p.prec == 1 && p.w_bf16) hipLaunchKernelGGL((conv_igemm_kernel<128, 1, true>), grid, dim3(256), 0, st, p);
         else if (p.prec == 1) NG_LAUNCH_CONV(128, 1);
         else NG_LAUNCH_CONV(128, 2);
     } else {
         if (p.prec == 0) NG_LAUNCH_CONV(64, 0);
+        else if (p.prec == 1 && p.in_bf16) hipLaunchKernelGGL((conv_igemm_kernel<64, 1, true, true>), grid, dim3(256), 0, st, p);
         else if (p.prec == 1 && p.w_bf16) hipLaunchKernelGGL((conv_igemm_kernel<64, 1, true>), grid, dim3(256), 0, st, p);
         else if (p.prec == 1) NG_LAUNCH_CONV(64, 1);
         else NG_LAUNCH_CONV(64, 2);
@@ -105,7 +107,7 @@ extern "C" int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int
         NG_REQUIRE(descs[i]->ksplit <= 1, "conv_igemm_group: split-K descriptors are not groupable");
         const bool w = descs[i]->N > 64;
         NG_REQUIRE(i == 0 || w == wide, "conv_igemm_group: all problems must use the same tile width (N <= 64 or N > 64)");
-        NG_REQUIRE(g.p[i].prec == g.p[0].prec && g.p[i].w_bf16 == g.p[0].w_bf16, "conv_igemm_group: all problems must use the same precision and weight storage");
+        NG_REQUIRE(g.p[i].prec == g.p[0].prec && g.p[i].w_bf16 == g.p[0].w_bf16 && g.p[i].in_bf16 == g.p[0].in_bf16, "conv_igemm_group: all problems must use the same precision and weight storage");
         wide = w;
         g.first[i] = total;
         total += g.p[i].mtiles * g.p[i].ntiles;
@@ -116,14 +118,16 @@ extern "C" int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int prec = g.p[0].prec;
 #define NG_LAUNCH_GROUP(BN, PREC) hipLaunchKernelGGL((conv_group_kernel<BN, PREC>), dim3(total), dim3(256), 0, st, g)
-    const bool wb = g.p[0].w_bf16 != 0;
+    const bool wb = g.p[0].w_bf16 != 0, ab = g.p[0].in_bf16 != 0;
     if (wide) {
         if (prec == 0) NG_LAUNCH_GROUP(128, 0);
+        else if (prec == 1 && ab) hipLaunchKernelGGL((conv_group_kernel<128, 1, true, true>), dim3(total), dim3(256), 0, st, g);
         else if (prec == 1 && wb) hipLaunchKernelGGL((conv_group_kernel<128, 1, true>), dim3(total), dim3(256), 0, st, g);
         else if (prec == 1) NG_LAUNCH_GROUP(128, 1);
         else NG_LAUNCH_GROUP(128, 2);
     } else {
         if (prec == 0) NG_LAUNCH_GROUP(64, 0);
+        else if (prec == 1 && ab) hipLaunchKernelGGL((conv_group_kernel<64, 1, true, true>), dim3(total), dim3(256), 0, st, g);
         else if (prec == 1 && wb) hipLaunchKernelGGL((conv_group_kernel<64, 1, true>), dim3(total), dim3(256), 0, st, g);
         else if (prec == 1) NG_LAUNCH_GROUP(64, 1);
         else NG_LAUNCH_GROUP(64, 2);

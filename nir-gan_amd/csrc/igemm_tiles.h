@@ -74,6 +74,7 @@ struct ConvParams {
     float* split_ws;           // [ksplit][M][N] dense
     unsigned long long* dbg;   // diagnostic build only
     int w_bf16;                // packed weights stored as bf16 (bf16 operand mode only)
+    int in_bf16;               // activations read from a bf16 twin (with w_bf16)
     int prec;                  // 0 fp32, 1 bf16 operands, 2 bf16x3 split (host-side dispatch only)
 };
 
@@ -81,9 +82,12 @@ struct ConvParams {
 // WB16 (bf16 mode only): the packed weights are STORED as bf16 (rounded once by the pack kernel instead of at every
 // fragment read -- same values): B rows are 64 B per K-step, one ds_read_b128 is one MFMA operand, 25 % fewer bytes and
 // LDS-DMA pieces per K-step.  64-byte rows: a wave-instruction lands 16 rows, the chunk swizzle is chunk ^ ((row>>2)&3).
-template <int BN, int PREC, bool WB16 = false>
+// AB16 (with WB16): the activations come from a producer's bf16 twin as well -- both operands are read as stored, no
+// conversion in the K loop, half the bytes and LDS-DMA pieces per K-step.
+template <int BN, int PREC, bool WB16 = false, bool AB16 = false>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* st0, char* st1) {
     static_assert(!WB16 || PREC == 1, "bf16-stored weights are consumed by the bf16 operand mode only");
+    static_assert(!AB16 || WB16, "bf16 activations come with bf16-stored weights");
     constexpr int BM = 128;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
@@ -98,19 +102,22 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     const int ksp = rid / tiles, id = rid - ksp * tiles;
     const int n0 = (id % p.ntiles) * BN, m0 = (id / p.ntiles) * BM;
 
-    // ---------------- loader state: each lane owns one 16-byte chunk of 4 A rows and BI B rows
+    // ---------------- loader state: each lane owns one 16-byte chunk of 4 A rows and BI B rows (fp32 rows of 128 B, 8 per
+    // wave-instruction); bf16 rows are 64 B, 16 per wave-instruction
     const int lrow = lane >> 3, lchunk = lane & 7;
-    int a_base[4], a_col[4];
+    constexpr int AIW = AB16 ? 2 : 4;            // A loader instructions per wave
+    int a_base[AIW], a_col[AIW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + lrow;
-        const int lc = lchunk ^ ((row >> 1) & 7);
+    for (int i = 0; i < AIW; ++i) {
+        const int row = AB16 ? (wave * 2 + i) * 16 + (lane >> 2) : (wave * 4 + i) * 8 + lrow;
+        const int lc = AB16 ? ((lane & 3) ^ ((row >> 2) & 3)) : (lchunk ^ ((row >> 1) & 7));
+        const int cw = AB16 ? 8 : 4;             // elements per 16-byte chunk
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
         const int b = m / p.OHW, r = m - b * p.OHW;
         const int oh = r / p.OW, ow = r - oh * p.OW;
-        a_col[i] = lc * 4;
-        a_base[i] = b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + lc * 4;
+        a_col[i] = lc * cw;
+        a_base[i] = b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + lc * cw;
     }
     constexpr int BIW = WB16 ? BN / 64 : BI;     // B loader instructions per wave (16 rows of 64 B each when WB16)
     int b_base[BIW], b_col[BIW];
@@ -138,9 +145,16 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         char* sB = sA + A_BYTES;
         const int toff = p.tap_off[t] + c0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float* src = (c0 + a_col[i] < p.run) ? p.in + (a_base[i] + toff) : p.zero;
-            ng_glds16(src, sA + (wave * 4 + i) * 1024);
+        for (int i = 0; i < AIW; ++i) {
+            const bool ok = c0 + a_col[i] < p.run;
+            if constexpr (AB16) {
+                const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p.in);
+                const float* src = ok ? reinterpret_cast<const float*>(in16 + (a_base[i] + toff)) : p.zero;
+                ng_glds16(src, sA + (wave * 2 + i) * 1024);
+            } else {
+                const float* src = ok ? p.in + (a_base[i] + toff) : p.zero;
+                ng_glds16(src, sA + (wave * 4 + i) * 1024);
+            }
         }
         const int woff = t * p.run + c0;
 #pragma unroll
@@ -164,8 +178,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int row = wr * 64 + mt * 32 + (lane & 31);
-        a_off[mt] = row * 128;
-        a_key[mt] = (row >> 1) & 7;
+        a_off[mt] = row * (AB16 ? 64 : 128);
+        a_key[mt] = AB16 ? (row >> 2) & 3 : (row >> 1) & 7;
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -212,14 +226,18 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
             // bf16 pipe: one MFMA contracts 16 k = the chunks 4h..4h+3 of the 32-float slice; lanes 0-31 hold the 8 k of
             // chunks 4h, 4h+1 of their row, lanes 32-63 those of chunks 4h+2, 4h+3 (same assignment for A and B)
             f32x8 a[2][2], b[2][NT];
-            bf16x8 bw[2][NT];
+            bf16x8 aw[2][2], bw[2][NT];
             auto load = [&](int h, int slot) {
                 const int c0 = 4 * h + 2 * half;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + ((c0 ^ a_key[mt]) << 4));
-                    const f32x4 hi = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + (((c0 + 1) ^ a_key[mt]) << 4));
-                    a[slot][mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if constexpr (AB16) {
+                        aw[slot][mt] = *reinterpret_cast<const bf16x8*>(sA + a_off[mt] + (((2 * h + half) ^ a_key[mt]) << 4));
+                    } else {
+                        const f32x4 lo = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + ((c0 ^ a_key[mt]) << 4));
+                        const f32x4 hi = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + (((c0 + 1) ^ a_key[mt]) << 4));
+                        a[slot][mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -245,7 +263,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        if constexpr (WB16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ng_bf16_round(a[slot][mt]), bw[slot][nt], acc[mt][nt], 0, 0, 0);
+                        if constexpr (AB16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[slot][mt], bw[slot][nt], acc[mt][nt], 0, 0, 0);
+                        else if constexpr (WB16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ng_bf16_round(a[slot][mt]), bw[slot][nt], acc[mt][nt], 0, 0, 0);
                         else ng_mfma_bf16<PREC>(a[slot][mt], b[slot][nt], acc[mt][nt]);
                     }
                 if (!PF && h + 1 < 2) load(h + 1, 0);
@@ -690,6 +709,8 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.prec = d->precision;
     p.w_bf16 = d->w_bf16 ? 1 : 0;
     NG_REQUIRE(!p.w_bf16 || (d->precision == 1 && d->run % 8 == 0), "conv: bf16-stored weights need precision 1 and run %% 8 == 0 (run=%d)", d->run);
+    p.in_bf16 = d->in_bf16 ? 1 : 0;
+    NG_REQUIRE(!p.in_bf16 || (p.w_bf16 && d->in_cs % 8 == 0), "conv: bf16 activations need bf16-stored weights and in_cs %% 8 == 0 (in_cs=%d)", d->in_cs);
     p.dbg = nullptr;
     p.ksplit = 1;
     p.split_ws = nullptr;

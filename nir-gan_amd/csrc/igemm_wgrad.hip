@@ -24,12 +24,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const ng::WgradPara
 // horizontally fused launch: the data-gradient tiles of a stride-1 convolution followed by the tiles of its
 // weight gradient (both consume the same dY).  One grid: the weight-gradient blocks fill the partly empty
 // last round of the data-gradient, and the other way round.
-template <int PREC = 0, bool WB16 = false>
+template <int PREC = 0, bool WB16 = false, bool AB16 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const ng::ConvParams cp, const ng::WgradParams wp, const int conv_blocks) {
     __shared__ __attribute__((aligned(16))) char st0[32768];
     __shared__ __attribute__((aligned(16))) char st1[32768];
     if (int(blockIdx.x) < conv_blocks)
-        ng::conv_tile<128, PREC, WB16>(cp, blockIdx.x, st0, st1);
+        ng::conv_tile<128, PREC, WB16, AB16>(cp, blockIdx.x, st0, st1);
     else
         ng::wgrad_tile<128, PREC>(wp, int(blockIdx.x) - conv_blocks, st0, st1);
 }
@@ -160,6 +160,7 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     const dim3 grid(conv_blocks + wgrad_blocks);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (cp.prec == 0) hipLaunchKernelGGL(conv_wgrad_pair_kernel<0>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
+    else if (cp.prec == 1 && cp.in_bf16) hipLaunchKernelGGL((conv_wgrad_pair_kernel<1, true, true>), grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else if (cp.prec == 1 && cp.w_bf16) hipLaunchKernelGGL((conv_wgrad_pair_kernel<1, true>), grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else if (cp.prec == 1) hipLaunchKernelGGL(conv_wgrad_pair_kernel<1>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else hipLaunchKernelGGL(conv_wgrad_pair_kernel<2>, grid, dim3(256), 0, st, cp, wp, conv_blocks);

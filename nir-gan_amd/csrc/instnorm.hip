@@ -33,6 +33,11 @@ __device__ __forceinline__ int halo_images(int h, int H, int P, int* out) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+typedef __bf16 in_bf16x4 __attribute__((ext_vector_type(4)));
+// the bf16 twin of a buffer: same element offset, value rounded to nearest even
+__device__ __forceinline__ void st4_twin(unsigned short* twin, size_t off, f32x4 v) {
+    if (twin) *reinterpret_cast<in_bf16x4*>(twin + off) = __builtin_convertvector(v, in_bf16x4);
+}
 
 // block-level sum over the row groups of two float4 accumulators; result valid for tid < q4
 __device__ __forceinline__ void rg_reduce2(f32x4& s1, f32x4& s2, f32x4* lds, int tid, int q4, int nrg) {
@@ -59,6 +64,7 @@ struct InFwd {
     const float* residual; int r_row, r_img, r_org;
     float* out; int o_row, o_img, o_pad, border;
     float* ws; int nchunk, ppc;
+    unsigned short* out16;
 };
 
 __global__ __launch_bounds__(256) void in_stats_kernel(const InFwd p) {
@@ -152,6 +158,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
     int end = start + p.ppc;
     end = end < p.HW ? end : p.HW;
     float* ob = p.out + size_t(b) * p.o_img;
+    unsigned short* ob16 = p.out16 ? p.out16 + size_t(b) * p.o_img : nullptr;
     const float* rb = p.residual ? p.residual + size_t(b) * p.r_img + p.r_org : nullptr;
     for (int pix = start + rg; pix < end; pix += nrg) {
         const int h = pix / p.W, w = pix - h * p.W;
@@ -162,9 +169,15 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
             int hs[3], wsx[3];
             const int nh = halo_images(h, p.H, p.o_pad, hs), nw = halo_images(w, p.W, p.o_pad, wsx);
             for (int i = 0; i < nh; ++i)
-                for (int j = 0; j < nw; ++j) st4(ob + size_t(hs[i]) * p.o_row + size_t(wsx[j]) * p.C + q * 4, v);
+                for (int j = 0; j < nw; ++j) {
+                    const size_t off = size_t(hs[i]) * p.o_row + size_t(wsx[j]) * p.C + q * 4;
+                    st4(ob + off, v);
+                    st4_twin(ob16, off, v);
+                }
         } else {
-            st4(ob + size_t(h + p.o_pad) * p.o_row + size_t(w + p.o_pad) * p.C + q * 4, v);
+            const size_t off = size_t(h + p.o_pad) * p.o_row + size_t(w + p.o_pad) * p.C + q * 4;
+            st4(ob + off, v);
+            st4_twin(ob16, off, v);
         }
     }
 }
@@ -180,6 +193,7 @@ struct InBwd {
     float* gsum_out;
     float* dbias;
     float* ws; int nchunk, ppc;
+    unsigned short* dy16;
 };
 
 __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
@@ -227,7 +241,11 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gz[i] = z[i] > 0.f ? gz[i] : gz[i] * neg;
             }
-            st4(db + size_t(h) * p.d_row + size_t(w) * p.C + q * 4, gz);
+            {
+                const size_t off = size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
+                st4(db + off, gz);
+                if (!p.norm) st4_twin(p.dy16 ? p.dy16 + size_t(b) * p.d_img + p.d_org : nullptr, off, gz);   // no second pass: this IS dy
+            }
             s1 += gz;
             if (p.norm) s2 += gz * z;
         }
@@ -274,10 +292,13 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     end = end < p.HW ? end : p.HW;
     for (int pix = start + rg; pix < end; pix += nrg) {
         const int h = pix / p.W, w = pix - h * p.W;
-        float* dp = db + size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
+        const size_t off = size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
+        float* dp = db + off;
         const f32x4 gz = ld4(dp);
         const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
-        st4(dp, rstd * (gz - m1 - z * m2));
+        const f32x4 r = rstd * (gz - m1 - z * m2);
+        st4(dp, r);
+        st4_twin(p.dy16 ? p.dy16 + size_t(b) * p.d_img + p.d_org : nullptr, off, r);
     }
 }
 
@@ -301,6 +322,8 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
     p.residual = d->residual; p.r_row = d->r_wp * d->C; p.r_img = d->r_hp * p.r_row; p.r_org = d->r_pad * p.r_row + d->r_pad * d->C;
     p.out = d->out; p.o_row = d->o_wp * d->C; p.o_img = d->o_hp * p.o_row; p.o_pad = d->o_pad; p.border = d->border;
     p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C); p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
+    p.out16 = static_cast<unsigned short*>(d->out_bf16);
+    NG_REQUIRE(!d->out_bf16 || (d->C % 8 == 0 && (reinterpret_cast<uintptr_t>(d->out_bf16) & 15) == 0), "instnorm_fwd: bf16 twin needs C %% 8 == 0 and 16-byte alignment");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->norm) {
         NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
@@ -330,6 +353,8 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     p.dy = d->dy; p.d_row = d->d_wp * d->C; p.d_img = d->d_hp * p.d_row; p.d_org = d->d_pad * p.d_row + d->d_pad * d->C;
     p.gsum_out = d->gsum_out; p.dbias = d->dbias;
     p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C); p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
+    p.dy16 = static_cast<unsigned short*>(d->dy_bf16);
+    NG_REQUIRE(!d->dy_bf16 || (d->C % 8 == 0 && (reinterpret_cast<uintptr_t>(d->dy_bf16) & 15) == 0), "instnorm_bwd: bf16 twin needs C %% 8 == 0 and 16-byte alignment");
     NG_REQUIRE(!d->norm || d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C + int64_t(d->B) * 2 * d->C, "instnorm_bwd: ws too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);

@@ -73,12 +73,20 @@ class Ctx:
 class Halo:
     """[B][H+2p][W+2p][C] fp32 buffer; the interior starts at (p, p)."""
 
-    def __init__(self, ctx: Ctx, B, H, W, C, pad=0, tensor: Optional[torch.Tensor] = None):
+    def __init__(self, ctx: Ctx, B, H, W, C, pad=0, tensor: Optional[torch.Tensor] = None, twin: bool = False):
         self.B, self.H, self.W, self.C, self.pad = B, H, W, C, pad
         self.hp, self.wp = H + 2 * pad, W + 2 * pad
         self.t = tensor if tensor is not None else ctx.zeros(B, self.hp, self.wp, C)
         assert self.t.numel() == B * self.hp * self.wp * C
         ctx.keep.append(self.t)          # descriptors hold raw pointers: the context owns every buffer
+        # bf16 operand mode: an instance-norm producer mirrors every store into a bf16 twin of the same geometry (rounded
+        # once, to nearest even); convolutions read the twin.  RULE: a buffer with a twin is written by emit_in_fwd (as
+        # `out`) or emit_in_bwd (as `dy`) ONLY -- they are the kernels that keep the twin in step.
+        self.t16 = None
+        if twin and ctx.precision == 1 and C % 8 == 0:
+            self.t16 = torch.zeros(B, self.hp, self.wp, C, dtype=torch.bfloat16, device=ctx.device)
+            ctx.bytes += self.t16.numel() * 2
+            ctx.keep.append(self.t16)
 
     @property
     def ptr(self):
@@ -209,6 +217,8 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
               in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None, allow_split=True):
     d = L.ConvDesc()
     d.inp, d.in_elems = inp.ptr, inp.elems
+    if inp.t16 is not None and w.dtype == torch.bfloat16 and taps.run % 8 == 0:
+        d.inp, d.in_bf16 = inp.t16.data_ptr(), 1          # both operands as stored (bf16 twin of the producer, bf16 weights)
     d.in_hp, d.in_wp, d.in_cs = (in_hw or (inp.hp, inp.wp)) + (inp.C,)
     d.run, d.in_stride, d.in_oh, d.in_ow = taps.run, in_stride, in_oh, in_ow
     _set_taps(d, taps.dh, taps.dw)
@@ -312,6 +322,8 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
     if residual is not None:
         d.residual, d.r_hp, d.r_wp, d.r_pad = residual.ptr, residual.hp, residual.wp, residual.pad
     d.out, d.o_hp, d.o_wp, d.o_pad, d.border = out.ptr, out.hp, out.wp, out.pad, border
+    if out.t16 is not None:
+        d.out_bf16 = out.t16.data_ptr()
     ctx.keep.append(d)
     plan.add("nirgan_instnorm_fwd", C.byref(d))
     return d
@@ -339,6 +351,8 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     d.B, d.H, d.W, d.C = B, H, W, Cc
     d.dy, d.d_hp, d.d_wp, d.d_pad = dy.ptr, dy.hp, dy.wp, dy.pad
+    if dy.t16 is not None:
+        d.dy_bf16 = dy.t16.data_ptr()
     if gsum is not None:
         d.gsum_out = gsum.ptr
     if dbias is not None:
@@ -389,7 +403,7 @@ class ConvIN:
         assert inp.pad >= (p if kind != "convT" else 1), (name, inp.pad, p)
         B = inp.B
         self.y = Halo(ctx, B, self.OH, self.OW, cout, 0)
-        self.out = Halo(ctx, B, self.OH, self.OW, cout, out_pad)
+        self.out = Halo(ctx, B, self.OH, self.OW, cout, out_pad, twin=True)
         self.out_border = out_border
         self.stats = (ctx.zeros(B, cout), ctx.zeros(B, cout)) if norm else None
         eng.scratch.want(B, self.OH, self.OW, cout)
@@ -430,7 +444,7 @@ class ConvIN:
             zpad = k - 1 if need_dgrad else 0
         else:
             zpad = 1 if need_dgrad else 0
-        self.dy = Halo(ctx, self.inp.B, self.OH, self.OW, self.cout, zpad)
+        self.dy = Halo(ctx, self.inp.B, self.OH, self.OW, self.cout, zpad, twin=True)
 
     def emit_bwd(self, plan: Plan, pack: Plan, *, g: Optional[Halo], g_fold=False, g2: Optional[Halo] = None,
                  gsum: Optional[Halo] = None, gw: Optional[torch.Tensor], gb: Optional[torch.Tensor], dgrad_out: Optional[Halo],

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("out", fp), ("out_elems", i64), ("out_hp", i32), ("out_wp", i32), ("out_cs", i32),
                 ("out_stride", i32), ("out_oh", i32), ("out_ow", i32),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32), ("zero_page", fp),
-                ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32), ("w_bf16", i32)]
+                ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32), ("w_bf16", i32), ("in_bf16", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -48,7 +48,7 @@ class InFwdDesc(C.Structure):
                 ("mean", fp), ("rstd", fp), ("act", i32), ("slope", f32),
                 ("residual", fp), ("r_hp", i32), ("r_wp", i32), ("r_pad", i32),
                 ("out", fp), ("o_hp", i32), ("o_wp", i32), ("o_pad", i32), ("border", i32),
-                ("ws", fp), ("ws_elems", i64)]
+                ("ws", fp), ("ws_elems", i64), ("out_bf16", fp)]
 
 
 class InBwdDesc(C.Structure):
@@ -57,7 +57,7 @@ class InBwdDesc(C.Structure):
                 ("y", fp), ("mean", fp), ("rstd", fp), ("norm", i32),
                 ("B", i32), ("H", i32), ("W", i32), ("C", i32),
                 ("dy", fp), ("d_hp", i32), ("d_wp", i32), ("d_pad", i32),
-                ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64)]
+                ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64), ("dy_bf16", fp)]
 
 
 class ChanDgradDesc(C.Structure):

@@ -41,6 +41,13 @@ def contract(A: np.ndarray, B: np.ndarray, precision: int) -> np.ndarray:
     return ah @ bh + ah @ bm + am @ bh
 
 
+def mirror_twin(twin_ptr, buf: np.ndarray) -> None:
+    """bf16 twin of a buffer: same geometry, every value rounded to nearest even (what the producers' mirrored stores leave)."""
+    if twin_ptr:
+        t = np.ctypeslib.as_array((C.c_uint16 * buf.size).from_address(int(twin_ptr)))
+        t[:] = (bf16_round(buf.reshape(-1)).view(np.uint32) >> 16).astype(np.uint16)
+
+
 def obj(ref):
     return ref._obj if hasattr(ref, "_obj") else ref
 
@@ -92,7 +99,11 @@ class EmuBackend:
         if d.run % 4 or d.in_cs % 4:
             return self._fail("conv: run/in_cs not multiple of 4")
         K = d.ntaps * d.run
-        inp = arr(d.inp, d.in_elems)
+        if d.in_bf16:
+            i16 = np.ctypeslib.as_array((C.c_uint16 * int(d.in_elems)).from_address(int(d.inp)))
+            inp = (i16.astype(np.uint32) << 16).view(np.float32)
+        else:
+            inp = arr(d.inp, d.in_elems)
         if d.w_bf16:
             w16 = np.ctypeslib.as_array((C.c_uint16 * int(d.w_elems)).from_address(int(d.w)))[: d.N * K]
             w = (w16.astype(np.uint32) << 16).view(np.float32).reshape(d.N, K)
@@ -361,6 +372,7 @@ class EmuBackend:
             hh = reflect(np.arange(d.o_hp) - P, H)
             ww = reflect(np.arange(d.o_wp) - P, W)
             out[:] = a[:, hh][:, :, ww]
+        mirror_twin(d.out_bf16, out)      # the device mirrors exactly the stores it makes; untouched (zero) halo stays zero in both
         return 0
 
     def nirgan_instnorm_bwd(self, ref, stream=None):
@@ -408,6 +420,7 @@ class EmuBackend:
             dy = gz
         o = arr(d.dy, B * d.d_hp * d.d_wp * Cc).reshape(B, d.d_hp, d.d_wp, Cc)
         o[:, d.d_pad:d.d_pad + H, d.d_pad:d.d_pad + W] = dy
+        mirror_twin(d.dy_bf16, o)
         if d.dbias:
             arr(d.dbias, Cc)[:] += dy.sum((0, 1, 2))
         return 0

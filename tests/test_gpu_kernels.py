@@ -476,3 +476,50 @@ def test_conv_random_shapes_fuzz():
         tw.run(gp2, cp2)
         close(ggw, cgw, 1e-4, f"{case} {precision} wgrad")
         close(ggx.t, cgx.t, 2e-5, f"{case} {precision} dgrad")
+
+
+def test_bf16_twins_and_twin_fed_convolution():
+    """bf16 mode: the instance-norm kernels mirror every store into a bf16 twin (forward `out`, backward `dy`), bit for bit
+    the round-to-nearest-even of the fp32 buffer, halo included; a convolution fed from the twin (in_bf16) with bf16-stored
+    weights equals the numpy restatement and equals the same convolution fed from the fp32 buffer (same operand values)."""
+    from conv_cases import _packed
+    B, H, W, Cc, Cout = 2, 12, 10, 64, 128
+    gen = torch.Generator().manual_seed(5)
+    tw = Twin("bf16")
+    res = []
+    for ctx in (tw.gctx, tw.cctx):
+        dev = ctx.device
+        y = Halo(ctx, B, H, W, Cc, 0)
+        y.t.copy_(torch.randn(y.t.shape, generator=torch.Generator().manual_seed(6)).to(dev))
+        out = Halo(ctx, B, H, W, Cc, 1, twin=True)
+        assert out.t16 is not None
+        stats = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
+        ws = ctx.zeros(int(L.backend().nirgan_instnorm_ws_elems(B, H, W, Cc)) if ctx is tw.gctx else 1 << 16)
+        plan = Plan(ctx)
+        emit_in_fwd(plan, ctx, y, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats, ws=ws)
+        w = (torch.randn(Cout, Cc, 3, 3, generator=torch.Generator().manual_seed(7)) * 0.05).to(dev)
+        spec = G.conv_fwd_pack(Cout, Cc, 3)
+        wp = _packed(ctx, plan, w, spec)
+        assert wp.dtype == torch.bfloat16
+        o = Halo(ctx, B, H, W, Cout, 0)
+        d = emit_conv(plan, ctx, out, G.conv_fwd_taps(3, Cc), wp, None, o, N=Cout, OH=H, OW=W)
+        assert d.in_bf16 == 1 and d.w_bf16 == 1
+        # the same convolution from the fp32 buffer (twin detached): identical operand values after rounding
+        o2 = Halo(ctx, B, H, W, Cout, 0)
+        t16, out.t16 = out.t16, None
+        d2 = emit_conv(plan, ctx, out, G.conv_fwd_taps(3, Cc), wp, None, o2, N=Cout, OH=H, OW=W)
+        out.t16 = t16
+        assert d2.in_bf16 == 0
+        # backward twin
+        g = Halo(ctx, B, H, W, Cc, 0)
+        g.t.copy_(torch.randn(g.t.shape, generator=torch.Generator().manual_seed(8)).to(dev))
+        dy = Halo(ctx, B, H, W, Cc, 2, twin=True)
+        emit_in_bwd(plan, ctx, g=g, act=L.ACT_RELU, y=y, stats=stats, norm=True, dy=dy, ws=ws, shape=(B, H, W, Cc))
+        res.append((plan, out, o, o2, dy))
+    (gp, gout, go, go2, gdy), (cp, cout_, co, co2, cdy) = res
+    tw.run(gp, cp)
+    assert torch.equal(gout.t16.cpu(), gout.t.cpu().to(torch.bfloat16)), "forward twin is not RNE(out)"
+    assert torch.equal(gdy.t16.cpu(), gdy.t.cpu().to(torch.bfloat16)), "backward twin is not RNE(dy)"
+    assert float(gout.t[:, 0].abs().max()) > 0 and float(gdy.t[:, :2].abs().max()) == 0     # reflect halo filled, zero halo kept
+    close(go.t, co.t, 1e-5, "twin-fed conv vs restatement")
+    close(go.t, go2.t, 1e-6, "twin-fed conv vs fp32-fed conv")
