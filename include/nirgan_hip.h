@@ -114,6 +114,8 @@ typedef struct {
     int nsplit, rows_per_split;           /* rows_per_split % 32 == 0, nsplit*rows_per_split >= B*OH*OW */
     const float* zero_page;
     int precision;                        /* as in nirgan_conv_desc */
+    int pq_bf16;                          /* 1: p and q point to bf16 twins (same geometry; the producers' out_bf16 / dy_bf16);
+                                           * precision 1, N > 64, and N, run, p_cs, q_cs multiples of 8 */
 } nirgan_wgrad_desc;
 
 int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream);

@@ -429,6 +429,7 @@ struct WgradParams {
     int K, OW, OH, OHW, M, N;
     int rows_per_split, nsplit, ntiles_n, ntiles_k;
     int prec;
+    int pq_bf16;               // p and q point to bf16 twins (bf16 operand mode, N > 64)
 };
 
 
@@ -667,6 +668,190 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
     }
 }
 
+// Weight-gradient tile over bf16 TWINS (bf16 operand mode, 128 rows n x 128 columns J): both operands are read as stored.
+// LDS images P16[m][n] and Q16[m][J]: 32 pixel rows of 256 B, filled by LDS-DMA (a piece = 4 rows), the 16-byte chunk of a row
+// XOR-swizzled with f(row) = ((row&3)<<2) | ((row>>2)&3) on the source side.  The MFMA wants k (= pixel m) contiguous per
+// lane, the images have it along rows: ds_read_b64_tr_b16 reads, per 16-lane group, a 4-row x 16-column block and hands lane
+// i column i with the 4 rows in its 4 elements -- two of them are one 32x32x16 operand (8 k).  16 reads of 8 B per wave and
+// K-step instead of 32 ds_read_b64 of fp32, 16 DMA pieces instead of 32, no conversion.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void wgrad_tile16(const WgradParams& p, const int block_id, char* st0, char* st1) {
+    constexpr int TN = 128;
+    constexpr int P_BYTES = 32 * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.ntiles_n * p.ntiles_k;
+    const int id = ng_xcd_remap(block_id, tiles * p.nsplit);
+    const int split = id / tiles, tile = id - split * tiles;
+    const int n0 = (tile % p.ntiles_n) * TN, j0 = (tile / p.ntiles_n) * 128;
+    const int mstart = split * p.rows_per_split;
+    int mend = mstart + p.rows_per_split;
+    mend = mend < p.M ? mend : p.M;
+    const int nk = mend > mstart ? (mend - mstart + 31) >> 5 : 0;
+    const unsigned short* P16 = reinterpret_cast<const unsigned short*>(p.p);
+    const unsigned short* Q16 = reinterpret_cast<const unsigned short*>(p.q);
+
+    // ---------------- loader state: wave w owns pieces 2w, 2w+1 of each image (rows 8w .. 8w+7)
+    const int lrow = lane >> 4, pch = lane & 15;
+    struct Pix { int b, oh, ow; };
+    auto decompose = [&](int m) {
+        Pix x;
+        x.b = m / p.OHW;
+        const int r = m - x.b * p.OHW;
+        x.oh = r / p.OW;
+        x.ow = r - x.oh * p.OW;
+        return x;
+    };
+    auto advance = [&](Pix& x) {
+        x.ow += 32;
+        while (x.ow >= p.OW) { x.ow -= p.OW; ++x.oh; }
+        while (x.oh >= p.OH) { x.oh -= p.OH; ++x.b; }
+    };
+    Pix px[2];
+    int p_n[2], q_add[2];
+    bool p_ok[2], q_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 4 + lrow;
+        const int lc = pch ^ (((row & 3) << 2) | ((row >> 2) & 3));      // logical chunk (8 elements) this lane fetches
+        px[i] = decompose(mstart + row);
+        p_ok[i] = n0 + lc * 8 < p.N;
+        p_n[i] = p_ok[i] ? n0 + lc * 8 : 0;
+        const int j = j0 + lc * 8;
+        q_ok[i] = j < p.K;
+        q_add[i] = 0;
+        if (q_ok[i]) {
+            const int t = j / p.run;
+            q_add[i] = p.tap_off[t] + (j - t * p.run);
+        }
+    }
+    auto issue = [&](char* sP, int mb) {
+        char* sQ = sP + P_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ins = wave * 2 + i;
+            const int m = mb + ins * 4 + lrow;
+            const unsigned short* sp = P16 + (px[i].b * p.p_img + px[i].oh * p.p_row + px[i].ow * p.p_cs + p.p_org + p_n[i]);
+            const float* src = (p_ok[i] && m < mend) ? reinterpret_cast<const float*>(sp) : p.zero;
+            ng_glds16(src, sP + ins * 1024);
+            const unsigned short* sq = Q16 + (px[i].b * p.q_img + px[i].oh * p.q_stride * p.q_row + px[i].ow * p.q_stride * p.q_cs + p.q_org + q_add[i]);
+            const unsigned short* sq0 = Q16 + (p.q_org + q_add[i]);
+            src = (q_ok[i] && m < p.M) ? reinterpret_cast<const float*>(sq) : (q_ok[i] ? reinterpret_cast<const float*>(sq0) : p.zero);
+            ng_glds16(src, sQ + ins * 1024);
+            advance(px[i]);
+        }
+    };
+
+    // ---------------- compute state
+    const int wr = wave >> 1, wc = wave & 1;
+    const int half = lane >> 5;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    // byte offset of this lane's 8 bytes inside a 4-row block whose first row is 16h + 8*(g>>1) + 4j and first chunk c0:
+    //   256*(row) + 16*((c0 + (pp>>1)) ^ f(row)) + 8*(pp&1),  f(row) = (q<<2) | ((2*(g>>1) + j) & 3)   (h drops out of f)
+    int rowoff[2], key[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        rowoff[j] = 256 * (8 * (g >> 1) + 4 * j + q) + 8 * (pp & 1);
+        key[j] = (q << 2) | ((2 * (g >> 1) + j) & 3);
+    }
+    int a_ch[2], b_ch[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        a_ch[e] = wr * 8 + e * 4 + 2 * (g & 1) + (pp >> 1);
+        b_ch[e] = wc * 8 + e * 4 + 2 * (g & 1) + (pp >> 1);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+
+    auto frag = [&](const char* img, int h, int ch) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((NG_LDS s16x4*)(img + 4096 * h + rowoff[0] + 16 * (ch ^ key[0])));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((NG_LDS s16x4*)(img + 4096 * h + rowoff[1] + 16 * (ch ^ key[1])));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto compute = [&](const char* sP) {
+        const char* sQ = sP + P_BYTES;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                a[e] = frag(sP, h, a_ch[e]);
+                b[e] = frag(sQ, h, b_ch[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[e], b[f], acc[e][f], 0, 0, 0);
+        }
+    };
+
+    if (nk > 0) {
+        issue(st0, mstart);
+        int s = 0;
+        for (; s + 2 < nk; s += 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue(st1, mstart + (s + 1) * 32);
+            compute(st0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            issue(st0, mstart + (s + 2) * 32);
+            compute(st1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nk) {
+            issue(st1, mstart + (s + 1) * 32);
+            compute(st0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(st1);
+        } else {
+            compute(st0);
+        }
+    }
+
+    // ---------------- store the partial tile through LDS: accumulator row i = (r&3)+8*(r>>2)+4*half is n = wr*64 + e*32 + i
+    __syncthreads();
+    {
+        float* half_base = reinterpret_cast<float*>(wr == 0 ? st0 : st1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    half_base[(e * 32 + i) * 128 + wc * 64 + f * 32 + (lane & 31)] = acc[e][f][r];
+                }
+    }
+    __syncthreads();
+    {
+        float* slab = p.slabs + size_t(split) * p.N * p.K;
+        const int chunk = tid & 31, row0 = tid >> 5;
+        const int jj = j0 + chunk * 4;
+        if (jj < p.K) {
+#pragma unroll 4
+            for (int row = row0; row < TN; row += 8) {
+                const int n = n0 + row;
+                if (n < p.N) {
+                    const float* src = reinterpret_cast<const float*>(row < TN / 2 ? st0 : st1) + (row % (TN / 2)) * 128 + chunk * 4;
+                    *reinterpret_cast<f32x4*>(slab + size_t(n) * p.K + jj) = *reinterpret_cast<const f32x4*>(src);
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host: descriptor -> parameters
 inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     NG_REQUIRE(d != nullptr, "conv: null descriptor");
@@ -765,6 +950,9 @@ inline int build_wgrad_params(const nirgan_wgrad_desc* d, WgradParams& p) {
     p.ntiles_n = d->N > 64 ? (d->N + 127) / 128 : 1;
     NG_REQUIRE(d->precision >= 0 && d->precision <= 2, "wgrad_igemm: precision=%d (0 fp32, 1 bf16, 2 bf16x3)", d->precision);
     p.prec = d->precision;
+    p.pq_bf16 = d->pq_bf16 ? 1 : 0;
+    NG_REQUIRE(!p.pq_bf16 || (d->precision == 1 && d->N > 64 && d->N % 8 == 0 && d->run % 8 == 0 && d->p_cs % 8 == 0 && d->q_cs % 8 == 0),
+               "wgrad_igemm: bf16 twins need precision 1, N > 64 and N, run, p_cs, q_cs multiples of 8");
     return NIRGAN_OK;
 }
 

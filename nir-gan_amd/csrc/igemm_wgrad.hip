@@ -21,15 +21,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const ng::WgradPara
     ng::wgrad_tile<TN, PREC>(p, blockIdx.x, st0, st1);
 }
 
+// weight gradient over the producers' bf16 twins (bf16 operand mode, N > 64)
+__global__ __launch_bounds__(256, 2) void wgrad_igemm16_kernel(const ng::WgradParams p) {
+    __shared__ __attribute__((aligned(16))) char st0[32768];
+    __shared__ __attribute__((aligned(16))) char st1[32768];
+    ng::wgrad_tile16(p, blockIdx.x, st0, st1);
+}
+
 // horizontally fused launch: the data-gradient tiles of a stride-1 convolution followed by the tiles of its
 // weight gradient (both consume the same dY).  One grid: the weight-gradient blocks fill the partly empty
 // last round of the data-gradient, and the other way round.
-template <int PREC = 0, bool WB16 = false, bool AB16 = false>
+template <int PREC = 0, bool WB16 = false, bool AB16 = false, bool TW16 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const ng::ConvParams cp, const ng::WgradParams wp, const int conv_blocks) {
     __shared__ __attribute__((aligned(16))) char st0[32768];
     __shared__ __attribute__((aligned(16))) char st1[32768];
     if (int(blockIdx.x) < conv_blocks)
         ng::conv_tile<128, PREC, WB16, AB16>(cp, blockIdx.x, st0, st1);
+    else if constexpr (TW16)
+        ng::wgrad_tile16(wp, int(blockIdx.x) - conv_blocks, st0, st1);
     else
         ng::wgrad_tile<128, PREC>(wp, int(blockIdx.x) - conv_blocks, st0, st1);
 }
@@ -133,6 +142,10 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(p.ntiles_n * p.ntiles_k * p.nsplit);
+    if (p.pq_bf16) {
+        hipLaunchKernelGGL(wgrad_igemm16_kernel, grid, dim3(256), 0, st, p);
+        return nirgan_check_launch("wgrad_igemm");
+    }
 #define NG_LAUNCH_WGRAD(TN, PREC) hipLaunchKernelGGL((wgrad_igemm_kernel<TN, PREC>), grid, dim3(256), 0, st, p)
     if (d->N > 64) {
         if (p.prec == 0) NG_LAUNCH_WGRAD(128, 0); else if (p.prec == 1) NG_LAUNCH_WGRAD(128, 1); else NG_LAUNCH_WGRAD(128, 2);
@@ -150,7 +163,7 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     if (rc != NIRGAN_OK) return rc;
     rc = ng::build_wgrad_params(w, wp);
     if (rc != NIRGAN_OK) return rc;
-    if (c->N <= 64 || w->N <= 64 || c->ksplit > 1) {      // narrow or split-K variants: two ordinary launches
+    if (c->N <= 64 || w->N <= 64 || c->ksplit > 1 || (wp.pq_bf16 && !cp.in_bf16)) {      // narrow, split-K or mixed-storage variants: two ordinary launches
         rc = nirgan_conv_igemm(c, stream);
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
@@ -160,6 +173,7 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     const dim3 grid(conv_blocks + wgrad_blocks);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (cp.prec == 0) hipLaunchKernelGGL(conv_wgrad_pair_kernel<0>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
+    else if (cp.prec == 1 && cp.in_bf16 && wp.pq_bf16) hipLaunchKernelGGL((conv_wgrad_pair_kernel<1, true, true, true>), grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else if (cp.prec == 1 && cp.in_bf16) hipLaunchKernelGGL((conv_wgrad_pair_kernel<1, true, true>), grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else if (cp.prec == 1 && cp.w_bf16) hipLaunchKernelGGL((conv_wgrad_pair_kernel<1, true>), grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else if (cp.prec == 1) hipLaunchKernelGGL(conv_wgrad_pair_kernel<1>, grid, dim3(256), 0, st, cp, wp, conv_blocks);

@@ -40,7 +40,7 @@ class WgradDesc(C.Structure):
                 ("tap_dh", i32 * MAX_TAPS), ("tap_dw", i32 * MAX_TAPS),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32),
                 ("slabs", fp), ("slab_elems", i64), ("nsplit", i32), ("rows_per_split", i32), ("zero_page", fp),
-                ("precision", i32)]
+                ("precision", i32), ("pq_bf16", i32)]
 
 
 class InFwdDesc(C.Structure):

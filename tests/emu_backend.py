@@ -147,7 +147,11 @@ class EmuBackend:
             return self._fail("wgrad: bad split")
         if ((d.N + 3) & ~3) > d.p_cs:
             return self._fail("wgrad: N exceeds p_cs")
-        p, q = arr(d.p, d.p_elems), arr(d.q, d.q_elems)
+        if d.pq_bf16:
+            rd = lambda ptr, n: (np.ctypeslib.as_array((C.c_uint16 * int(n)).from_address(int(ptr))).astype(np.uint32) << 16).view(np.float32)   # noqa: E731
+            p, q = rd(d.p, d.p_elems), rd(d.q, d.q_elems)
+        else:
+            p, q = arr(d.p, d.p_elems), arr(d.q, d.q_elems)
         slabs = arr(d.slabs, d.slab_elems)[: d.nsplit * d.N * K].reshape(d.nsplit, d.N, K)
         p_row, q_row = d.p_wp * d.p_cs, d.q_wp * d.q_cs
         oh, ow = np.arange(d.OH)[:, None], np.arange(d.OW)[None, :]

@@ -515,9 +515,25 @@ def test_bf16_twins_and_twin_fed_convolution():
         g.t.copy_(torch.randn(g.t.shape, generator=torch.Generator().manual_seed(8)).to(dev))
         dy = Halo(ctx, B, H, W, Cc, 2, twin=True)
         emit_in_bwd(plan, ctx, g=g, act=L.ACT_RELU, y=y, stats=stats, norm=True, dy=dy, ws=ws, shape=(B, H, W, Cc))
-        res.append((plan, out, o, o2, dy))
-    (gp, gout, go, go2, gdy), (cp, cout_, co, co2, cdy) = res
+        # weight gradient of that convolution from the twins (dY of the conv output through a norm-free backward pass so that
+        # its twin is written), and the same from the fp32 buffers
+        gc = Halo(ctx, B, H, W, Cout, 0)
+        gc.t.copy_(torch.randn(gc.t.shape, generator=torch.Generator().manual_seed(9)).to(dev))
+        dyc = Halo(ctx, B, H, W, Cout, 2, twin=True)
+        emit_in_bwd(plan, ctx, g=gc, act=L.ACT_NONE, norm=False, dy=dyc, shape=(B, H, W, Cout))
+        gw16, gw32 = ctx.zeros(Cout, Cc, 3, 3), ctx.zeros(Cout, Cc, 3, 3)
+        dw = emit_wgrad(plan, ctx, dyc, out, G.conv_fwd_taps(3, Cc), spec, gw16, N=Cout, OH=H, OW=W, p_oh=2, p_ow=2)
+        assert dw.pq_bf16 == 1
+        ta, tb = dyc.t16, out.t16
+        dyc.t16 = out.t16 = None
+        dw2 = emit_wgrad(plan, ctx, dyc, out, G.conv_fwd_taps(3, Cc), spec, gw32, N=Cout, OH=H, OW=W, p_oh=2, p_ow=2)
+        dyc.t16, out.t16 = ta, tb
+        assert dw2.pq_bf16 == 0
+        res.append((plan, out, o, o2, dy, gw16, gw32))
+    (gp, gout, go, go2, gdy, ggw16, ggw32), (cp, cout_, co, co2, cdy, cgw16, cgw32) = res
     tw.run(gp, cp)
+    close(ggw16, cgw16, 1e-4, "twin-fed weight gradient vs restatement")
+    close(ggw16, ggw32, 1e-5, "twin-fed weight gradient vs fp32-fed")
     assert torch.equal(gout.t16.cpu(), gout.t.cpu().to(torch.bfloat16)), "forward twin is not RNE(out)"
     assert torch.equal(gdy.t16.cpu(), gdy.t.cpu().to(torch.bfloat16)), "backward twin is not RNE(dy)"
     assert float(gout.t[:, 0].abs().max()) > 0 and float(gdy.t[:, :2].abs().max()) == 0     # reflect halo filled, zero halo kept
