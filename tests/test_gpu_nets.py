@@ -441,3 +441,29 @@ def test_micro_batches_on_two_streams_match_the_single_stream_step():
     # second step: trajectories have separated by Adam's amplification of rounding noise only
     for k in a[1][0]:
         close(torch.tensor(b[1][0][k]), torch.tensor(a[1][0][k]), 5e-3, "step 2 " + k)
+
+
+def test_fullsize_inject_generator_forward_against_oracle():
+    """configs[3] geometry at one tile: ngf 64, 9 blocks, 256x256 with the YAML's reflect pad 10 -> the SatCLIP map (128x128
+    from the 256 -> 16384 fc) is resized to the 138x138 feature map and multiplies it (generator_inject.py:110-127); the
+    forward against the CPU oracle at 1e-3, scale 0.5 so that the modulation is not a rounding-level effect."""
+    from model.generator_inject import define_G_inject
+    ns = types.SimpleNamespace
+    cfg = ns(base_configs=ns(input_nc=3, output_nc=1, ngf=64, netG="resnet_9blocks", norm="instance", no_dropout=True,
+                             init_type="normal", init_gain=0.02),
+             satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
+                        scaling_param=True, scaling_param_init=0.5))
+    torch.manual_seed(0)
+    net = define_G_inject(cfg)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    rgb, _ = synth(1, 256, 256, 31)
+    emb = torch.randn(1, 256, generator=torch.Generator().manual_seed(32))
+    net = net.to(DEV)
+    net.data_pad = 10
+    with torch.no_grad():
+        pred = net(rgb.to(DEV), emb.to(DEV)).cpu()
+    ref = O.px_forward(sd, rgb, 9, 10, emb, {"style": "multiply", "use_scale": True})
+    assert pred.shape == ref.shape == (1, 1, 256, 256)
+    close(pred, ref, 1e-3, "inject forward")
+    plain = O.px_forward({**sd, "scale_param": torch.tensor(0.0)}, rgb, 9, 10, emb, {"style": "multiply", "use_scale": True})
+    assert (ref - plain).abs().max().item() > 1e-2          # the injection changes the output visibly
