@@ -467,3 +467,25 @@ def test_fullsize_inject_generator_forward_against_oracle():
     close(pred, ref, 1e-3, "inject forward")
     plain = O.px_forward({**sd, "scale_param": torch.tensor(0.0)}, rgb, 9, 10, emb, {"style": "multiply", "use_scale": True})
     assert (ref - plain).abs().max().item() > 1e-2          # the injection changes the output visibly
+
+
+def test_size_512_and_128_forward_against_oracle():
+    """The other tile sizes of configs[3]/[4] (512x512 and 128x128): generator and PatchGAN forward against the oracle.
+    512: res blocks at 128x128 (64 M-tiles per sample), PatchGAN map 62x62; 128: res blocks at 32x32, PatchGAN map 14x14."""
+    from model import networks
+    torch.manual_seed(0)
+    netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02)
+    netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
+    sdG = {k: v.clone() for k, v in netG.state_dict().items()}
+    sdD = {k: v.clone() for k, v in netD.state_dict().items()}
+    netG, netD = netG.to(DEV).eval(), netD.to(DEV).eval()
+    for size, B in ((512, 1), (128, 3)):
+        rgb, nir = synth(B, size, size, 50 + size)
+        with torch.no_grad():
+            pred = netG(rgb.to(DEV)).cpu()
+            dout = netD(torch.cat((rgb, nir), 1).to(DEV)).cpu()
+        ref = O.generator_forward(sdG, rgb, 6)
+        close(pred, ref, 1e-3, f"G forward {size}")
+        dref = O.discriminator_forward(sdD, torch.cat((rgb, nir), 1))
+        assert dout.shape == dref.shape == (B, 1, size // 8 - 2, size // 8 - 2)
+        close(dout, dref, 1e-3, f"D forward {size}")
