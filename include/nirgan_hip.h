@@ -343,6 +343,26 @@ typedef struct {
 int64_t nirgan_hist_match_ws_bytes(int B, int N);
 int nirgan_hist_match(const nirgan_hist_match_desc* d, void* stream);
 
+/* -------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) forward of nn.Conv2d(C, K, 3, stride 1) over a halo'd input (halo 1: zero padding or the
+ * reflect halo the producer wrote) -- model/networks.py:405-427 (the two 3x3 convolutions of a ResnetBlock).  Exact fp32
+ * products, 2.25x fewer than the direct contraction; the result differs from it by fp32 rounding only (transform constants
+ * 0, +-1/2, +-1).  U = nirgan_wino_weights(W) is [16][K][C] (W in the reference layout [K][C][3][3]); V is a workspace of
+ * 16*B*(H/2)*(W/2)*C floats; y is dense [B][H][W][K].  H, W even, C % 32 == 0, K % 128 == 0.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x; int x_hp, x_wp;       /* [B][H+2][W+2][C] */
+    int B, H, W, C, K;
+    const float* U; const float* bias;
+    float* V; int64_t V_elems;
+    float* y;
+    const float* zero_page;
+} nirgan_wino_desc;
+
+int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K);   /* V elements + U elements */
+int nirgan_wino_weights(const float* w, int K, int C, float* U, void* stream);
+int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).
  * ------------------------------------------------------------------------------------- */

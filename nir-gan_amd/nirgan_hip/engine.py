@@ -14,6 +14,7 @@ ResnetGenerator_inject.forward (model/generator_inject.py:105-135), NLayerDiscri
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -287,6 +288,34 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     return d
 
 
+def wino_applicable(ctx: Ctx, inp: Halo, k, s, p, cout, OH, OW) -> bool:
+    """Winograd F(2x2, 3x3) forward (csrc/winograd.hip): exact-fp32 mode, stride-1 3x3 over a halo of exactly 1, even output,
+    channel counts the tile supports.  In this network: the two convolutions of every ResnetBlock (64 % of the FLOPs)."""
+    return (ctx.precision == 0 and k == 3 and s == 1 and p == 1 and inp.pad == 1 and OH % 2 == 0 and OW % 2 == 0
+            and inp.C % 32 == 0 and cout % 128 == 0 and OH == inp.H and OW == inp.W
+            and os.environ.get("NIRGAN_NO_WINOGRAD") != "1")
+
+
+def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, inp: Halo, weight: torch.Tensor, bias, out: Halo, *, cout):
+    """U = G g G^T in the pack plan (re-run when the weights change); input transform + fused GEMM/output transform in `plan`."""
+    B, H, W, Cc = inp.B, inp.H, inp.W, inp.C
+    T = B * (H // 2) * (W // 2)
+    U = ctx.zeros(16 * cout * Cc)
+    ctx.keep.append(U)
+    pack.add("nirgan_wino_weights", weight.data_ptr(), cout, Cc, U.data_ptr())
+    if not hasattr(ctx, "wino_pool"):
+        ctx.wino_pool = SplitPool(ctx)                 # the transform-domain input of ONE layer at a time (launches run serially)
+    V = ctx.wino_pool.get(16 * T * Cc)
+    d = L.WinoDesc()
+    d.x, d.x_hp, d.x_wp = inp.ptr, inp.hp, inp.wp
+    d.B, d.H, d.W, d.C, d.K = B, H, W, Cc, cout
+    d.U, d.bias, d.V, d.V_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), out.ptr
+    d.zero_page = ctx.zero_page.data_ptr()
+    ctx.keep.append(d)
+    plan.add("nirgan_wino_conv3x3", C.byref(d))
+    return d
+
+
 def emit_conv_group(plan: Plan, ctx: Ctx, descs: list):
     """One launch for up to 4 conv descriptors (sub-pixel phases)."""
     for i in range(0, len(descs), 4):
@@ -416,7 +445,9 @@ class ConvIN:
     def emit_fwd(self, plan: Plan, pack: Plan):
         eng, ctx, inp = self.eng, self.eng.ctx, self.inp
         k, s, p = self.k, self.s, self.p
-        if self.kind == "conv":
+        if self.kind == "conv" and wino_applicable(ctx, inp, k, s, p, self.cout, self.OH, self.OW):
+            emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, cout=self.cout)
+        elif self.kind == "conv":
             taps = G.conv_fwd_taps(k, inp.C)
             w = eng.weights.packed(pack, self.weight, G.conv_fwd_pack(self.cout, inp.C, k))
             emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,

@@ -113,6 +113,11 @@ class HistMatchDesc(C.Structure):
     _fields_ = [("image", fp), ("reference", fp), ("B", i32), ("N", i32), ("ws", fp), ("ws_bytes", i64), ("out", fp)]
 
 
+class WinoDesc(C.Structure):
+    _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
+                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("y", fp), ("zero_page", fp)]
+
+
 class PlanEntry(C.Structure):
     _fields_ = [("op", i32), ("desc", fp)]
 
@@ -130,6 +135,9 @@ PROTOTYPES = {
     "nirgan_pack_rows_bf16": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_location_encoder": (i32, [C.POINTER(LocEncDesc), fp]),
+    "nirgan_wino_ws_elems": (i64, [i32, i32, i32, i32, i32]),
+    "nirgan_wino_weights": (i32, [fp, i32, i32, fp, fp]),
+    "nirgan_wino_conv3x3": (i32, [C.POINTER(WinoDesc), fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),
     "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),
     "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),

@@ -283,6 +283,48 @@ class EmuBackend:
         arr(d.out, d.B * d.dims[d.nlayers], np.float64)[:] = h.reshape(-1)
         return 0
 
+    # ------------------------------------------------------------------ Winograd F(2x2, 3x3)
+    _G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+    _BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+    _AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+
+    def nirgan_wino_ws_elems(self, B, H, W, Cc, K):
+        return 16 * B * (H // 2) * (W // 2) * Cc + 16 * K * Cc
+
+    def nirgan_wino_weights(self, w, K, Cc, U, stream=None):
+        self.calls.append("wino_w")
+        g = arr(w, K * Cc * 9).reshape(K, Cc, 3, 3).astype(np.float64)
+        u = np.einsum("ai,kcij,bj->abkc", self._G, g, self._G)
+        arr(U, 16 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
+        return 0
+
+    def nirgan_wino_conv3x3(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("wino")
+        if d.H % 2 or d.W % 2 or d.C % 32 or d.K % 128 or d.x_hp != d.H + 2 or d.x_wp != d.W + 2:
+            return self._fail("wino_conv3x3: bad geometry")
+        B, H, W, Cc, K = d.B, d.H, d.W, d.C, d.K
+        T = B * (H // 2) * (W // 2)
+        if d.V_elems < 16 * T * Cc:
+            return self._fail("wino_conv3x3: V workspace too small")
+        x = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
+        U = arr(d.U, 16 * K * Cc).reshape(4, 4, K, Cc).astype(np.float64)
+        # 4x4 input tiles with stride 2
+        tiles = np.stack([np.stack([x[:, a:a + H:2, c:c + W:2] for c in range(4)], 0) for a in range(4)], 0)   # [4][4][B][TH][TW][C]
+        V = np.einsum("ai,ijbyxc,cj->acbyx" + "c", self._BT, tiles, self._BT.T) if False else np.einsum("ai,ijbyxc,lj->albyxc", self._BT, tiles, self._BT)
+        arr(d.V, 16 * T * Cc)[:] = V.reshape(-1).astype(np.float32)
+        M = np.einsum("albyxc,alkc->albyxk", V, U)
+        Y = np.einsum("pa,albyxk,ql->pqbyxk", self._AT, M, self._AT)                 # [2][2][B][TH][TW][K]
+        out = arr(d.y, B * H * W * K).reshape(B, H, W, K)
+        bias = arr(d.bias, K)
+        for p_ in range(2):
+            for q_ in range(2):
+                v = Y[p_, q_]
+                if bias is not None:
+                    v = v + bias
+                out[:, p_::2, q_::2] = v.astype(np.float32)
+        return 0
+
     # ------------------------------------------------------------------ histogram matching
     def nirgan_hist_match_ws_bytes(self, B, N):
         P = 2048

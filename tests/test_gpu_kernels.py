@@ -539,3 +539,40 @@ def test_bf16_twins_and_twin_fed_convolution():
     assert float(gout.t[:, 0].abs().max()) > 0 and float(gdy.t[:, :2].abs().max()) == 0     # reflect halo filled, zero halo kept
     close(go.t, co.t, 1e-5, "twin-fed conv vs restatement")
     close(go.t, go2.t, 1e-6, "twin-fed conv vs fp32-fed conv")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128), (1, 64, 64, 256, 256), (3, 6, 4, 32, 128)])
+def test_winograd_conv3x3_matches_direct(shape):
+    """nirgan_wino_weights + nirgan_wino_conv3x3 against torch's conv2d (the reference's nn.Conv2d arithmetic) and the numpy
+    restatement: fp32 rounding only (tolerance 3e-5 of the output's max; the direct MFMA path sits at 1e-5)."""
+    import ctypes as C
+    B, H, W, Cc, K = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, H + 2, W + 2, Cc, generator=g)                    # halo included: any values (reflect or zero in the nets)
+    w = torch.randn(K, Cc, 3, 3, generator=g) * 0.05
+    b = torch.randn(K, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1).float()
+    outs = []
+    emu = EmuBackend()
+    for dev, be in ((DEV, None), ("cpu", emu)):
+        xt, wt, bt = x.to(dev).contiguous(), w.to(dev).contiguous(), b.to(dev)
+        T = B * (H // 2) * (W // 2)
+        U = torch.zeros(16 * K * Cc, device=dev)
+        V = torch.zeros(16 * T * Cc, device=dev)
+        y = torch.zeros(B, H, W, K, device=dev)
+        zero = torch.zeros(64, device=dev)
+        d = L.WinoDesc()
+        d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = xt.data_ptr(), H + 2, W + 2, B, H, W, Cc, K
+        d.U, d.bias, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), bt.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
+        if be is None:
+            st = torch.cuda.current_stream().cuda_stream
+            L.call("nirgan_wino_weights", wt.data_ptr(), K, Cc, U.data_ptr(), st)
+            L.call("nirgan_wino_conv3x3", C.byref(d), st)
+            torch.cuda.synchronize()
+        else:
+            assert be.nirgan_wino_weights(wt.data_ptr(), K, Cc, U.data_ptr()) == 0
+            assert be.nirgan_wino_conv3x3(d) == 0
+        outs.append(y.cpu())
+    close(outs[1], ref, 1e-5, "restatement vs torch")
+    close(outs[0], ref, 3e-5, "device vs torch")
+    close(outs[0], outs[1], 3e-5, "device vs restatement")
