@@ -51,7 +51,9 @@ def mfma_probes(trainer):
     conv_igemm_kernel<128>: 2*M*N*K per launch.  conv_wgrad_pair_kernel (data-gradient tiles + weight-gradient
     tiles of one layer in one grid): the sum of both problems' 2*M*N*K."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
-    kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0]}
+    kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0],
+             "wino_conv3x3 (input transform + wino_gemm_kernel)": [0.0, 0],
+             "wino_wgrad_pair_kernel (+ input transform)": [0.0, 0]}
     for pl in plans:
         pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}
         for i, (name, args) in enumerate(pl.ops):
@@ -62,6 +64,18 @@ def mfma_probes(trainer):
                     kinds[k][0] += 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run
                     kinds[k][1] += 1
                     pl.probe_idx[i] = k
+            elif name == "nirgan_wino_conv3x3":
+                d = args[0]._obj
+                k = "wino_conv3x3 (input transform + wino_gemm_kernel)"
+                kinds[k][0] += 2.0 * 16 * d.B * (d.H // 2) * (d.W // 2) * d.C * d.K      # EXECUTED MFMA flops (4/9 of the direct layer's)
+                kinds[k][1] += 1
+                pl.probe_idx[i] = k
+            elif name == "nirgan_wino_wgrad_pair":
+                c, w = args[0]._obj, args[1]._obj
+                k = "wino_wgrad_pair_kernel (+ input transform)"
+                kinds[k][0] += 2.0 * 16 * c.B * (c.H // 2) * (c.W // 2) * c.C * c.K + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run   # executed
+                kinds[k][1] += 1
+                pl.probe_idx[i] = k
             elif name == "nirgan_conv_igemm_group":
                 ds = [args[0][j].contents for j in range(args[1])]
                 if ds[0].N > 64:

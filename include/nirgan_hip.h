@@ -360,8 +360,14 @@ typedef struct {
 } nirgan_wino_desc;
 
 int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K);   /* V elements + U elements */
-int nirgan_wino_weights(const float* w, int K, int C, float* U, void* stream);
+/* transpose_flip = 0: U for the forward filter, w = [K][C][3][3].  1: U for the DATA GRADIENT, whose filter is
+ * g'[k][c][i][j] = w[c][k][2-i][2-j] with w = [C][K][3][3] the forward weight (C = forward Cout, K = forward Cin): the
+ * full correlation over dY with a zero halo of 2 is then nirgan_wino_conv3x3 with x = dY, H x W = the padded input size. */
+int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);
 int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);
+/* the Winograd data gradient of a layer (c: x = dY, transpose_flip weights) and its weight gradient (w) in ONE grid, like
+ * nirgan_conv_wgrad_pair: the weight-gradient tiles fill the partly empty rounds of the Winograd tiles */
+int nirgan_wino_wgrad_pair(const nirgan_wino_desc* c, const nirgan_wgrad_desc* w, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).

@@ -248,8 +248,9 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
 
 
 def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.PackSpec, grad: torch.Tensor, *,
-               N, OH, OW, p_oh, p_ow, q_stride=1, q_oh=0, q_ow=0, accumulate=False, slabs_pool=None, pair_with=None):
-    """pair_with: a ConvDesc (built with plan=None) launched in the same grid (nirgan_conv_wgrad_pair)."""
+               N, OH, OW, p_oh, p_ow, q_stride=1, q_oh=0, q_ow=0, accumulate=False, slabs_pool=None, pair_with=None, pair_wino=None):
+    """pair_with: a ConvDesc (built with plan=None) launched in the same grid (nirgan_conv_wgrad_pair);
+    pair_wino: a WinoDesc (emit_wino(plan=None)) launched in the same grid (nirgan_wino_wgrad_pair)."""
     K = taps.n * taps.run
     assert K == spec.K, (K, spec.K)
     tiles = (-(-N // 128) if N > 64 else 1) * (-(-K // 128))
@@ -260,6 +261,11 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
         conv_blocks = -(-(c.B * c.OH * c.OW) // 128) * (-(-c.N // 128) if c.N > 64 else 1)
         total = 512 * max(1, round((conv_blocks + 1024) / 512))
         target = max(total - conv_blocks, 512)
+    if pair_wino is not None:
+        c = pair_wino
+        wino_blocks = -(-(c.B * (c.H // 2) * (c.W // 2)) // 64) * (c.K // 128)
+        total = 512 * max(1, round((wino_blocks + 1024) / 512))
+        target = max(total - wino_blocks, 512)
     nsplit, rows = G.wgrad_split(M, tiles, target)
     need = nsplit * N * K
     slabs = slabs_pool.get(need) if slabs_pool is not None else ctx.zeros(need)
@@ -279,7 +285,9 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     d.precision = ctx.precision
     ctx.keep.append(d)
     imap = ctx.i32(spec.index_map)
-    if pair_with is not None:
+    if pair_wino is not None:
+        plan.add("nirgan_wino_wgrad_pair", C.byref(pair_wino), C.byref(d))
+    elif pair_with is not None:
         plan.add("nirgan_conv_wgrad_pair", C.byref(pair_with), C.byref(d))
     else:
         plan.add("nirgan_wgrad_igemm", C.byref(d))
@@ -296,23 +304,40 @@ def wino_applicable(ctx: Ctx, inp: Halo, k, s, p, cout, OH, OW) -> bool:
             and os.environ.get("NIRGAN_NO_WINOGRAD") != "1")
 
 
-def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, inp: Halo, weight: torch.Tensor, bias, out: Halo, *, cout):
-    """U = G g G^T in the pack plan (re-run when the weights change); input transform + fused GEMM/output transform in `plan`."""
-    B, H, W, Cc = inp.B, inp.H, inp.W, inp.C
+def wino_dgrad_applicable(ctx: Ctx, k, s, dgrad_out: Halo, cout, cin) -> bool:
+    return (ctx.precision == 0 and k == 3 and s == 1 and dgrad_out.hp % 2 == 0 and dgrad_out.wp % 2 == 0
+            and cout % 32 == 0 and cin % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD") != "1"
+            and os.environ.get("NIRGAN_NO_WINOGRAD_DGRAD") != "1")
+
+
+class _FullExtent:
+    """A halo'd buffer seen as the dense [B][hp][wp][C] tensor it is in memory (the data gradient covers the padded extent)."""
+
+    def __init__(self, h: Halo):
+        self.B, self.hp, self.wp, self.C, self.ptr = h.B, h.hp, h.wp, h.C, h.ptr
+
+
+def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y: Halo, *, H, W, cin, cout, flip=False):
+    """U = G g G^T in the pack plan (re-run when the weights change); input transform + fused GEMM/output transform in `plan`.
+    x: buffer of [B][H+2][W+2][cin] (its own halo'd geometry must match), y: dense [B][H][W][cout] (a buffer's full padded
+    extent counts as dense).  flip: data gradient (x = dY with a zero halo of 2, H x W = the padded input size)."""
+    assert x.hp == H + 2 and x.wp == W + 2 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
+    B = x.B
     T = B * (H // 2) * (W // 2)
-    U = ctx.zeros(16 * cout * Cc)
+    U = ctx.zeros(16 * cout * cin)
     ctx.keep.append(U)
-    pack.add("nirgan_wino_weights", weight.data_ptr(), cout, Cc, U.data_ptr())
+    pack.add("nirgan_wino_weights", weight.data_ptr(), cout, cin, 1 if flip else 0, U.data_ptr())
     if not hasattr(ctx, "wino_pool"):
         ctx.wino_pool = SplitPool(ctx)                 # the transform-domain input of ONE layer at a time (launches run serially)
-    V = ctx.wino_pool.get(16 * T * Cc)
+    V = ctx.wino_pool.get(16 * T * cin)
     d = L.WinoDesc()
-    d.x, d.x_hp, d.x_wp = inp.ptr, inp.hp, inp.wp
-    d.B, d.H, d.W, d.C, d.K = B, H, W, Cc, cout
-    d.U, d.bias, d.V, d.V_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), out.ptr
+    d.x, d.x_hp, d.x_wp = x.ptr, x.hp, x.wp
+    d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
+    d.U, d.bias, d.V, d.V_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), y.ptr
     d.zero_page = ctx.zero_page.data_ptr()
     ctx.keep.append(d)
-    plan.add("nirgan_wino_conv3x3", C.byref(d))
+    if plan is not None:
+        plan.add("nirgan_wino_conv3x3", C.byref(d))
     return d
 
 
@@ -446,7 +471,7 @@ class ConvIN:
         eng, ctx, inp = self.eng, self.eng.ctx, self.inp
         k, s, p = self.k, self.s, self.p
         if self.kind == "conv" and wino_applicable(ctx, inp, k, s, p, self.cout, self.OH, self.OW):
-            emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, cout=self.cout)
+            emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C, cout=self.cout)
         elif self.kind == "conv":
             taps = G.conv_fwd_taps(k, inp.C)
             w = eng.weights.packed(pack, self.weight, G.conv_fwd_pack(self.cout, inp.C, k))
@@ -493,6 +518,16 @@ class ConvIN:
                     shape=(inp.B, self.OH, self.OW, self.cout))
         dy = self.dy
         # stride-1 convolutions that need both gradients: one fused launch (data-gradient tiles + weight-gradient tiles)
+        if (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
+                and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C)):
+            # exact-fp32 mode, 3x3: the data gradient is a Winograd convolution of dY (zero halo 2) with the flipped filter over the
+            # padded input extent; the weight gradient keeps the direct tile (stand-alone launch)
+            wd = emit_wino(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
+                           cin=self.cout, cout=inp.C, flip=True)
+            emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
+                       N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
+                       q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_wino=wd)
+            return
         if self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None:
             assert dgrad_out.H == inp.H and dgrad_out.pad == p and dy.pad == k - 1
             hw = [(kh, kw) for kh in range(k) for kw in range(k)]

@@ -16,7 +16,7 @@ d = L.WinoDesc()
 d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = x.data_ptr(), H + 2, W + 2, B, H, W, Cc, K
 d.U, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
 st = torch.cuda.current_stream().cuda_stream
-L.call("nirgan_wino_weights", w.data_ptr(), K, Cc, U.data_ptr(), st)
+L.call("nirgan_wino_weights", w.data_ptr(), K, Cc, 0, U.data_ptr(), st)
 
 
 def timeit(fn, reps=20):
@@ -33,6 +33,6 @@ def timeit(fn, reps=20):
 
 
 ms = timeit(lambda: L.call("nirgan_wino_conv3x3", C.byref(d), st))
-msw = timeit(lambda: L.call("nirgan_wino_weights", w.data_ptr(), K, Cc, U.data_ptr(), st))
+msw = timeit(lambda: L.call("nirgan_wino_weights", w.data_ptr(), K, Cc, 0, U.data_ptr(), st))
 fl = 2.0 * B * H * W * K * 9 * Cc
 print(f"winograd conv3x3 (input transform + GEMM/output transform): {ms * 1e3:.1f} us = {fl / ms / 1e9:.1f} TFLOP/s direct-equivalent; weight transform {msw * 1e3:.1f} us")

@@ -291,9 +291,12 @@ class EmuBackend:
     def nirgan_wino_ws_elems(self, B, H, W, Cc, K):
         return 16 * B * (H // 2) * (W // 2) * Cc + 16 * K * Cc
 
-    def nirgan_wino_weights(self, w, K, Cc, U, stream=None):
+    def nirgan_wino_weights(self, w, K, Cc, flip, U, stream=None):
         self.calls.append("wino_w")
-        g = arr(w, K * Cc * 9).reshape(K, Cc, 3, 3).astype(np.float64)
+        if flip:
+            g = arr(w, K * Cc * 9).reshape(Cc, K, 3, 3).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
+        else:
+            g = arr(w, K * Cc * 9).reshape(K, Cc, 3, 3).astype(np.float64)
         u = np.einsum("ai,kcij,bj->abkc", self._G, g, self._G)
         arr(U, 16 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
         return 0
@@ -324,6 +327,10 @@ class EmuBackend:
                     v = v + bias
                 out[:, p_::2, q_::2] = v.astype(np.float32)
         return 0
+
+    def nirgan_wino_wgrad_pair(self, cref, wref, stream=None):
+        rc = self.nirgan_wino_conv3x3(cref)
+        return rc if rc else self.nirgan_wgrad_igemm(wref)
 
     # ------------------------------------------------------------------ histogram matching
     def nirgan_hist_match_ws_bytes(self, B, N):

@@ -566,13 +566,48 @@ def test_winograd_conv3x3_matches_direct(shape):
         d.U, d.bias, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), bt.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
         if be is None:
             st = torch.cuda.current_stream().cuda_stream
-            L.call("nirgan_wino_weights", wt.data_ptr(), K, Cc, U.data_ptr(), st)
+            L.call("nirgan_wino_weights", wt.data_ptr(), K, Cc, 0, U.data_ptr(), st)
             L.call("nirgan_wino_conv3x3", C.byref(d), st)
             torch.cuda.synchronize()
         else:
-            assert be.nirgan_wino_weights(wt.data_ptr(), K, Cc, U.data_ptr()) == 0
+            assert be.nirgan_wino_weights(wt.data_ptr(), K, Cc, 0, U.data_ptr()) == 0
             assert be.nirgan_wino_conv3x3(d) == 0
         outs.append(y.cpu())
     close(outs[1], ref, 1e-5, "restatement vs torch")
     close(outs[0], ref, 3e-5, "device vs torch")
     close(outs[0], outs[1], 3e-5, "device vs restatement")
+
+
+def test_winograd_data_gradient_matches_autograd():
+    """nirgan_wino_weights(transpose_flip=1) + nirgan_wino_conv3x3 over dY with a zero halo of 2 = the data gradient of
+    nn.Conv2d(C, K, 3, padding=1) on the PADDED input extent (the ring is the adjoint of the reflect / zero padding's source)."""
+    import ctypes as C
+    B, H, W, Cin, Cout = 2, 10, 14, 128, 64          # forward: Cin -> Cout; the gradient contracts over Cout and has Cin outputs
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    # reference: gradient wrt the padded input xp (B, Cin, H+2, W+2) of conv2d(xp, w) (no padding) -- full correlation
+    xp = torch.zeros(B, Cin, H + 2, W + 2, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xp, w.double()).backward(dy.double())
+    ref = xp.grad.permute(0, 2, 3, 1).float()
+    z = torch.zeros(B, H + 4, W + 4, Cout)
+    z[:, 2:-2, 2:-2] = dy.permute(0, 2, 3, 1)
+    Hp, Wp = H + 2, W + 2
+    T = B * (Hp // 2) * (Wp // 2)
+    zt, wt = z.to(DEV).contiguous(), w.to(DEV).contiguous()
+    U, V = torch.zeros(16 * Cin * Cout, device=DEV), torch.zeros(16 * T * Cout, device=DEV)
+    y, zero = torch.zeros(B, Hp, Wp, Cin, device=DEV), torch.zeros(64, device=DEV)
+    d = L.WinoDesc()
+    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = zt.data_ptr(), H + 4, W + 4, B, Hp, Wp, Cout, Cin
+    d.U, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    L.call("nirgan_wino_weights", wt.data_ptr(), Cin, Cout, 1, U.data_ptr(), st)
+    L.call("nirgan_wino_conv3x3", C.byref(d), st)
+    torch.cuda.synchronize()
+    close(y.cpu(), ref, 3e-5, "winograd data gradient")
+    emu = EmuBackend()
+    U2, V2, y2 = torch.zeros(16 * Cin * Cout), torch.zeros(16 * T * Cout), torch.zeros(B, Hp, Wp, Cin)
+    zc, wc = z.contiguous(), w.contiguous()
+    d.x, d.U, d.V, d.y, d.zero_page = zc.data_ptr(), U2.data_ptr(), V2.data_ptr(), y2.data_ptr(), torch.zeros(64).data_ptr()
+    assert emu.nirgan_wino_weights(wc.data_ptr(), Cin, Cout, 1, U2.data_ptr()) == 0 and emu.nirgan_wino_conv3x3(d) == 0
+    close(y2, ref, 1e-5, "restatement of the data gradient")
