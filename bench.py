@@ -52,8 +52,8 @@ def mfma_probes(trainer):
     tiles of one layer in one grid): the sum of both problems' 2*M*N*K."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0],
-             "wino_conv3x3 (input transform + wino_gemm_kernel)": [0.0, 0],
-             "wino_wgrad_pair_kernel (+ input transform)": [0.0, 0]}
+             "wino_gemm_kernel": [0.0, 0],
+             "wino_wgrad_pair_kernel": [0.0, 0]}
     for pl in plans:
         pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}
         for i, (name, args) in enumerate(pl.ops):
@@ -64,15 +64,15 @@ def mfma_probes(trainer):
                     kinds[k][0] += 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run
                     kinds[k][1] += 1
                     pl.probe_idx[i] = k
-            elif name == "nirgan_wino_conv3x3":
+            elif name == "nirgan_wino_gemm":
                 d = args[0]._obj
-                k = "wino_conv3x3 (input transform + wino_gemm_kernel)"
+                k = "wino_gemm_kernel"
                 kinds[k][0] += 2.0 * 16 * d.B * (d.H // 2) * (d.W // 2) * d.C * d.K      # EXECUTED MFMA flops (4/9 of the direct layer's)
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
             elif name == "nirgan_wino_wgrad_pair":
                 c, w = args[0]._obj, args[1]._obj
-                k = "wino_wgrad_pair_kernel (+ input transform)"
+                k = "wino_wgrad_pair_kernel"
                 kinds[k][0] += 2.0 * 16 * c.B * (c.H // 2) * (c.W // 2) * c.C * c.K + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run   # executed
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
@@ -306,6 +306,10 @@ def main():
                     r["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, mean over the kernel's launches)"
                     if "mfma_busy_fraction_of_active_cycles" in ent:
                         r["pmc_mfma_busy"] = round(ent["mfma_busy_fraction_of_active_cycles"], 4)
+            for r in roofs:
+                if r["kernel"].startswith("wino"):
+                    r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(2x2,3x3) part performs 16/36 of the direct layer's "
+                                          "multiplies")
             roofs.sort(key=lambda r: -r["share_of_step_time"])
             roof = roofs[0] if roofs else None
             roof_other = roofs[1:] or None

@@ -364,8 +364,10 @@ int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K);   /* V elements
  * g'[k][c][i][j] = w[c][k][2-i][2-j] with w = [C][K][3][3] the forward weight (C = forward Cout, K = forward Cin): the
  * full correlation over dY with a zero halo of 2 is then nirgan_wino_conv3x3 with x = dY, H x W = the padded input size. */
 int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);
-int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);
-/* the Winograd data gradient of a layer (c: x = dY, transpose_flip weights) and its weight gradient (w) in ONE grid, like
+int nirgan_wino_input(const nirgan_wino_desc* d, void* stream);     /* V = B^T d B from x */
+int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream);      /* y from V and U (frequency-folding GEMM + bias) */
+int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);   /* both */
+/* the GEMM stage of the Winograd data gradient of a layer (c: x = dY, transpose_flip weights; nirgan_wino_input(c) must have run) and its weight gradient (w) in ONE grid, like
  * nirgan_conv_wgrad_pair: the weight-gradient tiles fill the partly empty rounds of the Winograd tiles */
 int nirgan_wino_wgrad_pair(const nirgan_wino_desc* c, const nirgan_wgrad_desc* w, void* stream);
 

@@ -198,11 +198,11 @@ extern "C" int nirgan_wino_wgrad_pair(const nirgan_wino_desc* c, const nirgan_wg
     int rc = ng::build_wgrad_params(w, wp);
     if (rc != NIRGAN_OK) return rc;
     if (w->N <= 64 || wp.prec != 0 || wp.pq_bf16) {           // not the wide fp32 tile: two ordinary launches
-        rc = nirgan_wino_conv3x3(c, stream);
+        rc = nirgan_wino_gemm(c, stream);
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
     ng::WinoG g;
-    rc = ng_wino_stage1(c, stream, &g);                        // validation + input transform
+    rc = ng_wino_gemm_params(c, &g);
     if (rc != NIRGAN_OK) return rc;
     const int wino_blocks = g.mtiles * g.ntiles;
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit;

@@ -186,4 +186,4 @@ inline void build_wino_params(const nirgan_wino_desc* d, WinoG& g) {
 
 }  // namespace ng
 
-int ng_wino_stage1(const nirgan_wino_desc* d, void* stream, ng::WinoG* g);   // winograd.hip
+int ng_wino_gemm_params(const nirgan_wino_desc* d, ng::WinoG* g);   // winograd.hip: validation + parameters

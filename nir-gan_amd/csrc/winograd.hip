@@ -105,8 +105,7 @@ extern "C" int nirgan_wino_weights(const float* w, int K, int C, int transpose_f
     return nirgan_check_launch("wino_weights");
 }
 
-// validation + input transform launch + parameters of the GEMM stage (shared with nirgan_wino_wgrad_pair, igemm_wgrad.hip)
-int ng_wino_stage1(const nirgan_wino_desc* d, void* stream, ng::WinoG* g) {
+static int wino_check(const nirgan_wino_desc* d) {
     NG_REQUIRE(d && d->x && d->U && d->V && d->y && d->zero_page, "wino_conv3x3: null pointer");
     NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && !(d->H & 1) && !(d->W & 1), "wino_conv3x3: H and W must be even (H=%d W=%d)", d->H, d->W);
     NG_REQUIRE(d->C % 32 == 0 && d->C > 0 && d->K > 0 && d->K % 128 == 0, "wino_conv3x3: C %% 32 == 0 and K %% 128 == 0 (C=%d K=%d)", d->C, d->K);
@@ -115,19 +114,38 @@ int ng_wino_stage1(const nirgan_wino_desc* d, void* stream, ng::WinoG* g) {
     const long long T = (long long)d->B * (d->H / 2) * (d->W / 2);
     NG_REQUIRE(16 * T * d->C < (1ll << 31) * 4 && T < (1ll << 31) / d->C, "wino_conv3x3: problem too large for 32-bit tile offsets");
     NG_REQUIRE(d->V_elems >= 16 * T * d->C, "wino_conv3x3: V workspace too small");
+    return NIRGAN_OK;
+}
+
+// validation + parameters of the GEMM stage (shared with nirgan_wino_wgrad_pair, igemm_wgrad.hip)
+int ng_wino_gemm_params(const nirgan_wino_desc* d, ng::WinoG* g) {
+    const int rc = wino_check(d);
+    if (rc != NIRGAN_OK) return rc;
+    ng::build_wino_params(d, *g);
+    return NIRGAN_OK;
+}
+
+extern "C" int nirgan_wino_input(const nirgan_wino_desc* d, void* stream) {
+    const int rc = wino_check(d);
+    if (rc != NIRGAN_OK) return rc;
+    const long long T = (long long)d->B * (d->H / 2) * (d->W / 2);
     WinoIn in;
     in.x = d->x; in.V = d->V; in.B = d->B; in.H = d->H; in.W = d->W; in.C = d->C;
     in.x_row = d->x_wp * d->C; in.x_img = d->x_hp * in.x_row; in.TH = d->H / 2; in.TW = d->W / 2; in.T = T;
     const long long nthreads = T * (d->C / 4);
     hipLaunchKernelGGL(wino_input_kernel, dim3(unsigned((nthreads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in);
-    ng::build_wino_params(d, *g);
-    return NIRGAN_OK;
+    return nirgan_check_launch("wino_input");
+}
+
+extern "C" int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream) {
+    ng::WinoG g;
+    const int rc = ng_wino_gemm_params(d, &g);
+    if (rc != NIRGAN_OK) return rc;
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3(g.mtiles * g.ntiles), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    return nirgan_check_launch("wino_gemm");
 }
 
 extern "C" int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream) {
-    ng::WinoG g;
-    const int rc = ng_wino_stage1(d, stream, &g);
-    if (rc != NIRGAN_OK) return rc;
-    hipLaunchKernelGGL(wino_gemm_kernel, dim3(g.mtiles * g.ntiles), dim3(256), 0, static_cast<hipStream_t>(stream), g);
-    return nirgan_check_launch("wino_conv3x3");
+    const int rc = nirgan_wino_input(d, stream);
+    return rc != NIRGAN_OK ? rc : nirgan_wino_gemm(d, stream);
 }

@@ -286,6 +286,7 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     ctx.keep.append(d)
     imap = ctx.i32(spec.index_map)
     if pair_wino is not None:
+        plan.add("nirgan_wino_input", C.byref(pair_wino))
         plan.add("nirgan_wino_wgrad_pair", C.byref(pair_wino), C.byref(d))
     elif pair_with is not None:
         plan.add("nirgan_conv_wgrad_pair", C.byref(pair_with), C.byref(d))
@@ -337,7 +338,8 @@ def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, b
     d.zero_page = ctx.zero_page.data_ptr()
     ctx.keep.append(d)
     if plan is not None:
-        plan.add("nirgan_wino_conv3x3", C.byref(d))
+        plan.add("nirgan_wino_input", C.byref(d))
+        plan.add("nirgan_wino_gemm", C.byref(d))
     return d
 
 

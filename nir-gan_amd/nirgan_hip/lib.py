@@ -137,6 +137,8 @@ PROTOTYPES = {
     "nirgan_location_encoder": (i32, [C.POINTER(LocEncDesc), fp]),
     "nirgan_wino_ws_elems": (i64, [i32, i32, i32, i32, i32]),
     "nirgan_wino_weights": (i32, [fp, i32, i32, i32, fp, fp]),
+    "nirgan_wino_input": (i32, [C.POINTER(WinoDesc), fp]),
+    "nirgan_wino_gemm": (i32, [C.POINTER(WinoDesc), fp]),
     "nirgan_wino_conv3x3": (i32, [C.POINTER(WinoDesc), fp]),
     "nirgan_wino_wgrad_pair": (i32, [C.POINTER(WinoDesc), C.POINTER(WgradDesc), fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),

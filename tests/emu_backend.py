@@ -301,6 +301,12 @@ class EmuBackend:
         arr(U, 16 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
         return 0
 
+    def nirgan_wino_input(self, ref, stream=None):
+        return 0          # the restatement computes V inside the GEMM stage from x (V is written there as well)
+
+    def nirgan_wino_gemm(self, ref, stream=None):
+        return self.nirgan_wino_conv3x3(ref)
+
     def nirgan_wino_conv3x3(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("wino")
