@@ -348,7 +348,7 @@ int nirgan_hist_match(const nirgan_hist_match_desc* d, void* stream);
  * reflect halo the producer wrote) -- model/networks.py:405-427 (the two 3x3 convolutions of a ResnetBlock).  Exact fp32
  * products, 2.25x fewer than the direct contraction; the result differs from it by fp32 rounding only (transform constants
  * 0, +-1/2, +-1).  U = nirgan_wino_weights(W) is [16][K][C] (W in the reference layout [K][C][3][3]); V is a workspace of
- * 16*B*(H/2)*(W/2)*C floats; y is dense [B][H][W][K].  H, W even, C % 32 == 0, K % 128 == 0.
+ * 16*B*ceil(H/2)*ceil(W/2)*C floats; y is dense [B][H][W][K].  C % 32 == 0, K % 128 == 0; odd H / W cost one half-used tile row / column.
  * ------------------------------------------------------------------------------------- */
 typedef struct {
     const float* x; int x_hp, x_wp;       /* [B][H+2][W+2][C] */

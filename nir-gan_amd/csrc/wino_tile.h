@@ -162,6 +162,7 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
                 const int ty = r2 % p.TH, b = r2 / p.TH;
                 f32x4 v = *reinterpret_cast<const f32x4*>(buf + row * BN + chunk * 4);
                 v += bv;
+                if (2 * ty + oa >= p.H || 2 * tx + ob >= p.W) continue;        // odd extent: the last half tile has no pixel there
                 float* dst = p.y + ((size_t(b) * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.K + n;
                 if (n + 4 <= p.K) {
                     *reinterpret_cast<f32x4*>(dst) = v;
@@ -178,9 +179,9 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
 
 // descriptor -> parameters of the GEMM stage (validation lives in winograd.hip::check_wino)
 inline void build_wino_params(const nirgan_wino_desc* d, WinoG& g) {
-    const long long T = (long long)d->B * (d->H / 2) * (d->W / 2);
+    const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
     g.V = d->V; g.U = d->U; g.bias = d->bias; g.y = d->y; g.zero = d->zero_page;
-    g.T = int(T); g.C = d->C; g.K = d->K; g.TH = d->H / 2; g.TW = d->W / 2; g.H = d->H; g.W = d->W;
+    g.T = int(T); g.C = d->C; g.K = d->K; g.TH = (d->H + 1) / 2; g.TW = (d->W + 1) / 2; g.H = d->H; g.W = d->W;
     g.mtiles = int((T + 63) / 64); g.ntiles = d->K / 128;
 }
 

@@ -55,11 +55,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoIn p) {
     const long long r = t / p.TW;
     const int ty = int(r % p.TH), b = int(r / p.TH);
     const float* src = p.x + size_t(b) * p.x_img + size_t(2 * ty) * p.x_row + size_t(2 * tx) * p.C + q * 4;
+    // odd H / W: the last tile row / column reaches one line past the halo; those lines feed only outputs that are never stored
+    const int amax = p.H + 2 - 2 * ty, cmax = p.W + 2 - 2 * tx;      // valid lines / columns of this tile (4, or 3 at an odd edge)
     f32x4 d[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[a][c] = *reinterpret_cast<const f32x4*>(src + size_t(a) * p.x_row + size_t(c) * p.C);
+        for (int c = 0; c < 4; ++c)
+            d[a][c] = (a < amax && c < cmax) ? *reinterpret_cast<const f32x4*>(src + size_t(a) * p.x_row + size_t(c) * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 m[4][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -93,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const ng::WinoG p) {
 }  // namespace
 
 extern "C" int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K) {
-    if (B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0 || K <= 0) return 0;
-    return 16ll * B * (H / 2) * (W / 2) * C + 16ll * K * C;
+    if (B <= 0 || H <= 1 || W <= 1 || C <= 0 || K <= 0) return 0;
+    return 16ll * B * ((H + 1) / 2) * ((W + 1) / 2) * C + 16ll * K * C;
 }
 
 extern "C" int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream) {
@@ -107,11 +110,11 @@ extern "C" int nirgan_wino_weights(const float* w, int K, int C, int transpose_f
 
 static int wino_check(const nirgan_wino_desc* d) {
     NG_REQUIRE(d && d->x && d->U && d->V && d->y && d->zero_page, "wino_conv3x3: null pointer");
-    NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && !(d->H & 1) && !(d->W & 1), "wino_conv3x3: H and W must be even (H=%d W=%d)", d->H, d->W);
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1, "wino_conv3x3: empty problem (H=%d W=%d)", d->H, d->W);
     NG_REQUIRE(d->C % 32 == 0 && d->C > 0 && d->K > 0 && d->K % 128 == 0, "wino_conv3x3: C %% 32 == 0 and K %% 128 == 0 (C=%d K=%d)", d->C, d->K);
     NG_REQUIRE(d->x_hp == d->H + 2 && d->x_wp == d->W + 2, "wino_conv3x3: the input must carry a halo of exactly 1 (%dx%d for %dx%d)", d->x_hp, d->x_wp, d->H, d->W);
     NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->y) && ng_aligned16(d->zero_page), "wino_conv3x3: pointers must be 16-byte aligned");
-    const long long T = (long long)d->B * (d->H / 2) * (d->W / 2);
+    const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
     NG_REQUIRE(16 * T * d->C < (1ll << 31) * 4 && T < (1ll << 31) / d->C, "wino_conv3x3: problem too large for 32-bit tile offsets");
     NG_REQUIRE(d->V_elems >= 16 * T * d->C, "wino_conv3x3: V workspace too small");
     return NIRGAN_OK;
@@ -128,10 +131,10 @@ int ng_wino_gemm_params(const nirgan_wino_desc* d, ng::WinoG* g) {
 extern "C" int nirgan_wino_input(const nirgan_wino_desc* d, void* stream) {
     const int rc = wino_check(d);
     if (rc != NIRGAN_OK) return rc;
-    const long long T = (long long)d->B * (d->H / 2) * (d->W / 2);
+    const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
     WinoIn in;
     in.x = d->x; in.V = d->V; in.B = d->B; in.H = d->H; in.W = d->W; in.C = d->C;
-    in.x_row = d->x_wp * d->C; in.x_img = d->x_hp * in.x_row; in.TH = d->H / 2; in.TW = d->W / 2; in.T = T;
+    in.x_row = d->x_wp * d->C; in.x_img = d->x_hp * in.x_row; in.TH = (d->H + 1) / 2; in.TW = (d->W + 1) / 2; in.T = T;
     const long long nthreads = T * (d->C / 4);
     hipLaunchKernelGGL(wino_input_kernel, dim3(unsigned((nthreads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in);
     return nirgan_check_launch("wino_input");

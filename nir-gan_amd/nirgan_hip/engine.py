@@ -263,7 +263,7 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
         target = max(total - conv_blocks, 512)
     if pair_wino is not None:
         c = pair_wino
-        wino_blocks = -(-(c.B * (c.H // 2) * (c.W // 2)) // 64) * (c.K // 128)
+        wino_blocks = -(-(c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2)) // 64) * (c.K // 128)
         total = 512 * max(1, round((wino_blocks + 1024) / 512))
         target = max(total - wino_blocks, 512)
     nsplit, rows = G.wgrad_split(M, tiles, target)
@@ -300,13 +300,13 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
 def wino_applicable(ctx: Ctx, inp: Halo, k, s, p, cout, OH, OW) -> bool:
     """Winograd F(2x2, 3x3) forward (csrc/winograd.hip): exact-fp32 mode, stride-1 3x3 over a halo of exactly 1, even output,
     channel counts the tile supports.  In this network: the two convolutions of every ResnetBlock (64 % of the FLOPs)."""
-    return (ctx.precision == 0 and k == 3 and s == 1 and p == 1 and inp.pad == 1 and OH % 2 == 0 and OW % 2 == 0
+    return (ctx.precision == 0 and k == 3 and s == 1 and p == 1 and inp.pad == 1
             and inp.C % 32 == 0 and cout % 128 == 0 and OH == inp.H and OW == inp.W
             and os.environ.get("NIRGAN_NO_WINOGRAD") != "1")
 
 
 def wino_dgrad_applicable(ctx: Ctx, k, s, dgrad_out: Halo, cout, cin) -> bool:
-    return (ctx.precision == 0 and k == 3 and s == 1 and dgrad_out.hp % 2 == 0 and dgrad_out.wp % 2 == 0
+    return (ctx.precision == 0 and k == 3 and s == 1
             and cout % 32 == 0 and cin % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD") != "1"
             and os.environ.get("NIRGAN_NO_WINOGRAD_DGRAD") != "1")
 
@@ -324,7 +324,7 @@ def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, b
     extent counts as dense).  flip: data gradient (x = dY with a zero halo of 2, H x W = the padded input size)."""
     assert x.hp == H + 2 and x.wp == W + 2 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
     B = x.B
-    T = B * (H // 2) * (W // 2)
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
     U = ctx.zeros(16 * cout * cin)
     ctx.keep.append(U)
     pack.add("nirgan_wino_weights", weight.data_ptr(), cout, cin, 1 if flip else 0, U.data_ptr())

@@ -289,7 +289,7 @@ class EmuBackend:
     _AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
 
     def nirgan_wino_ws_elems(self, B, H, W, Cc, K):
-        return 16 * B * (H // 2) * (W // 2) * Cc + 16 * K * Cc
+        return 16 * B * ((H + 1) // 2) * ((W + 1) // 2) * Cc + 16 * K * Cc
 
     def nirgan_wino_weights(self, w, K, Cc, flip, U, stream=None):
         self.calls.append("wino_w")
@@ -310,17 +310,20 @@ class EmuBackend:
     def nirgan_wino_conv3x3(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("wino")
-        if d.H % 2 or d.W % 2 or d.C % 32 or d.K % 128 or d.x_hp != d.H + 2 or d.x_wp != d.W + 2:
+        if d.C % 32 or d.K % 128 or d.x_hp != d.H + 2 or d.x_wp != d.W + 2 or d.H < 2 or d.W < 2:
             return self._fail("wino_conv3x3: bad geometry")
         B, H, W, Cc, K = d.B, d.H, d.W, d.C, d.K
-        T = B * (H // 2) * (W // 2)
+        TH, TW = (H + 1) // 2, (W + 1) // 2
+        T = B * TH * TW
         if d.V_elems < 16 * T * Cc:
             return self._fail("wino_conv3x3: V workspace too small")
-        x = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
+        x0 = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
+        x = np.zeros((B, 2 * TH + 2, 2 * TW + 2, Cc))               # odd extents: one zero line past the halo (feeds unused outputs)
+        x[:, :d.x_hp, :d.x_wp] = x0
         U = arr(d.U, 16 * K * Cc).reshape(4, 4, K, Cc).astype(np.float64)
-        # 4x4 input tiles with stride 2
-        tiles = np.stack([np.stack([x[:, a:a + H:2, c:c + W:2] for c in range(4)], 0) for a in range(4)], 0)   # [4][4][B][TH][TW][C]
-        V = np.einsum("ai,ijbyxc,cj->acbyx" + "c", self._BT, tiles, self._BT.T) if False else np.einsum("ai,ijbyxc,lj->albyxc", self._BT, tiles, self._BT)
+        He, We = 2 * TH, 2 * TW
+        tiles = np.stack([np.stack([x[:, a:a + He:2, c:c + We:2] for c in range(4)], 0) for a in range(4)], 0)   # [4][4][B][TH][TW][C]
+        V = np.einsum("ai,ijbyxc,lj->albyxc", self._BT, tiles, self._BT)
         arr(d.V, 16 * T * Cc)[:] = V.reshape(-1).astype(np.float32)
         M = np.einsum("albyxc,alkc->albyxk", V, U)
         Y = np.einsum("pa,albyxk,ql->pqbyxk", self._AT, M, self._AT)                 # [2][2][B][TH][TW][K]
@@ -331,7 +334,8 @@ class EmuBackend:
                 v = Y[p_, q_]
                 if bias is not None:
                     v = v + bias
-                out[:, p_::2, q_::2] = v.astype(np.float32)
+                nh, nw = len(range(p_, H, 2)), len(range(q_, W, 2))
+                out[:, p_::2, q_::2] = v[:, :nh, :nw].astype(np.float32)
         return 0
 
     def nirgan_wino_wgrad_pair(self, cref, wref, stream=None):

@@ -541,7 +541,7 @@ def test_bf16_twins_and_twin_fed_convolution():
     close(go.t, go2.t, 1e-6, "twin-fed conv vs fp32-fed conv")
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128), (1, 64, 64, 256, 256), (3, 6, 4, 32, 128)])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128), (1, 64, 64, 256, 256), (3, 6, 4, 32, 128), (2, 9, 7, 64, 128), (1, 69, 69, 256, 256)])
 def test_winograd_conv3x3_matches_direct(shape):
     """nirgan_wino_weights + nirgan_wino_conv3x3 against torch's conv2d (the reference's nn.Conv2d arithmetic) and the numpy
     restatement: fp32 rounding only (tolerance 3e-5 of the output's max; the direct MFMA path sits at 1e-5)."""
@@ -556,7 +556,7 @@ def test_winograd_conv3x3_matches_direct(shape):
     emu = EmuBackend()
     for dev, be in ((DEV, None), ("cpu", emu)):
         xt, wt, bt = x.to(dev).contiguous(), w.to(dev).contiguous(), b.to(dev)
-        T = B * (H // 2) * (W // 2)
+        T = B * ((H + 1) // 2) * ((W + 1) // 2)
         U = torch.zeros(16 * K * Cc, device=dev)
         V = torch.zeros(16 * T * Cc, device=dev)
         y = torch.zeros(B, H, W, K, device=dev)
