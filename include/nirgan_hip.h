@@ -114,6 +114,8 @@ typedef struct {
     int nsplit, rows_per_split;           /* rows_per_split % 32 == 0, nsplit*rows_per_split >= B*OH*OW */
     const float* zero_page;
     int precision;                        /* as in nirgan_conv_desc */
+    int nplanes; int64_t p_plane, q_plane;/* > 1: that many independent problems of this geometry in one grid; plane i reads
+                                           * p + i*p_plane, q + i*q_plane (floats) and writes slabs [i][nsplit][N][K] (fp32 tile only) */
     int pq_bf16;                          /* 1: p and q point to bf16 twins (same geometry; the producers' out_bf16 / dy_bf16);
                                            * precision 1, N > 64, and N, run, p_cs, q_cs multiples of 8 */
 } nirgan_wgrad_desc;
@@ -370,6 +372,18 @@ int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);   /* both */
 /* the GEMM stage of the Winograd data gradient of a layer (c: x = dY, transpose_flip weights; nirgan_wino_input(c) must have run) and its weight gradient (w) in ONE grid, like
  * nirgan_conv_wgrad_pair: the weight-gradient tiles fill the partly empty rounds of the Winograd tiles */
 int nirgan_wino_wgrad_pair(const nirgan_wino_desc* c, const nirgan_wgrad_desc* w, void* stream);
+
+/* Winograd-domain WEIGHT gradient of the same layers: dU[f][k][c] = sum_t Yt[f][t][k] * V[f][t][c] with Yt = A dY A^T
+ * (nirgan_wino_dy) and V = B^T x B (nirgan_wino_input of the forward input) -- 16 weight-gradient problems of [T x K] x [T x C],
+ * run as ONE nirgan_wgrad_igemm / nirgan_wino_wgrad_pair launch with nplanes = 16 -- then dW = G^T dU G
+ * (nirgan_wino_wgrad_finish: sums the split slabs in order and writes / accumulates the reference layout [K][C][3][3]). */
+typedef struct {
+    const float* dy; int dy_hp, dy_wp, dy_pad;   /* halo'd [B][H+2pad][W+2pad][K] */
+    int B, H, W, K;
+    float* Yt; int64_t Yt_elems;                 /* [16][B*ceil(H/2)*ceil(W/2)][K] */
+} nirgan_wino_dy_desc;
+int nirgan_wino_dy(const nirgan_wino_dy_desc* d, void* stream);
+int nirgan_wino_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).

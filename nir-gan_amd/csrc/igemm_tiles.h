@@ -430,6 +430,8 @@ struct WgradParams {
     int rows_per_split, nsplit, ntiles_n, ntiles_k;
     int prec;
     int pq_bf16;               // p and q point to bf16 twins (bf16 operand mode, N > 64)
+    int nplanes;               // independent problems of identical geometry in one grid (Winograd-domain weight gradient: 16)
+    long long p_plane, q_plane;   // floats between consecutive planes of p / q; slabs are [plane][split][N][K]
 };
 
 
@@ -446,13 +448,17 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles = p.ntiles_n * p.ntiles_k;
-    const int id = ng_xcd_remap(block_id, tiles * p.nsplit);
+    const int per_plane = tiles * p.nsplit;
+    const int rid = ng_xcd_remap(block_id, per_plane * p.nplanes);
+    const int plane = rid / per_plane, id = rid - plane * per_plane;
     const int split = id / tiles, tile = id - split * tiles;
     const int n0 = (tile % p.ntiles_n) * TN, j0 = (tile / p.ntiles_n) * 128;
     const int mstart = split * p.rows_per_split;
     int mend = mstart + p.rows_per_split;
     mend = mend < p.M ? mend : p.M;
     const int nk = mend > mstart ? (mend - mstart + 31) >> 5 : 0;
+    const float* const Pp = p.p + size_t(plane) * p.p_plane;
+    const float* const Qp = p.q + size_t(plane) * p.q_plane;
 
     // ---------------- loader state
     const int p_lrow = lane / LPR, p_chunk = lane % LPR;
@@ -494,7 +500,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
         for (int i = 0; i < PI; ++i) {
             const int ins = wave * PI + i;
             const int m = mb + ins * RPI + p_lrow;
-            const float* src = p.p + (pp[i].b * p.p_img + pp[i].oh * p.p_row + pp[i].ow * p.p_cs + p.p_org + p_n);
+            const float* src = Pp + (pp[i].b * p.p_img + pp[i].oh * p.p_row + pp[i].ow * p.p_cs + p.p_org + p_n);
             src = (p_ok && m < mend) ? src : p.zero;
             ng_glds16(src, sP + ins * 1024);
             advance(pp[i]);
@@ -503,8 +509,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
         for (int i = 0; i < 4; ++i) {
             const int ins = wave * 4 + i;
             const int m = mb + ins * 2 + q_lrow;
-            const float* src = p.q + (qp[i].b * p.q_img + qp[i].oh * p.q_stride * p.q_row + qp[i].ow * p.q_stride * p.q_cs + p.q_org + q_add);
-            src = (q_ok && m < p.M) ? src : (q_ok ? p.q + (p.q_org + q_add) : p.zero);
+            const float* src = Qp + (qp[i].b * p.q_img + qp[i].oh * p.q_stride * p.q_row + qp[i].ow * p.q_stride * p.q_cs + p.q_org + q_add);
+            src = (q_ok && m < p.M) ? src : (q_ok ? Qp + (p.q_org + q_add) : p.zero);
             ng_glds16(src, sQ + ins * 1024);
             advance(qp[i]);
         }
@@ -652,7 +658,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
     }
     __syncthreads();
     {
-        float* slab = p.slabs + size_t(split) * p.N * p.K;
+        float* slab = p.slabs + (size_t(plane) * p.nsplit + split) * p.N * p.K;
         const int chunk = tid & 31, row0 = tid >> 5;
         const int jj = j0 + chunk * 4;
         if (jj < p.K) {
@@ -950,6 +956,11 @@ inline int build_wgrad_params(const nirgan_wgrad_desc* d, WgradParams& p) {
     p.ntiles_n = d->N > 64 ? (d->N + 127) / 128 : 1;
     NG_REQUIRE(d->precision >= 0 && d->precision <= 2, "wgrad_igemm: precision=%d (0 fp32, 1 bf16, 2 bf16x3)", d->precision);
     p.prec = d->precision;
+    p.nplanes = d->nplanes > 1 ? d->nplanes : 1;
+    p.p_plane = d->p_plane; p.q_plane = d->q_plane;
+    NG_REQUIRE(p.nplanes == 1 || (d->precision == 0 && !d->pq_bf16 && d->p_plane > 0 && d->q_plane > 0), "wgrad_igemm: planes need the fp32 tile and positive plane strides");
+    NG_REQUIRE(d->slab_elems >= int64_t(p.nplanes) * d->nsplit * d->N * K, "wgrad_igemm: slab_elems too small for %d planes", p.nplanes);
+    NG_REQUIRE(d->p_elems >= (p.nplanes - 1) * d->p_plane + int64_t(d->B) * d->p_hp * d->p_wp * d->p_cs && d->q_elems >= (p.nplanes - 1) * d->q_plane + int64_t(d->B) * d->q_hp * d->q_wp * d->q_cs, "wgrad_igemm: p/q too small for the planes");
     p.pq_bf16 = d->pq_bf16 ? 1 : 0;
     NG_REQUIRE(!p.pq_bf16 || (d->precision == 1 && d->N > 64 && d->N % 8 == 0 && d->run % 8 == 0 && d->p_cs % 8 == 0 && d->q_cs % 8 == 0),
                "wgrad_igemm: bf16 twins need precision 1, N > 64 and N, run, p_cs, q_cs multiples of 8");

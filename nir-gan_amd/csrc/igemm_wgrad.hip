@@ -153,7 +153,7 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     const int rc = ng::build_wgrad_params(d, p);
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(p.ntiles_n * p.ntiles_k * p.nsplit);
+    const dim3 grid(p.ntiles_n * p.ntiles_k * p.nsplit * p.nplanes);
     if (p.pq_bf16) {
         hipLaunchKernelGGL(wgrad_igemm16_kernel, grid, dim3(256), 0, st, p);
         return nirgan_check_launch("wgrad_igemm");
@@ -205,7 +205,7 @@ extern "C" int nirgan_wino_wgrad_pair(const nirgan_wino_desc* c, const nirgan_wg
     rc = ng_wino_gemm_params(c, &g);
     if (rc != NIRGAN_OK) return rc;
     const int wino_blocks = g.mtiles * g.ntiles;
-    const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit;
+    const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit * wp.nplanes;
     hipLaunchKernelGGL(wino_wgrad_pair_kernel, dim3(wino_blocks + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, wp, wino_blocks);
     return nirgan_check_launch("wino_wgrad_pair");
 }

@@ -82,6 +82,80 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoIn p) {
     }
 }
 
+struct WinoDy { const float* dy; float* Yt; int B, H, W, K, d_row, d_img, d_org, TH, TW; long long T; };
+
+// Yt[f][t][k] = (A dY A^T)[f] for the 2x2 output-gradient tile t; A = [[1,0],[1,1],[1,-1],[0,-1]].  One thread = one tile x 4 channels.
+__global__ __launch_bounds__(256) void wino_dy_kernel(const WinoDy p) {
+    const int q4 = p.K / 4;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= p.T * q4) return;
+    const long long t = i / q4;
+    const int q = int(i - t * q4);
+    const int tx = int(t % p.TW);
+    const long long r = t / p.TW;
+    const int ty = int(r % p.TH), b = int(r / p.TH);
+    const float* src = p.dy + size_t(b) * p.d_img + p.d_org + size_t(2 * ty) * p.d_row + size_t(2 * tx) * p.K + q * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const bool h1 = 2 * ty + 1 < p.H, w1 = 2 * tx + 1 < p.W;                      // odd extents: the last half tile
+    const f32x4 d00 = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 d01 = w1 ? *reinterpret_cast<const f32x4*>(src + p.K) : z;
+    const f32x4 d10 = h1 ? *reinterpret_cast<const f32x4*>(src + p.d_row) : z;
+    const f32x4 d11 = (h1 && w1) ? *reinterpret_cast<const f32x4*>(src + p.d_row + p.K) : z;
+    const f32x4 r0[2] = {d00, d01}, r1[2] = {d00 + d10, d01 + d11}, r2[2] = {d00 - d10, d01 - d11}, r3[2] = {z - d10, z - d11};
+    const size_t plane = size_t(p.T) * p.K;
+    float* Y = p.Yt + size_t(t) * p.K + q * 4;
+    auto row = [&](int a, const f32x4* rr) {
+        *reinterpret_cast<f32x4*>(Y + (a * 4 + 0) * plane) = rr[0];
+        *reinterpret_cast<f32x4*>(Y + (a * 4 + 1) * plane) = rr[0] + rr[1];
+        *reinterpret_cast<f32x4*>(Y + (a * 4 + 2) * plane) = rr[0] - rr[1];
+        *reinterpret_cast<f32x4*>(Y + (a * 4 + 3) * plane) = z - rr[1];
+    };
+    row(0, r0); row(1, r1); row(2, r2); row(3, r3);
+}
+
+struct WinoFin { const float* slabs; int nsplit, K, C; float* grad; int accumulate; };
+
+// dW[k][c] = G^T (sum over splits of dU[.][k][c]) G, written in the reference layout [K][C][3][3]; splits in order (deterministic).
+// A block takes 64 (k, c) pairs: thread (e, fg) sums frequencies 4 fg .. 4 fg + 3 of pair e over the splits (coalesced 256-B rows,
+// four independent chains), the 16 sums meet in LDS and threads 0-63 apply the 3x4 / 4x3 transforms.
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const WinoFin p) {
+    __shared__ float u_s[16][64];
+    const int e = threadIdx.x & 63, fg = threadIdx.x >> 6;
+    const long long i = blockIdx.x * 64ll + e;
+    const size_t kc = size_t(p.K) * p.C;
+    const bool ok = i < (long long)kc;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const float* src = p.slabs + size_t(fg * 4) * p.nsplit * kc + i;
+        for (int sp = 0; sp < p.nsplit; ++sp) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[j] += src[(size_t(j) * p.nsplit + sp) * kc];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u_s[fg * 4 + j][e] = sum[j];
+    __syncthreads();
+    if (fg != 0 || !ok) return;
+    float u[4][4];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) u[f >> 2][f & 3] = u_s[f][e];
+    // G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+    float t[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+        t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+        t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+    }
+    float* g = p.grad + size_t(i) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float g0 = t[a][0] + 0.5f * (t[a][1] + t[a][2]), g1 = 0.5f * (t[a][1] - t[a][2]), g2 = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+        if (p.accumulate) { g[a * 3] += g0; g[a * 3 + 1] += g1; g[a * 3 + 2] += g2; }
+        else { g[a * 3] = g0; g[a * 3 + 1] = g1; g[a * 3 + 2] = g2; }
+    }
+}
+
 }  // namespace
 
 #include "wino_tile.h"
@@ -129,8 +203,12 @@ int ng_wino_gemm_params(const nirgan_wino_desc* d, ng::WinoG* g) {
 }
 
 extern "C" int nirgan_wino_input(const nirgan_wino_desc* d, void* stream) {
-    const int rc = wino_check(d);
-    if (rc != NIRGAN_OK) return rc;
+    // the input transform needs x, V and the geometry only (the weight-gradient path transforms the forward input without a GEMM)
+    NG_REQUIRE(d && d->x && d->V, "wino_input: null pointer");
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino_input: bad shape");
+    NG_REQUIRE(d->x_hp == d->H + 2 && d->x_wp == d->W + 2, "wino_input: the input must carry a halo of exactly 1");
+    NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->V), "wino_input: pointers must be 16-byte aligned");
+    NG_REQUIRE(d->V_elems >= 16ll * d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) * d->C, "wino_input: V workspace too small");
     const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
     WinoIn in;
     in.x = d->x; in.V = d->V; in.B = d->B; in.H = d->H; in.W = d->W; in.C = d->C;
@@ -151,4 +229,27 @@ extern "C" int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream) {
 extern "C" int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream) {
     const int rc = nirgan_wino_input(d, stream);
     return rc != NIRGAN_OK ? rc : nirgan_wino_gemm(d, stream);
+}
+
+extern "C" int nirgan_wino_dy(const nirgan_wino_dy_desc* d, void* stream) {
+    NG_REQUIRE(d && d->dy && d->Yt, "wino_dy: null pointer");
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0 && d->dy_pad >= 0, "wino_dy: bad shape");
+    NG_REQUIRE(d->dy_hp == d->H + 2 * d->dy_pad && d->dy_wp == d->W + 2 * d->dy_pad, "wino_dy: dy geometry mismatch");
+    NG_REQUIRE(ng_aligned16(d->dy) && ng_aligned16(d->Yt), "wino_dy: pointers must be 16-byte aligned");
+    WinoDy p;
+    p.dy = d->dy; p.Yt = d->Yt; p.B = d->B; p.H = d->H; p.W = d->W; p.K = d->K;
+    p.d_row = d->dy_wp * d->K; p.d_img = d->dy_hp * p.d_row; p.d_org = d->dy_pad * p.d_row + d->dy_pad * d->K;
+    p.TH = (d->H + 1) / 2; p.TW = (d->W + 1) / 2; p.T = (long long)d->B * p.TH * p.TW;
+    NG_REQUIRE(d->Yt_elems >= 16 * p.T * d->K, "wino_dy: workspace too small");
+    const long long n = p.T * (d->K / 4);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("wino_dy");
+}
+
+extern "C" int nirgan_wino_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream) {
+    NG_REQUIRE(slabs && grad && nsplit >= 1 && K > 0 && C > 0, "wino_wgrad_finish: bad arguments");
+    WinoFin p{slabs, nsplit, K, C, grad, accumulate ? 1 : 0};
+    const long long n = (long long)K * C;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(unsigned((n + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("wino_wgrad_finish");
 }

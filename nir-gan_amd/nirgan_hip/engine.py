@@ -318,7 +318,8 @@ class _FullExtent:
         self.B, self.hp, self.wp, self.C, self.ptr = h.B, h.hp, h.wp, h.C, h.ptr
 
 
-def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y: Halo, *, H, W, cin, cout, flip=False):
+def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y: Halo, *, H, W, cin, cout, flip=False,
+              own_V: bool = False):
     """U = G g G^T in the pack plan (re-run when the weights change); input transform + fused GEMM/output transform in `plan`.
     x: buffer of [B][H+2][W+2][cin] (its own halo'd geometry must match), y: dense [B][H][W][cout] (a buffer's full padded
     extent counts as dense).  flip: data gradient (x = dY with a zero halo of 2, H x W = the padded input size)."""
@@ -328,9 +329,13 @@ def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, b
     U = ctx.zeros(16 * cout * cin)
     ctx.keep.append(U)
     pack.add("nirgan_wino_weights", weight.data_ptr(), cout, cin, 1 if flip else 0, U.data_ptr())
-    if not hasattr(ctx, "wino_pool"):
-        ctx.wino_pool = SplitPool(ctx)                 # the transform-domain input of ONE layer at a time (launches run serially)
-    V = ctx.wino_pool.get(16 * T * cin)
+    if own_V:                                          # kept for the layer's weight gradient (same x): 16 x the tile bytes, resident
+        V = ctx.zeros(16 * T * cin)
+        ctx.keep.append(V)
+    else:
+        if not hasattr(ctx, "wino_pool"):
+            ctx.wino_pool = SplitPool(ctx)             # the transform-domain input of ONE layer at a time (launches run serially)
+        V = ctx.wino_pool.get(16 * T * cin)
     d = L.WinoDesc()
     d.x, d.x_hp, d.x_wp = x.ptr, x.hp, x.wp
     d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
@@ -340,6 +345,60 @@ def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, b
     if plan is not None:
         plan.add("nirgan_wino_input", C.byref(d))
         plan.add("nirgan_wino_gemm", C.byref(d))
+    return d
+
+
+def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, OH, OW, cin, cout, slabs_pool, pair_wino,
+                    accumulate=False, V_fwd: Optional[L.WinoDesc] = None):
+    """Weight gradient of a Winograd layer in the transform domain: V = B^T x B of the forward input, Yt = A dY A^T, 16 problems
+    dU[f] = Yt[f]^T V[f] over the tiles as ONE weight-gradient launch with 16 planes (fused with the Winograd data-gradient tiles of
+    `pair_wino`), then dW = G^T dU G.  16/36 of the direct weight gradient's multiplies."""
+    B = inp.B
+    assert inp.pad == 1 and inp.H == OH and inp.W == OW and inp.C == cin and dy.C == cout
+    T = B * ((OH + 1) // 2) * ((OW + 1) // 2)
+    for name in ("wino_pool_x", "wino_pool_y"):
+        if not hasattr(ctx, name):
+            setattr(ctx, name, SplitPool(ctx))
+    Yt = ctx.wino_pool_y.get(16 * T * cout)
+    vin = None
+    if V_fwd is not None:                              # the forward pass of this step left V = B^T x B of the same x in its own buffer
+        V_ptr, V_elems = V_fwd.V, V_fwd.V_elems
+    else:
+        V = ctx.wino_pool_x.get(16 * T * cin)
+        vin = L.WinoDesc()
+        vin.x, vin.x_hp, vin.x_wp, vin.B, vin.H, vin.W, vin.C, vin.K = inp.ptr, inp.hp, inp.wp, B, OH, OW, cin, cout
+        vin.V, vin.V_elems = V.data_ptr(), V.numel()
+        V_ptr, V_elems = V.data_ptr(), V.numel()
+    ydesc = L.WinoDyDesc()
+    ydesc.dy, ydesc.dy_hp, ydesc.dy_wp, ydesc.dy_pad = dy.ptr, dy.hp, dy.wp, dy.pad
+    ydesc.B, ydesc.H, ydesc.W, ydesc.K = B, OH, OW, cout
+    ydesc.Yt, ydesc.Yt_elems = Yt.data_ptr(), Yt.numel()
+    tiles = (-(-cout // 128)) * (-(-cin // 128)) * 16
+    c = pair_wino
+    wino_blocks = -(-(c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2)) // 64) * (c.K // 128)
+    total = 512 * max(1, round((wino_blocks + 1024) / 512))
+    nsplit, rows = G.wgrad_split(T, tiles, max(total - wino_blocks, 512))
+    need = 16 * nsplit * cout * cin
+    slabs = slabs_pool.get(need)
+    d = L.WgradDesc()
+    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), 16 * T * cout, 1, T, cout, 0, 0
+    assert V_elems >= 16 * T * cin
+    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = V_ptr, 16 * T * cin, 1, T, cin
+    d.q_stride, d.q_oh, d.q_ow = 1, 0, 0
+    d.run = cin
+    _set_taps(d, [0], [0])
+    d.B, d.OH, d.OW, d.N = 1, 1, T, cout
+    d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
+    d.zero_page = ctx.zero_page.data_ptr()
+    d.precision = 0
+    d.nplanes, d.p_plane, d.q_plane = 16, T * cout, T * cin
+    ctx.keep.extend([vin, ydesc, d, slabs])
+    plan.add("nirgan_wino_input", C.byref(pair_wino))          # V of dY for the data gradient
+    if vin is not None:
+        plan.add("nirgan_wino_input", C.byref(vin))            # V of the forward input
+    plan.add("nirgan_wino_dy", C.byref(ydesc))
+    plan.add("nirgan_wino_wgrad_pair", C.byref(pair_wino), C.byref(d))
+    plan.add("nirgan_wino_wgrad_finish", slabs.data_ptr(), nsplit, cout, cin, grad.data_ptr(), 1 if accumulate else 0)
     return d
 
 
@@ -473,7 +532,10 @@ class ConvIN:
         eng, ctx, inp = self.eng, self.eng.ctx, self.inp
         k, s, p = self.k, self.s, self.p
         if self.kind == "conv" and wino_applicable(ctx, inp, k, s, p, self.cout, self.OH, self.OW):
-            emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C, cout=self.cout)
+            keep = bool(getattr(eng, "need_backward", False)) and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"
+            self.wino_fwd = emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
+                                      cout=self.cout, own_V=keep)
+            self.wino_fwd_keeps_V = keep
         elif self.kind == "conv":
             taps = G.conv_fwd_taps(k, inp.C)
             w = eng.weights.packed(pack, self.weight, G.conv_fwd_pack(self.cout, inp.C, k))
@@ -526,9 +588,13 @@ class ConvIN:
             # padded input extent; the weight gradient keeps the direct tile (stand-alone launch)
             wd = emit_wino(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
                            cin=self.cout, cout=inp.C, flip=True)
-            emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
-                       N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
-                       q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_wino=wd)
+            if inp.pad == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1":
+                emit_wino_wgrad(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
+                                pair_wino=wd, V_fwd=(self.wino_fwd if getattr(self, "wino_fwd_keeps_V", False) else None))
+            else:
+                emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
+                           N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
+                           q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_wino=wd)
             return
         if self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None:
             assert dgrad_out.H == inp.H and dgrad_out.pad == p and dy.pad == k - 1

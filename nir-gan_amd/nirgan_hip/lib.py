@@ -40,7 +40,7 @@ class WgradDesc(C.Structure):
                 ("tap_dh", i32 * MAX_TAPS), ("tap_dw", i32 * MAX_TAPS),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32),
                 ("slabs", fp), ("slab_elems", i64), ("nsplit", i32), ("rows_per_split", i32), ("zero_page", fp),
-                ("precision", i32), ("pq_bf16", i32)]
+                ("precision", i32), ("nplanes", i32), ("p_plane", i64), ("q_plane", i64), ("pq_bf16", i32)]
 
 
 class InFwdDesc(C.Structure):
@@ -118,6 +118,11 @@ class WinoDesc(C.Structure):
                 ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("y", fp), ("zero_page", fp)]
 
 
+class WinoDyDesc(C.Structure):
+    _fields_ = [("dy", fp), ("dy_hp", i32), ("dy_wp", i32), ("dy_pad", i32), ("B", i32), ("H", i32), ("W", i32), ("K", i32),
+                ("Yt", fp), ("Yt_elems", i64)]
+
+
 class PlanEntry(C.Structure):
     _fields_ = [("op", i32), ("desc", fp)]
 
@@ -141,6 +146,8 @@ PROTOTYPES = {
     "nirgan_wino_gemm": (i32, [C.POINTER(WinoDesc), fp]),
     "nirgan_wino_conv3x3": (i32, [C.POINTER(WinoDesc), fp]),
     "nirgan_wino_wgrad_pair": (i32, [C.POINTER(WinoDesc), C.POINTER(WgradDesc), fp]),
+    "nirgan_wino_dy": (i32, [C.POINTER(WinoDyDesc), fp]),
+    "nirgan_wino_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),
     "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),
     "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),

@@ -57,6 +57,7 @@ class GeneratorEngine(_Engine):
                  precision="fp32"):
         dev = params["model.1.weight"].device
         super().__init__(dev, precision)
+        self.need_backward = need_backward
         ctx = self.ctx
         self.params, self.grads = params, grads
         self.n_blocks, self.B, self.H, self.W, self.data_pad = n_blocks, B, H, W, data_pad

@@ -141,6 +141,21 @@ class EmuBackend:
 
     def nirgan_wgrad_igemm(self, ref, stream=None):
         d = obj(ref)
+        if d.nplanes > 1:                      # independent problems of identical geometry: run them one by one
+            import copy
+            K = d.ntaps * d.run
+            for i in range(d.nplanes):
+                one = type(d)()
+                C.memmove(C.byref(one), C.byref(d), C.sizeof(d))
+                one.nplanes = 1
+                one.p, one.q = int(d.p) + 4 * i * d.p_plane, int(d.q) + 4 * i * d.q_plane
+                one.p_elems, one.q_elems = d.p_elems - i * d.p_plane, d.q_elems - i * d.q_plane
+                one.slabs = int(d.slabs) + 4 * i * d.nsplit * d.N * K
+                one.slab_elems = d.nsplit * d.N * K
+                rc = self.nirgan_wgrad_igemm(one)
+                if rc:
+                    return rc
+            return 0
         self.calls.append("wgrad")
         K = d.ntaps * d.run
         if d.rows_per_split % 32 or d.nsplit * d.rows_per_split < d.B * d.OH * d.OW:
@@ -302,7 +317,16 @@ class EmuBackend:
         return 0
 
     def nirgan_wino_input(self, ref, stream=None):
-        return 0          # the restatement computes V inside the GEMM stage from x (V is written there as well)
+        d = obj(ref)
+        B, H, W, Cc = d.B, d.H, d.W, d.C
+        TH, TW = (H + 1) // 2, (W + 1) // 2
+        x0 = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
+        x = np.zeros((B, 2 * TH + 2, 2 * TW + 2, Cc))
+        x[:, :d.x_hp, :d.x_wp] = x0
+        tiles = np.stack([np.stack([x[:, a:a + 2 * TH:2, c:c + 2 * TW:2] for c in range(4)], 0) for a in range(4)], 0)
+        V = np.einsum("ai,ijbyxc,lj->albyxc", self._BT, tiles, self._BT)
+        arr(d.V, 16 * B * TH * TW * Cc)[:] = V.reshape(-1).astype(np.float32)
+        return 0
 
     def nirgan_wino_gemm(self, ref, stream=None):
         return self.nirgan_wino_conv3x3(ref)
@@ -336,6 +360,34 @@ class EmuBackend:
                     v = v + bias
                 nh, nw = len(range(p_, H, 2)), len(range(q_, W, 2))
                 out[:, p_::2, q_::2] = v[:, :nh, :nw].astype(np.float32)
+        return 0
+
+    def nirgan_wino_dy(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("wino_dy")
+        B, H, W, K = d.B, d.H, d.W, d.K
+        TH, TW = (H + 1) // 2, (W + 1) // 2
+        T = B * TH * TW
+        if d.Yt_elems < 16 * T * K or d.dy_hp != H + 2 * d.dy_pad:
+            return self._fail("wino_dy: bad geometry / workspace")
+        dy = arr(d.dy, B * d.dy_hp * d.dy_wp * K).reshape(B, d.dy_hp, d.dy_wp, K).astype(np.float64)
+        z = np.zeros((B, 2 * TH, 2 * TW, K))
+        z[:, :H, :W] = dy[:, d.dy_pad:d.dy_pad + H, d.dy_pad:d.dy_pad + W]
+        tiles = np.stack([np.stack([z[:, a::2, c::2] for c in range(2)], 0) for a in range(2)], 0)       # [2][2][B][TH][TW][K]
+        A = self._AT.T                                                                                   # 4 x 2
+        Yt = np.einsum("ia,abnyxk,jb->ijnyxk", A, tiles, A)
+        arr(d.Yt, 16 * T * K)[:] = Yt.reshape(-1).astype(np.float32)
+        return 0
+
+    def nirgan_wino_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
+        self.calls.append("wino_fin")
+        u = arr(slabs, 16 * nsplit * K * Cc).reshape(4, 4, nsplit, K, Cc).astype(np.float64).sum(2)
+        g = np.einsum("ai,abkc,bj->kcij", self._G, u, self._G)
+        o = arr(grad, K * Cc * 9).reshape(K, Cc, 3, 3)
+        if accumulate:
+            o += g.astype(np.float32)
+        else:
+            o[:] = g.astype(np.float32)
         return 0
 
     def nirgan_wino_wgrad_pair(self, cref, wref, stream=None):

@@ -611,3 +611,44 @@ def test_winograd_data_gradient_matches_autograd():
     d.x, d.U, d.V, d.y, d.zero_page = zc.data_ptr(), U2.data_ptr(), V2.data_ptr(), y2.data_ptr(), torch.zeros(64).data_ptr()
     assert emu.nirgan_wino_weights(wc.data_ptr(), Cin, Cout, 1, U2.data_ptr()) == 0 and emu.nirgan_wino_conv3x3(d) == 0
     close(y2, ref, 1e-5, "restatement of the data gradient")
+
+
+@pytest.mark.parametrize("hw", [(12, 16), (9, 11)])
+def test_winograd_backward_pair_matches_autograd(hw):
+    """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it: Winograd data gradient (over the padded extent) and
+    Winograd-domain weight gradient (16 planes in one launch, fused with the data-gradient tiles, then G^T dU G) against torch autograd
+    of conv2d on the padded input; device and numpy restatement.  Even and odd extents."""
+    from nirgan_hip.engine import emit_wino, emit_wino_wgrad, SlabPool, _FullExtent
+    H, W = hw
+    B, Cin, Cout = 2, 128, 128
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, H + 2, W + 2, Cin, generator=g)               # forward input incl. its halo (reflect-written in the nets)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    dyv = torch.randn(B, H, W, Cout, generator=g)
+    xp = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    wt = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xp, wt).backward(dyv.permute(0, 3, 1, 2).double())
+    ref_gx, ref_gw = xp.grad.permute(0, 2, 3, 1).float(), wt.grad.float()
+    tw = Twin("fp32")
+    res = []
+    for ctx in (tw.gctx, tw.cctx):
+        dev = ctx.device
+        inp = Halo(ctx, B, H, W, Cin, 1)
+        inp.t.copy_(x.to(dev))
+        dy = Halo(ctx, B, H, W, Cout, 2)
+        dy.interior().copy_(dyv.to(dev))
+        gx = Halo(ctx, B, H, W, Cin, 1)
+        gw = ctx.zeros(Cout, Cin, 3, 3)
+        wd = w.to(dev).contiguous()
+        ctx.keep.append(wd)
+        plan, pack = Plan(ctx), Plan(ctx)
+        wdesc = emit_wino(None, pack, ctx, dy, wd, None, _FullExtent(gx), H=gx.hp, W=gx.wp, cin=Cout, cout=Cin, flip=True)
+        emit_wino_wgrad(plan, ctx, dy, inp, gw, OH=H, OW=W, cin=Cin, cout=Cout, slabs_pool=SlabPool(ctx), pair_wino=wdesc)
+        res.append((pack, plan, gx, gw))
+    (gpk, gpl, ggx, ggw), (cpk, cpl, cgx, cgw) = res
+    tw.run(gpk, cpk)
+    tw.run(gpl, cpl)
+    close(cgx.t, ref_gx, 1e-5, "restatement: data gradient")
+    close(cgw, ref_gw, 1e-5, "restatement: weight gradient")
+    close(ggx.t, ref_gx, 3e-5, "device: data gradient")
+    close(ggw, ref_gw, 1e-4, "device: weight gradient")
