@@ -376,10 +376,15 @@ def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tenso
     tiles = (-(-cout // 128)) * (-(-cin // 128)) * 16
     c = pair_wino
     wino_blocks = -(-(c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2)) // 64) * (c.K // 128)
-    # whole rounds of the chip's 512 workgroup slots; few, long weight-gradient blocks (each ends with a 64 KB slab store): measured
-    # 651 us with 7 splits (2 rounds), 679 with 15 (3 rounds), 655 with 23 (4 rounds) for the res-block layer at bs 16
-    total = 512 * max(1, round((wino_blocks + 512) / 512))
-    nsplit, rows = G.wgrad_split(T, tiles, max(total - wino_blocks, 256))
+    # 256 CUs x 2 resident workgroups = 512 slots.  When both parts fit ONE residency with weight-gradient blocks no longer than ~1.3
+    # Winograd blocks (>= 6 splits), launch exactly that (res-block layer at bs 16: 8 splits, 649 us; 15 splits 676, 23 splits 658);
+    # otherwise many short blocks pack best behind the Winograd tiles (profiles/r01_wino_split_sweep.txt: 23 splits are within 1.5 %
+    # of the best at bs 32, padding 10 and 512x512, where 5-8 splits lose 6-13 %)
+    room = 1024 - wino_blocks
+    target = room if room // tiles >= 6 else 23 * tiles
+    nsplit, rows = G.wgrad_split(T, tiles, target)
+    if os.environ.get("NIRGAN_WINO_SPLITS"):           # experiments (scripts/sweep_wino_splits.sh)
+        nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ["NIRGAN_WINO_SPLITS"]))
     need = 16 * nsplit * cout * cin
     slabs = slabs_pool.get(need)
     d = L.WgradDesc()
