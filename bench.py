@@ -67,13 +67,15 @@ def mfma_probes(trainer):
             elif name == "nirgan_wino_gemm":
                 d = args[0]._obj
                 k = "wino_gemm_kernel"
-                kinds[k][0] += 2.0 * 16 * d.B * ((d.H + 1) // 2) * ((d.W + 1) // 2) * d.C * d.K      # EXECUTED MFMA flops (4/9 of the direct layer's)
+                nf = (max(d.r, 3) + 1) ** 2                                                       # 16 frequencies for 3x3, 25 for 4x4
+                kinds[k][0] += 2.0 * nf * d.B * ((d.H + 1) // 2) * ((d.W + 1) // 2) * d.C * d.K      # EXECUTED MFMA flops (16/36, 25/64 of the direct layer's)
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
             elif name == "nirgan_wino_wgrad_pair":
                 c, w = args[0]._obj, args[1]._obj
                 k = "wino_wgrad_pair_kernel"
-                kinds[k][0] += 2.0 * 16 * c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2) * c.C * c.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run   # executed
+                nf = (max(c.r, 3) + 1) ** 2
+                kinds[k][0] += 2.0 * nf * c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2) * c.C * c.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run   # executed
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
             elif name == "nirgan_conv_igemm_group":

@@ -359,13 +359,18 @@ typedef struct {
     float* V; int64_t V_elems;
     float* y;
     const float* zero_page;
+    int r;                                /* filter size: 0 or 3 = F(2x2,3x3) above; 4 = F(2x2,4x4): nn.Conv2d(C, K, 4, stride 1) of the PatchGAN
+                                             (model/networks.py:573-579), x is [B][H+3][W+3][C] for H x W outputs, 25 frequencies, U / V hold 25 planes */
 } nirgan_wino_desc;
 
 int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K);   /* V elements + U elements */
+int64_t nirgan_wino_ws_elems_r(int B, int H, int W, int C, int K, int r);
 /* transpose_flip = 0: U for the forward filter, w = [K][C][3][3].  1: U for the DATA GRADIENT, whose filter is
  * g'[k][c][i][j] = w[c][k][2-i][2-j] with w = [C][K][3][3] the forward weight (C = forward Cout, K = forward Cin): the
  * full correlation over dY with a zero halo of 2 is then nirgan_wino_conv3x3 with x = dY, H x W = the padded input size. */
 int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);
+/* the same for an r x r filter (r = 3 or 4; w = [K][C][r][r], U = [(r+1)^2][K][C]) */
+int nirgan_wino_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream);
 int nirgan_wino_input(const nirgan_wino_desc* d, void* stream);     /* V = B^T d B from x */
 int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream);      /* y from V and U (frequency-folding GEMM + bias) */
 int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);   /* both */
@@ -381,9 +386,11 @@ typedef struct {
     const float* dy; int dy_hp, dy_wp, dy_pad;   /* halo'd [B][H+2pad][W+2pad][K] */
     int B, H, W, K;
     float* Yt; int64_t Yt_elems;                 /* [16][B*ceil(H/2)*ceil(W/2)][K] */
+    int r;                                       /* filter size (0 / 3, or 4: 25 planes) */
 } nirgan_wino_dy_desc;
 int nirgan_wino_dy(const nirgan_wino_dy_desc* d, void* stream);
 int nirgan_wino_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
+int nirgan_wino_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream);   /* [K][C][r][r] */
 
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).

@@ -9,10 +9,18 @@ struct WinoG {
     const float* V; const float* U; const float* bias; float* y; const float* zero;
     int T, C, K, TH, TW, H, W;
     int mtiles, ntiles;
+    int a;                       // frequencies per dimension: 4 = F(2x2,3x3), 5 = F(2x2,4x4)
 };
 
-// A^T = [[1,1,1,0],[0,1,-1,-1]]: coefficient of frequency f1 in output row a
-__device__ __forceinline__ int at_coef(int a, int f) { return a == 0 ? (f < 3 ? 1 : 0) : (f == 0 ? 0 : (f == 1 ? 1 : -1)); }
+// coefficient of frequency f in output row `row` of A^T: [[1,1,1,0],[0,1,-1,-1]] for F(2,3), [[1,1,1,1,0],[0,1,-1,-1/2,1]] for F(2,4)
+__device__ __forceinline__ float at_coef(int row, int f, int a) {
+    if (row == 0) return f < a - 1 ? 1.f : 0.f;
+    if (f == 0) return 0.f;
+    if (f == 1) return 1.f;
+    if (f == 2) return -1.f;
+    if (a == 4) return -1.f;                     // F(2,3): f == 3
+    return f == 3 ? -0.5f : 1.f;                 // F(2,4): f == 3, 4
+}
 
 constexpr int WINO_LDS_BYTES = 2 * (64 * 128 + 128 * 128);      // two stages of (64 tile rows + 128 channel rows) x 128 B = 48 KB
 
@@ -92,16 +100,15 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
                 for (int nt = 0; nt < 2; ++nt) M[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[nt][j], M[nt], 0, 0, 0);
         }
     };
-    // fold the finished frequency f into the four outputs (coefficients 0, +1, -1) and clear the product
+    // fold the finished frequency f into the four outputs (coefficients 0, +-1; also -1/2, 1/4 for the 4x4 filter) and clear the product
     auto fold = [&](int f) {
-        const int f1 = f >> 2, f2 = f & 3;
+        const int f1 = f / p.a, f2 = f - f1 * p.a;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int cf = at_coef(a, f1) * at_coef(b, f2);
-                if (cf != 0) {
-                    const float s = float(cf);
+                const float s = at_coef(a, f1, p.a) * at_coef(b, f2, p.a);
+                if (s != 0.f) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) Y[a * 2 + b][nt] += s * M[nt];
                 }
@@ -113,7 +120,7 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
     };
 
     // ---------------- one K loop over (frequency, 32-channel slice); stage parity = step parity
-    const int nk = 16 * csteps;
+    const int nk = p.a * p.a * csteps;
     int f_i = 0, c_i = 0;             // coordinates of the step being ISSUED
     int f_c = 0, c_c = 0;             // coordinates of the step being COMPUTED
     auto next = [&](int& f, int& c) {
@@ -183,6 +190,7 @@ inline void build_wino_params(const nirgan_wino_desc* d, WinoG& g) {
     g.V = d->V; g.U = d->U; g.bias = d->bias; g.y = d->y; g.zero = d->zero_page;
     g.T = int(T); g.C = d->C; g.K = d->K; g.TH = (d->H + 1) / 2; g.TW = (d->W + 1) / 2; g.H = d->H; g.W = d->W;
     g.mtiles = int((T + 63) / 64); g.ntiles = d->K / 128;
+    g.a = d->r == 4 ? 5 : 4;
 }
 
 }  // namespace ng

@@ -156,6 +156,192 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const WinoFin p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// F(2x2, 4x4): nn.Conv2d(C, K, 4, stride 1) of the PatchGAN (model/networks.py:573-579), 25 products per 2x2 outputs instead of 64.
+// Cook-Toom over the points 0, 1, -1, -1/2, inf; row 0 of G / B^T rescaled so that B^T (applied to the activations) holds dyadic
+// constants only.  y = A^T [(G g G^T) . (B^T d B)] A over 5x5 input tiles at stride 2.
+__host__ __device__ constexpr float w4_G(int i, int j) {
+    constexpr float m[5][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f / 3, 1.f / 3, 1.f / 3, 1.f / 3}, {-1.f, 1.f, -1.f, 1.f},
+                               {8.f / 3, -4.f / 3, 2.f / 3, -1.f / 3}, {0.f, 0.f, 0.f, 1.f}};
+    return m[i][j];
+}
+__host__ __device__ constexpr float w4_BT(int i, int j) {
+    constexpr float m[5][5] = {{1.f, 2.f, -1.f, -2.f, 0.f}, {0.f, .5f, 1.5f, 1.f, 0.f}, {0.f, -.5f, -.5f, 1.f, 0.f},
+                               {0.f, -1.f, 0.f, 1.f, 0.f}, {0.f, -.5f, -1.f, .5f, 1.f}};
+    return m[i][j];
+}
+__host__ __device__ constexpr float w4_AT(int i, int j) {
+    constexpr float m[2][5] = {{1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, -.5f, 1.f}};
+    return m[i][j];
+}
+// acc += c * x with the constant folded after unrolling (0: nothing, +-1: add / subtract)
+template <typename T>
+__device__ __forceinline__ void wmac(T& acc, const float c, const T& x) {
+    if (c == 0.f) return;
+    if (c == 1.f) acc += x;
+    else if (c == -1.f) acc -= x;
+    else acc += c * x;
+}
+
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const WinoW p) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= (long long)p.K * p.C) return;
+    const int k = int(i / p.C), c = int(i - (long long)k * p.C);
+    // flip: the data-gradient filter g'[k][c][i][j] = W[c][k][3-i][3-j]
+    const float* g = p.flip ? p.w + (size_t(c) * p.K + k) * 16 : p.w + (size_t(k) * p.C + c) * 16;
+    float gv[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) gv[a][b] = p.flip ? g[15 - (a * 4 + b)] : g[a * 4 + b];
+    float t[5][4];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wmac(s, w4_G(a, r), gv[r][b]);
+            t[a][b] = s;
+        }
+    const size_t plane = size_t(p.K) * p.C;
+    float* U = p.U + size_t(k) * p.C + c;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wmac(s, w4_G(b, r), t[a][r]);
+            U[(a * 5 + b) * plane] = s;
+        }
+}
+
+// one thread = one 5x5 tile x 4 channels; the buffer holds (H+3) x (W+3) pixels for H x W outputs
+__global__ __launch_bounds__(256) void wino4_input_kernel(const WinoIn p) {
+    const int q4 = p.C / 4;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= p.T * q4) return;
+    const long long t = i / q4;
+    const int q = int(i - t * q4);
+    const int tx = int(t % p.TW);
+    const long long r = t / p.TW;
+    const int ty = int(r % p.TH), b = int(r / p.TH);
+    const float* src = p.x + size_t(b) * p.x_img + size_t(2 * ty) * p.x_row + size_t(2 * tx) * p.C + q * 4;
+    const int amax = p.H + 3 - 2 * ty, cmax = p.W + 3 - 2 * tx;      // valid lines / columns of this tile (5, or 4 at an odd edge)
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 m[5][5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        f32x4 d[5];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+            d[a] = (a < amax && c < cmax) ? *reinterpret_cast<const f32x4*>(src + size_t(a) * p.x_row + size_t(c) * p.C) : z;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            f32x4 s = z;
+#pragma unroll
+            for (int a = 0; a < 5; ++a) wmac(s, w4_BT(f, a), d[a]);
+            m[f][c] = s;
+        }
+    }
+    const size_t plane = size_t(p.T) * p.C;
+    float* V = p.V + size_t(t) * p.C + q * 4;
+#pragma unroll
+    for (int f1 = 0; f1 < 5; ++f1)
+#pragma unroll
+        for (int f2 = 0; f2 < 5; ++f2) {
+            f32x4 s = z;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) wmac(s, w4_BT(f2, c), m[f1][c]);
+            *reinterpret_cast<f32x4*>(V + (f1 * 5 + f2) * plane) = s;
+        }
+}
+
+// Yt[f][t][k] = (A dY A^T)[f], A = (A^T)^T is 5 x 2
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const WinoDy p) {
+    const int q4 = p.K / 4;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= p.T * q4) return;
+    const long long t = i / q4;
+    const int q = int(i - t * q4);
+    const int tx = int(t % p.TW);
+    const long long r = t / p.TW;
+    const int ty = int(r % p.TH), b = int(r / p.TH);
+    const float* src = p.dy + size_t(b) * p.d_img + p.d_org + size_t(2 * ty) * p.d_row + size_t(2 * tx) * p.K + q * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const bool h1 = 2 * ty + 1 < p.H, w1 = 2 * tx + 1 < p.W;
+    f32x4 d[2][2];
+    d[0][0] = *reinterpret_cast<const f32x4*>(src);
+    d[0][1] = w1 ? *reinterpret_cast<const f32x4*>(src + p.K) : z;
+    d[1][0] = h1 ? *reinterpret_cast<const f32x4*>(src + p.d_row) : z;
+    d[1][1] = (h1 && w1) ? *reinterpret_cast<const f32x4*>(src + p.d_row + p.K) : z;
+    f32x4 rr[5][2];
+#pragma unroll
+    for (int f = 0; f < 5; ++f)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 s = z;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) wmac(s, w4_AT(a, f), d[a][c]);
+            rr[f][c] = s;
+        }
+    const size_t plane = size_t(p.T) * p.K;
+    float* Y = p.Yt + size_t(t) * p.K + q * 4;
+#pragma unroll
+    for (int f1 = 0; f1 < 5; ++f1)
+#pragma unroll
+        for (int f2 = 0; f2 < 5; ++f2) {
+            f32x4 s = z;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) wmac(s, w4_AT(c, f2), rr[f1][c]);
+            *reinterpret_cast<f32x4*>(Y + (f1 * 5 + f2) * plane) = s;
+        }
+}
+
+// dW[k][c] = G^T (sum over splits of dU[.][k][c]) G in the reference layout [K][C][4][4]; 64 (k, c) pairs per block, thread (e, fg) sums
+// the frequencies fg, fg + 4, ... of pair e over the splits in order
+__global__ __launch_bounds__(256) void wino4_wgrad_finish_kernel(const WinoFin p) {
+    __shared__ float u_s[25][64];
+    const int e = threadIdx.x & 63, fg = threadIdx.x >> 6;
+    const long long i = blockIdx.x * 64ll + e;
+    const size_t kc = size_t(p.K) * p.C;
+    const bool ok = i < (long long)kc;
+    for (int f = fg; f < 25; f += 4) {
+        float s0 = 0.f, s1 = 0.f;
+        if (ok) {
+            const float* src = p.slabs + size_t(f) * p.nsplit * kc + i;
+            int sp = 0;
+            for (; sp + 1 < p.nsplit; sp += 2) { s0 += src[size_t(sp) * kc]; s1 += src[size_t(sp + 1) * kc]; }
+            if (sp < p.nsplit) s0 += src[size_t(sp) * kc];
+        }
+        u_s[f][e] = s0 + s1;
+    }
+    __syncthreads();
+    if (fg != 0 || !ok) return;
+    float t[4][5];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            float s = 0.f;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) wmac(s, w4_G(f, a), u_s[f * 5 + b][e]);
+            t[a][b] = s;
+        }
+    float* g = p.grad + size_t(i) * 16;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            float s = 0.f;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) wmac(s, w4_G(f, b), t[a][f]);
+            if (p.accumulate) g[a * 4 + b] += s; else g[a * 4 + b] = s;
+        }
+}
+
 }  // namespace
 
 #include "wino_tile.h"
@@ -169,28 +355,44 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const ng::WinoG p) {
 
 }  // namespace
 
-extern "C" int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K) {
-    if (B <= 0 || H <= 1 || W <= 1 || C <= 0 || K <= 0) return 0;
-    return 16ll * B * ((H + 1) / 2) * ((W + 1) / 2) * C + 16ll * K * C;
+static inline int wino_r(int r) { return r == 0 ? 3 : r; }
+
+extern "C" int64_t nirgan_wino_ws_elems_r(int B, int H, int W, int C, int K, int r) {
+    r = wino_r(r);
+    if (B <= 0 || H <= 1 || W <= 1 || C <= 0 || K <= 0 || (r != 3 && r != 4)) return 0;
+    const long long nf = (r + 1) * (r + 1);
+    return nf * B * ((H + 1) / 2) * ((W + 1) / 2) * C + nf * K * C;
 }
 
-extern "C" int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream) {
+extern "C" int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K) { return nirgan_wino_ws_elems_r(B, H, W, C, K, 3); }
+
+extern "C" int nirgan_wino_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream) {
+    r = wino_r(r);
     NG_REQUIRE(w && U && K > 0 && C > 0, "wino_weights: bad arguments");
+    NG_REQUIRE(r == 3 || r == 4, "wino_weights: filter size %d (3 or 4)", r);
     WinoW p{w, U, K, C, transpose_flip ? 1 : 0};
     const long long n = (long long)K * C;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    if (r == 3) hipLaunchKernelGGL(wino_weight_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino4_weight_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino_weights");
 }
 
+extern "C" int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream) {
+    return nirgan_wino_weights_r(w, K, C, 3, transpose_flip, U, stream);
+}
+
 static int wino_check(const nirgan_wino_desc* d) {
-    NG_REQUIRE(d && d->x && d->U && d->V && d->y && d->zero_page, "wino_conv3x3: null pointer");
-    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1, "wino_conv3x3: empty problem (H=%d W=%d)", d->H, d->W);
-    NG_REQUIRE(d->C % 32 == 0 && d->C > 0 && d->K > 0 && d->K % 128 == 0, "wino_conv3x3: C %% 32 == 0 and K %% 128 == 0 (C=%d K=%d)", d->C, d->K);
-    NG_REQUIRE(d->x_hp == d->H + 2 && d->x_wp == d->W + 2, "wino_conv3x3: the input must carry a halo of exactly 1 (%dx%d for %dx%d)", d->x_hp, d->x_wp, d->H, d->W);
-    NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->y) && ng_aligned16(d->zero_page), "wino_conv3x3: pointers must be 16-byte aligned");
-    const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
-    NG_REQUIRE(16 * T * d->C < (1ll << 31) * 4 && T < (1ll << 31) / d->C, "wino_conv3x3: problem too large for 32-bit tile offsets");
-    NG_REQUIRE(d->V_elems >= 16 * T * d->C, "wino_conv3x3: V workspace too small");
+    NG_REQUIRE(d && d->x && d->U && d->V && d->y && d->zero_page, "wino_conv: null pointer");
+    const int r = wino_r(d->r);
+    NG_REQUIRE(r == 3 || r == 4, "wino_conv: filter size %d (3 or 4)", r);
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1, "wino_conv: empty problem (H=%d W=%d)", d->H, d->W);
+    NG_REQUIRE(d->C % 32 == 0 && d->C > 0 && d->K > 0 && d->K % 128 == 0, "wino_conv: C %% 32 == 0 and K %% 128 == 0 (C=%d K=%d)", d->C, d->K);
+    NG_REQUIRE(d->x_hp == d->H + r - 1 && d->x_wp == d->W + r - 1, "wino_conv: the input must be (H+%d) x (W+%d) for the %dx%d filter (%dx%d for %dx%d)",
+               r - 1, r - 1, r, r, d->x_hp, d->x_wp, d->H, d->W);
+    NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->y) && ng_aligned16(d->zero_page), "wino_conv: pointers must be 16-byte aligned");
+    const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2), nf = (r + 1) * (r + 1);
+    NG_REQUIRE(T < (1ll << 31) / d->C, "wino_conv: problem too large for 32-bit tile offsets");
+    NG_REQUIRE(d->V_elems >= nf * T * d->C, "wino_conv: V workspace too small");
     return NIRGAN_OK;
 }
 
@@ -205,16 +407,20 @@ int ng_wino_gemm_params(const nirgan_wino_desc* d, ng::WinoG* g) {
 extern "C" int nirgan_wino_input(const nirgan_wino_desc* d, void* stream) {
     // the input transform needs x, V and the geometry only (the weight-gradient path transforms the forward input without a GEMM)
     NG_REQUIRE(d && d->x && d->V, "wino_input: null pointer");
+    const int r = wino_r(d->r);
+    NG_REQUIRE(r == 3 || r == 4, "wino_input: filter size %d (3 or 4)", r);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino_input: bad shape");
-    NG_REQUIRE(d->x_hp == d->H + 2 && d->x_wp == d->W + 2, "wino_input: the input must carry a halo of exactly 1");
+    NG_REQUIRE(d->x_hp == d->H + r - 1 && d->x_wp == d->W + r - 1, "wino_input: the input must be (H+%d) x (W+%d)", r - 1, r - 1);
     NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->V), "wino_input: pointers must be 16-byte aligned");
-    NG_REQUIRE(d->V_elems >= 16ll * d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2) * d->C, "wino_input: V workspace too small");
-    const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+    const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2), nf = (r + 1) * (r + 1);
+    NG_REQUIRE(d->V_elems >= nf * T * d->C, "wino_input: V workspace too small");
     WinoIn in;
     in.x = d->x; in.V = d->V; in.B = d->B; in.H = d->H; in.W = d->W; in.C = d->C;
     in.x_row = d->x_wp * d->C; in.x_img = d->x_hp * in.x_row; in.TH = (d->H + 1) / 2; in.TW = (d->W + 1) / 2; in.T = T;
     const long long nthreads = T * (d->C / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3(unsigned((nthreads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in);
+    const dim3 grid(unsigned((nthreads + 255) / 256));
+    if (r == 3) hipLaunchKernelGGL(wino_input_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
+    else hipLaunchKernelGGL(wino4_input_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
     return nirgan_check_launch("wino_input");
 }
 
@@ -233,6 +439,8 @@ extern "C" int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream) {
 
 extern "C" int nirgan_wino_dy(const nirgan_wino_dy_desc* d, void* stream) {
     NG_REQUIRE(d && d->dy && d->Yt, "wino_dy: null pointer");
+    const int r = wino_r(d->r);
+    NG_REQUIRE(r == 3 || r == 4, "wino_dy: filter size %d (3 or 4)", r);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0 && d->dy_pad >= 0, "wino_dy: bad shape");
     NG_REQUIRE(d->dy_hp == d->H + 2 * d->dy_pad && d->dy_wp == d->W + 2 * d->dy_pad, "wino_dy: dy geometry mismatch");
     NG_REQUIRE(ng_aligned16(d->dy) && ng_aligned16(d->Yt), "wino_dy: pointers must be 16-byte aligned");
@@ -240,16 +448,26 @@ extern "C" int nirgan_wino_dy(const nirgan_wino_dy_desc* d, void* stream) {
     p.dy = d->dy; p.Yt = d->Yt; p.B = d->B; p.H = d->H; p.W = d->W; p.K = d->K;
     p.d_row = d->dy_wp * d->K; p.d_img = d->dy_hp * p.d_row; p.d_org = d->dy_pad * p.d_row + d->dy_pad * d->K;
     p.TH = (d->H + 1) / 2; p.TW = (d->W + 1) / 2; p.T = (long long)d->B * p.TH * p.TW;
-    NG_REQUIRE(d->Yt_elems >= 16 * p.T * d->K, "wino_dy: workspace too small");
+    NG_REQUIRE(d->Yt_elems >= (long long)(r + 1) * (r + 1) * p.T * d->K, "wino_dy: workspace too small");
     const long long n = p.T * (d->K / 4);
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    const dim3 grid(unsigned((n + 255) / 256));
+    if (r == 3) hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino4_dy_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino_dy");
 }
 
-extern "C" int nirgan_wino_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream) {
+extern "C" int nirgan_wino_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream) {
+    r = wino_r(r);
     NG_REQUIRE(slabs && grad && nsplit >= 1 && K > 0 && C > 0, "wino_wgrad_finish: bad arguments");
+    NG_REQUIRE(r == 3 || r == 4, "wino_wgrad_finish: filter size %d (3 or 4)", r);
     WinoFin p{slabs, nsplit, K, C, grad, accumulate ? 1 : 0};
     const long long n = (long long)K * C;
-    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(unsigned((n + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    const dim3 grid(unsigned((n + 63) / 64));
+    if (r == 3) hipLaunchKernelGGL(wino_wgrad_finish_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino4_wgrad_finish_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino_wgrad_finish");
+}
+
+extern "C" int nirgan_wino_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream) {
+    return nirgan_wino_wgrad_finish_r(slabs, nsplit, K, C, 3, grad, accumulate, stream);
 }

@@ -297,16 +297,21 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     return d
 
 
+# filter sizes with a Winograd path: 3 = F(2x2,3x3) (ResnetBlock), 4 = F(2x2,4x4) (the stride-1 256 -> 512 layer of the PatchGAN)
+_WINO_K = (3,) if os.environ.get("NIRGAN_NO_WINOGRAD4") == "1" else (3, 4)
+
+
 def wino_applicable(ctx: Ctx, inp: Halo, k, s, p, cout, OH, OW) -> bool:
-    """Winograd F(2x2, 3x3) forward (csrc/winograd.hip): exact-fp32 mode, stride-1 3x3 over a halo of exactly 1, even output,
-    channel counts the tile supports.  In this network: the two convolutions of every ResnetBlock (64 % of the FLOPs)."""
-    return (ctx.precision == 0 and k == 3 and s == 1 and p == 1 and inp.pad == 1
-            and inp.C % 32 == 0 and cout % 128 == 0 and OH == inp.H and OW == inp.W
+    """Winograd F(2x2, kxk) forward (csrc/winograd.hip): exact-fp32 mode, stride-1 3x3 / 4x4 with padding 1 over a halo of exactly 1,
+    channel counts the tile supports.  In this network: the two convolutions of every ResnetBlock (64 % of the FLOPs) and the
+    stride-1 4x4 layer of the discriminator."""
+    return (ctx.precision == 0 and k in _WINO_K and s == 1 and p == 1 and inp.pad == 1
+            and inp.C % 32 == 0 and cout % 128 == 0 and OH == inp.H + 3 - k and OW == inp.W + 3 - k and OH > 1 and OW > 1
             and os.environ.get("NIRGAN_NO_WINOGRAD") != "1")
 
 
 def wino_dgrad_applicable(ctx: Ctx, k, s, dgrad_out: Halo, cout, cin) -> bool:
-    return (ctx.precision == 0 and k == 3 and s == 1
+    return (ctx.precision == 0 and k in _WINO_K and s == 1
             and cout % 32 == 0 and cin % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD") != "1"
             and os.environ.get("NIRGAN_NO_WINOGRAD_DGRAD") != "1")
 
@@ -319,24 +324,26 @@ class _FullExtent:
 
 
 def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y: Halo, *, H, W, cin, cout, flip=False,
-              own_V: bool = False):
+              own_V: bool = False, r: int = 3):
     """U = G g G^T in the pack plan (re-run when the weights change); input transform + fused GEMM/output transform in `plan`.
-    x: buffer of [B][H+2][W+2][cin] (its own halo'd geometry must match), y: dense [B][H][W][cout] (a buffer's full padded
+    x: buffer of [B][H+r-1][W+r-1][cin] (its own halo'd geometry must match), y: dense [B][H][W][cout] (a buffer's full padded
     extent counts as dense).  flip: data gradient (x = dY with a zero halo of 2, H x W = the padded input size)."""
-    assert x.hp == H + 2 and x.wp == W + 2 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
+    assert x.hp == H + r - 1 and x.wp == W + r - 1 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
     B = x.B
     T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    U = ctx.zeros(16 * cout * cin)
+    nf = (r + 1) * (r + 1)
+    U = ctx.zeros(nf * cout * cin)
     ctx.keep.append(U)
-    pack.add("nirgan_wino_weights", weight.data_ptr(), cout, cin, 1 if flip else 0, U.data_ptr())
-    if own_V:                                          # kept for the layer's weight gradient (same x): 16 x the tile bytes, resident
-        V = ctx.zeros(16 * T * cin)
+    pack.add("nirgan_wino_weights_r", weight.data_ptr(), cout, cin, r, 1 if flip else 0, U.data_ptr())
+    if own_V:                                          # kept for the layer's weight gradient (same x): nf x the tile bytes, resident
+        V = ctx.zeros(nf * T * cin)
         ctx.keep.append(V)
     else:
         if not hasattr(ctx, "wino_pool"):
             ctx.wino_pool = SplitPool(ctx)             # the transform-domain input of ONE layer at a time (launches run serially)
-        V = ctx.wino_pool.get(16 * T * cin)
+        V = ctx.wino_pool.get(nf * T * cin)
     d = L.WinoDesc()
+    d.r = r
     d.x, d.x_hp, d.x_wp = x.ptr, x.hp, x.wp
     d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
     d.U, d.bias, d.V, d.V_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), y.ptr
@@ -349,23 +356,25 @@ def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, b
 
 
 def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, OH, OW, cin, cout, slabs_pool, pair_wino,
-                    accumulate=False, V_fwd: Optional[L.WinoDesc] = None):
+                    accumulate=False, V_fwd: Optional[L.WinoDesc] = None, r: int = 3):
     """Weight gradient of a Winograd layer in the transform domain: V = B^T x B of the forward input, Yt = A dY A^T, 16 problems
     dU[f] = Yt[f]^T V[f] over the tiles as ONE weight-gradient launch with 16 planes (fused with the Winograd data-gradient tiles of
     `pair_wino`), then dW = G^T dU G.  16/36 of the direct weight gradient's multiplies."""
     B = inp.B
-    assert inp.pad == 1 and inp.H == OH and inp.W == OW and inp.C == cin and dy.C == cout
+    assert inp.pad == 1 and inp.H == OH + r - 3 and inp.W == OW + r - 3 and inp.C == cin and dy.C == cout
     T = B * ((OH + 1) // 2) * ((OW + 1) // 2)
+    nf = (r + 1) * (r + 1)
     for name in ("wino_pool_x", "wino_pool_y"):
         if not hasattr(ctx, name):
             setattr(ctx, name, SplitPool(ctx))
-    Yt = ctx.wino_pool_y.get(16 * T * cout)
+    Yt = ctx.wino_pool_y.get(nf * T * cout)
     vin = None
     if V_fwd is not None:                              # the forward pass of this step left V = B^T x B of the same x in its own buffer
         V_ptr, V_elems = V_fwd.V, V_fwd.V_elems
     else:
-        V = ctx.wino_pool_x.get(16 * T * cin)
+        V = ctx.wino_pool_x.get(nf * T * cin)
         vin = L.WinoDesc()
+        vin.r = r
         vin.x, vin.x_hp, vin.x_wp, vin.B, vin.H, vin.W, vin.C, vin.K = inp.ptr, inp.hp, inp.wp, B, OH, OW, cin, cout
         vin.V, vin.V_elems = V.data_ptr(), V.numel()
         V_ptr, V_elems = V.data_ptr(), V.numel()
@@ -373,7 +382,8 @@ def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tenso
     ydesc.dy, ydesc.dy_hp, ydesc.dy_wp, ydesc.dy_pad = dy.ptr, dy.hp, dy.wp, dy.pad
     ydesc.B, ydesc.H, ydesc.W, ydesc.K = B, OH, OW, cout
     ydesc.Yt, ydesc.Yt_elems = Yt.data_ptr(), Yt.numel()
-    tiles = (-(-cout // 128)) * (-(-cin // 128)) * 16
+    ydesc.r = r
+    tiles = (-(-cout // 128)) * (-(-cin // 128)) * nf
     c = pair_wino
     wino_blocks = -(-(c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2)) // 64) * (c.K // 128)
     # 256 CUs x 2 resident workgroups = 512 slots.  When both parts fit ONE residency with weight-gradient blocks no longer than ~1.3
@@ -383,14 +393,15 @@ def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tenso
     room = 1024 - wino_blocks
     target = room if room // tiles >= 6 else 23 * tiles
     nsplit, rows = G.wgrad_split(T, tiles, target)
-    if os.environ.get("NIRGAN_WINO_SPLITS"):           # experiments (scripts/sweep_wino_splits.sh)
-        nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ["NIRGAN_WINO_SPLITS"]))
-    need = 16 * nsplit * cout * cin
+    env = "NIRGAN_WINO_SPLITS" if r == 3 else "NIRGAN_WINO4_SPLITS"
+    if os.environ.get(env):                            # experiments (scripts/sweep_wino_splits.sh)
+        nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ[env]))
+    need = nf * nsplit * cout * cin
     slabs = slabs_pool.get(need)
     d = L.WgradDesc()
-    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), 16 * T * cout, 1, T, cout, 0, 0
-    assert V_elems >= 16 * T * cin
-    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = V_ptr, 16 * T * cin, 1, T, cin
+    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), nf * T * cout, 1, T, cout, 0, 0
+    assert V_elems >= nf * T * cin
+    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = V_ptr, nf * T * cin, 1, T, cin
     d.q_stride, d.q_oh, d.q_ow = 1, 0, 0
     d.run = cin
     _set_taps(d, [0], [0])
@@ -398,14 +409,14 @@ def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tenso
     d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
     d.zero_page = ctx.zero_page.data_ptr()
     d.precision = 0
-    d.nplanes, d.p_plane, d.q_plane = 16, T * cout, T * cin
+    d.nplanes, d.p_plane, d.q_plane = nf, T * cout, T * cin
     ctx.keep.extend([vin, ydesc, d, slabs])
     plan.add("nirgan_wino_input", C.byref(pair_wino))          # V of dY for the data gradient
     if vin is not None:
         plan.add("nirgan_wino_input", C.byref(vin))            # V of the forward input
     plan.add("nirgan_wino_dy", C.byref(ydesc))
     plan.add("nirgan_wino_wgrad_pair", C.byref(pair_wino), C.byref(d))
-    plan.add("nirgan_wino_wgrad_finish", slabs.data_ptr(), nsplit, cout, cin, grad.data_ptr(), 1 if accumulate else 0)
+    plan.add("nirgan_wino_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, r, grad.data_ptr(), 1 if accumulate else 0)
     return d
 
 
@@ -500,6 +511,7 @@ class _Scratch:
     def get(self) -> torch.Tensor:
         if self.t is None or self.t.numel() < self.n:
             self.t = self.ctx.zeros(max(self.n, 4))
+            self.ctx.keep.append(self.t)      # descriptors emitted against a smaller, earlier workspace keep their (still valid) pointer
         return self.t
 
 
@@ -541,7 +553,7 @@ class ConvIN:
         if self.kind == "conv" and wino_applicable(ctx, inp, k, s, p, self.cout, self.OH, self.OW):
             keep = bool(getattr(eng, "need_backward", False)) and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"
             self.wino_fwd = emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
-                                      cout=self.cout, own_V=keep)
+                                      cout=self.cout, own_V=keep, r=k)
             self.wino_fwd_keeps_V = keep
         elif self.kind == "conv":
             taps = G.conv_fwd_taps(k, inp.C)
@@ -594,10 +606,10 @@ class ConvIN:
             # exact-fp32 mode, 3x3: the data gradient is a Winograd convolution of dY (zero halo 2) with the flipped filter over the
             # padded input extent; the weight gradient keeps the direct tile (stand-alone launch)
             wd = emit_wino(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
-                           cin=self.cout, cout=inp.C, flip=True)
-            if inp.pad == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1":
+                           cin=self.cout, cout=inp.C, flip=True, r=k)
+            if inp.pad == 1 and p == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1":
                 emit_wino_wgrad(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
-                                pair_wino=wd, V_fwd=(self.wino_fwd if getattr(self, "wino_fwd_keeps_V", False) else None))
+                                pair_wino=wd, V_fwd=(self.wino_fwd if getattr(self, "wino_fwd_keeps_V", False) else None), r=k)
             else:
                 emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
                            N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
@@ -634,6 +646,12 @@ class ConvIN:
         if self.kind == "conv" and s == 1:
             # full correlation: gradient wrt the halo'd input (size H+2p), folded / cropped by the consumer
             assert dgrad_out.H == inp.H and dgrad_out.pad == p and dy.pad == k - 1
+            if (gw is None and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C)
+                    and os.environ.get("NIRGAN_NO_WINOGRAD_DGRAD_ONLY") != "1"):
+                # frozen parameters (the discriminator inside the generator step): the data gradient alone, as a Winograd convolution
+                emit_wino(plan, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
+                          cin=self.cout, cout=inp.C, flip=True, r=k)
+                return
             taps = G.conv_dgrad_s1_taps(k, self.cout)
             hw = [(kh, kw) for kh in range(k) for kw in range(k)]
             w = eng.weights.packed(pack, self.weight, G.conv_dgrad_pack(self.cout, inp.C, k, hw))

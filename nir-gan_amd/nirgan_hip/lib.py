@@ -115,12 +115,12 @@ class HistMatchDesc(C.Structure):
 
 class WinoDesc(C.Structure):
     _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
-                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("y", fp), ("zero_page", fp)]
+                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32)]
 
 
 class WinoDyDesc(C.Structure):
     _fields_ = [("dy", fp), ("dy_hp", i32), ("dy_wp", i32), ("dy_pad", i32), ("B", i32), ("H", i32), ("W", i32), ("K", i32),
-                ("Yt", fp), ("Yt_elems", i64)]
+                ("Yt", fp), ("Yt_elems", i64), ("r", i32)]
 
 
 class PlanEntry(C.Structure):
@@ -142,6 +142,9 @@ PROTOTYPES = {
     "nirgan_location_encoder": (i32, [C.POINTER(LocEncDesc), fp]),
     "nirgan_wino_ws_elems": (i64, [i32, i32, i32, i32, i32]),
     "nirgan_wino_weights": (i32, [fp, i32, i32, i32, fp, fp]),
+    "nirgan_wino_ws_elems_r": (i64, [i32, i32, i32, i32, i32, i32]),
+    "nirgan_wino_weights_r": (i32, [fp, i32, i32, i32, i32, fp, fp]),
+    "nirgan_wino_wgrad_finish_r": (i32, [fp, i32, i32, i32, i32, fp, i32, fp]),
     "nirgan_wino_input": (i32, [C.POINTER(WinoDesc), fp]),
     "nirgan_wino_gemm": (i32, [C.POINTER(WinoDesc), fp]),
     "nirgan_wino_conv3x3": (i32, [C.POINTER(WinoDesc), fp]),

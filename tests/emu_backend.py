@@ -298,34 +298,59 @@ class EmuBackend:
         arr(d.out, d.B * d.dims[d.nlayers], np.float64)[:] = h.reshape(-1)
         return 0
 
-    # ------------------------------------------------------------------ Winograd F(2x2, 3x3)
-    _G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
-    _BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
-    _AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+    # ------------------------------------------------------------------ Winograd F(2x2, 3x3) and F(2x2, 4x4)
+    _MATS = {
+        3: (np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]),
+            np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64),
+            np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)),
+        # Cook-Toom over 0, 1, -1, -1/2, inf (csrc/winograd.hip w4_G / w4_BT / w4_AT)
+        4: (np.array([[1, 0, 0, 0], [1 / 3, 1 / 3, 1 / 3, 1 / 3], [-1, 1, -1, 1], [8 / 3, -4 / 3, 2 / 3, -1 / 3], [0, 0, 0, 1]]),
+            np.array([[1, 2, -1, -2, 0], [0, .5, 1.5, 1, 0], [0, -.5, -.5, 1, 0], [0, -1, 0, 1, 0], [0, -.5, -1, .5, 1]]),
+            np.array([[1, 1, 1, 1, 0], [0, 1, -1, -.5, 1]])),
+    }
+
+    @staticmethod
+    def _r(r):
+        return 3 if r == 0 else r
 
     def nirgan_wino_ws_elems(self, B, H, W, Cc, K):
-        return 16 * B * ((H + 1) // 2) * ((W + 1) // 2) * Cc + 16 * K * Cc
+        return self.nirgan_wino_ws_elems_r(B, H, W, Cc, K, 3)
+
+    def nirgan_wino_ws_elems_r(self, B, H, W, Cc, K, r):
+        nf = (self._r(r) + 1) ** 2
+        return nf * B * ((H + 1) // 2) * ((W + 1) // 2) * Cc + nf * K * Cc
 
     def nirgan_wino_weights(self, w, K, Cc, flip, U, stream=None):
+        return self.nirgan_wino_weights_r(w, K, Cc, 3, flip, U)
+
+    def nirgan_wino_weights_r(self, w, K, Cc, r, flip, U, stream=None):
         self.calls.append("wino_w")
+        r = self._r(r)
+        Gm = self._MATS[r][0]
         if flip:
-            g = arr(w, K * Cc * 9).reshape(Cc, K, 3, 3).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
+            g = arr(w, K * Cc * r * r).reshape(Cc, K, r, r).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
         else:
-            g = arr(w, K * Cc * 9).reshape(K, Cc, 3, 3).astype(np.float64)
-        u = np.einsum("ai,kcij,bj->abkc", self._G, g, self._G)
-        arr(U, 16 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
+            g = arr(w, K * Cc * r * r).reshape(K, Cc, r, r).astype(np.float64)
+        u = np.einsum("ai,kcij,bj->abkc", Gm, g, Gm)
+        arr(U, (r + 1) ** 2 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
         return 0
 
-    def nirgan_wino_input(self, ref, stream=None):
-        d = obj(ref)
+    def _wino_tiles(self, d):
+        r = self._r(d.r)
+        a = r + 1
         B, H, W, Cc = d.B, d.H, d.W, d.C
         TH, TW = (H + 1) // 2, (W + 1) // 2
         x0 = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
-        x = np.zeros((B, 2 * TH + 2, 2 * TW + 2, Cc))
+        x = np.zeros((B, 2 * TH + r - 1, 2 * TW + r - 1, Cc))       # odd extents: one zero line past the buffer (feeds unused outputs)
         x[:, :d.x_hp, :d.x_wp] = x0
-        tiles = np.stack([np.stack([x[:, a:a + 2 * TH:2, c:c + 2 * TW:2] for c in range(4)], 0) for a in range(4)], 0)
-        V = np.einsum("ai,ijbyxc,lj->albyxc", self._BT, tiles, self._BT)
-        arr(d.V, 16 * B * TH * TW * Cc)[:] = V.reshape(-1).astype(np.float32)
+        tiles = np.stack([np.stack([x[:, i:i + 2 * TH:2, j:j + 2 * TW:2] for j in range(a)], 0) for i in range(a)], 0)   # [a][a][B][TH][TW][C]
+        BT = self._MATS[r][1]
+        return np.einsum("ai,ijbyxc,lj->albyxc", BT, tiles, BT)
+
+    def nirgan_wino_input(self, ref, stream=None):
+        d = obj(ref)
+        V = self._wino_tiles(d)
+        arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino_gemm(self, ref, stream=None):
@@ -334,23 +359,21 @@ class EmuBackend:
     def nirgan_wino_conv3x3(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("wino")
-        if d.C % 32 or d.K % 128 or d.x_hp != d.H + 2 or d.x_wp != d.W + 2 or d.H < 2 or d.W < 2:
-            return self._fail("wino_conv3x3: bad geometry")
+        r = self._r(d.r)
+        a = r + 1
+        if r not in (3, 4) or d.C % 32 or d.K % 128 or d.x_hp != d.H + r - 1 or d.x_wp != d.W + r - 1 or d.H < 2 or d.W < 2:
+            return self._fail("wino_conv: bad geometry")
         B, H, W, Cc, K = d.B, d.H, d.W, d.C, d.K
         TH, TW = (H + 1) // 2, (W + 1) // 2
         T = B * TH * TW
-        if d.V_elems < 16 * T * Cc:
-            return self._fail("wino_conv3x3: V workspace too small")
-        x0 = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
-        x = np.zeros((B, 2 * TH + 2, 2 * TW + 2, Cc))               # odd extents: one zero line past the halo (feeds unused outputs)
-        x[:, :d.x_hp, :d.x_wp] = x0
-        U = arr(d.U, 16 * K * Cc).reshape(4, 4, K, Cc).astype(np.float64)
-        He, We = 2 * TH, 2 * TW
-        tiles = np.stack([np.stack([x[:, a:a + He:2, c:c + We:2] for c in range(4)], 0) for a in range(4)], 0)   # [4][4][B][TH][TW][C]
-        V = np.einsum("ai,ijbyxc,lj->albyxc", self._BT, tiles, self._BT)
-        arr(d.V, 16 * T * Cc)[:] = V.reshape(-1).astype(np.float32)
+        if d.V_elems < a * a * T * Cc:
+            return self._fail("wino_conv: V workspace too small")
+        U = arr(d.U, a * a * K * Cc).reshape(a, a, K, Cc).astype(np.float64)
+        V = self._wino_tiles(d)
+        arr(d.V, a * a * T * Cc)[:] = V.reshape(-1).astype(np.float32)
         M = np.einsum("albyxc,alkc->albyxk", V, U)
-        Y = np.einsum("pa,albyxk,ql->pqbyxk", self._AT, M, self._AT)                 # [2][2][B][TH][TW][K]
+        AT = self._MATS[r][2]
+        Y = np.einsum("pa,albyxk,ql->pqbyxk", AT, M, AT)                             # [2][2][B][TH][TW][K]
         out = arr(d.y, B * H * W * K).reshape(B, H, W, K)
         bias = arr(d.bias, K)
         for p_ in range(2):
@@ -365,25 +388,33 @@ class EmuBackend:
     def nirgan_wino_dy(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("wino_dy")
+        r = self._r(d.r)
+        a = r + 1
         B, H, W, K = d.B, d.H, d.W, d.K
         TH, TW = (H + 1) // 2, (W + 1) // 2
         T = B * TH * TW
-        if d.Yt_elems < 16 * T * K or d.dy_hp != H + 2 * d.dy_pad:
+        if d.Yt_elems < a * a * T * K or d.dy_hp != H + 2 * d.dy_pad:
             return self._fail("wino_dy: bad geometry / workspace")
         dy = arr(d.dy, B * d.dy_hp * d.dy_wp * K).reshape(B, d.dy_hp, d.dy_wp, K).astype(np.float64)
         z = np.zeros((B, 2 * TH, 2 * TW, K))
         z[:, :H, :W] = dy[:, d.dy_pad:d.dy_pad + H, d.dy_pad:d.dy_pad + W]
-        tiles = np.stack([np.stack([z[:, a::2, c::2] for c in range(2)], 0) for a in range(2)], 0)       # [2][2][B][TH][TW][K]
-        A = self._AT.T                                                                                   # 4 x 2
+        tiles = np.stack([np.stack([z[:, i::2, j::2] for j in range(2)], 0) for i in range(2)], 0)       # [2][2][B][TH][TW][K]
+        A = self._MATS[r][2].T                                                                           # a x 2
         Yt = np.einsum("ia,abnyxk,jb->ijnyxk", A, tiles, A)
-        arr(d.Yt, 16 * T * K)[:] = Yt.reshape(-1).astype(np.float32)
+        arr(d.Yt, a * a * T * K)[:] = Yt.reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
+        return self.nirgan_wino_wgrad_finish_r(slabs, nsplit, K, Cc, 3, grad, accumulate)
+
+    def nirgan_wino_wgrad_finish_r(self, slabs, nsplit, K, Cc, r, grad, accumulate, stream=None):
         self.calls.append("wino_fin")
-        u = arr(slabs, 16 * nsplit * K * Cc).reshape(4, 4, nsplit, K, Cc).astype(np.float64).sum(2)
-        g = np.einsum("ai,abkc,bj->kcij", self._G, u, self._G)
-        o = arr(grad, K * Cc * 9).reshape(K, Cc, 3, 3)
+        r = self._r(r)
+        a = r + 1
+        u = arr(slabs, a * a * nsplit * K * Cc).reshape(a, a, nsplit, K, Cc).astype(np.float64).sum(2)
+        Gm = self._MATS[r][0]
+        g = np.einsum("ai,abkc,bj->kcij", Gm, u, Gm)
+        o = arr(grad, K * Cc * r * r).reshape(K, Cc, r, r)
         if accumulate:
             o += g.astype(np.float32)
         else:

@@ -613,6 +613,93 @@ def test_winograd_data_gradient_matches_autograd():
     close(y2, ref, 1e-5, "restatement of the data gradient")
 
 
+def _wino4_case(B, H, W, Cc, K, seed=23):
+    """F(2x2,4x4) problem: x [B][H+3][W+3][C] (the buffer a 4x4 / padding-1 convolution with H x W outputs reads), w [K][C][4][4]."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, H + 3, W + 3, Cc, generator=g)
+    w = torch.randn(K, Cc, 4, 4, generator=g) * 0.05
+    b = torch.randn(K, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1).float()
+    return x, w, b, ref
+
+
+def _run_wino4(x, w, b, dev, be):
+    import ctypes as C
+    B, H, W, Cc, K = x.shape[0], x.shape[1] - 3, x.shape[2] - 3, x.shape[3], w.shape[0]
+    xt, wt, bt = x.to(dev).contiguous(), w.to(dev).contiguous(), b.to(dev)
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
+    U, V = torch.zeros(25 * K * Cc, device=dev), torch.zeros(25 * T * Cc, device=dev)
+    y, zero = torch.zeros(B, H, W, K, device=dev), torch.zeros(64, device=dev)
+    d = L.WinoDesc()
+    d.r = 4
+    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = xt.data_ptr(), H + 3, W + 3, B, H, W, Cc, K
+    d.U, d.bias, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), bt.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
+    if be is None:
+        st = torch.cuda.current_stream().cuda_stream
+        L.call("nirgan_wino_weights_r", wt.data_ptr(), K, Cc, 4, 0, U.data_ptr(), st)
+        L.call("nirgan_wino_conv3x3", C.byref(d), st)
+        torch.cuda.synchronize()
+    else:
+        assert be.nirgan_wino_weights_r(wt.data_ptr(), K, Cc, 4, 0, U.data_ptr()) == 0
+        assert be.nirgan_wino_conv3x3(d) == 0
+    return y.cpu()
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128), (2, 31, 31, 256, 512), (3, 7, 5, 32, 128), (1, 6, 9, 96, 256)])
+def test_winograd_conv4x4_matches_direct(shape):
+    """F(2x2,4x4) (the PatchGAN's stride-1 4x4 layer, 25 products per 2x2 outputs): device and numpy restatement against torch's
+    conv2d in float64.  Transform constants 0, +-1/2, +-1, 3/2, 2 on the activations (dyadic), thirds on the weights; tolerance
+    5e-5 of the output's max (F(2x2,3x3): 3e-5, direct MFMA: 1e-5)."""
+    x, w, b, ref = _wino4_case(*shape)
+    dev_y = _run_wino4(x, w, b, DEV, None)
+    emu_y = _run_wino4(x, w, b, "cpu", EmuBackend())
+    close(emu_y, ref, 1e-5, "restatement vs torch")
+    close(dev_y, ref, 5e-5, "device vs torch")
+    close(dev_y, emu_y, 5e-5, "device vs restatement")
+
+
+@pytest.mark.parametrize("hw", [(9, 13), (8, 10), (32, 32)])
+def test_winograd4_backward_pair_matches_autograd(hw):
+    """Backward of Conv2d(Cin, Cout, 4, stride 1, padding 1) as the discriminator engine emits it in exact-fp32 mode: Winograd data
+    gradient over the padded input extent (dY with a zero halo of 3, flipped filter) fused with the Winograd-domain weight gradient
+    (25 planes, then G^T dU G) against torch autograd of conv2d on the padded input; even and odd output extents."""
+    from nirgan_hip.engine import emit_wino, emit_wino_wgrad, SlabPool, _FullExtent
+    Hi, Wi = hw                                                      # input extent; outputs are (Hi-1) x (Wi-1)
+    H, W = Hi - 1, Wi - 1
+    B, Cin, Cout = 2, 128, 256
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, Hi + 2, Wi + 2, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
+    dyv = torch.randn(B, H, W, Cout, generator=g)
+    xp = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    wt = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xp, wt).backward(dyv.permute(0, 3, 1, 2).double())
+    ref_gx, ref_gw = xp.grad.permute(0, 2, 3, 1).float(), wt.grad.float()
+    tw = Twin("fp32")
+    res = []
+    for ctx in (tw.gctx, tw.cctx):
+        dev = ctx.device
+        inp = Halo(ctx, B, Hi, Wi, Cin, 1)
+        inp.t.copy_(x.to(dev))
+        dy = Halo(ctx, B, H, W, Cout, 3)
+        dy.interior().copy_(dyv.to(dev))
+        gx = Halo(ctx, B, Hi, Wi, Cin, 1)
+        gw = ctx.zeros(Cout, Cin, 4, 4)
+        wd = w.to(dev).contiguous()
+        ctx.keep.append(wd)
+        plan, pack = Plan(ctx), Plan(ctx)
+        wdesc = emit_wino(None, pack, ctx, dy, wd, None, _FullExtent(gx), H=gx.hp, W=gx.wp, cin=Cout, cout=Cin, flip=True, r=4)
+        emit_wino_wgrad(plan, ctx, dy, inp, gw, OH=H, OW=W, cin=Cin, cout=Cout, slabs_pool=SlabPool(ctx), pair_wino=wdesc, r=4)
+        res.append((pack, plan, gx, gw))
+    (gpk, gpl, ggx, ggw), (cpk, cpl, cgx, cgw) = res
+    tw.run(gpk, cpk)
+    tw.run(gpl, cpl)
+    close(cgx.t, ref_gx, 1e-5, "restatement: data gradient")
+    close(cgw, ref_gw, 1e-5, "restatement: weight gradient")
+    close(ggx.t, ref_gx, 5e-5, "device: data gradient")
+    close(ggw, ref_gw, 1e-4, "device: weight gradient")
+
+
 @pytest.mark.parametrize("hw", [(12, 16), (9, 11)])
 def test_winograd_backward_pair_matches_autograd(hw):
     """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it: Winograd data gradient (over the padded extent) and

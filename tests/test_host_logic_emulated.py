@@ -615,3 +615,51 @@ def test_fused_trainer_sees_external_weight_changes(emu, golden_dir):
     for k in ("loss_D", "loss_G", "loss_G_l1"):
         close(after[k], fresh[k], 1e-6, k)
     assert abs(after["loss_G"] - float(z["loss_G"])) > 1e-3 * abs(float(z["loss_G"]))      # and it did change something
+
+
+def test_winograd_4x4_restatement_matches_conv2d(emu):
+    """The numpy restatement of F(2x2,4x4) (the matrices csrc/winograd.hip uses for the PatchGAN's stride-1 4x4 layer) against torch's
+    conv2d: forward over an odd extent, and the flipped-filter data gradient."""
+    B, H, W, Cc, K = 2, 5, 8, 32, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H + 3, W + 3, Cc, generator=g)
+    w = (torch.randn(K, Cc, 4, 4, generator=g) * 0.05).contiguous()
+    b = torch.randn(K, generator=g)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1).float()
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
+    U, V, y = torch.zeros(25 * K * Cc), torch.zeros(25 * T * Cc), torch.zeros(B, H, W, K)
+    d = L.WinoDesc()
+    d.r = 4
+    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = x.data_ptr(), H + 3, W + 3, B, H, W, Cc, K
+    d.U, d.bias, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), b.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), torch.zeros(64).data_ptr()
+    assert emu.nirgan_wino_weights_r(w.data_ptr(), K, Cc, 4, 0, U.data_ptr()) == 0 and emu.nirgan_wino_conv3x3(d) == 0
+    close(y, ref, 1e-5, "F(2x2,4x4) forward")
+    d.x_hp += 1                                                  # wrong buffer geometry is refused
+    assert emu.nirgan_wino_conv3x3(d) != 0
+
+
+def test_discriminator_winograd_layer_through_the_trainer(emu):
+    """ndf = 32 makes the PatchGAN's stride-1 4x4 layer 128 -> 256 channels, wide enough for the Winograd path (forward, fused
+    data/weight gradient in the D step, data gradient alone in the G step): one fused step against the oracle's trainer."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    torch.manual_seed(11)     # (seed 3 puts a ReLU pre-activation of the last block at 2e-7: the mask flips between two valid fp32 evaluations)
+    netG = networks.define_G(3, 1, 8, "resnet_6blocks", "instance", False, "normal", 0.02)
+    netD = networks.define_D(4, 32, "basic", 3, "instance", "normal", 0.02)
+    G0 = {k: v.detach().clone() for k, v in netG.state_dict().items()}
+    D0 = {k: v.detach().clone() for k, v in netD.state_dict().items()}
+    rgb, nir = torch.rand(2, 3, 32, 32), torch.rand(2, 1, 32, 32)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0)      # lr 0: the generator step sees the same D as the oracle's (no Adam sign noise)
+    out = tr.step(rgb, nir).as_dict()
+    assert emu.calls.count("wino") >= 4 and "wino_dy" in emu.calls and "wino_fin" in emu.calls, "the Winograd path did not run"
+    ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
+    o = ref.step(rgb, nir)
+    close(out["loss_D"], o["loss_D"], 1e-5, "loss_D")
+    close(out["loss_G"], o["loss_G"], 1e-5, "loss_G")
+    gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
+    for k, v in ref.last["grads_D"].items():
+        if k not in O.shadowed_bias_keys("D"):
+            close(gD[k], v, 2e-4, "gD " + k)
+    for k, v in ref.last["grads_G"].items():
+        if v is not None and k not in O.shadowed_bias_keys("G", 6):
+            close(gG[k], v, 2e-4, "gG " + k)
