@@ -388,10 +388,11 @@ def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tenso
     wino_blocks = -(-(c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2)) // 64) * (c.K // 128)
     # 256 CUs x 2 resident workgroups = 512 slots.  When both parts fit ONE residency with weight-gradient blocks no longer than ~1.3
     # Winograd blocks (>= 6 splits), launch exactly that (res-block layer at bs 16: 8 splits, 649 us; 15 splits 676, 23 splits 658);
-    # otherwise many short blocks pack best behind the Winograd tiles (profiles/r01_wino_split_sweep.txt: 23 splits are within 1.5 %
-    # of the best at bs 32, padding 10 and 512x512, where 5-8 splits lose 6-13 %)
+    # otherwise ~1500 short blocks pack best behind the Winograd tiles (profiles/r01_wino_split_sweep.txt: 23 splits of the 64 res-layer
+    # tiles are within 1.5 % of the best at bs 32, padding 10 and 512x512, where 5-8 splits lose 6-13 %; the PatchGAN's 4x4 layer with
+    # 200 tiles measures 1040 us at 4, 8 and 22 splits alike)
     room = 1024 - wino_blocks
-    target = room if room // tiles >= 6 else 23 * tiles
+    target = room if room // tiles >= 6 else max(1472, 2 * tiles)
     nsplit, rows = G.wgrad_split(T, tiles, target)
     env = "NIRGAN_WINO_SPLITS" if r == 3 else "NIRGAN_WINO4_SPLITS"
     if os.environ.get(env):                            # experiments (scripts/sweep_wino_splits.sh)
