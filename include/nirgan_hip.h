@@ -304,6 +304,26 @@ int64_t nirgan_image_metrics_ws_elems(int planes, int H, int W);
 int nirgan_image_metrics(const nirgan_metrics_desc* d, void* stream);
 
 /* -------------------------------------------------------------------------------------
+ * SSIM term of the generator objective, value AND gradient: model/pix2pix.py:233-237 adds
+ * lambda_ssim * ssim_loss(pred, nir); utils/losses.py:10-30: 1 - kornia.metrics.ssim(img1, img2, window_size=11).mean()
+ * (Gaussian window sigma 1.5, reflect border, max_val 1, eps 1e-12 in the denominator).
+ *   *loss      += weight * (1 - mean SSIM)                (atomic add; NULL = skip)
+ *   *value      = 1 - mean SSIM                            (NULL = skip)
+ *   grad_pred  += weight * d(1 - mean SSIM) / d pred       (dense [planes][H][W]; NULL = value only)
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* pred; const float* target;  /* dense [planes][H][W] */
+    int planes, H, W;
+    int window; float sigma, max_val, eps;
+    float weight;
+    float* ws; int64_t ws_elems;             /* nirgan_ssim_loss_ws_elems(planes, H, W, window) floats */
+    float* loss; float* value; float* grad_pred;
+} nirgan_ssim_loss_desc;
+
+int64_t nirgan_ssim_loss_ws_elems(int planes, int H, int W, int window);
+int nirgan_ssim_loss(const nirgan_ssim_loss_desc* d, void* stream);
+
+/* -------------------------------------------------------------------------------------
  * SatCLIP location encoder, fp64 like the reference (model/satclip/load_lightweight.py:29,
  * satclip_wrapper.py:30-35; called from model/pix2pix.py:481-484 once per batch):
  * positional_encoding/spherical_harmonics.py:26-42 + spherical_harmonics_closed_form.py:8-40 (real spherical

@@ -76,8 +76,10 @@ class Px2Px_PL(_Base):
         if self.opt.lambda_rs_losses > 0.0:
             from utils.remote_sensing_indices import RemoteSensingIndices
             self.rs_losses = RemoteSensingIndices(mode="loss", criterion=self.opt.rs_losses_criterium)
-        if _cfg(self.opt, "lambda_ssim", 0.0) > 0.0 or _cfg(self.opt, "lambda_hist", 0.0) > 0.0:
-            raise NotImplementedError("lambda_ssim / lambda_hist > 0 are not on the MI355X path (0.0 in every shipped config)")
+        self.lambda_ssim = float(_cfg(self.opt, "lambda_ssim", 0.0) or 0.0)
+        if (_cfg(self.opt, "lambda_hist", 0.0) or 0.0) > 0.0:
+            # the reference's own branch calls an undefined hist_loss (pix2pix.py:239-243): it cannot run there either
+            raise NotImplementedError("lambda_hist > 0 is not on the MI355X path (the reference's training_step calls an undefined hist_loss)")
         self.satclip = use_sat
         # frozen SatCLIP location encoder (pix2pix.py:69-80): built from the checkpoint when it is there (no network
         # here: the file must be local); without it ``coords`` must already carry the B x 256 embeddings
@@ -151,6 +153,11 @@ class Px2Px_PL(_Base):
             loss_G_L1 = self.criterionL1(pred, nir)
             self._log("model_loss/generator_L1", loss_G_L1)
             loss_G = loss_G_GAN * self.opt.lambda_GAN + loss_G_L1 * self.opt.lambda_L1
+            if self.lambda_ssim > 0.0:                                   # pix2pix.py:233-237
+                from utils.losses import ssim_loss
+                loss_G_ssim = ssim_loss(pred, nir)
+                self._log("model_loss/generator_ssim", loss_G_ssim)
+                loss_G = loss_G + loss_G_ssim * self.lambda_ssim
             if self.opt.lambda_rs_losses > 0.0:
                 losses_rs_indices = self.rs_losses.get_and_weight_losses(rgb, nir, pred,
                                                                          loss_config=dict(self.opt.internal_rs_loss_weights))
@@ -247,7 +254,7 @@ class Px2Px_PL(_Base):
                 self.netG, self.netD, n_blocks=self.netG.n_blocks, lr=self.opt.lr, beta1=self.opt.beta1,
                 lambda_gan=self.opt.lambda_GAN, lambda_l1=self.opt.lambda_L1, lambda_rs=self.opt.lambda_rs_losses,
                 rs_weights=dict(self.opt.internal_rs_loss_weights), rs_criterion=self.opt.rs_losses_criterium,
-                padding=pad, inject=inject, reducer=reducer)
+                padding=pad, inject=inject, reducer=reducer, lambda_ssim=self.lambda_ssim)
         return self._fused
 
     def train_batch(self, batch):

@@ -103,6 +103,11 @@ class MetricsDesc(C.Structure):
                 ("ws", fp), ("ws_elems", i64), ("means", fp)]
 
 
+class SsimLossDesc(C.Structure):
+    _fields_ = [("pred", fp), ("target", fp), ("planes", i32), ("H", i32), ("W", i32), ("window", i32), ("sigma", f32), ("max_val", f32),
+                ("eps", f32), ("weight", f32), ("ws", fp), ("ws_elems", i64), ("loss", fp), ("value", fp), ("grad_pred", fp)]
+
+
 class LocEncDesc(C.Structure):
     _fields_ = [("lonlat", fp), ("B", i32), ("L", i32), ("sh_norm", fp), ("nlayers", i32),
                 ("weights", C.POINTER(fp)), ("biases", C.POINTER(fp)), ("dims", C.POINTER(i32)),
@@ -155,6 +160,8 @@ PROTOTYPES = {
     "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),
     "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),
     "nirgan_image_metrics": (i32, [C.POINTER(MetricsDesc), fp]),
+    "nirgan_ssim_loss_ws_elems": (i64, [i32, i32, i32, i32]),
+    "nirgan_ssim_loss": (i32, [C.POINTER(SsimLossDesc), fp]),
     "nirgan_instnorm_ws_elems": (i64, [i32, i32, i32, i32]),
     "nirgan_instnorm_fwd": (i32, [C.POINTER(InFwdDesc), fp]),
     "nirgan_instnorm_bwd": (i32, [C.POINTER(InBwdDesc), fp]),

@@ -6,7 +6,8 @@ two-optimizer schedule, configure_optimizers :485-492):
     optimizer 0 (D): pred = G(rgb);  loss_D = MSE(D(cat(rgb, pred.detach())), 0) + MSE(D(cat(rgb, nir)), 1);
                      backward; Adam(D)
     optimizer 1 (G): D frozen (already updated);  loss_G = l_GAN*MSE(D(cat(rgb, pred)), 1) + l_L1*L1(pred, nir)
-                     [+ l_rs * sum_i w_i * crit(index_i(nir), index_i(pred))];  backward; Adam(G)
+                     [+ l_rs * sum_i w_i * crit(index_i(nir), index_i(pred))] [+ l_ssim * (1 - mean SSIM_11(pred, nir))];
+                     backward; Adam(G)
 
 Differences from the reference that do not change results: the generator forward runs once
 (its parameters do not change between the two optimizer passes, so the second forward would
@@ -54,6 +55,19 @@ class _Micro:
         d.extra, d.extra_cs, d.extra_c, d.extra_scale = self.D1.gpred.data_ptr(), 1, 0, 1.0
         d.sums, d.grad_pred = tr.losses.data_ptr() + 3 * 4, self.G.dpred.data_ptr()
         self.pix = d
+        # optional SSIM term (model/pix2pix.py:233-237; lambda_ssim is 0.0 in the shipped configs): runs after the pixel losses and
+        # ADDS its gradient to dpred, its weighted value to losses[10]
+        self.ssim = None
+        if tr.lambda_ssim > 0.0:
+            be = L.backend()
+            self.ssim_ws = torch.zeros(int(be.nirgan_ssim_loss_ws_elems(B, H, W, 11)), dtype=torch.float32, device=dev)
+            sd = L.SsimLossDesc()
+            sd.pred, sd.target, sd.planes, sd.H, sd.W = self.G.pred.data_ptr(), self.nir.data_ptr(), B, H, W
+            sd.window, sd.sigma, sd.max_val, sd.eps = 11, 1.5, 1.0, 1e-12
+            sd.weight = tr.lambda_ssim * scale
+            sd.ws, sd.ws_elems = self.ssim_ws.data_ptr(), self.ssim_ws.numel()
+            sd.loss, sd.value, sd.grad_pred = tr.losses.data_ptr() + 10 * 4, None, self.G.dpred.data_ptr()
+            self.ssim = sd
 
 
 class _ShapeState:
@@ -100,7 +114,7 @@ class Pix2PixTrainer:
     def __init__(self, netG: torch.nn.Module, netD: torch.nn.Module, *, n_blocks: int, lr=2e-4, beta1=0.5,
                  lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0, rs_weights: Optional[Dict[str, float]] = None,
                  rs_criterion="l1", padding=0, inject: Optional[dict] = None, reducer=None, precision="fp32",
-                 micro_batches: int = 1):
+                 micro_batches: int = 1, lambda_ssim: float = 0.0):
         self.netG, self.netD = netG, netD
         self.flatG = netG._flat() if hasattr(netG, "_flat") else FlatParams(netG)
         self.flatD = netD._flat() if hasattr(netD, "_flat") else FlatParams(netD)
@@ -108,6 +122,7 @@ class Pix2PixTrainer:
         self.lr, self.beta1 = lr, beta1
         self.lr_d, self.lr_g = None, None   # per-network overrides (ReduceLROnPlateau steps them separately); None = self.lr
         self.lambda_gan, self.lambda_l1, self.lambda_rs = float(lambda_gan), float(lambda_l1), float(lambda_rs)
+        self.lambda_ssim = float(lambda_ssim)
         self.rs_weights = rs_weights or {}
         if rs_criterion not in ("l1", "l2"):
             raise NotImplementedError(f"Criterion '{rs_criterion}' not implemented. 'l1' or 'l2' are supported.")
@@ -134,7 +149,7 @@ class Pix2PixTrainer:
         if rebuilt:
             self._states.clear()          # the flat ranges moved: every descriptor holds stale pointers
         if self.losses is None or rebuilt:
-            # 0 D_fake 1 D_real 2 G_gan 3.. pix sums[7]
+            # 0 D_fake 1 D_real 2 G_gan 3.. pix sums[7] 10 weighted SSIM term
             self.losses = torch.zeros(16, dtype=torch.float32, device=self.flatG.flat.device)
         st = self._states.get((B, H, W))
         if st is None:
@@ -169,6 +184,8 @@ class Pix2PixTrainer:
         L.check(be.nirgan_lsgan(m.D1.out.data_ptr(), m.n_patch, 1.0, self.lambda_gan * m.scale, lp + 8, m.D1.dout.data_ptr(), st), "lsgan")
         m.D1.backward(None, frozen=True, version=self.flatD.values_version(), pred_only=True)
         L.check(be.nirgan_pix_loss(C.byref(m.pix), st), "pix_loss")
+        if m.ssim is not None:
+            L.check(be.nirgan_ssim_loss(C.byref(m.ssim), st), "ssim_loss")
         m.G.backward(None, version=self.flatG.values_version())
 
     def _fork(self, state: _ShapeState):
@@ -239,5 +256,8 @@ class LossView:
                     rs += w * v[4 + i] / self.npix
             out["loss_G_rs"] = rs
             loss_g += tr.lambda_rs * rs
+        if tr.lambda_ssim > 0.0:
+            out["loss_G_ssim"] = v[10] / tr.lambda_ssim
+            loss_g += v[10]
         out["loss_G"] = loss_g
         return out

@@ -441,14 +441,23 @@ def d_step_loss(pD: Params, rgb, nir, pred) -> Tuple[torch.Tensor, torch.Tensor,
     return loss_fake + loss_real, loss_fake, loss_real
 
 
+def ssim_loss(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> torch.Tensor:
+    """utils/losses.py:10-30: 1 - kornia.metrics.ssim(img1, img2, window_size).mean() (restated by ssim_map above)."""
+    return 1.0 - ssim_map(img1.float(), img2.float(), window_size).mean()
+
+
 def g_step_loss(pD: Params, rgb, nir, pred, lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0,
-                rs_weights: Optional[dict] = None, rs_criterion: str = "l1") -> Tuple[torch.Tensor, dict]:
+                rs_weights: Optional[dict] = None, rs_criterion: str = "l1", lambda_ssim: float = 0.0) -> Tuple[torch.Tensor, dict]:
     """optimizer_idx 1 (pix2pix.py:215-257)."""
     pred_fake = discriminator_forward(pD, torch.cat((rgb, pred), 1))
     l_gan = lsgan_loss(pred_fake, True)                                   # :220
     l_l1 = l1_loss(pred, nir)                                             # :222
     loss = l_gan * lambda_gan + l_l1 * lambda_l1                          # :226-229
     parts = {"gan": l_gan, "l1": l_l1}
+    if lambda_ssim > 0.0:                                                 # :233-237
+        l_ssim = ssim_loss(pred, nir)
+        loss = loss + l_ssim * lambda_ssim
+        parts["ssim"] = l_ssim
     if lambda_rs > 0.0:                                                   # :246-251
         l_rs = rs_weighted_loss(rgb, nir, pred, rs_weights, rs_criterion)
         loss = loss + l_rs * lambda_rs
@@ -480,12 +489,13 @@ class OracleTrainer:
 
     def __init__(self, pG: Params, pD: Params, n_blocks: int, padding: int = 0,
                  lr=2e-4, beta1=0.5, lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0,
-                 rs_weights: Optional[dict] = None, rs_criterion="l1", inject_cfg: Optional[dict] = None):
+                 rs_weights: Optional[dict] = None, rs_criterion="l1", inject_cfg: Optional[dict] = None, lambda_ssim: float = 0.0):
         self.pG = {k: v.detach().clone().requires_grad_(True) for k, v in pG.items()}
         self.pD = {k: v.detach().clone().requires_grad_(True) for k, v in pD.items()}
         self.n_blocks, self.padding = n_blocks, padding
         self.lr, self.beta1 = lr, beta1
         self.lam = (lambda_gan, lambda_l1, lambda_rs)
+        self.lambda_ssim = lambda_ssim
         self.rs_weights, self.rs_criterion = rs_weights, rs_criterion
         self.inject_cfg = inject_cfg
         self.state = {id(t): (torch.zeros_like(t), torch.zeros_like(t)) for t in
@@ -514,7 +524,7 @@ class OracleTrainer:
         # ---- optimizer_idx 1: generator (D frozen, already updated)
         pred = px_forward(self.pG, rgb, self.n_blocks, self.padding, embeds, self.inject_cfg)
         pD_frozen = {k: v.detach() for k, v in self.pD.items()}
-        loss_g, parts = g_step_loss(pD_frozen, rgb, nir, pred, lg, l1w, lrs, self.rs_weights, self.rs_criterion)
+        loss_g, parts = g_step_loss(pD_frozen, rgb, nir, pred, lg, l1w, lrs, self.rs_weights, self.rs_criterion, self.lambda_ssim)
         gG = torch.autograd.grad(loss_g, list(self.pG.values()), allow_unused=True)
         gG = dict(zip(self.pG.keys(), gG))
         self._adam(self.pG, gG)

@@ -477,6 +477,46 @@ class EmuBackend:
         out[0], out[1], out[2] = (a - b).abs().mean().item(), ((a - b) ** 2).mean().item(), ssim.mean().item()
         return 0
 
+    # ------------------------------------------------------------------ SSIM loss (value + gradient through torch autograd, fp64)
+    def nirgan_ssim_loss_ws_elems(self, planes, H, W, window):
+        if planes <= 0 or H <= 0 or W <= 0 or window < 1 or window > 11 or window % 2 == 0:
+            return 0
+        r = window // 2
+        return 3 * planes * H * W + 3 * planes * (H + 2 * r) * (W + 2 * r) + planes * ((H + 31) // 32) * ((W + 31) // 32)
+
+    def nirgan_ssim_loss(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("ssim_loss")
+        r = d.window // 2
+        if d.window % 2 == 0 or d.window > 11 or d.H <= r or d.W <= r:
+            return self._fail("ssim_loss: bad window")
+        if d.ws_elems < self.nirgan_ssim_loss_ws_elems(d.planes, d.H, d.W, d.window):
+            return self._fail("ssim_loss: workspace too small")
+        n = d.planes * d.H * d.W
+        with torch.enable_grad():                 # (callers may sit inside an autograd.Function.forward)
+            a = torch.from_numpy(arr(d.pred, n).reshape(d.planes, 1, d.H, d.W).astype(np.float64)).requires_grad_(True)
+            b = torch.from_numpy(arr(d.target, n).reshape(d.planes, 1, d.H, d.W).astype(np.float64))
+            x = torch.arange(d.window, dtype=torch.float64) - r
+            k = torch.exp(-x * x / (2.0 * d.sigma ** 2))
+            k = (k / k.sum())
+            k2 = (k[:, None] * k[None, :])[None, None]
+
+            def filt(t):
+                return F.conv2d(F.pad(t, (r, r, r, r), mode="reflect"), k2)
+            c1, c2 = (0.01 * d.max_val) ** 2, (0.03 * d.max_val) ** 2
+            mu1, mu2 = filt(a), filt(b)
+            s1, s2, s12 = filt(a * a) - mu1 * mu1, filt(b * b) - mu2 * mu2, filt(a * b) - mu1 * mu2
+            ssim = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2) + d.eps)
+            v = 1.0 - ssim.mean()
+            g = torch.autograd.grad(v, a)[0] if d.grad_pred else None
+        if d.value:
+            arr(d.value, 1)[0] = v.item()
+        if d.loss:
+            arr(d.loss, 1)[0] += d.weight * v.item()
+        if d.grad_pred:
+            arr(d.grad_pred, n)[:] += (d.weight * g).reshape(-1).numpy().astype(np.float32)
+        return 0
+
     # ------------------------------------------------------------------ instance norm
     def nirgan_instnorm_ws_elems(self, B, H, W, Cc):
         return B * _in_nchunk(B, H * W, Cc) * 2 * Cc + B * 2 * Cc

@@ -330,6 +330,41 @@ def test_image_metrics_kernel(shape, window):
             close(torch.tensor(m[k]), torch.tensor(r[k]), 1e-4, k)
 
 
+@pytest.mark.parametrize("shape,window", [((2, 1, 40, 50), 11), ((16, 1, 256, 256), 11), ((3, 2, 33, 31), 5), ((1, 1, 12, 9), 11)])
+def test_ssim_loss_value_and_gradient(shape, window):
+    """nirgan_ssim_loss (utils/losses.py:10-30 = 1 - kornia.metrics.ssim(.., 11).mean(), the lambda_ssim term of model/pix2pix.py:233-237)
+    against torch autograd of the oracle's restatement in float64: value, gradient wrt the prediction (adjoint of the reflect-padded
+    Gaussian filter), the += / weight contract of the C ABI, and the autograd bridge of utils.losses.ssim_loss."""
+    import ctypes as C
+    import nirgan_oracle as O
+    from utils.losses import ssim_loss
+    g = torch.Generator().manual_seed(6)
+    pred = torch.rand(*shape, generator=g)
+    target = (pred + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    p64 = pred.double().requires_grad_(True)
+    ref_v = 1.0 - O.ssim_map(p64, target.double(), window).mean()
+    ref_g, = torch.autograd.grad(ref_v, p64)
+    B, Cc, H, W = shape
+    pd, td = pred.to(DEV).contiguous(), target.to(DEV).contiguous()
+    ws = torch.zeros(int(L.backend().nirgan_ssim_loss_ws_elems(B * Cc, H, W, window)), device=DEV)
+    loss, value = torch.full((1,), 2.0, device=DEV), torch.zeros(1, device=DEV)
+    base = (1e-4 * torch.randn(*shape, generator=g)).to(DEV)        # (small: grad - base below must not drown in fp32 cancellation)
+    grad = base.clone()
+    d = L.SsimLossDesc()
+    d.pred, d.target, d.planes, d.H, d.W = pd.data_ptr(), td.data_ptr(), B * Cc, H, W
+    d.window, d.sigma, d.max_val, d.eps, d.weight = window, 1.5, 1.0, 1e-12, 0.75
+    d.ws, d.ws_elems, d.loss, d.value, d.grad_pred = ws.data_ptr(), ws.numel(), loss.data_ptr(), value.data_ptr(), grad.data_ptr()
+    L.call("nirgan_ssim_loss", C.byref(d), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    close(value.cpu(), ref_v.detach().float().reshape(1), 2e-5, "1 - mean SSIM")
+    close(loss.cpu() - 2.0, 0.75 * ref_v.detach().float().reshape(1), 2e-5, "weighted loss added to the accumulator")
+    close((grad - base).cpu(), 0.75 * ref_g.float(), 1e-4, "gradient added to grad_pred")
+    pa = pd.clone().requires_grad_(True)
+    (2.0 * ssim_loss(pa, td, window)).backward()
+    close(pa.grad.cpu(), 2.0 * ref_g.float(), 1e-4, "autograd bridge")
+    close(ssim_loss(pd, td, window).cpu(), ref_v.detach().float(), 2e-5, "value-only call")
+
+
 def test_location_encoder_kernel(golden_dir, tmp_path):
     """nirgan_location_encoder (fp64) against the reference's closed-form harmonics (fixture f6) and the oracle's
     Siren restatement; a SatCLIP-sized encoder (L = 10 -> 512 -> 512 -> 256, B = 32) against the oracle."""

@@ -100,6 +100,28 @@ def test_golden_small_nets_fused_step(golden_dir, name):
         close(pD[k], p0, 1e-6, "adam " + k)
 
 
+@pytest.mark.parametrize("micro", [1, 2])
+def test_fused_step_with_the_ssim_term(golden_dir, micro):
+    """lambda_ssim > 0 (model/pix2pix.py:233-237, utils/losses.py:10-30): the fused HIP step with the SSIM term against the oracle's
+    trainer carrying the same term (lr 0: both generator passes see the same discriminator)."""
+    from nirgan_hip.trainer import Pix2PixTrainer
+    z = load(golden_dir, "f1_g9_rs_pad.npz")
+    nb, pad = int(z["n_blocks"]), int(z["padding"])
+    netG, netD = make_nets(z, nb)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=nb, padding=pad, lr=0.0, lambda_ssim=40.0, micro_batches=micro)
+    rgb, nir = torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])
+    out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
+    ref = O.OracleTrainer(sub(z, "G0/"), sub(z, "D0/"), nb, padding=pad, lr=0.0, lambda_ssim=40.0)
+    o = ref.step(rgb, nir)
+    for k in ("loss_G", "loss_G_ssim", "loss_G_l1", "loss_D"):
+        close(out[k], o[k], 1e-3, k)
+    gG = tr.flatG.grad_views()
+    shadow = O.shadowed_bias_keys("G", nb)
+    for k, v in ref.last["grads_G"].items():
+        if v is not None and k not in shadow:
+            grad_close(gG[k], v, "gG " + k)
+
+
 def test_golden_inject_generator(golden_dir, capsys):
     from model import networks
     from model.generator_inject import define_G_inject

@@ -313,6 +313,21 @@ def test_px2px_pl_surface(emu, golden_dir):
     m.logged.clear()
     m.training_step(batch, 11, 0)
     assert "train/SSIM" not in m.logged
+    # lambda_ssim > 0 (pix2pix.py:233-237): the autograd path adds lambda * ssim_loss(pred, nir) and logs it; the fused trainer gets the
+    # same weight; lambda_hist > 0 cannot run in the reference either (undefined hist_loss) and is refused
+    cfg.base_configs.lambda_ssim = 25.0
+    m2 = Px2Px_PL(cfg)
+    m2.load_state_dict(m.state_dict())
+    m2.train()
+    lg = m2.training_step(batch, 0, 1)
+    want = m.training_step(batch, 0, 1).detach() + 25.0 * float(m2.logged["model_loss/generator_ssim"])
+    assert abs(float(lg.detach()) - float(want)) <= 1e-5 * abs(float(want))
+    lg.backward()
+    assert all(torch.isfinite(p_.grad).all() for p_ in m2.netG.parameters() if p_.grad is not None)
+    assert m2.fused_trainer().lambda_ssim == 25.0 and "loss_G_ssim" in m2.train_batch(batch).as_dict()
+    cfg.base_configs.lambda_hist = 1.0
+    with pytest.raises(NotImplementedError):
+        Px2Px_PL(cfg)
 
 
 # ---------------------------------------------------------------------------------- operand precision modes
@@ -453,7 +468,7 @@ def test_mixed_resolution_buckets_share_one_trainer(emu, golden_dir):
 
 def test_calculate_metrics_surface(emu):
     """utils.calculate_metrics.calculate_metrics keeps the reference's signature/keys (utils/calculate_metrics.py:5-36)
-    and agrees with the oracle's restatement; ssim_loss is value-only."""
+    and agrees with the oracle's restatement; ssim_loss carries its gradient wrt the prediction."""
     from utils.calculate_metrics import calculate_metrics, image_metrics_device
     from utils.losses import emd_loss, ssim_loss
     g = torch.Generator().manual_seed(2)
@@ -464,8 +479,12 @@ def test_calculate_metrics_surface(emu):
     for k in ref:
         close(got[k], ref[k], 1e-5, k)
     close(ssim_loss(pred, target), 1.0 - O.ssim_map(pred, target, 11).mean(), 1e-5, "ssim_loss")
+    p1, p2 = pred.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+    (3.0 * ssim_loss(p1, target)).backward()
+    (3.0 * O.ssim_loss(p2, target)).backward()
+    close(p1.grad, p2.grad, 1e-5, "ssim_loss gradient")
     with pytest.raises(NotImplementedError):
-        ssim_loss(pred.clone().requires_grad_(True), target)
+        ssim_loss(pred, target.clone().requires_grad_(True))
     with pytest.raises(NotImplementedError):
         emd_loss(pred, target)
     with pytest.raises(ValueError):
@@ -663,3 +682,25 @@ def test_discriminator_winograd_layer_through_the_trainer(emu):
     for k, v in ref.last["grads_G"].items():
         if v is not None and k not in O.shadowed_bias_keys("G", 6):
             close(gG[k], v, 2e-4, "gG " + k)
+
+
+def test_fused_trainer_with_the_ssim_term(emu, golden_dir):
+    """lambda_ssim > 0 (model/pix2pix.py:233-237): the fused step adds lambda_ssim * (1 - mean SSIM_11(pred, nir)) to the generator
+    objective and its gradient to dpred; against the oracle's trainer with the same term.  Also with two micro-batches."""
+    from nirgan_hip.trainer import Pix2PixTrainer
+    z = load(golden_dir, "f1_g6_d.npz")
+    rgb, nir = torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])
+    ref = O.OracleTrainer(sub(z, "G0/"), sub(z, "D0/"), 6, lr=0.0, lambda_ssim=40.0)
+    o = ref.step(rgb, nir)
+    assert abs(float(o["loss_G"]) - float(z["loss_G"])) > 1.0                  # the term is not negligible here
+    for micro in (1, 2):
+        netG, netD = make_nets(z, 6)
+        tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0, lambda_ssim=40.0, micro_batches=micro)
+        out = tr.step(rgb, nir).as_dict()
+        assert "ssim_loss" in emu.calls
+        close(out["loss_G"], o["loss_G"], 1e-5, "loss_G")
+        close(out["loss_G_ssim"], o["loss_G_ssim"], 1e-5, "loss_G_ssim")
+        gG = tr.flatG.grad_views()
+        for k, v in ref.last["grads_G"].items():
+            if v is not None and k not in O.shadowed_bias_keys("G", 6):
+                close(gG[k], v, 2e-4, f"gG {k} (micro {micro})")
