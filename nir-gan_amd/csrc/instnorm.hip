@@ -196,6 +196,25 @@ struct InBwd {
     unsigned short* dy16;
 };
 
+// gradient wrt the block output at pixel (h, w) = pix of sample b: the (reflect-folded) halo'd gradient plus the dense skip gradient
+__device__ __forceinline__ f32x4 in_bwd_gsum(const InBwd& p, const float* gb, const float* g2b, int h, int w, int pix, int q) {
+    f32x4 ga = {0, 0, 0, 0};
+    if (gb) {
+        if (p.g_fold) {
+            int hs[3], wsx[3];
+            const int nh = halo_images(h, p.H, p.g_pad, hs), nw = halo_images(w, p.W, p.g_pad, wsx);
+            for (int i = 0; i < nh; ++i)
+                for (int j = 0; j < nw; ++j) ga += ld4(gb + size_t(hs[i]) * p.g_row + size_t(wsx[j]) * p.C + q * 4);
+        } else {
+            ga = ld4(gb + size_t(h + p.g_pad) * p.g_row + size_t(w + p.g_pad) * p.C + q * 4);
+        }
+    }
+    if (g2b) ga += ld4(g2b + size_t(pix) * p.C + q * 4);
+    return ga;
+}
+
+// with norm: the sums of g_z and g_z * z only (pass 2 rebuilds g_z from the same inputs instead of reading it back: one tensor write
+// less); without norm: dy = g_z, written here
 __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
     __shared__ f32x4 lds[512];
     const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
@@ -217,18 +236,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
         end = end < p.HW ? end : p.HW;
         for (int pix = start + rg; pix < end; pix += nrg) {
             const int h = pix / p.W, w = pix - h * p.W;
-            f32x4 ga = {0, 0, 0, 0};
-            if (gb) {
-                if (p.g_fold) {
-                    int hs[3], wsx[3];
-                    const int nh = halo_images(h, p.H, p.g_pad, hs), nw = halo_images(w, p.W, p.g_pad, wsx);
-                    for (int i = 0; i < nh; ++i)
-                        for (int j = 0; j < nw; ++j) ga += ld4(gb + size_t(hs[i]) * p.g_row + size_t(wsx[j]) * p.C + q * 4);
-                } else {
-                    ga = ld4(gb + size_t(h + p.g_pad) * p.g_row + size_t(w + p.g_pad) * p.C + q * 4);
-                }
-            }
-            if (g2b) ga += ld4(g2b + size_t(pix) * p.C + q * 4);
+            const f32x4 ga = in_bwd_gsum(p, gb, g2b, h, w, pix, q);
             if (p.gsum_out) st4(p.gsum_out + (size_t(b) * p.HW + pix) * p.C + q * 4, ga);
             // z = (y - mean) * rstd is recomputed exactly as the forward computed it: its sign is the activation
             // mask (ReLU / LeakyReLU), so the activated tensor does not have to be read back
@@ -241,10 +249,10 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gz[i] = z[i] > 0.f ? gz[i] : gz[i] * neg;
             }
-            {
+            if (!p.norm) {                                                                      // no second pass: this IS dy
                 const size_t off = size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
                 st4(db + off, gz);
-                if (!p.norm) st4_twin(p.dy16 ? p.dy16 + size_t(b) * p.d_img + p.d_org : nullptr, off, gz);   // no second pass: this IS dy
+                st4_twin(p.dy16 ? p.dy16 + size_t(b) * p.d_img + p.d_org : nullptr, off, gz);
             }
             s1 += gz;
             if (p.norm) s2 += gz * z;
@@ -286,6 +294,12 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     const f32x4 mean = ld4(p.mean + size_t(b) * p.C + q * 4);
     const f32x4 rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
     const float* yb = p.y + size_t(b) * p.HW * p.C;
+    // g_z again, from what pass 1 read: the folded sum it stored for the skip path when there is one, else the halo'd gradient itself
+    const float* gsb = p.gsum_out ? p.gsum_out + size_t(b) * p.HW * p.C : nullptr;
+    const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
+    const float* g2b = p.g2 ? p.g2 + size_t(b) * p.HW * p.C : nullptr;
+    const bool masked = p.act == NIRGAN_ACT_RELU || p.act == NIRGAN_ACT_LRELU;
+    const float neg = p.act == NIRGAN_ACT_RELU ? 0.f : p.slope;
     float* db = p.dy + size_t(b) * p.d_img + p.d_org;
     const int start = chunk * p.ppc;
     int end = start + p.ppc;
@@ -293,11 +307,14 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     for (int pix = start + rg; pix < end; pix += nrg) {
         const int h = pix / p.W, w = pix - h * p.W;
         const size_t off = size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
-        float* dp = db + off;
-        const f32x4 gz = ld4(dp);
+        f32x4 gz = gsb ? ld4(gsb + size_t(pix) * p.C + q * 4) : in_bwd_gsum(p, gb, g2b, h, w, pix, q);
         const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
+        if (masked) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gz[i] = z[i] > 0.f ? gz[i] : gz[i] * neg;
+        }
         const f32x4 r = rstd * (gz - m1 - z * m2);
-        st4(dp, r);
+        st4(db + off, r);
         st4_twin(p.dy16 ? p.dy16 + size_t(b) * p.d_img + p.d_org : nullptr, off, r);
     }
 }
