@@ -323,6 +323,20 @@ typedef struct {
 int64_t nirgan_ssim_loss_ws_elems(int planes, int H, int W, int window);
 int nirgan_ssim_loss(const nirgan_ssim_loss_desc* d, void* stream);
 
+/* emd_loss of utils/losses.py:64-78, value and gradient wrt pred: mean | cumsum(softmax(pred.reshape(B,-1),1),1) -
+ * cumsum(softmax(target.reshape(B,-1),1),1) | over the B*N elements; scans in double (as torch's CPU cumsum accumulates).
+ * *loss += weight * emd (atomic; NULL = skip), *value = emd (NULL = skip), grad_pred += weight * d emd / d pred (NULL = value only). */
+typedef struct {
+    const float* pred; const float* target;  /* dense [B][N] */
+    int B; int64_t N;                        /* N = C*H*W < 2^24 */
+    float weight;
+    void* ws; int64_t ws_bytes;              /* nirgan_emd_loss_ws_bytes(B, N, grad_pred != NULL), 8-byte aligned */
+    float* loss; float* value; float* grad_pred;
+} nirgan_emd_loss_desc;
+
+int64_t nirgan_emd_loss_ws_bytes(int B, int64_t N, int with_grad);
+int nirgan_emd_loss(const nirgan_emd_loss_desc* d, void* stream);
+
 /* -------------------------------------------------------------------------------------
  * SatCLIP location encoder, fp64 like the reference (model/satclip/load_lightweight.py:29,
  * satclip_wrapper.py:30-35; called from model/pix2pix.py:481-484 once per batch):

@@ -108,6 +108,11 @@ class SsimLossDesc(C.Structure):
                 ("eps", f32), ("weight", f32), ("ws", fp), ("ws_elems", i64), ("loss", fp), ("value", fp), ("grad_pred", fp)]
 
 
+class EmdLossDesc(C.Structure):
+    _fields_ = [("pred", fp), ("target", fp), ("B", i32), ("N", i64), ("weight", f32), ("ws", fp), ("ws_bytes", i64),
+                ("loss", fp), ("value", fp), ("grad_pred", fp)]
+
+
 class LocEncDesc(C.Structure):
     _fields_ = [("lonlat", fp), ("B", i32), ("L", i32), ("sh_norm", fp), ("nlayers", i32),
                 ("weights", C.POINTER(fp)), ("biases", C.POINTER(fp)), ("dims", C.POINTER(i32)),
@@ -162,6 +167,8 @@ PROTOTYPES = {
     "nirgan_image_metrics": (i32, [C.POINTER(MetricsDesc), fp]),
     "nirgan_ssim_loss_ws_elems": (i64, [i32, i32, i32, i32]),
     "nirgan_ssim_loss": (i32, [C.POINTER(SsimLossDesc), fp]),
+    "nirgan_emd_loss_ws_bytes": (i64, [i32, i64, i32]),
+    "nirgan_emd_loss": (i32, [C.POINTER(EmdLossDesc), fp]),
     "nirgan_instnorm_ws_elems": (i64, [i32, i32, i32, i32]),
     "nirgan_instnorm_fwd": (i32, [C.POINTER(InFwdDesc), fp]),
     "nirgan_instnorm_bwd": (i32, [C.POINTER(InBwdDesc), fp]),

@@ -4,8 +4,9 @@
 (utils/losses.py:10-30), value AND gradient wrt ``img1`` on the device (csrc/ssimloss.hip, nirgan_ssim_loss): the term
 model/pix2pix.py:233-237 adds to the generator objective when ``lambda_ssim > 0`` (0.0 in the shipped configs).
 Only ``img1`` (the prediction) may require grad -- the reference differentiates it wrt ``pred`` alone (``nir`` is data).
-``emd_loss`` (softmax + cumsum over H*W, :64-78) is dead code in the reference (training_step calls an undefined
-``hist_loss`` when ``lambda_hist > 0``, pix2pix.py:239-243) and is not on the MI355X path.
+``emd_loss(pred, target)`` (softmax + cumsum over C*H*W per sample, mean absolute CDF difference, :64-78) likewise: value and
+gradient wrt ``pred`` (csrc/emdloss.hip, nirgan_emd_loss; scans in double).  The reference's training step never reaches it
+(``lambda_hist > 0`` calls an undefined ``hist_loss``, pix2pix.py:239-243), so it is a library function here too.
 """
 import ctypes as C
 
@@ -58,6 +59,46 @@ def ssim_loss(img1, img2, window_size=11):
     return _ssim_loss_device(img1, img2, int(window_size), want_grad=False)[0]
 
 
+def _emd_loss_device(pred: torch.Tensor, target: torch.Tensor, want_grad: bool):
+    if pred.shape != target.shape or pred.dim() < 2:
+        raise ValueError(f"emd_loss needs equal-shaped [B, ...] tensors, got {tuple(pred.shape)} and {tuple(target.shape)}")
+    if pred.device != target.device or (pred.device.type != "cuda" and not L.is_emulated()):
+        raise RuntimeError("nirgan_hip runs on MI355X (cuda device) only; there is no CPU path")
+    p = pred.detach().to(torch.float32).contiguous()
+    t = target.detach().to(torch.float32).contiguous()
+    # the reference asserts finiteness on the host (utils/losses.py:66-69): same contract, one fused check
+    assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(t).all())
+    B, N = p.shape[0], p[0].numel()
+    be = L.backend()
+    ws = torch.empty((int(be.nirgan_emd_loss_ws_bytes(B, N, 1 if want_grad else 0)) + 7) // 8, dtype=torch.float64, device=p.device)
+    value = torch.zeros(1, dtype=torch.float32, device=p.device)
+    grad = torch.zeros_like(p) if want_grad else None
+    d = L.EmdLossDesc()
+    d.pred, d.target, d.B, d.N, d.weight = p.data_ptr(), t.data_ptr(), B, N, 1.0
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 8
+    d.loss, d.value, d.grad_pred = None, value.data_ptr(), (grad.data_ptr() if want_grad else None)
+    st = torch.cuda.current_stream(p.device).cuda_stream if p.device.type == "cuda" else None
+    L.check(be.nirgan_emd_loss(C.byref(d), st), "emd_loss")
+    return value.reshape(()), grad
+
+
+class _EmdLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        value, grad = _emd_loss_device(pred, target, want_grad=True)
+        ctx.save_for_backward(grad)
+        ctx.dtype = pred.dtype
+        return value
+
+    @staticmethod
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return (gout * grad).to(ctx.dtype), None
+
+
 def emd_loss(pred, target):
-    raise NotImplementedError("emd_loss (lambda_hist) is not on the MI355X path: the reference's training step calls an undefined "
-                              "hist_loss for it (model/pix2pix.py:239-243), 0.0 in every shipped config")
+    if target.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("emd_loss differentiates wrt pred only")
+    if pred.requires_grad and torch.is_grad_enabled():
+        return _EmdLoss.apply(pred, target)
+    return _emd_loss_device(pred, target, want_grad=False)[0]

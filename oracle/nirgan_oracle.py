@@ -446,6 +446,12 @@ def ssim_loss(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11) -> 
     return 1.0 - ssim_map(img1.float(), img2.float(), window_size).mean()
 
 
+def emd_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """utils/losses.py:64-78."""
+    pred, target = pred.reshape(pred.shape[0], -1), target.reshape(target.shape[0], -1)
+    return torch.mean(torch.abs(torch.cumsum(F.softmax(pred, dim=1), dim=1) - torch.cumsum(F.softmax(target, dim=1), dim=1)))
+
+
 def g_step_loss(pD: Params, rgb, nir, pred, lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0,
                 rs_weights: Optional[dict] = None, rs_criterion: str = "l1", lambda_ssim: float = 0.0) -> Tuple[torch.Tensor, dict]:
     """optimizer_idx 1 (pix2pix.py:215-257)."""

@@ -517,6 +517,31 @@ class EmuBackend:
             arr(d.grad_pred, n)[:] += (d.weight * g).reshape(-1).numpy().astype(np.float32)
         return 0
 
+    # ------------------------------------------------------------------ emd_loss (softmax -> cumsum -> mean |difference|)
+    def nirgan_emd_loss_ws_bytes(self, B, N, with_grad):
+        return 0 if B <= 0 or N <= 0 else B * 8 + (B * N * 4 if with_grad else 0)
+
+    def nirgan_emd_loss(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("emd_loss")
+        if d.B <= 0 or d.N <= 0 or d.N >= 1 << 24:
+            return self._fail("emd_loss: out of range")
+        if d.ws_bytes < self.nirgan_emd_loss_ws_bytes(d.B, d.N, bool(d.grad_pred)):
+            return self._fail("emd_loss: workspace too small")
+        n = d.B * d.N
+        with torch.enable_grad():
+            a = torch.from_numpy(arr(d.pred, n).reshape(d.B, d.N).astype(np.float64)).requires_grad_(True)
+            b = torch.from_numpy(arr(d.target, n).reshape(d.B, d.N).astype(np.float64))
+            v = (torch.cumsum(torch.softmax(a, 1), 1) - torch.cumsum(torch.softmax(b, 1), 1)).abs().mean()
+            g = torch.autograd.grad(v, a)[0] if d.grad_pred else None
+        if d.value:
+            arr(d.value, 1)[0] = v.item()
+        if d.loss:
+            arr(d.loss, 1)[0] += d.weight * v.item()
+        if d.grad_pred:
+            arr(d.grad_pred, n)[:] += (d.weight * g).reshape(-1).numpy().astype(np.float32)
+        return 0
+
     # ------------------------------------------------------------------ instance norm
     def nirgan_instnorm_ws_elems(self, B, H, W, Cc):
         return B * _in_nchunk(B, H * W, Cc) * 2 * Cc + B * 2 * Cc

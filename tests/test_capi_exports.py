@@ -28,6 +28,8 @@ def test_descriptor_validation_rejects_bad_arguments_without_launching():
     be = L.backend()
     assert be.nirgan_image_metrics(L.MetricsDesc(), None) == -1 and b"image_metrics" in be.nirgan_last_error()
     assert be.nirgan_image_metrics_ws_elems(2, 256, 256) == 2 * 8 * 8 * 3
+    assert be.nirgan_emd_loss(L.EmdLossDesc(), None) == -1 and b"emd_loss" in be.nirgan_last_error()
+    assert be.nirgan_emd_loss_ws_bytes(3, 1000, 1) == 3 * 8 + 3 * 1000 * 4 and be.nirgan_emd_loss_ws_bytes(3, 1000, 0) == 24
     assert be.nirgan_ssim_loss(L.SsimLossDesc(), None) == -1 and b"ssim_loss" in be.nirgan_last_error()
     assert be.nirgan_ssim_loss_ws_elems(2, 64, 32, 11) == 3 * 2 * 64 * 32 + 3 * 2 * 74 * 42 + 2 * 2 * 1 and be.nirgan_ssim_loss_ws_elems(2, 64, 32, 4) == 0
     assert be.nirgan_location_encoder(L.LocEncDesc(), None) == -1 and b"location_encoder" in be.nirgan_last_error()
@@ -48,7 +50,7 @@ def test_struct_layouts_match_the_header(tmp_path):
              ("nirgan_pix_loss_desc", L.PixLossDesc, "grad_pred"), ("nirgan_inject_fwd_desc", L.InjectFwdDesc, "o_pad"),
              ("nirgan_inject_bwd_desc", L.InjectBwdDesc, "dscale"), ("nirgan_plan_entry", L.PlanEntry, "desc"),
              ("nirgan_metrics_desc", L.MetricsDesc, "means"), ("nirgan_locenc_desc", L.LocEncDesc, "features"),
-             ("nirgan_hist_match_desc", L.HistMatchDesc, "out"), ("nirgan_ssim_loss_desc", L.SsimLossDesc, "grad_pred"),
+             ("nirgan_hist_match_desc", L.HistMatchDesc, "out"), ("nirgan_ssim_loss_desc", L.SsimLossDesc, "grad_pred"), ("nirgan_emd_loss_desc", L.EmdLossDesc, "grad_pred"),
              ("nirgan_wino_desc", L.WinoDesc, "r"),
              ("nirgan_wino_dy_desc", L.WinoDyDesc, "r")]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "nirgan_hip.h"\nint main(void){\n'

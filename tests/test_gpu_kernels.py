@@ -365,6 +365,29 @@ def test_ssim_loss_value_and_gradient(shape, window):
     close(ssim_loss(pd, td, window).cpu(), ref_v.detach().float(), 2e-5, "value-only call")
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 40, 50), (16, 1, 256, 256), (3, 2, 33, 31), (1, 1, 3, 5)])
+def test_emd_loss_value_and_gradient(shape):
+    """nirgan_emd_loss (utils/losses.py:64-78) against the oracle's restatement: value in float32 as the reference evaluates it, gradient
+    wrt the prediction against autograd in float64 (sign of the CDF difference -> suffix sums -> softmax backward)."""
+    import nirgan_oracle as O
+    from utils.losses import emd_loss
+    g = torch.Generator().manual_seed(8)
+    pred = torch.rand(*shape, generator=g)
+    target = (pred + 0.2 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    ref_v = O.emd_loss(pred, target)
+    p64 = pred.double().requires_grad_(True)
+    ref_g, = torch.autograd.grad(O.emd_loss(p64, target.double()), p64)
+    pd, td = pred.to(DEV), target.to(DEV)
+    close(emd_loss(pd, td).cpu(), ref_v, 1e-3, "emd value")     # float32 CDFs (ulp 6e-8 near 1) against differences of ~3e-4: the reference's own float evaluation is this noisy
+    pa = pd.clone().requires_grad_(True)
+    (3.0 * emd_loss(pa, td)).backward()
+    # a CDF difference within float rounding of 0 flips its sign term: compare in L2 (a flip moves every earlier suffix sum by 2 of up to N)
+    e = (pa.grad.cpu() - 3.0 * ref_g.float()).norm() / (3.0 * ref_g.float()).norm()
+    assert e < 1e-3, f"emd gradient: rel L2 {e:.3e}"
+    again = emd_loss(pd, td).cpu()
+    assert torch.equal(again, emd_loss(pd, td).cpu())
+
+
 def test_location_encoder_kernel(golden_dir, tmp_path):
     """nirgan_location_encoder (fp64) against the reference's closed-form harmonics (fixture f6) and the oracle's
     Siren restatement; a SatCLIP-sized encoder (L = 10 -> 512 -> 512 -> 256, B = 32) against the oracle."""

@@ -485,8 +485,13 @@ def test_calculate_metrics_surface(emu):
     close(p1.grad, p2.grad, 1e-5, "ssim_loss gradient")
     with pytest.raises(NotImplementedError):
         ssim_loss(pred, target.clone().requires_grad_(True))
+    close(emd_loss(pred, target), O.emd_loss(pred, target), 5e-4, "emd_loss")      # float32 CDFs near 1.0 carry 6e-8, their differences are ~6e-4
+    e1, e2 = pred.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+    (5.0 * emd_loss(e1, target)).backward()
+    (5.0 * O.emd_loss(e2.double(), target.double())).backward()
+    close(e1.grad, e2.grad, 1e-4, "emd_loss gradient")
     with pytest.raises(NotImplementedError):
-        emd_loss(pred, target)
+        emd_loss(pred, target.clone().requires_grad_(True))
     with pytest.raises(ValueError):
         image_metrics_device(pred, target[:, :, :-1])
     with pytest.raises(RuntimeError):
