@@ -83,7 +83,7 @@ struct ConvParams {
 // fragment read -- same values): B rows are 64 B per K-step, one ds_read_b128 is one MFMA operand, 25 % fewer bytes and
 // LDS-DMA pieces per K-step.  64-byte rows: a wave-instruction lands 16 rows, the chunk swizzle is chunk ^ ((row>>2)&3).
 // AB16 (with WB16): the activations come from a producer's bf16 twin as well -- both operands are read as stored, no
-// conversion in the K loop, half the bytes and LDS-DMA pieces per K-step.
+// conversion in the K loop; the 128-byte staging rows then hold 64 k, so a K-step contracts 64 k (half the barriers per product).
 template <int BN, int PREC, bool WB16 = false, bool AB16 = false>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* st0, char* st1) {
     static_assert(!WB16 || PREC == 1, "bf16-stored weights are consumed by the bf16 operand mode only");
@@ -94,6 +94,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int NT = BN / 64;   // 32-column MFMA tiles per wave
     constexpr int BI = BN / 32;   // B loader instructions per wave (8 rows each)
+    // AB16: both operands are bf16 in memory -> the 128-byte staging rows of the fp32 geometry hold 64 k each: a K-step of 64
+    // (half the barriers and DMA waits per product of the 32-k steps the fp32-fed paths take)
+    constexpr bool WIDE = AB16;
+    constexpr int KS = WIDE ? 64 : 32;            // k per K-step
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,12 +109,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     // ---------------- loader state: each lane owns one 16-byte chunk of 4 A rows and BI B rows (fp32 rows of 128 B, 8 per
     // wave-instruction); bf16 rows are 64 B, 16 per wave-instruction
     const int lrow = lane >> 3, lchunk = lane & 7;
-    constexpr int AIW = AB16 ? 2 : 4;            // A loader instructions per wave
+    constexpr int AIW = 4;                       // A loader instructions per wave
     int a_base[AIW], a_col[AIW];
 #pragma unroll
     for (int i = 0; i < AIW; ++i) {
-        const int row = AB16 ? (wave * 2 + i) * 16 + (lane >> 2) : (wave * 4 + i) * 8 + lrow;
-        const int lc = AB16 ? ((lane & 3) ^ ((row >> 2) & 3)) : (lchunk ^ ((row >> 1) & 7));
+        const int row = (wave * 4 + i) * 8 + lrow;
+        const int lc = lchunk ^ ((row >> 1) & 7);
         const int cw = AB16 ? 8 : 4;             // elements per 16-byte chunk
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
@@ -119,12 +123,19 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         a_col[i] = lc * cw;
         a_base[i] = b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + lc * cw;
     }
-    constexpr int BIW = WB16 ? BN / 64 : BI;     // B loader instructions per wave (16 rows of 64 B each when WB16)
+    constexpr int BIW = (WB16 && !WIDE) ? BN / 64 : BI;     // B loader instructions per wave (16 rows of 64 B each for bf16 weights under fp32 activations)
     int b_base[BIW], b_col[BIW];
     bool b_ok[BIW];
 #pragma unroll
     for (int i = 0; i < BIW; ++i) {
-        if constexpr (WB16) {
+        if constexpr (WIDE) {
+            const int row = (wave * BI + i) * 8 + lrow;
+            const int lc = lchunk ^ ((row >> 1) & 7);
+            const int n = n0 + row;
+            b_ok[i] = n < p.N;
+            b_col[i] = lc * 8;                                   // in bf16 elements
+            b_base[i] = (b_ok[i] ? n : 0) * p.K + lc * 8;
+        } else if constexpr (WB16) {
             const int row = (wave * BIW + i) * 16 + (lane >> 2);
             const int lc = (lane & 3) ^ ((row >> 2) & 3);
             const int n = n0 + row;
@@ -150,7 +161,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
             if constexpr (AB16) {
                 const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p.in);
                 const float* src = ok ? reinterpret_cast<const float*>(in16 + (a_base[i] + toff)) : p.zero;
-                ng_glds16(src, sA + (wave * 2 + i) * 1024);
+                ng_glds16(src, sA + (wave * 4 + i) * 1024);
             } else {
                 const float* src = ok ? p.in + (a_base[i] + toff) : p.zero;
                 ng_glds16(src, sA + (wave * 4 + i) * 1024);
@@ -160,7 +171,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 #pragma unroll
         for (int i = 0; i < BIW; ++i) {
             const bool ok = b_ok[i] && c0 + b_col[i] < p.run;
-            if constexpr (WB16) {
+            if constexpr (WB16) {                                   // (wide or narrow rows: BIW pieces of 1 KB per wave either way)
                 const unsigned short* w16 = reinterpret_cast<const unsigned short*>(p.w);
                 const float* src = ok ? reinterpret_cast<const float*>(w16 + (b_base[i] + woff)) : p.zero;
                 ng_glds16(src, sB + (wave * BIW + i) * 1024);
@@ -178,14 +189,14 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int row = wr * 64 + mt * 32 + (lane & 31);
-        a_off[mt] = row * (AB16 ? 64 : 128);
-        a_key[mt] = AB16 ? (row >> 2) & 3 : (row >> 1) & 7;
+        a_off[mt] = row * 128;
+        a_key[mt] = (row >> 1) & 7;
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int row = wc * (BN / 2) + nt * 32 + (lane & 31);
-        b_off[nt] = row * (WB16 ? 64 : 128);
-        b_key[nt] = WB16 ? (row >> 2) & 3 : (row >> 1) & 7;
+        b_off[nt] = row * ((WB16 && !WIDE) ? 64 : 128);
+        b_key[nt] = (WB16 && !WIDE) ? (row >> 2) & 3 : (row >> 1) & 7;
     }
     f32x16 acc[2][NT];
 #pragma unroll
@@ -222,22 +233,41 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][mt][j], b[g & 1][nt][j], acc[mt][nt], 0, 0, 0);
             }
+        } else if constexpr (WIDE) {
+            // both operands stored as bf16, 128-byte rows = 64 k: group h contracts k 16h .. 16h+15, lanes 0-31 take the 16-byte
+            // chunk 2h of their row, lanes 32-63 chunk 2h+1; fragments of group h+1 are read under the MFMAs of group h
+            bf16x8 aw[2][2], bw[2][NT];
+            auto load = [&](int h, int slot) {
+                const int chunk = 2 * h + half;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    aw[slot][mt] = *reinterpret_cast<const bf16x8*>(sA + a_off[mt] + ((chunk ^ a_key[mt]) << 4));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bw[slot][nt] = *reinterpret_cast<const bf16x8*>(sB + b_off[nt] + ((chunk ^ b_key[nt]) << 4));
+            };
+            load(0, 0);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (h + 1 < 4) load(h + 1, (h + 1) & 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[h & 1][mt], bw[h & 1][nt], acc[mt][nt], 0, 0, 0);
+            }
         } else {
             // bf16 pipe: one MFMA contracts 16 k = the chunks 4h..4h+3 of the 32-float slice; lanes 0-31 hold the 8 k of
             // chunks 4h, 4h+1 of their row, lanes 32-63 those of chunks 4h+2, 4h+3 (same assignment for A and B)
             f32x8 a[2][2], b[2][NT];
-            bf16x8 aw[2][2], bw[2][NT];
+            bf16x8 bw[2][NT];
             auto load = [&](int h, int slot) {
                 const int c0 = 4 * h + 2 * half;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    if constexpr (AB16) {
-                        aw[slot][mt] = *reinterpret_cast<const bf16x8*>(sA + a_off[mt] + (((2 * h + half) ^ a_key[mt]) << 4));
-                    } else {
-                        const f32x4 lo = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + ((c0 ^ a_key[mt]) << 4));
-                        const f32x4 hi = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + (((c0 + 1) ^ a_key[mt]) << 4));
-                        a[slot][mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + ((c0 ^ a_key[mt]) << 4));
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(sA + a_off[mt] + (((c0 + 1) ^ a_key[mt]) << 4));
+                    a[slot][mt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -263,8 +293,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        if constexpr (AB16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[slot][mt], bw[slot][nt], acc[mt][nt], 0, 0, 0);
-                        else if constexpr (WB16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ng_bf16_round(a[slot][mt]), bw[slot][nt], acc[mt][nt], 0, 0, 0);
+                        if constexpr (WB16) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ng_bf16_round(a[slot][mt]), bw[slot][nt], acc[mt][nt], 0, 0, 0);
                         else ng_mfma_bf16<PREC>(a[slot][mt], b[slot][nt], acc[mt][nt]);
                     }
                 if (!PF && h + 1 < 2) load(h + 1, 0);
@@ -273,12 +302,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     };
 
     // ---------------- main loop: K-steps enumerate (tap, 32-float slice of the run)
-    const int csteps = (p.run + 31) >> 5;
+    const int csteps = (p.run + KS - 1) / KS;
     const int nk_all = p.ntaps * csteps;
     const int per = (nk_all + p.ksplit - 1) / p.ksplit;
     const int ks0 = ksp * per;
     const int nk = (ks0 + per < nk_all ? per : nk_all - ks0);      // > 0: the host never over-splits
-    int t = ks0 / csteps, c0 = (ks0 - t * csteps) * 32;
+    int t = ks0 / csteps, c0 = (ks0 - t * csteps) * KS;
     // steady state: the LDS-DMA of step s+1 and its address arithmetic are issued BETWEEN the MFMAs of step s.
     // The two stages are distinct LDS objects and the loop is unrolled by two, so the compiler knows the DMA
     // writes do not alias the fragment reads and can interleave them; the sched_group_barrier sequence asks for
@@ -300,7 +329,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         }
     };
     auto next = [&](int& tt, int& cc) {
-        cc += 32;
+        cc += KS;
         if (cc >= p.run) { cc = 0; ++tt; }
     };
     NG_DIAG_DECL
@@ -685,7 +714,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void wgrad_tile16(const WgradParams& p, const int block_id, char* st0, char* st1) {
     constexpr int TN = 128;
-    constexpr int P_BYTES = 32 * 256;
+    constexpr int MS = 64;                     // pixel rows per K-step (a K-step of 64: half the barriers of the 32-row steps the fp32 tile takes)
+    constexpr int P_BYTES = MS * 256;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -696,11 +726,11 @@ __device__ __forceinline__ void wgrad_tile16(const WgradParams& p, const int blo
     const int mstart = split * p.rows_per_split;
     int mend = mstart + p.rows_per_split;
     mend = mend < p.M ? mend : p.M;
-    const int nk = mend > mstart ? (mend - mstart + 31) >> 5 : 0;
+    const int nk = mend > mstart ? (mend - mstart + MS - 1) / MS : 0;
     const unsigned short* P16 = reinterpret_cast<const unsigned short*>(p.p);
     const unsigned short* Q16 = reinterpret_cast<const unsigned short*>(p.q);
 
-    // ---------------- loader state: wave w owns pieces 2w, 2w+1 of each image (rows 8w .. 8w+7)
+    // ---------------- loader state: wave w owns pieces 4w .. 4w+3 of each image (rows 16w .. 16w+15)
     const int lrow = lane >> 4, pch = lane & 15;
     struct Pix { int b, oh, ow; };
     auto decompose = [&](int m) {
@@ -712,16 +742,17 @@ __device__ __forceinline__ void wgrad_tile16(const WgradParams& p, const int blo
         return x;
     };
     auto advance = [&](Pix& x) {
-        x.ow += 32;
+        x.ow += MS;
         while (x.ow >= p.OW) { x.ow -= p.OW; ++x.oh; }
         while (x.oh >= p.OH) { x.oh -= p.OH; ++x.b; }
     };
-    Pix px[2];
-    int p_n[2], q_add[2];
-    bool p_ok[2], q_ok[2];
+    constexpr int PI = MS / 16;                // loader instructions per wave and image
+    Pix px[PI];
+    int p_n[PI], q_add[PI];
+    bool p_ok[PI], q_ok[PI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 4 + lrow;
+    for (int i = 0; i < PI; ++i) {
+        const int row = (wave * PI + i) * 4 + lrow;
         const int lc = pch ^ (((row & 3) << 2) | ((row >> 2) & 3));      // logical chunk (8 elements) this lane fetches
         px[i] = decompose(mstart + row);
         p_ok[i] = n0 + lc * 8 < p.N;
@@ -737,8 +768,8 @@ __device__ __forceinline__ void wgrad_tile16(const WgradParams& p, const int blo
     auto issue = [&](char* sP, int mb) {
         char* sQ = sP + P_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ins = wave * 2 + i;
+        for (int i = 0; i < PI; ++i) {
+            const int ins = wave * PI + i;
             const int m = mb + ins * 4 + lrow;
             const unsigned short* sp = P16 + (px[i].b * p.p_img + px[i].oh * p.p_row + px[i].ow * p.p_cs + p.p_org + p_n[i]);
             const float* src = (p_ok[i] && m < mend) ? reinterpret_cast<const float*>(sp) : p.zero;
@@ -786,7 +817,7 @@ __device__ __forceinline__ void wgrad_tile16(const WgradParams& p, const int blo
     auto compute = [&](const char* sP) {
         const char* sQ = sP + P_BYTES;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < MS / 16; ++h) {
             bf16x8 a[2], b[2];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -806,17 +837,17 @@ __device__ __forceinline__ void wgrad_tile16(const WgradParams& p, const int blo
         for (; s + 2 < nk; s += 2) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            issue(st1, mstart + (s + 1) * 32);
+            issue(st1, mstart + (s + 1) * MS);
             compute(st0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            issue(st0, mstart + (s + 2) * 32);
+            issue(st0, mstart + (s + 2) * MS);
             compute(st1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (s + 1 < nk) {
-            issue(st1, mstart + (s + 1) * 32);
+            issue(st1, mstart + (s + 1) * MS);
             compute(st0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
