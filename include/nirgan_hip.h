@@ -405,6 +405,9 @@ int64_t nirgan_wino_ws_elems_r(int B, int H, int W, int C, int K, int r);
 int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);
 /* the same for an r x r filter (r = 3 or 4; w = [K][C][r][r], U = [(r+1)^2][K][C]) */
 int nirgan_wino_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream);
+/* all weight transforms of a step in ONE launch: jobs_device = njobs x 8 int64 {w, U, K, C, r, transpose_flip, first_block, 0} in device
+ * memory, first_block = running sum of ceil(K*C/256) over the preceding jobs, total_blocks = the sum over all jobs */
+int nirgan_wino_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
 int nirgan_wino_input(const nirgan_wino_desc* d, void* stream);     /* V = B^T d B from x */
 int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream);      /* y from V and U (frequency-folding GEMM + bias) */
 int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);   /* both */

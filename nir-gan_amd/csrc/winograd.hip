@@ -15,8 +15,7 @@ namespace {
 struct WinoW { const float* w; float* U; int K, C, flip; };
 
 // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-__global__ __launch_bounds__(256) void wino_weight_kernel(const WinoW p) {
-    const long long i = blockIdx.x * 256ll + threadIdx.x;
+__device__ __forceinline__ void wino_weight_one(const WinoW& p, const long long i) {
     if (i >= (long long)p.K * p.C) return;
     const int k = int(i / p.C), c = int(i - (long long)k * p.C);
     // flip: the data-gradient filter g'[k][c][i][j] = W[c][k][2-i][2-j] (W stored [C][K][3][3]: rows are the forward OUTPUT channels)
@@ -41,6 +40,8 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const WinoW p) {
         U[(a * 4 + 3) * plane] = u3;
     }
 }
+
+__global__ __launch_bounds__(256) void wino_weight_kernel(const WinoW p) { wino_weight_one(p, blockIdx.x * 256ll + threadIdx.x); }
 
 struct WinoIn { const float* x; float* V; int B, H, W, C, x_row, x_img, TH, TW; long long T; };
 
@@ -184,8 +185,7 @@ __device__ __forceinline__ void wmac(T& acc, const float c, const T& x) {
     else acc += c * x;
 }
 
-__global__ __launch_bounds__(256) void wino4_weight_kernel(const WinoW p) {
-    const long long i = blockIdx.x * 256ll + threadIdx.x;
+__device__ __forceinline__ void wino4_weight_one(const WinoW& p, const long long i) {
     if (i >= (long long)p.K * p.C) return;
     const int k = int(i / p.C), c = int(i - (long long)k * p.C);
     // flip: the data-gradient filter g'[k][c][i][j] = W[c][k][3-i][3-j]
@@ -216,6 +216,19 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const WinoW p) {
             for (int r = 0; r < 4; ++r) wmac(s, w4_G(b, r), t[a][r]);
             U[(a * 5 + b) * plane] = s;
         }
+}
+
+__global__ __launch_bounds__(256) void wino4_weight_kernel(const WinoW p) { wino4_weight_one(p, blockIdx.x * 256ll + threadIdx.x); }
+
+// every weight transform of a plan in one launch: jobs in device memory (8 x int64 each): w, U, K, C, r, transpose_flip, first_block, 0
+__global__ __launch_bounds__(256) void wino_weights_batch_kernel(const long long* __restrict__ jobs, int njobs) {
+    int j = 0;
+    for (int i = 1; i < njobs; ++i)
+        if (int(blockIdx.x) >= int(jobs[i * 8 + 6])) j = i;
+    const long long* J = jobs + j * 8;
+    const WinoW p{reinterpret_cast<const float*>(J[0]), reinterpret_cast<float*>(J[1]), int(J[2]), int(J[3]), int(J[5])};
+    const long long i = (long long)(int(blockIdx.x) - int(J[6])) * 256 + threadIdx.x;
+    if (J[4] == 4) wino4_weight_one(p, i); else wino_weight_one(p, i);
 }
 
 // one thread = one 5x5 tile x 4 channels; the buffer holds (H+3) x (W+3) pixels for H x W outputs
@@ -379,6 +392,13 @@ extern "C" int nirgan_wino_weights_r(const float* w, int K, int C, int r, int tr
 
 extern "C" int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream) {
     return nirgan_wino_weights_r(w, K, C, 3, transpose_flip, U, stream);
+}
+
+extern "C" int nirgan_wino_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream) {
+    NG_REQUIRE(jobs_device && njobs >= 1 && njobs <= 256 && total_blocks >= 1, "wino_weights_batch: bad arguments");
+    hipLaunchKernelGGL(wino_weights_batch_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(jobs_device), njobs);
+    return nirgan_check_launch("wino_weights_batch");
 }
 
 static int wino_check(const nirgan_wino_desc* d) {

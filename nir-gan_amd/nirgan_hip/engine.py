@@ -129,6 +129,20 @@ class Plan:
         self.ops = [(n, a) for n, a in self.ops if n not in ("nirgan_pack_rows", "nirgan_pack_rows_bf16")]
         self.ops.append(("nirgan_pack_rows_batch", (table.data_ptr(), len(rows), first)))
 
+    def fuse_wino_weights(self):
+        """The same for the Winograd weight transforms (two per residual-block convolution and step: forward and flipped filter)."""
+        jobs = [a for n, a in self.ops if n == "nirgan_wino_weights_r"]
+        if len(jobs) < 2 or len(jobs) > 256:
+            return
+        rows, first = [], 0
+        for w, K, Cc, r, flip, U in jobs:
+            rows.append([w, U, K, Cc, r, flip, first, 0])
+            first += (K * Cc + 255) // 256
+        table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
+        self.ctx.keep.append(table)
+        self.ops = [(n, a) for n, a in self.ops if n != "nirgan_wino_weights_r"]
+        self.ops.append(("nirgan_wino_weights_batch", (table.data_ptr(), len(rows), first)))
+
     def run(self):
         be = L.backend()
         st = self.ctx.stream()

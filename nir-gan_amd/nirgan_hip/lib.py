@@ -154,6 +154,7 @@ PROTOTYPES = {
     "nirgan_wino_weights": (i32, [fp, i32, i32, i32, fp, fp]),
     "nirgan_wino_ws_elems_r": (i64, [i32, i32, i32, i32, i32, i32]),
     "nirgan_wino_weights_r": (i32, [fp, i32, i32, i32, i32, fp, fp]),
+    "nirgan_wino_weights_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_wino_wgrad_finish_r": (i32, [fp, i32, i32, i32, i32, fp, i32, fp]),
     "nirgan_wino_input": (i32, [C.POINTER(WinoDesc), fp]),
     "nirgan_wino_gemm": (i32, [C.POINTER(WinoDesc), fp]),

@@ -38,8 +38,9 @@ class _Engine:
     def refresh_weights(self, version: int, backward: bool = False):
         """Re-pack weights when the parameters changed (version = optimizer step counter)."""
         if not getattr(self, "_packs_fused", False):
-            self.pack_fwd.fuse_packs()
-            self.pack_bwd.fuse_packs()
+            for pl in (self.pack_fwd, self.pack_bwd):
+                pl.fuse_packs()
+                pl.fuse_wino_weights()
             self._packs_fused = True
         if self._packed_version != version:
             self.pack_fwd.run()

@@ -335,6 +335,18 @@ class EmuBackend:
         arr(U, (r + 1) ** 2 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
         return 0
 
+    def nirgan_wino_weights_batch(self, jobs, njobs, total_blocks, stream=None):
+        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 8)).from_address(int(jobs))).reshape(njobs, 8)
+        blocks = 0
+        for w, U, K, Cc, r, flip, first, _ in J:
+            if first != blocks:
+                return self._fail("wino_weights_batch: first_block mismatch")
+            rc = self.nirgan_wino_weights_r(int(w), int(K), int(Cc), int(r), int(flip), int(U))
+            if rc:
+                return rc
+            blocks += (int(K) * int(Cc) + 255) // 256
+        return 0 if blocks == total_blocks else self._fail("wino_weights_batch: total_blocks mismatch")
+
     def _wino_tiles(self, d):
         r = self._r(d.r)
         a = r + 1
