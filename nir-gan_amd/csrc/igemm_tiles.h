@@ -210,6 +210,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     // buffer), so the LDS latency sits under 1024 MFMA cycles instead of in front of them
     auto compute = [&](const char* sA) {
         const char* sB = sA + A_BYTES;
+        // the MFMA block outranks the other workgroup's loader phase on the shared SIMD (measured: fused Winograd backward launch 0.675 ->
+        // 0.664 ms, bf16 step -1 %; the split mode's conversion-heavy block loses 2 % with it)
+        if constexpr (PREC != 2) __builtin_amdgcn_s_setprio(2);
         if constexpr (PREC == 0) {
             f32x4 a[2][2], b[2][NT];
             auto load = [&](int g, int slot) {
@@ -299,6 +302,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                 if (!PF && h + 1 < 2) load(h + 1, 0);
             }
         }
+        if constexpr (PREC != 2) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---------------- main loop: K-steps enumerate (tap, 32-float slice of the run)
@@ -561,6 +565,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
     // 4 pixel-pair steps per group: the 8 fragment reads of group g+1 are issued before the 16 MFMAs of group g
     auto compute = [&](const char* sP) {
         const char* sQ = sP + P_BYTES;
+        if constexpr (PREC != 2) __builtin_amdgcn_s_setprio(2);
         if constexpr (PREC == 0) {
             float a[2][4][EA];
             f32x2 b[2][4];
@@ -621,6 +626,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
                 if (!PF && q + 1 < 2) load(q + 1, 0);
             }
         }
+        if constexpr (PREC != 2) __builtin_amdgcn_s_setprio(0);
     };
 
     // same structure as conv_tile: two distinct LDS stage objects, loop unrolled by two, the LDS-DMA of the next

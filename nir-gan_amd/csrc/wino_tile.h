@@ -87,6 +87,7 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
     }
     auto compute = [&](const char* sA) {
         const char* sB = sA + A_BYTES;
+        __builtin_amdgcn_s_setprio(2);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int chunk = 2 * g + half;
@@ -99,6 +100,7 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) M[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[nt][j], M[nt], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
     };
     // fold the finished frequency f into the four outputs (coefficients 0, +-1; also -1/2, 1/4 for the 4x4 filter) and clear the product
     auto fold = [&](int f) {
