@@ -395,6 +395,10 @@ typedef struct {
     const float* zero_page;
     int r;                                /* filter size: 0 or 3 = F(2x2,3x3) above; 4 = F(2x2,4x4): nn.Conv2d(C, K, 4, stride 1) of the PatchGAN
                                              (model/networks.py:573-579), x is [B][H+3][W+3][C] for H x W outputs, 25 frequencies, U / V hold 25 planes */
+    int fsplit;                           /* nirgan_wino_gemm only, 0 / 1 = off: the frequencies are divided over fsplit workgroups per tile (few tiles:
+                                             the 16-image PatchGAN passes fill a quarter of the chip otherwise); partial outputs go to split_ws
+                                             ([fsplit][B*H*W*K] floats) and one pass adds them (+ bias) into y */
+    float* split_ws; int64_t split_ws_elems;
 } nirgan_wino_desc;
 
 int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K);   /* V elements + U elements */

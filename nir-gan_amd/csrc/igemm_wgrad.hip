@@ -204,6 +204,7 @@ extern "C" int nirgan_wino_wgrad_pair(const nirgan_wino_desc* c, const nirgan_wg
     ng::WinoG g;
     rc = ng_wino_gemm_params(c, &g);
     if (rc != NIRGAN_OK) return rc;
+    NG_REQUIRE(g.fsplit == 1, "wino_wgrad_pair: the fused launch takes unsplit Winograd tiles (fsplit=%d)", g.fsplit);
     const int wino_blocks = g.mtiles * g.ntiles;
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit * wp.nplanes;
     hipLaunchKernelGGL(wino_wgrad_pair_kernel, dim3(wino_blocks + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, wp, wino_blocks);

@@ -10,6 +10,8 @@ struct WinoG {
     int T, C, K, TH, TW, H, W;
     int mtiles, ntiles;
     int a;                       // frequencies per dimension: 4 = F(2x2,3x3), 5 = F(2x2,4x4)
+    int fsplit;                  // workgroups per tile, each over a contiguous range of the a*a frequencies (1 = all)
+    float* ws; long long ws_stride;   // fsplit > 1: partial outputs [split][B*H*W*K]
 };
 
 // coefficient of frequency f in output row `row` of A^T: [[1,1,1,0],[0,1,-1,-1]] for F(2,3), [[1,1,1,1,0],[0,1,-1,-1/2,1]] for F(2,4)
@@ -32,8 +34,12 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
     char* st1 = lds + STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int id = ng_xcd_remap(block_id, p.mtiles * p.ntiles);
+    const int tiles = p.mtiles * p.ntiles;
+    const int rid = ng_xcd_remap(block_id, tiles * p.fsplit);
+    const int sp = rid / tiles, id = rid - sp * tiles;
     const int n0 = (id % p.ntiles) * BN, m0 = (id / p.ntiles) * BM;
+    const int nf = p.a * p.a;
+    const int f_begin = sp * nf / p.fsplit, f_end = (sp + 1) * nf / p.fsplit;     // this workgroup's frequencies
 
     // ---------------- loader: wave w owns A pieces 2w, 2w+1 (8 tile rows each) and B pieces 4w .. 4w+3
     const int lrow = lane >> 3, lchunk = lane & 7;
@@ -122,14 +128,14 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
     };
 
     // ---------------- one K loop over (frequency, 32-channel slice); stage parity = step parity
-    const int nk = p.a * p.a * csteps;
-    int f_i = 0, c_i = 0;             // coordinates of the step being ISSUED
-    int f_c = 0, c_c = 0;             // coordinates of the step being COMPUTED
+    const int nk = (f_end - f_begin) * csteps;
+    int f_i = f_begin, c_i = 0;       // coordinates of the step being ISSUED
+    int f_c = f_begin, c_c = 0;       // coordinates of the step being COMPUTED
     auto next = [&](int& f, int& c) {
         c += 32;
         if (c >= p.C) { c = 0; ++f; }
     };
-    issue(st0, 0, 0);
+    issue(st0, f_begin, 0);
     for (int s = 0; s < nk; ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -148,10 +154,11 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
     const int chunk = tid & 31, row0 = tid >> 5;             // 32 lanes x float4 per tile row, 8 rows per pass
     const int n = n0 + chunk * 4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) {
+    if (p.bias != nullptr && p.fsplit == 1) {               // split: the reduce pass adds the bias
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = n + j < p.K ? p.bias[n + j] : 0.f;
     }
+    float* ybase = p.fsplit == 1 ? p.y : p.ws + sp * p.ws_stride;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         __syncthreads();                                    // K loop / previous round done with the buffer
@@ -172,7 +179,7 @@ __device__ __forceinline__ void wino_tile(const WinoG& p, const int block_id, ch
                 f32x4 v = *reinterpret_cast<const f32x4*>(buf + row * BN + chunk * 4);
                 v += bv;
                 if (2 * ty + oa >= p.H || 2 * tx + ob >= p.W) continue;        // odd extent: the last half tile has no pixel there
-                float* dst = p.y + ((size_t(b) * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.K + n;
+                float* dst = ybase + ((size_t(b) * p.H + 2 * ty + oa) * p.W + 2 * tx + ob) * p.K + n;
                 if (n + 4 <= p.K) {
                     *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
@@ -193,6 +200,8 @@ inline void build_wino_params(const nirgan_wino_desc* d, WinoG& g) {
     g.T = int(T); g.C = d->C; g.K = d->K; g.TH = (d->H + 1) / 2; g.TW = (d->W + 1) / 2; g.H = d->H; g.W = d->W;
     g.mtiles = int((T + 63) / 64); g.ntiles = d->K / 128;
     g.a = d->r == 4 ? 5 : 4;
+    g.fsplit = d->fsplit > 1 ? d->fsplit : 1;
+    g.ws = d->split_ws; g.ws_stride = (long long)d->B * d->H * d->W * d->K;
 }
 
 }  // namespace ng

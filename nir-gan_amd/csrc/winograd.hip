@@ -366,6 +366,17 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const ng::WinoG p) {
     ng::wino_tile(p, blockIdx.x, lds);
 }
 
+// y = sum over the frequency splits of the partial outputs (+ bias): float4 per thread, splits in order
+__global__ __launch_bounds__(256) void wino_split_reduce_kernel(const ng::WinoG p) {
+    const long long n4 = p.ws_stride / 4;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(p.ws + i * 4);
+        for (int k = 1; k < p.fsplit; ++k) s += *reinterpret_cast<const f32x4*>(p.ws + k * p.ws_stride + i * 4);
+        if (p.bias != nullptr) s += *reinterpret_cast<const f32x4*>(p.bias + (i * 4) % p.K);
+        *reinterpret_cast<f32x4*>(p.y + i * 4) = s;
+    }
+}
+
 }  // namespace
 
 static inline int wino_r(int r) { return r == 0 ? 3 : r; }
@@ -413,6 +424,11 @@ static int wino_check(const nirgan_wino_desc* d) {
     const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2), nf = (r + 1) * (r + 1);
     NG_REQUIRE(T < (1ll << 31) / d->C, "wino_conv: problem too large for 32-bit tile offsets");
     NG_REQUIRE(d->V_elems >= nf * T * d->C, "wino_conv: V workspace too small");
+    if (d->fsplit > 1) {
+        NG_REQUIRE(d->fsplit <= nf, "wino_conv: fsplit=%d exceeds the %lld frequencies", d->fsplit, nf);
+        NG_REQUIRE(d->split_ws && ng_aligned16(d->split_ws) && d->split_ws_elems >= (long long)d->fsplit * d->B * d->H * d->W * d->K,
+                   "wino_conv: split workspace missing or too small");
+    }
     return NIRGAN_OK;
 }
 
@@ -448,7 +464,12 @@ extern "C" int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream) {
     ng::WinoG g;
     const int rc = ng_wino_gemm_params(d, &g);
     if (rc != NIRGAN_OK) return rc;
-    hipLaunchKernelGGL(wino_gemm_kernel, dim3(g.mtiles * g.ntiles), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    hipLaunchKernelGGL(wino_gemm_kernel, dim3(g.mtiles * g.ntiles * g.fsplit), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    if (g.fsplit > 1) {
+        const long long n4 = g.ws_stride / 4;
+        const long long blocks = (n4 + 255) / 256;
+        hipLaunchKernelGGL(wino_split_reduce_kernel, dim3(unsigned(blocks < 8192 ? blocks : 8192)), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    }
     return nirgan_check_launch("wino_gemm");
 }
 

@@ -364,6 +364,14 @@ def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, b
     d.zero_page = ctx.zero_page.data_ptr()
     ctx.keep.append(d)
     if plan is not None:
+        # few tiles (the 16-image PatchGAN passes: 256 / 146 workgroups for 512 slots): divide the frequencies over 2-4 workgroups per tile
+        blocks = -(-T // 64) * (cout // 128)
+        fs = min(4, 512 // max(blocks, 1), nf // 4) if os.environ.get("NIRGAN_NO_WINO_FSPLIT") != "1" else 1
+        if blocks < 384 and fs > 1 and (B * H * W * cout) % 4 == 0 and cout % 4 == 0:
+            if not hasattr(ctx, "split_pool"):
+                ctx.split_pool = SplitPool(ctx)
+            ws = ctx.split_pool.get(fs * B * H * W * cout)
+            d.fsplit, d.split_ws, d.split_ws_elems = fs, ws.data_ptr(), ws.numel()
         plan.add("nirgan_wino_input", C.byref(d))
         plan.add("nirgan_wino_gemm", C.byref(d))
     return d

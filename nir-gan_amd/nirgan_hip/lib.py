@@ -125,7 +125,8 @@ class HistMatchDesc(C.Structure):
 
 class WinoDesc(C.Structure):
     _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
-                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32)]
+                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32), ("fsplit", i32),
+                ("split_ws", fp), ("split_ws_elems", i64)]
 
 
 class WinoDyDesc(C.Structure):

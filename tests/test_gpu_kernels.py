@@ -681,7 +681,7 @@ def _wino4_case(B, H, W, Cc, K, seed=23):
     return x, w, b, ref
 
 
-def _run_wino4(x, w, b, dev, be):
+def _run_wino4(x, w, b, dev, be, fsplit=0):
     import ctypes as C
     B, H, W, Cc, K = x.shape[0], x.shape[1] - 3, x.shape[2] - 3, x.shape[3], w.shape[0]
     xt, wt, bt = x.to(dev).contiguous(), w.to(dev).contiguous(), b.to(dev)
@@ -692,6 +692,9 @@ def _run_wino4(x, w, b, dev, be):
     d.r = 4
     d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = xt.data_ptr(), H + 3, W + 3, B, H, W, Cc, K
     d.U, d.bias, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), bt.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
+    if fsplit > 1:
+        ws = torch.full((fsplit * y.numel(),), float("nan"), device=dev)
+        d.fsplit, d.split_ws, d.split_ws_elems = fsplit, ws.data_ptr(), ws.numel()
     if be is None:
         st = torch.cuda.current_stream().cuda_stream
         L.call("nirgan_wino_weights_r", wt.data_ptr(), K, Cc, 4, 0, U.data_ptr(), st)
@@ -714,6 +717,9 @@ def test_winograd_conv4x4_matches_direct(shape):
     close(emu_y, ref, 1e-5, "restatement vs torch")
     close(dev_y, ref, 5e-5, "device vs torch")
     close(dev_y, emu_y, 5e-5, "device vs restatement")
+    # the frequencies divided over 3 / 25 workgroups per tile (launches with few tiles): partial outputs + one reduce pass
+    for fs in (3, 25):
+        close(_run_wino4(x, w, b, DEV, None, fsplit=fs), dev_y, 2e-6, f"fsplit {fs}")
 
 
 @pytest.mark.parametrize("hw", [(9, 13), (8, 10), (32, 32)])
