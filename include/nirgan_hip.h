@@ -430,6 +430,9 @@ typedef struct {
     int r;                                       /* filter size (0 / 3, or 4: 25 planes) */
 } nirgan_wino_dy_desc;
 int nirgan_wino_dy(const nirgan_wino_dy_desc* d, void* stream);
+/* nirgan_wino_input(c) and nirgan_wino_dy(y) of the SAME output-gradient buffer (c->x == y->dy, zero halo r-1) in one pass: the 2x2 block
+ * of tile (ty, tx) is the lower-right corner of the data-gradient patch (ty, tx), so dY is read once for both transforms */
+int nirgan_wino_input_dy(const nirgan_wino_desc* c, const nirgan_wino_dy_desc* y, void* stream);
 int nirgan_wino_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
 int nirgan_wino_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream);   /* [K][C][r][r] */
 

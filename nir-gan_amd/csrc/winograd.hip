@@ -43,7 +43,9 @@ __device__ __forceinline__ void wino_weight_one(const WinoW& p, const long long 
 
 __global__ __launch_bounds__(256) void wino_weight_kernel(const WinoW p) { wino_weight_one(p, blockIdx.x * 256ll + threadIdx.x); }
 
-struct WinoIn { const float* x; float* V; int B, H, W, C, x_row, x_img, TH, TW; long long T; };
+struct WinoIn { const float* x; float* V; int B, H, W, C, x_row, x_img, TH, TW; long long T;
+                float* Yt; int yTH, yTW; long long yT; };   // Yt != nullptr: x is a dY buffer (zero halo r-1) and the tile's lower-right 2x2 block is ALSO
+                                                             // emitted as Yt = A dY A^T of output-gradient tile (ty, tx) (one read of dY for both transforms)
 
 // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; one thread = one tile x 4 channels
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoIn p) {
@@ -80,6 +82,21 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoIn p) {
         *reinterpret_cast<f32x4*>(V + (a * 4 + 1) * plane) = m[a][1] + m[a][2];
         *reinterpret_cast<f32x4*>(V + (a * 4 + 2) * plane) = m[a][2] - m[a][1];
         *reinterpret_cast<f32x4*>(V + (a * 4 + 3) * plane) = m[a][1] - m[a][3];
+    }
+    if (p.Yt != nullptr && ty < p.yTH && tx < p.yTW) {
+        // dY rows 2ty, 2ty+1 / columns 2tx, 2tx+1 are d[2..3][2..3] (rows past an odd extent read the zero halo)
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 r0[2] = {d[2][2], d[2][3]}, r1[2] = {d[2][2] + d[3][2], d[2][3] + d[3][3]};
+        const f32x4 r2[2] = {d[2][2] - d[3][2], d[2][3] - d[3][3]}, r3[2] = {z - d[3][2], z - d[3][3]};
+        const size_t yplane = size_t(p.yT) * p.C;
+        float* Y = p.Yt + ((size_t(b) * p.yTH + ty) * p.yTW + tx) * p.C + q * 4;
+        auto row = [&](int a, const f32x4* rr) {
+            *reinterpret_cast<f32x4*>(Y + (a * 4 + 0) * yplane) = rr[0];
+            *reinterpret_cast<f32x4*>(Y + (a * 4 + 1) * yplane) = rr[0] + rr[1];
+            *reinterpret_cast<f32x4*>(Y + (a * 4 + 2) * yplane) = rr[0] - rr[1];
+            *reinterpret_cast<f32x4*>(Y + (a * 4 + 3) * yplane) = z - rr[1];
+        };
+        row(0, r0); row(1, r1); row(2, r2); row(3, r3);
     }
 }
 
@@ -245,12 +262,14 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const WinoIn p) {
     const int amax = p.H + 3 - 2 * ty, cmax = p.W + 3 - 2 * tx;      // valid lines / columns of this tile (5, or 4 at an odd edge)
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 m[5][5];
+    f32x4 dd[2][2];                            // the patch's lower-right 2x2 block = output-gradient tile (ty, tx) when x is a dY buffer
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
         f32x4 d[5];
 #pragma unroll
         for (int a = 0; a < 5; ++a)
             d[a] = (a < amax && c < cmax) ? *reinterpret_cast<const f32x4*>(src + size_t(a) * p.x_row + size_t(c) * p.C) : z;
+        if (c >= 3) { dd[0][c - 3] = d[3]; dd[1][c - 3] = d[4]; }
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
             f32x4 s = z;
@@ -270,6 +289,29 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const WinoIn p) {
             for (int c = 0; c < 5; ++c) wmac(s, w4_BT(f2, c), m[f1][c]);
             *reinterpret_cast<f32x4*>(V + (f1 * 5 + f2) * plane) = s;
         }
+    if (p.Yt != nullptr && ty < p.yTH && tx < p.yTW) {
+        f32x4 rr[5][2];
+#pragma unroll
+        for (int f = 0; f < 5; ++f)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 s = z;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wmac(s, w4_AT(a, f), dd[a][c]);
+                rr[f][c] = s;
+            }
+        const size_t yplane = size_t(p.yT) * p.C;
+        float* Y = p.Yt + ((size_t(b) * p.yTH + ty) * p.yTW + tx) * p.C + q * 4;
+#pragma unroll
+        for (int f1 = 0; f1 < 5; ++f1)
+#pragma unroll
+            for (int f2 = 0; f2 < 5; ++f2) {
+                f32x4 s = z;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) wmac(s, w4_AT(c, f2), rr[f1][c]);
+                *reinterpret_cast<f32x4*>(Y + (f1 * 5 + f2) * yplane) = s;
+            }
+    }
 }
 
 // Yt[f][t][k] = (A dY A^T)[f], A = (A^T)^T is 5 x 2
@@ -440,7 +482,7 @@ int ng_wino_gemm_params(const nirgan_wino_desc* d, ng::WinoG* g) {
     return NIRGAN_OK;
 }
 
-extern "C" int nirgan_wino_input(const nirgan_wino_desc* d, void* stream) {
+static int wino_input_impl(const nirgan_wino_desc* d, const nirgan_wino_dy_desc* y, void* stream) {
     // the input transform needs x, V and the geometry only (the weight-gradient path transforms the forward input without a GEMM)
     NG_REQUIRE(d && d->x && d->V, "wino_input: null pointer");
     const int r = wino_r(d->r);
@@ -453,11 +495,29 @@ extern "C" int nirgan_wino_input(const nirgan_wino_desc* d, void* stream) {
     WinoIn in;
     in.x = d->x; in.V = d->V; in.B = d->B; in.H = d->H; in.W = d->W; in.C = d->C;
     in.x_row = d->x_wp * d->C; in.x_img = d->x_hp * in.x_row; in.TH = (d->H + 1) / 2; in.TW = (d->W + 1) / 2; in.T = T;
+    in.Yt = nullptr; in.yTH = in.yTW = 0; in.yT = 0;
+    if (y != nullptr) {
+        // the same dY buffer seen twice: zero halo r-1, the data gradient covers (H + r - 1) x (W + r - 1) outputs
+        NG_REQUIRE(y->dy == d->x && y->Yt && wino_r(y->r) == r && y->dy_pad == r - 1 && y->B == d->B && y->K == d->C
+                   && y->dy_hp == d->x_hp && y->dy_wp == d->x_wp && d->H == y->H + r - 1 && d->W == y->W + r - 1,
+                   "wino_input_dy: the two descriptors do not describe the same output-gradient buffer");
+        NG_REQUIRE(ng_aligned16(y->Yt), "wino_input_dy: pointers must be 16-byte aligned");
+        in.yTH = (y->H + 1) / 2; in.yTW = (y->W + 1) / 2; in.yT = (long long)y->B * in.yTH * in.yTW;
+        NG_REQUIRE(y->Yt_elems >= nf * in.yT * y->K, "wino_input_dy: Yt workspace too small");
+        in.Yt = y->Yt;
+    }
     const long long nthreads = T * (d->C / 4);
     const dim3 grid(unsigned((nthreads + 255) / 256));
     if (r == 3) hipLaunchKernelGGL(wino_input_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
     else hipLaunchKernelGGL(wino4_input_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
     return nirgan_check_launch("wino_input");
+}
+
+extern "C" int nirgan_wino_input(const nirgan_wino_desc* d, void* stream) { return wino_input_impl(d, nullptr, stream); }
+
+extern "C" int nirgan_wino_input_dy(const nirgan_wino_desc* d, const nirgan_wino_dy_desc* y, void* stream) {
+    NG_REQUIRE(y != nullptr, "wino_input_dy: null pointer");
+    return wino_input_impl(d, y, stream);
 }
 
 extern "C" int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream) {

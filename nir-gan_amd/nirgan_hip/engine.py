@@ -434,10 +434,16 @@ def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tenso
     d.precision = 0
     d.nplanes, d.p_plane, d.q_plane = nf, T * cout, T * cin
     ctx.keep.extend([vin, ydesc, d, slabs])
-    plan.add("nirgan_wino_input", C.byref(pair_wino))          # V of dY for the data gradient
+    if pair_wino.x == ydesc.dy and dy.pad == r - 1 and os.environ.get("NIRGAN_NO_WINO_INPUT_DY") != "1":
+        plan.add("nirgan_wino_input_dy", C.byref(pair_wino), C.byref(ydesc))      # V of dY (data gradient) and Yt (weight gradient): one read of dY
+        fused_dy = True
+    else:
+        plan.add("nirgan_wino_input", C.byref(pair_wino))      # V of dY for the data gradient
+        fused_dy = False
     if vin is not None:
         plan.add("nirgan_wino_input", C.byref(vin))            # V of the forward input
-    plan.add("nirgan_wino_dy", C.byref(ydesc))
+    if not fused_dy:
+        plan.add("nirgan_wino_dy", C.byref(ydesc))
     plan.add("nirgan_wino_wgrad_pair", C.byref(pair_wino), C.byref(d))
     plan.add("nirgan_wino_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, r, grad.data_ptr(), 1 if accumulate else 0)
     return d

@@ -416,6 +416,14 @@ class EmuBackend:
         arr(d.Yt, a * a * T * K)[:] = Yt.reshape(-1).astype(np.float32)
         return 0
 
+    def nirgan_wino_input_dy(self, cref, yref, stream=None):
+        c, y = obj(cref), obj(yref)
+        r = self._r(c.r)
+        if c.x != y.dy or y.dy_pad != r - 1 or c.H != y.H + r - 1 or c.W != y.W + r - 1 or c.C != y.K or self._r(y.r) != r:
+            return self._fail("wino_input_dy: the two descriptors do not describe the same output-gradient buffer")
+        rc = self.nirgan_wino_input(cref)
+        return rc if rc else self.nirgan_wino_dy(yref)
+
     def nirgan_wino_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
         return self.nirgan_wino_wgrad_finish_r(slabs, nsplit, K, Cc, 3, grad, accumulate)
 
