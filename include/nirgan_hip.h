@@ -163,7 +163,7 @@ typedef struct {
     float* mean; float* rstd;             /* [B][C] */
     int act; float slope;
     const float* residual; int r_hp, r_wp, r_pad;   /* optional [B][r_hp][r_wp][C], interior at r_pad */
-    float* out; int o_hp, o_wp, o_pad; int border;
+    float* out; int o_hp, o_wp, o_pad; int border;   /* out = NULL (with norm): statistics only */
     float* ws; int64_t ws_elems;          /* >= B * nchunk * 2 * C floats, see nirgan_instnorm_ws_elems */
     void* out_bf16;                       /* optional twin of `out` (same geometry, bf16 elements): every store is mirrored, rounded
                                            * to nearest even -- the operand the bf16 mode's convolutions read (in_bf16) */
@@ -413,6 +413,10 @@ int nirgan_wino_weights_r(const float* w, int K, int C, int r, int transpose_fli
  * memory, first_block = running sum of ceil(K*C/256) over the preceding jobs, total_blocks = the sum over all jobs */
 int nirgan_wino_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
 int nirgan_wino_input(const nirgan_wino_desc* d, void* stream);     /* V = B^T d B from x */
+/* the same V straight from a convolution's raw output y (dense [B][H][W][C], d->x unused): x = act((y - mean) * rstd) under a REFLECT
+ * halo of 1 (InstanceNorm + ReLU + ReflectionPad2d(1) between the two convolutions of a ResnetBlock, model/networks.py:405-421),
+ * evaluated on the fly: nirgan_instnorm_fwd with out = NULL (statistics only) then this call replace the apply pass + the transform */
+int nirgan_wino_input_norm(const nirgan_wino_desc* d, const float* y, const float* mean, const float* rstd, int act, float slope, void* stream);
 int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream);      /* y from V and U (frequency-folding GEMM + bias) */
 int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);   /* both */
 /* the GEMM stage of the Winograd data gradient of a layer (c: x = dY, transpose_flip weights; nirgan_wino_input(c) must have run) and its weight gradient (w) in ONE grid, like

@@ -327,10 +327,11 @@ extern "C" int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C) {
 }
 
 extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
-    NG_REQUIRE(d && d->y && d->out, "instnorm_fwd: null pointer");
+    NG_REQUIRE(d && d->y && (d->out || d->norm), "instnorm_fwd: null pointer");
+    const bool stats_only = d->out == nullptr;        // mean / rstd only: the consumer normalises on the fly (nirgan_wino_input_norm)
     NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C >= 4 && d->C % 4 == 0 && d->C <= 1024, "instnorm_fwd: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
     NG_REQUIRE(ng_aligned16(d->y) && ng_aligned16(d->out) && ng_aligned16(d->residual), "instnorm_fwd: pointers must be 16-byte aligned");
-    NG_REQUIRE(d->o_pad >= 0 && d->o_hp == d->H + 2 * d->o_pad && d->o_wp == d->W + 2 * d->o_pad, "instnorm_fwd: output halo geometry mismatch");
+    NG_REQUIRE(stats_only || (d->o_pad >= 0 && d->o_hp == d->H + 2 * d->o_pad && d->o_wp == d->W + 2 * d->o_pad), "instnorm_fwd: output halo geometry mismatch");
     NG_REQUIRE(d->border != NIRGAN_BORDER_REFLECT || (d->o_pad < d->H && d->o_pad < d->W), "instnorm_fwd: reflect halo wider than the image");
     NG_REQUIRE(!d->residual || (d->r_hp == d->H + 2 * d->r_pad && d->r_wp == d->W + 2 * d->r_pad), "instnorm_fwd: residual geometry mismatch");
     InFwd p;
@@ -347,7 +348,7 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
         hipLaunchKernelGGL(in_stats_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
         hipLaunchKernelGGL(in_finalize_kernel, dim3(d->B), dim3(256), 0, st, p, d->B);
     }
-    hipLaunchKernelGGL(in_apply_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+    if (!stats_only) hipLaunchKernelGGL(in_apply_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     return nirgan_check_launch("instnorm_fwd");
 }
 

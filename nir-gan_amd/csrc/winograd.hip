@@ -100,6 +100,67 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoIn p) {
     }
 }
 
+struct WinoInN { const float* y; const float* mean; const float* rstd; float* V; int B, H, W, C, TH, TW; long long T; int act; float slope; };
+
+// the same transform straight from a convolution's raw output y (dense [B][H][W][C]): x = act((y - mean) * rstd) with a REFLECT halo
+// of 1, evaluated on the fly -- the instance-norm apply pass and the halo'd activation buffer of a layer whose only consumer is this
+// transform (first convolution of a ResnetBlock -> second) are never written.  Same arithmetic as in_apply_kernel (bitwise equal V).
+__global__ __launch_bounds__(256) void wino_input_norm_kernel(const WinoInN p) {
+    const int q4 = p.C / 4;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= p.T * q4) return;
+    const long long t = i / q4;
+    const int q = int(i - t * q4);
+    const int tx = int(t % p.TW);
+    const long long r = t / p.TW;
+    const int ty = int(r % p.TH), b = int(r / p.TH);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(p.mean + size_t(b) * p.C + q * 4);
+    const f32x4 rstd = *reinterpret_cast<const f32x4*>(p.rstd + size_t(b) * p.C + q * 4);
+    const float* yb = p.y + size_t(b) * p.H * p.W * p.C + q * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int rb = 2 * ty + a;                                   // row of the virtual halo'd buffer: 0 .. H+1 (beyond: zero, odd extents)
+        const int yr = ng_reflect(rb - 1, p.H);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cb = 2 * tx + c;
+            const int yc = ng_reflect(cb - 1, p.W);
+            if (rb < p.H + 2 && cb < p.W + 2) {
+                f32x4 v = (*reinterpret_cast<const f32x4*>(yb + (size_t(yr) * p.W + yc) * p.C) - mean) * rstd;
+                if (p.act == NIRGAN_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                } else if (p.act == NIRGAN_ACT_LRELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                }
+                d[a][c] = v;
+            } else {
+                d[a][c] = z;
+            }
+        }
+    }
+    f32x4 m[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        m[0][c] = d[0][c] - d[2][c];
+        m[1][c] = d[1][c] + d[2][c];
+        m[2][c] = d[2][c] - d[1][c];
+        m[3][c] = d[1][c] - d[3][c];
+    }
+    const size_t plane = size_t(p.T) * p.C;
+    float* V = p.V + size_t(t) * p.C + q * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        *reinterpret_cast<f32x4*>(V + (a * 4 + 0) * plane) = m[a][0] - m[a][2];
+        *reinterpret_cast<f32x4*>(V + (a * 4 + 1) * plane) = m[a][1] + m[a][2];
+        *reinterpret_cast<f32x4*>(V + (a * 4 + 2) * plane) = m[a][2] - m[a][1];
+        *reinterpret_cast<f32x4*>(V + (a * 4 + 3) * plane) = m[a][1] - m[a][3];
+    }
+}
+
 struct WinoDy { const float* dy; float* Yt; int B, H, W, K, d_row, d_img, d_org, TH, TW; long long T; };
 
 // Yt[f][t][k] = (A dY A^T)[f] for the 2x2 output-gradient tile t; A = [[1,0],[1,1],[1,-1],[0,-1]].  One thread = one tile x 4 channels.
@@ -514,6 +575,20 @@ static int wino_input_impl(const nirgan_wino_desc* d, const nirgan_wino_dy_desc*
 }
 
 extern "C" int nirgan_wino_input(const nirgan_wino_desc* d, void* stream) { return wino_input_impl(d, nullptr, stream); }
+
+extern "C" int nirgan_wino_input_norm(const nirgan_wino_desc* d, const float* y, const float* mean, const float* rstd, int act, float slope, void* stream) {
+    NG_REQUIRE(d && d->V && y && mean && rstd, "wino_input_norm: null pointer");
+    NG_REQUIRE(wino_r(d->r) == 3, "wino_input_norm: 3x3 filters only");
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino_input_norm: bad shape");
+    NG_REQUIRE(act == NIRGAN_ACT_NONE || act == NIRGAN_ACT_RELU || act == NIRGAN_ACT_LRELU, "wino_input_norm: activation %d", act);
+    NG_REQUIRE(ng_aligned16(y) && ng_aligned16(d->V) && ng_aligned16(mean) && ng_aligned16(rstd), "wino_input_norm: pointers must be 16-byte aligned");
+    const long long T = (long long)d->B * ((d->H + 1) / 2) * ((d->W + 1) / 2);
+    NG_REQUIRE(d->V_elems >= 16 * T * d->C, "wino_input_norm: V workspace too small");
+    WinoInN in{y, mean, rstd, d->V, d->B, d->H, d->W, d->C, (d->H + 1) / 2, (d->W + 1) / 2, T, act, slope};
+    const long long nthreads = T * (d->C / 4);
+    hipLaunchKernelGGL(wino_input_norm_kernel, dim3(unsigned((nthreads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), in);
+    return nirgan_check_launch("wino_input_norm");
+}
 
 extern "C" int nirgan_wino_input_dy(const nirgan_wino_desc* d, const nirgan_wino_dy_desc* y, void* stream) {
     NG_REQUIRE(y != nullptr, "wino_input_dy: null pointer");

@@ -338,7 +338,7 @@ class _FullExtent:
 
 
 def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y: Halo, *, H, W, cin, cout, flip=False,
-              own_V: bool = False, r: int = 3):
+              own_V: bool = False, r: int = 3, x_norm=None):
     """U = G g G^T in the pack plan (re-run when the weights change); input transform + fused GEMM/output transform in `plan`.
     x: buffer of [B][H+r-1][W+r-1][cin] (its own halo'd geometry must match), y: dense [B][H][W][cout] (a buffer's full padded
     extent counts as dense).  flip: data gradient (x = dY with a zero halo of 2, H x W = the padded input size)."""
@@ -372,7 +372,12 @@ def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, b
                 ctx.split_pool = SplitPool(ctx)
             ws = ctx.split_pool.get(fs * B * H * W * cout)
             d.fsplit, d.split_ws, d.split_ws_elems = fs, ws.data_ptr(), ws.numel()
-        plan.add("nirgan_wino_input", C.byref(d))
+        if x_norm is not None:             # (y, (mean, rstd), act) of the producer: its apply pass is folded into this transform
+            yh, st, act = x_norm
+            assert r == 3 and yh.pad == 0 and yh.H == H and yh.W == W and yh.C == cin
+            plan.add("nirgan_wino_input_norm", C.byref(d), yh.ptr, st[0].data_ptr(), st[1].data_ptr(), act, 0.2)
+        else:
+            plan.add("nirgan_wino_input", C.byref(d))
         plan.add("nirgan_wino_gemm", C.byref(d))
     return d
 
@@ -475,8 +480,10 @@ class SlabPool:
 
 
 def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.ACT_NONE, slope=0.2, residual: Optional[Halo] = None,
-                border=L.BORDER_KEEP, stats=None, ws=None):
+                border=L.BORDER_KEEP, stats=None, ws=None, stats_only=False):
+    """stats_only: mean / rstd only -- the layer's single consumer normalises on the fly (nirgan_wino_input_norm), `out` stays unwritten."""
     assert y.pad == 0 and out.H == y.H and out.W == y.W and out.C == y.C
+    assert not stats_only or (norm and residual is None)
     d = L.InFwdDesc()
     d.y, d.B, d.H, d.W, d.C = y.ptr, y.B, y.H, y.W, y.C
     d.norm, d.eps = (1 if norm else 0), IN_EPS
@@ -486,9 +493,10 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
     d.act, d.slope = act, slope
     if residual is not None:
         d.residual, d.r_hp, d.r_wp, d.r_pad = residual.ptr, residual.hp, residual.wp, residual.pad
-    d.out, d.o_hp, d.o_wp, d.o_pad, d.border = out.ptr, out.hp, out.wp, out.pad, border
-    if out.t16 is not None:
-        d.out_bf16 = out.t16.data_ptr()
+    if not stats_only:
+        d.out, d.o_hp, d.o_wp, d.o_pad, d.border = out.ptr, out.hp, out.wp, out.pad, border
+        if out.t16 is not None:
+            d.out_bf16 = out.t16.data_ptr()
     ctx.keep.append(d)
     plan.add("nirgan_instnorm_fwd", C.byref(d))
     return d
@@ -581,8 +589,10 @@ class ConvIN:
         k, s, p = self.k, self.s, self.p
         if self.kind == "conv" and wino_applicable(ctx, inp, k, s, p, self.cout, self.OH, self.OW):
             keep = bool(getattr(eng, "need_backward", False)) and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"
+            prod = getattr(self, "producer", None)
+            xn = (prod.y, prod.stats, prod.act) if prod is not None and getattr(prod, "defer_apply", False) else None
             self.wino_fwd = emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
-                                      cout=self.cout, own_V=keep, r=k)
+                                      cout=self.cout, own_V=keep, r=k, x_norm=xn)
             self.wino_fwd_keeps_V = keep
         elif self.kind == "conv":
             taps = G.conv_fwd_taps(k, inp.C)
@@ -604,7 +614,8 @@ class ConvIN:
                                        out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow))
             emit_conv_group(plan, ctx, descs)
         emit_in_fwd(plan, ctx, self.y, self.out, norm=self.norm, act=(L.ACT_NONE if self.keep_z else self.act),
-                    residual=self.residual, border=self.out_border, stats=self.stats, ws=eng.scratch.get())
+                    residual=self.residual, border=self.out_border, stats=self.stats, ws=eng.scratch.get(),
+                    stats_only=getattr(self, "defer_apply", False))
 
     # ---- backward: g (+g2) is the gradient wrt `out`; produces dy (zero halo) then weight / data gradients
     def alloc_bwd(self, need_dgrad: bool):

@@ -163,6 +163,7 @@ PROTOTYPES = {
     "nirgan_wino_wgrad_pair": (i32, [C.POINTER(WinoDesc), C.POINTER(WgradDesc), fp]),
     "nirgan_wino_dy": (i32, [C.POINTER(WinoDyDesc), fp]),
     "nirgan_wino_input_dy": (i32, [C.POINTER(WinoDesc), C.POINTER(WinoDyDesc), fp]),
+    "nirgan_wino_input_norm": (i32, [C.POINTER(WinoDesc), fp, fp, fp, i32, f32, fp]),
     "nirgan_wino_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),
     "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),

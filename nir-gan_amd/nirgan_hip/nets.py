@@ -9,13 +9,14 @@ the parameter gradients (and, for the PatchGAN, the gradient wrt its input).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
 
 from . import geometry as G
 from . import lib as L
-from .engine import ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, emit_conv, emit_wgrad
+from .engine import ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, emit_conv, emit_wgrad, wino_applicable
 
 
 def generator_layout(n_blocks: int) -> dict:
@@ -105,6 +106,13 @@ class GeneratorEngine(_Engine):
             c2 = ConvIN(self, f"b{j}c2", "conv", c1.out, P(i, "conv_block.5.weight"), P(i, "conv_block.5.bias"), k=3, s=1, p=1,
                         cout=4 * ngf, act=L.ACT_NONE, residual=u, out_pad=1,
                         out_border=L.BORDER_REFLECT if j < n_blocks - 1 else L.BORDER_KEEP)
+            # c1's normalised output has ONE reader, c2's Winograd input transform: fold InstanceNorm + ReLU + reflect pad into that
+            # transform and never write the buffer.  Needs c2's V kept for its weight gradient (else the backward re-reads c1.out).
+            wgrad_keeps_v = os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"
+            if (wino_applicable(self.ctx, c2.inp, 3, 1, 1, c2.cout, c2.OH, c2.OW) and (wgrad_keeps_v or not self.need_backward)
+                    and os.environ.get("NIRGAN_NO_WINO_INPUT_NORM") != "1"):
+                c1.defer_apply = True
+                c2.producer = c1
             self.blocks.append((i, c1, c2))
             u = c2.out
         i0, i1 = lay["up"]

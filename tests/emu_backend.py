@@ -365,10 +365,26 @@ class EmuBackend:
         arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
         return 0
 
-    def nirgan_wino_gemm(self, ref, stream=None):
-        return self.nirgan_wino_conv3x3(ref)
+    def nirgan_wino_input_norm(self, ref, y, mean, rstd, act, slope, stream=None):
+        d = obj(ref)
+        self.calls.append("wino_in_norm")
+        if self._r(d.r) != 3:
+            return self._fail("wino_input_norm: 3x3 filters only")
+        B, H, W, Cc = d.B, d.H, d.W, d.C
+        yv = arr(y, B * H * W * Cc).reshape(B, H, W, Cc)
+        m, r = arr(mean, B * Cc).reshape(B, 1, 1, Cc), arr(rstd, B * Cc).reshape(B, 1, 1, Cc)
+        a = self._act(((yv - m) * r).astype(np.float32).astype(np.float64), act, slope).astype(np.float32)       # in_apply's fp32 arithmetic
+        hh, ww = reflect(np.arange(H + 2) - 1, H), reflect(np.arange(W + 2) - 1, W)
+        x = np.ascontiguousarray(a[:, hh][:, :, ww])
+        keep = d.x, d.x_hp, d.x_wp
+        d.x, d.x_hp, d.x_wp = x.ctypes.data, H + 2, W + 2
+        V = self._wino_tiles(d)
+        d.x, d.x_hp, d.x_wp = keep
+        arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
+        return 0
 
-    def nirgan_wino_conv3x3(self, ref, stream=None):
+    def nirgan_wino_gemm(self, ref, stream=None):
+        """The GEMM stage alone: consumes the V a preceding input transform left in the workspace, like the device."""
         d = obj(ref)
         self.calls.append("wino")
         r = self._r(d.r)
@@ -381,8 +397,7 @@ class EmuBackend:
         if d.V_elems < a * a * T * Cc:
             return self._fail("wino_conv: V workspace too small")
         U = arr(d.U, a * a * K * Cc).reshape(a, a, K, Cc).astype(np.float64)
-        V = self._wino_tiles(d)
-        arr(d.V, a * a * T * Cc)[:] = V.reshape(-1).astype(np.float32)
+        V = arr(d.V, a * a * T * Cc).reshape(a, a, B, TH, TW, Cc).astype(np.float64)
         M = np.einsum("albyxc,alkc->albyxk", V, U)
         AT = self._MATS[r][2]
         Y = np.einsum("pa,albyxk,ql->pqbyxk", AT, M, AT)                             # [2][2][B][TH][TW][K]
@@ -396,6 +411,16 @@ class EmuBackend:
                 nh, nw = len(range(p_, H, 2)), len(range(q_, W, 2))
                 out[:, p_::2, q_::2] = v[:, :nh, :nw].astype(np.float32)
         return 0
+
+    def nirgan_wino_conv3x3(self, ref, stream=None):
+        d = obj(ref)
+        r = self._r(d.r)
+        if r not in (3, 4) or d.x_hp != d.H + r - 1 or d.x_wp != d.W + r - 1 or d.H < 2 or d.W < 2:
+            return self._fail("wino_conv: bad geometry")
+        if d.V_elems < (r + 1) ** 2 * d.B * ((d.H + 1) // 2) * ((d.W + 1) // 2) * d.C:
+            return self._fail("wino_conv: V workspace too small")
+        rc = self.nirgan_wino_input(ref)
+        return rc if rc else self.nirgan_wino_gemm(ref)
 
     def nirgan_wino_dy(self, ref, stream=None):
         d = obj(ref)
@@ -442,7 +467,7 @@ class EmuBackend:
         return 0
 
     def nirgan_wino_wgrad_pair(self, cref, wref, stream=None):
-        rc = self.nirgan_wino_conv3x3(cref)
+        rc = self.nirgan_wino_gemm(cref)              # the input transform of cref has run (nirgan_wino_input / _input_dy)
         return rc if rc else self.nirgan_wgrad_igemm(wref)
 
     # ------------------------------------------------------------------ histogram matching
@@ -578,7 +603,7 @@ class EmuBackend:
         d = obj(ref)
         self.calls.append("in_fwd")
         B, H, W, Cc = d.B, d.H, d.W, d.C
-        if d.o_hp != H + 2 * d.o_pad or d.o_wp != W + 2 * d.o_pad:
+        if d.out and (d.o_hp != H + 2 * d.o_pad or d.o_wp != W + 2 * d.o_pad):
             return self._fail("in_fwd: geometry")
         y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float64)
         if d.norm:
@@ -592,6 +617,8 @@ class EmuBackend:
             z = (y - mean[:, None]) * rstd[:, None]
         else:
             z = y
+        if not d.out:                      # statistics only
+            return 0 if d.norm else self._fail("in_fwd: null pointer")
         a = self._act(z, d.act, d.slope).reshape(B, H, W, Cc)
         if d.residual:
             r = arr(d.residual, B * d.r_hp * d.r_wp * Cc).reshape(B, d.r_hp, d.r_wp, Cc)

@@ -764,6 +764,42 @@ def test_winograd4_backward_pair_matches_autograd(hw):
     close(ggw, ref_gw, 1e-4, "device: weight gradient")
 
 
+@pytest.mark.parametrize("hw", [(12, 16), (9, 11), (64, 64)])
+def test_winograd_input_transform_with_the_instance_norm_folded_in(hw):
+    """nirgan_instnorm_fwd(out = NULL: statistics only) + nirgan_wino_input_norm(y, mean, rstd, ReLU) = the V that the full
+    instance-norm pass (ReLU, reflect halo 1) followed by nirgan_wino_input produces -- bitwise, same fp32 arithmetic."""
+    import ctypes as C
+    H, W = hw
+    B, Cc = 2, 128
+    g = torch.Generator().manual_seed(31)
+    y = (torch.randn(B, H, W, Cc, generator=g) * 1.7 + 0.3).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    ctx = Ctx(DEV, "fp32")
+    yh = Halo(ctx, B, H, W, Cc, 0)
+    yh.t.copy_(y)
+    out = Halo(ctx, B, H, W, Cc, 1)
+    stats = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
+    ws = ctx.zeros(int(L.backend().nirgan_instnorm_ws_elems(B, H, W, Cc)))
+    from nirgan_hip.engine import emit_in_fwd
+    full, only = Plan(ctx), Plan(ctx)
+    emit_in_fwd(full, ctx, yh, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats, ws=ws)
+    stats2 = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
+    emit_in_fwd(only, ctx, yh, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats2, ws=ws, stats_only=True)
+    full.run()
+    T = B * ((H + 1) // 2) * ((W + 1) // 2)
+    V1, V2 = torch.zeros(16 * T * Cc, device=DEV), torch.full((16 * T * Cc,), float("nan"), device=DEV)
+    d = L.WinoDesc()
+    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = out.ptr, H + 2, W + 2, B, H, W, Cc, 128
+    d.V, d.V_elems = V1.data_ptr(), V1.numel()
+    L.call("nirgan_wino_input", C.byref(d), st)
+    only.run()
+    assert torch.equal(stats[0], stats2[0]) and torch.equal(stats[1], stats2[1])
+    d.V = V2.data_ptr()
+    L.call("nirgan_wino_input_norm", C.byref(d), yh.ptr, stats2[0].data_ptr(), stats2[1].data_ptr(), L.ACT_RELU, 0.2, st)
+    torch.cuda.synchronize()
+    assert torch.equal(V1, V2), f"max diff {(V1 - V2).abs().max().item():.3e}"
+
+
 @pytest.mark.parametrize("hw", [(12, 16), (9, 11)])
 def test_winograd_backward_pair_matches_autograd(hw):
     """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it: Winograd data gradient (over the padded extent) and

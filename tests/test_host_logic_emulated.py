@@ -709,3 +709,28 @@ def test_fused_trainer_with_the_ssim_term(emu, golden_dir):
         for k, v in ref.last["grads_G"].items():
             if v is not None and k not in O.shadowed_bias_keys("G", 6):
                 close(gG[k], v, 2e-4, f"gG {k} (micro {micro})")
+
+
+def test_generator_winograd_layers_through_the_trainer(emu):
+    """ngf = 32 makes the residual-block convolutions 128 -> 128 channels, wide enough for the Winograd path: forward with the
+    instance-norm apply of each block's first convolution folded into the second one's input transform (nirgan_wino_input_norm),
+    fused data/weight gradients with one transform pass over dY (nirgan_wino_input_dy).  One fused step against the oracle."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    torch.manual_seed(5)
+    netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
+    netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
+    G0 = {k: v.detach().clone() for k, v in netG.state_dict().items()}
+    D0 = {k: v.detach().clone() for k, v in netD.state_dict().items()}
+    rgb, nir = torch.rand(2, 3, 32, 32), torch.rand(2, 1, 32, 32)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0)
+    out = tr.step(rgb, nir).as_dict()
+    assert emu.calls.count("wino_in_norm") == 6 and emu.calls.count("wino") >= 24, "the Winograd path did not run as expected"
+    ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
+    o = ref.step(rgb, nir)
+    close(tr.G.pred, ref.last["pred"], 2e-5, "pred")
+    close(out["loss_G"], o["loss_G"], 1e-5, "loss_G")
+    gG = tr.flatG.grad_views()
+    for k, v in ref.last["grads_G"].items():
+        if v is not None and k not in O.shadowed_bias_keys("G", 6):
+            close(gG[k], v, 2e-4, "gG " + k)
