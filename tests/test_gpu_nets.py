@@ -100,6 +100,38 @@ def test_golden_small_nets_fused_step(golden_dir, name):
         close(pD[k], p0, 1e-6, "adam " + k)
 
 
+def test_medium_width_nets_take_the_winograd_paths():
+    """ngf = ndf = 32 on 64x64 tiles: every Winograd variant at small tile counts in one fused step against the oracle -- residual blocks
+    (128 channels at 16x16: frequency-split GEMMs, the instance-norm apply folded into the second convolution's input transform, fused dY
+    transforms, Winograd-domain weight gradient) and the PatchGAN's 4x4 layer (128 -> 256 channels at 8x8 -> 7x7: odd extent)."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    torch.manual_seed(7)
+    netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
+    netD = networks.define_D(4, 32, "basic", 3, "instance", "normal", 0.02)
+    G0 = {k: v.detach().clone() for k, v in netG.state_dict().items()}
+    D0 = {k: v.detach().clone() for k, v in netD.state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    rgb, nir = torch.rand(2, 3, 64, 64, generator=g), torch.rand(2, 1, 64, 64, generator=g)
+    tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=6, lr=0.0)
+    out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
+    names = [n for pl in (tr.G.fwd, tr.G.bwd, tr.D2.fwd, tr.D2.bwd, tr.D1.bwd_pred) for n, _ in pl.ops]
+    for want in ("nirgan_wino_input_norm", "nirgan_wino_input_dy", "nirgan_wino_wgrad_pair", "nirgan_wino_wgrad_finish_r", "nirgan_wino_gemm"):
+        assert want in names, want
+    ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
+    o = ref.step(rgb, nir)
+    close(tr.G.pred, ref.last["pred"], 1e-3, "pred")
+    for k in ("loss_D", "loss_G", "loss_G_l1"):
+        close(out[k], o[k], 1e-3, k)
+    gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
+    for k, v in ref.last["grads_D"].items():
+        if k not in O.shadowed_bias_keys("D"):
+            grad_close(gD[k], v, "gD " + k)
+    for k, v in ref.last["grads_G"].items():
+        if v is not None and k not in O.shadowed_bias_keys("G", 6):
+            grad_close(gG[k], v, "gG " + k)
+
+
 @pytest.mark.parametrize("micro", [1, 2])
 def test_fused_step_with_the_ssim_term(golden_dir, micro):
     """lambda_ssim > 0 (model/pix2pix.py:233-237, utils/losses.py:10-30): the fused HIP step with the SSIM term against the oracle's
