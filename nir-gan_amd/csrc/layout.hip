@@ -178,6 +178,73 @@ __global__ __launch_bounds__(256) void chan_dgrad_kernel(const ChanDgradP p) {
     }
 }
 
+// k = 4, stride 2, padding 1 (the PatchGAN's first convolution, model/networks.py:559): output-stationary on dY.  A block takes 8x8 dY
+// positions plus a ring of one (10x10), forms the 16 tap products T[pos][kh][kw] = sum_co dY[pos][co] * W[co][c][kh][kw] once per
+// position in LDS (each dY vector is read once per block instead of once per tap and pixel), then every one of its 16x16 input pixels
+// adds its four taps: out(h, w) = sum over kh = (h+1)%2 + {0,2}, kw likewise, of T[(h+1-kh)/2][(w+1-kw)/2][kh][kw].
+__global__ __launch_bounds__(256) void chan_dgrad_k4s2_kernel(const ChanDgradP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* wsel = reinterpret_cast<float*>(smem_raw);        // [16][C]
+    float* T = wsel + 16 * p.C;                              // [100][16]
+    for (int i = threadIdx.x; i < 16 * p.C; i += 256) {
+        const int t = i / p.C, co = i - t * p.C;
+        wsel[i] = p.w[(size_t(co) * p.cin + p.channel) * 16 + t];
+    }
+    __syncthreads();
+    const int tiles_x = (p.OW + 7) / 8, tiles_y = (p.OH + 7) / 8;
+    const int ntiles = p.B * tiles_y * tiles_x;
+    const int q4 = p.C / 4;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int oh0 = ty * 8 - 1, ow0 = tx * 8 - 1;        // first position of the 10x10 patch
+        // phase 1: thread (pos, half) forms 8 of the 16 tap products of its position
+        {
+            const int pos = threadIdx.x & 127, th = threadIdx.x >> 7;
+            if (pos < 100) {
+                const int py = pos / 10, px = pos - py * 10;
+                const int oh = oh0 + py, ow = ow0 + px;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (oh >= 0 && oh < p.OH && ow >= 0 && ow < p.OW) {
+                    const float* d = p.dy + size_t(b) * p.dy_img + size_t(oh + p.dy_pad) * p.dy_row + size_t(ow + p.dy_pad) * p.C;
+                    for (int q = 0; q < q4; ++q) {
+                        const f32x4 dv = *reinterpret_cast<const f32x4*>(d + q * 4);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(wsel + (th * 8 + t) * p.C + q * 4);
+                            acc[t] += dv[0] * wv[0] + dv[1] * wv[1] + dv[2] * wv[2] + dv[3] * wv[3];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) T[pos * 16 + th * 8 + t] = acc[t];
+            }
+        }
+        __syncthreads();
+        // phase 2: the 16x16 input pixels of the tile
+        {
+            const int y = threadIdx.x >> 4, x = threadIdx.x & 15;
+            const int h = ty * 16 + y, w = tx * 16 + x;
+            if (h < p.H && w < p.W) {
+                const int kh0 = (h + 1) & 1, kw0 = (w + 1) & 1;
+                float s = 0.f;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int kh = kh0 + 2 * a;
+                    const int py = ((h + 1 - kh) >> 1) - oh0;            // 0 .. 9 by construction
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int kw = kw0 + 2 * c;
+                        const int px = ((w + 1 - kw) >> 1) - ow0;
+                        s += T[(py * 10 + px) * 16 + kh * 4 + kw];
+                    }
+                }
+                p.out[(size_t(b) * p.H + h) * p.W + w] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 inline int grid_for(int64_t total) {
     const int64_t g = (total + 255) / 256;
     return int(g < 8192 ? (g < 1 ? 1 : g) : 8192);
@@ -262,6 +329,12 @@ extern "C" int nirgan_conv_channel_dgrad(const nirgan_chan_dgrad_desc* d, void* 
     p.dy = d->dy; p.C = d->C; p.dy_row = d->dy_wp * d->C; p.dy_img = d->dy_hp * p.dy_row; p.dy_pad = d->dy_pad; p.OH = OH; p.OW = OW;
     p.w = d->w; p.cin = d->cin; p.k = d->k; p.stride = d->stride; p.pad = d->pad; p.channel = d->channel;
     p.B = d->B; p.H = d->H; p.W = d->W; p.out = d->out;
+    if (d->k == 4 && d->stride == 2 && d->pad == 1 && d->H == 2 * OH && d->W == 2 * OW && 16 * d->C * 4 + 1600 * 4 <= 65536) {
+        const int64_t ntiles = int64_t(d->B) * ((OH + 7) / 8) * ((OW + 7) / 8);
+        hipLaunchKernelGGL(chan_dgrad_k4s2_kernel, dim3(int(ntiles < 8192 ? ntiles : 8192)), dim3(256), size_t(16) * d->C * 4 + 1600 * 4,
+                           static_cast<hipStream_t>(stream), p);
+        return nirgan_check_launch("conv_channel_dgrad");
+    }
     const int64_t npix = int64_t(d->B) * d->H * d->W;
     int64_t g = (npix + 15) / 16;
     g = g < 4096 ? g : 4096;

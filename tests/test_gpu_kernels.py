@@ -261,10 +261,12 @@ def test_bilinear_and_inject_match_torch():
     close(gds, s2.grad[:, 0], 1e-5, "bilinear bwd")
 
 
-def test_channel_dgrad_matches_torch():
-    """dD/dpred only: data gradient of Conv2d(4, 64, 4, stride 2, padding 1) wrt input channel 3."""
+@pytest.mark.parametrize("shape", [(2, 20, 24, 64), (3, 64, 48, 32), (1, 6, 10, 8), (2, 256, 256, 64)])
+def test_channel_dgrad_matches_torch(shape):
+    """dD/dpred only: data gradient of Conv2d(4, 64, 4, stride 2, padding 1) wrt input channel 3 (the output-stationary k4/s2 kernel:
+    partial 8x8 tiles, borders, several images)."""
     gen = torch.Generator().manual_seed(13)
-    B, H, W, Cout = 2, 20, 24, 64
+    B, H, W, Cout = shape
     OH, OW = H // 2, W // 2
     w = torch.randn(Cout, 4, 4, 4, generator=gen) * 0.1
     dy = torch.randn(B, Cout, OH, OW, generator=gen)
