@@ -1,6 +1,7 @@
 // NCHW boundary <-> halo'd NHWC, and the tap-plane gather/scatter of the single-output-channel
 // convolutions (7x7 64->1 + tanh of the generator, 4x4 512->1 of the PatchGAN).  HBM-bound.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -70,6 +71,58 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const GatherP p) {
     p.dst[(int64_t(b) * H2 + y) * W2 + x] = s;
 }
 
+// Full k x k tap sets in row-major order (dh = t / k, dw = t % k: what the 7x7 and 4x4 single-channel convolutions emit): a block takes
+// 32 x 32 outputs and walks the kernel rows; per row it stages only the k planes of that row for the (32 x (32+k-1)) records it needs
+// ([r][c][j], 7 or 4 floats per record: odd / small stride, conflict-free across the 32 x-neighbours), 4 outputs per thread.  34 KB of LDS
+// instead of the 110 KB window of all planes (one block per CU), halo re-reads 1.4x instead of 2.1x.
+__global__ __launch_bounds__(256) void tap_gather_rows_kernel(const GatherP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* lds = reinterpret_cast<float*>(smem_raw);
+    const int H2 = p.OH - 2 * p.crop, W2 = p.OW - 2 * p.crop;
+    const int tiles_x = (W2 + 31) / 32, tiles_y = (H2 + 31) / 32;
+    const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+    const int ty0 = (tile / tiles_x) * 32, tx0 = (tile % tiles_x) * 32;
+    const int k = p.kw, rw = 32 + k - 1;
+    const float* qb = p.q + int64_t(b) * p.q_img;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;      // outputs (ly + 8 i, lx), i = 0..3
+    float s[4];
+    const float b0 = p.bias ? p.bias[0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = b0;
+    const int per_row = rw * k;                                  // floats staged per window row
+    for (int kh = 0; kh < p.kh; ++kh) {
+        __syncthreads();                                         // the previous kernel row is consumed
+        // a thread keeps its (column, plane) and walks the 32 rows: the index arithmetic is paid once, the loads of a row are
+        // k-float runs at the record stride
+        for (int cj = threadIdx.x; cj < per_row; cj += 256) {
+            const int c = cj / k, j = cj - c * k;
+            int gx = tx0 + p.crop + c;
+            gx = gx < p.q_wp ? gx : p.q_wp - 1;                  // clamped rows / columns feed masked-off outputs only
+            const float* col = qb + int64_t(gx) * p.q_cs + kh * k + j;
+            const int gy0 = ty0 + p.crop + kh;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+                int gy = gy0 + r;
+                gy = gy < p.q_hp ? gy : p.q_hp - 1;
+                lds[r * per_row + cj] = col[int64_t(gy) * p.q_row];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* row = lds + (ly + 8 * i) * per_row + lx * k;
+            float a = 0.f;
+            for (int kw = 0; kw < k; ++kw) a += row[kw * k + kw];
+            s[i] += a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = tx0 + lx, y = ty0 + ly + 8 * i;
+        if (x < W2 && y < H2) p.dst[(int64_t(b) * H2 + y) * W2 + x] = p.act == NIRGAN_ACT_TANH ? tanhf(s[i]) : s[i];
+    }
+}
+
 struct ScatterP {
     const float* dout; const float* out; int act;
     int B, OH, OW, crop;
@@ -80,6 +133,10 @@ struct ScatterP {
 
 // one thread per (pixel of dq, group of 4 taps): dq[b][hh][ww][t] = dz[hh-dh_t][ww-dw_t]
 __global__ void tap_scatter_kernel(const ScatterP p) {
+    // the tap tables are indexed per lane (t = 4 tq + k): from LDS, not from the kernel arguments (a divergent index into those is serialised)
+    __shared__ int s_dh[64], s_dw[64];
+    if (threadIdx.x < 64) { s_dh[threadIdx.x] = p.dh[threadIdx.x] + p.crop; s_dw[threadIdx.x] = p.dw[threadIdx.x] + p.crop; }
+    __syncthreads();
     const int H2 = p.OH - 2 * p.crop, W2 = p.OW - 2 * p.crop;
     const int q4 = p.q_cs / 4;
     const int64_t total = int64_t(p.B) * p.q_hp * p.q_wp * q4;
@@ -92,7 +149,7 @@ __global__ void tap_scatter_kernel(const ScatterP p) {
         for (int k = 0; k < 4; ++k) {
             const int t = tq * 4 + k;
             if (t < p.ntaps) {
-                const int h = hh - p.dh[t] - p.crop, w = ww - p.dw[t] - p.crop;
+                const int h = hh - s_dh[t], w = ww - s_dw[t];
                 if (h >= 0 && h < H2 && w >= 0 && w < W2) {
                     const int64_t o = (int64_t(b) * H2 + h) * W2 + w;
                     float g = p.dout[o];
@@ -285,6 +342,14 @@ extern "C" int nirgan_tap_gather(const nirgan_tap_gather_desc* d, void* stream) 
     p.kh = kh; p.kw = kw;
     p.bias = d->bias; p.act = d->act; p.B = d->B; p.OH = d->OH; p.OW = d->OW; p.crop = d->crop; p.dst = d->dst;
     const int H2 = d->OH - 2 * d->crop, W2 = d->OW - 2 * d->crop;
+    bool rowmajor = kh == kw && d->ntaps == kh * kw;
+    for (int t = 0; rowmajor && t < d->ntaps; ++t) rowmajor = d->tap_dh[t] == t / kw && d->tap_dw[t] == t % kw;
+    static const bool no_rows = getenv("NIRGAN_TAP_GATHER_WINDOW") != nullptr;      // A/B switch: the all-planes window kernel everywhere
+    if (rowmajor && !no_rows && int64_t(H2) * W2 >= 4096) {     // (small maps: the all-planes window kernel below has more blocks)
+        const int grid = d->B * ((W2 + 31) / 32) * ((H2 + 31) / 32);
+        hipLaunchKernelGGL(tap_gather_rows_kernel, dim3(grid), dim3(256), size_t(32) * (32 + kw - 1) * kw * 4, static_cast<hipStream_t>(stream), p);
+        return nirgan_check_launch("tap_gather");
+    }
     const size_t lds = size_t(8 + kh - 1) * (32 + kw - 1) * (d->q_cs | 1) * 4;
     NG_REQUIRE(lds <= 160 * 1024, "tap_gather: window does not fit LDS");
     static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(tap_gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();

@@ -227,6 +227,32 @@ def test_layout_tap_and_loss_kernels(golden_dir):
     close(p.grad, torch.from_numpy(z["l1_grad"]), 1e-6, "l1 grad")
 
 
+@pytest.mark.parametrize("case", [(2, 7, 70, 70, 3, 52), (1, 7, 262, 262, 0, 52), (3, 4, 67, 80, 0, 16), (2, 7, 40, 40, 0, 52), (2, 4, 31, 31, 0, 16)])
+def test_tap_gather_kernels(case):
+    """nirgan_tap_gather: out[y][x] = act(bias + sum_t Q[y+crop+dh_t][x+crop+dw_t][t]) over the k*k tap planes of a single-output-channel
+    convolution (7x7 64->1 + tanh with the data-padding crop, model/networks.py:367-368; 4x4 512->1, :579)."""
+    import ctypes as C
+    B, k, OH, OW, crop, qcs = case
+    g = torch.Generator().manual_seed(19)
+    qh, qw = OH + k - 1, OW + k - 1
+    q = torch.randn(B, qh, qw, qcs, generator=g)
+    bias = torch.randn(1, generator=g)
+    H2, W2 = OH - 2 * crop, OW - 2 * crop
+    ref = torch.zeros(B, H2, W2, dtype=torch.float64) + bias.double()
+    for t in range(k * k):
+        dh, dw = t // k, t % k
+        ref += q[:, crop + dh:crop + dh + H2, crop + dw:crop + dw + W2, t].double()
+    ref = torch.tanh(ref).float()
+    qd, bd, out = q.to(DEV), bias.to(DEV), torch.zeros(B, H2, W2, device=DEV)
+    d = L.TapGatherDesc()
+    d.q, d.q_hp, d.q_wp, d.q_cs, d.ntaps = qd.data_ptr(), qh, qw, qcs, k * k
+    for t in range(k * k):
+        d.tap_dh[t], d.tap_dw[t] = t // k, t % k
+    d.bias, d.act, d.B, d.OH, d.OW, d.crop, d.dst = bd.data_ptr(), L.ACT_TANH, B, OH, OW, crop, out.data_ptr()
+    L.call("nirgan_tap_gather", C.byref(d), torch.cuda.current_stream().cuda_stream)
+    close(out, ref, 5e-6, "tap gather")
+
+
 def test_adam_kernel_matches_torch_optimizer():
     torch.manual_seed(3)
     n = 100003
