@@ -177,6 +177,85 @@ def f1(n_blocks, name, lam_rs=0.0, padding=0, H=32):
     print("wrote", name, "loss_D", float(res["loss_D"]), "loss_G", float(res["loss_G"]))
 
 
+# ---------------------------------------------------------------- legacy Pix2PixModel.optimize_parameters
+def ref_legacy_batch(netG, netD, real_A, real_B, lam_l1=100.0):
+    """The legacy loop with the reference's own modules and torch.optim.Adam, in the order of
+    model/pix2pix_model.py:113-154 (forward, backward_D with the 0.5 factor, optimizer_D.step, D frozen, backward_G =
+    GAN + lambda_L1 * L1 without a lambda_GAN, optimizer_G.step).  The class itself cannot be constructed as shipped
+     and its two ``.backward()`` calls are commented out (:129, :141); they are executed here,
+    as upstream pix2pix does and as optimize_parameters needs to do anything."""
+    crit = ref_networks.GANLoss("lsgan")
+    l1 = torch.nn.L1Loss()
+    optG = torch.optim.Adam(netG.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    optD = torch.optim.Adam(netD.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    res = {}
+    fake_B = netG(real_A)                                         # forward()
+    res["fake_B"] = fake_B.detach().clone()
+    for p in netD.parameters():
+        p.requires_grad_(True)
+    optD.zero_grad()
+    pf = netD(torch.cat((real_A, fake_B), 1).detach())            # backward_D()
+    lf = crit(pf, False)
+    pr = netD(torch.cat((real_A, real_B), 1))
+    lr_ = crit(pr, True)
+    loss_d = (lf + lr_) * 0.5
+    loss_d.backward()
+    res["loss_D"], res["loss_D_fake"], res["loss_D_real"] = loss_d.detach(), lf.detach(), lr_.detach()
+    res["grads_D"] = {k: p.grad.detach().clone() for k, p in netD.named_parameters()}
+    optD.step()
+    res["params_D_after"] = sd(netD)
+    for p in netD.parameters():
+        p.requires_grad_(False)
+    optG.zero_grad()
+    pf = netD(torch.cat((real_A, fake_B), 1))                     # backward_G()
+    l_gan = crit(pf, True)
+    l_l1 = l1(fake_B, real_B) * lam_l1
+    loss_g = l_gan + l_l1
+    loss_g.backward()
+    res["loss_G"], res["loss_G_GAN"], res["loss_G_L1"] = loss_g.detach(), l_gan.detach(), l_l1.detach()
+    res["grads_G"] = {k: p.grad.detach().clone() for k, p in netG.named_parameters()}
+    optG.step()
+    res["params_G_after"] = sd(netG)
+    for p in netD.parameters():
+        p.requires_grad_(True)
+    return res
+
+
+def f1_legacy(name):
+    """Same nets and tiles as f1_g6_d.npz (seed 0 / 1234; its G0/*, D0/*, rgb, nir are the inputs: not stored twice)."""
+    torch.manual_seed(0)
+    netG = ref_networks.define_G(3, 1, 8, "resnet_6blocks", "instance", False, "normal", 0.02)
+    netD = ref_networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
+    base = np.load(os.path.join(OUT, "f1_g6_d.npz"))
+    for k, v in sd(netG).items():
+        assert np.array_equal(base["G0/" + k], v.numpy()), k
+    for k, v in sd(netD).items():
+        assert np.array_equal(base["D0/" + k], v.numpy()), k
+    pG0, pD0 = sd(netG), sd(netD)
+    rgb, nir, _ = synth(2, 32, 32, 1234)
+    assert np.array_equal(base["rgb"], rgb.numpy()) and np.array_equal(base["nir"], nir.numpy())
+    res = ref_legacy_batch(netG, netD, rgb, nir)
+    # oracle cross-check: the trainer with the D loss halved and lambda_GAN = 1
+    tr = O.OracleTrainer(pG0, pD0, 6, d_loss_scale=0.5)
+    out = tr.step(rgb, nir)
+    close(out["loss_D"], res["loss_D"], what="legacy loss_D")
+    close(out["loss_G"], res["loss_G"], what="legacy loss_G")
+    for k, v in res["grads_D"].items():
+        close(tr.last["grads_D"][k], v, 1e-5, "legacy grad D " + k)
+    for k, v in res["params_G_after"].items():
+        if k not in O.shadowed_bias_keys("G", 6):
+            close(tr.pG[k], v, 1e-6, "legacy param G " + k)
+    arrs = {"base": np.array("f1_g6_d.npz")}
+    for k in ("fake_B", "loss_D", "loss_D_fake", "loss_D_real", "loss_G", "loss_G_GAN", "loss_G_L1"):
+        arrs[k] = res[k].numpy()
+    arrs.update(npd("gD/", res["grads_D"]))
+    arrs.update(npd("gG/", res["grads_G"]))
+    arrs.update(npd("D1/", res["params_D_after"]))
+    arrs.update(npd("G1/", res["params_G_after"]))
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name, "loss_D", float(res["loss_D"]), "loss_G", float(res["loss_G"]))
+
+
 # ---------------------------------------------------------------- inject generator
 def ns(**kw):
     return types.SimpleNamespace(**kw)
@@ -216,6 +295,13 @@ def f_inject(name):
     arrs["g_fc_weight_sum"] = gG["fc.weight"].double().sum().numpy()
     arrs["g_fc_weight_abs"] = gG["fc.weight"].double().abs().sum().numpy()
     arrs.update(npd("gG/", {k: v for k, v in gG.items() if not k.startswith("fc.")}))
+    # the reference's torch.optim.Adam results (fc: first rows + checksums only, it is 4.2 M values)
+    arrs.update(npd("D1/", res["params_D_after"]))
+    G1 = res["params_G_after"]
+    arrs.update(npd("G1/", {k: v for k, v in G1.items() if not k.startswith("fc.")}))
+    arrs["G1_fc_bias"] = G1["fc.bias"].numpy()
+    arrs["G1_fc_weight_rows0_8"] = G1["fc.weight"][:8].numpy()
+    arrs["G1_fc_weight_sum"] = G1["fc.weight"].double().sum().numpy()
     np.savez_compressed(os.path.join(OUT, name), **arrs)
     print("wrote", name, "loss_G", float(res["loss_G"]), "dscale", float(gG["scale_param"]))
 
@@ -356,7 +442,44 @@ def f6(name):
     print("wrote", name)
 
 
+def f7(name, L=10):
+    """SatCLIP 'analytic' harmonics (the SphericalHarmonics default, positional_encoding/spherical_harmonics.py:10,24-25).
+    The tabulated file spherical_harmonics_ylm.py is absent from the reference tree (.MISSING_LARGE_BLOBS) but its generator
+    spherical_harmonics_generate_ylms.py is there.  That script prints all 101^2 functions at import, so only its
+    imports, the two sympy symbols and ``calc_ylm`` (:11-36) are executed here (taken from its AST, unmodified); each
+    function is then evaluated exactly as the generated file would: ``str(calc_ylm(l, m).evalf())`` with torch's cos / sin
+    in float64, through SphericalHarmonics.forward's loop (spherical_harmonics.py:26-42)."""
+    import ast
+    path = os.path.join(REF, "model", "satclip", "positional_encoding", "spherical_harmonics_generate_ylms.py")
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))
+            or (isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") in ("theta", "phi"))
+            or (isinstance(n, ast.FunctionDef) and n.name == "calc_ylm")]
+    env = {}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), env)
+    lonlat = torch.from_numpy(np.load(os.path.join(OUT, "f6_locenc.npz"))["lonlat"])
+    phi, theta = torch.deg2rad(lonlat[:, 0] + 180), torch.deg2rad(lonlat[:, 1] + 90)
+    Y = []
+    for l in range(L):
+        for m in range(-l, l + 1):
+            src = str(env["calc_ylm"](l, m).evalf())
+            y = eval(src, {"cos": torch.cos, "sin": torch.sin, "theta": theta, "phi": phi})
+            if isinstance(y, float):
+                y = y * torch.ones_like(phi)
+            Y.append(y)
+    Y = torch.stack(Y, dim=-1)
+    mine = O.spherical_harmonics(lonlat, L, "analytic")
+    close(mine, Y, 1e-12, f"analytic spherical harmonics L={L}")
+    cf = O.spherical_harmonics(lonlat, L, "closed-form")
+    print("analytic vs closed-form: max diff", float((Y - cf).abs().max()), "of", float(Y.abs().max()))
+    np.savez_compressed(os.path.join(OUT, name), lonlat=lonlat.numpy(), **{f"Y{L}": Y.numpy()})
+    print("wrote", name)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] in ("f1_legacy", "f7"):       # add one fixture without touching the others
+        {"f1_legacy": lambda: f1_legacy("f1_legacy.npz"), "f7": lambda: f7("f7_sh_analytic.npz")}[sys.argv[1]]()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "f6":       # add the location-encoder fixture without touching the others
         f6("f6_locenc.npz")
         sys.exit(0)
@@ -366,3 +489,5 @@ if __name__ == "__main__":
     f3("f3_losses.npz")
     f5("f5_fullsize.npz")
     f6("f6_locenc.npz")
+    f1_legacy("f1_legacy.npz")
+    f7("f7_sh_analytic.npz")

@@ -329,8 +329,10 @@ def calculate_metrics(pred: torch.Tensor, target: torch.Tensor, phase: str = "tr
 # SatCLIP location encoder, fp64 (load_lightweight.py:29).
 #   spherical_harmonics: positional_encoding/spherical_harmonics.py:26-42 with the closed-form SH of
 #     spherical_harmonics_closed_form.py:8-40 -- PINNED: oracle/make_golden.py imports that file and commits
-#     tests/golden/f6_locenc.npz.  The 'analytic' variant (spherical_harmonics_ylm.py) is missing from the reference
-#     tree; it tabulates the same functions.
+#     tests/golden/f6_locenc.npz.  The 'analytic' variant (spherical_harmonics_ylm.py, the default and what the published
+#     checkpoints record) is missing from the reference tree, but its generator spherical_harmonics_generate_ylms.py is there:
+#     it differs from closed-form by (-1)^m for m != 0 and by a factor pi for m == 0 (sh_factor) -- PINNED:
+#     make_golden.py::f7 evaluates the generator's calc_ylm (sympy) as the generated file would and commits f7_sh_analytic.npz.
 #   siren_forward: location_encoder.py:73-151 restated from the text -- the module is NOT importable
 #     (model/satclip/__init__.py pulls pytorch_lightning; positional_encoding/__init__.py needs the missing ylm file):
 #     parity UNPINNED for the MLP part; it is three F.linear + sin calls.
@@ -355,7 +357,23 @@ def _assoc_legendre(l: int, m: int, x: torch.Tensor) -> torch.Tensor:
     return pll
 
 
-def spherical_harmonics(lonlat: torch.Tensor, legendre_polys: int = 10) -> torch.Tensor:
+def sh_factor(l: int, m: int, calculation: str = "closed-form") -> float:
+    """Constant in front of P_l^|m|(cos theta) * {1, cos(m phi), sin(|m| phi)}; P carries the Condon-Shortley phase in both variants.
+
+    'closed-form' (spherical_harmonics_closed_form.py:25-40): sqrt2 (m != 0) * sqrt((2l+1)(l-|m|)! / (4 pi (l+|m|)!)).
+    'analytic' (spherical_harmonics_generate_ylms.py:19-36, the generator of the missing spherical_harmonics_ylm.py): the same
+    normalisation times (-1)**m for m != 0 (sympy's assoc_legendre already holds the phase, the script multiplies it in again),
+    and for m == 0 the script's ``sqrt((2*l + 1) / 4 * pi)`` = sqrt((2l+1) pi / 4) (operator precedence: pi is multiplied)."""
+    am = abs(m)
+    k = math.sqrt((2.0 * l + 1.0) * math.factorial(l - am) / (4 * math.pi * math.factorial(l + am)))
+    if calculation == "closed-form":
+        return k if m == 0 else math.sqrt(2.0) * k
+    if calculation == "analytic":
+        return math.sqrt((2 * l + 1) / 4 * math.pi) if m == 0 else (-1.0) ** am * math.sqrt(2.0) * k
+    raise NotImplementedError(calculation)
+
+
+def spherical_harmonics(lonlat: torch.Tensor, legendre_polys: int = 10, calculation: str = "closed-form") -> torch.Tensor:
     lon, lat = lonlat[:, 0], lonlat[:, 1]
     phi, theta = torch.deg2rad(lon + 180), torch.deg2rad(lat + 90)
     ct = torch.cos(theta)
@@ -363,13 +381,13 @@ def spherical_harmonics(lonlat: torch.Tensor, legendre_polys: int = 10) -> torch
     for l in range(legendre_polys):
         for m in range(-l, l + 1):
             am = abs(m)
-            k = math.sqrt((2.0 * l + 1.0) * math.factorial(l - am) / (4 * math.pi * math.factorial(l + am)))
+            k = sh_factor(l, m, calculation)
             if m == 0:
                 y = k * _assoc_legendre(l, 0, ct)
             elif m > 0:
-                y = math.sqrt(2.0) * k * torch.cos(m * phi) * _assoc_legendre(l, m, ct)
+                y = k * torch.cos(m * phi) * _assoc_legendre(l, m, ct)
             else:
-                y = math.sqrt(2.0) * k * torch.sin(-m * phi) * _assoc_legendre(l, am, ct)
+                y = k * torch.sin(-m * phi) * _assoc_legendre(l, am, ct)
             Y.append(y)
     return torch.stack(Y, dim=-1)
 
@@ -381,9 +399,10 @@ def siren_forward(p: Params, x: torch.Tensor, num_layers: int, w0: float = 1.0, 
     return F.linear(x, p["nnet.last_layer.weight"], p.get("nnet.last_layer.bias"))
 
 
-def location_encoder_forward(p: Params, lonlat: torch.Tensor, legendre_polys: int, num_layers: int) -> torch.Tensor:
+def location_encoder_forward(p: Params, lonlat: torch.Tensor, legendre_polys: int, num_layers: int,
+                             calculation: str = "closed-form") -> torch.Tensor:
     """LocationEncoder.forward (location_encoder.py:267-274) on fp64 lon/lat."""
-    return siren_forward(p, spherical_harmonics(lonlat.double(), legendre_polys), num_layers)
+    return siren_forward(p, spherical_harmonics(lonlat.double(), legendre_polys, calculation), num_layers)
 
 
 # --------------------------------------------------------------------------------------
@@ -495,7 +514,9 @@ class OracleTrainer:
 
     def __init__(self, pG: Params, pD: Params, n_blocks: int, padding: int = 0,
                  lr=2e-4, beta1=0.5, lambda_gan=1.0, lambda_l1=100.0, lambda_rs=0.0,
-                 rs_weights: Optional[dict] = None, rs_criterion="l1", inject_cfg: Optional[dict] = None, lambda_ssim: float = 0.0):
+                 rs_weights: Optional[dict] = None, rs_criterion="l1", inject_cfg: Optional[dict] = None, lambda_ssim: float = 0.0,
+                 d_loss_scale: float = 1.0):
+        self.d_loss_scale = d_loss_scale      # 0.5 = the legacy Pix2PixModel.backward_D (model/pix2pix_model.py:128)
         self.pG = {k: v.detach().clone().requires_grad_(True) for k, v in pG.items()}
         self.pD = {k: v.detach().clone().requires_grad_(True) for k, v in pD.items()}
         self.n_blocks, self.padding = n_blocks, padding
@@ -524,6 +545,7 @@ class OracleTrainer:
         # ---- optimizer_idx 0: discriminator
         pred = px_forward(self.pG, rgb, self.n_blocks, self.padding, embeds, self.inject_cfg)
         loss_d, lf, lr_ = d_step_loss(self.pD, rgb, nir, pred)
+        loss_d = loss_d * self.d_loss_scale if self.d_loss_scale != 1.0 else loss_d
         gD = torch.autograd.grad(loss_d, list(self.pD.values()))
         gD = dict(zip(self.pD.keys(), gD))
         self._adam(self.pD, gD)

@@ -425,15 +425,19 @@ def test_location_encoder_kernel(golden_dir, tmp_path):
     z = np.load(os.path.join(golden_dir, "f6_locenc.npz"))
     lonlat = torch.from_numpy(z["lonlat"]).to(DEV)
     for L_ in (10, 16):
-        close(SphericalHarmonics(L_).to(DEV)(lonlat).cpu().float(), torch.from_numpy(z[f"Y{L_}"]).float(), 1e-6, "harmonics")
-        assert (SphericalHarmonics(L_).to(DEV)(lonlat).cpu() - torch.from_numpy(z[f"Y{L_}"])).abs().max().item() < 1e-12
+        got = SphericalHarmonics(L_, "closed-form").to(DEV)(lonlat).cpu()
+        assert (got - torch.from_numpy(z[f"Y{L_}"])).abs().max().item() < 1e-12
+    # the default 'analytic' variant against the reference's generator script evaluated with sympy (fixture f7)
+    z7 = np.load(os.path.join(golden_dir, "f7_sh_analytic.npz"))
+    got = SphericalHarmonics(10).to(DEV)(lonlat).cpu()
+    assert (got - torch.from_numpy(z7["Y10"])).abs().max().item() < 1e-12
     torch.manual_seed(4)
     enc = LocationEncoder(get_positional_encoding("sphericalharmonics", 10, "analytic"), get_neural_network("siren", 100, 256, 512, 2)).double().eval().to(DEV)
     g = torch.Generator().manual_seed(9)
     ll = torch.stack((torch.rand(32, generator=g, dtype=torch.float64) * 360 - 180, torch.rand(32, generator=g, dtype=torch.float64) * 180 - 90), -1)
     got = enc(ll.to(DEV)).cpu()
     p = {"nnet." + k: v.detach().cpu() for k, v in enc.nnet.state_dict().items()}
-    ref = O.location_encoder_forward(p, ll, 10, 2)
+    ref = O.location_encoder_forward(p, ll, 10, 2, "analytic")
     assert got.dtype == torch.float64 and (got - ref).abs().max().item() < 1e-11 * max(ref.abs().max().item(), 1.0)
 
 

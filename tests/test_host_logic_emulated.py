@@ -498,8 +498,8 @@ def test_calculate_metrics_surface(emu):
         image_metrics_device(pred[:, :, :2, :2], target[:, :, :2, :2])      # smaller than the window radius
 
 
-def _locenc_checkpoint(z):
-    hp = {"le_type": "sphericalharmonics", "legendre_polys": 10, "harmonics_calculation": "analytic", "min_radius": 1,
+def _locenc_checkpoint(z, calculation="analytic"):
+    hp = {"le_type": "sphericalharmonics", "legendre_polys": 10, "harmonics_calculation": calculation, "min_radius": 1,
           "max_radius": 360, "frequency_num": 10, "pe_type": "siren", "embed_dim": 32, "capacity": 64, "num_hidden_layers": 2}
     sd = {"model.location." + k: v for k, v in sub(z, "siren/").items()}
     sd["model.visual.conv1.weight"] = torch.zeros(1)            # the rest of SatCLIP is ignored by the loader
@@ -517,7 +517,16 @@ def test_satclip_location_encoder_surface(emu, golden_dir, tmp_path):
     z = load(golden_dir, "f6_locenc.npz")
     lonlat = torch.from_numpy(z["lonlat"])
     for L_ in (10, 16):
-        close(SphericalHarmonics(L_)(lonlat), z[f"Y{L_}"], 1e-12, f"harmonics L={L_}")
+        close(SphericalHarmonics(L_, "closed-form")(lonlat), z[f"Y{L_}"], 1e-12, f"harmonics L={L_}")
+    # 'analytic' (the default; what published checkpoints record) is NOT closed-form: (-1)^m on m != 0, a factor pi on m == 0.
+    # Fixture f7 = the reference's generator script (sympy) evaluated as the tabulated file would be
+    z7 = load(golden_dir, "f7_sh_analytic.npz")
+    assert np.array_equal(z7["lonlat"], z["lonlat"])
+    ya = SphericalHarmonics(10)(lonlat)
+    close(ya, z7["Y10"], 1e-12, "analytic harmonics L=10")
+    assert abs(float(ya[0, 0]) - 0.886226925452758) < 1e-14 and (ya - torch.from_numpy(z["Y10"])).abs().max() > 1.0
+    with pytest.raises(NotImplementedError):
+        SphericalHarmonics(10, "discretized")
     net = get_neural_network("siren", 100, 32, 64, 2)
     assert sorted(net.state_dict()) == sorted(k[len("nnet."):] for k in sub(z, "siren/"))
     assert float(net.layers[0].weight.detach().abs().max()) <= 1 / 100 and net.layers[0].activation.w0 == 30.0
@@ -526,11 +535,14 @@ def test_satclip_location_encoder_surface(emu, golden_dir, tmp_path):
     enc = get_satclip_loc_encoder(str(path), "cpu")
     assert isinstance(enc, LocationEncoder) and not enc.training and enc.nnet.last_layer.weight.dtype == torch.float64
     out = enc(lonlat)
-    assert out.dtype == torch.float64
-    close(out, z["siren_out"], 1e-12, "encoder vs oracle")
+    assert out.dtype == torch.float64 and enc.posenc.harmonics_calculation == "analytic"
+    close(out, O.location_encoder_forward(sub(z, "siren/"), lonlat, 10, 2, "analytic"), 1e-12, "encoder vs oracle (analytic)")
+    path_cf = tmp_path / "satclip_cf.ckpt"
+    torch.save(_locenc_checkpoint(z, "closed-form"), path_cf)
+    close(get_satclip_loc_encoder(str(path_cf), "cpu")(lonlat), z["siren_out"], 1e-12, "encoder vs oracle (closed-form)")
     emb = SatClIP_wrapper(str(path), device="cpu").predict(lonlat.float())
     assert emb.dtype == torch.float32 and emb.shape == (lonlat.shape[0], 32) and not emb.requires_grad
-    close(emb, O.location_encoder_forward(sub(z, "siren/"), lonlat.float().double(), 10, 2).float(), 1e-6, "wrapper")
+    close(emb, O.location_encoder_forward(sub(z, "siren/"), lonlat.float().double(), 10, 2, "analytic").float(), 1e-6, "wrapper")
     with pytest.raises(NotImplementedError):
         get_positional_encoding("grid")
     with pytest.raises(NotImplementedError):
