@@ -263,7 +263,8 @@ int nirgan_lsgan(const float* pred, int64_t n, float target, float weight,
  * criterion 0 = l1, 1 = l2.  torch.nn.L1Loss model/pix2pix.py:60,222;
  * RemoteSensingIndices utils/remote_sensing_indices.py:23-71,84-319. */
 typedef struct {
-    const float* rgb; const float* nir; const float* pred;
+    const float* rgb;                     /* [B][3][H][W]; NULL = plain L1 on (pred, nir): every index weight 0, log_all 0 */
+    const float* nir; const float* pred;
     int B, H, W;
     float w_l1, w_ndvi, w_ndwi, w_gndvi, w_savi, w_msavi, w_evi;  /* already multiplied by lambda_rs */
     int criterion;

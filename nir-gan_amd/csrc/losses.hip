@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void pix_loss_kernel(const PixP p) {
     float acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
         const int64_t b = i / p.HW, px = i - b * p.HW;
-        const float R = p.rgb[(b * 3 + 0) * p.HW + px];
-        const float G = p.rgb[(b * 3 + 1) * p.HW + px];
-        const float Bl = p.rgb[(b * 3 + 2) * p.HW + px];
+        // rgb == nullptr: plain L1 (torch.nn.L1Loss on two single-band tensors); no index term is evaluated then
+        const float R = p.rgb ? p.rgb[(b * 3 + 0) * p.HW + px] : 0.f;
+        const float G = p.rgb ? p.rgb[(b * 3 + 1) * p.HW + px] : 0.f;
+        const float Bl = p.rgb ? p.rgb[(b * 3 + 2) * p.HW + px] : 0.f;
         const float x = p.nir[i], y = p.pred[i];
         float g = 0.f, v, dv;
         {   // L1 (torch.nn.L1Loss)
@@ -128,7 +129,9 @@ extern "C" int nirgan_lsgan(const float* pred, int64_t n, float target, float we
 }
 
 extern "C" int nirgan_pix_loss(const nirgan_pix_loss_desc* d, void* stream) {
-    NG_REQUIRE(d && d->rgb && d->nir && d->pred && d->sums, "pix_loss: null pointer");
+    NG_REQUIRE(d && d->nir && d->pred && d->sums, "pix_loss: null pointer");
+    NG_REQUIRE(d->rgb || (!d->log_all && d->w_ndvi == 0.f && d->w_ndwi == 0.f && d->w_gndvi == 0.f && d->w_savi == 0.f &&
+                          d->w_msavi == 0.f && d->w_evi == 0.f), "pix_loss: the spectral indices need rgb");
     NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0, "pix_loss: bad shape");
     NG_REQUIRE(d->criterion == 0 || d->criterion == 1, "pix_loss: criterion must be 0 (l1) or 1 (l2)");
     NG_REQUIRE(!d->extra || (d->extra_c >= 0 && d->extra_c < d->extra_cs), "pix_loss: extra channel out of range");

@@ -46,9 +46,11 @@ class HipL1Loss(torch.nn.Module):
     """torch.nn.L1Loss() for (prediction, target) NIR tiles on the fused HIP pixel-loss pass."""
 
     def forward(self, pred, target):
-        B, _, H, W = pred.shape
-        rgb = torch.zeros(B, 3, H, W, dtype=torch.float32, device=pred.device)
-        return HF.PixLossFn.apply(rgb, target, pred, (1.0, 0, 0, 0, 0, 0, 0), 0)
+        if pred.dim() != 4 or pred.shape != target.shape:
+            raise ValueError(f"HipL1Loss: prediction {tuple(pred.shape)} and target {tuple(target.shape)} must be equal 4-d shapes")
+        B, C, H, W = pred.shape
+        # the mean over all elements does not care how they are split over (B, C): any channel count runs as B*C planes
+        return HF.PixLossFn.apply(None, target.reshape(B * C, 1, H, W), pred.reshape(B * C, 1, H, W), (1.0, 0, 0, 0, 0, 0, 0), 0)
 
 
 class Px2Px_PL(_Base):

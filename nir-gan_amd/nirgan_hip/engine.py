@@ -102,6 +102,9 @@ class Halo:
         return self.t[:, p:p + self.H, p:p + self.W, :]
 
 
+HOOK = "__hook__"
+
+
 class Plan:
     def __init__(self, ctx: Ctx):
         self.ctx = ctx
@@ -111,6 +114,18 @@ class Plan:
 
     def add(self, name: str, *args):
         self.ops.append((name, args))
+
+    def insert_hook(self, index: int, fn) -> None:
+        """Host callback between two launches (data parallel: start a gradient bucket's all-reduce as soon as the launches
+        that complete it are on the stream).  ``index`` counts C-ABI ops; earlier hooks do not shift it."""
+        pos, seen = len(self.ops), 0
+        for j, (n, _) in enumerate(self.ops):
+            if n is not HOOK:
+                if seen == index:
+                    pos = j
+                    break
+                seen += 1
+        self.ops.insert(pos, (HOOK, (fn,)))
 
     def extend(self, other: "Plan"):
         self.ops.extend(other.ops)
@@ -149,12 +164,18 @@ class Plan:
         if self.probe_idx:
             return self._run_probed(be, st)
         for name, args in self.ops:
+            if name is HOOK:
+                args[0]()
+                continue
             rc = getattr(be, name)(*args, st)
             if rc != 0:
                 L.check(rc, name)
 
     def _run_probed(self, be, st):
         for i, (name, args) in enumerate(self.ops):
+            if name is HOOK:
+                args[0]()
+                continue
             if i in self.probe_idx:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()

@@ -3,8 +3,10 @@
 What the reference delegates to ``pytorch_lightning.Trainer.fit`` (train.py:118-136) and what of it touches the hot
 path: per batch the two optimizer passes (here ONE fused call, ``model.train_batch``), per epoch the validation scalars
 (``validation_step``: val/L1, val/L2, val/PSNR, val/SSIM) and ``ReduceLROnPlateau`` on ``config.Schedulers.metric``
-for both optimizers (model/pix2pix.py:485-492), plus a checkpoint whose ``state_dict`` has the reference's keys
-(train.py:61-65 / create_synthetic_dataset.py:24-26 load it with ``strict=False``).  Loggers, wandb, image plots and
+for both optimizers (model/pix2pix.py:485-492), plus a checkpoint in Lightning's layout: ``state_dict`` with the
+reference's keys (train.py:61-65 / create_synthetic_dataset.py:24-26 load it with ``strict=False``), ``optimizer_states``
+(both Adams: moments and step counts, torch.optim.Adam's format) and ``lr_schedulers`` (both ReduceLROnPlateau), so that
+``resume_from`` continues a run the way ``Trainer(resume_from_checkpoint=...)`` does (train.py:66-70,126).  Loggers, wandb, image plots and
 callbacks are out of scope.  Data parallel: pass a ``parallel.GradReducer`` (one process per GPU, RCCL); validation
 metrics are averaged over ranks when a process group is initialised.
 """
@@ -30,7 +32,7 @@ def _rank_mean(value: float, device) -> float:
 
 def fit(model, train_loader: Iterable[dict], val_loader: Optional[Iterable[dict]] = None, *, max_epochs: int = 1,
         device=None, reducer=None, log_every: int = 10, on_log: Optional[Callable[[Dict[str, float]], None]] = None,
-        ckpt_path: Optional[str] = None) -> Dict[str, list]:
+        ckpt_path: Optional[str] = None, resume_from: Optional[str] = None) -> Dict[str, list]:
     """Train ``model`` (model.pix2pix.Px2Px_PL).  Returns the history {'train': [...], 'val': [...], 'lr': [...]}."""
     device = device or next(model.parameters()).device
     trainer = model.fused_trainer(reducer=reducer)
@@ -38,8 +40,20 @@ def fit(model, train_loader: Iterable[dict], val_loader: Optional[Iterable[dict]
     sched_d, sched_g = scheds[0]["scheduler"], scheds[1]["scheduler"]
     monitor = scheds[0]["monitor"]
     history = {"train": [], "val": [], "lr": []}
-    step = 0
-    for epoch in range(max_epochs):
+    step, first_epoch = 0, 0
+    if resume_from is not None:
+        ck = torch.load(resume_from, map_location=device, weights_only=False)
+        model.load_state_dict(ck["state_dict"], strict=False)
+        trainer.flatG.touch()
+        trainer.flatD.touch()
+        if "optimizer_states" in ck:                     # order of configure_optimizers: [D, G] (pix2pix.py:490)
+            optim_d.load_state_dict(ck["optimizer_states"][0])
+            optim_g.load_state_dict(ck["optimizer_states"][1])
+            trainer.lr_d, trainer.lr_g = optim_d.param_groups[0]["lr"], optim_g.param_groups[0]["lr"]
+        for sch, sd in zip((sched_d, sched_g), ck.get("lr_schedulers", [])):
+            sch.load_state_dict(sd)
+        step, first_epoch = int(ck.get("global_step", 0)), int(ck.get("epoch", -1)) + 1
+    for epoch in range(first_epoch, max_epochs):
         model.train()
         for batch in train_loader:
             view = model.train_batch(_to_device(batch, device))
@@ -71,5 +85,7 @@ def fit(model, train_loader: Iterable[dict], val_loader: Optional[Iterable[dict]
         history["lr"].append({"epoch": epoch, "lr_d": trainer.lr if trainer.lr_d is None else trainer.lr_d,
                               "lr_g": trainer.lr if trainer.lr_g is None else trainer.lr_g})
         if ckpt_path is not None and (reducer is None or getattr(reducer, "rank", 0) == 0):
-            torch.save({"epoch": epoch, "global_step": step, "state_dict": model.state_dict()}, ckpt_path)
+            torch.save({"epoch": epoch, "global_step": step, "state_dict": model.state_dict(),
+                        "optimizer_states": [optim_d.state_dict(), optim_g.state_dict()],
+                        "lr_schedulers": [sched_d.state_dict(), sched_g.state_dict()]}, ckpt_path)
     return history

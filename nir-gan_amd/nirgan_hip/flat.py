@@ -36,10 +36,16 @@ class FlatParams:
             self.names.append(n)
             self.slices[n] = (off, p.numel(), p.shape)
             off += -(-p.numel() // 4) * 4
+        same_layout = getattr(self, "total", None) == off and self.m is not None
         self.total = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.m = self.v = None
+        # Adam moments follow the parameters across a re-bind (``.to(device)`` after training started); step_count stays with them
+        if same_layout:
+            self.m, self.v = self.m.to(dev).clone(), self.v.to(dev).clone()
+        else:
+            self.m = self.v = None
+            self.step_count = 0
         with torch.no_grad():
             for n, p in named:
                 o, k, shp = self.slices[n]
@@ -58,6 +64,18 @@ class FlatParams:
             return True
         return False
 
+    def touch(self) -> None:
+        """Parameter values were written behind the nn.Parameters' backs (broadcast, checkpoint copy into ``flat``): packed /
+        Winograd-domain weight caches keyed on values_version() must rebuild."""
+        self.version += 1
+
+    def moments(self):
+        """(m, v) of the fused Adam, allocated on first use."""
+        if self.m is None:
+            self.m = torch.zeros_like(self.flat)
+            self.v = torch.zeros_like(self.flat)
+        return self.m, self.v
+
     def param_views(self) -> Dict[str, torch.Tensor]:
         return {n: self.flat[o:o + k].view(s) for n, (o, k, s) in self.slices.items()}
 
@@ -70,9 +88,7 @@ class FlatParams:
 
     def adam_step(self, lr: float, beta1: float, beta2: float = 0.999, eps: float = 1e-8, stream=None):
         """torch.optim.Adam(lr, betas=(beta1, 0.999)) on the whole network (model/pix2pix.py:486-487)."""
-        if self.m is None:
-            self.m = torch.zeros_like(self.flat)
-            self.v = torch.zeros_like(self.flat)
+        self.moments()
         self.step_count += 1
         L.call("nirgan_adam", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                self.total, lr, beta1, beta2, eps, self.step_count, stream)

@@ -149,11 +149,13 @@ class PixLossFn(torch.autograd.Function):
     def forward(ctx, rgb, nir, pred, weights: Tuple[float, ...], criterion: int):
         _require_device(pred, "pixel losses")
         B, _, H, W = pred.shape
-        rgb_, nir_, pred_ = (t.detach().contiguous().float() for t in (rgb, nir, pred))
+        nir_, pred_ = (t.detach().contiguous().float() for t in (nir, pred))
+        rgb_ = None if rgb is None else rgb.detach().contiguous().float()      # None: plain L1 (no index term)
         sums = torch.zeros(8, dtype=torch.float32, device=pred_.device)
         grad = torch.empty_like(pred_)
         d = L.PixLossDesc()
-        d.rgb, d.nir, d.pred, d.B, d.H, d.W = rgb_.data_ptr(), nir_.data_ptr(), pred_.data_ptr(), B, H, W
+        d.rgb = None if rgb_ is None else rgb_.data_ptr()
+        d.nir, d.pred, d.B, d.H, d.W = nir_.data_ptr(), pred_.data_ptr(), B, H, W
         (d.w_l1, d.w_ndvi, d.w_ndwi, d.w_gndvi, d.w_savi, d.w_msavi, d.w_evi) = [float(w) for w in weights]
         d.criterion, d.log_all = criterion, 0
         d.sums, d.grad_pred = sums.data_ptr(), grad.data_ptr()

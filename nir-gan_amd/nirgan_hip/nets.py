@@ -231,6 +231,9 @@ class GeneratorEngine(_Engine):
                         gb=GW(i, "conv_block.5.bias"), dgrad_out=gq, act=L.ACT_NONE)
             c1.emit_bwd(b, pk, g=gq, g_fold=True, gw=GW(i, "conv_block.1.weight"), gb=GW(i, "conv_block.1.bias"), dgrad_out=gp)
             g_in, g_fold, g_skip = gp, True, skip_next
+        # data parallel: from here on the gradients of [first residual block .. last conv] are final (28 of 31 MB for 6 blocks)
+        first_tail = f"model.{lay['blocks'][0]}.conv_block.1.weight" if self.blocks else f"model.{i0}.weight"
+        self.bwd_tail = (len(b.ops), first_tail, f"model.{il}.bias")
         g_a2 = Halo(ctx, B, self.L2.OH, self.L2.OW, self.L2.cout, 0)
         self.L3.emit_bwd(b, pk, g=g_in, g_fold=g_fold, g2=g_skip, gw=GW(7), gb=GW(7, "bias"), dgrad_out=g_a2)
         g_a1 = Halo(ctx, B, self.L1.OH, self.L1.OW, self.L1.cout, 0)
@@ -314,6 +317,8 @@ class DiscriminatorEngine(_Engine):
                     plan.add("nirgan_fill", gr[k].data_ptr(), gr[k].numel(), 0.0)
             self.C5.emit_bwd(plan, pk, GW(11), GW(11, "bias"))
             self.C4.emit_bwd(plan, pk, g=self.C5.gin, g_fold=False, gw=GW(8), gb=GW(8, "bias"), dgrad_out=self.g3p)
+            if not frozen:   # data parallel: the two last layers' gradients (8.4 of 11 MB) are final here
+                self.bwd_tail = (len(plan.ops), "model.8.weight", "model.11.bias")
             self.C3.emit_bwd(plan, pk, g=self.g3p, g_fold=False, gw=GW(5), gb=GW(5, "bias"), dgrad_out=self.g2)
             self.C2.emit_bwd(plan, pk, g=self.g2, gw=GW(2), gb=GW(2, "bias"), dgrad_out=self.g1)
             self.C1.emit_bwd(plan, pk, g=self.g1, gw=GW(0), gb=GW(0, "bias"), dgrad_out=self.gx4 if mode == "input" else None)

@@ -3,6 +3,12 @@
 ``HipAdam(net.parameters(), lr, betas)`` has torch.optim.Adam's interface
 (model/pix2pix.py:486-487); ``step()`` gathers the autograd gradients into the network's flat
 gradient range and runs one nirgan_adam launch over the flat parameter range.
+
+The moments and the step count live in the network's ``FlatParams`` (shared with the fused
+``Pix2PixTrainer``).  ``state_dict()`` / ``load_state_dict()`` speak torch.optim.Adam's format
+(per parameter ``step``, ``exp_avg``, ``exp_avg_sq``; the param-group keys torch writes), so the
+``optimizer_states`` of a Lightning checkpoint (train.py:66-70,126 ``resume_from_checkpoint``)
+load here and a checkpoint written here loads into ``torch.optim.Adam``.
 """
 from __future__ import annotations
 
@@ -14,10 +20,64 @@ from .flat import FlatParams
 class HipAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, net: torch.nn.Module = None):
         params = list(params)
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # the extra keys are what torch.optim.Adam keeps in its param groups: written so that its load_state_dict accepts ours
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                                      capturable=False, differentiable=False, fused=None))
         if net is None:
             raise ValueError("HipAdam needs net= (the module whose parameters it owns)")
+        if len(self.param_groups) != 1:
+            raise ValueError("HipAdam runs one launch over the whole network: a single param group")
         self.net = net
+        named = {id(p): n for n, p in net.named_parameters()}
+        self._names = [named[id(p)] for p in self.param_groups[0]["params"]]
+        if len(self._names) != len(named):
+            raise ValueError("HipAdam must own every parameter of net (the fused kernel updates the flat range)")
+
+    # ------------------------------------------------------------------ state <-> flat moments
+    def _bind_state(self) -> None:
+        """self.state[p] = views into the flat moments (nothing before the first step, like torch)."""
+        flat: FlatParams = self.net._flat()
+        self.state.clear()
+        if flat.step_count == 0 or flat.m is None:
+            return
+        for n, p in zip(self._names, self.param_groups[0]["params"]):
+            o, k, shp = flat.slices[n]
+            self.state[p] = {"step": torch.tensor(float(flat.step_count)),
+                             "exp_avg": flat.m[o:o + k].view(shp), "exp_avg_sq": flat.v[o:o + k].view(shp)}
+
+    def state_dict(self):
+        self._bind_state()
+        sd = super().state_dict()
+        # snapshots, not live views of the flat range
+        sd["state"] = {i: {k: v.detach().clone() for k, v in st.items()} for i, st in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)       # casts to the parameters' device / dtype, restores lr & betas
+        flat: FlatParams = self.net._flat()
+        loaded = dict(self.state)
+        if loaded:
+            m, v = flat.moments()
+            m.zero_()
+            v.zero_()
+            steps = set()
+            for n, p in zip(self._names, self.param_groups[0]["params"]):
+                st = loaded.get(p)
+                if st is None:
+                    continue
+                o, k, _ = flat.slices[n]
+                m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) != 1:
+                raise ValueError(f"HipAdam keeps one step count per network; the checkpoint has {sorted(steps)}")
+            flat.step_count = steps.pop()
+        else:
+            flat.step_count = 0
+            if flat.m is not None:
+                flat.m.zero_()
+                flat.v.zero_()
+        self._bind_state()
 
     @torch.no_grad()
     def step(self, closure=None):

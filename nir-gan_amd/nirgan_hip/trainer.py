@@ -93,6 +93,27 @@ class _ShapeState:
             self.micros.append(_Micro(tr, i * per, (i + 1) * per, H, W, gG, gD, 1.0 / n))
         dev = tr.flatG.flat.device
         self.streams = [None] + [torch.cuda.Stream(dev) if dev.type == "cuda" else None for _ in range(n - 1)]
+        # data parallel, single part: two gradient buckets per network -- the tail of the flat gradient goes to RCCL from inside
+        # the backward plan, as soon as the launches that complete it are on the stream (parallel.GradReducer.begin); the head
+        # follows after the plan.  With micro-batches the side parts are added after the plans: one bucket, after the join.
+        self.bucketed = tr.reducer is not None and n == 1
+        self.headD = self.headG = None
+        if self.bucketed:
+            m = self.micros[0]
+            self.headD = self._hook_tail(tr, m.D2, tr.flatD)
+            self.headG = self._hook_tail(tr, m.G, tr.flatG)
+
+    @staticmethod
+    def _hook_tail(tr, eng, flat):
+        """Insert the tail bucket's ``begin`` into eng.bwd; returns the complementary slices of the flat gradient."""
+        index, first, last = eng.bwd_tail
+        lo = flat.slices[first][0]
+        o, k, _ = flat.slices[last]
+        hi = min(flat.total, o + -(-k // 4) * 4)
+        assert 0 <= lo < hi <= flat.total
+        tail = flat.grad[lo:hi]
+        eng.bwd.insert_hook(index, lambda: tr.reducer.begin(tail))
+        return [part for part in (flat.grad[:lo], flat.grad[hi:]) if part.numel()]
 
 
 class _on_stream:
@@ -136,6 +157,18 @@ class Pix2PixTrainer:
         self._shape = None
         self.losses = None
         self.steps = 0
+        self._synced_ptrs = None
+
+    def _sync_initial_weights(self):
+        """What DDP does when it wraps a module (the reference: Lightning strategy "ddp", train.py:118-120): every rank starts
+        from rank 0's parameters.  Redone when the flat ranges were re-materialised (``.to(device)``)."""
+        if self.reducer is None:
+            return
+        ptrs = (self.flatG.flat.data_ptr(), self.flatD.flat.data_ptr())
+        if ptrs != self._synced_ptrs:
+            self.reducer.broadcast_params(self.flatG)
+            self.reducer.broadcast_params(self.flatD)
+            self._synced_ptrs = ptrs
 
     def _micro_count(self, B, H, W) -> int:
         n = self.micro_batches
@@ -146,6 +179,7 @@ class Pix2PixTrainer:
     # ------------------------------------------------------------------ engines for one shape
     def _prepare(self, B, H, W):
         rebuilt = self.flatG.ensure() | self.flatD.ensure()
+        self._sync_initial_weights()
         if rebuilt:
             self._states.clear()          # the flat ranges moved: every descriptor holds stale pointers
         if self.losses is None or rebuilt:
@@ -202,6 +236,17 @@ class Pix2PixTrainer:
         for buf in extras:
             L.call("nirgan_axpy", flat.grad.data_ptr(), buf.data_ptr(), flat.total, 1.0, st)
 
+    def _reduce(self, state: _ShapeState, flat: FlatParams, head):
+        """Average the network's gradient over the ranks before its Adam step (DDP's all-reduce during backward)."""
+        if self.reducer is None:
+            return
+        if state.bucketed:
+            for part in head:                 # the tail bucket has been in flight since the middle of the backward plan
+                self.reducer.begin(part)
+            self.reducer.finish()
+        else:
+            self.reducer.all_reduce_mean(flat.grad)
+
     # ------------------------------------------------------------------ one batch
     def step(self, rgb: torch.Tensor, nir: torch.Tensor, embeds: Optional[torch.Tensor] = None) -> "LossView":
         B, _, H, W = rgb.shape
@@ -218,8 +263,7 @@ class Pix2PixTrainer:
             with _on_stream(s):
                 self._d_pass(m, None if embeds is None else embeds[m.lo:m.hi])
         self._join(state, self.flatD, state.extraD)
-        if self.reducer is not None:
-            self.reducer.all_reduce_mean(self.flatD.grad)
+        self._reduce(state, self.flatD, state.headD)
         self.flatD.adam_step(self.lr if self.lr_d is None else self.lr_d, self.beta1, stream=st)
         # ---- optimizer 1: generator against the updated, frozen discriminator
         self._fork(state)
@@ -227,8 +271,7 @@ class Pix2PixTrainer:
             with _on_stream(s):
                 self._g_pass(m)
         self._join(state, self.flatG, state.extraG)
-        if self.reducer is not None:
-            self.reducer.all_reduce_mean(self.flatG.grad)
+        self._reduce(state, self.flatG, state.headG)
         self.flatG.adam_step(self.lr if self.lr_g is None else self.lr_g, self.beta1, stream=st)
         self.steps += 1
         return LossView(self, B * H * W)

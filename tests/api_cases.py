@@ -1,0 +1,376 @@
+"""Bodies of the API-level parity tests, shared by the CPU suite (C ABI served by the numpy emulator:
+tests/test_api_emulated.py) and the MI355X suite (the HIP library: tests/test_gpu_api.py).
+
+They drive the classes the reference's scripts drive -- ``Px2Px_PL`` exactly as Lightning 1.9's two-optimizer loop
+does (training_step(batch, i, 0) -> backward -> optimizer_D.step -> toggle -> training_step(batch, i, 1) -> backward ->
+optimizer_G.step; model/pix2pix.py:165-257, :485-492), ``Pix2PixModel.optimize_parameters``
+(model/pix2pix_model.py:100-154), the Lightning-free ``fit`` loop, tiled inference and checkpoint loading
+(create_synthetic_dataset.py:21-28,100-118) -- and compare with the golden vectors of the reference itself:
+losses, every non-shadowed gradient and the parameters after the reference's ``torch.optim.Adam`` steps.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nirgan_oracle as O
+
+RS_W = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333, "lambda_savi": 0.0, "lambda_msavi": 0.0,
+        "lambda_gndvi": 0.0}
+
+
+class Tol:
+    """out: outputs / losses (max error relative to the reference's max); grad: (rel-L2, max-rel) per gradient tensor."""
+
+    def __init__(self, out, grad_l2, grad_max):
+        self.out, self.grad_l2, self.grad_max = out, grad_l2, grad_max
+
+
+CPU_TOL = Tol(2e-5, 1e-4, 2e-4)       # numpy emulator: same arithmetic as the oracle up to summation order
+GPU_TOL = Tol(1e-3, 1e-3, 1e-2)       # BASELINE.json: 1e-3 relative fp32 (measured 1e-6..1e-5)
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    return {k: z[k] for k in z.files}
+
+
+def sub(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(v.copy()) for k, v in z.items() if k.startswith(prefix)}
+
+
+def close(a, b, tol, what=""):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what + ": non-finite"
+    err, ref = (a - b).abs().max().item(), b.abs().max().item()
+    assert err <= tol * max(ref, 1e-20), f"{what}: err {err:.3e} ref {ref:.3e}"
+
+
+def grad_close(a, b, tol: Tol, what):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    assert a.shape == b.shape and torch.isfinite(a).all(), what
+    nrm, mx = b.norm().item(), b.abs().max().item()
+    e2, em = (a - b).norm().item(), (a - b).abs().max().item()
+    assert e2 <= tol.grad_l2 * max(nrm, 1e-20), f"{what}: rel L2 {e2 / max(nrm, 1e-20):.3e}"
+    assert em <= tol.grad_max * max(mx, 1e-20), f"{what}: max err {em:.3e} of {mx:.3e}"
+
+
+def adam_close(p_new, p_ref, g_ref, what, lr=2e-4):
+    """Parameters after the FIRST Adam step against the reference's torch.optim.Adam result.  The first step is
+    p - lr * g / (|g| + eps'): +-lr wherever |g| >> 1e-8, so the comparison is tight (1e-5 of max|p|, i.e. ~2 % of one
+    step) on every element whose reference gradient has a definite sign, and bounded by one step elsewhere (an element
+    whose gradient is rounding noise may step the other way in two correct fp32 evaluations)."""
+    p_new, p_ref, g_ref = (torch.as_tensor(t).detach().float().cpu() for t in (p_new, p_ref, g_ref))
+    assert p_new.shape == p_ref.shape and torch.isfinite(p_new).all(), what
+    live = g_ref.abs() > 1e-4 * g_ref.abs().max().clamp_min(1e-30)
+    zero = g_ref == 0                                     # e.g. fc rows no resized pixel reads: parameter untouched
+    d = (p_new - p_ref).abs()
+    assert live.sum().item() >= 0.9 * (~zero).sum().item() or g_ref.numel() < 16, f"{what}: gradient mostly noise?"
+    tight = max(1e-5 * p_ref.abs().max().item(), 0.02 * lr)
+    assert (d * live).max().item() <= tight, f"{what}: {(d * live).max().item():.3e} > {tight:.3e}"
+    assert (d * zero).max().item() <= 1e-7, f"{what}: a parameter with zero gradient moved"
+    assert d.max().item() <= 2.0 * lr * 1.001 + 1e-7, f"{what}: moved by more than a step: {d.max().item():.3e}"
+
+
+def regen_fc(z):
+    g = torch.Generator().manual_seed(int(z["fc_seed"]))
+    return torch.randn(16384, 256, generator=g) * 0.02, torch.randn(16384, generator=g) * 0.02
+
+
+def px_config(n_blocks=6, ngf=8, padding=0, lambda_rs=0.0, inject=False, patience_g=25, patience_d=25, lambda_ssim=0.0):
+    """The keys of configs/config_px2px.yaml / config_px2px_SatCLIP.yaml that the hot path reads, small widths."""
+    from utils.config import to_attr
+    return to_attr({
+        "base_configs": {"isTrain": True, "input_nc": 3, "output_nc": 1, "ngf": ngf, "ndf": ngf, "netD": "basic",
+                         "netG": f"resnet_{n_blocks}blocks", "norm": "instance", "no_dropout": True, "init_type": "normal",
+                         "init_gain": 0.02, "n_layers_D": 3, "gan_mode": "lsgan", "lr": 0.0002, "beta1": 0.5, "direction": "AtoB",
+                         "lambda_GAN": 1.0, "lambda_L1": 100.0, "lambda_ssim": lambda_ssim, "lambda_hist": 0.0,
+                         "lambda_rs_losses": lambda_rs, "rs_losses_criterium": "l1", "internal_rs_loss_weights": dict(RS_W)},
+        "satclip": {"use_satclip": bool(inject), "satclip_style": "inject", "satclip_inject_style": "multiply",
+                    "scaling_param": True, "scaling_param_init": 0.01, "post_correction": False, "post_correction_init": 1.0},
+        "Schedulers": {"metric": "val/L1", "patience_g": patience_g, "patience_d": patience_d},
+        "custom_configs": {"Logging": {"num_val_images": 0, "log_input_stats": False}},
+        "Data": {"padding": padding > 0, "padding_amount": padding}})
+
+
+def _load_golden_weights(m, z, inject):
+    sd = {"netG." + k: v for k, v in sub(z, "G0/").items()}
+    if inject:
+        sd["netG.fc.weight"], sd["netG.fc.bias"] = regen_fc(z)
+    sd.update({"netD." + k: v for k, v in sub(z, "D0/").items()})
+    res = m.load_state_dict(sd, strict=False)
+    assert not [k for k in res.missing_keys if k.startswith(("netG.", "netD."))], res.missing_keys
+    assert not res.unexpected_keys
+
+
+# ------------------------------------------------------------------------------------------------ a9: Px2Px_PL
+def px2px_pl_lightning_sequence(dev, golden_dir, name, tol: Tol):
+    from model.pix2pix import Px2Px_PL
+    z = load(golden_dir, name)
+    inject = "embeds" in z
+    nb = 9 if inject else int(z["n_blocks"])
+    pad = 0 if inject else int(z["padding"])
+    lam_rs = 0.0 if inject else float(z["lambda_rs"])
+    m = Px2Px_PL(px_config(nb, 8, pad, lam_rs, inject))
+    _load_golden_weights(m, z, inject)
+    m = m.to(dev)
+    batch = {"rgb": torch.from_numpy(z["rgb"]).to(dev), "nir": torch.from_numpy(z["nir"]).to(dev)}
+    if inject:
+        batch["coords"] = torch.from_numpy(z["embeds"]).to(dev)      # B x 256: precomputed SatCLIP embeddings (pix2pix.py:509-526)
+    shadowG, shadowD = O.shadowed_bias_keys("G", nb), O.shadowed_bias_keys("D")
+
+    # predict_step: eval mode only (pix2pix.py:135), pad -> G -> crop
+    with pytest.raises(AssertionError):
+        m.train().predict_step(batch["rgb"])
+    m.eval()
+    p = m.predict_step(batch["rgb"], batch["coords"]) if inject else m.predict_step(batch["rgb"])
+    assert p.shape == z["pred"].shape and not p.requires_grad
+    close(p, z["pred"], tol.out, "predict_step")
+    with pytest.raises(AssertionError):
+        m.training_step(batch, 0, 0)
+    m.train()
+
+    (opt_d, opt_g), scheds = m.configure_optimizers()                # [D, G]: optimizer_idx 0 = D (pix2pix.py:490)
+    assert opt_d.net is m.netD and opt_g.net is m.netG and len(scheds) == 2
+    # ---- optimizer_idx 0
+    loss_d = m.training_step(batch, 0, 0)
+    close(loss_d, z["loss_D"], tol.out, "loss_D")
+    if "loss_D_fake" in z:
+        close(m.logged["model_loss/discriminator_fake"], z["loss_D_fake"], tol.out, "loss_D_fake")
+        close(m.logged["model_loss/discriminator_real"], z["loss_D_real"], tol.out, "loss_D_real")
+    opt_d.zero_grad()
+    loss_d.backward()
+    assert all(q.grad is None for q in m.netG.parameters()), "the D step must not reach the generator (fake_AB.detach())"
+    for k, q in m.netD.named_parameters():
+        if k not in shadowD and "gD/" + k in z:
+            grad_close(q.grad, z["gD/" + k], tol, "gD " + k)
+    opt_d.step()
+    if "D1/model.0.weight" in z:
+        for k, q in m.netD.named_parameters():
+            if k not in shadowD:
+                adam_close(q, z["D1/" + k], z["gD/" + k] if "gD/" + k in z else q.grad, "D1 " + k)
+    # ---- optimizer_idx 1 (Lightning's toggle_optimizer: the other optimizer's parameters are frozen)
+    for q in m.netD.parameters():
+        q.requires_grad_(False)
+    loss_g = m.training_step(batch, 0, 1)
+    close(loss_g, z["loss_G"], tol.out, "loss_G")
+    close(m.logged["model_loss/generator_GAN_loss"], z["loss_G_gan"], tol.out, "loss_G_gan")
+    close(m.logged["model_loss/generator_L1"], z["loss_G_l1"], tol.out, "loss_G_l1")
+    if lam_rs > 0:
+        close(m.logged["model_loss/indices_loss_weighted"], z["loss_G_rs"], tol.out, "loss_G_rs")
+    opt_g.zero_grad()
+    loss_g.backward()
+    gG = sub(z, "gG/")
+    if inject:
+        gG["scale_param"], gG["fc.bias"] = torch.from_numpy(z["g_scale_param"]), torch.from_numpy(z["g_fc_bias"])
+    for k, q in m.netG.named_parameters():
+        if k in shadowG:
+            continue
+        if k == "fc.weight":
+            grad_close(q.grad[:8], z["g_fc_weight_rows0_8"], tol, "gG fc.weight[:8]")
+            s = float(q.grad.double().sum())
+            assert abs(s - float(z["g_fc_weight_sum"])) <= 1e-3 * float(z["g_fc_weight_abs"]) * tol.grad_max
+        else:
+            grad_close(q.grad, gG[k], tol, "gG " + k)
+    opt_g.step()
+    for q in m.netD.parameters():
+        q.requires_grad_(True)
+    if "G1/model.1.weight" in z:
+        for k, q in m.netG.named_parameters():
+            if k in shadowG:
+                continue
+            if k == "fc.weight":
+                adam_close(q[:8], z["G1_fc_weight_rows0_8"], z["g_fc_weight_rows0_8"], "G1 fc.weight[:8]")
+            elif k == "fc.bias":
+                adam_close(q, z["G1_fc_bias"], z["g_fc_bias"], "G1 fc.bias")
+            else:
+                adam_close(q, z["G1/" + k], gG[k], "G1 " + k)
+    # the optimizers' state is torch.optim.Adam's: one step taken, moments = (1-b) * g  (and it round-trips)
+    sd = opt_g.state_dict()
+    assert len(sd["state"]) == len(list(m.netG.parameters())) and float(sd["state"][0]["step"]) == 1.0
+    names = [n for n, _ in m.netG.named_parameters()]
+    i = names.index("model.1.weight")
+    close(sd["state"][i]["exp_avg"], 0.5 * m.netG.model[1].weight.grad, 1e-6, "exp_avg")
+    return m, batch, z
+
+
+def px2px_pl_train_batch(dev, golden_dir, name, tol: Tol):
+    """The fused path of the same class: train_batch = both optimizer passes in one call; same golden vectors."""
+    from model.pix2pix import Px2Px_PL
+    z = load(golden_dir, name)
+    nb, pad, lam_rs = int(z["n_blocks"]), int(z["padding"]), float(z["lambda_rs"])
+    m = Px2Px_PL(px_config(nb, 8, pad, lam_rs))
+    _load_golden_weights(m, z, False)
+    m = m.to(dev).train()
+    batch = {"rgb": torch.from_numpy(z["rgb"]).to(dev), "nir": torch.from_numpy(z["nir"]).to(dev)}
+    out = m.train_batch(batch).as_dict()
+    for k in ("loss_D", "loss_G", "loss_G_gan", "loss_G_l1"):
+        close(out[k], z[k], tol.out, k)
+    tr = m.fused_trainer()
+    close(tr.pred, z["pred"], tol.out, "pred")
+    gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
+    for k, q in m.netD.named_parameters():
+        if k not in O.shadowed_bias_keys("D"):
+            grad_close(gD[k], z["gD/" + k], tol, "gD " + k)
+            adam_close(q, z["D1/" + k], z["gD/" + k], "D1 " + k)
+    for k, q in m.netG.named_parameters():
+        if k not in O.shadowed_bias_keys("G", nb):
+            grad_close(gG[k], z["gG/" + k], tol, "gG " + k)
+            adam_close(q, z["G1/" + k], z["gG/" + k], "G1 " + k)
+    # HipAdam built afterwards sees the fused steps' state (shared flat moments)
+    (opt_d, opt_g), _ = m.configure_optimizers()
+    assert float(opt_d.state_dict()["state"][0]["step"]) == 1.0 and float(opt_g.state_dict()["state"][0]["step"]) == 1.0
+
+
+# ------------------------------------------------------------------------------------------------ a10: Pix2PixModel
+def pix2pix_model_optimize_parameters(dev, golden_dir, tol: Tol):
+    from model.pix2pix_model import Pix2PixModel
+    base, z = load(golden_dir, "f1_g6_d.npz"), load(golden_dir, "f1_legacy.npz")
+    assert str(z["base"]) == "f1_g6_d.npz"
+    model = Pix2PixModel(px_config(6, 8))
+    model.netG.load_state_dict(sub(base, "G0/"))
+    model.netD.load_state_dict(sub(base, "D0/"))
+    model.to(dev)
+    model.set_input({"A": torch.from_numpy(base["rgb"]).to(dev), "B": torch.from_numpy(base["nir"]).to(dev)})
+    assert model.real_A.shape[1] == 3 and model.real_B.shape[1] == 1
+    model.optimize_parameters()
+    close(model.fake_B, z["fake_B"], tol.out, "fake_B")
+    close(model.loss_D, z["loss_D"], tol.out, "loss_D (x0.5)")
+    close(model.loss_D_fake, z["loss_D_fake"], tol.out, "loss_D_fake")
+    close(model.loss_D_real, z["loss_D_real"], tol.out, "loss_D_real")
+    close(model.loss_G_GAN, z["loss_G_GAN"], tol.out, "loss_G_GAN")
+    close(model.loss_G_L1, z["loss_G_L1"], tol.out, "loss_G_L1 (x lambda_L1)")
+    close(model.loss_G, z["loss_G"], tol.out, "loss_G")
+    # 0.5 * (the Lightning module's loss_D): pix2pix_model.py:128 vs pix2pix.py:206
+    close(2.0 * model.loss_D, base["loss_D"], tol.out, "factor 0.5")
+    for k, q in model.netD.named_parameters():
+        assert not q.requires_grad                      # left frozen after the G update (pix2pix_model.py:151)
+        if k not in O.shadowed_bias_keys("D"):
+            grad_close(q.grad, z["gD/" + k], tol, "gD " + k)
+            adam_close(q, z["D1/" + k], z["gD/" + k], "D1 " + k)
+    for k, q in model.netG.named_parameters():
+        if k not in O.shadowed_bias_keys("G", 6):
+            grad_close(q.grad, z["gG/" + k], tol, "gG " + k)
+            adam_close(q, z["G1/" + k], z["gG/" + k], "G1 " + k)
+    model.optimize_parameters()                         # a second batch runs (D re-enabled, grads zeroed, state kept)
+    assert np.isfinite(float(model.loss_G.detach())) and np.isfinite(float(model.loss_D.detach()))
+    assert float(model.optimizer_G.state_dict()["state"][0]["step"]) == 2.0
+
+
+# ------------------------------------------------------------------------------------------------ N4: fit loop
+def _loaders(dev, n_train=2, n_val=1, size=32, seed=1):
+    g = torch.Generator().manual_seed(seed)
+
+    def mk():
+        return {"rgb": 0.02 + 0.58 * torch.rand(2, 3, size, size, generator=g), "nir": 0.05 + 0.75 * torch.rand(2, 1, size, size, generator=g)}
+    return [mk() for _ in range(n_train)], [mk() for _ in range(n_val)]
+
+
+def fit_loop_schedulers_checkpoint_resume(dev, tmp_path, tol: Tol):
+    """fit(): LR drops decided by ReduceLROnPlateau reach both fused Adam steps; the checkpoint has Lightning's layout
+    (state_dict / optimizer_states / lr_schedulers) and a resumed run continues exactly like the uninterrupted one."""
+    from model.pix2pix import Px2Px_PL
+    from nirgan_hip.fit import fit
+    cfg = px_config(6, 8, patience_g=0, patience_d=0)
+
+    def fresh():
+        torch.manual_seed(0)
+        return Px2Px_PL(cfg).to(dev)
+    train, val = _loaders(dev)
+    # patience 0 + 'min' mode: any epoch that does not improve val/L1 by > 1e-4 relative cuts the lr by 10
+    m_full = fresh()
+    ck3 = tmp_path / "full.ckpt"
+    hist = fit(m_full, train, val, max_epochs=3, log_every=1, ckpt_path=str(ck3), device=dev)
+    assert len(hist["train"]) == 6 and len(hist["val"]) == 3 and {"val/L1", "val/L2", "val/PSNR", "val/SSIM"} <= set(hist["val"][0])
+    tr = m_full.fused_trainer()
+    assert tr.steps == 6 and tr.flatG.step_count == 6 and tr.flatD.step_count == 6
+    # validation scalars against the oracle's metrics on the model's own prediction
+    m_full.eval()
+    p = m_full.predict_step(val[0]["rgb"].to(dev)).cpu()
+    ref = O.calculate_metrics(p, val[0]["nir"], "val")
+    m_full.logged.clear()
+    m_full.validation_step({k: v.to(dev) for k, v in val[0].items()}, 0)
+    for k in ("val/L1", "val/L2", "val/PSNR", "val/SSIM"):
+        assert abs(float(m_full.logged[k]) - ref[k]) <= 1e-4 * abs(ref[k]) + 1e-7, k
+    # whatever the schedulers decided is what the fused steps use
+    last = hist["lr"][-1]
+    assert tr.lr_g == last["lr_g"] and tr.lr_d == last["lr_d"] and last["lr_g"] <= 2e-4
+    vals = [h["val/L1"] for h in hist["val"]]
+    expect = 2e-4
+    best = float("inf")
+    for v in vals:                                   # ReduceLROnPlateau(mode='min', patience=0, factor=0.1, threshold=1e-4 rel)
+        if v < best * (1 - 1e-4):
+            best = v
+        else:
+            expect *= 0.1
+    assert abs(last["lr_g"] - expect) <= 1e-12 and abs(last["lr_d"] - expect) <= 1e-12
+    # checkpoint layout + strict=False load the way train.py:61-65 / create_synthetic_dataset.py:24-26 do
+    ck = torch.load(str(ck3), weights_only=False)
+    assert {"state_dict", "optimizer_states", "lr_schedulers", "epoch", "global_step"} <= set(ck)
+    assert "netG.model.1.weight" in ck["state_dict"] and "netD.model.11.bias" in ck["state_dict"] and "criterionGAN.real_label" in ck["state_dict"]
+    assert float(ck["optimizer_states"][0]["state"][0]["step"]) == 6.0
+    m2 = fresh()
+    res = m2.load_state_dict(ck["state_dict"], strict=False)
+    assert not res.missing_keys
+    close(m2.netG.model[1].weight, m_full.netG.model[1].weight, 0.0, "reloaded weights")
+    # interrupted after 2 epochs + resumed == uninterrupted (weights, Adam moments, step counts, scheduler state)
+    m_a = fresh()
+    ck2 = tmp_path / "two.ckpt"
+    fit(m_a, train, val, max_epochs=2, log_every=0, ckpt_path=str(ck2), device=dev)
+    m_b = fresh()
+    with torch.no_grad():
+        for q in m_b.parameters():
+            q.add_(0.123)                               # everything must come from the checkpoint
+    hist_b = fit(m_b, train, val, max_epochs=3, log_every=0, resume_from=str(ck2), device=dev)
+    assert len(hist_b["val"]) == 1 and hist_b["lr"][-1] == hist["lr"][-1]
+    trb = m_b.fused_trainer()
+    assert trb.flatG.step_count == 6 and trb.flatD.step_count == 6
+    for (k, qa), (_, qb) in zip(m_full.named_parameters(), m_b.named_parameters()):
+        close(qb, qa, 1e-6, "resumed " + k)
+    close(trb.flatG.m, tr.flatG.m, 1e-5, "resumed exp_avg")
+    close(trb.flatG.v, tr.flatG.v, 1e-5, "resumed exp_avg_sq")
+    # torch.optim.Adam accepts the optimizer state written here (a Lightning resume with the stock optimizer)
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(q, device="cpu")) for q in m_full.netG.parameters()],
+                               lr=2e-4, betas=(0.5, 0.999))
+    ref_opt.load_state_dict(ck["optimizer_states"][1])
+    assert ref_opt.param_groups[0]["lr"] == last["lr_g"]
+
+
+# ------------------------------------------------------------------------------------------------ N1: inference
+def tiled_inference_and_checkpoint_loading(dev, golden_dir, tmp_path, tol: Tol):
+    """create_synthetic_dataset.py:21-28,100-118: load a Lightning checkpoint with strict=False, eval, model(hr) under
+    no_grad; predict_tiled on a scene that is no multiple of the tile core, against the oracle run through the same
+    tiling; fp16 .npz writer."""
+    from model.pix2pix import Px2Px_PL
+    from nirgan_hip.inference import predict_tiled, save_nir_npz
+    z = load(golden_dir, "f1_g9_rs_pad.npz")
+    pad = int(z["padding"])
+    ck = {"state_dict": {**{"netG." + k: v for k, v in sub(z, "G0/").items()}, **{"netD." + k: v for k, v in sub(z, "D0/").items()},
+                         "criterionGAN.real_label": torch.tensor(1.0), "criterionGAN.fake_label": torch.tensor(0.0),
+                         "satclip_model.model.nnet.last_layer.weight": torch.zeros(3)},      # unexpected key: strict=False tolerates it
+          "epoch": 3, "global_step": 7, "pytorch-lightning_version": "1.9.0"}
+    path = tmp_path / "S2.ckpt"
+    torch.save(ck, str(path))
+    torch.manual_seed(5)
+    model = Px2Px_PL(px_config(9, 8, pad, 1.0))
+    res = model.load_state_dict(torch.load(str(path), weights_only=False)["state_dict"], strict=False)
+    assert res.unexpected_keys == ["satclip_model.model.nnet.last_layer.weight"] and not res.missing_keys
+    model = model.eval().to(dev)
+    hr = torch.from_numpy(z["rgb"])
+    with torch.no_grad():
+        pred = model(hr.to(dev))
+    close(pred, z["pred"], tol.out, "model(hr) after checkpoint load")
+    # tiled: 70 x 90 scene, 32-pixel tiles with 8 pixels of context per side (core 16: neither 70 nor 90 is a multiple)
+    g = torch.Generator().manual_seed(11)
+    scene = 0.02 + 0.58 * torch.rand(2, 3, 70, 90, generator=g)
+    pG = sub(z, "G0/")
+    got = predict_tiled(model, scene.to(dev), tile=32, margin=8, batch=5)
+    want = predict_tiled(lambda t: O.px_forward(pG, t, 9, pad), scene, tile=32, margin=8, batch=7)
+    assert got.shape == (2, 1, 70, 90)
+    close(got, want, tol.out, "predict_tiled")
+    fn = save_nir_npz(got[0], str(tmp_path), "tile_0")
+    back = np.load(fn)["nir"]
+    assert back.dtype == np.float16 and back.shape == (1, 70, 90)
+    np.testing.assert_allclose(back.astype(np.float32), got[0].cpu().numpy(), atol=1e-3)

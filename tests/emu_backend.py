@@ -766,7 +766,9 @@ class EmuBackend:
         B, H, W = d.B, d.H, d.W
         n = B * H * W
         # fp32 like the kernel: the indices are singular where pred + band ~ 0 (pred comes out of tanh)
-        rgb = torch.from_numpy(arr(d.rgb, 3 * n).reshape(B, 3, H, W).copy())
+        if not d.rgb and (d.log_all or any(w != 0 for w in (d.w_ndvi, d.w_ndwi, d.w_gndvi, d.w_savi, d.w_msavi, d.w_evi))):
+            return self._fail("pix_loss: the spectral indices need rgb")
+        rgb = torch.from_numpy(arr(d.rgb, 3 * n).reshape(B, 3, H, W).copy()) if d.rgb else torch.zeros(B, 3, H, W)
         x = torch.from_numpy(arr(d.nir, n).reshape(B, 1, H, W).copy())
         y = torch.from_numpy(arr(d.pred, n).reshape(B, 1, H, W).copy()).requires_grad_(True)
         R, Gc, Bl = rgb[:, 0:1], rgb[:, 1:2], rgb[:, 2:3]

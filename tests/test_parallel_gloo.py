@@ -39,7 +39,7 @@ def _batch():
     return 0.02 + 0.58 * torch.rand(4, 3, 32, 32, generator=g), 0.05 + 0.75 * torch.rand(4, 1, 32, 32, generator=g)
 
 
-def _worker(rank, world, port, out_dir, micro):
+def _worker(rank, world, port, out_dir, micro, perturb=False):
     _setup_path()
     torch.set_num_threads(2)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -48,22 +48,31 @@ def _worker(rank, world, port, out_dir, micro):
     from nirgan_hip.trainer import Pix2PixTrainer
     z = np.load(os.path.join(ROOT, "tests", "golden", "f1_g6_d.npz"))
     netG, netD = _build(z)
+    if perturb and rank != 0:          # ranks that did not seed alike: DDP semantics = everyone starts from rank 0's weights
+        torch.manual_seed(100 + rank)
+        with torch.no_grad():
+            for p in list(netG.parameters()) + list(netD.parameters()):
+                p.add_(0.05 * torch.randn_like(p))
     red = GradReducer()
     tr = Pix2PixTrainer(netG, netD, n_blocks=6, reducer=red, micro_batches=micro)
     rgb, nir = _batch()
     out = tr.step(shard_batch(rgb, rank, world), shard_batch(nir, rank, world)).as_dict()
+    if micro == 1:                     # two buckets per network: the tail went out from inside the backward plans
+        assert tr._state.bucketed and any(n == "__hook__" for n, _ in tr.G.bwd.ops) and any(n == "__hook__" for n, _ in tr.D2.bwd.ops)
+        assert sum(p_.numel() for p_ in tr._state.headG) < 0.2 * tr.flatG.total and not red._pending
     torch.save({"gD": tr.flatD.grad.clone(), "gG": tr.flatG.grad.clone(), "pD": tr.flatD.flat.clone(),
                 "pG": tr.flatG.flat.clone(), "loss": out}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("micro", [1, 2])
-def test_two_rank_gradients_equal_single_process(tmp_path, micro):
-    """micro = 2: every rank additionally cuts its shard into two parts whose gradients are summed before the all-reduce."""
+@pytest.mark.parametrize("micro,perturb", [(1, False), (2, False), (1, True)])
+def test_two_rank_gradients_equal_single_process(tmp_path, micro, perturb):
+    """micro = 2: every rank additionally cuts its shard into two parts whose gradients are summed before the all-reduce.
+    perturb: rank 1 starts from different weights; the trainer broadcasts rank 0's (what DDP does when it wraps the module)."""
     _setup_path()
-    port = 29500 + (os.getpid() % 2000) + 7 * micro
-    mp.spawn(_worker, args=(2, port, str(tmp_path), micro), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * micro + 3 * perturb
+    mp.spawn(_worker, args=(2, port, str(tmp_path), micro, perturb), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in (0, 1))
     # both ranks hold identical reduced gradients and identical updated parameters
     for k in ("gD", "gG", "pD", "pG"):
