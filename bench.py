@@ -7,8 +7,13 @@ A "step" is one batch of the reference's loop (model/pix2pix.py:165-257): genera
 PatchGAN forward on fake+real, both backward passes, both Adam steps -- on synthetic random
 tiles already resident in HBM.  Workload = BASELINE.json configs[1]: 6-block
 ResnetGenerator + 3-layer PatchGAN, bs=16 256x256 per GPU, GAN + L1 loss, fp32 (exact-fp32
-MFMA).  N > 1: one process per GPU (torchrun), tile batches sharded data-parallel, flat
-gradients all-reduced with RCCL; per-GPU work is fixed ("weak").
+MFMA).  N > 1: one process per GPU, tile batches sharded data-parallel, flat gradients averaged
+with RCCL in two buckets per network; per-GPU work is fixed ("weak").  Started without a
+launcher (`python bench.py --gpus 8`) the parent spawns the N ranks itself (a child
+`python -m torch.distributed.run`; the parent never touches the GPU and exits with the
+children's status); started under torchrun it is one rank.  WORLD_SIZE must equal --gpus.
+`--verify-dp` checks, before timing, that the N-rank averaged gradients equal the single-process
+gradients on the concatenated batch.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel by share of step time
 (conv_wgrad_pair_kernel: data-gradient + weight-gradient tiles of one layer in one grid;
@@ -22,8 +27,11 @@ Other workloads (not the headline): --blocks 9 --lambda-rs 1 --bs 32 (configs[2]
 (configs[4]: resolution buckets, bf16 MFMA); --precision bf16x3 (split-fp32 on the bf16 pipe).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -111,8 +119,19 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(n_blocks, size, bs=4, steps=8):
-    """The CPU oracle (port of the reference's step) on a bounded sample of the same workload."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(n_blocks, size, bs=16, steps=3):
+    """The CPU oracle (port of the reference's step) on the metric's own configuration: bs = 16 (BASELINE.md section 3:
+    1 warm-up + >= 3 timed steps), all host cores of this process's share."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nirgan_oracle as O
     from model import networks
@@ -124,12 +143,77 @@ def cpu_baseline(n_blocks, size, bs=4, steps=8):
     tr = O.OracleTrainer(netG.state_dict(), netD.state_dict(), n_blocks)
     rgb, nir = synth(bs, size, size, 1234, "cpu")
     tr.step(rgb, nir)
-    t0 = time.perf_counter()
+    times = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         tr.step(rgb, nir)
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": bs / dt, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (plain PyTorch CPU fp32) train step, {n_blocks}-block, bs={bs}, {size}x{size}, 1 warm-up + {steps} timed steps"}
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": round(bs / dt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model(),
+            "s_per_step": round(dt, 3),
+            "sample": f"oracle (plain PyTorch CPU fp32) train step, {n_blocks}-block, bs={bs}, {size}x{size}, 1 warm-up + {steps} timed steps (median)"}
+
+
+def kernel_source_sha16() -> str:
+    """Hash of the HIP sources + headers the library is built from: profiles recorded for another version are stale."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "nir-gan_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def free_port() -> int:
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """No launcher around us: start the N ranks as a CHILD torchrun (never exec / never touch the GPU in this process)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def verify_dp(a, dev, rank, world, reducer, netG, netD, make_trainer, rgb, nir, embeds):
+    """SURVEY 8e "Verification": the gradients the N ranks hold after the all-reduce equal the single-process gradients on
+    the concatenated global batch (InstanceNorm is per sample, losses are means; lr 0 keeps the parameters in place)."""
+    import torch.distributed as dist
+    tr = make_trainer(reducer, 0.0)
+    tr.step(rgb, nir, embeds)
+    gD, gG = tr.flatD.grad.clone(), tr.flatG.grad.clone()
+    del tr
+    def gather(t):
+        if t is None:
+            return None
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t.contiguous())
+        return torch.cat(parts, 0)
+    one = make_trainer(None, 0.0)
+    one.step(gather(rgb), gather(nir), gather(embeds))
+    res = {}
+    for k, dp, ref in (("D", gD, one.flatD.grad), ("G", gG, one.flatG.grad)):
+        res["rel_l2_" + k] = float(((dp - ref).norm() / ref.norm().clamp_min(1e-30)).item())
+    del one
+    for f in (netG._flat(), netD._flat()):           # the two lr-0 steps must not count as training
+        f.step_count = 0
+        if f.m is not None:
+            f.m.zero_()
+            f.v.zero_()
+    torch.cuda.empty_cache() if dev.type == "cuda" else None
+    worst = torch.tensor([max(res.values())], dtype=torch.float64, device=dev)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    res["max_over_ranks"] = float(worst.item())
+    res["tol"] = a.verify_tol
+    res["global_batch"] = int(rgb.shape[0] * world)
+    res["ok"] = res["max_over_ranks"] <= a.verify_tol
+    return res
 
 
 def main():
@@ -155,21 +239,43 @@ def main():
                          "include the sharing, so the roofline entry is not a clean single-kernel figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--verify-dp", action="store_true",
+                    help="before timing: N-rank averaged gradients == single-process gradients on the concatenated batch")
+    ap.add_argument("--verify-tol", type=float, default=1e-4, help="relative L2 bound of --verify-dp (measured values are in the JSON)")
+    ap.add_argument("--ngf", type=int, default=64, help="network width (64 = the reference's; smaller only for the CPU launch test)")
+    ap.add_argument("--emulate-cpu", action="store_true",
+                    help="TEST SEAM (tests/test_bench_launch.py): gloo + the numpy emulator of the C ABI instead of RCCL + the HIP "
+                         "library, to exercise launching / sharding / verification without a GPU; the numbers mean nothing")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the launcher and the request disagree")
+    if a.emulate_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu_backend import EmuBackend
+        from nirgan_hip import lib as _L
+        _L.set_backend(EmuBackend())
+        torch.set_num_threads(2)
+        dev = torch.device("cpu")
+        a.no_probe = a.no_cpu_baseline = True
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     reducer = None
     if world > 1 or os.environ.get("NIRGAN_FORCE_DIST") == "1":     # the env var exercises RCCL on a single GPU (tests)
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.emulate_cpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         from nirgan_hip.parallel import GradReducer
         reducer = GradReducer()
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
@@ -180,7 +286,7 @@ def main():
         from model.generator_inject import define_G_inject
         ns = types.SimpleNamespace
         a.blocks = 9
-        cfg = ns(base_configs=ns(input_nc=3, output_nc=1, ngf=64, netG="resnet_9blocks", norm="instance", no_dropout=True,
+        cfg = ns(base_configs=ns(input_nc=3, output_nc=1, ngf=a.ngf, netG="resnet_9blocks", norm="instance", no_dropout=True,
                                  init_type="normal", init_gain=0.02),
                  satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
                             scaling_param=True, scaling_param_init=0.01))
@@ -188,12 +294,23 @@ def main():
         inject = {"style": "multiply", "use_scale": True}
         embeds = torch.randn(a.bs, 256, generator=torch.Generator().manual_seed(99 + rank)).to(dev)
     else:
-        netG = networks.define_G(3, 1, 64, f"resnet_{a.blocks}blocks", "instance", False, "normal", 0.02).to(dev)
-    netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)
+        netG = networks.define_G(3, 1, a.ngf, f"resnet_{a.blocks}blocks", "instance", False, "normal", 0.02).to(dev)
+    netD = networks.define_D(4, a.ngf, "basic", 3, "instance", "normal", 0.02).to(dev)
     rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333}
-    tr = Pix2PixTrainer(netG, netD, n_blocks=a.blocks, padding=a.padding, lambda_rs=a.lambda_rs, rs_weights=rs_w,
-                        inject=inject, reducer=reducer, precision=a.precision, micro_batches=a.micro)
+
+    def make_trainer(red, lr=2e-4):
+        return Pix2PixTrainer(netG, netD, n_blocks=a.blocks, lr=lr, padding=a.padding, lambda_rs=a.lambda_rs, rs_weights=rs_w,
+                              inject=inject, reducer=red, precision=a.precision, micro_batches=a.micro)
     rgb, nir = synth(a.bs, a.size, a.size, 1234 + rank, dev)
+    dp_check = None
+    if a.verify_dp:
+        if reducer is None:
+            sys.exit("bench.py: --verify-dp needs more than one rank (or NIRGAN_FORCE_DIST=1)")
+        dp_check = verify_dp(a, dev, rank, world, reducer, netG, netD, make_trainer, rgb, nir, embeds)
+        if not dp_check["ok"]:
+            print(json.dumps({"dp_verify": dp_check}), flush=True)
+            sys.exit(f"bench.py: data-parallel gradients differ from the single-process gradients: {dp_check}")
+    tr = make_trainer(reducer)          # with a reducer: broadcasts rank 0's weights first (what DDP does at wrap time)
     _step = tr.step
     tr.step = lambda r, n: _step(r, n, embeds)
     buckets, bucket_ms = None, None
@@ -251,8 +368,11 @@ def main():
     def barrier():
         if reducer is not None:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
+    if reducer is not None and dev.type == "cuda":
+        reducer.exposed_events = []        # HIP events around every wait for the gradient collectives
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -262,10 +382,18 @@ def main():
             tr.step(rgb, nir)
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms, comm_ms = [dt / a.steps * 1e3], None
     if reducer is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        exposed = 0.0
+        if reducer.exposed_events:
+            exposed = sum(e0.elapsed_time(e1) for e0, e1 in reducer.exposed_events) / a.steps
+        reducer.exposed_events = None
+        t = torch.tensor([dt / a.steps * 1e3, exposed], device=dev, dtype=torch.float64)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        rank_ms = [round(float(x[0]), 3) for x in allt]
+        comm_ms = [round(float(x[1]), 4) for x in allt]
+        dt = max(float(x[0]) for x in allt) * a.steps / 1e3          # MAX over ranks
     losses = tr.step(rgb, nir).as_dict()
     assert all(v == v and abs(v) < 1e30 for v in losses.values()), f"non-finite losses {losses}"
 
@@ -292,22 +420,37 @@ def main():
                               "launches_per_step": nlaunch, "avg_launch_ms": round(avg_ms, 5),
                               "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
                               "share_of_step_time": round(avg_ms * nlaunch / ms, 3)})
-            # HBM traffic per launch from the PMC passes recorded under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # separate passes over this same bench command, FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes; mean over
-            # the kernel's launches in a step); only valid for the workload it was measured on
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_summary.json")))
-            except Exception:
-                pmc = {}
+            # HBM traffic per launch: NOT measured in this run (PMC needs rocprofv3 passes around the process).  It is replayed from
+            # the PMC summary recorded under profiles/ by scripts/refresh_profiles.sh over this same command (rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes; mean over the
+            # kernel's launches in a step) -- only for the workload it was measured on and only while the kernel sources are the
+            # ones it was measured with (kernel_src_sha16); otherwise traffic stays null.
+            pmc, pmc_file = {}, None
+            for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_bench_summary.json")), reverse=True):
+                try:
+                    pmc, pmc_file = json.load(open(os.path.join(ROOT, "profiles", cand))), "profiles/" + cand
+                    break
+                except Exception:
+                    continue
+            meta = pmc.get("_meta", {}) if isinstance(pmc.get("_meta", {}), dict) else {}
+            src_now = kernel_source_sha16()
+            fresh = meta.get("kernel_src_sha16") == src_now
+            headline = (a.bs == 16 and a.size == 256 and a.blocks == 6 and a.padding == 0 and a.precision == "fp32"
+                        and not a.mixed and a.micro == 1 and not a.inject and a.lambda_rs == 0.0 and a.ngf == 64)
             for r in roofs:
-                ent = next((v for k, v in pmc.items() if k.split("<")[0] == r["kernel"].split("<")[0]
+                ent = next((v for k, v in pmc.items() if k != "_meta" and k.split("<")[0] == r["kernel"].split("<")[0]
                             and ("<" not in r["kernel"] or k.startswith(r["kernel"][:-1] + ","))), None)
-                if ent and a.bs == 16 and a.size == 256 and a.blocks == 6 and a.padding == 0 and a.precision == "fp32" \
-                        and not a.mixed and a.micro == 1 and "hbm_read_bytes_per_launch_corrected" in ent:
+                r["traffic_source"] = None
+                if ent and headline and fresh and "hbm_read_bytes_per_launch_corrected" in ent:
                     r["traffic"] = int(ent["hbm_read_bytes_per_launch_corrected"] + ent.get("hbm_write_bytes_per_launch", 0.0))
                     r["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, mean over the kernel's launches)"
+                    r["traffic_source"] = f"replayed from {pmc_file} (recorded by scripts/refresh_profiles.sh; kernel_src_sha16 {src_now}), not measured in this run"
                     if "mfma_busy_fraction_of_active_cycles" in ent:
                         r["pmc_mfma_busy"] = round(ent["mfma_busy_fraction_of_active_cycles"], 4)
+                        r["pmc_source"] = r["traffic_source"]
+                elif ent and headline and not fresh:
+                    r["traffic_source"] = (f"{pmc_file} was recorded for kernel sources {meta.get('kernel_src_sha16')}, this build is {src_now}: "
+                                           "stale, not reported (rerun scripts/refresh_profiles.sh)")
             for r in roofs:
                 if r["kernel"].startswith("wino"):
                     r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(2x2,3x3) part performs 16/36 of the direct layer's "
@@ -323,14 +466,31 @@ def main():
                         f"equal tile area), {a.blocks}-block ResnetGenerator + PatchGAN, GAN+L1"
                         + (f"+RS(l={a.lambda_rs})" if a.lambda_rs else "") + f", padding={a.padding}, {mfma}; value in 256x256-equivalent tiles/s")
         else:
-            workload = (f"configs[1]: {a.blocks}-block ResnetGenerator + 3-layer PatchGAN, bs={a.bs}/GPU, "
+            if a.inject:
+                tag = "configs[3]" if (a.size == 512 and a.bs == 8) else "configs[3]-like"
+            elif a.blocks == 9 and a.lambda_rs > 0:
+                tag = "configs[2]" if (a.size == 256 and a.bs == 32 and a.precision == "fp32") else "configs[2]-like"
+            elif a.blocks == 6 and a.lambda_rs == 0 and a.size == 256 and a.bs == 16 and a.precision == "fp32" and a.ngf == 64:
+                tag = "configs[1]" if a.padding == 0 else "configs[1] with the YAML's padding"
+            else:
+                tag = "custom"
+            workload = (f"{tag}: {a.blocks}-block ResnetGenerator" + (f" (ngf {a.ngf})" if a.ngf != 64 else "") + f" + 3-layer PatchGAN, bs={a.bs}/GPU, "
                         f"{a.size}x{a.size}, GAN+L1" + (f"+RS(l={a.lambda_rs})" if a.lambda_rs else "")
                         + (", SatCLIP inject" if a.inject else "") + f", padding={a.padding}, {mfma}")
         out = {"metric": "256x256 RGB tiles/sec (G+D fwd+bwd+step)", "value": round(value, 3), "unit": "tiles/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": workload, "global_batch": a.bs * world, "parallelism": f"dp{world}"},
-               "roofline": roof}
+               "roofline": roof, "kernel_src_sha16": kernel_source_sha16()}
+        if reducer is not None:
+            out["rccl_ranks"] = world if not a.emulate_cpu else 0
+            out["collective_backend"] = torch.distributed.get_backend()
+            out["ms_per_step_by_rank"] = rank_ms
+            out["comm_exposed_ms_per_step_by_rank"] = comm_ms
+            out["comm"] = ("two gradient buckets per network (tail started inside the backward plan, head after it); exposed = launch-stream "
+                           "time spent waiting for the collectives before each Adam step (HIP events)")
+        if dp_check is not None:
+            out["dp_verify"] = dp_check
         if a.micro > 1:
             out["config"]["micro_batches"] = a.micro
             if roof:
@@ -363,7 +523,7 @@ def main():
         if gflop_tile and not a.mixed and a.size == 256:
             out["step_tflops_algorithmic"] = round(gflop_tile * value / 1e3, 2)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.blocks, a.size)
+            out["cpu_baseline"] = cpu_baseline(a.blocks, a.size, bs=16 if a.size <= 256 else 4)
         print(json.dumps(out), flush=True)
     if reducer is not None:
         torch.distributed.destroy_process_group()

@@ -2,7 +2,19 @@
 """Summarise rocprofv3 --pmc counter CSVs per kernel: python3 scripts/pmc_summary.py <dir> [<dir> ...] > profiles/...json
 Each <dir> holds one pass (*_counter_collection.csv).  Output: per kernel name, launches and the per-launch mean of
 every counter found; FETCH_SIZE is reported raw (KB) and x2-corrected in bytes as MI355X_MICROARCH.md prescribes."""
-import csv, glob, json, os, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
+
+
+def kernel_source_sha16():
+    """Same hash as bench.py::kernel_source_sha16: ties the counters to the kernel sources they were measured with."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nir-gan_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(root)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(root, fn), "rb").read())
+    return h.hexdigest()[:16]
+
 
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for d in sys.argv[1:]:
@@ -32,4 +44,7 @@ for name, cs in acc.items():
         act = cs["GRBM_GUI_ACTIVE"][0] / cs["GRBM_GUI_ACTIVE"][1]
         e["mfma_busy_fraction_of_active_cycles"] = busy / (1024.0 * act / 8.0)
     out[short] = e
+out["_meta"] = {"kernel_src_sha16": kernel_source_sha16(), "command": "python3 bench.py --no-cpu-baseline --no-probe --steps 3 --warmup 1",
+                "passes": [os.path.basename(d.rstrip("/")) for d in sys.argv[1:]],
+                "recorded_by": "scripts/refresh_profiles.sh (rocprofv3 --pmc, one counter group per pass)"}
 json.dump(out, sys.stdout, indent=1, sort_keys=True)

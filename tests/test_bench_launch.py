@@ -1,0 +1,41 @@
+"""bench.py's launch contract on the CPU: `python bench.py --gpus N` with no launcher around it spawns
+the N ranks itself (child torchrun, rendezvous on 127.0.0.1), fails when WORLD_SIZE and --gpus disagree, verifies the
+data-parallel gradients against the single-process gradients on the concatenated batch and reports per-rank times.
+Runs with `--emulate-cpu` (gloo + the numpy emulator of the C ABI): launching / sharding / verification logic only --
+the measured path on the MI355X is the same code over RCCL and the HIP library."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--emulate-cpu", "--ngf", "8", "--size", "32", "--bs", "2", "--steps", "1", "--warmup", "1"]
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    return env
+
+
+def test_bench_spawns_its_own_ranks_and_verifies_dp():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--verify-dp"] + SMALL,
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                     # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 4
+    assert out["scaling"] == "weak" and out["value"] > 0 and len(out["ms_per_step_by_rank"]) == 2
+    assert abs(out["ms_per_step"] - max(out["ms_per_step_by_rank"])) < 1e-2      # MAX over ranks
+    dp = out["dp_verify"]
+    assert dp["ok"] and dp["global_batch"] == 4 and dp["rel_l2_D"] < 1e-4 and dp["rel_l2_G"] < 1e-4
+    assert out["config"]["workload"].startswith("custom")                          # not mislabelled as configs[1]
+
+
+def test_bench_refuses_a_world_size_that_is_not_the_request():
+    env = _env()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
