@@ -8,14 +8,20 @@
 
 Tolerances.  Forward outputs and losses: 1e-3 relative to the reference value (the bar of
 BASELINE.json; measured errors are ~1e-6..1e-5).  Gradients of the small golden nets: relative
-L2 error <= 1e-3 per tensor.  Gradients of the full-size nets: relative L2 <= 1e-2.  They are
-only piecewise smooth (ReLU / LeakyReLU masks, sign(pred - nir) of the L1 loss): an element
-within fp32 rounding of a kink flips between two CORRECT fp32 evaluations, and with 26 M
-activations per tile a few always do.  Measured on the MI355X box against the oracle evaluated
-in fp64 (scripts/diag_grad_error.py -> profiles/r01_grad_error_vs_fp64.txt): the reference's
-own fp32 CPU arithmetic is 2e-4..1e-2 away from fp64 on these tensors, the HIP path 2e-4..1.3e-2.
-The tight gradient checks are the per-kernel tests (1e-5, tests/test_gpu_kernels.py) and the
-golden small nets.  Biases feeding an InstanceNorm are excluded (mathematically dead, gradient
+L2 error <= 1e-3 per tensor.  Gradients of the full-size nets (ngf 64) are compared with the
+oracle evaluated in FP64 (the truth both fp32 implementations approximate), per tensor:
+rel-L2 <= 6e-3 (generator), 2e-3 (PatchGAN) for a given smooth output gradient, and <= 5e-3 / 1e-3
+for the whole fused step with `nir` moved off the L1 kink (|pred - nir| >= 1e-3).  Why not 1e-3
+everywhere: the gradients are only piecewise smooth (26 M ReLU / LeakyReLU masks per tile); ONE
+activation within fp32 rounding of zero flips between two correct evaluations and moves a
+gradient tensor by |g_i| / ||g|| ~ 1 / sqrt(4 M) = 5e-4 of its L2 norm, and instance-norm's
+backward subtracts near-equal means (cancellation).  Measured on the MI355X against fp64
+(scripts/diag_grad_error2.py -> profiles/r02_grad_error_kinkfree_vs_fp64.txt): the reference's own
+fp32 CPU arithmetic sits at 1.3e-3..3.2e-3 (engine) and 1e-2 (fused step) on these tensors, the HIP
+path at 1.2e-3..3.4e-3 and 2e-3 -- the bounds are ~1.5x the measured HIP values (kernels and seeds
+are deterministic), ten times tighter than round 1's 5e-2 and enough to expose a 1 % error in
+any one layer.  The 1e-5 gradient checks are the per-kernel tests (tests/test_gpu_kernels.py) and
+the 1e-3 ones the golden small nets.  Biases feeding an InstanceNorm are excluded (mathematically dead, gradient
 = rounding noise in the reference too).
 """
 import os
@@ -56,6 +62,19 @@ def grad_close(a, b, what, l2=1e-3, mx=1e-2):
     em = (a - b).abs().max().item()
     assert e2 <= l2 * max(nrm, 1e-20), f"{what}: rel L2 {e2 / max(nrm, 1e-20):.3e}"
     assert em <= mx * max(b.abs().max().item(), 1e-20), f"{what}: max err {em:.3e} of {b.abs().max().item():.3e}"
+
+
+def grad_close64(a, b64, what, l2, mx=5e-2):
+    """Against an fp64 reference: relative L2 and max error."""
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b64).detach().double().cpu()
+    assert a.shape == b.shape and torch.isfinite(a).all(), what
+    e2, em = ((a - b).norm() / b.norm().clamp_min(1e-30)).item(), ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+    assert e2 <= l2, f"{what}: rel L2 vs fp64 {e2:.3e} > {l2:.1e}"
+    assert em <= mx, f"{what}: max err vs fp64 {em:.3e}"
+
+
+def leaf64(sd):
+    return {k: v.detach().double().clone().requires_grad_(True) for k, v in sd.items()}
 
 
 def make_nets(z, n_blocks, ngf=8):
@@ -209,14 +228,14 @@ def test_fullsize_generator_engine_against_oracle(golden_dir, nb, pad, size):
     if pad == 0 and size == 256:   # the reference's own output on this tile (committed by oracle/make_golden.py)
         z5 = load(golden_dir, "f5_fullsize.npz")
         close(pred.detach().cpu().flatten()[torch.from_numpy(z5[f"g{nb}_idx"])], z5[f"g{nb}_samples"], 1e-3, "pred vs reference samples")
-    p32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    ref = O.px_forward(p32, rgb, nb, pad)
-    ref.backward(dout)
+    p64 = leaf64(sd)
+    ref = O.px_forward(p64, rgb.double(), nb, pad)
+    ref.backward(dout.double())
     close(pred, ref, 1e-3, "pred")
     shadow = O.shadowed_bias_keys("G", nb)
     for k, p in netG.named_parameters():
         if k not in shadow:
-            grad_close(p.grad, p32[k].grad, "gG " + k, l2=1e-2, mx=1e-1)
+            grad_close64(p.grad, p64[k].grad, "gG " + k, l2=6e-3)
 
 
 def test_fullsize_discriminator_engine_against_oracle():
@@ -224,7 +243,7 @@ def test_fullsize_discriminator_engine_against_oracle():
     from model import networks
     torch.manual_seed(0)
     netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
-    pD = {k: v.clone().requires_grad_(True) for k, v in netD.state_dict().items()}
+    pD = leaf64(netD.state_dict())
     rgb, nir = synth(2, 256, 256, 99)
     x = torch.cat((rgb, nir), 1)
     dout = torch.randn(2, 1, 30, 30, generator=torch.Generator().manual_seed(4))
@@ -232,23 +251,22 @@ def test_fullsize_discriminator_engine_against_oracle():
     xg = x.to(DEV).requires_grad_(True)
     y = netD(xg)
     y.backward(dout.to(DEV))
-    xr = x.clone().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
     yr = O.discriminator_forward(pD, xr)
-    yr.backward(dout)
+    yr.backward(dout.double())
     close(y, yr, 1e-3, "D out")
     for k, p in netD.named_parameters():
         if k not in O.shadowed_bias_keys("D"):
-            grad_close(p.grad, pD[k].grad, "gD " + k, l2=1e-2, mx=1e-1)
-    grad_close(xg.grad, xr.grad, "dD/dx", l2=1e-2, mx=1e-1)
+            grad_close64(p.grad, pD[k].grad, "gD " + k, l2=2e-3)
+    grad_close64(xg.grad, xr.grad, "dD/dx", l2=2e-3)
 
 
 def test_fullsize_fused_step_against_oracle():
-    """The whole two-optimizer step at reference size.  Output and losses to 1e-3.  The step's gradients
-    contain sign(pred - nir) (L1) and ReLU masks: an element within fp32 rounding of a kink flips between
-    two correct fp32 evaluations and moves dL/dpred by 2*lambda_L1/N at that pixel, i.e. ~2/sqrt(N) ~ 1 %
-    of its L2 norm per flip (the fp32 CPU oracle itself is ~1e-2 from its own fp64 evaluation, see
-    scripts/diag_grad_error.py; profiles/r01_grad_error_vs_fp64.txt).  So here the gradients are only
-    bounded at that floor; their tight check is the two engine tests above (given, smooth dout)."""
+    """The whole two-optimizer step at reference size against the oracle in fp64.  Output and losses to 1e-3.  `nir` is moved
+    off the L1 kink first (the 36 of 65 536 pixels with |pred - nir| < 1e-3 get a target 2e-3 away, on the same side), so that
+    sign(pred - nir) is the same in every evaluation; what remains are interior ReLU / LeakyReLU flips and fp32 conditioning
+    (module docstring): every gradient tensor within 5e-3 (generator) / 1e-3 (PatchGAN) of fp64 in relative L2 -- the fp32 CPU
+    oracle itself sits at 1e-2 / 5e-4 there (profiles/r02_grad_error_kinkfree_vs_fp64.txt)."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
     nb = 6
@@ -258,20 +276,28 @@ def test_fullsize_fused_step_against_oracle():
     netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
     pG, pD = {k: v.clone() for k, v in netG.state_dict().items()}, {k: v.clone() for k, v in netD.state_dict().items()}
     rgb, nir = synth(1, 256, 256, 1234)
+    p64 = {k: v.double() for k, v in pG.items()}
+    with torch.no_grad():
+        pred64 = O.px_forward(p64, rgb.double(), nb, 0).float()
+    d = pred64 - nir
+    near = d.abs() < 1e-3
+    assert 0 < int(near.sum()) < 500
+    nir = torch.where(near, pred64 - torch.where(d >= 0, 2e-3, -2e-3), nir)
     tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=nb)
     out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
-    ref = O.OracleTrainer(pG, pD, nb)
-    o = ref.step(rgb, nir)
+    ref = O.OracleTrainer(p64, {k: v.double() for k, v in pD.items()}, nb)
+    o = ref.step(rgb.double(), nir.double())
     close(tr.G.pred, ref.last["pred"], 1e-3, "pred")
+    assert ((tr.G.pred.cpu() - nir).sign() == (ref.last["pred"].float() - nir).sign()).all()
     for k in ("loss_D", "loss_G", "loss_G_gan", "loss_G_l1"):
         close(out[k], o[k], 1e-3, k)
     gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
     for k, v in ref.last["grads_D"].items():
         if k not in O.shadowed_bias_keys("D"):
-            grad_close(gD[k], v, "gD " + k, l2=1e-2, mx=1e-1)
+            grad_close64(gD[k], v, "gD " + k, l2=1e-3)
     for k, v in ref.last["grads_G"].items():
         if k not in O.shadowed_bias_keys("G", nb):
-            grad_close(gG[k], v, "gG " + k, l2=5e-2, mx=0.5)
+            grad_close64(gG[k], v, "gG " + k, l2=5e-3)
 
 
 def test_reference_full_discriminator_output(golden_dir):
@@ -462,6 +488,61 @@ def test_mixed_resolution_buckets_on_device():
         tol = 1e-3 if n < 3 else 5e-3
         close(got[n]["loss_D"], o["loss_D"], tol, f"loss_D step {n}")
         close(got[n]["loss_G"], o["loss_G"], tol, f"loss_G step {n}")
+
+
+def test_configs4_bf16_mixed_resolution_with_the_spectral_loss():
+    """BASELINE.json configs[4] as written: mixed-resolution buckets x bf16 MFMA x full G + D + spectral-index loss (9 blocks,
+    lambda_rs 1, NDVI/NDWI/EVI), one trainer.  Per bucket the fused step is compared with the oracle's bf16 restatement
+    (operands of every contraction rounded to bf16, fp32 accumulate: oracle.operand_precision) from the same weights (lr 0
+    keeps them in place): prediction inside the bf16 noise band, losses to 1e-2; the fp32 mode of the same trainer set to 1e-3
+    of the fp32 oracle.  Then the bucket sequence with lr > 0 stays finite with one engine set per bucket.  The output bias is
+    raised (as in fixture f1_g9_rs_pad) and the last conv's weights scaled down so that pred stays in (0.5, 1): the indices are singular where pred + band ~ 0."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    nb = 9
+
+    def nets():
+        torch.manual_seed(0)
+        g = networks.define_G(3, 1, 16, "resnet_9blocks", "instance", False, "normal", 0.02)
+        d = networks.define_D(4, 16, "basic", 3, "instance", "normal", 0.02)
+        with torch.no_grad():
+            list(g.parameters())[-1].fill_(1.5)
+            list(g.parameters())[-2].mul_(0.2)       # last conv: pre-tanh = 1.5 +- a narrow spread at every resolution
+        return g, d
+    buckets = [(8, 64), (2, 128), (1, 256)]
+    data = [synth(b, s_, s_, 60 + i) for i, (b, s_) in enumerate(buckets)]
+    g, d = nets()
+    sdG, sdD = {k: v.clone() for k, v in g.state_dict().items()}, {k: v.clone() for k, v in d.state_dict().items()}
+    for prec in ("fp32", "bf16"):
+        g, d = nets()
+        tr = Pix2PixTrainer(g.to(DEV), d.to(DEV), n_blocks=nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W, precision=prec)
+        for i, (rgb, nir) in enumerate(data):
+            out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
+            ref32 = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
+            o32 = ref32.step(rgb, nir)
+            if prec == "fp32":
+                close(tr.pred, ref32.last["pred"], 1e-3, f"fp32 pred bucket {i}")
+                for k in ("loss_D", "loss_G", "loss_G_rs"):
+                    close(out[k], o32[k], 1e-3, f"fp32 {k} bucket {i}")
+                continue
+            with O.operand_precision("bf16"):
+                ref = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
+                o = ref.step(rgb, nir)
+            assert float(ref.last["pred"].min()) > 0.3          # denominators pred + band stay away from 0
+            noise = (ref.last["pred"] - ref32.last["pred"]).abs().max().item()
+            assert noise > 1e-4
+            err = (tr.pred.cpu() - ref.last["pred"]).abs().max().item()
+            assert err < 0.75 * noise, f"bucket {i}: {err:.3e} vs bf16 noise {noise:.3e}"
+            for k in ("loss_D", "loss_G", "loss_G_rs", "loss_G_l1"):
+                close(out[k], o[k], 1e-2, f"bf16 {k} bucket {i}")
+        assert len(tr._states) == 3
+    g, d = nets()
+    tr = Pix2PixTrainer(g.to(DEV), d.to(DEV), n_blocks=nb, lambda_rs=1.0, rs_weights=RS_W, precision="bf16")
+    for n in range(6):
+        rgb, nir = data[n % 3]
+        out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
+        assert all(np.isfinite(v) for v in out.values()), (n, out)
+    assert len(tr._states) == 3 and tr.flatG.step_count == 6
 
 
 def test_micro_batches_on_two_streams_match_the_single_stream_step():
