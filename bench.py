@@ -60,8 +60,8 @@ def mfma_probes(trainer):
     tiles of one layer in one grid): the sum of both problems' 2*M*N*K."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0],
-             "wino_gemm_kernel": [0.0, 0],
-             "wino_wgrad_pair_kernel": [0.0, 0]}
+             "wino_gemm_kernel": [0.0, 0], "wino_wgrad_pair_kernel": [0.0, 0],
+             "wino6_gemm_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0]}
     for pl in plans:
         pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}
         for i, (name, args) in enumerate(pl.ops):
@@ -70,6 +70,20 @@ def mfma_probes(trainer):
                 if d.N > 64:
                     k = "conv_igemm_kernel<128>"
                     kinds[k][0] += 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run
+                    kinds[k][1] += 1
+                    pl.probe_idx[i] = k
+            elif name == "nirgan_wino6_gemm":
+                d = args[0]._obj
+                k = "wino6_gemm_kernel"
+                T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
+                kinds[k][0] += 2.0 * 36 * T * d.C * d.K          # EXECUTED flops: 36 plane GEMMs [T x C] x [C x K] (36/144 of the direct layer's multiplies)
+                kinds[k][1] += 1
+                pl.probe_idx[i] = k
+            elif name == "nirgan_wgrad_igemm":
+                w = args[0]._obj
+                if w.N > 64 and w.precision == 0 and not w.pq_bf16:
+                    k = "wgrad_igemm_kernel<128>"
+                    kinds[k][0] += 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
                     kinds[k][1] += 1
                     pl.probe_idx[i] = k
             elif name == "nirgan_wino_gemm":
@@ -452,9 +466,14 @@ def main():
                     r["traffic_source"] = (f"{pmc_file} was recorded for kernel sources {meta.get('kernel_src_sha16')}, this build is {src_now}: "
                                            "stale, not reported (rerun scripts/refresh_profiles.sh)")
             for r in roofs:
-                if r["kernel"].startswith("wino"):
+                if r["kernel"].startswith("wino6"):
+                    r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(4x4,3x3) plane GEMMs perform 36/144 of the direct layer's multiplies")
+                elif r["kernel"].startswith("wino"):
                     r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(2x2,3x3) part performs 16/36 of the direct layer's "
                                           "multiplies")
+                elif r["kernel"].startswith("wgrad_igemm"):
+                    r["flops_counted"] = ("EXECUTED matrix-pipe flops (includes the 36 transform-domain weight-gradient planes of the Winograd layers: "
+                                          "36/144 of the direct weight gradient's multiplies)")
             roofs.sort(key=lambda r: -r["share_of_step_time"])
             roof = roofs[0] if roofs else None
             roof_other = roofs[1:] or None

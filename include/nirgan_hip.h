@@ -441,6 +441,50 @@ int nirgan_wino_input_dy(const nirgan_wino_desc* c, const nirgan_wino_dy_desc* y
 int nirgan_wino_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
 int nirgan_wino_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream);   /* [K][C][r][r] */
 
+/* -------------------------------------------------------------------------------------
+ * Winograd F(4x4, 3x3) for the same layers (nn.Conv2d(C, K, 3, stride 1) over a halo of 1, model/networks.py:405-427): 36 products
+ * per 4x4 outputs (F(2x2,3x3): 64, direct: 144).  The 16 outputs of a tile do not fit the register file next to the product, so
+ * the stages are separate launches and the transform-domain product M goes through HBM once:
+ *   nirgan_wino6_input   V[f][t][c] = (B^T d B)[f]   6x6 patches at stride 4 of x; T = B*ceil(H/4)*ceil(W/4) tiles, f = 6 f1 + f2
+ *   nirgan_wino6_gemm    M[f][t][k] = sum_c V[f][t][c] U[f][k][c]   36 GEMMs in one grid on the direct 128x128 MFMA tile
+ *   nirgan_wino6_output  y[b][4ty+i][4tx+j][k] = (A^T M A)[i][j] + bias[k]
+ * Cook-Toom points 0, 1, -1, 2, -1/2, inf (matrices in csrc/wino6.hip); exact fp32 products, the result differs from the direct
+ * contraction by fp32 rounding only (measured 4e-6 of the output's maximum).  U = nirgan_wino6_weights(W) is [36][K][C].
+ * C % 4 == 0, K % 4 == 0, K > 64; extents that are no multiple of 4 cost one partly used tile row / column.
+ * Data gradient: the same calls with x = dY (zero halo 2), transpose_flip weights, H x W = the padded input extent.
+ * Weight gradient: dU[f][k][c] = sum_t Yt[f][t][k] V[f][t][c] with Yt = A dY A^T (nirgan_wino6_dy / nirgan_wino6_input_dy) and V of
+ * the forward input -- ONE nirgan_wgrad_igemm launch with nplanes = 36 -- then nirgan_wino6_wgrad_finish: dW = G^T (sum of the
+ * split slabs, in order) G in the reference layout [K][C][3][3].
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x; int x_hp, x_wp;       /* [B][H+2][W+2][C] */
+    int B, H, W, C, K;
+    const float* U; const float* bias;    /* [36][K][C]; [K] or NULL */
+    float* V; int64_t V_elems;            /* [36][T][C] */
+    float* M; int64_t M_elems;            /* [36][T][K] */
+    float* y;                             /* dense [B][H][W][K] */
+    const float* zero_page;
+} nirgan_wino6_desc;
+
+int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T */
+int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);   /* as nirgan_wino_weights */
+/* all weight transforms of a step in one launch: njobs x 8 int64 {w, U, K, C, transpose_flip, first_block, 0, 0} in device memory,
+ * first_block = running sum of ceil(K*C/256) */
+int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
+int nirgan_wino6_input(const nirgan_wino6_desc* d, void* stream);
+/* V straight from a convolution's raw output y (dense [B][H][W][C], d->x unused): x = act((y - mean) * rstd) under a REFLECT halo of 1,
+ * evaluated on the fly (as nirgan_wino_input_norm) */
+int nirgan_wino6_input_norm(const nirgan_wino6_desc* d, const float* y, const float* mean, const float* rstd, int act, float slope, void* stream);
+int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream);
+int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream);
+int nirgan_wino6_conv3x3(const nirgan_wino6_desc* d, void* stream);   /* input + gemm + output */
+/* Yt [36][B*ceil(H/4)*ceil(W/4)][K]; the descriptor's r field is ignored */
+int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream);
+/* nirgan_wino6_input(c) and nirgan_wino6_dy(y) of the SAME output-gradient buffer (c->x == y->dy, zero halo 2) in one pass: the 4x4
+ * block of tile (ty, tx) is the lower-right corner of data-gradient patch (ty, tx) */
+int nirgan_wino6_input_dy(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, void* stream);
+int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).
  * ------------------------------------------------------------------------------------- */

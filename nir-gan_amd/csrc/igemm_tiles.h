@@ -85,7 +85,12 @@ struct ConvParams {
 // AB16 (with WB16): the activations come from a producer's bf16 twin as well -- both operands are read as stored, no
 // conversion in the K loop; the 128-byte staging rows then hold 64 k, so a K-step contracts 64 k (half the barriers per product).
 template <int BN, int PREC, bool WB16 = false, bool AB16 = false>
-__device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* st0, char* st1) {
+__device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* st0, char* st1,
+                                          const float* in_base = nullptr, const float* w_base = nullptr, float* out_base = nullptr) {
+    // optional base overrides: a plane-batched launch (csrc/wino6.hip) runs many problems of one geometry from one parameter block
+    const float* const p_in = in_base ? in_base : p.in;
+    const float* const p_w = w_base ? w_base : p.w;
+    float* const p_out = out_base ? out_base : p.out;
     static_assert(!WB16 || PREC == 1, "bf16-stored weights are consumed by the bf16 operand mode only");
     static_assert(!AB16 || WB16, "bf16 activations come with bf16-stored weights");
     constexpr int BM = 128;
@@ -159,11 +164,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         for (int i = 0; i < AIW; ++i) {
             const bool ok = c0 + a_col[i] < p.run;
             if constexpr (AB16) {
-                const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p.in);
+                const unsigned short* in16 = reinterpret_cast<const unsigned short*>(p_in);
                 const float* src = ok ? reinterpret_cast<const float*>(in16 + (a_base[i] + toff)) : p.zero;
                 ng_glds16(src, sA + (wave * 4 + i) * 1024);
             } else {
-                const float* src = ok ? p.in + (a_base[i] + toff) : p.zero;
+                const float* src = ok ? p_in + (a_base[i] + toff) : p.zero;
                 ng_glds16(src, sA + (wave * 4 + i) * 1024);
             }
         }
@@ -172,11 +177,11 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         for (int i = 0; i < BIW; ++i) {
             const bool ok = b_ok[i] && c0 + b_col[i] < p.run;
             if constexpr (WB16) {                                   // (wide or narrow rows: BIW pieces of 1 KB per wave either way)
-                const unsigned short* w16 = reinterpret_cast<const unsigned short*>(p.w);
+                const unsigned short* w16 = reinterpret_cast<const unsigned short*>(p_w);
                 const float* src = ok ? reinterpret_cast<const float*>(w16 + (b_base[i] + woff)) : p.zero;
                 ng_glds16(src, sB + (wave * BIW + i) * 1024);
             } else {
-                const float* src = ok ? p.w + (b_base[i] + woff) : p.zero;
+                const float* src = ok ? p_w + (b_base[i] + woff) : p.zero;
                 ng_glds16(src, sB + (wave * BI + i) * 1024);
             }
         }
@@ -385,7 +390,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) keep += acc[mt][nt][r];
-        if (keep == 123456.789f) p.out[0] = keep;        // keeps the accumulation alive, never true on real data
+        if (keep == 123456.789f) p_out[0] = keep;        // keeps the accumulation alive, never true on real data
         return;
     }
 #endif
@@ -432,7 +437,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                 f32x4 v = *reinterpret_cast<const f32x4*>(src);
                 v += bv;
                 float* dst = to_ws ? p.split_ws + ((size_t(ksp) * p.M + m) * p.N + n)
-                                   : p.out + (b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n);
+                                   : p_out + (b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n);
                 if (n + 4 <= p.N) {
                     *reinterpret_cast<f32x4*>(dst) = v;
                 } else {

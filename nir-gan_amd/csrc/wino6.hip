@@ -1,0 +1,465 @@
+// Winograd F(4x4, 3x3) for the stride-1 3x3 convolutions of the ResnetBlocks (model/networks.py:405-427) in exact-fp32 mode:
+// 36 products per 4x4 outputs instead of 144 (F(2x2,3x3): 64), i.e. 1.78x fewer matrix-pipe cycles than the F(2x2,3x3) path of
+// winograd.hip and 4x fewer than the direct contraction.  16 output accumulators per tile do not fit the register file next to the
+// product, so the transform-domain product goes through HBM once:
+//   wino6_weight      U[f][k][c] = (G g G^T)[f]                      per layer when the weights changed (36 x Cout x Cin)
+//   wino6_input       V[f][t][c] = (B^T d B)[f]                      6x6 patches (stride 4) of the halo'd NHWC input; HBM-bound
+//   wino6_gemm        M[f][t][k] = sum_c V[f][t][c] U[f][k][c]       36 independent [T x C] x [C x K] GEMMs in ONE grid on the direct
+//                                                                    128 x 128 tile (conv_tile: LDS-DMA staging, v_mfma_f32_32x32x2_f32)
+//   wino6_output      y[4ty+i][4tx+j][k] = (A^T M A)[i][j] + bias    HBM-bound
+// with f = 6 f1 + f2 and t = (image, tile row, tile column) over 4x4 output tiles.  The transform-domain tensors are 2.25 floats per
+// input element (F(2x2,3x3): 4), so the two extra passes move fewer bytes than the F(2x2) input transform alone did.
+// Data gradient: the same three stages on dY (zero halo 2) with the flipped, transposed filter over the padded input extent.
+// Weight gradient in the transform domain: dU[f][k][c] = sum_t Yt[f][t][k] V[f][t][c] with Yt = A dY A^T (36 weight-gradient
+// problems as ONE nirgan_wgrad_igemm launch with nplanes = 36, V kept from the forward), then dW = G^T dU G.
+//
+// Cook-Toom over the points 0, 1, -1, 2, -1/2, inf (fp32 error of the forward 3.8e-6 of the output's maximum against 5e-7 for a
+// sequential direct sum and 1.1e-5 for the textbook points 0, +-1, +-2, inf; scripts/exp_wino6_points.py), rows scaled so that B^T
+// (applied to the activations) is integer:
+//   B^T = [[2,3,-4,-3,2,0],[0,2,5,1,-2,0],[0,2,1,-5,2,0],[0,-1,-2,1,2,0],[0,-2,1,2,-1,0],[0,2,3,-4,-3,2]]
+//   G   = [[1/2,0,0],[1/6,1/6,1/6],[1/6,-1/6,1/6],[1/30,1/15,2/15],[16/15,-8/15,4/15],[0,0,1/2]]
+//   A^T = [[1,1,1,1,1,0],[0,1,-1,2,-1/2,0],[0,1,1,4,1/4,0],[0,1,-1,8,-1/8,1]]
+#include "igemm_tiles.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ 1-D transforms
+template <class T> __device__ __forceinline__ void w6_bt(const T* d, T* t) {            // t = B^T d
+    t[0] = 2.f * (d[0] + d[4]) + 3.f * (d[1] - d[3]) - 4.f * d[2];
+    t[1] = 2.f * (d[1] - d[4]) + 5.f * d[2] + d[3];
+    t[2] = 2.f * (d[1] + d[4]) + d[2] - 5.f * d[3];
+    t[3] = 2.f * (d[4] - d[2]) + (d[3] - d[1]);
+    t[4] = 2.f * (d[3] - d[1]) + (d[2] - d[4]);
+    t[5] = 2.f * (d[1] + d[5]) + 3.f * (d[2] - d[4]) - 4.f * d[3];
+}
+template <class T> __device__ __forceinline__ void w6_at(const T* m, T* y) {            // y = A^T m  (6 -> 4)
+    const T s12 = m[1] + m[2], d12 = m[1] - m[2];
+    y[0] = m[0] + s12 + m[3] + m[4];
+    y[1] = d12 + 2.f * m[3] - 0.5f * m[4];
+    y[2] = s12 + 4.f * m[3] + 0.25f * m[4];
+    y[3] = d12 + 8.f * m[3] - 0.125f * m[4] + m[5];
+}
+template <class T> __device__ __forceinline__ void w6_a(const T* e, T* u) {             // u = A e  (4 -> 6)
+    u[0] = e[0];
+    u[1] = (e[0] + e[2]) + (e[1] + e[3]);
+    u[2] = (e[0] + e[2]) - (e[1] + e[3]);
+    u[3] = e[0] + 2.f * e[1] + 4.f * e[2] + 8.f * e[3];
+    u[4] = e[0] - 0.5f * e[1] + 0.25f * e[2] - 0.125f * e[3];
+    u[5] = e[3];
+}
+__device__ __forceinline__ void w6_g(const float* g, float* w) {                        // w = G g  (3 -> 6)
+    w[0] = 0.5f * g[0];
+    w[1] = (g[0] + g[1] + g[2]) * (1.f / 6.f);
+    w[2] = (g[0] - g[1] + g[2]) * (1.f / 6.f);
+    w[3] = g[0] * (1.f / 30.f) + g[1] * (1.f / 15.f) + g[2] * (2.f / 15.f);
+    w[4] = g[0] * (16.f / 15.f) - g[1] * (8.f / 15.f) + g[2] * (4.f / 15.f);
+    w[5] = 0.5f * g[2];
+}
+__device__ __forceinline__ void w6_gt(const float* u, float* g) {                       // g = G^T u  (6 -> 3)
+    g[0] = 0.5f * u[0] + (u[1] + u[2]) * (1.f / 6.f) + u[3] * (1.f / 30.f) + u[4] * (16.f / 15.f);
+    g[1] = (u[1] - u[2]) * (1.f / 6.f) + u[3] * (1.f / 15.f) - u[4] * (8.f / 15.f);
+    g[2] = (u[1] + u[2]) * (1.f / 6.f) + u[3] * (2.f / 15.f) + u[4] * (4.f / 15.f) + 0.5f * u[5];
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+struct W6W { const float* w; float* U; int K, C, flip; };
+
+__device__ __forceinline__ void wino6_weight_one(const W6W& p, const long long i) {
+    if (i >= (long long)p.K * p.C) return;
+    const int k = int(i / p.C), c = int(i - (long long)k * p.C);
+    // flip: the data-gradient filter g'[k][c][i][j] = W[c][k][2-i][2-j] (W stored [C][K][3][3]: rows are the forward OUTPUT channels)
+    const float* g = p.flip ? p.w + (size_t(c) * p.K + k) * 9 : p.w + (size_t(k) * p.C + c) * 9;
+    float t[6][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float col[3] = {p.flip ? g[8 - j] : g[j], p.flip ? g[5 - j] : g[3 + j], p.flip ? g[2 - j] : g[6 + j]};
+        float o[6];
+        w6_g(col, o);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) t[a][j] = o[a];
+    }
+    const size_t plane = size_t(p.K) * p.C;
+    float* U = p.U + size_t(k) * p.C + c;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float o[6];
+        w6_g(t[a], o);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) U[(a * 6 + b) * plane] = o[b];
+    }
+}
+
+__global__ __launch_bounds__(256) void wino6_weight_kernel(const W6W p) { wino6_weight_one(p, blockIdx.x * 256ll + threadIdx.x); }
+
+// all F(4x4,3x3) weight transforms of a step in one launch: 8 x int64 per job {w, U, K, C, flip, first_block, 0, 0}
+__global__ __launch_bounds__(256) void wino6_weights_batch_kernel(const long long* __restrict__ jobs, int njobs) {
+    int j = 0;
+    for (int i = 1; i < njobs; ++i)
+        if (int(blockIdx.x) >= int(jobs[i * 8 + 5])) j = i;
+    const long long* J = jobs + j * 8;
+    W6W p{reinterpret_cast<const float*>(J[0]), reinterpret_cast<float*>(J[1]), int(J[2]), int(J[3]), int(J[4])};
+    wino6_weight_one(p, (long long)(int(blockIdx.x) - int(J[5])) * 256 + threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ input transform
+struct W6In {
+    const float* x; float* V; int B, C, x_row, x_img, x_hp, x_wp, TH, TW; long long T;
+    float* Yt; int yTH, yTW; long long yT;       // Yt != nullptr: x is a dY buffer with a zero halo of 2 and the lower-right 4x4 block of patch (ty, tx)
+                                                 // is output-gradient tile (ty, tx): Yt = A dY A^T is emitted from the same read of dY
+    // normalising variant: x = act((y - mean) * rstd) of a dense [B][H][W][C] tensor under a REFLECT halo of 1, evaluated on the fly
+    const float* y; const float* mean; const float* rstd; int H, W, act; float slope;
+};
+
+template <bool NORM>
+__global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
+    const int q4 = p.C / 4;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= p.T * q4) return;
+    const long long t = i / q4;
+    const int q = int(i - t * q4);
+    const int tx = int(t % p.TW);
+    const long long r = t / p.TW;
+    const int ty = int(r % p.TH), b = int(r / p.TH);
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mean = z4, rstd = z4;
+    const float* base;
+    if constexpr (NORM) {
+        mean = *reinterpret_cast<const f32x4*>(p.mean + size_t(b) * p.C + q * 4);
+        rstd = *reinterpret_cast<const f32x4*>(p.rstd + size_t(b) * p.C + q * 4);
+        base = p.y + size_t(b) * p.H * p.W * p.C + q * 4;
+    } else {
+        base = p.x + size_t(b) * p.x_img + q * 4;
+    }
+    // value of the (virtual) halo'd buffer at patch position (a, c); lines past the buffer (extent not a multiple of 4) read zero:
+    // they feed only outputs that are never stored
+    auto ld = [&](int a, int c) -> f32x4 {
+        const int rb = 4 * ty + a, cb = 4 * tx + c;
+        if (rb >= p.x_hp || cb >= p.x_wp) return z4;
+        if constexpr (NORM) {
+            const int yr = ng_reflect(rb - 1, p.H), yc = ng_reflect(cb - 1, p.W);
+            f32x4 v = (*reinterpret_cast<const f32x4*>(base + (size_t(yr) * p.W + yc) * p.C) - mean) * rstd;     // in_apply_kernel's arithmetic
+            if (p.act == NIRGAN_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            } else if (p.act == NIRGAN_ACT_LRELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+            }
+            return v;
+        } else {
+            return *reinterpret_cast<const f32x4*>(base + size_t(rb) * p.x_row + size_t(cb) * p.C);
+        }
+    };
+    f32x4 m[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        f32x4 d[6], o[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) d[a] = ld(a, c);
+        w6_bt(d, o);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) m[a][c] = o[a];
+    }
+    const size_t plane = size_t(p.T) * p.C;
+    float* V = p.V + size_t(t) * p.C + q * 4;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        f32x4 o[6];
+        w6_bt(m[a], o);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(V + (a * 6 + c) * plane) = o[c];
+    }
+    if constexpr (!NORM) {
+        if (p.Yt != nullptr && ty < p.yTH && tx < p.yTW) {
+            // output-gradient tile (ty, tx) = patch rows / columns 2 .. 5 (just read: L1 / L2 hits); rows past the extent read the zero halo
+            f32x4 u[6][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 e[4], o[6];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) e[a] = ld(2 + a, 2 + c);
+                w6_a(e, o);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) u[a][c] = o[a];
+            }
+            const size_t yplane = size_t(p.yT) * p.C;
+            float* Y = p.Yt + ((size_t(b) * p.yTH + ty) * p.yTW + tx) * p.C + q * 4;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                f32x4 o[6];
+                w6_a(u[a], o);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(Y + (a * 6 + c) * yplane) = o[c];
+            }
+        }
+    }
+}
+
+// Yt[f][t][k] = (A dY A^T)[f] alone (weight gradient without a Winograd data gradient next to it)
+struct W6Dy { const float* dy; float* Yt; int B, H, W, K, d_row, d_img, d_org, TH, TW; long long T; };
+
+__global__ __launch_bounds__(256) void wino6_dy_kernel(const W6Dy p) {
+    const int q4 = p.K / 4;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= p.T * q4) return;
+    const long long t = i / q4;
+    const int q = int(i - t * q4);
+    const int tx = int(t % p.TW);
+    const long long r = t / p.TW;
+    const int ty = int(r % p.TH), b = int(r / p.TH);
+    const float* src = p.dy + size_t(b) * p.d_img + p.d_org + q * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 u[6][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x4 e[4], o[6];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int h = 4 * ty + a, w = 4 * tx + c;
+            e[a] = (h < p.H && w < p.W) ? *reinterpret_cast<const f32x4*>(src + size_t(h) * p.d_row + size_t(w) * p.K) : z4;
+        }
+        w6_a(e, o);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) u[a][c] = o[a];
+    }
+    const size_t plane = size_t(p.T) * p.K;
+    float* Y = p.Yt + size_t(t) * p.K + q * 4;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        f32x4 o[6];
+        w6_a(u[a], o);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(Y + (a * 6 + c) * plane) = o[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ plane GEMMs
+struct W6Gemm { ng::ConvParams p; long long in_plane, w_plane, out_plane; int per_plane, total; };
+
+__global__ __launch_bounds__(256, 2) void wino6_gemm_kernel(const W6Gemm g) {
+    __shared__ __attribute__((aligned(16))) char st0[(128 + 128) * 128];
+    __shared__ __attribute__((aligned(16))) char st1[(128 + 128) * 128];
+    // consecutive logical ids on one XCD: the blocks of a plane share U[f] (256 KB) and, pairwise, their V rows in that XCD's L2
+    const int rid = ng_xcd_remap(blockIdx.x, g.total);
+    const int plane = rid / g.per_plane, local = rid - plane * g.per_plane;
+    ng::conv_tile<128, 0>(g.p, local, st0, st1, g.p.in + size_t(plane) * g.in_plane, g.p.w + size_t(plane) * g.w_plane,
+                          g.p.out + size_t(plane) * g.out_plane);
+}
+
+// ------------------------------------------------------------------------------------------------ output transform
+struct W6Out { const float* M; const float* bias; float* y; int B, H, W, K, TH, TW; long long T; };
+
+__global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
+    const int q4 = p.K / 4;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= p.T * q4) return;
+    const long long t = i / q4;
+    const int q = int(i - t * q4);
+    const int tx = int(t % p.TW);
+    const long long r = t / p.TW;
+    const int ty = int(r % p.TH), b = int(r / p.TH);
+    const size_t plane = size_t(p.T) * p.K;
+    const float* M = p.M + size_t(t) * p.K + q * 4;
+    f32x4 s[4][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        f32x4 m[6], o[4];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(M + (a * 6 + c) * plane);
+        w6_at(m, o);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s[a][c] = o[a];
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + q * 4);
+    float* yb = p.y + size_t(b) * p.H * p.W * p.K + q * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        f32x4 o[4];
+        w6_at(s[a], o);
+        const int h = 4 * ty + a;
+        if (h >= p.H) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int w = 4 * tx + c;
+            if (w < p.W) *reinterpret_cast<f32x4*>(yb + (size_t(h) * p.W + w) * p.K) = o[c] + bv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight-gradient finish
+struct W6Fin { const float* slabs; int nsplit, K, C; float* grad; int accumulate; };
+
+// dW[k][c] = G^T (sum over splits of dU[.][k][c]) G in the reference layout [K][C][3][3]; splits in order (deterministic).
+// A block takes 64 (k, c) pairs: thread (e, fg) sums frequencies 9 fg .. 9 fg + 8 of pair e over the splits (coalesced 256-B rows),
+// the 36 sums meet in LDS and threads 0-63 apply the 3x6 / 6x3 transforms.
+__global__ __launch_bounds__(256) void wino6_wgrad_finish_kernel(const W6Fin p) {
+    __shared__ float u_s[36][64];
+    const int e = threadIdx.x & 63, fg = threadIdx.x >> 6;
+    const long long i = blockIdx.x * 64ll + e;
+    const size_t kc = size_t(p.K) * p.C;
+    const bool ok = i < (long long)kc;
+    float sum[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const float* src = p.slabs + size_t(fg * 9) * p.nsplit * kc + i;          // slabs are [plane][split][K][C]
+        for (int sp = 0; sp < p.nsplit; ++sp) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sum[j] += src[(size_t(j) * p.nsplit + sp) * kc];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) u_s[fg * 9 + j][e] = sum[j];
+    __syncthreads();
+    if (fg != 0 || !ok) return;
+    float t[3][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float col[6], o[3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) col[a] = u_s[a * 6 + b][e];
+        w6_gt(col, o);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t[a][b] = o[a];
+    }
+    float* g = p.grad + size_t(i) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float o[3];
+        w6_gt(t[a], o);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (p.accumulate) g[a * 3 + b] += o[b]; else g[a * 3 + b] = o[b];
+        }
+    }
+}
+
+static inline long long w6_tiles(int B, int H, int W) { return (long long)B * ((H + 3) / 4) * ((W + 3) / 4); }
+
+}  // namespace
+
+extern "C" int64_t nirgan_wino6_tiles(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return w6_tiles(B, H, W);
+}
+
+extern "C" int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream) {
+    NG_REQUIRE(w && U && K > 0 && C > 0, "wino6_weights: bad arguments");
+    W6W p{w, U, K, C, transpose_flip ? 1 : 0};
+    const long long n = (long long)K * C;
+    hipLaunchKernelGGL(wino6_weight_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("wino6_weights");
+}
+
+extern "C" int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream) {
+    NG_REQUIRE(jobs_device && njobs >= 1 && njobs <= 256 && total_blocks >= 1, "wino6_weights_batch: bad arguments");
+    hipLaunchKernelGGL(wino6_weights_batch_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(jobs_device), njobs);
+    return nirgan_check_launch("wino6_weights_batch");
+}
+
+static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const float* ny, const float* mean, const float* rstd,
+                         int act, float slope, void* stream) {
+    NG_REQUIRE(d && d->V && (d->x || ny), "wino6_input: null pointer");
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino6_input: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
+    NG_REQUIRE(ny || (d->x_hp == d->H + 2 && d->x_wp == d->W + 2), "wino6_input: the input must be (H+2) x (W+2) (%dx%d for %dx%d)", d->x_hp, d->x_wp, d->H, d->W);
+    NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->V) && ng_aligned16(ny) && ng_aligned16(mean) && ng_aligned16(rstd), "wino6_input: pointers must be 16-byte aligned");
+    const long long T = w6_tiles(d->B, d->H, d->W);
+    NG_REQUIRE(T < (1ll << 31) / d->C, "wino6_input: problem too large for 32-bit tile offsets");
+    NG_REQUIRE(d->V_elems >= 36 * T * d->C, "wino6_input: V workspace too small");
+    W6In in;
+    in.x = d->x; in.V = d->V; in.B = d->B; in.C = d->C;
+    in.x_hp = d->H + 2; in.x_wp = d->W + 2; in.x_row = in.x_wp * d->C; in.x_img = in.x_hp * in.x_row;
+    in.TH = (d->H + 3) / 4; in.TW = (d->W + 3) / 4; in.T = T;
+    in.Yt = nullptr; in.yTH = in.yTW = 0; in.yT = 0;
+    in.y = ny; in.mean = mean; in.rstd = rstd; in.H = d->H; in.W = d->W; in.act = act; in.slope = slope;
+    if (y != nullptr) {
+        // the same dY buffer seen twice: zero halo 2, the data gradient covers (H_dy + 2) x (W_dy + 2) outputs
+        NG_REQUIRE(!ny && y->dy == d->x && y->Yt && y->dy_pad == 2 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp && y->dy_wp == d->x_wp
+                   && d->H == y->H + 2 && d->W == y->W + 2, "wino6_input_dy: the two descriptors do not describe the same output-gradient buffer");
+        NG_REQUIRE(ng_aligned16(y->Yt), "wino6_input_dy: pointers must be 16-byte aligned");
+        in.yTH = (y->H + 3) / 4; in.yTW = (y->W + 3) / 4; in.yT = (long long)y->B * in.yTH * in.yTW;
+        NG_REQUIRE(y->Yt_elems >= 36 * in.yT * y->K, "wino6_input_dy: Yt workspace too small");
+        in.Yt = y->Yt;
+    }
+    const long long nthreads = T * (d->C / 4);
+    const dim3 grid(unsigned((nthreads + 255) / 256));
+    if (ny) hipLaunchKernelGGL(wino6_input_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
+    else hipLaunchKernelGGL(wino6_input_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
+    return nirgan_check_launch("wino6_input");
+}
+
+extern "C" int nirgan_wino6_input(const nirgan_wino6_desc* d, void* stream) { return w6_input_impl(d, nullptr, nullptr, nullptr, nullptr, 0, 0.f, stream); }
+
+extern "C" int nirgan_wino6_input_dy(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, void* stream) {
+    NG_REQUIRE(y != nullptr, "wino6_input_dy: null pointer");
+    return w6_input_impl(d, y, nullptr, nullptr, nullptr, 0, 0.f, stream);
+}
+
+extern "C" int nirgan_wino6_input_norm(const nirgan_wino6_desc* d, const float* y, const float* mean, const float* rstd, int act, float slope, void* stream) {
+    NG_REQUIRE(y && mean && rstd, "wino6_input_norm: null pointer");
+    NG_REQUIRE(act == NIRGAN_ACT_NONE || act == NIRGAN_ACT_RELU || act == NIRGAN_ACT_LRELU, "wino6_input_norm: activation %d", act);
+    return w6_input_impl(d, nullptr, y, mean, rstd, act, slope, stream);
+}
+
+extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {
+    NG_REQUIRE(d && d->dy && d->Yt, "wino6_dy: null pointer");
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0 && d->dy_pad >= 0, "wino6_dy: bad shape");
+    NG_REQUIRE(d->dy_hp == d->H + 2 * d->dy_pad && d->dy_wp == d->W + 2 * d->dy_pad, "wino6_dy: dy geometry mismatch");
+    NG_REQUIRE(ng_aligned16(d->dy) && ng_aligned16(d->Yt), "wino6_dy: pointers must be 16-byte aligned");
+    W6Dy p;
+    p.dy = d->dy; p.Yt = d->Yt; p.B = d->B; p.H = d->H; p.W = d->W; p.K = d->K;
+    p.d_row = d->dy_wp * d->K; p.d_img = d->dy_hp * p.d_row; p.d_org = d->dy_pad * p.d_row + d->dy_pad * d->K;
+    p.TH = (d->H + 3) / 4; p.TW = (d->W + 3) / 4; p.T = (long long)d->B * p.TH * p.TW;
+    NG_REQUIRE(d->Yt_elems >= 36 * p.T * d->K, "wino6_dy: workspace too small");
+    const long long n = p.T * (d->K / 4);
+    hipLaunchKernelGGL(wino6_dy_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("wino6_dy");
+}
+
+extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
+    NG_REQUIRE(d && d->U && d->V && d->M && d->zero_page, "wino6_gemm: null pointer");
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0 && d->K > 64 && d->K % 4 == 0, "wino6_gemm: C %% 4 == 0, K > 64, K %% 4 == 0 (C=%d K=%d)", d->C, d->K);
+    const long long T = w6_tiles(d->B, d->H, d->W);
+    NG_REQUIRE(T * d->C < (1ll << 31) && T * d->K < (1ll << 31), "wino6_gemm: problem too large for 32-bit offsets");
+    NG_REQUIRE(d->V_elems >= 36 * T * d->C && d->M_elems >= 36 * T * d->K, "wino6_gemm: V / M workspace too small");
+    // one plane as a 1x1 'convolution' over a [1][T] image of C-channel pixels: the direct tile's descriptor
+    nirgan_conv_desc c = {};
+    c.in = d->V; c.in_elems = T * d->C; c.in_hp = 1; c.in_wp = int(T); c.in_cs = d->C; c.run = d->C; c.in_stride = 1;
+    c.ntaps = 1;
+    c.w = d->U; c.w_elems = (long long)d->K * d->C; c.bias = nullptr;
+    c.out = d->M; c.out_elems = T * d->K; c.out_hp = 1; c.out_wp = int(T); c.out_cs = d->K; c.out_stride = 1;
+    c.B = 1; c.OH = 1; c.OW = int(T); c.N = d->K; c.zero_page = d->zero_page;
+    W6Gemm g;
+    const int rc = ng::build_conv_params(&c, g.p);
+    if (rc != NIRGAN_OK) return rc;
+    g.in_plane = T * d->C; g.w_plane = (long long)d->K * d->C; g.out_plane = T * d->K;
+    g.per_plane = g.p.mtiles * g.p.ntiles; g.total = 36 * g.per_plane;
+    hipLaunchKernelGGL(wino6_gemm_kernel, dim3(g.total), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    return nirgan_check_launch("wino6_gemm");
+}
+
+extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
+    NG_REQUIRE(d && d->M && d->y, "wino6_output: null pointer");
+    NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0, "wino6_output: bad shape");
+    NG_REQUIRE(ng_aligned16(d->M) && ng_aligned16(d->y) && ng_aligned16(d->bias), "wino6_output: pointers must be 16-byte aligned");
+    const long long T = w6_tiles(d->B, d->H, d->W);
+    NG_REQUIRE(d->M_elems >= 36 * T * d->K, "wino6_output: M workspace too small");
+    W6Out p{d->M, d->bias, d->y, d->B, d->H, d->W, d->K, (d->H + 3) / 4, (d->W + 3) / 4, T};
+    const long long n = T * (d->K / 4);
+    hipLaunchKernelGGL(wino6_output_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("wino6_output");
+}
+
+extern "C" int nirgan_wino6_conv3x3(const nirgan_wino6_desc* d, void* stream) {
+    int rc = nirgan_wino6_input(d, stream);
+    if (rc == NIRGAN_OK) rc = nirgan_wino6_gemm(d, stream);
+    return rc != NIRGAN_OK ? rc : nirgan_wino6_output(d, stream);
+}
+
+extern "C" int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream) {
+    NG_REQUIRE(slabs && grad && nsplit >= 1 && K > 0 && C > 0, "wino6_wgrad_finish: bad arguments");
+    W6Fin p{slabs, nsplit, K, C, grad, accumulate ? 1 : 0};
+    const long long n = (long long)K * C;
+    hipLaunchKernelGGL(wino6_wgrad_finish_kernel, dim3(unsigned((n + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("wino6_wgrad_finish");
+}

@@ -158,6 +158,20 @@ class Plan:
         self.ops = [(n, a) for n, a in self.ops if n != "nirgan_wino_weights_r"]
         self.ops.append(("nirgan_wino_weights_batch", (table.data_ptr(), len(rows), first)))
 
+    def fuse_wino6_weights(self):
+        """And for the F(4x4,3x3) weight transforms (csrc/wino6.hip)."""
+        jobs = [a for n, a in self.ops if n == "nirgan_wino6_weights"]
+        if len(jobs) < 2 or len(jobs) > 256:
+            return
+        rows, first = [], 0
+        for w, K, Cc, flip, U in jobs:
+            rows.append([w, U, K, Cc, flip, first, 0, 0])
+            first += (K * Cc + 255) // 256
+        table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
+        self.ctx.keep.append(table)
+        self.ops = [(n, a) for n, a in self.ops if n != "nirgan_wino6_weights"]
+        self.ops.append(("nirgan_wino6_weights_batch", (table.data_ptr(), len(rows), first)))
+
     def run(self):
         be = L.backend()
         st = self.ctx.stream()
@@ -475,6 +489,106 @@ def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tenso
     return d
 
 
+def wino6_applicable(ctx: Ctx, k: int, cout: int) -> bool:
+    """Winograd F(4x4, 3x3) (csrc/wino6.hip) instead of F(2x2, 3x3) wherever the latter applies to a 3x3 filter: 36 instead of 64
+    products per 4x4 outputs; the transform-domain product makes one trip through HBM.  NIRGAN_NO_WINO6=1 keeps F(2x2,3x3) (A/B)."""
+    return k == 3 and cout > 64 and os.environ.get("NIRGAN_NO_WINO6") != "1"
+
+
+def _w6_tiles(B, H, W) -> int:
+    return B * (-(-H // 4)) * (-(-W // 4))
+
+
+def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y, *, H, W, cin, cout, flip=False,
+               own_V: bool = False, x_norm=None):
+    """U = G g G^T in the pack plan; input transform, 36 plane GEMMs, output transform in `plan` (None: the caller places them).
+    x: [B][H+2][W+2][cin] buffer, y: dense [B][H][W][cout].  flip: data gradient (x = dY with a zero halo of 2, H x W = padded input)."""
+    assert x.hp == H + 2 and x.wp == W + 2 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
+    B = x.B
+    T = _w6_tiles(B, H, W)
+    U = ctx.zeros(36 * cout * cin)
+    ctx.keep.append(U)
+    pack.add("nirgan_wino6_weights", weight.data_ptr(), cout, cin, 1 if flip else 0, U.data_ptr())
+    for name in ("wino6_pool_v", "wino6_pool_m"):
+        if not hasattr(ctx, name):
+            setattr(ctx, name, SplitPool(ctx))          # one layer at a time (launches run serially)
+    if own_V:                                          # kept for the layer's weight gradient (same x): 2.25 x the input bytes, resident
+        V = ctx.zeros(36 * T * cin)
+        ctx.keep.append(V)
+    else:
+        V = ctx.wino6_pool_v.get(36 * T * cin)
+    M = ctx.wino6_pool_m.get(36 * T * cout)
+    d = L.Wino6Desc()
+    d.x, d.x_hp, d.x_wp = x.ptr, x.hp, x.wp
+    d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
+    d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
+    d.zero_page = ctx.zero_page.data_ptr()
+    ctx.keep.append(d)
+    if plan is not None:
+        if x_norm is not None:             # (y, (mean, rstd), act) of the producer: its apply pass is folded into this transform
+            yh, st, act = x_norm
+            assert yh.pad == 0 and yh.H == H and yh.W == W and yh.C == cin
+            plan.add("nirgan_wino6_input_norm", C.byref(d), yh.ptr, st[0].data_ptr(), st[1].data_ptr(), act, 0.2)
+        else:
+            plan.add("nirgan_wino6_input", C.byref(d))
+        plan.add("nirgan_wino6_gemm", C.byref(d))
+        plan.add("nirgan_wino6_output", C.byref(d))
+    return d
+
+
+def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, OH, OW, cin, cout, slabs_pool,
+                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False):
+    """Backward of an F(4x4,3x3) layer: dY -> (V of dY for the data gradient, Yt = A dY A^T for the weight gradient) in one pass, the
+    data gradient's 36 plane GEMMs + output transform, the 36 transform-domain weight-gradient problems dU[f] = Yt[f]^T V[f] (V of the
+    forward input, kept by the forward) as one weight-gradient launch, dW = G^T dU G."""
+    B = inp.B
+    assert inp.pad == 1 and inp.H == OH and inp.W == OW and inp.C == cin and dy.C == cout and dy.pad == 2 and dgrad.x == dy.ptr
+    T = _w6_tiles(B, OH, OW)
+    for name in ("wino6_pool_x", "wino6_pool_y"):
+        if not hasattr(ctx, name):
+            setattr(ctx, name, SplitPool(ctx))
+    Yt = ctx.wino6_pool_y.get(36 * T * cout)
+    vin = None
+    if V_fwd is not None:
+        V_ptr, V_elems = V_fwd.V, V_fwd.V_elems
+    else:
+        V = ctx.wino6_pool_x.get(36 * T * cin)
+        vin = L.Wino6Desc()
+        vin.x, vin.x_hp, vin.x_wp, vin.B, vin.H, vin.W, vin.C, vin.K = inp.ptr, inp.hp, inp.wp, B, OH, OW, cin, cout
+        vin.V, vin.V_elems = V.data_ptr(), V.numel()
+        V_ptr, V_elems = V.data_ptr(), V.numel()
+    ydesc = L.WinoDyDesc()
+    ydesc.dy, ydesc.dy_hp, ydesc.dy_wp, ydesc.dy_pad = dy.ptr, dy.hp, dy.wp, dy.pad
+    ydesc.B, ydesc.H, ydesc.W, ydesc.K = B, OH, OW, cout
+    ydesc.Yt, ydesc.Yt_elems, ydesc.r = Yt.data_ptr(), Yt.numel(), 3
+    tiles = (-(-cout // 128)) * (-(-cin // 128)) * 36
+    nsplit, rows = G.wgrad_split(T, tiles, 1024)
+    if os.environ.get("NIRGAN_WINO6_SPLITS"):            # experiments
+        nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ["NIRGAN_WINO6_SPLITS"]))
+    slabs = slabs_pool.get(36 * nsplit * cout * cin)
+    d = L.WgradDesc()
+    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), 36 * T * cout, 1, T, cout, 0, 0
+    assert V_elems >= 36 * T * cin
+    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = V_ptr, 36 * T * cin, 1, T, cin
+    d.q_stride, d.q_oh, d.q_ow = 1, 0, 0
+    d.run = cin
+    _set_taps(d, [0], [0])
+    d.B, d.OH, d.OW, d.N = 1, 1, T, cout
+    d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
+    d.zero_page = ctx.zero_page.data_ptr()
+    d.precision = 0
+    d.nplanes, d.p_plane, d.q_plane = 36, T * cout, T * cin
+    ctx.keep.extend([vin, ydesc, d, slabs])
+    plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
+    if vin is not None:
+        plan.add("nirgan_wino6_input", C.byref(vin))
+    plan.add("nirgan_wino6_gemm", C.byref(dgrad))
+    plan.add("nirgan_wgrad_igemm", C.byref(d))
+    plan.add("nirgan_wino6_output", C.byref(dgrad))
+    plan.add("nirgan_wino6_wgrad_finish", slabs.data_ptr(), nsplit, cout, cin, grad.data_ptr(), 1 if accumulate else 0)
+    return d
+
+
 def emit_conv_group(plan: Plan, ctx: Ctx, descs: list):
     """One launch for up to 4 conv descriptors (sub-pixel phases)."""
     for i in range(0, len(descs), 4):
@@ -612,8 +726,13 @@ class ConvIN:
             keep = bool(getattr(eng, "need_backward", False)) and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"
             prod = getattr(self, "producer", None)
             xn = (prod.y, prod.stats, prod.act) if prod is not None and getattr(prod, "defer_apply", False) else None
-            self.wino_fwd = emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
-                                      cout=self.cout, own_V=keep, r=k, x_norm=xn)
+            if wino6_applicable(ctx, k, self.cout):
+                self.wino6 = True
+                self.wino_fwd = emit_wino6(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
+                                           cout=self.cout, own_V=keep, x_norm=xn)
+            else:
+                self.wino_fwd = emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
+                                          cout=self.cout, own_V=keep, r=k, x_norm=xn)
             self.wino_fwd_keeps_V = keep
         elif self.kind == "conv":
             taps = G.conv_fwd_taps(k, inp.C)
@@ -664,6 +783,15 @@ class ConvIN:
         # stride-1 convolutions that need both gradients: one fused launch (data-gradient tiles + weight-gradient tiles)
         if (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
                 and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C)):
+            if (wino6_applicable(ctx, k, inp.C) and inp.pad == 1 and p == 1 and self.cout % 128 == 0
+                    and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"):
+                # F(4x4,3x3): data gradient and transform-domain weight gradient, dY read once for both of its transforms
+                wd6 = emit_wino6(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
+                                 cin=self.cout, cout=inp.C, flip=True)
+                keepV = getattr(self, "wino_fwd_keeps_V", False) and getattr(self, "wino6", False)
+                emit_wino6_backward(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
+                                    dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None))
+                return
             # exact-fp32 mode, 3x3: the data gradient is a Winograd convolution of dY (zero halo 2) with the flipped filter over the
             # padded input extent; the weight gradient keeps the direct tile (stand-alone launch)
             wd = emit_wino(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
@@ -710,6 +838,10 @@ class ConvIN:
             if (gw is None and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C)
                     and os.environ.get("NIRGAN_NO_WINOGRAD_DGRAD_ONLY") != "1"):
                 # frozen parameters (the discriminator inside the generator step): the data gradient alone, as a Winograd convolution
+                if wino6_applicable(ctx, k, inp.C):
+                    emit_wino6(plan, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
+                               cin=self.cout, cout=inp.C, flip=True)
+                    return
                 emit_wino(plan, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
                           cin=self.cout, cout=inp.C, flip=True, r=k)
                 return

@@ -134,6 +134,11 @@ class WinoDyDesc(C.Structure):
                 ("Yt", fp), ("Yt_elems", i64), ("r", i32)]
 
 
+class Wino6Desc(C.Structure):
+    _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
+                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp)]
+
+
 class PlanEntry(C.Structure):
     _fields_ = [("op", i32), ("desc", fp)]
 
@@ -165,6 +170,17 @@ PROTOTYPES = {
     "nirgan_wino_input_dy": (i32, [C.POINTER(WinoDesc), C.POINTER(WinoDyDesc), fp]),
     "nirgan_wino_input_norm": (i32, [C.POINTER(WinoDesc), fp, fp, fp, i32, f32, fp]),
     "nirgan_wino_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
+    "nirgan_wino6_tiles": (i64, [i32, i32, i32]),
+    "nirgan_wino6_weights": (i32, [fp, i32, i32, i32, fp, fp]),
+    "nirgan_wino6_weights_batch": (i32, [fp, i32, i32, fp]),
+    "nirgan_wino6_input": (i32, [C.POINTER(Wino6Desc), fp]),
+    "nirgan_wino6_input_norm": (i32, [C.POINTER(Wino6Desc), fp, fp, fp, i32, f32, fp]),
+    "nirgan_wino6_gemm": (i32, [C.POINTER(Wino6Desc), fp]),
+    "nirgan_wino6_output": (i32, [C.POINTER(Wino6Desc), fp]),
+    "nirgan_wino6_conv3x3": (i32, [C.POINTER(Wino6Desc), fp]),
+    "nirgan_wino6_dy": (i32, [C.POINTER(WinoDyDesc), fp]),
+    "nirgan_wino6_input_dy": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), fp]),
+    "nirgan_wino6_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),
     "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),
     "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),

@@ -42,6 +42,7 @@ class _Engine:
             for pl in (self.pack_fwd, self.pack_bwd):
                 pl.fuse_packs()
                 pl.fuse_wino_weights()
+                pl.fuse_wino6_weights()
             self._packs_fused = True
         if self._packed_version != version:
             self.pack_fwd.run()

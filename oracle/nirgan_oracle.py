@@ -124,6 +124,69 @@ def _linear(x, w, b=None):
     return _rounded(lambda a, k: F.linear(a, k), x, w, b, (1, -1))
 
 
+# --------------------------------------------------------------------------------------
+# Kinks (test / diagnostic seam).  ReLU, LeakyReLU and |.| are the only non-smooth points of the step.  An element within fp32
+# rounding of a kink takes different branches in two CORRECT evaluations (26 M activations per tile: a few hundred always do), and
+# one flipped activation moves a gradient tensor by ~1e-3 of its norm -- which is what limits any fp32-vs-fp64 gradient comparison
+# at full size.  `record_kinks()` collects the branch decisions of an evaluation in call order; `forced_kinks(masks)` makes an
+# evaluation TAKE recorded decisions (from another evaluation of the same step, e.g. the device's), after which the comparison is
+# between smooth functions and can be tight.
+# --------------------------------------------------------------------------------------
+_KINKS = None        # None | ("record", list) | ("force", iterator)
+
+
+class record_kinks:
+    def __enter__(self):
+        global _KINKS
+        self.masks = []
+        _KINKS = ("record", self.masks)
+        return self.masks
+
+    def __exit__(self, *exc):
+        global _KINKS
+        _KINKS = None
+
+
+class forced_kinks:
+    def __init__(self, masks):
+        self.masks = list(masks)
+
+    def __enter__(self):
+        global _KINKS
+        self.it = iter(self.masks)
+        _KINKS = ("force", self.it)
+        return self
+
+    def __exit__(self, *exc):
+        global _KINKS
+        _KINKS = None
+        if exc[0] is None:
+            assert next(self.it, None) is None, "forced_kinks: more recorded decisions than kinks evaluated"
+
+
+def _branch(x: torch.Tensor) -> torch.Tensor:
+    """1 where the kink's upper branch is taken (x > 0): from x itself, or the recorded decision."""
+    if _KINKS is None:
+        return x > 0
+    if _KINKS[0] == "record":
+        _KINKS[1].append((x > 0).detach())
+        return x > 0
+    m = next(_KINKS[1])
+    assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
+    return m
+
+
+def _relu(x: torch.Tensor) -> torch.Tensor:
+    return F.relu(x) if _KINKS is None else x * _branch(x).to(x.dtype)
+
+
+def _lrelu(x: torch.Tensor, slope: float) -> torch.Tensor:
+    if _KINKS is None:
+        return F.leaky_relu(x, slope)
+    m = _branch(x).to(x.dtype)
+    return x * (m + slope * (1 - m))
+
+
 def _inorm(x: torch.Tensor) -> torch.Tensor:
     # InstanceNorm2d(affine=False, track_running_stats=False): networks.py:30
     return F.instance_norm(x, eps=IN_EPS)
@@ -135,7 +198,7 @@ def _inorm(x: torch.Tensor) -> torch.Tensor:
 def generator_trunk_head(p: Params, x: torch.Tensor) -> torch.Tensor:
     """model[:6] of the reference: pad3, conv7, IN, ReLU, conv3 s2, IN (generator_inject.py:107)."""
     x = _conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), p["model.1.weight"], p["model.1.bias"])
-    x = F.relu(_inorm(x))
+    x = _relu(_inorm(x))
     x = _conv2d(x, p["model.4.weight"], p["model.4.bias"], stride=2, padding=1)
     return _inorm(x)
 
@@ -143,20 +206,20 @@ def generator_trunk_head(p: Params, x: torch.Tensor) -> torch.Tensor:
 def generator_trunk_tail(p: Params, x: torch.Tensor, n_blocks: int) -> torch.Tensor:
     """model[6:] of the reference: ReLU, conv3 s2, IN, ReLU, blocks, 2x convT, pad3, conv7, tanh."""
     k = generator_keys(n_blocks)
-    x = F.relu(x)
+    x = _relu(x)
     x = _conv2d(x, p["model.7.weight"], p["model.7.bias"], stride=2, padding=1)
-    x = F.relu(_inorm(x))
+    x = _relu(_inorm(x))
     for i in k["blocks"]:          # ResnetBlock.forward: out = x + conv_block(x) (networks.py:430-434)
         h = _conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"),
                      p[f"model.{i}.conv_block.1.weight"], p[f"model.{i}.conv_block.1.bias"])
-        h = F.relu(_inorm(h))
+        h = _relu(_inorm(h))
         h = _conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"),
                      p[f"model.{i}.conv_block.5.weight"], p[f"model.{i}.conv_block.5.bias"])
         x = x + _inorm(h)
     for i in k["up"]:              # ConvTranspose2d k3 s2 p1 op1 (networks.py:360-363)
         x = _conv_transpose2d(x, p[f"model.{i}.weight"], p[f"model.{i}.bias"],
                                stride=2, padding=1, output_padding=1)
-        x = F.relu(_inorm(x))
+        x = _relu(_inorm(x))
     i = k["last"]
     x = _conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), p[f"model.{i}.weight"], p[f"model.{i}.bias"])
     return torch.tanh(x)
@@ -204,10 +267,10 @@ def generator_inject_forward(p: Params, x: torch.Tensor, embeds: torch.Tensor, n
 # --------------------------------------------------------------------------------------
 def discriminator_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     """NLayerDiscriminator(n_layers=3).forward: 70x70 PatchGAN, no sigmoid."""
-    x = F.leaky_relu(_conv2d(x, p["model.0.weight"], p["model.0.bias"], stride=2, padding=1), 0.2)
+    x = _lrelu(_conv2d(x, p["model.0.weight"], p["model.0.bias"], stride=2, padding=1), 0.2)
     for i, s in ((2, 2), (5, 2), (8, 1)):
         x = _conv2d(x, p[f"model.{i}.weight"], p[f"model.{i}.bias"], stride=s, padding=1)
-        x = F.leaky_relu(_inorm(x), 0.2)
+        x = _lrelu(_inorm(x), 0.2)
     return _conv2d(x, p["model.11.weight"], p["model.11.bias"], stride=1, padding=1)
 
 
@@ -228,7 +291,11 @@ def lsgan_loss(pred: torch.Tensor, target_is_real: bool) -> torch.Tensor:
 
 def l1_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """torch.nn.L1Loss() (pix2pix.py:60, used :222)."""
-    return F.l1_loss(pred, target)
+    if _KINKS is None:
+        return F.l1_loss(pred, target)
+    d = pred - target
+    m = _branch(d).to(d.dtype)
+    return (d * (2 * m - 1)).mean()
 
 
 def _crit(name: str):

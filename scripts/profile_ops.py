@@ -51,8 +51,16 @@ def describe(name, args):
         w = args[0]._obj
         M = w.B * w.OH * w.OW
         K = w.ntaps * w.run
-        blocks = (-(-w.N // 128) if w.N > 64 else 1) * (-(-K // 128)) * w.nsplit
-        return f"wgrad M={M} N={w.N} K={K} split={w.nsplit} blk={blocks}", 2.0 * M * w.N * K
+        npl = max(w.nplanes, 1)
+        blocks = (-(-w.N // 128) if w.N > 64 else 1) * (-(-K // 128)) * w.nsplit * npl
+        return f"wgrad M={M} N={w.N} K={K} split={w.nsplit} planes={npl} blk={blocks}", 2.0 * npl * M * w.N * K
+    if name == "nirgan_wino6_gemm":
+        d = args[0]._obj
+        T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
+        return f"wino6 gemm 36 x [T={T} x C={d.C}] x [K={d.K}] blk={36 * -(-T // 128) * -(-d.K // 128)} (executed flops)", 2.0 * 36 * T * d.C * d.K
+    if name in ("nirgan_wino6_input", "nirgan_wino6_input_norm", "nirgan_wino6_output", "nirgan_wino6_input_dy"):
+        d = args[0]._obj
+        return f"{name[7:]} B={d.B} {d.H}x{d.W} C={d.C} K={d.K}", 0.0
     if name == "nirgan_conv_wgrad_pair":
         c, w = args[0]._obj, args[1]._obj
         Mc, Mw = c.B * c.OH * c.OW, w.B * w.OH * w.OW

@@ -328,7 +328,7 @@ def fit_loop_schedulers_checkpoint_resume(dev, tmp_path, tol: Tol):
     trb = m_b.fused_trainer()
     assert trb.flatG.step_count == 6 and trb.flatD.step_count == 6
     for (k, qa), (_, qb) in zip(m_full.named_parameters(), m_b.named_parameters()):
-        close(qb, qa, 1e-6, "resumed " + k)
+        close(qb, qa, 1e-5, "resumed " + k)          # live biases accumulate with float atomics: order noise
     close(trb.flatG.m, tr.flatG.m, 1e-5, "resumed exp_avg")
     close(trb.flatG.v, tr.flatG.v, 1e-5, "resumed exp_avg_sq")
     # torch.optim.Adam accepts the optimizer state written here (a Lightning resume with the stock optimizer)

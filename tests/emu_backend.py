@@ -466,6 +466,132 @@ class EmuBackend:
             o[:] = g.astype(np.float32)
         return 0
 
+    # ------------------------------------------------------------------ Winograd F(4x4, 3x3) (csrc/wino6.hip)
+    _G6 = np.array([[1 / 2, 0, 0], [1 / 6, 1 / 6, 1 / 6], [1 / 6, -1 / 6, 1 / 6], [1 / 30, 1 / 15, 2 / 15], [16 / 15, -8 / 15, 4 / 15], [0, 0, 1 / 2]])
+    _BT6 = np.array([[2, 3, -4, -3, 2, 0], [0, 2, 5, 1, -2, 0], [0, 2, 1, -5, 2, 0], [0, -1, -2, 1, 2, 0], [0, -2, 1, 2, -1, 0], [0, 2, 3, -4, -3, 2]], dtype=np.float64)
+    _AT6 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -1 / 2, 0], [0, 1, 1, 4, 1 / 4, 0], [0, 1, -1, 8, -1 / 8, 1]], dtype=np.float64)
+
+    def nirgan_wino6_tiles(self, B, H, W):
+        return B * ((H + 3) // 4) * ((W + 3) // 4) if min(B, H, W) > 0 else 0
+
+    def nirgan_wino6_weights(self, w, K, Cc, flip, U, stream=None):
+        self.calls.append("wino6_w")
+        if flip:
+            g = arr(w, K * Cc * 9).reshape(Cc, K, 3, 3).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
+        else:
+            g = arr(w, K * Cc * 9).reshape(K, Cc, 3, 3).astype(np.float64)
+        u = np.einsum("ai,kcij,bj->abkc", self._G6, g, self._G6)
+        arr(U, 36 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
+        return 0
+
+    def nirgan_wino6_weights_batch(self, jobs, njobs, total_blocks, stream=None):
+        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 8)).from_address(int(jobs))).reshape(njobs, 8)
+        blocks = 0
+        for w, U, K, Cc, flip, first, _, _ in J:
+            if first != blocks:
+                return self._fail("wino6_weights_batch: first_block mismatch")
+            self.nirgan_wino6_weights(int(w), int(K), int(Cc), int(flip), int(U))
+            blocks += (int(K) * int(Cc) + 255) // 256
+        return 0 if blocks == total_blocks else self._fail("wino6_weights_batch: total_blocks mismatch")
+
+    def _wino6_V(self, x, B, H, W, Cc):
+        """x: [B][H+2][W+2][C] float64 -> V [6][6][B][TH][TW][C]"""
+        TH, TW = (H + 3) // 4, (W + 3) // 4
+        xp = np.zeros((B, 4 * TH + 2, 4 * TW + 2, Cc))
+        xp[:, :H + 2, :W + 2] = x
+        tiles = np.stack([np.stack([xp[:, i:i + 4 * TH:4, j:j + 4 * TW:4] for j in range(6)], 0) for i in range(6)], 0)
+        return np.einsum("ai,ijbyxc,lj->albyxc", self._BT6, tiles, self._BT6)
+
+    def nirgan_wino6_input(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("wino6_in")
+        if d.x_hp != d.H + 2 or d.x_wp != d.W + 2 or d.C % 4:
+            return self._fail("wino6_input: bad geometry")
+        B, H, W, Cc = d.B, d.H, d.W, d.C
+        if d.V_elems < 36 * self.nirgan_wino6_tiles(B, H, W) * Cc:
+            return self._fail("wino6_input: V workspace too small")
+        x = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
+        V = self._wino6_V(x, B, H, W, Cc)
+        arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
+        return 0
+
+    def nirgan_wino6_input_norm(self, ref, y, mean, rstd, act, slope, stream=None):
+        d = obj(ref)
+        self.calls.append("wino6_in_norm")
+        B, H, W, Cc = d.B, d.H, d.W, d.C
+        yv = arr(y, B * H * W * Cc).reshape(B, H, W, Cc)
+        m, r = arr(mean, B * Cc).reshape(B, 1, 1, Cc), arr(rstd, B * Cc).reshape(B, 1, 1, Cc)
+        a = self._act(((yv - m) * r).astype(np.float32).astype(np.float64), act, slope).astype(np.float32)       # in_apply's fp32 arithmetic
+        hh, ww = reflect(np.arange(H + 2) - 1, H), reflect(np.arange(W + 2) - 1, W)
+        V = self._wino6_V(a[:, hh][:, :, ww].astype(np.float64), B, H, W, Cc)
+        arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
+        return 0
+
+    def nirgan_wino6_gemm(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("wino6_gemm")
+        T = self.nirgan_wino6_tiles(d.B, d.H, d.W)
+        if d.K <= 64 or d.K % 4 or d.C % 4 or d.V_elems < 36 * T * d.C or d.M_elems < 36 * T * d.K:
+            return self._fail("wino6_gemm: bad geometry / workspace")
+        V = arr(d.V, 36 * T * d.C).reshape(36, T, d.C).astype(np.float64)
+        U = arr(d.U, 36 * d.K * d.C).reshape(36, d.K, d.C).astype(np.float64)
+        arr(d.M, 36 * T * d.K)[:] = np.einsum("ftc,fkc->ftk", V, U).reshape(-1).astype(np.float32)
+        return 0
+
+    def nirgan_wino6_output(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("wino6_out")
+        B, H, W, K = d.B, d.H, d.W, d.K
+        TH, TW = (H + 3) // 4, (W + 3) // 4
+        M = arr(d.M, 36 * B * TH * TW * K).reshape(6, 6, B, TH, TW, K).astype(np.float64)
+        Y = np.einsum("pa,albyxk,ql->bypxqk", self._AT6, M, self._AT6).reshape(B, 4 * TH, 4 * TW, K)
+        bias = arr(d.bias, K)
+        if bias is not None:
+            Y = Y + bias
+        arr(d.y, B * H * W * K).reshape(B, H, W, K)[:] = Y[:, :H, :W].astype(np.float32)
+        return 0
+
+    def nirgan_wino6_conv3x3(self, ref, stream=None):
+        for fn in (self.nirgan_wino6_input, self.nirgan_wino6_gemm, self.nirgan_wino6_output):
+            rc = fn(ref)
+            if rc:
+                return rc
+        return 0
+
+    def nirgan_wino6_dy(self, ref, stream=None):
+        d = obj(ref)
+        self.calls.append("wino6_dy")
+        B, H, W, K = d.B, d.H, d.W, d.K
+        TH, TW = (H + 3) // 4, (W + 3) // 4
+        if d.Yt_elems < 36 * B * TH * TW * K or d.dy_hp != H + 2 * d.dy_pad:
+            return self._fail("wino6_dy: bad geometry / workspace")
+        dy = arr(d.dy, B * d.dy_hp * d.dy_wp * K).reshape(B, d.dy_hp, d.dy_wp, K).astype(np.float64)
+        z = np.zeros((B, 4 * TH, 4 * TW, K))
+        z[:, :H, :W] = dy[:, d.dy_pad:d.dy_pad + H, d.dy_pad:d.dy_pad + W]
+        tiles = np.stack([np.stack([z[:, i::4, j::4] for j in range(4)], 0) for i in range(4)], 0)       # [4][4][B][TH][TW][K]
+        A = self._AT6.T                                                                                   # 6 x 4
+        Yt = np.einsum("ia,abnyxk,jb->ijnyxk", A, tiles, A)
+        arr(d.Yt, 36 * B * TH * TW * K)[:] = Yt.reshape(-1).astype(np.float32)
+        return 0
+
+    def nirgan_wino6_input_dy(self, cref, yref, stream=None):
+        c, y = obj(cref), obj(yref)
+        if c.x != y.dy or y.dy_pad != 2 or c.H != y.H + 2 or c.W != y.W + 2 or c.C != y.K:
+            return self._fail("wino6_input_dy: the two descriptors do not describe the same output-gradient buffer")
+        rc = self.nirgan_wino6_input(cref)
+        return rc if rc else self.nirgan_wino6_dy(yref)
+
+    def nirgan_wino6_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
+        self.calls.append("wino6_fin")
+        u = arr(slabs, 36 * nsplit * K * Cc).reshape(6, 6, nsplit, K, Cc).astype(np.float64).sum(2)
+        g = np.einsum("ai,abkc,bj->kcij", self._G6, u, self._G6)
+        o = arr(grad, K * Cc * 9).reshape(K, Cc, 3, 3)
+        if accumulate:
+            o += g.astype(np.float32)
+        else:
+            o[:] = g.astype(np.float32)
+        return 0
+
     def nirgan_wino_wgrad_pair(self, cref, wref, stream=None):
         rc = self.nirgan_wino_gemm(cref)              # the input transform of cref has run (nirgan_wino_input / _input_dy)
         return rc if rc else self.nirgan_wgrad_igemm(wref)

@@ -35,6 +35,8 @@ def test_descriptor_validation_rejects_bad_arguments_without_launching():
     assert be.nirgan_location_encoder(L.LocEncDesc(), None) == -1 and b"location_encoder" in be.nirgan_last_error()
     assert be.nirgan_hist_match(L.HistMatchDesc(), None) == -1 and b"hist_match" in be.nirgan_last_error()
     assert be.nirgan_hist_match_ws_bytes(2, 65536) == 2 * 65536 * 12 and be.nirgan_hist_match_ws_bytes(1, 1000) == 2048 * 12
+    assert be.nirgan_wino6_gemm(L.Wino6Desc(), None) == -1 and b"wino6_gemm" in be.nirgan_last_error()
+    assert be.nirgan_wino6_input(L.Wino6Desc(), None) == -1 and be.nirgan_wino6_tiles(16, 64, 64) == 4096 and be.nirgan_wino6_tiles(2, 69, 66) == 2 * 18 * 17
     d = L.ConvDesc()
     d.precision = 7
     assert be.nirgan_conv_igemm(d, None) == -1
@@ -52,7 +54,7 @@ def test_struct_layouts_match_the_header(tmp_path):
              ("nirgan_metrics_desc", L.MetricsDesc, "means"), ("nirgan_locenc_desc", L.LocEncDesc, "features"),
              ("nirgan_hist_match_desc", L.HistMatchDesc, "out"), ("nirgan_ssim_loss_desc", L.SsimLossDesc, "grad_pred"), ("nirgan_emd_loss_desc", L.EmdLossDesc, "grad_pred"),
              ("nirgan_wino_desc", L.WinoDesc, "split_ws_elems"),
-             ("nirgan_wino_dy_desc", L.WinoDyDesc, "r")]
+             ("nirgan_wino_dy_desc", L.WinoDyDesc, "r"), ("nirgan_wino6_desc", L.Wino6Desc, "zero_page")]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "nirgan_hip.h"\nint main(void){\n'
     for cname, _, last in pairs:
         src += f'printf("%zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));\n'

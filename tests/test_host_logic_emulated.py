@@ -723,12 +723,16 @@ def test_fused_trainer_with_the_ssim_term(emu, golden_dir):
                 close(gG[k], v, 2e-4, f"gG {k} (micro {micro})")
 
 
-def test_generator_winograd_layers_through_the_trainer(emu):
-    """ngf = 32 makes the residual-block convolutions 128 -> 128 channels, wide enough for the Winograd path: forward with the
-    instance-norm apply of each block's first convolution folded into the second one's input transform (nirgan_wino_input_norm),
-    fused data/weight gradients with one transform pass over dY (nirgan_wino_input_dy).  One fused step against the oracle."""
+@pytest.mark.parametrize("variant", ["F(4x4,3x3)", "F(2x2,3x3)"])
+def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant):
+    """ngf = 32 makes the residual-block convolutions 128 -> 128 channels, wide enough for the Winograd paths: forward with the
+    instance-norm apply of each block's first convolution folded into the second one's input transform, data gradient and
+    transform-domain weight gradient with one transform pass over dY.  One fused step against the oracle, with the default
+    F(4x4,3x3) path (csrc/wino6.hip: 36 plane GEMMs + separate output transform) and with F(2x2,3x3) (NIRGAN_NO_WINO6=1)."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
+    if variant == "F(2x2,3x3)":
+        monkeypatch.setenv("NIRGAN_NO_WINO6", "1")
     torch.manual_seed(5)
     netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
@@ -737,7 +741,13 @@ def test_generator_winograd_layers_through_the_trainer(emu):
     rgb, nir = torch.rand(2, 3, 32, 32), torch.rand(2, 1, 32, 32)
     tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0)
     out = tr.step(rgb, nir).as_dict()
-    assert emu.calls.count("wino_in_norm") == 6 and emu.calls.count("wino") >= 24, "the Winograd path did not run as expected"
+    if variant == "F(2x2,3x3)":
+        assert emu.calls.count("wino_in_norm") == 6 and emu.calls.count("wino") >= 24, "the Winograd path did not run as expected"
+    else:
+        # 12 forward + 12 data-gradient GEMM launches, 6 normalising input transforms, 12 weight-gradient finishes, V kept by the forward
+        assert emu.calls.count("wino6_in_norm") == 6 and emu.calls.count("wino6_gemm") == 24 and emu.calls.count("wino6_out") == 24
+        assert emu.calls.count("wino6_fin") == 12 and emu.calls.count("wino6_dy") == 12 and "wino_in_norm" not in emu.calls
+        assert emu.calls.count("wino6_in") == 6 + 12          # c1 forwards + the dY transforms (no re-transform of the forward input)
     ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
     o = ref.step(rgb, nir)
     close(tr.G.pred, ref.last["pred"], 2e-5, "pred")
