@@ -20,6 +20,7 @@
 //   G   = [[1/2,0,0],[1/6,1/6,1/6],[1/6,-1/6,1/6],[1/30,1/15,2/15],[16/15,-8/15,4/15],[0,0,1/2]]
 //   A^T = [[1,1,1,1,1,0],[0,1,-1,2,-1/2,0],[0,1,1,4,1/4,0],[0,1,-1,8,-1/8,1]]
 #include "igemm_tiles.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256) void wino6_dy_kernel(const W6Dy p) {
 // ------------------------------------------------------------------------------------------------ plane GEMMs
 struct W6Gemm { ng::ConvParams p; long long in_plane, w_plane, out_plane; int per_plane, total; };
 
+// general form: the direct 128 x 128 x 32 tile (two resident workgroups per CU)
 __global__ __launch_bounds__(256, 2) void wino6_gemm_kernel(const W6Gemm g) {
     __shared__ __attribute__((aligned(16))) char st0[(128 + 128) * 128];
     __shared__ __attribute__((aligned(16))) char st1[(128 + 128) * 128];
@@ -244,6 +246,134 @@ __global__ __launch_bounds__(256, 2) void wino6_gemm_kernel(const W6Gemm g) {
     const int plane = rid / g.per_plane, local = rid - plane * g.per_plane;
     ng::conv_tile<128, 0>(g.p, local, st0, st1, g.p.in + size_t(plane) * g.in_plane, g.p.w + size_t(plane) * g.w_plane,
                           g.p.out + size_t(plane) * g.out_plane);
+}
+
+// The plane GEMMs contract over C = 256 only: 8 K-steps of the tile above against a prologue + epilogue of ~20 k cycles per tile,
+// (measured 103-110 TFLOP/s at C = 256 against 126 at C = 1024, scripts/bench_wino6_gemm.py).  This variant stages 16 k per step:
+// 64-byte rows, 2 x 16 KB of LDS and 112 VGPRs, so up to FOUR workgroups are resident per CU.  Measured: within 2 % of the 32-k tile
+// either way (186 vs 188 us at T = 4096, 211 vs 220 at T = 4624, 355 vs 341 at T = 8192) -- more resident workgroups do not buy back
+// the per-tile cost; it is the default because the step as a whole runs 0.6 % faster with it (NIRGAN_WINO6_GEMM32=1 selects the other).
+//   A [T][C] (row-major, rows = tiles), B [K][C], Out [T][K];  128 x 128 block tile, 4 waves as 2 x 2, wave = 64 x 64.
+//   LDS-DMA piece = 16 rows x 64 B; the 16-byte chunk index is XOR-swizzled with (row >> 2) & 3 on the source side and at the
+//   ds_read_b128 (8 consecutive rows hit 8 distinct 16-byte bank groups).  Lanes 0-31 read chunk 2g, lanes 32-63 chunk 2g+1 of their
+//   row: MFMA j of group g contracts k = 8g + j and 8g + 4 + j (same permutation of k for A and B: the sum is unchanged).
+struct W6G16 { const float* A; const float* Bw; float* Out; const float* zero; int T, C, K, mtiles, ntiles, per_plane, total;
+               long long a_plane, b_plane, o_plane; };
+
+__global__ __launch_bounds__(256, 3) void wino6_gemm16_kernel(const W6G16 p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 16384];
+    constexpr int STAGE = 16384, A_BYTES = 8192;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rid = ng_xcd_remap(blockIdx.x, p.total);
+    const int plane = rid / p.per_plane;
+    const int id = rid - plane * p.per_plane;        // consecutive in time on one XCD: the two N tiles of an M tile share their V rows in L2
+    const int n0 = (id % p.ntiles) * 128, m0 = (id / p.ntiles) * 128;
+    const float* A = p.A + size_t(plane) * p.a_plane;
+    const float* Bw = p.Bw + size_t(plane) * p.b_plane;
+    float* Out = p.Out + size_t(plane) * p.o_plane;
+
+    // ---------------- loader: wave w owns A pieces 2w, 2w+1 and B pieces 2w, 2w+1 (16 rows x 64 B each)
+    const int prow = lane >> 2, lchunk = lane & 3;
+    int a_base[2], b_base[2];
+    bool b_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + prow;
+        const int sc = lchunk ^ ((row >> 2) & 3);
+        int m = m0 + row;
+        m = m < p.T ? m : p.T - 1;
+        a_base[i] = m * p.C + sc * 4;
+        const int n = n0 + row;
+        b_ok[i] = n < p.K;
+        b_base[i] = (b_ok[i] ? n : 0) * p.C + sc * 4;
+    }
+    auto issue = [&](char* sA, int c0) {
+        char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ng_glds16(A + (a_base[i] + c0), sA + (wave * 2 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ng_glds16(b_ok[i] ? Bw + (b_base[i] + c0) : p.zero, sB + (wave * 2 + i) * 1024);
+    };
+
+    // ---------------- compute: wave (wr, wc) = rows wr*64 .. +63, columns wc*64 .. +63
+    const int wr = wave >> 1, wc = wave & 1, half = lane >> 5;
+    int a_off[2], a_key[2], b_off[2], b_key[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = wr * 64 + t * 32 + (lane & 31), rb = wc * 64 + t * 32 + (lane & 31);
+        a_off[t] = ra * 64; a_key[t] = (ra >> 2) & 3;
+        b_off[t] = rb * 64; b_key[t] = (rb >> 2) & 3;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    auto compute = [&](const char* sA) {
+        const char* sB = sA + A_BYTES;
+        f32x4 a[2][2], b[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int chunk = 2 * g + half;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[g][t] = *reinterpret_cast<const f32x4*>(sA + a_off[t] + ((chunk ^ a_key[t]) << 4));
+                b[g][t] = *reinterpret_cast<const f32x4*>(sB + b_off[t] + ((chunk ^ b_key[t]) << 4));
+            }
+        }
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][mt][j], b[g][nt][j], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nk = p.C >> 4;
+    issue(lds, 0);
+    for (int s = 0; s < nk; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nk) issue(lds + ((s + 1) & 1) * STAGE, (s + 1) << 4);
+        compute(lds + (s & 1) * STAGE);
+    }
+
+    // ---------------- epilogue: the tile goes through LDS in two halves of 64 rows (32 KB) so that every store is a whole 16-byte
+    // row segment.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    float* buf = reinterpret_cast<float*>(lds);
+    const int chunk = tid & 31, row0 = tid >> 5;
+    const int n = n0 + chunk * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (wr == h) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int col = wc * 64 + nt * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) buf[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 128 + col] = acc[mt][nt][r];
+                }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int row = row0; row < 64; row += 8) {
+            const int m = m0 + h * 64 + row;
+            if (m < p.T && n < p.K) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(buf + row * 128 + chunk * 4);
+                *reinterpret_cast<f32x4*>(Out + size_t(m) * p.K + n) = v;           // K % 4 == 0: whole float4s
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ output transform
@@ -429,6 +559,16 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
     c.w = d->U; c.w_elems = (long long)d->K * d->C; c.bias = nullptr;
     c.out = d->M; c.out_elems = T * d->K; c.out_hp = 1; c.out_wp = int(T); c.out_cs = d->K; c.out_stride = 1;
     c.B = 1; c.OH = 1; c.OW = int(T); c.N = d->K; c.zero_page = d->zero_page;
+    if (d->C % 16 == 0 && getenv("NIRGAN_WINO6_GEMM32") == nullptr) {
+        // 16-k stages, three resident workgroups per CU (see wino6_gemm16_kernel)
+        NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm: pointers must be 16-byte aligned");
+        W6G16 q;
+        q.A = d->V; q.Bw = d->U; q.Out = d->M; q.zero = d->zero_page; q.T = int(T); q.C = d->C; q.K = d->K;
+        q.mtiles = int((T + 127) / 128); q.ntiles = (d->K + 127) / 128; q.per_plane = q.mtiles * q.ntiles; q.total = 36 * q.per_plane;
+        q.a_plane = T * d->C; q.b_plane = (long long)d->K * d->C; q.o_plane = T * d->K;
+        hipLaunchKernelGGL(wino6_gemm16_kernel, dim3(q.total), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+        return nirgan_check_launch("wino6_gemm");
+    }
     W6Gemm g;
     const int rc = ng::build_conv_params(&c, g.p);
     if (rc != NIRGAN_OK) return rc;

@@ -103,17 +103,40 @@ class Halo:
 
 
 HOOK = "__hook__"
+JOIN = "__join__"
+_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device):
+    """One auxiliary HIP stream per device for work that is off a plan's critical path (weight gradients under the HBM-bound
+    kernels of the data-gradient chain)."""
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return _SIDE_STREAMS[key]
 
 
 class Plan:
     def __init__(self, ctx: Ctx):
         self.ctx = ctx
         self.ops: list = []
+        self.side: set = set()       # indices of ops issued on the auxiliary stream (add_side)
         self.probe_idx = None        # bench.py: {op index: kernel label} to bracket with HIP events on the launch stream
         self.probe_events: list = []
 
     def add(self, name: str, *args):
         self.ops.append((name, args))
+
+    def add_side(self, name: str, *args):
+        """An op that may run on the device's auxiliary stream: it is ordered after everything the plan issued before it and before
+        the next join (add_join, any hook, the end of the plan).  The caller guarantees that nothing issued in between touches its
+        outputs or overwrites its inputs."""
+        self.ops.append((name, args))
+        self.side.add(len(self.ops) - 1)
+
+    def add_join(self):
+        """The launch stream waits for the auxiliary stream's work issued so far."""
+        self.ops.append((JOIN, ()))
 
     def insert_hook(self, index: int, fn) -> None:
         """Host callback between two launches (data parallel: start a gradient bucket's all-reduce as soon as the launches
@@ -126,12 +149,14 @@ class Plan:
                     break
                 seen += 1
         self.ops.insert(pos, (HOOK, (fn,)))
+        self.side = {i + 1 if i >= pos else i for i in self.side}
 
     def extend(self, other: "Plan"):
         self.ops.extend(other.ops)
 
     def fuse_packs(self):
         """Replace the nirgan_pack_rows ops of this plan by ONE nirgan_pack_rows_batch launch (job table in device memory)."""
+        assert not self.side, "pack plans carry no auxiliary-stream ops"
         packs = [(a, n == "nirgan_pack_rows_bf16") for n, a in self.ops if n in ("nirgan_pack_rows", "nirgan_pack_rows_bf16")]
         if len(packs) < 2 or len(packs) > 256:
             return
@@ -175,31 +200,58 @@ class Plan:
     def run(self):
         be = L.backend()
         st = self.ctx.stream()
-        if self.probe_idx:
-            return self._run_probed(be, st)
+        # auxiliary-stream ops are OPT-IN (NIRGAN_SIDE_STREAM=1): measured +1 % for the single-stream step (25.46 -> 25.23 ms) -- a kernel
+        # that already fills every CU leaves the other stream's HBM-bound kernels one workgroup per CU -- and -4 % with two micro-batches
+        use_side = bool(self.side) and self.ctx.device.type == "cuda" and os.environ.get("NIRGAN_SIDE_STREAM") == "1"
+        if self.probe_idx or use_side:
+            return self._run_streams(be, st, use_side)
         for name, args in self.ops:
             if name is HOOK:
                 args[0]()
+                continue
+            if name is JOIN:
                 continue
             rc = getattr(be, name)(*args, st)
             if rc != 0:
                 L.check(rc, name)
 
-    def _run_probed(self, be, st):
+    def _run_streams(self, be, st, use_side):
+        """The general runner: auxiliary-stream ops (fork after the preceding launch, join on demand) and / or per-op HIP events."""
+        main = torch.cuda.current_stream(self.ctx.device) if self.ctx.device.type == "cuda" else None
+        side = _side_stream(self.ctx.device) if use_side else None
+        forked = False
+
+        def join():
+            nonlocal forked
+            if forked:
+                main.wait_stream(side)
+                forked = False
+        probes = self.probe_idx or {}
         for i, (name, args) in enumerate(self.ops):
             if name is HOOK:
+                join()
                 args[0]()
                 continue
-            if i in self.probe_idx:
+            if name is JOIN:
+                join()
+                continue
+            on_side = use_side and i in self.side
+            if on_side and not forked:
+                side.wait_stream(main)           # ordered after everything issued so far
+                forked = True
+            stream_obj = side if on_side else main
+            handle = stream_obj.cuda_stream if stream_obj is not None else st
+            if i in probes:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                rc = getattr(be, name)(*args, st)
-                e.record()
-                self.probe_events.append((self.probe_idx[i], s, e))
+                s.record(stream_obj)
+                rc = getattr(be, name)(*args, handle)
+                e.record(stream_obj)
+                self.probe_events.append((probes[i], s, e))
             else:
-                rc = getattr(be, name)(*args, st)
+                rc = getattr(be, name)(*args, handle)
             if rc != 0:
                 L.check(rc, name)
+        join()
 
 
 def _set_taps(desc, dh, dw):
@@ -544,10 +596,17 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     B = inp.B
     assert inp.pad == 1 and inp.H == OH and inp.W == OW and inp.C == cin and dy.C == cout and dy.pad == 2 and dgrad.x == dy.ptr
     T = _w6_tiles(B, OH, OW)
-    for name in ("wino6_pool_x", "wino6_pool_y"):
+    for name in ("wino6_pool_x", "wino6_pool_y", "wino6_pool_y2", "wino6_slabs"):
         if not hasattr(ctx, name):
             setattr(ctx, name, SplitPool(ctx))
-    Yt = ctx.wino6_pool_y.get(36 * T * cout)
+    # the weight-gradient launches run on the auxiliary stream under the HBM-bound kernels that follow the data gradient (output
+    # transform, instance-norm backward, the next layer's dY transforms): Yt alternates between two buffers so that the next
+    # layer's transform does not overwrite what the previous layer's weight gradient is still reading; the slabs are its own pool
+    ctx.wino6_flip = getattr(ctx, "wino6_flip", 0) ^ 1
+    side_ok = V_fwd is not None
+    Yt = (ctx.wino6_pool_y2 if (ctx.wino6_flip and side_ok) else ctx.wino6_pool_y).get(36 * T * cout)
+    if side_ok:
+        slabs_pool = ctx.wino6_slabs
     vin = None
     if V_fwd is not None:
         V_ptr, V_elems = V_fwd.V, V_fwd.V_elems
@@ -582,10 +641,12 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
     if vin is not None:
         plan.add("nirgan_wino6_input", C.byref(vin))
+    plan.add_join()                          # the previous layer's weight gradient is done before this layer's GEMM takes the matrix pipe
     plan.add("nirgan_wino6_gemm", C.byref(dgrad))
-    plan.add("nirgan_wgrad_igemm", C.byref(d))
+    add_w = plan.add_side if side_ok else plan.add
+    add_w("nirgan_wgrad_igemm", C.byref(d))
     plan.add("nirgan_wino6_output", C.byref(dgrad))
-    plan.add("nirgan_wino6_wgrad_finish", slabs.data_ptr(), nsplit, cout, cin, grad.data_ptr(), 1 if accumulate else 0)
+    add_w("nirgan_wino6_wgrad_finish", slabs.data_ptr(), nsplit, cout, cin, grad.data_ptr(), 1 if accumulate else 0)
     return d
 
 
