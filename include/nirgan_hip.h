@@ -189,7 +189,8 @@ typedef struct {
     int act; float slope;
     const float* y; const float* mean; const float* rstd; int norm;
     int B, H, W, C;
-    float* dy; int d_hp, d_wp, d_pad;
+    float* dy; int d_hp, d_wp, d_pad;     /* dy = NULL (with norm): the two reductions only, their means stay in ws for a consumer that
+                                             evaluates dy on the fly (nirgan_wino6_input_dy_norm) */
     float* gsum_out;
     float* dbias;
     float* ws; int64_t ws_elems;
@@ -483,6 +484,11 @@ int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream);
 /* nirgan_wino6_input(c) and nirgan_wino6_dy(y) of the SAME output-gradient buffer (c->x == y->dy, zero halo 2) in one pass: the 4x4
  * block of tile (ty, tx) is the lower-right corner of data-gradient patch (ty, tx) */
 int nirgan_wino6_input_dy(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, void* stream);
+/* the same pass with dY NOT read from memory but evaluated on the fly as the instance-norm backward's result: n describes the block
+ * (g / g2 / gsum_out, y, mean, rstd, act, ws as given to nirgan_instnorm_bwd with dy = NULL, which leaves the two reduction passes'
+ * means in ws); every patch element is rstd * (g_z - mean(g_z) - z * mean(g_z * z)), bitwise what the second pass would have stored
+ * into c->x -- that buffer is neither written nor read (c->x / y->dy only describe its geometry: zero halo 2) */
+int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, const nirgan_in_bwd_desc* n, void* stream);
 int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -3,41 +3,9 @@
 // pixel chunks spread over the grid, per-(b,c) sums combined through a small partial buffer
 // in a fixed order (deterministic).  Sums are taken about a per-channel shift (the value at
 // pixel 0) so that E[x^2]-E[x]^2 does not cancel.
-#include "common.h"
+#include "instnorm_dev.h"
 
 namespace {
-
-__host__ __device__ inline int in_nrg(int C) {
-    const int q4 = C / 4;
-    return q4 >= 256 ? 1 : 256 / q4;
-}
-
-inline int in_nchunk(int B, int HW, int C) {
-    const int nrg = in_nrg(C);
-    int want = 1024 / B;
-    if (want < 1) want = 1;
-    int cap = HW / (nrg * 8);
-    if (cap < 1) cap = 1;
-    return want < cap ? want : cap;
-}
-
-// padded-buffer coordinates that hold a copy of interior coordinate h under a reflect halo
-// of width P (P < H): the interior itself plus its mirror images.  Returns the count (<= 3).
-__device__ __forceinline__ int halo_images(int h, int H, int P, int* out) {
-    int n = 0;
-    out[n++] = h + P;
-    if (h >= 1 && h <= P) out[n++] = P - h;
-    if (h >= H - 1 - P && h <= H - 2) out[n++] = P + 2 * (H - 1) - h;
-    return n;
-}
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-typedef __bf16 in_bf16x4 __attribute__((ext_vector_type(4)));
-// the bf16 twin of a buffer: same element offset, value rounded to nearest even
-__device__ __forceinline__ void st4_twin(unsigned short* twin, size_t off, f32x4 v) {
-    if (twin) *reinterpret_cast<in_bf16x4*>(twin + off) = __builtin_convertvector(v, in_bf16x4);
-}
 
 // block-level sum over the row groups of two float4 accumulators; result valid for tid < q4
 __device__ __forceinline__ void rg_reduce2(f32x4& s1, f32x4& s2, f32x4* lds, int tid, int q4, int nrg) {
@@ -182,37 +150,6 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
     }
 }
 
-struct InBwd {
-    const float* g; int g_row, g_img, g_pad, g_fold;
-    const float* g2;
-    const float* a; int a_row, a_img, a_org;
-    int act; float slope;
-    const float* y; const float* mean; const float* rstd; int norm;
-    int HW, W, H, C;
-    float* dy; int d_row, d_img, d_org;
-    float* gsum_out;
-    float* dbias;
-    float* ws; int nchunk, ppc;
-    unsigned short* dy16;
-};
-
-// gradient wrt the block output at pixel (h, w) = pix of sample b: the (reflect-folded) halo'd gradient plus the dense skip gradient
-__device__ __forceinline__ f32x4 in_bwd_gsum(const InBwd& p, const float* gb, const float* g2b, int h, int w, int pix, int q) {
-    f32x4 ga = {0, 0, 0, 0};
-    if (gb) {
-        if (p.g_fold) {
-            int hs[3], wsx[3];
-            const int nh = halo_images(h, p.H, p.g_pad, hs), nw = halo_images(w, p.W, p.g_pad, wsx);
-            for (int i = 0; i < nh; ++i)
-                for (int j = 0; j < nw; ++j) ga += ld4(gb + size_t(hs[i]) * p.g_row + size_t(wsx[j]) * p.C + q * 4);
-        } else {
-            ga = ld4(gb + size_t(h + p.g_pad) * p.g_row + size_t(w + p.g_pad) * p.C + q * 4);
-        }
-    }
-    if (g2b) ga += ld4(g2b + size_t(pix) * p.C + q * 4);
-    return ga;
-}
-
 // with norm: the sums of g_z and g_z * z only (pass 2 rebuilds g_z from the same inputs instead of reading it back: one tensor write
 // less); without norm: dy = g_z, written here
 __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
@@ -298,8 +235,6 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     const float* gsb = p.gsum_out ? p.gsum_out + size_t(b) * p.HW * p.C : nullptr;
     const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
     const float* g2b = p.g2 ? p.g2 + size_t(b) * p.HW * p.C : nullptr;
-    const bool masked = p.act == NIRGAN_ACT_RELU || p.act == NIRGAN_ACT_LRELU;
-    const float neg = p.act == NIRGAN_ACT_RELU ? 0.f : p.slope;
     float* db = p.dy + size_t(b) * p.d_img + p.d_org;
     const int start = chunk * p.ppc;
     int end = start + p.ppc;
@@ -307,13 +242,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     for (int pix = start + rg; pix < end; pix += nrg) {
         const int h = pix / p.W, w = pix - h * p.W;
         const size_t off = size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
-        f32x4 gz = gsb ? ld4(gsb + size_t(pix) * p.C + q * 4) : in_bwd_gsum(p, gb, g2b, h, w, pix, q);
-        const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
-        if (masked) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gz[i] = z[i] > 0.f ? gz[i] : gz[i] * neg;
-        }
-        const f32x4 r = rstd * (gz - m1 - z * m2);
+        const f32x4 r = in_bwd_dy(p, gb, g2b, gsb, yb, mean, rstd, m1, m2, h, w, q);
         st4(db + off, r);
         st4_twin(p.dy16 ? p.dy16 + size_t(b) * p.d_img + p.d_org : nullptr, off, r);
     }
@@ -353,32 +282,23 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
 }
 
 extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
-    NG_REQUIRE(d && d->dy && (d->g || d->g2), "instnorm_bwd: null pointer");
+    NG_REQUIRE(d && (d->dy || d->norm) && (d->g || d->g2), "instnorm_bwd: null pointer");
+    const bool sums_only = d->dy == nullptr;          // with norm: the two reductions only; the consumer evaluates dy on the fly (nirgan_wino6_input_dy_norm)
     NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C >= 4 && d->C % 4 == 0 && d->C <= 1024, "instnorm_bwd: bad shape");
     NG_REQUIRE(!d->g || (d->g_hp == d->H + 2 * d->g_pad && d->g_wp == d->W + 2 * d->g_pad), "instnorm_bwd: g geometry mismatch");
     NG_REQUIRE(!d->g_fold || (d->g_pad < d->H && d->g_pad < d->W), "instnorm_bwd: fold halo wider than the image");
-    NG_REQUIRE(d->d_hp == d->H + 2 * d->d_pad && d->d_wp == d->W + 2 * d->d_pad, "instnorm_bwd: dy geometry mismatch");
+    NG_REQUIRE(sums_only || (d->d_hp == d->H + 2 * d->d_pad && d->d_wp == d->W + 2 * d->d_pad), "instnorm_bwd: dy geometry mismatch");
     const bool masked = d->act == NIRGAN_ACT_RELU || d->act == NIRGAN_ACT_LRELU;
     NG_REQUIRE(!(masked || d->norm) || d->y, "instnorm_bwd: y (pre-activation input of the block) required for the mask / statistics");
     NG_REQUIRE(!d->norm || (d->mean && d->rstd && d->ws), "instnorm_bwd: mean/rstd/ws required when norm");
-    InBwd p;
-    p.g = d->g; p.g_row = d->g_wp * d->C; p.g_img = d->g_hp * p.g_row; p.g_pad = d->g_pad; p.g_fold = d->g_fold;
-    p.g2 = d->g2;
-    p.a = d->a; p.a_row = d->a_wp * d->C; p.a_img = d->a_hp * p.a_row; p.a_org = d->a_pad * p.a_row + d->a_pad * d->C;
-    p.act = d->act; p.slope = d->slope;
-    p.y = d->y; p.mean = d->mean; p.rstd = d->rstd; p.norm = d->norm;
-    p.H = d->H; p.W = d->W; p.HW = d->H * d->W; p.C = d->C;
-    p.dy = d->dy; p.d_row = d->d_wp * d->C; p.d_img = d->d_hp * p.d_row; p.d_org = d->d_pad * p.d_row + d->d_pad * d->C;
-    p.gsum_out = d->gsum_out; p.dbias = d->dbias;
-    p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C); p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
-    p.dy16 = static_cast<unsigned short*>(d->dy_bf16);
+    InBwd p = in_bwd_params(d);
     NG_REQUIRE(!d->dy_bf16 || (d->C % 8 == 0 && (reinterpret_cast<uintptr_t>(d->dy_bf16) & 15) == 0), "instnorm_bwd: bf16 twin needs C %% 8 == 0 and 16-byte alignment");
     NG_REQUIRE(!d->norm || d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C + int64_t(d->B) * 2 * d->C, "instnorm_bwd: ws too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     if (d->norm) {
         hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(d->B), dim3(256), 0, st, p, d->B);
-        hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p, d->B);
+        if (!sums_only) hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p, d->B);
     }
     return nirgan_check_launch("instnorm_bwd");
 }

@@ -20,6 +20,7 @@
 //   G   = [[1/2,0,0],[1/6,1/6,1/6],[1/6,-1/6,1/6],[1/30,1/15,2/15],[16/15,-8/15,4/15],[0,0,1/2]]
 //   A^T = [[1,1,1,1,1,0],[0,1,-1,2,-1/2,0],[0,1,1,4,1/4,0],[0,1,-1,8,-1/8,1]]
 #include "igemm_tiles.h"
+#include "instnorm_dev.h"
 #include <stdlib.h>
 
 namespace {
@@ -109,10 +110,15 @@ struct W6In {
                                                  // is output-gradient tile (ty, tx): Yt = A dY A^T is emitted from the same read of dY
     // normalising variant: x = act((y - mean) * rstd) of a dense [B][H][W][C] tensor under a REFLECT halo of 1, evaluated on the fly
     const float* y; const float* mean; const float* rstd; int H, W, act; float slope;
+    // dY variant that evaluates the instance-norm backward's second pass on the fly (MODE 2): x is NOT read; dY(h, w) =
+    // rstd * (g_z - mean(g_z) - z * mean(g_z z)) from the pass-1 sums (in_bwd_dy: bitwise what in_bwd_pass2_kernel would have stored)
+    InBwd nb; int nbB;
 };
 
-template <bool NORM>
+// MODE 0: x from the halo'd buffer; 1: forward input normalised on the fly; 2: output gradient from the instance-norm backward on the fly
+template <int MODE>
 __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
+    constexpr bool NORM = MODE == 1;
     const int q4 = p.C / 4;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= p.T * q4) return;
@@ -124,7 +130,20 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 mean = z4, rstd = z4;
     const float* base;
-    if constexpr (NORM) {
+    f32x4 m1 = z4, m2 = z4;
+    const float* gb = nullptr; const float* g2b = nullptr; const float* gsb = nullptr; const float* yb = nullptr;
+    if constexpr (MODE == 2) {
+        const InBwd& n = p.nb;
+        const float* mm = n.ws + size_t(p.nbB) * n.nchunk * 2 * n.C + size_t(b) * 2 * n.C;
+        m1 = ld4(mm + q * 4); m2 = ld4(mm + n.C + q * 4);
+        mean = ld4(n.mean + size_t(b) * n.C + q * 4);
+        rstd = ld4(n.rstd + size_t(b) * n.C + q * 4);
+        yb = n.y + size_t(b) * n.HW * n.C;
+        gsb = n.gsum_out ? n.gsum_out + size_t(b) * n.HW * n.C : nullptr;
+        gb = n.g ? n.g + size_t(b) * n.g_img : nullptr;
+        g2b = n.g2 ? n.g2 + size_t(b) * n.HW * n.C : nullptr;
+        base = nullptr;
+    } else if constexpr (NORM) {
         mean = *reinterpret_cast<const f32x4*>(p.mean + size_t(b) * p.C + q * 4);
         rstd = *reinterpret_cast<const f32x4*>(p.rstd + size_t(b) * p.C + q * 4);
         base = p.y + size_t(b) * p.H * p.W * p.C + q * 4;
@@ -136,7 +155,11 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     auto ld = [&](int a, int c) -> f32x4 {
         const int rb = 4 * ty + a, cb = 4 * tx + c;
         if (rb >= p.x_hp || cb >= p.x_wp) return z4;
-        if constexpr (NORM) {
+        if constexpr (MODE == 2) {
+            const int h = rb - 2, w = cb - 2;              // the dY buffer has a zero halo of 2
+            if (h < 0 || w < 0 || h >= p.nb.H || w >= p.nb.W) return z4;
+            return in_bwd_dy(p.nb, gb, g2b, gsb, yb, mean, rstd, m1, m2, h, w, q);
+        } else if constexpr (NORM) {
             const int yr = ng_reflect(rb - 1, p.H), yc = ng_reflect(cb - 1, p.W);
             f32x4 v = (*reinterpret_cast<const f32x4*>(base + (size_t(yr) * p.W + yc) * p.C) - mean) * rstd;     // in_apply_kernel's arithmetic
             if (p.act == NIRGAN_ACT_RELU) {
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(V + (a * 6 + c) * plane) = o[c];
     }
-    if constexpr (!NORM) {
+    if constexpr (MODE != 1) {
         if (p.Yt != nullptr && ty < p.yTH && tx < p.yTW) {
             // output-gradient tile (ty, tx) = patch rows / columns 2 .. 5 (just read: L1 / L2 hits); rows past the extent read the zero halo
             f32x4 u[6][4];
@@ -488,8 +511,8 @@ extern "C" int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs,
 }
 
 static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const float* ny, const float* mean, const float* rstd,
-                         int act, float slope, void* stream) {
-    NG_REQUIRE(d && d->V && (d->x || ny), "wino6_input: null pointer");
+                         int act, float slope, void* stream, const nirgan_in_bwd_desc* nb = nullptr) {
+    NG_REQUIRE(d && d->V && (d->x || ny || nb), "wino6_input: null pointer");
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino6_input: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
     NG_REQUIRE(ny || (d->x_hp == d->H + 2 && d->x_wp == d->W + 2), "wino6_input: the input must be (H+2) x (W+2) (%dx%d for %dx%d)", d->x_hp, d->x_wp, d->H, d->W);
     NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->V) && ng_aligned16(ny) && ng_aligned16(mean) && ng_aligned16(rstd), "wino6_input: pointers must be 16-byte aligned");
@@ -504,7 +527,7 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
     in.y = ny; in.mean = mean; in.rstd = rstd; in.H = d->H; in.W = d->W; in.act = act; in.slope = slope;
     if (y != nullptr) {
         // the same dY buffer seen twice: zero halo 2, the data gradient covers (H_dy + 2) x (W_dy + 2) outputs
-        NG_REQUIRE(!ny && y->dy == d->x && y->Yt && y->dy_pad == 2 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp && y->dy_wp == d->x_wp
+        NG_REQUIRE(!ny && (nb || y->dy == d->x) && y->Yt && y->dy_pad == 2 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp && y->dy_wp == d->x_wp
                    && d->H == y->H + 2 && d->W == y->W + 2, "wino6_input_dy: the two descriptors do not describe the same output-gradient buffer");
         NG_REQUIRE(ng_aligned16(y->Yt), "wino6_input_dy: pointers must be 16-byte aligned");
         in.yTH = (y->H + 3) / 4; in.yTW = (y->W + 3) / 4; in.yT = (long long)y->B * in.yTH * in.yTW;
@@ -513,8 +536,17 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
     }
     const long long nthreads = T * (d->C / 4);
     const dim3 grid(unsigned((nthreads + 255) / 256));
-    if (ny) hipLaunchKernelGGL(wino6_input_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
-    else hipLaunchKernelGGL(wino6_input_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
+    in.nbB = 0;
+    if (nb != nullptr) {
+        NG_REQUIRE(y != nullptr && nb->norm && nb->y && nb->mean && nb->rstd && nb->ws && (nb->g || nb->g2), "wino6_input_dy_norm: the instance-norm descriptor needs y, mean, rstd, ws and a gradient");
+        NG_REQUIRE(nb->B == d->B && nb->C == d->C && nb->H == y->H && nb->W == y->W, "wino6_input_dy_norm: the instance-norm descriptor describes another tensor");
+        NG_REQUIRE(!nb->g || (nb->g_hp == nb->H + 2 * nb->g_pad && nb->g_wp == nb->W + 2 * nb->g_pad), "wino6_input_dy_norm: g geometry mismatch");
+        in.nb = in_bwd_params(nb);
+        in.nbB = nb->B;
+        NG_REQUIRE(nb->ws_elems >= int64_t(nb->B) * in.nb.nchunk * 2 * nb->C + int64_t(nb->B) * 2 * nb->C, "wino6_input_dy_norm: ws too small");
+        hipLaunchKernelGGL(wino6_input_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
+    } else if (ny) hipLaunchKernelGGL(wino6_input_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
+    else hipLaunchKernelGGL(wino6_input_kernel<0>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
     return nirgan_check_launch("wino6_input");
 }
 
@@ -529,6 +561,11 @@ extern "C" int nirgan_wino6_input_norm(const nirgan_wino6_desc* d, const float* 
     NG_REQUIRE(y && mean && rstd, "wino6_input_norm: null pointer");
     NG_REQUIRE(act == NIRGAN_ACT_NONE || act == NIRGAN_ACT_RELU || act == NIRGAN_ACT_LRELU, "wino6_input_norm: activation %d", act);
     return w6_input_impl(d, nullptr, y, mean, rstd, act, slope, stream);
+}
+
+extern "C" int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const nirgan_in_bwd_desc* n, void* stream) {
+    NG_REQUIRE(y != nullptr && n != nullptr, "wino6_input_dy_norm: null pointer");
+    return w6_input_impl(d, y, nullptr, nullptr, nullptr, 0, 0.f, stream, n);
 }
 
 extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {

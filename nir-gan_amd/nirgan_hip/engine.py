@@ -589,7 +589,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
 
 
 def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, OH, OW, cin, cout, slabs_pool,
-                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False):
+                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False, norm_desc=None):
     """Backward of an F(4x4,3x3) layer: dY -> (V of dY for the data gradient, Yt = A dY A^T for the weight gradient) in one pass, the
     data gradient's 36 plane GEMMs + output transform, the 36 transform-domain weight-gradient problems dU[f] = Yt[f]^T V[f] (V of the
     forward input, kept by the forward) as one weight-gradient launch, dW = G^T dU G."""
@@ -638,7 +638,10 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     d.precision = 0
     d.nplanes, d.p_plane, d.q_plane = 36, T * cout, T * cin
     ctx.keep.extend([vin, ydesc, d, slabs])
-    plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
+    if norm_desc is not None:       # dY is not in memory: the instance-norm backward's second pass runs inside the transform
+        plan.add("nirgan_wino6_input_dy_norm", C.byref(dgrad), C.byref(ydesc), C.byref(norm_desc))
+    else:
+        plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
     if vin is not None:
         plan.add("nirgan_wino6_input", C.byref(vin))
     plan.add_join()                          # the previous layer's weight gradient is done before this layer's GEMM takes the matrix pipe
@@ -700,7 +703,9 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
 
 def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Optional[Halo] = None, a: Optional[Halo] = None,
                 act=L.ACT_NONE, slope=0.2, y: Optional[Halo] = None, stats=None, norm=True, dy: Halo, gsum: Optional[Halo] = None,
-                dbias: Optional[torch.Tensor] = None, ws=None, shape=None):
+                dbias: Optional[torch.Tensor] = None, ws=None, shape=None, sums_only: bool = False):
+    """sums_only (with norm): the two reduction passes only; dy is then evaluated on the fly by the consumer (nirgan_wino6_input_dy_norm)
+    and its buffer is neither written nor read."""
     B, H, W, Cc = shape
     d = L.InBwdDesc()
     if g is not None:
@@ -719,8 +724,9 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
         d.mean, d.rstd = stats[0].data_ptr(), stats[1].data_ptr()
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     d.B, d.H, d.W, d.C = B, H, W, Cc
-    d.dy, d.d_hp, d.d_wp, d.d_pad = dy.ptr, dy.hp, dy.wp, dy.pad
-    if dy.t16 is not None:
+    assert not sums_only or norm
+    d.dy, d.d_hp, d.d_wp, d.d_pad = (None if sums_only else dy.ptr), dy.hp, dy.wp, dy.pad
+    if dy.t16 is not None and not sums_only:
         d.dy_bf16 = dy.t16.data_ptr()
     if gsum is not None:
         d.gsum_out = gsum.ptr
@@ -835,23 +841,29 @@ class ConvIN:
         eng, ctx, inp = self.eng, self.eng.ctx, self.inp
         k, s, p = self.k, self.s, self.p
         act = self.act if act is None else act
-        emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, a=(mask if mask is not None else self.out), act=act,
-                    y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
-                    dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
-                    ws=eng.scratch.get(),
-                    shape=(inp.B, self.OH, self.OW, self.cout))
         dy = self.dy
+        # F(4x4,3x3) backward (below).  OPT-IN (NIRGAN_WINO6_DYNORM=1): the second pass of the instance-norm backward evaluated inside the
+        # dY transform (dY never stored).  Bitwise the same V / Yt, but measured SLOWER: 161 us against 84 (transform) + 31 (second pass)
+        # per layer -- every dY element is re-derived by the 2.25 patches that contain it, from two loads instead of one, at 240 VGPRs
+        w6_bwd = (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
+                  and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C) and wino6_applicable(ctx, k, inp.C)
+                  and inp.pad == 1 and p == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1")
+        fuse_dy = w6_bwd and self.norm and dy.t16 is None and os.environ.get("NIRGAN_WINO6_DYNORM") == "1"
+        nd = emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, a=(mask if mask is not None else self.out), act=act,
+                         y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
+                         dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
+                         ws=eng.scratch.get(),
+                         shape=(inp.B, self.OH, self.OW, self.cout), sums_only=fuse_dy)
         # stride-1 convolutions that need both gradients: one fused launch (data-gradient tiles + weight-gradient tiles)
         if (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
                 and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C)):
-            if (wino6_applicable(ctx, k, inp.C) and inp.pad == 1 and p == 1 and self.cout % 128 == 0
-                    and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"):
+            if w6_bwd:
                 # F(4x4,3x3): data gradient and transform-domain weight gradient, dY read once for both of its transforms
                 wd6 = emit_wino6(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
                                  cin=self.cout, cout=inp.C, flip=True)
                 keepV = getattr(self, "wino_fwd_keeps_V", False) and getattr(self, "wino6", False)
                 emit_wino6_backward(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
-                                    dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None))
+                                    dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None), norm_desc=(nd if fuse_dy else None))
                 return
             # exact-fp32 mode, 3x3: the data gradient is a Winograd convolution of dY (zero halo 2) with the flipped filter over the
             # padded input extent; the weight gradient keeps the direct tile (stand-alone launch)

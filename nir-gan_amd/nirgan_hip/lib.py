@@ -180,6 +180,7 @@ PROTOTYPES = {
     "nirgan_wino6_conv3x3": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_dy": (i32, [C.POINTER(WinoDyDesc), fp]),
     "nirgan_wino6_input_dy": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), fp]),
+    "nirgan_wino6_input_dy_norm": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), C.POINTER(InBwdDesc), fp]),
     "nirgan_wino6_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),
     "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),

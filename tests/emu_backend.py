@@ -581,6 +581,19 @@ class EmuBackend:
         rc = self.nirgan_wino6_input(cref)
         return rc if rc else self.nirgan_wino6_dy(yref)
 
+    def nirgan_wino6_input_dy_norm(self, cref, yref, nref, stream=None):
+        """dY evaluated from the instance-norm backward descriptor (whose own call ran with dy = NULL: reductions only), then the two
+        transforms.  The emulator materialises dY in the buffer the descriptors describe (the device never touches it)."""
+        c, y, n = obj(cref), obj(yref), obj(nref)
+        self.calls.append("wino6_dy_norm")
+        if n.dy or not n.norm or n.B != c.B or n.C != c.C or n.H != y.H or n.W != y.W:
+            return self._fail("wino6_input_dy_norm: bad instance-norm descriptor")
+        full = type(n)()
+        C.memmove(C.byref(full), C.byref(n), C.sizeof(n))
+        full.dy, full.d_hp, full.d_wp, full.d_pad = y.dy, y.dy_hp, y.dy_wp, y.dy_pad
+        rc = self.nirgan_instnorm_bwd(full)
+        return rc if rc else self.nirgan_wino6_input_dy(cref, yref)
+
     def nirgan_wino6_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
         self.calls.append("wino6_fin")
         u = arr(slabs, 36 * nsplit * K * Cc).reshape(6, 6, nsplit, K, Cc).astype(np.float64).sum(2)
@@ -802,6 +815,8 @@ class EmuBackend:
             dy = dy.reshape(B, H, W, Cc)
         else:
             dy = gz
+        if not d.dy:                       # reductions only (with norm): a consumer evaluates dy on the fly; gsum_out was written above
+            return 0 if d.norm else self._fail("in_bwd: dy missing")
         o = arr(d.dy, B * d.d_hp * d.d_wp * Cc).reshape(B, d.d_hp, d.d_wp, Cc)
         o[:, d.d_pad:d.d_pad + H, d.d_pad:d.d_pad + W] = dy
         mirror_twin(d.dy_bf16, o)

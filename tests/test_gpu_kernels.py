@@ -992,3 +992,62 @@ def test_wino6_input_transform_with_the_instance_norm_folded_in(hw):
     L.call("nirgan_wino6_input_norm", C.byref(d), yh.ptr, stats[0].data_ptr(), stats[1].data_ptr(), L.ACT_RELU, 0.2, st)
     torch.cuda.synchronize()
     assert torch.equal(V1, V2), f"max diff {(V1 - V2).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("case", [("fold+relu", 12, 16), ("fold+relu", 9, 11), ("skip", 64, 64), ("skip", 10, 7)])
+def test_wino6_dy_transform_with_the_instance_norm_backward_folded_in(case):
+    """nirgan_instnorm_bwd(dy = NULL: the two reductions only) + nirgan_wino6_input_dy_norm = the V / Yt that the full instance-norm
+    backward (which stores dY) followed by nirgan_wino6_input_dy produces -- bitwise: the second pass's arithmetic is evaluated inside
+    the transform and dY never exists in memory.  Both block kinds of the residual chain: first convolution (halo'd gradient folded
+    through the reflect padding, ReLU mask) and second convolution (dense skip-path sum from pass 1, no activation)."""
+    import ctypes as C
+    from nirgan_hip.engine import emit_in_bwd, emit_in_fwd
+    kind, H, W = case
+    B, Cc = 2, 128
+    g = torch.Generator().manual_seed(33)
+    ctx = Ctx(DEV, "fp32")
+    st = torch.cuda.current_stream().cuda_stream
+    yh = Halo(ctx, B, H, W, Cc, 0)
+    yh.t.copy_((torch.randn(B, H, W, Cc, generator=g) * 1.3 + 0.2).to(DEV))
+    out = Halo(ctx, B, H, W, Cc, 1)
+    stats = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
+    ws = ctx.zeros(int(L.backend().nirgan_instnorm_ws_elems(B, H, W, Cc)))
+    f = Plan(ctx)
+    emit_in_fwd(f, ctx, yh, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats, ws=ws)
+    f.run()
+    gh = Halo(ctx, B, H, W, Cc, 1)
+    gh.t.copy_(torch.randn(B, H + 2, W + 2, Cc, generator=g).to(DEV))
+    g2 = Halo(ctx, B, H, W, Cc, 0)
+    g2.t.copy_(torch.randn(B, H, W, Cc, generator=g).to(DEV))
+    gsum = Halo(ctx, B, H, W, Cc, 0)
+    dy = Halo(ctx, B, H, W, Cc, 2)
+    kw = dict(g=gh, g_fold=True, y=yh, stats=stats, norm=True, dy=dy, ws=ws, shape=(B, H, W, Cc))
+    if kind == "skip":
+        kw.update(g2=g2, gsum=gsum, act=L.ACT_NONE)
+    else:
+        kw.update(act=L.ACT_RELU)
+    full, sums = Plan(ctx), Plan(ctx)
+    emit_in_bwd(full, ctx, **kw)
+    nd = emit_in_bwd(sums, ctx, sums_only=True, **kw)
+    Td, Ty = B * ((H + 5) // 4) * ((W + 5) // 4), B * ((H + 3) // 4) * ((W + 3) // 4)
+    res = []
+    for fused in (False, True):
+        V = torch.full((36 * Td * Cc,), float("nan"), device=DEV)
+        Yt = torch.full((36 * Ty * Cc,), float("nan"), device=DEV)
+        d = L.Wino6Desc()
+        d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = dy.ptr, H + 4, W + 4, B, H + 2, W + 2, Cc, 128
+        d.V, d.V_elems = V.data_ptr(), V.numel()
+        yd = L.WinoDyDesc()
+        yd.dy, yd.dy_hp, yd.dy_wp, yd.dy_pad, yd.B, yd.H, yd.W, yd.K = dy.ptr, H + 4, W + 4, 2, B, H, W, Cc
+        yd.Yt, yd.Yt_elems, yd.r = Yt.data_ptr(), Yt.numel(), 3
+        if fused:
+            dy.t.fill_(float("nan"))          # the fused pass must not read the buffer
+            sums.run()
+            L.call("nirgan_wino6_input_dy_norm", C.byref(d), C.byref(yd), C.byref(nd), st)
+        else:
+            full.run()
+            L.call("nirgan_wino6_input_dy", C.byref(d), C.byref(yd), st)
+        torch.cuda.synchronize()
+        res.append((V, Yt))
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0]), "V differs"
+    assert torch.equal(res[0][1], res[1][1]), "Yt differs"
