@@ -16,8 +16,8 @@ children's status); started under torchrun it is one rank.  WORLD_SIZE must equa
 gradients on the concatenated batch.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel by share of step time
-(conv_wgrad_pair_kernel: data-gradient + weight-gradient tiles of one layer in one grid;
-`roofline_other` lists conv_igemm_kernel<128> and conv_group_kernel<128>): algorithmic FLOPs
+(round 2: wino6_gemm16_kernel, the 36 plane GEMMs of the Winograd F(4x4,3x3) residual-block
+layers, 24 launches per step; `roofline_other` lists the other MFMA kernels): EXECUTED FLOPs
 of its launches (2*M*N*K from the descriptors) / their duration, bracketed by HIP events on
 the launch stream inside the timed steps.  `cpu_baseline` times the CPU oracle (a port, on a
 bounded sample) on rank 0 at N = 1.
@@ -61,7 +61,8 @@ def mfma_probes(trainer):
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0],
              "wino_gemm_kernel": [0.0, 0], "wino_wgrad_pair_kernel": [0.0, 0],
-             "wino6_gemm_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0]}
+             "wino6_gemm16_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0]}
+    algo_bytes = {}
     for pl in plans:
         pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}
         for i, (name, args) in enumerate(pl.ops):
@@ -74,9 +75,10 @@ def mfma_probes(trainer):
                     pl.probe_idx[i] = k
             elif name == "nirgan_wino6_gemm":
                 d = args[0]._obj
-                k = "wino6_gemm_kernel"
+                k = "wino6_gemm16_kernel"
                 T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
                 kinds[k][0] += 2.0 * 36 * T * d.C * d.K          # EXECUTED flops: 36 plane GEMMs [T x C] x [C x K] (36/144 of the direct layer's multiplies)
+                algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * 36 * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
             elif name == "nirgan_wgrad_igemm":
@@ -114,6 +116,7 @@ def mfma_probes(trainer):
                     kinds[k][0] += 2.0 * c.B * c.OH * c.OW * c.N * c.ntaps * c.run + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
                     kinds[k][1] += 1
                     pl.probe_idx[i] = k
+    mfma_probes.algo_bytes = algo_bytes
     return kinds, plans
 
 
@@ -433,6 +436,7 @@ def main():
                               "frac": round(ach / PEAKS[a.precision], 4), "traffic": None, "kernel": k,
                               "launches_per_step": nlaunch, "avg_launch_ms": round(avg_ms, 5),
                               "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
+                              "algorithmic_bytes_per_launch": (int(mfma_probes.algo_bytes[k] / nlaunch) if k in getattr(mfma_probes, "algo_bytes", {}) else None),
                               "share_of_step_time": round(avg_ms * nlaunch / ms, 3)})
             # HBM traffic per launch: NOT measured in this run (PMC needs rocprofv3 passes around the process).  It is replayed from
             # the PMC summary recorded under profiles/ by scripts/refresh_profiles.sh over this same command (rocprofv3 --pmc
