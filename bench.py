@@ -61,7 +61,7 @@ def mfma_probes(trainer):
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0],
              "wino_gemm_kernel": [0.0, 0], "wino_wgrad_pair_kernel": [0.0, 0],
-             "wino6_gemm16_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0]}
+             "wino6_gemm16_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0], "wino6_pair_kernel": [0.0, 0]}
     algo_bytes = {}
     for pl in plans:
         pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}
@@ -81,6 +81,15 @@ def mfma_probes(trainer):
                 algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * 36 * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
+            elif name == "nirgan_wino6_gemm_wgrad_pair":
+                d, w = args[0]._obj, args[1]._obj
+                k = "wino6_pair_kernel"
+                T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
+                kinds[k][0] += 2.0 * 36 * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run      # executed: data-gradient plane GEMMs + 36 weight-gradient planes
+                kinds[k][1] += 1
+                pl.probe_idx[i] = k
+                # V of dY read once, U once, M written once; Yt and the forward's V read once, slabs written once
+                algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * 36 * (T * d.C + d.K * d.C + T * d.K) + 4.0 * w.nplanes * (w.OW * (w.N + w.run) + w.nsplit * w.N * w.run)
             elif name == "nirgan_wgrad_igemm":
                 w = args[0]._obj
                 if w.N > 64 and w.precision == 0 and not w.pq_bf16:
@@ -471,7 +480,8 @@ def main():
                                            "stale, not reported (rerun scripts/refresh_profiles.sh)")
             for r in roofs:
                 if r["kernel"].startswith("wino6"):
-                    r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(4x4,3x3) plane GEMMs perform 36/144 of the direct layer's multiplies")
+                    r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(4x4,3x3) plane GEMMs (and, in the pair launch, the 36 transform-domain "
+                                          "weight-gradient planes) perform 36/144 of the direct layer's multiplies")
                 elif r["kernel"].startswith("wino"):
                     r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(2x2,3x3) part performs 16/36 of the direct layer's "
                                           "multiplies")

@@ -477,6 +477,10 @@ int nirgan_wino6_input(const nirgan_wino6_desc* d, void* stream);
  * evaluated on the fly (as nirgan_wino_input_norm) */
 int nirgan_wino6_input_norm(const nirgan_wino6_desc* d, const float* y, const float* mean, const float* rstd, int act, float slope, void* stream);
 int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream);
+/* the data gradient's plane GEMMs (c: x = dY, transpose_flip weights; its V written by nirgan_wino6_input_dy) and the layer's 36
+ * transform-domain weight-gradient problems (w: nplanes = 36) in ONE grid, like nirgan_wino_wgrad_pair: the long weight-gradient
+ * blocks first, the GEMM blocks pack behind them.  Semantics = nirgan_wino6_gemm(c) followed by nirgan_wgrad_igemm(w). */
+int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* c, const nirgan_wgrad_desc* w, void* stream);
 int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream);
 int nirgan_wino6_conv3x3(const nirgan_wino6_desc* d, void* stream);   /* input + gemm + output */
 /* Yt [36][B*ceil(H/4)*ceil(W/4)][K]; the descriptor's r field is ignored */

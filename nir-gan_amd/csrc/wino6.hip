@@ -271,6 +271,24 @@ __global__ __launch_bounds__(256, 2) void wino6_gemm_kernel(const W6Gemm g) {
                           g.p.out + size_t(plane) * g.out_plane);
 }
 
+// The data gradient's plane GEMMs and the 36 weight-gradient problems of the same layer in ONE grid (both read what the dY pass just
+// wrote): the long weight-gradient blocks (18 K-steps) are dispatched first, the GEMM blocks (8 K-steps) pack behind them, so neither
+// launch pays its own partly filled last round.  32-k stages for both halves (the direct tile and the weight-gradient tile share 64 KB).
+__global__ __launch_bounds__(256, 2) void wino6_pair_kernel(const W6Gemm g, const ng::WgradParams wp, const int wgrad_blocks, const int wgrad_first) {
+    __shared__ __attribute__((aligned(16))) char lds[65536];
+    const int bid = blockIdx.x;
+    const int gemm_first_id = wgrad_first ? wgrad_blocks : 0;
+    const bool is_wgrad = wgrad_first ? bid < wgrad_blocks : bid >= g.total;
+    if (is_wgrad) {
+        ng::wgrad_tile<128, 0>(wp, wgrad_first ? bid : bid - g.total, lds, lds + 32768);
+    } else {
+        const int rid = ng_xcd_remap(bid - gemm_first_id, g.total);
+        const int plane = rid / g.per_plane, local = rid - plane * g.per_plane;
+        ng::conv_tile<128, 0>(g.p, local, lds, lds + 32768, g.p.in + size_t(plane) * g.in_plane, g.p.w + size_t(plane) * g.w_plane,
+                              g.p.out + size_t(plane) * g.out_plane);
+    }
+}
+
 // The plane GEMMs contract over C = 256 only: 8 K-steps of the tile above against a prologue + epilogue of ~20 k cycles per tile,
 // (measured 103-110 TFLOP/s at C = 256 against 126 at C = 1024, scripts/bench_wino6_gemm.py).  This variant stages 16 k per step:
 // 64-byte rows, 2 x 16 KB of LDS and 112 VGPRs, so up to FOUR workgroups are resident per CU.  Measured: within 2 % of the 32-k tile
@@ -583,19 +601,49 @@ extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {
     return nirgan_check_launch("wino6_dy");
 }
 
-extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
+// validation + the 32-k form's parameters (one plane as a 1x1 'convolution' over a [1][T] image of C-channel pixels: the direct tile's descriptor)
+static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
     NG_REQUIRE(d && d->U && d->V && d->M && d->zero_page, "wino6_gemm: null pointer");
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0 && d->K > 64 && d->K % 4 == 0, "wino6_gemm: C %% 4 == 0, K > 64, K %% 4 == 0 (C=%d K=%d)", d->C, d->K);
-    const long long T = w6_tiles(d->B, d->H, d->W);
+    T = w6_tiles(d->B, d->H, d->W);
     NG_REQUIRE(T * d->C < (1ll << 31) && T * d->K < (1ll << 31), "wino6_gemm: problem too large for 32-bit offsets");
     NG_REQUIRE(d->V_elems >= 36 * T * d->C && d->M_elems >= 36 * T * d->K, "wino6_gemm: V / M workspace too small");
-    // one plane as a 1x1 'convolution' over a [1][T] image of C-channel pixels: the direct tile's descriptor
     nirgan_conv_desc c = {};
     c.in = d->V; c.in_elems = T * d->C; c.in_hp = 1; c.in_wp = int(T); c.in_cs = d->C; c.run = d->C; c.in_stride = 1;
     c.ntaps = 1;
     c.w = d->U; c.w_elems = (long long)d->K * d->C; c.bias = nullptr;
     c.out = d->M; c.out_elems = T * d->K; c.out_hp = 1; c.out_wp = int(T); c.out_cs = d->K; c.out_stride = 1;
     c.B = 1; c.OH = 1; c.OW = int(T); c.N = d->K; c.zero_page = d->zero_page;
+    const int rc = ng::build_conv_params(&c, g.p);
+    if (rc != NIRGAN_OK) return rc;
+    g.in_plane = T * d->C; g.w_plane = (long long)d->K * d->C; g.out_plane = T * d->K;
+    g.per_plane = g.p.mtiles * g.p.ntiles; g.total = 36 * g.per_plane;
+    return NIRGAN_OK;
+}
+
+extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const nirgan_wgrad_desc* w, void* stream) {
+    W6Gemm g;
+    long long T;
+    int rc = w6_gemm_params(d, g, T);
+    if (rc != NIRGAN_OK) return rc;
+    ng::WgradParams wp;
+    rc = ng::build_wgrad_params(w, wp);
+    if (rc != NIRGAN_OK) return rc;
+    if (w->N <= 64 || wp.prec != 0 || wp.pq_bf16) {           // not the wide fp32 tile: two ordinary launches
+        rc = nirgan_wino6_gemm(d, stream);
+        return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
+    }
+    const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit * wp.nplanes;
+    const int wgrad_first = getenv("NIRGAN_WINO6_PAIR_GEMM_FIRST") == nullptr ? 1 : 0;
+    hipLaunchKernelGGL(wino6_pair_kernel, dim3(g.total + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, wp, wgrad_blocks, wgrad_first);
+    return nirgan_check_launch("wino6_gemm_wgrad_pair");
+}
+
+extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
+    W6Gemm g;
+    long long T;
+    const int rc0 = w6_gemm_params(d, g, T);
+    if (rc0 != NIRGAN_OK) return rc0;
     if (d->C % 16 == 0 && getenv("NIRGAN_WINO6_GEMM32") == nullptr) {
         // 16-k stages, three resident workgroups per CU (see wino6_gemm16_kernel)
         NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm: pointers must be 16-byte aligned");
@@ -606,11 +654,6 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
         hipLaunchKernelGGL(wino6_gemm16_kernel, dim3(q.total), dim3(256), 0, static_cast<hipStream_t>(stream), q);
         return nirgan_check_launch("wino6_gemm");
     }
-    W6Gemm g;
-    const int rc = ng::build_conv_params(&c, g.p);
-    if (rc != NIRGAN_OK) return rc;
-    g.in_plane = T * d->C; g.w_plane = (long long)d->K * d->C; g.out_plane = T * d->K;
-    g.per_plane = g.p.mtiles * g.p.ntiles; g.total = 36 * g.per_plane;
     hipLaunchKernelGGL(wino6_gemm_kernel, dim3(g.total), dim3(256), 0, static_cast<hipStream_t>(stream), g);
     return nirgan_check_launch("wino6_gemm");
 }

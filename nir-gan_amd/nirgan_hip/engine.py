@@ -645,9 +645,12 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     if vin is not None:
         plan.add("nirgan_wino6_input", C.byref(vin))
     plan.add_join()                          # the previous layer's weight gradient is done before this layer's GEMM takes the matrix pipe
-    plan.add("nirgan_wino6_gemm", C.byref(dgrad))
     add_w = plan.add_side if side_ok else plan.add
-    add_w("nirgan_wgrad_igemm", C.byref(d))
+    if os.environ.get("NIRGAN_NO_WINO6_PAIR") != "1" and os.environ.get("NIRGAN_SIDE_STREAM") != "1":      # 24.87 -> 24.64 ms per step
+        plan.add("nirgan_wino6_gemm_wgrad_pair", C.byref(dgrad), C.byref(d))      # one grid: weight-gradient blocks first, GEMM blocks behind
+    else:
+        plan.add("nirgan_wino6_gemm", C.byref(dgrad))
+        add_w("nirgan_wgrad_igemm", C.byref(d))
     plan.add("nirgan_wino6_output", C.byref(dgrad))
     add_w("nirgan_wino6_wgrad_finish", slabs.data_ptr(), nsplit, cout, cin, grad.data_ptr(), 1 if accumulate else 0)
     return d

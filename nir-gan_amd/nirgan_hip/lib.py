@@ -176,6 +176,7 @@ PROTOTYPES = {
     "nirgan_wino6_input": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_input_norm": (i32, [C.POINTER(Wino6Desc), fp, fp, fp, i32, f32, fp]),
     "nirgan_wino6_gemm": (i32, [C.POINTER(Wino6Desc), fp]),
+    "nirgan_wino6_gemm_wgrad_pair": (i32, [C.POINTER(Wino6Desc), C.POINTER(WgradDesc), fp]),
     "nirgan_wino6_output": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_conv3x3": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_dy": (i32, [C.POINTER(WinoDyDesc), fp]),

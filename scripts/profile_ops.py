@@ -54,6 +54,11 @@ def describe(name, args):
         npl = max(w.nplanes, 1)
         blocks = (-(-w.N // 128) if w.N > 64 else 1) * (-(-K // 128)) * w.nsplit * npl
         return f"wgrad M={M} N={w.N} K={K} split={w.nsplit} planes={npl} blk={blocks}", 2.0 * npl * M * w.N * K
+    if name == "nirgan_wino6_gemm_wgrad_pair":
+        d, w = args[0]._obj, args[1]._obj
+        T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
+        fl = 2.0 * 36 * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
+        return f"wino6 pair: dgrad gemm 36 x [T={T} x {d.C}] x [{d.K}] + wgrad 36 planes M={w.OW} split={w.nsplit} (executed flops)", fl
     if name == "nirgan_wino6_gemm":
         d = args[0]._obj
         T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)

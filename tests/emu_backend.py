@@ -538,6 +538,10 @@ class EmuBackend:
         arr(d.M, 36 * T * d.K)[:] = np.einsum("ftc,fkc->ftk", V, U).reshape(-1).astype(np.float32)
         return 0
 
+    def nirgan_wino6_gemm_wgrad_pair(self, cref, wref, stream=None):
+        rc = self.nirgan_wino6_gemm(cref)
+        return rc if rc else self.nirgan_wgrad_igemm(wref)
+
     def nirgan_wino6_output(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("wino6_out")
