@@ -465,11 +465,15 @@ typedef struct {
     float* M; int64_t M_elems;            /* [36][T][K] */
     float* y;                             /* dense [B][H][W][K] */
     const float* zero_page;
+    int r;                                /* filter size: 0 or 3 = F(4x4,3x3) above; 4 = F(4x4,4x4): nn.Conv2d(C, K, 4, stride 1) of the PatchGAN
+                                             (model/networks.py:573-579): x is [B][H+3][W+3][C] for H x W outputs, 7x7 patches, 49 planes in
+                                             U / V / M / Yt; Cook-Toom over 0, 1, -1, 2, -2, 1/2, inf; fp32 error 1e-5 of the output's maximum */
 } nirgan_wino6_desc;
 
 int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T */
 int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);   /* as nirgan_wino_weights */
-/* all weight transforms of a step in one launch: njobs x 8 int64 {w, U, K, C, transpose_flip, first_block, 0, 0} in device memory,
+int nirgan_wino6_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream);   /* w = [K][C][r][r], U = [(r+3)^2][K][C] */
+/* all weight transforms of a step in one launch: njobs x 8 int64 {w, U, K, C, transpose_flip, first_block, r, 0} in device memory,
  * first_block = running sum of ceil(K*C/256) */
 int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
 int nirgan_wino6_input(const nirgan_wino6_desc* d, void* stream);
@@ -483,7 +487,7 @@ int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream);
 int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* c, const nirgan_wgrad_desc* w, void* stream);
 int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream);
 int nirgan_wino6_conv3x3(const nirgan_wino6_desc* d, void* stream);   /* input + gemm + output */
-/* Yt [36][B*ceil(H/4)*ceil(W/4)][K]; the descriptor's r field is ignored */
+/* Yt [(r+3)^2][B*ceil(H/4)*ceil(W/4)][K]; the descriptor's r field selects the filter size (0 / 3 or 4) */
 int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream);
 /* nirgan_wino6_input(c) and nirgan_wino6_dy(y) of the SAME output-gradient buffer (c->x == y->dy, zero halo 2) in one pass: the 4x4
  * block of tile (ty, tx) is the lower-right corner of data-gradient patch (ty, tx) */
@@ -494,6 +498,7 @@ int nirgan_wino6_input_dy(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc*
  * into c->x -- that buffer is neither written nor read (c->x / y->dy only describe its geometry: zero halo 2) */
 int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, const nirgan_in_bwd_desc* n, void* stream);
 int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
+int nirgan_wino6_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream);   /* [K][C][r][r] */
 
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).

@@ -63,50 +63,147 @@ __device__ __forceinline__ void w6_gt(const float* u, float* g) {               
     g[2] = (u[1] + u[2]) * (1.f / 6.f) + u[3] * (2.f / 15.f) + u[4] * (4.f / 15.f) + 0.5f * u[5];
 }
 
+
+// F(4x4, 4x4) -- nn.Conv2d(C, K, 4, stride 1) of the PatchGAN (model/networks.py:573-579): 49 products per 4x4 outputs (F(2x2,4x4): 100,
+// direct: 256).  Cook-Toom over 0, 1, -1, 2, -2, 1/2, inf (fp32 error of the forward 1.0e-5 of the output's maximum, weight gradient
+// 5e-6: scripts/exp_wino6_points.py), rows scaled so that B^T is integer.
+__host__ __device__ constexpr float w7_BT(int i, int j) {
+    constexpr float m[7][7] = {{4, -8, -5, 10, 1, -2, 0}, {0, -4, 4, 9, -1, -2, 0}, {0, -4, 12, -7, -3, 2, 0}, {0, 2, -3, -4, 3, 2, 0},
+                               {0, 2, -5, 0, 5, -2, 0}, {0, 4, 0, -5, 0, 1, 0}, {0, -4, 8, 5, -10, -1, 2}};
+    return m[i][j];
+}
+__host__ __device__ constexpr float w7_G(int i, int j) {
+    constexpr float m[7][4] = {{1.f / 4, 0, 0, 0}, {1.f / 6, 1.f / 6, 1.f / 6, 1.f / 6}, {1.f / 18, -1.f / 18, 1.f / 18, -1.f / 18},
+                               {1.f / 72, 1.f / 36, 1.f / 18, 1.f / 9}, {1.f / 120, -1.f / 60, 1.f / 30, -1.f / 15},
+                               {32.f / 45, 16.f / 45, 8.f / 45, 4.f / 45}, {0, 0, 0, 1.f / 2}};
+    return m[i][j];
+}
+__host__ __device__ constexpr float w7_AT(int i, int j) {
+    constexpr float m[4][7] = {{1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0.5f, 0}, {0, 1, 1, 4, 4, 0.25f, 0}, {0, 1, -1, 8, -8, 0.125f, 1}};
+    return m[i][j];
+}
+// acc += c * x with the constant folded after unrolling (0: nothing, +-1: add / subtract)
+template <typename T> __device__ __forceinline__ void w6_mac(T& acc, const float c, const T& x) {
+    if (c == 0.f) return;
+    if (c == 1.f) acc += x;
+    else if (c == -1.f) acc -= x;
+    else acc += c * x;
+}
+
+// R = filter size (3 or 4): N = R + 3 points per dimension, N * N planes, 4x4 outputs per tile, patches of N x N at stride 4
+template <int R> struct W6 {
+    static constexpr int N = R + 3, NP = N * N;
+    template <class T> static __device__ __forceinline__ void bt(const T* d, T* t) {                // t = B^T d   (N -> N)
+        if constexpr (R == 3) w6_bt(d, t);
+        else {
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                T s = d[0] * 0.f;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) w6_mac(s, w7_BT(o, i), d[i]);
+                t[o] = s;
+            }
+        }
+    }
+    template <class T> static __device__ __forceinline__ void at(const T* m, T* y) {                // y = A^T m   (N -> 4)
+        if constexpr (R == 3) w6_at(m, y);
+        else {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                T s = m[0] * 0.f;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) w6_mac(s, w7_AT(o, i), m[i]);
+                y[o] = s;
+            }
+        }
+    }
+    template <class T> static __device__ __forceinline__ void a(const T* e, T* u) {                 // u = A e     (4 -> N)
+        if constexpr (R == 3) w6_a(e, u);
+        else {
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                T s = e[0] * 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w6_mac(s, w7_AT(i, o), e[i]);
+                u[o] = s;
+            }
+        }
+    }
+    static __device__ __forceinline__ void g(const float* gg, float* w) {                           // w = G g     (R -> N)
+        if constexpr (R == 3) w6_g(gg, w);
+        else {
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w6_mac(s, w7_G(o, i), gg[i]);
+                w[o] = s;
+            }
+        }
+    }
+    static __device__ __forceinline__ void gt(const float* u, float* gg) {                          // g = G^T u   (N -> R)
+        if constexpr (R == 3) w6_gt(u, gg);
+        else {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) w6_mac(s, w7_G(i, o), u[i]);
+                gg[o] = s;
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------ weights
 struct W6W { const float* w; float* U; int K, C, flip; };
 
+template <int R>
 __device__ __forceinline__ void wino6_weight_one(const W6W& p, const long long i) {
+    constexpr int N = W6<R>::N, RR = R * R;
     if (i >= (long long)p.K * p.C) return;
     const int k = int(i / p.C), c = int(i - (long long)k * p.C);
-    // flip: the data-gradient filter g'[k][c][i][j] = W[c][k][2-i][2-j] (W stored [C][K][3][3]: rows are the forward OUTPUT channels)
-    const float* g = p.flip ? p.w + (size_t(c) * p.K + k) * 9 : p.w + (size_t(k) * p.C + c) * 9;
-    float t[6][3];
+    // flip: the data-gradient filter g'[k][c][i][j] = W[c][k][R-1-i][R-1-j] (W stored [C][K][R][R]: rows are the forward OUTPUT channels)
+    const float* g = p.flip ? p.w + (size_t(c) * p.K + k) * RR : p.w + (size_t(k) * p.C + c) * RR;
+    float t[N][R];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const float col[3] = {p.flip ? g[8 - j] : g[j], p.flip ? g[5 - j] : g[3 + j], p.flip ? g[2 - j] : g[6 + j]};
-        float o[6];
-        w6_g(col, o);
+    for (int j = 0; j < R; ++j) {
+        float col[R], o[N];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) t[a][j] = o[a];
+        for (int a = 0; a < R; ++a) col[a] = p.flip ? g[RR - 1 - (a * R + j)] : g[a * R + j];
+        W6<R>::g(col, o);
+#pragma unroll
+        for (int a = 0; a < N; ++a) t[a][j] = o[a];
     }
     const size_t plane = size_t(p.K) * p.C;
     float* U = p.U + size_t(k) * p.C + c;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        float o[6];
-        w6_g(t[a], o);
+    for (int a = 0; a < N; ++a) {
+        float o[N];
+        W6<R>::g(t[a], o);
 #pragma unroll
-        for (int b = 0; b < 6; ++b) U[(a * 6 + b) * plane] = o[b];
+        for (int b = 0; b < N; ++b) U[(a * N + b) * plane] = o[b];
     }
 }
 
-__global__ __launch_bounds__(256) void wino6_weight_kernel(const W6W p) { wino6_weight_one(p, blockIdx.x * 256ll + threadIdx.x); }
+template <int R>
+__global__ __launch_bounds__(256) void wino6_weight_kernel(const W6W p) { wino6_weight_one<R>(p, blockIdx.x * 256ll + threadIdx.x); }
 
-// all F(4x4,3x3) weight transforms of a step in one launch: 8 x int64 per job {w, U, K, C, flip, first_block, 0, 0}
+// all F(4x4, RxR) weight transforms of a step in one launch: 8 x int64 per job {w, U, K, C, flip, first_block, r, 0}
 __global__ __launch_bounds__(256) void wino6_weights_batch_kernel(const long long* __restrict__ jobs, int njobs) {
     int j = 0;
     for (int i = 1; i < njobs; ++i)
         if (int(blockIdx.x) >= int(jobs[i * 8 + 5])) j = i;
     const long long* J = jobs + j * 8;
     W6W p{reinterpret_cast<const float*>(J[0]), reinterpret_cast<float*>(J[1]), int(J[2]), int(J[3]), int(J[4])};
-    wino6_weight_one(p, (long long)(int(blockIdx.x) - int(J[5])) * 256 + threadIdx.x);
+    const long long i = (long long)(int(blockIdx.x) - int(J[5])) * 256 + threadIdx.x;
+    if (J[6] == 4) wino6_weight_one<4>(p, i); else wino6_weight_one<3>(p, i);
 }
 
 // ------------------------------------------------------------------------------------------------ input transform
 struct W6In {
     const float* x; float* V; int B, C, x_row, x_img, x_hp, x_wp, TH, TW; long long T;
-    float* Yt; int yTH, yTW; long long yT;       // Yt != nullptr: x is a dY buffer with a zero halo of 2 and the lower-right 4x4 block of patch (ty, tx)
+    float* Yt; int yTH, yTW; long long yT;       // Yt != nullptr: x is a dY buffer with a zero halo of R-1 and the lower-right 4x4 block of patch (ty, tx)
                                                  // is output-gradient tile (ty, tx): Yt = A dY A^T is emitted from the same read of dY
     // normalising variant: x = act((y - mean) * rstd) of a dense [B][H][W][C] tensor under a REFLECT halo of 1, evaluated on the fly
     const float* y; const float* mean; const float* rstd; int H, W, act; float slope;
@@ -115,11 +212,20 @@ struct W6In {
     InBwd nb; int nbB;
 };
 
-// MODE 0: x from the halo'd buffer; 1: forward input normalised on the fly; 2: output gradient from the instance-norm backward on the fly
-template <int MODE>
+template <int VW> struct W6Vec;
+template <> struct W6Vec<4> { typedef f32x4 T; };
+template <> struct W6Vec<2> { typedef f32x2 T; };
+
+// One thread = one N x N patch x VW channels (4 for the 6x6 patches of F(4x4,3x3); 2 for the 7x7 patches of F(4x4,4x4): 49 float4
+// intermediates would not fit the register file).  MODE 0: x from the halo'd buffer; 1: forward input normalised on the fly (3x3 only);
+// 2: output gradient from the instance-norm backward on the fly (3x3 only).
+template <int R, int MODE>
 __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     constexpr bool NORM = MODE == 1;
-    const int q4 = p.C / 4;
+    constexpr int N = W6<R>::N, VW = R == 3 ? 4 : 2;
+    typedef typename W6Vec<VW>::T V4;
+    static_assert(MODE == 0 || R == 3, "the fused variants exist for the 3x3 filter");
+    const int q4 = p.C / VW;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= p.T * q4) return;
     const long long t = i / q4;
@@ -127,10 +233,12 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     const int tx = int(t % p.TW);
     const long long r = t / p.TW;
     const int ty = int(r % p.TH), b = int(r / p.TH);
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 mean = z4, rstd = z4;
+    V4 z4;
+#pragma unroll
+    for (int e = 0; e < VW; ++e) z4[e] = 0.f;
+    V4 mean = z4, rstd = z4;
     const float* base;
-    f32x4 m1 = z4, m2 = z4;
+    V4 m1 = z4, m2 = z4;
     const float* gb = nullptr; const float* g2b = nullptr; const float* gsb = nullptr; const float* yb = nullptr;
     if constexpr (MODE == 2) {
         const InBwd& n = p.nb;
@@ -144,76 +252,76 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
         g2b = n.g2 ? n.g2 + size_t(b) * n.HW * n.C : nullptr;
         base = nullptr;
     } else if constexpr (NORM) {
-        mean = *reinterpret_cast<const f32x4*>(p.mean + size_t(b) * p.C + q * 4);
-        rstd = *reinterpret_cast<const f32x4*>(p.rstd + size_t(b) * p.C + q * 4);
-        base = p.y + size_t(b) * p.H * p.W * p.C + q * 4;
+        mean = *reinterpret_cast<const V4*>(p.mean + size_t(b) * p.C + q * VW);
+        rstd = *reinterpret_cast<const V4*>(p.rstd + size_t(b) * p.C + q * VW);
+        base = p.y + size_t(b) * p.H * p.W * p.C + q * VW;
     } else {
-        base = p.x + size_t(b) * p.x_img + q * 4;
+        base = p.x + size_t(b) * p.x_img + q * VW;
     }
     // value of the (virtual) halo'd buffer at patch position (a, c); lines past the buffer (extent not a multiple of 4) read zero:
     // they feed only outputs that are never stored
-    auto ld = [&](int a, int c) -> f32x4 {
+    auto ld = [&](int a, int c) -> V4 {
         const int rb = 4 * ty + a, cb = 4 * tx + c;
         if (rb >= p.x_hp || cb >= p.x_wp) return z4;
         if constexpr (MODE == 2) {
-            const int h = rb - 2, w = cb - 2;              // the dY buffer has a zero halo of 2
+            const int h = rb - (R - 1), w = cb - (R - 1);      // the dY buffer has a zero halo of R - 1
             if (h < 0 || w < 0 || h >= p.nb.H || w >= p.nb.W) return z4;
             return in_bwd_dy(p.nb, gb, g2b, gsb, yb, mean, rstd, m1, m2, h, w, q);
         } else if constexpr (NORM) {
             const int yr = ng_reflect(rb - 1, p.H), yc = ng_reflect(cb - 1, p.W);
-            f32x4 v = (*reinterpret_cast<const f32x4*>(base + (size_t(yr) * p.W + yc) * p.C) - mean) * rstd;     // in_apply_kernel's arithmetic
+            V4 v = (*reinterpret_cast<const V4*>(base + (size_t(yr) * p.W + yc) * p.C) - mean) * rstd;     // in_apply_kernel's arithmetic
             if (p.act == NIRGAN_ACT_RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                for (int e = 0; e < VW; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
             } else if (p.act == NIRGAN_ACT_LRELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                for (int e = 0; e < VW; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
             }
             return v;
         } else {
-            return *reinterpret_cast<const f32x4*>(base + size_t(rb) * p.x_row + size_t(cb) * p.C);
+            return *reinterpret_cast<const V4*>(base + size_t(rb) * p.x_row + size_t(cb) * p.C);
         }
     };
-    f32x4 m[6][6];
+    V4 m[N][N];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        f32x4 d[6], o[6];
+    for (int c = 0; c < N; ++c) {
+        V4 d[N], o[N];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) d[a] = ld(a, c);
-        w6_bt(d, o);
+        for (int a = 0; a < N; ++a) d[a] = ld(a, c);
+        W6<R>::bt(d, o);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) m[a][c] = o[a];
+        for (int a = 0; a < N; ++a) m[a][c] = o[a];
     }
     const size_t plane = size_t(p.T) * p.C;
-    float* V = p.V + size_t(t) * p.C + q * 4;
+    float* V = p.V + size_t(t) * p.C + q * VW;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        f32x4 o[6];
-        w6_bt(m[a], o);
+    for (int a = 0; a < N; ++a) {
+        V4 o[N];
+        W6<R>::bt(m[a], o);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(V + (a * 6 + c) * plane) = o[c];
+        for (int c = 0; c < N; ++c) *reinterpret_cast<V4*>(V + (a * N + c) * plane) = o[c];
     }
     if constexpr (MODE != 1) {
         if (p.Yt != nullptr && ty < p.yTH && tx < p.yTW) {
-            // output-gradient tile (ty, tx) = patch rows / columns 2 .. 5 (just read: L1 / L2 hits); rows past the extent read the zero halo
-            f32x4 u[6][4];
+            // output-gradient tile (ty, tx) = patch rows / columns R-1 .. R+2 (just read: L1 / L2 hits); rows past the extent read the zero halo
+            V4 u[N][4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                f32x4 e[4], o[6];
+                V4 e[4], o[N];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) e[a] = ld(2 + a, 2 + c);
-                w6_a(e, o);
+                for (int a = 0; a < 4; ++a) e[a] = ld(R - 1 + a, R - 1 + c);
+                W6<R>::a(e, o);
 #pragma unroll
-                for (int a = 0; a < 6; ++a) u[a][c] = o[a];
+                for (int a = 0; a < N; ++a) u[a][c] = o[a];
             }
             const size_t yplane = size_t(p.yT) * p.C;
-            float* Y = p.Yt + ((size_t(b) * p.yTH + ty) * p.yTW + tx) * p.C + q * 4;
+            float* Y = p.Yt + ((size_t(b) * p.yTH + ty) * p.yTW + tx) * p.C + q * VW;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                f32x4 o[6];
-                w6_a(u[a], o);
+            for (int a = 0; a < N; ++a) {
+                V4 o[N];
+                W6<R>::a(u[a], o);
 #pragma unroll
-                for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(Y + (a * 6 + c) * yplane) = o[c];
+                for (int c = 0; c < N; ++c) *reinterpret_cast<V4*>(Y + (a * N + c) * yplane) = o[c];
             }
         }
     }
@@ -222,7 +330,9 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
 // Yt[f][t][k] = (A dY A^T)[f] alone (weight gradient without a Winograd data gradient next to it)
 struct W6Dy { const float* dy; float* Yt; int B, H, W, K, d_row, d_img, d_org, TH, TW; long long T; };
 
+template <int R>
 __global__ __launch_bounds__(256) void wino6_dy_kernel(const W6Dy p) {
+    constexpr int N = W6<R>::N;
     const int q4 = p.K / 4;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= p.T * q4) return;
@@ -233,27 +343,27 @@ __global__ __launch_bounds__(256) void wino6_dy_kernel(const W6Dy p) {
     const int ty = int(r % p.TH), b = int(r / p.TH);
     const float* src = p.dy + size_t(b) * p.d_img + p.d_org + q * 4;
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 u[6][4];
+    f32x4 u[N][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        f32x4 e[4], o[6];
+        f32x4 e[4], o[N];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int h = 4 * ty + a, w = 4 * tx + c;
             e[a] = (h < p.H && w < p.W) ? *reinterpret_cast<const f32x4*>(src + size_t(h) * p.d_row + size_t(w) * p.K) : z4;
         }
-        w6_a(e, o);
+        W6<R>::a(e, o);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) u[a][c] = o[a];
+        for (int a = 0; a < N; ++a) u[a][c] = o[a];
     }
     const size_t plane = size_t(p.T) * p.K;
     float* Y = p.Yt + size_t(t) * p.K + q * 4;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        f32x4 o[6];
-        w6_a(u[a], o);
+    for (int a = 0; a < N; ++a) {
+        f32x4 o[N];
+        W6<R>::a(u[a], o);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) *reinterpret_cast<f32x4*>(Y + (a * 6 + c) * plane) = o[c];
+        for (int c = 0; c < N; ++c) *reinterpret_cast<f32x4*>(Y + (a * N + c) * plane) = o[c];
     }
 }
 
@@ -420,7 +530,9 @@ __global__ __launch_bounds__(256, 3) void wino6_gemm16_kernel(const W6G16 p) {
 // ------------------------------------------------------------------------------------------------ output transform
 struct W6Out { const float* M; const float* bias; float* y; int B, H, W, K, TH, TW; long long T; };
 
+template <int R>
 __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
+    constexpr int N = W6<R>::N;
     const int q4 = p.K / 4;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= p.T * q4) return;
@@ -431,13 +543,13 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
     const int ty = int(r % p.TH), b = int(r / p.TH);
     const size_t plane = size_t(p.T) * p.K;
     const float* M = p.M + size_t(t) * p.K + q * 4;
-    f32x4 s[4][6];
+    f32x4 s[4][N];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        f32x4 m[6], o[4];
+    for (int c = 0; c < N; ++c) {
+        f32x4 m[N], o[4];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(M + (a * 6 + c) * plane);
-        w6_at(m, o);
+        for (int a = 0; a < N; ++a) m[a] = *reinterpret_cast<const f32x4*>(M + (a * N + c) * plane);
+        W6<R>::at(m, o);
 #pragma unroll
         for (int a = 0; a < 4; ++a) s[a][c] = o[a];
     }
@@ -447,7 +559,7 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         f32x4 o[4];
-        w6_at(s[a], o);
+        W6<R>::at(s[a], o);
         const int h = 4 * ty + a;
         if (h >= p.H) continue;
 #pragma unroll
@@ -461,50 +573,60 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
 // ------------------------------------------------------------------------------------------------ weight-gradient finish
 struct W6Fin { const float* slabs; int nsplit, K, C; float* grad; int accumulate; };
 
-// dW[k][c] = G^T (sum over splits of dU[.][k][c]) G in the reference layout [K][C][3][3]; splits in order (deterministic).
-// A block takes 64 (k, c) pairs: thread (e, fg) sums frequencies 9 fg .. 9 fg + 8 of pair e over the splits (coalesced 256-B rows),
-// the 36 sums meet in LDS and threads 0-63 apply the 3x6 / 6x3 transforms.
+// dW[k][c] = G^T (sum over splits of dU[.][k][c]) G in the reference layout [K][C][R][R]; splits in order (deterministic).
+// A block takes 64 (k, c) pairs: thread (e, fg) sums the planes fg, fg + 4, ... of pair e over the splits (coalesced 256-B rows),
+// the N * N sums meet in LDS and threads 0-63 apply the R x N / N x R transforms.
+template <int R>
 __global__ __launch_bounds__(256) void wino6_wgrad_finish_kernel(const W6Fin p) {
-    __shared__ float u_s[36][64];
+    constexpr int N = W6<R>::N, NP = N * N, PER = (NP + 3) / 4;
+    __shared__ float u_s[NP][64];
     const int e = threadIdx.x & 63, fg = threadIdx.x >> 6;
     const long long i = blockIdx.x * 64ll + e;
     const size_t kc = size_t(p.K) * p.C;
     const bool ok = i < (long long)kc;
-    float sum[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float sum[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) sum[j] = 0.f;
     if (ok) {
-        const float* src = p.slabs + size_t(fg * 9) * p.nsplit * kc + i;          // slabs are [plane][split][K][C]
+        const float* src = p.slabs + i;                                            // slabs are [plane][split][K][C]
         for (int sp = 0; sp < p.nsplit; ++sp) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) sum[j] += src[(size_t(j) * p.nsplit + sp) * kc];
+            for (int j = 0; j < PER; ++j) {
+                const int f = fg + 4 * j;
+                if (f < NP) sum[j] += src[(size_t(f) * p.nsplit + sp) * kc];
+            }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 9; ++j) u_s[fg * 9 + j][e] = sum[j];
+    for (int j = 0; j < PER; ++j)
+        if (fg + 4 * j < NP) u_s[fg + 4 * j][e] = sum[j];
     __syncthreads();
     if (fg != 0 || !ok) return;
-    float t[3][6];
+    float t[R][N];
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        float col[6], o[3];
+    for (int b = 0; b < N; ++b) {
+        float col[N], o[R];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) col[a] = u_s[a * 6 + b][e];
-        w6_gt(col, o);
+        for (int a = 0; a < N; ++a) col[a] = u_s[a * N + b][e];
+        W6<R>::gt(col, o);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) t[a][b] = o[a];
+        for (int a = 0; a < R; ++a) t[a][b] = o[a];
     }
-    float* g = p.grad + size_t(i) * 9;
+    float* g = p.grad + size_t(i) * (R * R);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float o[3];
-        w6_gt(t[a], o);
+    for (int a = 0; a < R; ++a) {
+        float o[R];
+        W6<R>::gt(t[a], o);
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            if (p.accumulate) g[a * 3 + b] += o[b]; else g[a * 3 + b] = o[b];
+        for (int b = 0; b < R; ++b) {
+            if (p.accumulate) g[a * R + b] += o[b]; else g[a * R + b] = o[b];
         }
     }
 }
 
 static inline long long w6_tiles(int B, int H, int W) { return (long long)B * ((H + 3) / 4) * ((W + 3) / 4); }
+static inline int w6_r(int r) { return r == 0 ? 3 : r; }                 // filter size: 0 / 3 = F(4x4,3x3), 4 = F(4x4,4x4)
+static inline int w6_np(int r) { return (r + 3) * (r + 3); }             // planes: 36 / 49
 
 }  // namespace
 
@@ -513,12 +635,20 @@ extern "C" int64_t nirgan_wino6_tiles(int B, int H, int W) {
     return w6_tiles(B, H, W);
 }
 
-extern "C" int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream) {
+extern "C" int nirgan_wino6_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream) {
+    r = w6_r(r);
     NG_REQUIRE(w && U && K > 0 && C > 0, "wino6_weights: bad arguments");
+    NG_REQUIRE(r == 3 || r == 4, "wino6_weights: filter size %d (3 or 4)", r);
     W6W p{w, U, K, C, transpose_flip ? 1 : 0};
     const long long n = (long long)K * C;
-    hipLaunchKernelGGL(wino6_weight_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    const dim3 grid(unsigned((n + 255) / 256));
+    if (r == 3) hipLaunchKernelGGL(wino6_weight_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino6_weight_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino6_weights");
+}
+
+extern "C" int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream) {
+    return nirgan_wino6_weights_r(w, K, C, 3, transpose_flip, U, stream);
 }
 
 extern "C" int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream) {
@@ -531,29 +661,34 @@ extern "C" int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs,
 static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const float* ny, const float* mean, const float* rstd,
                          int act, float slope, void* stream, const nirgan_in_bwd_desc* nb = nullptr) {
     NG_REQUIRE(d && d->V && (d->x || ny || nb), "wino6_input: null pointer");
+    const int r = w6_r(d->r), np = w6_np(r);
+    NG_REQUIRE(r == 3 || r == 4, "wino6_input: filter size %d (3 or 4)", r);
+    NG_REQUIRE(r == 3 || (!ny && !nb), "wino6_input: the fused variants exist for the 3x3 filter");
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino6_input: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
-    NG_REQUIRE(ny || (d->x_hp == d->H + 2 && d->x_wp == d->W + 2), "wino6_input: the input must be (H+2) x (W+2) (%dx%d for %dx%d)", d->x_hp, d->x_wp, d->H, d->W);
+    NG_REQUIRE(ny || (d->x_hp == d->H + r - 1 && d->x_wp == d->W + r - 1), "wino6_input: the input must be (H+%d) x (W+%d) (%dx%d for %dx%d)", r - 1, r - 1, d->x_hp, d->x_wp, d->H, d->W);
     NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->V) && ng_aligned16(ny) && ng_aligned16(mean) && ng_aligned16(rstd), "wino6_input: pointers must be 16-byte aligned");
     const long long T = w6_tiles(d->B, d->H, d->W);
     NG_REQUIRE(T < (1ll << 31) / d->C, "wino6_input: problem too large for 32-bit tile offsets");
-    NG_REQUIRE(d->V_elems >= 36 * T * d->C, "wino6_input: V workspace too small");
+    NG_REQUIRE(d->V_elems >= np * T * d->C, "wino6_input: V workspace too small");
     W6In in;
     in.x = d->x; in.V = d->V; in.B = d->B; in.C = d->C;
-    in.x_hp = d->H + 2; in.x_wp = d->W + 2; in.x_row = in.x_wp * d->C; in.x_img = in.x_hp * in.x_row;
+    in.x_hp = d->H + r - 1; in.x_wp = d->W + r - 1; in.x_row = in.x_wp * d->C; in.x_img = in.x_hp * in.x_row;
     in.TH = (d->H + 3) / 4; in.TW = (d->W + 3) / 4; in.T = T;
     in.Yt = nullptr; in.yTH = in.yTW = 0; in.yT = 0;
     in.y = ny; in.mean = mean; in.rstd = rstd; in.H = d->H; in.W = d->W; in.act = act; in.slope = slope;
     if (y != nullptr) {
-        // the same dY buffer seen twice: zero halo 2, the data gradient covers (H_dy + 2) x (W_dy + 2) outputs
-        NG_REQUIRE(!ny && (nb || y->dy == d->x) && y->Yt && y->dy_pad == 2 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp && y->dy_wp == d->x_wp
-                   && d->H == y->H + 2 && d->W == y->W + 2, "wino6_input_dy: the two descriptors do not describe the same output-gradient buffer");
+        // the same dY buffer seen twice: zero halo r-1, the data gradient covers (H_dy + r - 1) x (W_dy + r - 1) outputs
+        NG_REQUIRE(!ny && (nb || y->dy == d->x) && y->Yt && w6_r(y->r) == r && y->dy_pad == r - 1 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp
+                   && y->dy_wp == d->x_wp && d->H == y->H + r - 1 && d->W == y->W + r - 1,
+                   "wino6_input_dy: the two descriptors do not describe the same output-gradient buffer");
         NG_REQUIRE(ng_aligned16(y->Yt), "wino6_input_dy: pointers must be 16-byte aligned");
         in.yTH = (y->H + 3) / 4; in.yTW = (y->W + 3) / 4; in.yT = (long long)y->B * in.yTH * in.yTW;
-        NG_REQUIRE(y->Yt_elems >= 36 * in.yT * y->K, "wino6_input_dy: Yt workspace too small");
+        NG_REQUIRE(y->Yt_elems >= np * in.yT * y->K, "wino6_input_dy: Yt workspace too small");
         in.Yt = y->Yt;
     }
-    const long long nthreads = T * (d->C / 4);
+    const long long nthreads = T * (d->C / (r == 3 ? 4 : 2));
     const dim3 grid(unsigned((nthreads + 255) / 256));
+    hipStream_t st = static_cast<hipStream_t>(stream);
     in.nbB = 0;
     if (nb != nullptr) {
         NG_REQUIRE(y != nullptr && nb->norm && nb->y && nb->mean && nb->rstd && nb->ws && (nb->g || nb->g2), "wino6_input_dy_norm: the instance-norm descriptor needs y, mean, rstd, ws and a gradient");
@@ -562,9 +697,10 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
         in.nb = in_bwd_params(nb);
         in.nbB = nb->B;
         NG_REQUIRE(nb->ws_elems >= int64_t(nb->B) * in.nb.nchunk * 2 * nb->C + int64_t(nb->B) * 2 * nb->C, "wino6_input_dy_norm: ws too small");
-        hipLaunchKernelGGL(wino6_input_kernel<2>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
-    } else if (ny) hipLaunchKernelGGL(wino6_input_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
-    else hipLaunchKernelGGL(wino6_input_kernel<0>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), in);
+        hipLaunchKernelGGL((wino6_input_kernel<3, 2>), grid, dim3(256), 0, st, in);
+    } else if (ny) hipLaunchKernelGGL((wino6_input_kernel<3, 1>), grid, dim3(256), 0, st, in);
+    else if (r == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 0>), grid, dim3(256), 0, st, in);
+    else hipLaunchKernelGGL((wino6_input_kernel<4, 0>), grid, dim3(256), 0, st, in);
     return nirgan_check_launch("wino6_input");
 }
 
@@ -588,6 +724,8 @@ extern "C" int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* d, const nirg
 
 extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {
     NG_REQUIRE(d && d->dy && d->Yt, "wino6_dy: null pointer");
+    const int r = w6_r(d->r);
+    NG_REQUIRE(r == 3 || r == 4, "wino6_dy: filter size %d (3 or 4)", r);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0 && d->dy_pad >= 0, "wino6_dy: bad shape");
     NG_REQUIRE(d->dy_hp == d->H + 2 * d->dy_pad && d->dy_wp == d->W + 2 * d->dy_pad, "wino6_dy: dy geometry mismatch");
     NG_REQUIRE(ng_aligned16(d->dy) && ng_aligned16(d->Yt), "wino6_dy: pointers must be 16-byte aligned");
@@ -595,19 +733,23 @@ extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {
     p.dy = d->dy; p.Yt = d->Yt; p.B = d->B; p.H = d->H; p.W = d->W; p.K = d->K;
     p.d_row = d->dy_wp * d->K; p.d_img = d->dy_hp * p.d_row; p.d_org = d->dy_pad * p.d_row + d->dy_pad * d->K;
     p.TH = (d->H + 3) / 4; p.TW = (d->W + 3) / 4; p.T = (long long)d->B * p.TH * p.TW;
-    NG_REQUIRE(d->Yt_elems >= 36 * p.T * d->K, "wino6_dy: workspace too small");
+    NG_REQUIRE(d->Yt_elems >= w6_np(r) * p.T * d->K, "wino6_dy: workspace too small");
     const long long n = p.T * (d->K / 4);
-    hipLaunchKernelGGL(wino6_dy_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    const dim3 grid(unsigned((n + 255) / 256));
+    if (r == 3) hipLaunchKernelGGL(wino6_dy_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino6_dy_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino6_dy");
 }
 
 // validation + the 32-k form's parameters (one plane as a 1x1 'convolution' over a [1][T] image of C-channel pixels: the direct tile's descriptor)
 static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
     NG_REQUIRE(d && d->U && d->V && d->M && d->zero_page, "wino6_gemm: null pointer");
+    const int r = w6_r(d->r), np = w6_np(r);
+    NG_REQUIRE(r == 3 || r == 4, "wino6_gemm: filter size %d (3 or 4)", r);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0 && d->K > 64 && d->K % 4 == 0, "wino6_gemm: C %% 4 == 0, K > 64, K %% 4 == 0 (C=%d K=%d)", d->C, d->K);
     T = w6_tiles(d->B, d->H, d->W);
     NG_REQUIRE(T * d->C < (1ll << 31) && T * d->K < (1ll << 31), "wino6_gemm: problem too large for 32-bit offsets");
-    NG_REQUIRE(d->V_elems >= 36 * T * d->C && d->M_elems >= 36 * T * d->K, "wino6_gemm: V / M workspace too small");
+    NG_REQUIRE(d->V_elems >= np * T * d->C && d->M_elems >= np * T * d->K, "wino6_gemm: V / M workspace too small");
     nirgan_conv_desc c = {};
     c.in = d->V; c.in_elems = T * d->C; c.in_hp = 1; c.in_wp = int(T); c.in_cs = d->C; c.run = d->C; c.in_stride = 1;
     c.ntaps = 1;
@@ -617,7 +759,7 @@ static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
     const int rc = ng::build_conv_params(&c, g.p);
     if (rc != NIRGAN_OK) return rc;
     g.in_plane = T * d->C; g.w_plane = (long long)d->K * d->C; g.out_plane = T * d->K;
-    g.per_plane = g.p.mtiles * g.p.ntiles; g.total = 36 * g.per_plane;
+    g.per_plane = g.p.mtiles * g.p.ntiles; g.total = np * g.per_plane;
     return NIRGAN_OK;
 }
 
@@ -645,11 +787,11 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
     const int rc0 = w6_gemm_params(d, g, T);
     if (rc0 != NIRGAN_OK) return rc0;
     if (d->C % 16 == 0 && getenv("NIRGAN_WINO6_GEMM32") == nullptr) {
-        // 16-k stages, three resident workgroups per CU (see wino6_gemm16_kernel)
+        // 16-k stages, up to four resident workgroups per CU (see wino6_gemm16_kernel)
         NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm: pointers must be 16-byte aligned");
         W6G16 q;
         q.A = d->V; q.Bw = d->U; q.Out = d->M; q.zero = d->zero_page; q.T = int(T); q.C = d->C; q.K = d->K;
-        q.mtiles = int((T + 127) / 128); q.ntiles = (d->K + 127) / 128; q.per_plane = q.mtiles * q.ntiles; q.total = 36 * q.per_plane;
+        q.mtiles = int((T + 127) / 128); q.ntiles = (d->K + 127) / 128; q.per_plane = q.mtiles * q.ntiles; q.total = w6_np(w6_r(d->r)) * q.per_plane;
         q.a_plane = T * d->C; q.b_plane = (long long)d->K * d->C; q.o_plane = T * d->K;
         hipLaunchKernelGGL(wino6_gemm16_kernel, dim3(q.total), dim3(256), 0, static_cast<hipStream_t>(stream), q);
         return nirgan_check_launch("wino6_gemm");
@@ -660,13 +802,17 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
 
 extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
     NG_REQUIRE(d && d->M && d->y, "wino6_output: null pointer");
+    const int r = w6_r(d->r);
+    NG_REQUIRE(r == 3 || r == 4, "wino6_output: filter size %d (3 or 4)", r);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0, "wino6_output: bad shape");
     NG_REQUIRE(ng_aligned16(d->M) && ng_aligned16(d->y) && ng_aligned16(d->bias), "wino6_output: pointers must be 16-byte aligned");
     const long long T = w6_tiles(d->B, d->H, d->W);
-    NG_REQUIRE(d->M_elems >= 36 * T * d->K, "wino6_output: M workspace too small");
+    NG_REQUIRE(d->M_elems >= w6_np(r) * T * d->K, "wino6_output: M workspace too small");
     W6Out p{d->M, d->bias, d->y, d->B, d->H, d->W, d->K, (d->H + 3) / 4, (d->W + 3) / 4, T};
     const long long n = T * (d->K / 4);
-    hipLaunchKernelGGL(wino6_output_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    const dim3 grid(unsigned((n + 255) / 256));
+    if (r == 3) hipLaunchKernelGGL(wino6_output_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino6_output_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino6_output");
 }
 
@@ -676,10 +822,18 @@ extern "C" int nirgan_wino6_conv3x3(const nirgan_wino6_desc* d, void* stream) {
     return rc != NIRGAN_OK ? rc : nirgan_wino6_output(d, stream);
 }
 
-extern "C" int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream) {
+extern "C" int nirgan_wino6_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream) {
+    r = w6_r(r);
     NG_REQUIRE(slabs && grad && nsplit >= 1 && K > 0 && C > 0, "wino6_wgrad_finish: bad arguments");
+    NG_REQUIRE(r == 3 || r == 4, "wino6_wgrad_finish: filter size %d (3 or 4)", r);
     W6Fin p{slabs, nsplit, K, C, grad, accumulate ? 1 : 0};
     const long long n = (long long)K * C;
-    hipLaunchKernelGGL(wino6_wgrad_finish_kernel, dim3(unsigned((n + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    const dim3 grid(unsigned((n + 63) / 64));
+    if (r == 3) hipLaunchKernelGGL(wino6_wgrad_finish_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino6_wgrad_finish_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino6_wgrad_finish");
+}
+
+extern "C" int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream) {
+    return nirgan_wino6_wgrad_finish_r(slabs, nsplit, K, C, 3, grad, accumulate, stream);
 }

@@ -185,16 +185,16 @@ class Plan:
 
     def fuse_wino6_weights(self):
         """And for the F(4x4,3x3) weight transforms (csrc/wino6.hip)."""
-        jobs = [a for n, a in self.ops if n == "nirgan_wino6_weights"]
+        jobs = [a for n, a in self.ops if n == "nirgan_wino6_weights_r"]
         if len(jobs) < 2 or len(jobs) > 256:
             return
         rows, first = [], 0
-        for w, K, Cc, flip, U in jobs:
-            rows.append([w, U, K, Cc, flip, first, 0, 0])
+        for w, K, Cc, r, flip, U in jobs:
+            rows.append([w, U, K, Cc, flip, first, r, 0])
             first += (K * Cc + 255) // 256
         table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
         self.ctx.keep.append(table)
-        self.ops = [(n, a) for n, a in self.ops if n != "nirgan_wino6_weights"]
+        self.ops = [(n, a) for n, a in self.ops if n != "nirgan_wino6_weights_r"]
         self.ops.append(("nirgan_wino6_weights_batch", (table.data_ptr(), len(rows), first)))
 
     def run(self):
@@ -542,9 +542,14 @@ def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tenso
 
 
 def wino6_applicable(ctx: Ctx, k: int, cout: int) -> bool:
-    """Winograd F(4x4, 3x3) (csrc/wino6.hip) instead of F(2x2, 3x3) wherever the latter applies to a 3x3 filter: 36 instead of 64
-    products per 4x4 outputs; the transform-domain product makes one trip through HBM.  NIRGAN_NO_WINO6=1 keeps F(2x2,3x3) (A/B)."""
-    return k == 3 and cout > 64 and os.environ.get("NIRGAN_NO_WINO6") != "1"
+    """Winograd F(4x4, kxk) (csrc/wino6.hip) instead of F(2x2, kxk) wherever the latter applies: 36 instead of 64 products per 4x4
+    outputs for the 3x3 filters of the residual blocks, 49 instead of 100 for the PatchGAN's stride-1 4x4 layer; the transform-domain
+    product makes one trip through HBM.  NIRGAN_NO_WINO6=1 keeps F(2x2,3x3), NIRGAN_NO_WINO7=1 keeps F(2x2,4x4) (A/B)."""
+    if cout <= 64:
+        return False
+    if k == 3:
+        return os.environ.get("NIRGAN_NO_WINO6") != "1"
+    return k == 4 and os.environ.get("NIRGAN_NO_WINO7") != "1" and os.environ.get("NIRGAN_NO_WINO6") != "1"
 
 
 def _w6_tiles(B, H, W) -> int:
@@ -552,25 +557,27 @@ def _w6_tiles(B, H, W) -> int:
 
 
 def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y, *, H, W, cin, cout, flip=False,
-               own_V: bool = False, x_norm=None):
-    """U = G g G^T in the pack plan; input transform, 36 plane GEMMs, output transform in `plan` (None: the caller places them).
-    x: [B][H+2][W+2][cin] buffer, y: dense [B][H][W][cout].  flip: data gradient (x = dY with a zero halo of 2, H x W = padded input)."""
-    assert x.hp == H + 2 and x.wp == W + 2 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
+               own_V: bool = False, x_norm=None, r: int = 3):
+    """U = G g G^T in the pack plan; input transform, (r+3)^2 plane GEMMs, output transform in `plan` (None: the caller places them).
+    x: [B][H+r-1][W+r-1][cin] buffer, y: dense [B][H][W][cout].  flip: data gradient (x = dY with a zero halo of r-1, H x W = padded input)."""
+    assert x.hp == H + r - 1 and x.wp == W + r - 1 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
     B = x.B
     T = _w6_tiles(B, H, W)
-    U = ctx.zeros(36 * cout * cin)
+    NP = (r + 3) ** 2
+    U = ctx.zeros(NP * cout * cin)
     ctx.keep.append(U)
-    pack.add("nirgan_wino6_weights", weight.data_ptr(), cout, cin, 1 if flip else 0, U.data_ptr())
+    pack.add("nirgan_wino6_weights_r", weight.data_ptr(), cout, cin, r, 1 if flip else 0, U.data_ptr())
     for name in ("wino6_pool_v", "wino6_pool_m"):
         if not hasattr(ctx, name):
             setattr(ctx, name, SplitPool(ctx))          # one layer at a time (launches run serially)
     if own_V:                                          # kept for the layer's weight gradient (same x): 2.25 x the input bytes, resident
-        V = ctx.zeros(36 * T * cin)
+        V = ctx.zeros(NP * T * cin)
         ctx.keep.append(V)
     else:
-        V = ctx.wino6_pool_v.get(36 * T * cin)
-    M = ctx.wino6_pool_m.get(36 * T * cout)
+        V = ctx.wino6_pool_v.get(NP * T * cin)
+    M = ctx.wino6_pool_m.get(NP * T * cout)
     d = L.Wino6Desc()
+    d.r = r
     d.x, d.x_hp, d.x_wp = x.ptr, x.hp, x.wp
     d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
     d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
@@ -579,7 +586,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     if plan is not None:
         if x_norm is not None:             # (y, (mean, rstd), act) of the producer: its apply pass is folded into this transform
             yh, st, act = x_norm
-            assert yh.pad == 0 and yh.H == H and yh.W == W and yh.C == cin
+            assert r == 3 and yh.pad == 0 and yh.H == H and yh.W == W and yh.C == cin
             plan.add("nirgan_wino6_input_norm", C.byref(d), yh.ptr, st[0].data_ptr(), st[1].data_ptr(), act, 0.2)
         else:
             plan.add("nirgan_wino6_input", C.byref(d))
@@ -589,13 +596,14 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
 
 
 def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, OH, OW, cin, cout, slabs_pool,
-                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False, norm_desc=None):
+                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False, norm_desc=None, r: int = 3):
     """Backward of an F(4x4,3x3) layer: dY -> (V of dY for the data gradient, Yt = A dY A^T for the weight gradient) in one pass, the
     data gradient's 36 plane GEMMs + output transform, the 36 transform-domain weight-gradient problems dU[f] = Yt[f]^T V[f] (V of the
     forward input, kept by the forward) as one weight-gradient launch, dW = G^T dU G."""
     B = inp.B
-    assert inp.pad == 1 and inp.H == OH and inp.W == OW and inp.C == cin and dy.C == cout and dy.pad == 2 and dgrad.x == dy.ptr
+    assert inp.pad == 1 and inp.H == OH + r - 3 and inp.W == OW + r - 3 and inp.C == cin and dy.C == cout and dy.pad == r - 1 and dgrad.x == dy.ptr
     T = _w6_tiles(B, OH, OW)
+    NP = (r + 3) ** 2
     for name in ("wino6_pool_x", "wino6_pool_y", "wino6_pool_y2", "wino6_slabs"):
         if not hasattr(ctx, name):
             setattr(ctx, name, SplitPool(ctx))
@@ -604,31 +612,32 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     # layer's transform does not overwrite what the previous layer's weight gradient is still reading; the slabs are its own pool
     ctx.wino6_flip = getattr(ctx, "wino6_flip", 0) ^ 1
     side_ok = V_fwd is not None
-    Yt = (ctx.wino6_pool_y2 if (ctx.wino6_flip and side_ok) else ctx.wino6_pool_y).get(36 * T * cout)
+    Yt = (ctx.wino6_pool_y2 if (ctx.wino6_flip and side_ok) else ctx.wino6_pool_y).get(NP * T * cout)
     if side_ok:
         slabs_pool = ctx.wino6_slabs
     vin = None
     if V_fwd is not None:
         V_ptr, V_elems = V_fwd.V, V_fwd.V_elems
     else:
-        V = ctx.wino6_pool_x.get(36 * T * cin)
+        V = ctx.wino6_pool_x.get(NP * T * cin)
         vin = L.Wino6Desc()
+        vin.r = r
         vin.x, vin.x_hp, vin.x_wp, vin.B, vin.H, vin.W, vin.C, vin.K = inp.ptr, inp.hp, inp.wp, B, OH, OW, cin, cout
         vin.V, vin.V_elems = V.data_ptr(), V.numel()
         V_ptr, V_elems = V.data_ptr(), V.numel()
     ydesc = L.WinoDyDesc()
     ydesc.dy, ydesc.dy_hp, ydesc.dy_wp, ydesc.dy_pad = dy.ptr, dy.hp, dy.wp, dy.pad
     ydesc.B, ydesc.H, ydesc.W, ydesc.K = B, OH, OW, cout
-    ydesc.Yt, ydesc.Yt_elems, ydesc.r = Yt.data_ptr(), Yt.numel(), 3
-    tiles = (-(-cout // 128)) * (-(-cin // 128)) * 36
+    ydesc.Yt, ydesc.Yt_elems, ydesc.r = Yt.data_ptr(), Yt.numel(), r
+    tiles = (-(-cout // 128)) * (-(-cin // 128)) * NP
     nsplit, rows = G.wgrad_split(T, tiles, 1024)
     if os.environ.get("NIRGAN_WINO6_SPLITS"):            # experiments
         nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ["NIRGAN_WINO6_SPLITS"]))
-    slabs = slabs_pool.get(36 * nsplit * cout * cin)
+    slabs = slabs_pool.get(NP * nsplit * cout * cin)
     d = L.WgradDesc()
-    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), 36 * T * cout, 1, T, cout, 0, 0
-    assert V_elems >= 36 * T * cin
-    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = V_ptr, 36 * T * cin, 1, T, cin
+    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), NP * T * cout, 1, T, cout, 0, 0
+    assert V_elems >= NP * T * cin
+    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = V_ptr, NP * T * cin, 1, T, cin
     d.q_stride, d.q_oh, d.q_ow = 1, 0, 0
     d.run = cin
     _set_taps(d, [0], [0])
@@ -636,7 +645,7 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
     d.zero_page = ctx.zero_page.data_ptr()
     d.precision = 0
-    d.nplanes, d.p_plane, d.q_plane = 36, T * cout, T * cin
+    d.nplanes, d.p_plane, d.q_plane = NP, T * cout, T * cin
     ctx.keep.extend([vin, ydesc, d, slabs])
     if norm_desc is not None:       # dY is not in memory: the instance-norm backward's second pass runs inside the transform
         plan.add("nirgan_wino6_input_dy_norm", C.byref(dgrad), C.byref(ydesc), C.byref(norm_desc))
@@ -652,7 +661,7 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
         plan.add("nirgan_wino6_gemm", C.byref(dgrad))
         add_w("nirgan_wgrad_igemm", C.byref(d))
     plan.add("nirgan_wino6_output", C.byref(dgrad))
-    add_w("nirgan_wino6_wgrad_finish", slabs.data_ptr(), nsplit, cout, cin, grad.data_ptr(), 1 if accumulate else 0)
+    add_w("nirgan_wino6_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, r, grad.data_ptr(), 1 if accumulate else 0)
     return d
 
 
@@ -799,7 +808,7 @@ class ConvIN:
             if wino6_applicable(ctx, k, self.cout):
                 self.wino6 = True
                 self.wino_fwd = emit_wino6(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
-                                           cout=self.cout, own_V=keep, x_norm=xn)
+                                           cout=self.cout, own_V=keep, x_norm=xn, r=k)
             else:
                 self.wino_fwd = emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
                                           cout=self.cout, own_V=keep, r=k, x_norm=xn)
@@ -851,7 +860,7 @@ class ConvIN:
         w6_bwd = (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
                   and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C) and wino6_applicable(ctx, k, inp.C)
                   and inp.pad == 1 and p == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1")
-        fuse_dy = w6_bwd and self.norm and dy.t16 is None and os.environ.get("NIRGAN_WINO6_DYNORM") == "1"
+        fuse_dy = w6_bwd and k == 3 and self.norm and dy.t16 is None and os.environ.get("NIRGAN_WINO6_DYNORM") == "1"
         nd = emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, a=(mask if mask is not None else self.out), act=act,
                          y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
                          dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
@@ -863,10 +872,10 @@ class ConvIN:
             if w6_bwd:
                 # F(4x4,3x3): data gradient and transform-domain weight gradient, dY read once for both of its transforms
                 wd6 = emit_wino6(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
-                                 cin=self.cout, cout=inp.C, flip=True)
+                                 cin=self.cout, cout=inp.C, flip=True, r=k)
                 keepV = getattr(self, "wino_fwd_keeps_V", False) and getattr(self, "wino6", False)
                 emit_wino6_backward(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
-                                    dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None), norm_desc=(nd if fuse_dy else None))
+                                    dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None), norm_desc=(nd if fuse_dy else None), r=k)
                 return
             # exact-fp32 mode, 3x3: the data gradient is a Winograd convolution of dY (zero halo 2) with the flipped filter over the
             # padded input extent; the weight gradient keeps the direct tile (stand-alone launch)
@@ -916,7 +925,7 @@ class ConvIN:
                 # frozen parameters (the discriminator inside the generator step): the data gradient alone, as a Winograd convolution
                 if wino6_applicable(ctx, k, inp.C):
                     emit_wino6(plan, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
-                               cin=self.cout, cout=inp.C, flip=True)
+                               cin=self.cout, cout=inp.C, flip=True, r=k)
                     return
                 emit_wino(plan, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
                           cin=self.cout, cout=inp.C, flip=True, r=k)

@@ -136,7 +136,7 @@ class WinoDyDesc(C.Structure):
 
 class Wino6Desc(C.Structure):
     _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
-                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp)]
+                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32)]
 
 
 class PlanEntry(C.Structure):
@@ -172,6 +172,7 @@ PROTOTYPES = {
     "nirgan_wino_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_wino6_tiles": (i64, [i32, i32, i32]),
     "nirgan_wino6_weights": (i32, [fp, i32, i32, i32, fp, fp]),
+    "nirgan_wino6_weights_r": (i32, [fp, i32, i32, i32, i32, fp, fp]),
     "nirgan_wino6_weights_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_wino6_input": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_input_norm": (i32, [C.POINTER(Wino6Desc), fp, fp, fp, i32, f32, fp]),
@@ -183,6 +184,7 @@ PROTOTYPES = {
     "nirgan_wino6_input_dy": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), fp]),
     "nirgan_wino6_input_dy_norm": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), C.POINTER(InBwdDesc), fp]),
     "nirgan_wino6_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
+    "nirgan_wino6_wgrad_finish_r": (i32, [fp, i32, i32, i32, i32, fp, i32, fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),
     "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),
     "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),

@@ -466,58 +466,85 @@ class EmuBackend:
             o[:] = g.astype(np.float32)
         return 0
 
-    # ------------------------------------------------------------------ Winograd F(4x4, 3x3) (csrc/wino6.hip)
-    _G6 = np.array([[1 / 2, 0, 0], [1 / 6, 1 / 6, 1 / 6], [1 / 6, -1 / 6, 1 / 6], [1 / 30, 1 / 15, 2 / 15], [16 / 15, -8 / 15, 4 / 15], [0, 0, 1 / 2]])
-    _BT6 = np.array([[2, 3, -4, -3, 2, 0], [0, 2, 5, 1, -2, 0], [0, 2, 1, -5, 2, 0], [0, -1, -2, 1, 2, 0], [0, -2, 1, 2, -1, 0], [0, 2, 3, -4, -3, 2]], dtype=np.float64)
-    _AT6 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -1 / 2, 0], [0, 1, 1, 4, 1 / 4, 0], [0, 1, -1, 8, -1 / 8, 1]], dtype=np.float64)
+    # ------------------------------------------------------------------ Winograd F(4x4, 3x3) / F(4x4, 4x4) (csrc/wino6.hip)
+    _W6 = {
+        3: (np.array([[1 / 2, 0, 0], [1 / 6, 1 / 6, 1 / 6], [1 / 6, -1 / 6, 1 / 6], [1 / 30, 1 / 15, 2 / 15], [16 / 15, -8 / 15, 4 / 15], [0, 0, 1 / 2]]),
+            np.array([[2, 3, -4, -3, 2, 0], [0, 2, 5, 1, -2, 0], [0, 2, 1, -5, 2, 0], [0, -1, -2, 1, 2, 0], [0, -2, 1, 2, -1, 0], [0, 2, 3, -4, -3, 2]], dtype=np.float64),
+            np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -1 / 2, 0], [0, 1, 1, 4, 1 / 4, 0], [0, 1, -1, 8, -1 / 8, 1]], dtype=np.float64)),
+        # Cook-Toom over 0, 1, -1, 2, -2, 1/2, inf (csrc/wino6.hip w7_G / w7_BT / w7_AT)
+        4: (np.array([[1 / 4, 0, 0, 0], [1 / 6, 1 / 6, 1 / 6, 1 / 6], [1 / 18, -1 / 18, 1 / 18, -1 / 18], [1 / 72, 1 / 36, 1 / 18, 1 / 9],
+                      [1 / 120, -1 / 60, 1 / 30, -1 / 15], [32 / 45, 16 / 45, 8 / 45, 4 / 45], [0, 0, 0, 1 / 2]]),
+            np.array([[4, -8, -5, 10, 1, -2, 0], [0, -4, 4, 9, -1, -2, 0], [0, -4, 12, -7, -3, 2, 0], [0, 2, -3, -4, 3, 2, 0],
+                      [0, 2, -5, 0, 5, -2, 0], [0, 4, 0, -5, 0, 1, 0], [0, -4, 8, 5, -10, -1, 2]], dtype=np.float64),
+            np.array([[1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 1 / 2, 0], [0, 1, 1, 4, 4, 1 / 4, 0], [0, 1, -1, 8, -8, 1 / 8, 1]], dtype=np.float64)),
+    }
+
+    @staticmethod
+    def _r6(r):
+        return 3 if r == 0 else r
 
     def nirgan_wino6_tiles(self, B, H, W):
         return B * ((H + 3) // 4) * ((W + 3) // 4) if min(B, H, W) > 0 else 0
 
     def nirgan_wino6_weights(self, w, K, Cc, flip, U, stream=None):
+        return self.nirgan_wino6_weights_r(w, K, Cc, 3, flip, U)
+
+    def nirgan_wino6_weights_r(self, w, K, Cc, r, flip, U, stream=None):
         self.calls.append("wino6_w")
+        r = self._r6(r)
+        if r not in self._W6:
+            return self._fail("wino6_weights: filter size")
+        Gm = self._W6[r][0]
+        n = r + 3
         if flip:
-            g = arr(w, K * Cc * 9).reshape(Cc, K, 3, 3).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
+            g = arr(w, K * Cc * r * r).reshape(Cc, K, r, r).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
         else:
-            g = arr(w, K * Cc * 9).reshape(K, Cc, 3, 3).astype(np.float64)
-        u = np.einsum("ai,kcij,bj->abkc", self._G6, g, self._G6)
-        arr(U, 36 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
+            g = arr(w, K * Cc * r * r).reshape(K, Cc, r, r).astype(np.float64)
+        u = np.einsum("ai,kcij,bj->abkc", Gm, g, Gm)
+        arr(U, n * n * K * Cc)[:] = u.reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino6_weights_batch(self, jobs, njobs, total_blocks, stream=None):
         J = np.ctypeslib.as_array((C.c_int64 * (njobs * 8)).from_address(int(jobs))).reshape(njobs, 8)
         blocks = 0
-        for w, U, K, Cc, flip, first, _, _ in J:
+        for w, U, K, Cc, flip, first, r, _ in J:
             if first != blocks:
                 return self._fail("wino6_weights_batch: first_block mismatch")
-            self.nirgan_wino6_weights(int(w), int(K), int(Cc), int(flip), int(U))
+            rc = self.nirgan_wino6_weights_r(int(w), int(K), int(Cc), int(r), int(flip), int(U))
+            if rc:
+                return rc
             blocks += (int(K) * int(Cc) + 255) // 256
         return 0 if blocks == total_blocks else self._fail("wino6_weights_batch: total_blocks mismatch")
 
-    def _wino6_V(self, x, B, H, W, Cc):
-        """x: [B][H+2][W+2][C] float64 -> V [6][6][B][TH][TW][C]"""
+    def _wino6_V(self, x, B, H, W, Cc, r=3):
+        """x: [B][H+r-1][W+r-1][C] float64 -> V [n][n][B][TH][TW][C], n = r + 3"""
+        n = r + 3
         TH, TW = (H + 3) // 4, (W + 3) // 4
-        xp = np.zeros((B, 4 * TH + 2, 4 * TW + 2, Cc))
-        xp[:, :H + 2, :W + 2] = x
-        tiles = np.stack([np.stack([xp[:, i:i + 4 * TH:4, j:j + 4 * TW:4] for j in range(6)], 0) for i in range(6)], 0)
-        return np.einsum("ai,ijbyxc,lj->albyxc", self._BT6, tiles, self._BT6)
+        xp = np.zeros((B, 4 * TH + r - 1, 4 * TW + r - 1, Cc))
+        xp[:, :H + r - 1, :W + r - 1] = x
+        tiles = np.stack([np.stack([xp[:, i:i + 4 * TH:4, j:j + 4 * TW:4] for j in range(n)], 0) for i in range(n)], 0)
+        BT = self._W6[r][1]
+        return np.einsum("ai,ijbyxc,lj->albyxc", BT, tiles, BT)
 
     def nirgan_wino6_input(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("wino6_in")
-        if d.x_hp != d.H + 2 or d.x_wp != d.W + 2 or d.C % 4:
+        r = self._r6(d.r)
+        if r not in self._W6 or d.x_hp != d.H + r - 1 or d.x_wp != d.W + r - 1 or d.C % 4:
             return self._fail("wino6_input: bad geometry")
         B, H, W, Cc = d.B, d.H, d.W, d.C
-        if d.V_elems < 36 * self.nirgan_wino6_tiles(B, H, W) * Cc:
+        if d.V_elems < (r + 3) ** 2 * self.nirgan_wino6_tiles(B, H, W) * Cc:
             return self._fail("wino6_input: V workspace too small")
         x = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
-        V = self._wino6_V(x, B, H, W, Cc)
+        V = self._wino6_V(x, B, H, W, Cc, r)
         arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino6_input_norm(self, ref, y, mean, rstd, act, slope, stream=None):
         d = obj(ref)
         self.calls.append("wino6_in_norm")
+        if self._r6(d.r) != 3:
+            return self._fail("wino6_input_norm: 3x3 filters only")
         B, H, W, Cc = d.B, d.H, d.W, d.C
         yv = arr(y, B * H * W * Cc).reshape(B, H, W, Cc)
         m, r = arr(mean, B * Cc).reshape(B, 1, 1, Cc), arr(rstd, B * Cc).reshape(B, 1, 1, Cc)
@@ -531,11 +558,12 @@ class EmuBackend:
         d = obj(ref)
         self.calls.append("wino6_gemm")
         T = self.nirgan_wino6_tiles(d.B, d.H, d.W)
-        if d.K <= 64 or d.K % 4 or d.C % 4 or d.V_elems < 36 * T * d.C or d.M_elems < 36 * T * d.K:
+        nplanes = (self._r6(d.r) + 3) ** 2
+        if d.K <= 64 or d.K % 4 or d.C % 4 or d.V_elems < nplanes * T * d.C or d.M_elems < nplanes * T * d.K:
             return self._fail("wino6_gemm: bad geometry / workspace")
-        V = arr(d.V, 36 * T * d.C).reshape(36, T, d.C).astype(np.float64)
-        U = arr(d.U, 36 * d.K * d.C).reshape(36, d.K, d.C).astype(np.float64)
-        arr(d.M, 36 * T * d.K)[:] = np.einsum("ftc,fkc->ftk", V, U).reshape(-1).astype(np.float32)
+        V = arr(d.V, nplanes * T * d.C).reshape(nplanes, T, d.C).astype(np.float64)
+        U = arr(d.U, nplanes * d.K * d.C).reshape(nplanes, d.K, d.C).astype(np.float64)
+        arr(d.M, nplanes * T * d.K)[:] = np.einsum("ftc,fkc->ftk", V, U).reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino6_gemm_wgrad_pair(self, cref, wref, stream=None):
@@ -546,9 +574,12 @@ class EmuBackend:
         d = obj(ref)
         self.calls.append("wino6_out")
         B, H, W, K = d.B, d.H, d.W, d.K
+        r = self._r6(d.r)
+        n = r + 3
         TH, TW = (H + 3) // 4, (W + 3) // 4
-        M = arr(d.M, 36 * B * TH * TW * K).reshape(6, 6, B, TH, TW, K).astype(np.float64)
-        Y = np.einsum("pa,albyxk,ql->bypxqk", self._AT6, M, self._AT6).reshape(B, 4 * TH, 4 * TW, K)
+        M = arr(d.M, n * n * B * TH * TW * K).reshape(n, n, B, TH, TW, K).astype(np.float64)
+        AT = self._W6[r][2]
+        Y = np.einsum("pa,albyxk,ql->bypxqk", AT, M, AT).reshape(B, 4 * TH, 4 * TW, K)
         bias = arr(d.bias, K)
         if bias is not None:
             Y = Y + bias
@@ -566,21 +597,24 @@ class EmuBackend:
         d = obj(ref)
         self.calls.append("wino6_dy")
         B, H, W, K = d.B, d.H, d.W, d.K
+        r = self._r6(d.r)
+        n = r + 3
         TH, TW = (H + 3) // 4, (W + 3) // 4
-        if d.Yt_elems < 36 * B * TH * TW * K or d.dy_hp != H + 2 * d.dy_pad:
+        if r not in self._W6 or d.Yt_elems < n * n * B * TH * TW * K or d.dy_hp != H + 2 * d.dy_pad:
             return self._fail("wino6_dy: bad geometry / workspace")
         dy = arr(d.dy, B * d.dy_hp * d.dy_wp * K).reshape(B, d.dy_hp, d.dy_wp, K).astype(np.float64)
         z = np.zeros((B, 4 * TH, 4 * TW, K))
         z[:, :H, :W] = dy[:, d.dy_pad:d.dy_pad + H, d.dy_pad:d.dy_pad + W]
         tiles = np.stack([np.stack([z[:, i::4, j::4] for j in range(4)], 0) for i in range(4)], 0)       # [4][4][B][TH][TW][K]
-        A = self._AT6.T                                                                                   # 6 x 4
+        A = self._W6[r][2].T                                                                              # n x 4
         Yt = np.einsum("ia,abnyxk,jb->ijnyxk", A, tiles, A)
-        arr(d.Yt, 36 * B * TH * TW * K)[:] = Yt.reshape(-1).astype(np.float32)
+        arr(d.Yt, n * n * B * TH * TW * K)[:] = Yt.reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino6_input_dy(self, cref, yref, stream=None):
         c, y = obj(cref), obj(yref)
-        if c.x != y.dy or y.dy_pad != 2 or c.H != y.H + 2 or c.W != y.W + 2 or c.C != y.K:
+        r = self._r6(c.r)
+        if c.x != y.dy or y.dy_pad != r - 1 or c.H != y.H + r - 1 or c.W != y.W + r - 1 or c.C != y.K or self._r6(y.r) != r:
             return self._fail("wino6_input_dy: the two descriptors do not describe the same output-gradient buffer")
         rc = self.nirgan_wino6_input(cref)
         return rc if rc else self.nirgan_wino6_dy(yref)
@@ -590,7 +624,7 @@ class EmuBackend:
         transforms.  The emulator materialises dY in the buffer the descriptors describe (the device never touches it)."""
         c, y, n = obj(cref), obj(yref), obj(nref)
         self.calls.append("wino6_dy_norm")
-        if n.dy or not n.norm or n.B != c.B or n.C != c.C or n.H != y.H or n.W != y.W:
+        if n.dy or not n.norm or n.B != c.B or n.C != c.C or n.H != y.H or n.W != y.W or self._r6(c.r) != 3:
             return self._fail("wino6_input_dy_norm: bad instance-norm descriptor")
         full = type(n)()
         C.memmove(C.byref(full), C.byref(n), C.sizeof(n))
@@ -599,10 +633,16 @@ class EmuBackend:
         return rc if rc else self.nirgan_wino6_input_dy(cref, yref)
 
     def nirgan_wino6_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
+        return self.nirgan_wino6_wgrad_finish_r(slabs, nsplit, K, Cc, 3, grad, accumulate)
+
+    def nirgan_wino6_wgrad_finish_r(self, slabs, nsplit, K, Cc, r, grad, accumulate, stream=None):
         self.calls.append("wino6_fin")
-        u = arr(slabs, 36 * nsplit * K * Cc).reshape(6, 6, nsplit, K, Cc).astype(np.float64).sum(2)
-        g = np.einsum("ai,abkc,bj->kcij", self._G6, u, self._G6)
-        o = arr(grad, K * Cc * 9).reshape(K, Cc, 3, 3)
+        r = self._r6(r)
+        n = r + 3
+        u = arr(slabs, n * n * nsplit * K * Cc).reshape(n, n, nsplit, K, Cc).astype(np.float64).sum(2)
+        Gm = self._W6[r][0]
+        g = np.einsum("ai,abkc,bj->kcij", Gm, u, Gm)
+        o = arr(grad, K * Cc * r * r).reshape(K, Cc, r, r)
         if accumulate:
             o += g.astype(np.float32)
         else:

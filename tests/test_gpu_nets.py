@@ -124,8 +124,8 @@ def test_golden_small_nets_fused_step(golden_dir, name):
 def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     """ngf = ndf = 32 on 64x64 tiles: every Winograd variant at small tile counts in one fused step against the oracle -- residual blocks
     (128 channels at 16x16: the instance-norm apply folded into the second convolution's input transform, fused dY transforms,
-    transform-domain weight gradient; F(4x4,3x3) by default, F(2x2,3x3) with its frequency-split GEMMs under NIRGAN_NO_WINO6=1) and the
-    PatchGAN's 4x4 layer (128 -> 256 channels at 8x8 -> 7x7: odd extent)."""
+    transform-domain weight gradient) and the PatchGAN's 4x4 layer (128 -> 256 channels at 8x8 -> 7x7: odd extent): F(4x4,3x3) / F(4x4,4x4) by
+    default, F(2x2,3x3) / F(2x2,4x4) with their frequency-split GEMMs under NIRGAN_NO_WINO6=1."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
     if variant == "F(2x2,3x3)":
@@ -140,11 +140,16 @@ def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=6, lr=0.0)
     out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
     names = [n for pl in (tr.G.fwd, tr.G.bwd, tr.D2.fwd, tr.D2.bwd, tr.D1.bwd_pred) for n, _ in pl.ops]
-    want6 = ("nirgan_wino6_input_norm", "nirgan_wino6_input_dy", "nirgan_wino6_gemm", "nirgan_wino6_output", "nirgan_wino6_wgrad_finish")
-    for want in ("nirgan_wino_input_dy", "nirgan_wino_wgrad_pair", "nirgan_wino_wgrad_finish_r", "nirgan_wino_gemm") + (
-            want6 if variant == "F(4x4,3x3)" else ("nirgan_wino_input_norm",)):
-        assert want in names, want
-    assert variant == "F(4x4,3x3)" or not any(n.startswith("nirgan_wino6") for n in names)
+    if variant == "F(4x4,3x3)":      # residual blocks as F(4x4,3x3) AND the PatchGAN's 4x4 layer as F(4x4,4x4): no F(2x2) launch left
+        for want in ("nirgan_wino6_input_norm", "nirgan_wino6_input_dy", "nirgan_wino6_gemm", "nirgan_wino6_gemm_wgrad_pair", "nirgan_wino6_output",
+                     "nirgan_wino6_wgrad_finish_r"):
+            assert want in names, want
+        assert not any(n in ("nirgan_wino_gemm", "nirgan_wino_wgrad_pair", "nirgan_wino_input") for n in names)
+        assert sum(1 for pl in (tr.D2.fwd, tr.D2.bwd, tr.D1.fwd, tr.D1.bwd_pred) for n, a in pl.ops if n.startswith("nirgan_wino6_gemm")) == 4
+    else:
+        for want in ("nirgan_wino_input_dy", "nirgan_wino_wgrad_pair", "nirgan_wino_wgrad_finish_r", "nirgan_wino_gemm", "nirgan_wino_input_norm"):
+            assert want in names, want
+        assert not any(n.startswith("nirgan_wino6") for n in names)
     ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
     o = ref.step(rgb, nir)
     close(tr.G.pred, ref.last["pred"], 1e-3, "pred")

@@ -674,11 +674,15 @@ def test_winograd_4x4_restatement_matches_conv2d(emu):
     assert emu.nirgan_wino_conv3x3(d) != 0
 
 
-def test_discriminator_winograd_layer_through_the_trainer(emu):
-    """ndf = 32 makes the PatchGAN's stride-1 4x4 layer 128 -> 256 channels, wide enough for the Winograd path (forward, fused
-    data/weight gradient in the D step, data gradient alone in the G step): one fused step against the oracle's trainer."""
+@pytest.mark.parametrize("variant", ["F(4x4,4x4)", "F(2x2,4x4)"])
+def test_discriminator_winograd_layer_through_the_trainer(emu, monkeypatch, variant):
+    """ndf = 32 makes the PatchGAN's stride-1 4x4 layer 128 -> 256 channels, wide enough for the Winograd paths (forward, data + weight
+    gradient in the D step, data gradient alone in the G step): one fused step against the oracle's trainer, with the default
+    F(4x4,4x4) (49 plane GEMMs, csrc/wino6.hip) and with F(2x2,4x4) (NIRGAN_NO_WINO7=1)."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
+    if variant == "F(2x2,4x4)":
+        monkeypatch.setenv("NIRGAN_NO_WINO7", "1")
     torch.manual_seed(11)     # (seed 3 puts a ReLU pre-activation of the last block at 2e-7: the mask flips between two valid fp32 evaluations)
     netG = networks.define_G(3, 1, 8, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 32, "basic", 3, "instance", "normal", 0.02)
@@ -687,7 +691,10 @@ def test_discriminator_winograd_layer_through_the_trainer(emu):
     rgb, nir = torch.rand(2, 3, 32, 32), torch.rand(2, 1, 32, 32)
     tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0)      # lr 0: the generator step sees the same D as the oracle's (no Adam sign noise)
     out = tr.step(rgb, nir).as_dict()
-    assert emu.calls.count("wino") >= 4 and "wino_dy" in emu.calls and "wino_fin" in emu.calls, "the Winograd path did not run"
+    if variant == "F(2x2,4x4)":
+        assert emu.calls.count("wino") >= 4 and "wino_dy" in emu.calls and "wino_fin" in emu.calls, "the Winograd path did not run"
+    else:       # D2 forward + its data gradient, D1 forward + its data gradient: 4 GEMM launches; one weight gradient (D step)
+        assert emu.calls.count("wino6_gemm") == 4 and emu.calls.count("wino6_fin") == 1 and emu.calls.count("wino6_dy") == 1 and "wino" not in emu.calls
     ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
     o = ref.step(rgb, nir)
     close(out["loss_D"], o["loss_D"], 1e-5, "loss_D")
