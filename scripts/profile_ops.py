@@ -57,12 +57,12 @@ def describe(name, args):
     if name == "nirgan_wino6_gemm_wgrad_pair":
         d, w = args[0]._obj, args[1]._obj
         T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
-        fl = 2.0 * 36 * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
-        return f"wino6 pair: dgrad gemm 36 x [T={T} x {d.C}] x [{d.K}] + wgrad 36 planes M={w.OW} split={w.nsplit} (executed flops)", fl
+        fl = 2.0 * (max(d.r, 3) + 3) ** 2 * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
+        return f"wino6 pair: dgrad gemm {(max(d.r, 3) + 3) ** 2} x [T={T} x {d.C}] x [{d.K}] + wgrad {w.nplanes} planes M={w.OW} split={w.nsplit} (executed flops)", fl
     if name == "nirgan_wino6_gemm":
         d = args[0]._obj
         T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
-        return f"wino6 gemm 36 x [T={T} x C={d.C}] x [K={d.K}] blk={36 * -(-T // 128) * -(-d.K // 128)} (executed flops)", 2.0 * 36 * T * d.C * d.K
+        return f"wino6 gemm {(max(d.r, 3) + 3) ** 2} x [T={T} x C={d.C}] x [K={d.K}] blk={(max(d.r, 3) + 3) ** 2 * -(-T // 128) * -(-d.K // 128)} (executed flops)", 2.0 * (max(d.r, 3) + 3) ** 2 * T * d.C * d.K
     if name in ("nirgan_wino6_input", "nirgan_wino6_input_norm", "nirgan_wino6_output", "nirgan_wino6_input_dy"):
         d = args[0]._obj
         return f"{name[7:]} B={d.B} {d.H}x{d.W} C={d.C} K={d.K}", 0.0
