@@ -250,6 +250,39 @@ typedef struct {
 int nirgan_tap_scatter(const nirgan_tap_scatter_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The generator's last layer as direct kernels: Conv2d(64, 1, 7) + bias + tanh (+ crop) over the
+ * reflect-padded halo'd NHWC input, and its backward (model/networks.py:366-368 -- ReflectionPad2d(3),
+ * Conv2d(ngf, output_nc, kernel_size=7, padding=0), Tanh; the crop is model/pix2pix.py:101-110).
+ * A wave's 64 lanes are the 64 input channels; C must be 64 and k 7 (other widths keep the
+ * tap-plane route above).  Same results as nirgan_conv_igemm + nirgan_tap_gather /
+ * nirgan_tap_scatter + nirgan_wgrad_igemm + nirgan_conv_igemm up to fp32 summation order.
+ *   forward : out[b][y][x] = act(bias + sum_{ka,kb,c} x[b][y+crop+ka][x+crop+kb][c] * w[ka*7+kb][c])
+ *   dz      : zero-bordered image of dout * act'(out) (workspace shared by the two gradients);
+ *             gbias (optional) accumulates sum dz
+ *   dgrad   : gx over the whole halo'd grid [B][x_hp][x_wp][64]
+ *   wgrad   : gw[c*49 + t] (the Conv2d weight's own [1][64][7][7] layout), overwritten; fixed
+ *             summation order (bitwise reproducible)
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+    const float* x; int x_hp, x_wp;       /* [B][x_hp][x_wp][C], x_hp = OH + k - 1 */
+    int B, OH, OW, crop, C, k;
+    const float* w;                       /* [k*k][C] tap-major (the tap-plane forward pack) */
+    const float* bias; int act;
+    float* out;                           /* [B][OH-2crop][OW-2crop] */
+    const float* dout;                    /* gradient wrt out */
+    float* dz; int64_t dz_elems;          /* >= nirgan_endconv_dz_elems(B, OH, OW) floats, 16-byte aligned */
+    float* gx;
+    float* gw; float* gbias;
+    float* ws; int64_t ws_elems;          /* >= nirgan_endconv_ws_elems(B, OH, OW) floats */
+} nirgan_endconv_desc;
+int64_t nirgan_endconv_dz_elems(int B, int OH, int OW);
+int64_t nirgan_endconv_ws_elems(int B, int OH, int OW);
+int nirgan_endconv_fwd(const nirgan_endconv_desc* d, void* stream);
+int nirgan_endconv_dz(const nirgan_endconv_desc* d, void* stream);
+int nirgan_endconv_dgrad(const nirgan_endconv_desc* d, void* stream);
+int nirgan_endconv_wgrad(const nirgan_endconv_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Losses (forward value + gradient in one pass).
  * ------------------------------------------------------------------------------------- */
 /* LSGAN: loss_out[0] += weight * mean((pred - target)^2); grad = weight * 2 (pred-target)/n.

@@ -959,8 +959,10 @@ class ConvIN:
 
 
 class TapPlaneConv:
-    """Conv2d(C, 1, k, padding=p) (+bias, +tanh, +crop) as a 1x1 product into k*k tap planes
-    followed by a shifted gather-sum (model/networks.py:367-368 and :579)."""
+    """Conv2d(C, 1, k, padding=p) (+bias, +tanh, +crop) (model/networks.py:367-368 and :579).
+
+    Conv2d(64, 1, 7), the generator's last layer, runs as direct kernels with the 64 channels on the 64 lanes of a wave
+    (csrc/endconv.hip); other widths as a 1x1 product into k*k tap planes followed by a shifted gather-sum."""
 
     def __init__(self, eng, name, inp: Halo, weight, bias, *, k, p, act=L.ACT_NONE, crop=0):
         self.eng, self.name, self.inp, self.weight, self.bias = eng, name, inp, weight, bias
@@ -970,13 +972,27 @@ class TapPlaneConv:
         self.nt = k * k
         self.qcs = -(-self.nt // 4) * 4
         self.OH, self.OW = inp.hp - k + 1, inp.wp - k + 1
-        self.q = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
+        self.direct = (inp.C == 64 and k == 7 and ctx.precision != 1 and os.environ.get("NIRGAN_NO_ENDCONV") != "1")
+        if not self.direct:
+            self.q = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
         self.whole_in = Halo(ctx, inp.B, inp.hp, inp.wp, inp.C, 0, tensor=inp.t)     # same memory, halo as image
         self.dst = ctx.zeros(inp.B, 1, self.OH - 2 * crop, self.OW - 2 * crop)
+
+    def _direct_desc(self, w):
+        inp = self.inp
+        d = L.EndConvDesc()
+        d.x, d.x_hp, d.x_wp = inp.ptr, inp.hp, inp.wp
+        d.B, d.OH, d.OW, d.crop, d.C, d.k = inp.B, self.OH, self.OW, self.crop, inp.C, self.k
+        d.w, d.bias, d.act, d.out = w.data_ptr(), _ptr(self.bias), self.act, self.dst.data_ptr()
+        self.eng.ctx.keep.append(d)
+        return d
 
     def emit_fwd(self, plan: Plan, pack: Plan):
         eng, ctx = self.eng, self.eng.ctx
         w = eng.weights.packed(pack, self.weight, G.tapplane_fwd_pack(self.inp.C, self.k), rows_alloc=self.qcs)
+        if self.direct:
+            plan.add("nirgan_endconv_fwd", C.byref(self._direct_desc(w)))
+            return
         emit_conv(plan, ctx, self.whole_in, G.Taps([0], [0], self.inp.C), w, None, self.q, N=self.qcs,
                   OH=self.inp.hp, OW=self.inp.wp)
         d = L.TapGatherDesc()
@@ -990,13 +1006,29 @@ class TapPlaneConv:
 
     def alloc_bwd(self):
         ctx, inp = self.eng.ctx, self.inp
-        self.dq = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
+        if self.direct:
+            be = L.backend()
+            self.dz = ctx.zeros(be.nirgan_endconv_dz_elems(inp.B, self.OH, self.OW))
+            self.ws = ctx.zeros(be.nirgan_endconv_ws_elems(inp.B, self.OH, self.OW))
+        else:
+            self.dq = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
         self.gin = Halo(ctx, inp.B, inp.H, inp.W, inp.C, inp.pad)     # gradient wrt the halo'd input
         self.gin_whole = Halo(ctx, inp.B, inp.hp, inp.wp, inp.C, 0, tensor=self.gin.t)
         self.dout = ctx.zeros(inp.B, 1, self.OH - 2 * self.crop, self.OW - 2 * self.crop)
 
     def emit_bwd(self, plan: Plan, pack: Plan, gw: Optional[torch.Tensor], gb: Optional[torch.Tensor]):
         eng, ctx, inp = self.eng, self.eng.ctx, self.inp
+        if self.direct:
+            w = eng.weights.packed(pack, self.weight, G.tapplane_fwd_pack(inp.C, self.k), rows_alloc=self.qcs)
+            d = self._direct_desc(w)
+            d.dout, d.dz, d.dz_elems = self.dout.data_ptr(), self.dz.data_ptr(), self.dz.numel()
+            d.gx, d.gw, d.gbias = self.gin.ptr, _ptr(gw), _ptr(gb)
+            d.ws, d.ws_elems = self.ws.data_ptr(), self.ws.numel()
+            plan.add("nirgan_endconv_dz", C.byref(d))
+            if gw is not None:
+                plan.add("nirgan_endconv_wgrad", C.byref(d))
+            plan.add("nirgan_endconv_dgrad", C.byref(d))
+            return
         d = L.TapScatterDesc()
         d.dout, d.out, d.act = self.dout.data_ptr(), self.dst.data_ptr(), self.act
         d.B, d.OH, d.OW, d.crop, d.ntaps = inp.B, self.OH, self.OW, self.crop, self.nt

@@ -139,6 +139,12 @@ class Wino6Desc(C.Structure):
                 ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32)]
 
 
+class EndConvDesc(C.Structure):
+    _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("OH", i32), ("OW", i32), ("crop", i32), ("C", i32), ("k", i32),
+                ("w", fp), ("bias", fp), ("act", i32), ("out", fp), ("dout", fp), ("dz", fp), ("dz_elems", i64), ("gx", fp),
+                ("gw", fp), ("gbias", fp), ("ws", fp), ("ws_elems", i64)]
+
+
 class PlanEntry(C.Structure):
     _fields_ = [("op", i32), ("desc", fp)]
 
@@ -200,6 +206,12 @@ PROTOTYPES = {
     "nirgan_conv_channel_dgrad": (i32, [C.POINTER(ChanDgradDesc), fp]),
     "nirgan_tap_gather": (i32, [C.POINTER(TapGatherDesc), fp]),
     "nirgan_tap_scatter": (i32, [C.POINTER(TapScatterDesc), fp]),
+    "nirgan_endconv_dz_elems": (i64, [i32, i32, i32]),
+    "nirgan_endconv_ws_elems": (i64, [i32, i32, i32]),
+    "nirgan_endconv_fwd": (i32, [C.POINTER(EndConvDesc), fp]),
+    "nirgan_endconv_dz": (i32, [C.POINTER(EndConvDesc), fp]),
+    "nirgan_endconv_dgrad": (i32, [C.POINTER(EndConvDesc), fp]),
+    "nirgan_endconv_wgrad": (i32, [C.POINTER(EndConvDesc), fp]),
     "nirgan_lsgan": (i32, [fp, i64, f32, f32, fp, fp, fp]),
     "nirgan_pix_loss": (i32, [C.POINTER(PixLossDesc), fp]),
     "nirgan_adam": (i32, [fp, fp, fp, fp, i64, f32, f32, f32, f32, i32, fp]),

@@ -933,6 +933,86 @@ class EmuBackend:
             arr(d.dbias, 1)[0] += dz.sum()
         return 0
 
+    # ------------------------------------------------------------------ direct Conv2d(64, 1, 7) (+tanh, crop)
+    def nirgan_endconv_dz_elems(self, B, OH, OW):
+        return B * (OH + 12) * ((OW + 12 + 3) // 4 * 4 + 8) if min(B, OH, OW) > 0 else 0
+
+    def nirgan_endconv_ws_elems(self, B, OH, OW):
+        return min((B * (OH + 6) + 3) // 4, 512) * 49 * 64 if min(B, OH) > 0 else 0
+
+    def _endconv(self, ref, what):
+        d = obj(ref)
+        if d.C != 64 or d.k != 7:
+            return None, self._fail(f"{what}: the direct kernels cover Conv2d(64, 1, 7) only")
+        if d.x_hp != d.OH + 6 or d.x_wp != d.OW + 6 or d.B <= 0 or d.OH <= 2 * d.crop or d.OW <= 2 * d.crop:
+            return None, self._fail(f"{what}: bad shape")
+        self.calls.append(what)
+        return d, 0
+
+    def _endconv_dz_image(self, d):
+        S = (d.x_wp + 6 + 3) // 4 * 4 + 8
+        return arr(d.dz, d.B * (d.x_hp + 6) * S).reshape(d.B, d.x_hp + 6, S)
+
+    def nirgan_endconv_fwd(self, ref, stream=None):
+        d, rc = self._endconv(ref, "endconv_fwd")
+        if d is None:
+            return rc
+        x = arr(d.x, d.B * d.x_hp * d.x_wp * 64).reshape(d.B, d.x_hp, d.x_wp, 64).astype(np.float64)
+        w = arr(d.w, 49 * 64).reshape(7, 7, 64).astype(np.float64)
+        z = np.zeros((d.B, d.OH, d.OW))
+        for a in range(7):
+            for b in range(7):
+                z += x[:, a:a + d.OH, b:b + d.OW, :] @ w[a, b]
+        if d.bias:
+            z += arr(d.bias, 1)[0]
+        if d.act == 3:
+            z = np.tanh(z)
+        c = d.crop
+        arr(d.out, d.B * (d.OH - 2 * c) * (d.OW - 2 * c)).reshape(d.B, d.OH - 2 * c, d.OW - 2 * c)[:] = z[:, c:d.OH - c, c:d.OW - c]
+        return 0
+
+    def nirgan_endconv_dz(self, ref, stream=None):
+        d, rc = self._endconv(ref, "endconv_dz")
+        if d is None:
+            return rc
+        c = d.crop
+        H2, W2 = d.OH - 2 * c, d.OW - 2 * c
+        dz = arr(d.dout, d.B * H2 * W2).reshape(d.B, H2, W2).astype(np.float64)
+        if d.act == 3:
+            dz = dz * (1 - arr(d.out, d.B * H2 * W2).reshape(d.B, H2, W2).astype(np.float64) ** 2)
+        img = self._endconv_dz_image(d)
+        img[:] = 0
+        img[:, 6 + c:6 + c + H2, 6 + c:6 + c + W2] = dz
+        if d.gbias:
+            arr(d.gbias, 1)[0] += dz.sum()
+        return 0
+
+    def nirgan_endconv_dgrad(self, ref, stream=None):
+        d, rc = self._endconv(ref, "endconv_dgrad")
+        if d is None:
+            return rc
+        img = self._endconv_dz_image(d).astype(np.float64)
+        w = arr(d.w, 49 * 64).reshape(7, 7, 64).astype(np.float64)
+        gx = np.zeros((d.B, d.x_hp, d.x_wp, 64))
+        for a in range(7):
+            for b in range(7):
+                gx += img[:, 6 - a:6 - a + d.x_hp, 6 - b:6 - b + d.x_wp, None] * w[a, b]
+        arr(d.gx, gx.size).reshape(gx.shape)[:] = gx
+        return 0
+
+    def nirgan_endconv_wgrad(self, ref, stream=None):
+        d, rc = self._endconv(ref, "endconv_wgrad")
+        if d is None:
+            return rc
+        img = self._endconv_dz_image(d).astype(np.float64)
+        x = arr(d.x, d.B * d.x_hp * d.x_wp * 64).reshape(d.B, d.x_hp, d.x_wp, 64).astype(np.float64)
+        gw = np.zeros((7, 7, 64))
+        for a in range(7):
+            for b in range(7):
+                gw[a, b] = np.einsum("bhw,bhwc->c", img[:, 6 - a:6 - a + d.x_hp, 6 - b:6 - b + d.x_wp], x)
+        arr(d.gw, 49 * 64).reshape(64, 49)[:] = gw.reshape(49, 64).T
+        return 0
+
     # ------------------------------------------------------------------ losses
     def nirgan_lsgan(self, pred, n, target, weight, loss_out, grad, stream=None):
         self.calls.append("lsgan")

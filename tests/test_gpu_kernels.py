@@ -1054,3 +1054,13 @@ def test_wino6_dy_transform_with_the_instance_norm_backward_folded_in(case):
         res.append((V, Yt))
     assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0]), "V differs"
     assert torch.equal(res[0][1], res[1][1]), "Yt differs"
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 10, 1), (1, 70, 67, 0), (16, 256, 256, 0), (2, 276, 276, 10), (3, 5, 130, 2)])
+def test_direct_last_layer_kernels(shape):
+    """Conv2d(64, 1, 7) + bias + tanh + crop and its three gradients as direct kernels (csrc/endconv.hip) against torch's conv2d +
+    autograd in fp64: full configs[1] size, the padding-10 geometry, ragged row / column groups."""
+    from endconv_case import run_endconv
+    B, OH, OW, crop = shape
+    run_endconv(DEV, B, OH, OW, crop)
+    run_endconv(DEV, 1, 8, 8, 0, act=L.ACT_NONE) if B == 2 and OH == 9 else None

@@ -763,3 +763,11 @@ def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant
     for k, v in ref.last["grads_G"].items():
         if v is not None and k not in O.shadowed_bias_keys("G", 6):
             close(gG[k], v, 2e-4, "gG " + k)
+
+
+def test_direct_last_layer_restatement_matches_conv2d(emu):
+    """The numpy emulation of nirgan_endconv_* (what the emulated trainer tests run the last layer on when ngf = 64) against
+    torch's conv2d + autograd."""
+    from endconv_case import run_endconv
+    run_endconv("cpu", 2, 9, 10, 1, tol=1e-6)
+    run_endconv("cpu", 1, 7, 5, 0, tol=1e-6, act=L.ACT_NONE)
