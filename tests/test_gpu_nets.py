@@ -274,20 +274,27 @@ def test_fullsize_discriminator_engine_against_oracle():
     grad_close64(xg.grad, xr.grad, "dD/dx", l2=2e-3)
 
 
-def device_kinks(tr, nir):
-    """Branch decisions (ReLU / LeakyReLU masks, sign of pred - nir) of the fused step the trainer just ran, in the call order of
-    oracle.OracleTrainer.step: G forward, D(fake), D(real), G forward again, D(fake) against the updated D, L1."""
-    def nchw(h):
-        return (h.interior() > 0).permute(0, 3, 1, 2).cpu()
-    G, D2, D1 = tr.G, tr.D2, tr.D1
-    B = G.B
+def nchw(h):
+    return (h.interior() > 0).permute(0, 3, 1, 2).cpu()
+
+
+def generator_kinks(G):
+    """ReLU masks of the generator engine's last forward, in the oracle's call order."""
     g = [nchw(G.L1.out), nchw(G.L2.out), nchw(G.L3.out)]
     for _, c1, _c2 in G.blocks:
         if getattr(c1, "defer_apply", False):        # the activated tensor is never written: z = (y - mean) * rstd > 0  <=>  y > mean
             g.append((c1.y.t > c1.stats[0][:, None, None, :]).permute(0, 3, 1, 2).cpu())
         else:
             g.append(nchw(c1.out))
-    g += [nchw(G.U1.out), nchw(G.U2.out)]
+    return g + [nchw(G.U1.out), nchw(G.U2.out)]
+
+
+def device_kinks(tr, nir):
+    """Branch decisions (ReLU / LeakyReLU masks, sign of pred - nir) of the fused step the trainer just ran, in the call order of
+    oracle.OracleTrainer.step: G forward, D(fake), D(real), G forward again, D(fake) against the updated D, L1."""
+    G, D2, D1 = tr.G, tr.D2, tr.D1
+    B = G.B
+    g = generator_kinks(G)
     d2 = [nchw(c.out) for c in (D2.C1, D2.C2, D2.C3, D2.C4)]
     d1 = [nchw(c.out) for c in (D1.C1, D1.C2, D1.C3, D1.C4)]
     return g + [m[:B] for m in d2] + [m[B:] for m in d2] + g + d1 + [(tr.G.pred.cpu() - nir) > 0]
@@ -642,6 +649,50 @@ def test_fullsize_inject_generator_forward_against_oracle():
     close(pred, ref, 1e-3, "inject forward")
     plain = O.px_forward({**sd, "scale_param": torch.tensor(0.0)}, rgb, 9, 10, emb, {"style": "multiply", "use_scale": True})
     assert (ref - plain).abs().max().item() > 1e-2          # the injection changes the output visibly
+
+
+def test_fullsize_inject_generator_backward_at_512_against_oracle():
+    """configs[3] per-tile geometry, full width: ngf 64, 9 blocks, a 512x512 tile with the YAML's reflect pad 10 (532x532 inside the
+    network, the 128x128 SatCLIP map resized to the 133x133 feature map), forward AND backward through the autograd bridge
+    for a given output gradient against the fp64 oracle: every parameter gradient incl. the 256 -> 16384 fc and scale_param
+    (generator_inject.py:105-135)."""
+    from model.generator_inject import define_G_inject
+    ns = types.SimpleNamespace
+    cfg = ns(base_configs=ns(input_nc=3, output_nc=1, ngf=64, netG="resnet_9blocks", norm="instance", no_dropout=True,
+                             init_type="normal", init_gain=0.02),
+             satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
+                        scaling_param=True, scaling_param_init=0.5))
+    torch.manual_seed(0)
+    net = define_G_inject(cfg)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    rgb, _ = synth(1, 512, 512, 33)
+    emb = torch.randn(1, 256, generator=torch.Generator().manual_seed(34))
+    dout = torch.randn(1, 1, 512, 512, generator=torch.Generator().manual_seed(35))
+    net = net.to(DEV)
+    net.data_pad = 10
+    pred = net(rgb.to(DEV), emb.to(DEV))
+    pred.backward(dout.to(DEV))
+    # the oracle takes the ReLU branches the device took (see test_fullsize_fused_step_against_oracle): both sides evaluate the same
+    # smooth function, so the bounds can be tight -- unforced, the ~1e-4 of activations that sit within fp32 rounding of zero move
+    # every gradient tensor by 4e-3 and the scalar scale_param gradient (a sum with heavy cancellation) by 4e-2
+    eng = net._pool().free[(1, 512, 512, 10, True)][-1]
+    kinks = generator_kinks(eng)
+    p64 = leaf64(sd)
+    with O.forced_kinks(kinks):
+        ref = O.px_forward(p64, rgb.double(), 9, 10, emb.double(), {"style": "multiply", "use_scale": True})
+        ref.backward(dout.double())
+    assert pred.shape == ref.shape == (1, 1, 512, 512)
+    close(pred, ref, 1e-3, "inject 512 pred")
+    shadow = O.shadowed_bias_keys("G", 9)
+    seen, worst = set(), 0.0
+    for k, p in net.named_parameters():
+        if k in shadow or k not in p64 or p64[k].grad is None:
+            continue
+        worst = max(worst, ((p.grad.double().cpu() - p64[k].grad).norm() / p64[k].grad.norm()).item())
+        grad_close64(p.grad, p64[k].grad, "inject gG " + k, l2=2e-3 if k == "scale_param" else 3e-4, mx=3e-3)
+        seen.add(k)
+    assert {"fc.weight", "fc.bias", "scale_param"} <= seen, sorted(seen)[:8]
+    print(f"inject generator at 512 (+10), kinks forced: worst rel-L2 over the gradient tensors {worst:.2e}")
 
 
 def test_size_512_and_128_forward_against_oracle():
