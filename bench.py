@@ -16,8 +16,9 @@ children's status); started under torchrun it is one rank.  WORLD_SIZE must equa
 gradients on the concatenated batch.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel by share of step time
-(round 2: wino6_gemm16_kernel, the 36 plane GEMMs of the Winograd F(4x4,3x3) residual-block
-layers, 24 launches per step; `roofline_other` lists the other MFMA kernels): EXECUTED FLOPs
+(round 2: wino6_pair16p_kernel -- the data-gradient plane GEMMs of a Winograd F(4x4,3x3)
+residual-block layer as persistent workgroups + its 36 transform-domain weight-gradient planes in one
+grid, 12 launches per step; `roofline_other` lists the other MFMA kernels): EXECUTED FLOPs
 of its launches (2*M*N*K from the descriptors) / their duration, bracketed by HIP events on
 the launch stream inside the timed steps.  `cpu_baseline` times the CPU oracle (a port, on a
 bounded sample) on rank 0 at N = 1.
@@ -61,7 +62,9 @@ def mfma_probes(trainer):
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0],
              "wino_gemm_kernel": [0.0, 0], "wino_wgrad_pair_kernel": [0.0, 0],
-             "wino6_gemm16_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0], "wino6_pair_kernel": [0.0, 0]}
+             "wino6_gemm16_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0], "wino6_pair_kernel": [0.0, 0],
+             "wino6_gemm16p_kernel": [0.0, 0], "wino6_pair16p_kernel": [0.0, 0]}
+    persistent = os.environ.get("NIRGAN_WINO6_GEMM_NOPERSIST") is None       # csrc/wino6.hip::w6_persistent_ok: the C = 256 launches
     algo_bytes = {}
     for pl in plans:
         pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}
@@ -75,7 +78,7 @@ def mfma_probes(trainer):
                     pl.probe_idx[i] = k
             elif name == "nirgan_wino6_gemm":
                 d = args[0]._obj
-                k = "wino6_gemm16_kernel"
+                k = "wino6_gemm16p_kernel" if (persistent and d.C == 256) else "wino6_gemm16_kernel"
                 T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
                 kinds[k][0] += 2.0 * (max(d.r, 3) + 3) ** 2 * T * d.C * d.K          # EXECUTED flops: 36 plane GEMMs [T x C] x [C x K] (36/144 of the direct layer's multiplies)
                 algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * (max(d.r, 3) + 3) ** 2 * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once
@@ -83,7 +86,7 @@ def mfma_probes(trainer):
                 pl.probe_idx[i] = k
             elif name == "nirgan_wino6_gemm_wgrad_pair":
                 d, w = args[0]._obj, args[1]._obj
-                k = "wino6_pair_kernel"
+                k = "wino6_pair16p_kernel" if (persistent and d.C == 256) else "wino6_pair_kernel"
                 T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
                 kinds[k][0] += 2.0 * (max(d.r, 3) + 3) ** 2 * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run      # executed: data-gradient plane GEMMs + 36 weight-gradient planes
                 kinds[k][1] += 1

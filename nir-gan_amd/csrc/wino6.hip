@@ -527,6 +527,188 @@ __global__ __launch_bounds__(256, 3) void wino6_gemm16_kernel(const W6G16 p) {
     }
 }
 
+// The same tile as a PERSISTENT workgroup with the epilogue folded into the next tile's K loop.  Measured on the kernel above: a tile
+// of 16 K-steps spends ~3.5 us per wave outside its MFMA stream (first DMA wait + epilogue through LDS), and because equal tiles keep
+// the resident workgroups of a CU in lockstep those phases coincide instead of filling each other (0.64 of peak at C = 256 against
+// 0.82 at C = 1024).  Here a workgroup walks its tiles as ONE stream of K-steps: the DMA of the next tile's first step is issued
+// during this tile's last step, and the finished tile's accumulators (a second set, 64 AGPRs) drain one 8 x 32 piece per K-step of
+// the next tile -- 4 ds_write_b32 into a wave-private 1 KB transpose buffer, one ds_read_b128, one 16-byte-per-lane store -- under
+// that step's 32 MFMAs.  No barrier beyond the one per K-step, no MFMA-free phase except the very first DMA wait.
+constexpr int W6P_LDS = 2 * 16384 + 4 * 2 * 1280;
+
+__device__ __forceinline__ void w6_gemm16p_body(const W6G16& p, const int first, const int stride, char* lds) {
+    constexpr int STAGE = 16384, A_BYTES = 8192;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = p.C >> 4;                         // host guarantees nk >= 16: the drain of a tile takes 16 K-steps of the next
+
+    // ---------------- loader: wave w owns A pieces 2w, 2w+1 and B pieces 2w, 2w+1 (16 rows x 64 B each)
+    const int prow = lane >> 2, lchunk = lane & 3;
+    struct Ld { const float* A; const float* Bw; int a_base[2], b_base[2]; bool b_ok[2]; };
+    auto setup = [&](int logical, Ld& l, int& plane, int& m0, int& n0) {
+        const int rid = ng_xcd_remap(logical, p.total);
+        plane = rid / p.per_plane;
+        const int id = rid - plane * p.per_plane;
+        n0 = (id % p.ntiles) * 128;
+        m0 = (id / p.ntiles) * 128;
+        l.A = p.A + size_t(plane) * p.a_plane;
+        l.Bw = p.Bw + size_t(plane) * p.b_plane;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 16 + prow;
+            const int sc = lchunk ^ ((row >> 2) & 3);
+            int m = m0 + row;
+            m = m < p.T ? m : p.T - 1;
+            l.a_base[i] = m * p.C + sc * 4;
+            const int n = n0 + row;
+            l.b_ok[i] = n < p.K;
+            l.b_base[i] = (l.b_ok[i] ? n : 0) * p.C + sc * 4;
+        }
+    };
+    auto issue = [&](const Ld& l, char* sA, int c0) {
+        char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ng_glds16(l.A + (l.a_base[i] + c0), sA + (wave * 2 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ng_glds16(l.b_ok[i] ? l.Bw + (l.b_base[i] + c0) : p.zero, sB + (wave * 2 + i) * 1024);
+    };
+
+    // ---------------- compute: wave (wr, wc) = rows wr*64 .. +63, columns wc*64 .. +63
+    const int wr = wave >> 1, wc = wave & 1, half = lane >> 5;
+    int a_off[2], a_key[2], b_off[2], b_key[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ra = wr * 64 + t * 32 + (lane & 31), rb = wc * 64 + t * 32 + (lane & 31);
+        a_off[t] = ra * 64; a_key[t] = (ra >> 2) & 3;
+        b_off[t] = rb * 64; b_key[t] = (rb >> 2) & 3;
+    }
+    auto compute = [&](const char* sA, f32x16 (&acc)[2][2]) {
+        const char* sB = sA + A_BYTES;
+        f32x4 a[2][2], b[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int chunk = 2 * g + half;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[g][t] = *reinterpret_cast<const f32x4*>(sA + a_off[t] + ((chunk ^ a_key[t]) << 4));
+                b[g][t] = *reinterpret_cast<const f32x4*>(sB + b_off[t] + ((chunk ^ b_key[t]) << 4));
+            }
+        }
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][mt][j], b[g][nt][j], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---------------- drain: piece q = (mt, nt, j) of a finished tile: registers 4j .. 4j+3 of acc[mt][nt] = rows 8j + {0..3} + 4 half of
+    // that 32 x 32 block.  Wave-private transpose buffer [8 rows][40 floats] (the 8-float pad keeps the two half-waves on disjoint banks),
+    // double-buffered by piece parity so that the only ordering needed is the wave's own lgkmcnt.
+    float* tb = reinterpret_cast<float*>(lds + 2 * STAGE) + wave * 640;
+    const int t_wr = ((lane >> 5) * 4) * 40 + (lane & 31);           // + (r & 3) * 40
+    const int t_rd = (lane >> 3) * 40 + (lane & 7) * 4;              // lane -> (row lane/8, 4 columns)
+    auto drain = [&](const f32x16 (&acc)[2][2], int q, int plane, int m0, int n0) {
+        const int mt = q >> 3, nt = (q >> 2) & 1, j = q & 3;
+        float* b = tb + (q & 1) * 320;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[t_wr + r * 40] = acc[mt][nt][4 * j + r];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(b + t_rd);
+        const int rr = lane >> 3;                                     // buffer row = (r & 3) + 4 half  ->  tile row 8j + rr
+        const int m = m0 + wr * 64 + mt * 32 + 8 * j + rr;
+        const int n = n0 + wc * 64 + nt * 32 + (lane & 7) * 4;
+        if (m < p.T && n < p.K) *reinterpret_cast<f32x4*>(p.Out + size_t(plane) * p.o_plane + size_t(m) * p.K + n) = v;
+    };
+
+    f32x16 accA[2][2], accB[2][2];
+    auto zero = [&](f32x16 (&acc)[2][2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    };
+
+    // one tile: nk K-steps into `cur`, draining `prev` (the previous tile, if any) along the first 16 of them; the DMA of the next
+    // tile's first step goes out during the last step.  `stage` = parity of the running step count.
+    int step = 0;
+    Ld lcur, lnext;
+    int plane, m0, n0, pplane = 0, pm0 = 0, pn0 = 0, nplane = 0, nm0 = 0, nn0 = 0;
+    auto one_step = [&](f32x16 (&cur)[2][2], int s, int next_logical) {
+        if (s + 1 < nk) issue(lcur, lds + ((step + 1) & 1) * STAGE, (s + 1) << 4);
+        else if (next_logical < p.total) {
+            setup(next_logical, lnext, nplane, nm0, nn0);
+            issue(lnext, lds + ((step + 1) & 1) * STAGE, 0);
+        }
+        compute(lds + (step & 1) * STAGE, cur);
+        ++step;
+    };
+    auto run_tile = [&](f32x16 (&cur)[2][2], const f32x16 (&prev)[2][2], bool have_prev, int next_logical) {
+        zero(cur);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                       // the piece index is a compile-time constant: register-indexed drain
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (have_prev) drain(prev, s, pplane, pm0, pn0);
+            one_step(cur, s, next_logical);
+        }
+        for (int s = 16; s < nk; ++s) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            one_step(cur, s, next_logical);
+        }
+        pplane = plane; pm0 = m0; pn0 = n0;
+        lcur = lnext; plane = nplane; m0 = nm0; n0 = nn0;
+    };
+    // tiles first, first + stride, ...: a drawn-from-a-counter assignment was tried (tests green) and measured 12 % SLOWER -- tiles in
+    // flight at the same time stop being neighbours, and the XCD-local L2 sharing of V rows and U planes is worth more than the balance
+    if (first >= p.total) return;
+    setup(first, lcur, plane, m0, n0);
+    issue(lcur, lds, 0);
+    int logical = first;
+    bool have_prev = false;
+    while (true) {
+        run_tile(accA, accB, have_prev, logical + stride);
+        logical += stride;
+        have_prev = true;
+        if (logical >= p.total) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) drain(accA, q, pplane, pm0, pn0);
+            break;
+        }
+        run_tile(accB, accA, true, logical + stride);
+        logical += stride;
+        if (logical >= p.total) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) drain(accB, q, pplane, pm0, pn0);
+            break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void wino6_gemm16p_kernel(const W6G16 p) {
+    __shared__ __attribute__((aligned(16))) char lds[W6P_LDS];
+    w6_gemm16p_body(p, blockIdx.x, gridDim.x, lds);
+}
+
+// The weight-gradient tiles of a layer (dispatched first: long blocks, 1.97 rounds of the chip) and the data gradient's plane GEMMs
+// as persistent workgroups behind them in ONE grid: both read what the dY pass just wrote, the GEMM's workgroups start in the slots the
+// weight gradient's last round frees, and M is the last thing written before the output transform reads it (GEMM first: the output
+// transform loses 8 us to the weight gradient's traffic in between).
+__global__ __launch_bounds__(256, 2) void wino6_pair16p_kernel(const W6G16 q, const int gemm_blocks, const ng::WgradParams wp, const int wgrad_blocks) {
+    __shared__ __attribute__((aligned(16))) char lds[65536];
+    static_assert(W6P_LDS <= 65536, "the persistent GEMM's LDS must fit the pair kernel's");
+    const int bid = blockIdx.x;
+    if (bid < wgrad_blocks) ng::wgrad_tile<128, 0>(wp, bid, lds, lds + 32768);
+    else w6_gemm16p_body(q, bid - wgrad_blocks, gemm_blocks, lds);
+}
+
 // ------------------------------------------------------------------------------------------------ output transform
 struct W6Out { const float* M; const float* bias; float* y; int B, H, W, K, TH, TW; long long T; };
 
@@ -763,6 +945,19 @@ static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
     return NIRGAN_OK;
 }
 
+// The persistent tile (wino6_gemm16p_kernel) where it measures faster: C = 256 (16 K-steps per tile: 186 -> 165 us at T = 4096, 211 ->
+// 196 at T = 4624, 251 -> 236 for the PatchGAN's 49 x [2048 x 256] x [512]).  At C = 512 a tile is twice as long and the uneven last
+// round of fixed assignments costs more than the folded epilogue saves (579 vs 536 us for the PatchGAN layer's pair launch).
+static bool w6_persistent_ok(const nirgan_wino6_desc* d) { return d->C == 256; }
+
+static W6G16 w6_g16_params(const nirgan_wino6_desc* d, long long T) {
+    W6G16 q;
+    q.A = d->V; q.Bw = d->U; q.Out = d->M; q.zero = d->zero_page; q.T = int(T); q.C = d->C; q.K = d->K;
+    q.mtiles = int((T + 127) / 128); q.ntiles = (d->K + 127) / 128; q.per_plane = q.mtiles * q.ntiles; q.total = w6_np(w6_r(d->r)) * q.per_plane;
+    q.a_plane = T * d->C; q.b_plane = (long long)d->K * d->C; q.o_plane = T * d->K;
+    return q;
+}
+
 extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const nirgan_wgrad_desc* w, void* stream) {
     W6Gemm g;
     long long T;
@@ -776,6 +971,14 @@ extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const ni
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit * wp.nplanes;
+    static const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;
+    if (w6_persistent_ok(d) && !no_persist) {
+        NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm_wgrad_pair: pointers must be 16-byte aligned");
+        const W6G16 q = w6_g16_params(d, T);
+        const int gemm_blocks = q.total < 512 ? q.total : 512;
+        hipLaunchKernelGGL(wino6_pair16p_kernel, dim3(gemm_blocks + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), q, gemm_blocks, wp, wgrad_blocks);
+        return nirgan_check_launch("wino6_gemm_wgrad_pair");
+    }
     const int wgrad_first = getenv("NIRGAN_WINO6_PAIR_GEMM_FIRST") == nullptr ? 1 : 0;
     hipLaunchKernelGGL(wino6_pair_kernel, dim3(g.total + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, wp, wgrad_blocks, wgrad_first);
     return nirgan_check_launch("wino6_gemm_wgrad_pair");
@@ -789,10 +992,14 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
     if (d->C % 16 == 0 && getenv("NIRGAN_WINO6_GEMM32") == nullptr) {
         // 16-k stages, up to four resident workgroups per CU (see wino6_gemm16_kernel)
         NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm: pointers must be 16-byte aligned");
-        W6G16 q;
-        q.A = d->V; q.Bw = d->U; q.Out = d->M; q.zero = d->zero_page; q.T = int(T); q.C = d->C; q.K = d->K;
-        q.mtiles = int((T + 127) / 128); q.ntiles = (d->K + 127) / 128; q.per_plane = q.mtiles * q.ntiles; q.total = w6_np(w6_r(d->r)) * q.per_plane;
-        q.a_plane = T * d->C; q.b_plane = (long long)d->K * d->C; q.o_plane = T * d->K;
+        const W6G16 q = w6_g16_params(d, T);
+        static const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;
+        if (w6_persistent_ok(d) && !no_persist) {
+            // persistent workgroups, epilogue folded into the next tile's K loop: 2 per CU
+            const int grid = q.total < 512 ? q.total : 512;
+            hipLaunchKernelGGL(wino6_gemm16p_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+            return nirgan_check_launch("wino6_gemm");
+        }
         hipLaunchKernelGGL(wino6_gemm16_kernel, dim3(q.total), dim3(256), 0, static_cast<hipStream_t>(stream), q);
         return nirgan_check_launch("wino6_gemm");
     }
