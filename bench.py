@@ -54,6 +54,17 @@ def synth(B, H, W, seed, device):
     return rgb.to(device), nir.to(device)
 
 
+
+def w6_planes(r):
+    """planes of a wino6 descriptor's variant code: 0 / 3 = F(4x4,3x3): 36, 4 = F(4x4,4x4): 49, 6 = F(6x6,3x3): 64"""
+    return 64 if r == 6 else (max(r, 3) + 3) ** 2
+
+
+def w6_tiles(d):
+    mo = 6 if d.r == 6 else 4
+    return d.B * (-(-d.H // mo)) * (-(-d.W // mo))
+
+
 def mfma_probes(trainer):
     """Algorithmic FLOPs of one step's launches of the two big MFMA kernels, and hooks that bracket them.
 
@@ -79,20 +90,20 @@ def mfma_probes(trainer):
             elif name == "nirgan_wino6_gemm":
                 d = args[0]._obj
                 k = "wino6_gemm16p_kernel" if (persistent and d.C == 256) else "wino6_gemm16_kernel"
-                T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
-                kinds[k][0] += 2.0 * (max(d.r, 3) + 3) ** 2 * T * d.C * d.K          # EXECUTED flops: 36 plane GEMMs [T x C] x [C x K] (36/144 of the direct layer's multiplies)
-                algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * (max(d.r, 3) + 3) ** 2 * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once
+                T = w6_tiles(d)
+                kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K          # EXECUTED flops: 36 plane GEMMs [T x C] x [C x K] (36/144 of the direct layer's multiplies)
+                algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
             elif name == "nirgan_wino6_gemm_wgrad_pair":
                 d, w = args[0]._obj, args[1]._obj
                 k = "wino6_pair16p_kernel" if (persistent and d.C == 256) else "wino6_pair_kernel"
-                T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
-                kinds[k][0] += 2.0 * (max(d.r, 3) + 3) ** 2 * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run      # executed: data-gradient plane GEMMs + 36 weight-gradient planes
+                T = w6_tiles(d)
+                kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run      # executed: data-gradient plane GEMMs + 36 weight-gradient planes
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
                 # V of dY read once, U once, M written once; Yt and the forward's V read once, slabs written once
-                algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * (max(d.r, 3) + 3) ** 2 * (T * d.C + d.K * d.C + T * d.K) + 4.0 * w.nplanes * (w.OW * (w.N + w.run) + w.nsplit * w.N * w.run)
+                algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K) + 4.0 * w.nplanes * (w.OW * (w.N + w.run) + w.nsplit * w.N * w.run)
             elif name == "nirgan_wgrad_igemm":
                 w = args[0]._obj
                 if w.N > 64 and w.precision == 0 and not w.pq_bf16:

@@ -500,10 +500,15 @@ typedef struct {
     const float* zero_page;
     int r;                                /* filter size: 0 or 3 = F(4x4,3x3) above; 4 = F(4x4,4x4): nn.Conv2d(C, K, 4, stride 1) of the PatchGAN
                                              (model/networks.py:573-579): x is [B][H+3][W+3][C] for H x W outputs, 7x7 patches, 49 planes in
-                                             U / V / M / Yt; Cook-Toom over 0, 1, -1, 2, -2, 1/2, inf; fp32 error 1e-5 of the output's maximum */
+                                             U / V / M / Yt; Cook-Toom over 0, 1, -1, 2, -2, 1/2, inf; fp32 error 1e-5 of the output's maximum;
+                                             6 = F(6x6,3x3): 3x3 filters as above with 6x6 outputs per tile, 8x8 patches at stride 6, 64 planes,
+                                             T = B * ceil(H/6) * ceil(W/6) (nirgan_wino6_tiles_r); Cook-Toom over 0, 1, -1, 2, -2, 1/2, -1/2, inf;
+                                             fp32 error 1.7e-5 of the output's maximum.  The same code goes into nirgan_wino_dy_desc.r,
+                                             nirgan_wino6_weights_r and nirgan_wino6_wgrad_finish_r for the layer */
 } nirgan_wino6_desc;
 
-int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T */
+int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T of the 4x4-output variants */
+int64_t nirgan_wino6_tiles_r(int B, int H, int W, int r);          /* T of variant r (0 / 3, 4, 6); 0 for an unknown variant */
 int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);   /* as nirgan_wino_weights */
 int nirgan_wino6_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream);   /* w = [K][C][r][r], U = [(r+3)^2][K][C] */
 /* all weight transforms of a step in one launch: njobs x 8 int64 {w, U, K, C, transpose_flip, first_block, r, 0} in device memory,

@@ -82,6 +82,24 @@ __host__ __device__ constexpr float w7_AT(int i, int j) {
     constexpr float m[4][7] = {{1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0.5f, 0}, {0, 1, 1, 4, 4, 0.25f, 0}, {0, 1, -1, 8, -8, 0.125f, 1}};
     return m[i][j];
 }
+// F(6x6, 3x3): 64 products per 6x6 outputs (1.78 per output; F(4x4,3x3): 2.25, direct: 9).  Cook-Toom over 0, 1, -1, 2, -2, 1/2, -1/2, inf,
+// rows scaled so that B^T is integer; fp32 error of the forward 1.7e-5 of the output's maximum, weight gradient 4e-6
+// (scripts/exp_wino6_points.py) -- the level of F(4x4,4x4) above.
+__host__ __device__ constexpr float w8_BT(int i, int j) {
+    constexpr float m[8][8] = {{4, 0, -21, 0, 21, 0, -4, 0}, {0, -4, -4, 17, 17, -4, -4, 0}, {0, 4, -4, -17, 17, 4, -4, 0}, {0, 2, 1, -10, -5, 8, 4, 0},
+                               {0, -2, 1, 10, -5, -8, 4, 0}, {0, 4, 8, -5, -10, 1, 2, 0}, {0, -4, 8, 5, -10, -1, 2, 0}, {0, -4, 0, 21, 0, -21, 0, 4}};
+    return m[i][j];
+}
+__host__ __device__ constexpr float w8_G(int i, int j) {
+    constexpr float m[8][3] = {{1.f / 4, 0, 0}, {1.f / 18, 1.f / 18, 1.f / 18}, {1.f / 18, -1.f / 18, 1.f / 18}, {1.f / 360, 1.f / 180, 1.f / 90},
+                               {1.f / 360, -1.f / 180, 1.f / 90}, {16.f / 45, 8.f / 45, 4.f / 45}, {16.f / 45, -8.f / 45, 4.f / 45}, {0, 0, 1.f / 4}};
+    return m[i][j];
+}
+__host__ __device__ constexpr float w8_AT(int i, int j) {
+    constexpr float m[6][8] = {{1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 1.f / 2, -1.f / 2, 0}, {0, 1, 1, 4, 4, 1.f / 4, 1.f / 4, 0},
+                               {0, 1, -1, 8, -8, 1.f / 8, -1.f / 8, 0}, {0, 1, 1, 16, 16, 1.f / 16, 1.f / 16, 0}, {0, 1, -1, 32, -32, 1.f / 32, -1.f / 32, 1}};
+    return m[i][j];
+}
 // acc += c * x with the constant folded after unrolling (0: nothing, +-1: add / subtract)
 template <typename T> __device__ __forceinline__ void w6_mac(T& acc, const float c, const T& x) {
     if (c == 0.f) return;
@@ -90,65 +108,69 @@ template <typename T> __device__ __forceinline__ void w6_mac(T& acc, const float
     else acc += c * x;
 }
 
-// R = filter size (3 or 4): N = R + 3 points per dimension, N * N planes, 4x4 outputs per tile, patches of N x N at stride 4
-template <int R> struct W6 {
-    static constexpr int N = R + 3, NP = N * N;
+// V = variant: 3 = F(4x4,3x3), 4 = F(4x4,4x4), 6 = F(6x6,3x3).  R = filter size, MO x MO outputs per tile, N = MO + R - 1 points per
+// dimension, N * N planes, patches of N x N at stride MO.
+template <int V> struct W6 {
+    static constexpr int R = V == 6 ? 3 : V, MO = V == 6 ? 6 : 4, N = MO + R - 1, NP = N * N;
+    static __host__ __device__ constexpr float cBT(int i, int j) { return V == 4 ? w7_BT(i, j) : w8_BT(i, j); }
+    static __host__ __device__ constexpr float cG(int i, int j) { return V == 4 ? w7_G(i, j) : w8_G(i, j); }
+    static __host__ __device__ constexpr float cAT(int i, int j) { return V == 4 ? w7_AT(i, j) : w8_AT(i, j); }
     template <class T> static __device__ __forceinline__ void bt(const T* d, T* t) {                // t = B^T d   (N -> N)
-        if constexpr (R == 3) w6_bt(d, t);
+        if constexpr (V == 3) w6_bt(d, t);
         else {
 #pragma unroll
-            for (int o = 0; o < 7; ++o) {
+            for (int o = 0; o < N; ++o) {
                 T s = d[0] * 0.f;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) w6_mac(s, w7_BT(o, i), d[i]);
+                for (int i = 0; i < N; ++i) w6_mac(s, cBT(o, i), d[i]);
                 t[o] = s;
             }
         }
     }
-    template <class T> static __device__ __forceinline__ void at(const T* m, T* y) {                // y = A^T m   (N -> 4)
-        if constexpr (R == 3) w6_at(m, y);
+    template <class T> static __device__ __forceinline__ void at(const T* m, T* y) {                // y = A^T m   (N -> MO)
+        if constexpr (V == 3) w6_at(m, y);
         else {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < MO; ++o) {
                 T s = m[0] * 0.f;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) w6_mac(s, w7_AT(o, i), m[i]);
+                for (int i = 0; i < N; ++i) w6_mac(s, cAT(o, i), m[i]);
                 y[o] = s;
             }
         }
     }
-    template <class T> static __device__ __forceinline__ void a(const T* e, T* u) {                 // u = A e     (4 -> N)
-        if constexpr (R == 3) w6_a(e, u);
+    template <class T> static __device__ __forceinline__ void a(const T* e, T* u) {                 // u = A e     (MO -> N)
+        if constexpr (V == 3) w6_a(e, u);
         else {
 #pragma unroll
-            for (int o = 0; o < 7; ++o) {
+            for (int o = 0; o < N; ++o) {
                 T s = e[0] * 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w6_mac(s, w7_AT(i, o), e[i]);
+                for (int i = 0; i < MO; ++i) w6_mac(s, cAT(i, o), e[i]);
                 u[o] = s;
             }
         }
     }
     static __device__ __forceinline__ void g(const float* gg, float* w) {                           // w = G g     (R -> N)
-        if constexpr (R == 3) w6_g(gg, w);
+        if constexpr (V == 3) w6_g(gg, w);
         else {
 #pragma unroll
-            for (int o = 0; o < 7; ++o) {
+            for (int o = 0; o < N; ++o) {
                 float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w6_mac(s, w7_G(o, i), gg[i]);
+                for (int i = 0; i < R; ++i) w6_mac(s, cG(o, i), gg[i]);
                 w[o] = s;
             }
         }
     }
     static __device__ __forceinline__ void gt(const float* u, float* gg) {                          // g = G^T u   (N -> R)
-        if constexpr (R == 3) w6_gt(u, gg);
+        if constexpr (V == 3) w6_gt(u, gg);
         else {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
+            for (int o = 0; o < R; ++o) {
                 float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) w6_mac(s, w7_G(i, o), u[i]);
+                for (int i = 0; i < N; ++i) w6_mac(s, cG(i, o), u[i]);
                 gg[o] = s;
             }
         }
@@ -158,9 +180,9 @@ template <int R> struct W6 {
 // ------------------------------------------------------------------------------------------------ weights
 struct W6W { const float* w; float* U; int K, C, flip; };
 
-template <int R>
+template <int V>
 __device__ __forceinline__ void wino6_weight_one(const W6W& p, const long long i) {
-    constexpr int N = W6<R>::N, RR = R * R;
+    constexpr int N = W6<V>::N, R = W6<V>::R, RR = R * R;
     if (i >= (long long)p.K * p.C) return;
     const int k = int(i / p.C), c = int(i - (long long)k * p.C);
     // flip: the data-gradient filter g'[k][c][i][j] = W[c][k][R-1-i][R-1-j] (W stored [C][K][R][R]: rows are the forward OUTPUT channels)
@@ -171,7 +193,7 @@ __device__ __forceinline__ void wino6_weight_one(const W6W& p, const long long i
         float col[R], o[N];
 #pragma unroll
         for (int a = 0; a < R; ++a) col[a] = p.flip ? g[RR - 1 - (a * R + j)] : g[a * R + j];
-        W6<R>::g(col, o);
+        W6<V>::g(col, o);
 #pragma unroll
         for (int a = 0; a < N; ++a) t[a][j] = o[a];
     }
@@ -180,16 +202,16 @@ __device__ __forceinline__ void wino6_weight_one(const W6W& p, const long long i
 #pragma unroll
     for (int a = 0; a < N; ++a) {
         float o[N];
-        W6<R>::g(t[a], o);
+        W6<V>::g(t[a], o);
 #pragma unroll
         for (int b = 0; b < N; ++b) U[(a * N + b) * plane] = o[b];
     }
 }
 
-template <int R>
-__global__ __launch_bounds__(256) void wino6_weight_kernel(const W6W p) { wino6_weight_one<R>(p, blockIdx.x * 256ll + threadIdx.x); }
+template <int V>
+__global__ __launch_bounds__(256) void wino6_weight_kernel(const W6W p) { wino6_weight_one<V>(p, blockIdx.x * 256ll + threadIdx.x); }
 
-// all F(4x4, RxR) weight transforms of a step in one launch: 8 x int64 per job {w, U, K, C, flip, first_block, r, 0}
+// all weight transforms of a step in one launch: 8 x int64 per job {w, U, K, C, flip, first_block, variant, 0}
 __global__ __launch_bounds__(256) void wino6_weights_batch_kernel(const long long* __restrict__ jobs, int njobs) {
     int j = 0;
     for (int i = 1; i < njobs; ++i)
@@ -197,7 +219,9 @@ __global__ __launch_bounds__(256) void wino6_weights_batch_kernel(const long lon
     const long long* J = jobs + j * 8;
     W6W p{reinterpret_cast<const float*>(J[0]), reinterpret_cast<float*>(J[1]), int(J[2]), int(J[3]), int(J[4])};
     const long long i = (long long)(int(blockIdx.x) - int(J[5])) * 256 + threadIdx.x;
-    if (J[6] == 4) wino6_weight_one<4>(p, i); else wino6_weight_one<3>(p, i);
+    if (J[6] == 4) wino6_weight_one<4>(p, i);
+    else if (J[6] == 6) wino6_weight_one<6>(p, i);
+    else wino6_weight_one<3>(p, i);
 }
 
 // ------------------------------------------------------------------------------------------------ input transform
@@ -216,13 +240,15 @@ template <int VW> struct W6Vec;
 template <> struct W6Vec<4> { typedef f32x4 T; };
 template <> struct W6Vec<2> { typedef f32x2 T; };
 
-// One thread = one N x N patch x VW channels (4 for the 6x6 patches of F(4x4,3x3); 2 for the 7x7 patches of F(4x4,4x4): 49 float4
-// intermediates would not fit the register file).  MODE 0: x from the halo'd buffer; 1: forward input normalised on the fly (3x3 only);
-// 2: output gradient from the instance-norm backward on the fly (3x3 only).
-template <int R, int MODE>
+// One thread = one N x N patch x VW channels (4 for the 6x6 patches of F(4x4,3x3); 2 for the 7x7 / 8x8 patches of F(4x4,4x4) /
+// F(6x6,3x3): 49 / 64 float4 intermediates would not fit the register file).  MODE 0: x from the halo'd buffer; 1: forward input
+// normalised on the fly (3x3 filters); 2: output gradient from the instance-norm backward on the fly (3x3 filters).
+template <int V> struct W6VW { static constexpr int value = V == 3 ? 4 : 2; };
+
+template <int V, int MODE>
 __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     constexpr bool NORM = MODE == 1;
-    constexpr int N = W6<R>::N, VW = R == 3 ? 4 : 2;
+    constexpr int N = W6<V>::N, R = W6<V>::R, MO = W6<V>::MO, VW = W6VW<V>::value;
     typedef typename W6Vec<VW>::T V4;
     static_assert(MODE == 0 || R == 3, "the fused variants exist for the 3x3 filter");
     const int q4 = p.C / VW;
@@ -243,6 +269,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     if constexpr (MODE == 2) {
         const InBwd& n = p.nb;
         const float* mm = n.ws + size_t(p.nbB) * n.nchunk * 2 * n.C + size_t(b) * 2 * n.C;
+        static_assert(MODE != 2 || VW == 4, "the instance-norm-backward variant works on channel quads");
         m1 = ld4(mm + q * 4); m2 = ld4(mm + n.C + q * 4);
         mean = ld4(n.mean + size_t(b) * n.C + q * 4);
         rstd = ld4(n.rstd + size_t(b) * n.C + q * 4);
@@ -258,10 +285,10 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     } else {
         base = p.x + size_t(b) * p.x_img + q * VW;
     }
-    // value of the (virtual) halo'd buffer at patch position (a, c); lines past the buffer (extent not a multiple of 4) read zero:
+    // value of the (virtual) halo'd buffer at patch position (a, c); lines past the buffer (extent not a multiple of MO) read zero:
     // they feed only outputs that are never stored
     auto ld = [&](int a, int c) -> V4 {
-        const int rb = 4 * ty + a, cb = 4 * tx + c;
+        const int rb = MO * ty + a, cb = MO * tx + c;
         if (rb >= p.x_hp || cb >= p.x_wp) return z4;
         if constexpr (MODE == 2) {
             const int h = rb - (R - 1), w = cb - (R - 1);      // the dY buffer has a zero halo of R - 1
@@ -288,29 +315,29 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
         V4 d[N], o[N];
 #pragma unroll
         for (int a = 0; a < N; ++a) d[a] = ld(a, c);
-        W6<R>::bt(d, o);
+        W6<V>::bt(d, o);
 #pragma unroll
         for (int a = 0; a < N; ++a) m[a][c] = o[a];
     }
     const size_t plane = size_t(p.T) * p.C;
-    float* V = p.V + size_t(t) * p.C + q * VW;
+    float* Vp = p.V + size_t(t) * p.C + q * VW;
 #pragma unroll
     for (int a = 0; a < N; ++a) {
         V4 o[N];
-        W6<R>::bt(m[a], o);
+        W6<V>::bt(m[a], o);
 #pragma unroll
-        for (int c = 0; c < N; ++c) *reinterpret_cast<V4*>(V + (a * N + c) * plane) = o[c];
+        for (int c = 0; c < N; ++c) *reinterpret_cast<V4*>(Vp + (a * N + c) * plane) = o[c];
     }
     if constexpr (MODE != 1) {
         if (p.Yt != nullptr && ty < p.yTH && tx < p.yTW) {
-            // output-gradient tile (ty, tx) = patch rows / columns R-1 .. R+2 (just read: L1 / L2 hits); rows past the extent read the zero halo
-            V4 u[N][4];
+            // output-gradient tile (ty, tx) = patch rows / columns R-1 .. R+MO-2 (just read: L1 / L2 hits); rows past the extent read the zero halo
+            V4 u[N][MO];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                V4 e[4], o[N];
+            for (int c = 0; c < MO; ++c) {
+                V4 e[MO], o[N];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) e[a] = ld(R - 1 + a, R - 1 + c);
-                W6<R>::a(e, o);
+                for (int a = 0; a < MO; ++a) e[a] = ld(R - 1 + a, R - 1 + c);
+                W6<V>::a(e, o);
 #pragma unroll
                 for (int a = 0; a < N; ++a) u[a][c] = o[a];
             }
@@ -319,7 +346,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
 #pragma unroll
             for (int a = 0; a < N; ++a) {
                 V4 o[N];
-                W6<R>::a(u[a], o);
+                W6<V>::a(u[a], o);
 #pragma unroll
                 for (int c = 0; c < N; ++c) *reinterpret_cast<V4*>(Y + (a * N + c) * yplane) = o[c];
             }
@@ -330,10 +357,11 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
 // Yt[f][t][k] = (A dY A^T)[f] alone (weight gradient without a Winograd data gradient next to it)
 struct W6Dy { const float* dy; float* Yt; int B, H, W, K, d_row, d_img, d_org, TH, TW; long long T; };
 
-template <int R>
+template <int V>
 __global__ __launch_bounds__(256) void wino6_dy_kernel(const W6Dy p) {
-    constexpr int N = W6<R>::N;
-    const int q4 = p.K / 4;
+    constexpr int N = W6<V>::N, MO = W6<V>::MO, VW = W6VW<V>::value;
+    typedef typename W6Vec<VW>::T V4;
+    const int q4 = p.K / VW;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= p.T * q4) return;
     const long long t = i / q4;
@@ -341,29 +369,31 @@ __global__ __launch_bounds__(256) void wino6_dy_kernel(const W6Dy p) {
     const int tx = int(t % p.TW);
     const long long r = t / p.TW;
     const int ty = int(r % p.TH), b = int(r / p.TH);
-    const float* src = p.dy + size_t(b) * p.d_img + p.d_org + q * 4;
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 u[N][4];
+    const float* src = p.dy + size_t(b) * p.d_img + p.d_org + q * VW;
+    V4 z4;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        f32x4 e[4], o[N];
+    for (int e = 0; e < VW; ++e) z4[e] = 0.f;
+    V4 u[N][MO];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int h = 4 * ty + a, w = 4 * tx + c;
-            e[a] = (h < p.H && w < p.W) ? *reinterpret_cast<const f32x4*>(src + size_t(h) * p.d_row + size_t(w) * p.K) : z4;
+    for (int c = 0; c < MO; ++c) {
+        V4 e[MO], o[N];
+#pragma unroll
+        for (int a = 0; a < MO; ++a) {
+            const int h = MO * ty + a, w = MO * tx + c;
+            e[a] = (h < p.H && w < p.W) ? *reinterpret_cast<const V4*>(src + size_t(h) * p.d_row + size_t(w) * p.K) : z4;
         }
-        W6<R>::a(e, o);
+        W6<V>::a(e, o);
 #pragma unroll
         for (int a = 0; a < N; ++a) u[a][c] = o[a];
     }
     const size_t plane = size_t(p.T) * p.K;
-    float* Y = p.Yt + size_t(t) * p.K + q * 4;
+    float* Y = p.Yt + size_t(t) * p.K + q * VW;
 #pragma unroll
     for (int a = 0; a < N; ++a) {
-        f32x4 o[N];
-        W6<R>::a(u[a], o);
+        V4 o[N];
+        W6<V>::a(u[a], o);
 #pragma unroll
-        for (int c = 0; c < N; ++c) *reinterpret_cast<f32x4*>(Y + (a * N + c) * plane) = o[c];
+        for (int c = 0; c < N; ++c) *reinterpret_cast<V4*>(Y + (a * N + c) * plane) = o[c];
     }
 }
 
@@ -712,10 +742,11 @@ __global__ __launch_bounds__(256, 2) void wino6_pair16p_kernel(const W6G16 q, co
 // ------------------------------------------------------------------------------------------------ output transform
 struct W6Out { const float* M; const float* bias; float* y; int B, H, W, K, TH, TW; long long T; };
 
-template <int R>
+template <int V>
 __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
-    constexpr int N = W6<R>::N;
-    const int q4 = p.K / 4;
+    constexpr int N = W6<V>::N, MO = W6<V>::MO, VW = W6VW<V>::value;
+    typedef typename W6Vec<VW>::T V4;
+    const int q4 = p.K / VW;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= p.T * q4) return;
     const long long t = i / q4;
@@ -724,30 +755,32 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
     const long long r = t / p.TW;
     const int ty = int(r % p.TH), b = int(r / p.TH);
     const size_t plane = size_t(p.T) * p.K;
-    const float* M = p.M + size_t(t) * p.K + q * 4;
-    f32x4 s[4][N];
+    const float* M = p.M + size_t(t) * p.K + q * VW;
+    V4 s[MO][N];
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-        f32x4 m[N], o[4];
+        V4 m[N], o[MO];
 #pragma unroll
-        for (int a = 0; a < N; ++a) m[a] = *reinterpret_cast<const f32x4*>(M + (a * N + c) * plane);
-        W6<R>::at(m, o);
+        for (int a = 0; a < N; ++a) m[a] = *reinterpret_cast<const V4*>(M + (a * N + c) * plane);
+        W6<V>::at(m, o);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) s[a][c] = o[a];
+        for (int a = 0; a < MO; ++a) s[a][c] = o[a];
     }
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + q * 4);
-    float* yb = p.y + size_t(b) * p.H * p.W * p.K + q * 4;
+    V4 bv;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        f32x4 o[4];
-        W6<R>::at(s[a], o);
-        const int h = 4 * ty + a;
+    for (int e = 0; e < VW; ++e) bv[e] = 0.f;
+    if (p.bias != nullptr) bv = *reinterpret_cast<const V4*>(p.bias + q * VW);
+    float* yb = p.y + size_t(b) * p.H * p.W * p.K + q * VW;
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+        V4 o[MO];
+        W6<V>::at(s[a], o);
+        const int h = MO * ty + a;
         if (h >= p.H) continue;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int w = 4 * tx + c;
-            if (w < p.W) *reinterpret_cast<f32x4*>(yb + (size_t(h) * p.W + w) * p.K) = o[c] + bv;
+        for (int c = 0; c < MO; ++c) {
+            const int w = MO * tx + c;
+            if (w < p.W) *reinterpret_cast<V4*>(yb + (size_t(h) * p.W + w) * p.K) = o[c] + bv;
         }
     }
 }
@@ -758,9 +791,9 @@ struct W6Fin { const float* slabs; int nsplit, K, C; float* grad; int accumulate
 // dW[k][c] = G^T (sum over splits of dU[.][k][c]) G in the reference layout [K][C][R][R]; splits in order (deterministic).
 // A block takes 64 (k, c) pairs: thread (e, fg) sums the planes fg, fg + 4, ... of pair e over the splits (coalesced 256-B rows),
 // the N * N sums meet in LDS and threads 0-63 apply the R x N / N x R transforms.
-template <int R>
+template <int V>
 __global__ __launch_bounds__(256) void wino6_wgrad_finish_kernel(const W6Fin p) {
-    constexpr int N = W6<R>::N, NP = N * N, PER = (NP + 3) / 4;
+    constexpr int N = W6<V>::N, R = W6<V>::R, NP = N * N, PER = (NP + 3) / 4;
     __shared__ float u_s[NP][64];
     const int e = threadIdx.x & 63, fg = threadIdx.x >> 6;
     const long long i = blockIdx.x * 64ll + e;
@@ -790,7 +823,7 @@ __global__ __launch_bounds__(256) void wino6_wgrad_finish_kernel(const W6Fin p) 
         float col[N], o[R];
 #pragma unroll
         for (int a = 0; a < N; ++a) col[a] = u_s[a * N + b][e];
-        W6<R>::gt(col, o);
+        W6<V>::gt(col, o);
 #pragma unroll
         for (int a = 0; a < R; ++a) t[a][b] = o[a];
     }
@@ -798,7 +831,7 @@ __global__ __launch_bounds__(256) void wino6_wgrad_finish_kernel(const W6Fin p) 
 #pragma unroll
     for (int a = 0; a < R; ++a) {
         float o[R];
-        W6<R>::gt(t[a], o);
+        W6<V>::gt(t[a], o);
 #pragma unroll
         for (int b = 0; b < R; ++b) {
             if (p.accumulate) g[a * R + b] += o[b]; else g[a * R + b] = o[b];
@@ -806,26 +839,33 @@ __global__ __launch_bounds__(256) void wino6_wgrad_finish_kernel(const W6Fin p) 
     }
 }
 
-static inline long long w6_tiles(int B, int H, int W) { return (long long)B * ((H + 3) / 4) * ((W + 3) / 4); }
-static inline int w6_r(int r) { return r == 0 ? 3 : r; }                 // filter size: 0 / 3 = F(4x4,3x3), 4 = F(4x4,4x4)
-static inline int w6_np(int r) { return (r + 3) * (r + 3); }             // planes: 36 / 49
+// the descriptors' `r` field selects the variant: 0 / 3 = F(4x4,3x3), 4 = F(4x4,4x4), 6 = F(6x6,3x3)
+static inline int w6_r(int r) { return r == 0 ? 3 : r; }
+static inline bool w6_known(int v) { return v == 3 || v == 4 || v == 6; }
+static inline int w6_filter(int v) { return v == 6 ? 3 : v; }            // filter size
+static inline int w6_mo(int v) { return v == 6 ? 6 : 4; }                // outputs per tile and dimension
+static inline int w6_np(int v) { const int n = w6_mo(v) + w6_filter(v) - 1; return n * n; }      // planes: 36 / 49 / 64
+static inline long long w6_tiles(int B, int H, int W, int v) { const int m = w6_mo(v); return (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m); }
 
 }  // namespace
 
-extern "C" int64_t nirgan_wino6_tiles(int B, int H, int W) {
-    if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return w6_tiles(B, H, W);
+extern "C" int64_t nirgan_wino6_tiles_r(int B, int H, int W, int r) {
+    if (B <= 0 || H <= 0 || W <= 0 || !w6_known(w6_r(r))) return 0;
+    return w6_tiles(B, H, W, w6_r(r));
 }
+
+extern "C" int64_t nirgan_wino6_tiles(int B, int H, int W) { return nirgan_wino6_tiles_r(B, H, W, 3); }
 
 extern "C" int nirgan_wino6_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream) {
     r = w6_r(r);
     NG_REQUIRE(w && U && K > 0 && C > 0, "wino6_weights: bad arguments");
-    NG_REQUIRE(r == 3 || r == 4, "wino6_weights: filter size %d (3 or 4)", r);
+    NG_REQUIRE(w6_known(r), "wino6_weights: variant %d (3, 4 or 6)", r);
     W6W p{w, U, K, C, transpose_flip ? 1 : 0};
     const long long n = (long long)K * C;
     const dim3 grid(unsigned((n + 255) / 256));
     if (r == 3) hipLaunchKernelGGL(wino6_weight_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(wino6_weight_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else if (r == 4) hipLaunchKernelGGL(wino6_weight_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino6_weight_kernel<6>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino6_weights");
 }
 
@@ -843,32 +883,33 @@ extern "C" int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs,
 static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const float* ny, const float* mean, const float* rstd,
                          int act, float slope, void* stream, const nirgan_in_bwd_desc* nb = nullptr) {
     NG_REQUIRE(d && d->V && (d->x || ny || nb), "wino6_input: null pointer");
-    const int r = w6_r(d->r), np = w6_np(r);
-    NG_REQUIRE(r == 3 || r == 4, "wino6_input: filter size %d (3 or 4)", r);
+    const int v = w6_r(d->r), np = w6_np(v), r = w6_filter(v), mo = w6_mo(v);
+    NG_REQUIRE(w6_known(v), "wino6_input: variant %d (3, 4 or 6)", v);
     NG_REQUIRE(r == 3 || (!ny && !nb), "wino6_input: the fused variants exist for the 3x3 filter");
+    NG_REQUIRE(v == 3 || !nb, "wino6_input_dy_norm: F(4x4,3x3) only");
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino6_input: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
     NG_REQUIRE(ny || (d->x_hp == d->H + r - 1 && d->x_wp == d->W + r - 1), "wino6_input: the input must be (H+%d) x (W+%d) (%dx%d for %dx%d)", r - 1, r - 1, d->x_hp, d->x_wp, d->H, d->W);
     NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->V) && ng_aligned16(ny) && ng_aligned16(mean) && ng_aligned16(rstd), "wino6_input: pointers must be 16-byte aligned");
-    const long long T = w6_tiles(d->B, d->H, d->W);
+    const long long T = w6_tiles(d->B, d->H, d->W, v);
     NG_REQUIRE(T < (1ll << 31) / d->C, "wino6_input: problem too large for 32-bit tile offsets");
     NG_REQUIRE(d->V_elems >= np * T * d->C, "wino6_input: V workspace too small");
     W6In in;
     in.x = d->x; in.V = d->V; in.B = d->B; in.C = d->C;
     in.x_hp = d->H + r - 1; in.x_wp = d->W + r - 1; in.x_row = in.x_wp * d->C; in.x_img = in.x_hp * in.x_row;
-    in.TH = (d->H + 3) / 4; in.TW = (d->W + 3) / 4; in.T = T;
+    in.TH = (d->H + mo - 1) / mo; in.TW = (d->W + mo - 1) / mo; in.T = T;
     in.Yt = nullptr; in.yTH = in.yTW = 0; in.yT = 0;
     in.y = ny; in.mean = mean; in.rstd = rstd; in.H = d->H; in.W = d->W; in.act = act; in.slope = slope;
     if (y != nullptr) {
         // the same dY buffer seen twice: zero halo r-1, the data gradient covers (H_dy + r - 1) x (W_dy + r - 1) outputs
-        NG_REQUIRE(!ny && (nb || y->dy == d->x) && y->Yt && w6_r(y->r) == r && y->dy_pad == r - 1 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp
+        NG_REQUIRE(!ny && (nb || y->dy == d->x) && y->Yt && w6_r(y->r) == v && y->dy_pad == r - 1 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp
                    && y->dy_wp == d->x_wp && d->H == y->H + r - 1 && d->W == y->W + r - 1,
                    "wino6_input_dy: the two descriptors do not describe the same output-gradient buffer");
         NG_REQUIRE(ng_aligned16(y->Yt), "wino6_input_dy: pointers must be 16-byte aligned");
-        in.yTH = (y->H + 3) / 4; in.yTW = (y->W + 3) / 4; in.yT = (long long)y->B * in.yTH * in.yTW;
+        in.yTH = (y->H + mo - 1) / mo; in.yTW = (y->W + mo - 1) / mo; in.yT = (long long)y->B * in.yTH * in.yTW;
         NG_REQUIRE(y->Yt_elems >= np * in.yT * y->K, "wino6_input_dy: Yt workspace too small");
         in.Yt = y->Yt;
     }
-    const long long nthreads = T * (d->C / (r == 3 ? 4 : 2));
+    const long long nthreads = T * (d->C / (v == 3 ? 4 : 2));
     const dim3 grid(unsigned((nthreads + 255) / 256));
     hipStream_t st = static_cast<hipStream_t>(stream);
     in.nbB = 0;
@@ -880,9 +921,11 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
         in.nbB = nb->B;
         NG_REQUIRE(nb->ws_elems >= int64_t(nb->B) * in.nb.nchunk * 2 * nb->C + int64_t(nb->B) * 2 * nb->C, "wino6_input_dy_norm: ws too small");
         hipLaunchKernelGGL((wino6_input_kernel<3, 2>), grid, dim3(256), 0, st, in);
-    } else if (ny) hipLaunchKernelGGL((wino6_input_kernel<3, 1>), grid, dim3(256), 0, st, in);
-    else if (r == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 0>), grid, dim3(256), 0, st, in);
-    else hipLaunchKernelGGL((wino6_input_kernel<4, 0>), grid, dim3(256), 0, st, in);
+    } else if (ny && v == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 1>), grid, dim3(256), 0, st, in);
+    else if (ny) hipLaunchKernelGGL((wino6_input_kernel<6, 1>), grid, dim3(256), 0, st, in);
+    else if (v == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 0>), grid, dim3(256), 0, st, in);
+    else if (v == 4) hipLaunchKernelGGL((wino6_input_kernel<4, 0>), grid, dim3(256), 0, st, in);
+    else hipLaunchKernelGGL((wino6_input_kernel<6, 0>), grid, dim3(256), 0, st, in);
     return nirgan_check_launch("wino6_input");
 }
 
@@ -906,30 +949,31 @@ extern "C" int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* d, const nirg
 
 extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {
     NG_REQUIRE(d && d->dy && d->Yt, "wino6_dy: null pointer");
-    const int r = w6_r(d->r);
-    NG_REQUIRE(r == 3 || r == 4, "wino6_dy: filter size %d (3 or 4)", r);
+    const int v = w6_r(d->r), mo = w6_mo(v);
+    NG_REQUIRE(w6_known(v), "wino6_dy: variant %d (3, 4 or 6)", v);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0 && d->dy_pad >= 0, "wino6_dy: bad shape");
     NG_REQUIRE(d->dy_hp == d->H + 2 * d->dy_pad && d->dy_wp == d->W + 2 * d->dy_pad, "wino6_dy: dy geometry mismatch");
     NG_REQUIRE(ng_aligned16(d->dy) && ng_aligned16(d->Yt), "wino6_dy: pointers must be 16-byte aligned");
     W6Dy p;
     p.dy = d->dy; p.Yt = d->Yt; p.B = d->B; p.H = d->H; p.W = d->W; p.K = d->K;
     p.d_row = d->dy_wp * d->K; p.d_img = d->dy_hp * p.d_row; p.d_org = d->dy_pad * p.d_row + d->dy_pad * d->K;
-    p.TH = (d->H + 3) / 4; p.TW = (d->W + 3) / 4; p.T = (long long)d->B * p.TH * p.TW;
-    NG_REQUIRE(d->Yt_elems >= w6_np(r) * p.T * d->K, "wino6_dy: workspace too small");
-    const long long n = p.T * (d->K / 4);
+    p.TH = (d->H + mo - 1) / mo; p.TW = (d->W + mo - 1) / mo; p.T = (long long)d->B * p.TH * p.TW;
+    NG_REQUIRE(d->Yt_elems >= w6_np(v) * p.T * d->K, "wino6_dy: workspace too small");
+    const long long n = p.T * (d->K / (v == 3 ? 4 : 2));
     const dim3 grid(unsigned((n + 255) / 256));
-    if (r == 3) hipLaunchKernelGGL(wino6_dy_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(wino6_dy_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    if (v == 3) hipLaunchKernelGGL(wino6_dy_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else if (v == 4) hipLaunchKernelGGL(wino6_dy_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino6_dy_kernel<6>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino6_dy");
 }
 
 // validation + the 32-k form's parameters (one plane as a 1x1 'convolution' over a [1][T] image of C-channel pixels: the direct tile's descriptor)
 static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
     NG_REQUIRE(d && d->U && d->V && d->M && d->zero_page, "wino6_gemm: null pointer");
-    const int r = w6_r(d->r), np = w6_np(r);
-    NG_REQUIRE(r == 3 || r == 4, "wino6_gemm: filter size %d (3 or 4)", r);
+    const int v = w6_r(d->r), np = w6_np(v);
+    NG_REQUIRE(w6_known(v), "wino6_gemm: variant %d (3, 4 or 6)", v);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0 && d->K > 64 && d->K % 4 == 0, "wino6_gemm: C %% 4 == 0, K > 64, K %% 4 == 0 (C=%d K=%d)", d->C, d->K);
-    T = w6_tiles(d->B, d->H, d->W);
+    T = w6_tiles(d->B, d->H, d->W, v);
     NG_REQUIRE(T * d->C < (1ll << 31) && T * d->K < (1ll << 31), "wino6_gemm: problem too large for 32-bit offsets");
     NG_REQUIRE(d->V_elems >= np * T * d->C && d->M_elems >= np * T * d->K, "wino6_gemm: V / M workspace too small");
     nirgan_conv_desc c = {};
@@ -1009,17 +1053,18 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
 
 extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
     NG_REQUIRE(d && d->M && d->y, "wino6_output: null pointer");
-    const int r = w6_r(d->r);
-    NG_REQUIRE(r == 3 || r == 4, "wino6_output: filter size %d (3 or 4)", r);
+    const int v = w6_r(d->r), mo = w6_mo(v);
+    NG_REQUIRE(w6_known(v), "wino6_output: variant %d (3, 4 or 6)", v);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0, "wino6_output: bad shape");
     NG_REQUIRE(ng_aligned16(d->M) && ng_aligned16(d->y) && ng_aligned16(d->bias), "wino6_output: pointers must be 16-byte aligned");
-    const long long T = w6_tiles(d->B, d->H, d->W);
-    NG_REQUIRE(d->M_elems >= w6_np(r) * T * d->K, "wino6_output: M workspace too small");
-    W6Out p{d->M, d->bias, d->y, d->B, d->H, d->W, d->K, (d->H + 3) / 4, (d->W + 3) / 4, T};
-    const long long n = T * (d->K / 4);
+    const long long T = w6_tiles(d->B, d->H, d->W, v);
+    NG_REQUIRE(d->M_elems >= w6_np(v) * T * d->K, "wino6_output: M workspace too small");
+    W6Out p{d->M, d->bias, d->y, d->B, d->H, d->W, d->K, (d->H + mo - 1) / mo, (d->W + mo - 1) / mo, T};
+    const long long n = T * (d->K / (v == 3 ? 4 : 2));
     const dim3 grid(unsigned((n + 255) / 256));
-    if (r == 3) hipLaunchKernelGGL(wino6_output_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(wino6_output_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    if (v == 3) hipLaunchKernelGGL(wino6_output_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else if (v == 4) hipLaunchKernelGGL(wino6_output_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino6_output_kernel<6>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino6_output");
 }
 
@@ -1032,12 +1077,13 @@ extern "C" int nirgan_wino6_conv3x3(const nirgan_wino6_desc* d, void* stream) {
 extern "C" int nirgan_wino6_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream) {
     r = w6_r(r);
     NG_REQUIRE(slabs && grad && nsplit >= 1 && K > 0 && C > 0, "wino6_wgrad_finish: bad arguments");
-    NG_REQUIRE(r == 3 || r == 4, "wino6_wgrad_finish: filter size %d (3 or 4)", r);
+    NG_REQUIRE(w6_known(r), "wino6_wgrad_finish: variant %d (3, 4 or 6)", r);
     W6Fin p{slabs, nsplit, K, C, grad, accumulate ? 1 : 0};
     const long long n = (long long)K * C;
     const dim3 grid(unsigned((n + 63) / 64));
     if (r == 3) hipLaunchKernelGGL(wino6_wgrad_finish_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    else hipLaunchKernelGGL(wino6_wgrad_finish_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else if (r == 4) hipLaunchKernelGGL(wino6_wgrad_finish_kernel<4>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(wino6_wgrad_finish_kernel<6>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("wino6_wgrad_finish");
 }
 

@@ -552,8 +552,24 @@ def wino6_applicable(ctx: Ctx, k: int, cout: int) -> bool:
     return k == 4 and os.environ.get("NIRGAN_NO_WINO7") != "1" and os.environ.get("NIRGAN_NO_WINO6") != "1"
 
 
-def _w6_tiles(B, H, W) -> int:
-    return B * (-(-H // 4)) * (-(-W // 4))
+def wino6_variant(r: int) -> int:
+    """The `r` code of the wino6 descriptors for a filter size: 3 = F(4x4,3x3), 4 = F(4x4,4x4), 6 = F(6x6,3x3).  3x3 filters take
+    F(6x6,3x3) -- 64 products per 36 outputs instead of 36 per 16, in the plane GEMMs AND in the bytes of the transform-domain tensors --
+    unless NIRGAN_NO_WINO8=1 (A/B) or the opt-in dY-norm fusion, which exists for F(4x4,3x3) only, is on."""
+    if r == 3 and os.environ.get("NIRGAN_NO_WINO8") != "1" and os.environ.get("NIRGAN_WINO6_DYNORM") != "1":
+        return 6
+    return r
+
+
+def _w6_geo(v: int):
+    """(outputs per tile and dimension, planes) of a variant."""
+    mo, filt = (6, 3) if v == 6 else (4, v)
+    return mo, (mo + filt - 1) ** 2
+
+
+def _w6_tiles(B, H, W, v: int = 3) -> int:
+    mo = _w6_geo(v)[0]
+    return B * (-(-H // mo)) * (-(-W // mo))
 
 
 def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y, *, H, W, cin, cout, flip=False,
@@ -562,11 +578,12 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     x: [B][H+r-1][W+r-1][cin] buffer, y: dense [B][H][W][cout].  flip: data gradient (x = dY with a zero halo of r-1, H x W = padded input)."""
     assert x.hp == H + r - 1 and x.wp == W + r - 1 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
     B = x.B
-    T = _w6_tiles(B, H, W)
-    NP = (r + 3) ** 2
+    v = wino6_variant(r)
+    T = _w6_tiles(B, H, W, v)
+    NP = _w6_geo(v)[1]
     U = ctx.zeros(NP * cout * cin)
     ctx.keep.append(U)
-    pack.add("nirgan_wino6_weights_r", weight.data_ptr(), cout, cin, r, 1 if flip else 0, U.data_ptr())
+    pack.add("nirgan_wino6_weights_r", weight.data_ptr(), cout, cin, v, 1 if flip else 0, U.data_ptr())
     for name in ("wino6_pool_v", "wino6_pool_m"):
         if not hasattr(ctx, name):
             setattr(ctx, name, SplitPool(ctx))          # one layer at a time (launches run serially)
@@ -577,7 +594,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
         V = ctx.wino6_pool_v.get(NP * T * cin)
     M = ctx.wino6_pool_m.get(NP * T * cout)
     d = L.Wino6Desc()
-    d.r = r
+    d.r = v
     d.x, d.x_hp, d.x_wp = x.ptr, x.hp, x.wp
     d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
     d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
@@ -602,8 +619,10 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     forward input, kept by the forward) as one weight-gradient launch, dW = G^T dU G."""
     B = inp.B
     assert inp.pad == 1 and inp.H == OH + r - 3 and inp.W == OW + r - 3 and inp.C == cin and dy.C == cout and dy.pad == r - 1 and dgrad.x == dy.ptr
-    T = _w6_tiles(B, OH, OW)
-    NP = (r + 3) ** 2
+    v = wino6_variant(r)
+    assert dgrad.r == v
+    T = _w6_tiles(B, OH, OW, v)
+    NP = _w6_geo(v)[1]
     for name in ("wino6_pool_x", "wino6_pool_y", "wino6_pool_y2", "wino6_slabs"):
         if not hasattr(ctx, name):
             setattr(ctx, name, SplitPool(ctx))
@@ -621,14 +640,14 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     else:
         V = ctx.wino6_pool_x.get(NP * T * cin)
         vin = L.Wino6Desc()
-        vin.r = r
+        vin.r = v
         vin.x, vin.x_hp, vin.x_wp, vin.B, vin.H, vin.W, vin.C, vin.K = inp.ptr, inp.hp, inp.wp, B, OH, OW, cin, cout
         vin.V, vin.V_elems = V.data_ptr(), V.numel()
         V_ptr, V_elems = V.data_ptr(), V.numel()
     ydesc = L.WinoDyDesc()
     ydesc.dy, ydesc.dy_hp, ydesc.dy_wp, ydesc.dy_pad = dy.ptr, dy.hp, dy.wp, dy.pad
     ydesc.B, ydesc.H, ydesc.W, ydesc.K = B, OH, OW, cout
-    ydesc.Yt, ydesc.Yt_elems, ydesc.r = Yt.data_ptr(), Yt.numel(), r
+    ydesc.Yt, ydesc.Yt_elems, ydesc.r = Yt.data_ptr(), Yt.numel(), v
     tiles = (-(-cout // 128)) * (-(-cin // 128)) * NP
     nsplit, rows = G.wgrad_split(T, tiles, 1024)
     if os.environ.get("NIRGAN_WINO6_SPLITS"):            # experiments
@@ -661,7 +680,7 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
         plan.add("nirgan_wino6_gemm", C.byref(dgrad))
         add_w("nirgan_wgrad_igemm", C.byref(d))
     plan.add("nirgan_wino6_output", C.byref(dgrad))
-    add_w("nirgan_wino6_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, r, grad.data_ptr(), 1 if accumulate else 0)
+    add_w("nirgan_wino6_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, v, grad.data_ptr(), 1 if accumulate else 0)
     return d
 
 

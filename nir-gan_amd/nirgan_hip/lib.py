@@ -177,6 +177,7 @@ PROTOTYPES = {
     "nirgan_wino_input_norm": (i32, [C.POINTER(WinoDesc), fp, fp, fp, i32, f32, fp]),
     "nirgan_wino_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_wino6_tiles": (i64, [i32, i32, i32]),
+    "nirgan_wino6_tiles_r": (i64, [i32, i32, i32, i32]),
     "nirgan_wino6_weights": (i32, [fp, i32, i32, i32, fp, fp]),
     "nirgan_wino6_weights_r": (i32, [fp, i32, i32, i32, i32, fp, fp]),
     "nirgan_wino6_weights_batch": (i32, [fp, i32, i32, fp]),

@@ -26,6 +26,17 @@ plans = {"G.fwd": tr.G.fwd, "G.bwd": tr.G.bwd, "D2.fwd": tr.D2.fwd, "D2.bwd": tr
          "G.pack": tr.G.pack_fwd, "G.packb": tr.G.pack_bwd}
 
 
+
+def w6_planes(r):
+    """planes of a wino6 descriptor's variant code: 0 / 3 = F(4x4,3x3): 36, 4 = F(4x4,4x4): 49, 6 = F(6x6,3x3): 64"""
+    return 64 if r == 6 else (max(r, 3) + 3) ** 2
+
+
+def w6_tiles(d):
+    mo = 6 if d.r == 6 else 4
+    return d.B * (-(-d.H // mo)) * (-(-d.W // mo))
+
+
 def describe(name, args):
     if name == "nirgan_conv_igemm":
         d = args[0]._obj
@@ -56,13 +67,13 @@ def describe(name, args):
         return f"wgrad M={M} N={w.N} K={K} split={w.nsplit} planes={npl} blk={blocks}", 2.0 * npl * M * w.N * K
     if name == "nirgan_wino6_gemm_wgrad_pair":
         d, w = args[0]._obj, args[1]._obj
-        T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
-        fl = 2.0 * (max(d.r, 3) + 3) ** 2 * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
-        return f"wino6 pair: dgrad gemm {(max(d.r, 3) + 3) ** 2} x [T={T} x {d.C}] x [{d.K}] + wgrad {w.nplanes} planes M={w.OW} split={w.nsplit} (executed flops)", fl
+        T = w6_tiles(d)
+        fl = 2.0 * w6_planes(d.r) * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
+        return f"wino6 pair: dgrad gemm {w6_planes(d.r)} x [T={T} x {d.C}] x [{d.K}] + wgrad {w.nplanes} planes M={w.OW} split={w.nsplit} (executed flops)", fl
     if name == "nirgan_wino6_gemm":
         d = args[0]._obj
-        T = d.B * ((d.H + 3) // 4) * ((d.W + 3) // 4)
-        return f"wino6 gemm {(max(d.r, 3) + 3) ** 2} x [T={T} x C={d.C}] x [K={d.K}] blk={(max(d.r, 3) + 3) ** 2 * -(-T // 128) * -(-d.K // 128)} (executed flops)", 2.0 * (max(d.r, 3) + 3) ** 2 * T * d.C * d.K
+        T = w6_tiles(d)
+        return f"wino6 gemm {w6_planes(d.r)} x [T={T} x C={d.C}] x [K={d.K}] blk={w6_planes(d.r) * -(-T // 128) * -(-d.K // 128)} (executed flops)", 2.0 * w6_planes(d.r) * T * d.C * d.K
     if name in ("nirgan_wino6_input", "nirgan_wino6_input_norm", "nirgan_wino6_output", "nirgan_wino6_input_dy"):
         d = args[0]._obj
         return f"{name[7:]} B={d.B} {d.H}x{d.W} C={d.C} K={d.K}", 0.0

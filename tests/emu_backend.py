@@ -477,14 +477,34 @@ class EmuBackend:
             np.array([[4, -8, -5, 10, 1, -2, 0], [0, -4, 4, 9, -1, -2, 0], [0, -4, 12, -7, -3, 2, 0], [0, 2, -3, -4, 3, 2, 0],
                       [0, 2, -5, 0, 5, -2, 0], [0, 4, 0, -5, 0, 1, 0], [0, -4, 8, 5, -10, -1, 2]], dtype=np.float64),
             np.array([[1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 1 / 2, 0], [0, 1, 1, 4, 4, 1 / 4, 0], [0, 1, -1, 8, -8, 1 / 8, 1]], dtype=np.float64)),
+        # F(6x6,3x3): Cook-Toom over 0, 1, -1, 2, -2, 1/2, -1/2, inf (csrc/wino6.hip w8_G / w8_BT / w8_AT)
+        6: (np.array([[1 / 4, 0, 0], [1 / 18, 1 / 18, 1 / 18], [1 / 18, -1 / 18, 1 / 18], [1 / 360, 1 / 180, 1 / 90], [1 / 360, -1 / 180, 1 / 90],
+                      [16 / 45, 8 / 45, 4 / 45], [16 / 45, -8 / 45, 4 / 45], [0, 0, 1 / 4]]),
+            np.array([[4, 0, -21, 0, 21, 0, -4, 0], [0, -4, -4, 17, 17, -4, -4, 0], [0, 4, -4, -17, 17, 4, -4, 0], [0, 2, 1, -10, -5, 8, 4, 0],
+                      [0, -2, 1, 10, -5, -8, 4, 0], [0, 4, 8, -5, -10, 1, 2, 0], [0, -4, 8, 5, -10, -1, 2, 0], [0, -4, 0, 21, 0, -21, 0, 4]], dtype=np.float64),
+            np.array([[1, 1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 1 / 2, -1 / 2, 0], [0, 1, 1, 4, 4, 1 / 4, 1 / 4, 0], [0, 1, -1, 8, -8, 1 / 8, -1 / 8, 0],
+                      [0, 1, 1, 16, 16, 1 / 16, 1 / 16, 0], [0, 1, -1, 32, -32, 1 / 32, -1 / 32, 1]], dtype=np.float64)),
     }
 
     @staticmethod
     def _r6(r):
         return 3 if r == 0 else r
 
+    @staticmethod
+    def _geo6(v):
+        """variant code -> (filter size, outputs per tile and dimension, points per dimension)"""
+        filt, mo = (3, 6) if v == 6 else (v, 4)
+        return filt, mo, mo + filt - 1
+
     def nirgan_wino6_tiles(self, B, H, W):
-        return B * ((H + 3) // 4) * ((W + 3) // 4) if min(B, H, W) > 0 else 0
+        return self.nirgan_wino6_tiles_r(B, H, W, 3)
+
+    def nirgan_wino6_tiles_r(self, B, H, W, r):
+        v = self._r6(r)
+        if v not in self._W6 or min(B, H, W) <= 0:
+            return 0
+        mo = self._geo6(v)[1]
+        return B * (-(-H // mo)) * (-(-W // mo))
 
     def nirgan_wino6_weights(self, w, K, Cc, flip, U, stream=None):
         return self.nirgan_wino6_weights_r(w, K, Cc, 3, flip, U)
@@ -495,7 +515,7 @@ class EmuBackend:
         if r not in self._W6:
             return self._fail("wino6_weights: filter size")
         Gm = self._W6[r][0]
-        n = r + 3
+        r, _, n = self._geo6(r)
         if flip:
             g = arr(w, K * Cc * r * r).reshape(Cc, K, r, r).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
         else:
@@ -516,49 +536,53 @@ class EmuBackend:
             blocks += (int(K) * int(Cc) + 255) // 256
         return 0 if blocks == total_blocks else self._fail("wino6_weights_batch: total_blocks mismatch")
 
-    def _wino6_V(self, x, B, H, W, Cc, r=3):
-        """x: [B][H+r-1][W+r-1][C] float64 -> V [n][n][B][TH][TW][C], n = r + 3"""
-        n = r + 3
-        TH, TW = (H + 3) // 4, (W + 3) // 4
-        xp = np.zeros((B, 4 * TH + r - 1, 4 * TW + r - 1, Cc))
+    def _wino6_V(self, x, B, H, W, Cc, v=3):
+        """x: [B][H+r-1][W+r-1][C] float64 -> V [n][n][B][TH][TW][C]"""
+        r, mo, n = self._geo6(v)
+        TH, TW = -(-H // mo), -(-W // mo)
+        xp = np.zeros((B, mo * TH + r - 1, mo * TW + r - 1, Cc))
         xp[:, :H + r - 1, :W + r - 1] = x
-        tiles = np.stack([np.stack([xp[:, i:i + 4 * TH:4, j:j + 4 * TW:4] for j in range(n)], 0) for i in range(n)], 0)
-        BT = self._W6[r][1]
+        tiles = np.stack([np.stack([xp[:, i:i + mo * TH:mo, j:j + mo * TW:mo] for j in range(n)], 0) for i in range(n)], 0)
+        BT = self._W6[v][1]
         return np.einsum("ai,ijbyxc,lj->albyxc", BT, tiles, BT)
 
     def nirgan_wino6_input(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("wino6_in")
-        r = self._r6(d.r)
-        if r not in self._W6 or d.x_hp != d.H + r - 1 or d.x_wp != d.W + r - 1 or d.C % 4:
+        v = self._r6(d.r)
+        if v not in self._W6:
+            return self._fail("wino6_input: variant")
+        r, mo, n = self._geo6(v)
+        if d.x_hp != d.H + r - 1 or d.x_wp != d.W + r - 1 or d.C % 4:
             return self._fail("wino6_input: bad geometry")
         B, H, W, Cc = d.B, d.H, d.W, d.C
-        if d.V_elems < (r + 3) ** 2 * self.nirgan_wino6_tiles(B, H, W) * Cc:
+        if d.V_elems < n * n * self.nirgan_wino6_tiles_r(B, H, W, v) * Cc:
             return self._fail("wino6_input: V workspace too small")
         x = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
-        V = self._wino6_V(x, B, H, W, Cc, r)
+        V = self._wino6_V(x, B, H, W, Cc, v)
         arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino6_input_norm(self, ref, y, mean, rstd, act, slope, stream=None):
         d = obj(ref)
         self.calls.append("wino6_in_norm")
-        if self._r6(d.r) != 3:
+        v = self._r6(d.r)
+        if v not in (3, 6):
             return self._fail("wino6_input_norm: 3x3 filters only")
         B, H, W, Cc = d.B, d.H, d.W, d.C
         yv = arr(y, B * H * W * Cc).reshape(B, H, W, Cc)
         m, r = arr(mean, B * Cc).reshape(B, 1, 1, Cc), arr(rstd, B * Cc).reshape(B, 1, 1, Cc)
         a = self._act(((yv - m) * r).astype(np.float32).astype(np.float64), act, slope).astype(np.float32)       # in_apply's fp32 arithmetic
         hh, ww = reflect(np.arange(H + 2) - 1, H), reflect(np.arange(W + 2) - 1, W)
-        V = self._wino6_V(a[:, hh][:, :, ww].astype(np.float64), B, H, W, Cc)
+        V = self._wino6_V(a[:, hh][:, :, ww].astype(np.float64), B, H, W, Cc, v)
         arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino6_gemm(self, ref, stream=None):
         d = obj(ref)
         self.calls.append("wino6_gemm")
-        T = self.nirgan_wino6_tiles(d.B, d.H, d.W)
-        nplanes = (self._r6(d.r) + 3) ** 2
+        T = self.nirgan_wino6_tiles_r(d.B, d.H, d.W, d.r)
+        nplanes = self._geo6(self._r6(d.r))[2] ** 2
         if d.K <= 64 or d.K % 4 or d.C % 4 or d.V_elems < nplanes * T * d.C or d.M_elems < nplanes * T * d.K:
             return self._fail("wino6_gemm: bad geometry / workspace")
         V = arr(d.V, nplanes * T * d.C).reshape(nplanes, T, d.C).astype(np.float64)
@@ -574,12 +598,12 @@ class EmuBackend:
         d = obj(ref)
         self.calls.append("wino6_out")
         B, H, W, K = d.B, d.H, d.W, d.K
-        r = self._r6(d.r)
-        n = r + 3
-        TH, TW = (H + 3) // 4, (W + 3) // 4
+        v = self._r6(d.r)
+        r, mo, n = self._geo6(v)
+        TH, TW = -(-H // mo), -(-W // mo)
         M = arr(d.M, n * n * B * TH * TW * K).reshape(n, n, B, TH, TW, K).astype(np.float64)
-        AT = self._W6[r][2]
-        Y = np.einsum("pa,albyxk,ql->bypxqk", AT, M, AT).reshape(B, 4 * TH, 4 * TW, K)
+        AT = self._W6[v][2]
+        Y = np.einsum("pa,albyxk,ql->bypxqk", AT, M, AT).reshape(B, mo * TH, mo * TW, K)
         bias = arr(d.bias, K)
         if bias is not None:
             Y = Y + bias
@@ -597,24 +621,27 @@ class EmuBackend:
         d = obj(ref)
         self.calls.append("wino6_dy")
         B, H, W, K = d.B, d.H, d.W, d.K
-        r = self._r6(d.r)
-        n = r + 3
-        TH, TW = (H + 3) // 4, (W + 3) // 4
-        if r not in self._W6 or d.Yt_elems < n * n * B * TH * TW * K or d.dy_hp != H + 2 * d.dy_pad:
+        v = self._r6(d.r)
+        if v not in self._W6:
+            return self._fail("wino6_dy: variant")
+        r, mo, n = self._geo6(v)
+        TH, TW = -(-H // mo), -(-W // mo)
+        if d.Yt_elems < n * n * B * TH * TW * K or d.dy_hp != H + 2 * d.dy_pad:
             return self._fail("wino6_dy: bad geometry / workspace")
         dy = arr(d.dy, B * d.dy_hp * d.dy_wp * K).reshape(B, d.dy_hp, d.dy_wp, K).astype(np.float64)
-        z = np.zeros((B, 4 * TH, 4 * TW, K))
+        z = np.zeros((B, mo * TH, mo * TW, K))
         z[:, :H, :W] = dy[:, d.dy_pad:d.dy_pad + H, d.dy_pad:d.dy_pad + W]
-        tiles = np.stack([np.stack([z[:, i::4, j::4] for j in range(4)], 0) for i in range(4)], 0)       # [4][4][B][TH][TW][K]
-        A = self._W6[r][2].T                                                                              # n x 4
+        tiles = np.stack([np.stack([z[:, i::mo, j::mo] for j in range(mo)], 0) for i in range(mo)], 0)   # [mo][mo][B][TH][TW][K]
+        A = self._W6[v][2].T                                                                              # n x mo
         Yt = np.einsum("ia,abnyxk,jb->ijnyxk", A, tiles, A)
         arr(d.Yt, n * n * B * TH * TW * K)[:] = Yt.reshape(-1).astype(np.float32)
         return 0
 
     def nirgan_wino6_input_dy(self, cref, yref, stream=None):
         c, y = obj(cref), obj(yref)
-        r = self._r6(c.r)
-        if c.x != y.dy or y.dy_pad != r - 1 or c.H != y.H + r - 1 or c.W != y.W + r - 1 or c.C != y.K or self._r6(y.r) != r:
+        v = self._r6(c.r)
+        r = self._geo6(v)[0]
+        if c.x != y.dy or y.dy_pad != r - 1 or c.H != y.H + r - 1 or c.W != y.W + r - 1 or c.C != y.K or self._r6(y.r) != v:
             return self._fail("wino6_input_dy: the two descriptors do not describe the same output-gradient buffer")
         rc = self.nirgan_wino6_input(cref)
         return rc if rc else self.nirgan_wino6_dy(yref)
@@ -637,10 +664,10 @@ class EmuBackend:
 
     def nirgan_wino6_wgrad_finish_r(self, slabs, nsplit, K, Cc, r, grad, accumulate, stream=None):
         self.calls.append("wino6_fin")
-        r = self._r6(r)
-        n = r + 3
+        v = self._r6(r)
+        r, _, n = self._geo6(v)
         u = arr(slabs, n * n * nsplit * K * Cc).reshape(n, n, nsplit, K, Cc).astype(np.float64).sum(2)
-        Gm = self._W6[r][0]
+        Gm = self._W6[v][0]
         g = np.einsum("ai,abkc,bj->kcij", Gm, u, Gm)
         o = arr(grad, K * Cc * r * r).reshape(K, Cc, r, r)
         if accumulate:

@@ -875,21 +875,24 @@ def test_winograd_backward_pair_matches_autograd(hw):
 
 # ---------------------------------------------------------------------------------- Winograd F(4x4, 3x3) (csrc/wino6.hip)
 @pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128, 3), (1, 64, 64, 256, 256, 3), (3, 6, 5, 32, 128, 3), (2, 9, 7, 64, 192, 3), (1, 69, 69, 256, 256, 3),
-                                   (16, 64, 64, 256, 256, 3), (2, 8, 12, 64, 128, 4), (2, 31, 31, 256, 512, 4), (3, 7, 5, 32, 128, 4), (32, 31, 31, 256, 512, 4)])
+                                   (16, 64, 64, 256, 256, 3), (2, 8, 12, 64, 128, 4), (2, 31, 31, 256, 512, 4), (3, 7, 5, 32, 128, 4), (32, 31, 31, 256, 512, 4),
+                                   (2, 8, 12, 64, 128, 6), (1, 64, 64, 256, 256, 6), (3, 6, 5, 32, 128, 6), (2, 9, 7, 64, 192, 6), (1, 69, 69, 256, 256, 6),
+                                   (16, 64, 64, 256, 256, 6), (16, 66, 66, 256, 256, 6)])
 def test_wino6_conv3x3_matches_direct(shape):
     """nirgan_wino6_weights_r + input / (r+3)^2 plane GEMMs / output transform against torch's conv2d in float64 (the reference's
     nn.Conv2d arithmetic) and the numpy restatement: fp32 rounding only.  F(4x4,3x3) and F(4x4,4x4); extents that are multiples of 4,
     odd, smaller than a tile; K = 192 leaves a half-used N tile; the benchmark's residual-block layer and its PatchGAN 4x4 layer."""
     import ctypes as C
-    B, H, W, Cc, K, r = shape
-    NP = (r + 3) ** 2
+    B, H, W, Cc, K, v = shape                                            # v: the descriptors' variant code, 6 = F(6x6,3x3)
+    r, mo = (3, 6) if v == 6 else (v, 4)
+    NP = (mo + r - 1) ** 2
     g = torch.Generator().manual_seed(21)
     x = torch.randn(B, H + r - 1, W + r - 1, Cc, generator=g)            # halo included: any values (reflect or zero in the nets)
     w = torch.randn(K, Cc, r, r, generator=g) * 0.05
     b = torch.randn(K, generator=g)
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1).float()
-    T = B * ((H + 3) // 4) * ((W + 3) // 4)
-    assert int(L.backend().nirgan_wino6_tiles(B, H, W)) == T
+    T = B * (-(-H // mo)) * (-(-W // mo))
+    assert int(L.backend().nirgan_wino6_tiles_r(B, H, W, v)) == T
     outs = []
     emu = EmuBackend()
     for dev, be in ((DEV, None), ("cpu", emu)):
@@ -902,34 +905,39 @@ def test_wino6_conv3x3_matches_direct(shape):
         y = torch.full((B, H, W, K), float("nan"), device=dev)
         zero = torch.zeros(64, device=dev)
         d = L.Wino6Desc()
-        d.r = r
+        d.r = v
         d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = xt.data_ptr(), H + r - 1, W + r - 1, B, H, W, Cc, K
         d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems = U.data_ptr(), bt.data_ptr(), V.data_ptr(), V.numel(), M.data_ptr(), M.numel()
         d.y, d.zero_page = y.data_ptr(), zero.data_ptr()
         if be is None:
             st = torch.cuda.current_stream().cuda_stream
-            L.call("nirgan_wino6_weights_r", wt.data_ptr(), K, Cc, r, 0, U.data_ptr(), st)
+            L.call("nirgan_wino6_weights_r", wt.data_ptr(), K, Cc, v, 0, U.data_ptr(), st)
             L.call("nirgan_wino6_conv3x3", C.byref(d), st)
             torch.cuda.synchronize()
         else:
-            assert be.nirgan_wino6_weights_r(wt.data_ptr(), K, Cc, r, 0, U.data_ptr()) == 0
+            assert be.nirgan_wino6_weights_r(wt.data_ptr(), K, Cc, v, 0, U.data_ptr()) == 0
             assert be.nirgan_wino6_conv3x3(d) == 0
         outs.append(y.cpu())
-    tol = 3e-5 if r == 3 else 8e-5          # F(4x4,4x4): seven points; measured 1e-5 .. 3e-5
+    tol = 3e-5 if v == 3 else 8e-5          # F(4x4,4x4) / F(6x6,3x3): seven / eight points; measured 1e-5 .. 3e-5
     close(outs[0], ref, tol, "device vs torch")
     if len(outs) > 1:
         close(outs[1], ref, 1e-5, "restatement vs torch")
         close(outs[0], outs[1], tol, "device vs restatement")
 
 
-@pytest.mark.parametrize("hw", [(12, 16, 3), (9, 11, 3), (64, 64, 3), (12, 16, 4), (9, 11, 4), (31, 31, 4)])
-def test_wino6_backward_matches_autograd(hw):
+@pytest.mark.parametrize("hw", [(12, 16, 3, 3), (9, 11, 3, 3), (64, 64, 3, 3), (12, 16, 4, 4), (9, 11, 4, 4), (31, 31, 4, 4), (12, 16, 3, 6), (9, 11, 3, 6),
+                                (64, 64, 3, 6), (13, 6, 3, 6)])
+def test_wino6_backward_matches_autograd(hw, monkeypatch):
     """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it with F(4x4,3x3): data gradient over the padded
     extent (dY transformed once for both uses), transform-domain weight gradient (36 planes in one weight-gradient launch, then
     G^T dU G) against torch autograd of conv2d in float64; device and numpy restatement.  Even and odd extents; V re-derived from the
     forward input here (the nets keep the forward's V: covered by the net-level tests)."""
     from nirgan_hip.engine import emit_wino6, emit_wino6_backward, SlabPool, _FullExtent
-    H, W, r = hw                                      # H x W = the layer's OUTPUT extent; its input is (H + r - 3) x (W + r - 3) + halo 1
+    H, W, r, v = hw                                   # H x W = the layer's OUTPUT extent; its input is (H + r - 3) x (W + r - 3) + halo 1
+    if v == 3:
+        monkeypatch.setenv("NIRGAN_NO_WINO8", "1")    # 3x3 filters: F(4x4,3x3) instead of the default F(6x6,3x3)
+    from nirgan_hip.engine import wino6_variant
+    assert wino6_variant(r) == v
     B, Cin, Cout = 2, 128, 128
     g = torch.Generator().manual_seed(12)
     x = torch.randn(B, H + r - 1, W + r - 1, Cin, generator=g)
@@ -961,17 +969,17 @@ def test_wino6_backward_matches_autograd(hw):
     tw.run(gpl, cpl)
     close(cgx.t, ref_gx, 1e-5, "restatement: data gradient")
     close(cgw, ref_gw, 1e-5, "restatement: weight gradient")
-    close(ggx.t, ref_gx, 3e-5 if r == 3 else 8e-5, "device: data gradient")
+    close(ggx.t, ref_gx, 3e-5 if v == 3 else 8e-5, "device: data gradient")
     close(ggw, ref_gw, 1e-4, "device: weight gradient")
 
 
-@pytest.mark.parametrize("hw", [(12, 16), (9, 11), (64, 64)])
+@pytest.mark.parametrize("hw", [(12, 16, 3), (9, 11, 3), (64, 64, 3), (12, 16, 6), (9, 11, 6), (64, 64, 6)])
 def test_wino6_input_transform_with_the_instance_norm_folded_in(hw):
     """nirgan_instnorm_fwd(out = NULL: statistics only) + nirgan_wino6_input_norm(y, mean, rstd, ReLU) = the V that the full
     instance-norm pass (ReLU, reflect halo 1) followed by nirgan_wino6_input produces -- bitwise, same fp32 arithmetic."""
     import ctypes as C
     from nirgan_hip.engine import emit_in_fwd
-    H, W = hw
+    H, W, v = hw
     B, Cc = 2, 128
     g = torch.Generator().manual_seed(31)
     y = (torch.randn(B, H, W, Cc, generator=g) * 1.7 + 0.3).to(DEV)
@@ -985,9 +993,11 @@ def test_wino6_input_transform_with_the_instance_norm_folded_in(hw):
     full = Plan(ctx)
     emit_in_fwd(full, ctx, yh, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats, ws=ws)
     full.run()
-    T = B * ((H + 3) // 4) * ((W + 3) // 4)
-    V1, V2 = torch.zeros(36 * T * Cc, device=DEV), torch.full((36 * T * Cc,), float("nan"), device=DEV)
+    T = int(L.backend().nirgan_wino6_tiles_r(B, H, W, v))
+    NP = 64 if v == 6 else 36
+    V1, V2 = torch.zeros(NP * T * Cc, device=DEV), torch.full((NP * T * Cc,), float("nan"), device=DEV)
     d = L.Wino6Desc()
+    d.r = v
     d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = out.ptr, H + 2, W + 2, B, H, W, Cc, 128
     d.V, d.V_elems = V1.data_ptr(), V1.numel()
     L.call("nirgan_wino6_input", C.byref(d), st)

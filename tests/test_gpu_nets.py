@@ -120,16 +120,18 @@ def test_golden_small_nets_fused_step(golden_dir, name):
         close(pD[k], p0, 1e-6, "adam " + k)
 
 
-@pytest.mark.parametrize("variant", ["F(4x4,3x3)", "F(2x2,3x3)"])
+@pytest.mark.parametrize("variant", ["F(6x6,3x3)", "F(4x4,3x3)", "F(2x2,3x3)"])
 def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     """ngf = ndf = 32 on 64x64 tiles: every Winograd variant at small tile counts in one fused step against the oracle -- residual blocks
     (128 channels at 16x16: the instance-norm apply folded into the second convolution's input transform, fused dY transforms,
-    transform-domain weight gradient) and the PatchGAN's 4x4 layer (128 -> 256 channels at 8x8 -> 7x7: odd extent): F(4x4,3x3) / F(4x4,4x4) by
-    default, F(2x2,3x3) / F(2x2,4x4) with their frequency-split GEMMs under NIRGAN_NO_WINO6=1."""
+    transform-domain weight gradient) and the PatchGAN's 4x4 layer (128 -> 256 channels at 8x8 -> 7x7: odd extent): F(6x6,3x3) / F(4x4,4x4) by
+    default, F(4x4,3x3) under NIRGAN_NO_WINO8=1, F(2x2,3x3) / F(2x2,4x4) with their frequency-split GEMMs under NIRGAN_NO_WINO6=1."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
     if variant == "F(2x2,3x3)":
         monkeypatch.setenv("NIRGAN_NO_WINO6", "1")
+    if variant == "F(4x4,3x3)":
+        monkeypatch.setenv("NIRGAN_NO_WINO8", "1")
     torch.manual_seed(7)
     netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 32, "basic", 3, "instance", "normal", 0.02)
@@ -140,7 +142,9 @@ def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=6, lr=0.0)
     out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
     names = [n for pl in (tr.G.fwd, tr.G.bwd, tr.D2.fwd, tr.D2.bwd, tr.D1.bwd_pred) for n, _ in pl.ops]
-    if variant == "F(4x4,3x3)":      # residual blocks as F(4x4,3x3) AND the PatchGAN's 4x4 layer as F(4x4,4x4): no F(2x2) launch left
+    if variant != "F(2x2,3x3)":      # residual blocks as F(6x6,3x3) / F(4x4,3x3) AND the PatchGAN's 4x4 layer as F(4x4,4x4): no F(2x2) launch left
+        rcodes = {a[0]._obj.r for pl in (tr.G.fwd, tr.G.bwd) for n, a in pl.ops if n == "nirgan_wino6_gemm"}
+        assert rcodes == ({6} if variant == "F(6x6,3x3)" else {3}), rcodes
         for want in ("nirgan_wino6_input_norm", "nirgan_wino6_input_dy", "nirgan_wino6_gemm", "nirgan_wino6_gemm_wgrad_pair", "nirgan_wino6_output",
                      "nirgan_wino6_wgrad_finish_r"):
             assert want in names, want
@@ -156,12 +160,15 @@ def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     for k in ("loss_D", "loss_G", "loss_G_l1"):
         close(out[k], o[k], 1e-3, k)
     gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
+    # unforced fp32-vs-fp32 comparison on a 2 x 64 x 64 batch: a handful of activations within rounding of zero flip; F(6x6,3x3) carries
+    # 5x the rounding noise of F(4x4,3x3) (1.7e-5 against 3.4e-6 of a layer's output range), so more of them do
+    l2 = 4e-3 if variant == "F(6x6,3x3)" else 1e-3
     for k, v in ref.last["grads_D"].items():
         if k not in O.shadowed_bias_keys("D"):
-            grad_close(gD[k], v, "gD " + k)
+            grad_close(gD[k], v, "gD " + k, l2=l2, mx=4e-2 if variant == "F(6x6,3x3)" else 1e-2)
     for k, v in ref.last["grads_G"].items():
         if v is not None and k not in O.shadowed_bias_keys("G", 6):
-            grad_close(gG[k], v, "gG " + k)
+            grad_close(gG[k], v, "gG " + k, l2=l2, mx=4e-2 if variant == "F(6x6,3x3)" else 1e-2)
 
 
 @pytest.mark.parametrize("micro", [1, 2])
@@ -241,14 +248,22 @@ def test_fullsize_generator_engine_against_oracle(golden_dir, nb, pad, size):
     if pad == 0 and size == 256:   # the reference's own output on this tile (committed by oracle/make_golden.py)
         z5 = load(golden_dir, "f5_fullsize.npz")
         close(pred.detach().cpu().flatten()[torch.from_numpy(z5[f"g{nb}_idx"])], z5[f"g{nb}_samples"], 1e-3, "pred vs reference samples")
+    # the oracle takes the ReLU branches the device took (see test_fullsize_fused_step_against_oracle): both evaluate the same smooth
+    # function and every gradient tensor is held to 3e-4; unforced, the activations within fp32 rounding of zero that flip move the
+    # tensors by 4e-3 .. 7e-3 and single elements by 7e-2 (the kink noise of DESIGN 4, not kernel error)
+    kinks = generator_kinks(netG._pool().free[(1, size, size, pad, True)][-1])
     p64 = leaf64(sd)
-    ref = O.px_forward(p64, rgb.double(), nb, pad)
-    ref.backward(dout.double())
+    with O.forced_kinks(kinks):
+        ref = O.px_forward(p64, rgb.double(), nb, pad)
+        ref.backward(dout.double())
     close(pred, ref, 1e-3, "pred")
     shadow = O.shadowed_bias_keys("G", nb)
+    worst = 0.0
     for k, p in netG.named_parameters():
         if k not in shadow:
-            grad_close64(p.grad, p64[k].grad, "gG " + k, l2=6e-3)
+            worst = max(worst, ((p.grad.double().cpu() - p64[k].grad).norm() / p64[k].grad.norm()).item())
+            grad_close64(p.grad, p64[k].grad, "gG " + k, l2=3e-4, mx=3e-3)
+    print(f"generator {nb} blocks pad {pad}, kinks forced: worst rel-L2 over the gradient tensors {worst:.2e}")
 
 
 def test_fullsize_discriminator_engine_against_oracle():
@@ -373,7 +388,9 @@ def test_batch16_properties():
         p16b = netG(rgb)
         p4 = netG(rgb[4:8].contiguous())
     assert torch.equal(p16, p16b), "forward is not deterministic"
-    close(p16[4:8], p4, 1e-4, "sample independence")       # same tiles, other batch: only the reduction order differs
+    # same tiles, other batch: only the reduction order of the instance-norm statistics differs (chunking depends on B), a ~1e-7
+    # difference in mean / rstd that the 14 normalised layers and the F(6x6,3x3) transforms carry to 1e-4 of the output's range
+    close(p16[4:8], p4, 3e-4, "sample independence")
     netG.train()
     tr = Pix2PixTrainer(netG, netD, n_blocks=6)
     for _ in range(3):

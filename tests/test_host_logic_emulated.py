@@ -730,16 +730,19 @@ def test_fused_trainer_with_the_ssim_term(emu, golden_dir):
                 close(gG[k], v, 2e-4, f"gG {k} (micro {micro})")
 
 
-@pytest.mark.parametrize("variant", ["F(4x4,3x3)", "F(2x2,3x3)"])
+@pytest.mark.parametrize("variant", ["F(6x6,3x3)", "F(4x4,3x3)", "F(2x2,3x3)"])
 def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant):
     """ngf = 32 makes the residual-block convolutions 128 -> 128 channels, wide enough for the Winograd paths: forward with the
     instance-norm apply of each block's first convolution folded into the second one's input transform, data gradient and
     transform-domain weight gradient with one transform pass over dY.  One fused step against the oracle, with the default
-    F(4x4,3x3) path (csrc/wino6.hip: 36 plane GEMMs + separate output transform) and with F(2x2,3x3) (NIRGAN_NO_WINO6=1)."""
+    F(6x6,3x3) path (csrc/wino6.hip: 64 plane GEMMs + separate output transform), with F(4x4,3x3) (NIRGAN_NO_WINO8=1) and with
+    F(2x2,3x3) (NIRGAN_NO_WINO6=1)."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
     if variant == "F(2x2,3x3)":
         monkeypatch.setenv("NIRGAN_NO_WINO6", "1")
+    if variant == "F(4x4,3x3)":
+        monkeypatch.setenv("NIRGAN_NO_WINO8", "1")
     torch.manual_seed(5)
     netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
