@@ -16,8 +16,8 @@ children's status); started under torchrun it is one rank.  WORLD_SIZE must equa
 gradients on the concatenated batch.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel by share of step time
-(round 2: wino6_pair16p_kernel -- the data-gradient plane GEMMs of a Winograd F(4x4,3x3)
-residual-block layer as persistent workgroups + its 36 transform-domain weight-gradient planes in one
+(round 2: wino6_pair16p_kernel -- the data-gradient plane GEMMs of a Winograd F(6x6,3x3)
+residual-block layer as persistent workgroups + its 64 transform-domain weight-gradient planes in one
 grid, 12 launches per step; `roofline_other` lists the other MFMA kernels): EXECUTED FLOPs
 of its launches (2*M*N*K from the descriptors) / their duration, bracketed by HIP events on
 the launch stream inside the timed steps.  `cpu_baseline` times the CPU oracle (a port, on a
@@ -91,7 +91,7 @@ def mfma_probes(trainer):
                 d = args[0]._obj
                 k = "wino6_gemm16p_kernel" if (persistent and d.C == 256) else "wino6_gemm16_kernel"
                 T = w6_tiles(d)
-                kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K          # EXECUTED flops: 36 plane GEMMs [T x C] x [C x K] (36/144 of the direct layer's multiplies)
+                kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K          # EXECUTED flops: the plane GEMMs [T x C] x [C x K] (64/324 of the direct layer's multiplies for F(6x6,3x3))
                 algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
@@ -99,7 +99,7 @@ def mfma_probes(trainer):
                 d, w = args[0]._obj, args[1]._obj
                 k = "wino6_pair16p_kernel" if (persistent and d.C == 256) else "wino6_pair_kernel"
                 T = w6_tiles(d)
-                kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run      # executed: data-gradient plane GEMMs + 36 weight-gradient planes
+                kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run      # executed: data-gradient plane GEMMs + the weight-gradient planes
                 kinds[k][1] += 1
                 pl.probe_idx[i] = k
                 # V of dY read once, U once, M written once; Yt and the forward's V read once, slabs written once
@@ -494,14 +494,16 @@ def main():
                                            "stale, not reported (rerun scripts/refresh_profiles.sh)")
             for r in roofs:
                 if r["kernel"].startswith("wino6"):
-                    r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(4x4,3x3) plane GEMMs (and, in the pair launch, the 36 transform-domain "
-                                          "weight-gradient planes) perform 36/144 of the direct layer's multiplies")
+                    r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd plane GEMMs (and, in the pair launch, the transform-domain weight-gradient "
+                                          "planes) perform 64/324 of the direct layer's multiplies for the F(6x6,3x3) residual-block layers (36/144 with "
+                                          "NIRGAN_NO_WINO8=1) and 49/256 for the PatchGAN's F(4x4,4x4) layer; rows of a plane's last, partly filled M tile "
+                                          "(T = 1936 = 15.1 tiles of 128) are executed but not counted")
                 elif r["kernel"].startswith("wino"):
                     r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(2x2,3x3) part performs 16/36 of the direct layer's "
                                           "multiplies")
                 elif r["kernel"].startswith("wgrad_igemm"):
-                    r["flops_counted"] = ("EXECUTED matrix-pipe flops (includes the 36 transform-domain weight-gradient planes of the Winograd layers: "
-                                          "36/144 of the direct weight gradient's multiplies)")
+                    r["flops_counted"] = ("EXECUTED matrix-pipe flops (includes transform-domain weight-gradient planes of Winograd layers that are "
+                                          "launched on their own)")
             roofs.sort(key=lambda r: -r["share_of_step_time"])
             roof = roofs[0] if roofs else None
             roof_other = roofs[1:] or None

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Derivation (sympy, exact) and fp32 accuracy of Cook-Toom F(4x4,3x3) transforms for several point sets: the matrices of
-csrc/wino6.hip are the output for the points (0, 1, -1, 2, -1/2, inf).  CPU only."""
+"""Derivation (sympy, exact) and fp32 accuracy of Cook-Toom transforms for several point sets.  First part: F(4x4,3x3), whose matrices in
+csrc/wino6.hip are the output for the points (0, 1, -1, 2, -1/2, inf).  Second part (general_test): F(m x m, r x r) for any m, r --
+F(4x4,4x4) over (0, 1, -1, 2, -2, 1/2, inf) = w7_*, F(6x6,3x3) over (0, 1, -1, 2, -2, 1/2, -1/2, inf) = w8_*, and the alternatives that
+were measured against them.  CPU only."""
 import numpy as np, sympy as sp, itertools
 from fractions import Fraction
 def mats(points, m=4, r=3):
@@ -68,3 +70,43 @@ def test(points, seed=0, C=256, T=64):
     print("wgrad: wino32 err/max %.2e  (wino64 %.2e)" % (np.abs(dg32 - dg64).max() / np.abs(dg64).max(), np.abs(wg(np.float64) - dg64).max() / np.abs(dg64).max()))
 for pts in ([0, 1, -1, 2, -2], [0, 1, -1, sp.Rational(1,2), -sp.Rational(1,2)], [0, 1, -1, 2, -sp.Rational(1,2)], [0,1,-1,sp.Rational(1,2),-2]):
     test(pts)
+
+
+# ---------------------------------------------------------------------------------------------------------------- general F(m, r)
+def general_test(points, m, r, C=256, T=48, K=8, seed=0, show=False):
+    n = m + r - 1
+    AT, G, BT = mats(points, m, r)
+    G, BT = scale_rows(G, BT)
+    if show:
+        print("BT ="); sp.pprint(BT); print("G ="); sp.pprint(G); print("AT ="); sp.pprint(AT)
+    ATn, Gn, BTn = (np.array(M.tolist(), dtype=np.float64) for M in (AT, G, BT))
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((T, C, n, n)); g = rng.standard_normal((K, C, r, r)) * 0.02
+    y64 = np.zeros((T, K, m, m))
+    for a in range(r):
+        for b in range(r):
+            y64 += np.einsum('tcij,kc->tkij', d[:, :, a:a+m, b:b+m], g[:, :, a, b])
+    dt = np.float32
+    A_, G_, B_ = ATn.astype(dt), Gn.astype(dt), BTn.astype(dt)
+    U = np.einsum('ia,kcab,jb->kcij', G_, g.astype(dt), G_).astype(dt)
+    V = np.einsum('ia,tcab,jb->tcij', B_, d.astype(dt), B_).astype(dt)
+    M = np.einsum('tcij,kcij->tkij', V, U).astype(dt)
+    y32 = np.einsum('pi,tkij,qj->tkpq', A_, M, A_).astype(dt)
+    e = np.abs(y32 - y64).max() / np.abs(y64).max()
+    dY = rng.standard_normal((T, K, m, m))
+    dg64 = np.zeros((K, C, r, r))
+    for a in range(r):
+        for b in range(r):
+            dg64[:, :, a, b] = np.einsum('tkij,tcij->kc', dY, d[:, :, a:a+m, b:b+m])
+    Yt = np.einsum('pi,tkpq,qj->tkij', A_, dY.astype(dt), A_).astype(dt)
+    dU = np.einsum('tkij,tcij->kcij', Yt, V).astype(dt)
+    dg32 = np.einsum('ia,kcij,jb->kcab', G_, dU, G_).astype(dt)
+    ew = np.abs(dg32 - dg64).max() / np.abs(dg64).max()
+    print(f"F({m}x{m},{r}x{r}) points {points}: forward err/max {e:.2e}   weight gradient err/max {ew:.2e}   |BT|max {np.abs(BTn).max():.1f}")
+h, q, t = sp.Rational(1, 2), sp.Rational(1, 4), sp.Rational(1, 3)
+general_test([0, 1, -1, 2, -h], 4, 3)
+general_test([0, 1, -1, 2, -2, h], 4, 4, show=True)                 # csrc/wino6.hip w7_*
+general_test([0, 1, -1, 2, -2, h, -h], 6, 3, show=True)             # csrc/wino6.hip w8_*
+for pts in ([0, 1, -1, h, -h, 2, -q], [0, 1, -1, sp.Rational(3, 2), -sp.Rational(3, 2), sp.Rational(2, 3), -sp.Rational(2, 3)],
+            [0, 1, -1, h, -h, sp.Rational(3, 2), -sp.Rational(3, 2)], [0, 1, -1, 2, -2, t, -t]):
+    general_test(pts, 6, 3)
