@@ -649,7 +649,12 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     ydesc.B, ydesc.H, ydesc.W, ydesc.K = B, OH, OW, cout
     ydesc.Yt, ydesc.Yt_elems, ydesc.r = Yt.data_ptr(), Yt.numel(), v
     tiles = (-(-cout // 128)) * (-(-cin // 128)) * NP
-    nsplit, rows = G.wgrad_split(T, tiles, 1024)
+    # 256 output channels: the pair launch is 512 persistent workgroups that walk the weight-gradient units before their GEMM tiles
+    # (csrc/wino6.hip::wino6_pair16p_kernel) -- one unit each (two splits per output tile) instead of the two rounds of short blocks
+    # the one-tile-per-workgroup launch wants: half the slab traffic, 743 -> 750 tiles/s
+    persistent = (cout == 256 and os.environ.get("NIRGAN_WINO6_GEMM_NOPERSIST") is None and os.environ.get("NIRGAN_WINO6_WGRAD_NOPERSIST") is None
+                  and os.environ.get("NIRGAN_NO_WINO6_PAIR") != "1" and os.environ.get("NIRGAN_SIDE_STREAM") != "1")
+    nsplit, rows = G.wgrad_split(T, tiles, 512 if persistent else 1024)
     if os.environ.get("NIRGAN_WINO6_SPLITS"):            # experiments
         nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ["NIRGAN_WINO6_SPLITS"]))
     slabs = slabs_pool.get(NP * nsplit * cout * cin)

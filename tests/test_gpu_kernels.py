@@ -926,19 +926,21 @@ def test_wino6_conv3x3_matches_direct(shape):
 
 
 @pytest.mark.parametrize("hw", [(12, 16, 3, 3), (9, 11, 3, 3), (64, 64, 3, 3), (12, 16, 4, 4), (9, 11, 4, 4), (31, 31, 4, 4), (12, 16, 3, 6), (9, 11, 3, 6),
-                                (64, 64, 3, 6), (13, 6, 3, 6)])
+                                (64, 64, 3, 6), (13, 6, 3, 6), (64, 64, 3, 6, 256), (21, 17, 3, 6, 256), (22, 18, 3, 3, 256), (40, 40, 3, 6, 256, 384)])
 def test_wino6_backward_matches_autograd(hw, monkeypatch):
     """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it with F(4x4,3x3): data gradient over the padded
     extent (dY transformed once for both uses), transform-domain weight gradient (36 planes in one weight-gradient launch, then
     G^T dU G) against torch autograd of conv2d in float64; device and numpy restatement.  Even and odd extents; V re-derived from the
     forward input here (the nets keep the forward's V: covered by the net-level tests)."""
     from nirgan_hip.engine import emit_wino6, emit_wino6_backward, SlabPool, _FullExtent
-    H, W, r, v = hw                                   # H x W = the layer's OUTPUT extent; its input is (H + r - 3) x (W + r - 3) + halo 1
+    H, W, r, v = hw[:4]                               # H x W = the layer's OUTPUT extent; its input is (H + r - 3) x (W + r - 3) + halo 1
     if v == 3:
         monkeypatch.setenv("NIRGAN_NO_WINO8", "1")    # 3x3 filters: F(4x4,3x3) instead of the default F(6x6,3x3)
     from nirgan_hip.engine import wino6_variant
     assert wino6_variant(r) == v
-    B, Cin, Cout = 2, 128, 128
+    # 256 input channels of the data-gradient GEMM (= the layer's output channels) take the persistent pair launch: the transform-domain
+    # weight gradient and the plane GEMMs walked by the same 512 workgroups (csrc/wino6.hip::wino6_pair16p_kernel)
+    B, Cin, Cout = 2, (hw[5] if len(hw) > 5 else hw[4] if len(hw) > 4 else 128), (hw[4] if len(hw) > 4 else 128)
     g = torch.Generator().manual_seed(12)
     x = torch.randn(B, H + r - 1, W + r - 1, Cin, generator=g)
     w = torch.randn(Cout, Cin, r, r, generator=g) * 0.05
