@@ -1187,8 +1187,8 @@ extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const ni
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit * wp.nplanes;
-    static const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;
-    static const bool no_persist_wgrad = getenv("NIRGAN_WINO6_WGRAD_NOPERSIST") != nullptr;
+    const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;          // (read per launch: the tests switch it)
+    const bool no_persist_wgrad = getenv("NIRGAN_WINO6_WGRAD_NOPERSIST") != nullptr;
     if (w6_persistent_ok(d) && !no_persist) {
         NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm_wgrad_pair: pointers must be 16-byte aligned");
         const W6G16 q = w6_g16_params(d, T);
@@ -1217,7 +1217,7 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
         // 16-k stages, up to four resident workgroups per CU (see wino6_gemm16_kernel)
         NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm: pointers must be 16-byte aligned");
         const W6G16 q = w6_g16_params(d, T);
-        static const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;
+        const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;          // (read per launch: the tests switch it)
         if (w6_persistent_ok(d) && !no_persist) {
             // persistent workgroups, epilogue folded into the next tile's K loop: 2 per CU
             const int grid = q.total < 512 ? q.total : 512;

@@ -926,7 +926,8 @@ def test_wino6_conv3x3_matches_direct(shape):
 
 
 @pytest.mark.parametrize("hw", [(12, 16, 3, 3), (9, 11, 3, 3), (64, 64, 3, 3), (12, 16, 4, 4), (9, 11, 4, 4), (31, 31, 4, 4), (12, 16, 3, 6), (9, 11, 3, 6),
-                                (64, 64, 3, 6), (13, 6, 3, 6), (64, 64, 3, 6, 256), (21, 17, 3, 6, 256), (22, 18, 3, 3, 256), (40, 40, 3, 6, 256, 384)])
+                                (64, 64, 3, 6), (13, 6, 3, 6), (64, 64, 3, 6, 256), (21, 17, 3, 6, 256), (22, 18, 3, 3, 256), (40, 40, 3, 6, 256, 384),
+                                (64, 64, 3, 6, 256, 256, "NIRGAN_WINO6_WGRAD_NOPERSIST"), (64, 64, 3, 6, 256, 256, "NIRGAN_WINO6_GEMM_NOPERSIST")])
 def test_wino6_backward_matches_autograd(hw, monkeypatch):
     """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it with F(4x4,3x3): data gradient over the padded
     extent (dY transformed once for both uses), transform-domain weight gradient (36 planes in one weight-gradient launch, then
@@ -934,6 +935,8 @@ def test_wino6_backward_matches_autograd(hw, monkeypatch):
     forward input here (the nets keep the forward's V: covered by the net-level tests)."""
     from nirgan_hip.engine import emit_wino6, emit_wino6_backward, SlabPool, _FullExtent
     H, W, r, v = hw[:4]                               # H x W = the layer's OUTPUT extent; its input is (H + r - 3) x (W + r - 3) + halo 1
+    if len(hw) > 6:
+        monkeypatch.setenv(hw[6], "1")                # the A/B fallbacks of the persistent pair launch (csrc/wino6.hip reads them per launch)
     if v == 3:
         monkeypatch.setenv("NIRGAN_NO_WINO8", "1")    # 3x3 filters: F(4x4,3x3) instead of the default F(6x6,3x3)
     from nirgan_hip.engine import wino6_variant
