@@ -167,6 +167,10 @@ typedef struct {
     float* ws; int64_t ws_elems;          /* >= B * nchunk * 2 * C floats, see nirgan_instnorm_ws_elems */
     void* out_bf16;                       /* optional twin of `out` (same geometry, bf16 elements): every store is mirrored, rounded
                                            * to nearest even -- the operand the bf16 mode's convolutions read (in_bf16) */
+    int stats_chunks;                     /* > 0 (with norm): the producer of y already left the per-(b, c) partial sums
+                                           * S1 = sum (y - shift_c), S2 = sum (y - shift_c)^2 in ws as [B][stats_chunks][2][C]
+                                           * (nirgan_wino6_output with stats_ws): the pass over y that would form them is skipped */
+    const float* stats_shift;             /* [C], the shift those sums are taken about (the convolution's bias); NULL = 0 */
 } nirgan_in_fwd_desc;
 
 int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C);
@@ -505,6 +509,10 @@ typedef struct {
                                              T = B * ceil(H/6) * ceil(W/6) (nirgan_wino6_tiles_r); Cook-Toom over 0, 1, -1, 2, -2, 1/2, -1/2, inf;
                                              fp32 error 1.7e-5 of the output's maximum.  The same code goes into nirgan_wino_dy_desc.r,
                                              nirgan_wino6_weights_r and nirgan_wino6_wgrad_finish_r for the layer */
+    float* stats_ws; int64_t stats_ws_elems;   /* optional (nirgan_wino6_output): per-tile partial sums of the output for the instance norm that
+                                             follows, [B][tiles per image][2][K] = T * 2 * K floats: sum and sum of squares of the tile's
+                                             stored outputs WITHOUT the bias (i.e. about the shift `bias`); feed nirgan_instnorm_fwd with
+                                             ws = stats_ws, stats_chunks = tiles per image, stats_shift = bias */
 } nirgan_wino6_desc;
 
 int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T of the 4x4-output variants */

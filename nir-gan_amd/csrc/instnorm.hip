@@ -33,6 +33,7 @@ struct InFwd {
     float* out; int o_row, o_img, o_pad, border;
     float* ws; int nchunk, ppc;
     unsigned short* out16;
+    int pre_chunks; const float* shift;      // partial sums left by the producer of y: chunk count and the shift they are taken about
 };
 
 __global__ __launch_bounds__(256) void in_stats_kernel(const InFwd p) {
@@ -84,11 +85,14 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const InFwd p, int B) 
     __shared__ f32x4 lds[512];
     const int b = blockIdx.x, tid = threadIdx.x;
     f32x4 s1, s2;
-    chunk_sums(p.ws + size_t(b) * p.nchunk * 2 * p.C, p.nchunk, p.C, tid, lds, s1, s2);
+    const int nchunk = p.pre_chunks > 0 ? p.pre_chunks : p.nchunk;
+    chunk_sums(p.ws + size_t(b) * nchunk * 2 * p.C, nchunk, p.C, tid, lds, s1, s2);
     if (tid >= p.C / 4) return;
     const int q = tid;
     const float inv = 1.f / float(p.HW);
-    const f32x4 k = ld4(p.y + size_t(b) * p.HW * p.C + q * 4);
+    f32x4 k = {0.f, 0.f, 0.f, 0.f};
+    if (p.pre_chunks > 0) { if (p.shift != nullptr) k = ld4(p.shift + q * 4); }
+    else k = ld4(p.y + size_t(b) * p.HW * p.C + q * 4);
     const f32x4 m = s1 * inv;
     f32x4 var = s2 * inv - m * m, rstd;
 #pragma unroll
@@ -272,9 +276,12 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
     p.out16 = static_cast<unsigned short*>(d->out_bf16);
     NG_REQUIRE(!d->out_bf16 || (d->C % 8 == 0 && (reinterpret_cast<uintptr_t>(d->out_bf16) & 15) == 0), "instnorm_fwd: bf16 twin needs C %% 8 == 0 and 16-byte alignment");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    p.pre_chunks = d->norm && d->stats_chunks > 0 ? d->stats_chunks : 0;
+    p.shift = d->stats_shift;
     if (d->norm) {
-        NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
-        hipLaunchKernelGGL(in_stats_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+        NG_REQUIRE(ng_aligned16(d->stats_shift), "instnorm_fwd: stats_shift must be 16-byte aligned");
+        NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * (p.pre_chunks > 0 ? p.pre_chunks : p.nchunk) * 2 * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
+        if (p.pre_chunks == 0) hipLaunchKernelGGL(in_stats_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
         hipLaunchKernelGGL(in_finalize_kernel, dim3(d->B), dim3(256), 0, st, p, d->B);
     }
     if (!stats_only) hipLaunchKernelGGL(in_apply_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);

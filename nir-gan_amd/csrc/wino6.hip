@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256, 2) void wino6_pair16_kernel(const W6G16 q, con
 }
 
 // ------------------------------------------------------------------------------------------------ output transform
-struct W6Out { const float* M; const float* bias; float* y; int B, H, W, K, TH, TW; long long T; };
+struct W6Out { const float* M; const float* bias; float* y; int B, H, W, K, TH, TW; long long T; float* stats; };
 
 template <int V>
 __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
@@ -943,6 +943,9 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
     for (int e = 0; e < VW; ++e) bv[e] = 0.f;
     if (p.bias != nullptr) bv = *reinterpret_cast<const V4*>(p.bias + q * VW);
     float* yb = p.y + size_t(b) * p.H * p.W * p.K + q * VW;
+    // partial sums for the instance norm that follows (sum and sum of squares of this tile's stored outputs, taken about the bias):
+    // the statistics pass over y is not needed then
+    V4 s1 = bv * 0.f, s2 = bv * 0.f;
 #pragma unroll
     for (int a = 0; a < MO; ++a) {
         V4 o[MO];
@@ -952,8 +955,17 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
 #pragma unroll
         for (int c = 0; c < MO; ++c) {
             const int w = MO * tx + c;
-            if (w < p.W) *reinterpret_cast<V4*>(yb + (size_t(h) * p.W + w) * p.K) = o[c] + bv;
+            if (w < p.W) {
+                *reinterpret_cast<V4*>(yb + (size_t(h) * p.W + w) * p.K) = o[c] + bv;
+                s1 += o[c];
+                s2 += o[c] * o[c];
+            }
         }
+    }
+    if (p.stats != nullptr) {
+        float* sp = p.stats + size_t(t) * 2 * p.K + q * VW;
+        *reinterpret_cast<V4*>(sp) = s1;
+        *reinterpret_cast<V4*>(sp + p.K) = s2;
     }
 }
 
@@ -1239,7 +1251,8 @@ extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
     NG_REQUIRE(ng_aligned16(d->M) && ng_aligned16(d->y) && ng_aligned16(d->bias), "wino6_output: pointers must be 16-byte aligned");
     const long long T = w6_tiles(d->B, d->H, d->W, v);
     NG_REQUIRE(d->M_elems >= w6_np(v) * T * d->K, "wino6_output: M workspace too small");
-    W6Out p{d->M, d->bias, d->y, d->B, d->H, d->W, d->K, (d->H + mo - 1) / mo, (d->W + mo - 1) / mo, T};
+    NG_REQUIRE(!d->stats_ws || (d->stats_ws_elems >= T * 2 * d->K && ng_aligned16(d->stats_ws)), "wino6_output: stats_ws too small or unaligned");
+    W6Out p{d->M, d->bias, d->y, d->B, d->H, d->W, d->K, (d->H + mo - 1) / mo, (d->W + mo - 1) / mo, T, d->stats_ws};
     const long long n = T * (d->K / (v == 3 ? 4 : 2));
     const dim3 grid(unsigned((n + 255) / 256));
     if (v == 3) hipLaunchKernelGGL(wino6_output_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);

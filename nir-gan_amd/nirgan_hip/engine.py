@@ -573,7 +573,7 @@ def _w6_tiles(B, H, W, v: int = 3) -> int:
 
 
 def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y, *, H, W, cin, cout, flip=False,
-               own_V: bool = False, x_norm=None, r: int = 3):
+               own_V: bool = False, x_norm=None, r: int = 3, stats_ws: Optional[torch.Tensor] = None):
     """U = G g G^T in the pack plan; input transform, (r+3)^2 plane GEMMs, output transform in `plan` (None: the caller places them).
     x: [B][H+r-1][W+r-1][cin] buffer, y: dense [B][H][W][cout].  flip: data gradient (x = dY with a zero halo of r-1, H x W = padded input)."""
     assert x.hp == H + r - 1 and x.wp == W + r - 1 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
@@ -599,6 +599,9 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
     d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
     d.zero_page = ctx.zero_page.data_ptr()
+    if stats_ws is not None:        # the output transform leaves the instance norm's partial sums (one chunk per tile): no statistics pass over y
+        assert stats_ws.numel() >= T * 2 * cout
+        d.stats_ws, d.stats_ws_elems = stats_ws.data_ptr(), stats_ws.numel()
     ctx.keep.append(d)
     if plan is not None:
         if x_norm is not None:             # (y, (mean, rstd), act) of the producer: its apply pass is folded into this transform
@@ -715,8 +718,9 @@ class SlabPool:
 
 
 def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.ACT_NONE, slope=0.2, residual: Optional[Halo] = None,
-                border=L.BORDER_KEEP, stats=None, ws=None, stats_only=False):
-    """stats_only: mean / rstd only -- the layer's single consumer normalises on the fly (nirgan_wino_input_norm), `out` stays unwritten."""
+                border=L.BORDER_KEEP, stats=None, ws=None, stats_only=False, pre_stats=None):
+    """stats_only: mean / rstd only -- the layer's single consumer normalises on the fly (nirgan_wino_input_norm), `out` stays unwritten.
+    pre_stats = (chunks per sample, shift tensor or None): the producer of y left the partial sums in `ws` (nirgan_wino6_output)."""
     assert y.pad == 0 and out.H == y.H and out.W == y.W and out.C == y.C
     assert not stats_only or (norm and residual is None)
     d = L.InFwdDesc()
@@ -725,6 +729,8 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
     if norm:
         d.mean, d.rstd = stats[0].data_ptr(), stats[1].data_ptr()
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
+        if pre_stats is not None:
+            d.stats_chunks, d.stats_shift = pre_stats[0], _ptr(pre_stats[1])
     d.act, d.slope = act, slope
     if residual is not None:
         d.residual, d.r_hp, d.r_wp, d.r_pad = residual.ptr, residual.hp, residual.wp, residual.pad
@@ -825,14 +831,23 @@ class ConvIN:
     def emit_fwd(self, plan: Plan, pack: Plan):
         eng, ctx, inp = self.eng, self.eng.ctx, self.inp
         k, s, p = self.k, self.s, self.p
+        pre = None          # (chunks per sample, shift, workspace) when the convolution's last kernel leaves the instance norm's partial sums
         if self.kind == "conv" and wino_applicable(ctx, inp, k, s, p, self.cout, self.OH, self.OW):
             keep = bool(getattr(eng, "need_backward", False)) and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"
             prod = getattr(self, "producer", None)
             xn = (prod.y, prod.stats, prod.act) if prod is not None and getattr(prod, "defer_apply", False) else None
             if wino6_applicable(ctx, k, self.cout):
                 self.wino6 = True
+                sws = None
+                if self.norm and os.environ.get("NIRGAN_NO_WINO6_STATS") != "1":
+                    # instance-norm statistics from the output transform's own pass (one chunk of partial sums per tile)
+                    T = _w6_tiles(inp.B, self.OH, self.OW, wino6_variant(k))
+                    if not hasattr(ctx, "wino6_pool_stats"):
+                        ctx.wino6_pool_stats = SplitPool(ctx)
+                    sws = ctx.wino6_pool_stats.get(T * 2 * self.cout)
+                    pre = (T // inp.B, self.bias, sws)
                 self.wino_fwd = emit_wino6(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
-                                           cout=self.cout, own_V=keep, x_norm=xn, r=k)
+                                           cout=self.cout, own_V=keep, x_norm=xn, r=k, stats_ws=sws)
             else:
                 self.wino_fwd = emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
                                           cout=self.cout, own_V=keep, r=k, x_norm=xn)
@@ -857,8 +872,8 @@ class ConvIN:
                                        out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow))
             emit_conv_group(plan, ctx, descs)
         emit_in_fwd(plan, ctx, self.y, self.out, norm=self.norm, act=(L.ACT_NONE if self.keep_z else self.act),
-                    residual=self.residual, border=self.out_border, stats=self.stats, ws=eng.scratch.get(),
-                    stats_only=getattr(self, "defer_apply", False))
+                    residual=self.residual, border=self.out_border, stats=self.stats, ws=(pre[2] if pre is not None else eng.scratch.get()),
+                    stats_only=getattr(self, "defer_apply", False), pre_stats=(pre[:2] if pre is not None else None))
 
     # ---- backward: g (+g2) is the gradient wrt `out`; produces dy (zero halo) then weight / data gradients
     def alloc_bwd(self, need_dgrad: bool):

@@ -48,7 +48,7 @@ class InFwdDesc(C.Structure):
                 ("mean", fp), ("rstd", fp), ("act", i32), ("slope", f32),
                 ("residual", fp), ("r_hp", i32), ("r_wp", i32), ("r_pad", i32),
                 ("out", fp), ("o_hp", i32), ("o_wp", i32), ("o_pad", i32), ("border", i32),
-                ("ws", fp), ("ws_elems", i64), ("out_bf16", fp)]
+                ("ws", fp), ("ws_elems", i64), ("out_bf16", fp), ("stats_chunks", i32), ("stats_shift", fp)]
 
 
 class InBwdDesc(C.Structure):
@@ -136,7 +136,7 @@ class WinoDyDesc(C.Structure):
 
 class Wino6Desc(C.Structure):
     _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
-                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32)]
+                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32), ("stats_ws", fp), ("stats_ws_elems", i64)]
 
 
 class EndConvDesc(C.Structure):

@@ -604,6 +604,17 @@ class EmuBackend:
         M = arr(d.M, n * n * B * TH * TW * K).reshape(n, n, B, TH, TW, K).astype(np.float64)
         AT = self._W6[v][2]
         Y = np.einsum("pa,albyxk,ql->bypxqk", AT, M, AT).reshape(B, mo * TH, mo * TW, K)
+        if d.stats_ws:
+            # per-tile partial sums of the stored outputs, without the bias
+            if d.stats_ws_elems < B * TH * TW * 2 * K:
+                return self._fail("wino6_output: stats_ws too small")
+            Yv = Y.copy()
+            Yv[:, H:] = 0
+            Yv[:, :, W:] = 0
+            tiles = Yv.reshape(B, TH, mo, TW, mo, K)
+            st = arr(d.stats_ws, B * TH * TW * 2 * K).reshape(B, TH, TW, 2, K)
+            st[:, :, :, 0] = tiles.sum((2, 4))
+            st[:, :, :, 1] = (tiles ** 2).sum((2, 4))
         bias = arr(d.bias, K)
         if bias is not None:
             Y = Y + bias
@@ -817,10 +828,22 @@ class EmuBackend:
             return self._fail("in_fwd: geometry")
         y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float64)
         if d.norm:
-            if d.ws_elems < self.nirgan_instnorm_ws_elems(B, H, W, Cc):
-                return self._fail("in_fwd: ws too small")
-            mean = y.mean(1)
-            var = y.var(1)
+            if d.stats_chunks > 0:
+                # partial sums left by the producer (nirgan_wino6_output): [B][chunks][2][C] about the shift
+                n = d.stats_chunks
+                if d.ws_elems < B * n * 2 * Cc:
+                    return self._fail("in_fwd: ws too small")
+                self.calls.append("in_fwd_pre")
+                part = arr(d.ws, B * n * 2 * Cc).reshape(B, n, 2, Cc).astype(np.float64).sum(1)
+                k = arr(d.stats_shift, Cc).astype(np.float64) if d.stats_shift else np.zeros(Cc)
+                m = part[:, 0] / (H * W)
+                mean = k + m
+                var = np.maximum(part[:, 1] / (H * W) - m * m, 0.0)
+            else:
+                if d.ws_elems < self.nirgan_instnorm_ws_elems(B, H, W, Cc):
+                    return self._fail("in_fwd: ws too small")
+                mean = y.mean(1)
+                var = y.var(1)
             rstd = 1.0 / np.sqrt(var + d.eps)
             arr(d.mean, B * Cc).reshape(B, Cc)[:] = mean
             arr(d.rstd, B * Cc).reshape(B, Cc)[:] = rstd

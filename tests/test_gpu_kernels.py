@@ -1079,3 +1079,50 @@ def test_direct_last_layer_kernels(shape):
     B, OH, OW, crop = shape
     run_endconv(DEV, B, OH, OW, crop)
     run_endconv(DEV, 1, 8, 8, 0, act=L.ACT_NONE) if B == 2 and OH == 9 else None
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 16, 64, 128, 6), (16, 64, 64, 256, 256, 6), (3, 9, 7, 32, 128, 3), (2, 31, 31, 64, 128, 4)])
+def test_wino6_output_leaves_the_instance_norm_partial_sums(shape):
+    """nirgan_wino6_output with stats_ws + nirgan_instnorm_fwd(stats_chunks, stats_shift = bias) gives the mean / rstd of the
+    separate statistics pass over y (model/networks.py:30: InstanceNorm2d, biased variance): same sums in another order and about
+    another shift (the bias instead of the first pixel), so equal to fp32 rounding; ragged tiles count only their stored outputs."""
+    import ctypes as C
+    B, H, W, Cc, K, v = shape
+    r, mo = (3, 6) if v == 6 else (v, 4)
+    NP = (mo + r - 1) ** 2
+    g = torch.Generator().manual_seed(41)
+    be = L.backend()
+    T = int(be.nirgan_wino6_tiles_r(B, H, W, v))
+    x = torch.randn(B, H + r - 1, W + r - 1, Cc, generator=g).to(DEV)
+    w = (torch.randn(K, Cc, r, r, generator=g) * 0.05).to(DEV)
+    bias = (torch.randn(K, generator=g) * 2.0).to(DEV)                   # a large bias: the shift matters
+    U, V, M = torch.zeros(NP * K * Cc, device=DEV), torch.zeros(NP * T * Cc, device=DEV), torch.zeros(NP * T * K, device=DEV)
+    y = torch.zeros(B, H, W, K, device=DEV)
+    zero = torch.zeros(64, device=DEV)
+    sws = torch.full((T * 2 * K,), float("nan"), device=DEV)
+    d = L.Wino6Desc()
+    d.r = v
+    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = x.data_ptr(), H + r - 1, W + r - 1, B, H, W, Cc, K
+    d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems = U.data_ptr(), bias.data_ptr(), V.data_ptr(), V.numel(), M.data_ptr(), M.numel()
+    d.y, d.zero_page, d.stats_ws, d.stats_ws_elems = y.data_ptr(), zero.data_ptr(), sws.data_ptr(), sws.numel()
+    st = torch.cuda.current_stream().cuda_stream
+    L.call("nirgan_wino6_weights_r", w.data_ptr(), K, Cc, v, 0, U.data_ptr(), st)
+    L.call("nirgan_wino6_conv3x3", C.byref(d), st)
+    res = []
+    for pre in (True, False):
+        mean, rstd = torch.zeros(B, K, device=DEV), torch.zeros(B, K, device=DEV)
+        ws = sws if pre else torch.zeros(int(be.nirgan_instnorm_ws_elems(B, H, W, K)), device=DEV)
+        n = L.InFwdDesc()
+        n.y, n.B, n.H, n.W, n.C, n.norm, n.eps = y.data_ptr(), B, H, W, K, 1, 1e-5
+        n.mean, n.rstd, n.ws, n.ws_elems = mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel()
+        if pre:
+            n.stats_chunks, n.stats_shift = T // B, bias.data_ptr()
+        L.call("nirgan_instnorm_fwd", C.byref(n), st)
+        torch.cuda.synchronize()
+        res.append((mean.cpu(), rstd.cpu()))
+    y64 = y.double().cpu().reshape(B, H * W, K)
+    close(res[0][0], y64.mean(1), 1e-6, "mean from the output transform's partial sums")
+    close(res[1][0], y64.mean(1), 1e-6, "mean from the statistics pass")
+    ref_rstd = 1.0 / torch.sqrt(y64.var(1, unbiased=False) + 1e-5)
+    close(res[0][1], ref_rstd, 2e-6, "rstd from the output transform's partial sums")
+    close(res[1][1], ref_rstd, 2e-6, "rstd from the statistics pass")

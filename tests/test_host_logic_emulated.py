@@ -758,6 +758,7 @@ def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant
         assert emu.calls.count("wino6_in_norm") == 6 and emu.calls.count("wino6_gemm") == 24 and emu.calls.count("wino6_out") == 24
         assert emu.calls.count("wino6_fin") == 12 and emu.calls.count("wino6_dy") == 12 and "wino_in_norm" not in emu.calls
         assert emu.calls.count("wino6_in") == 6 + 12          # c1 forwards + the dY transforms (no re-transform of the forward input)
+        assert emu.calls.count("in_fwd_pre") == 12             # instance-norm statistics from the output transforms' partial sums
     ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
     o = ref.step(rgb, nir)
     close(tr.G.pred, ref.last["pred"], 2e-5, "pred")
