@@ -714,6 +714,170 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
     }
 }
 
+// The fp32 128 x 128 weight-gradient tile as PERSISTENT workgroups (round 2).  Equal tiles keep the resident workgroups of a CU in
+// lockstep, so their MFMA-free phases (first DMA wait, epilogue through LDS) coincide instead of filling each other; here a workgroup
+// walks its (plane, split, tile) units -- unit, unit + stride, ... -- as ONE stream of 32-pixel K-steps with the LDS images and
+// fragment reads of wgrad_tile<128, 0>, issues the next unit's first DMA during this unit's last step, and drains the finished
+// unit's accumulators (a second set, 64 AGPRs) two 8-byte stores per K-step straight from registers: a lane's (acc[e][0][r],
+// acc[e][1][r]) are two adjacent columns of a slab row, 32 lanes = 256 contiguous bytes, no LDS transpose.
+// For problems in MATRIX FORM only: both operands plain row-major matrices per plane (one tap, unit stride, one image row -- the
+// transform-domain weight gradient dU[f] = Yt[f]^T V[f] of the Winograd layers), where the pixel walk reduces to `t * row stride`.
+// The same skeleton with wgrad_tile's general walk (taps, strides, (b, oh, ow) advanced per step) was built and measured on the
+// stride-2 / transposed layers' weight gradients: correct, but 256 VGPRs + 320 B of scratch and the walk inside 16 unrolled steps made
+// it 40-50 % SLOWER than one tile per workgroup (582 vs 383 us); removed.
+// Host: every split holds rows (nk >= 1), fp32 operands, N > 64 (wgrad_persist_ok && wgrad_matrix_form).
+struct WgradUnit { const float* Pp; const float* Qp; float* slab; int n0, j0, mstart, mend, nk; bool p_ok, q_ok; int p_n, q_add; };
+
+__device__ __forceinline__ void wgrad_persist(const WgradParams& p, const int first, const int stride, char* lds) {
+    constexpr int TN = 128, P_BYTES = 32 * TN * 4, Q_BYTES = 32 * 128 * 4, STAGE = P_BYTES + Q_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.ntiles_n * p.ntiles_k, per_plane = tiles * p.nsplit, total = per_plane * p.nplanes;
+    const int lrow = lane >> 5, chunk = lane & 31;
+
+    auto setup = [&](int logical, WgradUnit& u) {
+        const int rid = ng_xcd_remap(logical, total);
+        const int plane = rid / per_plane, id = rid - plane * per_plane;
+        const int split = id / tiles, tile = id - split * tiles;
+        u.n0 = (tile % p.ntiles_n) * TN;
+        u.j0 = (tile / p.ntiles_n) * 128;
+        u.mstart = split * p.rows_per_split;
+        const int mend = u.mstart + p.rows_per_split;
+        u.mend = mend < p.M ? mend : p.M;
+        u.nk = (u.mend - u.mstart + 31) >> 5;
+        u.Pp = p.p + size_t(plane) * p.p_plane + p.p_org;
+        u.Qp = p.q + size_t(plane) * p.q_plane + p.q_org;
+        u.slab = p.slabs + (size_t(plane) * p.nsplit + split) * p.N * p.K;
+        u.p_ok = u.n0 + chunk * 4 < p.N;
+        u.p_n = u.p_ok ? u.n0 + chunk * 4 : 0;
+        const int q_j = u.j0 + chunk * 4;
+        u.q_ok = q_j < p.K;
+        u.q_add = 0;
+        if (u.q_ok) u.q_add = q_j;
+    };
+    // wave w owns P pieces 4w .. 4w+3 and Q pieces 4w .. 4w+3 (a piece = 2 pixel rows x 512 B); mb = first pixel of the step
+    auto issue = [&](const WgradUnit& u, char* sP, int mb) {
+        char* sQ = sP + P_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ins = wave * 4 + i;
+            const int t = mb + ins * 2 + lrow;
+            ng_glds16((u.p_ok && t < u.mend) ? u.Pp + (t * p.p_cs + u.p_n) : p.zero, sP + ins * 1024);
+            // rows past M meet P = 0: any valid address does
+            ng_glds16(u.q_ok ? u.Qp + ((t < p.M ? t : 0) * p.q_cs + u.q_add) : p.zero, sQ + ins * 1024);
+        }
+    };
+
+    const int wr = wave >> 1, wc = wave & 1, half = lane >> 5;
+    const int a_off = half * (TN * 4) + (wr * (TN / 2) + 2 * (lane & 31)) * 4;
+    const int b_off = half * 512 + (wc * 64 + 2 * (lane & 31)) * 4;
+    // 4 pixel-pair steps per group: the 8 fragment reads of group g+1 are issued before the 16 MFMAs of group g
+    auto compute = [&](const char* sP, f32x16 (&acc)[2][2]) {
+        const char* sQ = sP + P_BYTES;
+        __builtin_amdgcn_s_setprio(2);
+        f32x2 a[2][4], b[2][4];
+        auto load = [&](int g, int slot) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kk = 4 * g + i;
+                a[slot][i] = *reinterpret_cast<const f32x2*>(sP + a_off + kk * (2 * TN * 4));
+                b[slot][i] = *reinterpret_cast<const f32x2*>(sQ + b_off + kk * 1024);
+            }
+        };
+        load(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) load(g + 1, (g + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][0], acc[e][0], 0, 0, 0);
+                    acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][1], acc[e][1], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // piece q = (e, r): accumulator row i = (r & 3) + 8 (r >> 2) + 4 half  ->  slab row n0 + wr * 64 + 2 i + e, columns j0 + wc * 64 + 2 (lane & 31) + {0, 1}
+    struct Done { float* slab; int n0, j0; };                     // what the drain of a finished unit needs
+    auto drain = [&](const f32x16 (&acc)[2][2], int q, const Done& u) {
+        const int e = q >> 4, r = q & 15;
+        const int n = u.n0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + e;
+        const int c = u.j0 + wc * 64 + 2 * (lane & 31);
+        if (n < p.N && c < p.K) {                                  // K % 4 == 0 and c even: both columns exist
+            f32x2 v;
+            v[0] = acc[e][0][r];
+            v[1] = acc[e][1][r];
+            *reinterpret_cast<f32x2*>(u.slab + size_t(n) * p.K + c) = v;
+        }
+    };
+    auto zero = [&](f32x16 (&acc)[2][2]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+    };
+
+    f32x16 accA[2][2], accB[2][2];
+    int step = 0;
+    WgradUnit ucur, unext;
+    Done uprev = {nullptr, 0, 0};
+    auto one_step = [&](f32x16 (&cur)[2][2], int s, int next_logical) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < ucur.nk) issue(ucur, lds + ((step + 1) & 1) * STAGE, ucur.mstart + (s + 1) * 32);
+        else if (next_logical < total) {
+            setup(next_logical, unext);
+            issue(unext, lds + ((step + 1) & 1) * STAGE, unext.mstart);
+        }
+        compute(lds + (step & 1) * STAGE, cur);
+        ++step;
+    };
+    auto run_unit = [&](f32x16 (&cur)[2][2], const f32x16 (&prev)[2][2], bool have_prev, int next_logical) {
+        zero(cur);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                       // compile-time piece indices: register-indexed drain
+            if (have_prev) { drain(prev, 2 * s, uprev); drain(prev, 2 * s + 1, uprev); }
+            if (s < ucur.nk) one_step(cur, s, next_logical);
+        }
+        for (int s = 16; s < ucur.nk; ++s) one_step(cur, s, next_logical);
+        uprev = Done{ucur.slab, ucur.n0, ucur.j0};
+        ucur = unext;
+    };
+    if (first >= total) return;
+    setup(first, ucur);
+    issue(ucur, lds, ucur.mstart);
+    int logical = first;
+    bool have_prev = false;
+    while (true) {
+        run_unit(accA, accB, have_prev, logical + stride);
+        logical += stride;
+        have_prev = true;
+        if (logical >= total) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) drain(accA, q, uprev);
+            break;
+        }
+        run_unit(accB, accA, true, logical + stride);
+        logical += stride;
+        if (logical >= total) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) drain(accB, q, uprev);
+            break;
+        }
+    }
+}
+
+// whether wgrad_persist covers a problem: the wide fp32 tile, rows in every split
+inline bool wgrad_persist_ok(const WgradParams& p) {
+    return p.prec == 0 && !p.pq_bf16 && p.N > 64 && p.K % 4 == 0 && (long long)(p.nsplit - 1) * p.rows_per_split < p.M;
+}
+inline bool wgrad_matrix_form(const WgradParams& p) {
+    return p.ntaps == 1 && p.tap_off[0] == 0 && p.q_stride == 1 && p.OH == 1 && p.OW == p.M;
+}
+
 // Weight-gradient tile over bf16 TWINS (bf16 operand mode, 128 rows n x 128 columns J): both operands are read as stored.
 // LDS images P16[m][n] and Q16[m][J]: 32 pixel rows of 256 B, filled by LDS-DMA (a piece = 4 rows), the 16-byte chunk of a row
 // XOR-swizzled with f(row) = ((row&3)<<2) | ((row>>2)&3) on the source side.  The MFMA wants k (= pixel m) contiguous per

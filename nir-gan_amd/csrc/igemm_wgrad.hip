@@ -11,6 +11,7 @@
 //   The split partial sums go to slabs (plain stores) and are summed by reduce_rows in a fixed
 //   order, so gradients are bitwise reproducible run to run.
 #include "igemm_tiles.h"
+#include <cstdlib>
 #include "wino_tile.h"
 
 namespace {
@@ -23,6 +24,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_kernel(const ng::WgradPara
 }
 
 // weight gradient over the producers' bf16 twins (bf16 operand mode, N > 64)
+__global__ __launch_bounds__(256, 2) void wgrad_persist_kernel(const ng::WgradParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[65536];
+    ng::wgrad_persist(p, blockIdx.x, gridDim.x, lds);
+}
+
 __global__ __launch_bounds__(256, 2) void wgrad_igemm16_kernel(const ng::WgradParams p) {
     __shared__ __attribute__((aligned(16))) char st0[32768];
     __shared__ __attribute__((aligned(16))) char st1[32768];
@@ -154,6 +160,12 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(p.ntiles_n * p.ntiles_k * p.nsplit * p.nplanes);
+    // matrix-form problems (the transform-domain weight gradient of a Winograd layer launched on its own) with more units than resident
+    // workgroups: persistent workgroups with the epilogue folded into the next unit's K loop (igemm_tiles.h::wgrad_persist)
+    if (ng::wgrad_persist_ok(p) && ng::wgrad_matrix_form(p) && grid.x > 512 && getenv("NIRGAN_WGRAD_NOPERSIST") == nullptr) {
+        hipLaunchKernelGGL(wgrad_persist_kernel, dim3(512), dim3(256), 0, st, p);
+        return nirgan_check_launch("wgrad_igemm");
+    }
     if (p.pq_bf16) {
         hipLaunchKernelGGL(wgrad_igemm16_kernel, grid, dim3(256), 0, st, p);
         return nirgan_check_launch("wgrad_igemm");

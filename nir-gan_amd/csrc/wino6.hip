@@ -740,157 +740,6 @@ __global__ __launch_bounds__(256, 2) void wino6_gemm16p_kernel(const W6G16 p) {
     w6_gemm16p_body(p, blockIdx.x, gridDim.x, lds);
 }
 
-// The transform-domain weight gradient dU[f][n][c] = sum_t Yt[f][t][n] * V[f][t][c] as persistent workgroups, the same way: both
-// operands are plain row-major [T][256] matrices per plane (the generic weight-gradient tile's taps, strides and pixel walks reduce
-// to `t * row stride`), so a workgroup walks its (plane, split, tile) units as one stream of 32-row K-steps with the LDS images and
-// fragment reads of ng::wgrad_tile<128, 0> (P[32 rows][128 n], Q[32 rows][128 c], pixel pairs on the two half-waves), issues the next
-// unit's first DMA during this unit's last step, and drains the finished unit's accumulators (second set, 64 AGPRs) two 8-byte
-// stores per K-step straight from registers: a lane's (acc[e][0][r], acc[e][1][r]) are two adjacent columns of slab row n, 32 lanes
-// = 256 contiguous bytes.  Units in index order: unit + i * stride.
-struct W6Wg { const float* Pp; const float* Qp; float* slab; int n0, j0, mstart, mend, nk; bool p_ok, q_ok; int p_n, q_j; };
-
-__device__ __forceinline__ void w6_wgradp_body(const ng::WgradParams& p, const int first, const int stride, char* lds) {
-    constexpr int TN = 128, P_BYTES = 32 * TN * 4, Q_BYTES = 32 * 128 * 4, STAGE = P_BYTES + Q_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles = p.ntiles_n * p.ntiles_k, per_plane = tiles * p.nsplit, total = per_plane * p.nplanes;
-    const int lrow = lane >> 5, chunk = lane & 31;
-
-    auto setup = [&](int logical, W6Wg& u) {
-        const int rid = ng_xcd_remap(logical, total);
-        const int plane = rid / per_plane, id = rid - plane * per_plane;
-        const int split = id / tiles, tile = id - split * tiles;
-        u.n0 = (tile % p.ntiles_n) * TN;
-        u.j0 = (tile / p.ntiles_n) * 128;
-        u.mstart = split * p.rows_per_split;
-        const int mend = u.mstart + p.rows_per_split;
-        u.mend = mend < p.M ? mend : p.M;
-        u.nk = (u.mend - u.mstart + 31) >> 5;                   // host: every split holds rows (nk >= 1)
-        u.Pp = p.p + size_t(plane) * p.p_plane + p.p_org;
-        u.Qp = p.q + size_t(plane) * p.q_plane + p.q_org;
-        u.slab = p.slabs + (size_t(plane) * p.nsplit + split) * p.N * p.K;
-        u.p_ok = u.n0 + chunk * 4 < p.N;
-        u.p_n = u.p_ok ? u.n0 + chunk * 4 : 0;
-        u.q_j = u.j0 + chunk * 4;
-        u.q_ok = u.q_j < p.K;
-    };
-    // wave w owns P pieces 4w .. 4w+3 and Q pieces 4w .. 4w+3 (a piece = 2 rows x 512 B)
-    auto issue = [&](const W6Wg& u, char* sP, int mb) {
-        char* sQ = sP + P_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ins = wave * 4 + i;
-            const int t = mb + ins * 2 + lrow;
-            ng_glds16((u.p_ok && t < u.mend) ? u.Pp + (t * p.p_cs + u.p_n) : p.zero, sP + ins * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ins = wave * 4 + i;
-            const int t = mb + ins * 2 + lrow;
-            ng_glds16(u.q_ok ? u.Qp + ((t < p.M ? t : 0) * p.q_cs + u.q_j) : p.zero, sQ + ins * 1024);      // rows past M meet P = 0
-        }
-    };
-
-    const int wr = wave >> 1, wc = wave & 1, half = lane >> 5;
-    const int a_off = half * (TN * 4) + (wr * (TN / 2) + 2 * (lane & 31)) * 4;
-    const int b_off = half * 512 + (wc * 64 + 2 * (lane & 31)) * 4;
-    // 4 pixel-pair steps per group: the 8 fragment reads of group g+1 are issued before the 16 MFMAs of group g
-    auto compute = [&](const char* sP, f32x16 (&acc)[2][2]) {
-        const char* sQ = sP + P_BYTES;
-        __builtin_amdgcn_s_setprio(2);
-        f32x2 a[2][4], b[2][4];
-        auto load = [&](int g, int slot) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kk = 4 * g + i;
-                a[slot][i] = *reinterpret_cast<const f32x2*>(sP + a_off + kk * (2 * TN * 4));
-                b[slot][i] = *reinterpret_cast<const f32x2*>(sQ + b_off + kk * 1024);
-            }
-        };
-        load(0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g + 1 < 4) load(g + 1, (g + 1) & 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][0], acc[e][0], 0, 0, 0);
-                    acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][1], acc[e][1], 0, 0, 0);
-                }
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // piece q = (e, r): accumulator row i = (r & 3) + 8 (r >> 2) + 4 half  ->  slab row n0 + wr * 64 + 2 i + e, columns j0 + wc * 64 + 2 (lane & 31) + {0, 1}
-    auto drain = [&](const f32x16 (&acc)[2][2], int q, const W6Wg& u) {
-        const int e = q >> 4, r = q & 15;
-        const int n = u.n0 + wr * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + e;
-        const int c = u.j0 + wc * 64 + 2 * (lane & 31);
-        if (n < p.N && c < p.K) {                                  // K % 4 == 0 and c even: both columns exist
-            f32x2 v;
-            v[0] = acc[e][0][r];
-            v[1] = acc[e][1][r];
-            *reinterpret_cast<f32x2*>(u.slab + size_t(n) * p.K + c) = v;
-        }
-    };
-    auto zero = [&](f32x16 (&acc)[2][2]) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
-    };
-
-    f32x16 accA[2][2], accB[2][2];
-    int step = 0;
-    W6Wg ucur, unext, uprev;
-    auto one_step = [&](f32x16 (&cur)[2][2], int s, int next_logical) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < ucur.nk) issue(ucur, lds + ((step + 1) & 1) * STAGE, ucur.mstart + (s + 1) * 32);
-        else if (next_logical < total) {
-            setup(next_logical, unext);
-            issue(unext, lds + ((step + 1) & 1) * STAGE, unext.mstart);
-        }
-        compute(lds + (step & 1) * STAGE, cur);
-        ++step;
-    };
-    auto run_unit = [&](f32x16 (&cur)[2][2], const f32x16 (&prev)[2][2], bool have_prev, int next_logical) {
-        zero(cur);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {                       // compile-time piece indices: register-indexed drain
-            if (have_prev) { drain(prev, 2 * s, uprev); drain(prev, 2 * s + 1, uprev); }
-            if (s < ucur.nk) one_step(cur, s, next_logical);
-        }
-        for (int s = 16; s < ucur.nk; ++s) one_step(cur, s, next_logical);
-        uprev = ucur;
-        ucur = unext;
-    };
-    if (first >= total) return;
-    setup(first, ucur);
-    issue(ucur, lds, ucur.mstart);
-    int logical = first;
-    bool have_prev = false;
-    while (true) {
-        run_unit(accA, accB, have_prev, logical + stride);
-        logical += stride;
-        have_prev = true;
-        if (logical >= total) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) drain(accA, q, uprev);
-            break;
-        }
-        run_unit(accB, accA, true, logical + stride);
-        logical += stride;
-        if (logical >= total) {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) drain(accB, q, uprev);
-            break;
-        }
-    }
-}
-
 // One grid for a layer's backward products: 512 persistent workgroups, each first walks its share of the transform-domain weight-
 // gradient units (both operands were just written by the dY pass and the forward), then its share of the data gradient's plane-GEMM
 // tiles -- M is the last thing written before the output transform reads it.  With F(6x6,3x3) at bs 16 the shares are exact:
@@ -898,7 +747,7 @@ __device__ __forceinline__ void w6_wgradp_body(const ng::WgradParams& p, const i
 __global__ __launch_bounds__(256, 2) void wino6_pair16p_kernel(const W6G16 q, const int nblocks, const ng::WgradParams wp) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
     static_assert(W6P_LDS <= 65536, "the persistent GEMM's LDS must fit the pair kernel's");
-    w6_wgradp_body(wp, blockIdx.x, nblocks, lds);
+    ng::wgrad_persist(wp, blockIdx.x, nblocks, lds);
     __syncthreads();
     w6_gemm16p_body(q, blockIdx.x, nblocks, lds);
 }
@@ -1206,8 +1055,7 @@ extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const ni
         const W6G16 q = w6_g16_params(d, T);
         const int gemm_blocks = q.total < 512 ? q.total : 512;
         // the persistent weight-gradient walk needs the plane-matrix form (one tap, unit stride, one image row) and rows in every split
-        const bool matrix_form = wp.ntaps == 1 && wp.tap_off[0] == 0 && wp.q_stride == 1 && wp.OH == 1 && wp.OW == wp.M && wp.K % 4 == 0
-                                 && (long long)(wp.nsplit - 1) * wp.rows_per_split < wp.M && wgrad_blocks >= gemm_blocks;
+        const bool matrix_form = ng::wgrad_persist_ok(wp) && ng::wgrad_matrix_form(wp);
         if (matrix_form && !no_persist_wgrad) {
             hipLaunchKernelGGL(wino6_pair16p_kernel, dim3(gemm_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), q, gemm_blocks, wp);
             return nirgan_check_launch("wino6_gemm_wgrad_pair");
