@@ -877,7 +877,9 @@ def test_winograd_backward_pair_matches_autograd(hw):
 @pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128, 3), (1, 64, 64, 256, 256, 3), (3, 6, 5, 32, 128, 3), (2, 9, 7, 64, 192, 3), (1, 69, 69, 256, 256, 3),
                                    (16, 64, 64, 256, 256, 3), (2, 8, 12, 64, 128, 4), (2, 31, 31, 256, 512, 4), (3, 7, 5, 32, 128, 4), (32, 31, 31, 256, 512, 4),
                                    (2, 8, 12, 64, 128, 6), (1, 64, 64, 256, 256, 6), (3, 6, 5, 32, 128, 6), (2, 9, 7, 64, 192, 6), (1, 69, 69, 256, 256, 6),
-                                   (16, 64, 64, 256, 256, 6), (16, 66, 66, 256, 256, 6)])
+                                   (16, 64, 64, 256, 256, 6), (16, 66, 66, 256, 256, 6),
+                                   # the persistent plane GEMM (C = 256) with partly filled N tiles, few tiles per workgroup, ragged M tiles
+                                   (2, 20, 14, 256, 192, 6), (2, 20, 14, 256, 320, 3), (1, 7, 9, 256, 128, 6), (5, 33, 31, 256, 256, 6)])
 def test_wino6_conv3x3_matches_direct(shape):
     """nirgan_wino6_weights_r + input / (r+3)^2 plane GEMMs / output transform against torch's conv2d in float64 (the reference's
     nn.Conv2d arithmetic) and the numpy restatement: fp32 rounding only.  F(4x4,3x3) and F(4x4,4x4); extents that are multiples of 4,
