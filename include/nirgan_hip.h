@@ -89,6 +89,13 @@ typedef struct {
      * elements).  Only together with w_bf16 (precision 1, run % 8 == 0, in_cs % 8 == 0): both operands are then read as
      * stored, half the bytes and LDS-DMA pieces per K-step, no conversion in the K loop. */
     int in_bf16;
+    /* optional: partial sums for the instance norm that follows (nirgan_instnorm_fwd with stats_chunks / stats_shift).  Every 64 output
+     * pixels x N channels held by a wave leave sum and sum of squares of the convolution WITHOUT the bias in
+     * stats_ws[b][stats_chunk0 + chunk][2][N]; chunk = (tile within the sample) * 2 + the wave's row half.  The problem then has
+     * OH * OW % 128 == 0 (a tile does not cross samples) and no split-K; it contributes OH * OW / 64 chunks per sample, a launch of
+     * several problems over one output (the sub-pixel phases of a transposed convolution) numbers them with stats_chunk0, and
+     * stats_chunks is the total per sample (the row stride of stats_ws).  stats_ws >= B * stats_chunks * 2 * N floats. */
+    float* stats_ws; int64_t stats_ws_elems; int stats_chunk0, stats_chunks;
 } nirgan_conv_desc;
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);

@@ -76,6 +76,8 @@ struct ConvParams {
     int w_bf16;                // packed weights stored as bf16 (bf16 operand mode only)
     int in_bf16;               // activations read from a bf16 twin (with w_bf16)
     int prec;                  // 0 fp32, 1 bf16 operands, 2 bf16x3 split (host-side dispatch only)
+    float* stats;              // partial sums for the instance norm that follows: [B][stats_cps][2][N], see nirgan_conv_desc
+    int stats_chunk0, stats_cps;
 };
 
 
@@ -394,6 +396,33 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         return;
     }
 #endif
+    // ---------------- partial sums for the instance norm that follows: the wave's 64 rows x BN/2 columns leave sum and sum of
+    // squares per column (rows past M came from the zero page: they add nothing), taken WITHOUT the bias (the shift of the
+    // statistics); the two half-waves hold the same column, one exchange joins them.  Fixed order, no atomics.
+    if (p.stats != nullptr) {
+        const int b = m0 / p.OHW;                                    // host: OHW % 128 == 0, a tile stays inside one sample
+        const int chunk = p.stats_chunk0 + ((m0 - b * p.OHW) >> 7) * 2 + wr;
+        float* sp = p.stats + (size_t(b) * p.stats_cps + chunk) * 2 * p.N;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mt][nt][r];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int col = n0 + wc * (BN / 2) + nt * 32 + (lane & 31);
+            if (half == 0 && col < p.N) {
+                sp[col] = s1;
+                sp[p.N + col] = s2;
+            }
+        }
+    }
     // ---------------- epilogue: the accumulators go through LDS (the two stage buffers are free now: rows 0-63
     // of the tile in st0, rows 64-127 in st1) so that every output pixel row is written with 16 bytes per lane in
     // whole 128-B lines.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -1111,6 +1140,13 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.dbg = nullptr;
     p.ksplit = 1;
     p.split_ws = nullptr;
+    p.stats = nullptr; p.stats_chunk0 = 0; p.stats_cps = 0;
+    if (d->stats_ws != nullptr) {
+        NG_REQUIRE(d->ksplit <= 1 && p.OHW % 128 == 0, "conv: the instance-norm partial sums need OH*OW %% 128 == 0 and no split-K (OH*OW=%d)", p.OHW);
+        NG_REQUIRE(d->stats_chunk0 >= 0 && d->stats_chunk0 + p.OHW / 64 <= d->stats_chunks, "conv: stats_chunk0 + OH*OW/64 exceeds stats_chunks");
+        NG_REQUIRE(d->stats_ws_elems >= int64_t(d->B) * d->stats_chunks * 2 * d->N, "conv: stats_ws too small");
+        p.stats = d->stats_ws; p.stats_chunk0 = d->stats_chunk0; p.stats_cps = d->stats_chunks;
+    }
     if (d->ksplit > 1) {
         const int nk = d->ntaps * ((d->run + 31) / 32);
         NG_REQUIRE(d->split_ws != nullptr && ng_aligned16(d->split_ws), "conv: split_ws missing or misaligned");

@@ -692,6 +692,28 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     return d
 
 
+def attach_conv_stats(ctx: Ctx, descs: list, bias) -> Optional[tuple]:
+    """Let the convolution launches behind `descs` (one problem, or the sub-pixel phases of a transposed convolution writing one
+    output) leave the partial sums of the instance norm that follows (csrc/igemm_tiles.h, conv_tile epilogue): returns
+    (chunks per sample, shift, workspace) for emit_in_fwd(pre_stats=...), or None when a problem does not qualify."""
+    if os.environ.get("NIRGAN_NO_CONV_STATS") == "1" or any(d.ksplit > 1 or (d.OH * d.OW) % 128 for d in descs):
+        return None
+    # worth it from ~16 K pixels per sample (the 128x128 and 256x256 layers: 16 / 54 us of statistics pass each); below, the pass
+    # costs 2-4 us and the layer keeps it (NIRGAN_CONV_STATS_MIN overrides the threshold: the kernel tests run small layers through it)
+    if sum(d.OH * d.OW for d in descs) < int(os.environ.get("NIRGAN_CONV_STATS_MIN", "16384")):
+        return None
+    B, N = descs[0].B, descs[0].N
+    total = sum(d.OH * d.OW // 64 for d in descs)
+    if not hasattr(ctx, "conv_pool_stats"):
+        ctx.conv_pool_stats = SplitPool(ctx)
+    ws = ctx.conv_pool_stats.get(B * total * 2 * N)
+    first = 0
+    for d in descs:
+        d.stats_ws, d.stats_ws_elems, d.stats_chunk0, d.stats_chunks = ws.data_ptr(), ws.numel(), first, total
+        first += d.OH * d.OW // 64
+    return total, bias, ws
+
+
 def emit_conv_group(plan: Plan, ctx: Ctx, descs: list):
     """One launch for up to 4 conv descriptors (sub-pixel phases)."""
     for i in range(0, len(descs), 4):
@@ -855,13 +877,17 @@ class ConvIN:
         elif self.kind == "conv":
             taps = G.conv_fwd_taps(k, inp.C)
             w = eng.weights.packed(pack, self.weight, G.conv_fwd_pack(self.cout, inp.C, k))
-            emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
-                      in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
+            cd = emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
+                           in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
+            if self.norm:
+                pre = attach_conv_stats(ctx, [cd], self.bias)
         elif self.kind == "rowpacked":
             taps = G.conv_rowpacked_taps(k, inp.C)
             w = eng.weights.packed(pack, self.weight, G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C))
-            emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
-                      in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
+            cd = emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
+                           in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
+            if self.norm:
+                pre = attach_conv_stats(ctx, [cd], self.bias)
         else:  # convT: 4 sub-pixel phases over the zero-halo-1 input, one launch
             descs = []
             for ph in G.convT_fwd_phases(inp.H, inp.W, k, p):
@@ -870,6 +896,8 @@ class ConvIN:
                 descs.append(emit_conv(None, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=ph.n_h, OW=ph.n_w,
                                        in_oh=ph.in_oh + inp.pad - 1, in_ow=ph.in_ow + inp.pad - 1,
                                        out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow))
+            if self.norm:
+                pre = attach_conv_stats(ctx, descs, self.bias)
             emit_conv_group(plan, ctx, descs)
         emit_in_fwd(plan, ctx, self.y, self.out, norm=self.norm, act=(L.ACT_NONE if self.keep_z else self.act),
                     residual=self.residual, border=self.out_border, stats=self.stats, ws=(pre[2] if pre is not None else eng.scratch.get()),

@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("out", fp), ("out_elems", i64), ("out_hp", i32), ("out_wp", i32), ("out_cs", i32),
                 ("out_stride", i32), ("out_oh", i32), ("out_ow", i32),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32), ("zero_page", fp),
-                ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32), ("w_bf16", i32), ("in_bf16", i32)]
+                ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32), ("w_bf16", i32), ("in_bf16", i32),
+                ("stats_ws", fp), ("stats_ws_elems", i64), ("stats_chunk0", i32), ("stats_chunks", i32)]
 
 
 class WgradDesc(C.Structure):

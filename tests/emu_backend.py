@@ -127,12 +127,23 @@ class EmuBackend:
                 return self._fail("conv: input cols out of range")
         if d.N > d.out_cs or (d.OH - 1) * d.out_stride + d.out_oh >= d.out_hp or (d.OW - 1) * d.out_stride + d.out_ow >= d.out_wp:
             return self._fail("conv: output out of range")
+        stats = None
+        if d.stats_ws:
+            ohw = d.OH * d.OW
+            if d.ksplit > 1 or ohw % 128 or d.stats_chunk0 < 0 or d.stats_chunk0 + ohw // 64 > d.stats_chunks or d.stats_ws_elems < d.B * d.stats_chunks * 2 * d.N:
+                return self._fail("conv: the instance-norm partial sums need OH*OW % 128 == 0, no split-K and a large enough stats_ws")
+            stats = arr(d.stats_ws, d.B * d.stats_chunks * 2 * d.N).reshape(d.B, d.stats_chunks, 2, d.N)
+            self.calls.append("conv_stats")
         for b in range(d.B):
             acc = np.zeros((d.OH, d.OW, d.N), dtype=np.float64)
             for t in range(d.ntaps):
                 off = (d.tap_dh[t] * d.in_wp + d.tap_dw[t]) * d.in_cs
                 A = inp[b * in_img + base[..., None] + off + rr]
                 acc += contract(A.reshape(-1, d.run), np.ascontiguousarray(w[:, t * d.run:(t + 1) * d.run].T), d.precision).reshape(d.OH, d.OW, d.N)
+            if stats is not None:                      # per 64 pixels: sum and sum of squares without the bias
+                ch = acc.reshape(-1, 64, d.N)
+                stats[b, d.stats_chunk0:d.stats_chunk0 + ch.shape[0], 0] = ch.sum(1)
+                stats[b, d.stats_chunk0:d.stats_chunk0 + ch.shape[0], 1] = (ch ** 2).sum(1)
             if bias is not None:
                 acc += bias
             idx = b * out_img + obase[..., None] + np.arange(d.N)

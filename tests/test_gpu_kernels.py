@@ -1128,3 +1128,62 @@ def test_wino6_output_leaves_the_instance_norm_partial_sums(shape):
     ref_rstd = 1.0 / torch.sqrt(y64.var(1, unbiased=False) + 1e-5)
     close(res[0][1], ref_rstd, 2e-6, "rstd from the output transform's partial sums")
     close(res[1][1], ref_rstd, 2e-6, "rstd from the statistics pass")
+
+
+@pytest.mark.parametrize("case", [("conv", 2, 32, 32, 32, 64, 3, 1), ("conv", 3, 32, 32, 64, 128, 3, 2), ("convT", 2, 16, 16, 128, 64, 3, 2), ("conv", 16, 128, 128, 128, 256, 3, 2),
+                                  ("conv", 2, 32, 32, 16, 8, 3, 1), ("conv", 2, 64, 64, 8, 16, 3, 2), ("convT", 2, 16, 16, 32, 16, 3, 2), ("conv", 2, 16, 16, 32, 32, 3, 1), ("rowpacked", 2, 64, 64, 4, 8, 7, 1), ("rowpacked", 16, 256, 256, 4, 64, 7, 1),
+                                  ("conv", 2, 32, 32, 4, 8, 4, 2), ("conv", 2, 16, 16, 32, 32, 3, 1, "residual")])
+def test_conv_epilogue_leaves_the_instance_norm_partial_sums(case):
+    """A ConvIN layer with the direct tiles: the convolution's epilogue leaves per-(64 pixels) partial sums of its output without the
+    bias, nirgan_instnorm_fwd merges them (stats_chunks, stats_shift = bias) -- the output of the layer (normalised, ReLU, halo) equals
+    the one produced with the separate statistics pass (NIRGAN_NO_CONV_STATS=1) to fp32 rounding; device against the numpy restatement
+    too.  Stride-1, stride-2, and the four sub-pixel phases of a transposed convolution numbering their chunks into one workspace."""
+    import os
+    from nirgan_hip.engine import ConvIN
+    kind, B, H, W, Cin, Cout, k, s_ = case[:8]
+
+    class Eng:
+        pass
+
+    def build(ctx, stats):
+        from nirgan_hip.engine import Weights, _Scratch, SlabPool
+        os.environ.pop("NIRGAN_NO_CONV_STATS", None)
+        os.environ["NIRGAN_CONV_STATS_MIN"] = "0"          # small layers too (the engines keep the separate pass below 16 K pixels)
+        if not stats:
+            os.environ["NIRGAN_NO_CONV_STATS"] = "1"
+        try:
+            g = torch.Generator().manual_seed(5)
+            eng = Eng()
+            eng.ctx, eng.weights, eng.scratch, eng.slabs, eng.need_backward = ctx, Weights(ctx), _Scratch(ctx), SlabPool(ctx), False
+            pad = k // 2 if kind == "rowpacked" else 1
+            inp = Halo(ctx, B, H, W, Cin, pad)
+            inp.t.copy_(torch.randn(inp.t.shape, generator=g).to(ctx.device))
+            cin_w = 3 if kind == "rowpacked" else Cin
+            wshape = (Cin, Cout, k, k) if kind == "convT" else (Cout, cin_w, k, k)
+            w = (torch.randn(wshape, generator=g) * 0.05).to(ctx.device)
+            bias = (torch.randn(Cout, generator=g) * 3.0).to(ctx.device)
+            res = None
+            if len(case) > 8:
+                res = Halo(ctx, B, H, W, Cout, 1)
+                res.t.copy_(torch.randn(res.t.shape, generator=g).to(ctx.device))
+            layer = ConvIN(eng, "t", kind, inp, w, bias, k=k, s=s_, p=pad, cout=Cout, norm=True, act=(L.ACT_NONE if res is not None else L.ACT_RELU), out_pad=1,
+                           out_border=L.BORDER_REFLECT, residual=res, cin_real=(3 if kind == "rowpacked" else None))
+            plan, pack = Plan(ctx), Plan(ctx)
+            layer.emit_fwd(plan, pack)
+            pack.run()
+            plan.run()
+            return layer.out.t.detach().cpu().clone(), layer.stats[0].cpu().clone(), layer.stats[1].cpu().clone(), plan
+        finally:
+            os.environ.pop("NIRGAN_NO_CONV_STATS", None)
+            os.environ.pop("NIRGAN_CONV_STATS_MIN", None)
+
+    gctx = Ctx(DEV, "fp32")
+    o1, m1, r1, plan1 = build(gctx, True)
+    o0, m0, r0, plan0 = build(Ctx(DEV, "fp32"), False)
+    torch.cuda.synchronize()
+    d1 = [a[0]._obj for n, a in plan1.ops if n == "nirgan_instnorm_fwd"][0]
+    d0 = [a[0]._obj for n, a in plan0.ops if n == "nirgan_instnorm_fwd"][0]
+    assert d1.stats_chunks > 0 and d0.stats_chunks == 0
+    close(m1, m0, 1e-6, "mean")
+    close(r1, r0, 3e-6, "rstd")
+    close(o1, o0, 1e-5, "layer output")

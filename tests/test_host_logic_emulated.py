@@ -775,3 +775,20 @@ def test_direct_last_layer_restatement_matches_conv2d(emu):
     from endconv_case import run_endconv
     run_endconv("cpu", 2, 9, 10, 1, tol=1e-6)
     run_endconv("cpu", 1, 7, 5, 0, tol=1e-6, act=L.ACT_NONE)
+
+
+def test_conv_epilogue_statistics_through_the_trainer(emu, monkeypatch, golden_dir):
+    """The direct-tile layers leave the instance norm's partial sums in the convolution's epilogue (the engines do that from 16 K
+    pixels per sample; NIRGAN_CONV_STATS_MIN=0 here): one fused step on the golden small nets, same bounds as without."""
+    from nirgan_hip.trainer import Pix2PixTrainer
+    monkeypatch.setenv("NIRGAN_CONV_STATS_MIN", "0")
+    z = load(golden_dir, "f1_g9_rs_pad.npz")
+    nb = int(z["n_blocks"])
+    netG, netD = make_nets(z, nb)
+    rs_w = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333, "lambda_savi": 0.0, "lambda_msavi": 0.0, "lambda_gndvi": 0.0}
+    tr = Pix2PixTrainer(netG, netD, n_blocks=nb, lambda_rs=float(z["lambda_rs"]), rs_weights=rs_w, padding=int(z["padding"]))
+    out = tr.step(torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])).as_dict()
+    assert emu.calls.count("conv_stats") >= 10 and emu.calls.count("in_fwd_pre") >= 10
+    close(tr.G.pred, z["pred"], 1e-4, "pred")
+    for k in ("loss_D", "loss_G", "loss_G_l1"):
+        close(out[k], z[k], 1e-4, k)
