@@ -577,17 +577,23 @@ __global__ __launch_bounds__(256, 3) void wino6_gemm16_kernel(const W6G16 p) {
 // during this tile's last step, and the finished tile's accumulators (a second set, 64 AGPRs) drain one 8 x 32 piece per K-step of
 // the next tile -- 4 ds_write_b32 into a wave-private 1 KB transpose buffer, one ds_read_b128, one 16-byte-per-lane store -- under
 // that step's 32 MFMAs.  No barrier beyond the one per K-step, no MFMA-free phase except the very first DMA wait.
-constexpr int W6P_LDS = 2 * 16384 + 4 * 2 * 1280;
+// KS = k per stage: 16 (64-byte rows, 2 x 16 KB of stages) or 32 (128-byte rows, 2 x 32 KB: half the barriers per product)
+template <int KS> constexpr int w6p_lds() { return 2 * 2 * 128 * KS * 4 + 4 * 2 * 1280; }
+constexpr int W6P_LDS = w6p_lds<16>();
 
-__device__ __forceinline__ void w6_gemm16p_body(const W6G16& p, const int first, const int stride, char* lds) {
-    constexpr int STAGE = 16384, A_BYTES = 8192;
+template <int KS>
+__device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, const int stride, char* lds) {
+    constexpr int ROWB = KS * 4, CH = KS / 4, RPP = 1024 / ROWB, PW = (128 / RPP) / 4, NG = KS / 8, PPS = KS / 16;
+    constexpr int A_BYTES = 128 * ROWB, STAGE = 2 * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nk = p.C >> 4;                         // host guarantees nk >= 16: the drain of a tile takes 16 K-steps of the next
+    const int nk = p.C / KS;                         // host guarantees nk * PPS >= 16: the drain of a tile takes 16 / PPS K-steps of the next
 
-    // ---------------- loader: wave w owns A pieces 2w, 2w+1 and B pieces 2w, 2w+1 (16 rows x 64 B each)
-    const int prow = lane >> 2, lchunk = lane & 3;
-    struct Ld { const float* A; const float* Bw; int a_base[2], b_base[2]; bool b_ok[2]; };
+    // ---------------- loader: wave w owns A pieces PW w .. and B pieces PW w .. (a piece = RPP rows x ROWB bytes = 1 KB); the 16-byte
+    // chunk of a row is XOR-swizzled with key(row) on the source side and at the fragment reads
+    auto key = [](int row) { return KS == 16 ? (row >> 2) & 3 : (row >> 1) & 7; };
+    const int prow = lane / CH, lchunk = lane % CH;
+    struct Ld { const float* A; const float* Bw; int a_base[PW], b_base[PW]; bool b_ok[PW]; };
     auto setup = [&](int logical, Ld& l, int& plane, int& m0, int& n0) {
         const int rid = ng_xcd_remap(logical, p.total);
         plane = rid / p.per_plane;
@@ -597,9 +603,9 @@ __device__ __forceinline__ void w6_gemm16p_body(const W6G16& p, const int first,
         l.A = p.A + size_t(plane) * p.a_plane;
         l.Bw = p.Bw + size_t(plane) * p.b_plane;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave * 2 + i) * 16 + prow;
-            const int sc = lchunk ^ ((row >> 2) & 3);
+        for (int i = 0; i < PW; ++i) {
+            const int row = (wave * PW + i) * RPP + prow;
+            const int sc = lchunk ^ key(row);
             int m = m0 + row;
             m = m < p.T ? m : p.T - 1;
             l.a_base[i] = m * p.C + sc * 4;
@@ -611,9 +617,9 @@ __device__ __forceinline__ void w6_gemm16p_body(const W6G16& p, const int first,
     auto issue = [&](const Ld& l, char* sA, int c0) {
         char* sB = sA + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ng_glds16(l.A + (l.a_base[i] + c0), sA + (wave * 2 + i) * 1024);
+        for (int i = 0; i < PW; ++i) ng_glds16(l.A + (l.a_base[i] + c0), sA + (wave * PW + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) ng_glds16(l.b_ok[i] ? l.Bw + (l.b_base[i] + c0) : p.zero, sB + (wave * 2 + i) * 1024);
+        for (int i = 0; i < PW; ++i) ng_glds16(l.b_ok[i] ? l.Bw + (l.b_base[i] + c0) : p.zero, sB + (wave * PW + i) * 1024);
     };
 
     // ---------------- compute: wave (wr, wc) = rows wr*64 .. +63, columns wc*64 .. +63
@@ -622,31 +628,35 @@ __device__ __forceinline__ void w6_gemm16p_body(const W6G16& p, const int first,
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int ra = wr * 64 + t * 32 + (lane & 31), rb = wc * 64 + t * 32 + (lane & 31);
-        a_off[t] = ra * 64; a_key[t] = (ra >> 2) & 3;
-        b_off[t] = rb * 64; b_key[t] = (rb >> 2) & 3;
+        a_off[t] = ra * ROWB; a_key[t] = key(ra);
+        b_off[t] = rb * ROWB; b_key[t] = key(rb);
     }
+    // group g contracts k 8g .. 8g+7: lanes 0-31 read chunk 2g, lanes 32-63 chunk 2g+1 of their row; the fragment reads of group g+1 are
+    // issued before the 16 MFMAs of group g
     auto compute = [&](const char* sA, f32x16 (&acc)[2][2]) {
         const char* sB = sA + A_BYTES;
         f32x4 a[2][2], b[2][2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        auto load = [&](int g, int slot) {
             const int chunk = 2 * g + half;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                a[g][t] = *reinterpret_cast<const f32x4*>(sA + a_off[t] + ((chunk ^ a_key[t]) << 4));
-                b[g][t] = *reinterpret_cast<const f32x4*>(sB + b_off[t] + ((chunk ^ b_key[t]) << 4));
+                a[slot][t] = *reinterpret_cast<const f32x4*>(sA + a_off[t] + ((chunk ^ a_key[t]) << 4));
+                b[slot][t] = *reinterpret_cast<const f32x4*>(sB + b_off[t] + ((chunk ^ b_key[t]) << 4));
             }
-        }
+        };
+        load(0, 0);
         __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load(g + 1, (g + 1) & 1);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][mt][j], b[g][nt][j], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][mt][j], b[g & 1][nt][j], acc[mt][nt], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -684,7 +694,7 @@ __device__ __forceinline__ void w6_gemm16p_body(const W6G16& p, const int first,
     Ld lcur, lnext;
     int plane, m0, n0, pplane = 0, pm0 = 0, pn0 = 0, nplane = 0, nm0 = 0, nn0 = 0;
     auto one_step = [&](f32x16 (&cur)[2][2], int s, int next_logical) {
-        if (s + 1 < nk) issue(lcur, lds + ((step + 1) & 1) * STAGE, (s + 1) << 4);
+        if (s + 1 < nk) issue(lcur, lds + ((step + 1) & 1) * STAGE, (s + 1) * KS);
         else if (next_logical < p.total) {
             setup(next_logical, lnext, nplane, nm0, nn0);
             issue(lnext, lds + ((step + 1) & 1) * STAGE, 0);
@@ -695,13 +705,16 @@ __device__ __forceinline__ void w6_gemm16p_body(const W6G16& p, const int first,
     auto run_tile = [&](f32x16 (&cur)[2][2], const f32x16 (&prev)[2][2], bool have_prev, int next_logical) {
         zero(cur);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {                       // the piece index is a compile-time constant: register-indexed drain
+        for (int s = 0; s < 16 / PPS; ++s) {                 // the piece index is a compile-time constant: register-indexed drain
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (have_prev) drain(prev, s, pplane, pm0, pn0);
+            if (have_prev) {
+#pragma unroll
+                for (int q = 0; q < PPS; ++q) drain(prev, PPS * s + q, pplane, pm0, pn0);
+            }
             one_step(cur, s, next_logical);
         }
-        for (int s = 16; s < nk; ++s) {
+        for (int s = 16 / PPS; s < nk; ++s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             one_step(cur, s, next_logical);
@@ -736,9 +749,12 @@ __device__ __forceinline__ void w6_gemm16p_body(const W6G16& p, const int first,
 }
 
 __global__ __launch_bounds__(256, 2) void wino6_gemm16p_kernel(const W6G16 p) {
-    __shared__ __attribute__((aligned(16))) char lds[W6P_LDS];
-    w6_gemm16p_body(p, blockIdx.x, gridDim.x, lds);
+    __shared__ __attribute__((aligned(16))) char lds[w6p_lds<16>()];
+    w6_gemmp_body<16>(p, blockIdx.x, gridDim.x, lds);
 }
+
+// (KS = 32 -- 128-byte rows, half the barriers per product, 74 KB of LDS -- was instantiated and measured: 176 / 195 us against
+// 178 / 194 us at T = 4096 / 4624: the barrier count is not what holds the tile at 0.7)
 
 // One grid for a layer's backward products: 512 persistent workgroups, each first walks its share of the transform-domain weight-
 // gradient units (both operands were just written by the dY pass and the forward), then its share of the data gradient's plane-GEMM
@@ -749,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void wino6_pair16p_kernel(const W6G16 q, co
     static_assert(W6P_LDS <= 65536, "the persistent GEMM's LDS must fit the pair kernel's");
     ng::wgrad_persist(wp, blockIdx.x, nblocks, lds);
     __syncthreads();
-    w6_gemm16p_body(q, blockIdx.x, nblocks, lds);
+    w6_gemmp_body<16>(q, blockIdx.x, nblocks, lds);
 }
 
 // (fallback) the weight-gradient tiles one per workgroup, dispatched first, and the persistent GEMM workgroups behind them
@@ -757,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void wino6_pair16_kernel(const W6G16 q, con
     __shared__ __attribute__((aligned(16))) char lds[65536];
     const int bid = blockIdx.x;
     if (bid < wgrad_blocks) ng::wgrad_tile<128, 0>(wp, bid, lds, lds + 32768);
-    else w6_gemm16p_body(q, bid - wgrad_blocks, gemm_blocks, lds);
+    else w6_gemmp_body<16>(q, bid - wgrad_blocks, gemm_blocks, lds);
 }
 
 // ------------------------------------------------------------------------------------------------ output transform
