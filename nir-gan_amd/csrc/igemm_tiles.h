@@ -801,7 +801,8 @@ __device__ __forceinline__ void wgrad_persist(const WgradParams& p, const int fi
     const int a_off = half * (TN * 4) + (wr * (TN / 2) + 2 * (lane & 31)) * 4;
     const int b_off = half * 512 + (wc * 64 + 2 * (lane & 31)) * 4;
     // 4 pixel-pair steps per group: the 8 fragment reads of group g+1 are issued before the 16 MFMAs of group g
-    auto compute = [&](const char* sP, f32x16 (&acc)[2][2]) {
+    // `between(g)` runs after the MFMAs of group g have been issued: the drain of the previous unit executes in their shadow
+    auto compute = [&](const char* sP, f32x16 (&acc)[2][2], auto&& between) {
         const char* sQ = sP + P_BYTES;
         __builtin_amdgcn_s_setprio(2);
         f32x2 a[2][4], b[2][4];
@@ -824,6 +825,9 @@ __device__ __forceinline__ void wgrad_persist(const WgradParams& p, const int fi
                     acc[e][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][0], acc[e][0], 0, 0, 0);
                     acc[e][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][i][e], b[g & 1][i][1], acc[e][1], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
+            between(g);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -853,7 +857,7 @@ __device__ __forceinline__ void wgrad_persist(const WgradParams& p, const int fi
     int step = 0;
     WgradUnit ucur, unext;
     Done uprev = {nullptr, 0, 0};
-    auto one_step = [&](f32x16 (&cur)[2][2], int s, int next_logical) {
+    auto one_step = [&](f32x16 (&cur)[2][2], int s, int next_logical, auto&& between) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (s + 1 < ucur.nk) issue(ucur, lds + ((step + 1) & 1) * STAGE, ucur.mstart + (s + 1) * 32);
@@ -861,17 +865,24 @@ __device__ __forceinline__ void wgrad_persist(const WgradParams& p, const int fi
             setup(next_logical, unext);
             issue(unext, lds + ((step + 1) & 1) * STAGE, unext.mstart);
         }
-        compute(lds + (step & 1) * STAGE, cur);
+        compute(lds + (step & 1) * STAGE, cur, between);
         ++step;
     };
     auto run_unit = [&](f32x16 (&cur)[2][2], const f32x16 (&prev)[2][2], bool have_prev, int next_logical) {
         zero(cur);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {                       // compile-time piece indices: register-indexed drain
-            if (have_prev) { drain(prev, 2 * s, uprev); drain(prev, 2 * s + 1, uprev); }
-            if (s < ucur.nk) one_step(cur, s, next_logical);
+            if (s < ucur.nk) {
+                one_step(cur, s, next_logical, [&](int g) {
+                    if (have_prev && g == 0) drain(prev, 2 * s, uprev);
+                    if (have_prev && g == 1) drain(prev, 2 * s + 1, uprev);
+                });
+            } else if (have_prev) {                          // a unit shorter than 16 steps: what is left of the drain goes out here
+                drain(prev, 2 * s, uprev);
+                drain(prev, 2 * s + 1, uprev);
+            }
         }
-        for (int s = 16; s < ucur.nk; ++s) one_step(cur, s, next_logical);
+        for (int s = 16; s < ucur.nk; ++s) one_step(cur, s, next_logical, [](int) {});
         uprev = Done{ucur.slab, ucur.n0, ucur.j0};
         ucur = unext;
     };

@@ -633,7 +633,9 @@ __device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, c
     }
     // group g contracts k 8g .. 8g+7: lanes 0-31 read chunk 2g, lanes 32-63 chunk 2g+1 of their row; the fragment reads of group g+1 are
     // issued before the 16 MFMAs of group g
-    auto compute = [&](const char* sA, f32x16 (&acc)[2][2]) {
+    // `between(g)` runs after the MFMAs of group g have been issued: whatever it does executes in their shadow (the drain of the
+    // previous tile: measured 13 % of the launch when it sat in front of the step's MFMAs, where its LDS round trip stalled the wave)
+    auto compute = [&](const char* sA, f32x16 (&acc)[2][2], auto&& between) {
         const char* sB = sA + A_BYTES;
         f32x4 a[2][2], b[2][2];
         auto load = [&](int g, int slot) {
@@ -656,6 +658,9 @@ __device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, c
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][mt][j], b[g & 1][nt][j], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            between(g);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -666,16 +671,24 @@ __device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, c
     float* tb = reinterpret_cast<float*>(lds + 2 * STAGE) + wave * 640;
     const int t_wr = ((lane >> 5) * 4) * 40 + (lane & 31);           // + (r & 3) * 40
     const int t_rd = (lane >> 3) * 40 + (lane & 7) * 4;              // lane -> (row lane/8, 4 columns)
-    auto drain = [&](const f32x16 (&acc)[2][2], int q, int plane, int m0, int n0) {
+    f32x4 dv;                                                        // the piece on its way from the transpose buffer to memory
+    auto drain_lds = [&](const f32x16 (&acc)[2][2], int q) {
         const int mt = q >> 3, nt = (q >> 2) & 1, j = q & 3;
         float* b = tb + (q & 1) * 320;
 #pragma unroll
         for (int r = 0; r < 4; ++r) b[t_wr + r * 40] = acc[mt][nt][4 * j + r];
-        const f32x4 v = *reinterpret_cast<const f32x4*>(b + t_rd);
+        dv = *reinterpret_cast<const f32x4*>(b + t_rd);
+    };
+    auto drain_store = [&](int q, int plane, int m0, int n0) {
+        const int mt = q >> 3, nt = (q >> 2) & 1, j = q & 3;
         const int rr = lane >> 3;                                     // buffer row = (r & 3) + 4 half  ->  tile row 8j + rr
         const int m = m0 + wr * 64 + mt * 32 + 8 * j + rr;
         const int n = n0 + wc * 64 + nt * 32 + (lane & 7) * 4;
-        if (m < p.T && n < p.K) *reinterpret_cast<f32x4*>(p.Out + size_t(plane) * p.o_plane + size_t(m) * p.K + n) = v;
+        if (m < p.T && n < p.K) *reinterpret_cast<f32x4*>(p.Out + size_t(plane) * p.o_plane + size_t(m) * p.K + n) = dv;
+    };
+    auto drain = [&](const f32x16 (&acc)[2][2], int q, int plane, int m0, int n0) {
+        drain_lds(acc, q);
+        drain_store(q, plane, m0, n0);
     };
 
     f32x16 accA[2][2], accB[2][2];
@@ -693,31 +706,39 @@ __device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, c
     int step = 0;
     Ld lcur, lnext;
     int plane, m0, n0, pplane = 0, pm0 = 0, pn0 = 0, nplane = 0, nm0 = 0, nn0 = 0;
-    auto one_step = [&](f32x16 (&cur)[2][2], int s, int next_logical) {
+    auto one_step = [&](f32x16 (&cur)[2][2], int s, int next_logical, auto&& between) {
         if (s + 1 < nk) issue(lcur, lds + ((step + 1) & 1) * STAGE, (s + 1) * KS);
         else if (next_logical < p.total) {
             setup(next_logical, lnext, nplane, nm0, nn0);
             issue(lnext, lds + ((step + 1) & 1) * STAGE, 0);
         }
-        compute(lds + (step & 1) * STAGE, cur);
+        compute(lds + (step & 1) * STAGE, cur, between);
         ++step;
     };
     auto run_tile = [&](f32x16 (&cur)[2][2], const f32x16 (&prev)[2][2], bool have_prev, int next_logical) {
         zero(cur);
+        static_assert(PPS == 1 || PPS == 2, "one or two drain pieces per K-step");
 #pragma unroll
         for (int s = 0; s < 16 / PPS; ++s) {                 // the piece index is a compile-time constant: register-indexed drain
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (have_prev) {
-#pragma unroll
-                for (int q = 0; q < PPS; ++q) drain(prev, PPS * s + q, pplane, pm0, pn0);
-            }
-            one_step(cur, s, next_logical);
+            // the LDS half of a piece after the first MFMA group, its store after the next one (the round trip is long over by then)
+            one_step(cur, s, next_logical, [&](int g) {
+                if (!have_prev) return;
+                if (PPS == 1) {
+                    if (g == 0) drain_lds(prev, s);
+                    if (g == NG - 1) drain_store(s, pplane, pm0, pn0);
+                } else {
+                    if (g == 0) drain_lds(prev, 2 * s);
+                    if (g == 1) { drain_store(2 * s, pplane, pm0, pn0); drain_lds(prev, 2 * s + 1); }
+                    if (g == NG - 1) drain_store(2 * s + 1, pplane, pm0, pn0);
+                }
+            });
         }
         for (int s = 16 / PPS; s < nk; ++s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            one_step(cur, s, next_logical);
+            one_step(cur, s, next_logical, [](int) {});
         }
         pplane = plane; pm0 = m0; pn0 = n0;
         lcur = lnext; plane = nplane; m0 = nm0; n0 = nn0;
