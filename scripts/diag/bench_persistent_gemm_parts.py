@@ -1,3 +1,7 @@
+"""Times nirgan_wino6_gemm on the F(6x6,3x3) forward shape under NIRGAN_DIAG=1..4.  The DIAG variants were TEMPORARY template flags of
+csrc/wino6.hip::w6_gemmp_body (1: no LDS-DMA inside the K loop, 2: no drain of the previous tile, 3: no s_waitcnt + barrier per K-step,
+4: VALU stand-in for the MFMAs); they are not in the tree -- against the shipped library every row measures the shipped kernel.
+Recorded result: profiles/r02_microbench_persistent_gemm_parts.txt."""
 import ctypes as C, os, sys
 sys.path.insert(0, "/root/repo/nir-gan_amd")
 import torch
