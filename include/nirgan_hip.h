@@ -206,6 +206,9 @@ typedef struct {
     float* dbias;
     float* ws; int64_t ws_elems;
     void* dy_bf16;                        /* optional twin of `dy` (same geometry, bf16), as out_bf16 */
+    int sums_chunks;                      /* > 0 (with norm): the first pass is done -- the producer of the gradient (nirgan_wino6_output with
+                                             fuse_gz) left the folded gradient g_a in gsum_out and the partial sums of g_z and g_z * z in ws as
+                                             [B][sums_chunks][2][C]; g / g2 are not read.  ws >= B * sums_chunks * 2 * C + B * 2 * C floats */
 } nirgan_in_bwd_desc;
 
 int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream);
@@ -520,6 +523,15 @@ typedef struct {
                                              follows, [B][tiles per image][2][K] = T * 2 * K floats: sum and sum of squares of the tile's
                                              stored outputs WITHOUT the bias (i.e. about the shift `bias`); feed nirgan_instnorm_fwd with
                                              ws = stats_ws, stats_chunks = tiles per image, stats_shift = bias */
+    /* optional (nirgan_wino6_output of a DATA GRADIENT over the padded extent, 3x3 filters): the first pass of the instance-norm backward
+       of the layer that consumes this gradient, in the same kernel.  H x W here is the padded extent (interior (H-2) x (W-2), reflect halo
+       of 1): the tile's outputs are folded onto the interior in registers (adjoint of ReflectionPad2d(1); the far halo line and its
+       partner must fall in one tile: (H-3) / m == (H-1) / m for tile size m, same for W), fuse_g2 (optional, dense) is added, the
+       result g_a goes to fuse_gz (dense [B][H-2][W-2][K]) INSTEAD of y (which is not written and may be NULL), and the tile's partial sums
+       of g_z = g_a * act'(z) and g_z * z, z = (fuse_y - mean) * rstd, go to fuse_part as [B][tiles per image][2][K].  Feed
+       nirgan_instnorm_bwd with gsum_out = fuse_gz, ws = fuse_part, sums_chunks = tiles per image. */
+    const float* fuse_y; const float* fuse_mean; const float* fuse_rstd; const float* fuse_g2;
+    float* fuse_gz; float* fuse_part; int64_t fuse_part_elems; int fuse_act; float fuse_slope;
 } nirgan_wino6_desc;
 
 int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T of the 4x4-output variants */

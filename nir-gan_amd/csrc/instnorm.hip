@@ -217,10 +217,10 @@ __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const InBwd p, int
     __shared__ f32x4 lds[512];
     const int b = blockIdx.x, tid = threadIdx.x;
     f32x4 s1, s2;
-    chunk_sums(p.ws + size_t(b) * p.nchunk * 2 * p.C, p.nchunk, p.C, tid, lds, s1, s2);
+    chunk_sums(p.ws + size_t(b) * p.pchunks * 2 * p.C, p.pchunks, p.C, tid, lds, s1, s2);
     if (tid >= p.C / 4) return;
     const float inv = 1.f / float(p.HW);
-    float* m = p.ws + size_t(B) * p.nchunk * 2 * p.C + size_t(b) * 2 * p.C;
+    float* m = p.ws + size_t(B) * p.pchunks * 2 * p.C + size_t(b) * 2 * p.C;
     st4(m + tid * 4, s1 * inv);
     st4(m + p.C + tid * 4, s2 * inv);
 }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     const int q4 = p.C / 4, nrg = in_nrg(p.C);
     const int q = tid % q4, rg = tid / q4;
     if (rg >= nrg) return;
-    const float* mm = p.ws + size_t(B) * p.nchunk * 2 * p.C + size_t(b) * 2 * p.C;
+    const float* mm = p.ws + size_t(B) * p.pchunks * 2 * p.C + size_t(b) * 2 * p.C;
     const f32x4 m1 = ld4(mm + q * 4), m2 = ld4(mm + p.C + q * 4);
     const f32x4 mean = ld4(p.mean + size_t(b) * p.C + q * 4);
     const f32x4 rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
@@ -300,9 +300,13 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     NG_REQUIRE(!d->norm || (d->mean && d->rstd && d->ws), "instnorm_bwd: mean/rstd/ws required when norm");
     InBwd p = in_bwd_params(d);
     NG_REQUIRE(!d->dy_bf16 || (d->C % 8 == 0 && (reinterpret_cast<uintptr_t>(d->dy_bf16) & 15) == 0), "instnorm_bwd: bf16 twin needs C %% 8 == 0 and 16-byte alignment");
-    NG_REQUIRE(!d->norm || d->ws_elems >= int64_t(d->B) * p.nchunk * 2 * d->C + int64_t(d->B) * 2 * d->C, "instnorm_bwd: ws too small");
+    NG_REQUIRE(!d->norm || d->ws_elems >= int64_t(d->B) * p.pchunks * 2 * d->C + int64_t(d->B) * 2 * d->C, "instnorm_bwd: ws too small");
+    // sums_chunks > 0: the producer of the gradient (nirgan_wino6_output in its fused mode) already left the folded gradient in gsum_out
+    // and the partial sums of the first pass in ws
+    const bool pre = d->norm && d->sums_chunks > 0;
+    NG_REQUIRE(!pre || (d->gsum_out != nullptr && !sums_only), "instnorm_bwd: sums_chunks needs the folded gradient in gsum_out and a dy to write");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+    if (!pre) hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     if (d->norm) {
         hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(d->B), dim3(256), 0, st, p, d->B);
         if (!sums_only) hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p, d->B);

@@ -49,6 +49,7 @@ struct InBwd {
     float* dbias;
     float* ws; int nchunk, ppc;
     unsigned short* dy16;
+    int pchunks;               // chunks of partial sums per sample in ws (= nchunk, or the producer's count: nirgan_in_bwd_desc.sums_chunks)
 };
 
 // gradient wrt the block output at pixel (h, w) = pix of sample b: the (reflect-folded) halo'd gradient plus the dense skip gradient
@@ -82,6 +83,7 @@ inline InBwd in_bwd_params(const nirgan_in_bwd_desc* d) {
     p.gsum_out = d->gsum_out; p.dbias = d->dbias;
     p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C); p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
     p.dy16 = static_cast<unsigned short*>(d->dy_bf16);
+    p.pchunks = d->norm && d->sums_chunks > 0 ? d->sums_chunks : p.nchunk;
     return p;
 }
 

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     const float* gb = nullptr; const float* g2b = nullptr; const float* gsb = nullptr; const float* yb = nullptr;
     if constexpr (MODE == 2) {
         const InBwd& n = p.nb;
-        const float* mm = n.ws + size_t(p.nbB) * n.nchunk * 2 * n.C + size_t(b) * 2 * n.C;
+        const float* mm = n.ws + size_t(p.nbB) * n.pchunks * 2 * n.C + size_t(b) * 2 * n.C;
         static_assert(MODE != 2 || VW == 4, "the instance-norm-backward variant works on channel quads");
         m1 = ld4(mm + q * 4); m2 = ld4(mm + n.C + q * 4);
         mean = ld4(n.mean + size_t(b) * n.C + q * 4);
@@ -855,6 +855,108 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ output transform + first pass of the
+// instance-norm backward of the layer that consumes this data gradient (nirgan_wino6_desc.fuse_*).  The tile's MO x MO outputs over the
+// padded extent stay in registers: the reflect halo (width 1) is folded onto the interior there (rows, then columns: the adjoint of
+// ReflectionPad2d(1) is separable; the host guarantees that the far halo line and its partner share a tile), the skip gradient is
+// added, g_a is stored dense, and the tile's sums of g_z = g_a * act'(z) and g_z * z leave as one chunk of partial sums.
+// (the pointers are separate __restrict__ kernel arguments: inside a parameter struct the stores of g_a would fence the loads of the
+// next pixel -- 90 us per layer instead of the ~55 the bytes cost)
+struct W6Fuse { const float* __restrict__ y; const float* __restrict__ mean; const float* __restrict__ rstd; const float* __restrict__ g2;
+                float* __restrict__ gz; float* __restrict__ part; int act; float slope; };
+
+template <int V>
+__global__ __launch_bounds__(256) void wino6_output_inbwd_kernel(const W6Out p, const float* __restrict__ fy, const float* __restrict__ fmean,
+                                                                 const float* __restrict__ frstd, const float* __restrict__ fg2,
+                                                                 float* __restrict__ fgz, float* __restrict__ fpart, const int fact, const float fslope) {
+    const W6Fuse f{fy, fmean, frstd, fg2, fgz, fpart, fact, fslope};
+    constexpr int N = W6<V>::N, MO = W6<V>::MO, VW = W6VW<V>::value;
+    typedef typename W6Vec<VW>::T V4;
+    const int q4 = p.K / VW;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= p.T * q4) return;
+    const long long t = i / q4;
+    const int q = int(i - t * q4);
+    const int tx = int(t % p.TW);
+    const long long r = t / p.TW;
+    const int ty = int(r % p.TH), b = int(r / p.TH);
+    const size_t plane = size_t(p.T) * p.K;
+    const float* M = p.M + size_t(t) * p.K + q * VW;
+    // A^T M A row by row of M: a row of 8 planes is reduced over the columns (8 -> 6), then spread over the 6 output rows with the
+    // constants of A^T's column -- 36 accumulators instead of the 48 intermediates of the two-pass form (the fused mode needs the
+    // whole tile in registers for the fold; this keeps the kernel at three waves per SIMD)
+    static_assert(V != 3, "the row-streaming form reads A^T from the tables (F(4x4,4x4) / F(6x6,3x3))");
+    V4 o[MO][MO];
+#pragma unroll
+    for (int a = 0; a < MO; ++a)
+#pragma unroll
+        for (int c = 0; c < MO; ++c) o[a][c] = V4{} * 0.f;
+#pragma unroll
+    for (int ap = 0; ap < N; ++ap) {
+        V4 m[N], tr[MO];
+#pragma unroll
+        for (int c = 0; c < N; ++c) m[c] = *reinterpret_cast<const V4*>(M + (ap * N + c) * plane);
+        W6<V>::at(m, tr);
+#pragma unroll
+        for (int a = 0; a < MO; ++a)
+#pragma unroll
+            for (int c = 0; c < MO; ++c) w6_mac(o[a][c], W6<V>::cAT(a, ap), tr[c]);
+    }
+    const int Hi = p.H - 2, Wi = p.W - 2;                     // interior extent; padded coordinate = interior + 1
+    // fold: padded line 0 onto padded line 2, padded line Hi + 1 onto padded line Hi - 1 (rows, then columns)
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+        const int hp = MO * ty + a;
+        if (a >= 2 && hp == 2) {
+#pragma unroll
+            for (int c = 0; c < MO; ++c) o[a][c] += o[a - 2][c];
+        }
+        if (a + 2 < MO && hp == Hi - 1) {
+#pragma unroll
+            for (int c = 0; c < MO; ++c) o[a][c] += o[a + 2][c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MO; ++c) {
+        const int wp = MO * tx + c;
+        if (c >= 2 && wp == 2) {
+#pragma unroll
+            for (int a = 0; a < MO; ++a) o[a][c] += o[a][c - 2];
+        }
+        if (c + 2 < MO && wp == Wi - 1) {
+#pragma unroll
+            for (int a = 0; a < MO; ++a) o[a][c] += o[a][c + 2];
+        }
+    }
+    const V4 mean = *reinterpret_cast<const V4*>(f.mean + size_t(b) * p.K + q * VW);
+    const V4 rstd = *reinterpret_cast<const V4*>(f.rstd + size_t(b) * p.K + q * VW);
+    const float neg = f.act == NIRGAN_ACT_RELU ? 0.f : f.act == NIRGAN_ACT_LRELU ? f.slope : 1.f;
+    const size_t img = size_t(b) * Hi * Wi * p.K + q * VW;
+    V4 s1 = mean * 0.f, s2 = mean * 0.f;
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+        const int h = MO * ty + a - 1;
+        if (h < 0 || h >= Hi) continue;
+#pragma unroll
+        for (int c = 0; c < MO; ++c) {
+            const int w = MO * tx + c - 1;
+            if (w < 0 || w >= Wi) continue;
+            const size_t off = img + (size_t(h) * Wi + w) * p.K;
+            V4 ga = o[a][c];
+            if (f.g2 != nullptr) ga += *reinterpret_cast<const V4*>(f.g2 + off);
+            *reinterpret_cast<V4*>(f.gz + off) = ga;
+            const V4 z = (*reinterpret_cast<const V4*>(f.y + off) - mean) * rstd;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) ga[e] = z[e] > 0.f ? ga[e] : ga[e] * neg;
+            s1 += ga;
+            s2 += ga * z;
+        }
+    }
+    float* sp = f.part + size_t(t) * 2 * p.K + q * VW;
+    *reinterpret_cast<V4*>(sp) = s1;
+    *reinterpret_cast<V4*>(sp + p.K) = s2;
+}
+
 // ------------------------------------------------------------------------------------------------ weight-gradient finish
 struct W6Fin { const float* slabs; int nsplit, K, C; float* grad; int accumulate; };
 
@@ -1129,7 +1231,7 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
 }
 
 extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
-    NG_REQUIRE(d && d->M && d->y, "wino6_output: null pointer");
+    NG_REQUIRE(d && d->M && (d->y || d->fuse_gz), "wino6_output: null pointer");
     const int v = w6_r(d->r), mo = w6_mo(v);
     NG_REQUIRE(w6_known(v), "wino6_output: variant %d (3, 4 or 6)", v);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->K > 0 && d->K % 4 == 0, "wino6_output: bad shape");
@@ -1137,6 +1239,23 @@ extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
     const long long T = w6_tiles(d->B, d->H, d->W, v);
     NG_REQUIRE(d->M_elems >= w6_np(v) * T * d->K, "wino6_output: M workspace too small");
     NG_REQUIRE(!d->stats_ws || (d->stats_ws_elems >= T * 2 * d->K && ng_aligned16(d->stats_ws)), "wino6_output: stats_ws too small or unaligned");
+    if (d->fuse_gz != nullptr) {
+        // the data gradient's output transform + the first pass of the consumer's instance-norm backward
+        NG_REQUIRE(v == 6 && !d->bias && !d->stats_ws, "wino6_output: the fused instance-norm backward pass is for F(6x6,3x3) data gradients (no bias, no forward statistics)");
+        NG_REQUIRE(d->fuse_y && d->fuse_mean && d->fuse_rstd && d->fuse_part, "wino6_output: fuse_y / fuse_mean / fuse_rstd / fuse_part required with fuse_gz");
+        NG_REQUIRE(ng_aligned16(d->fuse_y) && ng_aligned16(d->fuse_mean) && ng_aligned16(d->fuse_rstd) && ng_aligned16(d->fuse_g2) && ng_aligned16(d->fuse_gz) && ng_aligned16(d->fuse_part),
+                   "wino6_output: fuse pointers must be 16-byte aligned");
+        NG_REQUIRE(d->H >= 6 && d->W >= 6 && (d->H - 3) / mo == (d->H - 1) / mo && (d->W - 3) / mo == (d->W - 1) / mo,
+                   "wino6_output: the far halo line and its fold partner must share a tile (H=%d W=%d tile %d)", d->H, d->W, mo);
+        NG_REQUIRE(d->fuse_part_elems >= T * 2 * d->K, "wino6_output: fuse_part too small");
+        NG_REQUIRE(d->fuse_act == NIRGAN_ACT_NONE || d->fuse_act == NIRGAN_ACT_RELU || d->fuse_act == NIRGAN_ACT_LRELU, "wino6_output: fuse_act %d", d->fuse_act);
+        W6Out pf{d->M, nullptr, nullptr, d->B, d->H, d->W, d->K, (d->H + mo - 1) / mo, (d->W + mo - 1) / mo, T, nullptr};
+        const long long nf = T * (d->K / (v == 3 ? 4 : 2));
+        const dim3 gridf(unsigned((nf + 255) / 256));
+        hipStream_t sf = static_cast<hipStream_t>(stream);
+        hipLaunchKernelGGL(wino6_output_inbwd_kernel<6>, gridf, dim3(256), 0, sf, pf, d->fuse_y, d->fuse_mean, d->fuse_rstd, d->fuse_g2, d->fuse_gz, d->fuse_part, d->fuse_act, d->fuse_slope);
+        return nirgan_check_launch("wino6_output");
+    }
     W6Out p{d->M, d->bias, d->y, d->B, d->H, d->W, d->K, (d->H + mo - 1) / mo, (d->W + mo - 1) / mo, T, d->stats_ws};
     const long long n = T * (d->K / (v == 3 ? 4 : 2));
     const dim3 grid(unsigned((n + 255) / 256));

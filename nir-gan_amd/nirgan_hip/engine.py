@@ -767,9 +767,10 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
 
 def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Optional[Halo] = None, a: Optional[Halo] = None,
                 act=L.ACT_NONE, slope=0.2, y: Optional[Halo] = None, stats=None, norm=True, dy: Halo, gsum: Optional[Halo] = None,
-                dbias: Optional[torch.Tensor] = None, ws=None, shape=None, sums_only: bool = False):
+                dbias: Optional[torch.Tensor] = None, ws=None, shape=None, sums_only: bool = False, pre_sums: int = 0):
     """sums_only (with norm): the two reduction passes only; dy is then evaluated on the fly by the consumer (nirgan_wino6_input_dy_norm)
-    and its buffer is neither written nor read."""
+    and its buffer is neither written nor read.  pre_sums = chunks per sample: the producer of g (the data gradient's output transform in
+    its fused mode) already left the folded gradient in `gsum` and the first pass's partial sums in `ws`."""
     B, H, W, Cc = shape
     d = L.InBwdDesc()
     if g is not None:
@@ -794,6 +795,9 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
         d.dy_bf16 = dy.t16.data_ptr()
     if gsum is not None:
         d.gsum_out = gsum.ptr
+    if pre_sums:
+        assert norm and gsum is not None and not sums_only
+        d.sums_chunks = pre_sums
     if dbias is not None:
         d.dbias = dbias.data_ptr()
     ctx.keep.append(d)
@@ -928,11 +932,39 @@ class ConvIN:
                   and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C) and wino6_applicable(ctx, k, inp.C)
                   and inp.pad == 1 and p == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1")
         fuse_dy = w6_bwd and k == 3 and self.norm and dy.t16 is None and os.environ.get("NIRGAN_WINO6_DYNORM") == "1"
+        # OPT-IN (NIRGAN_INBWD_FUSE=1): the gradient arrives from a Winograd data gradient over the padded extent (reflect halo of 1 to
+        # fold): that launch's output transform is switched to its fused mode -- it folds the halo in registers, adds the skip gradient,
+        # stores the folded gradient dense and leaves the partial sums of this layer's first backward pass; the halo'd buffer `g` is then
+        # never written or read.  Measured NEUTRAL: the first pass disappears (94 -> 45 us per layer) but the output transform with its
+        # 36 x (y, skip, store) accesses per thread runs at 3.4 TB/s instead of 5.1 (39 -> 86 us): 765 vs 761-766 tiles/s.
+        pre_sums, ws = 0, eng.scratch.get()
+        od = getattr(g, "w6_out_desc", None) if g is not None else None
+        if (od is not None and od.r == 6 and g_fold and self.norm and not fuse_dy and g.pad == 1 and dy.t16 is None
+                and os.environ.get("NIRGAN_INBWD_FUSE") == "1"):
+            mo = _w6_geo(od.r if od.r else 3)[0]
+            Hp, Wp = od.H, od.W
+            if (Hp == self.OH + 2 and Wp == self.OW + 2 and od.K == self.cout and od.B == inp.B and min(Hp, Wp) >= 6
+                    and (Hp - 3) // mo == (Hp - 1) // mo and (Wp - 3) // mo == (Wp - 1) // mo):
+                chunks = (-(-Hp // mo)) * (-(-Wp // mo))
+                if gsum is None:                   # no skip path: the folded gradient lives in a pooled dense buffer until the second pass
+                    key = ("inbwd_gz", inp.B, self.OH, self.OW, self.cout)
+                    pool = ctx.__dict__.setdefault("inbwd_pool", {})
+                    if key not in pool:
+                        pool[key] = Halo(ctx, inp.B, self.OH, self.OW, self.cout, 0)
+                    gsum = pool[key]
+                if not hasattr(ctx, "inbwd_part"):
+                    ctx.inbwd_part = SplitPool(ctx)
+                ws = ctx.inbwd_part.get(inp.B * chunks * 2 * self.cout + inp.B * 2 * self.cout)
+                od.fuse_y, od.fuse_mean, od.fuse_rstd = self.y.ptr, self.stats[0].data_ptr(), self.stats[1].data_ptr()
+                od.fuse_g2 = g2.ptr if g2 is not None else None
+                od.fuse_gz, od.fuse_part, od.fuse_part_elems = gsum.ptr, ws.data_ptr(), ws.numel()
+                od.fuse_act, od.fuse_slope = act, 0.2
+                pre_sums = chunks
         nd = emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, a=(mask if mask is not None else self.out), act=act,
                          y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
                          dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
-                         ws=eng.scratch.get(),
-                         shape=(inp.B, self.OH, self.OW, self.cout), sums_only=fuse_dy)
+                         ws=ws,
+                         shape=(inp.B, self.OH, self.OW, self.cout), sums_only=fuse_dy, pre_sums=pre_sums)
         # stride-1 convolutions that need both gradients: one fused launch (data-gradient tiles + weight-gradient tiles)
         if (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
                 and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C)):
@@ -943,6 +975,8 @@ class ConvIN:
                 keepV = getattr(self, "wino_fwd_keeps_V", False) and getattr(self, "wino6", False)
                 emit_wino6_backward(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
                                     dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None), norm_desc=(nd if fuse_dy else None), r=k)
+                if k == 3:
+                    dgrad_out.w6_out_desc = wd6          # the consumer of this gradient may switch the output transform to its fused mode
                 return
             # exact-fp32 mode, 3x3: the data gradient is a Winograd convolution of dY (zero halo 2) with the flipped filter over the
             # padded input extent; the weight gradient keeps the direct tile (stand-alone launch)

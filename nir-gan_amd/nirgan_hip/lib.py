@@ -58,7 +58,7 @@ class InBwdDesc(C.Structure):
                 ("y", fp), ("mean", fp), ("rstd", fp), ("norm", i32),
                 ("B", i32), ("H", i32), ("W", i32), ("C", i32),
                 ("dy", fp), ("d_hp", i32), ("d_wp", i32), ("d_pad", i32),
-                ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64), ("dy_bf16", fp)]
+                ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64), ("dy_bf16", fp), ("sums_chunks", i32)]
 
 
 class ChanDgradDesc(C.Structure):
@@ -137,7 +137,9 @@ class WinoDyDesc(C.Structure):
 
 class Wino6Desc(C.Structure):
     _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
-                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32), ("stats_ws", fp), ("stats_ws_elems", i64)]
+                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32), ("stats_ws", fp), ("stats_ws_elems", i64),
+                ("fuse_y", fp), ("fuse_mean", fp), ("fuse_rstd", fp), ("fuse_g2", fp), ("fuse_gz", fp), ("fuse_part", fp), ("fuse_part_elems", i64),
+                ("fuse_act", i32), ("fuse_slope", f32)]
 
 
 class EndConvDesc(C.Structure):

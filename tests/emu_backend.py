@@ -615,6 +615,35 @@ class EmuBackend:
         M = arr(d.M, n * n * B * TH * TW * K).reshape(n, n, B, TH, TW, K).astype(np.float64)
         AT = self._W6[v][2]
         Y = np.einsum("pa,albyxk,ql->bypxqk", AT, M, AT).reshape(B, mo * TH, mo * TW, K)
+        if d.fuse_gz:
+            # data gradient over the padded extent + the first pass of the consumer's instance-norm backward: fold the reflect halo
+            # (rows, then columns), add the skip gradient, store g_a dense, leave the per-tile partial sums of g_z and g_z * z
+            if v != 6 or d.bias or H < 6 or W < 6 or (H - 3) // mo != (H - 1) // mo or (W - 3) // mo != (W - 1) // mo:
+                return self._fail("wino6_output: fused instance-norm backward: geometry")
+            if d.fuse_part_elems < B * TH * TW * 2 * K:
+                return self._fail("wino6_output: fuse_part too small")
+            self.calls.append("wino6_out_inbwd")
+            R = Y[:, :H, :W].copy()
+            R[:, 2] += R[:, 0]
+            R[:, H - 3] += R[:, H - 1]
+            R[:, :, 2] += R[:, :, 0]
+            R[:, :, W - 3] += R[:, :, W - 1]
+            Hi, Wi = H - 2, W - 2
+            ga = R[:, 1:H - 1, 1:W - 1]
+            if d.fuse_g2:
+                ga = ga + arr(d.fuse_g2, B * Hi * Wi * K).reshape(B, Hi, Wi, K)
+            arr(d.fuse_gz, B * Hi * Wi * K).reshape(B, Hi, Wi, K)[:] = ga.astype(np.float32)
+            yv = arr(d.fuse_y, B * Hi * Wi * K).reshape(B, Hi, Wi, K).astype(np.float64)
+            z = (yv - arr(d.fuse_mean, B * K).reshape(B, 1, 1, K)) * arr(d.fuse_rstd, B * K).reshape(B, 1, 1, K)
+            gzv = ga
+            if d.fuse_act in (1, 2):
+                gzv = np.where(z > 0, ga, ga * (0.0 if d.fuse_act == 1 else d.fuse_slope))
+            grid = np.zeros((2, B, mo * TH, mo * TW, K))
+            grid[0, :, 1:H - 1, 1:W - 1] = gzv
+            grid[1, :, 1:H - 1, 1:W - 1] = gzv * z
+            part = grid.reshape(2, B, TH, mo, TW, mo, K).sum((3, 5))                 # [2][B][TH][TW][K]
+            arr(d.fuse_part, B * TH * TW * 2 * K).reshape(B, TH, TW, 2, K)[:] = part.transpose(1, 2, 3, 0, 4)
+            return 0
         if d.stats_ws:
             # per-tile partial sums of the stored outputs, without the bias
             if d.stats_ws_elems < B * TH * TW * 2 * K:
@@ -882,7 +911,15 @@ class EmuBackend:
         self.calls.append("in_bwd")
         B, H, W, Cc = d.B, d.H, d.W, d.C
         ga = np.zeros((B, H, W, Cc), dtype=np.float64)
-        if d.g:
+        pre = d.norm and d.sums_chunks > 0
+        if pre:
+            # the producer (nirgan_wino6_output, fused mode) left g_a in gsum_out and the first pass's partial sums in ws
+            if not d.gsum_out or not d.dy or d.ws_elems < B * d.sums_chunks * 2 * Cc + B * 2 * Cc:
+                return self._fail("in_bwd: sums_chunks needs gsum_out, dy and a large enough ws")
+            self.calls.append("in_bwd_pre")
+            ga = arr(d.gsum_out, B * H * W * Cc).reshape(B, H, W, Cc).astype(np.float64)
+            psum = arr(d.ws, B * d.sums_chunks * 2 * Cc).reshape(B, d.sums_chunks, 2, Cc).astype(np.float64).sum(1) / (H * W)
+        elif d.g:
             if d.g_hp != H + 2 * d.g_pad or d.g_wp != W + 2 * d.g_pad:
                 return self._fail("in_bwd: g geometry")
             g = arr(d.g, B * d.g_hp * d.g_wp * Cc).reshape(B, d.g_hp, d.g_wp, Cc).astype(np.float64)
@@ -897,9 +934,9 @@ class EmuBackend:
                 ga += tmp2
             else:
                 ga += g[:, P:P + H, P:P + W]
-        if d.g2:
+        if d.g2 and not pre:
             ga += arr(d.g2, B * H * W * Cc).reshape(B, H, W, Cc)
-        if d.gsum_out:
+        if d.gsum_out and not pre:
             arr(d.gsum_out, B * H * W * Cc).reshape(B, H, W, Cc)[:] = ga
         z = None
         if d.norm or d.act in (1, 2):
@@ -916,7 +953,10 @@ class EmuBackend:
         if d.norm:
             zz = z.astype(np.float64)
             gzf = gz.reshape(B, H * W, Cc)
-            dy = rstd * (gzf - gzf.mean(1, keepdims=True) - zz * (gzf * zz).mean(1, keepdims=True))
+            m1, m2 = gzf.mean(1, keepdims=True), (gzf * zz).mean(1, keepdims=True)
+            if pre:                          # the means as the producer's partial sums give them
+                m1, m2 = psum[:, 0][:, None, :], psum[:, 1][:, None, :]
+            dy = rstd * (gzf - m1 - zz * m2)
             dy = dy.reshape(B, H, W, Cc)
         else:
             dy = gz

@@ -732,3 +732,38 @@ def test_size_512_and_128_forward_against_oracle():
         dref = O.discriminator_forward(sdD, torch.cat((rgb, nir), 1))
         assert dout.shape == dref.shape == (B, 1, size // 8 - 2, size // 8 - 2)
         close(dout, dref, 1e-3, f"D forward {size}")
+
+
+@pytest.mark.parametrize("cfg", [(32, 2, 64), (64, 2, 256)])
+def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypatch, cfg):
+    """The data gradient's output transform in its fused mode (csrc/wino6.hip::wino6_output_inbwd_kernel: reflect fold in registers,
+    skip gradient, dense folded gradient, partial sums of the consumer's first backward pass; opt-in, NIRGAN_INBWD_FUSE=1) against the
+    separate first pass: same forward (bitwise), gradients equal to fp32 rounding -- the backward has no branch that a
+    rounding difference could flip, the masks come from the forward."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    ngf, B, size = cfg
+    rgb, nir = synth(B, size, size, 77)
+
+    def run(fused):
+        if fused:
+            monkeypatch.setenv("NIRGAN_INBWD_FUSE", "1")
+        else:
+            monkeypatch.delenv("NIRGAN_INBWD_FUSE", raising=False)
+        torch.manual_seed(3)
+        netG = networks.define_G(3, 1, ngf, "resnet_6blocks", "instance", False, "normal", 0.02)
+        netD = networks.define_D(4, ngf, "basic", 3, "instance", "normal", 0.02)
+        tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=6, lr=0.0)
+        tr.step(rgb.to(DEV), nir.to(DEV))
+        torch.cuda.synchronize()
+        n_fused = sum(1 for n, a in tr.G.bwd.ops if n == "nirgan_wino6_output" and a[0]._obj.fuse_gz)
+        n_pre = sum(1 for n, a in tr.G.bwd.ops if n == "nirgan_instnorm_bwd" and a[0]._obj.sums_chunks > 0)
+        return tr.G.pred.clone(), tr.flatG.grad.clone(), tr.flatD.grad.clone(), n_fused, n_pre
+
+    p1, g1, d1, nf1, np1 = run(True)
+    p0, g0, d0, nf0, np0 = run(False)
+    assert nf1 == 12 and np1 == 12 and nf0 == 0 and np0 == 0, (nf1, np1, nf0, np0)
+    assert torch.equal(p1, p0)
+    assert ((d1 - d0).norm() / d0.norm()).item() < 1e-6        # the discriminator's own backward is untouched (its live bias uses float atomics)
+    rel = ((g1 - g0).norm() / g0.norm()).item()
+    assert rel < 2e-5, rel

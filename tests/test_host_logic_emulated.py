@@ -743,6 +743,7 @@ def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant
         monkeypatch.setenv("NIRGAN_NO_WINO6", "1")
     if variant == "F(4x4,3x3)":
         monkeypatch.setenv("NIRGAN_NO_WINO8", "1")
+    monkeypatch.setenv("NIRGAN_INBWD_FUSE", "1")      # the opt-in fused first pass of the instance-norm backward (F(6x6,3x3) only)
     torch.manual_seed(5)
     netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
@@ -759,6 +760,13 @@ def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant
         assert emu.calls.count("wino6_fin") == 12 and emu.calls.count("wino6_dy") == 12 and "wino_in_norm" not in emu.calls
         assert emu.calls.count("wino6_in") == 6 + 12          # c1 forwards + the dY transforms (no re-transform of the forward input)
         assert emu.calls.count("in_fwd_pre") == 12             # instance-norm statistics from the output transforms' partial sums
+        if variant == "F(6x6,3x3)":
+            # the first pass of the instance-norm backward inside the data gradient's output transform: the 12 layers whose gradient
+            # arrives from a Winograd data gradient (11 block convolutions + the last stride-2 layer); 8x8 maps padded to 10x10 put
+            # the far halo line and its fold partner into one 6x6 tile (with 4x4 tiles they straddle two: not fused)
+            assert emu.calls.count("wino6_out_inbwd") == 12 and emu.calls.count("in_bwd_pre") == 12
+        else:
+            assert "wino6_out_inbwd" not in emu.calls
     ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
     o = ref.step(rgb, nir)
     close(tr.G.pred, ref.last["pred"], 2e-5, "pred")
