@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Loss curves of the exact-fp32 step with the three convolution algorithms of the residual blocks -- F(6x6,3x3) (default),
+F(4x4,3x3) (NIRGAN_NO_WINO8=1), direct tiles (NIRGAN_NO_WINOGRAD=1) -- on the same data and initial weights: 240 steps over 8 fixed
+synthetic batches with a learnable relation (nir = smooth function of rgb), bs 16 @128^2, 6-block generator.  GAN training is
+chaotic: the curves separate after a few dozen steps whatever the rounding (see the fp32 / bf16x3 columns of
+profiles/r01_precision_training_curves.txt); what to look for is that they stay in one band and reach the same level."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nir-gan_amd"))
+import torch
+from model import networks
+from nirgan_hip.trainer import Pix2PixTrainer
+
+dev = "cuda:0"
+g = torch.Generator().manual_seed(3)
+batches = []
+for _ in range(8):
+    base = torch.nn.functional.interpolate(torch.rand(16, 3, 16, 16, generator=g), size=(128, 128), mode="bilinear", align_corners=False)
+    rgb = (0.05 + 0.5 * base + 0.02 * torch.rand(16, 3, 128, 128, generator=g))
+    nir = (0.1 + 0.6 * rgb[:, 0:1] + 0.3 * rgb[:, 1:2] * rgb[:, 2:3]).clamp(0, 1)
+    batches.append((rgb.to(dev), nir.to(dev)))
+variants = (("F(6x6,3x3)", {}), ("F(4x4,3x3)", {"NIRGAN_NO_WINO8": "1"}), ("direct tiles", {"NIRGAN_NO_WINOGRAD": "1"}))
+print("step   " + "".join(f"{n:>30s}" for n, _ in variants))
+rows, first = {}, {}
+for name, env in variants:
+    for k in ("NIRGAN_NO_WINO8", "NIRGAN_NO_WINOGRAD"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    torch.manual_seed(0)
+    netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(dev)
+    netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=6)
+    for step in range(240):
+        v = tr.step(*batches[step % 8])
+        if step == 0:
+            first[name] = v.as_dict()
+        if step % 20 == 19:
+            d = v.as_dict()
+            rows.setdefault(step + 1, []).append(f"  L1 {d['loss_G_l1']:.4f} D {d['loss_D']:.3f} Ggan {d['loss_G_gan']:.3f}")
+for step, cols in rows.items():
+    print(f"{step:4d}   " + "".join(f"{c:>30s}" for c in cols))
+print("first step (same weights, same batch):")
+for n, d in first.items():
+    print(f"  {n:14s} loss_D {d['loss_D']:.7f}  loss_G {d['loss_G']:.7f}  L1 {d['loss_G_l1']:.7f}")
