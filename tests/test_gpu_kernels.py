@@ -929,7 +929,8 @@ def test_wino6_conv3x3_matches_direct(shape):
 
 @pytest.mark.parametrize("hw", [(12, 16, 3, 3), (9, 11, 3, 3), (64, 64, 3, 3), (12, 16, 4, 4), (9, 11, 4, 4), (31, 31, 4, 4), (12, 16, 3, 6), (9, 11, 3, 6),
                                 (64, 64, 3, 6), (13, 6, 3, 6), (64, 64, 3, 6, 256), (21, 17, 3, 6, 256), (22, 18, 3, 3, 256), (40, 40, 3, 6, 256, 384),
-                                (64, 64, 3, 6, 256, 256, "NIRGAN_WINO6_WGRAD_NOPERSIST"), (64, 64, 3, 6, 256, 256, "NIRGAN_WINO6_GEMM_NOPERSIST")])
+                                (64, 64, 3, 6, 256, 256, "NIRGAN_WINO6_WGRAD_NOPERSIST"), (64, 64, 3, 6, 256, 256, "NIRGAN_WINO6_GEMM_NOPERSIST"),
+                                (64, 64, 3, 6, 256, 256, "NIRGAN_NO_WINO6_PAIR"), (64, 64, 3, 6, 256, 256, "NIRGAN_WGRAD_NOPERSIST")])
 def test_wino6_backward_matches_autograd(hw, monkeypatch):
     """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it with F(4x4,3x3): data gradient over the padded
     extent (dY transformed once for both uses), transform-domain weight gradient (36 planes in one weight-gradient launch, then
@@ -939,6 +940,8 @@ def test_wino6_backward_matches_autograd(hw, monkeypatch):
     H, W, r, v = hw[:4]                               # H x W = the layer's OUTPUT extent; its input is (H + r - 3) x (W + r - 3) + halo 1
     if len(hw) > 6:
         monkeypatch.setenv(hw[6], "1")                # the A/B fallbacks of the persistent pair launch (csrc/wino6.hip reads them per launch)
+        if hw[6] == "NIRGAN_WGRAD_NOPERSIST":         # two separate launches, the weight gradient one tile per workgroup
+            monkeypatch.setenv("NIRGAN_NO_WINO6_PAIR", "1")
     if v == 3:
         monkeypatch.setenv("NIRGAN_NO_WINO8", "1")    # 3x3 filters: F(4x4,3x3) instead of the default F(6x6,3x3)
     from nirgan_hip.engine import wino6_variant
