@@ -928,33 +928,49 @@ __global__ __launch_bounds__(256) void wino6_output_inbwd_kernel(const W6Out p, 
             for (int a = 0; a < MO; ++a) o[a][c] += o[a][c + 2];
         }
     }
-    const V4 mean = *reinterpret_cast<const V4*>(f.mean + size_t(b) * p.K + q * VW);
-    const V4 rstd = *reinterpret_cast<const V4*>(f.rstd + size_t(b) * p.K + q * VW);
+    // Per-pixel phase on channel QUADS: lanes 2k and 2k+1 hold the channel pairs 4k..4k+1 and 4k+2..4k+3 of the same tile; they swap
+    // halves of the tile (one DPP move per value) so that the even lane owns tile rows 0..2 and the odd lane rows 3..5 with four
+    // channels each -- 18 pixels x 16 bytes per lane instead of 36 x 8: half the memory instructions of this phase.
+    static_assert(VW == 2 && MO == 6, "the lane-pair exchange is written for channel pairs and 6x6 tiles");
+    const bool odd = (threadIdx.x & 1) != 0;                    // q is odd exactly when the lane is (K / 2 and the block size are even)
+    const int quad = (q >> 1) * 4;
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(f.mean + size_t(b) * p.K + quad);
+    const f32x4 rstd = *reinterpret_cast<const f32x4*>(f.rstd + size_t(b) * p.K + quad);
     const float neg = f.act == NIRGAN_ACT_RELU ? 0.f : f.act == NIRGAN_ACT_LRELU ? f.slope : 1.f;
-    const size_t img = size_t(b) * Hi * Wi * p.K + q * VW;
-    V4 s1 = mean * 0.f, s2 = mean * 0.f;
+    const size_t img = size_t(b) * Hi * Wi * p.K + quad;
+    auto swap1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)); };   // lane i <- lane i ^ 1
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a < MO; ++a) {
-        const int h = MO * ty + a - 1;
-        if (h < 0 || h >= Hi) continue;
+    for (int a = 0; a < 3; ++a) {
+        const int h = MO * ty + (odd ? a + 3 : a) - 1;
 #pragma unroll
         for (int c = 0; c < MO; ++c) {
+            const V4 mine = odd ? o[a + 3][c] : o[a][c], send = odd ? o[a][c] : o[a + 3][c];
+            V4 got;
+            got[0] = swap1(send[0]);
+            got[1] = swap1(send[1]);
+            f32x4 ga = odd ? f32x4{got[0], got[1], mine[0], mine[1]} : f32x4{mine[0], mine[1], got[0], got[1]};
             const int w = MO * tx + c - 1;
-            if (w < 0 || w >= Wi) continue;
+            if (h < 0 || h >= Hi || w < 0 || w >= Wi) continue;
             const size_t off = img + (size_t(h) * Wi + w) * p.K;
-            V4 ga = o[a][c];
-            if (f.g2 != nullptr) ga += *reinterpret_cast<const V4*>(f.g2 + off);
-            *reinterpret_cast<V4*>(f.gz + off) = ga;
-            const V4 z = (*reinterpret_cast<const V4*>(f.y + off) - mean) * rstd;
+            if (f.g2 != nullptr) ga += *reinterpret_cast<const f32x4*>(f.g2 + off);
+            *reinterpret_cast<f32x4*>(f.gz + off) = ga;
+            const f32x4 z = (*reinterpret_cast<const f32x4*>(f.y + off) - mean) * rstd;
 #pragma unroll
-            for (int e = 0; e < VW; ++e) ga[e] = z[e] > 0.f ? ga[e] : ga[e] * neg;
+            for (int e = 0; e < 4; ++e) ga[e] = z[e] > 0.f ? ga[e] : ga[e] * neg;
             s1 += ga;
             s2 += ga * z;
         }
     }
-    float* sp = f.part + size_t(t) * 2 * p.K + q * VW;
-    *reinterpret_cast<V4*>(sp) = s1;
-    *reinterpret_cast<V4*>(sp + p.K) = s2;
+    // the two lanes of a pair hold the sums of the two halves of the tile for the same four channels: add them, the even lane writes
+    // the sum of g_z, the odd lane the sum of g_z * z
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s1[e] += swap1(s1[e]);
+        s2[e] += swap1(s2[e]);
+    }
+    float* sp = f.part + size_t(t) * 2 * p.K + quad;
+    *reinterpret_cast<f32x4*>(odd ? sp + p.K : sp) = odd ? s2 : s1;
 }
 
 // ------------------------------------------------------------------------------------------------ weight-gradient finish

@@ -932,15 +932,15 @@ class ConvIN:
                   and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C) and wino6_applicable(ctx, k, inp.C)
                   and inp.pad == 1 and p == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1")
         fuse_dy = w6_bwd and k == 3 and self.norm and dy.t16 is None and os.environ.get("NIRGAN_WINO6_DYNORM") == "1"
-        # OPT-IN (NIRGAN_INBWD_FUSE=1): the gradient arrives from a Winograd data gradient over the padded extent (reflect halo of 1 to
-        # fold): that launch's output transform is switched to its fused mode -- it folds the halo in registers, adds the skip gradient,
-        # stores the folded gradient dense and leaves the partial sums of this layer's first backward pass; the halo'd buffer `g` is then
-        # never written or read.  Measured NEUTRAL: the first pass disappears (94 -> 45 us per layer) but the output transform with its
-        # 36 x (y, skip, store) accesses per thread runs at 3.4 TB/s instead of 5.1 (39 -> 86 us): 765 vs 761-766 tiles/s.
+        # The gradient arrives from an F(6x6,3x3) data gradient over the padded extent (reflect halo of 1 to fold): that launch's output
+        # transform is switched to its fused mode -- it folds the halo in registers (lane pairs exchange half tiles so that the per-pixel
+        # phase moves 16 bytes per lane), adds the skip gradient, stores the folded gradient dense and leaves the partial sums of this
+        # layer's first backward pass; the halo'd buffer `g` is then never written or read.  The first pass disappears (94 -> 45 us per
+        # layer) for an output transform of 67 us instead of 39: 21.16 -> 20.87 ms per step.  NIRGAN_NO_INBWD_FUSE=1 keeps the two passes.
         pre_sums, ws = 0, eng.scratch.get()
         od = getattr(g, "w6_out_desc", None) if g is not None else None
         if (od is not None and od.r == 6 and g_fold and self.norm and not fuse_dy and g.pad == 1 and dy.t16 is None
-                and os.environ.get("NIRGAN_INBWD_FUSE") == "1"):
+                and os.environ.get("NIRGAN_NO_INBWD_FUSE") != "1"):
             mo = _w6_geo(od.r if od.r else 3)[0]
             Hp, Wp = od.H, od.W
             if (Hp == self.OH + 2 and Wp == self.OW + 2 and od.K == self.cout and od.B == inp.B and min(Hp, Wp) >= 6

@@ -737,7 +737,7 @@ def test_size_512_and_128_forward_against_oracle():
 @pytest.mark.parametrize("cfg", [(32, 2, 64), (64, 2, 256)])
 def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypatch, cfg):
     """The data gradient's output transform in its fused mode (csrc/wino6.hip::wino6_output_inbwd_kernel: reflect fold in registers,
-    skip gradient, dense folded gradient, partial sums of the consumer's first backward pass; opt-in, NIRGAN_INBWD_FUSE=1) against the
+    skip gradient, dense folded gradient, partial sums of the consumer's first backward pass; NIRGAN_NO_INBWD_FUSE=1 turns it off) against the
     separate first pass: same forward (bitwise), gradients equal to fp32 rounding -- the backward has no branch that a
     rounding difference could flip, the masks come from the forward."""
     from model import networks
@@ -747,9 +747,9 @@ def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypat
 
     def run(fused):
         if fused:
-            monkeypatch.setenv("NIRGAN_INBWD_FUSE", "1")
+            monkeypatch.delenv("NIRGAN_NO_INBWD_FUSE", raising=False)
         else:
-            monkeypatch.delenv("NIRGAN_INBWD_FUSE", raising=False)
+            monkeypatch.setenv("NIRGAN_NO_INBWD_FUSE", "1")
         torch.manual_seed(3)
         netG = networks.define_G(3, 1, ngf, "resnet_6blocks", "instance", False, "normal", 0.02)
         netD = networks.define_D(4, ngf, "basic", 3, "instance", "normal", 0.02)

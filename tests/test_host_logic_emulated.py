@@ -743,7 +743,6 @@ def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant
         monkeypatch.setenv("NIRGAN_NO_WINO6", "1")
     if variant == "F(4x4,3x3)":
         monkeypatch.setenv("NIRGAN_NO_WINO8", "1")
-    monkeypatch.setenv("NIRGAN_INBWD_FUSE", "1")      # the opt-in fused first pass of the instance-norm backward (F(6x6,3x3) only)
     torch.manual_seed(5)
     netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
