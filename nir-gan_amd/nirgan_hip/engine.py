@@ -269,15 +269,16 @@ class Weights:
         self.ctx = ctx
         self.cache: Dict[tuple, torch.Tensor] = {}
 
-    def packed(self, plan: Plan, param: torch.Tensor, spec: G.PackSpec, rows_alloc: Optional[int] = None) -> torch.Tensor:
-        key = (param.data_ptr(), spec.key)
+    def packed(self, plan: Plan, param: torch.Tensor, spec: G.PackSpec, rows_alloc: Optional[int] = None, fp32: bool = False) -> torch.Tensor:
+        key = (param.data_ptr(), spec.key, fp32)
         if key in self.cache:
             return self.cache[key]
         rows = max(spec.N, rows_alloc or 0)
         imap = self.ctx.i32(spec.index_map)
         # bf16 operand mode: the packed copy is STORED as bf16 (rounded once here instead of at every fragment read) when
         # its rows stay 16-byte aligned; consumers recognise it by the tensor's dtype (emit_conv)
-        if self.ctx.precision == 1 and spec.run > 0 and spec.run % 8 == 0 and spec.K % 8 == 0:
+        # (fp32=True: a consumer that computes in fp32 in every mode -- the direct last-layer kernels)
+        if self.ctx.precision == 1 and spec.run > 0 and spec.run % 8 == 0 and spec.K % 8 == 0 and not fp32:
             buf = torch.zeros(rows, spec.K, dtype=torch.bfloat16, device=self.ctx.device)
             self.ctx.bytes += buf.numel() * 2
             plan.add("nirgan_pack_rows_bf16", param.data_ptr(), param.numel(), spec.row_stride, imap.data_ptr(),
@@ -1073,7 +1074,7 @@ class TapPlaneConv:
         self.nt = k * k
         self.qcs = -(-self.nt // 4) * 4
         self.OH, self.OW = inp.hp - k + 1, inp.wp - k + 1
-        self.direct = (inp.C == 64 and k == 7 and ctx.precision != 1 and os.environ.get("NIRGAN_NO_ENDCONV") != "1")
+        self.direct = (inp.C == 64 and k == 7 and os.environ.get("NIRGAN_NO_ENDCONV") != "1")      # exact fp32 kernels in every precision mode
         if not self.direct:
             self.q = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
         self.whole_in = Halo(ctx, inp.B, inp.hp, inp.wp, inp.C, 0, tensor=inp.t)     # same memory, halo as image
@@ -1090,7 +1091,7 @@ class TapPlaneConv:
 
     def emit_fwd(self, plan: Plan, pack: Plan):
         eng, ctx = self.eng, self.eng.ctx
-        w = eng.weights.packed(pack, self.weight, G.tapplane_fwd_pack(self.inp.C, self.k), rows_alloc=self.qcs)
+        w = eng.weights.packed(pack, self.weight, G.tapplane_fwd_pack(self.inp.C, self.k), rows_alloc=self.qcs, fp32=self.direct)
         if self.direct:
             plan.add("nirgan_endconv_fwd", C.byref(self._direct_desc(w)))
             return
@@ -1120,7 +1121,7 @@ class TapPlaneConv:
     def emit_bwd(self, plan: Plan, pack: Plan, gw: Optional[torch.Tensor], gb: Optional[torch.Tensor]):
         eng, ctx, inp = self.eng, self.eng.ctx, self.inp
         if self.direct:
-            w = eng.weights.packed(pack, self.weight, G.tapplane_fwd_pack(inp.C, self.k), rows_alloc=self.qcs)
+            w = eng.weights.packed(pack, self.weight, G.tapplane_fwd_pack(inp.C, self.k), rows_alloc=self.qcs, fp32=True)
             d = self._direct_desc(w)
             d.dout, d.dz, d.dz_elems = self.dout.data_ptr(), self.dz.data_ptr(), self.dz.numel()
             d.gx, d.gw, d.gbias = self.gin.ptr, _ptr(gw), _ptr(gb)

@@ -430,6 +430,33 @@ def test_data_parallel_equivalence_on_device():
         assert err < 1e-4, (name, err)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_reduced_operand_modes_stay_close_to_fp32_at_full_width(precision):
+    """ngf 64 (the width at which the generator's last layer runs as the direct fp32 kernels in every mode, csrc/endconv.hip, fed with
+    fp32-packed weights): prediction and generator gradient of one step in the bf16 operand modes against the fp32 step -- bf16 operands
+    cost ~2e-2, the split mode is fp32-like.  (Caught: bf16-stored packed weights handed to the fp32 kernels.)"""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    rgb, nir = synth(2, 128, 128, 5)
+
+    def run(prec):
+        torch.manual_seed(0)
+        netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
+        netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+        tr = Pix2PixTrainer(netG, netD, n_blocks=6, precision=prec, lr=0.0)
+        tr.step(rgb.to(DEV), nir.to(DEV))
+        torch.cuda.synchronize()
+        assert any(n == "nirgan_endconv_fwd" for n, _ in tr.G.fwd.ops)
+        return tr.G.pred.clone(), tr.flatG.grad.clone()
+
+    p0, g0 = run("fp32")
+    p1, g1 = run(precision)
+    ep = ((p1 - p0).norm() / p0.norm()).item()
+    eg = ((g1 - g0).norm() / g0.norm()).item()
+    bound = (5e-2, 8e-2) if precision == "bf16" else (1e-4, 5e-3)
+    assert ep < bound[0] and eg < bound[1], (ep, eg)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_training_is_stable_over_many_steps(precision):
     """41 optimizer steps on a fixed batch: finite everywhere and the L1 term drops (in every operand precision: the bf16
