@@ -96,6 +96,16 @@ typedef struct {
      * several problems over one output (the sub-pixel phases of a transposed convolution) numbers them with stats_chunk0, and
      * stats_chunks is the total per sample (the row stride of stats_ws).  stats_ws >= B * stats_chunks * 2 * N floats. */
     float* stats_ws; int64_t stats_ws_elems; int stats_chunk0, stats_chunks;
+    /* optional: the launch writes the gradient wrt the OUTPUT of a convolution + instance-norm (+ReLU / LeakyReLU) layer (it is the data
+     * gradient of that layer's consumer); the first pass of that layer's backward (nirgan_instnorm_bwd: sums of g_z = g * act'(z) and of
+     * g_z * z, z = (y - mean) * rstd) is then taken in the epilogue, next to the store of g: every 128-pixel tile leaves its sums in
+     * fuse_part[b][fuse_chunk0 + tile within the sample][2][N] (fixed order, no atomics) and nirgan_instnorm_bwd runs with
+     * sums_chunks = fuse_chunks (its first pass is not launched).  fuse_y: the layer's pre-normalisation output, dense
+     * [B][fuse_h][fuse_w][N]; the launch's output pixel (oh, ow) is y pixel (oh * out_stride + fuse_oh, ow * out_stride + fuse_ow).
+     * Needs OH * OW % 128 == 0, N % 4 == 0, no split-K, no bias.  fuse_part >= B * fuse_chunks * 2 * N floats. */
+    const float* fuse_y; const float* fuse_mean; const float* fuse_rstd;
+    int fuse_h, fuse_w, fuse_oh, fuse_ow, fuse_act; float fuse_slope;
+    float* fuse_part; int64_t fuse_part_elems; int fuse_chunk0, fuse_chunks;
 } nirgan_conv_desc;
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
@@ -206,9 +216,11 @@ typedef struct {
     float* dbias;
     float* ws; int64_t ws_elems;
     void* dy_bf16;                        /* optional twin of `dy` (same geometry, bf16), as out_bf16 */
-    int sums_chunks;                      /* > 0 (with norm): the first pass is done -- the producer of the gradient (nirgan_wino6_output with
-                                             fuse_gz) left the folded gradient g_a in gsum_out and the partial sums of g_z and g_z * z in ws as
-                                             [B][sums_chunks][2][C]; g / g2 are not read.  ws >= B * sums_chunks * 2 * C + B * 2 * C floats */
+    int sums_chunks;                      /* > 0 (with norm): the first pass is done -- the producer of the gradient left the partial sums of g_z
+                                             and g_z * z in ws as [B][sums_chunks][2][C].  Either nirgan_wino6_output with fuse_gz (the folded
+                                             gradient g_a then sits in gsum_out; g / g2 are not read), or a convolution launch with
+                                             nirgan_conv_desc.fuse_* (gsum_out NULL: the second pass reads g itself, which then has no fold
+                                             and no g2).  ws >= B * sums_chunks * 2 * C + B * 2 * C floats */
 } nirgan_in_bwd_desc;
 
 int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream);

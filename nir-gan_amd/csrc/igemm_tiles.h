@@ -78,6 +78,10 @@ struct ConvParams {
     int prec;                  // 0 fp32, 1 bf16 operands, 2 bf16x3 split (host-side dispatch only)
     float* stats;              // partial sums for the instance norm that follows: [B][stats_cps][2][N], see nirgan_conv_desc
     int stats_chunk0, stats_cps;
+    // first pass of the instance-norm backward of the layer whose output gradient this launch writes (nirgan_conv_desc.fuse_*)
+    const float* f_y; const float* f_mean; const float* f_rstd; float* f_part;
+    int f_img, f_row, f_org, f_act, f_chunk0, f_cps;
+    float f_slope;
 };
 
 
@@ -459,6 +463,16 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         const int r0 = mc - b * p.OHW;
         int oh = r0 / p.OW, ow = r0 - oh * p.OW;
         const int OH = p.OHW / p.OW;
+        // fused first pass of the consumer layer's instance-norm backward: this thread's 4 channels over its rows of the tile (host:
+        // OHW % 128 == 0 -- one sample per tile -- and N % 4 == 0)
+        const bool fused = p.f_y != nullptr;
+        const int fb = m0 / p.OHW;
+        f32x4 fm = {0.f, 0.f, 0.f, 0.f}, fr = {1.f, 1.f, 1.f, 1.f}, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (fused && n < p.N) {
+            fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(fb) * p.N + n);
+            fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(fb) * p.N + n);
+        }
+        const float fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
 #pragma unroll 4
         for (int row = row0; row < BM; row += RPP) {
             if (m < p.M && n < p.N) {
@@ -474,11 +488,40 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                     for (int j = 0; j < 4; ++j)
                         if (n + j < p.N) dst[j] = v[j];
                 }
+                if (fused) {
+                    const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.f_y + (size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n));
+                    const f32x4 z = (y4 - fm) * fr;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gz = z[j] > 0.f ? v[j] : v[j] * fneg;
+                        s1[j] += gz;
+                        s2[j] += gz * z[j];
+                    }
+                }
             }
             m += RPP;
             ow += RPP;
             while (ow >= p.OW) { ow -= p.OW; ++oh; }
             while (oh >= OH) { oh -= OH; ++b; }
+        }
+        if (fused) {
+            // the RPP threads of a channel quad join through LDS (the staged tile has been read), fixed order
+            __syncthreads();
+            f32x4* red = reinterpret_cast<f32x4*>(st0);
+            red[tid * 2] = s1;
+            red[tid * 2 + 1] = s2;
+            __syncthreads();
+            if (tid < LPR && n < p.N) {
+                f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int r = 0; r < RPP; ++r) {
+                    t1 += red[(r * LPR + tid) * 2];
+                    t2 += red[(r * LPR + tid) * 2 + 1];
+                }
+                float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((m0 - fb * p.OHW) >> 7)) * 2 * p.N + n;
+                *reinterpret_cast<f32x4*>(pp) = t1;
+                *reinterpret_cast<f32x4*>(pp + p.N) = t2;
+            }
         }
     }
     NG_DIAG_STORE(p.dbg, block_id)
@@ -1157,6 +1200,20 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
         NG_REQUIRE(d->stats_chunk0 >= 0 && d->stats_chunk0 + p.OHW / 64 <= d->stats_chunks, "conv: stats_chunk0 + OH*OW/64 exceeds stats_chunks");
         NG_REQUIRE(d->stats_ws_elems >= int64_t(d->B) * d->stats_chunks * 2 * d->N, "conv: stats_ws too small");
         p.stats = d->stats_ws; p.stats_chunk0 = d->stats_chunk0; p.stats_cps = d->stats_chunks;
+    }
+    p.f_y = nullptr; p.f_mean = nullptr; p.f_rstd = nullptr; p.f_part = nullptr;
+    p.f_img = p.f_row = p.f_org = p.f_chunk0 = p.f_cps = 0; p.f_act = NIRGAN_ACT_NONE; p.f_slope = 0.f;
+    if (d->fuse_y != nullptr) {
+        NG_REQUIRE(d->ksplit <= 1 && p.OHW % 128 == 0 && d->N % 4 == 0 && d->bias == nullptr, "conv: the fused instance-norm backward sums need OH*OW %% 128 == 0, N %% 4 == 0, no split-K and no bias (OH*OW=%d N=%d)", p.OHW, d->N);
+        NG_REQUIRE(d->fuse_mean && d->fuse_rstd && d->fuse_part && ng_aligned16(d->fuse_y) && ng_aligned16(d->fuse_mean) && ng_aligned16(d->fuse_rstd) && ng_aligned16(d->fuse_part), "conv: fuse_mean / fuse_rstd / fuse_part missing or misaligned");
+        NG_REQUIRE(d->fuse_oh >= 0 && d->fuse_ow >= 0 && (d->OH - 1) * d->out_stride + d->fuse_oh < d->fuse_h && (d->OW - 1) * d->out_stride + d->fuse_ow < d->fuse_w, "conv: fused window out of y's %d x %d extent", d->fuse_h, d->fuse_w);
+        NG_REQUIRE(int64_t(d->B) * d->fuse_h * d->fuse_w * d->N < (int64_t(1) << 31), "conv: fuse_y must be < 2^31 floats");
+        NG_REQUIRE(d->fuse_chunk0 >= 0 && d->fuse_chunk0 + p.OHW / 128 <= d->fuse_chunks, "conv: fuse_chunk0 + OH*OW/128 exceeds fuse_chunks");
+        NG_REQUIRE(d->fuse_part_elems >= int64_t(d->B) * d->fuse_chunks * 2 * d->N, "conv: fuse_part too small");
+        NG_REQUIRE(d->fuse_act == NIRGAN_ACT_NONE || d->fuse_act == NIRGAN_ACT_RELU || d->fuse_act == NIRGAN_ACT_LRELU, "conv: fuse_act=%d", d->fuse_act);
+        p.f_y = d->fuse_y; p.f_mean = d->fuse_mean; p.f_rstd = d->fuse_rstd; p.f_part = d->fuse_part;
+        p.f_row = d->fuse_w * d->N; p.f_img = d->fuse_h * p.f_row; p.f_org = d->fuse_oh * p.f_row + d->fuse_ow * d->N;
+        p.f_act = d->fuse_act; p.f_slope = d->fuse_slope; p.f_chunk0 = d->fuse_chunk0; p.f_cps = d->fuse_chunks;
     }
     if (d->ksplit > 1) {
         const int nk = d->ntaps * ((d->run + 31) / 32);

@@ -301,10 +301,12 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     InBwd p = in_bwd_params(d);
     NG_REQUIRE(!d->dy_bf16 || (d->C % 8 == 0 && (reinterpret_cast<uintptr_t>(d->dy_bf16) & 15) == 0), "instnorm_bwd: bf16 twin needs C %% 8 == 0 and 16-byte alignment");
     NG_REQUIRE(!d->norm || d->ws_elems >= int64_t(d->B) * p.pchunks * 2 * d->C + int64_t(d->B) * 2 * d->C, "instnorm_bwd: ws too small");
-    // sums_chunks > 0: the producer of the gradient (nirgan_wino6_output in its fused mode) already left the folded gradient in gsum_out
-    // and the partial sums of the first pass in ws
+    // sums_chunks > 0: the producer of the gradient already left the partial sums of the first pass in ws -- nirgan_wino6_output in its
+    // fused mode (the folded gradient then sits in gsum_out) or a convolution launch with nirgan_conv_desc.fuse_* (the gradient is g
+    // itself: no fold, no second gradient)
     const bool pre = d->norm && d->sums_chunks > 0;
-    NG_REQUIRE(!pre || (d->gsum_out != nullptr && !sums_only), "instnorm_bwd: sums_chunks needs the folded gradient in gsum_out and a dy to write");
+    NG_REQUIRE(!pre || !sums_only, "instnorm_bwd: sums_chunks needs a dy to write");
+    NG_REQUIRE(!pre || d->gsum_out != nullptr || (d->g != nullptr && !d->g_fold && d->g2 == nullptr), "instnorm_bwd: sums_chunks needs the folded gradient in gsum_out, or a plain g (no fold, no g2)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!pre) hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     if (d->norm) {

@@ -797,7 +797,7 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
     if gsum is not None:
         d.gsum_out = gsum.ptr
     if pre_sums:
-        assert norm and gsum is not None and not sums_only
+        assert norm and not sums_only and (gsum is not None or (g is not None and not g_fold and g2 is None))
         d.sums_chunks = pre_sums
     if dbias is not None:
         d.dbias = dbias.data_ptr()
@@ -961,6 +961,28 @@ class ConvIN:
                 od.fuse_gz, od.fuse_part, od.fuse_part_elems = gsum.ptr, ws.data_ptr(), ws.numel()
                 od.fuse_act, od.fuse_slope = act, 0.2
                 pre_sums = chunks
+        # The gradient arrives from direct-tile data-gradient launches (the sub-pixel phases of a stride-2 convolution, or a transposed
+        # convolution's strided one): their epilogue takes this layer's first backward pass next to the store (nirgan_conv_desc.fuse_*).
+        # Worth it on the large maps only (threshold as for the forward statistics); NIRGAN_NO_CONV_INBWD=1 keeps the separate pass.
+        cds = getattr(g, "conv_out_descs", None) if g is not None else None
+        if (cds and not pre_sums and self.norm and not g_fold and g2 is None and gsum is None and not fuse_dy and self.cout % 4 == 0
+                and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and os.environ.get("NIRGAN_NO_CONV_INBWD") != "1"
+                and all(c.ksplit <= 1 and (c.OH * c.OW) % 128 == 0 and c.N == self.cout and not c.bias for c in cds)
+                and sum(c.OH * c.OW for c in cds) == self.OH * self.OW
+                and self.OH * self.OW >= int(os.environ.get("NIRGAN_CONV_STATS_MIN", "16384"))):
+            chunks = sum(c.OH * c.OW // 128 for c in cds)
+            if not hasattr(ctx, "inbwd_part"):
+                ctx.inbwd_part = SplitPool(ctx)
+            ws = ctx.inbwd_part.get(inp.B * chunks * 2 * self.cout + inp.B * 2 * self.cout)
+            first = 0
+            for c in cds:
+                c.fuse_y, c.fuse_mean, c.fuse_rstd = self.y.ptr, self.stats[0].data_ptr(), self.stats[1].data_ptr()
+                c.fuse_h, c.fuse_w = self.OH, self.OW
+                c.fuse_oh, c.fuse_ow = c.out_oh - g.pad, c.out_ow - g.pad
+                c.fuse_act, c.fuse_slope = act, 0.2
+                c.fuse_part, c.fuse_part_elems, c.fuse_chunk0, c.fuse_chunks = ws.data_ptr(), ws.numel(), first, chunks
+                first += c.OH * c.OW // 128
+            pre_sums = chunks
         nd = emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, a=(mask if mask is not None else self.out), act=act,
                          y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
                          dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
@@ -1051,11 +1073,13 @@ class ConvIN:
                                        OH=ph.n_h, OW=ph.n_w, in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2,
                                        out_oh=ph.out_oh + dgrad_out.pad, out_ow=ph.out_ow + dgrad_out.pad))
             emit_conv_group(plan, ctx, descs)
+            dgrad_out.conv_out_descs = descs             # the consumer of this gradient may have the epilogues take its first backward pass
         elif self.kind == "convT":
             assert dgrad_out.H == inp.H and dy.pad == 1
             w = eng.weights.packed(pack, self.weight, G.convT_dgrad_pack(inp.C, self.cout, k))
-            emit_conv(plan, ctx, dy, G.convT_dgrad_taps(k, self.cout), w, None, dgrad_out, N=inp.C, OH=inp.H, OW=inp.W,
-                      in_stride=2, in_oh=dy.pad - p, in_ow=dy.pad - p, out_oh=dgrad_out.pad, out_ow=dgrad_out.pad)
+            cd = emit_conv(plan, ctx, dy, G.convT_dgrad_taps(k, self.cout), w, None, dgrad_out, N=inp.C, OH=inp.H, OW=inp.W,
+                           in_stride=2, in_oh=dy.pad - p, in_ow=dy.pad - p, out_oh=dgrad_out.pad, out_ow=dgrad_out.pad)
+            dgrad_out.conv_out_descs = [cd]
         else:
             raise NotImplementedError(self.kind)
 

@@ -31,7 +31,9 @@ class ConvDesc(C.Structure):
                 ("out_stride", i32), ("out_oh", i32), ("out_ow", i32),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32), ("zero_page", fp),
                 ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32), ("w_bf16", i32), ("in_bf16", i32),
-                ("stats_ws", fp), ("stats_ws_elems", i64), ("stats_chunk0", i32), ("stats_chunks", i32)]
+                ("stats_ws", fp), ("stats_ws_elems", i64), ("stats_chunk0", i32), ("stats_chunks", i32),
+                ("fuse_y", fp), ("fuse_mean", fp), ("fuse_rstd", fp), ("fuse_h", i32), ("fuse_w", i32), ("fuse_oh", i32), ("fuse_ow", i32),
+                ("fuse_act", i32), ("fuse_slope", f32), ("fuse_part", fp), ("fuse_part_elems", i64), ("fuse_chunk0", i32), ("fuse_chunks", i32)]
 
 
 class WgradDesc(C.Structure):

@@ -127,6 +127,12 @@ class EmuBackend:
                 return self._fail("conv: input cols out of range")
         if d.N > d.out_cs or (d.OH - 1) * d.out_stride + d.out_oh >= d.out_hp or (d.OW - 1) * d.out_stride + d.out_ow >= d.out_wp:
             return self._fail("conv: output out of range")
+        if d.fuse_y:
+            if (d.ksplit > 1 or (d.OH * d.OW) % 128 or d.N % 4 or d.bias or not (d.fuse_mean and d.fuse_rstd and d.fuse_part)
+                    or (d.OH - 1) * d.out_stride + d.fuse_oh >= d.fuse_h or (d.OW - 1) * d.out_stride + d.fuse_ow >= d.fuse_w
+                    or d.fuse_chunk0 < 0 or d.fuse_chunk0 + d.OH * d.OW // 128 > d.fuse_chunks or d.fuse_part_elems < d.B * d.fuse_chunks * 2 * d.N):
+                return self._fail("conv: the fused instance-norm backward sums need OH*OW % 128 == 0, N % 4 == 0, no split-K, no bias, a window inside y and a large enough fuse_part")
+            self.calls.append("conv_inbwd")
         stats = None
         if d.stats_ws:
             ohw = d.OH * d.OW
@@ -148,6 +154,17 @@ class EmuBackend:
                 acc += bias
             idx = b * out_img + obase[..., None] + np.arange(d.N)
             out[idx] = acc.astype(np.float32)
+            if d.fuse_y:                               # first pass of the consumer layer's instance-norm backward, per 128-pixel tile
+                yv = arr(d.fuse_y, d.B * d.fuse_h * d.fuse_w * d.N).reshape(d.B, d.fuse_h, d.fuse_w, d.N)
+                ys = yv[b, d.fuse_oh:d.fuse_oh + (d.OH - 1) * d.out_stride + 1:d.out_stride, d.fuse_ow:d.fuse_ow + (d.OW - 1) * d.out_stride + 1:d.out_stride]
+                z = ((ys - arr(d.fuse_mean, d.B * d.N).reshape(d.B, d.N)[b]) * arr(d.fuse_rstd, d.B * d.N).reshape(d.B, d.N)[b]).astype(np.float32)
+                gv = acc.astype(np.float32).astype(np.float64)
+                neg = 0.0 if d.fuse_act == 1 else (d.fuse_slope if d.fuse_act == 2 else 1.0)
+                gz = np.where(z > 0, gv, gv * neg)
+                part = arr(d.fuse_part, d.B * d.fuse_chunks * 2 * d.N).reshape(d.B, d.fuse_chunks, 2, d.N)
+                nch = d.OH * d.OW // 128
+                part[b, d.fuse_chunk0:d.fuse_chunk0 + nch, 0] = gz.reshape(nch, 128, d.N).sum(1)
+                part[b, d.fuse_chunk0:d.fuse_chunk0 + nch, 1] = (gz * z).reshape(nch, 128, d.N).sum(1)
         return 0
 
     def nirgan_wgrad_igemm(self, ref, stream=None):
@@ -913,12 +930,19 @@ class EmuBackend:
         ga = np.zeros((B, H, W, Cc), dtype=np.float64)
         pre = d.norm and d.sums_chunks > 0
         if pre:
-            # the producer (nirgan_wino6_output, fused mode) left g_a in gsum_out and the first pass's partial sums in ws
-            if not d.gsum_out or not d.dy or d.ws_elems < B * d.sums_chunks * 2 * Cc + B * 2 * Cc:
-                return self._fail("in_bwd: sums_chunks needs gsum_out, dy and a large enough ws")
+            # the producer left the first pass's partial sums in ws: nirgan_wino6_output in its fused mode (g_a then sits in gsum_out), or
+            # a convolution launch with fuse_* (the gradient is g itself: no fold, no second gradient)
+            if not d.dy or d.ws_elems < B * d.sums_chunks * 2 * Cc + B * 2 * Cc:
+                return self._fail("in_bwd: sums_chunks needs dy and a large enough ws")
+            if not d.gsum_out and (not d.g or d.g_fold or d.g2):
+                return self._fail("in_bwd: sums_chunks needs gsum_out or a plain g")
             self.calls.append("in_bwd_pre")
-            ga = arr(d.gsum_out, B * H * W * Cc).reshape(B, H, W, Cc).astype(np.float64)
             psum = arr(d.ws, B * d.sums_chunks * 2 * Cc).reshape(B, d.sums_chunks, 2, Cc).astype(np.float64).sum(1) / (H * W)
+            if d.gsum_out:
+                ga = arr(d.gsum_out, B * H * W * Cc).reshape(B, H, W, Cc).astype(np.float64)
+            else:
+                g = arr(d.g, B * d.g_hp * d.g_wp * Cc).reshape(B, d.g_hp, d.g_wp, Cc).astype(np.float64)
+                ga = g[:, d.g_pad:d.g_pad + H, d.g_pad:d.g_pad + W].copy()
         elif d.g:
             if d.g_hp != H + 2 * d.g_pad or d.g_wp != W + 2 * d.g_pad:
                 return self._fail("in_bwd: g geometry")

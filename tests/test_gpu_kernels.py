@@ -1190,3 +1190,78 @@ def test_conv_epilogue_leaves_the_instance_norm_partial_sums(case):
     close(m1, m0, 1e-6, "mean")
     close(r1, r0, 3e-6, "rstd")
     close(o1, o0, 1e-5, "layer output")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 8, "plain", L.ACT_RELU), (2, 32, 16, 64, 64, "plain", L.ACT_LRELU), (3, 16, 16, 32, 128, "plain", L.ACT_RELU),
+                                  (2, 16, 8, 64, 256, "plain", L.ACT_NONE), (2, 32, 32, 16, 64, "phases", L.ACT_RELU), (2, 32, 32, 32, 128, "phases", L.ACT_LRELU)])
+def test_conv_epilogue_takes_the_instance_norm_backward_first_pass(case):
+    """nirgan_conv_desc.fuse_*: a launch that writes the gradient wrt a ConvIN layer's output leaves, per 128-pixel tile, the sums of
+    g_z = g act'(z) and g_z z (csrc/igemm_tiles.h, conv_tile epilogue) -- against numpy on the stored g, for the 64- and 128-wide tiles,
+    two N tiles, and the four sub-pixel phases of a stride-2 data gradient numbering their chunks into one workspace; then
+    nirgan_instnorm_bwd with sums_chunks against its own first pass."""
+    B, H, W, Cin, N, mode, act = case
+    gen = torch.Generator().manual_seed(31)
+    ctx = Ctx(DEV)
+    k = 3
+    y = (torch.randn(B, H, W, N, generator=gen) * 1.5 + 0.3).to(DEV)                  # the layer's pre-normalisation output
+    mean = y.mean((1, 2)).contiguous()
+    rstd = (1.0 / torch.sqrt(y.var((1, 2), unbiased=False) + 1e-5)).contiguous()
+    g = Halo(ctx, B, H, W, N, 1)                                                     # the gradient buffer the launches write (zero halo)
+    chunks = H * W // 128
+    part = ctx.zeros(B * chunks * 2 * N + B * 2 * N)
+    descs = []
+    if mode == "plain":
+        x = Halo(ctx, B, H, W, Cin, 1)
+        x.t.copy_(torch.randn(x.t.shape, generator=gen))
+        spec = G.conv_fwd_pack(N, Cin, k)
+        w = (torch.randn(N, Cin, k, k, generator=gen) * 0.05).to(DEV)
+        wp = ctx.zeros(spec.N, spec.K)
+        L.call("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), wp.data_ptr(), spec.N, spec.K, None)
+        descs.append(emit_conv(None, ctx, x, G.conv_fwd_taps(k, Cin), wp, None, g, N=N, OH=H, OW=W, out_oh=1, out_ow=1, allow_split=False))
+    else:
+        # the data gradient of a 3x3 stride-2 convolution N -> Cin: dy is (H/2, W/2, Cin), the four phases interleave into g
+        dy = Halo(ctx, B, H // 2, W // 2, Cin, 1)
+        dy.t[:, 1:-1, 1:-1].copy_(torch.randn(B, H // 2, W // 2, Cin, generator=gen))
+        w = (torch.randn(Cin, N, k, k, generator=gen) * 0.05).to(DEV)
+        for ph in G.conv_dgrad_s2_phases(H, W, k, 1):
+            spec = G.conv_dgrad_pack(Cin, N, k, ph.taps_hw)
+            wp = ctx.zeros(spec.N, spec.K)
+            ctx.keep.append(wp)
+            L.call("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), wp.data_ptr(), spec.N, spec.K, None)
+            descs.append(emit_conv(None, ctx, dy, G.Taps(ph.dh, ph.dw, Cin), wp, None, g, N=N, OH=ph.n_h, OW=ph.n_w, in_oh=ph.in_oh, in_ow=ph.in_ow,
+                                   out_stride=2, out_oh=ph.out_oh + 1, out_ow=ph.out_ow + 1))
+    first = 0
+    for d in descs:
+        d.fuse_y, d.fuse_mean, d.fuse_rstd = y.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        d.fuse_h, d.fuse_w, d.fuse_oh, d.fuse_ow = H, W, d.out_oh - 1, d.out_ow - 1
+        d.fuse_act, d.fuse_slope = act, 0.2
+        d.fuse_part, d.fuse_part_elems, d.fuse_chunk0, d.fuse_chunks = part.data_ptr(), part.numel(), first, chunks
+        first += d.OH * d.OW // 128
+    assert first == chunks
+    st = torch.cuda.current_stream().cuda_stream
+    if mode == "plain":
+        L.call("nirgan_conv_igemm", C.byref(descs[0]), st)
+    else:
+        arr = (C.POINTER(L.ConvDesc) * 4)(*[C.pointer(d) for d in descs])
+        L.call("nirgan_conv_igemm_group", arr, 4, st)
+    torch.cuda.synchronize()
+    gi = g.t[:, 1:-1, 1:-1].double().cpu()
+    z = ((y - mean[:, None, None]) * rstd[:, None, None]).cpu()
+    neg = {L.ACT_NONE: 1.0, L.ACT_RELU: 0.0, L.ACT_LRELU: 0.2}[act]
+    gz = torch.where(z > 0, gi, gi * neg)
+    got = part[:B * chunks * 2 * N].view(B, chunks, 2, N).double().cpu().sum(1)
+    scale = gz.abs().sum((1, 2)).max().item()
+    assert (got[:, 0] - gz.sum((1, 2))).abs().max().item() < 2e-6 * scale
+    assert (got[:, 1] - (gz * z.double()).sum((1, 2))).abs().max().item() < 4e-6 * scale
+    # the consumer: nirgan_instnorm_bwd with the sums in place against its own first pass
+    outs = []
+    for pre in (chunks, 0):
+        dyo = Halo(ctx, B, H, W, N, 1)
+        ws = part if pre else ctx.zeros(L.backend().nirgan_instnorm_ws_elems(B, H, W, N))
+        plan = Plan(ctx)
+        yh = Halo(ctx, B, H, W, N, 0, tensor=y)
+        emit_in_bwd(plan, ctx, g=g, g_fold=False, act=act, y=yh, stats=(mean, rstd), norm=True, dy=dyo, ws=ws, shape=(B, H, W, N), pre_sums=pre)
+        plan.run()
+        outs.append(dyo.t.clone())
+    torch.cuda.synchronize()
+    close(outs[0], outs[1], 2e-5, "dy with the sums from the epilogue")

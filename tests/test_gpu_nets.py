@@ -784,7 +784,7 @@ def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypat
         tr.step(rgb.to(DEV), nir.to(DEV))
         torch.cuda.synchronize()
         n_fused = sum(1 for n, a in tr.G.bwd.ops if n == "nirgan_wino6_output" and a[0]._obj.fuse_gz)
-        n_pre = sum(1 for n, a in tr.G.bwd.ops if n == "nirgan_instnorm_bwd" and a[0]._obj.sums_chunks > 0)
+        n_pre = sum(1 for n, a in tr.G.bwd.ops if n == "nirgan_instnorm_bwd" and a[0]._obj.sums_chunks > 0 and a[0]._obj.gsum_out)
         return tr.G.pred.clone(), tr.flatG.grad.clone(), tr.flatD.grad.clone(), n_fused, n_pre
 
     p1, g1, d1, nf1, np1 = run(True)
@@ -794,3 +794,40 @@ def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypat
     assert ((d1 - d0).norm() / d0.norm()).item() < 1e-6        # the discriminator's own backward is untouched (its live bias uses float atomics)
     rel = ((g1 - g0).norm() / g0.norm()).item()
     assert rel < 2e-5, rel
+
+
+def test_instance_norm_backward_first_pass_inside_the_conv_epilogues(monkeypatch):
+    """The up/down-sampling layers' data gradients (direct tiles) take the consumer layer's first backward pass in their epilogue
+    (nirgan_conv_desc.fuse_*, from 16 K pixels per sample: the 128x128 maps of a 128x128 tile) -- against the separate pass
+    (NIRGAN_NO_CONV_INBWD=1): same forward bitwise, gradients equal to fp32 rounding."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    rgb, nir = synth(2, 128, 128, 78)
+
+    def run(fused):
+        if fused:
+            monkeypatch.delenv("NIRGAN_NO_CONV_INBWD", raising=False)
+        else:
+            monkeypatch.setenv("NIRGAN_NO_CONV_INBWD", "1")
+        torch.manual_seed(3)
+        netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02)
+        netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
+        tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=6, lr=0.0)
+        tr.step(rgb.to(DEV), nir.to(DEV))
+        torch.cuda.synchronize()
+        n = 0
+        for plan in (tr.G.bwd, tr.D2.bwd, tr.D1.bwd_pred):
+            for name, a in plan.ops:
+                if name == "nirgan_conv_igemm" and a[0]._obj.fuse_y:
+                    n += 1
+                if name == "nirgan_conv_igemm_group":
+                    n += sum(1 for i in range(a[1]) if a[0][i].contents.fuse_y)
+        return tr.G.pred.clone(), tr.flatG.grad.clone(), tr.flatD.grad.clone(), n
+
+    p1, g1, d1, n1 = run(True)
+    p0, g0, d0, n0 = run(False)
+    assert n1 >= 4 and n0 == 0, (n1, n0)
+    assert torch.equal(p1, p0)
+    assert ((d1 - d0).norm() / d0.norm()).item() < 1e-5
+    rel = ((g1 - g0).norm() / g0.norm()).item()
+    assert rel < 1e-5, rel

@@ -799,3 +799,28 @@ def test_conv_epilogue_statistics_through_the_trainer(emu, monkeypatch, golden_d
     close(tr.G.pred, z["pred"], 1e-4, "pred")
     for k in ("loss_D", "loss_G", "loss_G_l1"):
         close(out[k], z[k], 1e-4, k)
+
+
+def test_conv_epilogue_takes_the_instance_norm_backward_first_pass(emu, monkeypatch, golden_dir):
+    """The sub-pixel phase launches of a stride-2 data gradient leave the consumer layer's first backward pass (sums of g_z and g_z z per
+    128-pixel tile, nirgan_conv_desc.fuse_*; the engines do that from 16 K pixels per sample, NIRGAN_CONV_STATS_MIN=0 here, forward
+    statistics kept on their own pass so that the forward is the golden one): gradients of the golden small net within the usual bounds."""
+    from nirgan_hip.trainer import Pix2PixTrainer
+    monkeypatch.setenv("NIRGAN_CONV_STATS_MIN", "0")
+    monkeypatch.setenv("NIRGAN_NO_CONV_STATS", "1")
+    z = load(golden_dir, "f1_g6_d.npz")
+    nb = int(z["n_blocks"])
+    netG, netD = make_nets(z, nb)
+    tr = Pix2PixTrainer(netG, netD, n_blocks=nb, padding=int(z["padding"]))
+    out = tr.step(torch.from_numpy(z["rgb"]), torch.from_numpy(z["nir"])).as_dict()
+    assert emu.calls.count("conv_inbwd") >= 5 and emu.calls.count("in_bwd_pre") >= 2, (emu.calls.count("conv_inbwd"), emu.calls.count("in_bwd_pre"))
+    close(tr.G.pred, z["pred"], 2e-5, "pred")
+    close(out["loss_G"], z["loss_G"], 1e-5, "loss_G")
+    gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
+    for k, v in sub(z, "gD/").items():
+        if k not in O.shadowed_bias_keys("D"):
+            close(gD[k], v, 2e-4, "gD " + k)
+    shadow = O.shadowed_bias_keys("G", nb)
+    for k, v in sub(z, "gG/").items():
+        if k not in shadow:
+            close(gG[k], v, 2e-4, "gG " + k)
