@@ -68,3 +68,18 @@ def test_struct_layouts_match_the_header(tmp_path):
         size, off = (int(x) for x in line.split())
         assert C.sizeof(ct) == size, cname
         assert getattr(ct, ct._fields_[-1][0]).offset == off, cname
+
+
+def test_integration_stub_mirrors_the_descriptor():
+    """INTEGRATION.md shows the ctypes mirror a maintainer would write for nirgan_conv_desc: it has to match the library's own mirror
+    (field names, order, size) -- the library reads the whole descriptor."""
+    import ctypes as C
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    m = re.search(r"class ConvDesc\(C\.Structure\):.*?\n((?:    .*\n)+)", text)
+    assert m, "INTEGRATION.md: the ConvDesc stub is gone"
+    ns = {"C": C}
+    exec("class ConvDesc(C.Structure):\n" + m.group(1), ns)
+    stub = ns["ConvDesc"]
+    assert [f[0] for f in stub._fields_] == [f[0] for f in L.ConvDesc._fields_]
+    assert C.sizeof(stub) == C.sizeof(L.ConvDesc)
