@@ -324,15 +324,18 @@ def test_fullsize_fused_step_against_oracle():
     path and at 1e-2 for the reference's own fp32 CPU arithmetic (profiles/r02_grad_error_kinkfree_vs_fp64.txt); that the device's
     branch decisions are legitimate is checked separately: they differ from the fp64 evaluation's own in < 1e-4 of the elements, all
     of them within 1e-4 of the kink."""
+    _fused_step_against_oracle(1, 256, 256, 6, 1234)
+
+
+def _fused_step_against_oracle(B, H, W, nb, seed):
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
-    nb = 6
     torch.manual_seed(0)
     netG = networks.define_G(3, 1, 64, f"resnet_{nb}blocks", "instance", False, "normal", 0.02)
     torch.manual_seed(0)
     netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
     pG, pD = {k: v.clone() for k, v in netG.state_dict().items()}, {k: v.clone() for k, v in netD.state_dict().items()}
-    rgb, nir = synth(1, 256, 256, 1234)
+    rgb, nir = synth(B, H, W, seed)
     tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=nb)
     out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
     kinks = device_kinks(tr, nir)
@@ -359,7 +362,14 @@ def test_fullsize_fused_step_against_oracle():
             if k not in shadow:
                 worst = max(worst, ((gdev[k].double().cpu() - v).norm() / v.norm()).item())
                 grad_close64(gdev[k], v, f"{name} {k}", l2=3e-4, mx=3e-3)
-    print(f"fused step, kinks forced: worst rel-L2 over all gradient tensors {worst:.2e}; {flips} of {total} branch decisions differ from fp64's own")
+    print(f"fused step {B}x{H}x{W}, kinks forced: worst rel-L2 over all gradient tensors {worst:.2e}; {flips} of {total} branch decisions differ from fp64's own")
+
+
+@pytest.mark.parametrize("shape", [(3, 72, 104), (2, 100, 60), (1, 36, 40)])
+def test_ragged_sizes_fused_step_against_oracle(shape):
+    """The same comparison on tiles that are neither square nor powers of two (multiples of 4, as the reference's down/up path needs):
+    ragged Winograd tiles (trunk maps 18 x 26, 25 x 15, 9 x 10), partial M tiles everywhere, odd PatchGAN maps."""
+    _fused_step_against_oracle(*shape, 6, 91)
 
 
 def test_reference_full_discriminator_output(golden_dir):
