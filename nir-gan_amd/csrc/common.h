@@ -48,6 +48,19 @@ __device__ __forceinline__ void ng_glds16(const float* src, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((const NG_GLOBAL void*)src, (NG_LDS void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same with the address as SGPR base + 32-bit VGPR byte offset (global_load_lds_dwordx4 v_off, s[base:base+1]): no vector
+// arithmetic per piece.  `base` must be wave-uniform (it is pinned to SGPRs here); the empty asm keeps the zero-extension of the
+// offset inside the basic block of the load, where instruction selection can fold it (hoisted, it becomes a 64-bit VALU add).
+__device__ __forceinline__ const char* ng_uniform_ptr(const char* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(a)), hi = __builtin_amdgcn_readfirstlane(unsigned(a >> 32));
+    return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__device__ __forceinline__ void ng_glds16_so(const char* base, unsigned off, void* lds_wave_base) {
+    asm volatile("" : "+v"(off));
+    __builtin_amdgcn_global_load_lds((const NG_GLOBAL void*)(base + off), (NG_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
 // reflect index into [0, n) (nn.ReflectionPad2d semantics, pad < n)
 __host__ __device__ __forceinline__ int ng_reflect(int i, int n) {
     if (i < 0) i = -i;

@@ -82,6 +82,7 @@ struct ConvParams {
     const float* f_y; const float* f_mean; const float* f_rstd; float* f_part;
     int f_img, f_row, f_org, f_act, f_chunk0, f_cps;
     float f_slope;
+    int off32;                 // both operand buffers span < 4 GB: per-lane 32-bit byte offsets from a scalar base (the loader's fast path)
 };
 
 
@@ -163,9 +164,28 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         }
     }
 
+    // fast path of a K-step that lies inside the run, for a tile whose weight rows all exist: the address of a piece is a scalar base
+    // (tap + slice of the run) + a per-lane byte offset that is constant for the whole tile -- no vector arithmetic per piece
+    constexpr int ESA = AB16 ? 2 : 4, ESB = WB16 ? 2 : 4;
+    unsigned a_boff[AIW], b_boff[BIW];
+#pragma unroll
+    for (int i = 0; i < AIW; ++i) a_boff[i] = unsigned(a_base[i]) * unsigned(ESA);
+#pragma unroll
+    for (int i = 0; i < BIW; ++i) b_boff[i] = unsigned(b_base[i]) * unsigned(ESB);
+    const bool inside = p.off32 != 0 && n0 + BN <= p.N;
+
     auto issue = [&](char* sA, int t, int c0) {
         char* sB = sA + A_BYTES;
         const int toff = p.tap_off[t] + c0;
+        if (inside && c0 + KS <= p.run) {
+            const char* ab = ng_uniform_ptr(reinterpret_cast<const char*>(p_in) + (long long)toff * ESA);
+            const char* bb = ng_uniform_ptr(reinterpret_cast<const char*>(p_w) + (long long)(t * p.run + c0) * ESB);
+#pragma unroll
+            for (int i = 0; i < AIW; ++i) ng_glds16_so(ab, a_boff[i], sA + (wave * 4 + i) * 1024);
+#pragma unroll
+            for (int i = 0; i < BIW; ++i) ng_glds16_so(bb, b_boff[i], sB + (wave * (WB16 ? BIW : BI) + i) * 1024);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < AIW; ++i) {
             const bool ok = c0 + a_col[i] < p.run;
@@ -542,6 +562,7 @@ struct WgradParams {
     int pq_bf16;               // p and q point to bf16 twins (bf16 operand mode, N > 64)
     int nplanes;               // independent problems of identical geometry in one grid (Winograd-domain weight gradient: 16)
     long long p_plane, q_plane;   // floats between consecutive planes of p / q; slabs are [plane][split][N][K]
+    int fast32;                // fp32-stored operands in buffers < 4 GB, taps at non-negative offsets, OW % 32 == 0 and M % 32 == 0: the scalar-walk loader applies
 };
 
 
@@ -604,8 +625,35 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
 #pragma unroll
     for (int i = 0; i < 4; ++i) qp[i] = decompose(mstart + (wave * 4 + i) * 2 + q_lrow);
 
+    // scalar-walk fast path (host: fast32; here: the tile's rows and columns all exist): a K-step is 32 consecutive pixels of ONE image
+    // row, so its first pixel (sb, soh, sow) walks in scalar registers, the address of a piece is a scalar base + a per-lane byte
+    // offset that is constant for the whole tile, and the per-lane pixel walk below (multiplies, compares, wrap loops) is not needed
+    // (lanes whose channel n or column j does not exist read a valid address instead of the zero page: what they feed are rows / columns
+    // of the tile that are never stored, and no product crosses rows or columns)
+    const bool fast = p.fast32 != 0;
+    unsigned pl_off[PI], ql_off[4];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) pl_off[i] = unsigned(((wave * PI + i) * RPI + p_lrow) * p.p_cs + (p_ok ? p_chunk * 4 : 0)) * 4u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ql_off[i] = unsigned(((wave * 4 + i) * 2 + q_lrow) * p.q_stride * p.q_cs + q_add) * 4u;
+    int sb = __builtin_amdgcn_readfirstlane(mstart / p.OHW);
+    int soh = __builtin_amdgcn_readfirstlane((mstart - sb * p.OHW) / p.OW);
+    int sow = __builtin_amdgcn_readfirstlane(mstart - sb * p.OHW - soh * p.OW);
+
     auto issue = [&](char* sP, int mb) {
         char* sQ = sP + P_BYTES;
+        if (fast) {
+            const char* pb = ng_uniform_ptr(reinterpret_cast<const char*>(Pp + (size_t(sb) * p.p_img + size_t(soh) * p.p_row + sow * p.p_cs + p.p_org + (n0 < p.N ? n0 : 0))));
+            const char* qb = ng_uniform_ptr(reinterpret_cast<const char*>(Qp + (size_t(sb) * p.q_img + size_t(soh) * p.q_stride * p.q_row + sow * p.q_stride * p.q_cs + p.q_org)));
+#pragma unroll
+            for (int i = 0; i < PI; ++i) ng_glds16_so(pb, pl_off[i], sP + (wave * PI + i) * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ng_glds16_so(qb, ql_off[i], sQ + (wave * 4 + i) * 1024);
+            sow += 32;
+            if (sow >= p.OW) { sow = 0; ++soh; }
+            if (soh >= p.OH) { soh = 0; ++sb; }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
             const int ins = wave * PI + i;
@@ -798,7 +846,7 @@ __device__ __forceinline__ void wgrad_tile(const WgradParams& p, const int block
 // stride-2 / transposed layers' weight gradients: correct, but 256 VGPRs + 320 B of scratch and the walk inside 16 unrolled steps made
 // it 40-50 % SLOWER than one tile per workgroup (582 vs 383 us); removed.
 // Host: every split holds rows (nk >= 1), fp32 operands, N > 64 (wgrad_persist_ok && wgrad_matrix_form).
-struct WgradUnit { const float* Pp; const float* Qp; float* slab; int n0, j0, mstart, mend, nk; bool p_ok, q_ok; int p_n, q_add; };
+struct WgradUnit { const float* Pp; const float* Qp; float* slab; int n0, j0, mstart, mend, nk; bool p_ok, q_ok; int p_n, q_add; bool inside; };
 
 __device__ __forceinline__ void wgrad_persist(const WgradParams& p, const int first, const int stride, char* lds) {
     constexpr int TN = 128, P_BYTES = 32 * TN * 4, Q_BYTES = 32 * 128 * 4, STAGE = P_BYTES + Q_BYTES;
@@ -807,6 +855,8 @@ __device__ __forceinline__ void wgrad_persist(const WgradParams& p, const int fi
     const int tiles = p.ntiles_n * p.ntiles_k, per_plane = tiles * p.nsplit, total = per_plane * p.nplanes;
     const int lrow = lane >> 5, chunk = lane & 31;
 
+    // (32-bit byte offsets inside a plane)
+    const bool off32 = (long long)p.M * p.p_cs < (1ll << 29) && (long long)p.M * p.q_cs < (1ll << 29);
     auto setup = [&](int logical, WgradUnit& u) {
         const int rid = ng_xcd_remap(logical, total);
         const int plane = rid / per_plane, id = rid - plane * per_plane;
@@ -826,10 +876,30 @@ __device__ __forceinline__ void wgrad_persist(const WgradParams& p, const int fi
         u.q_ok = q_j < p.K;
         u.q_add = 0;
         if (u.q_ok) u.q_add = q_j;
+        u.inside = u.n0 + TN <= p.N && u.j0 + 128 <= p.K && off32;       // every lane's column exists: no zero-page selects
     };
+    // per-lane byte offsets of a piece from the step's first pixel (constants of the launch): piece i of this wave holds pixel rows
+    // (4 wave + i) * 2 + lrow
+    unsigned pl_off[4], ql_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pl_off[i] = unsigned(((wave * 4 + i) * 2 + lrow) * p.p_cs + chunk * 4) * 4u;
+        ql_off[i] = unsigned(((wave * 4 + i) * 2 + lrow) * p.q_cs + chunk * 4) * 4u;
+    }
     // wave w owns P pieces 4w .. 4w+3 and Q pieces 4w .. 4w+3 (a piece = 2 pixel rows x 512 B); mb = first pixel of the step
     auto issue = [&](const WgradUnit& u, char* sP, int mb) {
         char* sQ = sP + P_BYTES;
+        if (u.inside && mb + 32 <= u.mend) {
+            // a whole step inside the unit: SGPR base + constant per-lane offsets, no vector arithmetic per piece
+            const char* pb = ng_uniform_ptr(reinterpret_cast<const char*>(u.Pp + (size_t(mb) * p.p_cs + u.n0)));
+            const char* qb = ng_uniform_ptr(reinterpret_cast<const char*>(u.Qp + (size_t(mb) * p.q_cs + u.j0)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ng_glds16_so(pb, pl_off[i], sP + (wave * 4 + i) * 1024);
+                ng_glds16_so(qb, ql_off[i], sQ + (wave * 4 + i) * 1024);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ins = wave * 4 + i;
@@ -1191,6 +1261,7 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     NG_REQUIRE(!p.w_bf16 || (d->precision == 1 && d->run % 8 == 0), "conv: bf16-stored weights need precision 1 and run %% 8 == 0 (run=%d)", d->run);
     p.in_bf16 = d->in_bf16 ? 1 : 0;
     NG_REQUIRE(!p.in_bf16 || (p.w_bf16 && d->in_cs % 8 == 0), "conv: bf16 activations need bf16-stored weights and in_cs %% 8 == 0 (in_cs=%d)", d->in_cs);
+    p.off32 = (d->in_elems * (p.in_bf16 ? 2 : 4) < (int64_t(1) << 32) && d->w_elems * (p.w_bf16 ? 2 : 4) < (int64_t(1) << 32)) ? 1 : 0;
     p.dbg = nullptr;
     p.ksplit = 1;
     p.split_ws = nullptr;
@@ -1272,6 +1343,12 @@ inline int build_wgrad_params(const nirgan_wgrad_desc* d, WgradParams& p) {
     NG_REQUIRE(d->slab_elems >= int64_t(p.nplanes) * d->nsplit * d->N * K, "wgrad_igemm: slab_elems too small for %d planes", p.nplanes);
     NG_REQUIRE(d->p_elems >= (p.nplanes - 1) * d->p_plane + int64_t(d->B) * d->p_hp * d->p_wp * d->p_cs && d->q_elems >= (p.nplanes - 1) * d->q_plane + int64_t(d->B) * d->q_hp * d->q_wp * d->q_cs, "wgrad_igemm: p/q too small for the planes");
     p.pq_bf16 = d->pq_bf16 ? 1 : 0;
+    {
+        bool taps_ok = true;
+        for (int t = 0; t < d->ntaps; ++t) taps_ok = taps_ok && (d->tap_dh[t] * p.q_row + d->tap_dw[t] * d->q_cs >= 0);
+        p.fast32 = (taps_ok && !d->pq_bf16 && d->OW % 32 == 0 && p.M % 32 == 0 && d->rows_per_split % 32 == 0
+                    && d->p_elems * 4 < (int64_t(1) << 32) && d->q_elems * 4 < (int64_t(1) << 32)) ? 1 : 0;
+    }
     NG_REQUIRE(!p.pq_bf16 || (d->precision == 1 && d->N > 64 && d->N % 8 == 0 && d->run % 8 == 0 && d->p_cs % 8 == 0 && d->q_cs % 8 == 0),
                "wgrad_igemm: bf16 twins need precision 1, N > 64 and N, run, p_cs, q_cs multiples of 8");
     return NIRGAN_OK;

@@ -593,33 +593,37 @@ __device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, c
     // chunk of a row is XOR-swizzled with key(row) on the source side and at the fragment reads
     auto key = [](int row) { return KS == 16 ? (row >> 2) & 3 : (row >> 1) & 7; };
     const int prow = lane / CH, lchunk = lane % CH;
-    struct Ld { const float* A; const float* Bw; int a_base[PW], b_base[PW]; bool b_ok[PW]; };
+    // per-lane BYTE offsets (32 bits) from the plane's uniform base pointers: the LDS-DMA then takes its address as SGPR base + VGPR
+    // offset and a K-step advances the scalar base only -- no vector arithmetic per piece
+    struct Ld { const char* A; const char* Bw; unsigned a_off[PW], b_off[PW]; };
     auto setup = [&](int logical, Ld& l, int& plane, int& m0, int& n0) {
         const int rid = ng_xcd_remap(logical, p.total);
         plane = rid / p.per_plane;
         const int id = rid - plane * p.per_plane;
         n0 = (id % p.ntiles) * 128;
         m0 = (id / p.ntiles) * 128;
-        l.A = p.A + size_t(plane) * p.a_plane;
-        l.Bw = p.Bw + size_t(plane) * p.b_plane;
+        l.A = reinterpret_cast<const char*>(p.A + size_t(plane) * p.a_plane);
+        l.Bw = reinterpret_cast<const char*>(p.Bw + size_t(plane) * p.b_plane);
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int row = (wave * PW + i) * RPP + prow;
             const int sc = lchunk ^ key(row);
             int m = m0 + row;
             m = m < p.T ? m : p.T - 1;
-            l.a_base[i] = m * p.C + sc * 4;
-            const int n = n0 + row;
-            l.b_ok[i] = n < p.K;
-            l.b_base[i] = (l.b_ok[i] ? n : 0) * p.C + sc * 4;
+            l.a_off[i] = unsigned(m * p.C + sc * 4) * 4u;
+            int n = n0 + row;
+            n = n < p.K ? n : p.K - 1;                       // rows past K re-read the last one: their columns are never stored
+            l.b_off[i] = unsigned(n * p.C + sc * 4) * 4u;
         }
     };
     auto issue = [&](const Ld& l, char* sA, int c0) {
         char* sB = sA + A_BYTES;
+        const char* ab = ng_uniform_ptr(l.A + size_t(c0) * 4);
+        const char* bb = ng_uniform_ptr(l.Bw + size_t(c0) * 4);
 #pragma unroll
-        for (int i = 0; i < PW; ++i) ng_glds16(l.A + (l.a_base[i] + c0), sA + (wave * PW + i) * 1024);
+        for (int i = 0; i < PW; ++i) ng_glds16_so(ab, l.a_off[i], sA + (wave * PW + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < PW; ++i) ng_glds16(l.b_ok[i] ? l.Bw + (l.b_base[i] + c0) : p.zero, sB + (wave * PW + i) * 1024);
+        for (int i = 0; i < PW; ++i) ng_glds16_so(bb, l.b_off[i], sB + (wave * PW + i) * 1024);
     };
 
     // ---------------- compute: wave (wr, wc) = rows wr*64 .. +63, columns wc*64 .. +63
