@@ -172,7 +172,8 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
     for (int i = 0; i < AIW; ++i) a_boff[i] = unsigned(a_base[i]) * unsigned(ESA);
 #pragma unroll
     for (int i = 0; i < BIW; ++i) b_boff[i] = unsigned(b_base[i]) * unsigned(ESB);
-    const bool inside = p.off32 != 0 && n0 + BN <= p.N;
+    // (weight rows past N read row 0 -- b_base already points there: they feed columns that are never stored and never summed)
+    const bool inside = p.off32 != 0;
 
     auto issue = [&](char* sA, int t, int c0) {
         char* sB = sA + A_BYTES;
