@@ -661,7 +661,7 @@ __device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, c
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[g & 1][nt][j], a[g & 1][mt][j], acc[mt][nt], 0, 0, 0);   // rows = K columns, see the drain
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g & 1][mt][j], b[g & 1][nt][j], acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             between(g);
             __builtin_amdgcn_sched_barrier(0);
@@ -669,21 +669,31 @@ __device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, c
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // ---------------- drain: the MFMAs take the U fragment as their first operand, so an accumulator block holds M^T: lane = pixel row
-    // t (lane & 31), registers 4j .. 4j+3 = the four CONSECUTIVE output channels 8j + 4 half + {0..3} -- 16 contiguous bytes of M[t][.]:
-    // piece q = (mt, nt, j) is ONE global_store_dwordx4 straight from the registers (the two half-waves write adjacent chunks; the four
-    // j complete a pixel's 128-byte line), no transpose through LDS
-    auto drain_lds = [&](const f32x16 (&acc)[2][2], int q) { (void)acc; (void)q; };
-    auto drain_store_acc = [&](const f32x16 (&acc)[2][2], int q, int plane, int m0, int n0) {
+    // ---------------- drain: piece q = (mt, nt, j) of a finished tile: registers 4j .. 4j+3 of acc[mt][nt] = rows 8j + {0..3} + 4 half of
+    // that 32 x 32 block.  Wave-private transpose buffer [8 rows][40 floats] (the 8-float pad keeps the two half-waves on disjoint banks),
+    // double-buffered by piece parity so that the only ordering needed is the wave's own lgkmcnt.
+    float* tb = reinterpret_cast<float*>(lds + 2 * STAGE) + wave * 640;
+    const int t_wr = ((lane >> 5) * 4) * 40 + (lane & 31);           // + (r & 3) * 40
+    const int t_rd = (lane >> 3) * 40 + (lane & 7) * 4;              // lane -> (row lane/8, 4 columns)
+    f32x4 dv;                                                        // the piece on its way from the transpose buffer to memory
+    auto drain_lds = [&](const f32x16 (&acc)[2][2], int q) {
         const int mt = q >> 3, nt = (q >> 2) & 1, j = q & 3;
-        const int m = m0 + wr * 64 + mt * 32 + (lane & 31);
-        const int n = n0 + wc * 64 + nt * 32 + 8 * j + 4 * half;
-        f32x4 v;
+        float* b = tb + (q & 1) * 320;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][4 * j + r];
-        if (m < p.T && n < p.K) *reinterpret_cast<f32x4*>(p.Out + size_t(plane) * p.o_plane + size_t(m) * p.K + n) = v;
+        for (int r = 0; r < 4; ++r) b[t_wr + r * 40] = acc[mt][nt][4 * j + r];
+        dv = *reinterpret_cast<const f32x4*>(b + t_rd);
     };
-    auto drain = [&](const f32x16 (&acc)[2][2], int q, int plane, int m0, int n0) { drain_store_acc(acc, q, plane, m0, n0); };
+    auto drain_store = [&](int q, int plane, int m0, int n0) {
+        const int mt = q >> 3, nt = (q >> 2) & 1, j = q & 3;
+        const int rr = lane >> 3;                                     // buffer row = (r & 3) + 4 half  ->  tile row 8j + rr
+        const int m = m0 + wr * 64 + mt * 32 + 8 * j + rr;
+        const int n = n0 + wc * 64 + nt * 32 + (lane & 7) * 4;
+        if (m < p.T && n < p.K) *reinterpret_cast<f32x4*>(p.Out + size_t(plane) * p.o_plane + size_t(m) * p.K + n) = dv;
+    };
+    auto drain = [&](const f32x16 (&acc)[2][2], int q, int plane, int m0, int n0) {
+        drain_lds(acc, q);
+        drain_store(q, plane, m0, n0);
+    };
 
     f32x16 accA[2][2], accB[2][2];
     auto zero = [&](f32x16 (&acc)[2][2]) {
@@ -720,10 +730,12 @@ __device__ __forceinline__ void w6_gemmp_body(const W6G16& p, const int first, c
             one_step(cur, s, next_logical, [&](int g) {
                 if (!have_prev) return;
                 if (PPS == 1) {
-                    if (g == 0) drain_store_acc(prev, s, pplane, pm0, pn0);
+                    if (g == 0) drain_lds(prev, s);
+                    if (g == NG - 1) drain_store(s, pplane, pm0, pn0);
                 } else {
-                    if (g == 0) drain_store_acc(prev, 2 * s, pplane, pm0, pn0);
-                    if (g == NG - 1) drain_store_acc(prev, 2 * s + 1, pplane, pm0, pn0);
+                    if (g == 0) drain_lds(prev, 2 * s);
+                    if (g == 1) { drain_store(2 * s, pplane, pm0, pn0); drain_lds(prev, 2 * s + 1); }
+                    if (g == NG - 1) drain_store(2 * s + 1, pplane, pm0, pn0);
                 }
             });
         }
