@@ -563,7 +563,7 @@ struct WgradParams {
     int pq_bf16;               // p and q point to bf16 twins (bf16 operand mode, N > 64)
     int nplanes;               // independent problems of identical geometry in one grid (Winograd-domain weight gradient: 16)
     long long p_plane, q_plane;   // floats between consecutive planes of p / q; slabs are [plane][split][N][K]
-    int fast32;                // fp32-stored operands in buffers < 4 GB, taps at non-negative offsets, OW % 32 == 0 and M % 32 == 0: the scalar-walk loader applies
+    int fast32;                // buffers < 4 GB, taps at non-negative offsets, OW / M / split length multiples of the K-step (32 pixels; 64 for bf16 twins): the scalar-walk loader applies
 };
 
 
@@ -1094,8 +1094,33 @@ __device__ __forceinline__ void wgrad_tile16(const WgradParams& p, const int blo
             q_add[i] = p.tap_off[t] + (j - t * p.run);
         }
     }
+    // scalar-walk fast path, as in wgrad_tile: a K-step is 64 consecutive pixels of one image row
+    const bool fast = p.fast32 != 0;
+    unsigned pl_off[PI], ql_off[PI];
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int row = (wave * PI + i) * 4 + lrow;
+        pl_off[i] = unsigned(row * p.p_cs + (p_ok[i] ? p_n[i] - n0 : 0)) * 2u;
+        ql_off[i] = unsigned(row * p.q_stride * p.q_cs + q_add[i]) * 2u;
+    }
+    int sb = __builtin_amdgcn_readfirstlane(mstart / p.OHW);
+    int soh = __builtin_amdgcn_readfirstlane((mstart - sb * p.OHW) / p.OW);
+    int sow = __builtin_amdgcn_readfirstlane(mstart - sb * p.OHW - soh * p.OW);
     auto issue = [&](char* sP, int mb) {
         char* sQ = sP + P_BYTES;
+        if (fast) {
+            const char* pb = ng_uniform_ptr(reinterpret_cast<const char*>(P16 + (size_t(sb) * p.p_img + size_t(soh) * p.p_row + sow * p.p_cs + p.p_org + (n0 < p.N ? n0 : 0))));
+            const char* qb = ng_uniform_ptr(reinterpret_cast<const char*>(Q16 + (size_t(sb) * p.q_img + size_t(soh) * p.q_stride * p.q_row + sow * p.q_stride * p.q_cs + p.q_org)));
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
+                ng_glds16_so(pb, pl_off[i], sP + (wave * PI + i) * 1024);
+                ng_glds16_so(qb, ql_off[i], sQ + (wave * PI + i) * 1024);
+            }
+            sow += MS;
+            if (sow >= p.OW) { sow = 0; ++soh; }
+            if (soh >= p.OH) { soh = 0; ++sb; }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PI; ++i) {
             const int ins = wave * PI + i;
@@ -1347,8 +1372,9 @@ inline int build_wgrad_params(const nirgan_wgrad_desc* d, WgradParams& p) {
     {
         bool taps_ok = true;
         for (int t = 0; t < d->ntaps; ++t) taps_ok = taps_ok && (d->tap_dh[t] * p.q_row + d->tap_dw[t] * d->q_cs >= 0);
-        p.fast32 = (taps_ok && !d->pq_bf16 && d->OW % 32 == 0 && p.M % 32 == 0 && d->rows_per_split % 32 == 0
-                    && d->p_elems * 4 < (int64_t(1) << 32) && d->q_elems * 4 < (int64_t(1) << 32)) ? 1 : 0;
+        const int ms = d->pq_bf16 ? 64 : 32, es = d->pq_bf16 ? 2 : 4;          // pixels per K-step, bytes per stored element
+        p.fast32 = (taps_ok && d->OW % ms == 0 && p.M % ms == 0 && d->rows_per_split % ms == 0
+                    && d->p_elems * es < (int64_t(1) << 32) && d->q_elems * es < (int64_t(1) << 32)) ? 1 : 0;
     }
     NG_REQUIRE(!p.pq_bf16 || (d->precision == 1 && d->N > 64 && d->N % 8 == 0 && d->run % 8 == 0 && d->p_cs % 8 == 0 && d->q_cs % 8 == 0),
                "wgrad_igemm: bf16 twins need precision 1, N > 64 and N, run, p_cs, q_cs multiples of 8");

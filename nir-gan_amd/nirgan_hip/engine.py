@@ -368,15 +368,16 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
         wino_blocks = -(-(c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2)) // 64) * (c.K // 128)
         total = 512 * max(1, round((wino_blocks + 1024) / 512))
         target = max(total - wino_blocks, 512)
-    nsplit, rows = G.wgrad_split(M, tiles, target)
+    twins = (ctx.precision == 1 and p.t16 is not None and q.t16 is not None and N > 64 and N % 8 == 0 and taps.run % 8 == 0
+             and (pair_with is None or pair_with.in_bf16))
+    nsplit, rows = G.wgrad_split(M, tiles, target, 64 if twins else 32)
     need = nsplit * N * K
     slabs = slabs_pool.get(need) if slabs_pool is not None else ctx.zeros(need)
     ctx.keep.append(slabs)
     d = L.WgradDesc()
     d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = p.ptr, p.elems, p.hp, p.wp, p.C, p_oh, p_ow
     d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = q.ptr, q.elems, q.hp, q.wp, q.C
-    if (ctx.precision == 1 and p.t16 is not None and q.t16 is not None and N > 64 and N % 8 == 0 and taps.run % 8 == 0
-            and (pair_with is None or pair_with.in_bf16)):
+    if twins:
         d.p, d.q, d.pq_bf16 = p.t16.data_ptr(), q.t16.data_ptr(), 1     # both operands from the producers' bf16 twins
     d.q_stride, d.q_oh, d.q_ow = q_stride, q_oh, q_ow
     d.run = taps.run

@@ -186,13 +186,13 @@ def linear_pack(nout: int, nin: int) -> PackSpec:
     return PackSpec(nout, nin, nin, np.arange(nin, dtype=np.int32), ("ln", nout, nin), nin)
 
 
-def wgrad_split(M: int, tiles: int, target_blocks: int = 1024) -> Tuple[int, int]:
+def wgrad_split(M: int, tiles: int, target_blocks: int = 1024, row_mult: int = 32) -> Tuple[int, int]:
     """(nsplit, rows_per_split) for the weight-gradient GEMM.
 
     256 CUs x 2 resident blocks = 512 slots: tiles*nsplit is kept AT OR BELOW a whole number of rounds
     (<= target_blocks) so that no nearly-empty trailing round appears; rows are a multiple of 32."""
     want = max(1, target_blocks // max(tiles, 1))
-    rows = max(32, -(-M // want))
-    rows = -(-rows // 32) * 32
+    rows = max(row_mult, -(-M // want))
+    rows = -(-rows // row_mult) * row_mult           # whole K-steps per split (64 pixels when both operands are bf16 twins)
     nsplit = -(-M // rows)
     return nsplit, rows
