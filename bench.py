@@ -74,7 +74,7 @@ def mfma_probes(trainer):
     kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0],
              "wino_gemm_kernel": [0.0, 0], "wino_wgrad_pair_kernel": [0.0, 0],
              "wino6_gemm16_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0], "wino6_pair_kernel": [0.0, 0],
-             "wino6_gemm16p_kernel": [0.0, 0], "wino6_pair16p_kernel": [0.0, 0]}
+             "wino6_gemm16p_kernel": [0.0, 0], "wino6_gemm32p_kernel": [0.0, 0], "wino6_pair16p_kernel": [0.0, 0]}
     persistent = os.environ.get("NIRGAN_WINO6_GEMM_NOPERSIST") is None       # csrc/wino6.hip::w6_persistent_ok: the C = 256 launches
     algo_bytes = {}
     for pl in plans:
@@ -89,7 +89,8 @@ def mfma_probes(trainer):
                     pl.probe_idx[i] = k
             elif name == "nirgan_wino6_gemm":
                 d = args[0]._obj
-                k = "wino6_gemm16p_kernel" if (persistent and d.C == 256) else "wino6_gemm16_kernel"
+                gp = "wino6_gemm16p_kernel" if os.environ.get("NIRGAN_WINO6_GEMM16P") else "wino6_gemm32p_kernel"      # csrc/wino6.hip::nirgan_wino6_gemm
+                k = gp if (persistent and d.C == 256) else "wino6_gemm16_kernel"
                 T = w6_tiles(d)
                 kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K          # EXECUTED flops: the plane GEMMs [T x C] x [C x K] (64/324 of the direct layer's multiplies for F(6x6,3x3))
                 algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once

@@ -778,6 +778,11 @@ __global__ __launch_bounds__(256, 2) void wino6_gemm16p_kernel(const W6G16 p) {
     w6_gemmp_body<16>(p, blockIdx.x, gridDim.x, lds);
 }
 
+__global__ __launch_bounds__(256, 2) void wino6_gemm32p_kernel(const W6G16 p) {
+    __shared__ __attribute__((aligned(16))) char lds[w6p_lds<32>()];
+    w6_gemmp_body<32>(p, blockIdx.x, gridDim.x, lds);
+}
+
 // (KS = 32 -- 128-byte rows, half the barriers per product, 74 KB of LDS -- was instantiated and measured: 176 / 195 us against
 // 178 / 194 us at T = 4096 / 4624: the barrier count is not what holds the tile at 0.7)
 
@@ -786,11 +791,10 @@ __global__ __launch_bounds__(256, 2) void wino6_gemm16p_kernel(const W6G16 p) {
 // tiles -- M is the last thing written before the output transform reads it.  With F(6x6,3x3) at bs 16 the shares are exact:
 // 1 024 weight-gradient units = 2 per workgroup, 2 048 GEMM tiles = 4 per workgroup.
 __global__ __launch_bounds__(256, 2) void wino6_pair16p_kernel(const W6G16 q, const int nblocks, const ng::WgradParams wp) {
-    __shared__ __attribute__((aligned(16))) char lds[65536];
-    static_assert(W6P_LDS <= 65536, "the persistent GEMM's LDS must fit the pair kernel's");
+    __shared__ __attribute__((aligned(16))) char lds[w6p_lds<32>() > 65536 ? w6p_lds<32>() : 65536];
     ng::wgrad_persist(wp, blockIdx.x, nblocks, lds);
     __syncthreads();
-    w6_gemmp_body<16>(q, blockIdx.x, nblocks, lds);
+    w6_gemmp_body<32>(q, blockIdx.x, nblocks, lds);          // 32-k stages: see wino6_gemm32p_kernel
 }
 
 // (fallback) the weight-gradient tiles one per workgroup, dispatched first, and the persistent GEMM workgroups behind them
@@ -1240,6 +1244,12 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
         if (w6_persistent_ok(d) && !no_persist) {
             // persistent workgroups, epilogue folded into the next tile's K loop: 2 per CU
             const int grid = q.total < 512 ? q.total : 512;
+            // 32-k stages (half the barriers per product; 76 KB of LDS, still two workgroups per CU): 145.8 -> 141.7 us once the loader
+            // carries no vector arithmetic (before that: no difference); NIRGAN_WINO6_GEMM16P=1 keeps the 16-k stages
+            if (getenv("NIRGAN_WINO6_GEMM16P") == nullptr) {
+                hipLaunchKernelGGL(wino6_gemm32p_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+                return nirgan_check_launch("wino6_gemm");
+            }
             hipLaunchKernelGGL(wino6_gemm16p_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), q);
             return nirgan_check_launch("wino6_gemm");
         }
