@@ -90,7 +90,7 @@ def mfma_probes(trainer):
             elif name == "nirgan_wino6_gemm":
                 d = args[0]._obj
                 gp = "wino6_gemm16p_kernel" if os.environ.get("NIRGAN_WINO6_GEMM16P") else "wino6_gemm32p_kernel"      # csrc/wino6.hip::nirgan_wino6_gemm
-                k = gp if (persistent and d.C == 256) else "wino6_gemm16_kernel"
+                k = gp if (persistent and d.C in (256, 512)) else "wino6_gemm16_kernel"
                 T = w6_tiles(d)
                 kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K          # EXECUTED flops: the plane GEMMs [T x C] x [C x K] (64/324 of the direct layer's multiplies for F(6x6,3x3))
                 algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once

@@ -1188,7 +1188,8 @@ static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
 // The persistent tile (wino6_gemm16p_kernel) where it measures faster: C = 256 (16 K-steps per tile: 186 -> 165 us at T = 4096, 211 ->
 // 196 at T = 4624, 251 -> 236 for the PatchGAN's 49 x [2048 x 256] x [512]).  At C = 512 a tile is twice as long and the uneven last
 // round of fixed assignments costs more than the folded epilogue saves (579 vs 536 us for the PatchGAN layer's pair launch).
-static bool w6_persistent_ok(const nirgan_wino6_desc* d) { return d->C == 256; }
+// (C = 512, the PatchGAN's F(4x4,4x4) data gradient: the plain GEMM gains 12 % as persistent workgroups, the pair launch loses 9 %)
+static bool w6_persistent_ok(const nirgan_wino6_desc* d, bool pair = true) { return d->C == 256 || (d->C == 512 && !pair); }
 
 static W6G16 w6_g16_params(const nirgan_wino6_desc* d, long long T) {
     W6G16 q;
@@ -1241,7 +1242,7 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
         NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm: pointers must be 16-byte aligned");
         const W6G16 q = w6_g16_params(d, T);
         const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;          // (read per launch: the tests switch it)
-        if (w6_persistent_ok(d) && !no_persist) {
+        if (w6_persistent_ok(d, false) && !no_persist) {
             // persistent workgroups, epilogue folded into the next tile's K loop: 2 per CU
             const int grid = q.total < 512 ? q.total : 512;
             // 32-k stages (half the barriers per product; 76 KB of LDS, still two workgroups per CU): 145.8 -> 141.7 us once the loader
