@@ -879,7 +879,9 @@ def test_winograd_backward_pair_matches_autograd(hw):
                                    (2, 8, 12, 64, 128, 6), (1, 64, 64, 256, 256, 6), (3, 6, 5, 32, 128, 6), (2, 9, 7, 64, 192, 6), (1, 69, 69, 256, 256, 6),
                                    (16, 64, 64, 256, 256, 6), (16, 66, 66, 256, 256, 6),
                                    # the persistent plane GEMM (C = 256) with partly filled N tiles, few tiles per workgroup, ragged M tiles
-                                   (2, 20, 14, 256, 192, 6), (2, 20, 14, 256, 320, 3), (1, 7, 9, 256, 128, 6), (5, 33, 31, 256, 256, 6)])
+                                   (2, 20, 14, 256, 192, 6), (2, 20, 14, 256, 320, 3), (1, 7, 9, 256, 128, 6), (5, 33, 31, 256, 256, 6),
+                                   # C = 512: the plain plane GEMM runs as persistent workgroups too (16 K-steps of 32 per tile)
+                                   (2, 20, 14, 512, 192, 6), (16, 34, 34, 512, 256, 4), (3, 9, 13, 512, 128, 3)])
 def test_wino6_conv3x3_matches_direct(shape):
     """nirgan_wino6_weights_r + input / (r+3)^2 plane GEMMs / output transform against torch's conv2d in float64 (the reference's
     nn.Conv2d arithmetic) and the numpy restatement: fp32 rounding only.  F(4x4,3x3) and F(4x4,4x4); extents that are multiples of 4,
@@ -1265,3 +1267,32 @@ def test_conv_epilogue_takes_the_instance_norm_backward_first_pass(case):
         outs.append(dyo.t.clone())
     torch.cuda.synchronize()
     close(outs[0], outs[1], 2e-5, "dy with the sums from the epilogue")
+
+
+def test_wino6_plane_gemm_stage_depths_agree(monkeypatch):
+    """The persistent plane GEMM on 32-k stages (default) and on 16-k stages (NIRGAN_WINO6_GEMM16P=1): the same products in the same
+    k order -- equal to fp32 rounding on the benchmark's residual-block shape and on a ragged one."""
+    import ctypes as C
+    for (B, H, W, Cc, K) in ((16, 64, 64, 256, 256), (3, 21, 17, 256, 192)):
+        g = torch.Generator().manual_seed(9)
+        T = B * (-(-H // 6)) * (-(-W // 6))
+        V = torch.randn(64 * T * Cc, generator=g).to(DEV)
+        U = (torch.randn(64 * K * Cc, generator=g) * 0.05).to(DEV)
+        zero = torch.zeros(64, device=DEV)
+        outs = []
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("NIRGAN_WINO6_GEMM16P", env)
+            else:
+                monkeypatch.delenv("NIRGAN_WINO6_GEMM16P", raising=False)
+            M = torch.full((64 * T * K,), float("nan"), device=DEV)
+            d = L.Wino6Desc()
+            d.r, d.B, d.H, d.W, d.C, d.K = 6, B, H, W, Cc, K
+            d.U, d.V, d.V_elems, d.M, d.M_elems, d.zero_page = U.data_ptr(), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), zero.data_ptr()
+            L.call("nirgan_wino6_gemm", C.byref(d), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            outs.append(M.clone())
+        monkeypatch.delenv("NIRGAN_WINO6_GEMM16P", raising=False)
+        ref = torch.bmm(V.view(64, T, Cc).double(), U.view(64, K, Cc).double().transpose(1, 2)).float().reshape(-1)
+        close(outs[0], ref, 2e-5, "32-k stages vs fp64")
+        close(outs[1], outs[0], 2e-6, "16-k vs 32-k stages")
