@@ -576,6 +576,9 @@ int nirgan_wino6_input_dy(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc*
 int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, const nirgan_in_bwd_desc* n, void* stream);
 int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
 int nirgan_wino6_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream);   /* [K][C][r][r] */
+/* the same for n <= 16 layers of one geometry in ONE grid (host arrays of device pointers; every layer then keeps its own slabs until the
+ * call): a single layer's finish is launch latency for 33 MB, twelve of them in one launch run at the memory rate */
+int nirgan_wino6_wgrad_finish_batch(const float* const* slabs, float* const* grads, int n, int nsplit, int K, int C, int r, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * SatCLIP injection (model/generator_inject.py:110-127).

@@ -662,7 +662,10 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     nsplit, rows = G.wgrad_split(T, tiles, 512 if persistent else 1024)
     if os.environ.get("NIRGAN_WINO6_SPLITS"):            # experiments
         nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ["NIRGAN_WINO6_SPLITS"]))
-    slabs = slabs_pool.get(NP * nsplit * cout * cin)
+    # deferred finish (ctx.w6_deferred is a list while a network collects the layers of one trunk): the layer keeps its own slabs and the
+    # inverse transforms of all of them run as ONE launch behind the trunk (emit_w6_deferred_finishes)
+    deferred = getattr(ctx, "w6_deferred", None) if (persistent and not side_ok_stream(ctx)) else None
+    slabs = ctx.zeros(NP * nsplit * cout * cin) if deferred is not None else slabs_pool.get(NP * nsplit * cout * cin)
     d = L.WgradDesc()
     d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), NP * T * cout, 1, T, cout, 0, 0
     assert V_elems >= NP * T * cin
@@ -690,8 +693,34 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
         plan.add("nirgan_wino6_gemm", C.byref(dgrad))
         add_w("nirgan_wgrad_igemm", C.byref(d))
     plan.add("nirgan_wino6_output", C.byref(dgrad))
-    add_w("nirgan_wino6_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, v, grad.data_ptr(), 1 if accumulate else 0)
+    if deferred is not None:
+        deferred.append((slabs, nsplit, cout, cin, v, grad, 1 if accumulate else 0))
+    else:
+        add_w("nirgan_wino6_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, v, grad.data_ptr(), 1 if accumulate else 0)
     return d
+
+
+def side_ok_stream(ctx: Ctx) -> bool:
+    return os.environ.get("NIRGAN_SIDE_STREAM") == "1"
+
+
+def emit_w6_deferred_finishes(plan: Plan, ctx: Ctx):
+    """One nirgan_wino6_wgrad_finish_batch per geometry for the layers collected in ctx.w6_deferred (at most 16 per launch): a single
+    layer's inverse transform is 17 us of launch latency for 33 MB of slabs, twelve in one grid run at the memory rate."""
+    items, ctx.w6_deferred = (getattr(ctx, "w6_deferred", None) or []), None
+    groups = {}
+    for slabs, nsplit, K, Cc, v, grad, acc in items:
+        groups.setdefault((nsplit, K, Cc, v, acc), []).append((slabs, grad))
+    for (nsplit, K, Cc, v, acc), lst in groups.items():
+        for i in range(0, len(lst), 16):
+            part = lst[i:i + 16]
+            if len(part) == 1:
+                plan.add("nirgan_wino6_wgrad_finish_r", part[0][0].data_ptr(), nsplit, K, Cc, v, part[0][1].data_ptr(), acc)
+                continue
+            sp = (C.c_void_p * len(part))(*[a.data_ptr() for a, _ in part])
+            gp = (C.c_void_p * len(part))(*[g.data_ptr() for _, g in part])
+            ctx.keep.extend([sp, gp])
+            plan.add("nirgan_wino6_wgrad_finish_batch", sp, gp, len(part), nsplit, K, Cc, v, acc)
 
 
 def attach_conv_stats(ctx: Ctx, descs: list, bias) -> Optional[tuple]:

@@ -197,6 +197,7 @@ PROTOTYPES = {
     "nirgan_wino6_input_dy_norm": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), C.POINTER(InBwdDesc), fp]),
     "nirgan_wino6_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_wino6_wgrad_finish_r": (i32, [fp, i32, i32, i32, i32, fp, i32, fp]),
+    "nirgan_wino6_wgrad_finish_batch": (i32, [fp, fp, i32, i32, i32, i32, i32, i32, fp]),
     "nirgan_hist_match_ws_bytes": (i64, [i32, i32]),
     "nirgan_hist_match": (i32, [C.POINTER(HistMatchDesc), fp]),
     "nirgan_image_metrics_ws_elems": (i64, [i32, i32, i32]),

@@ -16,7 +16,7 @@ import torch
 
 from . import geometry as G
 from . import lib as L
-from .engine import ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, emit_conv, emit_wgrad, wino_applicable
+from .engine import ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, emit_conv, emit_w6_deferred_finishes, emit_wgrad, wino_applicable
 
 
 def generator_layout(n_blocks: int) -> dict:
@@ -219,6 +219,7 @@ class GeneratorEngine(_Engine):
         g_in, g_fold, g_skip = g_top, False, None
         dense = [Halo(ctx, B, H3, W3, c4, 0), Halo(ctx, B, H3, W3, c4, 0)] if self.blocks else []
         flip = 0
+        ctx.w6_deferred = [] if os.environ.get("NIRGAN_NO_W6_FINISH_BATCH") != "1" else None      # collect the blocks' weight-gradient finishes
         for j in range(len(self.blocks) - 1, -1, -1):
             i, c1, c2 = self.blocks[j]
             gq = Halo(ctx, B, H3, W3, c4, 1)
@@ -232,6 +233,7 @@ class GeneratorEngine(_Engine):
                         gb=GW(i, "conv_block.5.bias"), dgrad_out=gq, act=L.ACT_NONE)
             c1.emit_bwd(b, pk, g=gq, g_fold=True, gw=GW(i, "conv_block.1.weight"), gb=GW(i, "conv_block.1.bias"), dgrad_out=gp)
             g_in, g_fold, g_skip = gp, True, skip_next
+        emit_w6_deferred_finishes(b, ctx)         # the blocks' Winograd weight gradients: one inverse-transform launch for all of them
         # data parallel: from here on the gradients of [first residual block .. last conv] are final (28 of 31 MB for 6 blocks)
         first_tail = f"model.{lay['blocks'][0]}.conv_block.1.weight" if self.blocks else f"model.{i0}.weight"
         self.bwd_tail = (len(b.ops), first_tail, f"model.{il}.bias")

@@ -744,6 +744,18 @@ class EmuBackend:
             o[:] = g.astype(np.float32)
         return 0
 
+    def nirgan_wino6_wgrad_finish_batch(self, slabs, grads, n, nsplit, K, Cc, r, accumulate, stream=None):
+        if not (1 <= n <= 16):
+            return self._fail("wino6_wgrad_finish_batch: 1..16 layers")
+        sp = C.cast(slabs, C.POINTER(C.c_void_p))
+        gp = C.cast(grads, C.POINTER(C.c_void_p))
+        self.calls.append("wino6_fin_batch")
+        for i in range(n):
+            rc = self.nirgan_wino6_wgrad_finish_r(sp[i], nsplit, K, Cc, r, gp[i], accumulate)
+            if rc:
+                return rc
+        return 0
+
     def nirgan_wino_wgrad_pair(self, cref, wref, stream=None):
         rc = self.nirgan_wino_gemm(cref)              # the input transform of cref has run (nirgan_wino_input / _input_dy)
         return rc if rc else self.nirgan_wgrad_igemm(wref)

@@ -1296,3 +1296,42 @@ def test_wino6_plane_gemm_stage_depths_agree(monkeypatch):
         ref = torch.bmm(V.view(64, T, Cc).double(), U.view(64, K, Cc).double().transpose(1, 2)).float().reshape(-1)
         close(outs[0], ref, 2e-5, "32-k stages vs fp64")
         close(outs[1], outs[0], 2e-6, "16-k vs 32-k stages")
+
+
+@pytest.mark.parametrize("case", [(6, 3, 2, 256, 256), (4, 2, 1, 128, 64), (3, 16, 2, 32, 32)])
+def test_wino6_weight_gradient_finish_batch(case):
+    """nirgan_wino6_wgrad_finish_batch (n layers of one geometry in one grid) against n single nirgan_wino6_wgrad_finish_r calls: bitwise,
+    with and without accumulation; and the numpy restatement."""
+    import ctypes as C
+    v, n, nsplit, K, Cc = case
+    r = 3 if v == 6 else v
+    NP = 64 if v == 6 else (v + 3) ** 2
+    g = torch.Generator().manual_seed(4)
+    slabs = [torch.randn(NP * nsplit * K * Cc, generator=g).to(DEV) for _ in range(n)]
+    st = torch.cuda.current_stream().cuda_stream
+    for acc in (0, 1):
+        base = [torch.randn(K * Cc * r * r, generator=g).to(DEV) for _ in range(n)]
+        one = [b.clone() for b in base]
+        many = [b.clone() for b in base]
+        for s_, o in zip(slabs, one):
+            L.call("nirgan_wino6_wgrad_finish_r", s_.data_ptr(), nsplit, K, Cc, v, o.data_ptr(), acc, st)
+        sp = (C.c_void_p * n)(*[s_.data_ptr() for s_ in slabs])
+        gp = (C.c_void_p * n)(*[m.data_ptr() for m in many])
+        L.call("nirgan_wino6_wgrad_finish_batch", sp, gp, n, nsplit, K, Cc, v, acc, st)
+        torch.cuda.synchronize()
+        for o, m in zip(one, many):
+            assert torch.equal(o, m)
+    if K * Cc <= 8192:
+        emu = EmuBackend()
+        sc = [s_.cpu() for s_ in slabs]
+        oc = [torch.zeros(K * Cc * r * r) for _ in range(n)]
+        sp = (C.c_void_p * n)(*[s_.data_ptr() for s_ in sc])
+        gp = (C.c_void_p * n)(*[o.data_ptr() for o in oc])
+        assert emu.nirgan_wino6_wgrad_finish_batch(sp, gp, n, nsplit, K, Cc, v, 0) == 0
+        fresh = [torch.zeros(K * Cc * r * r, device=DEV) for _ in range(n)]
+        gp2 = (C.c_void_p * n)(*[f.data_ptr() for f in fresh])
+        sp2 = (C.c_void_p * n)(*[s_.data_ptr() for s_ in slabs])
+        L.call("nirgan_wino6_wgrad_finish_batch", sp2, gp2, n, nsplit, K, Cc, v, 0, st)
+        torch.cuda.synchronize()
+        for o, f in zip(oc, fresh):
+            close(f, o, 1e-5, "device vs restatement")
