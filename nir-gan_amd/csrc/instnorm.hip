@@ -65,16 +65,20 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InFwd p) {
 // sum of the chunk partials of sample b (blockIdx.x): row group rg adds chunks rg, rg+nrg, ... (independent loads, 8 in
 // flight), the groups are combined through LDS in group order -- a fixed order, so the result is reproducible.
 // Result valid for tid < q4.  (One thread per channel quad walking all chunks serially cost ~17 us of pure latency.)
-__device__ __forceinline__ void chunk_sums(const float* w, int nchunk, int C, int tid, f32x4* lds, f32x4& s1, f32x4& s2) {
-    const int q4 = C / 4, nrg = in_nrg(C);
+// A block takes the channels [c0, c0 + cw) (cw = 64 for C >= 64 and C % 64 == 0 -- blockIdx.y slices of 64 channels: 16 row groups
+// instead of 4 at C = 256, a quarter of the serial loads per thread -- else the whole C); result valid for tid < cw / 4.
+__device__ __forceinline__ int fin_cw(int C) { return (C >= 64 && C % 64 == 0) ? 64 : C; }
+__device__ __forceinline__ void chunk_sums(const float* w, int nchunk, int C, int tid, f32x4* lds, f32x4& s1, f32x4& s2, int c0 = 0, int cw = 0) {
+    cw = cw > 0 ? cw : C;
+    const int q4 = cw / 4, nrg = in_nrg(cw);
     const int q = tid % q4, rg = tid / q4;
     s1 = f32x4{0, 0, 0, 0};
     s2 = f32x4{0, 0, 0, 0};
     if (rg < nrg) {
 #pragma unroll 8
         for (int c = rg; c < nchunk; c += nrg) {
-            s1 += ld4(w + size_t(c) * 2 * C + q * 4);
-            s2 += ld4(w + size_t(c) * 2 * C + C + q * 4);
+            s1 += ld4(w + size_t(c) * 2 * C + c0 + q * 4);
+            s2 += ld4(w + size_t(c) * 2 * C + C + c0 + q * 4);
         }
     }
     rg_reduce2(s1, s2, lds, tid, q4, nrg);
@@ -86,9 +90,10 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const InFwd p, int B) 
     const int b = blockIdx.x, tid = threadIdx.x;
     f32x4 s1, s2;
     const int nchunk = p.pre_chunks > 0 ? p.pre_chunks : p.nchunk;
-    chunk_sums(p.ws + size_t(b) * nchunk * 2 * p.C, nchunk, p.C, tid, lds, s1, s2);
-    if (tid >= p.C / 4) return;
-    const int q = tid;
+    const int cw = fin_cw(p.C), c0 = blockIdx.y * cw;
+    chunk_sums(p.ws + size_t(b) * nchunk * 2 * p.C, nchunk, p.C, tid, lds, s1, s2, c0, cw);
+    if (tid >= cw / 4) return;
+    const int q = c0 / 4 + tid;
     const float inv = 1.f / float(p.HW);
     f32x4 k = {0.f, 0.f, 0.f, 0.f};
     if (p.pre_chunks > 0) { if (p.shift != nullptr) k = ld4(p.shift + q * 4); }
@@ -217,10 +222,11 @@ __global__ __launch_bounds__(256) void in_bwd_finalize_kernel(const InBwd p, int
     __shared__ f32x4 lds[512];
     const int b = blockIdx.x, tid = threadIdx.x;
     f32x4 s1, s2;
-    chunk_sums(p.ws + size_t(b) * p.pchunks * 2 * p.C, p.pchunks, p.C, tid, lds, s1, s2);
-    if (tid >= p.C / 4) return;
+    const int cw = fin_cw(p.C), c0 = blockIdx.y * cw;
+    chunk_sums(p.ws + size_t(b) * p.pchunks * 2 * p.C, p.pchunks, p.C, tid, lds, s1, s2, c0, cw);
+    if (tid >= cw / 4) return;
     const float inv = 1.f / float(p.HW);
-    float* m = p.ws + size_t(B) * p.pchunks * 2 * p.C + size_t(b) * 2 * p.C;
+    float* m = p.ws + size_t(B) * p.pchunks * 2 * p.C + size_t(b) * 2 * p.C + c0;
     st4(m + tid * 4, s1 * inv);
     st4(m + p.C + tid * 4, s2 * inv);
 }
@@ -282,7 +288,7 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
         NG_REQUIRE(ng_aligned16(d->stats_shift), "instnorm_fwd: stats_shift must be 16-byte aligned");
         NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * (p.pre_chunks > 0 ? p.pre_chunks : p.nchunk) * 2 * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
         if (p.pre_chunks == 0) hipLaunchKernelGGL(in_stats_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(in_finalize_kernel, dim3(d->B), dim3(256), 0, st, p, d->B);
+        hipLaunchKernelGGL(in_finalize_kernel, dim3(d->B, (d->C >= 64 && d->C % 64 == 0) ? d->C / 64 : 1), dim3(256), 0, st, p, d->B);
     }
     if (!stats_only) hipLaunchKernelGGL(in_apply_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     return nirgan_check_launch("instnorm_fwd");
@@ -310,7 +316,7 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!pre) hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
     if (d->norm) {
-        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(d->B), dim3(256), 0, st, p, d->B);
+        hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(d->B, (d->C >= 64 && d->C % 64 == 0) ? d->C / 64 : 1), dim3(256), 0, st, p, d->B);
         if (!sums_only) hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p, d->B);
     }
     return nirgan_check_launch("instnorm_bwd");

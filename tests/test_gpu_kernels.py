@@ -177,7 +177,13 @@ def test_instnorm_forward_backward(shape):
         close(gs[0], cs[0], 1e-5, "mean")
         close(gs[1], cs[1], 1e-5, "rstd")
         close(ggs.t, cgs.t, 1e-5, "gsum")
-        close(gdy.t, cdy.t, 2e-5, "in bwd")
+        # elements within 1e-5 of the activation's kink may take either branch (the two evaluations sum the statistics in different
+        # orders): they are left out of the element-wise comparison, at most a handful of them
+        zc = (yc.t - cs[0][:, None, None, :]) * cs[1][:, None, None, :]
+        near = (zc.abs() < 1e-5) if act != L.ACT_NONE else torch.zeros_like(zc, dtype=torch.bool)
+        assert int(near.sum()) <= 1e-4 * near.numel()
+        keep = torch.nn.functional.pad(~near, (0, 0, 2, 2, 2, 2), value=True).to(gdy.t.device)
+        close(torch.where(keep, gdy.t, torch.zeros_like(gdy.t)).cpu(), torch.where(keep.cpu(), cdy.t, torch.zeros_like(cdy.t)), 2e-5, "in bwd")
         # torch's instance_norm on the same data
         ref = torch.nn.functional.instance_norm(yc.t.permute(0, 3, 1, 2), eps=1e-5)
         if act == L.ACT_NONE and use_res:
