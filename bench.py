@@ -65,83 +65,73 @@ def w6_tiles(d):
     return d.B * (-(-d.H // mo)) * (-(-d.W // mo))
 
 
-def mfma_probes(trainer):
-    """Algorithmic FLOPs of one step's launches of the two big MFMA kernels, and hooks that bracket them.
+def op_mfma_work(name, args):
+    """(kernel label, EXECUTED matrix-pipe FLOPs, algorithmic HBM bytes or None) of one plan op, from its descriptor(s); None for
+    ops that do not run on the matrix pipe.  Labels of the Winograd launches come from the library itself
+    (nirgan_wino6_*_kernel_name mirror the launchers' dispatch), the others from the descriptor's tile width."""
+    from nirgan_hip import lib as L
+    be = L.backend()
+    if name == "nirgan_conv_igemm":
+        d = args[0]._obj
+        return f"conv_igemm_kernel<{128 if d.N > 64 else 64}>", 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run, None
+    if name == "nirgan_conv_igemm_group":
+        ds = [args[0][j].contents for j in range(args[1])]
+        return f"conv_group_kernel<{128 if ds[0].N > 64 else 64}>", sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds), None
+    if name == "nirgan_wgrad_igemm":
+        w = args[0]._obj
+        if w.precision != 0 or w.pq_bf16:
+            return "wgrad_igemm(bf16)", 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, None
+        return f"wgrad_igemm_kernel<{128 if w.N > 64 else 64}>", 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, None
+    if name == "nirgan_conv_wgrad_pair":
+        c, w = args[0]._obj, args[1]._obj
+        return "conv_wgrad_pair_kernel", 2.0 * c.B * c.OH * c.OW * c.N * c.ntaps * c.run + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, None
+    if name == "nirgan_wino6_gemm":
+        d = args[0]._obj
+        T = w6_tiles(d)
+        k = be.nirgan_wino6_gemm_kernel_name(args[0]).decode() if hasattr(be, "nirgan_wino6_gemm_kernel_name") else "wino6_gemm"
+        # EXECUTED flops: the plane GEMMs [T x C] x [C x K] (64/324 of the direct layer's multiplies for F(6x6,3x3)); V read once, U once, M written once
+        return k, 2.0 * w6_planes(d.r) * T * d.C * d.K, 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K)
+    if name == "nirgan_wino6_gemm_wgrad_pair":
+        d, w = args[0]._obj, args[1]._obj
+        T = w6_tiles(d)
+        k = be.nirgan_wino6_pair_kernel_name(args[0], args[1]).decode() if hasattr(be, "nirgan_wino6_pair_kernel_name") else "wino6_pair"
+        fl = 2.0 * w6_planes(d.r) * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
+        # V of dY read once, U once, M written once; Yt and the forward's V read once, slabs written once
+        by = 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K) + 4.0 * w.nplanes * (w.OW * (w.N + w.run) + w.nsplit * w.N * w.run)
+        return (k or "wino6_gemm+wgrad"), fl, by
+    if name in ("nirgan_endconv_dgrad", "nirgan_endconv_wgrad"):
+        d = args[0]._obj
+        px = d.B * d.x_hp * d.x_wp if name.endswith("dgrad") else d.B * d.OH * d.OW
+        return name.replace("nirgan_", "") + "_kernel", 2.0 * px * 49 * 64, None
+    return None
 
-    conv_igemm_kernel<128>: 2*M*N*K per launch.  conv_wgrad_pair_kernel (data-gradient tiles + weight-gradient
-    tiles of one layer in one grid): the sum of both problems' 2*M*N*K."""
+
+def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_group_kernel<128>", "wgrad_igemm_kernel<128>", "conv_wgrad_pair_kernel", "wino6_")):
+    """EXECUTED FLOPs of one step's launches of the big MFMA kernels, and the op indices to bracket with HIP events."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
-    kinds = {"conv_igemm_kernel<128>": [0.0, 0], "conv_wgrad_pair_kernel": [0.0, 0], "conv_group_kernel<128>": [0.0, 0],
-             "wino_gemm_kernel": [0.0, 0], "wino_wgrad_pair_kernel": [0.0, 0],
-             "wino6_gemm16_kernel": [0.0, 0], "wgrad_igemm_kernel<128>": [0.0, 0], "wino6_pair_kernel": [0.0, 0],
-             "wino6_gemm16p_kernel": [0.0, 0], "wino6_gemm32p_kernel": [0.0, 0], "wino6_pair16p_kernel": [0.0, 0]}
-    persistent = os.environ.get("NIRGAN_WINO6_GEMM_NOPERSIST") is None       # csrc/wino6.hip::w6_persistent_ok: the C = 256 launches
-    algo_bytes = {}
+    kinds, algo_bytes = {}, {}
     for pl in plans:
-        pl.probe_idx, pl.probe_events, pl.probe_kind = {}, [], {}
+        pl.probe_idx, pl.probe_events = {}, []
         for i, (name, args) in enumerate(pl.ops):
-            if name == "nirgan_conv_igemm":
-                d = args[0]._obj
-                if d.N > 64:
-                    k = "conv_igemm_kernel<128>"
-                    kinds[k][0] += 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run
-                    kinds[k][1] += 1
-                    pl.probe_idx[i] = k
-            elif name == "nirgan_wino6_gemm":
-                d = args[0]._obj
-                gp = "wino6_gemm16p_kernel" if os.environ.get("NIRGAN_WINO6_GEMM16P") else "wino6_gemm32p_kernel"      # csrc/wino6.hip::nirgan_wino6_gemm
-                k = gp if (persistent and d.C in (256, 512)) else "wino6_gemm16_kernel"
-                T = w6_tiles(d)
-                kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K          # EXECUTED flops: the plane GEMMs [T x C] x [C x K] (64/324 of the direct layer's multiplies for F(6x6,3x3))
-                algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K)      # V read once, U read once, M written once
-                kinds[k][1] += 1
-                pl.probe_idx[i] = k
-            elif name == "nirgan_wino6_gemm_wgrad_pair":
-                d, w = args[0]._obj, args[1]._obj
-                k = "wino6_pair16p_kernel" if (persistent and d.C == 256) else "wino6_pair_kernel"
-                T = w6_tiles(d)
-                kinds[k][0] += 2.0 * w6_planes(d.r) * T * d.C * d.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run      # executed: data-gradient plane GEMMs + the weight-gradient planes
-                kinds[k][1] += 1
-                pl.probe_idx[i] = k
-                # V of dY read once, U once, M written once; Yt and the forward's V read once, slabs written once
-                algo_bytes[k] = algo_bytes.get(k, 0.0) + 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K) + 4.0 * w.nplanes * (w.OW * (w.N + w.run) + w.nsplit * w.N * w.run)
-            elif name == "nirgan_wgrad_igemm":
-                w = args[0]._obj
-                if w.N > 64 and w.precision == 0 and not w.pq_bf16:
-                    k = "wgrad_igemm_kernel<128>"
-                    kinds[k][0] += 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
-                    kinds[k][1] += 1
-                    pl.probe_idx[i] = k
-            elif name == "nirgan_wino_gemm":
-                d = args[0]._obj
-                k = "wino_gemm_kernel"
-                nf = (max(d.r, 3) + 1) ** 2                                                       # 16 frequencies for 3x3, 25 for 4x4
-                kinds[k][0] += 2.0 * nf * d.B * ((d.H + 1) // 2) * ((d.W + 1) // 2) * d.C * d.K      # EXECUTED MFMA flops (16/36, 25/64 of the direct layer's)
-                kinds[k][1] += 1
-                pl.probe_idx[i] = k
-            elif name == "nirgan_wino_wgrad_pair":
-                c, w = args[0]._obj, args[1]._obj
-                k = "wino_wgrad_pair_kernel"
-                nf = (max(c.r, 3) + 1) ** 2
-                kinds[k][0] += 2.0 * nf * c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2) * c.C * c.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run   # executed
-                kinds[k][1] += 1
-                pl.probe_idx[i] = k
-            elif name == "nirgan_conv_igemm_group":
-                ds = [args[0][j].contents for j in range(args[1])]
-                if ds[0].N > 64:
-                    k = "conv_group_kernel<128>"
-                    kinds[k][0] += sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds)
-                    kinds[k][1] += 1
-                    pl.probe_idx[i] = k
-            elif name == "nirgan_conv_wgrad_pair":
-                c, w = args[0]._obj, args[1]._obj
-                if c.N > 64 and w.N > 64:
-                    k = "conv_wgrad_pair_kernel"
-                    kinds[k][0] += 2.0 * c.B * c.OH * c.OW * c.N * c.ntaps * c.run + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
-                    kinds[k][1] += 1
-                    pl.probe_idx[i] = k
+            if not isinstance(name, str):
+                continue
+            w = op_mfma_work(name, args)
+            if w is None or not w[0].startswith(tuple(want)):
+                continue
+            k, fl, by = w
+            kinds.setdefault(k, [0.0, 0])
+            kinds[k][0] += fl
+            kinds[k][1] += 1
+            if by is not None:
+                algo_bytes[k] = algo_bytes.get(k, 0.0) + by
+            pl.probe_idx[i] = k
     mfma_probes.algo_bytes = algo_bytes
     return kinds, plans
+
+
+def plan_executed_flops(plan) -> float:
+    """Executed matrix-pipe FLOPs of every launch of a plan (all tile widths; the Winograd layers at their executed count)."""
+    return sum(w[1] for w in (op_mfma_work(n, a) for n, a in plan.ops if isinstance(n, str)) if w is not None)
 
 
 def host_cores() -> int:
@@ -257,6 +247,23 @@ def verify_dp(a, dev, rank, world, reducer, netG, netD, make_trainer, rgb, nir, 
     return res
 
 
+class Tick:
+    """A HIP event on the launch stream, or a host timestamp on the CPU test seam (same elapsed_time interface, ms)."""
+
+    def __init__(self, dev):
+        self.ev = torch.cuda.Event(enable_timing=True) if dev.type == "cuda" else None
+        self.t = 0.0
+
+    def record(self):
+        if self.ev is not None:
+            self.ev.record()
+        else:
+            self.t = time.perf_counter()
+
+    def elapsed_time(self, other) -> float:
+        return self.ev.elapsed_time(other.ev) if self.ev is not None else (other.t - self.t) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +285,13 @@ def main():
                     help="cut each batch into this many parts that run concurrently on separate HIP streams (the HBM-bound "
                          "kernels of one part under the matrix-pipe kernels of the other); per-kernel event times then "
                          "include the sharing, so the roofline entry is not a clean single-kernel figure")
+    ap.add_argument("--api", choices=["fused", "lightning"], default="fused",
+                    help="fused: Px2Px_PL.train_batch / Pix2PixTrainer.step (one call per batch).  lightning: the drop-in surface exactly as "
+                         "Lightning 1.9's two-optimizer loop drives the reference (train.py:136): toggle_optimizer, training_step(batch, i, 0), "
+                         "zero_grad, backward, HipAdam.step, then the same for optimizer 1 -- through the autograd bridges")
+    ap.add_argument("--sustain", type=float, default=10.0,
+                    help="seconds of back-to-back steps AFTER the timed ones (the reference trains 200 000 steps, train.py:124; a 0.4 s burst "
+                         "says nothing about clocks under sustained load); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--verify-dp", action="store_true",
@@ -304,6 +318,7 @@ def main():
         torch.set_num_threads(2)
         dev = torch.device("cpu")
         a.no_probe = a.no_cpu_baseline = True
+        a.sustain = 0.0
     else:
         assert torch.cuda.is_available(), "bench.py needs an MI355X"
         torch.cuda.set_device(local)
@@ -354,10 +369,63 @@ def main():
     tr = make_trainer(reducer)          # with a reducer: broadcasts rank 0's weights first (what DDP does at wrap time)
     _step = tr.step
     tr.step = lambda r, n: _step(r, n, embeds)
+    pl_model = None
+    if a.api == "lightning":
+        assert not a.mixed and a.micro == 1 and reducer is None and not a.inject and a.precision == "fp32", "--api lightning: single GPU, plain fp32 step"
+        from model.pix2pix import Px2Px_PL
+        from utils.config import to_attr
+        cfg = to_attr({
+            "base_configs": {"isTrain": True, "input_nc": 3, "output_nc": 1, "ngf": a.ngf, "ndf": a.ngf, "netD": "basic",
+                             "netG": f"resnet_{a.blocks}blocks", "norm": "instance", "no_dropout": True, "init_type": "normal", "init_gain": 0.02,
+                             "n_layers_D": 3, "gan_mode": "lsgan", "lr": 0.0002, "beta1": 0.5, "direction": "AtoB", "lambda_GAN": 1.0,
+                             "lambda_L1": 100.0, "lambda_ssim": 0.0, "lambda_hist": 0.0, "lambda_rs_losses": a.lambda_rs,
+                             "rs_losses_criterium": "l1", "internal_rs_loss_weights": dict(rs_w)},
+            "satclip": {"use_satclip": False, "satclip_style": "inject", "satclip_inject_style": "multiply", "scaling_param": True,
+                        "scaling_param_init": 0.01, "post_correction": False, "post_correction_init": 1.0},
+            "Schedulers": {"metric": "val/L1", "patience_g": 25, "patience_d": 25},
+            "custom_configs": {"Logging": {"num_val_images": 0, "log_input_stats": False}},
+            "Data": {"padding": a.padding > 0, "padding_amount": a.padding}})
+        torch.manual_seed(0)
+        pl_model = Px2Px_PL(cfg).to(dev).train()
+        (opt_d, opt_g), _ = pl_model.configure_optimizers()
+        pG, pD = list(pl_model.netG.parameters()), list(pl_model.netD.parameters())
+        batch_idx = [0]
+
+        def toggle(on, off):             # LightningModule.toggle_optimizer: only the current optimizer's parameters take gradients
+            for q in off:
+                q.requires_grad_(False)
+            for q in on:
+                q.requires_grad_(True)
+
+        def pl_step(r, n):
+            batch = pl_step.batch if (r is rgb and n is nir) else {"rgb": r, "nir": n}
+            i = batch_idx[0]
+            batch_idx[0] += 1
+            toggle(pD, pG)
+            loss_d = pl_model.training_step(batch, i, 0)
+            opt_d.zero_grad()
+            loss_d.backward()
+            opt_d.step()
+            toggle(pG, pD)
+            loss_g = pl_model.training_step(batch, i, 1)
+            opt_g.zero_grad()
+            loss_g.backward()
+            opt_g.step()
+            toggle(pD + pG, [])
+            pl_step.last = (loss_d, loss_g)
+        pl_step.batch = {"rgb": rgb, "nir": nir}
+        # every batch a Lightning loop sees is a NEW pair of tensors: re-using one object would let the forward record of the
+        # previous batch's second pass match (functional._ForwardRecord is keyed on tensor identity + version); clone per step
+        _pl = pl_step
+
+        def pl_fresh(r, n):
+            pl_step.batch = {"rgb": r.clone(), "nir": n.clone()}
+            return _pl(r, n)
+        tr.step = pl_fresh
     buckets, bucket_ms = None, None
     if a.mixed:
         assert not a.inject and a.bs % 4 == 0, "--mixed: plain generator, bs % 4 == 0"
-        buckets = [(4 * a.bs, 128), (a.bs, 256), (a.bs // 4, 512)]
+        buckets = [(4 * a.bs, a.size // 2), (a.bs, a.size), (a.bs // 4, 2 * a.size)]      # --size 256 (default): 128 / 256 / 512
         data = [synth(b, sz, sz, 1234 + 17 * i + rank, dev) for i, (b, sz) in enumerate(buckets)]
         bucket_ms = [[] for _ in buckets]
         counter = [rank]                   # ranks start on different buckets
@@ -366,7 +434,7 @@ def main():
             i = counter[0] % len(buckets)
             counter[0] += 1
             if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = Tick(dev), Tick(dev)
                 e0.record()
             out = _step(data[i][0], data[i][1], None)
             if timed:
@@ -378,8 +446,12 @@ def main():
     for _ in range(max(a.warmup, 3 if a.mixed else 1)):
         tr.step(rgb, nir)
     if a.mixed:
-        tr._prepare(a.bs, 256, 256)        # the probes bracket the 256x256 bucket's launches
-    kinds, plans = mfma_probes(tr)
+        tr._prepare(a.bs, a.size, a.size)        # the probes bracket the middle (256x256) bucket's launches
+    if pl_model is not None:
+        a.no_probe = True               # the autograd bridge leases its own engines: per-kernel figures come from the fused run
+        kinds, plans = {}, []
+    else:
+        kinds, plans = mfma_probes(tr)
     # generator-forward MFMA utilisation (second half of BASELINE.json's metric): HIP events around the generator's
     # forward plan inside the timed steps (the launch stream is torch's current stream)
     gen_fwd_events, gen_bwd_events = [], []
@@ -435,7 +507,39 @@ def main():
         rank_ms = [round(float(x[0]), 3) for x in allt]
         comm_ms = [round(float(x[1]), 4) for x in allt]
         dt = max(float(x[0]) for x in allt) * a.steps / 1e3          # MAX over ranks
-    losses = tr.step(rgb, nir).as_dict()
+    # ---- sustained leg: back-to-back steps for >= --sustain seconds (no probes, chunks of 10 steps between two HIP events)
+    sustained = None
+    if a.sustain > 0 and dev.type == "cuda":
+        for pl in plans:
+            pl.probe_idx = None
+        chunk, ticks = 10, []
+        barrier()
+        s0 = time.perf_counter()
+        est = max(dt / a.steps, 1e-4)
+        n_chunks = max(3, int(a.sustain / (est * chunk)) + 1)
+        for _ in range(n_chunks):
+            e0, e1 = Tick(dev), Tick(dev)
+            e0.record()
+            for _ in range(chunk):
+                tr.step(rgb, nir, True) if a.mixed else tr.step(rgb, nir)
+            e1.record()
+            ticks.append((e0, e1))
+        barrier()
+        wall = time.perf_counter() - s0
+        per = sorted(e0.elapsed_time(e1) / chunk for e0, e1 in ticks)
+        third = max(1, len(per) // 3)
+        seq = [e0.elapsed_time(e1) / chunk for e0, e1 in ticks]
+        sustained = {"seconds": round(wall, 2), "steps": n_chunks * chunk, "tiles_per_s": round(a.bs * world * n_chunks * chunk / wall, 2),
+                     "ms_per_step_p50": round(per[len(per) // 2], 3), "ms_per_step_p95": round(per[min(len(per) - 1, int(0.95 * len(per)))], 3),
+                     "ms_per_step_first_third": round(sum(seq[:third]) / third, 3), "ms_per_step_last_third": round(sum(seq[-third:]) / third, 3),
+                     "vs_burst": round((a.bs * world * n_chunks * chunk / wall) / (a.bs * world * a.steps / dt), 4),
+                     "note": "steps issued back to back after the timed ones; chunks of 10 steps between HIP events on the launch stream "
+                             "(rank 0's own clock; the headline `value` stays the barrier-bracketed K steps)"}
+    out_l = tr.step(rgb, nir)
+    if pl_model is not None:
+        losses = {"loss_D": float(pl_step.last[0]), "loss_G": float(pl_step.last[1])}
+    else:
+        losses = out_l.as_dict()
     assert all(v == v and abs(v) < 1e30 for v in losses.values()), f"non-finite losses {losses}"
 
     if rank == 0:
@@ -557,9 +661,16 @@ def main():
             t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gen_fwd_events)
             px = sum(n for _, _, n in gen_fwd_events)
             tf = g256 * (px / 65536.0) / t_ms          # GFLOP / ms = TFLOP/s
-            out["gen_fwd"] = {"ms_per_call": round(t_ms / len(gen_fwd_events), 3), "tflops_algorithmic": round(tf, 2),
-                              "mfma_util": round(tf / PEAKS[a.precision], 4), "peak": round(PEAKS[a.precision], 1),
-                              "note": "generator forward incl. its instance-norm / layout kernels; algorithmic conv FLOPs / elapsed / dense MFMA peak"}
+            ex = plan_executed_flops(tr.G.fwd) / 1e9 if not (a.mixed or a.micro > 1) else None      # GFLOP per call, executed on the matrix pipe
+            ms_call = t_ms / len(gen_fwd_events)
+            out["gen_fwd"] = {"ms_per_call": round(ms_call, 3), "tflops_algorithmic": round(tf, 2),
+                              "algorithmic_over_peak": round(tf / PEAKS[a.precision], 4), "peak": round(PEAKS[a.precision], 1),
+                              "executed_gflop_per_call": None if ex is None else round(ex, 2),
+                              "executed_mfma_util": None if ex is None else round(ex / ms_call / PEAKS[a.precision], 4),
+                              "note": "generator forward incl. its instance-norm / transform / layout kernels.  algorithmic_over_peak = direct-"
+                                      "convolution FLOPs (SURVEY 8d) / elapsed / dense MFMA peak: NOT a utilisation -- the Winograd layers execute 64/324 "
+                                      "of those multiplies, so it can exceed 1.  executed_mfma_util = FLOPs the matrix pipe actually executes (from "
+                                      "the launch descriptors) / elapsed / peak: BASELINE.json's 'gen-fwd MFMA util'"}
         if gen_fwd_events and gen_bwd_events:
             # backward = data + weight gradients of every conv except the first layer's data gradient: 2g - g1,
             # g1 = 7x7x3x64 MACs per pixel (SURVEY 8d formula)
@@ -568,10 +679,31 @@ def main():
             t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gen_fwd_events + gen_bwd_events)
             px = sum(n for _, _, n in gen_fwd_events)
             tf = gfb * (px / 65536.0) / t_ms
-            out["gen_fwd_bwd"] = {"ms_per_step": round(t_ms / len(gen_fwd_events), 3), "tflops_algorithmic": round(tf, 2),
-                                  "mfma_util": round(tf / PEAKS[a.precision], 4)}
+            ex = (plan_executed_flops(tr.G.fwd) + plan_executed_flops(tr.G.bwd)) / 1e9 if not (a.mixed or a.micro > 1) else None
+            ms_fb = t_ms / len(gen_fwd_events)
+            out["gen_fwd_bwd"] = {"ms_per_step": round(ms_fb, 3), "tflops_algorithmic": round(tf, 2),
+                                  "algorithmic_over_peak": round(tf / PEAKS[a.precision], 4),
+                                  "executed_gflop_per_step": None if ex is None else round(ex, 2),
+                                  "executed_mfma_util": None if ex is None else round(ex / ms_fb / PEAKS[a.precision], 4)}
         if gflop_tile and not a.mixed and a.size == 256:
             out["step_tflops_algorithmic"] = round(gflop_tile * value / 1e3, 2)
+        if pl_model is None and not a.no_probe and not (a.mixed or a.micro > 1):
+            exs = sum(plan_executed_flops(pl) for pl in plans) / 1e9
+            out["whole_step"] = {"executed_mfma_gflop": round(exs, 1), "executed_mfma_util": round(exs / ms / PEAKS[a.precision], 4),
+                                 "note": "FLOPs the matrix pipe executes per step (launch descriptors) / ms_per_step / dense peak"}
+            wr = pmc.get("_whole_run") if (not a.no_probe and isinstance(pmc.get("_whole_run"), dict)) else None
+            if wr and headline and fresh:
+                gb = wr["hbm_read_gb_per_step"] + wr["hbm_write_gb_per_step"]
+                out["whole_step"].update({"pmc_mfma_busy": round(wr["mfma_busy_fraction_of_active_cycles"], 4),
+                                          "pmc_executed_mfma_gflop": round(wr["executed_mfma_gflop_per_step_fp32"], 1),
+                                          "pmc_hbm_gb": round(gb, 2), "hbm_tbps": round(gb / ms, 3),
+                                          "pmc_source": f"replayed from {pmc_file} (rocprofv3 --pmc passes over this command, scripts/refresh_profiles.sh), not measured in this run"})
+        if sustained is not None:
+            out["sustained"] = sustained
+        if pl_model is not None:
+            out["config"]["api"] = ("Px2Px_PL.training_step(batch, i, 0/1) + zero_grad + backward + HipAdam.step under toggle_optimizer, as "
+                                    "Lightning 1.9 drives the reference (train.py:136); generator forwards re-used: "
+                                    f"{pl_model.netG.__dict__.get('_fwd_reused', 0)}")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.blocks, a.size, bs=16 if a.size <= 256 else 4)
         print(json.dumps(out), flush=True)

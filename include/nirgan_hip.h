@@ -135,7 +135,10 @@ typedef struct {
                                            * p + i*p_plane, q + i*q_plane (floats) and writes slabs [i][nsplit][N][K] (fp32 tile only) */
     int pq_bf16;                          /* 1: p and q point to bf16 twins (same geometry; the producers' out_bf16 / dy_bf16);
                                            * precision 1, N > 64, and N, run, p_cs, q_cs multiples of 8 */
+    int algo;                             /* kernel choice where more than one applies (A/B measurements, tests): 0 = default (plane-matrix
+                                           * problems walk their units as persistent workgroups); NIRGAN_WGRAD_ONE_UNIT = one unit per workgroup */
 } nirgan_wgrad_desc;
+#define NIRGAN_WGRAD_ONE_UNIT 1
 
 int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream);
 
@@ -312,7 +315,8 @@ int nirgan_endconv_wgrad(const nirgan_endconv_desc* d, void* stream);
  * Losses (forward value + gradient in one pass).
  * ------------------------------------------------------------------------------------- */
 /* LSGAN: loss_out[0] += weight * mean((pred - target)^2); grad = weight * 2 (pred-target)/n.
- * GANLoss('lsgan') with MSELoss, model/networks.py:233,258-276. */
+ * GANLoss('lsgan') with MSELoss, model/networks.py:233,258-276.  One workgroup (patch maps are a few 10^4 values): the sum is
+ * bitwise reproducible. */
 int nirgan_lsgan(const float* pred, int64_t n, float target, float weight,
                  float* loss_out, float* grad, void* stream);
 
@@ -332,7 +336,10 @@ typedef struct {
     const float* extra; int extra_cs, extra_c; float extra_scale;  /* optional NHWC gradient term */
     float* sums;                          /* 7 floats, accumulated */
     float* grad_pred;                     /* [B][1][H][W] or NULL (forward only) */
+    float* ws; int64_t ws_elems;          /* >= NIRGAN_PIX_LOSS_WS_ELEMS floats: per-block partial sums, added up in block order
+                                             (no float atomics: the seven sums are bitwise reproducible); not shared between streams */
 } nirgan_pix_loss_desc;
+#define NIRGAN_PIX_LOSS_WS_ELEMS 8192
 int nirgan_pix_loss(const nirgan_pix_loss_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -544,7 +551,18 @@ typedef struct {
        nirgan_instnorm_bwd with gsum_out = fuse_gz, ws = fuse_part, sums_chunks = tiles per image. */
     const float* fuse_y; const float* fuse_mean; const float* fuse_rstd; const float* fuse_g2;
     float* fuse_gz; float* fuse_part; int64_t fuse_part_elems; int fuse_act; float fuse_slope;
+    int algo;                             /* plane-GEMM kernel choice (nirgan_wino6_gemm, nirgan_wino6_gemm_wgrad_pair) where more than one
+                                             applies: 0 = default (persistent workgroups on 32-k stages for C = 256 / 512);
+                                             NIRGAN_W6_ONE_TILE = one tile per workgroup (16-k stages); NIRGAN_W6_PERSIST16 = persistent workgroups
+                                             on 16-k stages; NIRGAN_W6_DIRECT_TILE = the direct convolution tile (32-k stages, one tile per
+                                             workgroup).  All compute the same products; kept for A/B measurements and the kernel tests. */
 } nirgan_wino6_desc;
+#define NIRGAN_W6_ONE_TILE 1
+#define NIRGAN_W6_PERSIST16 2
+#define NIRGAN_W6_DIRECT_TILE 3
+/* names of the kernels the two launchers above pick for a descriptor (what a profile of the launch shows) */
+const char* nirgan_wino6_gemm_kernel_name(const nirgan_wino6_desc* d);
+const char* nirgan_wino6_pair_kernel_name(const nirgan_wino6_desc* d, const nirgan_wgrad_desc* w);
 
 int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T of the 4x4-output variants */
 int64_t nirgan_wino6_tiles_r(int B, int H, int W, int r);          /* T of variant r (0 / 3, 4, 6); 0 for an unknown variant */
@@ -604,6 +622,7 @@ typedef struct {
     int style;
     int B, H, W, C;
     float* dz; float* de; float* dscale;
+    float* ws; int64_t ws_elems;          /* >= 2048 floats when dscale is set: per-block partial sums of dscale (fixed-order finish) */
 } nirgan_inject_bwd_desc;
 int nirgan_inject_bwd(const nirgan_inject_bwd_desc* d, void* stream);
 

@@ -73,3 +73,9 @@ __device__ __forceinline__ float ng_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// Fixed-order sum of per-block partial sums (no float atomics between blocks: results are bitwise reproducible).  ws[rows][nv], nv <= 8:
+// dst[i] += sum over rows of ws[row][i], one block, every launch the same association.  The final add is ONE atomic add per value, so
+// that two streams accumulating into the same scalar (micro-batches) commute.  Defined in elementwise.hip.
+int ng_partials_finish(const float* ws, int rows, int nv, float* dst, hipStream_t st);
+

@@ -64,20 +64,41 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ src, int B, int SH
     }
 }
 
+// adjoint of the resize as a GATHER over the source grid (no atomics: every source pixel sums the destination pixels whose
+// footprint holds it, in raster order -- bitwise reproducible).  A destination row oh reads source rows h0 = floor(src), h1 = h0 + 1
+// (clamped) with src = (oh + 0.5) * sh - 0.5: source row h can only be h0 or h1 of rows with src in (h - 1, h + 1), plus the clamped ends.
+__device__ __forceinline__ void bl_window(int h, float s, int S, int O, int& lo, int& hi) {
+    const float inv = 1.f / s;
+    int a = int(floorf((float(h) - 1.f + 0.5f) * inv - 0.5f)) - 1, b = int(ceilf((float(h) + 1.f + 0.5f) * inv - 0.5f)) + 1;
+    if (h == 0) a = 0;                      // negative source coordinates clamp onto row 0
+    if (h == S - 1) b = O - 1;              // and rows past the end onto the last one
+    lo = a < 0 ? 0 : a;
+    hi = b > O - 1 ? O - 1 : b;
+}
+
 __global__ void bilinear_bwd_kernel(const float* __restrict__ dd, int B, int OH, int OW, float* __restrict__ ds, int SH, int SW) {
     const float sh = float(SH) / float(OH), sw = float(SW) / float(OW);
-    const int64_t total = int64_t(B) * OH * OW;
+    const int64_t total = int64_t(B) * SH * SW;
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < total; i += int64_t(gridDim.x) * blockDim.x) {
-        const int ow = int(i % OW), oh = int((i / OW) % OH), b = int(i / (int64_t(OW) * OH));
-        int h0, h1, w0, w1; float lh, lw;
-        bl_coord(oh, sh, SH, h0, h1, lh);
-        bl_coord(ow, sw, SW, w0, w1, lw);
-        float* s = ds + int64_t(b) * SH * SW;
-        const float g = dd[i];
-        atomicAdd(s + h0 * SW + w0, (1.f - lh) * (1.f - lw) * g);
-        atomicAdd(s + h0 * SW + w1, (1.f - lh) * lw * g);
-        atomicAdd(s + h1 * SW + w0, lh * (1.f - lw) * g);
-        atomicAdd(s + h1 * SW + w1, lh * lw * g);
+        const int w = int(i % SW), h = int((i / SW) % SH), b = int(i / (int64_t(SW) * SH));
+        int olo, ohi, wlo, whi;
+        bl_window(h, sh, SH, OH, olo, ohi);
+        bl_window(w, sw, SW, OW, wlo, whi);
+        const float* d = dd + int64_t(b) * OH * OW;
+        float acc = 0.f;
+        for (int oh = olo; oh <= ohi; ++oh) {
+            int h0, h1; float lh;
+            bl_coord(oh, sh, SH, h0, h1, lh);
+            const float ch = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+            if (ch == 0.f) continue;
+            for (int ow = wlo; ow <= whi; ++ow) {
+                int w0, w1; float lw;
+                bl_coord(ow, sw, SW, w0, w1, lw);
+                const float cw = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+                if (cw != 0.f) acc += ch * cw * d[int64_t(oh) * OW + ow];
+            }
+        }
+        ds[i] = acc;
     }
 }
 
@@ -87,7 +108,7 @@ struct InjP {
     float* out; int o_row, o_img, o_org;
     // backward
     const float* g; const float* a; int a_row, a_img, a_org;
-    float* dz; float* de; float* dscale;
+    float* dz; float* de; float* dscale; float* ws;
 };
 
 // one wave per pixel group: lanes over channel quads
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(256) void inject_bwd_kernel(const InjP p, int64_t n
     ds_acc = ng_wave_sum(ds_acc);
     if ((tid & 63) == 0) red[tid >> 6] = ds_acc;
     __syncthreads();
-    if (tid == 0 && p.dscale) atomicAdd(p.dscale, red[0] + red[1] + red[2] + red[3]);
+    if (tid == 0 && p.dscale) p.ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);      // summed in block order by ng_partials_finish
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t rows, int cols, float* __restrict__ out, int accumulate) {
@@ -183,7 +204,29 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
     for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) y[i] += a * x[i];
 }
 
+
+// per-block partial sums -> dst, fixed association (see common.h::ng_partials_finish)
+__global__ __launch_bounds__(256) void partials_finish_kernel(const float* __restrict__ ws, int rows, int nv, float* dst) {
+    __shared__ float part[4][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = tid; r < rows; r += 256)
+        for (int i = 0; i < nv; ++i) acc[i] += ws[size_t(r) * nv + i];
+    for (int i = 0; i < nv; ++i) {
+        const float v = ng_wave_sum(acc[i]);
+        if (lane == 0) part[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < nv) atomicAdd(dst + tid, (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+}
+
 }  // namespace
+
+int ng_partials_finish(const float* ws, int rows, int nv, float* dst, hipStream_t st) {
+    NG_REQUIRE(ws && dst && rows > 0 && nv > 0 && nv <= 8, "partials_finish: bad arguments");
+    hipLaunchKernelGGL(partials_finish_kernel, dim3(1), dim3(256), 0, st, ws, rows, nv, dst);
+    return nirgan_check_launch("partials_finish");
+}
 
 extern "C" int nirgan_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                            float eps, int step, void* stream) {
@@ -207,8 +250,7 @@ extern "C" int nirgan_bilinear_fwd(const float* src, int B, int SH, int SW, floa
 extern "C" int nirgan_bilinear_bwd(const float* ddst, int B, int OH, int OW, float* dsrc, int SH, int SW, void* stream) {
     NG_REQUIRE(ddst && dsrc && B > 0 && SH > 0 && SW > 0 && OH > 0 && OW > 0, "bilinear_bwd: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(int64_t(B) * SH * SW)), dim3(256), 0, st, dsrc, int64_t(B) * SH * SW, 0.f);
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(int64_t(B) * OH * OW)), dim3(256), 0, st, ddst, B, OH, OW, dsrc, SH, SW);
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for(int64_t(B) * SH * SW)), dim3(256), 0, st, ddst, B, OH, OW, dsrc, SH, SW);
     return nirgan_check_launch("bilinear_bwd");
 }
 
@@ -237,7 +279,10 @@ extern "C" int nirgan_inject_bwd(const nirgan_inject_bwd_desc* d, void* stream) 
     const int ppi = 256 / q4;
     int64_t g = (npix + ppi - 1) / ppi;
     g = g < 2048 ? g : 2048;
+    NG_REQUIRE(!d->dscale || (d->ws && d->ws_elems >= g), "inject_bwd: dscale needs a workspace of %lld floats (block partial sums, fixed-order finish)", (long long)g);
+    p.ws = d->ws;
     hipLaunchKernelGGL(inject_bwd_kernel, dim3(int(g)), dim3(256), 0, static_cast<hipStream_t>(stream), p, npix);
+    if (d->dscale) return ng_partials_finish(d->ws, int(g), 1, d->dscale, static_cast<hipStream_t>(stream));
     return nirgan_check_launch("inject_bwd");
 }
 

@@ -29,7 +29,7 @@ struct EndP {
     float* out;
     const float* dout;
     float* dz; int dz_rows, dz_stride; int64_t dz_img;        // zero-bordered dz image
-    float* gx; float* gw; float* gbias; float* ws;
+    float* gx; float* gw; float* gbias; float* ws; int64_t ws_bias0;
 };
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void endconv_dz_kernel(const EndP p) {
         __shared__ float part[4];
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(p.gbias, part[0] + part[1] + part[2] + part[3]);
+        if (threadIdx.x == 0) p.ws[p.ws_bias0 + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);      // block order: ng_partials_finish
     }
 }
 
@@ -373,7 +373,7 @@ extern "C" int64_t nirgan_endconv_dz_elems(int B, int OH, int OW) {
 extern "C" int64_t nirgan_endconv_ws_elems(int B, int OH, int OW) {
     (void)OW;
     if (B <= 0 || OH <= 0) return 0;
-    return int64_t(wgrad_blocks(B, OH)) * ET * EC;
+    return int64_t(wgrad_blocks(B, OH)) * ET * EC + 1024;         // + the dz pass's per-block partial sums of the bias gradient
 }
 
 extern "C" int nirgan_endconv_fwd(const nirgan_endconv_desc* d, void* stream) {
@@ -394,7 +394,13 @@ extern "C" int nirgan_endconv_dz(const nirgan_endconv_desc* d, void* stream) {
     NG_REQUIRE(d->dz_elems >= nirgan_endconv_dz_elems(d->B, d->OH, d->OW) && ng_aligned16(d->dz), "endconv_dz: workspace too small or unaligned");
     const int64_t total = int64_t(p.B) * p.dz_img;
     const int64_t g = (total + 255) / 256;
-    hipLaunchKernelGGL(endconv_dz_kernel, dim3(int(g < 1024 ? g : 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    const int nb = int(g < 1024 ? g : 1024);
+    if (d->gbias) {
+        NG_REQUIRE(d->ws && d->ws_elems >= nirgan_endconv_ws_elems(d->B, d->OH, d->OW), "endconv_dz: gbias needs the partials workspace (nirgan_endconv_ws_elems)");
+        p.ws_bias0 = nirgan_endconv_ws_elems(d->B, d->OH, d->OW) - 1024;
+    }
+    hipLaunchKernelGGL(endconv_dz_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    if (d->gbias) return ng_partials_finish(p.ws + p.ws_bias0, nb, 1, d->gbias, static_cast<hipStream_t>(stream));
     return nirgan_check_launch("endconv_dz");
 }
 

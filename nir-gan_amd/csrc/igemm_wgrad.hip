@@ -162,7 +162,7 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     const dim3 grid(p.ntiles_n * p.ntiles_k * p.nsplit * p.nplanes);
     // matrix-form problems (the transform-domain weight gradient of a Winograd layer launched on its own) with more units than resident
     // workgroups: persistent workgroups with the epilogue folded into the next unit's K loop (igemm_tiles.h::wgrad_persist)
-    if (ng::wgrad_persist_ok(p) && ng::wgrad_matrix_form(p) && grid.x > 512 && getenv("NIRGAN_WGRAD_NOPERSIST") == nullptr) {
+    if (ng::wgrad_persist_ok(p) && ng::wgrad_matrix_form(p) && grid.x > 512 && d->algo != NIRGAN_WGRAD_ONE_UNIT) {
         hipLaunchKernelGGL(wgrad_persist_kernel, dim3(512), dim3(256), 0, st, p);
         return nirgan_check_launch("wgrad_igemm");
     }

@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
             st4(w + tid * 4, s1);
             st4(w + p.C + tid * 4, s2);
         } else if (p.dbias) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(p.dbias + tid * 4 + i, s1[i]);
+            // live bias (no instance norm behind it): this block's channel sums as one row of ws; nirgan_colsum adds the rows in order
+            st4(p.ws + (size_t(b) * p.nchunk + chunk) * p.C + tid * 4, s1);
         }
     }
 }
@@ -314,7 +314,10 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     NG_REQUIRE(!pre || !sums_only, "instnorm_bwd: sums_chunks needs a dy to write");
     NG_REQUIRE(!pre || d->gsum_out != nullptr || (d->g != nullptr && !d->g_fold && d->g2 == nullptr), "instnorm_bwd: sums_chunks needs the folded gradient in gsum_out, or a plain g (no fold, no g2)");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    NG_REQUIRE(d->norm || !d->dbias || (d->ws && d->ws_elems >= int64_t(d->B) * p.nchunk * d->C),
+               "instnorm_bwd: dbias needs ws (one row of channel sums per block, summed in fixed order)");
     if (!pre) hipLaunchKernelGGL(in_bwd_pass1_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
+    if (!d->norm && d->dbias) return nirgan_colsum(d->ws, int64_t(d->B) * p.nchunk, d->C, d->dbias, 1, stream);
     if (d->norm) {
         hipLaunchKernelGGL(in_bwd_finalize_kernel, dim3(d->B, (d->C >= 64 && d->C % 64 == 0) ? d->C / 64 : 1), dim3(256), 0, st, p, d->B);
         if (!sums_only) hipLaunchKernelGGL(in_bwd_pass2_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p, d->B);

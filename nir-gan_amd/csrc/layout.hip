@@ -165,21 +165,32 @@ __global__ void tap_scatter_kernel(const ScatterP p) {
     }
 }
 
-__global__ void tap_dbias_kernel(const float* __restrict__ dout, const float* __restrict__ out, int act, int64_t n, float* dbias) {
+// ONE block of 1024 threads (four elements in flight per thread and trip): the bias gradient of a single-output-channel layer is a sum
+// over its (small) output map; no atomics between blocks, bitwise reproducible.  dbias += the sum.
+__global__ __launch_bounds__(1024) void tap_dbias_kernel(const float* __restrict__ dout, const float* __restrict__ out, int act, int64_t n, float* dbias) {
     float s = 0.f;
-    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        float g = dout[i];
-        if (act == NIRGAN_ACT_TANH) {
-            const float y = out[i];
-            g *= 1.f - y * y;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = i0 + j * 1024;
+            g[j] = i < n ? dout[i] : 0.f;
+            if (act == NIRGAN_ACT_TANH && i < n) {
+                const float y = out[i];
+                g[j] *= 1.f - y * y;
+            }
         }
-        s += g;
+        s += (g[0] + g[1]) + (g[2] + g[3]);
     }
     s = ng_wave_sum(s);
-    __shared__ float part[4];
+    __shared__ float part[16];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dbias, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        dbias[0] += t;
+    }
 }
 
 struct ChanDgradP {
@@ -344,8 +355,7 @@ extern "C" int nirgan_tap_gather(const nirgan_tap_gather_desc* d, void* stream) 
     const int H2 = d->OH - 2 * d->crop, W2 = d->OW - 2 * d->crop;
     bool rowmajor = kh == kw && d->ntaps == kh * kw;
     for (int t = 0; rowmajor && t < d->ntaps; ++t) rowmajor = d->tap_dh[t] == t / kw && d->tap_dw[t] == t % kw;
-    static const bool no_rows = getenv("NIRGAN_TAP_GATHER_WINDOW") != nullptr;      // A/B switch: the all-planes window kernel everywhere
-    if (rowmajor && !no_rows && int64_t(H2) * W2 >= 4096) {     // (small maps: the all-planes window kernel below has more blocks)
+    if (rowmajor && int64_t(H2) * W2 >= 4096) {     // (small maps: the all-planes window kernel below has more blocks)
         const int grid = d->B * ((W2 + 31) / 32) * ((H2 + 31) / 32);
         hipLaunchKernelGGL(tap_gather_rows_kernel, dim3(grid), dim3(256), size_t(32) * (32 + kw - 1) * kw * 4, static_cast<hipStream_t>(stream), p);
         return nirgan_check_launch("tap_gather");
@@ -375,8 +385,7 @@ extern "C" int nirgan_tap_scatter(const nirgan_tap_scatter_desc* d, void* stream
     hipLaunchKernelGGL(tap_scatter_kernel, dim3(grid_for(total)), dim3(256), 0, st, p);
     if (d->dbias) {
         const int64_t n = int64_t(d->B) * (d->OH - 2 * d->crop) * (d->OW - 2 * d->crop);
-        const int g = grid_for(n) < 256 ? grid_for(n) : 256;
-        hipLaunchKernelGGL(tap_dbias_kernel, dim3(g), dim3(256), 0, st, d->dout, d->out, d->act, n, d->dbias);
+        hipLaunchKernelGGL(tap_dbias_kernel, dim3(1), dim3(1024), 0, st, d->dout, d->out, d->act, n, d->dbias);
     }
     return nirgan_check_launch("tap_scatter");
 }

@@ -1,34 +1,52 @@
 // LSGAN, L1 and spectral-index (NDVI/NDWI/GNDVI/SAVI/MSAVI/EVI) losses: value and gradient
-// wrt the prediction in one streaming pass over NCHW tiles.  HBM-bound; block partial sums go
-// to the accumulators with one atomic per block and value.
+// wrt the prediction in one streaming pass over NCHW tiles.  HBM-bound.  No float atomics between blocks: LSGAN (a few 10^4 patch
+// values) is ONE block; the pixel losses leave per-block partial sums in a workspace that ng_partials_finish adds up in block order,
+// so the loss scalars are bitwise reproducible.
 #include "common.h"
 
 namespace {
 
 template <int NV>
-__device__ __forceinline__ void block_accumulate(float (&v)[NV], float* dst) {
-    __shared__ float part[4][NV];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void block_partials(float (&v)[NV], float* dst) {      // dst[NV]: this block's sums, fixed association
+    __shared__ float part[16][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float s = ng_wave_sum(v[i]);
         if (lane == 0) part[wave][i] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NV) atomicAdd(dst + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < NV) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += part[w][threadIdx.x];
+        dst[threadIdx.x] = t;
+    }
 }
 
-__global__ __launch_bounds__(256) void lsgan_kernel(const float* __restrict__ pred, int64_t n, float target, float weight,
-                                                    float* loss_out, float* __restrict__ grad) {
+// one block of 1024 threads, four elements in flight per thread and trip
+__global__ __launch_bounds__(1024) void lsgan_kernel(const float* __restrict__ pred, int64_t n, float target, float weight,
+                                                     float* loss_out, float* __restrict__ grad) {
     const float inv = 1.f / float(n);
     float acc[1] = {0.f};
-    for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
-        const float d = pred[i] - target;
-        acc[0] += d * d;
-        if (grad) grad[i] = weight * 2.f * d * inv;
+    for (int64_t i0 = threadIdx.x; i0 < n; i0 += 4096) {
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = i0 + j * 1024;
+            d[j] = i < n ? pred[i] - target : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = i0 + j * 1024;
+            acc[0] += d[j] * d[j];
+            if (grad && i < n) grad[i] = weight * 2.f * d[j] * inv;
+        }
     }
     acc[0] *= weight * inv;
-    block_accumulate<1>(acc, loss_out);
+    __shared__ float total[1];
+    block_partials<1>(acc, total);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_out, total[0]);          // ONE add per launch: commutes with another stream's
 }
 
 struct PixP {
@@ -37,7 +55,7 @@ struct PixP {
     float w[7];   // l1, ndvi, ndwi, gndvi, savi, msavi, evi
     int criterion, log_all;
     const float* extra; int extra_cs, extra_c; float extra_scale;
-    float* sums; float* grad;
+    float* sums; float* grad; float* ws;
 };
 
 // value and derivative of criterion(a, f) wrt f, where a = idx(nir), f = idx(pred)
@@ -115,16 +133,14 @@ __global__ __launch_bounds__(256) void pix_loss_kernel(const PixP p) {
             p.grad[i] = g;
         }
     }
-    block_accumulate<7>(acc, p.sums);
+    block_partials<7>(acc, p.ws + size_t(blockIdx.x) * 7);
 }
 
 }  // namespace
 
 extern "C" int nirgan_lsgan(const float* pred, int64_t n, float target, float weight, float* loss_out, float* grad, void* stream) {
     NG_REQUIRE(pred && loss_out && n > 0, "lsgan: bad arguments");
-    int64_t g = (n + 255) / 256;
-    g = g < 1024 ? g : 1024;
-    hipLaunchKernelGGL(lsgan_kernel, dim3(int(g)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, n, target, weight, loss_out, grad);
+    hipLaunchKernelGGL(lsgan_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), pred, n, target, weight, loss_out, grad);
     return nirgan_check_launch("lsgan");
 }
 
@@ -143,7 +159,9 @@ extern "C" int nirgan_pix_loss(const nirgan_pix_loss_desc* d, void* stream) {
     p.sums = d->sums; p.grad = d->grad_pred;
     const int64_t n = int64_t(d->B) * p.HW;
     int64_t g = (n + 255) / 256;
-    g = g < 2048 ? g : 2048;
+    g = g < NIRGAN_PIX_LOSS_WS_ELEMS / 8 ? g : NIRGAN_PIX_LOSS_WS_ELEMS / 8;
+    NG_REQUIRE(d->ws && d->ws_elems >= NIRGAN_PIX_LOSS_WS_ELEMS, "pix_loss: workspace of NIRGAN_PIX_LOSS_WS_ELEMS floats required (block partial sums)");
+    p.ws = d->ws;
     hipLaunchKernelGGL(pix_loss_kernel, dim3(int(g)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    return nirgan_check_launch("pix_loss");
+    return ng_partials_finish(d->ws, int(g), 7, d->sums, static_cast<hipStream_t>(stream));
 }

@@ -1202,7 +1202,13 @@ static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
 // 196 at T = 4624, 251 -> 236 for the PatchGAN's 49 x [2048 x 256] x [512]).  At C = 512 a tile is twice as long and the uneven last
 // round of fixed assignments costs more than the folded epilogue saves (579 vs 536 us for the PatchGAN layer's pair launch).
 // (C = 512, the PatchGAN's F(4x4,4x4) data gradient: the plain GEMM gains 12 % as persistent workgroups, the pair launch loses 9 %)
-static bool w6_persistent_ok(const nirgan_wino6_desc* d, bool pair = true) { return d->C == 256 || (d->C == 512 && !pair); }
+// (the persistent bodies address a plane with 32-bit BYTE offsets, unsigned(row * C + chunk) * 4: T * C and K * C must stay below 2^30;
+// larger problems take the one-tile-per-workgroup kernels)
+static bool w6_persistent_ok(const nirgan_wino6_desc* d, bool pair = true) {
+    const long long T = w6_tiles(d->B, d->H, d->W, w6_r(d->r));
+    if (T * d->C >= (1ll << 30) || (long long)d->K * d->C >= (1ll << 30) || T * d->K >= (1ll << 30)) return false;
+    return d->C == 256 || (d->C == 512 && !pair);
+}
 
 static W6G16 w6_g16_params(const nirgan_wino6_desc* d, long long T) {
     W6G16 q;
@@ -1210,6 +1216,41 @@ static W6G16 w6_g16_params(const nirgan_wino6_desc* d, long long T) {
     q.mtiles = int((T + 127) / 128); q.ntiles = (d->K + 127) / 128; q.per_plane = q.mtiles * q.ntiles; q.total = w6_np(w6_r(d->r)) * q.per_plane;
     q.a_plane = T * d->C; q.b_plane = (long long)d->K * d->C; q.o_plane = T * d->K;
     return q;
+}
+
+// which kernel a descriptor's plane GEMMs run on (one place: the launchers and the name queries read it)
+enum W6Choice { W6_PERSIST32, W6_PERSIST16K, W6_ONE_TILE16, W6_DIRECT };
+static W6Choice w6_gemm_choice(const nirgan_wino6_desc* d, bool pair) {
+    if (d->C % 16 != 0 || d->algo == NIRGAN_W6_DIRECT_TILE) return W6_DIRECT;
+    if (pair) {                                        // the pair launch has the persistent 32-k form and the direct-tile form
+        return (w6_persistent_ok(d, true) && d->algo != NIRGAN_W6_ONE_TILE) ? W6_PERSIST32 : W6_DIRECT;
+    }
+    if (w6_persistent_ok(d, false) && d->algo != NIRGAN_W6_ONE_TILE) return d->algo == NIRGAN_W6_PERSIST16 ? W6_PERSIST16K : W6_PERSIST32;
+    return W6_ONE_TILE16;
+}
+
+extern "C" const char* nirgan_wino6_gemm_kernel_name(const nirgan_wino6_desc* d) {
+    if (!d) return "";
+    switch (w6_gemm_choice(d, false)) {
+        case W6_PERSIST32: return "wino6_gemm32p_kernel";
+        case W6_PERSIST16K: return "wino6_gemm16p_kernel";
+        case W6_ONE_TILE16: return "wino6_gemm16_kernel";
+        default: return "wino6_gemm_kernel";
+    }
+}
+
+// the weight-gradient half of a pair launch walks its units persistently when it has the plane-matrix form
+static bool w6_pair_wgrad_persistent(const ng::WgradParams& wp, const nirgan_wgrad_desc* w) {
+    return ng::wgrad_persist_ok(wp) && ng::wgrad_matrix_form(wp) && w->algo != NIRGAN_WGRAD_ONE_UNIT;
+}
+
+extern "C" const char* nirgan_wino6_pair_kernel_name(const nirgan_wino6_desc* d, const nirgan_wgrad_desc* w) {
+    if (!d || !w) return "";
+    ng::WgradParams wp;
+    if (ng::build_wgrad_params(w, wp) != NIRGAN_OK) return "";
+    if (w->N <= 64 || wp.prec != 0 || wp.pq_bf16) return "";                      // two ordinary launches
+    if (w6_gemm_choice(d, true) == W6_PERSIST32) return w6_pair_wgrad_persistent(wp, w) ? "wino6_pair16p_kernel" : "wino6_pair16_kernel";
+    return "wino6_pair_kernel";
 }
 
 extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const nirgan_wgrad_desc* w, void* stream) {
@@ -1225,23 +1266,19 @@ extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const ni
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit * wp.nplanes;
-    const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;          // (read per launch: the tests switch it)
-    const bool no_persist_wgrad = getenv("NIRGAN_WINO6_WGRAD_NOPERSIST") != nullptr;
-    if (w6_persistent_ok(d) && !no_persist) {
+    if (w6_gemm_choice(d, true) == W6_PERSIST32) {
         NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm_wgrad_pair: pointers must be 16-byte aligned");
         const W6G16 q = w6_g16_params(d, T);
         const int gemm_blocks = q.total < 512 ? q.total : 512;
         // the persistent weight-gradient walk needs the plane-matrix form (one tap, unit stride, one image row) and rows in every split
-        const bool matrix_form = ng::wgrad_persist_ok(wp) && ng::wgrad_matrix_form(wp);
-        if (matrix_form && !no_persist_wgrad) {
+        if (w6_pair_wgrad_persistent(wp, w)) {
             hipLaunchKernelGGL(wino6_pair16p_kernel, dim3(gemm_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), q, gemm_blocks, wp);
             return nirgan_check_launch("wino6_gemm_wgrad_pair");
         }
         hipLaunchKernelGGL(wino6_pair16_kernel, dim3(gemm_blocks + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), q, gemm_blocks, wp, wgrad_blocks);
         return nirgan_check_launch("wino6_gemm_wgrad_pair");
     }
-    const int wgrad_first = getenv("NIRGAN_WINO6_PAIR_GEMM_FIRST") == nullptr ? 1 : 0;
-    hipLaunchKernelGGL(wino6_pair_kernel, dim3(g.total + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, wp, wgrad_blocks, wgrad_first);
+    hipLaunchKernelGGL(wino6_pair_kernel, dim3(g.total + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, wp, wgrad_blocks, 1);
     return nirgan_check_launch("wino6_gemm_wgrad_pair");
 }
 
@@ -1250,27 +1287,19 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
     long long T;
     const int rc0 = w6_gemm_params(d, g, T);
     if (rc0 != NIRGAN_OK) return rc0;
-    if (d->C % 16 == 0 && getenv("NIRGAN_WINO6_GEMM32") == nullptr) {
-        // 16-k stages, up to four resident workgroups per CU (see wino6_gemm16_kernel)
-        NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm: pointers must be 16-byte aligned");
-        const W6G16 q = w6_g16_params(d, T);
-        const bool no_persist = getenv("NIRGAN_WINO6_GEMM_NOPERSIST") != nullptr;          // (read per launch: the tests switch it)
-        if (w6_persistent_ok(d, false) && !no_persist) {
-            // persistent workgroups, epilogue folded into the next tile's K loop: 2 per CU
-            const int grid = q.total < 512 ? q.total : 512;
-            // 32-k stages (half the barriers per product; 76 KB of LDS, still two workgroups per CU): 145.8 -> 141.7 us once the loader
-            // carries no vector arithmetic (before that: no difference); NIRGAN_WINO6_GEMM16P=1 keeps the 16-k stages
-            if (getenv("NIRGAN_WINO6_GEMM16P") == nullptr) {
-                hipLaunchKernelGGL(wino6_gemm32p_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), q);
-                return nirgan_check_launch("wino6_gemm");
-            }
-            hipLaunchKernelGGL(wino6_gemm16p_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), q);
-            return nirgan_check_launch("wino6_gemm");
-        }
-        hipLaunchKernelGGL(wino6_gemm16_kernel, dim3(q.total), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+    const W6Choice ch = w6_gemm_choice(d, false);
+    if (ch == W6_DIRECT) {
+        hipLaunchKernelGGL(wino6_gemm_kernel, dim3(g.total), dim3(256), 0, static_cast<hipStream_t>(stream), g);
         return nirgan_check_launch("wino6_gemm");
     }
-    hipLaunchKernelGGL(wino6_gemm_kernel, dim3(g.total), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm: pointers must be 16-byte aligned");
+    const W6G16 q = w6_g16_params(d, T);
+    const int grid = q.total < 512 ? q.total : 512;           // persistent workgroups, epilogue folded into the next tile's K loop: 2 per CU
+    // 32-k stages (half the barriers per product; 76 KB of LDS, still two workgroups per CU): 145.8 -> 141.7 us once the loader
+    // carries no vector arithmetic (before that: no difference)
+    if (ch == W6_PERSIST32) hipLaunchKernelGGL(wino6_gemm32p_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+    else if (ch == W6_PERSIST16K) hipLaunchKernelGGL(wino6_gemm16p_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), q);
+    else hipLaunchKernelGGL(wino6_gemm16_kernel, dim3(q.total), dim3(256), 0, static_cast<hipStream_t>(stream), q);       // 16-k stages, up to four resident workgroups per CU
     return nirgan_check_launch("wino6_gemm");
 }
 

@@ -285,11 +285,23 @@ class GANLoss(nn.Module):
             raise NotImplementedError('gan mode %s is not on the MI355X path (the shipped configs use lsgan)' % gan_mode)
         else:
             raise NotImplementedError('gan mode %s not implemented' % gan_mode)
-        self._labels = (float(target_real_label), float(target_fake_label))
+        self._label_cache = {}
+
+    def _label_value(self, target_is_real: bool) -> float:
+        """The float the fused loss kernel takes, read from the registered buffer (networks.py:229-230) -- a checkpoint that carries
+        other ``criterionGAN.real_label / fake_label`` values (train.py:61-65) or an in-place edit must reach the kernel.  One host
+        read per CHANGE of the buffer (keyed on storage and torch's version counter), none in the steady state."""
+        t = self.real_label if target_is_real else self.fake_label
+        key = (t.data_ptr(), t._version, t.device)
+        hit = self._label_cache.get(bool(target_is_real))
+        if hit is None or hit[0] != key:
+            hit = (key, float(t.detach().float().cpu().item()))
+            self._label_cache[bool(target_is_real)] = hit
+        return hit[1]
 
     def get_target_tensor(self, prediction, target_is_real):
         target_tensor = self.real_label if target_is_real else self.fake_label
         return target_tensor.expand_as(prediction)
 
     def __call__(self, prediction, target_is_real):
-        return HF.LsganFn.apply(prediction, self._labels[0] if target_is_real else self._labels[1])
+        return HF.LsganFn.apply(prediction, self._label_value(target_is_real))

@@ -137,10 +137,13 @@ class Px2Px_PL(_Base):
                 self._log("post_correction_param", self.netG.post_correction_param.item())
         if optimizer_idx == 0:
             fake_AB = torch.cat((rgb, pred), 1)
-            pred_fake = self.netD(fake_AB.detach())
-            loss_D_fake = self.criterionGAN(pred_fake, False)
             real_AB = torch.cat((rgb, nir), 1)
-            pred_real = self.netD(real_AB)
+            # the reference calls netD twice (pix2pix.py:197-204); InstanceNorm is per sample, so ONE pass over [fake ; real] gives
+            # the same two patch maps (and one backward instead of two)
+            nb = fake_AB.shape[0]
+            both = self.netD(torch.cat((fake_AB.detach(), real_AB), 0))
+            pred_fake, pred_real = both[:nb], both[nb:]
+            loss_D_fake = self.criterionGAN(pred_fake, False)
             loss_D_real = self.criterionGAN(pred_real, True)
             loss_D = (loss_D_fake + loss_D_real)
             self._log("model_loss/discriminator_real", loss_D_real)
@@ -222,6 +225,11 @@ class Px2Px_PL(_Base):
         B x 256 inputs are taken as precomputed embeddings (the reference's own smoke test feeds those, :509-526)."""
         if coords is not None and coords.dim() == 2 and coords.shape[-1] == 256:
             return coords.float()
+        # the same coords tensor in both optimizer passes of a batch gives the same embeddings OBJECT (the generator then
+        # recognises the repeated forward, functional._ForwardRecord)
+        hit = self.__dict__.get("_emb_record")
+        if hit is not None and hit[0] is coords and hit[1] == coords._version:
+            return hit[2]
         if coords is None or coords.dim() != 2 or coords.shape[-1] != 2:
             raise ValueError("coords must be B x 2 (lon, lat) or B x 256 precomputed SatCLIP embeddings")
         if self.satclip_model is None:
@@ -232,7 +240,9 @@ class Px2Px_PL(_Base):
             from model.satclip.satclip_wrapper import SatClIP_wrapper
             self.satclip_model = SatClIP_wrapper(self._satclip_path, device=coords.device).eval()
         with torch.no_grad():
-            return self.satclip_model.predict(coords.double()).float()
+            emb = self.satclip_model.predict(coords.double()).float()
+        self.__dict__["_emb_record"] = (coords, coords._version, emb)
+        return emb
 
     def configure_optimizers(self):
         optim_g = HipAdam(self.netG.parameters(), lr=self.opt.lr, betas=(self.opt.beta1, 0.999), net=self.netG)
@@ -266,4 +276,6 @@ class Px2Px_PL(_Base):
             rgb, nir, embeds = self.extract_batch(batch)
         else:
             (rgb, nir), embeds = self.extract_batch(batch), None
-        return self.fused_trainer().step(rgb, nir, embeds)
+        tr = self.fused_trainer()
+        tr.real_label, tr.fake_label = self.criterionGAN._label_value(True), self.criterionGAN._label_value(False)   # networks.py:229-230
+        return tr.step(rgb, nir, embeds)

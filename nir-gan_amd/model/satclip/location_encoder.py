@@ -17,17 +17,27 @@ from torch import nn
 from nirgan_hip import lib as L
 
 
+HARMONICS_VARIANTS = ("analytic", "closed-form", "analytic-generator-text")
+
+
 def sh_normalisation(legendre_polys: int, harmonics_calculation: str = "closed-form") -> torch.Tensor:
     """Per-feature constant K[l*l+l+m] in front of P_l^|m|(cos theta) * {1, cos(m phi), sin(|m| phi)} (P with the
     Condon-Shortley phase, as the device recurrence computes it).
 
     'closed-form' (spherical_harmonics_closed_form.py:25-40): [sqrt 2 if m != 0] * sqrt((2l+1)(l-|m|)! / (4 pi (l+|m|)!)).
-    'analytic' (the tabulated spherical_harmonics_ylm.py, generated by spherical_harmonics_generate_ylms.py:19-36): NOT the
-    same functions -- the generator multiplies (-1)**m onto sympy's assoc_legendre, which already carries that phase, so
-    odd orders flip sign against closed-form, and its m == 0 branch reads ``sqrt((2*l + 1) / 4 * pi)`` = sqrt((2l+1) pi / 4).
-    Published SatCLIP checkpoints were trained with 'analytic'; their Siren weights expect these values."""
-    if harmonics_calculation not in ("analytic", "closed-form"):
-        raise NotImplementedError(f"harmonics_calculation [{harmonics_calculation}] is not on the MI355X path")
+    'analytic' (the tabulated spherical_harmonics_ylm.py -- NOT in the reference tree; what published SatCLIP checkpoints record):
+      the orthonormal constant for m == 0 (= closed-form) and (-1)**m times the closed-form constant for m != 0: the table's
+      generator (spherical_harmonics_generate_ylms.py:19-36) multiplies (-1)**m onto sympy's assoc_legendre, which already
+      carries that phase, so odd orders flip sign against closed-form.
+    'analytic-generator-text': the generator script EXACTLY as its text in the reference reads, i.e. with its m == 0 branch
+      ``sqrt((2*l + 1) / 4 * pi)`` = sqrt((2l+1) pi / 4) -- pi times the orthonormal constant (operator precedence).  The
+      published table starts with Yl0_m0 = 0.2820947917... = sqrt(1/(4 pi)), i.e. it was generated with the orthonormal
+      constant, so this variant is NOT the default: a checkpoint trained on the table would get its ten zonal inputs scaled by
+      pi.  It is kept as an explicit option because it is the only variant the reference tree itself pins for every feature
+      (fixture f7 = this script evaluated with sympy); 'analytic' is pinned by f7 on the m != 0 features and by the
+      reference's closed-form file (fixture f6) on the m == 0 features."""
+    if harmonics_calculation not in HARMONICS_VARIANTS:
+        raise NotImplementedError(f"harmonics_calculation [{harmonics_calculation}] is not on the MI355X path {HARMONICS_VARIANTS}")
     out = []
     for l in range(legendre_polys):
         for m in range(-l, l + 1):
@@ -35,8 +45,10 @@ def sh_normalisation(legendre_polys: int, harmonics_calculation: str = "closed-f
             k = math.sqrt((2.0 * l + 1.0) * math.factorial(l - am) / (4 * math.pi * math.factorial(l + am)))
             if harmonics_calculation == "closed-form":
                 out.append(k if m == 0 else math.sqrt(2.0) * k)
+            elif m != 0:
+                out.append((-1.0) ** am * math.sqrt(2.0) * k)
             else:
-                out.append(math.sqrt((2 * l + 1) / 4 * math.pi) if m == 0 else (-1.0) ** am * math.sqrt(2.0) * k)
+                out.append(k if harmonics_calculation == "analytic" else math.sqrt((2 * l + 1) / 4 * math.pi))
     return torch.tensor(out, dtype=torch.float64)
 
 

@@ -22,6 +22,7 @@ import torch
 
 from . import geometry as G
 from . import lib as L
+from .options import OPT
 
 IN_EPS = 1e-5
 
@@ -103,40 +104,17 @@ class Halo:
 
 
 HOOK = "__hook__"
-JOIN = "__join__"
-_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
-
-
-def _side_stream(device):
-    """One auxiliary HIP stream per device for work that is off a plan's critical path (weight gradients under the HBM-bound
-    kernels of the data-gradient chain)."""
-    key = str(device)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device)
-    return _SIDE_STREAMS[key]
 
 
 class Plan:
     def __init__(self, ctx: Ctx):
         self.ctx = ctx
         self.ops: list = []
-        self.side: set = set()       # indices of ops issued on the auxiliary stream (add_side)
         self.probe_idx = None        # bench.py: {op index: kernel label} to bracket with HIP events on the launch stream
         self.probe_events: list = []
 
     def add(self, name: str, *args):
         self.ops.append((name, args))
-
-    def add_side(self, name: str, *args):
-        """An op that may run on the device's auxiliary stream: it is ordered after everything the plan issued before it and before
-        the next join (add_join, any hook, the end of the plan).  The caller guarantees that nothing issued in between touches its
-        outputs or overwrites its inputs."""
-        self.ops.append((name, args))
-        self.side.add(len(self.ops) - 1)
-
-    def add_join(self):
-        """The launch stream waits for the auxiliary stream's work issued so far."""
-        self.ops.append((JOIN, ()))
 
     def insert_hook(self, index: int, fn) -> None:
         """Host callback between two launches (data parallel: start a gradient bucket's all-reduce as soon as the launches
@@ -149,14 +127,12 @@ class Plan:
                     break
                 seen += 1
         self.ops.insert(pos, (HOOK, (fn,)))
-        self.side = {i + 1 if i >= pos else i for i in self.side}
 
     def extend(self, other: "Plan"):
         self.ops.extend(other.ops)
 
     def fuse_packs(self):
         """Replace the nirgan_pack_rows ops of this plan by ONE nirgan_pack_rows_batch launch (job table in device memory)."""
-        assert not self.side, "pack plans carry no auxiliary-stream ops"
         packs = [(a, n == "nirgan_pack_rows_bf16") for n, a in self.ops if n in ("nirgan_pack_rows", "nirgan_pack_rows_bf16")]
         if len(packs) < 2 or len(packs) > 256:
             return
@@ -200,58 +176,34 @@ class Plan:
     def run(self):
         be = L.backend()
         st = self.ctx.stream()
-        # auxiliary-stream ops are OPT-IN (NIRGAN_SIDE_STREAM=1): measured +1 % for the single-stream step (25.46 -> 25.23 ms) -- a kernel
-        # that already fills every CU leaves the other stream's HBM-bound kernels one workgroup per CU -- and -4 % with two micro-batches
-        use_side = bool(self.side) and self.ctx.device.type == "cuda" and os.environ.get("NIRGAN_SIDE_STREAM") == "1"
-        if self.probe_idx or use_side:
-            return self._run_streams(be, st, use_side)
+        if self.probe_idx:
+            return self._run_probed(be, st)
         for name, args in self.ops:
             if name is HOOK:
                 args[0]()
-                continue
-            if name is JOIN:
                 continue
             rc = getattr(be, name)(*args, st)
             if rc != 0:
                 L.check(rc, name)
 
-    def _run_streams(self, be, st, use_side):
-        """The general runner: auxiliary-stream ops (fork after the preceding launch, join on demand) and / or per-op HIP events."""
+    def _run_probed(self, be, st):
+        """bench.py: the same loop with HIP events around the ops listed in probe_idx (on the launch stream)."""
         main = torch.cuda.current_stream(self.ctx.device) if self.ctx.device.type == "cuda" else None
-        side = _side_stream(self.ctx.device) if use_side else None
-        forked = False
-
-        def join():
-            nonlocal forked
-            if forked:
-                main.wait_stream(side)
-                forked = False
         probes = self.probe_idx or {}
         for i, (name, args) in enumerate(self.ops):
             if name is HOOK:
-                join()
                 args[0]()
                 continue
-            if name is JOIN:
-                join()
-                continue
-            on_side = use_side and i in self.side
-            if on_side and not forked:
-                side.wait_stream(main)           # ordered after everything issued so far
-                forked = True
-            stream_obj = side if on_side else main
-            handle = stream_obj.cuda_stream if stream_obj is not None else st
-            if i in probes:
+            if i in probes and main is not None:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record(stream_obj)
-                rc = getattr(be, name)(*args, handle)
-                e.record(stream_obj)
+                s.record(main)
+                rc = getattr(be, name)(*args, st)
+                e.record(main)
                 self.probe_events.append((probes[i], s, e))
             else:
-                rc = getattr(be, name)(*args, handle)
+                rc = getattr(be, name)(*args, st)
             if rc != 0:
                 L.check(rc, name)
-        join()
 
 
 def _set_taps(desc, dh, dw):
@@ -601,6 +553,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
     d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
     d.zero_page = ctx.zero_page.data_ptr()
+    d.algo = OPT.w6_gemm_algo
     if stats_ws is not None:        # the output transform leaves the instance norm's partial sums (one chunk per tile): no statistics pass over y
         assert stats_ws.numel() >= T * 2 * cout
         d.stats_ws, d.stats_ws_elems = stats_ws.data_ptr(), stats_ws.numel()
@@ -628,16 +581,13 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     assert dgrad.r == v
     T = _w6_tiles(B, OH, OW, v)
     NP = _w6_geo(v)[1]
-    for name in ("wino6_pool_x", "wino6_pool_y", "wino6_pool_y2", "wino6_slabs"):
+    for name in ("wino6_pool_x", "wino6_pool_y", "wino6_slabs"):
         if not hasattr(ctx, name):
             setattr(ctx, name, SplitPool(ctx))
-    # the weight-gradient launches run on the auxiliary stream under the HBM-bound kernels that follow the data gradient (output
-    # transform, instance-norm backward, the next layer's dY transforms): Yt alternates between two buffers so that the next
-    # layer's transform does not overwrite what the previous layer's weight gradient is still reading; the slabs are its own pool
-    ctx.wino6_flip = getattr(ctx, "wino6_flip", 0) ^ 1
-    side_ok = V_fwd is not None
-    Yt = (ctx.wino6_pool_y2 if (ctx.wino6_flip and side_ok) else ctx.wino6_pool_y).get(NP * T * cout)
-    if side_ok:
+    # (round 3, measured: the weight gradient on an auxiliary stream as a one-workgroup-per-CU launch under the HBM-bound chain that
+    # follows the data gradient overlaps zero-sum -- profiles/r03_side_stream_1wg_per_cu_experiment.txt; the option is gone)
+    Yt = ctx.wino6_pool_y.get(NP * T * cout)
+    if V_fwd is not None:
         slabs_pool = ctx.wino6_slabs
     vin = None
     if V_fwd is not None:
@@ -657,14 +607,13 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     # 256 output channels: the pair launch is 512 persistent workgroups that walk the weight-gradient units before their GEMM tiles
     # (csrc/wino6.hip::wino6_pair16p_kernel) -- one unit each (two splits per output tile) instead of the two rounds of short blocks
     # the one-tile-per-workgroup launch wants: half the slab traffic, 743 -> 750 tiles/s
-    persistent = (cout == 256 and os.environ.get("NIRGAN_WINO6_GEMM_NOPERSIST") is None and os.environ.get("NIRGAN_WINO6_WGRAD_NOPERSIST") is None
-                  and os.environ.get("NIRGAN_NO_WINO6_PAIR") != "1" and os.environ.get("NIRGAN_SIDE_STREAM") != "1")
+    persistent = cout == 256 and OPT.w6_gemm_algo == 0 and OPT.wgrad_algo == 0 and OPT.w6_pair
     nsplit, rows = G.wgrad_split(T, tiles, 512 if persistent else 1024)
     if os.environ.get("NIRGAN_WINO6_SPLITS"):            # experiments
         nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ["NIRGAN_WINO6_SPLITS"]))
     # deferred finish (ctx.w6_deferred is a list while a network collects the layers of one trunk): the layer keeps its own slabs and the
     # inverse transforms of all of them run as ONE launch behind the trunk (emit_w6_deferred_finishes)
-    deferred = getattr(ctx, "w6_deferred", None) if (persistent and not side_ok_stream(ctx)) else None
+    deferred = getattr(ctx, "w6_deferred", None) if persistent else None
     slabs = ctx.zeros(NP * nsplit * cout * cin) if deferred is not None else slabs_pool.get(NP * nsplit * cout * cin)
     d = L.WgradDesc()
     d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), NP * T * cout, 1, T, cout, 0, 0
@@ -678,6 +627,7 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     d.zero_page = ctx.zero_page.data_ptr()
     d.precision = 0
     d.nplanes, d.p_plane, d.q_plane = NP, T * cout, T * cin
+    d.algo = OPT.wgrad_algo
     ctx.keep.extend([vin, ydesc, d, slabs])
     if norm_desc is not None:       # dY is not in memory: the instance-norm backward's second pass runs inside the transform
         plan.add("nirgan_wino6_input_dy_norm", C.byref(dgrad), C.byref(ydesc), C.byref(norm_desc))
@@ -685,23 +635,17 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
         plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
     if vin is not None:
         plan.add("nirgan_wino6_input", C.byref(vin))
-    plan.add_join()                          # the previous layer's weight gradient is done before this layer's GEMM takes the matrix pipe
-    add_w = plan.add_side if side_ok else plan.add
-    if os.environ.get("NIRGAN_NO_WINO6_PAIR") != "1" and os.environ.get("NIRGAN_SIDE_STREAM") != "1":      # 24.87 -> 24.64 ms per step
+    if OPT.w6_pair:                                # 24.87 -> 24.64 ms per step
         plan.add("nirgan_wino6_gemm_wgrad_pair", C.byref(dgrad), C.byref(d))      # one grid: weight-gradient blocks first, GEMM blocks behind
     else:
         plan.add("nirgan_wino6_gemm", C.byref(dgrad))
-        add_w("nirgan_wgrad_igemm", C.byref(d))
+        plan.add("nirgan_wgrad_igemm", C.byref(d))
     plan.add("nirgan_wino6_output", C.byref(dgrad))
     if deferred is not None:
         deferred.append((slabs, nsplit, cout, cin, v, grad, 1 if accumulate else 0))
     else:
-        add_w("nirgan_wino6_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, v, grad.data_ptr(), 1 if accumulate else 0)
+        plan.add("nirgan_wino6_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, v, grad.data_ptr(), 1 if accumulate else 0)
     return d
-
-
-def side_ok_stream(ctx: Ctx) -> bool:
-    return os.environ.get("NIRGAN_SIDE_STREAM") == "1"
 
 
 def emit_w6_deferred_finishes(plan: Plan, ctx: Ctx):
@@ -818,6 +762,7 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
         d.y = y.ptr
     if norm:
         d.mean, d.rstd = stats[0].data_ptr(), stats[1].data_ptr()
+    if norm or dbias is not None:       # partial sums of the two reduction passes / of the live bias gradient (one row per block)
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     d.B, d.H, d.W, d.C = B, H, W, Cc
     assert not sums_only or norm

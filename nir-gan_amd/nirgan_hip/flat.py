@@ -86,10 +86,15 @@ class FlatParams:
         """Changes whenever any parameter was modified in place (torch version counters) or re-bound."""
         return self.version * 1000003 + sum(p._version for p in self.module.parameters())
 
-    def adam_step(self, lr: float, beta1: float, beta2: float = 0.999, eps: float = 1e-8, stream=None):
-        """torch.optim.Adam(lr, betas=(beta1, 0.999)) on the whole network (model/pix2pix.py:486-487)."""
+    def adam_step(self, lr: float, beta1: float, beta2: float = 0.999, eps: float = 1e-8, stream=None, grad_ptr=None, ranges=None):
+        """torch.optim.Adam(lr, betas=(beta1, 0.999)) on the whole network (model/pix2pix.py:486-487).
+        grad_ptr: read the gradients from another buffer of the flat layout (the autograd bridge's) instead of ``self.grad``;
+        ranges: [(lo, hi)] element ranges to update (tensors without a gradient are left alone); default the whole range."""
         self.moments()
         self.step_count += 1
-        L.call("nirgan_adam", self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-               self.total, lr, beta1, beta2, eps, self.step_count, stream)
+        gp = self.grad.data_ptr() if grad_ptr is None else grad_ptr
+        for lo, hi in (ranges if ranges is not None else [(0, self.total)]):
+            if hi > lo:
+                L.call("nirgan_adam", self.flat.data_ptr() + 4 * lo, gp + 4 * lo, self.m.data_ptr() + 4 * lo, self.v.data_ptr() + 4 * lo,
+                       hi - lo, lr, beta1, beta2, eps, self.step_count, stream)
         self.version += 1

@@ -56,30 +56,62 @@ class EnginePool:
         return _Lease(self, key, eng)
 
 
+class _ForwardRecord:
+    """What the generator's last training-mode forward ran on: the input tensor OBJECTS (held, so their storage cannot be handed to
+    another tensor) with torch's version counters, the parameter version, and the engine lease that still holds every activation.
+    The reference runs the generator forward in BOTH optimizer passes of a batch with unchanged parameters (model/pix2pix.py:
+    178-180), which reproduces ``pred`` bit for bit; a second forward on the same tensors with the same parameters re-uses the
+    first one's activations instead (and gets a backward-capable graph even when the first pass ran with the generator frozen,
+    as Lightning's toggle_optimizer does).  Dropped by the next forward, by a backward through the lease, by any change."""
+
+    def __init__(self, rgb, embeds, ver, key, lease):
+        self.rgb, self.rgb_v = rgb, rgb._version
+        self.embeds, self.emb_v = embeds, (None if embeds is None else embeds._version)
+        self.ver, self.key, self.lease = ver, key, lease
+
+    def matches(self, rgb, embeds, ver, key) -> bool:
+        return (self.lease.eng is not None and rgb is self.rgb and rgb._version == self.rgb_v and embeds is self.embeds
+                and (embeds is None or embeds._version == self.emb_v) and ver == self.ver and key == self.key)
+
+
 class GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, grad_mode, rgb, embeds, *params):
         _require_device(rgb, "generator")
         B, _, H, W = rgb.shape
-        need_bwd = grad_mode and any(ctx.needs_input_grad[4:])
-        # inference (no_grad / frozen generator): a forward-only engine without backward buffers
-        lease = net._pool().lease((B, H, W, net.data_pad, need_bwd))
-        eng = lease.eng
+        wants = grad_mode and any(ctx.needs_input_grad[4:])
+        # training mode with autograd on: run on the backward-capable engine and remember the forward, so that the second
+        # optimizer pass of the batch does not repeat it; inference (no_grad / eval): a forward-only engine without backward buffers
+        need_bwd = wants or (grad_mode and net.training)
         ver = net._flat().values_version()
-        pred = eng.forward(rgb.detach().contiguous().float(), None if embeds is None else embeds.detach().contiguous().float(), version=ver)
-        out = pred.clone()
-        if need_bwd:
-            ctx.lease, ctx.net, ctx.ver, ctx.has_emb = lease, net, ver, embeds is not None
+        key = (B, H, W, net.data_pad, need_bwd)
+        rec = net.__dict__.get("_fwd_record")
+        net.__dict__["_fwd_record"] = None
+        if rec is not None and need_bwd and rec.matches(rgb, embeds, ver, key):
+            lease = rec.lease                                           # same tensors, same parameters: the activations are there
+            net.__dict__["_fwd_reused"] = net.__dict__.get("_fwd_reused", 0) + 1
         else:
-            lease.release()
+            rec = None
+            lease = net._pool().lease(key)
+            lease.eng.forward(rgb.detach().contiguous().float(), None if embeds is None else embeds.detach().contiguous().float(), version=ver)
+        out = lease.eng.pred.clone()
+        if need_bwd:
+            net.__dict__["_fwd_record"] = rec if rec is not None else _ForwardRecord(rgb, embeds, ver, key, lease)
+        if wants:
+            ctx.lease, ctx.net, ctx.ver, ctx.has_emb = lease, net, ver, embeds is not None
         return out
 
     @staticmethod
     def backward(ctx, dpred):
         lease, net = ctx.lease, ctx.net
+        rec = net.__dict__.get("_fwd_record")
+        if rec is not None and rec.lease is lease:
+            net.__dict__["_fwd_record"] = None                          # the engine goes back to the pool below
         eng = lease.eng
         eng.backward(dpred.contiguous(), version=ctx.ver)
         flat = net._flat()
+        # ONE buffer in the flat layout; the per-parameter gradients are views of it.  autograd keeps them as the .grad tensors
+        # (first accumulation) and HipAdam.step recognises the layout and reads the buffer in place (optim.py)
         g = flat.grad.clone()
         grads = tuple(g[o:o + k].view(s) for (o, k, s) in (flat.slices[n] for n in flat.names))
         lease.release()
@@ -159,6 +191,8 @@ class PixLossFn(torch.autograd.Function):
         (d.w_l1, d.w_ndvi, d.w_ndwi, d.w_gndvi, d.w_savi, d.w_msavi, d.w_evi) = [float(w) for w in weights]
         d.criterion, d.log_all = criterion, 0
         d.sums, d.grad_pred = sums.data_ptr(), grad.data_ptr()
+        ws = torch.empty(L.PIX_LOSS_WS_ELEMS, dtype=torch.float32, device=pred_.device)      # per call: block partial sums (fixed-order finish)
+        d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
         st = torch.cuda.current_stream(pred_.device).cuda_stream if pred_.device.type == "cuda" else None
         L.call("nirgan_pix_loss", C.byref(d), st)
         ctx.save_for_backward(grad)
@@ -181,6 +215,8 @@ def index_sums(rgb, nir, pred, criterion: int) -> torch.Tensor:
     d.rgb, d.nir, d.pred, d.B, d.H, d.W = rgb_.data_ptr(), nir_.data_ptr(), pred_.data_ptr(), B, H, W
     d.criterion, d.log_all = criterion, 1
     d.sums = sums.data_ptr()
+    ws = torch.empty(L.PIX_LOSS_WS_ELEMS, dtype=torch.float32, device=pred_.device)
+    d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     st = torch.cuda.current_stream(pred_.device).cuda_stream if pred_.device.type == "cuda" else None
     L.call("nirgan_pix_loss", C.byref(d), st)
     return sums[:7] / float(B * H * W)

@@ -43,7 +43,7 @@ class WgradDesc(C.Structure):
                 ("tap_dh", i32 * MAX_TAPS), ("tap_dw", i32 * MAX_TAPS),
                 ("B", i32), ("OH", i32), ("OW", i32), ("N", i32),
                 ("slabs", fp), ("slab_elems", i64), ("nsplit", i32), ("rows_per_split", i32), ("zero_page", fp),
-                ("precision", i32), ("nplanes", i32), ("p_plane", i64), ("q_plane", i64), ("pq_bf16", i32)]
+                ("precision", i32), ("nplanes", i32), ("p_plane", i64), ("q_plane", i64), ("pq_bf16", i32), ("algo", i32)]
 
 
 class InFwdDesc(C.Structure):
@@ -81,12 +81,15 @@ class TapScatterDesc(C.Structure):
                 ("dq", fp), ("q_hp", i32), ("q_wp", i32), ("q_cs", i32), ("dbias", fp)]
 
 
+PIX_LOSS_WS_ELEMS = 8192        # include/nirgan_hip.h: NIRGAN_PIX_LOSS_WS_ELEMS
+
+
 class PixLossDesc(C.Structure):
     _fields_ = [("rgb", fp), ("nir", fp), ("pred", fp), ("B", i32), ("H", i32), ("W", i32),
                 ("w_l1", f32), ("w_ndvi", f32), ("w_ndwi", f32), ("w_gndvi", f32), ("w_savi", f32),
                 ("w_msavi", f32), ("w_evi", f32), ("criterion", i32), ("log_all", i32),
                 ("extra", fp), ("extra_cs", i32), ("extra_c", i32), ("extra_scale", f32),
-                ("sums", fp), ("grad_pred", fp)]
+                ("sums", fp), ("grad_pred", fp), ("ws", fp), ("ws_elems", i64)]
 
 
 class InjectFwdDesc(C.Structure):
@@ -97,7 +100,7 @@ class InjectFwdDesc(C.Structure):
 class InjectBwdDesc(C.Structure):
     _fields_ = [("g", fp), ("a", fp), ("a_hp", i32), ("a_wp", i32), ("a_pad", i32), ("z", fp), ("e", fp),
                 ("scale", fp), ("style", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32),
-                ("dz", fp), ("de", fp), ("dscale", fp)]
+                ("dz", fp), ("de", fp), ("dscale", fp), ("ws", fp), ("ws_elems", i64)]
 
 
 class MetricsDesc(C.Structure):
@@ -141,7 +144,11 @@ class Wino6Desc(C.Structure):
     _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
                 ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32), ("stats_ws", fp), ("stats_ws_elems", i64),
                 ("fuse_y", fp), ("fuse_mean", fp), ("fuse_rstd", fp), ("fuse_g2", fp), ("fuse_gz", fp), ("fuse_part", fp), ("fuse_part_elems", i64),
-                ("fuse_act", i32), ("fuse_slope", f32)]
+                ("fuse_act", i32), ("fuse_slope", f32), ("algo", i32)]
+
+
+W6_ONE_TILE, W6_PERSIST16, W6_DIRECT_TILE = 1, 2, 3      # nirgan_wino6_desc.algo
+WGRAD_ONE_UNIT = 1                                       # nirgan_wgrad_desc.algo
 
 
 class EndConvDesc(C.Structure):
@@ -190,6 +197,8 @@ PROTOTYPES = {
     "nirgan_wino6_input_norm": (i32, [C.POINTER(Wino6Desc), fp, fp, fp, i32, f32, fp]),
     "nirgan_wino6_gemm": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_gemm_wgrad_pair": (i32, [C.POINTER(Wino6Desc), C.POINTER(WgradDesc), fp]),
+    "nirgan_wino6_gemm_kernel_name": (C.c_char_p, [C.POINTER(Wino6Desc)]),
+    "nirgan_wino6_pair_kernel_name": (C.c_char_p, [C.POINTER(Wino6Desc), C.POINTER(WgradDesc)]),
     "nirgan_wino6_output": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_conv3x3": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_dy": (i32, [C.POINTER(WinoDyDesc), fp]),

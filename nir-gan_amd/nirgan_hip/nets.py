@@ -178,6 +178,8 @@ class GeneratorEngine(_Engine):
         d.B, d.H, d.W, d.C = B, H2, W2, C2
         d.dz, d.de = self.dz2.ptr, self.de_map.data_ptr()
         d.dscale = gr["scale_param"].data_ptr() if use_scale else None
+        self.inject_ws = ctx.zeros(2048)                   # per-block partial sums of dscale, added in block order
+        d.ws, d.ws_elems = self.inject_ws.data_ptr(), self.inject_ws.numel()
         ctx.keep.append(d)
         if use_scale:
             b.add("nirgan_fill", gr["scale_param"].data_ptr(), 1, 0.0)

@@ -87,15 +87,57 @@ class HipAdam(torch.optim.Optimizer):
                 loss = closure()
         flat: FlatParams = self.net._flat()
         g = self.param_groups[0]
-        views = flat.grad_views()
-        have = False
-        for n, p in self.net.named_parameters():
-            if p.grad is None:
-                views[n].zero_()
-            else:
-                views[n].copy_(p.grad)
-                have = True
-        if have:
-            st = torch.cuda.current_stream(flat.device).cuda_stream if flat.device.type == "cuda" else None
+        st = torch.cuda.current_stream(flat.device).cuda_stream if flat.device.type == "cuda" else None
+        params = self.param_groups[0]["params"]
+        grads = [p.grad for p in params]
+        if all(gr is None for gr in grads):
+            return loss                                   # torch.optim.Adam: nothing to do, no step counted
+        if all(gr is not None for gr in grads):
+            # the autograd bridge (functional.GeneratorFn / DiscriminatorFn.backward) hands autograd views of ONE buffer in the flat
+            # layout and autograd keeps them as the .grad tensors: Adam then reads that buffer in place -- no per-parameter copy
+            base = self._aliased_flat_gradient(flat, grads)
+            if base is not None:
+                flat.adam_step(g["lr"], g["betas"][0], g["betas"][1], g["eps"], stream=st, grad_ptr=base)
+                return loss
+            views = flat.grad_views()
+            for n, gr in zip(self._names, grads):
+                views[n].copy_(gr)
             flat.adam_step(g["lr"], g["betas"][0], g["betas"][1], g["eps"], stream=st)
+            return loss
+        # some parameters have no gradient: torch.optim.Adam leaves those tensors (values AND moments) untouched.  The fused kernel
+        # runs over the contiguous runs of tensors that do have one (the step count stays one per network).
+        views = flat.grad_views()
+        runs, cur = [], None
+        for n, gr in zip(self._names, grads):
+            o, k, _ = flat.slices[n]
+            if gr is None:
+                cur = None
+                continue
+            views[n].copy_(gr)
+            end = o + -(-k // 4) * 4
+            if cur is not None and cur[1] == o:
+                cur[1] = end
+            else:
+                cur = [o, end]
+                runs.append(cur)
+        flat.adam_step(g["lr"], g["betas"][0], g["betas"][1], g["eps"], stream=st, ranges=[(a, min(b, flat.total)) for a, b in runs])
         return loss
+
+    def _aliased_flat_gradient(self, flat: FlatParams, grads):
+        """Address of a buffer that holds every gradient at its flat-layout offset (fp32, contiguous), or None."""
+        base = None
+        for n, gr in zip(self._names, grads):
+            o, k, _ = flat.slices[n]
+            if gr.dtype != torch.float32 or gr.device != flat.device or not gr.is_contiguous():
+                return None
+            b = gr.data_ptr() - 4 * o
+            if base is None:
+                base = b
+            elif b != base:
+                return None
+        if base is None or base % 16:
+            return None
+        # the padding elements between tensors must be readable: the views come from one allocation of flat.total floats
+        s0 = grads[0].untyped_storage()
+        lo, hi = s0.data_ptr(), s0.data_ptr() + s0.nbytes()
+        return base if (lo <= base and base + 4 * flat.total <= hi) else None

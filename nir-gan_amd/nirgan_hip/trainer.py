@@ -54,6 +54,8 @@ class _Micro:
         d.criterion, d.log_all = tr.rs_criterion, 0
         d.extra, d.extra_cs, d.extra_c, d.extra_scale = self.D1.gpred.data_ptr(), 1, 0, 1.0
         d.sums, d.grad_pred = tr.losses.data_ptr() + 3 * 4, self.G.dpred.data_ptr()
+        self.pix_ws = torch.zeros(L.PIX_LOSS_WS_ELEMS, dtype=torch.float32, device=dev)      # this micro-batch's own (streams run concurrently)
+        d.ws, d.ws_elems = self.pix_ws.data_ptr(), self.pix_ws.numel()
         self.pix = d
         # optional SSIM term (model/pix2pix.py:233-237; lambda_ssim is 0.0 in the shipped configs): runs after the pixel losses and
         # ADDS its gradient to dpred, its weighted value to losses[10]
@@ -144,6 +146,7 @@ class Pix2PixTrainer:
         self.lr_d, self.lr_g = None, None   # per-network overrides (ReduceLROnPlateau steps them separately); None = self.lr
         self.lambda_gan, self.lambda_l1, self.lambda_rs = float(lambda_gan), float(lambda_l1), float(lambda_rs)
         self.lambda_ssim = float(lambda_ssim)
+        self.real_label, self.fake_label = 1.0, 0.0      # GANLoss's target_real_label / target_fake_label buffers (networks.py:229-230)
         self.rs_weights = rs_weights or {}
         if rs_criterion not in ("l1", "l2"):
             raise NotImplementedError(f"Criterion '{rs_criterion}' not implemented. 'l1' or 'l2' are supported.")
@@ -207,15 +210,15 @@ class Pix2PixTrainer:
         pred = m.G.forward(m.rgb, embeds, version=self.flatG.values_version())              # generator forward (once)
         m.D2.forward(parts=[(m.rgb, 0, 0), (pred, 0, 3), (m.rgb, B, 0), (m.nir, B, 3)], version=self.flatD.values_version())
         out, dout = m.D2.out.data_ptr(), m.D2.dout.data_ptr()
-        L.check(be.nirgan_lsgan(out, npatch, 0.0, m.scale, lp, dout, st), "lsgan")
-        L.check(be.nirgan_lsgan(out + npatch * 4, npatch, 1.0, m.scale, lp + 4, dout + npatch * 4, st), "lsgan")
+        L.check(be.nirgan_lsgan(out, npatch, self.fake_label, m.scale, lp, dout, st), "lsgan")
+        L.check(be.nirgan_lsgan(out + npatch * 4, npatch, self.real_label, m.scale, lp + 4, dout + npatch * 4, st), "lsgan")
         m.D2.backward(None, frozen=False, version=self.flatD.values_version())
 
     def _g_pass(self, m: _Micro):
         be, st = L.backend(), m.G.ctx.stream()
         lp = self.losses.data_ptr()
         m.D1.forward(parts=[(m.rgb, 0, 0), (m.G.pred, 0, 3)], version=self.flatD.values_version())
-        L.check(be.nirgan_lsgan(m.D1.out.data_ptr(), m.n_patch, 1.0, self.lambda_gan * m.scale, lp + 8, m.D1.dout.data_ptr(), st), "lsgan")
+        L.check(be.nirgan_lsgan(m.D1.out.data_ptr(), m.n_patch, self.real_label, self.lambda_gan * m.scale, lp + 8, m.D1.dout.data_ptr(), st), "lsgan")
         m.D1.backward(None, frozen=True, version=self.flatD.values_version(), pred_only=True)
         L.check(be.nirgan_pix_loss(C.byref(m.pix), st), "pix_loss")
         if m.ssim is not None:

@@ -468,7 +468,7 @@ def f7(name, L=10):
                 y = y * torch.ones_like(phi)
             Y.append(y)
     Y = torch.stack(Y, dim=-1)
-    mine = O.spherical_harmonics(lonlat, L, "analytic")
+    mine = O.spherical_harmonics(lonlat, L, "analytic-generator-text")
     close(mine, Y, 1e-12, f"analytic spherical harmonics L={L}")
     cf = O.spherical_harmonics(lonlat, L, "closed-form")
     print("analytic vs closed-form: max diff", float((Y - cf).abs().max()), "of", float(Y.abs().max()))

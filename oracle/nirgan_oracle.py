@@ -347,7 +347,11 @@ def rs_weighted_loss(rgb, nir, pred, loss_config: Optional[dict] = None, criteri
         w = cfg.get("lambda_" + name, 0.0)
         if w > 0.0:
             a, b = idx[name]
-            total = total + w * crit(a, b)
+            if _KINKS is not None and criterion == "l1":          # |a - b| is a kink too (record / force it like the ReLUs)
+                d = a - b
+                total = total + w * (d * (2 * _branch(d).to(d.dtype) - 1)).mean()
+            else:
+                total = total + w * crit(a, b)
     return total
 
 
@@ -398,8 +402,10 @@ def calculate_metrics(pred: torch.Tensor, target: torch.Tensor, phase: str = "tr
 #     spherical_harmonics_closed_form.py:8-40 -- PINNED: oracle/make_golden.py imports that file and commits
 #     tests/golden/f6_locenc.npz.  The 'analytic' variant (spherical_harmonics_ylm.py, the default and what the published
 #     checkpoints record) is missing from the reference tree, but its generator spherical_harmonics_generate_ylms.py is there:
-#     it differs from closed-form by (-1)^m for m != 0 and by a factor pi for m == 0 (sh_factor) -- PINNED:
-#     make_golden.py::f7 evaluates the generator's calc_ylm (sympy) as the generated file would and commits f7_sh_analytic.npz.
+#     as its text reads it differs from closed-form by (-1)^m for m != 0 and by a factor pi for m == 0 (sh_factor,
+#     'analytic-generator-text') -- PINNED: make_golden.py::f7 evaluates the generator's calc_ylm (sympy) and commits
+#     f7_sh_analytic.npz.  The factor pi is an operator-precedence slip of that text which the published table does not show
+#     (its Yl0_m0 is 0.28209...): the default 'analytic' keeps the orthonormal constant for m == 0 (pinned by f6 there, by f7 elsewhere).
 #   siren_forward: location_encoder.py:73-151 restated from the text -- the module is NOT importable
 #     (model/satclip/__init__.py pulls pytorch_lightning; positional_encoding/__init__.py needs the missing ylm file):
 #     parity UNPINNED for the MLP part; it is three F.linear + sin calls.
@@ -425,18 +431,23 @@ def _assoc_legendre(l: int, m: int, x: torch.Tensor) -> torch.Tensor:
 
 
 def sh_factor(l: int, m: int, calculation: str = "closed-form") -> float:
-    """Constant in front of P_l^|m|(cos theta) * {1, cos(m phi), sin(|m| phi)}; P carries the Condon-Shortley phase in both variants.
+    """Constant in front of P_l^|m|(cos theta) * {1, cos(m phi), sin(|m| phi)}; P carries the Condon-Shortley phase in every variant.
 
     'closed-form' (spherical_harmonics_closed_form.py:25-40): sqrt2 (m != 0) * sqrt((2l+1)(l-|m|)! / (4 pi (l+|m|)!)).
-    'analytic' (spherical_harmonics_generate_ylms.py:19-36, the generator of the missing spherical_harmonics_ylm.py): the same
-    normalisation times (-1)**m for m != 0 (sympy's assoc_legendre already holds the phase, the script multiplies it in again),
-    and for m == 0 the script's ``sqrt((2*l + 1) / 4 * pi)`` = sqrt((2l+1) pi / 4) (operator precedence: pi is multiplied)."""
+    'analytic-generator-text' (spherical_harmonics_generate_ylms.py:19-36, the generator of the missing spherical_harmonics_ylm.py,
+    exactly as its text reads): the same normalisation times (-1)**m for m != 0 (sympy's assoc_legendre already holds the phase, the
+    script multiplies it in again), and for m == 0 the script's ``sqrt((2*l + 1) / 4 * pi)`` = sqrt((2l+1) pi / 4) (operator
+    precedence: pi is multiplied).  PINNED for every feature by fixture f7.
+    'analytic' (the build's default for published checkpoints): the generator's sign on m != 0, the ORTHONORMAL constant on m == 0
+    (the published table's first entry is 0.28209... = sqrt(1/(4 pi)), not 0.886...) -- pinned by f7 on m != 0 and by f6 on m == 0."""
     am = abs(m)
     k = math.sqrt((2.0 * l + 1.0) * math.factorial(l - am) / (4 * math.pi * math.factorial(l + am)))
     if calculation == "closed-form":
         return k if m == 0 else math.sqrt(2.0) * k
-    if calculation == "analytic":
-        return math.sqrt((2 * l + 1) / 4 * math.pi) if m == 0 else (-1.0) ** am * math.sqrt(2.0) * k
+    if calculation in ("analytic", "analytic-generator-text"):
+        if m != 0:
+            return (-1.0) ** am * math.sqrt(2.0) * k
+        return k if calculation == "analytic" else math.sqrt((2 * l + 1) / 4 * math.pi)
     raise NotImplementedError(calculation)
 
 

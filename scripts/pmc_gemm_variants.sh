@@ -5,7 +5,7 @@
 # its own fragments (2x the L1 traffic of the shared LDS image) and the vector-memory issue, not the barrier, is what starves the pipe; removed.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT/gpurun_out/pmc_variants; rm -rf $R; mkdir -p $R
+R=${GRAFT_REPO_ROOT:?run through gpurun}/gpurun_out/pmc_variants; rm -rf "$R"; mkdir -p "$R"
 for s in gemm16 gemm32; do
   script=bench_wino6_gemm.py
   [ $s = gemm32 ] && export NIRGAN_WINO6_GEMM32=1

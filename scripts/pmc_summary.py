@@ -44,6 +44,18 @@ for name, cs in acc.items():
         act = cs["GRBM_GUI_ACTIVE"][0] / cs["GRBM_GUI_ACTIVE"][1]
         e["mfma_busy_fraction_of_active_cycles"] = busy / (1024.0 * act / 8.0)
     out[short] = e
+# whole run: every kernel of the command (5 steps of the train step: 1 warm-up + 3 timed + the loss read-out, plus the one-off engine build)
+tb = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"][0] for cs in acc.values() if "SQ_VALU_MFMA_BUSY_CYCLES" in cs)
+ta = sum(cs["GRBM_GUI_ACTIVE"][0] for cs in acc.values() if "GRBM_GUI_ACTIVE" in cs)
+rd = sum(2.0 * 1024.0 * cs["FETCH_SIZE"][0] for cs in acc.values() if "FETCH_SIZE" in cs)
+wr = sum(1024.0 * cs["WRITE_SIZE"][0] for cs in acc.values() if "WRITE_SIZE" in cs)
+STEPS = int(os.environ.get("PMC_STEPS", "5"))
+out["_whole_run"] = {"steps": STEPS,
+                     "mfma_busy_fraction_of_active_cycles": (tb / (1024.0 * ta / 8.0)) if ta else None,
+                     # v_mfma_f32_32x32x2_f32: 64 busy cycles per instruction per SIMD, 4096 FLOP each = 64 FLOP per busy cycle
+                     "executed_mfma_gflop_per_step_fp32": tb * 64.0 / 1e9 / STEPS,
+                     "hbm_read_gb_per_step": rd / 1e9 / STEPS, "hbm_write_gb_per_step": wr / 1e9 / STEPS,
+                     "note": "sums over every kernel of the command; FETCH_SIZE x2-corrected (MI355X_MICROARCH.md); per step = / steps"}
 out["_meta"] = {"kernel_src_sha16": kernel_source_sha16(), "command": "python3 bench.py --no-cpu-baseline --no-probe --steps 3 --warmup 1",
                 "passes": [os.path.basename(d.rstrip("/")) for d in sys.argv[1:]],
                 "recorded_by": "scripts/refresh_profiles.sh (rocprofv3 --pmc, one counter group per pass)"}

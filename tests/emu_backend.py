@@ -618,6 +618,12 @@ class EmuBackend:
         arr(d.M, nplanes * T * d.K)[:] = np.einsum("ftc,fkc->ftk", V, U).reshape(-1).astype(np.float32)
         return 0
 
+    def nirgan_wino6_gemm_kernel_name(self, ref):
+        return b"emulated_wino6_gemm"
+
+    def nirgan_wino6_pair_kernel_name(self, cref, wref):
+        return b"emulated_wino6_pair"
+
     def nirgan_wino6_gemm_wgrad_pair(self, cref, wref, stream=None):
         rc = self.nirgan_wino6_gemm(cref)
         return rc if rc else self.nirgan_wgrad_igemm(wref)

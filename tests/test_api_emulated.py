@@ -40,3 +40,11 @@ def test_fit_loop_schedulers_checkpoint_resume(emu, tmp_path):
 
 def test_tiled_inference_and_checkpoint_loading(emu, golden_dir, tmp_path):
     A.tiled_inference_and_checkpoint_loading(DEV, golden_dir, tmp_path, A.CPU_TOL)
+
+
+def test_lightning_toggled_sequence_reuses_the_forward(emu, golden_dir):
+    A.lightning_toggled_sequence_reuses_the_forward(DEV, golden_dir, A.CPU_TOL)
+
+
+def test_ganloss_labels_and_adam_without_gradients(emu, golden_dir):
+    A.ganloss_labels_and_adam_without_gradients(DEV, golden_dir, A.CPU_TOL)

@@ -39,3 +39,22 @@ def test_bench_refuses_a_world_size_that_is_not_the_request():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL,
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_mixed_resolution_with_four_ranks_on_different_buckets():
+    """BASELINE.json configs[4]'s launch shape on the CPU: four gloo ranks, every rank-step draws one resolution bucket and the
+    ranks START on different buckets (rank r on bucket r mod 3), so one step all-reduces gradients that come from different tile
+    sizes (the parameters do not depend on the tile size).  --size 64 scales the 128/256/512 buckets to 32/64/128."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--mixed", "--emulate-cpu", "--ngf", "8",
+                        "--size", "64", "--bs", "4", "--steps", "3", "--warmup", "3", "--blocks", "6", "--lambda-rs", "1"],
+                       capture_output=True, text=True, env=_env(), timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["parallelism"] == "dp4" and out["config"]["global_batch"] == 16
+    assert len(out["ms_per_step_by_rank"]) == 4 and out["value"] > 0 and out["collective_backend"] == "gloo"
+    b = out["buckets_rank0"]
+    assert [(x["tiles"], x["size"]) for x in b] == [(16, 32), (4, 64), (1, 128)]
+    assert [x["steps"] for x in b] == [1, 1, 1], b          # three timed steps: rank 0 visited every bucket once
+    assert "configs[4]" in out["config"]["workload"]

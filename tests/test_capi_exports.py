@@ -46,15 +46,15 @@ def test_struct_layouts_match_the_header(tmp_path):
     """ctypes mirrors have exactly the C layout: sizeof and the offset of the last field, computed by gcc."""
     import ctypes as C
     import subprocess
-    pairs = [("nirgan_conv_desc", L.ConvDesc, "fuse_chunks"), ("nirgan_wgrad_desc", L.WgradDesc, "pq_bf16"),
+    pairs = [("nirgan_conv_desc", L.ConvDesc, "fuse_chunks"), ("nirgan_wgrad_desc", L.WgradDesc, "algo"),
              ("nirgan_in_fwd_desc", L.InFwdDesc, "stats_shift"), ("nirgan_in_bwd_desc", L.InBwdDesc, "sums_chunks"),
              ("nirgan_tap_gather_desc", L.TapGatherDesc, "dst"), ("nirgan_tap_scatter_desc", L.TapScatterDesc, "dbias"),
-             ("nirgan_pix_loss_desc", L.PixLossDesc, "grad_pred"), ("nirgan_inject_fwd_desc", L.InjectFwdDesc, "o_pad"),
-             ("nirgan_inject_bwd_desc", L.InjectBwdDesc, "dscale"), ("nirgan_plan_entry", L.PlanEntry, "desc"),
+             ("nirgan_pix_loss_desc", L.PixLossDesc, "ws_elems"), ("nirgan_inject_fwd_desc", L.InjectFwdDesc, "o_pad"),
+             ("nirgan_inject_bwd_desc", L.InjectBwdDesc, "ws_elems"), ("nirgan_plan_entry", L.PlanEntry, "desc"),
              ("nirgan_metrics_desc", L.MetricsDesc, "means"), ("nirgan_locenc_desc", L.LocEncDesc, "features"),
              ("nirgan_hist_match_desc", L.HistMatchDesc, "out"), ("nirgan_ssim_loss_desc", L.SsimLossDesc, "grad_pred"), ("nirgan_emd_loss_desc", L.EmdLossDesc, "grad_pred"),
              ("nirgan_wino_desc", L.WinoDesc, "split_ws_elems"),
-             ("nirgan_wino_dy_desc", L.WinoDyDesc, "r"), ("nirgan_wino6_desc", L.Wino6Desc, "fuse_slope")]
+             ("nirgan_wino_dy_desc", L.WinoDyDesc, "r"), ("nirgan_wino6_desc", L.Wino6Desc, "algo")]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "nirgan_hip.h"\nint main(void){\n'
     for cname, _, last in pairs:
         src += f'printf("%zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));\n'

@@ -31,3 +31,11 @@ def test_fit_loop_schedulers_checkpoint_resume(tmp_path):
 
 def test_tiled_inference_and_checkpoint_loading(golden_dir, tmp_path):
     A.tiled_inference_and_checkpoint_loading(DEV, golden_dir, tmp_path, A.GPU_TOL)
+
+
+def test_lightning_toggled_sequence_reuses_the_forward(golden_dir):
+    A.lightning_toggled_sequence_reuses_the_forward(DEV, golden_dir, A.GPU_TOL)
+
+
+def test_ganloss_labels_and_adam_without_gradients(golden_dir):
+    A.ganloss_labels_and_adam_without_gradients(DEV, golden_dir, A.GPU_TOL)

@@ -433,10 +433,16 @@ def test_location_encoder_kernel(golden_dir, tmp_path):
     for L_ in (10, 16):
         got = SphericalHarmonics(L_, "closed-form").to(DEV)(lonlat).cpu()
         assert (got - torch.from_numpy(z[f"Y{L_}"])).abs().max().item() < 1e-12
-    # the default 'analytic' variant against the reference's generator script evaluated with sympy (fixture f7)
+    # the generator script as its text reads, evaluated with sympy (fixture f7); the default 'analytic' = its signs with the
+    # orthonormal zonal constant (f7 on m != 0, f6 on m == 0)
     z7 = np.load(os.path.join(golden_dir, "f7_sh_analytic.npz"))
-    got = SphericalHarmonics(10).to(DEV)(lonlat).cpu()
+    got = SphericalHarmonics(10, "analytic-generator-text").to(DEV)(lonlat).cpu()
     assert (got - torch.from_numpy(z7["Y10"])).abs().max().item() < 1e-12
+    got = SphericalHarmonics(10).to(DEV)(lonlat).cpu()
+    zonal = [l * l + l for l in range(10)]
+    want = torch.from_numpy(z7["Y10"]).clone()
+    want[:, zonal] = torch.from_numpy(z["Y10"])[:, zonal]
+    assert (got - want).abs().max().item() < 1e-12
     torch.manual_seed(4)
     enc = LocationEncoder(get_positional_encoding("sphericalharmonics", 10, "analytic"), get_neural_network("siren", 100, 256, 512, 2)).double().eval().to(DEV)
     g = torch.Generator().manual_seed(9)
@@ -937,8 +943,8 @@ def test_wino6_conv3x3_matches_direct(shape):
 
 @pytest.mark.parametrize("hw", [(12, 16, 3, 3), (9, 11, 3, 3), (64, 64, 3, 3), (12, 16, 4, 4), (9, 11, 4, 4), (31, 31, 4, 4), (12, 16, 3, 6), (9, 11, 3, 6),
                                 (64, 64, 3, 6), (13, 6, 3, 6), (64, 64, 3, 6, 256), (21, 17, 3, 6, 256), (22, 18, 3, 3, 256), (40, 40, 3, 6, 256, 384),
-                                (64, 64, 3, 6, 256, 256, "NIRGAN_WINO6_WGRAD_NOPERSIST"), (64, 64, 3, 6, 256, 256, "NIRGAN_WINO6_GEMM_NOPERSIST"),
-                                (64, 64, 3, 6, 256, 256, "NIRGAN_NO_WINO6_PAIR"), (64, 64, 3, 6, 256, 256, "NIRGAN_WGRAD_NOPERSIST")])
+                                (64, 64, 3, 6, 256, 256, "wgrad_one_unit"), (64, 64, 3, 6, 256, 256, "gemm_one_tile"),
+                                (64, 64, 3, 6, 256, 256, "no_pair"), (64, 64, 3, 6, 256, 256, "no_pair_wgrad_one_unit")])
 def test_wino6_backward_matches_autograd(hw, monkeypatch):
     """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it with F(4x4,3x3): data gradient over the padded
     extent (dY transformed once for both uses), transform-domain weight gradient (36 planes in one weight-gradient launch, then
@@ -946,10 +952,14 @@ def test_wino6_backward_matches_autograd(hw, monkeypatch):
     forward input here (the nets keep the forward's V: covered by the net-level tests)."""
     from nirgan_hip.engine import emit_wino6, emit_wino6_backward, SlabPool, _FullExtent
     H, W, r, v = hw[:4]                               # H x W = the layer's OUTPUT extent; its input is (H + r - 3) x (W + r - 3) + halo 1
-    if len(hw) > 6:
-        monkeypatch.setenv(hw[6], "1")                # the A/B fallbacks of the persistent pair launch (csrc/wino6.hip reads them per launch)
-        if hw[6] == "NIRGAN_WGRAD_NOPERSIST":         # two separate launches, the weight gradient one tile per workgroup
-            monkeypatch.setenv("NIRGAN_NO_WINO6_PAIR", "1")
+    if len(hw) > 6:                                   # the A/B fallbacks of the persistent pair launch (descriptor field `algo`, set when the plan is built)
+        from nirgan_hip.options import OPT
+        if "wgrad_one_unit" in hw[6]:
+            monkeypatch.setattr(OPT, "wgrad_algo", L.WGRAD_ONE_UNIT)
+        if hw[6] == "gemm_one_tile":
+            monkeypatch.setattr(OPT, "w6_gemm_algo", L.W6_ONE_TILE)
+        if "no_pair" in hw[6]:                        # two separate launches
+            monkeypatch.setattr(OPT, "w6_pair", False)
     if v == 3:
         monkeypatch.setenv("NIRGAN_NO_WINO8", "1")    # 3x3 filters: F(4x4,3x3) instead of the default F(6x6,3x3)
     from nirgan_hip.engine import wino6_variant
@@ -1276,8 +1286,9 @@ def test_conv_epilogue_takes_the_instance_norm_backward_first_pass(case):
 
 
 def test_wino6_plane_gemm_stage_depths_agree(monkeypatch):
-    """The persistent plane GEMM on 32-k stages (default) and on 16-k stages (NIRGAN_WINO6_GEMM16P=1): the same products in the same
-    k order -- equal to fp32 rounding on the benchmark's residual-block shape and on a ragged one."""
+    """The plane GEMM kernels a descriptor can select (nirgan_wino6_desc.algo): persistent workgroups on 32-k stages (default) and on
+    16-k stages, one tile per workgroup, the direct convolution tile -- the same products in the same k order: equal to fp32 rounding
+    on the benchmark's residual-block shape and on a ragged one; the name query reports the kernel each one launches."""
     import ctypes as C
     for (B, H, W, Cc, K) in ((16, 64, 64, 256, 256), (3, 21, 17, 256, 192)):
         g = torch.Generator().manual_seed(9)
@@ -1286,22 +1297,22 @@ def test_wino6_plane_gemm_stage_depths_agree(monkeypatch):
         U = (torch.randn(64 * K * Cc, generator=g) * 0.05).to(DEV)
         zero = torch.zeros(64, device=DEV)
         outs = []
-        for env in (None, "1"):
-            if env:
-                monkeypatch.setenv("NIRGAN_WINO6_GEMM16P", env)
-            else:
-                monkeypatch.delenv("NIRGAN_WINO6_GEMM16P", raising=False)
+        names = []
+        for algo in (0, L.W6_PERSIST16, L.W6_ONE_TILE, L.W6_DIRECT_TILE):
             M = torch.full((64 * T * K,), float("nan"), device=DEV)
             d = L.Wino6Desc()
             d.r, d.B, d.H, d.W, d.C, d.K = 6, B, H, W, Cc, K
             d.U, d.V, d.V_elems, d.M, d.M_elems, d.zero_page = U.data_ptr(), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), zero.data_ptr()
+            d.algo = algo
+            names.append(L.backend().nirgan_wino6_gemm_kernel_name(C.byref(d)).decode())
             L.call("nirgan_wino6_gemm", C.byref(d), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             outs.append(M.clone())
-        monkeypatch.delenv("NIRGAN_WINO6_GEMM16P", raising=False)
+        assert names == ["wino6_gemm32p_kernel", "wino6_gemm16p_kernel", "wino6_gemm16_kernel", "wino6_gemm_kernel"], names
         ref = torch.bmm(V.view(64, T, Cc).double(), U.view(64, K, Cc).double().transpose(1, 2)).float().reshape(-1)
         close(outs[0], ref, 2e-5, "32-k stages vs fp64")
-        close(outs[1], outs[0], 2e-6, "16-k vs 32-k stages")
+        for o, n in zip(outs[1:], names[1:]):
+            close(o, outs[0], 2e-6, n + " vs 32-k persistent")
 
 
 @pytest.mark.parametrize("case", [(6, 3, 2, 256, 256), (4, 2, 1, 128, 64), (3, 16, 2, 32, 32)])

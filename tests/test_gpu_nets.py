@@ -304,7 +304,7 @@ def generator_kinks(G):
     return g + [nchw(G.U1.out), nchw(G.U2.out)]
 
 
-def device_kinks(tr, nir):
+def device_kinks(tr, nir, rgb=None):
     """Branch decisions (ReLU / LeakyReLU masks, sign of pred - nir) of the fused step the trainer just ran, in the call order of
     oracle.OracleTrainer.step: G forward, D(fake), D(real), G forward again, D(fake) against the updated D, L1."""
     G, D2, D1 = tr.G, tr.D2, tr.D1
@@ -312,7 +312,11 @@ def device_kinks(tr, nir):
     g = generator_kinks(G)
     d2 = [nchw(c.out) for c in (D2.C1, D2.C2, D2.C3, D2.C4)]
     d1 = [nchw(c.out) for c in (D1.C1, D1.C2, D1.C3, D1.C4)]
-    return g + [m[:B] for m in d2] + [m[B:] for m in d2] + g + d1 + [(tr.G.pred.cpu() - nir) > 0]
+    masks = g + [m[:B] for m in d2] + [m[B:] for m in d2] + g + d1 + [(tr.G.pred.cpu() - nir) > 0]
+    if tr.lambda_rs > 0.0 and rgb is not None:       # criterion l1 on the weighted spectral indices: sign of idx(nir) - idx(pred), dict order
+        idx = O.rs_index_pairs(rgb, nir, tr.G.pred.cpu(), "loss")
+        masks += [(idx[k][0] - idx[k][1]) > 0 for k in O.RS_ORDER if tr.rs_weights.get("lambda_" + k, 0.0) > 0.0]
+    return masks
 
 
 def test_fullsize_fused_step_against_oracle():
@@ -327,22 +331,29 @@ def test_fullsize_fused_step_against_oracle():
     _fused_step_against_oracle(1, 256, 256, 6, 1234)
 
 
-def _fused_step_against_oracle(B, H, W, nb, seed):
+RS_W3 = {"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333, "lambda_savi": 0.0, "lambda_msavi": 0.0, "lambda_gndvi": 0.0}
+
+
+def _fused_step_against_oracle(B, H, W, nb, seed, lambda_rs=0.0, out_bias=None):
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
     torch.manual_seed(0)
     netG = networks.define_G(3, 1, 64, f"resnet_{nb}blocks", "instance", False, "normal", 0.02)
     torch.manual_seed(0)
     netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
+    if out_bias is not None:          # as oracle/make_golden.py::f1: pred in (0.5, 1) keeps the index denominators pred + band away from 0
+        with torch.no_grad():
+            list(netG.parameters())[-1].fill_(out_bias)
     pG, pD = {k: v.clone() for k, v in netG.state_dict().items()}, {k: v.clone() for k, v in netD.state_dict().items()}
     rgb, nir = synth(B, H, W, seed)
-    tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=nb)
+    kw = dict(lambda_rs=lambda_rs, rs_weights=RS_W3) if lambda_rs > 0.0 else {}
+    tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=nb, **kw)
     out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
-    kinks = device_kinks(tr, nir)
+    kinks = device_kinks(tr, nir, rgb)
     p64G, p64D = {k: v.double() for k, v in pG.items()}, {k: v.double() for k, v in pD.items()}
     # (1) the device's decisions against the fp64 evaluation's own: only elements at the kink may differ
     with O.record_kinks() as own:
-        free = O.OracleTrainer(p64G, p64D, nb)
+        free = O.OracleTrainer(p64G, p64D, nb, **kw)
         free.step(rgb.double(), nir.double())
     assert len(own) == len(kinks)
     flips = sum(int((a != b).sum()) for a, b in zip(own, kinks))
@@ -350,10 +361,10 @@ def _fused_step_against_oracle(B, H, W, nb, seed):
     assert flips <= 1e-4 * total, (flips, total)
     # (2) same branches, smooth comparison
     with O.forced_kinks(kinks):
-        ref = O.OracleTrainer(p64G, p64D, nb)
+        ref = O.OracleTrainer(p64G, p64D, nb, **kw)
         o = ref.step(rgb.double(), nir.double())
     close(tr.G.pred, ref.last["pred"], 1e-3, "pred")
-    for k in ("loss_D", "loss_G", "loss_G_gan", "loss_G_l1"):
+    for k in ("loss_D", "loss_G", "loss_G_gan", "loss_G_l1") + (("loss_G_rs",) if lambda_rs > 0.0 else ()):
         close(out[k], o[k], 1e-3, k)
     gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
     worst = 0.0
@@ -366,6 +377,69 @@ def _fused_step_against_oracle(B, H, W, nb, seed):
                 worst = max(worst, ((gdev[k].double().cpu() - v).norm() / v.norm()).item())
                 grad_close64(gdev[k], v, f"{name} {k}", l2=3e-4, mx=3e-3)
     print(f"fused step {B}x{H}x{W}, kinks forced: worst rel-L2 over all gradient tensors {worst:.2e}; {flips} of {total} branch decisions differ from fp64's own")
+
+
+def test_configs2_fullsize_fused_step_with_the_spectral_loss_against_oracle():
+    """BASELINE.json configs[2] at full width: 9-block generator (configs/config_px2px.yaml:13), ngf 64, lambda_rs_losses 1 with the
+    YAML's NDVI / NDWI / EVI weights (:31-39; utils/remote_sensing_indices.py:23-71), the output bias raised as in fixture
+    f1_g9_rs_pad (3.0 here: at ngf 64 the last layer's pre-activation has a standard deviation of ~0.7, and one pixel with pred + band ~ 0 dominates the mean of a singular index), kinks teacher-forced (the |idx(nir) - idx(pred)| of the l1 criterion included): every gradient tensor of the
+    fused step within 3e-4 of fp64.  The bs-32 shape of the config runs in test_configs2_batch32_properties."""
+    _fused_step_against_oracle(1, 256, 256, 9, 77, lambda_rs=1.0, out_bias=3.0)
+
+
+def test_configs2_batch32_properties():
+    """configs[2] as BASELINE.json states it -- bs 32, 256 x 256, 9 blocks, spectral loss: finite losses, the spectral term present,
+    per-sample independence of the prediction, two identical runs bitwise equal."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    rgb, nir = synth(32, 256, 256, 5)
+    rgb, nir = rgb.to(DEV), nir.to(DEV)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        netG = networks.define_G(3, 1, 64, "resnet_9blocks", "instance", False, "normal", 0.02).to(DEV)
+        netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+        with torch.no_grad():
+            list(netG.parameters())[-1].fill_(1.5)
+        p4 = None
+        if not runs:                                     # the same tiles as a batch of 4, before anything is updated
+            netG.eval()
+            with torch.no_grad():
+                p4 = netG(rgb[8:12].contiguous())
+            netG.train()
+        tr = Pix2PixTrainer(netG, netD, n_blocks=9, lambda_rs=1.0, rs_weights=RS_W3)
+        out = tr.step(rgb, nir).as_dict()
+        assert all(np.isfinite(v) for v in out.values()) and out["loss_G_rs"] > 0.0, out
+        if p4 is not None:
+            close(tr.pred[8:12], p4, 3e-4, "sample independence at bs 32")
+        runs.append((out, tr.pred.clone(), tr.flatG.grad.clone(), tr.flatG.flat.clone()))
+        del tr
+    (o0, p0, g0, w0), (o1, p1, g1, w1) = runs
+    assert o0 == o1 and torch.equal(p0, p1) and torch.equal(g0, g1) and torch.equal(w0, w1), "two identical bs-32 steps differ"
+
+
+def test_fused_step_is_bitwise_reproducible():
+    """bs 16, the benchmark configuration: two runs from the same weights on the same tiles give bitwise-equal losses, gradients,
+    Adam moments and parameters after two steps -- every reduction (weight-gradient slabs, instance-norm partials, loss sums, live
+    bias gradients) is summed in a fixed order, nothing accumulates with float atomics across workgroups."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    rgb, nir = synth(16, 256, 256, 3)
+    rgb, nir = rgb.to(DEV), nir.to(DEV)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
+        netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+        tr = Pix2PixTrainer(netG, netD, n_blocks=6, lambda_rs=1.0, rs_weights=RS_W3)
+        outs = [tr.step(rgb, nir).as_dict() for _ in range(2)]
+        runs.append((outs, tr.flatD.grad.clone(), tr.flatG.grad.clone(), tr.flatD.flat.clone(), tr.flatG.flat.clone(),
+                     tr.flatG.m.clone(), tr.flatG.v.clone()))
+        del tr
+    a, b = runs
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y, what in zip(a[1:], b[1:], ("grad D", "grad G", "params D", "params G", "exp_avg G", "exp_avg_sq G")):
+        assert torch.equal(x, y), f"{what}: {(x - y).abs().max().item():.3e} apart"
 
 
 @pytest.mark.parametrize("shape", [(3, 72, 104), (2, 100, 60), (1, 36, 40)])

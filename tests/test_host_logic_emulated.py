@@ -518,13 +518,20 @@ def test_satclip_location_encoder_surface(emu, golden_dir, tmp_path):
     lonlat = torch.from_numpy(z["lonlat"])
     for L_ in (10, 16):
         close(SphericalHarmonics(L_, "closed-form")(lonlat), z[f"Y{L_}"], 1e-12, f"harmonics L={L_}")
-    # 'analytic' (the default; what published checkpoints record) is NOT closed-form: (-1)^m on m != 0, a factor pi on m == 0.
-    # Fixture f7 = the reference's generator script (sympy) evaluated as the tabulated file would be
+    # Fixture f7 = the reference's generator script (sympy) evaluated as its text reads ('analytic-generator-text': (-1)^m on m != 0
+    # and -- an operator-precedence slip -- a factor pi on m == 0).  The default 'analytic' keeps the generator's signs and the
+    # ORTHONORMAL zonal constant the published table shows (Yl0_m0 = 0.28209...): pinned by f7 on m != 0, by f6 on m == 0.
     z7 = load(golden_dir, "f7_sh_analytic.npz")
     assert np.array_equal(z7["lonlat"], z["lonlat"])
+    yg = SphericalHarmonics(10, "analytic-generator-text")(lonlat)
+    close(yg, z7["Y10"], 1e-12, "generator-text harmonics L=10")
+    assert abs(float(yg[0, 0]) - 0.886226925452758) < 1e-14
     ya = SphericalHarmonics(10)(lonlat)
-    close(ya, z7["Y10"], 1e-12, "analytic harmonics L=10")
-    assert abs(float(ya[0, 0]) - 0.886226925452758) < 1e-14 and (ya - torch.from_numpy(z["Y10"])).abs().max() > 1.0
+    zonal = torch.tensor([l * l + l for l in range(10)])
+    other = torch.tensor([f for f in range(100) if f not in set(zonal.tolist())])
+    close(ya[:, other], torch.from_numpy(z7["Y10"])[:, other], 1e-12, "analytic harmonics, m != 0 (f7)")
+    close(ya[:, zonal], torch.from_numpy(z["Y10"])[:, zonal], 1e-12, "analytic harmonics, m == 0 (f6)")
+    assert abs(float(ya[0, 0]) - 0.28209479177387814) < 1e-14 and (ya - torch.from_numpy(z["Y10"])).abs().max() > 0.5
     with pytest.raises(NotImplementedError):
         SphericalHarmonics(10, "discretized")
     net = get_neural_network("siren", 100, 32, 64, 2)
