@@ -601,7 +601,7 @@ def main():
                 if r["kernel"].startswith("wino6"):
                     r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd plane GEMMs (and, in the pair launch, the transform-domain weight-gradient "
                                           "planes) perform 64/324 of the direct layer's multiplies for the F(6x6,3x3) residual-block layers (36/144 with "
-                                          "NIRGAN_NO_WINO8=1) and 49/256 for the PatchGAN's F(4x4,4x4) layer; rows of a plane's last, partly filled M tile "
+                                          "NIRGAN_OPTIONS=winograd=f4) and 49/256 for the PatchGAN's F(4x4,4x4) layer; rows of a plane's last, partly filled M tile "
                                           "(T = 1936 = 15.1 tiles of 128) are executed but not counted")
                 elif r["kernel"].startswith("wino"):
                     r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd F(2x2,3x3) part performs 16/36 of the direct layer's "

@@ -447,66 +447,13 @@ typedef struct {
 int64_t nirgan_hist_match_ws_bytes(int B, int N);
 int nirgan_hist_match(const nirgan_hist_match_desc* d, void* stream);
 
-/* -------------------------------------------------------------------------------------
- * Winograd F(2x2, 3x3) forward of nn.Conv2d(C, K, 3, stride 1) over a halo'd input (halo 1: zero padding or the
- * reflect halo the producer wrote) -- model/networks.py:405-427 (the two 3x3 convolutions of a ResnetBlock).  Exact fp32
- * products, 2.25x fewer than the direct contraction; the result differs from it by fp32 rounding only (transform constants
- * 0, +-1/2, +-1).  U = nirgan_wino_weights(W) is [16][K][C] (W in the reference layout [K][C][3][3]); V is a workspace of
- * 16*B*ceil(H/2)*ceil(W/2)*C floats; y is dense [B][H][W][K].  C % 32 == 0, K % 128 == 0; odd H / W cost one half-used tile row / column.
- * ------------------------------------------------------------------------------------- */
-typedef struct {
-    const float* x; int x_hp, x_wp;       /* [B][H+2][W+2][C] */
-    int B, H, W, C, K;
-    const float* U; const float* bias;
-    float* V; int64_t V_elems;
-    float* y;
-    const float* zero_page;
-    int r;                                /* filter size: 0 or 3 = F(2x2,3x3) above; 4 = F(2x2,4x4): nn.Conv2d(C, K, 4, stride 1) of the PatchGAN
-                                             (model/networks.py:573-579), x is [B][H+3][W+3][C] for H x W outputs, 25 frequencies, U / V hold 25 planes */
-    int fsplit;                           /* nirgan_wino_gemm only, 0 / 1 = off: the frequencies are divided over fsplit workgroups per tile (few tiles:
-                                             the 16-image PatchGAN passes fill a quarter of the chip otherwise); partial outputs go to split_ws
-                                             ([fsplit][B*H*W*K] floats) and one pass adds them (+ bias) into y */
-    float* split_ws; int64_t split_ws_elems;
-} nirgan_wino_desc;
-
-int64_t nirgan_wino_ws_elems(int B, int H, int W, int C, int K);   /* V elements + U elements */
-int64_t nirgan_wino_ws_elems_r(int B, int H, int W, int C, int K, int r);
-/* transpose_flip = 0: U for the forward filter, w = [K][C][3][3].  1: U for the DATA GRADIENT, whose filter is
- * g'[k][c][i][j] = w[c][k][2-i][2-j] with w = [C][K][3][3] the forward weight (C = forward Cout, K = forward Cin): the
- * full correlation over dY with a zero halo of 2 is then nirgan_wino_conv3x3 with x = dY, H x W = the padded input size. */
-int nirgan_wino_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);
-/* the same for an r x r filter (r = 3 or 4; w = [K][C][r][r], U = [(r+1)^2][K][C]) */
-int nirgan_wino_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream);
-/* all weight transforms of a step in ONE launch: jobs_device = njobs x 8 int64 {w, U, K, C, r, transpose_flip, first_block, 0} in device
- * memory, first_block = running sum of ceil(K*C/256) over the preceding jobs, total_blocks = the sum over all jobs */
-int nirgan_wino_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
-int nirgan_wino_input(const nirgan_wino_desc* d, void* stream);     /* V = B^T d B from x */
-/* the same V straight from a convolution's raw output y (dense [B][H][W][C], d->x unused): x = act((y - mean) * rstd) under a REFLECT
- * halo of 1 (InstanceNorm + ReLU + ReflectionPad2d(1) between the two convolutions of a ResnetBlock, model/networks.py:405-421),
- * evaluated on the fly: nirgan_instnorm_fwd with out = NULL (statistics only) then this call replace the apply pass + the transform */
-int nirgan_wino_input_norm(const nirgan_wino_desc* d, const float* y, const float* mean, const float* rstd, int act, float slope, void* stream);
-int nirgan_wino_gemm(const nirgan_wino_desc* d, void* stream);      /* y from V and U (frequency-folding GEMM + bias) */
-int nirgan_wino_conv3x3(const nirgan_wino_desc* d, void* stream);   /* both */
-/* the GEMM stage of the Winograd data gradient of a layer (c: x = dY, transpose_flip weights; nirgan_wino_input(c) must have run) and its weight gradient (w) in ONE grid, like
- * nirgan_conv_wgrad_pair: the weight-gradient tiles fill the partly empty rounds of the Winograd tiles */
-int nirgan_wino_wgrad_pair(const nirgan_wino_desc* c, const nirgan_wgrad_desc* w, void* stream);
-
-/* Winograd-domain WEIGHT gradient of the same layers: dU[f][k][c] = sum_t Yt[f][t][k] * V[f][t][c] with Yt = A dY A^T
- * (nirgan_wino_dy) and V = B^T x B (nirgan_wino_input of the forward input) -- 16 weight-gradient problems of [T x K] x [T x C],
- * run as ONE nirgan_wgrad_igemm / nirgan_wino_wgrad_pair launch with nplanes = 16 -- then dW = G^T dU G
- * (nirgan_wino_wgrad_finish: sums the split slabs in order and writes / accumulates the reference layout [K][C][3][3]). */
+/* Output-gradient side of a Winograd layer's backward (used by nirgan_wino6_dy / nirgan_wino6_input_dy): Yt = A dY A^T per tile. */
 typedef struct {
     const float* dy; int dy_hp, dy_wp, dy_pad;   /* halo'd [B][H+2pad][W+2pad][K] */
     int B, H, W, K;
-    float* Yt; int64_t Yt_elems;                 /* [16][B*ceil(H/2)*ceil(W/2)][K] */
-    int r;                                       /* filter size (0 / 3, or 4: 25 planes) */
+    float* Yt; int64_t Yt_elems;                 /* [planes][tiles][K] */
+    int r;                                       /* variant code of the layer (nirgan_wino6_desc.r) */
 } nirgan_wino_dy_desc;
-int nirgan_wino_dy(const nirgan_wino_dy_desc* d, void* stream);
-/* nirgan_wino_input(c) and nirgan_wino_dy(y) of the SAME output-gradient buffer (c->x == y->dy, zero halo r-1) in one pass: the 2x2 block
- * of tile (ty, tx) is the lower-right corner of the data-gradient patch (ty, tx), so dY is read once for both transforms */
-int nirgan_wino_input_dy(const nirgan_wino_desc* c, const nirgan_wino_dy_desc* y, void* stream);
-int nirgan_wino_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
-int nirgan_wino_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream);   /* [K][C][r][r] */
 
 /* -------------------------------------------------------------------------------------
  * Winograd F(4x4, 3x3) for the same layers (nn.Conv2d(C, K, 3, stride 1) over a halo of 1, model/networks.py:405-427): 36 products
@@ -566,18 +513,18 @@ const char* nirgan_wino6_pair_kernel_name(const nirgan_wino6_desc* d, const nirg
 
 int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T of the 4x4-output variants */
 int64_t nirgan_wino6_tiles_r(int B, int H, int W, int r);          /* T of variant r (0 / 3, 4, 6); 0 for an unknown variant */
-int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);   /* as nirgan_wino_weights */
+int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);   /* transpose_flip = 0: U of the forward filter, w = [K][C][3][3]; 1: U of the DATA GRADIENT's filter g'[k][c][i][j] = w[c][k][2-i][2-j] with w = [C][K][3][3] the forward weight */
 int nirgan_wino6_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream);   /* w = [K][C][r][r], U = [(r+3)^2][K][C] */
 /* all weight transforms of a step in one launch: njobs x 8 int64 {w, U, K, C, transpose_flip, first_block, r, 0} in device memory,
  * first_block = running sum of ceil(K*C/256) */
 int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
 int nirgan_wino6_input(const nirgan_wino6_desc* d, void* stream);
 /* V straight from a convolution's raw output y (dense [B][H][W][C], d->x unused): x = act((y - mean) * rstd) under a REFLECT halo of 1,
- * evaluated on the fly (as nirgan_wino_input_norm) */
+ * evaluated on the fly: nirgan_instnorm_fwd with out = NULL (statistics only) then this call replace the apply pass + the transform */
 int nirgan_wino6_input_norm(const nirgan_wino6_desc* d, const float* y, const float* mean, const float* rstd, int act, float slope, void* stream);
 int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream);
 /* the data gradient's plane GEMMs (c: x = dY, transpose_flip weights; its V written by nirgan_wino6_input_dy) and the layer's 36
- * transform-domain weight-gradient problems (w: nplanes = 36) in ONE grid, like nirgan_wino_wgrad_pair: the long weight-gradient
+ * transform-domain weight-gradient problems (w: nplanes = 36) in ONE grid, like nirgan_conv_wgrad_pair: the long weight-gradient
  * blocks first, the GEMM blocks pack behind them.  Semantics = nirgan_wino6_gemm(c) followed by nirgan_wgrad_igemm(w). */
 int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* c, const nirgan_wgrad_desc* w, void* stream);
 int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream);
@@ -587,11 +534,6 @@ int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream);
 /* nirgan_wino6_input(c) and nirgan_wino6_dy(y) of the SAME output-gradient buffer (c->x == y->dy, zero halo 2) in one pass: the 4x4
  * block of tile (ty, tx) is the lower-right corner of data-gradient patch (ty, tx) */
 int nirgan_wino6_input_dy(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, void* stream);
-/* the same pass with dY NOT read from memory but evaluated on the fly as the instance-norm backward's result: n describes the block
- * (g / g2 / gsum_out, y, mean, rstd, act, ws as given to nirgan_instnorm_bwd with dy = NULL, which leaves the two reduction passes'
- * means in ws); every patch element is rstd * (g_z - mean(g_z) - z * mean(g_z * z)), bitwise what the second pass would have stored
- * into c->x -- that buffer is neither written nor read (c->x / y->dy only describe its geometry: zero halo 2) */
-int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, const nirgan_in_bwd_desc* n, void* stream);
 int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
 int nirgan_wino6_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream);   /* [K][C][r][r] */
 /* the same for n <= 16 layers of one geometry in ONE grid (host arrays of device pointers; every layer then keeps its own slabs until the

@@ -12,7 +12,6 @@
 //   order, so gradients are bitwise reproducible run to run.
 #include "igemm_tiles.h"
 #include <cstdlib>
-#include "wino_tile.h"
 
 namespace {
 
@@ -35,16 +34,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm16_kernel(const ng::WgradPa
     ng::wgrad_tile16(p, blockIdx.x, st0, st1);
 }
 
-// Winograd data-gradient tiles + weight-gradient tiles of the same layer in one grid (exact-fp32 mode): the 546 Winograd tiles of a
-// 66x66 padded extent are 1.07 rounds of the chip on their own; the weight-gradient tiles fill the rest
-__global__ __launch_bounds__(256, 2) void wino_wgrad_pair_kernel(const ng::WinoG g, const ng::WgradParams wp, const int wino_blocks) {
-    __shared__ __attribute__((aligned(16))) char lds[65536];
-    static_assert(ng::WINO_LDS_BYTES <= 65536, "the Winograd tile must fit the two stage buffers");
-    if (int(blockIdx.x) < wino_blocks)
-        ng::wino_tile(g, blockIdx.x, lds);
-    else
-        ng::wgrad_tile<128, 0>(wp, int(blockIdx.x) - wino_blocks, lds, lds + 32768);
-}
 
 // horizontally fused launch: the data-gradient tiles of a stride-1 convolution followed by the tiles of its
 // weight gradient (both consume the same dY).  One grid: the weight-gradient blocks fill the partly empty
@@ -203,24 +192,6 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     else if (cp.prec == 1) hipLaunchKernelGGL(conv_wgrad_pair_kernel<1>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else hipLaunchKernelGGL(conv_wgrad_pair_kernel<2>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
     return nirgan_check_launch("conv_wgrad_pair");
-}
-
-extern "C" int nirgan_wino_wgrad_pair(const nirgan_wino_desc* c, const nirgan_wgrad_desc* w, void* stream) {
-    ng::WgradParams wp;
-    int rc = ng::build_wgrad_params(w, wp);
-    if (rc != NIRGAN_OK) return rc;
-    if (w->N <= 64 || wp.prec != 0 || wp.pq_bf16) {           // not the wide fp32 tile: two ordinary launches
-        rc = nirgan_wino_gemm(c, stream);
-        return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
-    }
-    ng::WinoG g;
-    rc = ng_wino_gemm_params(c, &g);
-    if (rc != NIRGAN_OK) return rc;
-    NG_REQUIRE(g.fsplit == 1, "wino_wgrad_pair: the fused launch takes unsplit Winograd tiles (fsplit=%d)", g.fsplit);
-    const int wino_blocks = g.mtiles * g.ntiles;
-    const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit * wp.nplanes;
-    hipLaunchKernelGGL(wino_wgrad_pair_kernel, dim3(wino_blocks + wgrad_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, wp, wino_blocks);
-    return nirgan_check_launch("wino_wgrad_pair");
 }
 
 extern "C" int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,

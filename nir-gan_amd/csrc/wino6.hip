@@ -231,9 +231,6 @@ struct W6In {
                                                  // is output-gradient tile (ty, tx): Yt = A dY A^T is emitted from the same read of dY
     // normalising variant: x = act((y - mean) * rstd) of a dense [B][H][W][C] tensor under a REFLECT halo of 1, evaluated on the fly
     const float* y; const float* mean; const float* rstd; int H, W, act; float slope;
-    // dY variant that evaluates the instance-norm backward's second pass on the fly (MODE 2): x is NOT read; dY(h, w) =
-    // rstd * (g_z - mean(g_z) - z * mean(g_z z)) from the pass-1 sums (in_bwd_dy: bitwise what in_bwd_pass2_kernel would have stored)
-    InBwd nb; int nbB;
 };
 
 template <int VW> struct W6Vec;
@@ -242,7 +239,7 @@ template <> struct W6Vec<2> { typedef f32x2 T; };
 
 // One thread = one N x N patch x VW channels (4 for the 6x6 patches of F(4x4,3x3); 2 for the 7x7 / 8x8 patches of F(4x4,4x4) /
 // F(6x6,3x3): 49 / 64 float4 intermediates would not fit the register file).  MODE 0: x from the halo'd buffer; 1: forward input
-// normalised on the fly (3x3 filters); 2: output gradient from the instance-norm backward on the fly (3x3 filters).
+// normalised on the fly (3x3 filters).
 template <int V> struct W6VW { static constexpr int value = V == 3 ? 4 : 2; };
 
 template <int V, int MODE>
@@ -264,21 +261,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     for (int e = 0; e < VW; ++e) z4[e] = 0.f;
     V4 mean = z4, rstd = z4;
     const float* base;
-    V4 m1 = z4, m2 = z4;
-    const float* gb = nullptr; const float* g2b = nullptr; const float* gsb = nullptr; const float* yb = nullptr;
-    if constexpr (MODE == 2) {
-        const InBwd& n = p.nb;
-        const float* mm = n.ws + size_t(p.nbB) * n.pchunks * 2 * n.C + size_t(b) * 2 * n.C;
-        static_assert(MODE != 2 || VW == 4, "the instance-norm-backward variant works on channel quads");
-        m1 = ld4(mm + q * 4); m2 = ld4(mm + n.C + q * 4);
-        mean = ld4(n.mean + size_t(b) * n.C + q * 4);
-        rstd = ld4(n.rstd + size_t(b) * n.C + q * 4);
-        yb = n.y + size_t(b) * n.HW * n.C;
-        gsb = n.gsum_out ? n.gsum_out + size_t(b) * n.HW * n.C : nullptr;
-        gb = n.g ? n.g + size_t(b) * n.g_img : nullptr;
-        g2b = n.g2 ? n.g2 + size_t(b) * n.HW * n.C : nullptr;
-        base = nullptr;
-    } else if constexpr (NORM) {
+    if constexpr (NORM) {
         mean = *reinterpret_cast<const V4*>(p.mean + size_t(b) * p.C + q * VW);
         rstd = *reinterpret_cast<const V4*>(p.rstd + size_t(b) * p.C + q * VW);
         base = p.y + size_t(b) * p.H * p.W * p.C + q * VW;
@@ -313,13 +296,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
         } else {
             const int rb = MO * ty + a, cb = MO * tx + c;
             if (rb >= p.x_hp || cb >= p.x_wp) return z4;
-            if constexpr (MODE == 2) {
-                const int h = rb - (R - 1), w = cb - (R - 1);      // the dY buffer has a zero halo of R - 1
-                if (h < 0 || w < 0 || h >= p.nb.H || w >= p.nb.W) return z4;
-                return in_bwd_dy(p.nb, gb, g2b, gsb, yb, mean, rstd, m1, m2, h, w, q);
-            } else {
-                return *reinterpret_cast<const V4*>(base + size_t(rb) * p.x_row + size_t(cb) * p.C);
-            }
+            return *reinterpret_cast<const V4*>(base + size_t(rb) * p.x_row + size_t(cb) * p.C);
         }
     };
     V4 m[N][N];
@@ -341,7 +318,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
 #pragma unroll
         for (int c = 0; c < N; ++c) *reinterpret_cast<V4*>(Vp + (a * N + c) * plane) = o[c];
     }
-    if constexpr (MODE != 1) {
+    if constexpr (!NORM) {
         if (p.Yt != nullptr && ty < p.yTH && tx < p.yTW) {
             // output-gradient tile (ty, tx) = patch rows / columns R-1 .. R+MO-2 (just read: L1 / L2 hits); rows past the extent read the zero halo
             V4 u[N][MO];
@@ -1090,12 +1067,11 @@ extern "C" int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs,
 }
 
 static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const float* ny, const float* mean, const float* rstd,
-                         int act, float slope, void* stream, const nirgan_in_bwd_desc* nb = nullptr) {
-    NG_REQUIRE(d && d->V && (d->x || ny || nb), "wino6_input: null pointer");
+                         int act, float slope, void* stream) {
+    NG_REQUIRE(d && d->V && (d->x || ny), "wino6_input: null pointer");
     const int v = w6_r(d->r), np = w6_np(v), r = w6_filter(v), mo = w6_mo(v);
     NG_REQUIRE(w6_known(v), "wino6_input: variant %d (3, 4 or 6)", v);
-    NG_REQUIRE(r == 3 || (!ny && !nb), "wino6_input: the fused variants exist for the 3x3 filter");
-    NG_REQUIRE(v == 3 || !nb, "wino6_input_dy_norm: F(4x4,3x3) only");
+    NG_REQUIRE(r == 3 || !ny, "wino6_input: the normalising variant exists for the 3x3 filter");
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino6_input: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
     NG_REQUIRE(ny || (d->x_hp == d->H + r - 1 && d->x_wp == d->W + r - 1), "wino6_input: the input must be (H+%d) x (W+%d) (%dx%d for %dx%d)", r - 1, r - 1, d->x_hp, d->x_wp, d->H, d->W);
     NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->V) && ng_aligned16(ny) && ng_aligned16(mean) && ng_aligned16(rstd), "wino6_input: pointers must be 16-byte aligned");
@@ -1110,7 +1086,7 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
     in.y = ny; in.mean = mean; in.rstd = rstd; in.H = d->H; in.W = d->W; in.act = act; in.slope = slope;
     if (y != nullptr) {
         // the same dY buffer seen twice: zero halo r-1, the data gradient covers (H_dy + r - 1) x (W_dy + r - 1) outputs
-        NG_REQUIRE(!ny && (nb || y->dy == d->x) && y->Yt && w6_r(y->r) == v && y->dy_pad == r - 1 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp
+        NG_REQUIRE(!ny && y->dy == d->x && y->Yt && w6_r(y->r) == v && y->dy_pad == r - 1 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp
                    && y->dy_wp == d->x_wp && d->H == y->H + r - 1 && d->W == y->W + r - 1,
                    "wino6_input_dy: the two descriptors do not describe the same output-gradient buffer");
         NG_REQUIRE(ng_aligned16(y->Yt), "wino6_input_dy: pointers must be 16-byte aligned");
@@ -1121,16 +1097,7 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
     const long long nthreads = T * (d->C / (v == 3 ? 4 : 2));
     const dim3 grid(unsigned((nthreads + 255) / 256));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    in.nbB = 0;
-    if (nb != nullptr) {
-        NG_REQUIRE(y != nullptr && nb->norm && nb->y && nb->mean && nb->rstd && nb->ws && (nb->g || nb->g2), "wino6_input_dy_norm: the instance-norm descriptor needs y, mean, rstd, ws and a gradient");
-        NG_REQUIRE(nb->B == d->B && nb->C == d->C && nb->H == y->H && nb->W == y->W, "wino6_input_dy_norm: the instance-norm descriptor describes another tensor");
-        NG_REQUIRE(!nb->g || (nb->g_hp == nb->H + 2 * nb->g_pad && nb->g_wp == nb->W + 2 * nb->g_pad), "wino6_input_dy_norm: g geometry mismatch");
-        in.nb = in_bwd_params(nb);
-        in.nbB = nb->B;
-        NG_REQUIRE(nb->ws_elems >= int64_t(nb->B) * in.nb.nchunk * 2 * nb->C + int64_t(nb->B) * 2 * nb->C, "wino6_input_dy_norm: ws too small");
-        hipLaunchKernelGGL((wino6_input_kernel<3, 2>), grid, dim3(256), 0, st, in);
-    } else if (ny && v == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 1>), grid, dim3(256), 0, st, in);
+    if (ny && v == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 1>), grid, dim3(256), 0, st, in);
     else if (ny) hipLaunchKernelGGL((wino6_input_kernel<6, 1>), grid, dim3(256), 0, st, in);
     else if (v == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 0>), grid, dim3(256), 0, st, in);
     else if (v == 4) hipLaunchKernelGGL((wino6_input_kernel<4, 0>), grid, dim3(256), 0, st, in);
@@ -1149,11 +1116,6 @@ extern "C" int nirgan_wino6_input_norm(const nirgan_wino6_desc* d, const float* 
     NG_REQUIRE(y && mean && rstd, "wino6_input_norm: null pointer");
     NG_REQUIRE(act == NIRGAN_ACT_NONE || act == NIRGAN_ACT_RELU || act == NIRGAN_ACT_LRELU, "wino6_input_norm: activation %d", act);
     return w6_input_impl(d, nullptr, y, mean, rstd, act, slope, stream);
-}
-
-extern "C" int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const nirgan_in_bwd_desc* n, void* stream) {
-    NG_REQUIRE(y != nullptr && n != nullptr, "wino6_input_dy_norm: null pointer");
-    return w6_input_impl(d, y, nullptr, nullptr, nullptr, 0, 0.f, stream, n);
 }
 
 extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {

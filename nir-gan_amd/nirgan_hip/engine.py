@@ -14,7 +14,6 @@ ResnetGenerator_inject.forward (model/generator_inject.py:105-135), NLayerDiscri
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -145,22 +144,8 @@ class Plan:
         self.ops = [(n, a) for n, a in self.ops if n not in ("nirgan_pack_rows", "nirgan_pack_rows_bf16")]
         self.ops.append(("nirgan_pack_rows_batch", (table.data_ptr(), len(rows), first)))
 
-    def fuse_wino_weights(self):
-        """The same for the Winograd weight transforms (two per residual-block convolution and step: forward and flipped filter)."""
-        jobs = [a for n, a in self.ops if n == "nirgan_wino_weights_r"]
-        if len(jobs) < 2 or len(jobs) > 256:
-            return
-        rows, first = [], 0
-        for w, K, Cc, r, flip, U in jobs:
-            rows.append([w, U, K, Cc, r, flip, first, 0])
-            first += (K * Cc + 255) // 256
-        table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
-        self.ctx.keep.append(table)
-        self.ops = [(n, a) for n, a in self.ops if n != "nirgan_wino_weights_r"]
-        self.ops.append(("nirgan_wino_weights_batch", (table.data_ptr(), len(rows), first)))
-
     def fuse_wino6_weights(self):
-        """And for the F(4x4,3x3) weight transforms (csrc/wino6.hip)."""
+        """The same for the Winograd weight transforms (csrc/wino6.hip: two per residual-block convolution and step, forward and flipped filter)."""
         jobs = [a for n, a in self.ops if n == "nirgan_wino6_weights_r"]
         if len(jobs) < 2 or len(jobs) > 256:
             return
@@ -302,24 +287,18 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
 
 
 def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.PackSpec, grad: torch.Tensor, *,
-               N, OH, OW, p_oh, p_ow, q_stride=1, q_oh=0, q_ow=0, accumulate=False, slabs_pool=None, pair_with=None, pair_wino=None):
-    """pair_with: a ConvDesc (built with plan=None) launched in the same grid (nirgan_conv_wgrad_pair);
-    pair_wino: a WinoDesc (emit_wino(plan=None)) launched in the same grid (nirgan_wino_wgrad_pair)."""
+               N, OH, OW, p_oh, p_ow, q_stride=1, q_oh=0, q_ow=0, accumulate=False, slabs_pool=None, pair_with=None):
+    """pair_with: a ConvDesc (built with plan=None) launched in the same grid (nirgan_conv_wgrad_pair)."""
     K = taps.n * taps.run
     assert K == spec.K, (K, spec.K)
     tiles = (-(-N // 128) if N > 64 else 1) * (-(-K // 128))
     M = p.B * OH * OW
-    target = int(os.environ.get("NIRGAN_WGRAD_TARGET", "512"))         # blocks of a stand-alone launch: ONE round of the 512 slots (sweep: DESIGN 3.2)
+    target = 512         # blocks of a stand-alone launch: ONE round of the 512 slots (256 / 384 / 512 / 1024 / 2048: 765 / 759 / 789 / 782 / 771 tiles/s)
     if pair_with is not None:
         c = pair_with
         conv_blocks = -(-(c.B * c.OH * c.OW) // 128) * (-(-c.N // 128) if c.N > 64 else 1)
         total = 512 * max(1, round((conv_blocks + 1024) / 512))
         target = max(total - conv_blocks, 512)
-    if pair_wino is not None:
-        c = pair_wino
-        wino_blocks = -(-(c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2)) // 64) * (c.K // 128)
-        total = 512 * max(1, round((wino_blocks + 1024) / 512))
-        target = max(total - wino_blocks, 512)
     twins = (ctx.precision == 1 and p.t16 is not None and q.t16 is not None and N > 64 and N % 8 == 0 and taps.run % 8 == 0
              and (pair_with is None or pair_with.in_bf16))
     nsplit, rows = G.wgrad_split(M, tiles, target, 64 if twins else 32)
@@ -340,10 +319,7 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     d.precision = ctx.precision
     ctx.keep.append(d)
     imap = ctx.i32(spec.index_map)
-    if pair_wino is not None:
-        plan.add("nirgan_wino_input", C.byref(pair_wino))
-        plan.add("nirgan_wino_wgrad_pair", C.byref(pair_wino), C.byref(d))
-    elif pair_with is not None:
+    if pair_with is not None:
         plan.add("nirgan_conv_wgrad_pair", C.byref(pair_with), C.byref(d))
     else:
         plan.add("nirgan_wgrad_igemm", C.byref(d))
@@ -352,23 +328,17 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     return d
 
 
-# filter sizes with a Winograd path: 3 = F(2x2,3x3) (ResnetBlock), 4 = F(2x2,4x4) (the stride-1 256 -> 512 layer of the PatchGAN)
-_WINO_K = (3,) if os.environ.get("NIRGAN_NO_WINOGRAD4") == "1" else (3, 4)
-
-
 def wino_applicable(ctx: Ctx, inp: Halo, k, s, p, cout, OH, OW) -> bool:
-    """Winograd F(2x2, kxk) forward (csrc/winograd.hip): exact-fp32 mode, stride-1 3x3 / 4x4 with padding 1 over a halo of exactly 1,
-    channel counts the tile supports.  In this network: the two convolutions of every ResnetBlock (64 % of the FLOPs) and the
-    stride-1 4x4 layer of the discriminator."""
-    return (ctx.precision == 0 and k in _WINO_K and s == 1 and p == 1 and inp.pad == 1
-            and inp.C % 32 == 0 and cout % 128 == 0 and OH == inp.H + 3 - k and OW == inp.W + 3 - k and OH > 1 and OW > 1
-            and os.environ.get("NIRGAN_NO_WINOGRAD") != "1")
+    """Winograd forward (csrc/wino6.hip) instead of the direct tile: exact-fp32 mode, stride-1 3x3 / 4x4 with padding 1 over a halo of
+    exactly 1, channel counts the plane GEMMs support.  In this network: the two convolutions of every ResnetBlock (64 % of the direct
+    FLOPs) as F(6x6,3x3) -- F(4x4,3x3) with OPT.winograd = 'f4' -- and the stride-1 4x4 layer of the PatchGAN as F(4x4,4x4).
+    OPT.winograd = 'off' keeps the direct tiles everywhere (A/B)."""
+    return (ctx.precision == 0 and OPT.winograd != "off" and k in (3, 4) and s == 1 and p == 1 and inp.pad == 1
+            and inp.C % 32 == 0 and cout % 128 == 0 and OH == inp.H + 3 - k and OW == inp.W + 3 - k and OH > 1 and OW > 1)
 
 
 def wino_dgrad_applicable(ctx: Ctx, k, s, dgrad_out: Halo, cout, cin) -> bool:
-    return (ctx.precision == 0 and k in _WINO_K and s == 1
-            and cout % 32 == 0 and cin % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD") != "1"
-            and os.environ.get("NIRGAN_NO_WINOGRAD_DGRAD") != "1")
+    return ctx.precision == 0 and OPT.winograd != "off" and k in (3, 4) and s == 1 and cout % 32 == 0 and cin % 128 == 0
 
 
 class _FullExtent:
@@ -378,141 +348,11 @@ class _FullExtent:
         self.B, self.hp, self.wp, self.C, self.ptr = h.B, h.hp, h.wp, h.C, h.ptr
 
 
-def emit_wino(plan: Plan, pack: Plan, ctx: Ctx, x: Halo, weight: torch.Tensor, bias, y: Halo, *, H, W, cin, cout, flip=False,
-              own_V: bool = False, r: int = 3, x_norm=None):
-    """U = G g G^T in the pack plan (re-run when the weights change); input transform + fused GEMM/output transform in `plan`.
-    x: buffer of [B][H+r-1][W+r-1][cin] (its own halo'd geometry must match), y: dense [B][H][W][cout] (a buffer's full padded
-    extent counts as dense).  flip: data gradient (x = dY with a zero halo of 2, H x W = the padded input size)."""
-    assert x.hp == H + r - 1 and x.wp == W + r - 1 and x.C == cin and y.hp == H and y.wp == W and y.C == cout, (x.hp, x.wp, H, W, y.hp, y.wp)
-    B = x.B
-    T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    nf = (r + 1) * (r + 1)
-    U = ctx.zeros(nf * cout * cin)
-    ctx.keep.append(U)
-    pack.add("nirgan_wino_weights_r", weight.data_ptr(), cout, cin, r, 1 if flip else 0, U.data_ptr())
-    if own_V:                                          # kept for the layer's weight gradient (same x): nf x the tile bytes, resident
-        V = ctx.zeros(nf * T * cin)
-        ctx.keep.append(V)
-    else:
-        if not hasattr(ctx, "wino_pool"):
-            ctx.wino_pool = SplitPool(ctx)             # the transform-domain input of ONE layer at a time (launches run serially)
-        V = ctx.wino_pool.get(nf * T * cin)
-    d = L.WinoDesc()
-    d.r = r
-    d.x, d.x_hp, d.x_wp = x.ptr, x.hp, x.wp
-    d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
-    d.U, d.bias, d.V, d.V_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), y.ptr
-    d.zero_page = ctx.zero_page.data_ptr()
-    ctx.keep.append(d)
-    if plan is not None:
-        # few tiles (the 16-image PatchGAN passes: 256 / 146 workgroups for 512 slots): divide the frequencies over 2-4 workgroups per tile
-        blocks = -(-T // 64) * (cout // 128)
-        fs = min(4, 512 // max(blocks, 1), nf // 4) if os.environ.get("NIRGAN_NO_WINO_FSPLIT") != "1" else 1
-        if blocks < 384 and fs > 1 and (B * H * W * cout) % 4 == 0 and cout % 4 == 0:
-            if not hasattr(ctx, "split_pool"):
-                ctx.split_pool = SplitPool(ctx)
-            ws = ctx.split_pool.get(fs * B * H * W * cout)
-            d.fsplit, d.split_ws, d.split_ws_elems = fs, ws.data_ptr(), ws.numel()
-        if x_norm is not None:             # (y, (mean, rstd), act) of the producer: its apply pass is folded into this transform
-            yh, st, act = x_norm
-            assert r == 3 and yh.pad == 0 and yh.H == H and yh.W == W and yh.C == cin
-            plan.add("nirgan_wino_input_norm", C.byref(d), yh.ptr, st[0].data_ptr(), st[1].data_ptr(), act, 0.2)
-        else:
-            plan.add("nirgan_wino_input", C.byref(d))
-        plan.add("nirgan_wino_gemm", C.byref(d))
-    return d
-
-
-def emit_wino_wgrad(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, OH, OW, cin, cout, slabs_pool, pair_wino,
-                    accumulate=False, V_fwd: Optional[L.WinoDesc] = None, r: int = 3):
-    """Weight gradient of a Winograd layer in the transform domain: V = B^T x B of the forward input, Yt = A dY A^T, 16 problems
-    dU[f] = Yt[f]^T V[f] over the tiles as ONE weight-gradient launch with 16 planes (fused with the Winograd data-gradient tiles of
-    `pair_wino`), then dW = G^T dU G.  16/36 of the direct weight gradient's multiplies."""
-    B = inp.B
-    assert inp.pad == 1 and inp.H == OH + r - 3 and inp.W == OW + r - 3 and inp.C == cin and dy.C == cout
-    T = B * ((OH + 1) // 2) * ((OW + 1) // 2)
-    nf = (r + 1) * (r + 1)
-    for name in ("wino_pool_x", "wino_pool_y"):
-        if not hasattr(ctx, name):
-            setattr(ctx, name, SplitPool(ctx))
-    Yt = ctx.wino_pool_y.get(nf * T * cout)
-    vin = None
-    if V_fwd is not None:                              # the forward pass of this step left V = B^T x B of the same x in its own buffer
-        V_ptr, V_elems = V_fwd.V, V_fwd.V_elems
-    else:
-        V = ctx.wino_pool_x.get(nf * T * cin)
-        vin = L.WinoDesc()
-        vin.r = r
-        vin.x, vin.x_hp, vin.x_wp, vin.B, vin.H, vin.W, vin.C, vin.K = inp.ptr, inp.hp, inp.wp, B, OH, OW, cin, cout
-        vin.V, vin.V_elems = V.data_ptr(), V.numel()
-        V_ptr, V_elems = V.data_ptr(), V.numel()
-    ydesc = L.WinoDyDesc()
-    ydesc.dy, ydesc.dy_hp, ydesc.dy_wp, ydesc.dy_pad = dy.ptr, dy.hp, dy.wp, dy.pad
-    ydesc.B, ydesc.H, ydesc.W, ydesc.K = B, OH, OW, cout
-    ydesc.Yt, ydesc.Yt_elems = Yt.data_ptr(), Yt.numel()
-    ydesc.r = r
-    tiles = (-(-cout // 128)) * (-(-cin // 128)) * nf
-    c = pair_wino
-    wino_blocks = -(-(c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2)) // 64) * (c.K // 128)
-    # 256 CUs x 2 resident workgroups = 512 slots.  When both parts fit ONE residency with weight-gradient blocks no longer than ~1.3
-    # Winograd blocks (>= 6 splits), launch exactly that (res-block layer at bs 16: 8 splits, 649 us; 15 splits 676, 23 splits 658);
-    # otherwise ~1500 short blocks pack best behind the Winograd tiles (profiles/r01_wino_split_sweep.txt: 23 splits of the 64 res-layer
-    # tiles are within 1.5 % of the best at bs 32, padding 10 and 512x512, where 5-8 splits lose 6-13 %; the PatchGAN's 4x4 layer with
-    # 200 tiles measures 1040 us at 4, 8 and 22 splits alike)
-    room = 1024 - wino_blocks
-    target = room if room // tiles >= 6 else max(1472, 2 * tiles)
-    nsplit, rows = G.wgrad_split(T, tiles, target)
-    env = "NIRGAN_WINO_SPLITS" if r == 3 else "NIRGAN_WINO4_SPLITS"
-    if os.environ.get(env):                            # experiments (scripts/sweep_wino_splits.sh)
-        nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ[env]))
-    need = nf * nsplit * cout * cin
-    slabs = slabs_pool.get(need)
-    d = L.WgradDesc()
-    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = Yt.data_ptr(), nf * T * cout, 1, T, cout, 0, 0
-    assert V_elems >= nf * T * cin
-    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = V_ptr, nf * T * cin, 1, T, cin
-    d.q_stride, d.q_oh, d.q_ow = 1, 0, 0
-    d.run = cin
-    _set_taps(d, [0], [0])
-    d.B, d.OH, d.OW, d.N = 1, 1, T, cout
-    d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
-    d.zero_page = ctx.zero_page.data_ptr()
-    d.precision = 0
-    d.nplanes, d.p_plane, d.q_plane = nf, T * cout, T * cin
-    ctx.keep.extend([vin, ydesc, d, slabs])
-    if pair_wino.x == ydesc.dy and dy.pad == r - 1 and os.environ.get("NIRGAN_NO_WINO_INPUT_DY") != "1":
-        plan.add("nirgan_wino_input_dy", C.byref(pair_wino), C.byref(ydesc))      # V of dY (data gradient) and Yt (weight gradient): one read of dY
-        fused_dy = True
-    else:
-        plan.add("nirgan_wino_input", C.byref(pair_wino))      # V of dY for the data gradient
-        fused_dy = False
-    if vin is not None:
-        plan.add("nirgan_wino_input", C.byref(vin))            # V of the forward input
-    if not fused_dy:
-        plan.add("nirgan_wino_dy", C.byref(ydesc))
-    plan.add("nirgan_wino_wgrad_pair", C.byref(pair_wino), C.byref(d))
-    plan.add("nirgan_wino_wgrad_finish_r", slabs.data_ptr(), nsplit, cout, cin, r, grad.data_ptr(), 1 if accumulate else 0)
-    return d
-
-
-def wino6_applicable(ctx: Ctx, k: int, cout: int) -> bool:
-    """Winograd F(4x4, kxk) (csrc/wino6.hip) instead of F(2x2, kxk) wherever the latter applies: 36 instead of 64 products per 4x4
-    outputs for the 3x3 filters of the residual blocks, 49 instead of 100 for the PatchGAN's stride-1 4x4 layer; the transform-domain
-    product makes one trip through HBM.  NIRGAN_NO_WINO6=1 keeps F(2x2,3x3), NIRGAN_NO_WINO7=1 keeps F(2x2,4x4) (A/B)."""
-    if cout <= 64:
-        return False
-    if k == 3:
-        return os.environ.get("NIRGAN_NO_WINO6") != "1"
-    return k == 4 and os.environ.get("NIRGAN_NO_WINO7") != "1" and os.environ.get("NIRGAN_NO_WINO6") != "1"
-
-
 def wino6_variant(r: int) -> int:
     """The `r` code of the wino6 descriptors for a filter size: 3 = F(4x4,3x3), 4 = F(4x4,4x4), 6 = F(6x6,3x3).  3x3 filters take
     F(6x6,3x3) -- 64 products per 36 outputs instead of 36 per 16, in the plane GEMMs AND in the bytes of the transform-domain tensors --
-    unless NIRGAN_NO_WINO8=1 (A/B) or the opt-in dY-norm fusion, which exists for F(4x4,3x3) only, is on."""
-    if r == 3 and os.environ.get("NIRGAN_NO_WINO8") != "1" and os.environ.get("NIRGAN_WINO6_DYNORM") != "1":
-        return 6
-    return r
+    unless OPT.winograd = 'f4' (A/B)."""
+    return 6 if (r == 3 and OPT.winograd != "f4") else r
 
 
 def _w6_geo(v: int):
@@ -571,7 +411,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
 
 
 def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, OH, OW, cin, cout, slabs_pool,
-                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False, norm_desc=None, r: int = 3):
+                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False, r: int = 3):
     """Backward of an F(4x4,3x3) layer: dY -> (V of dY for the data gradient, Yt = A dY A^T for the weight gradient) in one pass, the
     data gradient's 36 plane GEMMs + output transform, the 36 transform-domain weight-gradient problems dU[f] = Yt[f]^T V[f] (V of the
     forward input, kept by the forward) as one weight-gradient launch, dW = G^T dU G."""
@@ -609,8 +449,6 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     # the one-tile-per-workgroup launch wants: half the slab traffic, 743 -> 750 tiles/s
     persistent = cout == 256 and OPT.w6_gemm_algo == 0 and OPT.wgrad_algo == 0 and OPT.w6_pair
     nsplit, rows = G.wgrad_split(T, tiles, 512 if persistent else 1024)
-    if os.environ.get("NIRGAN_WINO6_SPLITS"):            # experiments
-        nsplit, rows = G.wgrad_split(T, tiles, tiles * int(os.environ["NIRGAN_WINO6_SPLITS"]))
     # deferred finish (ctx.w6_deferred is a list while a network collects the layers of one trunk): the layer keeps its own slabs and the
     # inverse transforms of all of them run as ONE launch behind the trunk (emit_w6_deferred_finishes)
     deferred = getattr(ctx, "w6_deferred", None) if persistent else None
@@ -629,10 +467,7 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     d.nplanes, d.p_plane, d.q_plane = NP, T * cout, T * cin
     d.algo = OPT.wgrad_algo
     ctx.keep.extend([vin, ydesc, d, slabs])
-    if norm_desc is not None:       # dY is not in memory: the instance-norm backward's second pass runs inside the transform
-        plan.add("nirgan_wino6_input_dy_norm", C.byref(dgrad), C.byref(ydesc), C.byref(norm_desc))
-    else:
-        plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
+    plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
     if vin is not None:
         plan.add("nirgan_wino6_input", C.byref(vin))
     if OPT.w6_pair:                                # 24.87 -> 24.64 ms per step
@@ -671,11 +506,11 @@ def attach_conv_stats(ctx: Ctx, descs: list, bias) -> Optional[tuple]:
     """Let the convolution launches behind `descs` (one problem, or the sub-pixel phases of a transposed convolution writing one
     output) leave the partial sums of the instance norm that follows (csrc/igemm_tiles.h, conv_tile epilogue): returns
     (chunks per sample, shift, workspace) for emit_in_fwd(pre_stats=...), or None when a problem does not qualify."""
-    if os.environ.get("NIRGAN_NO_CONV_STATS") == "1" or any(d.ksplit > 1 or (d.OH * d.OW) % 128 for d in descs):
+    if not OPT.epilogue_stats or any(d.ksplit > 1 or (d.OH * d.OW) % 128 for d in descs):
         return None
     # worth it from ~16 K pixels per sample (the 128x128 and 256x256 layers: 16 / 54 us of statistics pass each); below, the pass
-    # costs 2-4 us and the layer keeps it (NIRGAN_CONV_STATS_MIN overrides the threshold: the kernel tests run small layers through it)
-    if sum(d.OH * d.OW for d in descs) < int(os.environ.get("NIRGAN_CONV_STATS_MIN", "16384")):
+    # costs 2-4 us and the layer keeps it (OPT.epilogue_min_pixels: the kernel tests run small layers through it)
+    if sum(d.OH * d.OW for d in descs) < OPT.epilogue_min_pixels:
         return None
     B, N = descs[0].B, descs[0].N
     total = sum(d.OH * d.OW // 64 for d in descs)
@@ -835,24 +670,20 @@ class ConvIN:
         k, s, p = self.k, self.s, self.p
         pre = None          # (chunks per sample, shift, workspace) when the convolution's last kernel leaves the instance norm's partial sums
         if self.kind == "conv" and wino_applicable(ctx, inp, k, s, p, self.cout, self.OH, self.OW):
-            keep = bool(getattr(eng, "need_backward", False)) and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"
+            keep = bool(getattr(eng, "need_backward", False))     # V = B^T x B stays resident for the layer's transform-domain weight gradient
             prod = getattr(self, "producer", None)
             xn = (prod.y, prod.stats, prod.act) if prod is not None and getattr(prod, "defer_apply", False) else None
-            if wino6_applicable(ctx, k, self.cout):
-                self.wino6 = True
-                sws = None
-                if self.norm and os.environ.get("NIRGAN_NO_WINO6_STATS") != "1":
-                    # instance-norm statistics from the output transform's own pass (one chunk of partial sums per tile)
-                    T = _w6_tiles(inp.B, self.OH, self.OW, wino6_variant(k))
-                    if not hasattr(ctx, "wino6_pool_stats"):
-                        ctx.wino6_pool_stats = SplitPool(ctx)
-                    sws = ctx.wino6_pool_stats.get(T * 2 * self.cout)
-                    pre = (T // inp.B, self.bias, sws)
-                self.wino_fwd = emit_wino6(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
-                                           cout=self.cout, own_V=keep, x_norm=xn, r=k, stats_ws=sws)
-            else:
-                self.wino_fwd = emit_wino(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
-                                          cout=self.cout, own_V=keep, r=k, x_norm=xn)
+            self.wino6 = True
+            sws = None
+            if self.norm and OPT.epilogue_stats:
+                # instance-norm statistics from the output transform's own pass (one chunk of partial sums per tile)
+                T = _w6_tiles(inp.B, self.OH, self.OW, wino6_variant(k))
+                if not hasattr(ctx, "wino6_pool_stats"):
+                    ctx.wino6_pool_stats = SplitPool(ctx)
+                sws = ctx.wino6_pool_stats.get(T * 2 * self.cout)
+                pre = (T // inp.B, self.bias, sws)
+            self.wino_fwd = emit_wino6(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
+                                       cout=self.cout, own_V=keep, x_norm=xn, r=k, stats_ws=sws)
             self.wino_fwd_keeps_V = keep
         elif self.kind == "conv":
             taps = G.conv_fwd_taps(k, inp.C)
@@ -901,22 +732,20 @@ class ConvIN:
         k, s, p = self.k, self.s, self.p
         act = self.act if act is None else act
         dy = self.dy
-        # F(4x4,3x3) backward (below).  OPT-IN (NIRGAN_WINO6_DYNORM=1): the second pass of the instance-norm backward evaluated inside the
-        # dY transform (dY never stored).  Bitwise the same V / Yt, but measured SLOWER: 161 us against 84 (transform) + 31 (second pass)
-        # per layer -- every dY element is re-derived by the 2.25 patches that contain it, from two loads instead of one, at 240 VGPRs
+        # Winograd backward (below).  (Round 2 measured the second pass of the instance-norm backward evaluated INSIDE the dY transform --
+        # dY never stored, bitwise the same V / Yt -- at 161 us against 84 + 31 per layer: every dY element is re-derived by the 2.25
+        # patches that contain it, at 240 VGPRs; that variant is gone.)
         w6_bwd = (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
-                  and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C) and wino6_applicable(ctx, k, inp.C)
-                  and inp.pad == 1 and p == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1")
-        fuse_dy = w6_bwd and k == 3 and self.norm and dy.t16 is None and os.environ.get("NIRGAN_WINO6_DYNORM") == "1"
+                  and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C) and inp.C > 64
+                  and inp.pad == 1 and p == 1 and self.cout % 128 == 0)
         # The gradient arrives from an F(6x6,3x3) data gradient over the padded extent (reflect halo of 1 to fold): that launch's output
         # transform is switched to its fused mode -- it folds the halo in registers (lane pairs exchange half tiles so that the per-pixel
         # phase moves 16 bytes per lane), adds the skip gradient, stores the folded gradient dense and leaves the partial sums of this
         # layer's first backward pass; the halo'd buffer `g` is then never written or read.  The first pass disappears (94 -> 45 us per
-        # layer) for an output transform of 67 us instead of 39: 21.16 -> 20.87 ms per step.  NIRGAN_NO_INBWD_FUSE=1 keeps the two passes.
+        # layer) for an output transform of 67 us instead of 39: 21.16 -> 20.87 ms per step.  OPT.fuse_inbwd = False keeps the two passes.
         pre_sums, ws = 0, eng.scratch.get()
         od = getattr(g, "w6_out_desc", None) if g is not None else None
-        if (od is not None and od.r == 6 and g_fold and self.norm and not fuse_dy and g.pad == 1 and dy.t16 is None
-                and os.environ.get("NIRGAN_NO_INBWD_FUSE") != "1"):
+        if od is not None and od.r == 6 and g_fold and self.norm and g.pad == 1 and dy.t16 is None and OPT.fuse_inbwd:
             mo = _w6_geo(od.r if od.r else 3)[0]
             Hp, Wp = od.H, od.W
             if (Hp == self.OH + 2 and Wp == self.OW + 2 and od.K == self.cout and od.B == inp.B and min(Hp, Wp) >= 6
@@ -938,13 +767,13 @@ class ConvIN:
                 pre_sums = chunks
         # The gradient arrives from direct-tile data-gradient launches (the sub-pixel phases of a stride-2 convolution, or a transposed
         # convolution's strided one): their epilogue takes this layer's first backward pass next to the store (nirgan_conv_desc.fuse_*).
-        # Worth it on the large maps only (threshold as for the forward statistics); NIRGAN_NO_CONV_INBWD=1 keeps the separate pass.
+        # Worth it on the large maps only (threshold as for the forward statistics); OPT.fuse_inbwd = False keeps the separate pass.
         cds = getattr(g, "conv_out_descs", None) if g is not None else None
-        if (cds and not pre_sums and self.norm and not g_fold and g2 is None and gsum is None and not fuse_dy and self.cout % 4 == 0
-                and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and os.environ.get("NIRGAN_NO_CONV_INBWD") != "1"
+        if (cds and not pre_sums and self.norm and not g_fold and g2 is None and gsum is None and self.cout % 4 == 0
+                and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and OPT.fuse_inbwd
                 and all(c.ksplit <= 1 and (c.OH * c.OW) % 128 == 0 and c.N == self.cout and not c.bias for c in cds)
                 and sum(c.OH * c.OW for c in cds) == self.OH * self.OW
-                and self.OH * self.OW >= int(os.environ.get("NIRGAN_CONV_STATS_MIN", "16384"))):
+                and self.OH * self.OW >= OPT.epilogue_min_pixels):
             chunks = sum(c.OH * c.OW // 128 for c in cds)
             if not hasattr(ctx, "inbwd_part"):
                 ctx.inbwd_part = SplitPool(ctx)
@@ -962,32 +791,19 @@ class ConvIN:
                          y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
                          dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
                          ws=ws,
-                         shape=(inp.B, self.OH, self.OW, self.cout), sums_only=fuse_dy, pre_sums=pre_sums)
-        # stride-1 convolutions that need both gradients: one fused launch (data-gradient tiles + weight-gradient tiles)
-        if (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
-                and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C)):
-            if w6_bwd:
-                # F(4x4,3x3): data gradient and transform-domain weight gradient, dY read once for both of its transforms
-                wd6 = emit_wino6(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
-                                 cin=self.cout, cout=inp.C, flip=True, r=k)
-                keepV = getattr(self, "wino_fwd_keeps_V", False) and getattr(self, "wino6", False)
-                emit_wino6_backward(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
-                                    dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None), norm_desc=(nd if fuse_dy else None), r=k)
-                if k == 3:
-                    dgrad_out.w6_out_desc = wd6          # the consumer of this gradient may switch the output transform to its fused mode
-                return
-            # exact-fp32 mode, 3x3: the data gradient is a Winograd convolution of dY (zero halo 2) with the flipped filter over the
-            # padded input extent; the weight gradient keeps the direct tile (stand-alone launch)
-            wd = emit_wino(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
-                           cin=self.cout, cout=inp.C, flip=True, r=k)
-            if inp.pad == 1 and p == 1 and self.cout % 128 == 0 and os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1":
-                emit_wino_wgrad(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
-                                pair_wino=wd, V_fwd=(self.wino_fwd if getattr(self, "wino_fwd_keeps_V", False) else None), r=k)
-            else:
-                emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
-                           N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
-                           q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_wino=wd)
+                         shape=(inp.B, self.OH, self.OW, self.cout), pre_sums=pre_sums)
+        # stride-1 convolutions that need both gradients
+        if w6_bwd:
+            # Winograd: data gradient and transform-domain weight gradient, dY read once for both of its transforms
+            wd6 = emit_wino6(None, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
+                             cin=self.cout, cout=inp.C, flip=True, r=k)
+            keepV = getattr(self, "wino_fwd_keeps_V", False) and getattr(self, "wino6", False)
+            emit_wino6_backward(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
+                                dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None), r=k)
+            if k == 3:
+                dgrad_out.w6_out_desc = wd6          # the consumer of this gradient may switch the output transform to its fused mode
             return
+        # direct tiles: one fused launch (data-gradient tiles + weight-gradient tiles)
         if self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None:
             assert dgrad_out.H == inp.H and dgrad_out.pad == p and dy.pad == k - 1
             hw = [(kh, kw) for kh in range(k) for kw in range(k)]
@@ -1019,15 +835,10 @@ class ConvIN:
         if self.kind == "conv" and s == 1:
             # full correlation: gradient wrt the halo'd input (size H+2p), folded / cropped by the consumer
             assert dgrad_out.H == inp.H and dgrad_out.pad == p and dy.pad == k - 1
-            if (gw is None and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C)
-                    and os.environ.get("NIRGAN_NO_WINOGRAD_DGRAD_ONLY") != "1"):
+            if gw is None and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C) and inp.C > 64:
                 # frozen parameters (the discriminator inside the generator step): the data gradient alone, as a Winograd convolution
-                if wino6_applicable(ctx, k, inp.C):
-                    emit_wino6(plan, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
-                               cin=self.cout, cout=inp.C, flip=True, r=k)
-                    return
-                emit_wino(plan, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
-                          cin=self.cout, cout=inp.C, flip=True, r=k)
+                emit_wino6(plan, pack, ctx, dy, self.weight, None, _FullExtent(dgrad_out), H=dgrad_out.hp, W=dgrad_out.wp,
+                           cin=self.cout, cout=inp.C, flip=True, r=k)
                 return
             taps = G.conv_dgrad_s1_taps(k, self.cout)
             hw = [(kh, kw) for kh in range(k) for kw in range(k)]
@@ -1073,7 +884,7 @@ class TapPlaneConv:
         self.nt = k * k
         self.qcs = -(-self.nt // 4) * 4
         self.OH, self.OW = inp.hp - k + 1, inp.wp - k + 1
-        self.direct = (inp.C == 64 and k == 7 and os.environ.get("NIRGAN_NO_ENDCONV") != "1")      # exact fp32 kernels in every precision mode
+        self.direct = inp.C == 64 and k == 7 and OPT.endconv_direct      # exact fp32 kernels in every precision mode
         if not self.direct:
             self.q = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
         self.whole_in = Halo(ctx, inp.B, inp.hp, inp.wp, inp.C, 0, tensor=inp.t)     # same memory, halo as image

@@ -129,12 +129,6 @@ class HistMatchDesc(C.Structure):
     _fields_ = [("image", fp), ("reference", fp), ("B", i32), ("N", i32), ("ws", fp), ("ws_bytes", i64), ("out", fp)]
 
 
-class WinoDesc(C.Structure):
-    _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
-                ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32), ("fsplit", i32),
-                ("split_ws", fp), ("split_ws_elems", i64)]
-
-
 class WinoDyDesc(C.Structure):
     _fields_ = [("dy", fp), ("dy_hp", i32), ("dy_wp", i32), ("dy_pad", i32), ("B", i32), ("H", i32), ("W", i32), ("K", i32),
                 ("Yt", fp), ("Yt_elems", i64), ("r", i32)]
@@ -174,20 +168,6 @@ PROTOTYPES = {
     "nirgan_pack_rows_bf16": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_location_encoder": (i32, [C.POINTER(LocEncDesc), fp]),
-    "nirgan_wino_ws_elems": (i64, [i32, i32, i32, i32, i32]),
-    "nirgan_wino_weights": (i32, [fp, i32, i32, i32, fp, fp]),
-    "nirgan_wino_ws_elems_r": (i64, [i32, i32, i32, i32, i32, i32]),
-    "nirgan_wino_weights_r": (i32, [fp, i32, i32, i32, i32, fp, fp]),
-    "nirgan_wino_weights_batch": (i32, [fp, i32, i32, fp]),
-    "nirgan_wino_wgrad_finish_r": (i32, [fp, i32, i32, i32, i32, fp, i32, fp]),
-    "nirgan_wino_input": (i32, [C.POINTER(WinoDesc), fp]),
-    "nirgan_wino_gemm": (i32, [C.POINTER(WinoDesc), fp]),
-    "nirgan_wino_conv3x3": (i32, [C.POINTER(WinoDesc), fp]),
-    "nirgan_wino_wgrad_pair": (i32, [C.POINTER(WinoDesc), C.POINTER(WgradDesc), fp]),
-    "nirgan_wino_dy": (i32, [C.POINTER(WinoDyDesc), fp]),
-    "nirgan_wino_input_dy": (i32, [C.POINTER(WinoDesc), C.POINTER(WinoDyDesc), fp]),
-    "nirgan_wino_input_norm": (i32, [C.POINTER(WinoDesc), fp, fp, fp, i32, f32, fp]),
-    "nirgan_wino_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_wino6_tiles": (i64, [i32, i32, i32]),
     "nirgan_wino6_tiles_r": (i64, [i32, i32, i32, i32]),
     "nirgan_wino6_weights": (i32, [fp, i32, i32, i32, fp, fp]),
@@ -203,7 +183,6 @@ PROTOTYPES = {
     "nirgan_wino6_conv3x3": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_dy": (i32, [C.POINTER(WinoDyDesc), fp]),
     "nirgan_wino6_input_dy": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), fp]),
-    "nirgan_wino6_input_dy_norm": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), C.POINTER(InBwdDesc), fp]),
     "nirgan_wino6_wgrad_finish": (i32, [fp, i32, i32, i32, fp, i32, fp]),
     "nirgan_wino6_wgrad_finish_r": (i32, [fp, i32, i32, i32, i32, fp, i32, fp]),
     "nirgan_wino6_wgrad_finish_batch": (i32, [fp, fp, i32, i32, i32, i32, i32, i32, fp]),

@@ -9,13 +9,13 @@ the parameter gradients (and, for the PatchGAN, the gradient wrt its input).
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Dict, Optional
 
 import torch
 
 from . import geometry as G
 from . import lib as L
+from .options import OPT
 from .engine import ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, emit_conv, emit_w6_deferred_finishes, emit_wgrad, wino_applicable
 
 
@@ -41,7 +41,6 @@ class _Engine:
         if not getattr(self, "_packs_fused", False):
             for pl in (self.pack_fwd, self.pack_bwd):
                 pl.fuse_packs()
-                pl.fuse_wino_weights()
                 pl.fuse_wino6_weights()
             self._packs_fused = True
         if self._packed_version != version:
@@ -109,9 +108,7 @@ class GeneratorEngine(_Engine):
                         out_border=L.BORDER_REFLECT if j < n_blocks - 1 else L.BORDER_KEEP)
             # c1's normalised output has ONE reader, c2's Winograd input transform: fold InstanceNorm + ReLU + reflect pad into that
             # transform and never write the buffer.  Needs c2's V kept for its weight gradient (else the backward re-reads c1.out).
-            wgrad_keeps_v = os.environ.get("NIRGAN_NO_WINOGRAD_WGRAD") != "1"
-            if (wino_applicable(self.ctx, c2.inp, 3, 1, 1, c2.cout, c2.OH, c2.OW) and (wgrad_keeps_v or not self.need_backward)
-                    and os.environ.get("NIRGAN_NO_WINO_INPUT_NORM") != "1"):
+            if wino_applicable(self.ctx, c2.inp, 3, 1, 1, c2.cout, c2.OH, c2.OW) and OPT.fold_apply:
                 c1.defer_apply = True
                 c2.producer = c1
             self.blocks.append((i, c1, c2))
@@ -221,7 +218,7 @@ class GeneratorEngine(_Engine):
         g_in, g_fold, g_skip = g_top, False, None
         dense = [Halo(ctx, B, H3, W3, c4, 0), Halo(ctx, B, H3, W3, c4, 0)] if self.blocks else []
         flip = 0
-        ctx.w6_deferred = [] if os.environ.get("NIRGAN_NO_W6_FINISH_BATCH") != "1" else None      # collect the blocks' weight-gradient finishes
+        ctx.w6_deferred = []      # collect the blocks' weight-gradient finishes
         for j in range(len(self.blocks) - 1, -1, -1):
             i, c1, c2 = self.blocks[j]
             gq = Halo(ctx, B, H3, W3, c4, 1)

@@ -2,9 +2,13 @@
 
 One process-wide object, read when an engine is BUILT (descriptors are static afterwards; the C library reads no environment
 variables and keeps no switches of its own -- kernel choices travel in the descriptors' ``algo`` fields).  Tests and scripts set
-attributes (``monkeypatch.setattr(OPT, "w6_pair", False)``); the defaults are the measured-fastest configuration.
+attributes (``monkeypatch.setattr(OPT, "w6_pair", False)``); the defaults are the measured-fastest configuration.  For A/B runs from
+the command line the ONE environment variable ``NIRGAN_OPTIONS`` is parsed once, at import: e.g.
+``NIRGAN_OPTIONS=winograd=off,fuse_inbwd=0 python bench.py``.
 """
 from __future__ import annotations
+
+import os
 
 
 class Options:
@@ -15,6 +19,18 @@ class Options:
     wgrad_algo: int = 0
     # data-gradient plane GEMMs and the transform-domain weight gradient of a layer in ONE grid (nirgan_wino6_gemm_wgrad_pair)
     w6_pair: bool = True
+    # Winograd for the stride-1 3x3 / 4x4 layers in exact-fp32 mode: "f6" = F(6x6,3x3) + F(4x4,4x4) (default), "f4" = F(4x4,3x3) +
+    # F(4x4,4x4), "off" = the direct tiles everywhere
+    winograd: str = "f6"
+    # instance-norm statistics from the producing kernel's own pass (convolution epilogue / Winograd output transform) and the first
+    # pass of its backward inside the kernel that produces the gradient, on maps of at least epilogue_min_pixels per sample
+    epilogue_stats: bool = True
+    fuse_inbwd: bool = True
+    epilogue_min_pixels: int = 16384
+    # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform
+    fold_apply: bool = True
+    # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
+    endconv_direct: bool = True
 
     def reset(self):
         for k, v in vars(Options).items():
@@ -22,4 +38,16 @@ class Options:
                 setattr(self, k, v)
 
 
+    def update_from(self, text: str):
+        """'name=value,name=value' with the names above; values parsed by the default's type."""
+        for item in filter(None, (t.strip() for t in text.split(","))):
+            k, _, v = item.partition("=")
+            if not hasattr(Options, k) or k.startswith("_"):
+                raise ValueError(f"NIRGAN_OPTIONS: unknown option '{k}'")
+            cur = getattr(Options, k)
+            setattr(self, k, (v.lower() in ("1", "true", "yes", "on")) if isinstance(cur, bool) else type(cur)(v))
+
+
 OPT = Options()
+if os.environ.get("NIRGAN_OPTIONS"):
+    OPT.update_from(os.environ["NIRGAN_OPTIONS"])

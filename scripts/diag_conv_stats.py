@@ -10,9 +10,8 @@ name = sys.argv[1] if len(sys.argv) > 1 else "f1_g9_rs_pad.npz"
 z = load(os.path.join(ROOT, "tests", "golden"), name)
 nb = 9 if "g9" in name else 6
 def run(stats):
-    os.environ.pop("NIRGAN_NO_CONV_STATS", None)
-    if not stats:
-        os.environ["NIRGAN_NO_CONV_STATS"] = "1"
+    from nirgan_hip.options import OPT
+    OPT.epilogue_stats = bool(stats)
     netG, netD = make_nets(z, nb)
     tr = Pix2PixTrainer(netG, netD, n_blocks=nb, lambda_rs=float(z["lambda_rs"]), rs_weights={"lambda_ndvi": 0.3333, "lambda_ndwi": 0.3333, "lambda_evi": 0.3333,
                         "lambda_savi": 0.0, "lambda_msavi": 0.0, "lambda_gndvi": 0.0}, padding=int(z["padding"]))

@@ -49,15 +49,6 @@ def describe(name, args):
         blk = sum(-(-(d.B * d.OH * d.OW) // 128) * (-(-d.N // 128) if d.N > 64 else 1) for d in ds)
         d = ds[0]
         return f"group x{len(ds)} M={d.B * d.OH * d.OW} N={d.N} K={d.ntaps}x{d.run} s{d.in_stride}/{d.out_stride} blk={blk}", fl
-    if name == "nirgan_wino_wgrad_pair":
-        c, w = args[0]._obj, args[1]._obj
-        r = max(c.r, 3)
-        fl = 2.0 * (r + 1) ** 2 * c.B * ((c.H + 1) // 2) * ((c.W + 1) // 2) * c.C * c.K + 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run
-        return f"wino{r}-dgrad {c.H}x{c.W} + wgrad M={w.B * w.OH * w.OW} N={w.N} K={w.ntaps * w.run} split={w.nsplit} (executed flops)", fl
-    if name == "nirgan_wino_gemm":
-        d = args[0]._obj
-        r = max(d.r, 3)
-        return f"winograd {r}x{r} B={d.B} {d.H}x{d.W} C={d.C} K={d.K} (executed flops)", 2.0 * (r + 1) ** 2 * d.B * ((d.H + 1) // 2) * ((d.W + 1) // 2) * d.C * d.K
     if name == "nirgan_wgrad_igemm":
         w = args[0]._obj
         M = w.B * w.OH * w.OW

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """400 training steps at the benchmark shape (bs 16, 256^2, 6-block, exact fp32) with the Winograd layers and, in a second process,
-with the direct tiles (NIRGAN_NO_WINOGRAD=1): same data, same initial weights.  The first steps agree to rounding; afterwards the two
+with the direct tiles (NIRGAN_OPTIONS=winograd=off): same data, same initial weights.  The first steps agree to rounding; afterwards the two
 GAN trajectories separate as any two fp32 runs do, and must stay finite and converge alike."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,7 +31,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     fin = all(bool(torch.isfinite(p).all()) for p in list(netG.parameters()) + list(netD.parameters()))
     print("parameters finite:", fin)
 else:
-    for name, env in (("winograd (default)", {}), ("direct tiles (NIRGAN_NO_WINOGRAD=1)", {"NIRGAN_NO_WINOGRAD": "1"})):
+    for name, env in (("winograd (default)", {}), ("direct tiles (NIRGAN_OPTIONS=winograd=off)", {"NIRGAN_OPTIONS": "winograd=off"})):
         print("==", name, flush=True)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env={**os.environ, **env}, capture_output=True, text=True)
         print("\n".join(l for l in r.stdout.splitlines()), flush=True)

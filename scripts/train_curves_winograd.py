@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Loss curves of the exact-fp32 step with the three convolution algorithms of the residual blocks -- F(6x6,3x3) (default),
-F(4x4,3x3) (NIRGAN_NO_WINO8=1), direct tiles (NIRGAN_NO_WINOGRAD=1) -- on the same data and initial weights: 240 steps over 8 fixed
+F(4x4,3x3) (OPT.winograd = 'f4'), direct tiles (OPT.winograd = 'off') -- on the same data and initial weights: 240 steps over 8 fixed
 synthetic batches with a learnable relation (nir = smooth function of rgb), bs 16 @128^2, 6-block generator.  GAN training is
 chaotic: the curves separate after a few dozen steps whatever the rounding (see the fp32 / bf16x3 columns of
 profiles/r01_precision_training_curves.txt); what to look for is that they stay in one band and reach the same level."""
@@ -19,13 +19,12 @@ for _ in range(8):
     rgb = (0.05 + 0.5 * base + 0.02 * torch.rand(16, 3, 128, 128, generator=g))
     nir = (0.1 + 0.6 * rgb[:, 0:1] + 0.3 * rgb[:, 1:2] * rgb[:, 2:3]).clamp(0, 1)
     batches.append((rgb.to(dev), nir.to(dev)))
-variants = (("F(6x6,3x3)", {}), ("F(4x4,3x3)", {"NIRGAN_NO_WINO8": "1"}), ("direct tiles", {"NIRGAN_NO_WINOGRAD": "1"}))
+variants = (("F(6x6,3x3)", "f6"), ("F(4x4,3x3)", "f4"), ("direct tiles", "off"))
+from nirgan_hip.options import OPT
 print("step   " + "".join(f"{n:>30s}" for n, _ in variants))
 rows, first = {}, {}
 for name, env in variants:
-    for k in ("NIRGAN_NO_WINO8", "NIRGAN_NO_WINOGRAD"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    OPT.winograd = env
     torch.manual_seed(0)
     netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(dev)
     netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)

@@ -326,174 +326,6 @@ class EmuBackend:
         arr(d.out, d.B * d.dims[d.nlayers], np.float64)[:] = h.reshape(-1)
         return 0
 
-    # ------------------------------------------------------------------ Winograd F(2x2, 3x3) and F(2x2, 4x4)
-    _MATS = {
-        3: (np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]),
-            np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64),
-            np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)),
-        # Cook-Toom over 0, 1, -1, -1/2, inf (csrc/winograd.hip w4_G / w4_BT / w4_AT)
-        4: (np.array([[1, 0, 0, 0], [1 / 3, 1 / 3, 1 / 3, 1 / 3], [-1, 1, -1, 1], [8 / 3, -4 / 3, 2 / 3, -1 / 3], [0, 0, 0, 1]]),
-            np.array([[1, 2, -1, -2, 0], [0, .5, 1.5, 1, 0], [0, -.5, -.5, 1, 0], [0, -1, 0, 1, 0], [0, -.5, -1, .5, 1]]),
-            np.array([[1, 1, 1, 1, 0], [0, 1, -1, -.5, 1]])),
-    }
-
-    @staticmethod
-    def _r(r):
-        return 3 if r == 0 else r
-
-    def nirgan_wino_ws_elems(self, B, H, W, Cc, K):
-        return self.nirgan_wino_ws_elems_r(B, H, W, Cc, K, 3)
-
-    def nirgan_wino_ws_elems_r(self, B, H, W, Cc, K, r):
-        nf = (self._r(r) + 1) ** 2
-        return nf * B * ((H + 1) // 2) * ((W + 1) // 2) * Cc + nf * K * Cc
-
-    def nirgan_wino_weights(self, w, K, Cc, flip, U, stream=None):
-        return self.nirgan_wino_weights_r(w, K, Cc, 3, flip, U)
-
-    def nirgan_wino_weights_r(self, w, K, Cc, r, flip, U, stream=None):
-        self.calls.append("wino_w")
-        r = self._r(r)
-        Gm = self._MATS[r][0]
-        if flip:
-            g = arr(w, K * Cc * r * r).reshape(Cc, K, r, r).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
-        else:
-            g = arr(w, K * Cc * r * r).reshape(K, Cc, r, r).astype(np.float64)
-        u = np.einsum("ai,kcij,bj->abkc", Gm, g, Gm)
-        arr(U, (r + 1) ** 2 * K * Cc)[:] = u.reshape(-1).astype(np.float32)
-        return 0
-
-    def nirgan_wino_weights_batch(self, jobs, njobs, total_blocks, stream=None):
-        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 8)).from_address(int(jobs))).reshape(njobs, 8)
-        blocks = 0
-        for w, U, K, Cc, r, flip, first, _ in J:
-            if first != blocks:
-                return self._fail("wino_weights_batch: first_block mismatch")
-            rc = self.nirgan_wino_weights_r(int(w), int(K), int(Cc), int(r), int(flip), int(U))
-            if rc:
-                return rc
-            blocks += (int(K) * int(Cc) + 255) // 256
-        return 0 if blocks == total_blocks else self._fail("wino_weights_batch: total_blocks mismatch")
-
-    def _wino_tiles(self, d):
-        r = self._r(d.r)
-        a = r + 1
-        B, H, W, Cc = d.B, d.H, d.W, d.C
-        TH, TW = (H + 1) // 2, (W + 1) // 2
-        x0 = arr(d.x, B * d.x_hp * d.x_wp * Cc).reshape(B, d.x_hp, d.x_wp, Cc).astype(np.float64)
-        x = np.zeros((B, 2 * TH + r - 1, 2 * TW + r - 1, Cc))       # odd extents: one zero line past the buffer (feeds unused outputs)
-        x[:, :d.x_hp, :d.x_wp] = x0
-        tiles = np.stack([np.stack([x[:, i:i + 2 * TH:2, j:j + 2 * TW:2] for j in range(a)], 0) for i in range(a)], 0)   # [a][a][B][TH][TW][C]
-        BT = self._MATS[r][1]
-        return np.einsum("ai,ijbyxc,lj->albyxc", BT, tiles, BT)
-
-    def nirgan_wino_input(self, ref, stream=None):
-        d = obj(ref)
-        V = self._wino_tiles(d)
-        arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
-        return 0
-
-    def nirgan_wino_input_norm(self, ref, y, mean, rstd, act, slope, stream=None):
-        d = obj(ref)
-        self.calls.append("wino_in_norm")
-        if self._r(d.r) != 3:
-            return self._fail("wino_input_norm: 3x3 filters only")
-        B, H, W, Cc = d.B, d.H, d.W, d.C
-        yv = arr(y, B * H * W * Cc).reshape(B, H, W, Cc)
-        m, r = arr(mean, B * Cc).reshape(B, 1, 1, Cc), arr(rstd, B * Cc).reshape(B, 1, 1, Cc)
-        a = self._act(((yv - m) * r).astype(np.float32).astype(np.float64), act, slope).astype(np.float32)       # in_apply's fp32 arithmetic
-        hh, ww = reflect(np.arange(H + 2) - 1, H), reflect(np.arange(W + 2) - 1, W)
-        x = np.ascontiguousarray(a[:, hh][:, :, ww])
-        keep = d.x, d.x_hp, d.x_wp
-        d.x, d.x_hp, d.x_wp = x.ctypes.data, H + 2, W + 2
-        V = self._wino_tiles(d)
-        d.x, d.x_hp, d.x_wp = keep
-        arr(d.V, V.size)[:] = V.reshape(-1).astype(np.float32)
-        return 0
-
-    def nirgan_wino_gemm(self, ref, stream=None):
-        """The GEMM stage alone: consumes the V a preceding input transform left in the workspace, like the device."""
-        d = obj(ref)
-        self.calls.append("wino")
-        r = self._r(d.r)
-        a = r + 1
-        if r not in (3, 4) or d.C % 32 or d.K % 128 or d.x_hp != d.H + r - 1 or d.x_wp != d.W + r - 1 or d.H < 2 or d.W < 2:
-            return self._fail("wino_conv: bad geometry")
-        B, H, W, Cc, K = d.B, d.H, d.W, d.C, d.K
-        TH, TW = (H + 1) // 2, (W + 1) // 2
-        T = B * TH * TW
-        if d.V_elems < a * a * T * Cc:
-            return self._fail("wino_conv: V workspace too small")
-        U = arr(d.U, a * a * K * Cc).reshape(a, a, K, Cc).astype(np.float64)
-        V = arr(d.V, a * a * T * Cc).reshape(a, a, B, TH, TW, Cc).astype(np.float64)
-        M = np.einsum("albyxc,alkc->albyxk", V, U)
-        AT = self._MATS[r][2]
-        Y = np.einsum("pa,albyxk,ql->pqbyxk", AT, M, AT)                             # [2][2][B][TH][TW][K]
-        out = arr(d.y, B * H * W * K).reshape(B, H, W, K)
-        bias = arr(d.bias, K)
-        for p_ in range(2):
-            for q_ in range(2):
-                v = Y[p_, q_]
-                if bias is not None:
-                    v = v + bias
-                nh, nw = len(range(p_, H, 2)), len(range(q_, W, 2))
-                out[:, p_::2, q_::2] = v[:, :nh, :nw].astype(np.float32)
-        return 0
-
-    def nirgan_wino_conv3x3(self, ref, stream=None):
-        d = obj(ref)
-        r = self._r(d.r)
-        if r not in (3, 4) or d.x_hp != d.H + r - 1 or d.x_wp != d.W + r - 1 or d.H < 2 or d.W < 2:
-            return self._fail("wino_conv: bad geometry")
-        if d.V_elems < (r + 1) ** 2 * d.B * ((d.H + 1) // 2) * ((d.W + 1) // 2) * d.C:
-            return self._fail("wino_conv: V workspace too small")
-        rc = self.nirgan_wino_input(ref)
-        return rc if rc else self.nirgan_wino_gemm(ref)
-
-    def nirgan_wino_dy(self, ref, stream=None):
-        d = obj(ref)
-        self.calls.append("wino_dy")
-        r = self._r(d.r)
-        a = r + 1
-        B, H, W, K = d.B, d.H, d.W, d.K
-        TH, TW = (H + 1) // 2, (W + 1) // 2
-        T = B * TH * TW
-        if d.Yt_elems < a * a * T * K or d.dy_hp != H + 2 * d.dy_pad:
-            return self._fail("wino_dy: bad geometry / workspace")
-        dy = arr(d.dy, B * d.dy_hp * d.dy_wp * K).reshape(B, d.dy_hp, d.dy_wp, K).astype(np.float64)
-        z = np.zeros((B, 2 * TH, 2 * TW, K))
-        z[:, :H, :W] = dy[:, d.dy_pad:d.dy_pad + H, d.dy_pad:d.dy_pad + W]
-        tiles = np.stack([np.stack([z[:, i::2, j::2] for j in range(2)], 0) for i in range(2)], 0)       # [2][2][B][TH][TW][K]
-        A = self._MATS[r][2].T                                                                           # a x 2
-        Yt = np.einsum("ia,abnyxk,jb->ijnyxk", A, tiles, A)
-        arr(d.Yt, a * a * T * K)[:] = Yt.reshape(-1).astype(np.float32)
-        return 0
-
-    def nirgan_wino_input_dy(self, cref, yref, stream=None):
-        c, y = obj(cref), obj(yref)
-        r = self._r(c.r)
-        if c.x != y.dy or y.dy_pad != r - 1 or c.H != y.H + r - 1 or c.W != y.W + r - 1 or c.C != y.K or self._r(y.r) != r:
-            return self._fail("wino_input_dy: the two descriptors do not describe the same output-gradient buffer")
-        rc = self.nirgan_wino_input(cref)
-        return rc if rc else self.nirgan_wino_dy(yref)
-
-    def nirgan_wino_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
-        return self.nirgan_wino_wgrad_finish_r(slabs, nsplit, K, Cc, 3, grad, accumulate)
-
-    def nirgan_wino_wgrad_finish_r(self, slabs, nsplit, K, Cc, r, grad, accumulate, stream=None):
-        self.calls.append("wino_fin")
-        r = self._r(r)
-        a = r + 1
-        u = arr(slabs, a * a * nsplit * K * Cc).reshape(a, a, nsplit, K, Cc).astype(np.float64).sum(2)
-        Gm = self._MATS[r][0]
-        g = np.einsum("ai,abkc,bj->kcij", Gm, u, Gm)
-        o = arr(grad, K * Cc * r * r).reshape(K, Cc, r, r)
-        if accumulate:
-            o += g.astype(np.float32)
-        else:
-            o[:] = g.astype(np.float32)
-        return 0
-
     # ------------------------------------------------------------------ Winograd F(4x4, 3x3) / F(4x4, 4x4) (csrc/wino6.hip)
     _W6 = {
         3: (np.array([[1 / 2, 0, 0], [1 / 6, 1 / 6, 1 / 6], [1 / 6, -1 / 6, 1 / 6], [1 / 30, 1 / 15, 2 / 15], [16 / 15, -8 / 15, 4 / 15], [0, 0, 1 / 2]]),
@@ -720,19 +552,6 @@ class EmuBackend:
         rc = self.nirgan_wino6_input(cref)
         return rc if rc else self.nirgan_wino6_dy(yref)
 
-    def nirgan_wino6_input_dy_norm(self, cref, yref, nref, stream=None):
-        """dY evaluated from the instance-norm backward descriptor (whose own call ran with dy = NULL: reductions only), then the two
-        transforms.  The emulator materialises dY in the buffer the descriptors describe (the device never touches it)."""
-        c, y, n = obj(cref), obj(yref), obj(nref)
-        self.calls.append("wino6_dy_norm")
-        if n.dy or not n.norm or n.B != c.B or n.C != c.C or n.H != y.H or n.W != y.W or self._r6(c.r) != 3:
-            return self._fail("wino6_input_dy_norm: bad instance-norm descriptor")
-        full = type(n)()
-        C.memmove(C.byref(full), C.byref(n), C.sizeof(n))
-        full.dy, full.d_hp, full.d_wp, full.d_pad = y.dy, y.dy_hp, y.dy_wp, y.dy_pad
-        rc = self.nirgan_instnorm_bwd(full)
-        return rc if rc else self.nirgan_wino6_input_dy(cref, yref)
-
     def nirgan_wino6_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
         return self.nirgan_wino6_wgrad_finish_r(slabs, nsplit, K, Cc, 3, grad, accumulate)
 
@@ -761,10 +580,6 @@ class EmuBackend:
             if rc:
                 return rc
         return 0
-
-    def nirgan_wino_wgrad_pair(self, cref, wref, stream=None):
-        rc = self.nirgan_wino_gemm(cref)              # the input transform of cref has run (nirgan_wino_input / _input_dy)
-        return rc if rc else self.nirgan_wgrad_igemm(wref)
 
     # ------------------------------------------------------------------ histogram matching
     def nirgan_hist_match_ws_bytes(self, B, N):

@@ -643,249 +643,6 @@ def test_bf16_twins_and_twin_fed_convolution():
     close(go.t, go2.t, 1e-6, "twin-fed conv vs fp32-fed conv")
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128), (1, 64, 64, 256, 256), (3, 6, 4, 32, 128), (2, 9, 7, 64, 128), (1, 69, 69, 256, 256)])
-def test_winograd_conv3x3_matches_direct(shape):
-    """nirgan_wino_weights + nirgan_wino_conv3x3 against torch's conv2d (the reference's nn.Conv2d arithmetic) and the numpy
-    restatement: fp32 rounding only (tolerance 3e-5 of the output's max; the direct MFMA path sits at 1e-5)."""
-    import ctypes as C
-    B, H, W, Cc, K = shape
-    g = torch.Generator().manual_seed(21)
-    x = torch.randn(B, H + 2, W + 2, Cc, generator=g)                    # halo included: any values (reflect or zero in the nets)
-    w = torch.randn(K, Cc, 3, 3, generator=g) * 0.05
-    b = torch.randn(K, generator=g)
-    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1).float()
-    outs = []
-    emu = EmuBackend()
-    for dev, be in ((DEV, None), ("cpu", emu)):
-        xt, wt, bt = x.to(dev).contiguous(), w.to(dev).contiguous(), b.to(dev)
-        T = B * ((H + 1) // 2) * ((W + 1) // 2)
-        U = torch.zeros(16 * K * Cc, device=dev)
-        V = torch.zeros(16 * T * Cc, device=dev)
-        y = torch.zeros(B, H, W, K, device=dev)
-        zero = torch.zeros(64, device=dev)
-        d = L.WinoDesc()
-        d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = xt.data_ptr(), H + 2, W + 2, B, H, W, Cc, K
-        d.U, d.bias, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), bt.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
-        if be is None:
-            st = torch.cuda.current_stream().cuda_stream
-            L.call("nirgan_wino_weights", wt.data_ptr(), K, Cc, 0, U.data_ptr(), st)
-            L.call("nirgan_wino_conv3x3", C.byref(d), st)
-            torch.cuda.synchronize()
-        else:
-            assert be.nirgan_wino_weights(wt.data_ptr(), K, Cc, 0, U.data_ptr()) == 0
-            assert be.nirgan_wino_conv3x3(d) == 0
-        outs.append(y.cpu())
-    close(outs[1], ref, 1e-5, "restatement vs torch")
-    close(outs[0], ref, 3e-5, "device vs torch")
-    close(outs[0], outs[1], 3e-5, "device vs restatement")
-
-
-def test_winograd_data_gradient_matches_autograd():
-    """nirgan_wino_weights(transpose_flip=1) + nirgan_wino_conv3x3 over dY with a zero halo of 2 = the data gradient of
-    nn.Conv2d(C, K, 3, padding=1) on the PADDED input extent (the ring is the adjoint of the reflect / zero padding's source)."""
-    import ctypes as C
-    B, H, W, Cin, Cout = 2, 10, 14, 128, 64          # forward: Cin -> Cout; the gradient contracts over Cout and has Cin outputs
-    g = torch.Generator().manual_seed(4)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
-    dy = torch.randn(B, Cout, H, W, generator=g)
-    # reference: gradient wrt the padded input xp (B, Cin, H+2, W+2) of conv2d(xp, w) (no padding) -- full correlation
-    xp = torch.zeros(B, Cin, H + 2, W + 2, dtype=torch.float64, requires_grad=True)
-    torch.nn.functional.conv2d(xp, w.double()).backward(dy.double())
-    ref = xp.grad.permute(0, 2, 3, 1).float()
-    z = torch.zeros(B, H + 4, W + 4, Cout)
-    z[:, 2:-2, 2:-2] = dy.permute(0, 2, 3, 1)
-    Hp, Wp = H + 2, W + 2
-    T = B * (Hp // 2) * (Wp // 2)
-    zt, wt = z.to(DEV).contiguous(), w.to(DEV).contiguous()
-    U, V = torch.zeros(16 * Cin * Cout, device=DEV), torch.zeros(16 * T * Cout, device=DEV)
-    y, zero = torch.zeros(B, Hp, Wp, Cin, device=DEV), torch.zeros(64, device=DEV)
-    d = L.WinoDesc()
-    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = zt.data_ptr(), H + 4, W + 4, B, Hp, Wp, Cout, Cin
-    d.U, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
-    st = torch.cuda.current_stream().cuda_stream
-    L.call("nirgan_wino_weights", wt.data_ptr(), Cin, Cout, 1, U.data_ptr(), st)
-    L.call("nirgan_wino_conv3x3", C.byref(d), st)
-    torch.cuda.synchronize()
-    close(y.cpu(), ref, 3e-5, "winograd data gradient")
-    emu = EmuBackend()
-    U2, V2, y2 = torch.zeros(16 * Cin * Cout), torch.zeros(16 * T * Cout), torch.zeros(B, Hp, Wp, Cin)
-    zc, wc = z.contiguous(), w.contiguous()
-    d.x, d.U, d.V, d.y, d.zero_page = zc.data_ptr(), U2.data_ptr(), V2.data_ptr(), y2.data_ptr(), torch.zeros(64).data_ptr()
-    assert emu.nirgan_wino_weights(wc.data_ptr(), Cin, Cout, 1, U2.data_ptr()) == 0 and emu.nirgan_wino_conv3x3(d) == 0
-    close(y2, ref, 1e-5, "restatement of the data gradient")
-
-
-def _wino4_case(B, H, W, Cc, K, seed=23):
-    """F(2x2,4x4) problem: x [B][H+3][W+3][C] (the buffer a 4x4 / padding-1 convolution with H x W outputs reads), w [K][C][4][4]."""
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, H + 3, W + 3, Cc, generator=g)
-    w = torch.randn(K, Cc, 4, 4, generator=g) * 0.05
-    b = torch.randn(K, generator=g)
-    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1).float()
-    return x, w, b, ref
-
-
-def _run_wino4(x, w, b, dev, be, fsplit=0):
-    import ctypes as C
-    B, H, W, Cc, K = x.shape[0], x.shape[1] - 3, x.shape[2] - 3, x.shape[3], w.shape[0]
-    xt, wt, bt = x.to(dev).contiguous(), w.to(dev).contiguous(), b.to(dev)
-    T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    U, V = torch.zeros(25 * K * Cc, device=dev), torch.zeros(25 * T * Cc, device=dev)
-    y, zero = torch.zeros(B, H, W, K, device=dev), torch.zeros(64, device=dev)
-    d = L.WinoDesc()
-    d.r = 4
-    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = xt.data_ptr(), H + 3, W + 3, B, H, W, Cc, K
-    d.U, d.bias, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), bt.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), zero.data_ptr()
-    if fsplit > 1:
-        ws = torch.full((fsplit * y.numel(),), float("nan"), device=dev)
-        d.fsplit, d.split_ws, d.split_ws_elems = fsplit, ws.data_ptr(), ws.numel()
-    if be is None:
-        st = torch.cuda.current_stream().cuda_stream
-        L.call("nirgan_wino_weights_r", wt.data_ptr(), K, Cc, 4, 0, U.data_ptr(), st)
-        L.call("nirgan_wino_conv3x3", C.byref(d), st)
-        torch.cuda.synchronize()
-    else:
-        assert be.nirgan_wino_weights_r(wt.data_ptr(), K, Cc, 4, 0, U.data_ptr()) == 0
-        assert be.nirgan_wino_conv3x3(d) == 0
-    return y.cpu()
-
-
-@pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128), (2, 31, 31, 256, 512), (3, 7, 5, 32, 128), (1, 6, 9, 96, 256)])
-def test_winograd_conv4x4_matches_direct(shape):
-    """F(2x2,4x4) (the PatchGAN's stride-1 4x4 layer, 25 products per 2x2 outputs): device and numpy restatement against torch's
-    conv2d in float64.  Transform constants 0, +-1/2, +-1, 3/2, 2 on the activations (dyadic), thirds on the weights; tolerance
-    5e-5 of the output's max (F(2x2,3x3): 3e-5, direct MFMA: 1e-5)."""
-    x, w, b, ref = _wino4_case(*shape)
-    dev_y = _run_wino4(x, w, b, DEV, None)
-    emu_y = _run_wino4(x, w, b, "cpu", EmuBackend())
-    close(emu_y, ref, 1e-5, "restatement vs torch")
-    close(dev_y, ref, 5e-5, "device vs torch")
-    close(dev_y, emu_y, 5e-5, "device vs restatement")
-    # the frequencies divided over 3 / 25 workgroups per tile (launches with few tiles): partial outputs + one reduce pass
-    for fs in (3, 25):
-        close(_run_wino4(x, w, b, DEV, None, fsplit=fs), dev_y, 2e-6, f"fsplit {fs}")
-
-
-@pytest.mark.parametrize("hw", [(9, 13), (8, 10), (32, 32)])
-def test_winograd4_backward_pair_matches_autograd(hw):
-    """Backward of Conv2d(Cin, Cout, 4, stride 1, padding 1) as the discriminator engine emits it in exact-fp32 mode: Winograd data
-    gradient over the padded input extent (dY with a zero halo of 3, flipped filter) fused with the Winograd-domain weight gradient
-    (25 planes, then G^T dU G) against torch autograd of conv2d on the padded input; even and odd output extents."""
-    from nirgan_hip.engine import emit_wino, emit_wino_wgrad, SlabPool, _FullExtent
-    Hi, Wi = hw                                                      # input extent; outputs are (Hi-1) x (Wi-1)
-    H, W = Hi - 1, Wi - 1
-    B, Cin, Cout = 2, 128, 256
-    g = torch.Generator().manual_seed(14)
-    x = torch.randn(B, Hi + 2, Wi + 2, Cin, generator=g)
-    w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
-    dyv = torch.randn(B, H, W, Cout, generator=g)
-    xp = x.permute(0, 3, 1, 2).double().requires_grad_(True)
-    wt = w.double().requires_grad_(True)
-    torch.nn.functional.conv2d(xp, wt).backward(dyv.permute(0, 3, 1, 2).double())
-    ref_gx, ref_gw = xp.grad.permute(0, 2, 3, 1).float(), wt.grad.float()
-    tw = Twin("fp32")
-    res = []
-    for ctx in (tw.gctx, tw.cctx):
-        dev = ctx.device
-        inp = Halo(ctx, B, Hi, Wi, Cin, 1)
-        inp.t.copy_(x.to(dev))
-        dy = Halo(ctx, B, H, W, Cout, 3)
-        dy.interior().copy_(dyv.to(dev))
-        gx = Halo(ctx, B, Hi, Wi, Cin, 1)
-        gw = ctx.zeros(Cout, Cin, 4, 4)
-        wd = w.to(dev).contiguous()
-        ctx.keep.append(wd)
-        plan, pack = Plan(ctx), Plan(ctx)
-        wdesc = emit_wino(None, pack, ctx, dy, wd, None, _FullExtent(gx), H=gx.hp, W=gx.wp, cin=Cout, cout=Cin, flip=True, r=4)
-        emit_wino_wgrad(plan, ctx, dy, inp, gw, OH=H, OW=W, cin=Cin, cout=Cout, slabs_pool=SlabPool(ctx), pair_wino=wdesc, r=4)
-        res.append((pack, plan, gx, gw))
-    (gpk, gpl, ggx, ggw), (cpk, cpl, cgx, cgw) = res
-    tw.run(gpk, cpk)
-    tw.run(gpl, cpl)
-    close(cgx.t, ref_gx, 1e-5, "restatement: data gradient")
-    close(cgw, ref_gw, 1e-5, "restatement: weight gradient")
-    close(ggx.t, ref_gx, 5e-5, "device: data gradient")
-    close(ggw, ref_gw, 1e-4, "device: weight gradient")
-
-
-@pytest.mark.parametrize("hw", [(12, 16), (9, 11), (64, 64)])
-def test_winograd_input_transform_with_the_instance_norm_folded_in(hw):
-    """nirgan_instnorm_fwd(out = NULL: statistics only) + nirgan_wino_input_norm(y, mean, rstd, ReLU) = the V that the full
-    instance-norm pass (ReLU, reflect halo 1) followed by nirgan_wino_input produces -- bitwise, same fp32 arithmetic."""
-    import ctypes as C
-    H, W = hw
-    B, Cc = 2, 128
-    g = torch.Generator().manual_seed(31)
-    y = (torch.randn(B, H, W, Cc, generator=g) * 1.7 + 0.3).to(DEV)
-    st = torch.cuda.current_stream().cuda_stream
-    ctx = Ctx(DEV, "fp32")
-    yh = Halo(ctx, B, H, W, Cc, 0)
-    yh.t.copy_(y)
-    out = Halo(ctx, B, H, W, Cc, 1)
-    stats = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
-    ws = ctx.zeros(int(L.backend().nirgan_instnorm_ws_elems(B, H, W, Cc)))
-    from nirgan_hip.engine import emit_in_fwd
-    full, only = Plan(ctx), Plan(ctx)
-    emit_in_fwd(full, ctx, yh, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats, ws=ws)
-    stats2 = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
-    emit_in_fwd(only, ctx, yh, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats2, ws=ws, stats_only=True)
-    full.run()
-    T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    V1, V2 = torch.zeros(16 * T * Cc, device=DEV), torch.full((16 * T * Cc,), float("nan"), device=DEV)
-    d = L.WinoDesc()
-    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = out.ptr, H + 2, W + 2, B, H, W, Cc, 128
-    d.V, d.V_elems = V1.data_ptr(), V1.numel()
-    L.call("nirgan_wino_input", C.byref(d), st)
-    only.run()
-    assert torch.equal(stats[0], stats2[0]) and torch.equal(stats[1], stats2[1])
-    d.V = V2.data_ptr()
-    L.call("nirgan_wino_input_norm", C.byref(d), yh.ptr, stats2[0].data_ptr(), stats2[1].data_ptr(), L.ACT_RELU, 0.2, st)
-    torch.cuda.synchronize()
-    assert torch.equal(V1, V2), f"max diff {(V1 - V2).abs().max().item():.3e}"
-
-
-@pytest.mark.parametrize("hw", [(12, 16), (9, 11)])
-def test_winograd_backward_pair_matches_autograd(hw):
-    """The exact-fp32 backward of a ResnetBlock convolution as the engines emit it: Winograd data gradient (over the padded extent) and
-    Winograd-domain weight gradient (16 planes in one launch, fused with the data-gradient tiles, then G^T dU G) against torch autograd
-    of conv2d on the padded input; device and numpy restatement.  Even and odd extents."""
-    from nirgan_hip.engine import emit_wino, emit_wino_wgrad, SlabPool, _FullExtent
-    H, W = hw
-    B, Cin, Cout = 2, 128, 128
-    g = torch.Generator().manual_seed(12)
-    x = torch.randn(B, H + 2, W + 2, Cin, generator=g)               # forward input incl. its halo (reflect-written in the nets)
-    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
-    dyv = torch.randn(B, H, W, Cout, generator=g)
-    xp = x.permute(0, 3, 1, 2).double().requires_grad_(True)
-    wt = w.double().requires_grad_(True)
-    torch.nn.functional.conv2d(xp, wt).backward(dyv.permute(0, 3, 1, 2).double())
-    ref_gx, ref_gw = xp.grad.permute(0, 2, 3, 1).float(), wt.grad.float()
-    tw = Twin("fp32")
-    res = []
-    for ctx in (tw.gctx, tw.cctx):
-        dev = ctx.device
-        inp = Halo(ctx, B, H, W, Cin, 1)
-        inp.t.copy_(x.to(dev))
-        dy = Halo(ctx, B, H, W, Cout, 2)
-        dy.interior().copy_(dyv.to(dev))
-        gx = Halo(ctx, B, H, W, Cin, 1)
-        gw = ctx.zeros(Cout, Cin, 3, 3)
-        wd = w.to(dev).contiguous()
-        ctx.keep.append(wd)
-        plan, pack = Plan(ctx), Plan(ctx)
-        wdesc = emit_wino(None, pack, ctx, dy, wd, None, _FullExtent(gx), H=gx.hp, W=gx.wp, cin=Cout, cout=Cin, flip=True)
-        emit_wino_wgrad(plan, ctx, dy, inp, gw, OH=H, OW=W, cin=Cin, cout=Cout, slabs_pool=SlabPool(ctx), pair_wino=wdesc)
-        res.append((pack, plan, gx, gw))
-    (gpk, gpl, ggx, ggw), (cpk, cpl, cgx, cgw) = res
-    tw.run(gpk, cpk)
-    tw.run(gpl, cpl)
-    close(cgx.t, ref_gx, 1e-5, "restatement: data gradient")
-    close(cgw, ref_gw, 1e-5, "restatement: weight gradient")
-    close(ggx.t, ref_gx, 3e-5, "device: data gradient")
-    close(ggw, ref_gw, 1e-4, "device: weight gradient")
-
-
-# ---------------------------------------------------------------------------------- Winograd F(4x4, 3x3) (csrc/wino6.hip)
 @pytest.mark.parametrize("shape", [(2, 8, 12, 64, 128, 3), (1, 64, 64, 256, 256, 3), (3, 6, 5, 32, 128, 3), (2, 9, 7, 64, 192, 3), (1, 69, 69, 256, 256, 3),
                                    (16, 64, 64, 256, 256, 3), (2, 8, 12, 64, 128, 4), (2, 31, 31, 256, 512, 4), (3, 7, 5, 32, 128, 4), (32, 31, 31, 256, 512, 4),
                                    (2, 8, 12, 64, 128, 6), (1, 64, 64, 256, 256, 6), (3, 6, 5, 32, 128, 6), (2, 9, 7, 64, 192, 6), (1, 69, 69, 256, 256, 6),
@@ -961,7 +718,8 @@ def test_wino6_backward_matches_autograd(hw, monkeypatch):
         if "no_pair" in hw[6]:                        # two separate launches
             monkeypatch.setattr(OPT, "w6_pair", False)
     if v == 3:
-        monkeypatch.setenv("NIRGAN_NO_WINO8", "1")    # 3x3 filters: F(4x4,3x3) instead of the default F(6x6,3x3)
+        from nirgan_hip.options import OPT as _OPT
+        monkeypatch.setattr(_OPT, "winograd", "f4")   # 3x3 filters: F(4x4,3x3) instead of the default F(6x6,3x3)
     from nirgan_hip.engine import wino6_variant
     assert wino6_variant(r) == v
     # 256 input channels of the data-gradient GEMM (= the layer's output channels) take the persistent pair launch: the transform-domain
@@ -1035,65 +793,6 @@ def test_wino6_input_transform_with_the_instance_norm_folded_in(hw):
     assert torch.equal(V1, V2), f"max diff {(V1 - V2).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("case", [("fold+relu", 12, 16), ("fold+relu", 9, 11), ("skip", 64, 64), ("skip", 10, 7)])
-def test_wino6_dy_transform_with_the_instance_norm_backward_folded_in(case):
-    """nirgan_instnorm_bwd(dy = NULL: the two reductions only) + nirgan_wino6_input_dy_norm = the V / Yt that the full instance-norm
-    backward (which stores dY) followed by nirgan_wino6_input_dy produces -- bitwise: the second pass's arithmetic is evaluated inside
-    the transform and dY never exists in memory.  Both block kinds of the residual chain: first convolution (halo'd gradient folded
-    through the reflect padding, ReLU mask) and second convolution (dense skip-path sum from pass 1, no activation)."""
-    import ctypes as C
-    from nirgan_hip.engine import emit_in_bwd, emit_in_fwd
-    kind, H, W = case
-    B, Cc = 2, 128
-    g = torch.Generator().manual_seed(33)
-    ctx = Ctx(DEV, "fp32")
-    st = torch.cuda.current_stream().cuda_stream
-    yh = Halo(ctx, B, H, W, Cc, 0)
-    yh.t.copy_((torch.randn(B, H, W, Cc, generator=g) * 1.3 + 0.2).to(DEV))
-    out = Halo(ctx, B, H, W, Cc, 1)
-    stats = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
-    ws = ctx.zeros(int(L.backend().nirgan_instnorm_ws_elems(B, H, W, Cc)))
-    f = Plan(ctx)
-    emit_in_fwd(f, ctx, yh, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats, ws=ws)
-    f.run()
-    gh = Halo(ctx, B, H, W, Cc, 1)
-    gh.t.copy_(torch.randn(B, H + 2, W + 2, Cc, generator=g).to(DEV))
-    g2 = Halo(ctx, B, H, W, Cc, 0)
-    g2.t.copy_(torch.randn(B, H, W, Cc, generator=g).to(DEV))
-    gsum = Halo(ctx, B, H, W, Cc, 0)
-    dy = Halo(ctx, B, H, W, Cc, 2)
-    kw = dict(g=gh, g_fold=True, y=yh, stats=stats, norm=True, dy=dy, ws=ws, shape=(B, H, W, Cc))
-    if kind == "skip":
-        kw.update(g2=g2, gsum=gsum, act=L.ACT_NONE)
-    else:
-        kw.update(act=L.ACT_RELU)
-    full, sums = Plan(ctx), Plan(ctx)
-    emit_in_bwd(full, ctx, **kw)
-    nd = emit_in_bwd(sums, ctx, sums_only=True, **kw)
-    Td, Ty = B * ((H + 5) // 4) * ((W + 5) // 4), B * ((H + 3) // 4) * ((W + 3) // 4)
-    res = []
-    for fused in (False, True):
-        V = torch.full((36 * Td * Cc,), float("nan"), device=DEV)
-        Yt = torch.full((36 * Ty * Cc,), float("nan"), device=DEV)
-        d = L.Wino6Desc()
-        d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = dy.ptr, H + 4, W + 4, B, H + 2, W + 2, Cc, 128
-        d.V, d.V_elems = V.data_ptr(), V.numel()
-        yd = L.WinoDyDesc()
-        yd.dy, yd.dy_hp, yd.dy_wp, yd.dy_pad, yd.B, yd.H, yd.W, yd.K = dy.ptr, H + 4, W + 4, 2, B, H, W, Cc
-        yd.Yt, yd.Yt_elems, yd.r = Yt.data_ptr(), Yt.numel(), 3
-        if fused:
-            dy.t.fill_(float("nan"))          # the fused pass must not read the buffer
-            sums.run()
-            L.call("nirgan_wino6_input_dy_norm", C.byref(d), C.byref(yd), C.byref(nd), st)
-        else:
-            full.run()
-            L.call("nirgan_wino6_input_dy", C.byref(d), C.byref(yd), st)
-        torch.cuda.synchronize()
-        res.append((V, Yt))
-    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0]), "V differs"
-    assert torch.equal(res[0][1], res[1][1]), "Yt differs"
-
-
 @pytest.mark.parametrize("shape", [(2, 9, 10, 1), (1, 70, 67, 0), (16, 256, 256, 0), (2, 276, 276, 10), (3, 5, 130, 2)])
 def test_direct_last_layer_kernels(shape):
     """Conv2d(64, 1, 7) + bias + tanh + crop and its three gradients as direct kernels (csrc/endconv.hip) against torch's conv2d +
@@ -1157,7 +856,7 @@ def test_wino6_output_leaves_the_instance_norm_partial_sums(shape):
 def test_conv_epilogue_leaves_the_instance_norm_partial_sums(case):
     """A ConvIN layer with the direct tiles: the convolution's epilogue leaves per-(64 pixels) partial sums of its output without the
     bias, nirgan_instnorm_fwd merges them (stats_chunks, stats_shift = bias) -- the output of the layer (normalised, ReLU, halo) equals
-    the one produced with the separate statistics pass (NIRGAN_NO_CONV_STATS=1) to fp32 rounding; device against the numpy restatement
+    the one produced with the separate statistics pass (OPT.epilogue_stats = False) to fp32 rounding; device against the numpy restatement
     too.  Stride-1, stride-2, and the four sub-pixel phases of a transposed convolution numbering their chunks into one workspace."""
     import os
     from nirgan_hip.engine import ConvIN
@@ -1168,10 +867,9 @@ def test_conv_epilogue_leaves_the_instance_norm_partial_sums(case):
 
     def build(ctx, stats):
         from nirgan_hip.engine import Weights, _Scratch, SlabPool
-        os.environ.pop("NIRGAN_NO_CONV_STATS", None)
-        os.environ["NIRGAN_CONV_STATS_MIN"] = "0"          # small layers too (the engines keep the separate pass below 16 K pixels)
-        if not stats:
-            os.environ["NIRGAN_NO_CONV_STATS"] = "1"
+        from nirgan_hip.options import OPT
+        OPT.epilogue_min_pixels = 0          # small layers too (the engines keep the separate pass below 16 K pixels)
+        OPT.epilogue_stats = bool(stats)
         try:
             g = torch.Generator().manual_seed(5)
             eng = Eng()
@@ -1195,8 +893,7 @@ def test_conv_epilogue_leaves_the_instance_norm_partial_sums(case):
             plan.run()
             return layer.out.t.detach().cpu().clone(), layer.stats[0].cpu().clone(), layer.stats[1].cpu().clone(), plan
         finally:
-            os.environ.pop("NIRGAN_NO_CONV_STATS", None)
-            os.environ.pop("NIRGAN_CONV_STATS_MIN", None)
+            OPT.reset()
 
     gctx = Ctx(DEV, "fp32")
     o1, m1, r1, plan1 = build(gctx, True)

@@ -120,18 +120,16 @@ def test_golden_small_nets_fused_step(golden_dir, name):
         close(pD[k], p0, 1e-6, "adam " + k)
 
 
-@pytest.mark.parametrize("variant", ["F(6x6,3x3)", "F(4x4,3x3)", "F(2x2,3x3)"])
+@pytest.mark.parametrize("variant", ["F(6x6,3x3)", "F(4x4,3x3)", "direct"])
 def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     """ngf = ndf = 32 on 64x64 tiles: every Winograd variant at small tile counts in one fused step against the oracle -- residual blocks
     (128 channels at 16x16: the instance-norm apply folded into the second convolution's input transform, fused dY transforms,
     transform-domain weight gradient) and the PatchGAN's 4x4 layer (128 -> 256 channels at 8x8 -> 7x7: odd extent): F(6x6,3x3) / F(4x4,4x4) by
-    default, F(4x4,3x3) under NIRGAN_NO_WINO8=1, F(2x2,3x3) / F(2x2,4x4) with their frequency-split GEMMs under NIRGAN_NO_WINO6=1."""
+    default, F(4x4,3x3) with OPT.winograd = "f4", the direct tiles everywhere with OPT.winograd = "off"."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
-    if variant == "F(2x2,3x3)":
-        monkeypatch.setenv("NIRGAN_NO_WINO6", "1")
-    if variant == "F(4x4,3x3)":
-        monkeypatch.setenv("NIRGAN_NO_WINO8", "1")
+    from nirgan_hip.options import OPT
+    monkeypatch.setattr(OPT, "winograd", {"F(6x6,3x3)": "f6", "F(4x4,3x3)": "f4", "direct": "off"}[variant])
     torch.manual_seed(7)
     netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 32, "basic", 3, "instance", "normal", 0.02)
@@ -142,18 +140,15 @@ def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     tr = Pix2PixTrainer(netG.to(DEV), netD.to(DEV), n_blocks=6, lr=0.0)
     out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
     names = [n for pl in (tr.G.fwd, tr.G.bwd, tr.D2.fwd, tr.D2.bwd, tr.D1.bwd_pred) for n, _ in pl.ops]
-    if variant != "F(2x2,3x3)":      # residual blocks as F(6x6,3x3) / F(4x4,3x3) AND the PatchGAN's 4x4 layer as F(4x4,4x4): no F(2x2) launch left
+    if variant != "direct":      # residual blocks as F(6x6,3x3) / F(4x4,3x3) AND the PatchGAN's 4x4 layer as F(4x4,4x4)
         rcodes = {a[0]._obj.r for pl in (tr.G.fwd, tr.G.bwd) for n, a in pl.ops if n == "nirgan_wino6_gemm"}
         assert rcodes == ({6} if variant == "F(6x6,3x3)" else {3}), rcodes
         for want in ("nirgan_wino6_input_norm", "nirgan_wino6_input_dy", "nirgan_wino6_gemm", "nirgan_wino6_gemm_wgrad_pair", "nirgan_wino6_output",
                      "nirgan_wino6_wgrad_finish_r"):
             assert want in names, want
-        assert not any(n in ("nirgan_wino_gemm", "nirgan_wino_wgrad_pair", "nirgan_wino_input") for n in names)
         assert sum(1 for pl in (tr.D2.fwd, tr.D2.bwd, tr.D1.fwd, tr.D1.bwd_pred) for n, a in pl.ops if n.startswith("nirgan_wino6_gemm")) == 4
     else:
-        for want in ("nirgan_wino_input_dy", "nirgan_wino_wgrad_pair", "nirgan_wino_wgrad_finish_r", "nirgan_wino_gemm", "nirgan_wino_input_norm"):
-            assert want in names, want
-        assert not any(n.startswith("nirgan_wino6") for n in names)
+        assert "nirgan_conv_wgrad_pair" in names and not any(n.startswith("nirgan_wino6") for n in names)
     ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
     o = ref.step(rgb, nir)
     close(tr.G.pred, ref.last["pred"], 1e-3, "pred")
@@ -851,7 +846,7 @@ def test_size_512_and_128_forward_against_oracle():
 @pytest.mark.parametrize("cfg", [(32, 2, 64), (64, 2, 256)])
 def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypatch, cfg):
     """The data gradient's output transform in its fused mode (csrc/wino6.hip::wino6_output_inbwd_kernel: reflect fold in registers,
-    skip gradient, dense folded gradient, partial sums of the consumer's first backward pass; NIRGAN_NO_INBWD_FUSE=1 turns it off) against the
+    skip gradient, dense folded gradient, partial sums of the consumer's first backward pass; OPT.fuse_inbwd = False turns it off) against the
     separate first pass: same forward (bitwise), gradients equal to fp32 rounding -- the backward has no branch that a
     rounding difference could flip, the masks come from the forward."""
     from model import networks
@@ -860,10 +855,8 @@ def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypat
     rgb, nir = synth(B, size, size, 77)
 
     def run(fused):
-        if fused:
-            monkeypatch.delenv("NIRGAN_NO_INBWD_FUSE", raising=False)
-        else:
-            monkeypatch.setenv("NIRGAN_NO_INBWD_FUSE", "1")
+        from nirgan_hip.options import OPT
+        monkeypatch.setattr(OPT, "fuse_inbwd", bool(fused))
         torch.manual_seed(3)
         netG = networks.define_G(3, 1, ngf, "resnet_6blocks", "instance", False, "normal", 0.02)
         netD = networks.define_D(4, ngf, "basic", 3, "instance", "normal", 0.02)
@@ -878,7 +871,7 @@ def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypat
     p0, g0, d0, nf0, np0 = run(False)
     assert nf1 == 12 and np1 == 12 and nf0 == 0 and np0 == 0, (nf1, np1, nf0, np0)
     assert torch.equal(p1, p0)
-    assert ((d1 - d0).norm() / d0.norm()).item() < 1e-6        # the discriminator's own backward is untouched (its live bias uses float atomics)
+    assert ((d1 - d0).norm() / d0.norm()).item() < 1e-6        # the discriminator's own backward is untouched (fixed-order reductions: only the fusion's own rounding differs)
     rel = ((g1 - g0).norm() / g0.norm()).item()
     assert rel < 2e-5, rel
 
@@ -886,16 +879,14 @@ def test_instance_norm_backward_first_pass_inside_the_output_transform(monkeypat
 def test_instance_norm_backward_first_pass_inside_the_conv_epilogues(monkeypatch):
     """The up/down-sampling layers' data gradients (direct tiles) take the consumer layer's first backward pass in their epilogue
     (nirgan_conv_desc.fuse_*, from 16 K pixels per sample: the 128x128 maps of a 128x128 tile) -- against the separate pass
-    (NIRGAN_NO_CONV_INBWD=1): same forward bitwise, gradients equal to fp32 rounding."""
+    (OPT.fuse_inbwd = False): same forward bitwise, gradients equal to fp32 rounding."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
     rgb, nir = synth(2, 128, 128, 78)
 
     def run(fused):
-        if fused:
-            monkeypatch.delenv("NIRGAN_NO_CONV_INBWD", raising=False)
-        else:
-            monkeypatch.setenv("NIRGAN_NO_CONV_INBWD", "1")
+        from nirgan_hip.options import OPT
+        monkeypatch.setattr(OPT, "fuse_inbwd", bool(fused))
         torch.manual_seed(3)
         netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02)
         netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)

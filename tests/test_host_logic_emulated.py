@@ -660,36 +660,15 @@ def test_fused_trainer_sees_external_weight_changes(emu, golden_dir):
     assert abs(after["loss_G"] - float(z["loss_G"])) > 1e-3 * abs(float(z["loss_G"]))      # and it did change something
 
 
-def test_winograd_4x4_restatement_matches_conv2d(emu):
-    """The numpy restatement of F(2x2,4x4) (the matrices csrc/winograd.hip uses for the PatchGAN's stride-1 4x4 layer) against torch's
-    conv2d: forward over an odd extent, and the flipped-filter data gradient."""
-    B, H, W, Cc, K = 2, 5, 8, 32, 128
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(B, H + 3, W + 3, Cc, generator=g)
-    w = (torch.randn(K, Cc, 4, 4, generator=g) * 0.05).contiguous()
-    b = torch.randn(K, generator=g)
-    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double()).permute(0, 2, 3, 1).float()
-    T = B * ((H + 1) // 2) * ((W + 1) // 2)
-    U, V, y = torch.zeros(25 * K * Cc), torch.zeros(25 * T * Cc), torch.zeros(B, H, W, K)
-    d = L.WinoDesc()
-    d.r = 4
-    d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = x.data_ptr(), H + 3, W + 3, B, H, W, Cc, K
-    d.U, d.bias, d.V, d.V_elems, d.y, d.zero_page = U.data_ptr(), b.data_ptr(), V.data_ptr(), V.numel(), y.data_ptr(), torch.zeros(64).data_ptr()
-    assert emu.nirgan_wino_weights_r(w.data_ptr(), K, Cc, 4, 0, U.data_ptr()) == 0 and emu.nirgan_wino_conv3x3(d) == 0
-    close(y, ref, 1e-5, "F(2x2,4x4) forward")
-    d.x_hp += 1                                                  # wrong buffer geometry is refused
-    assert emu.nirgan_wino_conv3x3(d) != 0
-
-
-@pytest.mark.parametrize("variant", ["F(4x4,4x4)", "F(2x2,4x4)"])
+@pytest.mark.parametrize("variant", ["F(4x4,4x4)", "direct"])
 def test_discriminator_winograd_layer_through_the_trainer(emu, monkeypatch, variant):
     """ndf = 32 makes the PatchGAN's stride-1 4x4 layer 128 -> 256 channels, wide enough for the Winograd paths (forward, data + weight
     gradient in the D step, data gradient alone in the G step): one fused step against the oracle's trainer, with the default
-    F(4x4,4x4) (49 plane GEMMs, csrc/wino6.hip) and with F(2x2,4x4) (NIRGAN_NO_WINO7=1)."""
+    F(4x4,4x4) (49 plane GEMMs, csrc/wino6.hip) and with the direct tiles (OPT.winograd = 'off')."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
-    if variant == "F(2x2,4x4)":
-        monkeypatch.setenv("NIRGAN_NO_WINO7", "1")
+    from nirgan_hip.options import OPT
+    monkeypatch.setattr(OPT, "winograd", "off" if variant == "direct" else "f6")
     torch.manual_seed(11)     # (seed 3 puts a ReLU pre-activation of the last block at 2e-7: the mask flips between two valid fp32 evaluations)
     netG = networks.define_G(3, 1, 8, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 32, "basic", 3, "instance", "normal", 0.02)
@@ -698,10 +677,10 @@ def test_discriminator_winograd_layer_through_the_trainer(emu, monkeypatch, vari
     rgb, nir = torch.rand(2, 3, 32, 32), torch.rand(2, 1, 32, 32)
     tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0)      # lr 0: the generator step sees the same D as the oracle's (no Adam sign noise)
     out = tr.step(rgb, nir).as_dict()
-    if variant == "F(2x2,4x4)":
-        assert emu.calls.count("wino") >= 4 and "wino_dy" in emu.calls and "wino_fin" in emu.calls, "the Winograd path did not run"
+    if variant == "direct":
+        assert not any(c.startswith("wino6") for c in emu.calls)
     else:       # D2 forward + its data gradient, D1 forward + its data gradient: 4 GEMM launches; one weight gradient (D step)
-        assert emu.calls.count("wino6_gemm") == 4 and emu.calls.count("wino6_fin") == 1 and emu.calls.count("wino6_dy") == 1 and "wino" not in emu.calls
+        assert emu.calls.count("wino6_gemm") == 4 and emu.calls.count("wino6_fin") == 1 and emu.calls.count("wino6_dy") == 1
     ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
     o = ref.step(rgb, nir)
     close(out["loss_D"], o["loss_D"], 1e-5, "loss_D")
@@ -737,19 +716,17 @@ def test_fused_trainer_with_the_ssim_term(emu, golden_dir):
                 close(gG[k], v, 2e-4, f"gG {k} (micro {micro})")
 
 
-@pytest.mark.parametrize("variant", ["F(6x6,3x3)", "F(4x4,3x3)", "F(2x2,3x3)"])
+@pytest.mark.parametrize("variant", ["F(6x6,3x3)", "F(4x4,3x3)", "direct"])
 def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant):
     """ngf = 32 makes the residual-block convolutions 128 -> 128 channels, wide enough for the Winograd paths: forward with the
     instance-norm apply of each block's first convolution folded into the second one's input transform, data gradient and
     transform-domain weight gradient with one transform pass over dY.  One fused step against the oracle, with the default
-    F(6x6,3x3) path (csrc/wino6.hip: 64 plane GEMMs + separate output transform), with F(4x4,3x3) (NIRGAN_NO_WINO8=1) and with
-    F(2x2,3x3) (NIRGAN_NO_WINO6=1)."""
+    F(6x6,3x3) path (csrc/wino6.hip: 64 plane GEMMs + separate output transform), with F(4x4,3x3) (OPT.winograd = "f4") and with
+    the direct tiles (OPT.winograd = "off")."""
     from model import networks
     from nirgan_hip.trainer import Pix2PixTrainer
-    if variant == "F(2x2,3x3)":
-        monkeypatch.setenv("NIRGAN_NO_WINO6", "1")
-    if variant == "F(4x4,3x3)":
-        monkeypatch.setenv("NIRGAN_NO_WINO8", "1")
+    from nirgan_hip.options import OPT
+    monkeypatch.setattr(OPT, "winograd", {"F(6x6,3x3)": "f6", "F(4x4,3x3)": "f4", "direct": "off"}[variant])
     torch.manual_seed(5)
     netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
     netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
@@ -758,12 +735,12 @@ def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant
     rgb, nir = torch.rand(2, 3, 32, 32), torch.rand(2, 1, 32, 32)
     tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0)
     out = tr.step(rgb, nir).as_dict()
-    if variant == "F(2x2,3x3)":
-        assert emu.calls.count("wino_in_norm") == 6 and emu.calls.count("wino") >= 24, "the Winograd path did not run as expected"
+    if variant == "direct":
+        assert not any(c.startswith("wino6") for c in emu.calls)
     else:
         # 12 forward + 12 data-gradient GEMM launches, 6 normalising input transforms, 12 weight-gradient finishes, V kept by the forward
         assert emu.calls.count("wino6_in_norm") == 6 and emu.calls.count("wino6_gemm") == 24 and emu.calls.count("wino6_out") == 24
-        assert emu.calls.count("wino6_fin") == 12 and emu.calls.count("wino6_dy") == 12 and "wino_in_norm" not in emu.calls
+        assert emu.calls.count("wino6_fin") == 12 and emu.calls.count("wino6_dy") == 12
         assert emu.calls.count("wino6_in") == 6 + 12          # c1 forwards + the dY transforms (no re-transform of the forward input)
         assert emu.calls.count("in_fwd_pre") == 12             # instance-norm statistics from the output transforms' partial sums
         if variant == "F(6x6,3x3)":
@@ -793,9 +770,10 @@ def test_direct_last_layer_restatement_matches_conv2d(emu):
 
 def test_conv_epilogue_statistics_through_the_trainer(emu, monkeypatch, golden_dir):
     """The direct-tile layers leave the instance norm's partial sums in the convolution's epilogue (the engines do that from 16 K
-    pixels per sample; NIRGAN_CONV_STATS_MIN=0 here): one fused step on the golden small nets, same bounds as without."""
+    pixels per sample; OPT.epilogue_min_pixels = 0 here): one fused step on the golden small nets, same bounds as without."""
     from nirgan_hip.trainer import Pix2PixTrainer
-    monkeypatch.setenv("NIRGAN_CONV_STATS_MIN", "0")
+    from nirgan_hip.options import OPT
+    monkeypatch.setattr(OPT, "epilogue_min_pixels", 0)
     z = load(golden_dir, "f1_g9_rs_pad.npz")
     nb = int(z["n_blocks"])
     netG, netD = make_nets(z, nb)
@@ -810,11 +788,12 @@ def test_conv_epilogue_statistics_through_the_trainer(emu, monkeypatch, golden_d
 
 def test_conv_epilogue_takes_the_instance_norm_backward_first_pass(emu, monkeypatch, golden_dir):
     """The sub-pixel phase launches of a stride-2 data gradient leave the consumer layer's first backward pass (sums of g_z and g_z z per
-    128-pixel tile, nirgan_conv_desc.fuse_*; the engines do that from 16 K pixels per sample, NIRGAN_CONV_STATS_MIN=0 here, forward
+    128-pixel tile, nirgan_conv_desc.fuse_*; the engines do that from 16 K pixels per sample, OPT.epilogue_min_pixels = 0 here, forward
     statistics kept on their own pass so that the forward is the golden one): gradients of the golden small net within the usual bounds."""
     from nirgan_hip.trainer import Pix2PixTrainer
-    monkeypatch.setenv("NIRGAN_CONV_STATS_MIN", "0")
-    monkeypatch.setenv("NIRGAN_NO_CONV_STATS", "1")
+    from nirgan_hip.options import OPT
+    monkeypatch.setattr(OPT, "epilogue_min_pixels", 0)
+    monkeypatch.setattr(OPT, "epilogue_stats", False)
     z = load(golden_dir, "f1_g6_d.npz")
     nb = int(z["n_blocks"])
     netG, netD = make_nets(z, nb)
