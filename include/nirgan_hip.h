@@ -583,6 +583,16 @@ int nirgan_axpy(float* y, const float* x, int64_t n, float alpha, void* stream);
 typedef struct { int op; const void* desc; } nirgan_plan_entry;
 int nirgan_run_plan(const nirgan_plan_entry* entries, int n, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Tiled inference on large scenes (create_synthetic_dataset.py:100-118 runs model(hr) per tile; model/pix2pix.py:91-93,107-108 hides
+ * tile-edge artefacts with reflect-pad / crop): scene [B][C][H][W] -> n overlapping tiles [n][C][tile][tile] (tile (b, ti, tj), b-major,
+ * covers rows ti*core - margin ..., core = tile - 2*margin, reflected at the scene's borders like F.pad(mode='reflect')), and the
+ * tiles' cores back into a scene (pixels past H x W dropped).  One launch per batch of tiles [first, first + n).
+ * ------------------------------------------------------------------------------------- */
+int64_t nirgan_tile_count(int B, int H, int W, int tile, int margin);      /* B * ceil(H/core) * ceil(W/core) */
+int nirgan_tile_gather(const float* scene, int B, int C, int H, int W, int tile, int margin, int first, int n, float* tiles, void* stream);
+int nirgan_tile_scatter(const float* tiles, int B, int C, int H, int W, int tile, int margin, int first, int n, float* scene, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -318,6 +318,45 @@ inline int grid_for(int64_t total) {
     return int(g < 8192 ? (g < 1 ? 1 : g) : 8192);
 }
 
+
+// ------------------------------------------------------------------------------------------------ tiled inference
+// A scene [B][C][H][W] is cut into tiles of `tile` pixels that overlap by 2 * margin: tile (b, ti, tj) covers scene rows
+// ti * core - margin .. + tile - 1 (core = tile - 2 margin), reflected at the scene's borders (torch's 'reflect' padding: the edge
+// pixel is not repeated) -- what F.pad(scene, (margin, margin + pw, margin, margin + ph), 'reflect') followed by a stack of slices
+// produces, in one launch per batch of tiles.  Tiles are numbered b-major, then ti, then tj; a launch takes tiles first .. first + n - 1.
+struct TileP { const float* scene; float* tiles; int B, C, H, W, tile, margin, core, nth, ntw, first, n; };
+
+__global__ __launch_bounds__(256) void tile_gather_kernel(const TileP p) {
+    const int64_t per = int64_t(p.C) * p.tile * p.tile, total = int64_t(p.n) * per;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        const int k = int(i / per);
+        int r = int(i - int64_t(k) * per);
+        const int c = r / (p.tile * p.tile);
+        r -= c * p.tile * p.tile;
+        const int y = r / p.tile, x = r - y * p.tile;
+        const int id = p.first + k, b = id / (p.nth * p.ntw), t = id - b * p.nth * p.ntw, ti = t / p.ntw, tj = t - ti * p.ntw;
+        const int h = ng_reflect(ti * p.core + y - p.margin, p.H), w = ng_reflect(tj * p.core + x - p.margin, p.W);
+        p.tiles[i] = p.scene[((int64_t(b) * p.C + c) * p.H + h) * p.W + w];
+    }
+}
+
+// the tiles' cores back into the scene [B][C][H][W] (C = 1 for the NIR prediction); pixels past the scene (its extent need not be a
+// multiple of the core) are dropped
+__global__ __launch_bounds__(256) void tile_scatter_kernel(const float* __restrict__ tiles, float* __restrict__ scene, const TileP p) {
+    const int64_t per = int64_t(p.C) * p.core * p.core, total = int64_t(p.n) * per;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += int64_t(gridDim.x) * 256) {
+        const int k = int(i / per);
+        int r = int(i - int64_t(k) * per);
+        const int c = r / (p.core * p.core);
+        r -= c * p.core * p.core;
+        const int y = r / p.core, x = r - y * p.core;
+        const int id = p.first + k, b = id / (p.nth * p.ntw), t = id - b * p.nth * p.ntw, ti = t / p.ntw, tj = t - ti * p.ntw;
+        const int h = ti * p.core + y, w = tj * p.core + x;
+        if (h < p.H && w < p.W)
+            scene[((int64_t(b) * p.C + c) * p.H + h) * p.W + w] = tiles[((int64_t(k) * p.C + c) * p.tile + y + p.margin) * p.tile + x + p.margin];
+    }
+}
+
 }  // namespace
 
 extern "C" int nirgan_nchw_to_halo(const float* src, int B, int Cs, int H, int W, float* dst, int dst_cs, int c0,
@@ -414,4 +453,41 @@ extern "C" int nirgan_conv_channel_dgrad(const nirgan_chan_dgrad_desc* d, void* 
     g = g < 4096 ? g : 4096;
     hipLaunchKernelGGL(chan_dgrad_kernel, dim3(int(g)), dim3(256), lds, static_cast<hipStream_t>(stream), p);
     return nirgan_check_launch("conv_channel_dgrad");
+}
+
+static int tile_params(TileP& p, int B, int C, int H, int W, int tile, int margin, int first, int n, const char* who) {
+    NG_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && tile > 0 && margin >= 0 && 2 * margin < tile, "%s: bad shape", who);
+    p.B = B; p.C = C; p.H = H; p.W = W; p.tile = tile; p.margin = margin; p.core = tile - 2 * margin;
+    p.nth = (H + p.core - 1) / p.core; p.ntw = (W + p.core - 1) / p.core;
+    // torch's reflect padding needs the pad narrower than the image: left/top = margin, right/bottom = margin + round-up of the extent
+    NG_REQUIRE(margin < H && margin < W && p.nth * p.core - H + margin < H && p.ntw * p.core - W + margin < W, "%s: the reflected border is wider than the scene (%d x %d, tile %d, margin %d)", who, H, W, tile, margin);
+    NG_REQUIRE(first >= 0 && n > 0 && int64_t(first) + n <= int64_t(B) * p.nth * p.ntw, "%s: tiles %d .. %d of %lld", who, first, first + n - 1, (long long)B * p.nth * p.ntw);
+    p.first = first; p.n = n;
+    return NIRGAN_OK;
+}
+
+extern "C" int64_t nirgan_tile_count(int B, int H, int W, int tile, int margin) {
+    if (B <= 0 || H <= 0 || W <= 0 || tile <= 0 || margin < 0 || 2 * margin >= tile) return 0;
+    const int core = tile - 2 * margin;
+    return int64_t(B) * ((H + core - 1) / core) * ((W + core - 1) / core);
+}
+
+extern "C" int nirgan_tile_gather(const float* scene, int B, int C, int H, int W, int tile, int margin, int first, int n, float* tiles, void* stream) {
+    NG_REQUIRE(scene && tiles, "tile_gather: null pointer");
+    TileP p;
+    const int rc = tile_params(p, B, C, H, W, tile, margin, first, n, "tile_gather");
+    if (rc != NIRGAN_OK) return rc;
+    p.scene = scene; p.tiles = tiles;
+    hipLaunchKernelGGL(tile_gather_kernel, dim3(grid_for(int64_t(n) * C * tile * tile)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return nirgan_check_launch("tile_gather");
+}
+
+extern "C" int nirgan_tile_scatter(const float* tiles, int B, int C, int H, int W, int tile, int margin, int first, int n, float* scene, void* stream) {
+    NG_REQUIRE(scene && tiles, "tile_scatter: null pointer");
+    TileP p;
+    const int rc = tile_params(p, B, C, H, W, tile, margin, first, n, "tile_scatter");
+    if (rc != NIRGAN_OK) return rc;
+    p.scene = nullptr; p.tiles = nullptr;
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_for(int64_t(n) * C * p.core * p.core)), dim3(256), 0, static_cast<hipStream_t>(stream), tiles, scene, p);
+    return nirgan_check_launch("tile_scatter");
 }

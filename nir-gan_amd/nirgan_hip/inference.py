@@ -17,22 +17,39 @@ import torch
 @torch.no_grad()
 def predict_tiled(model, rgb: torch.Tensor, tile: int = 512, margin: int = 16, batch: int = 8, embeds=None) -> torch.Tensor:
     """rgb: B x 3 x H x W (any H, W >= 4) -> B x 1 x H x W.  ``tile`` is the network input size (multiple of 4);
-    ``margin`` pixels on every side of a tile are context only."""
+    ``margin`` pixels on every side of a tile are context only.
+
+    On the device the reflect-padded scene is never materialised: one gather launch cuts a batch of overlapping tiles straight out
+    of the scene (nirgan_tile_gather reflects at the borders like ``F.pad(mode='reflect')``), the model runs on the batch, one
+    scatter launch writes the tiles' cores back (nirgan_tile_scatter) -- no per-tile Python.  Device tensors only (no CPU path; the
+    plain-torch statement of the same tiling lives with the oracle: oracle/nirgan_oracle.py::predict_tiled)."""
     assert tile % 4 == 0 and 0 <= margin < tile // 2
-    B, _, H, W = rgb.shape
+    B, C3, H, W = rgb.shape
     core = tile - 2 * margin
-    ph, pw = (-H) % core, (-W) % core
-    x = torch.nn.functional.pad(rgb, (margin, margin + pw, margin, margin + ph), mode="reflect")
-    out = torch.empty(B, 1, H + ph, W + pw, dtype=rgb.dtype, device=rgb.device)
-    coords = [(b, i, j) for b in range(B) for i in range(0, H + ph, core) for j in range(0, W + pw, core)]
-    for k in range(0, len(coords), batch):
-        chunk = coords[k:k + batch]
-        tiles = torch.stack([x[b, :, i:i + tile, j:j + tile] for b, i, j in chunk])
-        e = None if embeds is None else torch.stack([embeds[b] for b, _, _ in chunk])
-        pred = model(tiles) if e is None else model(tiles, e)
-        for (b, i, j), p in zip(chunk, pred):
-            out[b, :, i:i + core, j:j + core] = p[:, margin:margin + core, margin:margin + core]
-    return out[:, :, :H, :W]
+    from . import lib as L
+    if rgb.device.type != "cuda" and not L.is_emulated():
+        raise RuntimeError("predict_tiled runs on MI355X (cuda tensors) only; there is no CPU path")
+    be = L.backend()
+    scene = rgb.detach().to(torch.float32).contiguous()
+    total = int(be.nirgan_tile_count(B, H, W, tile, margin))
+    if total <= 0:
+        raise ValueError(f"predict_tiled: bad tiling (scene {H}x{W}, tile {tile}, margin {margin})")
+    per_image = total // B
+    out = torch.empty(B, 1, H, W, dtype=torch.float32, device=rgb.device)
+    st = torch.cuda.current_stream(rgb.device).cuda_stream if rgb.device.type == "cuda" else None
+    tiles = torch.empty(min(batch, total), C3, tile, tile, dtype=torch.float32, device=rgb.device)
+    for first in range(0, total, batch):
+        n = min(batch, total - first)
+        L.check(be.nirgan_tile_gather(scene.data_ptr(), B, C3, H, W, tile, margin, first, n, tiles.data_ptr(), st), "tile_gather")
+        x = tiles[:n]
+        if embeds is None:
+            pred = model(x)
+        else:
+            idx = torch.arange(first, first + n, device=embeds.device) // per_image      # tile -> scene it was cut from
+            pred = model(x, embeds.index_select(0, idx))
+        pred = pred.detach().to(torch.float32).contiguous()
+        L.check(be.nirgan_tile_scatter(pred.data_ptr(), B, 1, H, W, tile, margin, first, n, out.data_ptr(), st), "tile_scatter")
+    return out.to(rgb.dtype)
 
 
 def save_nir_npz(pred_nir: torch.Tensor, out_path: str, name: str) -> str:

@@ -168,6 +168,9 @@ PROTOTYPES = {
     "nirgan_pack_rows_bf16": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_location_encoder": (i32, [C.POINTER(LocEncDesc), fp]),
+    "nirgan_tile_count": (i64, [i32, i32, i32, i32, i32]),
+    "nirgan_tile_gather": (i32, [fp, i32, i32, i32, i32, i32, i32, i32, i32, fp, fp]),
+    "nirgan_tile_scatter": (i32, [fp, i32, i32, i32, i32, i32, i32, i32, i32, fp, fp]),
     "nirgan_wino6_tiles": (i64, [i32, i32, i32]),
     "nirgan_wino6_tiles_r": (i64, [i32, i32, i32, i32]),
     "nirgan_wino6_weights": (i32, [fp, i32, i32, i32, fp, fp]),

@@ -653,3 +653,26 @@ def shadowed_bias_keys(net: str, n_blocks: int = 6) -> set:
     for i in k["blocks"]:
         keys |= {f"model.{i}.conv_block.1.bias", f"model.{i}.conv_block.5.bias"}
     return keys
+
+
+# --------------------------------------------------------------------------------------
+# tiled inference: restatement of the product's tiling for the parity tests
+# --------------------------------------------------------------------------------------
+def predict_tiled(model, rgb, tile=512, margin=16, batch=8, embeds=None):
+    """Tiled inference stated with torch ops (pad the scene once with reflect, slice overlapping tiles, keep each tile's core): what
+    nirgan_hip.inference.predict_tiled does with its gather / scatter kernels (create_synthetic_dataset.py:100-118 per tile;
+    model/pix2pix.py:91-93,107-108 for the pad / crop idea).  Checker only."""
+    B, _, H, W = rgb.shape
+    core = tile - 2 * margin
+    ph, pw = (-H) % core, (-W) % core
+    x = torch.nn.functional.pad(rgb, (margin, margin + pw, margin, margin + ph), mode="reflect")
+    out = torch.empty(B, 1, H + ph, W + pw, dtype=rgb.dtype, device=rgb.device)
+    coords = [(b, i, j) for b in range(B) for i in range(0, H + ph, core) for j in range(0, W + pw, core)]
+    for k in range(0, len(coords), batch):
+        chunk = coords[k:k + batch]
+        tiles = torch.stack([x[b, :, i:i + tile, j:j + tile] for b, i, j in chunk])
+        e = None if embeds is None else torch.stack([embeds[b] for b, _, _ in chunk])
+        pred = model(tiles) if e is None else model(tiles, e)
+        for (b, i, j), p in zip(chunk, pred):
+            out[b, :, i:i + core, j:j + core] = p[:, margin:margin + core, margin:margin + core]
+    return out[:, :, :H, :W]

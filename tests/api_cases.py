@@ -470,7 +470,7 @@ def tiled_inference_and_checkpoint_loading(dev, golden_dir, tmp_path, tol: Tol):
     scene = 0.02 + 0.58 * torch.rand(2, 3, 70, 90, generator=g)
     pG = sub(z, "G0/")
     got = predict_tiled(model, scene.to(dev), tile=32, margin=8, batch=5)
-    want = predict_tiled(lambda t: O.px_forward(pG, t, 9, pad), scene, tile=32, margin=8, batch=7)
+    want = O.predict_tiled(lambda t: O.px_forward(pG, t, 9, pad), scene, tile=32, margin=8, batch=7)
     assert got.shape == (2, 1, 70, 90)
     close(got, want, tol.out, "predict_tiled")
     fn = save_nir_npz(got[0], str(tmp_path), "tile_0")

@@ -581,6 +581,59 @@ class EmuBackend:
                 return rc
         return 0
 
+    # ------------------------------------------------------------------ tiled inference
+    def nirgan_tile_count(self, B, H, W, tile, margin):
+        if B <= 0 or H <= 0 or W <= 0 or tile <= 0 or margin < 0 or 2 * margin >= tile:
+            return 0
+        core = tile - 2 * margin
+        return B * (-(-H // core)) * (-(-W // core))
+
+    def _tiling(self, B, H, W, tile, margin, first, n, who):
+        core = tile - 2 * margin
+        nth, ntw = -(-H // core), -(-W // core)
+        if not (margin < H and margin < W and nth * core - H + margin < H and ntw * core - W + margin < W):
+            return None, self._fail(f"{who}: the reflected border is wider than the scene")
+        if first < 0 or n <= 0 or first + n > B * nth * ntw:
+            return None, self._fail(f"{who}: tile range")
+        return (core, nth, ntw), 0
+
+    def nirgan_tile_gather(self, scene, B, Cc, H, W, tile, margin, first, n, tiles, stream=None):
+        self.calls.append("tile_gather")
+        geo, rc = self._tiling(B, H, W, tile, margin, first, n, "tile_gather")
+        if rc:
+            return rc
+        core, nth, ntw = geo
+        src = arr(scene, B * Cc * H * W).reshape(B, Cc, H, W)
+        dst = arr(tiles, n * Cc * tile * tile).reshape(n, Cc, tile, tile)
+
+        def refl(i, m):
+            i = np.abs(i)
+            return np.where(i >= m, 2 * m - 2 - i, i)
+        for k in range(n):
+            idx = first + k
+            b, t = divmod(idx, nth * ntw)
+            ti, tj = divmod(t, ntw)
+            hh = refl(ti * core + np.arange(tile) - margin, H)
+            ww = refl(tj * core + np.arange(tile) - margin, W)
+            dst[k] = src[b][:, hh][:, :, ww]
+        return 0
+
+    def nirgan_tile_scatter(self, tiles, B, Cc, H, W, tile, margin, first, n, scene, stream=None):
+        self.calls.append("tile_scatter")
+        geo, rc = self._tiling(B, H, W, tile, margin, first, n, "tile_scatter")
+        if rc:
+            return rc
+        core, nth, ntw = geo
+        src = arr(tiles, n * Cc * tile * tile).reshape(n, Cc, tile, tile)
+        dst = arr(scene, B * Cc * H * W).reshape(B, Cc, H, W)
+        for k in range(n):
+            b, t = divmod(first + k, nth * ntw)
+            ti, tj = divmod(t, ntw)
+            h0, w0 = ti * core, tj * core
+            h1, w1 = min(h0 + core, H), min(w0 + core, W)
+            dst[b, :, h0:h1, w0:w1] = src[k, :, margin:margin + h1 - h0, margin:margin + w1 - w0]
+        return 0
+
     # ------------------------------------------------------------------ histogram matching
     def nirgan_hist_match_ws_bytes(self, B, N):
         P = 2048

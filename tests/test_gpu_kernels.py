@@ -1049,3 +1049,33 @@ def test_wino6_weight_gradient_finish_batch(case):
         torch.cuda.synchronize()
         for o, f in zip(oc, fresh):
             close(f, o, 1e-5, "device vs restatement")
+
+
+@pytest.mark.parametrize("case", [(2, 3, 70, 90, 32, 8, 5), (1, 3, 256, 256, 128, 16, 3), (1, 1, 33, 47, 16, 2, 64), (3, 4, 40, 24, 24, 0, 4)])
+def test_tile_gather_and_scatter_match_pad_slice_stack(case):
+    """nirgan_tile_gather / nirgan_tile_scatter (tiled inference) against torch: F.pad(mode='reflect') of the scene, slices
+    of overlapping tiles, and the tiles' cores written back -- bit for bit (pure data movement), in batches that do not divide the tile
+    count; a scene too small for its reflected border is refused."""
+    B, Cc, H, W, tile, margin, batch = case
+    g = torch.Generator().manual_seed(17)
+    scene = torch.randn(B, Cc, H, W, generator=g)
+    core = tile - 2 * margin
+    ph, pw = (-H) % core, (-W) % core
+    xp = torch.nn.functional.pad(scene, (margin, margin + pw, margin, margin + ph), mode="reflect")
+    coords = [(b, i, j) for b in range(B) for i in range(0, H + ph, core) for j in range(0, W + pw, core)]
+    want = torch.stack([xp[b, :, i:i + tile, j:j + tile] for b, i, j in coords])
+    total = int(L.backend().nirgan_tile_count(B, H, W, tile, margin))
+    assert total == len(coords)
+    sd = scene.to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    got = torch.full((total, Cc, tile, tile), float("nan"), device=DEV)
+    back = torch.full((B, Cc, H, W), float("nan"), device=DEV)
+    for first in range(0, total, batch):
+        n = min(batch, total - first)
+        L.call("nirgan_tile_gather", sd.data_ptr(), B, Cc, H, W, tile, margin, first, n, got[first:].data_ptr(), st)
+        L.call("nirgan_tile_scatter", got[first:].data_ptr(), B, Cc, H, W, tile, margin, first, n, back.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want), "gathered tiles differ from pad + slice"
+    assert torch.equal(back.cpu(), scene), "scattering the tiles' cores does not reproduce the scene"
+    with pytest.raises(RuntimeError):
+        L.call("nirgan_tile_gather", sd.data_ptr(), B, Cc, H, W, 4 * max(H, W), max(H, W), 0, 1, got.data_ptr(), st)

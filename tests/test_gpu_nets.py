@@ -718,6 +718,56 @@ def test_configs4_bf16_mixed_resolution_with_the_spectral_loss():
     assert len(tr._states) == 3 and tr.flatG.step_count == 6
 
 
+def test_configs4_bf16_with_the_spectral_loss_at_full_width():
+    """BASELINE.json configs[4]'s arithmetic at the reference's width (ngf = ndf = 64, 9 blocks, NDVI / NDWI / EVI loss, bf16 operands on
+    the matrix pipe): two of the resolution buckets (2 @128, 1 @256) against the oracle's bf16 restatement (every contraction's operands
+    rounded to bf16 once, fp32 accumulate: oracle.operand_precision) from the same weights.  Rounding is discontinuous, so two correct
+    bf16 evaluations drift apart up to the bf16 noise level: the device has to sit INSIDE the band the restatement spans against the fp32
+    evaluation -- prediction within 0.75 of it, losses to 1e-2, every gradient tensor closer to the bf16 restatement than 1.5 x the
+    distance between the bf16 and the fp32 restatements.  Parity unpinned against the reference (it has no bf16 path)."""
+    from model import networks
+    from nirgan_hip.trainer import Pix2PixTrainer
+    nb = 9
+
+    def nets():
+        torch.manual_seed(0)
+        g = networks.define_G(3, 1, 64, "resnet_9blocks", "instance", False, "normal", 0.02)
+        d = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
+        with torch.no_grad():
+            list(g.parameters())[-1].fill_(1.5)
+            list(g.parameters())[-2].mul_(0.2)       # last conv: pre-tanh = 1.5 +- a narrow spread (pred + band stays away from 0)
+        return g, d
+    g, d = nets()
+    sdG, sdD = {k: v.clone() for k, v in g.state_dict().items()}, {k: v.clone() for k, v in d.state_dict().items()}
+    tr = Pix2PixTrainer(g.to(DEV), d.to(DEV), n_blocks=nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W, precision="bf16")
+    shadowG, shadowD = O.shadowed_bias_keys("G", nb), O.shadowed_bias_keys("D")
+    for i, (b, s_) in enumerate([(2, 128), (1, 256)]):
+        rgb, nir = synth(b, s_, s_, 80 + i)
+        out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
+        ref32 = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
+        ref32.step(rgb, nir)
+        with O.operand_precision("bf16"):
+            ref = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
+            o = ref.step(rgb, nir)
+        assert float(ref.last["pred"].min()) > 0.3
+        noise = (ref.last["pred"] - ref32.last["pred"]).abs().max().item()
+        err = (tr.pred.cpu() - ref.last["pred"]).abs().max().item()
+        assert noise > 1e-4 and err < 0.75 * noise, f"bucket {i}: pred {err:.3e} vs bf16 noise {noise:.3e}"
+        for k in ("loss_D", "loss_G", "loss_G_rs", "loss_G_l1"):
+            close(out[k], o[k], 1e-2, f"bf16 {k} bucket {i}")
+        worst = 0.0
+        for name, gdev, gref, g32, shadow in (("gD", tr.flatD.grad_views(), ref.last["grads_D"], ref32.last["grads_D"], shadowD),
+                                              ("gG", tr.flatG.grad_views(), ref.last["grads_G"], ref32.last["grads_G"], shadowG)):
+            for k, v in gref.items():
+                if k in shadow or v is None or v.numel() == 1:
+                    continue
+                band = (v - g32[k]).norm().item()
+                e = (gdev[k].cpu() - v).norm().item()
+                worst = max(worst, e / max(band, 1e-30))
+                assert e <= 1.5 * band + 1e-6 * v.norm().item(), f"bucket {i} {name} {k}: {e:.3e} from the bf16 restatement, band {band:.3e}"
+        print(f"configs[4] full width, bucket {b}@{s_}: pred {err:.2e} of noise {noise:.2e}; worst gradient distance / band {worst:.2f}")
+
+
 def test_micro_batches_on_two_streams_match_the_single_stream_step():
     """ngf = 64, bs 4 @128: the two-part step on two HIP streams gives the single-part step's losses and gradients
     (fp32 summation order of the weight gradients differs: 1e-4), over two consecutive steps (stream joins before each
