@@ -71,20 +71,29 @@ def op_mfma_work(name, args):
     (nirgan_wino6_*_kernel_name mirror the launchers' dispatch), the others from the descriptor's tile width."""
     from nirgan_hip import lib as L
     be = L.backend()
+    def conv_bytes(d):           # input buffer read once, packed weights once, output written once (fp32 or the producers' bf16 twins)
+        return d.B * d.in_hp * d.in_wp * d.in_cs * (2.0 if d.in_bf16 else 4.0) + d.N * d.ntaps * d.run * (2.0 if d.w_bf16 else 4.0) + d.B * d.OH * d.OW * d.N * 4.0
+
+    def wgrad_bytes(w):          # both operand images read once, slabs written once
+        e = 2.0 if w.pq_bf16 else 4.0
+        npl = max(w.nplanes, 1)
+        return npl * (w.B * w.p_hp * w.p_wp * w.p_cs * e + w.B * w.q_hp * w.q_wp * w.q_cs * e) + npl * w.nsplit * w.N * w.ntaps * w.run * 4.0
     if name == "nirgan_conv_igemm":
         d = args[0]._obj
-        return f"conv_igemm_kernel<{128 if d.N > 64 else 64}>", 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run, None
+        return f"conv_igemm_kernel<{128 if d.N > 64 else 64}>", 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run, conv_bytes(d)
     if name == "nirgan_conv_igemm_group":
         ds = [args[0][j].contents for j in range(args[1])]
-        return f"conv_group_kernel<{128 if ds[0].N > 64 else 64}>", sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds), None
+        by = conv_bytes(ds[0]) + sum(d.N * d.ntaps * d.run * (2.0 if d.w_bf16 else 4.0) + d.B * d.OH * d.OW * d.N * 4.0 for d in ds[1:])      # the phases share the input
+        return f"conv_group_kernel<{128 if ds[0].N > 64 else 64}>", sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds), by
     if name == "nirgan_wgrad_igemm":
         w = args[0]._obj
-        if w.precision != 0 or w.pq_bf16:
-            return "wgrad_igemm(bf16)", 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, None
-        return f"wgrad_igemm_kernel<{128 if w.N > 64 else 64}>", 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, None
+        label = f"wgrad_igemm_kernel<{128 if w.N > 64 else 64}>" + ("(bf16 twins)" if w.pq_bf16 else "")
+        return label, 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, wgrad_bytes(w)
     if name == "nirgan_conv_wgrad_pair":
         c, w = args[0]._obj, args[1]._obj
-        return "conv_wgrad_pair_kernel", 2.0 * c.B * c.OH * c.OW * c.N * c.ntaps * c.run + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, None
+        # (the weight gradient's p operand is the data gradient's input: counted once)
+        by = conv_bytes(c) + wgrad_bytes(w) - max(w.nplanes, 1) * w.B * w.p_hp * w.p_wp * w.p_cs * (2.0 if w.pq_bf16 else 4.0)
+        return "conv_wgrad_pair_kernel", 2.0 * c.B * c.OH * c.OW * c.N * c.ntaps * c.run + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, by
     if name == "nirgan_wino6_gemm":
         d = args[0]._obj
         T = w6_tiles(d)
@@ -104,6 +113,9 @@ def op_mfma_work(name, args):
         px = d.B * d.x_hp * d.x_wp if name.endswith("dgrad") else d.B * d.OH * d.OW
         return name.replace("nirgan_", "") + "_kernel", 2.0 * px * 49 * 64, None
     return None
+
+
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.3 achievable)
 
 
 def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_group_kernel<128>", "wgrad_igemm_kernel<128>", "conv_wgrad_pair_kernel", "wino6_")):
@@ -507,6 +519,25 @@ def main():
         rank_ms = [round(float(x[0]), 3) for x in allt]
         comm_ms = [round(float(x[1]), 4) for x in allt]
         dt = max(float(x[0]) for x in allt) * a.steps / 1e3          # MAX over ranks
+    # ---- share of the step spent outside the matrix pipe: 3 untimed steps with EVERY matrix-pipe launch bracketed by HIP events
+    mfma_share = None
+    if not a.no_probe and pl_model is None and a.micro == 1 and dev.type == "cuda":
+        saved = [(pl.probe_idx, pl.probe_events) for pl in plans]
+        for pl in plans:
+            pl.probe_idx = {i: "mfma" for i, (n, ar) in enumerate(pl.ops) if isinstance(n, str) and op_mfma_work(n, ar) is not None}
+            pl.probe_events = []
+        e0, e1 = Tick(dev), Tick(dev)
+        barrier()
+        e0.record()
+        for _ in range(3):        # (mixed: the middle bucket, whose plans the probes bracket)
+            _step(data[1][0], data[1][1], None) if a.mixed else tr.step(rgb, nir)
+        e1.record()
+        barrier()
+        t_all = e0.elapsed_time(e1)
+        t_mfma = sum(s_.elapsed_time(e_) for pl in plans for _, s_, e_ in pl.probe_events)
+        mfma_share = t_mfma / t_all
+        for pl, (pi, pe) in zip(plans, saved):
+            pl.probe_idx, pl.probe_events = pi, pe
     # ---- sustained leg: back-to-back steps for >= --sustain seconds (no probes, chunks of 10 steps between two HIP events)
     sustained = None
     if a.sustain > 0 and dev.type == "cuda":
@@ -560,11 +591,16 @@ def main():
                 per_launch_flop = flops / nlaunch
                 avg_ms = ev_ms / n_ev
                 ach = per_launch_flop / (avg_ms * 1e-3) / 1e12
+                by = (mfma_probes.algo_bytes[k] / nlaunch) if k in getattr(mfma_probes, "algo_bytes", {}) else None
+                gbps = None if by is None else by / (avg_ms * 1e-3) / 1e9
                 roofs.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAKS[a.precision], 1), "unit": "TFLOP/s",
                               "frac": round(ach / PEAKS[a.precision], 4), "traffic": None, "kernel": k,
                               "launches_per_step": nlaunch, "avg_launch_ms": round(avg_ms, 5),
                               "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
-                              "algorithmic_bytes_per_launch": (int(mfma_probes.algo_bytes[k] / nlaunch) if k in getattr(mfma_probes, "algo_bytes", {}) else None),
+                              "algorithmic_bytes_per_launch": None if by is None else int(by),
+                              # the OTHER bound of the same launch: its algorithmic bytes over the same time against the HBM peak
+                              "hbm_bound": None if by is None else {"achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4)},
+                              "binding": None if by is None else ("mfma" if ach / PEAKS[a.precision] >= gbps / PEAK_HBM_GBPS else "hbm"),
                               "share_of_step_time": round(avg_ms * nlaunch / ms, 3)})
             # HBM traffic per launch: NOT measured in this run (PMC needs rocprofv3 passes around the process).  It is replayed from
             # the PMC summary recorded under profiles/ by scripts/refresh_profiles.sh over this same command (rocprofv3 --pmc
@@ -691,6 +727,11 @@ def main():
             exs = sum(plan_executed_flops(pl) for pl in plans) / 1e9
             out["whole_step"] = {"executed_mfma_gflop": round(exs, 1), "executed_mfma_util": round(exs / ms / PEAKS[a.precision], 4),
                                  "note": "FLOPs the matrix pipe executes per step (launch descriptors) / ms_per_step / dense peak"}
+            if mfma_share is not None:
+                out["whole_step"]["matrix_pipe_launch_share"] = round(mfma_share, 4)
+                out["whole_step"]["hbm_bound_share"] = round(1.0 - mfma_share, 4)
+                out["whole_step"]["share_note"] = ("3 untimed steps with every matrix-pipe launch between HIP events: share of the step inside them; the "
+                                                   "rest (transforms, instance norm, layout, losses, Adam, launch gaps) is HBM / latency bound")
             wr = pmc.get("_whole_run") if (not a.no_probe and isinstance(pmc.get("_whole_run"), dict)) else None
             if wr and headline and fresh:
                 gb = wr["hbm_read_gb_per_step"] + wr["hbm_write_gb_per_step"]
@@ -698,6 +739,9 @@ def main():
                                           "pmc_executed_mfma_gflop": round(wr["executed_mfma_gflop_per_step_fp32"], 1),
                                           "pmc_hbm_gb": round(gb, 2), "hbm_tbps": round(gb / ms, 3),
                                           "pmc_source": f"replayed from {pmc_file} (rocprofv3 --pmc passes over this command, scripts/refresh_profiles.sh), not measured in this run"})
+        if a.mixed and mfma_share is not None:
+            out["middle_bucket"] = {"matrix_pipe_launch_share": round(mfma_share, 4), "hbm_bound_share": round(1.0 - mfma_share, 4),
+                                    "note": f"{a.bs} tiles @{a.size}: 3 untimed steps with every matrix-pipe launch between HIP events"}
         if sustained is not None:
             out["sustained"] = sustained
         if pl_model is not None:

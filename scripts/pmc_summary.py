@@ -56,7 +56,7 @@ out["_whole_run"] = {"steps": STEPS,
                      "executed_mfma_gflop_per_step_fp32": tb * 64.0 / 1e9 / STEPS,
                      "hbm_read_gb_per_step": rd / 1e9 / STEPS, "hbm_write_gb_per_step": wr / 1e9 / STEPS,
                      "note": "sums over every kernel of the command; FETCH_SIZE x2-corrected (MI355X_MICROARCH.md); per step = / steps"}
-out["_meta"] = {"kernel_src_sha16": kernel_source_sha16(), "command": "python3 bench.py --no-cpu-baseline --no-probe --steps 3 --warmup 1",
+out["_meta"] = {"kernel_src_sha16": kernel_source_sha16(), "command": "python3 bench.py --no-cpu-baseline --no-probe --sustain 0 --steps 3 --warmup 1",
                 "passes": [os.path.basename(d.rstrip("/")) for d in sys.argv[1:]],
                 "recorded_by": "scripts/refresh_profiles.sh (rocprofv3 --pmc, one counter group per pass)"}
 json.dump(out, sys.stdout, indent=1, sort_keys=True)
