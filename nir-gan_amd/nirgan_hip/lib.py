@@ -234,6 +234,10 @@ class _CLib:
             raise ImportError(
                 f"{path} not found: build the HIP extension first (python __graft_entry__.py). "
                 "The NIR-GAN MI355X path has no CPU fallback.")
+        # torch first: its wheel carries its own HIP runtime (torch/lib/libamdhip64.so).  If libnirgan_hip.so is loaded before it, the
+        # loader binds our kernels to /opt/rocm's copy, torch then brings a second runtime, and launches on torch's streams fail with
+        # "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process)
+        import torch  # noqa: F401
         self._dll = C.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(self._dll, name)       # AttributeError if a symbol is missing
