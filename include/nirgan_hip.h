@@ -507,6 +507,8 @@ typedef struct {
 #define NIRGAN_W6_ONE_TILE 1
 #define NIRGAN_W6_PERSIST16 2
 #define NIRGAN_W6_DIRECT_TILE 3
+#define NIRGAN_W6_PATCH_PER_THREAD 16      /* nirgan_wino6_input*: F(6x6,3x3) patches one per thread (A/B; default for the plain / dY transforms: a wave per patch x 32 channels) */
+#define NIRGAN_W6_PATCH_PER_LANES 17       /* ... and the lane-spread form also for the normalising variant (default there: one per thread) */
 /* names of the kernels the two launchers above pick for a descriptor (what a profile of the launch shows) */
 const char* nirgan_wino6_gemm_kernel_name(const nirgan_wino6_desc* d);
 const char* nirgan_wino6_pair_kernel_name(const nirgan_wino6_desc* d, const nirgan_wgrad_desc* w);

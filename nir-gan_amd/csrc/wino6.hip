@@ -344,6 +344,97 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     }
 }
 
+// The same transforms for the 8 x 8 patches of F(6x6,3x3) with the patch spread over the LANES instead of one thread's registers
+// (round 3).  The one-thread-per-patch kernel above keeps 64 x 2 channels in registers between its two passes: 166-174 VGPRs, two to
+// three waves per SIMD, eight dependent load rounds each -- latency holds it at 4.5 TB/s.  Here a wave takes one patch x 32 channels:
+// lane = (patch column c, channel quad qg); its 8 loads (the 8 rows of column c, 16 bytes each, whole 128-byte lines per pixel) are
+// all in flight at once; B^T runs down the column in registers, the 8 x 8 transpose goes through a wave-private 8 KB of LDS (written
+// as whole 1 KB rows), B^T runs along the row in the lane that now owns plane row a', and the 8 results leave as 16-byte stores (128
+// contiguous bytes per plane and instruction).  ~60 VGPRs.  Same arithmetic in the same order as the kernel above: bitwise equal.
+// MODE 0: halo'd buffer (Yt = A dY A^T from the same loads when p.Yt is set); 1: forward input normalised on the fly.
+template <int MODE>
+__global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
+    constexpr int V = 6, N = 8, MO = 6, R = 3;
+    constexpr bool NORM = MODE == 1;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[4][N * N * 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane >> 3, qg = lane & 7;
+    const int groups = p.C / 32;
+    const long long unit = blockIdx.x * 4ll + wave, units = p.T * groups;
+    const bool live = unit < units;
+    const long long t = live ? unit / groups : 0;
+    const int cg = live ? int(unit - t * groups) : 0;
+    const int tx = int(t % p.TW);
+    const long long r_ = t / p.TW;
+    const int ty = int(r_ % p.TH), b = int(r_ / p.TH);
+    const int ch = cg * 32 + qg * 4;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[N];
+    if constexpr (NORM) {
+        const f32x4 mean = ld4(p.mean + size_t(b) * p.C + ch), rstd = ld4(p.rstd + size_t(b) * p.C + ch);
+        const float neg = p.act == NIRGAN_ACT_RELU ? 0.f : p.act == NIRGAN_ACT_LRELU ? p.slope : 1.f;
+        const float* base = p.y + size_t(b) * p.H * p.W * p.C + ch;
+        const int cb = MO * tx + c;
+        const float cok = cb < p.x_wp ? 1.f : 0.f;
+        const int coff = ng_reflect((cb < p.x_wp ? cb : 0) - 1, p.W) * p.C;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const int rb = MO * ty + a;
+            const float ok = (rb < p.x_hp ? 1.f : 0.f) * cok;
+            const int roff = ng_reflect((rb < p.x_hp ? rb : 0) - 1, p.H) * p.W * p.C;
+            f32x4 v = (ld4(base + (roff + coff)) - mean) * rstd;                  // in_apply_kernel's arithmetic
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * neg;
+            d[a] = v * ok;
+        }
+    } else {
+        const float* base = p.x + size_t(b) * p.x_img + ch;
+        const int cb = MO * tx + c;
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const int rb = MO * ty + a;
+            d[a] = (rb < p.x_hp && cb < p.x_wp) ? ld4(base + size_t(rb) * p.x_row + size_t(cb) * p.C) : z4;
+        }
+    }
+    f32x4* buf = lds[wave];
+    f32x4 o[N], m[N];
+    W6<V>::bt(d, o);
+#pragma unroll
+    for (int a = 0; a < N; ++a) buf[(a * N + c) * 8 + qg] = o[a];
+    __syncthreads();
+    const int ap = c;                                           // this lane now owns plane row a' = its old column index
+#pragma unroll
+    for (int cc = 0; cc < N; ++cc) m[cc] = buf[(ap * N + cc) * 8 + qg];
+    W6<V>::bt(m, o);
+    if (live) {
+        const size_t plane = size_t(p.T) * p.C;
+        float* Vp = p.V + size_t(t) * p.C + ch;
+#pragma unroll
+        for (int cc = 0; cc < N; ++cc) st4(Vp + (ap * N + cc) * plane, o[cc]);
+    }
+    if constexpr (!NORM) {
+        if (p.Yt != nullptr) {                                  // uniform over the block
+            // output-gradient tile (ty, tx) = patch rows / columns 2 .. 7: the column pass of A on the rows already in registers
+            f32x4 u[N];
+            W6<V>::a(d + (R - 1), u);                           // lanes of columns 0, 1 carry values nobody reads
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < N; ++a) buf[(a * N + c) * 8 + qg] = u[a];
+            __syncthreads();
+            f32x4 e[MO];
+#pragma unroll
+            for (int cc = 0; cc < MO; ++cc) e[cc] = buf[(ap * N + (R - 1) + cc) * 8 + qg];
+            W6<V>::a(e, u);
+            if (live && ty < p.yTH && tx < p.yTW) {
+                const size_t yplane = size_t(p.yT) * p.C;
+                float* Y = p.Yt + ((size_t(b) * p.yTH + ty) * p.yTW + tx) * p.C + ch;
+#pragma unroll
+                for (int cc = 0; cc < N; ++cc) st4(Y + (ap * N + cc) * yplane, u[cc]);
+            }
+        }
+    }
+}
+
 // Yt[f][t][k] = (A dY A^T)[f] alone (weight gradient without a Winograd data gradient next to it)
 struct W6Dy { const float* dy; float* Yt; int B, H, W, K, d_row, d_img, d_org, TH, TW; long long T; };
 
@@ -1097,6 +1188,16 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
     const long long nthreads = T * (d->C / (v == 3 ? 4 : 2));
     const dim3 grid(unsigned((nthreads + 255) / 256));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // F(6x6,3x3): the 8 x 8 patches spread over the lanes, one wave per (patch, 32 channels).  Measured inside the step (bs 16):
+    // dY pass 73.8 -> 61.5 us, plain input 43.6 -> 41.3 us; the normalising variant 41.7 -> 44.5 us, so that one keeps the
+    // patch-per-thread kernel unless asked (algo = NIRGAN_W6_PATCH_PER_LANES).  Alone, back to back, both forms move 5.3 TB/s.
+    const bool coop = v == 6 && d->C % 32 == 0 && d->algo != NIRGAN_W6_PATCH_PER_THREAD && (!ny || d->algo == NIRGAN_W6_PATCH_PER_LANES);
+    if (coop) {
+        const dim3 cgrid(unsigned((T * (d->C / 32) + 3) / 4));
+        if (ny) hipLaunchKernelGGL(wino6_input_coop_kernel<1>, cgrid, dim3(256), 0, st, in);
+        else hipLaunchKernelGGL(wino6_input_coop_kernel<0>, cgrid, dim3(256), 0, st, in);
+        return nirgan_check_launch("wino6_input");
+    }
     if (ny && v == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 1>), grid, dim3(256), 0, st, in);
     else if (ny) hipLaunchKernelGGL((wino6_input_kernel<6, 1>), grid, dim3(256), 0, st, in);
     else if (v == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 0>), grid, dim3(256), 0, st, in);

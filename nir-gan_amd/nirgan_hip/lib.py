@@ -142,6 +142,7 @@ class Wino6Desc(C.Structure):
 
 
 W6_ONE_TILE, W6_PERSIST16, W6_DIRECT_TILE = 1, 2, 3      # nirgan_wino6_desc.algo
+W6_PATCH_PER_THREAD, W6_PATCH_PER_LANES = 16, 17                                 # nirgan_wino6_desc.algo for the input transforms (A/B)
 WGRAD_ONE_UNIT = 1                                       # nirgan_wgrad_desc.algo
 
 

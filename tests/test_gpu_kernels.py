@@ -1079,3 +1079,46 @@ def test_tile_gather_and_scatter_match_pad_slice_stack(case):
     assert torch.equal(back.cpu(), scene), "scattering the tiles' cores does not reproduce the scene"
     with pytest.raises(RuntimeError):
         L.call("nirgan_tile_gather", sd.data_ptr(), B, Cc, H, W, 4 * max(H, W), max(H, W), 0, 1, got.data_ptr(), st)
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 16, 64), (16, 64, 64, 256), (3, 9, 11, 32), (1, 21, 17, 96)])
+def test_wino6_input_transform_forms_agree_bitwise(shape):
+    """F(6x6,3x3) input transforms: the patch-per-thread kernel and the lane-spread kernel (one wave per patch x 32 channels, transpose
+    through LDS) run the same arithmetic in the same order -- V, and Yt of the dY pass, bit for bit; so does the normalising variant."""
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(41)
+    st = torch.cuda.current_stream().cuda_stream
+    T = B * (-(-(H + 2) // 6)) * (-(-(W + 2) // 6))            # data-gradient extent (H + 2) x (W + 2) over dY with a zero halo of 2
+    dy = torch.zeros(B, H + 4, W + 4, Cc)
+    dy[:, 2:-2, 2:-2] = torch.randn(B, H, W, Cc, generator=g)
+    dy = dy.to(DEV)
+    yT = B * (-(-H // 6)) * (-(-W // 6))
+    outs = []
+    for algo in (0, L.W6_PATCH_PER_THREAD):
+        V = torch.full((64 * T * Cc,), float("nan"), device=DEV)
+        Yt = torch.full((64 * yT * Cc,), float("nan"), device=DEV)
+        d = L.Wino6Desc()
+        d.r, d.B, d.H, d.W, d.C, d.K = 6, B, H + 2, W + 2, Cc, Cc
+        d.x, d.x_hp, d.x_wp, d.V, d.V_elems, d.algo = dy.data_ptr(), H + 4, W + 4, V.data_ptr(), V.numel(), algo
+        y = L.WinoDyDesc()
+        y.dy, y.dy_hp, y.dy_wp, y.dy_pad, y.B, y.H, y.W, y.K = dy.data_ptr(), H + 4, W + 4, 2, B, H, W, Cc
+        y.Yt, y.Yt_elems, y.r = Yt.data_ptr(), Yt.numel(), 6
+        L.call("nirgan_wino6_input_dy", C.byref(d), C.byref(y), st)
+        torch.cuda.synchronize()
+        outs.append((V.cpu(), Yt.cpu()))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # normalising variant: y dense [B][H][W][C], reflect halo of 1, ReLU
+    yv = (torch.randn(B, H, W, Cc, generator=g) * 1.3 + 0.2).to(DEV)
+    mean, rstd = (torch.randn(B, Cc, generator=g) * 0.1).to(DEV), (torch.rand(B, Cc, generator=g) + 0.5).to(DEV)
+    Tn = B * (-(-H // 6)) * (-(-W // 6))
+    res = []
+    for algo in (0, L.W6_PATCH_PER_LANES):
+        V = torch.full((64 * Tn * Cc,), float("nan"), device=DEV)
+        d = L.Wino6Desc()
+        d.r, d.B, d.H, d.W, d.C, d.K = 6, B, H, W, Cc, Cc
+        d.x_hp, d.x_wp, d.V, d.V_elems, d.algo = H + 2, W + 2, V.data_ptr(), V.numel(), algo
+        L.call("nirgan_wino6_input_norm", C.byref(d), yv.data_ptr(), mean.data_ptr(), rstd.data_ptr(), L.ACT_RELU, 0.2, st)
+        torch.cuda.synchronize()
+        res.append(V.cpu())
+    assert torch.isfinite(res[0]).all() and torch.equal(res[0], res[1])
