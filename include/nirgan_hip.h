@@ -90,11 +90,12 @@ typedef struct {
      * stored, half the bytes and LDS-DMA pieces per K-step, no conversion in the K loop. */
     int in_bf16;
     /* optional: partial sums for the instance norm that follows (nirgan_instnorm_fwd with stats_chunks / stats_shift).  Every 64 output
-     * pixels x N channels held by a wave leave sum and sum of squares of the convolution WITHOUT the bias in
-     * stats_ws[b][stats_chunk0 + chunk][2][N]; chunk = (tile within the sample) * 2 + the wave's row half.  The problem then has
-     * OH * OW % 128 == 0 (a tile does not cross samples) and no split-K; it contributes OH * OW / 64 chunks per sample, a launch of
-     * several problems over one output (the sub-pixel phases of a transposed convolution) numbers them with stats_chunk0, and
-     * stats_chunks is the total per sample (the row stride of stats_ws).  stats_ws >= B * stats_chunks * 2 * N floats. */
+     * pixels x N channels held by a wave leave FOUR values per channel in stats_ws[b][stats_chunk0 + chunk][4][N]: a shift k (the
+     * chunk's first pixel, WITHOUT the bias), sum (v - k), sum (v - k)^2, and the count 64 -- sums about a value of the data itself carry
+     * no cancellation, nirgan_instnorm_fwd re-bases the chunks onto one shift.  chunk = (tile within the sample) * 2 + the wave's row
+     * half.  The problem then has OH * OW % 128 == 0 (a tile does not cross samples) and no split-K; it contributes OH * OW / 64 chunks
+     * per sample, a launch of several problems over one output (the sub-pixel phases of a transposed convolution) numbers them with
+     * stats_chunk0, and stats_chunks is the total per sample (the row stride of stats_ws).  stats_ws >= B * stats_chunks * 4 * N floats. */
     float* stats_ws; int64_t stats_ws_elems; int stats_chunk0, stats_chunks;
     /* optional: the launch writes the gradient wrt the OUTPUT of a convolution + instance-norm (+ReLU / LeakyReLU) layer (it is the data
      * gradient of that layer's consumer); the first pass of that layer's backward (nirgan_instnorm_bwd: sums of g_z = g * act'(z) and of
@@ -187,10 +188,11 @@ typedef struct {
     float* ws; int64_t ws_elems;          /* >= B * nchunk * 2 * C floats, see nirgan_instnorm_ws_elems */
     void* out_bf16;                       /* optional twin of `out` (same geometry, bf16 elements): every store is mirrored, rounded
                                            * to nearest even -- the operand the bf16 mode's convolutions read (in_bf16) */
-    int stats_chunks;                     /* > 0 (with norm): the producer of y already left the per-(b, c) partial sums
-                                           * S1 = sum (y - shift_c), S2 = sum (y - shift_c)^2 in ws as [B][stats_chunks][2][C]
-                                           * (nirgan_wino6_output with stats_ws): the pass over y that would form them is skipped */
-    const float* stats_shift;             /* [C], the shift those sums are taken about (the convolution's bias); NULL = 0 */
+    int stats_chunks;                     /* > 0 (with norm): the producer of y already left per-chunk partial sums in ws as
+                                           * [B][stats_chunks][4][C] = {k, sum (v - k), sum (v - k)^2, count} with v = y - stats_shift and k a
+                                           * value of the chunk itself (nirgan_wino6_output / nirgan_conv_igemm with stats_ws): the pass
+                                           * over y that would form them is skipped, the chunks are re-based onto one shift in a fixed order */
+    const float* stats_shift;             /* [C], what the producer left out of v (the convolution's bias); NULL = 0 */
 } nirgan_in_fwd_desc;
 
 int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C);
@@ -486,8 +488,8 @@ typedef struct {
                                              fp32 error 1.7e-5 of the output's maximum.  The same code goes into nirgan_wino_dy_desc.r,
                                              nirgan_wino6_weights_r and nirgan_wino6_wgrad_finish_r for the layer */
     float* stats_ws; int64_t stats_ws_elems;   /* optional (nirgan_wino6_output): per-tile partial sums of the output for the instance norm that
-                                             follows, [B][tiles per image][2][K] = T * 2 * K floats: sum and sum of squares of the tile's
-                                             stored outputs WITHOUT the bias (i.e. about the shift `bias`); feed nirgan_instnorm_fwd with
+                                             follows, [B][tiles per image][4][K] = T * 4 * K floats: {k, sum (o - k), sum (o - k)^2, count} over the
+                                             tile's stored outputs o WITHOUT the bias, k = the tile's first output; feed nirgan_instnorm_fwd with
                                              ws = stats_ws, stats_chunks = tiles per image, stats_shift = bias */
     /* optional (nirgan_wino6_output of a DATA GRADIENT over the padded extent, 3x3 filters): the first pass of the instance-norm backward
        of the layer that consumes this gradient, in the same kernel.  H x W here is the padded extent (interior (H-2) x (W-2), reflect halo

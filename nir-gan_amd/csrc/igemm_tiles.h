@@ -421,21 +421,26 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         return;
     }
 #endif
-    // ---------------- partial sums for the instance norm that follows: the wave's 64 rows x BN/2 columns leave sum and sum of
-    // squares per column (rows past M came from the zero page: they add nothing), taken WITHOUT the bias (the shift of the
-    // statistics); the two half-waves hold the same column, one exchange joins them.  Fixed order, no atomics.
+    // ---------------- partial sums for the instance norm that follows: the wave's 64 rows x BN/2 columns leave, per column, FOUR values:
+    // a shift k (the column's value in the chunk's first row, without the bias), sum (v - k), sum (v - k)^2 and the count 64.  Taken
+    // about a value of the data itself the sums carry no cancellation (about the bias alone, a channel whose mean is far from its bias
+    // -- the first layer on all-positive reflectances -- lost digits of its variance: 4e-3 on a weight gradient of the golden net);
+    // nirgan_instnorm_fwd re-bases the chunks onto one shift in a fixed order.  The host guarantees OH*OW % 128 == 0: every row of the
+    // tile is a real pixel of ONE sample.  The two half-waves hold the same column; one exchange joins them.  No atomics.
     if (p.stats != nullptr) {
-        const int b = m0 / p.OHW;                                    // host: OHW % 128 == 0, a tile stays inside one sample
+        const int b = m0 / p.OHW;
         const int chunk = p.stats_chunk0 + ((m0 - b * p.OHW) >> 7) * 2 + wr;
-        float* sp = p.stats + (size_t(b) * p.stats_cps + chunk) * 2 * p.N;
+        float* sp = p.stats + (size_t(b) * p.stats_cps + chunk) * 4 * p.N;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            const float own = acc[0][nt][0], other = __shfl_xor(own, 32, 64);
+            const float k = half == 0 ? own : other;                 // row 0 of the chunk lives in the lower half-wave
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[mt][nt][r];
+                    const float v = acc[mt][nt][r] - k;
                     s1 += v;
                     s2 += v * v;
                 }
@@ -443,8 +448,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
             s2 += __shfl_xor(s2, 32, 64);
             const int col = n0 + wc * (BN / 2) + nt * 32 + (lane & 31);
             if (half == 0 && col < p.N) {
-                sp[col] = s1;
-                sp[p.N + col] = s2;
+                sp[col] = k;
+                sp[p.N + col] = s1;
+                sp[2 * p.N + col] = s2;
+                sp[3 * p.N + col] = 64.f;
             }
         }
     }
@@ -1295,7 +1302,7 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     if (d->stats_ws != nullptr) {
         NG_REQUIRE(d->ksplit <= 1 && p.OHW % 128 == 0, "conv: the instance-norm partial sums need OH*OW %% 128 == 0 and no split-K (OH*OW=%d)", p.OHW);
         NG_REQUIRE(d->stats_chunk0 >= 0 && d->stats_chunk0 + p.OHW / 64 <= d->stats_chunks, "conv: stats_chunk0 + OH*OW/64 exceeds stats_chunks");
-        NG_REQUIRE(d->stats_ws_elems >= int64_t(d->B) * d->stats_chunks * 2 * d->N, "conv: stats_ws too small");
+        NG_REQUIRE(d->stats_ws_elems >= int64_t(d->B) * d->stats_chunks * 4 * d->N, "conv: stats_ws too small (B * stats_chunks * 4 * N floats)");
         p.stats = d->stats_ws; p.stats_chunk0 = d->stats_chunk0; p.stats_cps = d->stats_chunks;
     }
     p.f_y = nullptr; p.f_mean = nullptr; p.f_rstd = nullptr; p.f_part = nullptr;

@@ -84,19 +84,40 @@ __device__ __forceinline__ void chunk_sums(const float* w, int nchunk, int C, in
     rg_reduce2(s1, s2, lds, tid, q4, nrg);
 }
 
+// The same for partial sums a PRODUCER left (convolution epilogue, Winograd output transform): per chunk and channel [k, s1, s2, n] =
+// shift, sum (v - k), sum (v - k)^2, count.  Every chunk is re-based onto the first chunk's shift K (values of the data itself, so
+// k - K is of the order of the spread): sum (v - K) = s1 + n (k - K), sum (v - K)^2 = s2 + 2 (k - K) s1 + n (k - K)^2 -- no term is
+// large against the variance, whatever the channel's mean.  Row groups add their chunks in a fixed order.  Result valid for tid < cw / 4.
+__device__ __forceinline__ void chunk_sums_rebased(const float* w, int nchunk, int C, int tid, f32x4* lds, f32x4& s1, f32x4& s2, f32x4& K, int c0, int cw) {
+    const int q4 = cw / 4, nrg = in_nrg(cw);
+    const int q = tid % q4, rg = tid / q4;
+    s1 = f32x4{0, 0, 0, 0};
+    s2 = f32x4{0, 0, 0, 0};
+    K = ld4(w + c0 + q * 4);
+    if (rg < nrg) {
+#pragma unroll 4
+        for (int c = rg; c < nchunk; c += nrg) {
+            const float* wc = w + size_t(c) * 4 * C + c0 + q * 4;
+            const f32x4 dk = ld4(wc) - K, a1 = ld4(wc + C), a2 = ld4(wc + 2 * C), n = ld4(wc + 3 * C);
+            s1 += a1 + n * dk;
+            s2 += a2 + 2.f * dk * a1 + n * dk * dk;
+        }
+    }
+    rg_reduce2(s1, s2, lds, tid, q4, nrg);
+}
+
 // one block per sample: chunk partials -> mean, rstd
 __global__ __launch_bounds__(256) void in_finalize_kernel(const InFwd p, int B) {
     __shared__ f32x4 lds[512];
     const int b = blockIdx.x, tid = threadIdx.x;
-    f32x4 s1, s2;
-    const int nchunk = p.pre_chunks > 0 ? p.pre_chunks : p.nchunk;
+    f32x4 s1, s2, k = {0.f, 0.f, 0.f, 0.f};
     const int cw = fin_cw(p.C), c0 = blockIdx.y * cw;
-    chunk_sums(p.ws + size_t(b) * nchunk * 2 * p.C, nchunk, p.C, tid, lds, s1, s2, c0, cw);
+    if (p.pre_chunks > 0) chunk_sums_rebased(p.ws + size_t(b) * p.pre_chunks * 4 * p.C, p.pre_chunks, p.C, tid, lds, s1, s2, k, c0, cw);
+    else chunk_sums(p.ws + size_t(b) * p.nchunk * 2 * p.C, p.nchunk, p.C, tid, lds, s1, s2, c0, cw);
     if (tid >= cw / 4) return;
     const int q = c0 / 4 + tid;
     const float inv = 1.f / float(p.HW);
-    f32x4 k = {0.f, 0.f, 0.f, 0.f};
-    if (p.pre_chunks > 0) { if (p.shift != nullptr) k = ld4(p.shift + q * 4); }
+    if (p.pre_chunks > 0) { if (p.shift != nullptr) k += ld4(p.shift + q * 4); }      // the producer's values exclude its bias
     else k = ld4(p.y + size_t(b) * p.HW * p.C + q * 4);
     const f32x4 m = s1 * inv;
     f32x4 var = s2 * inv - m * m, rstd;
@@ -286,7 +307,7 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
     p.shift = d->stats_shift;
     if (d->norm) {
         NG_REQUIRE(ng_aligned16(d->stats_shift), "instnorm_fwd: stats_shift must be 16-byte aligned");
-        NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * (p.pre_chunks > 0 ? p.pre_chunks : p.nchunk) * 2 * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
+        NG_REQUIRE(d->mean && d->rstd && d->ws && d->ws_elems >= int64_t(d->B) * (p.pre_chunks > 0 ? int64_t(p.pre_chunks) * 4 : int64_t(p.nchunk) * 2) * d->C, "instnorm_fwd: mean/rstd/ws missing or too small");
         if (p.pre_chunks == 0) hipLaunchKernelGGL(in_stats_kernel, dim3(p.nchunk, d->B), dim3(256), 0, st, p);
         hipLaunchKernelGGL(in_finalize_kernel, dim3(d->B, (d->C >= 64 && d->C % 64 == 0) ? d->C / 64 : 1), dim3(256), 0, st, p, d->B);
     }

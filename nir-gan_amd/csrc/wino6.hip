@@ -905,13 +905,17 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
     for (int e = 0; e < VW; ++e) bv[e] = 0.f;
     if (p.bias != nullptr) bv = *reinterpret_cast<const V4*>(p.bias + q * VW);
     float* yb = p.y + size_t(b) * p.H * p.W * p.K + q * VW;
-    // partial sums for the instance norm that follows (sum and sum of squares of this tile's stored outputs, taken about the bias):
-    // the statistics pass over y is not needed then
-    V4 s1 = bv * 0.f, s2 = bv * 0.f;
+    // partial sums for the instance norm that follows, per tile and channel FOUR values: a shift k (the tile's first output, without
+    // the bias), sum (o - k), sum (o - k)^2 over the tile's stored outputs, and their count (edge tiles store fewer): about a value of
+    // the data itself the sums carry no cancellation; nirgan_instnorm_fwd re-bases the tiles onto one shift.  The statistics pass over y
+    // is not needed then
+    V4 s1 = bv * 0.f, s2 = bv * 0.f, k0 = bv * 0.f;
+    int cnt = 0;
 #pragma unroll
     for (int a = 0; a < MO; ++a) {
         V4 o[MO];
         W6<V>::at(s[a], o);
+        if (a == 0) k0 = o[0];                      // (h, w) = (MO ty, MO tx) always exists
         const int h = MO * ty + a;
         if (h >= p.H) continue;
 #pragma unroll
@@ -919,15 +923,22 @@ __global__ __launch_bounds__(256) void wino6_output_kernel(const W6Out p) {
             const int w = MO * tx + c;
             if (w < p.W) {
                 *reinterpret_cast<V4*>(yb + (size_t(h) * p.W + w) * p.K) = o[c] + bv;
-                s1 += o[c];
-                s2 += o[c] * o[c];
+                const V4 dlt = o[c] - k0;
+                s1 += dlt;
+                s2 += dlt * dlt;
+                ++cnt;
             }
         }
     }
     if (p.stats != nullptr) {
-        float* sp = p.stats + size_t(t) * 2 * p.K + q * VW;
-        *reinterpret_cast<V4*>(sp) = s1;
-        *reinterpret_cast<V4*>(sp + p.K) = s2;
+        float* sp = p.stats + size_t(t) * 4 * p.K + q * VW;
+        V4 nv;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) nv[e] = float(cnt);
+        *reinterpret_cast<V4*>(sp) = k0;
+        *reinterpret_cast<V4*>(sp + p.K) = s1;
+        *reinterpret_cast<V4*>(sp + 2 * p.K) = s2;
+        *reinterpret_cast<V4*>(sp + 3 * p.K) = nv;
     }
 }
 
@@ -1374,7 +1385,7 @@ extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
     NG_REQUIRE(ng_aligned16(d->M) && ng_aligned16(d->y) && ng_aligned16(d->bias), "wino6_output: pointers must be 16-byte aligned");
     const long long T = w6_tiles(d->B, d->H, d->W, v);
     NG_REQUIRE(d->M_elems >= w6_np(v) * T * d->K, "wino6_output: M workspace too small");
-    NG_REQUIRE(!d->stats_ws || (d->stats_ws_elems >= T * 2 * d->K && ng_aligned16(d->stats_ws)), "wino6_output: stats_ws too small or unaligned");
+    NG_REQUIRE(!d->stats_ws || (d->stats_ws_elems >= T * 4 * d->K && ng_aligned16(d->stats_ws)), "wino6_output: stats_ws too small (T * 4 * K floats) or unaligned");
     if (d->fuse_gz != nullptr) {
         // the data gradient's output transform + the first pass of the consumer's instance-norm backward
         NG_REQUIRE(v == 6 && !d->bias && !d->stats_ws, "wino6_output: the fused instance-norm backward pass is for F(6x6,3x3) data gradients (no bias, no forward statistics)");

@@ -395,7 +395,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     d.zero_page = ctx.zero_page.data_ptr()
     d.algo = OPT.w6_gemm_algo
     if stats_ws is not None:        # the output transform leaves the instance norm's partial sums (one chunk per tile): no statistics pass over y
-        assert stats_ws.numel() >= T * 2 * cout
+        assert stats_ws.numel() >= T * 4 * cout
         d.stats_ws, d.stats_ws_elems = stats_ws.data_ptr(), stats_ws.numel()
     ctx.keep.append(d)
     if plan is not None:
@@ -508,15 +508,16 @@ def attach_conv_stats(ctx: Ctx, descs: list, bias) -> Optional[tuple]:
     (chunks per sample, shift, workspace) for emit_in_fwd(pre_stats=...), or None when a problem does not qualify."""
     if not OPT.epilogue_stats or any(d.ksplit > 1 or (d.OH * d.OW) % 128 for d in descs):
         return None
-    # worth it from ~16 K pixels per sample (the 128x128 and 256x256 layers: 16 / 54 us of statistics pass each); below, the pass
+    # worth it from ~16 K pixels per sample in fp32 (the 128x128 and 256x256 layers save 16 / 54 us of statistics pass each; the trunk is
+    # Winograd there) and from 4 K in the bf16 operand mode (its 64x64 trunk maps run on the direct tiles: 1436 -> 1453 tiles/s); below, the pass
     # costs 2-4 us and the layer keeps it (OPT.epilogue_min_pixels: the kernel tests run small layers through it)
-    if sum(d.OH * d.OW for d in descs) < OPT.epilogue_min_pixels:
+    if sum(d.OH * d.OW for d in descs) < (OPT.epilogue_min_pixels if ctx.precision == 0 else min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16)):
         return None
     B, N = descs[0].B, descs[0].N
     total = sum(d.OH * d.OW // 64 for d in descs)
     if not hasattr(ctx, "conv_pool_stats"):
         ctx.conv_pool_stats = SplitPool(ctx)
-    ws = ctx.conv_pool_stats.get(B * total * 2 * N)
+    ws = ctx.conv_pool_stats.get(B * total * 4 * N)
     first = 0
     for d in descs:
         d.stats_ws, d.stats_ws_elems, d.stats_chunk0, d.stats_chunks = ws.data_ptr(), ws.numel(), first, total
@@ -680,7 +681,7 @@ class ConvIN:
                 T = _w6_tiles(inp.B, self.OH, self.OW, wino6_variant(k))
                 if not hasattr(ctx, "wino6_pool_stats"):
                     ctx.wino6_pool_stats = SplitPool(ctx)
-                sws = ctx.wino6_pool_stats.get(T * 2 * self.cout)
+                sws = ctx.wino6_pool_stats.get(T * 4 * self.cout)
                 pre = (T // inp.B, self.bias, sws)
             self.wino_fwd = emit_wino6(plan, pack, ctx, inp, self.weight, self.bias, self.y, H=self.OH, W=self.OW, cin=inp.C,
                                        cout=self.cout, own_V=keep, x_norm=xn, r=k, stats_ws=sws)
@@ -773,7 +774,7 @@ class ConvIN:
                 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and OPT.fuse_inbwd
                 and all(c.ksplit <= 1 and (c.OH * c.OW) % 128 == 0 and c.N == self.cout and not c.bias for c in cds)
                 and sum(c.OH * c.OW for c in cds) == self.OH * self.OW
-                and self.OH * self.OW >= OPT.epilogue_min_pixels):
+                and self.OH * self.OW >= (OPT.epilogue_min_pixels if ctx.precision == 0 else min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16))):
             chunks = sum(c.OH * c.OW // 128 for c in cds)
             if not hasattr(ctx, "inbwd_part"):
                 ctx.inbwd_part = SplitPool(ctx)

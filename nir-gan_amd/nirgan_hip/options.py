@@ -27,6 +27,7 @@ class Options:
     epilogue_stats: bool = True
     fuse_inbwd: bool = True
     epilogue_min_pixels: int = 16384
+    epilogue_min_pixels_bf16: int = 4096      # bf16 operand mode: its residual trunk runs on the direct tiles (64 x 64 maps): 1436 -> 1453 tiles/s
     # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform
     fold_apply: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather

@@ -136,9 +136,9 @@ class EmuBackend:
         stats = None
         if d.stats_ws:
             ohw = d.OH * d.OW
-            if d.ksplit > 1 or ohw % 128 or d.stats_chunk0 < 0 or d.stats_chunk0 + ohw // 64 > d.stats_chunks or d.stats_ws_elems < d.B * d.stats_chunks * 2 * d.N:
+            if d.ksplit > 1 or ohw % 128 or d.stats_chunk0 < 0 or d.stats_chunk0 + ohw // 64 > d.stats_chunks or d.stats_ws_elems < d.B * d.stats_chunks * 4 * d.N:
                 return self._fail("conv: the instance-norm partial sums need OH*OW % 128 == 0, no split-K and a large enough stats_ws")
-            stats = arr(d.stats_ws, d.B * d.stats_chunks * 2 * d.N).reshape(d.B, d.stats_chunks, 2, d.N)
+            stats = arr(d.stats_ws, d.B * d.stats_chunks * 4 * d.N).reshape(d.B, d.stats_chunks, 4, d.N)
             self.calls.append("conv_stats")
         for b in range(d.B):
             acc = np.zeros((d.OH, d.OW, d.N), dtype=np.float64)
@@ -146,10 +146,14 @@ class EmuBackend:
                 off = (d.tap_dh[t] * d.in_wp + d.tap_dw[t]) * d.in_cs
                 A = inp[b * in_img + base[..., None] + off + rr]
                 acc += contract(A.reshape(-1, d.run), np.ascontiguousarray(w[:, t * d.run:(t + 1) * d.run].T), d.precision).reshape(d.OH, d.OW, d.N)
-            if stats is not None:                      # per 64 pixels: sum and sum of squares without the bias
+            if stats is not None:                      # per 64 pixels: {k = first pixel, sum (v - k), sum (v - k)^2, 64}, without the bias
                 ch = acc.reshape(-1, 64, d.N)
-                stats[b, d.stats_chunk0:d.stats_chunk0 + ch.shape[0], 0] = ch.sum(1)
-                stats[b, d.stats_chunk0:d.stats_chunk0 + ch.shape[0], 1] = (ch ** 2).sum(1)
+                k = ch[:, 0]
+                sl = slice(d.stats_chunk0, d.stats_chunk0 + ch.shape[0])
+                stats[b, sl, 0] = k
+                stats[b, sl, 1] = (ch - k[:, None]).sum(1)
+                stats[b, sl, 2] = ((ch - k[:, None]) ** 2).sum(1)
+                stats[b, sl, 3] = 64.0
             if bias is not None:
                 acc += bias
             idx = b * out_img + obase[..., None] + np.arange(d.N)
@@ -500,16 +504,20 @@ class EmuBackend:
             arr(d.fuse_part, B * TH * TW * 2 * K).reshape(B, TH, TW, 2, K)[:] = part.transpose(1, 2, 3, 0, 4)
             return 0
         if d.stats_ws:
-            # per-tile partial sums of the stored outputs, without the bias
-            if d.stats_ws_elems < B * TH * TW * 2 * K:
+            # per tile {k = its first output, sum (o - k), sum (o - k)^2, count} over the stored outputs, without the bias
+            if d.stats_ws_elems < B * TH * TW * 4 * K:
                 return self._fail("wino6_output: stats_ws too small")
-            Yv = Y.copy()
-            Yv[:, H:] = 0
-            Yv[:, :, W:] = 0
-            tiles = Yv.reshape(B, TH, mo, TW, mo, K)
-            st = arr(d.stats_ws, B * TH * TW * 2 * K).reshape(B, TH, TW, 2, K)
-            st[:, :, :, 0] = tiles.sum((2, 4))
-            st[:, :, :, 1] = (tiles ** 2).sum((2, 4))
+            valid = np.zeros((TH * mo, TW * mo), dtype=bool)
+            valid[:H, :W] = True
+            vt = valid.reshape(TH, mo, TW, mo)
+            tiles = Y.reshape(B, TH, mo, TW, mo, K)
+            k = tiles[:, :, 0, :, 0, :]                                              # [B][TH][TW][K]
+            dl = (tiles - k[:, :, None, :, None, :]) * vt[None, :, :, :, :, None]
+            st = arr(d.stats_ws, B * TH * TW * 4 * K).reshape(B, TH, TW, 4, K)
+            st[:, :, :, 0] = k
+            st[:, :, :, 1] = dl.sum((2, 4))
+            st[:, :, :, 2] = (dl ** 2).sum((2, 4))
+            st[:, :, :, 3] = vt.sum((1, 3))[None, :, :, None]
         bias = arr(d.bias, K)
         if bias is not None:
             Y = Y + bias
@@ -772,16 +780,20 @@ class EmuBackend:
         y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float64)
         if d.norm:
             if d.stats_chunks > 0:
-                # partial sums left by the producer (nirgan_wino6_output): [B][chunks][2][C] about the shift
+                # partial sums left by the producer: [B][chunks][4][C] = {k, sum (v - k), sum (v - k)^2, count}, re-based onto chunk 0's shift
                 n = d.stats_chunks
-                if d.ws_elems < B * n * 2 * Cc:
+                if d.ws_elems < B * n * 4 * Cc:
                     return self._fail("in_fwd: ws too small")
                 self.calls.append("in_fwd_pre")
-                part = arr(d.ws, B * n * 2 * Cc).reshape(B, n, 2, Cc).astype(np.float64).sum(1)
+                part = arr(d.ws, B * n * 4 * Cc).reshape(B, n, 4, Cc).astype(np.float64)
+                K0 = part[:, :1, 0]
+                dk = part[:, :, 0] - K0
+                S1 = (part[:, :, 1] + part[:, :, 3] * dk).sum(1)
+                S2 = (part[:, :, 2] + 2 * dk * part[:, :, 1] + part[:, :, 3] * dk * dk).sum(1)
                 k = arr(d.stats_shift, Cc).astype(np.float64) if d.stats_shift else np.zeros(Cc)
-                m = part[:, 0] / (H * W)
-                mean = k + m
-                var = np.maximum(part[:, 1] / (H * W) - m * m, 0.0)
+                m = S1 / (H * W)
+                mean = k + K0[:, 0] + m
+                var = np.maximum(S2 / (H * W) - m * m, 0.0)
             else:
                 if d.ws_elems < self.nirgan_instnorm_ws_elems(B, H, W, Cc):
                     return self._fail("in_fwd: ws too small")

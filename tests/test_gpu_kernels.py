@@ -821,7 +821,7 @@ def test_wino6_output_leaves_the_instance_norm_partial_sums(shape):
     U, V, M = torch.zeros(NP * K * Cc, device=DEV), torch.zeros(NP * T * Cc, device=DEV), torch.zeros(NP * T * K, device=DEV)
     y = torch.zeros(B, H, W, K, device=DEV)
     zero = torch.zeros(64, device=DEV)
-    sws = torch.full((T * 2 * K,), float("nan"), device=DEV)
+    sws = torch.full((T * 4 * K,), float("nan"), device=DEV)
     d = L.Wino6Desc()
     d.r = v
     d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = x.data_ptr(), H + r - 1, W + r - 1, B, H, W, Cc, K
@@ -1122,3 +1122,46 @@ def test_wino6_input_transform_forms_agree_bitwise(shape):
         torch.cuda.synchronize()
         res.append(V.cpu())
     assert torch.isfinite(res[0]).all() and torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("kind", ["conv", "wino6"])
+def test_producer_partial_sums_do_not_cancel_with_a_large_channel_mean(kind):
+    """The instance-norm statistics a producer leaves (convolution epilogue / Winograd output transform: per chunk {k, sum (v - k),
+    sum (v - k)^2, count} about a value of the chunk itself) for channels whose mean is ~1e3 times their spread: rstd from the merged
+    chunks within 1e-4 of float64 (sums about the bias alone lose the variance entirely there: relative error ~1e-7 (mean / std)^2)."""
+    from nirgan_hip.engine import ConvIN, Weights, _Scratch, SlabPool
+    from nirgan_hip.options import OPT
+    B, H, W, Cin, Cout = (16 if kind == "conv" else 2), 64, 64, 128, 128        # (the direct tile splits K below ~400 tiles: no epilogue sums then)
+    g = torch.Generator().manual_seed(77)
+
+    class Eng:
+        pass
+    OPT.epilogue_min_pixels = 0
+    OPT.winograd = "f6" if kind == "wino6" else "off"
+    try:
+        ctx = Ctx(DEV, "fp32")
+        eng = Eng()
+        eng.ctx, eng.weights, eng.scratch, eng.slabs, eng.need_backward = ctx, Weights(ctx), _Scratch(ctx), SlabPool(ctx), False
+        inp = Halo(ctx, B, H, W, Cin, 1)
+        # a constant per input channel plus a small texture: every output channel gets a large mean (sum of w * const) and a small spread
+        x = 5.0 + 0.01 * torch.randn(inp.t.shape, generator=g)
+        inp.t.copy_(x.to(DEV))
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05 + 0.02).to(DEV)
+        bias = torch.zeros(Cout, device=DEV)
+        layer = ConvIN(eng, "t", "conv", inp, w, bias, k=3, s=1, p=1, cout=Cout, norm=True, act=L.ACT_RELU, out_pad=1, out_border=L.BORDER_REFLECT)
+        plan, pack = Plan(ctx), Plan(ctx)
+        layer.emit_fwd(plan, pack)
+        pack.run()
+        plan.run()
+        torch.cuda.synchronize()
+        d = [a[0]._obj for n, a in plan.ops if n == "nirgan_instnorm_fwd"][0]
+        assert d.stats_chunks > 0, "the producer's partial sums were not used"
+        y = layer.y.t.double().cpu().reshape(B, H * W, Cout)
+        ratio = (y.mean(1).abs() / y.std(1)).median().item()
+        assert ratio > 300, ratio
+        ref = 1.0 / torch.sqrt(y.var(1, unbiased=False) + 1e-5)
+        err = ((layer.stats[1].double().cpu() - ref).abs() / ref).max().item()
+        assert err < 1e-4, f"{kind}: rstd off by {err:.2e} at mean/std {ratio:.0f}"
+        close(layer.stats[0], y.mean(1), 1e-6, "mean")
+    finally:
+        OPT.reset()
