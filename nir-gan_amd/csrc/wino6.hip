@@ -1060,6 +1060,102 @@ __global__ __launch_bounds__(256) void wino6_output_inbwd_kernel(const W6Out p, 
     *reinterpret_cast<f32x4*>(odd ? sp + p.K : sp) = odd ? s2 : s1;
 }
 
+// The same fused output transform with the tile spread over the lanes of a wave (round 3; the input-side counterpart is
+// wino6_input_coop_kernel): a wave takes one tile x 32 channels.  Lane (a', qg) loads the 8 planes of plane row a' (16 bytes each, 128
+// contiguous bytes per plane and instruction) and applies A^T along the row; the 8 x 6 intermediate is transposed through a wave-private
+// 6 KB of LDS; lane (c, qg), c < 6, applies A^T down its column and then owns the 6 pixels of tile column c x 4 channels: the reflect
+// fold runs along the column in registers and across columns by two lane shuffles (border tiles only), the per-pixel phase moves 16
+// bytes per lane on 6 adjacent pixels per instruction.  Same transform arithmetic in the same order as the kernel above (g_a bitwise
+// equal); the tile's two sums are added in another order (fixed: bitwise reproducible).  ~100 VGPRs instead of 158.
+__global__ __launch_bounds__(256) void wino6_output_inbwd_coop_kernel(const W6Out p, const float* __restrict__ fy, const float* __restrict__ fmean,
+                                                                      const float* __restrict__ frstd, const float* __restrict__ fg2,
+                                                                      float* __restrict__ fgz, float* __restrict__ fpart, const int fact, const float fslope) {
+    constexpr int V = 6, N = 8, MO = 6;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[4][MO * N * 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hi = lane >> 3, qg = lane & 7;                    // hi = plane row a' in phase 1, tile column c in phase 2
+    const int groups = p.K / 32;
+    const long long unit = blockIdx.x * 4ll + wave, units = p.T * groups;
+    const bool live = unit < units;
+    const long long t = live ? unit / groups : 0;
+    const int cg = live ? int(unit - t * groups) : 0;
+    const int tx = int(t % p.TW);
+    const long long r_ = t / p.TW;
+    const int ty = int(r_ % p.TH), b = int(r_ / p.TH);
+    const int ch = cg * 32 + qg * 4;
+    const size_t plane = size_t(p.T) * p.K;
+    const float* M = p.M + size_t(t) * p.K + ch;
+    f32x4 m[N], tr[MO];
+#pragma unroll
+    for (int c = 0; c < N; ++c) m[c] = ld4(M + (hi * N + c) * plane);
+    W6<V>::at(m, tr);                                           // A^T along plane row a' = hi: 8 -> 6 columns
+    f32x4* buf = lds[wave];
+#pragma unroll
+    for (int c = 0; c < MO; ++c) buf[(c * N + hi) * 8 + qg] = tr[c];
+    __syncthreads();
+    const int c = hi;                                           // this lane now owns tile column c (lanes with c >= 6 idle)
+    const bool col_ok = c < MO;
+    f32x4 o[MO];
+    {
+        f32x4 v[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a) v[a] = buf[((col_ok ? c : 0) * N + a) * 8 + qg];
+        W6<V>::at(v, o);                                        // A^T down the column: o[a] = sum over a' of AT(a, a') tr_a'[c], a' ascending
+    }
+    const int Hi = p.H - 2, Wi = p.W - 2;                       // interior extent; padded coordinate = interior + 1
+    // fold rows (padded line 0 onto 2, Hi + 1 onto Hi - 1): inside the lane
+#pragma unroll
+    for (int a = 0; a < MO; ++a) {
+        const int hp = MO * ty + a;
+        if (a >= 2 && hp == 2) o[a] += o[a - 2];
+        if (a + 2 < MO && hp == Hi - 1) o[a] += o[a + 2];
+    }
+    // fold columns: the partner column lives two lane rows (16 lanes) away; only the first / last tile column of the image needs it
+    const int wp = MO * tx + c;
+    const bool need_l = col_ok && c >= 2 && wp == 2, need_r = col_ok && c + 2 < MO && wp == Wi - 1;
+    const bool edge = tx == 0 || (MO * tx <= Wi - 1 && Wi - 1 < MO * tx + MO);      // wave-uniform
+    if (edge) {
+#pragma unroll
+        for (int a = 0; a < MO; ++a)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lft = __shfl(o[a][e], (lane + 48) & 63, 64), rgt = __shfl(o[a][e], (lane + 16) & 63, 64);      // lanes - 16 / + 16
+                o[a][e] += (need_l ? lft : 0.f) + (need_r ? rgt : 0.f);
+            }
+    }
+    const f32x4 mean = ld4(fmean + size_t(b) * p.K + ch), rstd = ld4(frstd + size_t(b) * p.K + ch);
+    const float neg = fact == NIRGAN_ACT_RELU ? 0.f : fact == NIRGAN_ACT_LRELU ? fslope : 1.f;
+    const size_t img = size_t(b) * Hi * Wi * p.K + ch;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    const int w = MO * tx + c - 1;
+    if (live && col_ok && w >= 0 && w < Wi) {
+#pragma unroll
+        for (int a = 0; a < MO; ++a) {
+            const int h = MO * ty + a - 1;
+            if (h < 0 || h >= Hi) continue;
+            const size_t off = img + (size_t(h) * Wi + w) * p.K;
+            f32x4 ga = o[a];
+            if (fg2 != nullptr) ga += ld4(fg2 + off);
+            st4(fgz + off, ga);
+            const f32x4 z = (ld4(fy + off) - mean) * rstd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ga[e] = z[e] > 0.f ? ga[e] : ga[e] * neg;
+            s1 += ga;
+            s2 += ga * z;
+        }
+    }
+    // the tile's sums: over the 8 lane rows (columns 6, 7 hold zeros), fixed butterfly
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int d = 8; d < 64; d <<= 1) {
+            s1[e] += __shfl_xor(s1[e], d, 64);
+            s2[e] += __shfl_xor(s2[e], d, 64);
+        }
+    }
+    if (live && hi < 2) st4(fpart + size_t(t) * 2 * p.K + (hi == 1 ? p.K : 0) + ch, hi == 1 ? s2 : s1);
+}
+
 // ------------------------------------------------------------------------------------------------ weight-gradient finish
 struct W6Fin { const float* slabs; int nsplit, K, C; float* grad; int accumulate; };
 // up to 16 layers of one geometry in one grid (blockIdx.y = layer): the finish of a single layer is 17 us of launch latency for 33 MB
@@ -1400,6 +1496,11 @@ extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
         const long long nf = T * (d->K / (v == 3 ? 4 : 2));
         const dim3 gridf(unsigned((nf + 255) / 256));
         hipStream_t sf = static_cast<hipStream_t>(stream);
+        if (d->K % 32 == 0 && d->algo != NIRGAN_W6_PATCH_PER_THREAD) {      // the tile spread over a wave's lanes
+            const dim3 cgrid(unsigned((T * (d->K / 32) + 3) / 4));
+            hipLaunchKernelGGL(wino6_output_inbwd_coop_kernel, cgrid, dim3(256), 0, sf, pf, d->fuse_y, d->fuse_mean, d->fuse_rstd, d->fuse_g2, d->fuse_gz, d->fuse_part, d->fuse_act, d->fuse_slope);
+            return nirgan_check_launch("wino6_output");
+        }
         hipLaunchKernelGGL(wino6_output_inbwd_kernel<6>, gridf, dim3(256), 0, sf, pf, d->fuse_y, d->fuse_mean, d->fuse_rstd, d->fuse_g2, d->fuse_gz, d->fuse_part, d->fuse_act, d->fuse_slope);
         return nirgan_check_launch("wino6_output");
     }

@@ -1165,3 +1165,47 @@ def test_producer_partial_sums_do_not_cancel_with_a_large_channel_mean(kind):
         close(layer.stats[0], y.mean(1), 1e-6, "mean")
     finally:
         OPT.reset()
+
+
+@pytest.mark.parametrize("shape", [(2, 10, 10, 64, "relu", True), (16, 64, 64, 256, "none", True), (3, 22, 16, 96, "lrelu", False), (1, 64, 34, 32, "relu", True)])
+def test_wino6_fused_output_transform_forms_and_restatement(shape):
+    """nirgan_wino6_output in its fused mode (output transform of a data gradient over the padded extent + reflect fold + skip gradient +
+    the partial sums of the consumer's first instance-norm backward pass): the tile-per-thread kernel, the lane-spread kernel and the
+    numpy restatement.  The folded gradient g_a agrees bit for bit between the two device forms; the tile sums to fp32 rounding."""
+    B, Hi, Wi, K, actn, skip = shape
+    act = {"relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "none": L.ACT_NONE}[actn]
+    H, W = Hi + 2, Wi + 2                                   # padded extent of the data gradient
+    assert (H - 3) // 6 == (H - 1) // 6 and (W - 3) // 6 == (W - 1) // 6
+    TH, TW = -(-H // 6), -(-W // 6)
+    T = B * TH * TW
+    g = torch.Generator().manual_seed(19)
+    M = torch.randn(64 * T * K, generator=g)
+    y = torch.randn(B, Hi, Wi, K, generator=g)
+    g2 = torch.randn(B, Hi, Wi, K, generator=g) if skip else None
+    mean, rstd = torch.randn(B, K, generator=g) * 0.2, torch.rand(B, K, generator=g) + 0.5
+    outs = []
+    emu = EmuBackend()
+    for mode in ("lanes", "thread", "emu"):
+        dev = "cpu" if mode == "emu" else DEV
+        bufs = [t_.to(dev) if t_ is not None else None for t_ in (M, y, g2, mean, rstd)]
+        gz = torch.full((B, Hi, Wi, K), float("nan"), device=dev)
+        part = torch.full((T * 2 * K,), float("nan"), device=dev)
+        d = L.Wino6Desc()
+        d.r, d.B, d.H, d.W, d.C, d.K = 6, B, H, W, K, K
+        d.M, d.M_elems = bufs[0].data_ptr(), bufs[0].numel()
+        d.fuse_y, d.fuse_mean, d.fuse_rstd = bufs[1].data_ptr(), bufs[3].data_ptr(), bufs[4].data_ptr()
+        d.fuse_g2 = bufs[2].data_ptr() if skip else None
+        d.fuse_gz, d.fuse_part, d.fuse_part_elems, d.fuse_act, d.fuse_slope = gz.data_ptr(), part.data_ptr(), part.numel(), act, 0.2
+        d.algo = L.W6_PATCH_PER_THREAD if mode == "thread" else 0
+        if mode == "emu":
+            assert emu.nirgan_wino6_output(d) == 0
+        else:
+            L.call("nirgan_wino6_output", C.byref(d), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        outs.append((gz.cpu(), part.cpu().view(T, 2, K), bufs))
+    (gl, pl, _), (gt, pt, _), (ge, pe, _) = outs
+    assert torch.isfinite(gl).all() and torch.isfinite(pl).all()
+    assert torch.equal(gl, gt), "folded gradient differs between the two device forms"
+    close(pl, pt, 2e-6, "tile sums, lanes vs thread")
+    close(gl, ge, 2e-5, "folded gradient vs restatement")
+    close(pl, pe, 2e-5, "tile sums vs restatement")
