@@ -352,9 +352,9 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
 // as whole 1 KB rows), B^T runs along the row in the lane that now owns plane row a', and the 8 results leave as 16-byte stores (128
 // contiguous bytes per plane and instruction).  ~60 VGPRs.  Same arithmetic in the same order as the kernel above: bitwise equal.
 // MODE 0: halo'd buffer (Yt = A dY A^T from the same loads when p.Yt is set); 1: forward input normalised on the fly.
-template <int MODE>
+template <int V, int MODE>
 __global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
-    constexpr int V = 6, N = 8, MO = 6, R = 3;
+    constexpr int N = W6<V>::N, MO = W6<V>::MO, R = W6<V>::R;       // F(6x6,3x3): 8, 6, 3; F(4x4,4x4): 7, 4, 4 (lane rows >= N idle)
     constexpr bool NORM = MODE == 1;
     __shared__ __attribute__((aligned(16))) f32x4 lds[4][N * N * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -393,20 +393,23 @@ __global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
 #pragma unroll
         for (int a = 0; a < N; ++a) {
             const int rb = MO * ty + a;
-            d[a] = (rb < p.x_hp && cb < p.x_wp) ? ld4(base + size_t(rb) * p.x_row + size_t(cb) * p.C) : z4;
+            d[a] = (c < N && rb < p.x_hp && cb < p.x_wp) ? ld4(base + size_t(rb) * p.x_row + size_t(cb) * p.C) : z4;
         }
     }
     f32x4* buf = lds[wave];
     f32x4 o[N], m[N];
     W6<V>::bt(d, o);
+    const bool lane_ok = c < N;                                 // (7 x 7 patches leave the eighth lane row idle)
+    if (lane_ok) {
 #pragma unroll
-    for (int a = 0; a < N; ++a) buf[(a * N + c) * 8 + qg] = o[a];
+        for (int a = 0; a < N; ++a) buf[(a * N + c) * 8 + qg] = o[a];
+    }
     __syncthreads();
-    const int ap = c;                                           // this lane now owns plane row a' = its old column index
+    const int ap = lane_ok ? c : 0;                             // this lane now owns plane row a' = its old column index
 #pragma unroll
     for (int cc = 0; cc < N; ++cc) m[cc] = buf[(ap * N + cc) * 8 + qg];
     W6<V>::bt(m, o);
-    if (live) {
+    if (live && lane_ok) {
         const size_t plane = size_t(p.T) * p.C;
         float* Vp = p.V + size_t(t) * p.C + ch;
 #pragma unroll
@@ -416,16 +419,18 @@ __global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
         if (p.Yt != nullptr) {                                  // uniform over the block
             // output-gradient tile (ty, tx) = patch rows / columns 2 .. 7: the column pass of A on the rows already in registers
             f32x4 u[N];
-            W6<V>::a(d + (R - 1), u);                           // lanes of columns 0, 1 carry values nobody reads
+            W6<V>::a(d + (R - 1), u);                           // lanes of columns < R - 1 carry values nobody reads
             __syncthreads();
+            if (lane_ok) {
 #pragma unroll
-            for (int a = 0; a < N; ++a) buf[(a * N + c) * 8 + qg] = u[a];
+                for (int a = 0; a < N; ++a) buf[(a * N + c) * 8 + qg] = u[a];
+            }
             __syncthreads();
             f32x4 e[MO];
 #pragma unroll
             for (int cc = 0; cc < MO; ++cc) e[cc] = buf[(ap * N + (R - 1) + cc) * 8 + qg];
             W6<V>::a(e, u);
-            if (live && ty < p.yTH && tx < p.yTW) {
+            if (live && lane_ok && ty < p.yTH && tx < p.yTW) {
                 const size_t yplane = size_t(p.yT) * p.C;
                 float* Y = p.Yt + ((size_t(b) * p.yTH + ty) * p.yTW + tx) * p.C + ch;
 #pragma unroll
@@ -1298,11 +1303,12 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
     // F(6x6,3x3): the 8 x 8 patches spread over the lanes, one wave per (patch, 32 channels).  Measured inside the step (bs 16):
     // dY pass 73.8 -> 61.5 us, plain input 43.6 -> 41.3 us; the normalising variant 41.7 -> 44.5 us, so that one keeps the
     // patch-per-thread kernel unless asked (algo = NIRGAN_W6_PATCH_PER_LANES).  Alone, back to back, both forms move 5.3 TB/s.
-    const bool coop = v == 6 && d->C % 32 == 0 && d->algo != NIRGAN_W6_PATCH_PER_THREAD && (!ny || d->algo == NIRGAN_W6_PATCH_PER_LANES);
+    const bool coop = (v == 6 || v == 4) && d->C % 32 == 0 && d->algo != NIRGAN_W6_PATCH_PER_THREAD && (!ny || d->algo == NIRGAN_W6_PATCH_PER_LANES);
     if (coop) {
         const dim3 cgrid(unsigned((T * (d->C / 32) + 3) / 4));
-        if (ny) hipLaunchKernelGGL(wino6_input_coop_kernel<1>, cgrid, dim3(256), 0, st, in);
-        else hipLaunchKernelGGL(wino6_input_coop_kernel<0>, cgrid, dim3(256), 0, st, in);
+        if (ny) hipLaunchKernelGGL((wino6_input_coop_kernel<6, 1>), cgrid, dim3(256), 0, st, in);
+        else if (v == 6) hipLaunchKernelGGL((wino6_input_coop_kernel<6, 0>), cgrid, dim3(256), 0, st, in);
+        else hipLaunchKernelGGL((wino6_input_coop_kernel<4, 0>), cgrid, dim3(256), 0, st, in);
         return nirgan_check_launch("wino6_input");
     }
     if (ny && v == 3) hipLaunchKernelGGL((wino6_input_kernel<3, 1>), grid, dim3(256), 0, st, in);
@@ -1505,6 +1511,7 @@ extern "C" int nirgan_wino6_output(const nirgan_wino6_desc* d, void* stream) {
         return nirgan_check_launch("wino6_output");
     }
     W6Out p{d->M, d->bias, d->y, d->B, d->H, d->W, d->K, (d->H + mo - 1) / mo, (d->W + mo - 1) / mo, T, d->stats_ws};
+    // (the plain output transform keeps the tile-per-thread kernel: its lane-spread form measured 39.8 against 35.3 us per launch)
     const long long n = T * (d->K / (v == 3 ? 4 : 2));
     const dim3 grid(unsigned((n + 255) / 256));
     if (v == 3) hipLaunchKernelGGL(wino6_output_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);

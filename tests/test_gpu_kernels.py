@@ -1209,3 +1209,36 @@ def test_wino6_fused_output_transform_forms_and_restatement(shape):
     close(pl, pt, 2e-6, "tile sums, lanes vs thread")
     close(gl, ge, 2e-5, "folded gradient vs restatement")
     close(pl, pe, 2e-5, "tile sums vs restatement")
+
+
+@pytest.mark.parametrize("case", [(6, 2, 12, 16, 64, 128), (6, 16, 64, 64, 256, 256), (6, 3, 9, 11, 32, 96), (4, 2, 9, 13, 64, 128), (4, 32, 31, 31, 256, 512), (4, 1, 6, 5, 32, 32)])
+def test_wino6_input_transform_forms_agree_for_both_patch_sizes(case):
+    """The lane-spread form of the input transform / dY pass against the patch-per-thread kernels (nirgan_wino6_desc.algo) for the 8 x 8
+    patches of F(6x6,3x3) and the 7 x 7 patches of F(4x4,4x4) (the eighth lane row idles): V and Yt bit for bit."""
+    v, B, H, W, Cc, K = case
+    mo, r = (6, 3) if v == 6 else (4, 4)
+    n = mo + r - 1
+    g = torch.Generator().manual_seed(23)
+    st = torch.cuda.current_stream().cuda_stream
+    # ---- input + dY pass: dY [B][H][W][K] with a zero halo of r - 1; the data gradient covers (H + r - 1) x (W + r - 1)
+    He, We = H + r - 1, W + r - 1
+    T = B * (-(-He // mo)) * (-(-We // mo))
+    yT = B * (-(-H // mo)) * (-(-W // mo))
+    dy = torch.zeros(B, H + 2 * (r - 1), W + 2 * (r - 1), K)
+    dy[:, r - 1:r - 1 + H, r - 1:r - 1 + W] = torch.randn(B, H, W, K, generator=g)
+    dy = dy.to(DEV)
+    res = []
+    for algo in (0, L.W6_PATCH_PER_THREAD):
+        V = torch.full((n * n * T * K,), float("nan"), device=DEV)
+        Yt = torch.full((n * n * yT * K,), float("nan"), device=DEV)
+        d = L.Wino6Desc()
+        d.r, d.B, d.H, d.W, d.C, d.K = v, B, He, We, K, Cc
+        d.x, d.x_hp, d.x_wp, d.V, d.V_elems, d.algo = dy.data_ptr(), dy.shape[1], dy.shape[2], V.data_ptr(), V.numel(), algo
+        y = L.WinoDyDesc()
+        y.dy, y.dy_hp, y.dy_wp, y.dy_pad, y.B, y.H, y.W, y.K = dy.data_ptr(), dy.shape[1], dy.shape[2], r - 1, B, H, W, K
+        y.Yt, y.Yt_elems, y.r = Yt.data_ptr(), Yt.numel(), v
+        L.call("nirgan_wino6_input_dy", C.byref(d), C.byref(y), st)
+        torch.cuda.synchronize()
+        res.append((V.cpu(), Yt.cpu()))
+    assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
