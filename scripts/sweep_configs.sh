@@ -1,6 +1,7 @@
+mkdir -p gpurun_out
 set -o pipefail
 O=gpurun_out/sweep_final.jsonl; : > $O
-run() { timeout -k 10 280 python3 bench.py --no-cpu-baseline "$@" 2> gpurun_out/sweep_err.log | grep '^{' >> $O; echo "done $*"; }
+run() { timeout -k 10 280 python3 bench.py --no-cpu-baseline --sustain 3 "$@" 2> gpurun_out/sweep_err.log | grep '^{' >> $O; echo "done $*"; }
 run --blocks 9 --lambda-rs 1 --bs 32 &&
 run --inject --size 512 --padding 10 --bs 8 &&
 run --padding 10 &&
