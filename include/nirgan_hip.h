@@ -538,6 +538,11 @@ int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream);
 /* nirgan_wino6_input(c) and nirgan_wino6_dy(y) of the SAME output-gradient buffer (c->x == y->dy, zero halo 2) in one pass: the 4x4
  * block of tile (ty, tx) is the lower-right corner of data-gradient patch (ty, tx) */
 int nirgan_wino6_input_dy(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, void* stream);
+/* the same pass with dY NOT read from memory but evaluated on the fly as the instance-norm backward's result (F(6x6,3x3), C % 32 == 0): n
+ * describes the block (g / g2 / gsum_out, y, mean, rstd, act, ws as given to nirgan_instnorm_bwd with dy = NULL, which leaves the two
+ * reduction passes' means in ws); every patch element is rstd * (g_z - mean(g_z) - z * mean(g_z * z)), bitwise what the second pass would
+ * have stored into c->x -- that buffer is neither written nor read (c->x / y->dy only describe its geometry: zero halo 2) */
+int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* c, const nirgan_wino_dy_desc* y, const nirgan_in_bwd_desc* n, void* stream);
 int nirgan_wino6_wgrad_finish(const float* slabs, int nsplit, int K, int C, float* grad, int accumulate, void* stream);
 int nirgan_wino6_wgrad_finish_r(const float* slabs, int nsplit, int K, int C, int r, float* grad, int accumulate, void* stream);   /* [K][C][r][r] */
 /* the same for n <= 16 layers of one geometry in ONE grid (host arrays of device pointers; every layer then keeps its own slabs until the

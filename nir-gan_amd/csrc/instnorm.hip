@@ -332,7 +332,6 @@ extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     // fused mode (the folded gradient then sits in gsum_out) or a convolution launch with nirgan_conv_desc.fuse_* (the gradient is g
     // itself: no fold, no second gradient)
     const bool pre = d->norm && d->sums_chunks > 0;
-    NG_REQUIRE(!pre || !sums_only, "instnorm_bwd: sums_chunks needs a dy to write");
     NG_REQUIRE(!pre || d->gsum_out != nullptr || (d->g != nullptr && !d->g_fold && d->g2 == nullptr), "instnorm_bwd: sums_chunks needs the folded gradient in gsum_out, or a plain g (no fold, no g2)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     NG_REQUIRE(d->norm || !d->dbias || (d->ws && d->ws_elems >= int64_t(d->B) * p.nchunk * d->C),

@@ -231,6 +231,9 @@ struct W6In {
                                                  // is output-gradient tile (ty, tx): Yt = A dY A^T is emitted from the same read of dY
     // normalising variant: x = act((y - mean) * rstd) of a dense [B][H][W][C] tensor under a REFLECT halo of 1, evaluated on the fly
     const float* y; const float* mean; const float* rstd; int H, W, act; float slope;
+    // dY variant that evaluates the instance-norm backward's second pass on the fly (lane-spread kernel, MODE 2): x is NOT read;
+    // dY(h, w) = rstd * (g_z - mean(g_z) - z * mean(g_z z)) from the first pass's sums (in_bwd_dy: bitwise what in_bwd_pass2_kernel stores)
+    InBwd nb; int nbB;
 };
 
 template <int VW> struct W6Vec;
@@ -351,7 +354,10 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
 // all in flight at once; B^T runs down the column in registers, the 8 x 8 transpose goes through a wave-private 8 KB of LDS (written
 // as whole 1 KB rows), B^T runs along the row in the lane that now owns plane row a', and the 8 results leave as 16-byte stores (128
 // contiguous bytes per plane and instruction).  ~60 VGPRs.  Same arithmetic in the same order as the kernel above: bitwise equal.
-// MODE 0: halo'd buffer (Yt = A dY A^T from the same loads when p.Yt is set); 1: forward input normalised on the fly.
+// MODE 0: halo'd buffer (Yt = A dY A^T from the same loads when p.Yt is set); 1: forward input normalised on the fly; 2: dY pass whose
+// elements are the instance-norm backward's second pass evaluated on the fly (dY is never stored: the pass that would write it and this
+// kernel's read of it disappear -- 540 -> 388 MB per residual-block layer; two loads per element instead of one, which the per-thread
+// form of round 2 could not afford at 240 VGPRs).
 template <int V, int MODE>
 __global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
     constexpr int N = W6<V>::N, MO = W6<V>::MO, R = W6<V>::R;       // F(6x6,3x3): 8, 6, 3; F(4x4,4x4): 7, 4, 4 (lane rows >= N idle)
@@ -386,6 +392,22 @@ __global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * neg;
             d[a] = v * ok;
+        }
+    } else if constexpr (MODE == 2) {
+        const InBwd& n = p.nb;
+        const int q = ch >> 2;
+        const float* mm = n.ws + size_t(p.nbB) * n.pchunks * 2 * n.C + size_t(b) * 2 * n.C;
+        const f32x4 m1 = ld4(mm + ch), m2 = ld4(mm + n.C + ch);
+        const f32x4 mean = ld4(n.mean + size_t(b) * n.C + ch), rstd = ld4(n.rstd + size_t(b) * n.C + ch);
+        const float* yb = n.y + size_t(b) * n.HW * n.C;
+        const float* gsb = n.gsum_out ? n.gsum_out + size_t(b) * n.HW * n.C : nullptr;
+        const float* gb = n.g ? n.g + size_t(b) * n.g_img : nullptr;
+        const float* g2b = n.g2 ? n.g2 + size_t(b) * n.HW * n.C : nullptr;
+        const int w = MO * tx + c - (R - 1);                    // the dY grid has a zero halo of R - 1
+#pragma unroll
+        for (int a = 0; a < N; ++a) {
+            const int h = MO * ty + a - (R - 1);
+            d[a] = (c < N && h >= 0 && w >= 0 && h < n.H && w < n.W) ? in_bwd_dy(n, gb, g2b, gsb, yb, mean, rstd, m1, m2, h, w, q) : z4;
         }
     } else {
         const float* base = p.x + size_t(b) * p.x_img + ch;
@@ -1270,11 +1292,12 @@ extern "C" int nirgan_wino6_weights_batch(const int64_t* jobs_device, int njobs,
 }
 
 static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const float* ny, const float* mean, const float* rstd,
-                         int act, float slope, void* stream) {
-    NG_REQUIRE(d && d->V && (d->x || ny), "wino6_input: null pointer");
+                         int act, float slope, void* stream, const nirgan_in_bwd_desc* nb = nullptr) {
+    NG_REQUIRE(d && d->V && (d->x || ny || nb), "wino6_input: null pointer");
     const int v = w6_r(d->r), np = w6_np(v), r = w6_filter(v), mo = w6_mo(v);
     NG_REQUIRE(w6_known(v), "wino6_input: variant %d (3, 4 or 6)", v);
-    NG_REQUIRE(r == 3 || !ny, "wino6_input: the normalising variant exists for the 3x3 filter");
+    NG_REQUIRE(r == 3 || (!ny && !nb), "wino6_input: the fused variants exist for the 3x3 filter");
+    NG_REQUIRE(!nb || (v == 6 && d->C % 32 == 0), "wino6_input_dy_norm: F(6x6,3x3) with C %% 32 == 0 only");
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0, "wino6_input: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
     NG_REQUIRE(ny || (d->x_hp == d->H + r - 1 && d->x_wp == d->W + r - 1), "wino6_input: the input must be (H+%d) x (W+%d) (%dx%d for %dx%d)", r - 1, r - 1, d->x_hp, d->x_wp, d->H, d->W);
     NG_REQUIRE(ng_aligned16(d->x) && ng_aligned16(d->V) && ng_aligned16(ny) && ng_aligned16(mean) && ng_aligned16(rstd), "wino6_input: pointers must be 16-byte aligned");
@@ -1289,7 +1312,7 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
     in.y = ny; in.mean = mean; in.rstd = rstd; in.H = d->H; in.W = d->W; in.act = act; in.slope = slope;
     if (y != nullptr) {
         // the same dY buffer seen twice: zero halo r-1, the data gradient covers (H_dy + r - 1) x (W_dy + r - 1) outputs
-        NG_REQUIRE(!ny && y->dy == d->x && y->Yt && w6_r(y->r) == v && y->dy_pad == r - 1 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp
+        NG_REQUIRE(!ny && (nb || y->dy == d->x) && y->Yt && w6_r(y->r) == v && y->dy_pad == r - 1 && y->B == d->B && y->K == d->C && y->dy_hp == d->x_hp
                    && y->dy_wp == d->x_wp && d->H == y->H + r - 1 && d->W == y->W + r - 1,
                    "wino6_input_dy: the two descriptors do not describe the same output-gradient buffer");
         NG_REQUIRE(ng_aligned16(y->Yt), "wino6_input_dy: pointers must be 16-byte aligned");
@@ -1303,6 +1326,18 @@ static int w6_input_impl(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* 
     // F(6x6,3x3): the 8 x 8 patches spread over the lanes, one wave per (patch, 32 channels).  Measured inside the step (bs 16):
     // dY pass 73.8 -> 61.5 us, plain input 43.6 -> 41.3 us; the normalising variant 41.7 -> 44.5 us, so that one keeps the
     // patch-per-thread kernel unless asked (algo = NIRGAN_W6_PATCH_PER_LANES).  Alone, back to back, both forms move 5.3 TB/s.
+    in.nbB = 0;
+    if (nb != nullptr) {
+        NG_REQUIRE(y != nullptr && nb->norm && nb->y && nb->mean && nb->rstd && nb->ws && (nb->g || nb->g2 || nb->gsum_out), "wino6_input_dy_norm: the instance-norm descriptor needs y, mean, rstd, ws and a gradient");
+        NG_REQUIRE(nb->B == d->B && nb->C == d->C && nb->H == y->H && nb->W == y->W, "wino6_input_dy_norm: the instance-norm descriptor describes another tensor");
+        NG_REQUIRE(!nb->g || (nb->g_hp == nb->H + 2 * nb->g_pad && nb->g_wp == nb->W + 2 * nb->g_pad), "wino6_input_dy_norm: g geometry mismatch");
+        in.nb = in_bwd_params(nb);
+        in.nbB = nb->B;
+        NG_REQUIRE(nb->ws_elems >= int64_t(nb->B) * in.nb.pchunks * 2 * nb->C + int64_t(nb->B) * 2 * nb->C, "wino6_input_dy_norm: ws too small");
+        const dim3 cgrid(unsigned((T * (d->C / 32) + 3) / 4));
+        hipLaunchKernelGGL((wino6_input_coop_kernel<6, 2>), cgrid, dim3(256), 0, st, in);
+        return nirgan_check_launch("wino6_input_dy_norm");
+    }
     const bool coop = (v == 6 || v == 4) && d->C % 32 == 0 && d->algo != NIRGAN_W6_PATCH_PER_THREAD && (!ny || d->algo == NIRGAN_W6_PATCH_PER_LANES);
     if (coop) {
         const dim3 cgrid(unsigned((T * (d->C / 32) + 3) / 4));
@@ -1330,6 +1365,11 @@ extern "C" int nirgan_wino6_input_norm(const nirgan_wino6_desc* d, const float* 
     NG_REQUIRE(y && mean && rstd, "wino6_input_norm: null pointer");
     NG_REQUIRE(act == NIRGAN_ACT_NONE || act == NIRGAN_ACT_RELU || act == NIRGAN_ACT_LRELU, "wino6_input_norm: activation %d", act);
     return w6_input_impl(d, nullptr, y, mean, rstd, act, slope, stream);
+}
+
+extern "C" int nirgan_wino6_input_dy_norm(const nirgan_wino6_desc* d, const nirgan_wino_dy_desc* y, const nirgan_in_bwd_desc* n, void* stream) {
+    NG_REQUIRE(y != nullptr && n != nullptr, "wino6_input_dy_norm: null pointer");
+    return w6_input_impl(d, y, nullptr, nullptr, nullptr, 0, 0.f, stream, n);
 }
 
 extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {

@@ -411,7 +411,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
 
 
 def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, OH, OW, cin, cout, slabs_pool,
-                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False, r: int = 3):
+                        dgrad: "L.Wino6Desc", V_fwd: Optional["L.Wino6Desc"] = None, accumulate=False, r: int = 3, norm_desc=None):
     """Backward of an F(4x4,3x3) layer: dY -> (V of dY for the data gradient, Yt = A dY A^T for the weight gradient) in one pass, the
     data gradient's 36 plane GEMMs + output transform, the 36 transform-domain weight-gradient problems dU[f] = Yt[f]^T V[f] (V of the
     forward input, kept by the forward) as one weight-gradient launch, dW = G^T dU G."""
@@ -467,7 +467,10 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     d.nplanes, d.p_plane, d.q_plane = NP, T * cout, T * cin
     d.algo = OPT.wgrad_algo
     ctx.keep.extend([vin, ydesc, d, slabs])
-    plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
+    if norm_desc is not None:    # dY evaluated on the fly from the instance-norm backward's sums: its buffer is neither written nor read
+        plan.add("nirgan_wino6_input_dy_norm", C.byref(dgrad), C.byref(ydesc), C.byref(norm_desc))
+    else:
+        plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
     if vin is not None:
         plan.add("nirgan_wino6_input", C.byref(vin))
     if OPT.w6_pair:                                # 24.87 -> 24.64 ms per step
@@ -608,7 +611,7 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
     if gsum is not None:
         d.gsum_out = gsum.ptr
     if pre_sums:
-        assert norm and not sums_only and (gsum is not None or (g is not None and not g_fold and g2 is None))
+        assert norm and (gsum is not None or (g is not None and not g_fold and g2 is None))
         d.sums_chunks = pre_sums
     if dbias is not None:
         d.dbias = dbias.data_ptr()
@@ -733,12 +736,14 @@ class ConvIN:
         k, s, p = self.k, self.s, self.p
         act = self.act if act is None else act
         dy = self.dy
-        # Winograd backward (below).  (Round 2 measured the second pass of the instance-norm backward evaluated INSIDE the dY transform --
-        # dY never stored, bitwise the same V / Yt -- at 161 us against 84 + 31 per layer: every dY element is re-derived by the 2.25
-        # patches that contain it, at 240 VGPRs; that variant is gone.)
+        # Winograd backward (below).  (Round 2 measured the second pass of the instance-norm backward evaluated INSIDE the per-thread dY
+        # transform at 161 us against 84 + 31 per layer -- every dY element re-derived by the 2.25 patches that contain it, at 240 VGPRs.
+        # The lane-spread transform of round 3 has the registers for it: OPT.fuse_dy_norm.)
         w6_bwd = (self.kind == "conv" and s == 1 and gw is not None and dgrad_out is not None and dgrad_out.pad == p and dy.pad == k - 1
                   and wino_dgrad_applicable(ctx, k, s, dgrad_out, self.cout, inp.C) and inp.C > 64
                   and inp.pad == 1 and p == 1 and self.cout % 128 == 0)
+        fuse_dy = (w6_bwd and k == 3 and self.norm and dy.t16 is None and OPT.fuse_dy_norm and wino6_variant(3) == 6
+                   and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU))
         # The gradient arrives from an F(6x6,3x3) data gradient over the padded extent (reflect halo of 1 to fold): that launch's output
         # transform is switched to its fused mode -- it folds the halo in registers (lane pairs exchange half tiles so that the per-pixel
         # phase moves 16 bytes per lane), adds the skip gradient, stores the folded gradient dense and leaves the partial sums of this
@@ -792,7 +797,7 @@ class ConvIN:
                          y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
                          dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
                          ws=ws,
-                         shape=(inp.B, self.OH, self.OW, self.cout), pre_sums=pre_sums)
+                         shape=(inp.B, self.OH, self.OW, self.cout), pre_sums=pre_sums, sums_only=fuse_dy)
         # stride-1 convolutions that need both gradients
         if w6_bwd:
             # Winograd: data gradient and transform-domain weight gradient, dY read once for both of its transforms
@@ -800,7 +805,7 @@ class ConvIN:
                              cin=self.cout, cout=inp.C, flip=True, r=k)
             keepV = getattr(self, "wino_fwd_keeps_V", False) and getattr(self, "wino6", False)
             emit_wino6_backward(plan, ctx, dy, inp, gw, OH=self.OH, OW=self.OW, cin=inp.C, cout=self.cout, slabs_pool=eng.slabs,
-                                dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None), r=k)
+                                dgrad=wd6, V_fwd=(self.wino_fwd if keepV else None), r=k, norm_desc=(nd if fuse_dy else None))
             if k == 3:
                 dgrad_out.w6_out_desc = wd6          # the consumer of this gradient may switch the output transform to its fused mode
             return

@@ -179,6 +179,7 @@ PROTOTYPES = {
     "nirgan_wino6_weights_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_wino6_input": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_input_norm": (i32, [C.POINTER(Wino6Desc), fp, fp, fp, i32, f32, fp]),
+    "nirgan_wino6_input_dy_norm": (i32, [C.POINTER(Wino6Desc), C.POINTER(WinoDyDesc), C.POINTER(InBwdDesc), fp]),
     "nirgan_wino6_gemm": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_gemm_wgrad_pair": (i32, [C.POINTER(Wino6Desc), C.POINTER(WgradDesc), fp]),
     "nirgan_wino6_gemm_kernel_name": (C.c_char_p, [C.POINTER(Wino6Desc)]),

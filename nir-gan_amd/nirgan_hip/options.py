@@ -28,6 +28,9 @@ class Options:
     fuse_inbwd: bool = True
     epilogue_min_pixels: int = 16384
     epilogue_min_pixels_bf16: int = 4096      # bf16 operand mode: its residual trunk runs on the direct tiles (64 x 64 maps): 1436 -> 1453 tiles/s
+    # the second pass of a residual-block layer's instance-norm backward evaluated inside the dY Winograd transform (lane-spread kernel):
+    # dY is neither written nor read (nirgan_wino6_input_dy_norm)
+    fuse_dy_norm: bool = True
     # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform
     fold_apply: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather

@@ -560,6 +560,21 @@ class EmuBackend:
         rc = self.nirgan_wino6_input(cref)
         return rc if rc else self.nirgan_wino6_dy(yref)
 
+    def nirgan_wino6_input_dy_norm(self, cref, yref, nref, stream=None):
+        """dY evaluated from the instance-norm backward descriptor (whose own call ran with dy = NULL: reductions only), then the two
+        transforms.  The emulator materialises dY in the buffer the descriptors describe (the device never touches it)."""
+        c, y, n = obj(cref), obj(yref), obj(nref)
+        self.calls.append("wino6_dy_norm")
+        if n.dy or not n.norm or n.B != c.B or n.C != c.C or n.H != y.H or n.W != y.W or self._r6(c.r) != 6 or c.C % 32:
+            return self._fail("wino6_input_dy_norm: bad instance-norm descriptor")
+        full = type(n)()
+        C.memmove(C.byref(full), C.byref(n), C.sizeof(n))
+        full.dy, full.d_hp, full.d_wp, full.d_pad = y.dy, y.dy_hp, y.dy_wp, y.dy_pad
+        mark = len(self.calls)
+        rc = self.nirgan_instnorm_bwd(full)
+        del self.calls[mark:]                 # the device runs no second instance-norm call: keep the call log as the device's
+        return rc if rc else self.nirgan_wino6_input_dy(cref, yref)
+
     def nirgan_wino6_wgrad_finish(self, slabs, nsplit, K, Cc, grad, accumulate, stream=None):
         return self.nirgan_wino6_wgrad_finish_r(slabs, nsplit, K, Cc, 3, grad, accumulate)
 
@@ -830,8 +845,8 @@ class EmuBackend:
         if pre:
             # the producer left the first pass's partial sums in ws: nirgan_wino6_output in its fused mode (g_a then sits in gsum_out), or
             # a convolution launch with fuse_* (the gradient is g itself: no fold, no second gradient)
-            if not d.dy or d.ws_elems < B * d.sums_chunks * 2 * Cc + B * 2 * Cc:
-                return self._fail("in_bwd: sums_chunks needs dy and a large enough ws")
+            if d.ws_elems < B * d.sums_chunks * 2 * Cc + B * 2 * Cc:
+                return self._fail("in_bwd: sums_chunks needs a large enough ws")
             if not d.gsum_out and (not d.g or d.g_fold or d.g2):
                 return self._fail("in_bwd: sums_chunks needs gsum_out or a plain g")
             self.calls.append("in_bwd_pre")

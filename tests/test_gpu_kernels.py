@@ -1081,6 +1081,71 @@ def test_tile_gather_and_scatter_match_pad_slice_stack(case):
         L.call("nirgan_tile_gather", sd.data_ptr(), B, Cc, H, W, 4 * max(H, W), max(H, W), 0, 1, got.data_ptr(), st)
 
 
+@pytest.mark.parametrize("case", [("fold", 12, 16, 64), ("skip", 12, 16, 64), ("fold", 64, 64, 256), ("skip", 64, 64, 256), ("skip", 9, 11, 32),
+                                  ("pre", 64, 64, 256)])
+def test_wino6_dy_transform_with_the_instance_norm_backward_folded_in(case):
+    """nirgan_instnorm_bwd(dy = NULL: the two reductions only) + nirgan_wino6_input_dy_norm = the V / Yt that the full instance-norm
+    backward (which stores dY) followed by nirgan_wino6_input_dy produces -- bitwise: the second pass's arithmetic is evaluated inside
+    the lane-spread transform and dY never exists in memory.  Block kinds of the residual chain: first convolution (halo'd gradient
+    folded through the reflect padding, ReLU mask), second convolution (dense skip-path sum from pass 1, no activation), and 'pre' -- the
+    folded gradient dense in gsum_out with the first pass's partial sums already in ws, as the fused output transform leaves them."""
+    from nirgan_hip.engine import emit_in_bwd, emit_in_fwd
+    kind, H, W, Cc = case
+    B = 2
+    g = torch.Generator().manual_seed(33)
+    ctx = Ctx(DEV, "fp32")
+    st = torch.cuda.current_stream().cuda_stream
+    yh = Halo(ctx, B, H, W, Cc, 0)
+    yh.t.copy_((torch.randn(B, H, W, Cc, generator=g) * 1.3 + 0.2).to(DEV))
+    out = Halo(ctx, B, H, W, Cc, 1)
+    stats = (ctx.zeros(B, Cc), ctx.zeros(B, Cc))
+    ws = ctx.zeros(int(L.backend().nirgan_instnorm_ws_elems(B, H, W, Cc)) + 64 * 2 * B * Cc)
+    f = Plan(ctx)
+    emit_in_fwd(f, ctx, yh, out, norm=True, act=L.ACT_RELU, border=L.BORDER_REFLECT, stats=stats, ws=ws)
+    f.run()
+    gh = Halo(ctx, B, H, W, Cc, 1)
+    gh.t.copy_(torch.randn(B, H + 2, W + 2, Cc, generator=g).to(DEV))
+    g2 = Halo(ctx, B, H, W, Cc, 0)
+    g2.t.copy_(torch.randn(B, H, W, Cc, generator=g).to(DEV))
+    gsum = Halo(ctx, B, H, W, Cc, 0)
+    dy = Halo(ctx, B, H, W, Cc, 2)
+    kw = dict(g=gh, g_fold=True, y=yh, stats=stats, norm=True, dy=dy, ws=ws, shape=(B, H, W, Cc))
+    if kind == "skip":
+        kw.update(g2=g2, gsum=gsum, act=L.ACT_NONE)
+    elif kind == "pre":
+        chunks = 16
+        gsum.t.copy_(torch.randn(B, H, W, Cc, generator=g).to(DEV))
+        ws[:B * chunks * 2 * Cc].copy_(torch.randn(B * chunks * 2 * Cc, generator=g).to(DEV))
+        kw.update(gsum=gsum, act=L.ACT_RELU, pre_sums=chunks)
+    else:
+        kw.update(act=L.ACT_RELU)
+    full, sums = Plan(ctx), Plan(ctx)
+    emit_in_bwd(full, ctx, **kw)
+    nd = emit_in_bwd(sums, ctx, sums_only=True, **kw)
+    Td, Ty = B * (-(-(H + 2) // 6)) * (-(-(W + 2) // 6)), B * (-(-H // 6)) * (-(-W // 6))
+    res = []
+    for fused in (False, True):
+        V = torch.full((64 * Td * Cc,), float("nan"), device=DEV)
+        Yt = torch.full((64 * Ty * Cc,), float("nan"), device=DEV)
+        d = L.Wino6Desc()
+        d.r, d.x, d.x_hp, d.x_wp, d.B, d.H, d.W, d.C, d.K = 6, dy.ptr, H + 4, W + 4, B, H + 2, W + 2, Cc, Cc
+        d.V, d.V_elems = V.data_ptr(), V.numel()
+        yd = L.WinoDyDesc()
+        yd.dy, yd.dy_hp, yd.dy_wp, yd.dy_pad, yd.B, yd.H, yd.W, yd.K = dy.ptr, H + 4, W + 4, 2, B, H, W, Cc
+        yd.Yt, yd.Yt_elems, yd.r = Yt.data_ptr(), Yt.numel(), 6
+        if fused:
+            dy.t.fill_(float("nan"))          # the fused pass must not read the buffer
+            sums.run()
+            L.call("nirgan_wino6_input_dy_norm", C.byref(d), C.byref(yd), C.byref(nd), st)
+        else:
+            full.run()
+            L.call("nirgan_wino6_input_dy", C.byref(d), C.byref(yd), st)
+        torch.cuda.synchronize()
+        res.append((V.cpu(), Yt.cpu()))
+    assert torch.isfinite(res[0][0]).all() and torch.equal(res[0][0], res[1][0]), "V differs"
+    assert torch.isfinite(res[0][1]).all() and torch.equal(res[0][1], res[1][1]), "Yt differs"
+
+
 @pytest.mark.parametrize("shape", [(2, 12, 16, 64), (16, 64, 64, 256), (3, 9, 11, 32), (1, 21, 17, 96)])
 def test_wino6_input_transform_forms_agree_bitwise(shape):
     """F(6x6,3x3) input transforms: the patch-per-thread kernel and the lane-spread kernel (one wave per patch x 32 channels, transpose

@@ -748,6 +748,7 @@ def test_generator_winograd_layers_through_the_trainer(emu, monkeypatch, variant
             # arrives from a Winograd data gradient (11 block convolutions + the last stride-2 layer); 8x8 maps padded to 10x10 put
             # the far halo line and its fold partner into one 6x6 tile (with 4x4 tiles they straddle two: not fused)
             assert emu.calls.count("wino6_out_inbwd") == 12 and emu.calls.count("in_bwd_pre") == 12
+            assert emu.calls.count("wino6_dy_norm") == 12      # the instance-norm backward's second pass inside the dY transform
         else:
             assert "wino6_out_inbwd" not in emu.calls
     ref = O.OracleTrainer(G0, D0, 6, lr=0.0)
