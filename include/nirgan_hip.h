@@ -184,7 +184,8 @@ typedef struct {
     float* mean; float* rstd;             /* [B][C] */
     int act; float slope;
     const float* residual; int r_hp, r_wp, r_pad;   /* optional [B][r_hp][r_wp][C], interior at r_pad */
-    float* out; int o_hp, o_wp, o_pad; int border;   /* out = NULL (with norm): statistics only */
+    float* out; int o_hp, o_wp, o_pad; int border;   /* out = NULL and out_bf16 = NULL (with norm): statistics only; out = NULL with
+                                                      * out_bf16: only the twin is stored (every consumer reads bf16) */
     float* ws; int64_t ws_elems;          /* >= B * nchunk * 2 * C floats, see nirgan_instnorm_ws_elems */
     void* out_bf16;                       /* optional twin of `out` (same geometry, bf16 elements): every store is mirrored, rounded
                                            * to nearest even -- the operand the bf16 mode's convolutions read (in_bf16) */
@@ -220,7 +221,8 @@ typedef struct {
     float* gsum_out;
     float* dbias;
     float* ws; int64_t ws_elems;
-    void* dy_bf16;                        /* optional twin of `dy` (same geometry, bf16), as out_bf16 */
+    void* dy_bf16;                        /* optional twin of `dy` (same geometry, bf16), as out_bf16; with norm and dy = NULL only the twin is
+                                           * stored (dy = NULL and dy_bf16 = NULL: the two reductions only) */
     int sums_chunks;                      /* > 0 (with norm): the first pass is done -- the producer of the gradient left the partial sums of g_z
                                              and g_z * z in ws as [B][sums_chunks][2][C].  Either nirgan_wino6_output with fuse_gz (the folded
                                              gradient g_a then sits in gsum_out; g / g2 are not read), or a convolution launch with

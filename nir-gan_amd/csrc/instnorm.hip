@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
     const int start = chunk * p.ppc;
     int end = start + p.ppc;
     end = end < p.HW ? end : p.HW;
-    float* ob = p.out + size_t(b) * p.o_img;
+    float* ob = p.out ? p.out + size_t(b) * p.o_img : nullptr;
     unsigned short* ob16 = p.out16 ? p.out16 + size_t(b) * p.o_img : nullptr;
     const float* rb = p.residual ? p.residual + size_t(b) * p.r_img + p.r_org : nullptr;
     for (int pix = start + rg; pix < end; pix += nrg) {
@@ -169,12 +169,12 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
             for (int i = 0; i < nh; ++i)
                 for (int j = 0; j < nw; ++j) {
                     const size_t off = size_t(hs[i]) * p.o_row + size_t(wsx[j]) * p.C + q * 4;
-                    st4(ob + off, v);
+                    if (ob) st4(ob + off, v);
                     st4_twin(ob16, off, v);
                 }
         } else {
             const size_t off = size_t(h + p.o_pad) * p.o_row + size_t(w + p.o_pad) * p.C + q * 4;
-            st4(ob + off, v);
+            if (ob) st4(ob + off, v);
             st4_twin(ob16, off, v);
         }
     }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     const float* gsb = p.gsum_out ? p.gsum_out + size_t(b) * p.HW * p.C : nullptr;
     const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
     const float* g2b = p.g2 ? p.g2 + size_t(b) * p.HW * p.C : nullptr;
-    float* db = p.dy + size_t(b) * p.d_img + p.d_org;
+    float* db = p.dy ? p.dy + size_t(b) * p.d_img + p.d_org : nullptr;
     const int start = chunk * p.ppc;
     int end = start + p.ppc;
     end = end < p.HW ? end : p.HW;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
         const int h = pix / p.W, w = pix - h * p.W;
         const size_t off = size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
         const f32x4 r = in_bwd_dy(p, gb, g2b, gsb, yb, mean, rstd, m1, m2, h, w, q);
-        st4(db + off, r);
+        if (db) st4(db + off, r);
         st4_twin(p.dy16 ? p.dy16 + size_t(b) * p.d_img + p.d_org : nullptr, off, r);
     }
 }
@@ -287,8 +287,10 @@ extern "C" int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C) {
 }
 
 extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
-    NG_REQUIRE(d && d->y && (d->out || d->norm), "instnorm_fwd: null pointer");
-    const bool stats_only = d->out == nullptr;        // mean / rstd only: the consumer normalises on the fly (nirgan_wino_input_norm)
+    NG_REQUIRE(d && d->y && (d->out || d->out_bf16 || d->norm), "instnorm_fwd: null pointer");
+    // neither output: mean / rstd only, the consumer normalises on the fly (nirgan_wino6_input_norm); out_bf16 alone: every consumer reads the
+    // bf16 twin (bf16 operand mode), the fp32 tensor is not stored
+    const bool stats_only = d->out == nullptr && d->out_bf16 == nullptr;
     NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C >= 4 && d->C % 4 == 0 && d->C <= 1024, "instnorm_fwd: bad shape B=%d H=%d W=%d C=%d", d->B, d->H, d->W, d->C);
     NG_REQUIRE(ng_aligned16(d->y) && ng_aligned16(d->out) && ng_aligned16(d->residual), "instnorm_fwd: pointers must be 16-byte aligned");
     NG_REQUIRE(stats_only || (d->o_pad >= 0 && d->o_hp == d->H + 2 * d->o_pad && d->o_wp == d->W + 2 * d->o_pad), "instnorm_fwd: output halo geometry mismatch");
@@ -317,7 +319,9 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
 
 extern "C" int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream) {
     NG_REQUIRE(d && (d->dy || d->norm) && (d->g || d->g2), "instnorm_bwd: null pointer");
-    const bool sums_only = d->dy == nullptr;          // with norm: the two reductions only; the consumer evaluates dy on the fly (nirgan_wino6_input_dy_norm)
+    // with norm, neither dy nor dy_bf16: the two reductions only, the consumer evaluates dy on the fly (nirgan_wino6_input_dy_norm); dy_bf16 alone:
+    // every consumer reads the bf16 twin, the fp32 tensor is not stored
+    const bool sums_only = d->dy == nullptr && d->dy_bf16 == nullptr;
     NG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C >= 4 && d->C % 4 == 0 && d->C <= 1024, "instnorm_bwd: bad shape");
     NG_REQUIRE(!d->g || (d->g_hp == d->H + 2 * d->g_pad && d->g_wp == d->W + 2 * d->g_pad), "instnorm_bwd: g geometry mismatch");
     NG_REQUIRE(!d->g_fold || (d->g_pad < d->H && d->g_pad < d->W), "instnorm_bwd: fold halo wider than the image");

@@ -297,7 +297,7 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     if pair_with is not None:
         c = pair_with
         conv_blocks = -(-(c.B * c.OH * c.OW) // 128) * (-(-c.N // 128) if c.N > 64 else 1)
-        total = 512 * max(1, round((conv_blocks + 1024) / 512))
+        total = 512 * max(1, round((conv_blocks + 1024) / 512))      # (bf16 mode, round 3: 256 / 512 / 1024 / 1536 wanted blocks: 13.46 / 13.50 / 13.45 / 13.74 ms)
         target = max(total - conv_blocks, 512)
     twins = (ctx.precision == 1 and p.t16 is not None and q.t16 is not None and N > 64 and N % 8 == 0 and taps.run % 8 == 0
              and (pair_with is None or pair_with.in_bf16))
@@ -574,9 +574,33 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
         d.out, d.o_hp, d.o_wp, d.o_pad, d.border = out.ptr, out.hp, out.wp, out.pad, border
         if out.t16 is not None:
             d.out_bf16 = out.t16.data_ptr()
+            out.fwd_desc = d          # a layer bundle that knows every reader takes the twin may drop the fp32 store (drop_fp32_store)
     ctx.keep.append(d)
     plan.add("nirgan_instnorm_fwd", C.byref(d))
     return d
+
+
+def reads_twin(desc) -> bool:
+    """Does this launch descriptor read its activation operand(s) from the producers' bf16 twins?"""
+    if isinstance(desc, L.ConvDesc):
+        return bool(desc.in_bf16)
+    if isinstance(desc, L.WgradDesc):
+        return bool(desc.pq_bf16)
+    return False
+
+
+def drop_fp32_store(writer, readers) -> bool:
+    """bf16 operand mode: when EVERY reader of a twinned buffer takes the twin (`readers`: the launch descriptors that consume it, all of
+    them), the instance-norm launch that writes it stores the twin only -- `writer` is its descriptor (forward: out, backward: dy)."""
+    if writer is None or not readers or not all(r is not None and reads_twin(r) for r in readers):
+        return False
+    if isinstance(writer, L.InFwdDesc) and writer.out_bf16:
+        writer.out = None
+        return True
+    if isinstance(writer, L.InBwdDesc) and writer.dy_bf16 and writer.norm:
+        writer.dy = None
+        return True
+    return False
 
 
 def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Optional[Halo] = None, a: Optional[Halo] = None,
@@ -694,6 +718,7 @@ class ConvIN:
             w = eng.weights.packed(pack, self.weight, G.conv_fwd_pack(self.cout, inp.C, k))
             cd = emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
                            in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
+            self.inp_readers = [cd]        # launches that read this layer's input buffer (a residual block drops dead fp32 stores by it)
             if self.norm:
                 pre = attach_conv_stats(ctx, [cd], self.bias)
         elif self.kind == "rowpacked":
@@ -816,23 +841,28 @@ class ConvIN:
             wd = eng.weights.packed(pack, self.weight, G.conv_dgrad_pack(self.cout, inp.C, k, hw))
             cdesc = emit_conv(None, ctx, dy, G.conv_dgrad_s1_taps(k, self.cout), wd, None, dgrad_out, N=inp.C,
                               OH=dgrad_out.hp, OW=dgrad_out.wp)
-            emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
-                       N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
-                       q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_with=cdesc)
+            wdesc = emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
+                               N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
+                               q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_with=cdesc)
+            self.inp_readers = getattr(self, "inp_readers", []) + [wdesc]
+            drop_fp32_store(nd, [cdesc, wdesc])     # both readers of dY take its twin (bf16 operand mode): the fp32 dY is not stored
             return
         # weight gradient (skipped when the parameters are frozen: gw is None)
         if gw is None:
             pass
         elif self.kind == "conv":
-            emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
+            self.inp_readers = getattr(self, "inp_readers", []) + [None]
+            self.inp_readers[-1] = emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
                        N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
                        q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs)
         elif self.kind == "rowpacked":
-            emit_wgrad(plan, ctx, dy, inp, G.conv_rowpacked_taps(k, inp.C), G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C), gw,
+            self.inp_readers = getattr(self, "inp_readers", []) + [None]
+            self.inp_readers[-1] = emit_wgrad(plan, ctx, dy, inp, G.conv_rowpacked_taps(k, inp.C), G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C), gw,
                        N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
                        q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs)
         else:  # convT: rows = input channels, gathered side = dY with stride 2
-            emit_wgrad(plan, ctx, inp, dy, G.convT_dgrad_taps(k, self.cout), G.convT_dgrad_pack(inp.C, self.cout, k), gw,
+            self.inp_readers = getattr(self, "inp_readers", []) + [None]
+            self.inp_readers[-1] = emit_wgrad(plan, ctx, inp, dy, G.convT_dgrad_taps(k, self.cout), G.convT_dgrad_pack(inp.C, self.cout, k), gw,
                        N=inp.C, OH=inp.H, OW=inp.W, p_oh=inp.pad, p_ow=inp.pad, q_stride=2,
                        q_oh=dy.pad - p, q_ow=dy.pad - p, slabs_pool=eng.slabs)
         # data gradient

@@ -31,6 +31,9 @@ class Options:
     # the second pass of a residual-block layer's instance-norm backward evaluated inside the dY Winograd transform (lane-spread kernel):
     # dY is neither written nor read (nirgan_wino6_input_dy_norm)
     fuse_dy_norm: bool = True
+    # data parallel: the tail of each flat gradient goes to RCCL from inside the backward plan (two buckets per network); False = ONE blocking
+    # all-reduce per network after the backward (the opt-out while multi-rank RCCL behaviour is unmeasured on hardware)
+    dp_buckets: bool = True
     # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform
     fold_apply: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather

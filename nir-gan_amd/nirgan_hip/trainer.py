@@ -23,6 +23,7 @@ from typing import Dict, Optional
 import torch
 
 from . import lib as L
+from .options import OPT
 from .flat import FlatParams
 from .nets import DiscriminatorEngine, GeneratorEngine
 
@@ -98,7 +99,7 @@ class _ShapeState:
         # data parallel, single part: two gradient buckets per network -- the tail of the flat gradient goes to RCCL from inside
         # the backward plan, as soon as the launches that complete it are on the stream (parallel.GradReducer.begin); the head
         # follows after the plan.  With micro-batches the side parts are added after the plans: one bucket, after the join.
-        self.bucketed = tr.reducer is not None and n == 1
+        self.bucketed = tr.reducer is not None and n == 1 and OPT.dp_buckets
         self.headD = self.headG = None
         if self.bucketed:
             m = self.micros[0]

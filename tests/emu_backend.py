@@ -820,13 +820,14 @@ class EmuBackend:
             z = (y - mean[:, None]) * rstd[:, None]
         else:
             z = y
-        if not d.out:                      # statistics only
+        if not d.out and not d.out_bf16:   # statistics only
             return 0 if d.norm else self._fail("in_fwd: null pointer")
         a = self._act(z, d.act, d.slope).reshape(B, H, W, Cc)
         if d.residual:
             r = arr(d.residual, B * d.r_hp * d.r_wp * Cc).reshape(B, d.r_hp, d.r_wp, Cc)
             a = a + r[:, d.r_pad:d.r_pad + H, d.r_pad:d.r_pad + W]
-        out = arr(d.out, B * d.o_hp * d.o_wp * Cc).reshape(B, d.o_hp, d.o_wp, Cc)
+        # out = NULL with a twin: only the bf16 twin is stored (its halo, untouched by KEEP borders, is zero like the fp32 buffer's would be)
+        out = arr(d.out, B * d.o_hp * d.o_wp * Cc).reshape(B, d.o_hp, d.o_wp, Cc) if d.out else np.zeros((B, d.o_hp, d.o_wp, Cc), np.float32)
         P = d.o_pad
         out[:, P:P + H, P:P + W] = a
         if d.border == 1 and P > 0:
@@ -897,9 +898,11 @@ class EmuBackend:
             dy = dy.reshape(B, H, W, Cc)
         else:
             dy = gz
-        if not d.dy:                       # reductions only (with norm): a consumer evaluates dy on the fly; gsum_out was written above
+        if not d.dy and not d.dy_bf16:     # reductions only (with norm): a consumer evaluates dy on the fly; gsum_out was written above
             return 0 if d.norm else self._fail("in_bwd: dy missing")
-        o = arr(d.dy, B * d.d_hp * d.d_wp * Cc).reshape(B, d.d_hp, d.d_wp, Cc)
+        if not d.dy and not d.norm:
+            return self._fail("in_bwd: dy missing")
+        o = arr(d.dy, B * d.d_hp * d.d_wp * Cc).reshape(B, d.d_hp, d.d_wp, Cc) if d.dy else np.zeros((B, d.d_hp, d.d_wp, Cc), np.float32)
         o[:, d.d_pad:d.d_pad + H, d.d_pad:d.d_pad + W] = dy
         mirror_twin(d.dy_bf16, o)
         if d.dbias:

@@ -54,10 +54,16 @@ def _worker(rank, world, port, out_dir, micro, perturb=False):
             for p in list(netG.parameters()) + list(netD.parameters()):
                 p.add_(0.05 * torch.randn_like(p))
     red = GradReducer()
+    one_bucket = micro == 0            # the opt-out: one blocking all-reduce per network after its backward (OPT.dp_buckets = False)
+    if one_bucket:
+        from nirgan_hip.options import OPT
+        OPT.dp_buckets, micro = False, 1
     tr = Pix2PixTrainer(netG, netD, n_blocks=6, reducer=red, micro_batches=micro)
     rgb, nir = _batch()
     out = tr.step(shard_batch(rgb, rank, world), shard_batch(nir, rank, world)).as_dict()
-    if micro == 1:                     # two buckets per network: the tail went out from inside the backward plans
+    if one_bucket:
+        assert not tr._state.bucketed and not any(n == "__hook__" for n, _ in tr.G.bwd.ops)
+    elif micro == 1:                   # two buckets per network: the tail went out from inside the backward plans
         assert tr._state.bucketed and any(n == "__hook__" for n, _ in tr.G.bwd.ops) and any(n == "__hook__" for n, _ in tr.D2.bwd.ops)
         assert sum(p_.numel() for p_ in tr._state.headG) < 0.2 * tr.flatG.total and not red._pending
     torch.save({"gD": tr.flatD.grad.clone(), "gG": tr.flatG.grad.clone(), "pD": tr.flatD.flat.clone(),
@@ -66,9 +72,9 @@ def _worker(rank, world, port, out_dir, micro, perturb=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("micro,perturb", [(1, False), (2, False), (1, True)])
+@pytest.mark.parametrize("micro,perturb", [(1, False), (2, False), (1, True), (0, False)])
 def test_two_rank_gradients_equal_single_process(tmp_path, micro, perturb):
-    """micro = 2: every rank additionally cuts its shard into two parts whose gradients are summed before the all-reduce.
+    """micro = 0: one part, OPT.dp_buckets = False (the single blocking all-reduce).  micro = 2: every rank additionally cuts its shard into two parts whose gradients are summed before the all-reduce.
     perturb: rank 1 starts from different weights; the trainer broadcasts rank 0's (what DDP does when it wraps the module)."""
     _setup_path()
     port = 29500 + (os.getpid() % 2000) + 7 * micro + 3 * perturb
