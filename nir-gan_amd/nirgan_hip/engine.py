@@ -89,8 +89,20 @@ class Halo:
             ctx.bytes += self.t16.numel() * 2
             ctx.keep.append(self.t16)
 
+        # bf16 operand mode: who reads the fp32 tensor?  Launches that may take the twin instead register their descriptor in `readers`
+        # (emit_conv / emit_wgrad, through operand_ptr()); every other use goes through `.ptr` and pins the fp32 tensor.  A twinned buffer
+        # that is never pinned and whose readers all take the twin is stored as bf16 only (drop_dead_fp32_stores).
+        self.readers, self.pinned, self.writers = [], False, []
+
     @property
     def ptr(self):
+        self.pinned = True
+        return self.t.data_ptr()
+
+    def operand_ptr(self, reader=None):
+        """fp32 address for a launch that is twin-aware: `reader` (its descriptor) says later whether it took the twin (reads_twin)."""
+        if reader is not None:
+            self.readers.append(reader)
         return self.t.data_ptr()
 
     @property
@@ -256,7 +268,7 @@ def choose_ksplit(tiles: int, nk: int) -> int:
 def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bias, out: Halo, *, N, OH, OW,
               in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None, allow_split=True):
     d = L.ConvDesc()
-    d.inp, d.in_elems = inp.ptr, inp.elems
+    d.inp, d.in_elems = inp.operand_ptr(d), inp.elems
     if inp.t16 is not None and w.dtype == torch.bfloat16 and taps.run % 8 == 0:
         d.inp, d.in_bf16 = inp.t16.data_ptr(), 1          # both operands as stored (bf16 twin of the producer, bf16 weights)
     d.in_hp, d.in_wp, d.in_cs = (in_hw or (inp.hp, inp.wp)) + (inp.C,)
@@ -306,8 +318,8 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     slabs = slabs_pool.get(need) if slabs_pool is not None else ctx.zeros(need)
     ctx.keep.append(slabs)
     d = L.WgradDesc()
-    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = p.ptr, p.elems, p.hp, p.wp, p.C, p_oh, p_ow
-    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = q.ptr, q.elems, q.hp, q.wp, q.C
+    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = p.operand_ptr(d), p.elems, p.hp, p.wp, p.C, p_oh, p_ow
+    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = q.operand_ptr(d), q.elems, q.hp, q.wp, q.C
     if twins:
         d.p, d.q, d.pq_bf16 = p.t16.data_ptr(), q.t16.data_ptr(), 1     # both operands from the producers' bf16 twins
     d.q_stride, d.q_oh, d.q_ow = q_stride, q_oh, q_ow
@@ -571,10 +583,10 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
     if residual is not None:
         d.residual, d.r_hp, d.r_wp, d.r_pad = residual.ptr, residual.hp, residual.wp, residual.pad
     if not stats_only:
-        d.out, d.o_hp, d.o_wp, d.o_pad, d.border = out.ptr, out.hp, out.wp, out.pad, border
+        d.out, d.o_hp, d.o_wp, d.o_pad, d.border = out.operand_ptr(), out.hp, out.wp, out.pad, border
         if out.t16 is not None:
             d.out_bf16 = out.t16.data_ptr()
-            out.fwd_desc = d          # a layer bundle that knows every reader takes the twin may drop the fp32 store (drop_fp32_store)
+            out.writers.append(d)     # the fp32 store is dropped when every reader takes the twin (drop_dead_fp32_stores)
     ctx.keep.append(d)
     plan.add("nirgan_instnorm_fwd", C.byref(d))
     return d
@@ -589,18 +601,22 @@ def reads_twin(desc) -> bool:
     return False
 
 
-def drop_fp32_store(writer, readers) -> bool:
-    """bf16 operand mode: when EVERY reader of a twinned buffer takes the twin (`readers`: the launch descriptors that consume it, all of
-    them), the instance-norm launch that writes it stores the twin only -- `writer` is its descriptor (forward: out, backward: dy)."""
-    if writer is None or not readers or not all(r is not None and reads_twin(r) for r in readers):
-        return False
-    if isinstance(writer, L.InFwdDesc) and writer.out_bf16:
-        writer.out = None
-        return True
-    if isinstance(writer, L.InBwdDesc) and writer.dy_bf16 and writer.norm:
-        writer.dy = None
-        return True
-    return False
+def drop_dead_fp32_stores(buffers) -> int:
+    """bf16 operand mode: a twinned buffer whose fp32 tensor nobody reads -- never pinned through `.ptr`, every registered reader takes
+    the twin (reads_twin) -- is stored as bf16 only: its instance-norm writers get out / dy = NULL (168 -> 101 MB per forward launch of a
+    64 x 64 x 256 map at bs 16, 235 -> 168 MB per backward launch).  Called once per engine, after all of its plans are built."""
+    n = 0
+    for h in buffers:
+        if h.t16 is None or h.pinned or not h.readers or not h.writers or not all(reads_twin(r) for r in h.readers):
+            continue
+        for w in h.writers:
+            if isinstance(w, L.InFwdDesc):
+                w.out = None
+                n += 1
+            elif isinstance(w, L.InBwdDesc) and w.norm:
+                w.dy = None
+                n += 1
+    return n
 
 
 def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Optional[Halo] = None, a: Optional[Halo] = None,
@@ -617,8 +633,7 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
     if g2 is not None:
         assert g2.pad == 0
         d.g2 = g2.ptr
-    if a is not None:
-        d.a, d.a_hp, d.a_wp, d.a_pad = a.ptr, a.hp, a.wp, a.pad
+    # (`a`, the activated output, is not read by any kernel: the mask is the sign of z recomputed from y; the descriptor field stays 0)
     d.act, d.slope = act, slope
     d.norm = 1 if norm else 0
     if y is not None:
@@ -629,9 +644,10 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
         d.ws, d.ws_elems = ws.data_ptr(), ws.numel()
     d.B, d.H, d.W, d.C = B, H, W, Cc
     assert not sums_only or norm
-    d.dy, d.d_hp, d.d_wp, d.d_pad = (None if sums_only else dy.ptr), dy.hp, dy.wp, dy.pad
+    d.dy, d.d_hp, d.d_wp, d.d_pad = (None if sums_only else dy.operand_ptr()), dy.hp, dy.wp, dy.pad
     if dy.t16 is not None and not sums_only:
         d.dy_bf16 = dy.t16.data_ptr()
+        dy.writers.append(d)
     if gsum is not None:
         d.gsum_out = gsum.ptr
     if pre_sums:
@@ -687,6 +703,7 @@ class ConvIN:
         B = inp.B
         self.y = Halo(ctx, B, self.OH, self.OW, cout, 0)
         self.out = Halo(ctx, B, self.OH, self.OW, cout, out_pad, twin=True)
+        eng.__dict__.setdefault("twinned", []).append(self.out)          # see drop_dead_fp32_stores
         self.out_border = out_border
         self.stats = (ctx.zeros(B, cout), ctx.zeros(B, cout)) if norm else None
         eng.scratch.want(B, self.OH, self.OW, cout)
@@ -718,7 +735,6 @@ class ConvIN:
             w = eng.weights.packed(pack, self.weight, G.conv_fwd_pack(self.cout, inp.C, k))
             cd = emit_conv(plan, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=self.OH, OW=self.OW,
                            in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
-            self.inp_readers = [cd]        # launches that read this layer's input buffer (a residual block drops dead fp32 stores by it)
             if self.norm:
                 pre = attach_conv_stats(ctx, [cd], self.bias)
         elif self.kind == "rowpacked":
@@ -753,6 +769,7 @@ class ConvIN:
         else:
             zpad = 1 if need_dgrad else 0
         self.dy = Halo(ctx, self.inp.B, self.OH, self.OW, self.cout, zpad, twin=True)
+        self.eng.__dict__.setdefault("twinned", []).append(self.dy)
 
     def emit_bwd(self, plan: Plan, pack: Plan, *, g: Optional[Halo], g_fold=False, g2: Optional[Halo] = None,
                  gsum: Optional[Halo] = None, gw: Optional[torch.Tensor], gb: Optional[torch.Tensor], dgrad_out: Optional[Halo],
@@ -818,7 +835,7 @@ class ConvIN:
                 c.fuse_part, c.fuse_part_elems, c.fuse_chunk0, c.fuse_chunks = ws.data_ptr(), ws.numel(), first, chunks
                 first += c.OH * c.OW // 128
             pre_sums = chunks
-        nd = emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, a=(mask if mask is not None else self.out), act=act,
+        nd = emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, act=act,
                          y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
                          dbias=(None if self.norm else gb),   # a bias in front of InstanceNorm has gradient exactly 0: left at 0
                          ws=ws,
@@ -841,28 +858,23 @@ class ConvIN:
             wd = eng.weights.packed(pack, self.weight, G.conv_dgrad_pack(self.cout, inp.C, k, hw))
             cdesc = emit_conv(None, ctx, dy, G.conv_dgrad_s1_taps(k, self.cout), wd, None, dgrad_out, N=inp.C,
                               OH=dgrad_out.hp, OW=dgrad_out.wp)
-            wdesc = emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
-                               N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
-                               q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_with=cdesc)
-            self.inp_readers = getattr(self, "inp_readers", []) + [wdesc]
-            drop_fp32_store(nd, [cdesc, wdesc])     # both readers of dY take its twin (bf16 operand mode): the fp32 dY is not stored
+            emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
+                       N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
+                       q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs, pair_with=cdesc)
             return
         # weight gradient (skipped when the parameters are frozen: gw is None)
         if gw is None:
             pass
         elif self.kind == "conv":
-            self.inp_readers = getattr(self, "inp_readers", []) + [None]
-            self.inp_readers[-1] = emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
+            emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
                        N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
                        q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs)
         elif self.kind == "rowpacked":
-            self.inp_readers = getattr(self, "inp_readers", []) + [None]
-            self.inp_readers[-1] = emit_wgrad(plan, ctx, dy, inp, G.conv_rowpacked_taps(k, inp.C), G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C), gw,
+            emit_wgrad(plan, ctx, dy, inp, G.conv_rowpacked_taps(k, inp.C), G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C), gw,
                        N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
                        q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs)
         else:  # convT: rows = input channels, gathered side = dY with stride 2
-            self.inp_readers = getattr(self, "inp_readers", []) + [None]
-            self.inp_readers[-1] = emit_wgrad(plan, ctx, inp, dy, G.convT_dgrad_taps(k, self.cout), G.convT_dgrad_pack(inp.C, self.cout, k), gw,
+            emit_wgrad(plan, ctx, inp, dy, G.convT_dgrad_taps(k, self.cout), G.convT_dgrad_pack(inp.C, self.cout, k), gw,
                        N=inp.C, OH=inp.H, OW=inp.W, p_oh=inp.pad, p_ow=inp.pad, q_stride=2,
                        q_oh=dy.pad - p, q_ow=dy.pad - p, slabs_pool=eng.slabs)
         # data gradient
@@ -924,6 +936,7 @@ class TapPlaneConv:
         if not self.direct:
             self.q = Halo(ctx, inp.B, inp.hp, inp.wp, self.qcs, 0)
         self.whole_in = Halo(ctx, inp.B, inp.hp, inp.wp, inp.C, 0, tensor=inp.t)     # same memory, halo as image
+        inp.pinned = True       # read as fp32 through the alias above (and by the direct kernels): never a twin-only buffer
         self.dst = ctx.zeros(inp.B, 1, self.OH - 2 * crop, self.OW - 2 * crop)
 
     def _direct_desc(self, w):

@@ -16,7 +16,7 @@ import torch
 from . import geometry as G
 from . import lib as L
 from .options import OPT
-from .engine import (ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, drop_fp32_store, emit_conv,
+from .engine import (ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, drop_dead_fp32_stores, emit_conv,
                      emit_w6_deferred_finishes, emit_wgrad, wino_applicable)
 
 
@@ -141,10 +141,8 @@ class GeneratorEngine(_Engine):
             raise NotImplementedError("post_correction=True is not on the MI355X path yet")
         if need_backward:
             self._build_backward()
-        # bf16 operand mode: the first convolution's activated output is read by the second convolution and its weight gradient only, both
-        # from the bf16 twin -- the fp32 tensor is not stored (168 -> 101 MB per layer at bs 16)
-        for _, c1, c2 in self.blocks:
-            drop_fp32_store(getattr(c1.out, "fwd_desc", None), getattr(c2, "inp_readers", None))
+        # bf16 operand mode: activations / output gradients that every reader takes from the bf16 twin are stored as bf16 only
+        drop_dead_fp32_stores(getattr(self, "twinned", []))
 
     # ------------------------------------------------------------------ SatCLIP injection
     def _emit_inject_fwd(self, f: Plan):
