@@ -107,6 +107,10 @@ typedef struct {
     const float* fuse_y; const float* fuse_mean; const float* fuse_rstd;
     int fuse_h, fuse_w, fuse_oh, fuse_ow, fuse_act; float fuse_slope;
     float* fuse_part; int64_t fuse_part_elems; int fuse_chunk0, fuse_chunks;
+    /* bf16 operand mode: `out` points to bf16 elements (same geometry, out_elems counts them) -- the convolution's output in front of an
+     * instance norm is stored rounded to nearest even while the statistics (stats_ws) come from the fp32 accumulators; the norm's launches
+     * read it with y_bf16 = 1.  Needs N % 4 == 0, out_cs % 4 == 0, no split-K.  fuse_y_bf16: fuse_y points to such a tensor. */
+    int out_bf16, fuse_y_bf16;
 } nirgan_conv_desc;
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
@@ -194,6 +198,7 @@ typedef struct {
                                            * value of the chunk itself (nirgan_wino6_output / nirgan_conv_igemm with stats_ws): the pass
                                            * over y that would form them is skipped, the chunks are re-based onto one shift in a fixed order */
     const float* stats_shift;             /* [C], what the producer left out of v (the convolution's bias); NULL = 0 */
+    int y_bf16;                           /* 1: y points to bf16 elements (a convolution launch with out_bf16) */
 } nirgan_in_fwd_desc;
 
 int64_t nirgan_instnorm_ws_elems(int B, int H, int W, int C);
@@ -228,6 +233,7 @@ typedef struct {
                                              gradient g_a then sits in gsum_out; g / g2 are not read), or a convolution launch with
                                              nirgan_conv_desc.fuse_* (gsum_out NULL: the second pass reads g itself, which then has no fold
                                              and no g2).  ws >= B * sums_chunks * 2 * C + B * 2 * C floats */
+    int y_bf16;                           /* 1: y points to bf16 elements (as nirgan_in_fwd_desc.y_bf16) */
 } nirgan_in_bwd_desc;
 
 int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream);

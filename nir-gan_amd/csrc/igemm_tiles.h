@@ -82,6 +82,7 @@ struct ConvParams {
     const float* f_y; const float* f_mean; const float* f_rstd; float* f_part;
     int f_img, f_row, f_org, f_act, f_chunk0, f_cps;
     float f_slope;
+    int out16, f_y16;          // the output / the fused pass's y are stored as bf16 (nirgan_conv_desc.out_bf16 / fuse_y_bf16)
     int off32;                 // both operand buffers span < 4 GB: per-lane 32-bit byte offsets from a scalar base (the loader's fast path)
 };
 
@@ -507,9 +508,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                 const float* src = reinterpret_cast<const float*>(row < 64 ? st0 : st1) + (row & 63) * BN + chunk * 4;
                 f32x4 v = *reinterpret_cast<const f32x4*>(src);
                 v += bv;
-                float* dst = to_ws ? p.split_ws + ((size_t(ksp) * p.M + m) * p.N + n)
-                                   : p_out + (b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n);
-                if (n + 4 <= p.N) {
+                const int oidx = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n;
+                float* dst = to_ws ? p.split_ws + ((size_t(ksp) * p.M + m) * p.N + n) : p_out + oidx;
+                if (p.out16) {                        // (host: N % 4 == 0, no split-K) four bf16, rounded to nearest even
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(p_out) + oidx) = __builtin_convertvector(v, bf16x4_t);
+                } else if (n + 4 <= p.N) {
                     *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
 #pragma unroll
@@ -517,7 +521,14 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
                         if (n + j < p.N) dst[j] = v[j];
                 }
                 if (fused) {
-                    const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.f_y + (size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n));
+                    const size_t yidx = size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n;
+                    f32x4 y4;
+                    if (p.f_y16) {
+                        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                        y4 = __builtin_convertvector(*reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const unsigned short*>(p.f_y) + yidx), f32x4);
+                    } else {
+                        y4 = *reinterpret_cast<const f32x4*>(p.f_y + yidx);
+                    }
                     const f32x4 z = (y4 - fm) * fr;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -1298,6 +1309,9 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.dbg = nullptr;
     p.ksplit = 1;
     p.split_ws = nullptr;
+    p.out16 = d->out_bf16 ? 1 : 0;
+    p.f_y16 = d->fuse_y_bf16 ? 1 : 0;
+    NG_REQUIRE(!p.out16 || (d->N % 4 == 0 && d->out_cs % 4 == 0 && d->ksplit <= 1), "conv: a bf16 output needs N %% 4 == 0, out_cs %% 4 == 0 and no split-K (N=%d)", d->N);
     p.stats = nullptr; p.stats_chunk0 = 0; p.stats_cps = 0;
     if (d->stats_ws != nullptr) {
         NG_REQUIRE(d->ksplit <= 1 && p.OHW % 128 == 0, "conv: the instance-norm partial sums need OH*OW %% 128 == 0 and no split-K (OH*OW=%d)", p.OHW);

@@ -25,7 +25,7 @@ __device__ __forceinline__ void rg_reduce2(f32x4& s1, f32x4& s2, f32x4* lds, int
 }
 
 struct InFwd {
-    const float* y; int HW, W, H, C;
+    const float* y; int y16; int HW, W, H, C;      // y16: y is stored as bf16 (instnorm_dev.h::ldy4)
     int norm; float eps;
     float* mean; float* rstd;
     int act; float slope;
@@ -41,15 +41,15 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InFwd p) {
     const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
     const int q4 = p.C / 4, nrg = in_nrg(p.C);
     const int q = tid % q4, rg = tid / q4;
-    const float* yb = p.y + size_t(b) * p.HW * p.C;
+    const float* yb = y_at(p.y, size_t(b) * p.HW * p.C, p.y16);
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     if (rg < nrg) {
-        const f32x4 k = ld4(yb + q * 4);
+        const f32x4 k = ldy4(yb, q * 4, p.y16);
         const int start = chunk * p.ppc;
         int end = start + p.ppc;
         end = end < p.HW ? end : p.HW;
         for (int pix = start + rg; pix < end; pix += nrg) {
-            const f32x4 v = ld4(yb + size_t(pix) * p.C + q * 4) - k;
+            const f32x4 v = ldy4(yb, size_t(pix) * p.C + q * 4, p.y16) - k;
             s1 += v;
             s2 += v * v;
         }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const InFwd p, int B) 
     const int q = c0 / 4 + tid;
     const float inv = 1.f / float(p.HW);
     if (p.pre_chunks > 0) { if (p.shift != nullptr) k += ld4(p.shift + q * 4); }      // the producer's values exclude its bias
-    else k = ld4(p.y + size_t(b) * p.HW * p.C + q * 4);
+    else k = ldy4(y_at(p.y, size_t(b) * p.HW * p.C, p.y16), q * 4, p.y16);
     const f32x4 m = s1 * inv;
     f32x4 var = s2 * inv - m * m, rstd;
 #pragma unroll
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
     const int q4 = p.C / 4, nrg = in_nrg(p.C);
     const int q = tid % q4, rg = tid / q4;
     if (rg >= nrg) return;
-    const float* yb = p.y + size_t(b) * p.HW * p.C;
+    const float* yb = y_at(p.y, size_t(b) * p.HW * p.C, p.y16);
     f32x4 mean = {0, 0, 0, 0}, rstd = {1, 1, 1, 1};
     if (p.norm) {
         mean = ld4(p.mean + size_t(b) * p.C + q * 4);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
     const float* rb = p.residual ? p.residual + size_t(b) * p.r_img + p.r_org : nullptr;
     for (int pix = start + rg; pix < end; pix += nrg) {
         const int h = pix / p.W, w = pix - h * p.W;
-        f32x4 v = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
+        f32x4 v = (ldy4(yb, size_t(pix) * p.C + q * 4, p.y16) - mean) * rstd;
         v = act4(v, p.act, p.slope);
         if (rb) v += ld4(rb + size_t(h) * p.r_row + size_t(w) * p.C + q * 4);
         if (p.border == NIRGAN_BORDER_REFLECT && p.o_pad > 0) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
         }
         const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
         const float* g2b = p.g2 ? p.g2 + size_t(b) * p.HW * p.C : nullptr;
-        const float* yb = p.y ? p.y + size_t(b) * p.HW * p.C : nullptr;
+        const float* yb = p.y ? y_at(p.y, size_t(b) * p.HW * p.C, p.y16) : nullptr;
         float* db = p.dy + size_t(b) * p.d_img + p.d_org;
         const int start = chunk * p.ppc;
         int end = start + p.ppc;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
             // mask (ReLU / LeakyReLU), so the activated tensor does not have to be read back
             f32x4 z = {0, 0, 0, 0};
             const bool masked = p.act == NIRGAN_ACT_RELU || p.act == NIRGAN_ACT_LRELU;
-            if (p.norm || masked) z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
+            if (p.norm || masked) z = (ldy4(yb, size_t(pix) * p.C + q * 4, p.y16) - mean) * rstd;
             f32x4 gz = ga;
             if (masked) {
                 const float neg = p.act == NIRGAN_ACT_RELU ? 0.f : p.slope;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     const f32x4 m1 = ld4(mm + q * 4), m2 = ld4(mm + p.C + q * 4);
     const f32x4 mean = ld4(p.mean + size_t(b) * p.C + q * 4);
     const f32x4 rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
-    const float* yb = p.y + size_t(b) * p.HW * p.C;
+    const float* yb = y_at(p.y, size_t(b) * p.HW * p.C, p.y16);
     // g_z again, from what pass 1 read: the folded sum it stored for the skip path when there is one, else the halo'd gradient itself
     const float* gsb = p.gsum_out ? p.gsum_out + size_t(b) * p.HW * p.C : nullptr;
     const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
@@ -297,7 +297,7 @@ extern "C" int nirgan_instnorm_fwd(const nirgan_in_fwd_desc* d, void* stream) {
     NG_REQUIRE(d->border != NIRGAN_BORDER_REFLECT || (d->o_pad < d->H && d->o_pad < d->W), "instnorm_fwd: reflect halo wider than the image");
     NG_REQUIRE(!d->residual || (d->r_hp == d->H + 2 * d->r_pad && d->r_wp == d->W + 2 * d->r_pad), "instnorm_fwd: residual geometry mismatch");
     InFwd p;
-    p.y = d->y; p.H = d->H; p.W = d->W; p.HW = d->H * d->W; p.C = d->C;
+    p.y = d->y; p.y16 = d->y_bf16 ? 1 : 0; p.H = d->H; p.W = d->W; p.HW = d->H * d->W; p.C = d->C;
     p.norm = d->norm; p.eps = d->eps; p.mean = d->mean; p.rstd = d->rstd; p.act = d->act; p.slope = d->slope;
     p.residual = d->residual; p.r_row = d->r_wp * d->C; p.r_img = d->r_hp * p.r_row; p.r_org = d->r_pad * p.r_row + d->r_pad * d->C;
     p.out = d->out; p.o_row = d->o_wp * d->C; p.o_img = d->o_hp * p.o_row; p.o_pad = d->o_pad; p.border = d->border;

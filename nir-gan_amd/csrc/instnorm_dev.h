@@ -31,6 +31,17 @@ __device__ __forceinline__ int halo_images(int h, int H, int P, int* out) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// y (a convolution's output in front of its instance norm) is fp32, or -- bf16 operand mode, y16 -- stored as bf16 by the producing
+// launch (nirgan_conv_desc.out_bf16; the statistics come from its fp32 accumulators): element offsets, 2 or 4 bytes each
+__device__ __forceinline__ const float* y_at(const float* y, size_t elems, int y16) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(y) + elems * (y16 ? 2 : 4));
+}
+__device__ __forceinline__ f32x4 ldy4(const float* yb, size_t off, int y16) {
+    if (!y16) return ld4(yb + off);
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const char*>(yb) + off * 2);
+    return __builtin_convertvector(v, f32x4);
+}
 typedef __bf16 in_bf16x4 __attribute__((ext_vector_type(4)));
 // the bf16 twin of a buffer: same element offset, value rounded to nearest even
 __device__ __forceinline__ void st4_twin(unsigned short* twin, size_t off, f32x4 v) {
@@ -49,6 +60,7 @@ struct InBwd {
     float* dbias;
     float* ws; int nchunk, ppc;
     unsigned short* dy16;
+    int y16;
     int pchunks;               // chunks of partial sums per sample in ws (= nchunk, or the producer's count: nirgan_in_bwd_desc.sums_chunks)
 };
 
@@ -77,7 +89,7 @@ inline InBwd in_bwd_params(const nirgan_in_bwd_desc* d) {
     p.g2 = d->g2;
     p.a = d->a; p.a_row = d->a_wp * d->C; p.a_img = d->a_hp * p.a_row; p.a_org = d->a_pad * p.a_row + d->a_pad * d->C;
     p.act = d->act; p.slope = d->slope;
-    p.y = d->y; p.mean = d->mean; p.rstd = d->rstd; p.norm = d->norm;
+    p.y = d->y; p.y16 = d->y_bf16 ? 1 : 0; p.mean = d->mean; p.rstd = d->rstd; p.norm = d->norm;
     p.H = d->H; p.W = d->W; p.HW = d->H * d->W; p.C = d->C;
     p.dy = d->dy; p.d_row = d->d_wp * d->C; p.d_img = d->d_hp * p.d_row; p.d_org = d->d_pad * p.d_row + d->d_pad * d->C;
     p.gsum_out = d->gsum_out; p.dbias = d->dbias;
@@ -93,7 +105,7 @@ __device__ __forceinline__ f32x4 in_bwd_dy(const InBwd& p, const float* gb, cons
                                            const f32x4 mean, const f32x4 rstd, const f32x4 m1, const f32x4 m2, int h, int w, int q) {
     const int pix = h * p.W + w;
     f32x4 gz = gsb ? ld4(gsb + size_t(pix) * p.C + q * 4) : in_bwd_gsum(p, gb, g2b, h, w, pix, q);
-    const f32x4 z = (ld4(yb + size_t(pix) * p.C + q * 4) - mean) * rstd;
+    const f32x4 z = (ldy4(yb, size_t(pix) * p.C + q * 4, p.y16) - mean) * rstd;
     if (p.act == NIRGAN_ACT_RELU || p.act == NIRGAN_ACT_LRELU) {
         const float neg = p.act == NIRGAN_ACT_RELU ? 0.f : p.slope;
 #pragma unroll

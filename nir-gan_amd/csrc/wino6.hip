@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
         const float* mm = n.ws + size_t(p.nbB) * n.pchunks * 2 * n.C + size_t(b) * 2 * n.C;
         const f32x4 m1 = ld4(mm + ch), m2 = ld4(mm + n.C + ch);
         const f32x4 mean = ld4(n.mean + size_t(b) * n.C + ch), rstd = ld4(n.rstd + size_t(b) * n.C + ch);
-        const float* yb = n.y + size_t(b) * n.HW * n.C;
+        const float* yb = y_at(n.y, size_t(b) * n.HW * n.C, n.y16);
         const float* gsb = n.gsum_out ? n.gsum_out + size_t(b) * n.HW * n.C : nullptr;
         const float* gb = n.g ? n.g + size_t(b) * n.g_img : nullptr;
         const float* g2b = n.g2 ? n.g2 + size_t(b) * n.HW * n.C : nullptr;

@@ -74,9 +74,14 @@ class Ctx:
 class Halo:
     """[B][H+2p][W+2p][C] fp32 buffer; the interior starts at (p, p)."""
 
-    def __init__(self, ctx: Ctx, B, H, W, C, pad=0, tensor: Optional[torch.Tensor] = None, twin: bool = False):
+    def __init__(self, ctx: Ctx, B, H, W, C, pad=0, tensor: Optional[torch.Tensor] = None, twin: bool = False, bf16: bool = False):
         self.B, self.H, self.W, self.C, self.pad = B, H, W, C, pad
         self.hp, self.wp = H + 2 * pad, W + 2 * pad
+        if bf16:        # stored as bf16 only (a convolution output in front of its instance norm, bf16 operand mode: ConvIN.y)
+            assert tensor is None and not twin
+            tensor = torch.zeros(B, self.hp, self.wp, C, dtype=torch.bfloat16, device=ctx.device)
+            ctx.bytes += tensor.numel() * 2
+        self.is16 = bf16
         self.t = tensor if tensor is not None else ctx.zeros(B, self.hp, self.wp, C)
         assert self.t.numel() == B * self.hp * self.wp * C
         ctx.keep.append(self.t)          # descriptors hold raw pointers: the context owns every buffer
@@ -279,6 +284,7 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     if d.w_bf16 and taps.run % 8:
         raise ValueError(f"bf16-stored weights need run % 8 == 0 (run={taps.run})")
     d.out, d.out_elems = out.ptr, out.elems
+    d.out_bf16 = 1 if getattr(out, "is16", False) else 0
     d.out_hp, d.out_wp, d.out_cs = out.hp, out.wp, out.C
     d.out_stride, d.out_oh, d.out_ow = out_stride, out_oh, out_ow
     d.B, d.OH, d.OW, d.N = inp.B, OH, OW, N
@@ -573,6 +579,7 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
     assert not stats_only or (norm and residual is None)
     d = L.InFwdDesc()
     d.y, d.B, d.H, d.W, d.C = y.ptr, y.B, y.H, y.W, y.C
+    d.y_bf16 = 1 if y.is16 else 0
     d.norm, d.eps = (1 if norm else 0), IN_EPS
     if norm:
         d.mean, d.rstd = stats[0].data_ptr(), stats[1].data_ptr()
@@ -637,7 +644,7 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
     d.act, d.slope = act, slope
     d.norm = 1 if norm else 0
     if y is not None:
-        d.y = y.ptr
+        d.y, d.y_bf16 = y.ptr, (1 if y.is16 else 0)
     if norm:
         d.mean, d.rstd = stats[0].data_ptr(), stats[1].data_ptr()
     if norm or dbias is not None:       # partial sums of the two reduction passes / of the live bias gradient (one row per block)
@@ -701,7 +708,13 @@ class ConvIN:
             self.OH, self.OW = G.conv_out(inp.H, k, s, p), G.conv_out(inp.W, k, s, p)
         assert inp.pad >= (p if kind != "convT" else 1), (name, inp.pad, p)
         B = inp.B
-        self.y = Halo(ctx, B, self.OH, self.OW, cout, 0)
+        # bf16 operand mode: y is stored as bf16 when the convolution's epilogue takes the statistics from its fp32 accumulators (predicted
+        # here by the rule of attach_conv_stats; emit_fwd falls back to fp32 when the launch did not qualify): every pass over y -- the
+        # convolution's store, the norm's apply, both passes of its backward -- moves half the bytes
+        phase_px = self.OH * self.OW // (4 if kind == "convT" else 1)
+        y16 = (ctx.precision == 1 and norm and OPT.bf16_y and OPT.epilogue_stats and cout % 4 == 0 and phase_px % 128 == 0
+               and self.OH * self.OW >= min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16))
+        self.y = Halo(ctx, B, self.OH, self.OW, cout, 0, bf16=y16)
         self.out = Halo(ctx, B, self.OH, self.OW, cout, out_pad, twin=True)
         eng.__dict__.setdefault("twinned", []).append(self.out)          # see drop_dead_fp32_stores
         self.out_border = out_border
@@ -737,6 +750,7 @@ class ConvIN:
                            in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
             if self.norm:
                 pre = attach_conv_stats(ctx, [cd], self.bias)
+            self._y_fallback(pre, [cd])
         elif self.kind == "rowpacked":
             taps = G.conv_rowpacked_taps(k, inp.C)
             w = eng.weights.packed(pack, self.weight, G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C))
@@ -744,6 +758,7 @@ class ConvIN:
                            in_stride=s, in_oh=inp.pad - p, in_ow=inp.pad - p)
             if self.norm:
                 pre = attach_conv_stats(ctx, [cd], self.bias)
+            self._y_fallback(pre, [cd])
         else:  # convT: 4 sub-pixel phases over the zero-halo-1 input, one launch
             descs = []
             for ph in G.convT_fwd_phases(inp.H, inp.W, k, p):
@@ -754,10 +769,18 @@ class ConvIN:
                                        out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow))
             if self.norm:
                 pre = attach_conv_stats(ctx, descs, self.bias)
+            self._y_fallback(pre, descs)
             emit_conv_group(plan, ctx, descs)
         emit_in_fwd(plan, ctx, self.y, self.out, norm=self.norm, act=(L.ACT_NONE if self.keep_z else self.act),
                     residual=self.residual, border=self.out_border, stats=self.stats, ws=(pre[2] if pre is not None else eng.scratch.get()),
                     stats_only=getattr(self, "defer_apply", False), pre_stats=(pre[:2] if pre is not None else None))
+
+    def _y_fallback(self, pre, descs):
+        """y was allocated as bf16 on the prediction that the launch leaves the statistics; it did not (split-K): back to fp32."""
+        if self.y.is16 and pre is None:
+            self.y = Halo(self.eng.ctx, self.inp.B, self.OH, self.OW, self.cout, 0)
+            for d in descs:
+                d.out, d.out_bf16 = self.y.ptr, 0
 
     # ---- backward: g (+g2) is the gradient wrt `out`; produces dy (zero halo) then weight / data gradients
     def alloc_bwd(self, need_dgrad: bool):
@@ -829,6 +852,7 @@ class ConvIN:
             first = 0
             for c in cds:
                 c.fuse_y, c.fuse_mean, c.fuse_rstd = self.y.ptr, self.stats[0].data_ptr(), self.stats[1].data_ptr()
+                c.fuse_y_bf16 = 1 if self.y.is16 else 0
                 c.fuse_h, c.fuse_w = self.OH, self.OW
                 c.fuse_oh, c.fuse_ow = c.out_oh - g.pad, c.out_ow - g.pad
                 c.fuse_act, c.fuse_slope = act, 0.2

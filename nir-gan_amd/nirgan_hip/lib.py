@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
                 ("ksplit", i32), ("split_ws", fp), ("split_ws_elems", i64), ("precision", i32), ("w_bf16", i32), ("in_bf16", i32),
                 ("stats_ws", fp), ("stats_ws_elems", i64), ("stats_chunk0", i32), ("stats_chunks", i32),
                 ("fuse_y", fp), ("fuse_mean", fp), ("fuse_rstd", fp), ("fuse_h", i32), ("fuse_w", i32), ("fuse_oh", i32), ("fuse_ow", i32),
-                ("fuse_act", i32), ("fuse_slope", f32), ("fuse_part", fp), ("fuse_part_elems", i64), ("fuse_chunk0", i32), ("fuse_chunks", i32)]
+                ("fuse_act", i32), ("fuse_slope", f32), ("fuse_part", fp), ("fuse_part_elems", i64), ("fuse_chunk0", i32), ("fuse_chunks", i32),
+                ("out_bf16", i32), ("fuse_y_bf16", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -51,7 +52,7 @@ class InFwdDesc(C.Structure):
                 ("mean", fp), ("rstd", fp), ("act", i32), ("slope", f32),
                 ("residual", fp), ("r_hp", i32), ("r_wp", i32), ("r_pad", i32),
                 ("out", fp), ("o_hp", i32), ("o_wp", i32), ("o_pad", i32), ("border", i32),
-                ("ws", fp), ("ws_elems", i64), ("out_bf16", fp), ("stats_chunks", i32), ("stats_shift", fp)]
+                ("ws", fp), ("ws_elems", i64), ("out_bf16", fp), ("stats_chunks", i32), ("stats_shift", fp), ("y_bf16", i32)]
 
 
 class InBwdDesc(C.Structure):
@@ -60,7 +61,7 @@ class InBwdDesc(C.Structure):
                 ("y", fp), ("mean", fp), ("rstd", fp), ("norm", i32),
                 ("B", i32), ("H", i32), ("W", i32), ("C", i32),
                 ("dy", fp), ("d_hp", i32), ("d_wp", i32), ("d_pad", i32),
-                ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64), ("dy_bf16", fp), ("sums_chunks", i32)]
+                ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64), ("dy_bf16", fp), ("sums_chunks", i32), ("y_bf16", i32)]
 
 
 class ChanDgradDesc(C.Structure):

@@ -34,6 +34,8 @@ class Options:
     # data parallel: the tail of each flat gradient goes to RCCL from inside the backward plan (two buckets per network); False = ONE blocking
     # all-reduce per network after the backward (the opt-out while multi-rank RCCL behaviour is unmeasured on hardware)
     dp_buckets: bool = True
+    # bf16 operand mode: a convolution output in front of an instance norm is stored as bf16 (statistics from the fp32 accumulators)
+    bf16_y: bool = True
     # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform
     fold_apply: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather

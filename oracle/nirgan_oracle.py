@@ -59,21 +59,28 @@ DISC_CONV_IDX = [0, 2, 5, 8, 11]   # NLayerDiscriminator(n_layers=3) (networks.p
 # weight gradient -- are rounded to bf16 (nearest even), products and sums are fp32, everything else is fp32.
 # The reference has no bf16 path: this mode is parity UNPINNED against the reference (it converges to the fp32
 # path as the rounding is removed, which tests/ check by construction: same code, rounding function = identity).
+# `y_bf16_min_pixels` (bf16 mode only) restates the build's storage rule for convolution outputs in front of an InstanceNorm: on maps of at
+# least that many pixels per sample (and H*W -- per sub-pixel phase for a transposed convolution -- a multiple of 128: the build's tiles)
+# the statistics come from the fp32 result, the tensor itself is kept rounded to bf16, and both the normalisation and its backward
+# use the rounded values (_StoredBf16Norm).  None = every tensor stays fp32.
 _PRECISION = "fp32"
+_Y16_MIN_PIXELS = None
 
 
 class operand_precision:
-    def __init__(self, mode: str):
+    def __init__(self, mode: str, y_bf16_min_pixels=None):
         assert mode in ("fp32", "bf16"), mode
-        self.mode = mode
+        assert y_bf16_min_pixels is None or mode == "bf16"
+        self.mode, self.y16 = mode, y_bf16_min_pixels
 
     def __enter__(self):
-        global _PRECISION
-        self.prev, _PRECISION = _PRECISION, self.mode
+        global _PRECISION, _Y16_MIN_PIXELS
+        self.prev, _PRECISION = (_PRECISION, _Y16_MIN_PIXELS), self.mode
+        _Y16_MIN_PIXELS = self.y16
 
     def __exit__(self, *exc):
-        global _PRECISION
-        _PRECISION = self.prev
+        global _PRECISION, _Y16_MIN_PIXELS
+        _PRECISION, _Y16_MIN_PIXELS = self.prev
 
 
 def _bf(x: torch.Tensor) -> torch.Tensor:
@@ -187,8 +194,33 @@ def _lrelu(x: torch.Tensor, slope: float) -> torch.Tensor:
     return x * (m + slope * (1 - m))
 
 
-def _inorm(x: torch.Tensor) -> torch.Tensor:
-    # InstanceNorm2d(affine=False, track_running_stats=False): networks.py:30
+class _StoredBf16Norm(torch.autograd.Function):
+    """InstanceNorm2d of a tensor that is STORED as bf16 (build's bf16 mode, see _Y16_MIN_PIXELS): mean / variance of the fp32 values,
+    z = (bf(y) - mean) * rstd; backward by the instance-norm rule evaluated at that z:
+    dy = rstd * (g - mean(g) - z * mean(g * z))."""
+
+    @staticmethod
+    def forward(ctx, y):
+        mean = y.mean((2, 3), keepdim=True)
+        var = y.var((2, 3), unbiased=False, keepdim=True)
+        rstd = torch.rsqrt(var + IN_EPS)
+        z = (_bf(y) - mean) * rstd
+        ctx.save_for_backward(z, rstd)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        z, rstd = ctx.saved_tensors
+        return rstd * (g - g.mean((2, 3), keepdim=True) - z * (g * z).mean((2, 3), keepdim=True))
+
+
+def _inorm(x: torch.Tensor, phases: int = 1) -> torch.Tensor:
+    # InstanceNorm2d(affine=False, track_running_stats=False): networks.py:30.  phases = 4 behind a stride-2 transposed convolution
+    # (the build computes it as four sub-pixel problems: its storage rule looks at the pixels of one)
+    hw = x.shape[-2] * x.shape[-1]
+    if (_PRECISION == "bf16" and _Y16_MIN_PIXELS is not None and hw >= _Y16_MIN_PIXELS and (hw // phases) % 128 == 0
+            and x.shape[1] % 4 == 0):
+        return _StoredBf16Norm.apply(x)
     return F.instance_norm(x, eps=IN_EPS)
 
 
@@ -219,7 +251,7 @@ def generator_trunk_tail(p: Params, x: torch.Tensor, n_blocks: int) -> torch.Ten
     for i in k["up"]:              # ConvTranspose2d k3 s2 p1 op1 (networks.py:360-363)
         x = _conv_transpose2d(x, p[f"model.{i}.weight"], p[f"model.{i}.bias"],
                                stride=2, padding=1, output_padding=1)
-        x = _relu(_inorm(x))
+        x = _relu(_inorm(x, phases=4))
     i = k["last"]
     x = _conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), p[f"model.{i}.weight"], p[f"model.{i}.bias"])
     return torch.tanh(x)

@@ -52,6 +52,18 @@ def obj(ref):
     return ref._obj if hasattr(ref, "_obj") else ref
 
 
+def arr16(ptr, n) -> np.ndarray:
+    """n bf16 elements at ptr as a uint16 view (writable)."""
+    return np.ctypeslib.as_array((C.c_uint16 * int(n)).from_address(int(ptr)))
+
+
+def load_y(ptr, n, is_bf16) -> np.ndarray:
+    """a convolution output in front of an instance norm: fp32, or (bf16 operand mode, y_bf16 / fuse_y_bf16) stored as bf16"""
+    if is_bf16:
+        return (arr16(ptr, n).astype(np.uint32) << 16).view(np.float32)
+    return arr(ptr, n)
+
+
 def _in_nchunk(B, HW, Cc):
     q4 = Cc // 4
     nrg = 1 if q4 >= 256 else 256 // q4
@@ -109,7 +121,9 @@ class EmuBackend:
             w = (w16.astype(np.uint32) << 16).view(np.float32).reshape(d.N, K)
         else:
             w = arr(d.w, d.w_elems)[: d.N * K].reshape(d.N, K)
-        out = arr(d.out, d.out_elems)
+        if d.out_bf16 and (d.N % 4 or d.out_cs % 4 or d.ksplit > 1):
+            return self._fail("conv: a bf16 output needs N % 4 == 0, out_cs % 4 == 0 and no split-K")
+        out = arr16(d.out, d.out_elems) if d.out_bf16 else arr(d.out, d.out_elems)
         bias = arr(d.bias, d.N)
         in_row, out_row = d.in_wp * d.in_cs, d.out_wp * d.out_cs
         in_img, out_img = d.in_hp * in_row, d.out_hp * out_row
@@ -157,9 +171,12 @@ class EmuBackend:
             if bias is not None:
                 acc += bias
             idx = b * out_img + obase[..., None] + np.arange(d.N)
-            out[idx] = acc.astype(np.float32)
+            if d.out_bf16:
+                out[idx] = (bf16_round(acc.astype(np.float32)).view(np.uint32) >> 16).astype(np.uint16)
+            else:
+                out[idx] = acc.astype(np.float32)
             if d.fuse_y:                               # first pass of the consumer layer's instance-norm backward, per 128-pixel tile
-                yv = arr(d.fuse_y, d.B * d.fuse_h * d.fuse_w * d.N).reshape(d.B, d.fuse_h, d.fuse_w, d.N)
+                yv = load_y(d.fuse_y, d.B * d.fuse_h * d.fuse_w * d.N, d.fuse_y_bf16).reshape(d.B, d.fuse_h, d.fuse_w, d.N)
                 ys = yv[b, d.fuse_oh:d.fuse_oh + (d.OH - 1) * d.out_stride + 1:d.out_stride, d.fuse_ow:d.fuse_ow + (d.OW - 1) * d.out_stride + 1:d.out_stride]
                 z = ((ys - arr(d.fuse_mean, d.B * d.N).reshape(d.B, d.N)[b]) * arr(d.fuse_rstd, d.B * d.N).reshape(d.B, d.N)[b]).astype(np.float32)
                 gv = acc.astype(np.float32).astype(np.float64)
@@ -792,7 +809,7 @@ class EmuBackend:
         B, H, W, Cc = d.B, d.H, d.W, d.C
         if d.out and (d.o_hp != H + 2 * d.o_pad or d.o_wp != W + 2 * d.o_pad):
             return self._fail("in_fwd: geometry")
-        y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float64)
+        y = load_y(d.y, B * H * W * Cc, d.y_bf16).reshape(B, H * W, Cc).astype(np.float64)
         if d.norm:
             if d.stats_chunks > 0:
                 # partial sums left by the producer: [B][chunks][4][C] = {k, sum (v - k), sum (v - k)^2, count}, re-based onto chunk 0's shift
@@ -878,7 +895,7 @@ class EmuBackend:
             arr(d.gsum_out, B * H * W * Cc).reshape(B, H, W, Cc)[:] = ga
         z = None
         if d.norm or d.act in (1, 2):
-            y = arr(d.y, B * H * W * Cc).reshape(B, H * W, Cc).astype(np.float32)
+            y = load_y(d.y, B * H * W * Cc, d.y_bf16).reshape(B, H * W, Cc).astype(np.float32)
             if d.norm:
                 mean = arr(d.mean, B * Cc).reshape(B, 1, Cc)
                 rstd = arr(d.rstd, B * Cc).reshape(B, 1, Cc)

@@ -907,6 +907,69 @@ def test_conv_epilogue_leaves_the_instance_norm_partial_sums(case):
     close(o1, o0, 1e-5, "layer output")
 
 
+@pytest.mark.parametrize("case", [("conv", 2, 64, 64, 32, 64, 3, 1), ("conv", 2, 128, 128, 64, 128, 3, 2), ("convT", 2, 32, 32, 128, 64, 3, 2), ("conv", 16, 64, 64, 256, 256, 3, 1)])
+def test_bf16_mode_stores_the_convolution_output_as_bf16(case):
+    """bf16 operand mode, nirgan_conv_desc.out_bf16 + nirgan_in_fwd_desc / nirgan_in_bwd_desc.y_bf16: the convolution stores its output
+    rounded to nearest-even bf16 -- bitwise the rounding of what the same launch stores as fp32 (OPT.bf16_y = False) -- while mean / rstd
+    come from the fp32 accumulators (bitwise the same in both forms); the norm's apply and the two passes of its backward then use the
+    rounded tensor: checked against torch on the widened values with the device's own statistics."""
+    from nirgan_hip.engine import ConvIN, SlabPool, Weights, _Scratch
+    from nirgan_hip.options import OPT
+    kind, B, H, W, Cin, Cout, k, s_ = case
+
+    class Eng:
+        pass
+
+    def build(y16):
+        OPT.bf16_y = y16
+        try:
+            ctx = Ctx(DEV, "bf16")
+            g = torch.Generator().manual_seed(5)
+            eng = Eng()
+            eng.ctx, eng.weights, eng.scratch, eng.slabs, eng.need_backward = ctx, Weights(ctx), _Scratch(ctx), SlabPool(ctx), True
+            inp_layer_out = Halo(ctx, B, H, W, Cin, 1, twin=True)
+            x = torch.randn(inp_layer_out.t.shape, generator=g).to(DEV)
+            inp_layer_out.t.copy_(x)
+            inp_layer_out.t16.copy_(x.to(torch.bfloat16))
+            wshape = (Cin, Cout, k, k) if kind == "convT" else (Cout, Cin, k, k)
+            w = (torch.randn(wshape, generator=g) * 0.05).to(DEV)
+            bias = (torch.randn(Cout, generator=g) * 3.0).to(DEV)
+            layer = ConvIN(eng, "t", kind, inp_layer_out, w, bias, k=k, s=s_, p=1, cout=Cout, norm=True, act=L.ACT_RELU, out_pad=1, out_border=L.BORDER_KEEP)
+            plan, pack = Plan(ctx), Plan(ctx)
+            layer.emit_fwd(plan, pack)
+            layer.alloc_bwd(need_dgrad=False)
+            gw = ctx.zeros(*wshape)
+            gh = Halo(ctx, B, layer.OH, layer.OW, Cout, 0)
+            gh.t.copy_(torch.randn(gh.t.shape, generator=g).to(DEV))
+            bplan = Plan(ctx)
+            layer.emit_bwd(bplan, pack, g=gh, gw=gw, gb=None, dgrad_out=None)
+            pack.run()
+            plan.run()
+            bplan.run()
+            torch.cuda.synchronize()
+            return layer, gh
+        finally:
+            OPT.reset()
+
+    l16, gh = build(True)
+    l32, _ = build(False)
+    assert l16.y.t.dtype == torch.bfloat16 and l32.y.t.dtype == torch.float32
+    assert torch.equal(l16.y.t, l32.y.t.to(torch.bfloat16)), "the bf16 store is not the rounding of the fp32 store"
+    assert torch.equal(l16.stats[0], l32.stats[0]) and torch.equal(l16.stats[1], l32.stats[1]), "statistics must come from the fp32 accumulators"
+    yq = l16.y.t.double()
+    mean, rstd = l16.stats[0].double()[:, None, None, :], l16.stats[1].double()[:, None, None, :]
+    z = (yq - mean) * rstd
+    out = l16.out.t16 if l16.out.t16 is not None else l16.out.t
+    close(out[:, 1:-1, 1:-1].double(), torch.relu(z).to(torch.bfloat16).double(), 2.0 ** -7, "apply on the rounded tensor")
+    gz = torch.where(z > 0, gh.t.double(), torch.zeros((), dtype=torch.float64, device=DEV))
+    dy = rstd * (gz - gz.mean((1, 2), keepdim=True) - z * (gz * z).mean((1, 2), keepdim=True))
+    P = l16.dy.pad
+    got = (l16.dy.t16 if l16.dy.t16 is not None else l16.dy.t)
+    got = got[:, P:got.shape[1] - P, P:got.shape[2] - P].double()
+    err = ((got - dy).norm() / dy.norm()).item()
+    assert err < 4e-3, f"instance-norm backward on the rounded tensor: {err:.2e}"          # bf16 twin of dy: 2^-9 per element
+
+
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 8, "plain", L.ACT_RELU), (2, 32, 16, 64, 64, "plain", L.ACT_LRELU), (3, 16, 16, 32, 128, "plain", L.ACT_RELU),
                                   (2, 16, 8, 64, 256, "plain", L.ACT_NONE), (2, 32, 32, 16, 64, "phases", L.ACT_RELU), (2, 32, 32, 32, 128, "phases", L.ACT_LRELU)])
 def test_conv_epilogue_takes_the_instance_norm_backward_first_pass(case):
