@@ -97,10 +97,12 @@ class Halo:
         # bf16 operand mode: who reads the fp32 tensor?  Launches that may take the twin instead register their descriptor in `readers`
         # (emit_conv / emit_wgrad, through operand_ptr()); every other use goes through `.ptr` and pins the fp32 tensor.  A twinned buffer
         # that is never pinned and whose readers all take the twin is stored as bf16 only (drop_dead_fp32_stores).
-        self.readers, self.pinned, self.writers = [], False, []
+        self.readers, self.pinned, self.writers, self.fp32_dead = [], False, [], False
 
     @property
     def ptr(self):
+        if self.fp32_dead:        # a launch emitted after the engine was finalised would read a tensor nobody writes any more
+            raise RuntimeError("this buffer is stored as bf16 only (drop_dead_fp32_stores ran): its fp32 tensor is not maintained")
         self.pinned = True
         return self.t.data_ptr()
 
@@ -613,16 +615,20 @@ def drop_dead_fp32_stores(buffers) -> int:
     the twin (reads_twin) -- is stored as bf16 only: its instance-norm writers get out / dy = NULL (168 -> 101 MB per forward launch of a
     64 x 64 x 256 map at bs 16, 235 -> 168 MB per backward launch).  Called once per engine, after all of its plans are built."""
     n = 0
+    if not OPT.bf16_twin_only:
+        return n
     for h in buffers:
         if h.t16 is None or h.pinned or not h.readers or not h.writers or not all(reads_twin(r) for r in h.readers):
             continue
+        if not all(isinstance(w, L.InFwdDesc) or (isinstance(w, L.InBwdDesc) and w.norm) for w in h.writers):
+            continue                  # (a backward launch without norm writes dy in its first pass: keeps fp32)
         for w in h.writers:
             if isinstance(w, L.InFwdDesc):
                 w.out = None
-                n += 1
-            elif isinstance(w, L.InBwdDesc) and w.norm:
+            else:
                 w.dy = None
-                n += 1
+            n += 1
+        h.fp32_dead = True
     return n
 
 

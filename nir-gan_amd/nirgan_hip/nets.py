@@ -298,6 +298,7 @@ class DiscriminatorEngine(_Engine):
         self._part_plans: dict = {}
         if need_backward:
             self._build_backward()
+        drop_dead_fp32_stores(getattr(self, "twinned", []))          # bf16 operand mode: see GeneratorEngine
 
     def _build_backward(self):
         ctx, b, pk, gr, B = self.ctx, self.bwd, self.pack_bwd, self.grads, self.B

@@ -36,6 +36,8 @@ class Options:
     dp_buckets: bool = True
     # bf16 operand mode: a convolution output in front of an instance norm is stored as bf16 (statistics from the fp32 accumulators)
     bf16_y: bool = True
+    # bf16 operand mode: activations / output gradients that every reader takes from the bf16 twin are stored as bf16 only
+    bf16_twin_only: bool = True
     # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform
     fold_apply: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
