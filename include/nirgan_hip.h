@@ -234,6 +234,8 @@ typedef struct {
                                              nirgan_conv_desc.fuse_* (gsum_out NULL: the second pass reads g itself, which then has no fold
                                              and no g2).  ws >= B * sums_chunks * 2 * C + B * 2 * C floats */
     int y_bf16;                           /* 1: y points to bf16 elements (as nirgan_in_fwd_desc.y_bf16) */
+    int g_bf16;                           /* 1: g points to bf16 elements (same halo'd geometry): the data-gradient launch that produced it stored
+                                           * it with nirgan_conv_desc.out_bf16 (bf16 operand mode; g2 and gsum_out stay fp32) */
 } nirgan_in_bwd_desc;
 
 int nirgan_instnorm_bwd(const nirgan_in_bwd_desc* d, void* stream);

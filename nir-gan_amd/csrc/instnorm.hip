@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
             mean = ld4(p.mean + size_t(b) * p.C + q * 4);
             rstd = ld4(p.rstd + size_t(b) * p.C + q * 4);
         }
-        const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
+        const float* gb = p.g ? y_at(p.g, size_t(b) * p.g_img, p.g16) : nullptr;
         const float* g2b = p.g2 ? p.g2 + size_t(b) * p.HW * p.C : nullptr;
         const float* yb = p.y ? y_at(p.y, size_t(b) * p.HW * p.C, p.y16) : nullptr;
         float* db = p.dy + size_t(b) * p.d_img + p.d_org;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     const float* yb = y_at(p.y, size_t(b) * p.HW * p.C, p.y16);
     // g_z again, from what pass 1 read: the folded sum it stored for the skip path when there is one, else the halo'd gradient itself
     const float* gsb = p.gsum_out ? p.gsum_out + size_t(b) * p.HW * p.C : nullptr;
-    const float* gb = p.g ? p.g + size_t(b) * p.g_img : nullptr;
+    const float* gb = p.g ? y_at(p.g, size_t(b) * p.g_img, p.g16) : nullptr;
     const float* g2b = p.g2 ? p.g2 + size_t(b) * p.HW * p.C : nullptr;
     float* db = p.dy ? p.dy + size_t(b) * p.d_img + p.d_org : nullptr;
     const int start = chunk * p.ppc;

@@ -60,7 +60,7 @@ struct InBwd {
     float* dbias;
     float* ws; int nchunk, ppc;
     unsigned short* dy16;
-    int y16;
+    int y16, g16;              // y / g stored as bf16 (nirgan_in_bwd_desc.y_bf16 / g_bf16): read through ldy4
     int pchunks;               // chunks of partial sums per sample in ws (= nchunk, or the producer's count: nirgan_in_bwd_desc.sums_chunks)
 };
 
@@ -72,9 +72,9 @@ __device__ __forceinline__ f32x4 in_bwd_gsum(const InBwd& p, const float* gb, co
             int hs[3], wsx[3];
             const int nh = halo_images(h, p.H, p.g_pad, hs), nw = halo_images(w, p.W, p.g_pad, wsx);
             for (int i = 0; i < nh; ++i)
-                for (int j = 0; j < nw; ++j) ga += ld4(gb + size_t(hs[i]) * p.g_row + size_t(wsx[j]) * p.C + q * 4);
+                for (int j = 0; j < nw; ++j) ga += ldy4(gb, size_t(hs[i]) * p.g_row + size_t(wsx[j]) * p.C + q * 4, p.g16);
         } else {
-            ga = ld4(gb + size_t(h + p.g_pad) * p.g_row + size_t(w + p.g_pad) * p.C + q * 4);
+            ga = ldy4(gb, size_t(h + p.g_pad) * p.g_row + size_t(w + p.g_pad) * p.C + q * 4, p.g16);
         }
     }
     if (g2b) ga += ld4(g2b + size_t(pix) * p.C + q * 4);
@@ -85,6 +85,7 @@ __device__ __forceinline__ f32x4 in_bwd_gsum(const InBwd& p, const float* gb, co
 // host: descriptor -> kernel parameters of the backward passes (validation lives in nirgan_instnorm_bwd)
 inline InBwd in_bwd_params(const nirgan_in_bwd_desc* d) {
     InBwd p;
+    p.g16 = d->g_bf16 ? 1 : 0;
     p.g = d->g; p.g_row = d->g_wp * d->C; p.g_img = d->g_hp * p.g_row; p.g_pad = d->g_pad; p.g_fold = d->g_fold;
     p.g2 = d->g2;
     p.a = d->a; p.a_row = d->a_wp * d->C; p.a_img = d->a_hp * p.a_row; p.a_org = d->a_pad * p.a_row + d->a_pad * d->C;

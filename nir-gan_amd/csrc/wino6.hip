@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
         const f32x4 mean = ld4(n.mean + size_t(b) * n.C + ch), rstd = ld4(n.rstd + size_t(b) * n.C + ch);
         const float* yb = y_at(n.y, size_t(b) * n.HW * n.C, n.y16);
         const float* gsb = n.gsum_out ? n.gsum_out + size_t(b) * n.HW * n.C : nullptr;
-        const float* gb = n.g ? n.g + size_t(b) * n.g_img : nullptr;
+        const float* gb = n.g ? y_at(n.g, size_t(b) * n.g_img, n.g16) : nullptr;
         const float* g2b = n.g2 ? n.g2 + size_t(b) * n.HW * n.C : nullptr;
         const int w = MO * tx + c - (R - 1);                    // the dY grid has a zero halo of R - 1
 #pragma unroll

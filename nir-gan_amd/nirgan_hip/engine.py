@@ -101,9 +101,17 @@ class Halo:
 
     @property
     def ptr(self):
+        if self.is16:             # only the launches that know the storage rule may touch it (ptr_any)
+            raise RuntimeError("this buffer holds bf16 elements: a launch site has to take it through ptr_any() and pass the *_bf16 flag")
         if self.fp32_dead:        # a launch emitted after the engine was finalised would read a tensor nobody writes any more
             raise RuntimeError("this buffer is stored as bf16 only (drop_dead_fp32_stores ran): its fp32 tensor is not maintained")
         self.pinned = True
+        return self.t.data_ptr()
+
+    def ptr_any(self):
+        """address of the tensor whatever its element type (fp32, or bf16 when is16): for the launch sites that pass the *_bf16 flag"""
+        if not self.is16:
+            return self.ptr
         return self.t.data_ptr()
 
     def operand_ptr(self, reader=None):
@@ -285,8 +293,10 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.w_bf16 = 1 if w.dtype == torch.bfloat16 else 0
     if d.w_bf16 and taps.run % 8:
         raise ValueError(f"bf16-stored weights need run % 8 == 0 (run={taps.run})")
-    d.out, d.out_elems = out.ptr, out.elems
     d.out_bf16 = 1 if getattr(out, "is16", False) else 0
+    d.out, d.out_elems = (out.ptr_any() if d.out_bf16 else out.ptr), out.elems
+    if d.out_bf16:
+        allow_split = False          # a bf16 output is stored by the tile's own epilogue (no split-K workspace pass)
     d.out_hp, d.out_wp, d.out_cs = out.hp, out.wp, out.C
     d.out_stride, d.out_oh, d.out_ow = out_stride, out_oh, out_ow
     d.B, d.OH, d.OW, d.N = inp.B, OH, OW, N
@@ -580,7 +590,7 @@ def emit_in_fwd(plan: Plan, ctx: Ctx, y: Halo, out: Halo, *, norm=True, act=L.AC
     assert y.pad == 0 and out.H == y.H and out.W == y.W and out.C == y.C
     assert not stats_only or (norm and residual is None)
     d = L.InFwdDesc()
-    d.y, d.B, d.H, d.W, d.C = y.ptr, y.B, y.H, y.W, y.C
+    d.y, d.B, d.H, d.W, d.C = y.ptr_any(), y.B, y.H, y.W, y.C
     d.y_bf16 = 1 if y.is16 else 0
     d.norm, d.eps = (1 if norm else 0), IN_EPS
     if norm:
@@ -608,6 +618,21 @@ def reads_twin(desc) -> bool:
     if isinstance(desc, L.WgradDesc):
         return bool(desc.pq_bf16)
     return False
+
+
+def one_pass_tiles(M: int, N: int) -> bool:
+    """Does a convolution launch of M output pixels x N channels store its tiles itself (choose_ksplit: no split-K from 400 tiles on)?
+    Only such a launch can store bf16 (out_bf16)."""
+    return -(-M // 128) * (-(-N // 128) if N > 64 else 1) >= OPT.bf16_store_min_tiles
+
+
+def grad_halo(ctx: Ctx, B, H, W, Cc, pad, phases: int = 1) -> Halo:
+    """The buffer a data-gradient launch writes and the consumer layer's instance-norm backward reads (with the reflect fold when pad > 0).
+    bf16 operand mode: stored as bf16 by the launch's epilogue (out_bf16) -- the gradient is rounded once more before it meets the next
+    contraction anyway (dy's twin); the sums of the fused first pass still come from the fp32 accumulators.  phases = 4 when the producer is
+    the four sub-pixel problems of a stride-2 layer.  Small problems (split-K) and OPT.bf16_g = False keep fp32."""
+    is16 = ctx.precision == 1 and OPT.bf16_g and Cc % 4 == 0 and one_pass_tiles(B * H * W // phases, Cc)
+    return Halo(ctx, B, H, W, Cc, pad, bf16=is16)
 
 
 def drop_dead_fp32_stores(buffers) -> int:
@@ -642,7 +667,8 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
     d = L.InBwdDesc()
     if g is not None:
         assert g.H == H and g.W == W and g.C == Cc
-        d.g, d.g_hp, d.g_wp, d.g_pad, d.g_fold = g.ptr, g.hp, g.wp, g.pad, (1 if g_fold else 0)
+        d.g, d.g_hp, d.g_wp, d.g_pad, d.g_fold = g.ptr_any(), g.hp, g.wp, g.pad, (1 if g_fold else 0)
+        d.g_bf16 = 1 if g.is16 else 0
     if g2 is not None:
         assert g2.pad == 0
         d.g2 = g2.ptr
@@ -650,7 +676,7 @@ def emit_in_bwd(plan: Plan, ctx: Ctx, *, g: Optional[Halo], g_fold=False, g2: Op
     d.act, d.slope = act, slope
     d.norm = 1 if norm else 0
     if y is not None:
-        d.y, d.y_bf16 = y.ptr, (1 if y.is16 else 0)
+        d.y, d.y_bf16 = y.ptr_any(), (1 if y.is16 else 0)
     if norm:
         d.mean, d.rstd = stats[0].data_ptr(), stats[1].data_ptr()
     if norm or dbias is not None:       # partial sums of the two reduction passes / of the live bias gradient (one row per block)
@@ -719,7 +745,7 @@ class ConvIN:
         # convolution's store, the norm's apply, both passes of its backward -- moves half the bytes
         phase_px = self.OH * self.OW // (4 if kind == "convT" else 1)
         y16 = (ctx.precision == 1 and norm and OPT.bf16_y and OPT.epilogue_stats and cout % 4 == 0 and phase_px % 128 == 0
-               and self.OH * self.OW >= min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16))
+               and self.OH * self.OW >= min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16) and one_pass_tiles(B * phase_px, cout))
         self.y = Halo(ctx, B, self.OH, self.OW, cout, 0, bf16=y16)
         self.out = Halo(ctx, B, self.OH, self.OW, cout, out_pad, twin=True)
         eng.__dict__.setdefault("twinned", []).append(self.out)          # see drop_dead_fp32_stores
@@ -857,7 +883,7 @@ class ConvIN:
             ws = ctx.inbwd_part.get(inp.B * chunks * 2 * self.cout + inp.B * 2 * self.cout)
             first = 0
             for c in cds:
-                c.fuse_y, c.fuse_mean, c.fuse_rstd = self.y.ptr, self.stats[0].data_ptr(), self.stats[1].data_ptr()
+                c.fuse_y, c.fuse_mean, c.fuse_rstd = self.y.ptr_any(), self.stats[0].data_ptr(), self.stats[1].data_ptr()
                 c.fuse_y_bf16 = 1 if self.y.is16 else 0
                 c.fuse_h, c.fuse_w = self.OH, self.OW
                 c.fuse_oh, c.fuse_ow = c.out_oh - g.pad, c.out_ow - g.pad

@@ -61,7 +61,7 @@ class InBwdDesc(C.Structure):
                 ("y", fp), ("mean", fp), ("rstd", fp), ("norm", i32),
                 ("B", i32), ("H", i32), ("W", i32), ("C", i32),
                 ("dy", fp), ("d_hp", i32), ("d_wp", i32), ("d_pad", i32),
-                ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64), ("dy_bf16", fp), ("sums_chunks", i32), ("y_bf16", i32)]
+                ("gsum_out", fp), ("dbias", fp), ("ws", fp), ("ws_elems", i64), ("dy_bf16", fp), ("sums_chunks", i32), ("y_bf16", i32), ("g_bf16", i32)]
 
 
 class ChanDgradDesc(C.Structure):

@@ -16,7 +16,7 @@ import torch
 from . import geometry as G
 from . import lib as L
 from .options import OPT
-from .engine import (ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, drop_dead_fp32_stores, emit_conv,
+from .engine import (ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, drop_dead_fp32_stores, emit_conv, grad_halo,
                      emit_w6_deferred_finishes, emit_wgrad, wino_applicable)
 
 
@@ -212,7 +212,7 @@ class GeneratorEngine(_Engine):
         b.add("nirgan_fill", GW(il, "bias").data_ptr(), 1, 0.0)
         self.last.emit_bwd(b, pk, GW(il), GW(il, "bias"))
         i0, i1 = lay["up"]
-        g_u1 = Halo(ctx, B, self.U1.OH, self.U1.OW, self.U1.cout, 0)
+        g_u1 = grad_halo(ctx, B, self.U1.OH, self.U1.OW, self.U1.cout, 0)
         self.U2.emit_bwd(b, pk, g=self.last.gin, g_fold=True, gw=GW(i1), gb=GW(i1, "bias"), dgrad_out=g_u1)
         c4, H3, W3 = self.L3.cout, self.L3.OH, self.L3.OW
         g_top = Halo(ctx, B, H3, W3, c4, 0)                # gradient wrt the last block's output
@@ -224,8 +224,8 @@ class GeneratorEngine(_Engine):
         ctx.w6_deferred = []      # collect the blocks' weight-gradient finishes
         for j in range(len(self.blocks) - 1, -1, -1):
             i, c1, c2 = self.blocks[j]
-            gq = Halo(ctx, B, H3, W3, c4, 1)
-            gp = Halo(ctx, B, H3, W3, c4, 1)
+            gq = grad_halo(ctx, B, H3, W3, c4, 1)
+            gp = grad_halo(ctx, B, H3, W3, c4, 1)
             if g_skip is None:
                 gsum, skip_next = None, g_in           # top of the chain: g_in is already dense
             else:
@@ -239,9 +239,10 @@ class GeneratorEngine(_Engine):
         # data parallel: from here on the gradients of [first residual block .. last conv] are final (28 of 31 MB for 6 blocks)
         first_tail = f"model.{lay['blocks'][0]}.conv_block.1.weight" if self.blocks else f"model.{i0}.weight"
         self.bwd_tail = (len(b.ops), first_tail, f"model.{il}.bias")
-        g_a2 = Halo(ctx, B, self.L2.OH, self.L2.OW, self.L2.cout, 0)
+        # (read by the SatCLIP modulation's backward as fp32 when there is one)
+        g_a2 = grad_halo(ctx, B, self.L2.OH, self.L2.OW, self.L2.cout, 0, phases=4) if self.inject is None else Halo(ctx, B, self.L2.OH, self.L2.OW, self.L2.cout, 0)
         self.L3.emit_bwd(b, pk, g=g_in, g_fold=g_fold, g2=g_skip, gw=GW(7), gb=GW(7, "bias"), dgrad_out=g_a2)
-        g_a1 = Halo(ctx, B, self.L1.OH, self.L1.OW, self.L1.cout, 0)
+        g_a1 = grad_halo(ctx, B, self.L1.OH, self.L1.OW, self.L1.cout, 0, phases=4)
         if self.inject is None:
             self.L2.emit_bwd(b, pk, g=g_a2, gw=GW(4), gb=GW(4, "bias"), dgrad_out=g_a1)
         else:
@@ -306,9 +307,9 @@ class DiscriminatorEngine(_Engine):
         self.dout = self.C5.dout
         for layer in (self.C1, self.C2, self.C3, self.C4):
             layer.alloc_bwd(need_dgrad=True)
-        self.g3p = Halo(ctx, B, self.C3.OH, self.C3.OW, self.C3.cout, 1)
-        self.g2 = Halo(ctx, B, self.C2.OH, self.C2.OW, self.C2.cout, 0)
-        self.g1 = Halo(ctx, B, self.C1.OH, self.C1.OW, self.C1.cout, 0)
+        self.g3p = grad_halo(ctx, B, self.C3.OH, self.C3.OW, self.C3.cout, 1)
+        self.g2 = grad_halo(ctx, B, self.C2.OH, self.C2.OW, self.C2.cout, 0, phases=4)
+        self.g1 = grad_halo(ctx, B, self.C1.OH, self.C1.OW, self.C1.cout, 0, phases=4)
         self.gx4 = Halo(ctx, B, self.H, self.W, 4, 0)
         self.gpred = ctx.zeros(B, self.H, self.W)
         self.bwd_frozen = Plan(ctx)       # parameters frozen: gradient wrt the whole 4-channel input (autograd bridge)

@@ -36,6 +36,11 @@ class Options:
     dp_buckets: bool = True
     # bf16 operand mode: a convolution output in front of an instance norm is stored as bf16 (statistics from the fp32 accumulators)
     bf16_y: bool = True
+    # bf16 operand mode: the data gradients that feed an instance-norm backward are stored as bf16 by the launch that produces them
+    bf16_g: bool = True
+    # ... both only for launches of at least this many output tiles (below, choose_ksplit divides K and the tiles go through a workspace;
+    # the tests set 0 to run small layers through the bf16 stores)
+    bf16_store_min_tiles: int = 400
     # bf16 operand mode: activations / output gradients that every reader takes from the bf16 twin are stored as bf16 only
     bf16_twin_only: bool = True
     # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform

@@ -62,25 +62,37 @@ DISC_CONV_IDX = [0, 2, 5, 8, 11]   # NLayerDiscriminator(n_layers=3) (networks.p
 # `y_bf16_min_pixels` (bf16 mode only) restates the build's storage rule for convolution outputs in front of an InstanceNorm: on maps of at
 # least that many pixels per sample (and H*W -- per sub-pixel phase for a transposed convolution -- a multiple of 128: the build's tiles)
 # the statistics come from the fp32 result, the tensor itself is kept rounded to bf16, and both the normalisation and its backward
-# use the rounded values (_StoredBf16Norm).  None = every tensor stays fp32.
+# use the rounded values (_StoredBf16Norm).  None = every tensor stays fp32.  `y_bf16_min_tiles`: the build stores bf16 only from launches
+# of at least that many 128 x 128 output tiles (B * H * W / phases pixels x C channels; smaller problems divide K over several
+# workgroups and keep fp32): 400 in the build, 0 = no such limit.
+# `g_bf16_min_tiles` (bf16 mode only; None = off) restates the same for the data gradients that feed an InstanceNorm backward: the
+# launch that computes the gradient wrt a layer's input stores it as bf16 (from that many output tiles on), i.e. dx of the marked
+# contractions (argument g16 of _conv2d / _conv_transpose2d) is rounded once more.
 _PRECISION = "fp32"
 _Y16_MIN_PIXELS = None
+_G16_MIN_TILES = None
 
 
 class operand_precision:
-    def __init__(self, mode: str, y_bf16_min_pixels=None):
+    def __init__(self, mode: str, y_bf16_min_pixels=None, y_bf16_min_tiles=0, g_bf16_min_tiles=None):
         assert mode in ("fp32", "bf16"), mode
-        assert y_bf16_min_pixels is None or mode == "bf16"
-        self.mode, self.y16 = mode, y_bf16_min_pixels
+        assert (y_bf16_min_pixels is None and g_bf16_min_tiles is None) or mode == "bf16"
+        self.mode, self.y16 = mode, (None if y_bf16_min_pixels is None else (y_bf16_min_pixels, y_bf16_min_tiles))
+        self.g16 = g_bf16_min_tiles
 
     def __enter__(self):
-        global _PRECISION, _Y16_MIN_PIXELS
-        self.prev, _PRECISION = (_PRECISION, _Y16_MIN_PIXELS), self.mode
-        _Y16_MIN_PIXELS = self.y16
+        global _PRECISION, _Y16_MIN_PIXELS, _G16_MIN_TILES
+        self.prev, _PRECISION = (_PRECISION, _Y16_MIN_PIXELS, _G16_MIN_TILES), self.mode
+        _Y16_MIN_PIXELS, _G16_MIN_TILES = self.y16, self.g16
 
     def __exit__(self, *exc):
-        global _PRECISION, _Y16_MIN_PIXELS
-        _PRECISION, _Y16_MIN_PIXELS = self.prev
+        global _PRECISION, _Y16_MIN_PIXELS, _G16_MIN_TILES
+        _PRECISION, _Y16_MIN_PIXELS, _G16_MIN_TILES = self.prev
+
+
+def _launch_tiles(pixels: int, channels: int) -> int:
+    """128 x 128 output tiles of a launch over `pixels` x `channels` (the build's 64-wide tile for <= 64 channels)"""
+    return -(-pixels // 128) * (-(-channels // 128) if channels > 64 else 1)
 
 
 def _bf(x: torch.Tensor) -> torch.Tensor:
@@ -91,8 +103,8 @@ class _RoundedContraction(torch.autograd.Function):
     """y = fn(bf(x), bf(w)); dx, dw = vjp of fn at (bf(x), bf(w)) applied to bf(dy)."""
 
     @staticmethod
-    def forward(ctx, x, w, fn):
-        ctx.fn = fn
+    def forward(ctx, x, w, fn, g16=None):
+        ctx.fn, ctx.g16 = fn, g16
         ctx.save_for_backward(x, w)
         with torch.no_grad():
             return fn(_bf(x), _bf(w))
@@ -104,25 +116,33 @@ class _RoundedContraction(torch.autograd.Function):
             xr, wr = _bf(x).detach().requires_grad_(True), _bf(w).detach().requires_grad_(True)
             y = ctx.fn(xr, wr)
             dx, dw = torch.autograd.grad(y, (xr, wr), _bf(dy))
-        return dx, dw, None
+        if ctx.g16 is not None and _G16_MIN_TILES is not None and dx.dim() == 4 and dx.shape[1] % 4 == 0:
+            phases, pad = ctx.g16           # producer = `phases` sub-problems; x carried a halo of `pad` the build does not count
+            pixels = dx.shape[0] * (dx.shape[2] - 2 * pad) * (dx.shape[3] - 2 * pad) // phases
+            if _launch_tiles(pixels, dx.shape[1]) >= _G16_MIN_TILES:
+                dx = _bf(dx)
+        return dx, dw, None, None
 
 
-def _rounded(fn, x, w, bias, bias_shape):
-    y = _RoundedContraction.apply(x, w, fn)
+def _rounded(fn, x, w, bias, bias_shape, g16=None):
+    y = _RoundedContraction.apply(x, w, fn, g16)
     return y if bias is None else y + bias.view(bias_shape)
 
 
-def _conv2d(x, w, b=None, stride=1, padding=0):
+def _conv2d(x, w, b=None, stride=1, padding=0, g16=None):
+    """g16 (bf16 mode's storage rule for data gradients, see _G16_MIN_TILES): halo of x that the build's gradient buffer does not count
+    (1 behind F.pad(.., 1), else 0) when the gradient wrt x feeds an InstanceNorm backward; None where it does not."""
     if _PRECISION == "fp32":
         return F.conv2d(x, w, b, stride=stride, padding=padding)
-    return _rounded(lambda a, k: F.conv2d(a, k, None, stride=stride, padding=padding), x, w, b, (1, -1, 1, 1))
+    return _rounded(lambda a, k: F.conv2d(a, k, None, stride=stride, padding=padding), x, w, b, (1, -1, 1, 1),
+                    None if g16 is None else (stride * stride, g16))
 
 
-def _conv_transpose2d(x, w, b=None, stride=1, padding=0, output_padding=0):
+def _conv_transpose2d(x, w, b=None, stride=1, padding=0, output_padding=0, g16=None):
     if _PRECISION == "fp32":
         return F.conv_transpose2d(x, w, b, stride=stride, padding=padding, output_padding=output_padding)
     return _rounded(lambda a, k: F.conv_transpose2d(a, k, None, stride=stride, padding=padding, output_padding=output_padding),
-                    x, w, b, (1, -1, 1, 1))
+                    x, w, b, (1, -1, 1, 1), None if g16 is None else (1, g16))
 
 
 def _linear(x, w, b=None):
@@ -217,10 +237,11 @@ class _StoredBf16Norm(torch.autograd.Function):
 def _inorm(x: torch.Tensor, phases: int = 1) -> torch.Tensor:
     # InstanceNorm2d(affine=False, track_running_stats=False): networks.py:30.  phases = 4 behind a stride-2 transposed convolution
     # (the build computes it as four sub-pixel problems: its storage rule looks at the pixels of one)
-    hw = x.shape[-2] * x.shape[-1]
-    if (_PRECISION == "bf16" and _Y16_MIN_PIXELS is not None and hw >= _Y16_MIN_PIXELS and (hw // phases) % 128 == 0
-            and x.shape[1] % 4 == 0):
-        return _StoredBf16Norm.apply(x)
+    hw, c = x.shape[-2] * x.shape[-1], x.shape[1]
+    if _PRECISION == "bf16" and _Y16_MIN_PIXELS is not None and hw >= _Y16_MIN_PIXELS[0] and (hw // phases) % 128 == 0 and c % 4 == 0:
+        tiles = -(-(x.shape[0] * hw // phases) // 128) * (-(-c // 128) if c > 64 else 1)
+        if tiles >= _Y16_MIN_PIXELS[1]:
+            return _StoredBf16Norm.apply(x)
     return F.instance_norm(x, eps=IN_EPS)
 
 
@@ -231,26 +252,28 @@ def generator_trunk_head(p: Params, x: torch.Tensor) -> torch.Tensor:
     """model[:6] of the reference: pad3, conv7, IN, ReLU, conv3 s2, IN (generator_inject.py:107)."""
     x = _conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), p["model.1.weight"], p["model.1.bias"])
     x = _relu(_inorm(x))
-    x = _conv2d(x, p["model.4.weight"], p["model.4.bias"], stride=2, padding=1)
+    x = _conv2d(x, p["model.4.weight"], p["model.4.bias"], stride=2, padding=1, g16=0)
     return _inorm(x)
 
 
-def generator_trunk_tail(p: Params, x: torch.Tensor, n_blocks: int) -> torch.Tensor:
+def generator_trunk_tail(p: Params, x: torch.Tensor, n_blocks: int, modulated: bool = False) -> torch.Tensor:
     """model[6:] of the reference: ReLU, conv3 s2, IN, ReLU, blocks, 2x convT, pad3, conv7, tanh."""
     k = generator_keys(n_blocks)
     x = _relu(x)
-    x = _conv2d(x, p["model.7.weight"], p["model.7.bias"], stride=2, padding=1)
+    # (modulated: the gradient wrt x goes to the SatCLIP modulation's backward, an fp32 tensor in the build)
+    x = _conv2d(x, p["model.7.weight"], p["model.7.bias"], stride=2, padding=1, g16=(None if modulated else 0))
     x = _relu(_inorm(x))
     for i in k["blocks"]:          # ResnetBlock.forward: out = x + conv_block(x) (networks.py:430-434)
         h = _conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"),
-                     p[f"model.{i}.conv_block.1.weight"], p[f"model.{i}.conv_block.1.bias"])
+                     p[f"model.{i}.conv_block.1.weight"], p[f"model.{i}.conv_block.1.bias"], g16=1)
         h = _relu(_inorm(h))
         h = _conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"),
-                     p[f"model.{i}.conv_block.5.weight"], p[f"model.{i}.conv_block.5.bias"])
+                     p[f"model.{i}.conv_block.5.weight"], p[f"model.{i}.conv_block.5.bias"], g16=1)
         x = x + _inorm(h)
     for i in k["up"]:              # ConvTranspose2d k3 s2 p1 op1 (networks.py:360-363)
+        # (the gradient wrt the first up-convolution's input is the skip path's dense fp32 tensor in the build: no g16 there)
         x = _conv_transpose2d(x, p[f"model.{i}.weight"], p[f"model.{i}.bias"],
-                               stride=2, padding=1, output_padding=1)
+                               stride=2, padding=1, output_padding=1, g16=(None if i == k["up"][0] else 0))
         x = _relu(_inorm(x, phases=4))
     i = k["last"]
     x = _conv2d(F.pad(x, (3, 3, 3, 3), mode="reflect"), p[f"model.{i}.weight"], p[f"model.{i}.bias"])
@@ -288,7 +311,7 @@ def generator_inject_forward(p: Params, x: torch.Tensor, embeds: torch.Tensor, n
     """ResnetGenerator_inject.forward (generator_inject.py:105-135)."""
     h = generator_trunk_head(p, x)
     h = inject_modulation(p, h, embeds, style, use_scale)
-    out = generator_trunk_tail(p, h, n_blocks)
+    out = generator_trunk_tail(p, h, n_blocks, modulated=True)
     if post_correction:                                           # :133-134
         out = out * p["post_correction_param"]
     return out
@@ -301,7 +324,7 @@ def discriminator_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     """NLayerDiscriminator(n_layers=3).forward: 70x70 PatchGAN, no sigmoid."""
     x = _lrelu(_conv2d(x, p["model.0.weight"], p["model.0.bias"], stride=2, padding=1), 0.2)
     for i, s in ((2, 2), (5, 2), (8, 1)):
-        x = _conv2d(x, p[f"model.{i}.weight"], p[f"model.{i}.bias"], stride=s, padding=1)
+        x = _conv2d(x, p[f"model.{i}.weight"], p[f"model.{i}.bias"], stride=s, padding=1, g16=0)
         x = _lrelu(_inorm(x), 0.2)
     return _conv2d(x, p["model.11.weight"], p["model.11.bias"], stride=1, padding=1)
 

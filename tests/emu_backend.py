@@ -872,12 +872,12 @@ class EmuBackend:
             if d.gsum_out:
                 ga = arr(d.gsum_out, B * H * W * Cc).reshape(B, H, W, Cc).astype(np.float64)
             else:
-                g = arr(d.g, B * d.g_hp * d.g_wp * Cc).reshape(B, d.g_hp, d.g_wp, Cc).astype(np.float64)
+                g = load_y(d.g, B * d.g_hp * d.g_wp * Cc, d.g_bf16).reshape(B, d.g_hp, d.g_wp, Cc).astype(np.float64)
                 ga = g[:, d.g_pad:d.g_pad + H, d.g_pad:d.g_pad + W].copy()
         elif d.g:
             if d.g_hp != H + 2 * d.g_pad or d.g_wp != W + 2 * d.g_pad:
                 return self._fail("in_bwd: g geometry")
-            g = arr(d.g, B * d.g_hp * d.g_wp * Cc).reshape(B, d.g_hp, d.g_wp, Cc).astype(np.float64)
+            g = load_y(d.g, B * d.g_hp * d.g_wp * Cc, d.g_bf16).reshape(B, d.g_hp, d.g_wp, Cc).astype(np.float64)
             P = d.g_pad
             if d.g_fold:
                 hh = reflect(np.arange(d.g_hp) - P, H)

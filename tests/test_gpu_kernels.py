@@ -922,6 +922,7 @@ def test_bf16_mode_stores_the_convolution_output_as_bf16(case):
 
     def build(y16):
         OPT.bf16_y = y16
+        OPT.bf16_store_min_tiles = 0         # small launches too (the engines keep fp32 below 400 output tiles: split-K territory)
         try:
             ctx = Ctx(DEV, "bf16")
             g = torch.Generator().manual_seed(5)
@@ -939,7 +940,7 @@ def test_bf16_mode_stores_the_convolution_output_as_bf16(case):
             layer.emit_fwd(plan, pack)
             layer.alloc_bwd(need_dgrad=False)
             gw = ctx.zeros(*wshape)
-            gh = Halo(ctx, B, layer.OH, layer.OW, Cout, 0)
+            gh = Halo(ctx, B, layer.OH, layer.OW, Cout, 0, bf16=y16)           # the gradient arrives as bf16 too (nirgan_in_bwd_desc.g_bf16)
             gh.t.copy_(torch.randn(gh.t.shape, generator=g).to(DEV))
             bplan = Plan(ctx)
             layer.emit_bwd(bplan, pack, g=gh, gw=gw, gb=None, dgrad_out=None)
@@ -947,13 +948,15 @@ def test_bf16_mode_stores_the_convolution_output_as_bf16(case):
             plan.run()
             bplan.run()
             torch.cuda.synchronize()
+            layer.bplan = bplan
             return layer, gh
         finally:
             OPT.reset()
 
     l16, gh = build(True)
     l32, _ = build(False)
-    assert l16.y.t.dtype == torch.bfloat16 and l32.y.t.dtype == torch.float32
+    assert l16.y.t.dtype == torch.bfloat16 and l32.y.t.dtype == torch.float32 and gh.t.dtype == torch.bfloat16
+    assert [a[0]._obj.g_bf16 for n, a in l16.bplan.ops if n == "nirgan_instnorm_bwd"] == [1]
     assert torch.equal(l16.y.t, l32.y.t.to(torch.bfloat16)), "the bf16 store is not the rounding of the fp32 store"
     assert torch.equal(l16.stats[0], l32.stats[0]) and torch.equal(l16.stats[1], l32.stats[1]), "statistics must come from the fp32 accumulators"
     yq = l16.y.t.double()

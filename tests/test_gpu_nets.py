@@ -437,6 +437,52 @@ def test_fused_step_is_bitwise_reproducible():
         assert torch.equal(x, y), f"{what}: {(x - y).abs().max().item():.3e} apart"
 
 
+def test_bf16_storage_rules_at_the_benchmark_scale():
+    """bs 16 at 256 x 256, ngf 64, bf16 operand mode: the step with the storage rules of DESIGN 3.3 (convolution outputs and data
+    gradients stored as bf16, no fp32 store where every reader takes the twin) against the same step with every tensor kept in fp32
+    (OPT.bf16_y / bf16_g / bf16_twin_only = False), and both against the exact-fp32 step.  The rules round tensors that are rounded
+    again one kernel later (or add one rounding of 2^-9 in front of a normalisation).  Rounding is discontinuous: two bf16 evaluations
+    that differ at all drift apart, layer by layer, up to the bf16 noise level itself (measured here: the rules move the prediction by
+    1.08 x the distance of the rule-free bf16 step from the fp32 step) -- so the bound is that level, tensor by tensor: within 2 x of what
+    the bf16 operand mode itself changes.  A wrong stride, a missed reader of a dropped fp32 tensor or a bf16 buffer read as fp32 shows
+    as O(1) = 20-50 x the noise."""
+    from model import networks
+    from nirgan_hip.options import OPT
+    from nirgan_hip.trainer import Pix2PixTrainer
+    rgb, nir = synth(16, 256, 256, 3)
+    rgb, nir = rgb.to(DEV), nir.to(DEV)
+    runs = []
+    for prec, rules in (("bf16", True), ("bf16", False), ("fp32", False)):
+        OPT.bf16_y = OPT.bf16_g = OPT.bf16_twin_only = rules
+        try:
+            torch.manual_seed(0)
+            netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
+            netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+            tr = Pix2PixTrainer(netG, netD, n_blocks=6, lr=0.0, precision=prec)
+            out = tr.step(rgb, nir).as_dict()
+            ys = sum(1 for l in [tr.G.L1, tr.G.L2, tr.G.L3, tr.G.U1, tr.G.U2] + [c for _, a, b in tr.G.blocks for c in (a, b)] if l.y.is16)
+            dead = sum(1 for h in tr.G.twinned + tr.D2.twinned if h.fp32_dead)
+            g16 = sum(1 for n_, a_ in tr.G.bwd.ops if n_ == "nirgan_instnorm_bwd" and a_[0]._obj.g_bf16)
+            runs.append((out, tr.G.pred.clone(), {k: v.clone() for k, v in tr.flatG.grad_views().items()},
+                         {k: v.clone() for k, v in tr.flatD.grad_views().items()}, ys, dead, g16))
+            del tr
+        finally:
+            OPT.reset()
+    A, Bq, Cf = runs
+    assert A[4] == 17 and A[5] >= 30 and A[6] >= 14 and Bq[4:] == (0, 0, 0) and Cf[4:] == (0, 0, 0), (A[4:], Bq[4:], Cf[4:])
+    noise = (Bq[1] - Cf[1]).norm().item()
+    assert noise > 0 and (A[1] - Bq[1]).norm().item() < 2 * noise, ((A[1] - Bq[1]).norm().item(), noise)
+    assert (A[1] - Cf[1]).norm().item() < 2 * noise and noise < 0.05 * Cf[1].norm().item()
+    for k in ("loss_D", "loss_G", "loss_G_l1"):
+        close(A[0][k], Bq[0][k], 5e-3, k)
+    worst = 0.0
+    for i, shadow in ((2, O.shadowed_bias_keys("G", 6)), (3, O.shadowed_bias_keys("D"))):
+        for k, v in Bq[i].items():
+            if k not in shadow:
+                worst = max(worst, ((A[i][k] - v).norm() / ((v - Cf[i][k]).norm() + 1e-20)).item())
+    assert worst < 2.0, worst        # no gradient tensor moves by more than twice what the bf16 mode itself moves it
+
+
 @pytest.mark.parametrize("shape", [(3, 72, 104), (2, 100, 60), (1, 36, 40)])
 def test_ragged_sizes_fused_step_against_oracle(shape):
     """The same comparison on tiles that are neither square nor powers of two (multiples of 4, as the reference's down/up path needs):
@@ -698,7 +744,7 @@ def test_configs4_bf16_mixed_resolution_with_the_spectral_loss():
                 for k in ("loss_D", "loss_G", "loss_G_rs"):
                     close(out[k], o32[k], 1e-3, f"fp32 {k} bucket {i}")
                 continue
-            with O.operand_precision("bf16", y_bf16_min_pixels=4096):      # the build's storage rule for convolution outputs
+            with O.operand_precision("bf16", y_bf16_min_pixels=4096, y_bf16_min_tiles=400, g_bf16_min_tiles=400):      # the build's storage rule for convolution outputs
                 ref = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
                 o = ref.step(rgb, nir)
             assert float(ref.last["pred"].min()) > 0.3          # denominators pred + band stay away from 0
@@ -746,7 +792,7 @@ def test_configs4_bf16_with_the_spectral_loss_at_full_width():
         out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
         ref32 = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
         ref32.step(rgb, nir)
-        with O.operand_precision("bf16", y_bf16_min_pixels=4096):      # the build's storage rule for convolution outputs
+        with O.operand_precision("bf16", y_bf16_min_pixels=4096, y_bf16_min_tiles=400, g_bf16_min_tiles=400):      # the build's storage rule for convolution outputs
             ref = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
             o = ref.step(rgb, nir)
         assert float(ref.last["pred"].min()) > 0.3

@@ -403,12 +403,14 @@ def test_bf16_mode_stores_convolution_outputs_as_bf16(emu, golden_dir, monkeypat
     accumulators (maps of >= OPT.epilogue_min_pixels_bf16 pixels, H*W % 128 == 0 per launch, no split-K) is kept as bf16; the norm's apply
     and both passes of its backward read the rounded tensor.  Thresholds lowered so that the golden net's 32 x 32 and 16 x 16 maps
     qualify.  (1) the stored tensor is the oracle's convolution rounded to bf16, the statistics are those of the UNROUNDED values;
-    (2) the step stays inside the bf16 noise band of the oracle's restatement of the same rule (operand_precision(y_bf16_min_pixels))."""
+    (2) the step -- with the data gradients that feed an instance-norm backward stored as bf16 too (OPT.bf16_g) -- stays inside the bf16
+    noise band of the oracle's restatement of the same rules (operand_precision(y_bf16_min_pixels, g_bf16_min_tiles))."""
     import torch.nn.functional as F
     from nirgan_hip.options import OPT
     from nirgan_hip.trainer import Pix2PixTrainer
     monkeypatch.setattr(OPT, "epilogue_min_pixels", 64)
     monkeypatch.setattr(OPT, "epilogue_min_pixels_bf16", 64)
+    monkeypatch.setattr(OPT, "bf16_store_min_tiles", 0)
     z = load(golden_dir, "f1_g6_d.npz")
     netG, netD = make_nets(z, 6)
     tr = Pix2PixTrainer(netG, netD, n_blocks=6, precision="bf16")
@@ -418,13 +420,14 @@ def test_bf16_mode_stores_convolution_outputs_as_bf16(emu, golden_dir, monkeypat
     stored = {n: getattr(eng, n).y.t.dtype for n in ("L1", "L2", "L3", "U1", "U2")}
     assert stored == {"L1": torch.bfloat16, "L2": torch.bfloat16, "L3": torch.float32, "U1": torch.float32, "U2": torch.bfloat16}, stored
     assert "in_fwd_pre" in emu.calls
+    assert sum(a[0]._obj.g_bf16 for n, a in eng.bwd.ops if n == "nirgan_instnorm_bwd") >= 14      # block layers, both down layers, first up layer
     with O.operand_precision("bf16"):
         y = O._conv2d(F.pad(rgb, (3, 3, 3, 3), mode="reflect"), pG["model.1.weight"], pG["model.1.bias"])
     got = _nchw(eng.L1.y).float()
     assert ((got - y).abs() <= y.abs() * 2.0 ** -8 + 1e-6).all(), "stored y is not the convolution rounded to bf16"
     close(eng.L1.stats[0], y.mean((2, 3)), 1e-5, "mean of the unrounded values")
     close(eng.L1.stats[1], torch.rsqrt(y.var((2, 3), unbiased=False) + 1e-5), 1e-4, "rstd of the unrounded values")
-    with O.operand_precision("bf16", y_bf16_min_pixels=64):
+    with O.operand_precision("bf16", y_bf16_min_pixels=64, g_bf16_min_tiles=0):
         ref = O.OracleTrainer(pG, sub(z, "D0/"), 6)
         o = ref.step(rgb, nir)
     pred32 = torch.from_numpy(z["pred"])
