@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void wino6_input_kernel(const W6In p) {
     typedef typename W6Vec<VW>::T V4;
     static_assert(MODE == 0 || R == 3, "the fused variants exist for the 3x3 filter");
     const int q4 = p.C / VW;
-    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    const long long i = ng_xcd_remap(blockIdx.x, gridDim.x) * 256ll + threadIdx.x;        // neighbouring patches on one XCD (see the lane-spread kernel)
     if (i >= p.T * q4) return;
     const long long t = i / q4;
     const int q = int(i - t * q4);
@@ -366,7 +366,10 @@ __global__ __launch_bounds__(256) void wino6_input_coop_kernel(const W6In p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane >> 3, qg = lane & 7;
     const int groups = p.C / 32;
-    const long long unit = blockIdx.x * 4ll + wave, units = p.T * groups;
+    // consecutive patches on ONE XCD (ng_xcd_remap): neighbouring patches share two of their eight rows and columns, and under the
+    // round-robin dispatch they sat on different XCDs -- every L2 fetched the overlap for itself (PMC: 230 MB read per launch of the fused
+    // dY pass against 134 MB of tensors)
+    const long long unit = ng_xcd_remap(blockIdx.x, gridDim.x) * 4ll + wave, units = p.T * groups;
     const bool live = unit < units;
     const long long t = live ? unit / groups : 0;
     const int cg = live ? int(unit - t * groups) : 0;
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256) void wino6_dy_kernel(const W6Dy p) {
     constexpr int N = W6<V>::N, MO = W6<V>::MO, VW = W6VW<V>::value;
     typedef typename W6Vec<VW>::T V4;
     const int q4 = p.K / VW;
-    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    const long long i = ng_xcd_remap(blockIdx.x, gridDim.x) * 256ll + threadIdx.x;
     if (i >= p.T * q4) return;
     const long long t = i / q4;
     const int q = int(i - t * q4);
