@@ -643,6 +643,16 @@ def drop_dead_fp32_stores(buffers) -> int:
     if not OPT.bf16_twin_only:
         return n
     for h in buffers:
+        if h.t16 is not None and h.writers and not any(reads_twin(r) for r in h.readers):
+            # the other way round: nobody reads the TWIN (the last up-convolution's output feeds the fp32 direct kernels of the last layer,
+            # the first layer's dY an N = 64 weight gradient that takes fp32): the mirrored store goes
+            for w in h.writers:
+                if isinstance(w, L.InFwdDesc):
+                    w.out_bf16 = None
+                else:
+                    w.dy_bf16 = None
+            n += 1
+            continue
         if h.t16 is None or h.pinned or not h.readers or not h.writers or not all(reads_twin(r) for r in h.readers):
             continue
         if not all(isinstance(w, L.InFwdDesc) or (isinstance(w, L.InBwdDesc) and w.norm) for w in h.writers):
