@@ -158,8 +158,11 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const InFwd p) {
     float* ob = p.out ? p.out + size_t(b) * p.o_img : nullptr;
     unsigned short* ob16 = p.out16 ? p.out16 + size_t(b) * p.o_img : nullptr;
     const float* rb = p.residual ? p.residual + size_t(b) * p.r_img + p.r_org : nullptr;
-    for (int pix = start + rg; pix < end; pix += nrg) {
-        const int h = pix / p.W, w = pix - h * p.W;
+    // (h, w) of the thread's pixel advance with it: one integer division per thread instead of one per pixel (a 32-bit division is ~25
+    // VALU instructions; these passes run at four waves per SIMD, where that issue time is not hidden)
+    int h = (start + rg) / p.W, w = (start + rg) - h * p.W;
+    for (int pix = start + rg; pix < end; pix += nrg, w += nrg) {
+        while (w >= p.W) { w -= p.W; ++h; }
         f32x4 v = (ldy4(yb, size_t(pix) * p.C + q * 4, p.y16) - mean) * rstd;
         v = act4(v, p.act, p.slope);
         if (rb) v += ld4(rb + size_t(h) * p.r_row + size_t(w) * p.C + q * 4);
@@ -201,8 +204,9 @@ __global__ __launch_bounds__(256) void in_bwd_pass1_kernel(const InBwd p) {
         const int start = chunk * p.ppc;
         int end = start + p.ppc;
         end = end < p.HW ? end : p.HW;
-        for (int pix = start + rg; pix < end; pix += nrg) {
-            const int h = pix / p.W, w = pix - h * p.W;
+        int h = (start + rg) / p.W, w = (start + rg) - h * p.W;          // advanced with the pixel (see in_apply_kernel)
+        for (int pix = start + rg; pix < end; pix += nrg, w += nrg) {
+            while (w >= p.W) { w -= p.W; ++h; }
             const f32x4 ga = in_bwd_gsum(p, gb, g2b, h, w, pix, q);
             if (p.gsum_out) st4(p.gsum_out + (size_t(b) * p.HW + pix) * p.C + q * 4, ga);
             // z = (y - mean) * rstd is recomputed exactly as the forward computed it: its sign is the activation
@@ -270,8 +274,9 @@ __global__ __launch_bounds__(256) void in_bwd_pass2_kernel(const InBwd p, int B)
     const int start = chunk * p.ppc;
     int end = start + p.ppc;
     end = end < p.HW ? end : p.HW;
-    for (int pix = start + rg; pix < end; pix += nrg) {
-        const int h = pix / p.W, w = pix - h * p.W;
+    int h = (start + rg) / p.W, w = (start + rg) - h * p.W;              // advanced with the pixel (see in_apply_kernel)
+    for (int pix = start + rg; pix < end; pix += nrg, w += nrg) {
+        while (w >= p.W) { w -= p.W; ++h; }
         const size_t off = size_t(h) * p.d_row + size_t(w) * p.C + q * 4;
         const f32x4 r = in_bwd_dy(p, gb, g2b, gsb, yb, mean, rstd, m1, m2, h, w, q);
         if (db) st4(db + off, r);
