@@ -12,7 +12,7 @@ __host__ __device__ inline int in_nrg(int C) {
 
 inline int in_nchunk(int B, int HW, int C) {
     const int nrg = in_nrg(C);
-    int want = 1024 / B;
+    int want = 2048 / B;          // 2 048 blocks: eight per CU, all resident (32 waves per CU); 1 024 left the passes latency-bound at 16 waves (bf16 step 12.56 -> 11.92 ms of op time)
     if (want < 1) want = 1;
     int cap = HW / (nrg * 8);
     if (cap < 1) cap = 1;
@@ -94,7 +94,12 @@ inline InBwd in_bwd_params(const nirgan_in_bwd_desc* d) {
     p.H = d->H; p.W = d->W; p.HW = d->H * d->W; p.C = d->C;
     p.dy = d->dy; p.d_row = d->d_wp * d->C; p.d_img = d->d_hp * p.d_row; p.d_org = d->d_pad * p.d_row + d->d_pad * d->C;
     p.gsum_out = d->gsum_out; p.dbias = d->dbias;
-    p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C); p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
+    p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C);
+    if (!d->norm) {       // no second pass: the rows of the live-bias sums are added by ONE block (nirgan_colsum, fixed order): keep them few
+        const int few = 1024 / d->B > 1 ? 1024 / d->B : 1;
+        p.nchunk = p.nchunk < few ? p.nchunk : few;
+    }
+    p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
     p.dy16 = static_cast<unsigned short*>(d->dy_bf16);
     p.pchunks = d->norm && d->sums_chunks > 0 ? d->sums_chunks : p.nchunk;
     return p;

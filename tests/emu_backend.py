@@ -67,7 +67,7 @@ def load_y(ptr, n, is_bf16) -> np.ndarray:
 def _in_nchunk(B, HW, Cc):
     q4 = Cc // 4
     nrg = 1 if q4 >= 256 else 256 // q4
-    want = max(1, 1024 // B)
+    want = max(1, 2048 // B)
     cap = max(1, HW // (nrg * 8))
     return min(want, cap)
 
