@@ -95,10 +95,6 @@ inline InBwd in_bwd_params(const nirgan_in_bwd_desc* d) {
     p.dy = d->dy; p.d_row = d->d_wp * d->C; p.d_img = d->d_hp * p.d_row; p.d_org = d->d_pad * p.d_row + d->d_pad * d->C;
     p.gsum_out = d->gsum_out; p.dbias = d->dbias;
     p.ws = d->ws; p.nchunk = in_nchunk(d->B, p.HW, d->C);
-    if (!d->norm) {       // no second pass: the rows of the live-bias sums are added by ONE block (nirgan_colsum, fixed order): keep them few
-        const int few = 1024 / d->B > 1 ? 1024 / d->B : 1;
-        p.nchunk = p.nchunk < few ? p.nchunk : few;
-    }
     p.ppc = (p.HW + p.nchunk - 1) / p.nchunk;
     p.dy16 = static_cast<unsigned short*>(d->dy_bf16);
     p.pchunks = d->norm && d->sums_chunks > 0 ? d->sums_chunks : p.nchunk;
