@@ -63,14 +63,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
         const float* src = slabs + size_t(n) * K + k4;
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
         int sp = grp;
-        for (; sp + 4 < nsplit; sp += 8) {
+        for (; sp + 12 < nsplit; sp += 16) {                 // four slabs in flight per wave (fixed association)
             s += *reinterpret_cast<const f32x4*>(src + sp * total);
             s1 += *reinterpret_cast<const f32x4*>(src + (sp + 4) * total);
+            s2 += *reinterpret_cast<const f32x4*>(src + (sp + 8) * total);
+            s3 += *reinterpret_cast<const f32x4*>(src + (sp + 12) * total);
         }
-        if (sp < nsplit) s += *reinterpret_cast<const f32x4*>(src + sp * total);
-        s += s1;
+        for (; sp < nsplit; sp += 4) s += *reinterpret_cast<const f32x4*>(src + sp * total);
+        s = (s + s1) + (s2 + s3);
     }
     part[grp][lane] = s;
     __syncthreads();
