@@ -13,6 +13,7 @@
 //   Two LDS stages, one barrier per K-step: the DMA of step s+1 flies under the 64 MFMAs
 //   (4096 cycles) of step s.  Out-of-range rows/channels read a zero page.
 #include "igemm_tiles.h"
+#include "igemm_tile256.h"
 
 namespace {
 
@@ -21,6 +22,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ng::ConvParams
     __shared__ __attribute__((aligned(16))) char st0[(128 + BN) * 128];
     __shared__ __attribute__((aligned(16))) char st1[(128 + BN) * 128];
     ng::conv_tile<BN, PREC, WB16, AB16>(p, blockIdx.x, st0, st1);
+}
+
+// the bf16 operand mode's 256 x 256 x 64 eight-phase tile (igemm_tile256.h): one workgroup of eight waves per CU
+__global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ng::ConvParams p) {
+    __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
+    ng::conv_tile256(p, blockIdx.x, lds);
 }
 
 // split-K second stage: out(m, n) = bias[n] + sum_s ws[s][m][n], written with the descriptor's output geometry
@@ -71,6 +78,10 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
     const int rc = ng::build_conv_params(d, p);
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) {
+        hipLaunchKernelGGL(conv_igemm256_kernel, dim3(((p.M + 255) >> 8) * (p.N >> 8)), dim3(512), 0, st, p);
+        return nirgan_check_launch("conv_igemm (256 x 256 tile)");
+    }
     const dim3 grid(p.mtiles * p.ntiles * p.ksplit);
 #define NG_LAUNCH_CONV(BN, PREC) hipLaunchKernelGGL((conv_igemm_kernel<BN, PREC>), grid, dim3(256), 0, st, p)
     if (d->N > 64) {

@@ -83,6 +83,7 @@ struct ConvParams {
     int f_img, f_row, f_org, f_act, f_chunk0, f_cps;
     float f_slope;
     int out16, f_y16;          // the output / the fused pass's y are stored as bf16 (nirgan_conv_desc.out_bf16 / fuse_y_bf16)
+    int algo;                  // nirgan_conv_desc.algo
     int off32;                 // both operand buffers span < 4 GB: per-lane 32-bit byte offsets from a scalar base (the loader's fast path)
 };
 
@@ -1306,6 +1307,7 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.in_bf16 = d->in_bf16 ? 1 : 0;
     NG_REQUIRE(!p.in_bf16 || (p.w_bf16 && d->in_cs % 8 == 0), "conv: bf16 activations need bf16-stored weights and in_cs %% 8 == 0 (in_cs=%d)", d->in_cs);
     p.off32 = (d->in_elems * (p.in_bf16 ? 2 : 4) < (int64_t(1) << 32) && d->w_elems * (p.w_bf16 ? 2 : 4) < (int64_t(1) << 32)) ? 1 : 0;
+    p.algo = d->algo;
     p.dbg = nullptr;
     p.ksplit = 1;
     p.split_ws = nullptr;

@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("stats_ws", fp), ("stats_ws_elems", i64), ("stats_chunk0", i32), ("stats_chunks", i32),
                 ("fuse_y", fp), ("fuse_mean", fp), ("fuse_rstd", fp), ("fuse_h", i32), ("fuse_w", i32), ("fuse_oh", i32), ("fuse_ow", i32),
                 ("fuse_act", i32), ("fuse_slope", f32), ("fuse_part", fp), ("fuse_part_elems", i64), ("fuse_chunk0", i32), ("fuse_chunks", i32),
-                ("out_bf16", i32), ("fuse_y_bf16", i32)]
+                ("out_bf16", i32), ("fuse_y_bf16", i32), ("algo", i32)]
 
 
 class WgradDesc(C.Structure):
@@ -145,6 +145,7 @@ class Wino6Desc(C.Structure):
 W6_ONE_TILE, W6_PERSIST16, W6_DIRECT_TILE = 1, 2, 3      # nirgan_wino6_desc.algo
 W6_PATCH_PER_THREAD, W6_PATCH_PER_LANES = 16, 17                                 # nirgan_wino6_desc.algo for the input transforms (A/B)
 WGRAD_ONE_UNIT = 1                                       # nirgan_wgrad_desc.algo
+CONV_TILE128 = 1                                         # nirgan_conv_desc.algo
 
 
 class EndConvDesc(C.Structure):
