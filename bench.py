@@ -80,20 +80,23 @@ def op_mfma_work(name, args):
         return npl * (w.B * w.p_hp * w.p_wp * w.p_cs * e + w.B * w.q_hp * w.q_wp * w.q_cs * e) + npl * w.nsplit * w.N * w.ntaps * w.run * 4.0
     if name == "nirgan_conv_igemm":
         d = args[0]._obj
-        return f"conv_igemm_kernel<{128 if d.N > 64 else 64}>", 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run, conv_bytes(d)
+        k = be.nirgan_conv_kernel_name(args[0]) if hasattr(be, "nirgan_conv_kernel_name") else None
+        return (k.decode() if k else f"conv_igemm_kernel<{128 if d.N > 64 else 64}>"), 2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run, conv_bytes(d)
     if name == "nirgan_conv_igemm_group":
         ds = [args[0][j].contents for j in range(args[1])]
         by = conv_bytes(ds[0]) + sum(d.N * d.ntaps * d.run * (2.0 if d.w_bf16 else 4.0) + d.B * d.OH * d.OW * d.N * 4.0 for d in ds[1:])      # the phases share the input
         return f"conv_group_kernel<{128 if ds[0].N > 64 else 64}>", sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds), by
     if name == "nirgan_wgrad_igemm":
         w = args[0]._obj
-        label = f"wgrad_igemm_kernel<{128 if w.N > 64 else 64}>" + ("(bf16 twins)" if w.pq_bf16 else "")
+        k = be.nirgan_wgrad_kernel_name(args[0]) if hasattr(be, "nirgan_wgrad_kernel_name") else None
+        label = k.decode() if k and k.decode().endswith("256_kernel") else f"wgrad_igemm_kernel<{128 if w.N > 64 else 64}>" + ("(bf16 twins)" if w.pq_bf16 else "")
         return label, 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, wgrad_bytes(w)
     if name == "nirgan_conv_wgrad_pair":
         c, w = args[0]._obj, args[1]._obj
         # (the weight gradient's p operand is the data gradient's input: counted once)
         by = conv_bytes(c) + wgrad_bytes(w) - max(w.nplanes, 1) * w.B * w.p_hp * w.p_wp * w.p_cs * (2.0 if w.pq_bf16 else 4.0)
-        return "conv_wgrad_pair_kernel", 2.0 * c.B * c.OH * c.OW * c.N * c.ntaps * c.run + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, by
+        k = be.nirgan_conv_wgrad_pair_kernel_name(args[0], args[1]) if hasattr(be, "nirgan_conv_wgrad_pair_kernel_name") else None
+        return (k.decode() if k and k.decode().startswith("conv_wgrad") else "conv_wgrad_pair_kernel"), 2.0 * c.B * c.OH * c.OW * c.N * c.ntaps * c.run + 2.0 * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, by
     if name == "nirgan_wino6_gemm":
         d = args[0]._obj
         T = w6_tiles(d)
@@ -118,7 +121,7 @@ def op_mfma_work(name, args):
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.3 achievable)
 
 
-def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_group_kernel<128>", "wgrad_igemm_kernel<128>", "conv_wgrad_pair_kernel", "wino6_")):
+def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_igemm256_kernel", "conv_group_kernel<128>", "wgrad_igemm_kernel<128>", "wgrad_igemm256_kernel", "conv_wgrad_pair", "wino6_")):
     """EXECUTED FLOPs of one step's launches of the big MFMA kernels, and the op indices to bracket with HIP events."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds, algo_bytes = {}, {}

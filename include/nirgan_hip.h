@@ -150,6 +150,8 @@ typedef struct {
                                            * problems walk their units as persistent workgroups); NIRGAN_WGRAD_ONE_UNIT = one unit per workgroup */
 } nirgan_wgrad_desc;
 #define NIRGAN_WGRAD_ONE_UNIT 1
+#define NIRGAN_WGRAD_TILE128 2   /* bf16 twins: never the 256 x 256 x 64 eight-phase tile (persistent workgroups, one per CU), which is the
+                                  * default for N % 256 == 0, ntaps * run % 256 == 0, OW % 64 == 0 or 64 % OW == 0, rows_per_split % 64 == 0 */
 
 int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream);
 
@@ -161,6 +163,12 @@ int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int n, void* s
  * read the same dY): one grid holds the tiles of both, so the partly filled last round of one problem is
  * filled by the other.  Semantics = nirgan_conv_igemm(c) followed by nirgan_wgrad_igemm(w). */
 int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wgrad_desc* w, void* stream);
+
+/* names of the kernels the three launchers above pick for a descriptor (what a profile of the launch shows; NULL for an invalid
+ * descriptor): the 128-row tiles or, in the bf16 operand mode, the 256 x 256 x 64 eight-phase tiles */
+const char* nirgan_conv_kernel_name(const nirgan_conv_desc* d);
+const char* nirgan_wgrad_kernel_name(const nirgan_wgrad_desc* d);
+const char* nirgan_conv_wgrad_pair_kernel_name(const nirgan_conv_desc* c, const nirgan_wgrad_desc* w);
 
 /* dst[n*dst_row_stride + map[k]] (= | +=) sum_s slabs[s][n][k]  for map[k] >= 0 */
 int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ng::ConvParams
 // the bf16 operand mode's 256 x 256 x 64 eight-phase tile (igemm_tile256.h): one workgroup of eight waves per CU
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ng::ConvParams p) {
     __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
-    ng::conv_tile256(p, blockIdx.x, lds);
+    ng::conv_tile256(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
 }
 
 // split-K second stage: out(m, n) = bias[n] + sum_s ws[s][m][n], written with the descriptor's output geometry
@@ -104,6 +104,13 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, p);
     }
     return nirgan_check_launch("conv_igemm");
+}
+
+extern "C" const char* nirgan_conv_kernel_name(const nirgan_conv_desc* d) {
+    ng::ConvParams p;
+    if (ng::build_conv_params(d, p) != NIRGAN_OK) return nullptr;
+    if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) return "conv_igemm256_kernel";
+    return d->N > 64 ? "conv_igemm_kernel<128>" : "conv_igemm_kernel<64>";
 }
 
 extern "C" int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int n, void* stream) {

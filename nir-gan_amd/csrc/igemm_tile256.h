@@ -11,16 +11,16 @@
 //                16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7) (applied on the DMA's source side and on the read side)
 //                B half j, row r holds weight row n0 + (r >> 5) * 64 + j * 32 + (r & 31): a wave's two column quadrants are adjacent
 //   MFMA         v_mfma_f32_16x16x32_bf16: quadrant x 64 k = 4 x 2 tiles x 2 k-steps = 16 per phase
-//   phases       K-tile k (buffer b): .1 read B half 0 + A half 0, C00;  .2 read B half 1, C01;  .3 read A half 1, C10;  .4 C11
-//   LDS-DMA      one half-tile (2 pieces per wave) per phase: .1 A1(k+1)  .2 B0(k+2)  .3 A0(k+2)  .4 B1(k+2), then vmcnt(6):
-//                everything but the three youngest halves has landed = K-tile k+1 complete, read from the NEXT phase on
+//   phases       K-tile k (buffer b): .1 read A half 0, C00;  .2 read B half 1, C01;  .3 read A half 1, C10;  .4 read B half 0 of k+1, C11
+//   LDS-DMA      one half-tile (2 pieces per wave) per phase: .1 A1(k+1)  .2 B0(k+2)  .3 A0(k+2)  .4 B1(k+2); every phase ends with
+//                vmcnt(10): all but the five youngest halves have landed, i.e. the half issued five phases ago, read from the NEXT phase on
 //   stagger      waves 4-7 run one barrier behind waves 0-3: on every SIMD one wave is in its MFMA segment while its partner issues
 //                fragment reads and DMA pieces
-// Hazards (the guide's placement rules): a half is read one phase AFTER the wait that retires its DMA; it is restaged two phases after
-// its last fragment read, or one phase after where an lgkmcnt before the reading phase's barrier retired those reads (B half 0: the
-// four B reads are issued first and retired by lgkmcnt(8)).
+// Hazards (the guide's placement rules): a half is read one phase AFTER the wait that retires its DMA, and restaged two phases after
+// its last fragment read (t256_kloop's table).
 #pragma once
 #include "igemm_tiles.h"
+#include <type_traits>
 
 namespace ng {
 
@@ -33,12 +33,130 @@ __device__ __forceinline__ void t256_bar() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void conv_tile256(const ConvParams& p, const int block_id, char* lds) {
+// The K loop of the eight-phase structure, shared by the convolution tile and the weight-gradient tile.  The callables work on the
+// caller's registers: issueA / issueB(buf, h) start the LDS-DMA of half h of the cursor's K-tile into buffer buf, advance() moves the
+// cursor to the next K-tile, readA(buf, h) / readB(which, buf, h) issue the fragment reads (B into register set `which`), mma(i, j)
+// waits for them and accumulates quadrant (i, j) from the A registers and B set j.
+//
+// Schedule of K-tile k (buffer b = k & 1), one half-tile of LDS-DMA and one set of fragment reads per phase:
+//     phase   fragment reads        MFMA block      LDS-DMA issued     wait at the end of the phase's load segment
+//     k.1     A half 0 of k         C00 (A0 B0)     A half 1 of k+1    vmcnt(10): the half issued five phases ago has landed
+//     k.2     B half 1 of k         C01 (A0 B1)     B half 0 of k+2    vmcnt(10)
+//     k.3     A half 1 of k         C10 (A1 B0)     A half 0 of k+2    vmcnt(10)
+//     k.4     B half 0 of k+1       C11 (A1 B1)     B half 1 of k+2    vmcnt(10)
+// Every slot of the ring then lives one 8-phase period: issued, retired by the wait five phases later, read in the sixth phase,
+// restaged two phases after that read.  The fragment reads are spread 2 : 1 : 2 : 1 over the phases (the first form of this loop read
+// A half 0 and B half 0 together in phase 1 and nothing in phase 4: the weight-gradient tile's 24 transposing reads of that phase, not
+// the 16 MFMAs of its partner wave, set the phase length -- 3 140 cycles per K-tile against 2 500 for the convolution tile).
+// In the last two K-tiles, where fewer than five younger halves exist, the waits drain (vmcnt(0)).
+template <class IA, class IB, class ADV, class RA, class RB, class MMA>
+__device__ __forceinline__ void t256_kloop(const int nk, const int wr, IA&& issueA, IB&& issueB, ADV&& advance, RA&& readA, RB&& readB, MMA&& mma) {
+    // prologue: K-tile 0 whole, three halves of K-tile 1 (its A half 1 goes out in phase 1), then "phase -1.4": B half 0 of K-tile 0
+    issueB(0, 0); issueA(0, 0); issueB(0, 1); issueA(0, 1);
+    advance();
+    if (nk > 1) {
+        issueB(1, 0); issueA(1, 0); issueB(1, 1);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // B half 0 of K-tile 0
+    } else {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    t256_bar();                               // ... from every wave
+    if (wr == 1) t256_bar();                  // the stagger: waves 4-7 run one barrier behind from here on
+    readB(0, 0, 0);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // A half 0 of K-tile 0
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    t256_bar();
+    t256_bar();                               // (the empty MFMA segment of that phase: keeps the two wave groups half a phase apart)
+    for (int k = 0; k < nk; k += 2) {
+        // ======== K-tile k, buffer 0
+        const bool more1 = k + 1 < nk, more2 = k + 2 < nk, more3 = k + 3 < nk;
+        // phase 1
+        readA(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more1) { issueA(1, 1); advance(); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t256_bar();
+        mma(0, 0);
+        t256_bar();
+        // phase 2
+        readB(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) { issueB(0, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t256_bar();
+        mma(0, 1);
+        t256_bar();
+        // phase 3
+        readA(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) { issueA(0, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t256_bar();
+        mma(1, 0);
+        t256_bar();
+        // phase 4
+        if (more1) readB(0, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) { issueB(0, 1); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t256_bar();
+        mma(1, 1);
+        t256_bar();
+        if (!more1) break;
+        // ======== K-tile k+1, buffer 1
+        // phase 5
+        readA(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) { issueA(0, 1); advance(); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t256_bar();
+        mma(0, 0);
+        t256_bar();
+        // phase 6
+        readB(1, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more3) { issueB(1, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t256_bar();
+        mma(0, 1);
+        t256_bar();
+        // phase 7
+        readA(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more3) { issueA(1, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t256_bar();
+        mma(1, 0);
+        t256_bar();
+        // phase 8
+        if (more2) readB(0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more3) { issueB(1, 1); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t256_bar();
+        mma(1, 1);
+        t256_bar();
+    }
+    if (wr == 0) t256_bar();                  // waves 0-3 wait for the staggered half: every fragment read and every DMA is done
+}
+
+// in-kernel stamps of the diagnostic build (scripts/diag/tile256_stamp.hip defines NG_DIAG256); none executes in the product build
+#ifdef NG_DIAG256
+#define T256_STAMP(i) { __builtin_amdgcn_sched_barrier(0); ng_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define T256_STAMP(i)
+#endif
+
+__device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, char* lds) {
+#ifdef NG_DIAG256
+    unsigned long long ng_t[8];
+    const unsigned long long ng_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    T256_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int mt256 = (p.M + 255) >> 8, nt256 = (p.N + 255) >> 8;
-    const int id = ng_xcd_remap(block_id, mt256 * nt256);
     const int n0 = (id % nt256) * 256, m0 = (id / nt256) * 256;
 
     // ---------------- loader state: per half-tile a wave issues pieces 2 wave, 2 wave + 1 (8 rows x 128 B each)
@@ -128,92 +246,11 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int bloc
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // ---------------- prologue: K-tile 0 whole, three halves of K-tile 1 (its A half 1 goes out in phase 1)
-    issueB(0, 0); issueA(0, 0); issueB(0, 1); issueA(0, 1);
-    advance();
-    if (nk > 1) {
-        issueB(1, 0); issueA(1, 0); issueB(1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    t256_bar();                               // every wave's pieces of K-tile 0 have landed
-    if (wr == 1) t256_bar();                  // the stagger: waves 4-7 run one barrier behind from here on
-
-    for (int k = 0; k < nk; k += 2) {
-        // ======== K-tile k, buffer 0
-        // phase 1
-        readB(B0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        readA(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 1 < nk) { issueA(1, 1); advance(); }
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the four B reads are done: B half 0 may be restaged next phase
-        t256_bar();
-        mma(acc[0][0], B0);
-        t256_bar();
-        // phase 2
-        readB(B1, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 2 < nk) issueB(0, 0);
-        t256_bar();
-        mma(acc[0][1], B1);
-        t256_bar();
-        // phase 3
-        readA(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 2 < nk) issueA(0, 0);
-        t256_bar();
-        mma(acc[1][0], B0);
-        t256_bar();
-        // phase 4
-        if (k + 2 < nk) {
-            issueB(0, 1);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K-tile k+1 has landed (read from the next phase on)
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        t256_bar();
-        mma(acc[1][1], B1);
-        t256_bar();
-        if (k + 1 >= nk) break;
-        // ======== K-tile k+1, buffer 1
-        // phase 5
-        readB(B0, 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        readA(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 2 < nk) { issueA(0, 1); advance(); }
-        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        t256_bar();
-        mma(acc[0][0], B0);
-        t256_bar();
-        // phase 6
-        readB(B1, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 3 < nk) issueB(1, 0);
-        t256_bar();
-        mma(acc[0][1], B1);
-        t256_bar();
-        // phase 7
-        readA(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 3 < nk) issueA(1, 0);
-        t256_bar();
-        mma(acc[1][0], B0);
-        t256_bar();
-        // phase 8
-        if (k + 3 < nk) {
-            issueB(1, 1);
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        t256_bar();
-        mma(acc[1][1], B1);
-        t256_bar();
-    }
-    if (wr == 0) t256_bar();                  // waves 0-3 wait for the staggered half: every fragment read and every DMA is done
+    T256_STAMP(1)
+    t256_kloop(nk, wr, issueA, issueB, advance, readA,
+                  [&](const int which, const int buf, const int h) { if (which == 0) readB(B0, buf, h); else readB(B1, buf, h); },
+                  [&](const int i, const int j) { if (j == 0) mma(acc[i][0], B0); else mma(acc[i][1], B1); });
+    T256_STAMP(2)
 
     // ---------------- partial sums for the instance norm that follows (nirgan_conv_desc.stats_ws): a wave's 64 rows x 64 columns leave,
     // per column, {k = the chunk's first row, sum (v - k), sum (v - k)^2, 64} -- same contract as conv_tile, chunk = 64 output pixels
@@ -254,17 +291,280 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int bloc
         }
     }
 
+    T256_STAMP(3)
     // ---------------- epilogue: each wave transposes its 64 x 64 (row half i) through its OWN 16 KB of LDS -- no workgroup barrier --
-    // and stores whole 256-byte (fp32) / 128-byte (bf16) row segments, 16 / 8 bytes per lane
+    // and stores whole 256-byte (fp32) / 128-byte (bf16) row segments, 16 bytes per lane either way (the store path is bound by
+    // the number of store instructions: 8-byte stores of a bf16 output took 16 k cycles per tile, twice the 16-byte ones)
     float* const stg = reinterpret_cast<float*>(lds + wave * 16384);
-    const int chunk = lane & 15, lrow = lane >> 4;
-    const int n = n0 + wc * 64 + chunk * 4;
-    const bool n_ok = n < p.N;                // (host: N % 4 == 0)
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr && n_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
     const int OH = p.OHW / p.OW;
     const bool fused = p.f_y != nullptr;
     const float fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
+    auto half_out = [&](const int i, auto wtag) {
+        constexpr int W = decltype(wtag)::value;          // output channels per lane: 4 (fp32 output) or 8 (bf16 output)
+        constexpr int LPR = 64 / W, RPP = 64 / LPR;       // lanes per row, rows per pass
+        typedef float fW __attribute__((ext_vector_type(W)));
+        typedef __bf16 bW __attribute__((ext_vector_type(W)));
+        const int chunk = lane % LPR, lrow = lane / LPR;
+        const int n = n0 + wc * 64 + chunk * W;
+        const bool n_ok = n < p.N;                         // (host: N % 256 == 0)
+        fW bv = {};
+        if (p.bias != nullptr && n_ok) bv = *reinterpret_cast<const fW*>(p.bias + n);
+        const int mbase = m0 + i * 128 + wr * 64;
+        int m = mbase + lrow;
+        const int mc = m < p.M ? m : p.M - 1;
+        int b = mc / p.OHW;
+        const int r0 = mc - b * p.OHW;
+        int oh = r0 / p.OW, ow = r0 - oh * p.OW;
+        const int fb = (mbase < p.M ? mbase : p.M - 1) / p.OHW;          // (fused: one sample per 128-row half, host: OH*OW % 128 == 0)
+        fW fm = {}, fr = {}, s1 = {}, s2 = {};
+        if (fused && n_ok) {
+            fm = *reinterpret_cast<const fW*>(p.f_mean + size_t(fb) * p.N + n);
+            fr = *reinterpret_cast<const fW*>(p.f_rstd + size_t(fb) * p.N + n);
+        }
+#pragma unroll 4
+        for (int pass = 0; pass < 64 / RPP; ++pass) {
+            if (m < p.M && n_ok) {
+                fW v = *reinterpret_cast<const fW*>(stg + (pass * RPP + lrow) * 64 + chunk * W);
+                v += bv;
+                const int oidx = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n;
+                if constexpr (W == 8) *reinterpret_cast<bW*>(reinterpret_cast<unsigned short*>(p.out) + oidx) = __builtin_convertvector(v, bW);
+                else *reinterpret_cast<fW*>(p.out + oidx) = v;
+                if (fused) {
+                    const size_t yidx = size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n;
+                    fW y;
+                    if (p.f_y16) y = __builtin_convertvector(*reinterpret_cast<const bW*>(reinterpret_cast<const unsigned short*>(p.f_y) + yidx), fW);
+                    else y = *reinterpret_cast<const fW*>(p.f_y + yidx);
+                    const fW z = (y - fm) * fr;
+#pragma unroll
+                    for (int q = 0; q < W; ++q) {
+                        const float gz = z[q] > 0.f ? v[q] : v[q] * fneg;
+                        s1[q] += gz;
+                        s2[q] += gz * z[q];
+                    }
+                }
+            }
+            m += RPP;
+            ow += RPP;
+            while (ow >= p.OW) { ow -= p.OW; ++oh; }
+            while (oh >= OH) { oh -= OH; ++b; }
+        }
+        if (fused) {
+            // first pass of the consumer layer's instance-norm backward: this wave's 64 rows, then the two waves of a 128-row chunk
+            // (wr = 0, 1) join through LDS in a fixed order.  All of a wave's staging reads are done (same wave, program order).
+#pragma unroll
+            for (int q = 0; q < W; ++q)
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) {
+                    s1[q] += __shfl_xor(s1[q], o, 64);
+                    s2[q] += __shfl_xor(s2[q], o, 64);
+                }
+            t256_bar();                                             // (uniform: `fused` is a launch constant) every wave's staging reads are done
+            fW* const red = reinterpret_cast<fW*>(lds);             // 8 waves x 64 columns x 2 sums: 4 KB
+            if (lane < LPR) {
+                red[(wave * LPR + chunk) * 2] = s1;
+                red[(wave * LPR + chunk) * 2 + 1] = s2;
+            }
+            t256_bar();
+            if (wr == 0 && lane < LPR && n_ok && mbase < p.M) {
+                const fW t1 = s1 + red[((wave + 4) * LPR + chunk) * 2], t2 = s2 + red[((wave + 4) * LPR + chunk) * 2 + 1];
+                float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((m0 + i * 128 - fb * p.OHW) >> 7)) * 2 * p.N + n;
+                *reinterpret_cast<fW*>(pp) = t1;
+                *reinterpret_cast<fW*>(pp + p.N) = t2;
+            }
+            t256_bar();
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        stg[(mt * 16 + (lane >> 4) * 4 + r) * 64 + j * 32 + nt * 16 + (lane & 15)] = acc[i][j][mt][nt][r];
+        if (p.out16) half_out(i, std::integral_constant<int, 8>{});
+        else half_out(i, std::integral_constant<int, 4>{});
+    }
+#ifdef NG_DIAG256
+    T256_STAMP(4)
+    if (lane == 0 && p.dbg != nullptr) {
+        unsigned long long* o = p.dbg + (size_t(id) * 8 + wave) * 7;
+        for (int q = 0; q < 5; ++q) o[q] = ng_t[q];
+        o[5] = ng_r0;
+        o[6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+// The weight gradient on the same structure: slab[split][n][J] = sum over the split's pixels m of P[m][n] * Q[m + tap(J)][c(J)], both
+// operands from the producers' bf16 twins (model/networks.py:405-427 through autograd: dW of the ResnetBlock convolutions).  A unit =
+// 256 rows n x 256 columns J x one split; a K-tile = 64 consecutive pixels.  The reduction index (the pixel) is the ROW of both
+// images, the MFMA wants it contiguous per lane: the half-tiles are 64 pixel rows x 128 columns in 256-byte rows and the fragments are
+// read with ds_read_b64_tr_b16 (a 16-lane group reads a 4-row x 16-column block, lane i receives column i): two reads = one
+// 16x16x32 operand.  Chunk c of row r sits at chunk c ^ 2 * ((r & 3) | ((r >> 3) & 1) << 2): the 8 rows a 32-lane half touches land on
+// 8 distinct 32-byte bank segments.  Q half j, LDS column x holds column j0 + (x >> 5) * 64 + j * 32 + (x & 31) of J (as the
+// convolution tile's B halves).  Host: OW % 64 == 0 or 64 % OW == 0, OH * OW % 64 == 0, rows_per_split % 64 == 0 -- a K-tile is a
+// fixed pattern of pixels relative to its first one, which walks in scalar registers.
+__device__ __forceinline__ void wgrad_tile256(const WgradParams& p, const int unit, char* lds) {
+#ifdef NG_DIAG256
+    unsigned long long ng_t[8];
+    const unsigned long long ng_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    T256_STAMP(0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntn = p.N >> 8, ntj = p.K >> 8;
+    const int nt_ = unit % ntn, rest = unit / ntn;
+    const int jt = rest % ntj, split = rest / ntj;
+    const int n0 = nt_ * 256, j0 = jt * 256;
+    const int mstart = split * p.rows_per_split;
+    int mend = mstart + p.rows_per_split;
+    mend = mend < p.M ? mend : p.M;
+    const int nk = mend > mstart ? (mend - mstart) >> 6 : 0;
+
+    // ---------------- loader state
+    const bool wide = (p.OW & 63) == 0;               // a K-tile is 64 pixels of one image row; otherwise 64 / OW whole rows
+    unsigned p_boff[2][2], q_boff[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 4 + (lane >> 4);
+            const int lc = (lane & 15) ^ (2 * ((row & 3) | (((row >> 3) & 1) << 2)));
+            const int rr = wide ? 0 : row / p.OW, rc = wide ? row : row - rr * p.OW;
+            p_boff[h][i] = unsigned(rr * p.p_row + rc * p.p_cs + h * 128 + lc * 8) * 2u;
+            const int J = j0 + ((lc >> 2) * 8 + h * 4 + (lc & 3)) * 8;
+            const int t = J / p.run;
+            q_boff[h][i] = unsigned(rr * p.q_stride * p.q_row + rc * p.q_stride * p.q_cs + p.tap_off[t] + (J - t * p.run)) * 2u;
+        }
+    // the K-tile cursor: first pixel (soh, sow) of the tile and the two base addresses, advanced by additions in scalar registers
+    const int sb0 = mstart / p.OHW;
+    int soh = (mstart - sb0 * p.OHW) / p.OW;
+    int sow = mstart - sb0 * p.OHW - soh * p.OW;
+    const char* pcur = reinterpret_cast<const char*>(p.p) + ((long long)sb0 * p.p_img + (long long)soh * p.p_row + sow * p.p_cs + p.p_org + n0) * 2;
+    const char* qcur = reinterpret_cast<const char*>(p.q) + ((long long)sb0 * p.q_img + (long long)soh * p.q_stride * p.q_row + sow * p.q_stride * p.q_cs + p.q_org) * 2;
+    const int rows_step = wide ? 1 : 64 / p.OW;                         // image rows a K-tile advances when it wraps / always
+    const long long p_step = wide ? 128ll * p.p_cs : 2ll * rows_step * p.p_row;
+    const long long q_step = wide ? 128ll * p.q_stride * p.q_cs : 2ll * rows_step * p.q_stride * p.q_row;
+    const long long p_wrap = 2ll * (p.p_row - p.OW * p.p_cs), q_wrap = 2ll * p.q_stride * (p.q_row - p.OW * p.q_cs);       // wide: end of an image row
+    const long long p_img_wrap = 2ll * (p.p_img - (long long)p.OH * p.p_row), q_img_wrap = 2ll * (p.q_img - (long long)p.OH * p.q_stride * p.q_row);
+    auto advance = [&]() {
+#ifdef NG_DIAG_NOADVANCE          // diagnostic build only: every K-tile re-reads the first one (L2-resident operands: what does the memory side cost?)
+        return;
+#endif
+        pcur += p_step;
+        qcur += q_step;
+        if (wide) {
+            sow += 64;
+            if (sow >= p.OW) { sow = 0; ++soh; pcur += p_wrap; qcur += q_wrap; }
+        } else {
+            soh += rows_step;
+        }
+        if (soh >= p.OH) { soh = 0; pcur += p_img_wrap; qcur += q_img_wrap; }
+    };
+    auto issueA = [&](const int buf, const int h) {
+        const char* base = ng_uniform_ptr(pcur);
+        char* dst = lds + (buf * 4 + h) * T256_HALF + wave * 2048;
+        ng_glds16_so(base, p_boff[h][0], dst);
+        ng_glds16_so(base, p_boff[h][1], dst + 1024);
+    };
+    auto issueB = [&](const int buf, const int h) {
+        const char* base = ng_uniform_ptr(qcur);
+        char* dst = lds + (buf * 4 + 2 + h) * T256_HALF + wave * 2048;
+        ng_glds16_so(base, q_boff[h][0], dst);
+        ng_glds16_so(base, q_boff[h][1], dst + 1024);
+    };
+
+    // ---------------- compute state
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int fl = 2 * (q | ((g & 1) << 2));
+    int a_ad[4], b_ad[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a_ad[mt] = (8 * g + q) * 256 + ((((wr * 4 + mt) * 2) | (pp >> 1)) ^ fl) * 16 + 8 * (pp & 1);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) b_ad[nt] = (8 * g + q) * 256 + ((((wc * 2 + nt) * 2) | (pp >> 1)) ^ fl) * 16 + 8 * (pp & 1);
+    // The transposing reads are INLINE ASM: for the ds_read_tr builtin hipcc (ROCm 7.2) waits vmcnt(0) before every read while an
+    // LDS-DMA is in flight (it cannot tell the read from the DMA's destination), which drains the ring every phase.  The compiler then
+    // neither counts these reads nor waits for them: mma() waits lgkmcnt(0) itself, fences the scheduler behind the wait (MFMAs are
+    // register-only and would otherwise be hoisted over it), and only THEN joins the two 8-byte halves of an operand -- any register
+    // copy the join needs happens after the data has arrived.  Offsets are 16-bit: buffer 1 reads through a second address (+ 64 KB).
+    const unsigned lds0 = unsigned(size_t((NG_LDS char*)lds));
+    unsigned a_ad0[4], a_ad1[4], b_ad0[2], b_ad1[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) { a_ad0[mt] = lds0 + unsigned(a_ad[mt]); a_ad1[mt] = a_ad0[mt] + 65536u; }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { b_ad0[nt] = lds0 + unsigned(b_ad[nt]) + 32768u; b_ad1[nt] = b_ad0[nt] + 65536u; }
+    s16x4 Ar[4][2][2], B0r[2][2][2], B1r[2][2][2];           // [tile][k-step][8-byte half]
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define T256_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+    auto readA = [&](const int buf, const int h) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const unsigned ad = buf ? a_ad1[mt] : a_ad0[mt];
+            if (h == 0) {
+                T256_TR(Ar[mt][0][0], ad, 0);     T256_TR(Ar[mt][0][1], ad, 1024);
+                T256_TR(Ar[mt][1][0], ad, 8192);  T256_TR(Ar[mt][1][1], ad, 8192 + 1024);
+            } else {
+                T256_TR(Ar[mt][0][0], ad, 16384);        T256_TR(Ar[mt][0][1], ad, 16384 + 1024);
+                T256_TR(Ar[mt][1][0], ad, 16384 + 8192); T256_TR(Ar[mt][1][1], ad, 16384 + 8192 + 1024);
+            }
+        }
+    };
+    auto readB = [&](s16x4 (&Bj)[2][2][2], const int buf, const int h) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const unsigned ad = buf ? b_ad1[nt] : b_ad0[nt];
+            if (h == 0) {
+                T256_TR(Bj[nt][0][0], ad, 0);     T256_TR(Bj[nt][0][1], ad, 1024);
+                T256_TR(Bj[nt][1][0], ad, 8192);  T256_TR(Bj[nt][1][1], ad, 8192 + 1024);
+            } else {
+                T256_TR(Bj[nt][0][0], ad, 16384);        T256_TR(Bj[nt][0][1], ad, 16384 + 1024);
+                T256_TR(Bj[nt][1][0], ad, 16384 + 8192); T256_TR(Bj[nt][1][1], ad, 16384 + 8192 + 1024);
+            }
+        }
+    };
+#undef T256_TR
+    auto join = [](const s16x4 lo, const s16x4 hi) -> bf16x8 {
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto mma = [&](f32x4 (&c)[4][2], const s16x4 (&Bj)[2][2][2]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    c[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(Ar[mt][s_][0], Ar[mt][s_][1]), join(Bj[nt][s_][0], Bj[nt][s_][1]), c[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    T256_STAMP(1)
+    if (nk > 0)
+        t256_kloop(nk, wr, issueA, issueB, advance, readA,
+                       [&](const int which, const int buf, const int h) { if (which == 0) readB(B0r, buf, h); else readB(B1r, buf, h); },
+                       [&](const int i, const int j) { if (j == 0) mma(acc[i][0], B0r); else mma(acc[i][1], B1r); });
+
+    T256_STAMP(2)
+    T256_STAMP(3)
+    // ---------------- the partial tile to its slab: rows n, 256-byte segments of J (through the wave's own 16 KB of LDS, as conv_tile256)
+    float* const stg = reinterpret_cast<float*>(lds + wave * 16384);
+    float* const slab = p.slabs + size_t(split) * p.N * p.K;
+    const int chunk = lane & 15, lrow = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -276,79 +576,30 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int bloc
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         stg[(mt * 16 + lrow * 4 + r) * 64 + j * 32 + nt * 16 + (lane & 15)] = acc[i][j][mt][nt][r];
-        const int mbase = m0 + i * 128 + wr * 64;
-        int m = mbase + lrow;
-        const int mc = m < p.M ? m : p.M - 1;
-        int b = mc / p.OHW;
-        const int r0 = mc - b * p.OHW;
-        int oh = r0 / p.OW, ow = r0 - oh * p.OW;
-        const int fb = (mbase < p.M ? mbase : p.M - 1) / p.OHW;          // (fused: one sample per 128-row half, host: OH*OW % 128 == 0)
-        f32x4 fm = {0.f, 0.f, 0.f, 0.f}, fr = {1.f, 1.f, 1.f, 1.f}, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-        if (fused && n_ok) {
-            fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(fb) * p.N + n);
-            fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(fb) * p.N + n);
-        }
+        float* dst = slab + size_t(n0 + i * 128 + wr * 64 + lrow) * p.K + j0 + wc * 64 + chunk * 4;
 #pragma unroll 4
-        for (int pass = 0; pass < 16; ++pass) {
-            if (m < p.M && n_ok) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pass * 4 + lrow) * 64 + chunk * 4);
-                v += bv;
-                const int oidx = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n;
-                if (p.out16) {
-                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(p.out) + oidx) = __builtin_convertvector(v, bf16x4_t);
-                } else {
-                    *reinterpret_cast<f32x4*>(p.out + oidx) = v;
-                }
-                if (fused) {
-                    const size_t yidx = size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n;
-                    f32x4 y4;
-                    if (p.f_y16) {
-                        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                        y4 = __builtin_convertvector(*reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const unsigned short*>(p.f_y) + yidx), f32x4);
-                    } else {
-                        y4 = *reinterpret_cast<const f32x4*>(p.f_y + yidx);
-                    }
-                    const f32x4 z = (y4 - fm) * fr;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float gz = z[q] > 0.f ? v[q] : v[q] * fneg;
-                        s1[q] += gz;
-                        s2[q] += gz * z[q];
-                    }
-                }
-            }
-            m += 4;
-            ow += 4;
-            while (ow >= p.OW) { ow -= p.OW; ++oh; }
-            while (oh >= OH) { oh -= OH; ++b; }
-        }
-        if (fused) {
-            // first pass of the consumer layer's instance-norm backward: this wave's 64 rows, then the two waves of a 128-row chunk
-            // (wr = 0, 1) join through LDS in a fixed order.  All of a wave's staging reads are done (same wave, program order).
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s1[q] += __shfl_xor(s1[q], 16, 64);
-                s2[q] += __shfl_xor(s2[q], 16, 64);
-                s1[q] += __shfl_xor(s1[q], 32, 64);
-                s2[q] += __shfl_xor(s2[q], 32, 64);
-            }
-            t256_bar();                                             // (uniform: `fused` is a launch constant) every wave's staging reads are done
-            f32x4* const red = reinterpret_cast<f32x4*>(lds);       // 8 waves x 16 lanes x 2 x 16 B = 4 KB
-            if (lane < 16) {
-                red[(wave * 16 + chunk) * 2] = s1;
-                red[(wave * 16 + chunk) * 2 + 1] = s2;
-            }
-            t256_bar();
-            if (wr == 0 && lane < 16 && n_ok && mbase < p.M) {
-                const f32x4 t1 = s1 + red[((wave + 4) * 16 + chunk) * 2], t2 = s2 + red[((wave + 4) * 16 + chunk) * 2 + 1];
-                float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((m0 + i * 128 - fb * p.OHW) >> 7)) * 2 * p.N + n;
-                *reinterpret_cast<f32x4*>(pp) = t1;
-                *reinterpret_cast<f32x4*>(pp + p.N) = t2;
-            }
-            t256_bar();
-        }
+        for (int pass = 0; pass < 16; ++pass)
+            *reinterpret_cast<f32x4*>(dst + size_t(pass * 4) * p.K) = *reinterpret_cast<const f32x4*>(stg + (pass * 4 + lrow) * 64 + chunk * 4);
     }
+#ifdef NG_DIAG256
+    T256_STAMP(4)
+    if (lane == 0 && p.dbg != nullptr) {
+        unsigned long long* o = p.dbg + (size_t(unit) * 8 + wave) * 7;
+        for (int q_ = 0; q_ < 5; ++q_) o[q_] = ng_t[q_];
+        o[5] = ng_r0;
+        o[6] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
+// whether wgrad_tile256 covers a problem (host)
+inline bool wgrad_tile256_ok(const WgradParams& p) {
+    if (!(p.prec == 1 && p.pq_bf16 && p.nplanes == 1)) return false;
+    if (p.N % 256 != 0 || p.K % 256 != 0 || p.run % 8 != 0) return false;
+    if (!((p.OW % 64 == 0) || (p.OW <= 64 && 64 % p.OW == 0)) || p.OHW % 64 != 0 || p.rows_per_split % 64 != 0) return false;
+    for (int t = 0; t < p.ntaps; ++t)
+        if (p.tap_off[t] < 0) return false;
+    return p.fast32_bytes != 0;
 }
 
 // whether the 256-wide tile covers a problem (host): both operands stored as bf16, whole 64-channel slices, whole 256-column tiles,

@@ -582,6 +582,8 @@ struct WgradParams {
     int pq_bf16;               // p and q point to bf16 twins (bf16 operand mode, N > 64)
     int nplanes;               // independent problems of identical geometry in one grid (Winograd-domain weight gradient: 16)
     long long p_plane, q_plane;   // floats between consecutive planes of p / q; slabs are [plane][split][N][K]
+    unsigned long long* dbg;   // diagnostic build only
+    int fast32_bytes;          // both twins span < 4 GB as bf16 (32-bit byte offsets)
     int fast32;                // buffers < 4 GB, taps at non-negative offsets, OW / M / split length multiples of the K-step (32 pixels; 64 for bf16 twins): the scalar-walk loader applies
 };
 
@@ -1392,10 +1394,12 @@ inline int build_wgrad_params(const nirgan_wgrad_desc* d, WgradParams& p) {
     NG_REQUIRE(d->slab_elems >= int64_t(p.nplanes) * d->nsplit * d->N * K, "wgrad_igemm: slab_elems too small for %d planes", p.nplanes);
     NG_REQUIRE(d->p_elems >= (p.nplanes - 1) * d->p_plane + int64_t(d->B) * d->p_hp * d->p_wp * d->p_cs && d->q_elems >= (p.nplanes - 1) * d->q_plane + int64_t(d->B) * d->q_hp * d->q_wp * d->q_cs, "wgrad_igemm: p/q too small for the planes");
     p.pq_bf16 = d->pq_bf16 ? 1 : 0;
+    p.dbg = nullptr;
     {
         bool taps_ok = true;
         for (int t = 0; t < d->ntaps; ++t) taps_ok = taps_ok && (d->tap_dh[t] * p.q_row + d->tap_dw[t] * d->q_cs >= 0);
         const int ms = d->pq_bf16 ? 64 : 32, es = d->pq_bf16 ? 2 : 4;          // pixels per K-step, bytes per stored element
+        p.fast32_bytes = (d->p_elems * es < (int64_t(1) << 32) && d->q_elems * es < (int64_t(1) << 32)) ? 1 : 0;
         p.fast32 = (taps_ok && d->OW % ms == 0 && p.M % ms == 0 && d->rows_per_split % ms == 0
                     && d->p_elems * es < (int64_t(1) << 32) && d->q_elems * es < (int64_t(1) << 32)) ? 1 : 0;
     }

@@ -11,6 +11,7 @@
 //   The split partial sums go to slabs (plain stores) and are summed by reduce_rows in a fixed
 //   order, so gradients are bitwise reproducible run to run.
 #include "igemm_tiles.h"
+#include "igemm_tile256.h"
 #include <cstdlib>
 
 namespace {
@@ -48,6 +49,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const ng::ConvP
         ng::wgrad_tile16(wp, int(blockIdx.x) - conv_blocks, st0, st1);
     else
         ng::wgrad_tile<128, PREC>(wp, int(blockIdx.x) - conv_blocks, st0, st1);
+}
+
+// The bf16 operand mode's 256-wide tiles (igemm_tile256.h) as PERSISTENT workgroups, one per CU.  A weight gradient on its own: every
+// workgroup walks units (256 x 256 x one split).  The fused launch: the first conv_wgs workgroups walk the data-gradient tiles, the
+// others the weight-gradient units -- the host divides the CUs so that both kinds finish together (pair256_split): a data gradient over
+// the padded extent of the benchmark layer has 273 tiles, 1.07 rounds of the chip on its own.
+// Between two items of a workgroup one barrier: every wave has read its epilogue staging back before the next item's LDS-DMA lands.
+__global__ __launch_bounds__(512, 2) void wgrad_igemm256_kernel(const ng::WgradParams p, const int units) {
+    __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
+    bool again = false;
+    for (int u = ng_xcd_remap(blockIdx.x, gridDim.x); u < units; u += gridDim.x) {
+        if (again) ng::t256_bar();
+        ng::wgrad_tile256(p, u, lds);
+        again = true;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_pair256_kernel(const ng::ConvParams cp, const ng::WgradParams wp, const int conv_wgs,
+                                                                     const int conv_tiles, const int wgrad_units) {
+    __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
+    bool again = false;
+    if (int(blockIdx.x) < conv_wgs) {
+        for (int t = ng_xcd_remap(blockIdx.x, conv_wgs); t < conv_tiles; t += conv_wgs) {
+            if (again) ng::t256_bar();
+            ng::conv_tile256(cp, t, lds);
+            again = true;
+        }
+    } else {
+        const int y = int(gridDim.x) - conv_wgs;
+        for (int u = ng_xcd_remap(int(blockIdx.x) - conv_wgs, y); u < wgrad_units; u += y) {
+            if (again) ng::t256_bar();
+            ng::wgrad_tile256(wp, u, lds);
+            again = true;
+        }
+    }
 }
 
 // grid (K/256, N): 64 lanes x float4 cover 256 consecutive k of one row; the 4 waves of the block take the
@@ -145,11 +181,42 @@ __global__ __launch_bounds__(256) void pack_rows_batch_kernel(const long long* _
 }  // namespace
 
 
+// CUs of the current device (the persistent launches start one workgroup per CU)
+static int ng_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+// Workgroups of the fused 256-wide launch that walk the data-gradient tiles (the rest walk weight-gradient units): the division that
+// minimises the longer of the two walks, an item costing its K-tiles + about 8 K-tiles' worth of prologue and epilogue.  Mirrored by
+// nirgan_hip/geometry.py::pair256_plan, which chooses the number of splits with the same cost.
+static int pair256_split(const int G, const int conv_tiles, const int conv_nk, const int units, const int unit_nk) {
+    const long long E = 8;
+    int best = 1;
+    long long best_cost = -1;
+    for (int x = 1; x < G; ++x) {
+        const long long c = (long long)((conv_tiles + x - 1) / x) * (conv_nk + E), w = (long long)((units + (G - x) - 1) / (G - x)) * (unit_nk + E);
+        const long long cost = c > w ? c : w;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = x; }
+    }
+    return best;
+}
+
 extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     ng::WgradParams p;
     const int rc = ng::build_wgrad_params(d, p);
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->algo != NIRGAN_WGRAD_TILE128 && ng::wgrad_tile256_ok(p)) {
+        const int units = (p.N >> 8) * (p.K >> 8) * p.nsplit, G = ng_cu_count();
+        hipLaunchKernelGGL(wgrad_igemm256_kernel, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
+        return nirgan_check_launch("wgrad_igemm (256 x 256 tile)");
+    }
     const dim3 grid(p.ntiles_n * p.ntiles_k * p.nsplit * p.nplanes);
     // matrix-form problems (the transform-domain weight gradient of a Winograd layer launched on its own) with more units than resident
     // workgroups: persistent workgroups with the epilogue folded into the next unit's K loop (igemm_tiles.h::wgrad_persist)
@@ -182,9 +249,15 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
         rc = nirgan_conv_igemm(c, stream);
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
+    NG_REQUIRE(cp.prec == wp.prec, "conv_wgrad_pair: both halves must use the same precision");
+    if (cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp) && ng::wgrad_tile256_ok(wp)) {
+        const int conv_tiles = ((cp.M + 255) >> 8) * (cp.N >> 8), units = (wp.N >> 8) * (wp.K >> 8) * wp.nsplit, G = ng_cu_count();
+        const int conv_wgs = pair256_split(G, conv_tiles, cp.ntaps * (cp.run >> 6), units, wp.rows_per_split >> 6);
+        hipLaunchKernelGGL(conv_wgrad_pair256_kernel, dim3(G), dim3(512), 0, static_cast<hipStream_t>(stream), cp, wp, conv_wgs, conv_tiles, units);
+        return nirgan_check_launch("conv_wgrad_pair (256 x 256 tiles)");
+    }
     const int conv_blocks = cp.mtiles * cp.ntiles;
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit;
-    NG_REQUIRE(cp.prec == wp.prec, "conv_wgrad_pair: both halves must use the same precision");
     const dim3 grid(conv_blocks + wgrad_blocks);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (cp.prec == 0) hipLaunchKernelGGL(conv_wgrad_pair_kernel<0>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
@@ -194,6 +267,24 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     else if (cp.prec == 1) hipLaunchKernelGGL(conv_wgrad_pair_kernel<1>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
     else hipLaunchKernelGGL(conv_wgrad_pair_kernel<2>, grid, dim3(256), 0, st, cp, wp, conv_blocks);
     return nirgan_check_launch("conv_wgrad_pair");
+}
+
+extern "C" const char* nirgan_wgrad_kernel_name(const nirgan_wgrad_desc* d) {
+    ng::WgradParams p;
+    if (ng::build_wgrad_params(d, p) != NIRGAN_OK) return nullptr;
+    if (d->algo != NIRGAN_WGRAD_TILE128 && ng::wgrad_tile256_ok(p)) return "wgrad_igemm256_kernel";
+    if (ng::wgrad_persist_ok(p) && ng::wgrad_matrix_form(p) && p.ntiles_n * p.ntiles_k * p.nsplit * p.nplanes > 512 && d->algo != NIRGAN_WGRAD_ONE_UNIT) return "wgrad_persist_kernel";
+    if (p.pq_bf16) return "wgrad_igemm16_kernel";
+    return d->N > 64 ? "wgrad_igemm_kernel<128>" : "wgrad_igemm_kernel<64>";
+}
+
+extern "C" const char* nirgan_conv_wgrad_pair_kernel_name(const nirgan_conv_desc* c, const nirgan_wgrad_desc* w) {
+    ng::ConvParams cp;
+    ng::WgradParams wp;
+    if (ng::build_conv_params(c, cp) != NIRGAN_OK || ng::build_wgrad_params(w, wp) != NIRGAN_OK) return nullptr;
+    if (c->N <= 64 || w->N <= 64 || c->ksplit > 1 || (wp.pq_bf16 && !cp.in_bf16)) return "(two launches)";
+    if (cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp) && ng::wgrad_tile256_ok(wp)) return "conv_wgrad_pair256_kernel";
+    return "conv_wgrad_pair_kernel";
 }
 
 extern "C" int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,

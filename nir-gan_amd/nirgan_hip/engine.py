@@ -302,6 +302,7 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.B, d.OH, d.OW, d.N = inp.B, OH, OW, N
     d.zero_page = ctx.zero_page.data_ptr()
     d.precision = ctx.precision
+    d.algo = 0 if OPT.tile256 else L.CONV_TILE128
     ctx.keep.append(d)
     if plan is not None:
         M = inp.B * OH * OW
@@ -332,6 +333,13 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     twins = (ctx.precision == 1 and p.t16 is not None and q.t16 is not None and N > 64 and N % 8 == 0 and taps.run % 8 == 0
              and (pair_with is None or pair_with.in_bf16))
     nsplit, rows = G.wgrad_split(M, tiles, target, 64 if twins else 32)
+    if twins and OPT.tile256 and G.wgrad256_ok(M, OH, OW, N, K, taps.run):
+        # the 256-wide persistent tiles (csrc/igemm_tile256.h): splits sized so that the data-gradient and weight-gradient workgroups
+        # of the fused launch finish together (the library divides the CUs with the same cost figure)
+        c = pair_with
+        fused = c is not None and c.in_bf16 and c.N % 256 == 0 and c.run % 64 == 0 and -(-(c.B * c.OH * c.OW) // 256) * (c.N // 256) >= 128
+        nsplit, rows = (G.pair256_plan(M, (N // 256) * (K // 256), -(-(c.B * c.OH * c.OW) // 256) * (c.N // 256), c.ntaps * (c.run // 64)) if fused
+                        else G.pair256_plan(M, (N // 256) * (K // 256)))
     need = nsplit * N * K
     slabs = slabs_pool.get(need) if slabs_pool is not None else ctx.zeros(need)
     ctx.keep.append(slabs)
@@ -347,6 +355,8 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
     d.zero_page = ctx.zero_page.data_ptr()
     d.precision = ctx.precision
+    if not OPT.tile256:
+        d.algo = L.WGRAD_TILE128
     ctx.keep.append(d)
     imap = ctx.i32(spec.index_map)
     if pair_with is not None:

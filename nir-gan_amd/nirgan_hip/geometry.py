@@ -196,3 +196,34 @@ def wgrad_split(M: int, tiles: int, target_blocks: int = 1024, row_mult: int = 3
     rows = -(-rows // row_mult) * row_mult           # whole K-steps per split (64 pixels when both operands are bf16 twins)
     nsplit = -(-M // rows)
     return nsplit, rows
+
+
+CUS = 256          # MI355X: the persistent 256-wide launches start one workgroup per CU (csrc/igemm_wgrad.hip::ng_cu_count)
+T256_FIXED = 8     # prologue + epilogue of one 256 x 256 item, in K-tiles (csrc/igemm_wgrad.hip::pair256_split uses the same figure)
+
+
+def wgrad256_ok(M: int, OH: int, OW: int, N: int, K: int, run: int) -> bool:
+    """The shapes csrc/igemm_tile256.h::wgrad_tile256_ok accepts (both operands bf16 twins is the caller's business)."""
+    return (N % 256 == 0 and K % 256 == 0 and run % 8 == 0 and (OW % 64 == 0 or (OW <= 64 and 64 % OW == 0))
+            and (OH * OW) % 64 == 0 and M % 64 == 0)
+
+
+def pair256_plan(M: int, units_per_split: int, conv_tiles: int = 0, conv_nk: int = 0, cus: int = CUS) -> Tuple[int, int]:
+    """(nsplit, rows_per_split) of a weight gradient on the 256-wide persistent tiles, alone (conv_tiles = 0) or fused with the data
+    gradient's conv_tiles tiles of conv_nk K-tiles each: the split count that minimises the longer walk -- data-gradient workgroups
+    ceil(conv_tiles / x) items, weight-gradient workgroups ceil(units / (cus - x)) units of M / 64 / nsplit K-tiles, every item + the
+    fixed part -- and, among equals, the fewest slabs."""
+    kt = M // 64
+    best = None
+    for ns in range(1, min(kt, 64) + 1):
+        per = -(-kt // ns)
+        if (ns - 1) * per >= kt:
+            continue                                  # an empty last split
+        units = units_per_split * ns
+        if conv_tiles:
+            cost = min(max(-(-conv_tiles // x) * (conv_nk + T256_FIXED), -(-units // (cus - x)) * (per + T256_FIXED)) for x in range(1, cus))
+        else:
+            cost = -(-units // cus) * (per + T256_FIXED)
+        if best is None or cost < best[0]:
+            best = (cost, ns, per * 64)
+    return best[1], best[2]

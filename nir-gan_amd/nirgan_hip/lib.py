@@ -144,7 +144,7 @@ class Wino6Desc(C.Structure):
 
 W6_ONE_TILE, W6_PERSIST16, W6_DIRECT_TILE = 1, 2, 3      # nirgan_wino6_desc.algo
 W6_PATCH_PER_THREAD, W6_PATCH_PER_LANES = 16, 17                                 # nirgan_wino6_desc.algo for the input transforms (A/B)
-WGRAD_ONE_UNIT = 1                                       # nirgan_wgrad_desc.algo
+WGRAD_ONE_UNIT, WGRAD_TILE128 = 1, 2                     # nirgan_wgrad_desc.algo
 CONV_TILE128 = 1                                         # nirgan_conv_desc.algo
 
 
@@ -166,6 +166,9 @@ PROTOTYPES = {
     "nirgan_wgrad_igemm": (i32, [C.POINTER(WgradDesc), fp]),
     "nirgan_conv_igemm_group": (i32, [C.POINTER(C.POINTER(ConvDesc)), i32, fp]),
     "nirgan_conv_wgrad_pair": (i32, [C.POINTER(ConvDesc), C.POINTER(WgradDesc), fp]),
+    "nirgan_conv_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc)]),
+    "nirgan_wgrad_kernel_name": (C.c_char_p, [C.POINTER(WgradDesc)]),
+    "nirgan_conv_wgrad_pair_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc), C.POINTER(WgradDesc)]),
     "nirgan_reduce_rows": (i32, [fp, i32, i32, i32, fp, fp, i64, i32, i32, fp]),
     "nirgan_pack_rows": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_bf16": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),

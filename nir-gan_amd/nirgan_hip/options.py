@@ -45,6 +45,8 @@ class Options:
     bf16_twin_only: bool = True
     # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform
     fold_apply: bool = True
+    # bf16 operand mode: the 256 x 256 x 64 eight-phase tiles (csrc/igemm_tile256.h) where they apply; False = the 128-row tiles (A/B)
+    tile256: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
     endconv_direct: bool = True
 

@@ -471,6 +471,15 @@ class EmuBackend:
         arr(d.M, nplanes * T * d.K)[:] = np.einsum("ftc,fkc->ftk", V, U).reshape(-1).astype(np.float32)
         return 0
 
+    def nirgan_conv_kernel_name(self, ref):
+        return b"emulated_conv"
+
+    def nirgan_wgrad_kernel_name(self, ref):
+        return b"emulated_wgrad"
+
+    def nirgan_conv_wgrad_pair_kernel_name(self, cref, wref):
+        return b"emulated_pair"
+
     def nirgan_wino6_gemm_kernel_name(self, ref):
         return b"emulated_wino6_gemm"
 

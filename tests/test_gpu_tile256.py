@@ -73,7 +73,7 @@ def test_tile256_against_the_128_row_tile_and_float64(case):
     torch.cuda.synchronize()
     a, r = y256.t.float(), y128.t.float()
     assert torch.isfinite(a).all(), "rows or columns left unwritten"
-    tol = 2 ** -8 if out16 else 2e-5            # (two bf16 roundings of sums that differ in the last fp32 bits may land one bf16 ulp apart)
+    tol = 2 ** -7 if out16 else 2e-5            # (two bf16 roundings of sums that differ in the last fp32 bits may land one bf16 ulp apart)
     assert _rel(a, r) <= tol, f"256-row tile vs 128-row tile: {_rel(a, r):.3e}"
     if B * H * W <= 40000:
         p = (k - 1) // 2 if k != 4 else 1
@@ -81,7 +81,7 @@ def test_tile256_against_the_128_row_tile_and_float64(case):
         ref = torch.nn.functional.conv2d(xi, w.to(torch.bfloat16).double(), None if b is None else b.double()).permute(0, 2, 3, 1)
         if out16:
             ref = ref.float().to(torch.bfloat16)
-        assert _rel(a, ref.float()) <= (2 ** -8 if out16 else 1e-5), f"256-row tile vs float64 conv2d on the rounded operands: {_rel(a, ref.float()):.3e}"
+        assert _rel(a, ref.float()) <= (2 ** -7 if out16 else 1e-5), f"256-row tile vs float64 conv2d on the rounded operands: {_rel(a, ref.float()):.3e}"
 
 
 def test_tile256_repeated_launches_agree_bitwise():
@@ -98,3 +98,127 @@ def test_tile256_repeated_launches_agree_bitwise():
             L.call("nirgan_conv_igemm", C.byref(d256), None)
             bad += (y256.t != first).any().to(torch.int64)          # (device-side: the launches stay back to back)
         assert int(bad.item()) == 0, f"{case}: {int(bad.item())} of 200 launches differ"
+
+
+# ------------------------------------------------------------------ weight gradient and the fused launch on the 256-wide tiles
+def _wgrad_problem(B, H, W, Cin, Cout, k, seed=0):
+    """dY (zero halo k - 1) and X (halo p) as bf16 twins, the convolution's weight-gradient descriptors for the default kernels and for
+    the 128-row ones, each with its own split and gradient tensor."""
+    from nirgan_hip.engine import emit_wgrad
+    ctx = Ctx(DEV, "bf16")
+    g = torch.Generator().manual_seed(seed)
+    p = (k - 1) // 2 if k != 4 else 1
+    OH, OW = H + 2 * p - k + 1, W + 2 * p - k + 1
+    x = Halo(ctx, B, H, W, Cin, p, twin=True)
+    x.t.copy_(torch.randn(x.t.shape, generator=g).to(DEV))
+    x.t16.copy_(x.t.to(torch.bfloat16))
+    dy = Halo(ctx, B, OH, OW, Cout, k - 1, twin=True)
+    dy.interior().copy_(torch.randn(B, OH, OW, Cout, generator=g).to(DEV))
+    dy.t16.copy_(dy.t.to(torch.bfloat16))
+    return ctx, x, dy, (OH, OW, p)
+
+
+def _emit_wgrad(ctx, x, dy, geo, Cin, Cout, k, tile128, pair_with=None):
+    from nirgan_hip.engine import emit_wgrad
+    from nirgan_hip.options import OPT
+    OH, OW, p = geo
+    gw = ctx.zeros(Cout, Cin, k, k)
+    plan = Plan(ctx)
+    OPT.tile256 = not tile128
+    try:
+        d = emit_wgrad(plan, ctx, dy, x, G.conv_fwd_taps(k, Cin), G.conv_fwd_pack(Cout, Cin, k), gw, N=Cout, OH=OH, OW=OW,
+                       p_oh=dy.pad, p_ow=dy.pad, q_oh=x.pad - p, q_ow=x.pad - p, pair_with=pair_with)
+    finally:
+        OPT.reset()
+    assert d.pq_bf16 == 1
+    return plan, d, gw
+
+
+WCASES = [
+    # B, H, W, Cin, Cout, k
+    (16, 64, 64, 256, 256, 3),       # the benchmark's residual-block layer: 9 column tiles x the planned splits
+    (4, 128, 128, 256, 256, 3),      # the 512-pixel bucket's maps (OW = 128: two K-tiles per image row)
+    (8, 32, 32, 256, 256, 3),        # OW = 32: a K-tile is two image rows
+    (6, 64, 64, 128, 256, 3),        # run = 128: a column tile spans two taps (and half of the ninth)  -> K = 1152, not a multiple of 256: 128-row tiles
+    (3, 64, 64, 256, 512, 1),        # two row tiles, one tap
+]
+
+
+@pytest.mark.parametrize("case", WCASES)
+def test_wgrad256_against_the_128_row_tile_and_float64(case):
+    B, H, W, Cin, Cout, k = case
+    ctx, x, dy, geo = _wgrad_problem(*case)
+    p256, d256, g256 = _emit_wgrad(ctx, x, dy, geo, Cin, Cout, k, False)
+    p128, d128, g128 = _emit_wgrad(ctx, x, dy, geo, Cin, Cout, k, True)
+    eligible = (9 if k == 3 else 1) * Cin % 256 == 0
+    assert (d256.rows_per_split % 64 == 0) and d128.algo == L.WGRAD_TILE128 and d256.algo == 0
+    p256.run()
+    p128.run()
+    torch.cuda.synchronize()
+    assert _rel(g256, g128) <= 2e-5, f"256-wide tile vs 128-row tile: {_rel(g256, g128):.3e}"
+    if eligible and case == WCASES[0]:
+        assert (d256.nsplit, d256.rows_per_split) == G.pair256_plan(B * H * W, 9), "the 256-wide plan chooses its own split"
+    if B * H * W <= 40000:
+        OH, OW, p = geo
+        xi = x.t16.double().permute(0, 3, 1, 2)
+        gi = dy.t16.double()[:, dy.pad:dy.pad + OH, dy.pad:dy.pad + OW].permute(0, 3, 1, 2)
+        ref = torch.nn.grad.conv2d_weight(xi, (Cout, Cin, k, k), gi)
+        assert _rel(g256, ref.float()) <= 1e-5, f"256-wide tile vs float64 on the rounded operands: {_rel(g256, ref.float()):.3e}"
+
+
+@pytest.mark.parametrize("case", [(16, 64, 64, 256, 256, 3, False), (16, 64, 64, 256, 256, 3, True), (8, 32, 32, 256, 256, 3, True), (5, 64, 128, 256, 256, 3, False)])
+def test_pair256_equals_separate_launches(case):
+    """nirgan_conv_wgrad_pair on the persistent 256-wide tiles (data-gradient tiles and weight-gradient units on disjoint sets of CUs) against
+    the same two descriptors launched on the 128-row tiles: data gradient over the padded extent (fp32 or bf16 store) and the reduced
+    weight gradient."""
+    from nirgan_hip.options import OPT
+    B, H, W, Cin, Cout, k, g16 = case
+    ctx, x, dy, geo = _wgrad_problem(B, H, W, Cin, Cout, k, seed=1)
+    w = (torch.randn(Cout, Cin, k, k, generator=torch.Generator().manual_seed(2)) * 0.05).to(DEV)
+    hw = [(a, b) for a in range(k) for b in range(k)]
+    wd = _packed16(ctx, w, G.conv_dgrad_pack(Cout, Cin, k, hw))
+    res = []
+    for tile128 in (False, True):
+        gx = Halo(ctx, B, H, W, Cin, 1, bf16=g16)
+        gx.t.fill_(float("nan"))
+        OPT.tile256 = not tile128
+        try:
+            cd = emit_conv(None, ctx, dy, G.conv_dgrad_s1_taps(k, Cout), wd, None, gx, N=Cin, OH=gx.hp, OW=gx.wp)
+        finally:
+            OPT.reset()
+        plan, d, gw = _emit_wgrad(ctx, x, dy, geo, Cin, Cout, k, tile128, pair_with=cd)
+        assert [n for n, _ in plan.ops] == ["nirgan_conv_wgrad_pair", "nirgan_reduce_rows"]
+        plan.run()
+        res.append((gx, gw, d))
+    torch.cuda.synchronize()
+    (gx256, gw256, d256), (gx128, gw128, d128) = res
+    assert torch.isfinite(gx256.t.float()).all()
+    assert _rel(gx256.t.float(), gx128.t.float()) <= (2 ** -7 if g16 else 2e-5)
+    assert _rel(gw256, gw128) <= 2e-5
+    xi = x.t16.double().permute(0, 3, 1, 2)
+    OH, OW, p = geo
+    if B * H * W <= 40000:
+        gi = dy.t16.double()[:, dy.pad:dy.pad + OH, dy.pad:dy.pad + OW].permute(0, 3, 1, 2)
+        assert _rel(gw256, torch.nn.grad.conv2d_weight(xi, (Cout, Cin, k, k), gi).float()) <= 1e-5
+
+
+def test_pair256_repeated_launches_agree_bitwise():
+    """Race screen of the persistent fused launch (two items per data-gradient workgroup, the barrier between items, the transposing
+    reads issued from inline asm): 150 launches, data gradient and slabs bitwise equal to the first."""
+    from nirgan_hip.options import OPT
+    B, H, W, Cin, Cout, k = 16, 64, 64, 256, 256, 3
+    ctx, x, dy, geo = _wgrad_problem(B, H, W, Cin, Cout, k, seed=5)
+    w = (torch.randn(Cout, Cin, k, k, generator=torch.Generator().manual_seed(2)) * 0.05).to(DEV)
+    wd = _packed16(ctx, w, G.conv_dgrad_pack(Cout, Cin, k, [(a, b) for a in range(k) for b in range(k)]))
+    gx = Halo(ctx, B, H, W, Cin, 1)
+    cd = emit_conv(None, ctx, dy, G.conv_dgrad_s1_taps(k, Cout), wd, None, gx, N=Cin, OH=gx.hp, OW=gx.wp)
+    plan, d, gw = _emit_wgrad(ctx, x, dy, geo, Cin, Cout, k, False, pair_with=cd)
+    plan.run()
+    torch.cuda.synchronize()
+    first_x, first_w = gx.t.clone(), gw.clone()
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    for it in range(150):
+        gx.t.fill_(0)
+        plan.run()
+        bad += (gx.t != first_x).any().to(torch.int64) + (gw != first_w).any().to(torch.int64)
+    assert int(bad.item()) == 0, f"{int(bad.item())} differing results in 150 launches"
