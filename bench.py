@@ -65,6 +65,21 @@ def w6_tiles(d):
     return d.B * (-(-d.H // mo)) * (-(-d.W // mo))
 
 
+def op_direct_flops(name, args):
+    """DIRECT-convolution FLOPs of a Winograd launch (SURVEY 8d's count for the layer: 2 * pixels * C * K * taps), None for launches whose
+    executed count is the direct count already.  `algorithmic_over_peak` of a roofline entry is built from it: what the launch is worth in
+    the reference's arithmetic, next to the executed `frac`."""
+    if name not in ("nirgan_wino6_gemm", "nirgan_wino6_gemm_wgrad_pair"):
+        return None
+    d = args[0]._obj
+    taps = 16 if d.r == 4 else 9
+    fl = 2.0 * d.B * d.H * d.W * d.C * d.K * taps                      # the plane GEMMs' layer over the extent the descriptor covers
+    if name == "nirgan_wino6_gemm_wgrad_pair":                         # + the layer's weight gradient over the forward's output extent
+        shrink = 3 if d.r == 4 else 2
+        fl += 2.0 * d.B * (d.H - shrink) * (d.W - shrink) * d.C * d.K * taps
+    return fl
+
+
 def op_mfma_work(name, args):
     """(kernel label, EXECUTED matrix-pipe FLOPs, algorithmic HBM bytes or None) of one plan op, from its descriptor(s); None for
     ops that do not run on the matrix pipe.  Labels of the Winograd launches come from the library itself
@@ -124,7 +139,7 @@ PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.
 def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_igemm256_kernel", "conv_group_kernel<128>", "wgrad_igemm_kernel<128>", "wgrad_igemm256_kernel", "conv_wgrad_pair", "wino6_")):
     """EXECUTED FLOPs of one step's launches of the big MFMA kernels, and the op indices to bracket with HIP events."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
-    kinds, algo_bytes = {}, {}
+    kinds, algo_bytes, direct = {}, {}, {}
     for pl in plans:
         pl.probe_idx, pl.probe_events = {}, []
         for i, (name, args) in enumerate(pl.ops):
@@ -137,10 +152,13 @@ def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_igemm256_kernel",
             kinds.setdefault(k, [0.0, 0])
             kinds[k][0] += fl
             kinds[k][1] += 1
+            dfl = op_direct_flops(name, args)
+            direct[k] = direct.get(k, 0.0) + (fl if dfl is None else dfl)
             if by is not None:
                 algo_bytes[k] = algo_bytes.get(k, 0.0) + by
             pl.probe_idx[i] = k
     mfma_probes.algo_bytes = algo_bytes
+    mfma_probes.direct = direct
     return kinds, plans
 
 
@@ -597,7 +615,10 @@ def main():
                 by = (mfma_probes.algo_bytes[k] / nlaunch) if k in getattr(mfma_probes, "algo_bytes", {}) else None
                 gbps = None if by is None else by / (avg_ms * 1e-3) / 1e9
                 roofs.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAKS[a.precision], 1), "unit": "TFLOP/s",
-                              "frac": round(ach / PEAKS[a.precision], 4), "traffic": None, "kernel": k,
+                              "frac": round(ach / PEAKS[a.precision], 4),
+                              # the same launches priced by the DIRECT convolution's FLOPs (the Winograd layers execute 64/324 and 49/256 of them)
+                              "algorithmic_over_peak": round(getattr(mfma_probes, "direct", {}).get(k, flops) / nlaunch / (avg_ms * 1e-3) / 1e12 / PEAKS[a.precision], 4),
+                              "traffic": None, "kernel": k,
                               "launches_per_step": nlaunch, "avg_launch_ms": round(avg_ms, 5),
                               "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
                               "algorithmic_bytes_per_launch": None if by is None else int(by),
@@ -680,6 +701,13 @@ def main():
             out["collective_backend"] = torch.distributed.get_backend()
             out["ms_per_step_by_rank"] = rank_ms
             out["comm_exposed_ms_per_step_by_rank"] = comm_ms
+        else:
+            # one process, no process group: the same fields as the N > 1 line (a scaling table reads them column by column)
+            out["rccl_ranks"] = 0 if a.emulate_cpu else 1
+            out["collective_backend"] = None
+            out["ms_per_step_by_rank"] = [round(ms, 3)]
+            out["comm_exposed_ms_per_step_by_rank"] = [0.0]
+        if reducer is not None:
             out["comm"] = ("two gradient buckets per network (tail started inside the backward plan, head after it); exposed = launch-stream "
                            "time spent waiting for the collectives before each Adam step (HIP events)")
         if dp_check is not None:

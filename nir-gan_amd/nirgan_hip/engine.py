@@ -98,6 +98,9 @@ class Halo:
         # (emit_conv / emit_wgrad, through operand_ptr()); every other use goes through `.ptr` and pins the fp32 tensor.  A twinned buffer
         # that is never pinned and whose readers all take the twin is stored as bf16 only (drop_dead_fp32_stores).
         self.readers, self.pinned, self.writers, self.fp32_dead = [], False, [], False
+        # set by drop_dead_fp32_stores: the storage decision of this buffer (fp32 + twin, twin only, fp32 only) is taken from the readers
+        # seen so far, so a launch emitted afterwards must not register as a new reader (it would read a tensor nobody maintains)
+        self.finalised = False
 
     @property
     def ptr(self):
@@ -116,6 +119,10 @@ class Halo:
 
     def operand_ptr(self, reader=None):
         """fp32 address for a launch that is twin-aware: `reader` (its descriptor) says later whether it took the twin (reads_twin)."""
+        if self.finalised and (self.fp32_dead or self.t16 is None or reader is None):
+            # after the engine's storage decisions: only a twin-aware reader of a buffer that still has BOTH tensors may come late
+            raise RuntimeError("this buffer's storage was finalised (drop_dead_fp32_stores ran): emit every launch before the engine is "
+                               "finalised, or read it through the tensor that is still maintained")
         if reader is not None:
             self.readers.append(reader)
         return self.t.data_ptr()
@@ -125,6 +132,8 @@ class Halo:
         return self.t.numel()
 
     def interior(self) -> torch.Tensor:
+        if self.fp32_dead:
+            raise RuntimeError("this buffer is stored as bf16 only (drop_dead_fp32_stores ran): its fp32 tensor is not maintained")
         p = self.pad
         return self.t[:, p:p + self.H, p:p + self.W, :]
 
@@ -650,6 +659,9 @@ def drop_dead_fp32_stores(buffers) -> int:
     the twin (reads_twin) -- is stored as bf16 only: its instance-norm writers get out / dy = NULL (168 -> 101 MB per forward launch of a
     64 x 64 x 256 map at bs 16, 235 -> 168 MB per backward launch).  Called once per engine, after all of its plans are built."""
     n = 0
+    buffers = list(buffers)
+    for h in buffers:
+        h.finalised = True
     if not OPT.bf16_twin_only:
         return n
     for h in buffers:
@@ -661,6 +673,7 @@ def drop_dead_fp32_stores(buffers) -> int:
                     w.out_bf16 = None
                 else:
                     w.dy_bf16 = None
+            h.t16 = None              # nobody maintains the twin any more: a later emit_conv / emit_wgrad must not pick it up
             n += 1
             continue
         if h.t16 is None or h.pinned or not h.readers or not h.writers or not all(reads_twin(r) for r in h.readers):

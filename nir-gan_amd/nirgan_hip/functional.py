@@ -27,6 +27,7 @@ def _require_device(t: torch.Tensor, what: str):
 class _Lease:
     def __init__(self, pool: "EnginePool", key, eng):
         self.pool, self.key, self.eng = pool, key, eng
+        self.bound = False          # an autograd node owns this lease: its backward runs the engine's backward plan and releases it
 
     def release(self):
         if self.eng is not None:
@@ -62,7 +63,11 @@ class _ForwardRecord:
     The reference runs the generator forward in BOTH optimizer passes of a batch with unchanged parameters (model/pix2pix.py:
     178-180), which reproduces ``pred`` bit for bit; a second forward on the same tensors with the same parameters re-uses the
     first one's activations instead (and gets a backward-capable graph even when the first pass ran with the generator frozen,
-    as Lightning's toggle_optimizer does).  Dropped by the next forward, by a backward through the lease, by any change."""
+    as Lightning's toggle_optimizer does).  Dropped by the next forward, by a backward through the lease, by any change.
+    A lease is handed to at most ONE autograd node: once a forward has bound it (its graph will run the engine's backward and return
+    the engine to the pool), a further forward on the same tensors runs on a fresh engine -- two backward-capable calls G(x), G(x) give two
+    independent graphs, as with the reference's nn.Module.  Changes are detected through torch's version counters, the same evidence
+    autograd itself uses for its saved tensors: writes that bypass them (``x.data.copy_``, numpy views of the storage) are not seen."""
 
     def __init__(self, rgb, embeds, ver, key, lease):
         self.rgb, self.rgb_v = rgb, rgb._version
@@ -70,7 +75,7 @@ class _ForwardRecord:
         self.ver, self.key, self.lease = ver, key, lease
 
     def matches(self, rgb, embeds, ver, key) -> bool:
-        return (self.lease.eng is not None and rgb is self.rgb and rgb._version == self.rgb_v and embeds is self.embeds
+        return (self.lease.eng is not None and not self.lease.bound and rgb is self.rgb and rgb._version == self.rgb_v and embeds is self.embeds
                 and (embeds is None or embeds._version == self.emb_v) and ver == self.ver and key == self.key)
 
 
@@ -98,6 +103,7 @@ class GeneratorFn(torch.autograd.Function):
         if need_bwd:
             net.__dict__["_fwd_record"] = rec if rec is not None else _ForwardRecord(rgb, embeds, ver, key, lease)
         if wants:
+            lease.bound = True
             ctx.lease, ctx.net, ctx.ver, ctx.has_emb = lease, net, ver, embeds is not None
         return out
 
@@ -108,6 +114,9 @@ class GeneratorFn(torch.autograd.Function):
         if rec is not None and rec.lease is lease:
             net.__dict__["_fwd_record"] = None                          # the engine goes back to the pool below
         eng = lease.eng
+        if eng is None:
+            raise RuntimeError("generator backward: this graph's activations were already consumed by an earlier backward "
+                               "(the engine went back to the pool); call backward once per forward, as with retain_graph=False")
         eng.backward(dpred.contiguous(), version=ctx.ver)
         flat = net._flat()
         # ONE buffer in the flat layout; the per-parameter gradients are views of it.  autograd keeps them as the .grad tensors
@@ -139,6 +148,8 @@ class DiscriminatorFn(torch.autograd.Function):
     def backward(ctx, dout):
         lease, net = ctx.lease, ctx.net
         eng = lease.eng
+        if eng is None:
+            raise RuntimeError("discriminator backward: this graph's activations were already consumed by an earlier backward")
         dout = dout.contiguous()
         flat = net._flat()
         gx = None

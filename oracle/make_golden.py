@@ -476,7 +476,59 @@ def f7(name, L=10):
     print("wrote", name)
 
 
+def to_ns(x):
+    if isinstance(x, dict):
+        return types.SimpleNamespace(**{k: to_ns(v) for k, v in x.items()})
+    return x
+
+
+def f0(name):
+    """configs[0] plumbing: the PARSED key/value tree of the reference's two training configs (configs/config_px2px.yaml,
+    configs/config_px2px_SatCLIP.yaml -- data, not the files' text) and the state_dict key list + shapes of the modules Px2Px_PL builds
+    from each (model/pix2pix.py:18-63: netG through define_G / define_G_inject, netD through define_D, criterionGAN), for the YAML's
+    own netG and for resnet_6blocks (BASELINE.json configs[0] / configs[1]).  Px2Px_PL itself cannot be instantiated here (Lightning is
+    absent) and ``satclip_model.*`` needs model/satclip/satclip-resnet50-l10.ckpt (git-ignored upstream): both are named in the fixture."""
+    import json
+    import yaml
+    out = {}
+    for fname in ("config_px2px.yaml", "config_px2px_SatCLIP.yaml"):
+        with open(os.path.join(REF, "configs", fname)) as f:
+            tree = yaml.safe_load(f)
+        entry = {"tree": tree, "state_dict": {}, "not_constructible_here": []}
+        for netG_name in (tree["base_configs"]["netG"], "resnet_6blocks"):
+            t = yaml.safe_load(yaml.safe_dump(tree))
+            t["base_configs"]["netG"] = netG_name
+            o = t["base_configs"]
+            torch.manual_seed(0)
+            sc = t.get("satclip", {})
+            if sc.get("use_satclip") and sc.get("satclip_style") == "inject":
+                try:
+                    netG = ref_define_G_inject(to_ns(t))      # attribute access on the tree, as OmegaConf gives the reference
+                except NotImplementedError as e:              # (model/generator_inject.py:199: only resnet_9blocks with SatCLIP)
+                    entry["state_dict"][netG_name] = {"raises": "NotImplementedError", "message": str(e)}
+                    continue
+            else:
+                netG = ref_networks.define_G(o["input_nc"], o["output_nc"], o["ngf"], o["netG"], o["norm"], not o["no_dropout"], o["init_type"], o["init_gain"])
+            netD = ref_networks.define_D(o["input_nc"] + o["output_nc"], o["ndf"], o["netD"], o["n_layers_D"], o["norm"], o["init_type"], o["init_gain"])
+            crit = ref_networks.GANLoss(o["gan_mode"])
+            keys = {}
+            for prefix, mod in (("netG.", netG), ("netD.", netD), ("criterionGAN.", crit)):
+                for k, v in mod.state_dict().items():
+                    keys[prefix + k] = list(v.shape)
+            entry["state_dict"][netG_name] = keys
+        if tree.get("satclip", {}).get("use_satclip"):
+            entry["not_constructible_here"].append("satclip_model.* (SatClIP_wrapper needs model/satclip/satclip-resnet50-l10.ckpt, git-ignored upstream)")
+        entry["not_constructible_here"].append("Px2Px_PL itself (pytorch_lightning is not installed): the key list is assembled from the modules its __init__ builds")
+        out[fname] = entry
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", name, {k: {g: ("raises" if "raises" in v else len(v)) for g, v in e["state_dict"].items()} for k, e in out.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "f0":
+        f0("f0_config.json")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ("f1_legacy", "f7"):       # add one fixture without touching the others
         {"f1_legacy": lambda: f1_legacy("f1_legacy.npz"), "f7": lambda: f7("f7_sh_analytic.npz")}[sys.argv[1]]()
         sys.exit(0)
@@ -491,3 +543,4 @@ if __name__ == "__main__":
     f6("f6_locenc.npz")
     f1_legacy("f1_legacy.npz")
     f7("f7_sh_analytic.npz")
+    f0("f0_config.json")

@@ -284,6 +284,86 @@ def lightning_toggled_sequence_reuses_the_forward(dev, golden_dir, tol: Tol):
     assert fwd_runs[0] == 2 and m.netG.__dict__.get("_fwd_reused", 0) == 1
 
 
+def two_generator_graphs_on_one_input(dev, golden_dir, tol: Tol):
+    """netG(x) twice on the SAME tensor with gradients wanted both times (advisor, round 3): each call owns its engine lease, both
+    backwards run and give the same parameter gradients (the reference's nn.Module semantics); a second backward through ONE graph
+    fails with a clear RuntimeError instead of an AttributeError on a released lease."""
+    from model.pix2pix import Px2Px_PL
+    z = load(golden_dir, "f1_g6_d.npz")
+    m = Px2Px_PL(px_config(6, 8))
+    _load_golden_weights(m, z, False)
+    m = m.to(dev).train()
+    rgb = torch.from_numpy(z["rgb"]).to(dev)
+    p1 = m.netG(rgb)
+    p2 = m.netG(rgb)
+    assert m.netG.__dict__.get("_fwd_reused", 0) == 0, "a lease bound to one autograd node was handed to a second forward"
+    assert torch.equal(p1, p2)
+    w = torch.linspace(-1.0, 1.0, p1.numel(), device=dev).reshape(p1.shape)
+    (p1 * w).sum().backward()
+    g1 = [q.grad.clone() for q in m.netG.parameters()]
+    for q in m.netG.parameters():
+        q.grad = None
+    (p2 * w).sum().backward()
+    for a, q in zip(g1, m.netG.parameters()):
+        assert torch.equal(a, q.grad), "the two graphs of one input differ"
+    p3 = m.netG(rgb)
+    loss = (p3 * w).sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already consumed"):
+        loss.backward()
+
+
+def reference_config_key_set(dev, golden_dir, tol: Tol, full_width: bool):
+    """BASELINE.json configs[0]: Px2Px_PL built from the reference's OWN config key set -- tests/golden/f0_config.json holds the parsed
+    trees of configs/config_px2px.yaml and configs/config_px2px_SatCLIP.yaml (train.py:32-48) and the reference's state_dict keys and
+    shapes for each (generated by oracle/make_golden.py::f0 from the reference's modules).  Checked: the key list and every shape for
+    the YAML's netG and for resnet_6blocks (which the reference refuses with SatCLIP: so does this build); then one batch of 4 tiles
+    through both optimizer passes with the YAML's Data.padding_amount = 10: finite losses, both networks stepped once.
+    full_width = False (the CPU run, C ABI served by the numpy emulator): the same trees with ngf = ndf = 8 on 64 x 64 tiles."""
+    import json
+    from model.pix2pix import Px2Px_PL
+    from utils.config import to_attr
+    with open(os.path.join(golden_dir, "f0_config.json")) as f:
+        fix = json.load(f)
+    assert set(fix) == {"config_px2px.yaml", "config_px2px_SatCLIP.yaml"}
+    for fname, entry in fix.items():
+        for netG_name, ref_keys in entry["state_dict"].items():
+            tree = json.loads(json.dumps(entry["tree"]))
+            tree["base_configs"]["netG"] = netG_name
+            if "raises" in ref_keys:
+                with pytest.raises(NotImplementedError):
+                    Px2Px_PL(to_attr(tree))
+                continue
+            m = Px2Px_PL(to_attr(tree))
+            got = {k: list(v.shape) for k, v in m.state_dict().items() if not k.startswith("satclip_model.")}
+            assert list(got) == list(ref_keys) or sorted(got) == sorted(ref_keys), (fname, netG_name, sorted(set(got) ^ set(ref_keys)))
+            for k, shp in ref_keys.items():
+                assert got[k] == shp, (fname, netG_name, k, got[k], shp)
+            del m
+    # one step from the plain config's tree, 6-block generator (configs[0]: bs 4, 256 x 256, padding 10)
+    tree = json.loads(json.dumps(fix["config_px2px.yaml"]["tree"]))
+    tree["base_configs"]["netG"] = "resnet_6blocks"
+    size = 256
+    if not full_width:
+        tree["base_configs"]["ngf"] = tree["base_configs"]["ndf"] = 8
+        size = 64
+    assert tree["Data"]["padding"] is True and tree["Data"]["padding_amount"] == 10
+    torch.manual_seed(0)
+    m = Px2Px_PL(to_attr(tree)).to(dev).train()
+    g = torch.Generator().manual_seed(11)
+    batch = {"rgb": (0.02 + 0.58 * torch.rand(4, 3, size, size, generator=g)).to(dev), "nir": (0.05 + 0.75 * torch.rand(4, 1, size, size, generator=g)).to(dev)}
+    before = {k: v.detach().clone() for k, v in m.state_dict().items() if k.endswith("model.1.weight")}
+    out = m.train_batch(batch).as_dict()
+    for k in ("loss_D", "loss_G", "loss_G_gan", "loss_G_l1"):
+        assert np.isfinite(float(out[k])), (k, out[k])
+    assert m.fused_trainer().padding == 10 and m.fused_trainer().G.data_pad == 10, "the YAML's padding did not reach the generator engine"
+    after = m.state_dict()
+    for k, v in before.items():
+        assert not torch.equal(v, after[k]), f"{k} was not stepped"
+    (opt_d, opt_g), _ = m.configure_optimizers()
+    assert float(opt_d.state_dict()["state"][0]["step"]) == 1.0 and float(opt_g.state_dict()["state"][0]["step"]) == 1.0
+
+
 def ganloss_labels_and_adam_without_gradients(dev, golden_dir, tol: Tol):
     """networks.py:229-256: the label values are registered buffers -- a checkpoint that carries other values (train.py:61-65,
     strict=False) must reach the loss; torch.optim.Adam leaves a parameter whose .grad is None untouched (values and moments)."""

@@ -48,3 +48,11 @@ def test_lightning_toggled_sequence_reuses_the_forward(emu, golden_dir):
 
 def test_ganloss_labels_and_adam_without_gradients(emu, golden_dir):
     A.ganloss_labels_and_adam_without_gradients(DEV, golden_dir, A.CPU_TOL)
+
+
+def test_two_generator_graphs_on_one_input(emu, golden_dir):
+    A.two_generator_graphs_on_one_input(DEV, golden_dir, A.CPU_TOL)
+
+
+def test_px2px_pl_from_the_reference_config_key_set(emu, golden_dir):
+    A.reference_config_key_set(DEV, golden_dir, A.CPU_TOL, full_width=False)

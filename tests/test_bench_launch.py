@@ -58,3 +58,37 @@ def test_bench_mixed_resolution_with_four_ranks_on_different_buckets():
     assert [(x["tiles"], x["size"]) for x in b] == [(16, 32), (4, 64), (1, 128)]
     assert [x["steps"] for x in b] == [1, 1, 1], b          # three timed steps: rank 0 visited every bucket once
     assert "configs[4]" in out["config"]["workload"]
+
+
+def test_bench_eight_ranks_mixed_resolution_verified():
+    """The driver's 8-GPU launch shape rehearsed on the CPU (no 8-GPU node is available to the builder): eight gloo ranks, mixed-resolution
+    buckets, the data-parallel gradients verified against the single-process gradients on the concatenated batch; every rank reports
+    its step time and its exposed all-reduce time."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mixed", "--emulate-cpu", "--ngf", "8",
+                        "--size", "64", "--bs", "4", "--steps", "1", "--warmup", "1", "--blocks", "6"],
+                       capture_output=True, text=True, env={**_env(), "OMP_NUM_THREADS": "1"}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 32
+    assert len(out["ms_per_step_by_rank"]) == 8 and len(out["comm_exposed_ms_per_step_by_rank"]) == 8
+    assert out["collective_backend"] == "gloo" and out["rccl_ranks"] == 0 and out["value"] > 0
+
+
+def test_bench_eight_ranks_verify_dp():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--verify-dp", "--emulate-cpu", "--ngf", "8",
+                        "--size", "32", "--bs", "1", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, env={**_env(), "OMP_NUM_THREADS": "1"}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    dp = out["dp_verify"]
+    assert out["n_gpus"] == 8 and dp["ok"] and dp["global_batch"] == 8 and dp["rel_l2_D"] < 1e-4 and dp["rel_l2_G"] < 1e-4
+
+
+def test_bench_single_process_line_has_the_scaling_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline"] + SMALL,
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and len(out["ms_per_step_by_rank"]) == 1 and out["comm_exposed_ms_per_step_by_rank"] == [0.0] and "rccl_ranks" in out
