@@ -114,10 +114,11 @@ typedef struct {
     /* kernel choice where more than one applies (A/B measurements, tests): 0 = default -- problems with both operands stored as bf16,
      * N % 256 == 0, run % 64 == 0 and at least 128 tiles of 256 x 256 run on the 256 x 256 x 64 eight-phase tile (one workgroup of
      * eight waves per CU, LDS-DMA in flight across the barriers), everything else on the 128-row tile; NIRGAN_CONV_TILE128 = always the
-     * 128-row tile.  Results of the two differ by fp32 summation order only. */
+     * 128-row tile; NIRGAN_CONV_TILE256 = the 256-wide tile also for exact-fp32 problems.  Results differ by fp32 summation order only. */
     int algo;
 } nirgan_conv_desc;
 #define NIRGAN_CONV_TILE128 1
+#define NIRGAN_CONV_TILE256 2   /* exact-fp32 problems (N % 256 == 0, run % 32 == 0, >= 128 tiles) on the 256-wide tile too (A/B: within 1 % of the 128-row tile) */
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
 

@@ -25,9 +25,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ng::ConvParams
 }
 
 // the bf16 operand mode's 256 x 256 x 64 eight-phase tile (igemm_tile256.h): one workgroup of eight waves per CU
+template <bool F32>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ng::ConvParams p) {
     __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
-    ng::conv_tile256(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
+    ng::conv_tile256<F32>(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
 }
 
 // split-K second stage: out(m, n) = bias[n] + sum_s ws[s][m][n], written with the descriptor's output geometry
@@ -79,7 +80,8 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) {
-        hipLaunchKernelGGL(conv_igemm256_kernel, dim3(((p.M + 255) >> 8) * (p.N >> 8)), dim3(512), 0, st, p);
+        if (p.prec == 0) hipLaunchKernelGGL(conv_igemm256_kernel<true>, dim3(((p.M + 255) >> 8) * (p.N >> 8)), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(conv_igemm256_kernel<false>, dim3(((p.M + 255) >> 8) * (p.N >> 8)), dim3(512), 0, st, p);
         return nirgan_check_launch("conv_igemm (256 x 256 tile)");
     }
     const dim3 grid(p.mtiles * p.ntiles * p.ksplit);
@@ -109,7 +111,7 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
 extern "C" const char* nirgan_conv_kernel_name(const nirgan_conv_desc* d) {
     ng::ConvParams p;
     if (ng::build_conv_params(d, p) != NIRGAN_OK) return nullptr;
-    if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) return "conv_igemm256_kernel";
+    if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) return p.prec == 0 ? "conv_igemm256_kernel<fp32>" : "conv_igemm256_kernel";
     return d->N > 64 ? "conv_igemm_kernel<128>" : "conv_igemm_kernel<64>";
 }
 

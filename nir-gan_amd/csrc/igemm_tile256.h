@@ -147,7 +147,20 @@ __device__ __forceinline__ void t256_kloop(const int nk, const int wr, IA&& issu
 #define T256_STAMP(i)
 #endif
 
-__device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, char* lds) {
+// F32 = true: the SAME structure in exact fp32 (v_mfma_f32_32x32x2_f32, the parity path's arithmetic): a K-tile is 32 k (the 128-byte
+// rows hold 32 floats), a phase is 2 x 1 tiles of 32 x 32 x 16 k-steps of 2 = 32 MFMAs of 64 cycles, so the load segment of the partner
+// wave (the same LDS-DMA pieces and fragment reads as in bf16) hides under 2 048 instead of 256 cycles of matrix work.  Fragments as in
+// conv_tile: one ds_read_b128 hands a lane 4 consecutive k of its row, lanes 0-31 chunk 2g, lanes 32-63 chunk 2g + 1, MFMA j of group g
+// contracts k = 8g + j and 8g + 4 + j.  `in_base / w_base / out_base`: base overrides for plane-batched launches (csrc/wino6.hip).
+template <bool F32 = false>
+__device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, char* lds,
+                                             const float* in_base = nullptr, const float* w_base = nullptr, float* out_base = nullptr) {
+    const float* const p_in = in_base ? in_base : p.in;
+    const float* const p_w = w_base ? w_base : p.w;
+    float* const p_out = out_base ? out_base : p.out;
+    constexpr int ES = F32 ? 4 : 2;             // bytes per operand element
+    constexpr int KT = F32 ? 32 : 64;           // k per K-tile (one 128-byte row)
+    constexpr int CW = 16 / ES;                 // elements per 16-byte chunk
 #ifdef NG_DIAG256
     unsigned long long ng_t[8];
     const unsigned long long ng_r0 = __builtin_amdgcn_s_memrealtime();
@@ -171,31 +184,31 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
             m = m < p.M ? m : p.M - 1;
             const int b = m / p.OHW, r = m - b * p.OHW;
             const int oh = r / p.OW, ow = r - oh * p.OW;
-            a_boff[h][i] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + lc * 8) * 2u;
+            a_boff[h][i] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + lc * CW) * unsigned(ES);
             int n = n0 + (row >> 5) * 64 + h * 32 + (row & 31);
             n = n < p.N ? n : 0;                 // (columns past N are never stored and never summed)
-            b_boff[h][i] = unsigned(n * p.K + lc * 8) * 2u;
+            b_boff[h][i] = unsigned(n * p.K + lc * CW) * unsigned(ES);
         }
     // K-tiles in slice-major order: 64-channel slice cc of the run, all taps -- a slice of the tile's input patch (one 128-byte line per
     // pixel) stays in L2 across its taps.  The tap offsets sit in one VGPR (lane t holds tap t): a cursor step costs no memory access.
     const int tapv = p.tap_off[lane & (NIRGAN_MAX_TAPS - 1)];
-    const int nk = p.ntaps * (p.run >> 6);
+    const int nk = p.ntaps * (p.run / KT);
     int ct = 0, cc = 0;
     auto advance = [&]() {
         ++ct;
-        if (ct == p.ntaps) { ct = 0; cc += 64; }
+        if (ct == p.ntaps) { ct = 0; cc += KT; }
     };
-    const char* const in8 = reinterpret_cast<const char*>(p.in);
-    const char* const w8 = reinterpret_cast<const char*>(p.w);
+    const char* const in8 = reinterpret_cast<const char*>(p_in);
+    const char* const w8 = reinterpret_cast<const char*>(p_w);
     auto issueA = [&](const int buf, const int h) {
         const int toff = __builtin_amdgcn_readlane(tapv, ct);
-        const char* base = ng_uniform_ptr(in8 + (long long)(toff + cc) * 2);
+        const char* base = ng_uniform_ptr(in8 + (long long)(toff + cc) * ES);
         char* dst = lds + (buf * 4 + h) * T256_HALF + wave * 2048;
         ng_glds16_so(base, a_boff[h][0], dst);
         ng_glds16_so(base, a_boff[h][1], dst + 1024);
     };
     auto issueB = [&](const int buf, const int h) {
-        const char* base = ng_uniform_ptr(w8 + (long long)(ct * p.run + cc) * 2);
+        const char* base = ng_uniform_ptr(w8 + (long long)(ct * p.run + cc) * ES);
         char* dst = lds + (buf * 4 + 2 + h) * T256_HALF + wave * 2048;
         ng_glds16_so(base, b_boff[h][0], dst);
         ng_glds16_so(base, b_boff[h][1], dst + 1024);
@@ -208,48 +221,92 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
     const int b_rd0 = (wc * 32 + (lane & 15)) * 128 + x0, b_rd1 = (wc * 32 + (lane & 15)) * 128 + x1;
     bf16x8 A[4][2], B0[2][2], B1[2][2];
     f32x4 acc[2][2][4][2];
+    // fp32: rows wr * 64 + mt * 32 + (lane & 31) of an A half, wc * 32 + (lane & 31) of a B half; group g reads chunk 2g + half
+    const int half = lane >> 5, keyf = (lane >> 1) & 7;
+    int f_rd[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int g = 0; g < 4; ++g) f_rd[g] = (lane & 31) * 128 + (((2 * g + half) ^ keyf) << 4);
+    f32x4 Af[2][4], B0f[4], B1f[4];
+    f32x16 accF[2][2][2];
+    if constexpr (F32) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accF[i][j][mt][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     auto readA = [&](const int buf, const int h) {
         const char* s = lds + (buf * 4 + h) * T256_HALF;
+        if constexpr (F32) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            A[mt][0] = *reinterpret_cast<const bf16x8*>(s + a_rd0 + mt * 2048);
-            A[mt][1] = *reinterpret_cast<const bf16x8*>(s + a_rd1 + mt * 2048);
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Af[mt][g] = *reinterpret_cast<const f32x4*>(s + (wr * 64 + mt * 32) * 128 + f_rd[g]);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                A[mt][0] = *reinterpret_cast<const bf16x8*>(s + a_rd0 + mt * 2048);
+                A[mt][1] = *reinterpret_cast<const bf16x8*>(s + a_rd1 + mt * 2048);
+            }
         }
     };
-    auto readB = [&](bf16x8 (&Bj)[2][2], const int buf, const int h) {
+    auto readB = [&](const int which, const int buf, const int h) {
         const char* s = lds + (buf * 4 + 2 + h) * T256_HALF;
+        if constexpr (F32) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            Bj[nt][0] = *reinterpret_cast<const bf16x8*>(s + b_rd0 + nt * 2048);
-            Bj[nt][1] = *reinterpret_cast<const bf16x8*>(s + b_rd1 + nt * 2048);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(s + (wc * 32) * 128 + f_rd[g]);
+                if (which == 0) B0f[g] = v; else B1f[g] = v;
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(s + b_rd0 + nt * 2048), v1 = *reinterpret_cast<const bf16x8*>(s + b_rd1 + nt * 2048);
+                if (which == 0) { B0[nt][0] = v0; B0[nt][1] = v1; } else { B1[nt][0] = v0; B1[nt][1] = v1; }
+            }
         }
     };
-    auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&Bj)[2][2]) {
+    auto mma = [&](const int i, const int j) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (F32) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    c[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][s], Bj[nt][s], c[mt][nt], 0, 0, 0);
+                    for (int mt = 0; mt < 2; ++mt)
+                        accF[i][j][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[mt][g][q], j == 0 ? B0f[g][q] : B1f[g][q], accF[i][j][mt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[i][j][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][s], j == 0 ? B0[nt][s] : B1[nt][s], acc[i][j][mt][nt], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
 
     T256_STAMP(1)
-    t256_kloop(nk, wr, issueA, issueB, advance, readA,
-                  [&](const int which, const int buf, const int h) { if (which == 0) readB(B0, buf, h); else readB(B1, buf, h); },
-                  [&](const int i, const int j) { if (j == 0) mma(acc[i][0], B0); else mma(acc[i][1], B1); });
+    t256_kloop(nk, wr, issueA, issueB, advance, readA, readB,
+               [&](const int i, const int j) {         // (i, j are literals at every call site: the branches fold after inlining)
+                   if (i == 0 && j == 0) mma(0, 0); else if (i == 0) mma(0, 1); else if (j == 0) mma(1, 0); else mma(1, 1);
+               });
     T256_STAMP(2)
 
     // ---------------- partial sums for the instance norm that follows (nirgan_conv_desc.stats_ws): a wave's 64 rows x 64 columns leave,
@@ -265,22 +322,35 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        const float k0 = __shfl(acc[i][j][0][nt][0], lane & 15, 64);
-                        float s1 = 0.f, s2 = 0.f;
+                        if (F32 && nt == 1) continue;             // fp32: one 32-column tile per (i, j), a column on lanes l and l + 32
+                        float k0, s1 = 0.f, s2 = 0.f;
+                        if constexpr (F32) {
+                            k0 = __shfl(accF[i][j][0][0], lane & 31, 64);
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
+                            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float v = acc[i][j][mt][nt][r] - k0;
-                                s1 += v;
-                                s2 += v * v;
-                            }
-                        s1 += __shfl_xor(s1, 16, 64);
-                        s2 += __shfl_xor(s2, 16, 64);
+                                for (int r = 0; r < 16; ++r) {
+                                    const float v = accF[i][j][mt][r] - k0;
+                                    s1 += v;
+                                    s2 += v * v;
+                                }
+                        } else {
+                            k0 = __shfl(acc[i][j][0][nt][0], lane & 15, 64);
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float v = acc[i][j][mt][nt][r] - k0;
+                                    s1 += v;
+                                    s2 += v * v;
+                                }
+                            s1 += __shfl_xor(s1, 16, 64);
+                            s2 += __shfl_xor(s2, 16, 64);
+                        }
                         s1 += __shfl_xor(s1, 32, 64);
                         s2 += __shfl_xor(s2, 32, 64);
-                        const int col = n0 + wc * 64 + j * 32 + nt * 16 + (lane & 15);
-                        if (lane < 16 && col < p.N) {
+                        const int col = n0 + wc * 64 + j * 32 + (F32 ? (lane & 31) : nt * 16 + (lane & 15));
+                        if (lane < (F32 ? 32 : 16) && col < p.N) {
                             sp[col] = k0;
                             sp[p.N + col] = s1;
                             sp[2 * p.N + col] = s2;
@@ -327,8 +397,8 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
                 fW v = *reinterpret_cast<const fW*>(stg + (pass * RPP + lrow) * 64 + chunk * W);
                 v += bv;
                 const int oidx = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n;
-                if constexpr (W == 8) *reinterpret_cast<bW*>(reinterpret_cast<unsigned short*>(p.out) + oidx) = __builtin_convertvector(v, bW);
-                else *reinterpret_cast<fW*>(p.out + oidx) = v;
+                if constexpr (W == 8) *reinterpret_cast<bW*>(reinterpret_cast<unsigned short*>(p_out) + oidx) = __builtin_convertvector(v, bW);
+                else *reinterpret_cast<fW*>(p_out + oidx) = v;
                 if (fused) {
                     const size_t yidx = size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n;
                     fW y;
@@ -376,15 +446,25 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
     };
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        if constexpr (F32) {                 // C/D of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int r = 0; r < 16; ++r)
+                        stg[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 64 + j * 32 + (lane & 31)] = accF[i][j][mt][r];
+        } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        stg[(mt * 16 + (lane >> 4) * 4 + r) * 64 + j * 32 + nt * 16 + (lane & 15)] = acc[i][j][mt][nt][r];
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            stg[(mt * 16 + (lane >> 4) * 4 + r) * 64 + j * 32 + nt * 16 + (lane & 15)] = acc[i][j][mt][nt][r];
+        }
         if (p.out16) half_out(i, std::integral_constant<int, 8>{});
         else half_out(i, std::integral_constant<int, 4>{});
     }
@@ -605,8 +685,12 @@ inline bool wgrad_tile256_ok(const WgradParams& p) {
 // whether the 256-wide tile covers a problem (host): both operands stored as bf16, whole 64-channel slices, whole 256-column tiles,
 // enough tiles to give most CUs one, 32-bit offsets
 inline bool conv_tile256_ok(const ConvParams& p) {
-    if (!(p.prec == 1 && p.in_bf16 && p.w_bf16 && p.off32 && p.ksplit == 1)) return false;
-    if (p.run % 64 != 0 || p.N % 256 != 0) return false;
+    // exact fp32 on this tile only on request (NIRGAN_CONV_TILE256): measured within 1 % of the 128-row tile on long K loops (138.3 against
+    // 136.7 TFLOP/s on the 3x3 256 -> 256 layer, profiles/r04_tile256_fp32_parts.txt) -- at 64 cycles per MFMA the load segment was
+    // never the limit -- so the parity path keeps the kernels its fixtures were measured with
+    const bool b16 = p.prec == 1 && p.in_bf16 && p.w_bf16, f32 = p.prec == 0 && !p.out16 && !p.f_y16 && p.algo == NIRGAN_CONV_TILE256;
+    if (!((b16 || f32) && p.off32 && p.ksplit == 1)) return false;
+    if (p.run % (b16 ? 64 : 32) != 0 || p.N % 256 != 0) return false;
     const long long tiles = (long long)((p.M + 255) >> 8) * (p.N >> 8);
     return tiles >= 128;
 }

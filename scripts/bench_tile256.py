@@ -10,16 +10,22 @@ import torch
 from nirgan_hip import geometry as G, lib as L
 from nirgan_hip.engine import Ctx, Halo, emit_conv
 
+PREC = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 reps = 20
 Cc = 256
-ctx = Ctx("cuda:0", "bf16")
+ctx = Ctx("cuda:0", PREC)
 g = torch.Generator().manual_seed(0)
 
 
 def packed16(w, spec):
+    if PREC == "fp32":
+        buf = torch.zeros(spec.N, spec.K, device="cuda:0")
+        L.call("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), buf.data_ptr(), spec.N, spec.K, None)
+        torch.cuda.synchronize()
+        return buf
     buf = torch.zeros(spec.N, spec.K, dtype=torch.bfloat16, device="cuda:0")
     L.call("nirgan_pack_rows_bf16", w.data_ptr(), w.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), buf.data_ptr(), spec.N, spec.K, None)
     torch.cuda.synchronize()
@@ -28,15 +34,16 @@ def packed16(w, spec):
 
 def problem(k, out16, algo, cin=Cc, cout=Cc):
     p = (k - 1) // 2
-    x = Halo(ctx, B, H, H, cin, p, twin=True)
+    x = Halo(ctx, B, H, H, cin, p, twin=(PREC == "bf16"))
     x.t.copy_(torch.randn(x.t.shape, generator=g).to("cuda:0"))
-    x.t16.copy_(x.t.to(torch.bfloat16))
+    if PREC == "bf16":
+        x.t16.copy_(x.t.to(torch.bfloat16))
     w = (torch.randn(cout, cin, k, k, generator=g) * 0.02).to("cuda:0")
     wp = packed16(w, G.conv_fwd_pack(cout, cin, k))
     ctx.keep.append(wp)
-    y = Halo(ctx, B, H, H, cout, 0, bf16=out16)
+    y = Halo(ctx, B, H, H, cout, 0, bf16=out16 and PREC == "bf16")
     d = emit_conv(None, ctx, x, G.conv_fwd_taps(k, cin), wp, None, y, N=cout, OH=H, OW=H, allow_split=False)
-    d.algo = algo
+    d.algo = L.CONV_TILE256 if (algo == 0 and PREC == "fp32") else algo
     return d, 2.0 * B * H * H * cout * k * k * cin
 
 
@@ -64,5 +71,8 @@ for n, (d, fl) in arms.items():
     med, mn = statistics.median(times[n]), min(times[n])
     print(f"{n:20s} median {med:7.1f} us  min {mn:7.1f} us   {fl / (med * 1e-6) / 1e12:7.1f} TF/s = {fl / (med * 1e-6) / 2.5e15:.3f} of 2.5 PFLOP/s", flush=True)
 t3, t1 = statistics.median(times["256 3x3 bf16-out"]), statistics.median(times["256 1x1 bf16-out"])
-print(f"per K-tile (256 x 256 x 64): {(t3 - t1) / 32 * 1e3:.0f} ns  -> loop-only rate {2.0 * 256 * 256 * 64 * 256 / ((t3 - t1) / 32 * 1e-6) / 1e12:.0f} TF/s; "
+PEAK = 2.5e15 if PREC == "bf16" else 157.3e12
+for n, (d, fl) in arms.items():
+    print(f"   {n:20s} {fl / (statistics.median(times[n]) * 1e-6) / PEAK:.3f} of the {PREC} peak")
+print(f"per 64 k of a 256 x 256 tile: {(t3 - t1) / 32 * 1e3:.0f} ns  -> loop-only rate {2.0 * 256 * 256 * 64 * 256 / ((t3 - t1) / 32 * 1e-6) / 1e12:.0f} TF/s; "
       f"fixed part (prologue + epilogue + launch): {t1 - 4 * (t3 - t1) / 32:.1f} us")

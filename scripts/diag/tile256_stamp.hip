@@ -12,7 +12,7 @@ void nirgan_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfp
 
 __global__ __launch_bounds__(512, 2) void k(const ng::ConvParams p) {
     __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
-    ng::conv_tile256(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
+    ng::conv_tile256<false>(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
 }
 
 static unsigned short bf16_of(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }

@@ -222,3 +222,70 @@ def test_pair256_repeated_launches_agree_bitwise():
         plan.run()
         bad += (gx.t != first_x).any().to(torch.int64) + (gw != first_w).any().to(torch.int64)
     assert int(bad.item()) == 0, f"{int(bad.item())} differing results in 150 launches"
+
+
+# ------------------------------------------------------------------ the same tile in exact fp32 (v_mfma_f32_32x32x2_f32)
+def _problem_f32(B, H, W, Cin, Cout, k, stride, bias, seed=0):
+    ctx = Ctx(DEV, "fp32")
+    g = torch.Generator().manual_seed(seed)
+    p = (k - 1) // 2 if k != 4 else 1
+    x = Halo(ctx, B, H, W, Cin, p)
+    x.t.copy_(torch.randn(x.t.shape, generator=g).to(DEV))
+    OH, OW = G.conv_out(H, k, stride, p), G.conv_out(W, k, stride, p)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.05).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV) if bias else None
+    spec = G.conv_fwd_pack(Cout, Cin, k)
+    wp = ctx.zeros(spec.N, spec.K)
+    L.call("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), wp.data_ptr(), spec.N, spec.K, None)
+    torch.cuda.synchronize()
+    outs, descs = [], []
+    for algo in (L.CONV_TILE256, 0):
+        y = Halo(ctx, B, OH, OW, Cout, 0)
+        y.t.fill_(float("nan"))
+        d = emit_conv(None, ctx, x, G.conv_fwd_taps(k, Cin), wp, b, y, N=Cout, OH=OH, OW=OW, in_stride=stride, allow_split=False)
+        d.algo = algo
+        outs.append(y)
+        descs.append(d)
+    return ctx, x, w, b, outs, descs
+
+
+F32_CASES = [
+    # B, H, W, Cin, Cout, k, stride, bias
+    (16, 128, 128, 128, 256, 3, 2, True),        # the generator's second down-sampling convolution at the benchmark batch
+    (8, 64, 64, 256, 256, 3, 1, False),          # a residual-block shape on the direct path (OPT.winograd = 'off')
+    (9, 61, 63, 96, 256, 3, 1, True),            # ragged last M tile, run = 96: three 32-k slices per tap
+    (16, 33, 35, 32, 512, 1, 1, True),           # one K-tile, two column tiles
+    (32, 32, 32, 256, 512, 4, 1, False),         # 4x4: 16 taps x 8 slices = 128 K-tiles
+]
+
+
+@pytest.mark.parametrize("case", F32_CASES)
+def test_tile256_fp32_against_the_128_row_tile_and_float64(case):
+    """Exact-fp32 mode, NIRGAN_CONV_TILE256 (the default keeps the 128-row tile there): the 256-wide tile against the 128-row tile (fp32 summation order only: both are exact fp32 FMA
+    chains) and against torch's conv2d in float64 (the reference's nn.Conv2d arithmetic, model/networks.py:349,405-427)."""
+    B, H, W, Cin, Cout, k, stride, bias = case
+    ctx, x, w, b, (y256, y128), (d256, d128) = _problem_f32(*case)
+    assert L.backend().nirgan_conv_kernel_name(C.byref(d256)).decode() == "conv_igemm256_kernel<fp32>"
+    assert L.backend().nirgan_conv_kernel_name(C.byref(d128)).decode() == "conv_igemm_kernel<128>"
+    L.call("nirgan_conv_igemm", C.byref(d256), None)
+    L.call("nirgan_conv_igemm", C.byref(d128), None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y256.t).all(), "rows or columns left unwritten"
+    assert _rel(y256.t, y128.t) <= 1e-5, f"256-wide tile vs 128-row tile: {_rel(y256.t, y128.t):.3e}"
+    if B * H * W <= 70000:
+        ref = torch.nn.functional.conv2d(x.t.double().permute(0, 3, 1, 2), w.double(), None if b is None else b.double(), stride=stride).permute(0, 2, 3, 1)
+        assert _rel(y256.t, ref.float()) <= 1e-5, f"256-wide tile vs float64 conv2d: {_rel(y256.t, ref.float()):.3e}"
+
+
+def test_tile256_fp32_repeated_launches_agree_bitwise():
+    for case in (F32_CASES[0], F32_CASES[2]):
+        ctx, x, w, b, (y256, _), (d256, _) = _problem_f32(*case, seed=3)
+        L.call("nirgan_conv_igemm", C.byref(d256), None)
+        torch.cuda.synchronize()
+        first = y256.t.clone()
+        bad = torch.zeros((), dtype=torch.int64, device=DEV)
+        for it in range(100):
+            y256.t.fill_(0)
+            L.call("nirgan_conv_igemm", C.byref(d256), None)
+            bad += (y256.t != first).any().to(torch.int64)
+        assert int(bad.item()) == 0, f"{case}: {int(bad.item())} of 100 launches differ"
