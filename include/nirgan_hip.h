@@ -112,7 +112,7 @@ typedef struct {
      * read it with y_bf16 = 1.  Needs N % 4 == 0, out_cs % 4 == 0, no split-K.  fuse_y_bf16: fuse_y points to such a tensor. */
     int out_bf16, fuse_y_bf16;
     /* kernel choice where more than one applies (A/B measurements, tests): 0 = default -- problems with both operands stored as bf16,
-     * N % 256 == 0, run % 64 == 0 and at least 128 tiles of 256 x 256 run on the 256 x 256 x 64 eight-phase tile (one workgroup of
+     * N % 256 == 0, run % 64 == 0 and rounds of 256 x 256 tiles that fill at least 62 % of the CUs run on the 256 x 256 x 64 eight-phase tile (one workgroup of
      * eight waves per CU, LDS-DMA in flight across the barriers), everything else on the 128-row tile; NIRGAN_CONV_TILE128 = always the
      * 128-row tile; NIRGAN_CONV_TILE256 = the 256-wide tile also for exact-fp32 problems.  Results differ by fp32 summation order only. */
     int algo;

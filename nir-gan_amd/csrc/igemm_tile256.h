@@ -683,8 +683,11 @@ inline bool wgrad_tile256_ok(const WgradParams& p) {
 }
 
 // whether the 256-wide tile covers a problem (host): both operands stored as bf16, whole 64-channel slices, whole 256-column tiles,
-// enough tiles to give most CUs one, 32-bit offsets
-inline bool conv_tile256_ok(const ConvParams& p) {
+// 32-bit offsets -- and enough tiles.  One workgroup per CU: a launch takes ceil(tiles / CUs) rounds whatever the last round holds, and a
+// round is worth about 0.62 of what the 128-row tile (two workgroups per CU, 0.33 of the peak against 0.50) needs for a round's worth of
+// work; so alone the tile is chosen when its rounds are at least 62 % full (128 tiles on 256 CUs: 55 us against 47; 273 tiles: 120 against
+// 118 -- the fused launch fills such a tail with weight-gradient units and only asks for `pair` = at least half a round).
+inline bool conv_tile256_ok(const ConvParams& p, const bool pair = false, const int cus = 256) {
     // exact fp32 on this tile only on request (NIRGAN_CONV_TILE256): measured within 1 % of the 128-row tile on long K loops (138.3 against
     // 136.7 TFLOP/s on the 3x3 256 -> 256 layer, profiles/r04_tile256_fp32_parts.txt) -- at 64 cycles per MFMA the load segment was
     // never the limit -- so the parity path keeps the kernels its fixtures were measured with
@@ -692,7 +695,9 @@ inline bool conv_tile256_ok(const ConvParams& p) {
     if (!((b16 || f32) && p.off32 && p.ksplit == 1)) return false;
     if (p.run % (b16 ? 64 : 32) != 0 || p.N % 256 != 0) return false;
     const long long tiles = (long long)((p.M + 255) >> 8) * (p.N >> 8);
-    return tiles >= 128;
+    if (pair) return tiles >= cus / 2;
+    const long long rounds = (tiles + cus - 1) / cus;
+    return tiles * 100 >= rounds * cus * 62;
 }
 
 }  // namespace ng

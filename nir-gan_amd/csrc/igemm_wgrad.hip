@@ -250,7 +250,7 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
     NG_REQUIRE(cp.prec == wp.prec, "conv_wgrad_pair: both halves must use the same precision");
-    if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp) && ng::wgrad_tile256_ok(wp)) {
+    if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp, true) && ng::wgrad_tile256_ok(wp)) {
         const int conv_tiles = ((cp.M + 255) >> 8) * (cp.N >> 8), units = (wp.N >> 8) * (wp.K >> 8) * wp.nsplit, G = ng_cu_count();
         const int conv_wgs = pair256_split(G, conv_tiles, cp.ntaps * (cp.run >> 6), units, wp.rows_per_split >> 6);
         hipLaunchKernelGGL(conv_wgrad_pair256_kernel, dim3(G), dim3(512), 0, static_cast<hipStream_t>(stream), cp, wp, conv_wgs, conv_tiles, units);
@@ -283,7 +283,7 @@ extern "C" const char* nirgan_conv_wgrad_pair_kernel_name(const nirgan_conv_desc
     ng::WgradParams wp;
     if (ng::build_conv_params(c, cp) != NIRGAN_OK || ng::build_wgrad_params(w, wp) != NIRGAN_OK) return nullptr;
     if (c->N <= 64 || w->N <= 64 || c->ksplit > 1 || (wp.pq_bf16 && !cp.in_bf16)) return "(two launches)";
-    if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp) && ng::wgrad_tile256_ok(wp)) return "conv_wgrad_pair256_kernel";
+    if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp, true) && ng::wgrad_tile256_ok(wp)) return "conv_wgrad_pair256_kernel";
     return "conv_wgrad_pair_kernel";
 }
 

@@ -908,7 +908,7 @@ def test_bf16_every_contraction_against_the_restatement_on_the_devices_own_input
     g = networks.define_G(3, 1, 64, "resnet_9blocks", "instance", False, "normal", 0.02)
     d = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02)
     tr = Pix2PixTrainer(g.to(DEV), d.to(DEV), n_blocks=nb, lr=0.0, precision="bf16")
-    rgb, nir = synth(8, 256, 256, 91)            # 8 tiles: the trunk launches run on the 256-wide tiles (128 of them), as the benchmark's do
+    rgb, nir = synth(12, 256, 256, 91)           # 12 tiles: the trunk launches run on the 256-wide tiles (192 of them), as the benchmark's do
     tr.step(rgb.to(DEV), nir.to(DEV))
     torch.cuda.synchronize()
     G, D2 = tr.G, tr.D2

@@ -56,11 +56,11 @@ CASES = [
     # B, H, W, Cin, Cout, k, bias, bf16 output
     (16, 64, 64, 256, 256, 3, False, False),     # the benchmark's residual-block convolution: 256 tiles, 36 K-tiles
     (16, 64, 64, 256, 256, 3, True, True),
-    (9, 61, 63, 128, 256, 3, True, False),       # ragged last M tile (34 587 rows), 18 K-tiles
-    (8, 64, 64, 64, 256, 3, False, False),       # 9 K-tiles: the odd tail (one buffer only in the last round)
-    (16, 33, 35, 64, 512, 1, True, False),       # one K-tile: prologue + four phases, two column tiles
-    (32, 31, 31, 256, 512, 4, False, False),     # the PatchGAN's stride-1 4x4 layer: 16 taps, 64 K-tiles, two column tiles
-    (5, 80, 52, 192, 256, 3, False, True),       # run = 192: three slices per tap
+    (11, 61, 63, 128, 256, 3, True, False),      # ragged last M tile (42 273 rows: 166 tiles), 18 K-tiles
+    (10, 64, 64, 64, 256, 3, False, False),      # 9 K-tiles: the odd tail (one buffer only in the last round)
+    (18, 33, 35, 64, 512, 1, True, False),       # one K-tile: prologue + four phases, two column tiles (164 tiles)
+    (32, 31, 31, 256, 512, 4, False, False),     # the PatchGAN's stride-1 4x4 layer: 16 taps, 64 K-tiles, two column tiles (242 tiles)
+    (10, 80, 52, 192, 256, 3, False, True),      # run = 192: three slices per tap (163 tiles)
 ]
 
 
@@ -68,6 +68,8 @@ CASES = [
 def test_tile256_against_the_128_row_tile_and_float64(case):
     B, H, W, Cin, Cout, k, bias, out16 = case
     ctx, x, w, b, (y256, y128), (d256, d128) = _problem(*case)
+    assert L.backend().nirgan_conv_kernel_name(C.byref(d256)).decode() == "conv_igemm256_kernel"
+    assert L.backend().nirgan_conv_kernel_name(C.byref(d128)).decode() == "conv_igemm_kernel<128>"
     L.call("nirgan_conv_igemm", C.byref(d256), None)
     L.call("nirgan_conv_igemm", C.byref(d128), None)
     torch.cuda.synchronize()
@@ -75,7 +77,7 @@ def test_tile256_against_the_128_row_tile_and_float64(case):
     assert torch.isfinite(a).all(), "rows or columns left unwritten"
     tol = 2 ** -7 if out16 else 2e-5            # (two bf16 roundings of sums that differ in the last fp32 bits may land one bf16 ulp apart)
     assert _rel(a, r) <= tol, f"256-row tile vs 128-row tile: {_rel(a, r):.3e}"
-    if B * H * W <= 40000:
+    if B * H * W <= 45000:
         p = (k - 1) // 2 if k != 4 else 1
         xi = x.t16.double().permute(0, 3, 1, 2)
         ref = torch.nn.functional.conv2d(xi, w.to(torch.bfloat16).double(), None if b is None else b.double()).permute(0, 2, 3, 1)
@@ -166,7 +168,7 @@ def test_wgrad256_against_the_128_row_tile_and_float64(case):
         assert _rel(g256, ref.float()) <= 1e-5, f"256-wide tile vs float64 on the rounded operands: {_rel(g256, ref.float()):.3e}"
 
 
-@pytest.mark.parametrize("case", [(16, 64, 64, 256, 256, 3, False), (16, 64, 64, 256, 256, 3, True), (8, 32, 32, 256, 256, 3, True), (5, 64, 128, 256, 256, 3, False)])
+@pytest.mark.parametrize("case", [(16, 64, 64, 256, 256, 3, False), (16, 64, 64, 256, 256, 3, True), (32, 32, 32, 256, 256, 3, True), (5, 64, 128, 256, 256, 3, False)])
 def test_pair256_equals_separate_launches(case):
     """nirgan_conv_wgrad_pair on the persistent 256-wide tiles (data-gradient tiles and weight-gradient units on disjoint sets of CUs) against
     the same two descriptors launched on the 128-row tiles: data gradient over the padded extent (fp32 or bf16 store) and the reduced
@@ -188,6 +190,7 @@ def test_pair256_equals_separate_launches(case):
             OPT.reset()
         plan, d, gw = _emit_wgrad(ctx, x, dy, geo, Cin, Cout, k, tile128, pair_with=cd)
         assert [n for n, _ in plan.ops] == ["nirgan_conv_wgrad_pair", "nirgan_reduce_rows"]
+        assert L.backend().nirgan_conv_wgrad_pair_kernel_name(C.byref(cd), C.byref(d)).decode() == ("conv_wgrad_pair_kernel" if tile128 else "conv_wgrad_pair256_kernel")
         plan.run()
         res.append((gx, gw, d))
     torch.cuda.synchronize()
@@ -197,7 +200,7 @@ def test_pair256_equals_separate_launches(case):
     assert _rel(gw256, gw128) <= 2e-5
     xi = x.t16.double().permute(0, 3, 1, 2)
     OH, OW, p = geo
-    if B * H * W <= 40000:
+    if B * H * W <= 45000:
         gi = dy.t16.double()[:, dy.pad:dy.pad + OH, dy.pad:dy.pad + OW].permute(0, 3, 1, 2)
         assert _rel(gw256, torch.nn.grad.conv2d_weight(xi, (Cout, Cin, k, k), gi).float()) <= 1e-5
 
@@ -252,9 +255,9 @@ def _problem_f32(B, H, W, Cin, Cout, k, stride, bias, seed=0):
 F32_CASES = [
     # B, H, W, Cin, Cout, k, stride, bias
     (16, 128, 128, 128, 256, 3, 2, True),        # the generator's second down-sampling convolution at the benchmark batch
-    (8, 64, 64, 256, 256, 3, 1, False),          # a residual-block shape on the direct path (OPT.winograd = 'off')
-    (9, 61, 63, 96, 256, 3, 1, True),            # ragged last M tile, run = 96: three 32-k slices per tap
-    (16, 33, 35, 32, 512, 1, 1, True),           # one K-tile, two column tiles
+    (12, 64, 64, 256, 256, 3, 1, False),         # a residual-block shape on the direct path (OPT.winograd = 'off')
+    (11, 61, 63, 96, 256, 3, 1, True),           # ragged last M tile, run = 96: three 32-k slices per tap
+    (18, 33, 35, 32, 512, 1, 1, True),           # one K-tile, two column tiles
     (32, 32, 32, 256, 512, 4, 1, False),         # 4x4: 16 taps x 8 slices = 128 K-tiles
 ]
 
