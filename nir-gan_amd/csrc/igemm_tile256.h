@@ -49,8 +49,14 @@ __device__ __forceinline__ void t256_bar() {
 // A half 0 and B half 0 together in phase 1 and nothing in phase 4: the weight-gradient tile's 24 transposing reads of that phase, not
 // the 16 MFMAs of its partner wave, set the phase length -- 3 140 cycles per K-tile against 2 500 for the convolution tile).
 // In the last two K-tiles, where fewer than five younger halves exist, the waits drain (vmcnt(0)).
+#ifdef NG_DIAG_PHASES
+__device__ unsigned long long ng_phase_acc[8 * 8];        // [wave][segment] of block 0 (diagnostic build only)
+#endif
 template <class IA, class IB, class ADV, class RA, class RB, class MMA>
 __device__ __forceinline__ void t256_kloop(const int nk, const int wr, IA&& issueA, IB&& issueB, ADV&& advance, RA&& readA, RB&& readB, MMA&& mma) {
+#ifdef NG_DIAG_PHASES
+    unsigned long long ng_ph[5] = {0, 0, 0, 0, 0}, ng_pt;
+#endif
     // prologue: K-tile 0 whole, three halves of K-tile 1 (its A half 1 goes out in phase 1), then "phase -1.4": B half 0 of K-tile 0
     issueB(0, 0); issueA(0, 0); issueB(0, 1); issueA(0, 1);
     advance();
@@ -67,76 +73,48 @@ __device__ __forceinline__ void t256_kloop(const int nk, const int wr, IA&& issu
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     t256_bar();
     t256_bar();                               // (the empty MFMA segment of that phase: keeps the two wave groups half a phase apart)
+#ifdef NG_DIAG_PHASES
+    ng_pt = __builtin_amdgcn_s_memtime();
+#endif
     for (int k = 0; k < nk; k += 2) {
         // ======== K-tile k, buffer 0
         const bool more1 = k + 1 < nk, more2 = k + 2 < nk, more3 = k + 3 < nk;
-        // phase 1
-        readA(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more1) { issueA(1, 1); advance(); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t256_bar();
-        mma(0, 0);
-        t256_bar();
-        // phase 2
-        readB(1, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more2) { issueB(0, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t256_bar();
-        mma(0, 1);
-        t256_bar();
-        // phase 3
-        readA(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more2) { issueA(0, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t256_bar();
-        mma(1, 0);
-        t256_bar();
-        // phase 4
-        if (more1) readB(0, 1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more2) { issueB(0, 1); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t256_bar();
-        mma(1, 1);
-        t256_bar();
+        // (the LDS-DMA issued BEFORE the phase's fragment reads was measured: 3 150 against 3 010 cycles per K-tile for the weight-gradient
+        // tile, 2 810 against 2 575 for the convolution tile -- the reads' latency then shows at the head of the MFMA segment)
+#ifdef NG_DIAG_PHASES      // diagnostic build only: where a phase's cycles go (load segment, barrier, read wait, MFMA issue, barrier)
+#define T256_PS(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ng_ph[i] += t_ - ng_pt; ng_pt = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define T256_PS(i)
+#endif
+#define T256_PHASE(READS, COND, ISSUE, I, J)                                                          \
+        READS;                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (COND) { ISSUE; T256_PS(0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }             \
+        else { T256_PS(0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                          \
+        T256_PS(1)                                                                                    \
+        t256_bar();                                                                                   \
+        T256_PS(2)                                                                                    \
+        mma(I, J);                                                                                    \
+        T256_PS(3)                                                                                    \
+        t256_bar();                                                                                   \
+        T256_PS(4)
+        T256_PHASE(readA(0, 0), more1, issueA(1, 1); advance(), 0, 0)                  // phase 1
+        T256_PHASE(readB(1, 0, 1), more2, issueB(0, 0), 0, 1)                          // phase 2
+        T256_PHASE(readA(0, 1), more2, issueA(0, 0), 1, 0)                             // phase 3
+        T256_PHASE(if (more1) readB(0, 1, 0), more2, issueB(0, 1), 1, 1)               // phase 4
         if (!more1) break;
         // ======== K-tile k+1, buffer 1
-        // phase 5
-        readA(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more2) { issueA(0, 1); advance(); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t256_bar();
-        mma(0, 0);
-        t256_bar();
-        // phase 6
-        readB(1, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more3) { issueB(1, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t256_bar();
-        mma(0, 1);
-        t256_bar();
-        // phase 7
-        readA(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more3) { issueA(1, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t256_bar();
-        mma(1, 0);
-        t256_bar();
-        // phase 8
-        if (more2) readB(0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more3) { issueB(1, 1); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t256_bar();
-        mma(1, 1);
-        t256_bar();
+        T256_PHASE(readA(1, 0), more2, issueA(0, 1); advance(), 0, 0)                  // phase 5
+        T256_PHASE(readB(1, 1, 1), more3, issueB(1, 0), 0, 1)                          // phase 6
+        T256_PHASE(readA(1, 1), more3, issueA(1, 0), 1, 0)                             // phase 7
+        T256_PHASE(if (more2) readB(0, 0, 0), more3, issueB(1, 1), 1, 1)               // phase 8
+#undef T256_PHASE
+#undef T256_PS
     }
+#ifdef NG_DIAG_PHASES
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
+        for (int q = 0; q < 5; ++q) ng_phase_acc[(threadIdx.x >> 6) * 8 + q] = ng_ph[q];
+#endif
     if (wr == 0) t256_bar();                  // waves 0-3 wait for the staggered half: every fragment read and every DMA is done
 }
 

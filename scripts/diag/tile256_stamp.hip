@@ -63,5 +63,15 @@ int main(int argc, char** argv) {
         for (int q = 0; q < 4; ++q) printf("  %s %.0f", names[q], s[q] / cnt);
         printf("\n");
     }
+#ifdef NG_DIAG_PHASES
+    unsigned long long ph[64];
+    hipMemcpyFromSymbol(ph, HIP_SYMBOL(ng::ng_phase_acc), sizeof(ph));
+    const char* seg[5] = {"reads + DMA issue", "vmcnt wait", "barrier", "lgkm wait + 16 MFMAs", "barrier"};
+    for (int wv = 0; wv < 8; wv += 4) {
+        printf("block 0 wave %d, cycles per phase:", wv);
+        for (int q = 0; q < 5; ++q) printf("  %s %.0f", seg[q], double(ph[wv * 8 + q]) / double(36 * 4));
+        printf("\n");
+    }
+#endif
     return 0;
 }

@@ -37,12 +37,20 @@ def w6_tiles(d):
     return d.B * (-(-d.H // mo)) * (-(-d.W // mo))
 
 
+def kname(fn, *a):
+    from nirgan_hip import lib as L
+    be = L.backend()
+    k = getattr(be, fn)(*a) if hasattr(be, fn) else None
+    k = k.decode() if k else ""
+    return " [256-wide tile]" if "256" in k else ""
+
+
 def describe(name, args):
     if name == "nirgan_conv_igemm":
         d = args[0]._obj
         M = d.B * d.OH * d.OW
         blocks = -(-M // 128) * (-(-d.N // 128) if d.N > 64 else 1)
-        return f"conv M={M} N={d.N} K={d.ntaps}x{d.run} s{d.in_stride}/{d.out_stride} blk={blocks}" + (f" ksplit={d.ksplit}" if d.ksplit > 1 else ""), 2.0 * M * d.N * d.ntaps * d.run
+        return f"conv M={M} N={d.N} K={d.ntaps}x{d.run} s{d.in_stride}/{d.out_stride} blk={blocks}" + (f" ksplit={d.ksplit}" if d.ksplit > 1 else "") + kname("nirgan_conv_kernel_name", args[0]), 2.0 * M * d.N * d.ntaps * d.run
     if name == "nirgan_conv_igemm_group":
         ds = [args[0][i].contents for i in range(args[1])]
         fl = sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds)
@@ -55,7 +63,7 @@ def describe(name, args):
         K = w.ntaps * w.run
         npl = max(w.nplanes, 1)
         blocks = (-(-w.N // 128) if w.N > 64 else 1) * (-(-K // 128)) * w.nsplit * npl
-        return f"wgrad M={M} N={w.N} K={K} split={w.nsplit} planes={npl} blk={blocks}", 2.0 * npl * M * w.N * K
+        return f"wgrad M={M} N={w.N} K={K} split={w.nsplit} planes={npl} blk={blocks}" + kname("nirgan_wgrad_kernel_name", args[0]), 2.0 * npl * M * w.N * K
     if name == "nirgan_wino6_gemm_wgrad_pair":
         d, w = args[0]._obj, args[1]._obj
         T = w6_tiles(d)
@@ -73,7 +81,7 @@ def describe(name, args):
         Mc, Mw = c.B * c.OH * c.OW, w.B * w.OH * w.OW
         cb = -(-Mc // 128) * (-(-c.N // 128))
         wb = (-(-w.N // 128)) * (-(-(w.ntaps * w.run) // 128)) * w.nsplit
-        return f"pair Mc={Mc} N={c.N} K={c.ntaps*c.run} | Mw={Mw} split={w.nsplit} blk={cb}+{wb}", 2.0 * Mc * c.N * c.ntaps * c.run + 2.0 * Mw * w.N * w.ntaps * w.run
+        return f"pair Mc={Mc} N={c.N} K={c.ntaps*c.run} | Mw={Mw} split={w.nsplit} blk={cb}+{wb}" + kname("nirgan_conv_wgrad_pair_kernel_name", args[0], args[1]), 2.0 * Mc * c.N * c.ntaps * c.run + 2.0 * Mw * w.N * w.ntaps * w.run
     if name in ("nirgan_instnorm_fwd", "nirgan_instnorm_bwd"):
         d = args[0]._obj
         return f"{name[7:]} B={d.B} {d.H}x{d.W}x{d.C}", 0.0
