@@ -534,6 +534,7 @@ typedef struct {
 #define NIRGAN_W6_ONE_TILE 1
 #define NIRGAN_W6_PERSIST16 2
 #define NIRGAN_W6_DIRECT_TILE 3
+#define NIRGAN_W6_TILE256 4                 /* nirgan_wino6_gemm: the exact-fp32 256 x 256 eight-phase tile as persistent workgroups (A/B; K % 256 == 0, C % 32 == 0) */
 #define NIRGAN_W6_PATCH_PER_THREAD 16      /* nirgan_wino6_input*: F(6x6,3x3) patches one per thread (A/B; default for the plain / dY transforms: a wave per patch x 32 channels) */
 #define NIRGAN_W6_PATCH_PER_LANES 17       /* ... and the lane-spread form also for the normalising variant (default there: one per thread) */
 /* names of the kernels the two launchers above pick for a descriptor (what a profile of the launch shows) */

@@ -20,6 +20,7 @@
 //   G   = [[1/2,0,0],[1/6,1/6,1/6],[1/6,-1/6,1/6],[1/30,1/15,2/15],[16/15,-8/15,4/15],[0,0,1/2]]
 //   A^T = [[1,1,1,1,1,0],[0,1,-1,2,-1/2,0],[0,1,1,4,1/4,0],[0,1,-1,8,-1/8,1]]
 #include "igemm_tiles.h"
+#include "igemm_tile256.h"
 #include "instnorm_dev.h"
 #include <stdlib.h>
 
@@ -520,6 +521,19 @@ __global__ __launch_bounds__(256, 2) void wino6_gemm_kernel(const W6Gemm g) {
     const int plane = rid / g.per_plane, local = rid - plane * g.per_plane;
     ng::conv_tile<128, 0>(g.p, local, st0, st1, g.p.in + size_t(plane) * g.in_plane, g.p.w + size_t(plane) * g.w_plane,
                           g.p.out + size_t(plane) * g.out_plane);
+}
+
+// (round 4, A/B: NIRGAN_W6_TILE256) the plane GEMMs on the exact-fp32 form of the 256 x 256 eight-phase tile (igemm_tile256.h), persistent
+// workgroups, one per CU, walking (plane, tile) pairs: measured against wino6_gemm32p_kernel in profiles/r04_plane_gemm_tile256.txt
+__global__ __launch_bounds__(512, 2) void wino6_gemm256_kernel(const W6Gemm g, const int per_plane, const int total) {
+    __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
+    bool again = false;
+    for (int rid = ng_xcd_remap(blockIdx.x, gridDim.x); rid < total; rid += gridDim.x) {
+        if (again) ng::t256_bar();
+        const int plane = rid / per_plane, local = rid - plane * per_plane;
+        ng::conv_tile256<true>(g.p, local, lds, g.p.in + size_t(plane) * g.in_plane, g.p.w + size_t(plane) * g.w_plane, g.p.out + size_t(plane) * g.out_plane);
+        again = true;
+    }
 }
 
 // The data gradient's plane GEMMs and the 36 weight-gradient problems of the same layer in ONE grid (both read what the dY pass just
@@ -1450,6 +1464,7 @@ static W6Choice w6_gemm_choice(const nirgan_wino6_desc* d, bool pair) {
 
 extern "C" const char* nirgan_wino6_gemm_kernel_name(const nirgan_wino6_desc* d) {
     if (!d) return "";
+    if (d->algo == NIRGAN_W6_TILE256 && d->C % 32 == 0 && d->K % 256 == 0) return "wino6_gemm256_kernel";
     switch (w6_gemm_choice(d, false)) {
         case W6_PERSIST32: return "wino6_gemm32p_kernel";
         case W6_PERSIST16K: return "wino6_gemm16p_kernel";
@@ -1507,6 +1522,11 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
     const int rc0 = w6_gemm_params(d, g, T);
     if (rc0 != NIRGAN_OK) return rc0;
     const W6Choice ch = w6_gemm_choice(d, false);
+    if (d->algo == NIRGAN_W6_TILE256 && d->C % 32 == 0 && d->K % 256 == 0 && g.p.off32) {
+        const int per_plane = ((g.p.M + 255) >> 8) * (g.p.N >> 8), total = w6_np(w6_r(d->r)) * per_plane;
+        hipLaunchKernelGGL(wino6_gemm256_kernel, dim3(total < 256 ? total : 256), dim3(512), 0, static_cast<hipStream_t>(stream), g, per_plane, total);
+        return nirgan_check_launch("wino6_gemm (256-wide tile)");
+    }
     if (ch == W6_DIRECT) {
         hipLaunchKernelGGL(wino6_gemm_kernel, dim3(g.total), dim3(256), 0, static_cast<hipStream_t>(stream), g);
         return nirgan_check_launch("wino6_gemm");

@@ -1061,7 +1061,7 @@ def test_wino6_plane_gemm_stage_depths_agree(monkeypatch):
         zero = torch.zeros(64, device=DEV)
         outs = []
         names = []
-        for algo in (0, L.W6_PERSIST16, L.W6_ONE_TILE, L.W6_DIRECT_TILE):
+        for algo in (0, L.W6_PERSIST16, L.W6_ONE_TILE, L.W6_DIRECT_TILE, L.W6_TILE256):
             M = torch.full((64 * T * K,), float("nan"), device=DEV)
             d = L.Wino6Desc()
             d.r, d.B, d.H, d.W, d.C, d.K = 6, B, H, W, Cc, K
@@ -1071,7 +1071,8 @@ def test_wino6_plane_gemm_stage_depths_agree(monkeypatch):
             L.call("nirgan_wino6_gemm", C.byref(d), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             outs.append(M.clone())
-        assert names == ["wino6_gemm32p_kernel", "wino6_gemm16p_kernel", "wino6_gemm16_kernel", "wino6_gemm_kernel"], names
+        assert names == ["wino6_gemm32p_kernel", "wino6_gemm16p_kernel", "wino6_gemm16_kernel", "wino6_gemm_kernel",
+                         "wino6_gemm256_kernel" if K % 256 == 0 else "wino6_gemm32p_kernel"], names
         ref = torch.bmm(V.view(64, T, Cc).double(), U.view(64, K, Cc).double().transpose(1, 2)).float().reshape(-1)
         close(outs[0], ref, 2e-5, "32-k stages vs fp64")
         for o, n in zip(outs[1:], names[1:]):
