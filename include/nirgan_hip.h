@@ -151,6 +151,7 @@ typedef struct {
                                            * problems walk their units as persistent workgroups); NIRGAN_WGRAD_ONE_UNIT = one unit per workgroup */
 } nirgan_wgrad_desc;
 #define NIRGAN_WGRAD_ONE_UNIT 1
+#define NIRGAN_WGRAD_RING10 3    /* the 256-wide tile with an LDS ring of 10 half-tile slots (160 KB) instead of 8 (128 KB): A/B, no gain measured */
 #define NIRGAN_WGRAD_TILE128 2   /* bf16 twins: never the 256 x 256 x 64 eight-phase tile (persistent workgroups, one per CU), which is the
                                   * default for N % 256 == 0, ntaps * run % 256 == 0, OW % 64 == 0 or 64 % OW == 0, rows_per_split % 64 == 0 */
 
@@ -174,6 +175,12 @@ const char* nirgan_conv_wgrad_pair_kernel_name(const nirgan_conv_desc* c, const 
 /* dst[n*dst_row_stride + map[k]] (= | +=) sum_s slabs[s][n][k]  for map[k] >= 0 */
 int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,
                        float* dst, int64_t dst_elems, int dst_row_stride, int accumulate, void* stream);
+
+/* The slab sums of several weight gradients in one launch (the residual trunk's layers: launch latency for 31 MB each otherwise).
+ * jobs_device: njobs x 9 int64 in DEVICE memory: {slabs, dst, map, nsplit, N, K, dst_elems, dst_row_stride | (accumulate ? 1 << 32 : 0),
+ * first_block}; job j owns blocks [first_block_j, first_block_j + N_j * ceil(K_j / 256)); total_blocks = their sum; K % 4 == 0,
+ * slabs 16-byte aligned.  Same arithmetic and association as nirgan_reduce_rows job by job. */
+int nirgan_reduce_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
 
 /* dst[n][k] = map[k] >= 0 ? src[n*src_row_stride + map[k]] : 0   (weight packing) */
 int nirgan_pack_rows(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,

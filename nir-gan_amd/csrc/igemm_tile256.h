@@ -25,7 +25,8 @@
 namespace ng {
 
 constexpr int T256_HALF = 128 * 128;          // bytes of one half-tile image
-constexpr int T256_LDS = 8 * T256_HALF;       // 128 KB
+constexpr int T256_LDS = 8 * T256_HALF;       // 128 KB: the ring of 8 slots (and the epilogue's 8 wave-private staging areas)
+constexpr int T256_LDS10 = 10 * T256_HALF;    // 160 KB: the ring of 10 slots
 
 __device__ __forceinline__ void t256_bar() {
     __builtin_amdgcn_sched_barrier(0);
@@ -34,87 +35,105 @@ __device__ __forceinline__ void t256_bar() {
 }
 
 // The K loop of the eight-phase structure, shared by the convolution tile and the weight-gradient tile.  The callables work on the
-// caller's registers: issueA / issueB(buf, h) start the LDS-DMA of half h of the cursor's K-tile into buffer buf, advance() moves the
-// cursor to the next K-tile, readA(buf, h) / readB(which, buf, h) issue the fragment reads (B into register set `which`), mma(i, j)
-// waits for them and accumulates quadrant (i, j) from the A registers and B set j.
+// caller's registers: issueA / issueB(slot, h) start the LDS-DMA of half h (rows h * 128 .. of the tile) of the cursor's K-tile into
+// ring slot `slot`, advance() moves the cursor to the next K-tile, readA(slot) / readB(which, slot) issue the fragment reads (B into
+// register set `which`), mma(i, j) waits for them and accumulates quadrant (i, j) from the A registers and B set j.
 //
-// Schedule of K-tile k (buffer b = k & 1), one half-tile of LDS-DMA and one set of fragment reads per phase:
-//     phase   fragment reads        MFMA block      LDS-DMA issued     wait at the end of the phase's load segment
-//     k.1     A half 0 of k         C00 (A0 B0)     A half 1 of k+1    vmcnt(10): the half issued five phases ago has landed
-//     k.2     B half 1 of k         C01 (A0 B1)     B half 0 of k+2    vmcnt(10)
-//     k.3     A half 1 of k         C10 (A1 B0)     A half 0 of k+2    vmcnt(10)
-//     k.4     B half 0 of k+1       C11 (A1 B1)     B half 1 of k+2    vmcnt(10)
-// Every slot of the ring then lives one 8-phase period: issued, retired by the wait five phases later, read in the sixth phase,
-// restaged two phases after that read.  The fragment reads are spread 2 : 1 : 2 : 1 over the phases (the first form of this loop read
-// A half 0 and B half 0 together in phase 1 and nothing in phase 4: the weight-gradient tile's 24 transposing reads of that phase, not
-// the 16 MFMAs of its partner wave, set the phase length -- 3 140 cycles per K-tile against 2 500 for the convolution tile).
-// In the last two K-tiles, where fewer than five younger halves exist, the waits drain (vmcnt(0)).
-#ifdef NG_DIAG_PHASES
-__device__ unsigned long long ng_phase_acc[8 * 8];        // [wave][segment] of block 0 (diagnostic build only)
-#endif
-template <class IA, class IB, class ADV, class RA, class RB, class MMA>
-__device__ __forceinline__ void t256_kloop(const int nk, const int wr, IA&& issueA, IB&& issueB, ADV&& advance, RA&& readA, RB&& readB, MMA&& mma) {
-#ifdef NG_DIAG_PHASES
-    unsigned long long ng_ph[5] = {0, 0, 0, 0, 0}, ng_pt;
-#endif
-    // prologue: K-tile 0 whole, three halves of K-tile 1 (its A half 1 goes out in phase 1), then "phase -1.4": B half 0 of K-tile 0
-    issueB(0, 0); issueA(0, 0); issueB(0, 1); issueA(0, 1);
-    advance();
-    if (nk > 1) {
-        issueB(1, 0); issueA(1, 0); issueB(1, 1);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // B half 0 of K-tile 0
+// The half-tiles of the K loop form ONE sequence h = 4 k + {0: B half 0, 1: A half 0, 2: B half 1, 3: A half 1} of K-tile k, and the
+// LDS holds a ring of S slots of 16 KB, half h in slot h mod S.  Global phase g = 4 k + part does three things:
+//     fragment reads of half g + 1            (part 0: A half 0, 1: B half 1, 2: A half 1, 3: B half 0 of K-tile k + 1)
+//     16 MFMAs of quadrant part               (C00 = A0 B0, C01 = A0 B1, C10 = A1 B0, C11 = A1 B1)
+//     LDS-DMA of half g + S - 1 into the slot that half g - 1 left two phases ago, then vmcnt(2 (S - 3)): all but the S - 3 youngest
+//     halves have landed, i.e. half g + 2 -- read in the NEXT phase
+// Every slot lives one ring period: issued, retired by the wait S - 3 phases later, read in the phase after that, restaged two phases
+// after the read.  S = 8 (128 KB) keeps five halves in flight, S = 10 (all 160 KB of a CU's LDS) seven.  The weight-gradient tile
+// streams every operand byte from beyond L2 once (the convolution tile re-reads its patch nine times from L2) and takes 3 010 cycles
+// per K-tile against 2 690 with the operands pinned in L2 (profiles/r04_tile256_stamps.txt) -- but NOT for want of prefetch distance:
+// the ring of 10 measures 3 039 (profiles/r04_tile256_ring10.txt).  What the farther operand costs is the ISSUE of the LDS-DMA pieces
+// (the load segment's length), not the wait for them: the CU's outstanding-request capacity, not the ring, bounds what is in flight.
+// The slot numbers are literals: the loop is unrolled over lcm(4, S) phases (2 K-tiles for S = 8, 5 for S = 10).  The fragment reads are
+// spread 2 : 1 : 2 : 1 over the phases; the first form of this loop (round 4, first day) read A half 0 and B half 0 together and waited
+// vmcnt(6) once per K-tile.  In the last K-tiles, where fewer than S - 3 younger halves exist, the waits drain (vmcnt(0)).
+template <int S> __device__ __forceinline__ void t256_wait_ring() {
+    static_assert(S == 8 || S == 10, "ring of 8 or 10 half-tile slots");
+    if constexpr (S == 8) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+}
+
+template <int S, int G, class IA, class IB, class ADV, class RA, class RB, class MMA>
+__device__ __forceinline__ void t256_phase(const int k, const int nk, IA& issueA, IB& issueB, ADV& advance, RA& readA, RB& readB, MMA& mma) {
+    constexpr int part = G & 3;
+    constexpr int jr = (G + 1) & 3, sr = (G + 1) % S;                  // the half whose fragments this phase reads: type, slot
+    constexpr int ji = (G + S - 1) & 3, si = (G + S - 1) % S;          // the half this phase stages
+    if (k + (part + 1) / 4 < nk) {
+        if constexpr (jr == 0) readB(0, sr);
+        else if constexpr (jr == 1) readA(sr);
+        else if constexpr (jr == 2) readB(1, sr);
+        else readA(sr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (the LDS-DMA issued BEFORE the phase's fragment reads was measured: 3 150 against 3 010 cycles per K-tile for the weight-gradient
+    // tile, 2 810 against 2 575 for the convolution tile -- the reads' latency then shows at the head of the MFMA segment)
+    if (k + (part + S - 1) / 4 < nk) {
+        if constexpr (ji == 0) issueB(si, 0);
+        else if constexpr (ji == 1) issueA(si, 0);
+        else if constexpr (ji == 2) issueB(si, 1);
+        else { issueA(si, 1); advance(); }
+        t256_wait_ring<S>();
     } else {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    t256_bar();
+    mma(part >> 1, part & 1);
+    t256_bar();
+}
+
+// K-tiles KT .. of one unrolled period; returns when the K-tiles run out
+template <int S, int KT, class IA, class IB, class ADV, class RA, class RB, class MMA>
+__device__ __forceinline__ void t256_period(const int k0, const int nk, IA& issueA, IB& issueB, ADV& advance, RA& readA, RB& readB, MMA& mma) {
+    constexpr int KTS = (S == 8 ? 8 : 20) / 4;
+    if constexpr (KT < KTS) {
+        if (k0 + KT >= nk) return;
+        t256_phase<S, 4 * KT + 0>(k0 + KT, nk, issueA, issueB, advance, readA, readB, mma);
+        t256_phase<S, 4 * KT + 1>(k0 + KT, nk, issueA, issueB, advance, readA, readB, mma);
+        t256_phase<S, 4 * KT + 2>(k0 + KT, nk, issueA, issueB, advance, readA, readB, mma);
+        t256_phase<S, 4 * KT + 3>(k0 + KT, nk, issueA, issueB, advance, readA, readB, mma);
+        t256_period<S, KT + 1>(k0, nk, issueA, issueB, advance, readA, readB, mma);
+    }
+}
+
+template <int S, int H, class IA, class IB, class ADV>
+__device__ __forceinline__ void t256_prologue_issue(const int nk, IA& issueA, IB& issueB, ADV& advance) {
+    if constexpr (H < S - 1) {
+        if ((H >> 2) < nk) {
+            if constexpr ((H & 3) == 0) issueB(H, 0);
+            else if constexpr ((H & 3) == 1) issueA(H, 0);
+            else if constexpr ((H & 3) == 2) issueB(H, 1);
+            else { issueA(H, 1); advance(); }
+        }
+        t256_prologue_issue<S, H + 1>(nk, issueA, issueB, advance);
+    }
+}
+
+template <int S, class IA, class IB, class ADV, class RA, class RB, class MMA>
+__device__ __forceinline__ void t256_kloop(const int nk, const int wr, IA&& issueA, IB&& issueB, ADV&& advance, RA&& readA, RB&& readB, MMA&& mma) {
+    // prologue: halves 0 .. S - 2, then "phase -1": the fragment reads of half 0 (B half 0 of K-tile 0)
+    t256_prologue_issue<S, 0>(nk, issueA, issueB, advance);
+    const bool full = 4 * nk >= S - 1;        // all S - 1 halves exist: the counted waits apply
+    if (full) {
+        if constexpr (S == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // half 0: all but the S - 2 younger ones
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     t256_bar();                               // ... from every wave
     if (wr == 1) t256_bar();                  // the stagger: waves 4-7 run one barrier behind from here on
-    readB(0, 0, 0);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // A half 0 of K-tile 0
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    readB(0, 0);
+    if (full) t256_wait_ring<S>();            // half 1
     t256_bar();
     t256_bar();                               // (the empty MFMA segment of that phase: keeps the two wave groups half a phase apart)
-#ifdef NG_DIAG_PHASES
-    ng_pt = __builtin_amdgcn_s_memtime();
-#endif
-    for (int k = 0; k < nk; k += 2) {
-        // ======== K-tile k, buffer 0
-        const bool more1 = k + 1 < nk, more2 = k + 2 < nk, more3 = k + 3 < nk;
-        // (the LDS-DMA issued BEFORE the phase's fragment reads was measured: 3 150 against 3 010 cycles per K-tile for the weight-gradient
-        // tile, 2 810 against 2 575 for the convolution tile -- the reads' latency then shows at the head of the MFMA segment)
-#ifdef NG_DIAG_PHASES      // diagnostic build only: where a phase's cycles go (load segment, barrier, read wait, MFMA issue, barrier)
-#define T256_PS(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ng_ph[i] += t_ - ng_pt; ng_pt = t_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define T256_PS(i)
-#endif
-#define T256_PHASE(READS, COND, ISSUE, I, J)                                                          \
-        READS;                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        if (COND) { ISSUE; T256_PS(0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }             \
-        else { T256_PS(0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                          \
-        T256_PS(1)                                                                                    \
-        t256_bar();                                                                                   \
-        T256_PS(2)                                                                                    \
-        mma(I, J);                                                                                    \
-        T256_PS(3)                                                                                    \
-        t256_bar();                                                                                   \
-        T256_PS(4)
-        T256_PHASE(readA(0, 0), more1, issueA(1, 1); advance(), 0, 0)                  // phase 1
-        T256_PHASE(readB(1, 0, 1), more2, issueB(0, 0), 0, 1)                          // phase 2
-        T256_PHASE(readA(0, 1), more2, issueA(0, 0), 1, 0)                             // phase 3
-        T256_PHASE(if (more1) readB(0, 1, 0), more2, issueB(0, 1), 1, 1)               // phase 4
-        if (!more1) break;
-        // ======== K-tile k+1, buffer 1
-        T256_PHASE(readA(1, 0), more2, issueA(0, 1); advance(), 0, 0)                  // phase 5
-        T256_PHASE(readB(1, 1, 1), more3, issueB(1, 0), 0, 1)                          // phase 6
-        T256_PHASE(readA(1, 1), more3, issueA(1, 0), 1, 0)                             // phase 7
-        T256_PHASE(if (more2) readB(0, 0, 0), more3, issueB(1, 1), 1, 1)               // phase 8
-#undef T256_PHASE
-#undef T256_PS
-    }
-#ifdef NG_DIAG_PHASES
-    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0)
-        for (int q = 0; q < 5; ++q) ng_phase_acc[(threadIdx.x >> 6) * 8 + q] = ng_ph[q];
-#endif
+    constexpr int KTS = (S == 8 ? 8 : 20) / 4;
+    for (int k0 = 0; k0 < nk; k0 += KTS) t256_period<S, 0>(k0, nk, issueA, issueB, advance, readA, readB, mma);
     if (wr == 0) t256_bar();                  // waves 0-3 wait for the staggered half: every fragment read and every DMA is done
 }
 
@@ -130,7 +149,7 @@ __device__ __forceinline__ void t256_kloop(const int nk, const int wr, IA&& issu
 // wave (the same LDS-DMA pieces and fragment reads as in bf16) hides under 2 048 instead of 256 cycles of matrix work.  Fragments as in
 // conv_tile: one ds_read_b128 hands a lane 4 consecutive k of its row, lanes 0-31 chunk 2g, lanes 32-63 chunk 2g + 1, MFMA j of group g
 // contracts k = 8g + j and 8g + 4 + j.  `in_base / w_base / out_base`: base overrides for plane-batched launches (csrc/wino6.hip).
-template <bool F32 = false>
+template <bool F32 = false, int S = 8>
 __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, char* lds,
                                              const float* in_base = nullptr, const float* w_base = nullptr, float* out_base = nullptr) {
     const float* const p_in = in_base ? in_base : p.in;
@@ -178,16 +197,16 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
     };
     const char* const in8 = reinterpret_cast<const char*>(p_in);
     const char* const w8 = reinterpret_cast<const char*>(p_w);
-    auto issueA = [&](const int buf, const int h) {
+    auto issueA = [&](const int slot, const int h) {
         const int toff = __builtin_amdgcn_readlane(tapv, ct);
         const char* base = ng_uniform_ptr(in8 + (long long)(toff + cc) * ES);
-        char* dst = lds + (buf * 4 + h) * T256_HALF + wave * 2048;
+        char* dst = lds + slot * T256_HALF + wave * 2048;
         ng_glds16_so(base, a_boff[h][0], dst);
         ng_glds16_so(base, a_boff[h][1], dst + 1024);
     };
-    auto issueB = [&](const int buf, const int h) {
+    auto issueB = [&](const int slot, const int h) {
         const char* base = ng_uniform_ptr(w8 + (long long)(ct * p.run + cc) * ES);
-        char* dst = lds + (buf * 4 + 2 + h) * T256_HALF + wave * 2048;
+        char* dst = lds + slot * T256_HALF + wave * 2048;
         ng_glds16_so(base, b_boff[h][0], dst);
         ng_glds16_so(base, b_boff[h][1], dst + 1024);
     };
@@ -225,8 +244,8 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    auto readA = [&](const int buf, const int h) {
-        const char* s = lds + (buf * 4 + h) * T256_HALF;
+    auto readA = [&](const int slot) {
+        const char* s = lds + slot * T256_HALF;
         if constexpr (F32) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -240,8 +259,8 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
             }
         }
     };
-    auto readB = [&](const int which, const int buf, const int h) {
-        const char* s = lds + (buf * 4 + 2 + h) * T256_HALF;
+    auto readB = [&](const int which, const int slot) {
+        const char* s = lds + slot * T256_HALF;
         if constexpr (F32) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -281,7 +300,7 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
     };
 
     T256_STAMP(1)
-    t256_kloop(nk, wr, issueA, issueB, advance, readA, readB,
+    t256_kloop<S>(nk, wr, issueA, issueB, advance, readA, readB,
                [&](const int i, const int j) {         // (i, j are literals at every call site: the branches fold after inlining)
                    if (i == 0 && j == 0) mma(0, 0); else if (i == 0) mma(0, 1); else if (j == 0) mma(1, 0); else mma(1, 1);
                });
@@ -466,6 +485,7 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
 // 8 distinct 32-byte bank segments.  Q half j, LDS column x holds column j0 + (x >> 5) * 64 + j * 32 + (x & 31) of J (as the
 // convolution tile's B halves).  Host: OW % 64 == 0 or 64 % OW == 0, OH * OW % 64 == 0, rows_per_split % 64 == 0 -- a K-tile is a
 // fixed pattern of pixels relative to its first one, which walks in scalar registers.
+template <int S = 8>
 __device__ __forceinline__ void wgrad_tile256(const WgradParams& p, const int unit, char* lds) {
 #ifdef NG_DIAG256
     unsigned long long ng_t[8];
@@ -524,15 +544,15 @@ __device__ __forceinline__ void wgrad_tile256(const WgradParams& p, const int un
         }
         if (soh >= p.OH) { soh = 0; pcur += p_img_wrap; qcur += q_img_wrap; }
     };
-    auto issueA = [&](const int buf, const int h) {
+    auto issueA = [&](const int slot, const int h) {
         const char* base = ng_uniform_ptr(pcur);
-        char* dst = lds + (buf * 4 + h) * T256_HALF + wave * 2048;
+        char* dst = lds + slot * T256_HALF + wave * 2048;
         ng_glds16_so(base, p_boff[h][0], dst);
         ng_glds16_so(base, p_boff[h][1], dst + 1024);
     };
-    auto issueB = [&](const int buf, const int h) {
+    auto issueB = [&](const int slot, const int h) {
         const char* base = ng_uniform_ptr(qcur);
-        char* dst = lds + (buf * 4 + 2 + h) * T256_HALF + wave * 2048;
+        char* dst = lds + slot * T256_HALF + wave * 2048;
         ng_glds16_so(base, q_boff[h][0], dst);
         ng_glds16_so(base, q_boff[h][1], dst + 1024);
     };
@@ -551,11 +571,15 @@ __device__ __forceinline__ void wgrad_tile256(const WgradParams& p, const int un
     // register-only and would otherwise be hoisted over it), and only THEN joins the two 8-byte halves of an operand -- any register
     // copy the join needs happens after the data has arrived.  Offsets are 16-bit: buffer 1 reads through a second address (+ 64 KB).
     const unsigned lds0 = unsigned(size_t((NG_LDS char*)lds));
-    unsigned a_ad0[4], a_ad1[4], b_ad0[2], b_ad1[2];
+    constexpr int NW = (S * T256_HALF + 65535) / 65536;       // 64 KB windows of the ring (the instruction's offset field has 16 bits)
+    unsigned a_adw[4][NW], b_adw[2][NW];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) { a_ad0[mt] = lds0 + unsigned(a_ad[mt]); a_ad1[mt] = a_ad0[mt] + 65536u; }
+    for (int w_ = 0; w_ < NW; ++w_) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) { b_ad0[nt] = lds0 + unsigned(b_ad[nt]) + 32768u; b_ad1[nt] = b_ad0[nt] + 65536u; }
+        for (int mt = 0; mt < 4; ++mt) a_adw[mt][w_] = lds0 + unsigned(a_ad[mt]) + 65536u * w_;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b_adw[nt][w_] = lds0 + unsigned(b_ad[nt]) + 65536u * w_;
+    }
     s16x4 Ar[4][2][2], B0r[2][2][2], B1r[2][2][2];           // [tile][k-step][8-byte half]
     f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -567,32 +591,29 @@ __device__ __forceinline__ void wgrad_tile256(const WgradParams& p, const int un
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define T256_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-    auto readA = [&](const int buf, const int h) {
+    // (slot is a literal at every call site: the window and the offset fold)
+#define T256_TR4(R, ad, slot)                                                                                     \
+    switch ((slot) & 3) {                                                                                          \
+        case 0: T256_TR(R[0][0], ad, 0); T256_TR(R[0][1], ad, 1024); T256_TR(R[1][0], ad, 8192); T256_TR(R[1][1], ad, 8192 + 1024); break;                               \
+        case 1: T256_TR(R[0][0], ad, 16384); T256_TR(R[0][1], ad, 16384 + 1024); T256_TR(R[1][0], ad, 16384 + 8192); T256_TR(R[1][1], ad, 16384 + 8192 + 1024); break;   \
+        case 2: T256_TR(R[0][0], ad, 32768); T256_TR(R[0][1], ad, 32768 + 1024); T256_TR(R[1][0], ad, 32768 + 8192); T256_TR(R[1][1], ad, 32768 + 8192 + 1024); break;   \
+        default: T256_TR(R[0][0], ad, 49152); T256_TR(R[0][1], ad, 49152 + 1024); T256_TR(R[1][0], ad, 49152 + 8192); T256_TR(R[1][1], ad, 49152 + 8192 + 1024); break;  \
+    }
+    auto readA = [&](const int slot) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const unsigned ad = buf ? a_ad1[mt] : a_ad0[mt];
-            if (h == 0) {
-                T256_TR(Ar[mt][0][0], ad, 0);     T256_TR(Ar[mt][0][1], ad, 1024);
-                T256_TR(Ar[mt][1][0], ad, 8192);  T256_TR(Ar[mt][1][1], ad, 8192 + 1024);
-            } else {
-                T256_TR(Ar[mt][0][0], ad, 16384);        T256_TR(Ar[mt][0][1], ad, 16384 + 1024);
-                T256_TR(Ar[mt][1][0], ad, 16384 + 8192); T256_TR(Ar[mt][1][1], ad, 16384 + 8192 + 1024);
-            }
+            const unsigned ad = a_adw[mt][slot >> 2];
+            T256_TR4(Ar[mt], ad, slot)
         }
     };
-    auto readB = [&](s16x4 (&Bj)[2][2][2], const int buf, const int h) {
+    auto readB = [&](const int which, const int slot) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const unsigned ad = buf ? b_ad1[nt] : b_ad0[nt];
-            if (h == 0) {
-                T256_TR(Bj[nt][0][0], ad, 0);     T256_TR(Bj[nt][0][1], ad, 1024);
-                T256_TR(Bj[nt][1][0], ad, 8192);  T256_TR(Bj[nt][1][1], ad, 8192 + 1024);
-            } else {
-                T256_TR(Bj[nt][0][0], ad, 16384);        T256_TR(Bj[nt][0][1], ad, 16384 + 1024);
-                T256_TR(Bj[nt][1][0], ad, 16384 + 8192); T256_TR(Bj[nt][1][1], ad, 16384 + 8192 + 1024);
-            }
+            const unsigned ad = b_adw[nt][slot >> 2];
+            if (which == 0) { T256_TR4(B0r[nt], ad, slot) } else { T256_TR4(B1r[nt], ad, slot) }
         }
     };
+#undef T256_TR4
 #undef T256_TR
     auto join = [](const s16x4 lo, const s16x4 hi) -> bf16x8 {
         const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -613,9 +634,8 @@ __device__ __forceinline__ void wgrad_tile256(const WgradParams& p, const int un
     };
     T256_STAMP(1)
     if (nk > 0)
-        t256_kloop(nk, wr, issueA, issueB, advance, readA,
-                       [&](const int which, const int buf, const int h) { if (which == 0) readB(B0r, buf, h); else readB(B1r, buf, h); },
-                       [&](const int i, const int j) { if (j == 0) mma(acc[i][0], B0r); else mma(acc[i][1], B1r); });
+        t256_kloop<S>(nk, wr, issueA, issueB, advance, readA, readB,
+                      [&](const int i, const int j) { if (j == 0) mma(acc[i][0], B0r); else mma(acc[i][1], B1r); });
 
     T256_STAMP(2)
     T256_STAMP(3)

@@ -56,19 +56,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const ng::ConvP
 // others the weight-gradient units -- the host divides the CUs so that both kinds finish together (pair256_split): a data gradient over
 // the padded extent of the benchmark layer has 273 tiles, 1.07 rounds of the chip on its own.
 // Between two items of a workgroup one barrier: every wave has read its epilogue staging back before the next item's LDS-DMA lands.
+// S = slots of the weight-gradient tile's LDS ring: 8 = 128 KB (default); 10 = the CU's whole 160 KB, seven half-tiles in flight instead of
+// five (NIRGAN_WGRAD_RING10, A/B: measured 3 039 against 3 014 cycles per K-tile -- the deeper ring buys nothing, profiles/r04_tile256_ring10.txt)
+template <int S>
 __global__ __launch_bounds__(512, 2) void wgrad_igemm256_kernel(const ng::WgradParams p, const int units) {
-    __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
+    __shared__ __attribute__((aligned(16))) char lds[S * ng::T256_HALF];
     bool again = false;
     for (int u = ng_xcd_remap(blockIdx.x, gridDim.x); u < units; u += gridDim.x) {
         if (again) ng::t256_bar();
-        ng::wgrad_tile256(p, u, lds);
+        ng::wgrad_tile256<S>(p, u, lds);
         again = true;
     }
 }
 
+template <int S>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_pair256_kernel(const ng::ConvParams cp, const ng::WgradParams wp, const int conv_wgs,
                                                                      const int conv_tiles, const int wgrad_units) {
-    __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
+    __shared__ __attribute__((aligned(16))) char lds[S * ng::T256_HALF];
     bool again = false;
     if (int(blockIdx.x) < conv_wgs) {
         for (int t = ng_xcd_remap(blockIdx.x, conv_wgs); t < conv_tiles; t += conv_wgs) {
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pair256_kernel(const ng::Co
         const int y = int(gridDim.x) - conv_wgs;
         for (int u = ng_xcd_remap(int(blockIdx.x) - conv_wgs, y); u < wgrad_units; u += y) {
             if (again) ng::t256_bar();
-            ng::wgrad_tile256(wp, u, lds);
+            ng::wgrad_tile256<S>(wp, u, lds);
             again = true;
         }
     }
@@ -120,6 +124,55 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
         if (mk < 0) continue;
         const int64_t o = int64_t(n) * dst_row_stride + mk;
         if (o < dst_elems) dst[o] = accumulate ? dst[o] + s[j] : s[j];
+    }
+}
+
+// The slab sums of several layers in ONE launch (the residual trunk's weight gradients in the bf16 operand mode: twelve launches of 14 us
+// -- launch latency for 31 MB each -- become one at the memory rate).  jobs in device memory, 9 x int64 each:
+// {slabs, dst, map, nsplit, N, K, dst_elems, dst_row_stride | accumulate << 32, first_block}; job j owns blocks
+// [first_block_j, first_block_j + N_j * ceil(K_j / 256)).  Same arithmetic and association as reduce_rows_kernel.
+__global__ __launch_bounds__(256) void reduce_rows_batch_kernel(const long long* __restrict__ jobs, int njobs) {
+    __shared__ f32x4 part[4][64];
+    int j = 0;
+    for (int i = 1; i < njobs; ++i)
+        if (int(blockIdx.x) >= int(jobs[i * 9 + 8])) j = i;
+    const long long* J = jobs + j * 9;
+    const float* slabs = reinterpret_cast<const float*>(J[0]);
+    float* dst = reinterpret_cast<float*>(J[1]);
+    const int32_t* map = reinterpret_cast<const int32_t*>(J[2]);
+    const int nsplit = int(J[3]), N = int(J[4]), K = int(J[5]);
+    const long long dst_elems = J[6];
+    const int dst_row_stride = int(J[7] & 0xffffffffll), accumulate = int(J[7] >> 32);
+    const int kblocks = (K + 255) / 256;
+    const int local = int(blockIdx.x) - int(J[8]);
+    const int n = local / kblocks, kb = local - n * kblocks;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int k4 = (kb * 64 + lane) * 4;
+    const size_t total = size_t(N) * K;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (k4 < K) {
+        const float* src = slabs + size_t(n) * K + k4;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
+        int sp = grp;
+        for (; sp + 12 < nsplit; sp += 16) {
+            s += *reinterpret_cast<const f32x4*>(src + sp * total);
+            s1 += *reinterpret_cast<const f32x4*>(src + (sp + 4) * total);
+            s2 += *reinterpret_cast<const f32x4*>(src + (sp + 8) * total);
+            s3 += *reinterpret_cast<const f32x4*>(src + (sp + 12) * total);
+        }
+        for (; sp < nsplit; sp += 4) s += *reinterpret_cast<const f32x4*>(src + sp * total);
+        s = (s + s1) + (s2 + s3);
+    }
+    part[grp][lane] = s;
+    __syncthreads();
+    if (grp != 0 || k4 >= K) return;
+    s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int mk = map[k4 + q];
+        if (mk < 0) continue;
+        const long long o = (long long)n * dst_row_stride + mk;
+        if (o < dst_elems) dst[o] = accumulate ? dst[o] + s[q] : s[q];
     }
 }
 
@@ -212,9 +265,10 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     const int rc = ng::build_wgrad_params(d, p);
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (d->algo != NIRGAN_WGRAD_TILE128 && ng::wgrad_tile256_ok(p)) {
+    if (d->algo != NIRGAN_WGRAD_TILE128 && d->algo != NIRGAN_WGRAD_ONE_UNIT && ng::wgrad_tile256_ok(p)) {
         const int units = (p.N >> 8) * (p.K >> 8) * p.nsplit, G = ng_cu_count();
-        hipLaunchKernelGGL(wgrad_igemm256_kernel, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
+        if (d->algo == NIRGAN_WGRAD_RING10) hipLaunchKernelGGL(wgrad_igemm256_kernel<10>, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
+        else hipLaunchKernelGGL(wgrad_igemm256_kernel<8>, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
         return nirgan_check_launch("wgrad_igemm (256 x 256 tile)");
     }
     const dim3 grid(p.ntiles_n * p.ntiles_k * p.nsplit * p.nplanes);
@@ -253,7 +307,8 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp, true) && ng::wgrad_tile256_ok(wp)) {
         const int conv_tiles = ((cp.M + 255) >> 8) * (cp.N >> 8), units = (wp.N >> 8) * (wp.K >> 8) * wp.nsplit, G = ng_cu_count();
         const int conv_wgs = pair256_split(G, conv_tiles, cp.ntaps * (cp.run >> 6), units, wp.rows_per_split >> 6);
-        hipLaunchKernelGGL(conv_wgrad_pair256_kernel, dim3(G), dim3(512), 0, static_cast<hipStream_t>(stream), cp, wp, conv_wgs, conv_tiles, units);
+        if (w->algo == NIRGAN_WGRAD_RING10) hipLaunchKernelGGL(conv_wgrad_pair256_kernel<10>, dim3(G), dim3(512), 0, static_cast<hipStream_t>(stream), cp, wp, conv_wgs, conv_tiles, units);
+        else hipLaunchKernelGGL(conv_wgrad_pair256_kernel<8>, dim3(G), dim3(512), 0, static_cast<hipStream_t>(stream), cp, wp, conv_wgs, conv_tiles, units);
         return nirgan_check_launch("conv_wgrad_pair (256 x 256 tiles)");
     }
     const int conv_blocks = cp.mtiles * cp.ntiles;
@@ -294,6 +349,13 @@ extern "C" int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, 
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((K + 255) / 256, N), dim3(256), 0, static_cast<hipStream_t>(stream),
                        slabs, nsplit, N, K, map, dst, dst_elems, dst_row_stride, accumulate);
     return nirgan_check_launch("reduce_rows");
+}
+
+extern "C" int nirgan_reduce_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream) {
+    NG_REQUIRE(jobs_device && njobs >= 1 && njobs <= 64 && total_blocks >= 1, "reduce_rows_batch: bad arguments");
+    hipLaunchKernelGGL(reduce_rows_batch_kernel, dim3(total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(jobs_device), njobs);
+    return nirgan_check_launch("reduce_rows_batch");
 }
 
 static int pack_rows_impl(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,

@@ -144,7 +144,7 @@ class Wino6Desc(C.Structure):
 
 W6_ONE_TILE, W6_PERSIST16, W6_DIRECT_TILE, W6_TILE256 = 1, 2, 3, 4      # nirgan_wino6_desc.algo
 W6_PATCH_PER_THREAD, W6_PATCH_PER_LANES = 16, 17                                 # nirgan_wino6_desc.algo for the input transforms (A/B)
-WGRAD_ONE_UNIT, WGRAD_TILE128 = 1, 2                     # nirgan_wgrad_desc.algo
+WGRAD_ONE_UNIT, WGRAD_TILE128, WGRAD_RING10 = 1, 2, 3      # nirgan_wgrad_desc.algo
 CONV_TILE128, CONV_TILE256 = 1, 2                        # nirgan_conv_desc.algo
 
 
@@ -170,6 +170,7 @@ PROTOTYPES = {
     "nirgan_wgrad_kernel_name": (C.c_char_p, [C.POINTER(WgradDesc)]),
     "nirgan_conv_wgrad_pair_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc), C.POINTER(WgradDesc)]),
     "nirgan_reduce_rows": (i32, [fp, i32, i32, i32, fp, fp, i64, i32, i32, fp]),
+    "nirgan_reduce_rows_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_pack_rows": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_bf16": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_batch": (i32, [fp, i32, i32, fp]),

@@ -17,7 +17,7 @@ from . import geometry as G
 from . import lib as L
 from .options import OPT
 from .engine import (ConvIN, Ctx, Halo, Plan, SlabPool, TapPlaneConv, Weights, _Scratch, drop_dead_fp32_stores, emit_conv, grad_halo,
-                     emit_w6_deferred_finishes, emit_wgrad, wino_applicable)
+                     emit_deferred_reduce_rows, emit_w6_deferred_finishes, emit_wgrad, wino_applicable)
 
 
 def generator_layout(n_blocks: int) -> dict:
@@ -222,6 +222,7 @@ class GeneratorEngine(_Engine):
         dense = [Halo(ctx, B, H3, W3, c4, 0), Halo(ctx, B, H3, W3, c4, 0)] if self.blocks else []
         flip = 0
         ctx.w6_deferred = []      # collect the blocks' weight-gradient finishes
+        ctx.rr_deferred = []      # ... and, bf16 operand mode, their slab sums
         for j in range(len(self.blocks) - 1, -1, -1):
             i, c1, c2 = self.blocks[j]
             gq = grad_halo(ctx, B, H3, W3, c4, 1)
@@ -236,6 +237,7 @@ class GeneratorEngine(_Engine):
             c1.emit_bwd(b, pk, g=gq, g_fold=True, gw=GW(i, "conv_block.1.weight"), gb=GW(i, "conv_block.1.bias"), dgrad_out=gp)
             g_in, g_fold, g_skip = gp, True, skip_next
         emit_w6_deferred_finishes(b, ctx)         # the blocks' Winograd weight gradients: one inverse-transform launch for all of them
+        emit_deferred_reduce_rows(b, ctx)         # bf16 operand mode: the blocks' slab sums as one launch
         # data parallel: from here on the gradients of [first residual block .. last conv] are final (28 of 31 MB for 6 blocks)
         first_tail = f"model.{lay['blocks'][0]}.conv_block.1.weight" if self.blocks else f"model.{i0}.weight"
         self.bwd_tail = (len(b.ops), first_tail, f"model.{il}.bias")

@@ -3,6 +3,9 @@
 // K loop, statistics, epilogue -- and what clock does the chip hold (s_memtime against s_memrealtime).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/diag/tile256_stamp scripts/diag/tile256_stamp.hip
 #define NG_DIAG256 1
+#ifndef RING
+#define RING 8
+#endif
 #include "../../nir-gan_amd/csrc/igemm_tile256.h"
 #include <vector>
 #include <cstring>
@@ -11,8 +14,8 @@
 void nirgan_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); }
 
 __global__ __launch_bounds__(512, 2) void k(const ng::ConvParams p) {
-    __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
-    ng::conv_tile256<false>(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
+    __shared__ __attribute__((aligned(16))) char lds[RING * ng::T256_HALF];
+    ng::conv_tile256<false, RING>(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
 }
 
 static unsigned short bf16_of(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
@@ -63,15 +66,5 @@ int main(int argc, char** argv) {
         for (int q = 0; q < 4; ++q) printf("  %s %.0f", names[q], s[q] / cnt);
         printf("\n");
     }
-#ifdef NG_DIAG_PHASES
-    unsigned long long ph[64];
-    hipMemcpyFromSymbol(ph, HIP_SYMBOL(ng::ng_phase_acc), sizeof(ph));
-    const char* seg[5] = {"reads + DMA issue", "vmcnt wait", "barrier", "lgkm wait + 16 MFMAs", "barrier"};
-    for (int wv = 0; wv < 8; wv += 4) {
-        printf("block 0 wave %d, cycles per phase:", wv);
-        for (int q = 0; q < 5; ++q) printf("  %s %.0f", seg[q], double(ph[wv * 8 + q]) / double(36 * 4));
-        printf("\n");
-    }
-#endif
     return 0;
 }

@@ -2,6 +2,9 @@
 // 256 -> 256, 3x3), one unit per workgroup; argument = number of splits (units = 9 x splits).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/diag/wgrad256_stamp scripts/diag/wgrad256_stamp.hip
 #define NG_DIAG256 1
+#ifndef RING
+#define RING 8
+#endif
 #include "../../nir-gan_amd/csrc/igemm_tile256.h"
 #include <vector>
 #include <cstring>
@@ -10,8 +13,8 @@
 void nirgan_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fprintf(stderr, "\n"); }
 
 __global__ __launch_bounds__(512, 2) void k(const ng::WgradParams p, const int units) {
-    __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
-    for (int u = ng_xcd_remap(blockIdx.x, gridDim.x); u < units; u += gridDim.x) ng::wgrad_tile256(p, u, lds);
+    __shared__ __attribute__((aligned(16))) char lds[RING * ng::T256_HALF];
+    for (int u = ng_xcd_remap(blockIdx.x, gridDim.x); u < units; u += gridDim.x) ng::wgrad_tile256<RING>(p, u, lds);
 }
 
 static unsigned short bf16_of(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
@@ -61,15 +64,5 @@ int main(int argc, char** argv) {
         for (int q = 0; q < 4; ++q) printf("  %s %.0f", names[q], s[q] / cnt);
         printf("  (K loop per K-tile %.0f)\n", s[1] / cnt / (rows / 64));
     }
-#ifdef NG_DIAG_PHASES
-    unsigned long long ph[64];
-    hipMemcpyFromSymbol(ph, HIP_SYMBOL(ng::ng_phase_acc), sizeof(ph));
-    const char* seg[5] = {"reads + DMA issue", "vmcnt wait", "barrier", "lgkm wait + 16 MFMAs", "barrier"};
-    for (int wv = 0; wv < 8; wv += 4) {
-        printf("block 0 wave %d, cycles per phase:", wv);
-        for (int q = 0; q < 5; ++q) printf("  %s %.0f", seg[q], double(ph[wv * 8 + q]) / double((rows / 64) * 4));
-        printf("\n");
-    }
-#endif
     return 0;
 }

@@ -290,6 +290,18 @@ class EmuBackend:
         o[:] = np.where(ok[None, :], s[idx], 0.0)
         return 0
 
+    def nirgan_reduce_rows_batch(self, jobs, njobs, total_blocks, stream=None):
+        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 9)).from_address(int(jobs))).reshape(njobs, 9)
+        blocks = 0
+        for slabs, dst, imap, nsplit, N, K, dst_elems, stride, first in J:
+            if first != blocks:
+                return self._fail("reduce_rows_batch: first_block mismatch")
+            rc = self.nirgan_reduce_rows(int(slabs), int(nsplit), int(N), int(K), int(imap), int(dst), int(dst_elems), int(stride) & 0xffffffff, int(stride) >> 32)
+            if rc:
+                return rc
+            blocks += int(N) * ((int(K) + 255) // 256)
+        return 0 if blocks == total_blocks else self._fail("reduce_rows_batch: total_blocks mismatch")
+
     def nirgan_pack_rows_batch(self, jobs, njobs, total_blocks, stream=None):
         J = np.ctypeslib.as_array((C.c_int64 * (njobs * 8)).from_address(int(jobs))).reshape(njobs, 8)
         blocks = 0
