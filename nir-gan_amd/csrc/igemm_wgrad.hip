@@ -246,14 +246,15 @@ static int ng_cu_count() {
 }
 
 // Workgroups of the fused 256-wide launch that walk the data-gradient tiles (the rest walk weight-gradient units): the division that
-// minimises the longer of the two walks, an item costing its K-tiles + about 8 K-tiles' worth of prologue and epilogue.  Mirrored by
-// nirgan_hip/geometry.py::pair256_plan, which chooses the number of splits with the same cost.
+// minimises the longer of the two walks.  Mirrored by nirgan_hip/geometry.py::pair256_plan, which chooses the number of splits with the
+// same cost figures.
 static int pair256_split(const int G, const int conv_tiles, const int conv_nk, const int units, const int unit_nk) {
-    const long long E = 8;
+    // in tenths of a convolution K-tile (2 500 cycles): a weight-gradient K-tile costs 1.2 (3 010 cycles: every operand byte comes from beyond
+    // L2), a convolution tile 6.5 more for prologue + epilogue, a weight-gradient unit 4 (profiles/r04_tile256_stamps.txt)
     int best = 1;
     long long best_cost = -1;
     for (int x = 1; x < G; ++x) {
-        const long long c = (long long)((conv_tiles + x - 1) / x) * (conv_nk + E), w = (long long)((units + (G - x) - 1) / (G - x)) * (unit_nk + E);
+        const long long c = (long long)((conv_tiles + x - 1) / x) * (conv_nk * 10 + 65), w = (long long)((units + (G - x) - 1) / (G - x)) * (unit_nk * 12 + 40);
         const long long cost = c > w ? c : w;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = x; }
     }

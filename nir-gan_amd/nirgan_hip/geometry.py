@@ -199,7 +199,9 @@ def wgrad_split(M: int, tiles: int, target_blocks: int = 1024, row_mult: int = 3
 
 
 CUS = 256          # MI355X: the persistent 256-wide launches start one workgroup per CU (csrc/igemm_wgrad.hip::ng_cu_count)
-T256_FIXED = 8     # prologue + epilogue of one 256 x 256 item, in K-tiles (csrc/igemm_wgrad.hip::pair256_split uses the same figure)
+# cost figures of the 256-wide items in tenths of a convolution K-tile (csrc/igemm_wgrad.hip::pair256_split uses the same ones; measured,
+# profiles/r04_tile256_stamps.txt): convolution K-tile 10 (2 500 cycles) + 65 per tile, weight-gradient K-tile 12 (3 010 cycles) + 40 per unit
+T256_CONV_KT, T256_CONV_FIXED, T256_WGRAD_KT, T256_WGRAD_FIXED = 10, 65, 12, 40
 
 
 def wgrad256_ok(M: int, OH: int, OW: int, N: int, K: int, run: int) -> bool:
@@ -211,8 +213,8 @@ def wgrad256_ok(M: int, OH: int, OW: int, N: int, K: int, run: int) -> bool:
 def pair256_plan(M: int, units_per_split: int, conv_tiles: int = 0, conv_nk: int = 0, cus: int = CUS) -> Tuple[int, int]:
     """(nsplit, rows_per_split) of a weight gradient on the 256-wide persistent tiles, alone (conv_tiles = 0) or fused with the data
     gradient's conv_tiles tiles of conv_nk K-tiles each: the split count that minimises the longer walk -- data-gradient workgroups
-    ceil(conv_tiles / x) items, weight-gradient workgroups ceil(units / (cus - x)) units of M / 64 / nsplit K-tiles, every item + the
-    fixed part -- and, among equals, the fewest slabs."""
+    ceil(conv_tiles / x) items, weight-gradient workgroups ceil(units / (cus - x)) units of M / 64 / nsplit K-tiles, at the measured cost
+    figures above -- and, among equals, the fewest slabs."""
     kt = M // 64
     best = None
     for ns in range(1, min(kt, 64) + 1):
@@ -220,10 +222,11 @@ def pair256_plan(M: int, units_per_split: int, conv_tiles: int = 0, conv_nk: int
         if (ns - 1) * per >= kt:
             continue                                  # an empty last split
         units = units_per_split * ns
+        wcost = per * T256_WGRAD_KT + T256_WGRAD_FIXED
         if conv_tiles:
-            cost = min(max(-(-conv_tiles // x) * (conv_nk + T256_FIXED), -(-units // (cus - x)) * (per + T256_FIXED)) for x in range(1, cus))
+            cost = min(max(-(-conv_tiles // x) * (conv_nk * T256_CONV_KT + T256_CONV_FIXED), -(-units // (cus - x)) * wcost) for x in range(1, cus))
         else:
-            cost = -(-units // cus) * (per + T256_FIXED)
+            cost = -(-units // cus) * wcost
         if best is None or cost < best[0]:
             best = (cost, ns, per * 64)
     return best[1], best[2]
