@@ -176,10 +176,12 @@ const char* nirgan_conv_wgrad_pair_kernel_name(const nirgan_conv_desc* c, const 
 int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,
                        float* dst, int64_t dst_elems, int dst_row_stride, int accumulate, void* stream);
 
-/* The slab sums of several weight gradients in one launch (the residual trunk's layers: launch latency for 31 MB each otherwise).
- * jobs_device: njobs x 9 int64 in DEVICE memory: {slabs, dst, map, nsplit, N, K, dst_elems, dst_row_stride | (accumulate ? 1 << 32 : 0),
- * first_block}; job j owns blocks [first_block_j, first_block_j + N_j * ceil(K_j / 256)); total_blocks = their sum; K % 4 == 0,
- * slabs 16-byte aligned.  Same arithmetic and association as nirgan_reduce_rows job by job. */
+/* The slab sums of several weight gradients in one launch (a network's layers: launch latency for up to 31 MB each otherwise).
+ * jobs_device: njobs x 10 int64 in DEVICE memory: {slabs, dst, map, nsplit, N, K, dst_elems, dst_row_stride | (accumulate ? 1 << 32 : 0),
+ * first_block, taps}.  taps = 0: job j owns N_j * ceil(K_j / 256) blocks and scatters through map, the arithmetic and association of
+ * nirgan_reduce_rows.  taps = T > 0: the caller asserts map[t * Cin + c] == c * T + t (K = T * Cin, Cin % 64 == 0, T <= 16: the Conv2d
+ * weight's own layout [N][Cin][kh][kw], dst_row_stride >= Cin * T): job j owns N_j * Cin / 64 blocks which store 64 * T contiguous
+ * floats each (same sums, no 4-byte scatter).  total_blocks = the sum; K % 4 == 0, slabs 16-byte aligned. */
 int nirgan_reduce_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
 
 /* dst[n][k] = map[k] >= 0 ? src[n*src_row_stride + map[k]] : 0   (weight packing) */

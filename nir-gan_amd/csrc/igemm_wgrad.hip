@@ -127,32 +127,35 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
-// The slab sums of several layers in ONE launch (the residual trunk's weight gradients in the bf16 operand mode: twelve launches of 14 us
-// -- launch latency for 31 MB each -- become one at the memory rate).  jobs in device memory, 9 x int64 each:
-// {slabs, dst, map, nsplit, N, K, dst_elems, dst_row_stride | accumulate << 32, first_block}; job j owns blocks
-// [first_block_j, first_block_j + N_j * ceil(K_j / 256)).  Same arithmetic and association as reduce_rows_kernel.
+// The slab sums of several layers in ONE launch (a network's weight gradients: a dozen launches of 12-14 us -- launch latency for up to
+// 31 MB each -- become one at the memory rate).  jobs in device memory, 10 x int64 each:
+// {slabs, dst, map, nsplit, N, K, dst_elems, dst_row_stride | accumulate << 32, first_block, taps}.
+//   taps = 0: the general form, job j owns N_j * ceil(K_j / 256) blocks -- a block sums 256 consecutive k of one row n and scatters them
+//             through map (same arithmetic and association as reduce_rows_kernel);
+//   taps = T: the map is the Conv2d weight's own (t, c) -> c * T + t (K = T * Cin, Cin % 64 == 0, geometry.conv_fwd_pack): job j owns
+//             N_j * Cin / 64 blocks -- a block sums the T x 64 values of 64 input channels of one row n (T contiguous 256-byte pieces per
+//             slab), transposes them through LDS and stores 64 * T CONTIGUOUS floats of the gradient.  The scatter of the general form
+//             writes 4 bytes every 4 * T: the PMC counted 402 MB of write traffic for 42 MB of gradients (18 layers).
+// The splits are added in the same order either way: wave w takes splits w, w + 4, ... (four running sums), then wave 0 joins them.
 __global__ __launch_bounds__(256) void reduce_rows_batch_kernel(const long long* __restrict__ jobs, int njobs) {
-    __shared__ f32x4 part[4][64];
+    __shared__ f32x4 part[4][256];
+    __shared__ float tile[64 * 16];
     int j = 0;
     for (int i = 1; i < njobs; ++i)
-        if (int(blockIdx.x) >= int(jobs[i * 9 + 8])) j = i;
-    const long long* J = jobs + j * 9;
+        if (int(blockIdx.x) >= int(jobs[i * 10 + 8])) j = i;
+    const long long* J = jobs + j * 10;
     const float* slabs = reinterpret_cast<const float*>(J[0]);
     float* dst = reinterpret_cast<float*>(J[1]);
     const int32_t* map = reinterpret_cast<const int32_t*>(J[2]);
     const int nsplit = int(J[3]), N = int(J[4]), K = int(J[5]);
     const long long dst_elems = J[6];
     const int dst_row_stride = int(J[7] & 0xffffffffll), accumulate = int(J[7] >> 32);
-    const int kblocks = (K + 255) / 256;
+    const int taps = int(J[9]);
     const int local = int(blockIdx.x) - int(J[8]);
-    const int n = local / kblocks, kb = local - n * kblocks;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int k4 = (kb * 64 + lane) * 4;
     const size_t total = size_t(N) * K;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (k4 < K) {
-        const float* src = slabs + size_t(n) * K + k4;
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
+    auto sum_splits = [&](const float* src) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
         int sp = grp;
         for (; sp + 12 < nsplit; sp += 16) {
             s += *reinterpret_cast<const f32x4*>(src + sp * total);
@@ -161,8 +164,33 @@ __global__ __launch_bounds__(256) void reduce_rows_batch_kernel(const long long*
             s3 += *reinterpret_cast<const f32x4*>(src + (sp + 12) * total);
         }
         for (; sp < nsplit; sp += 4) s += *reinterpret_cast<const f32x4*>(src + sp * total);
-        s = (s + s1) + (s2 + s3);
+        return (s + s1) + (s2 + s3);
+    };
+    if (taps > 0) {
+        const int cin = K / taps, cb = cin >> 6;
+        const int n = local / cb, c0 = (local - n * cb) << 6;
+        const int nf = taps * 16;                                       // float4s of the block: tap t, channels c0 + 4 q .. + 3
+        for (int f = lane; f < nf; f += 64) {
+            const int t = f >> 4, q = f & 15;
+            part[grp][f] = sum_splits(slabs + size_t(n) * K + t * cin + c0 + q * 4);
+        }
+        __syncthreads();
+        for (int f = threadIdx.x; f < nf; f += 256) {
+            const int t = f >> 4, q = f & 15;
+            const f32x4 v = (part[0][f] + part[1][f]) + (part[2][f] + part[3][f]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(q * 4 + e) * taps + t] = v[e];
+        }
+        __syncthreads();
+        float* drow = dst + (long long)n * dst_row_stride + (long long)c0 * taps;
+        for (int i = threadIdx.x; i < 64 * taps; i += 256) drow[i] = accumulate ? drow[i] + tile[i] : tile[i];
+        return;
     }
+    const int kblocks = (K + 255) / 256;
+    const int n = local / kblocks, kb = local - n * kblocks;
+    const int k4 = (kb * 64 + lane) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (k4 < K) s = sum_splits(slabs + size_t(n) * K + k4);
     part[grp][lane] = s;
     __syncthreads();
     if (grp != 0 || k4 >= K) return;

@@ -350,9 +350,10 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
         nsplit, rows = (G.pair256_plan(M, (N // 256) * (K // 256), -(-(c.B * c.OH * c.OW) // 256) * (c.N // 256), c.ntaps * (c.run // 64)) if fused
                         else G.pair256_plan(M, (N // 256) * (K // 256)))
     need = nsplit * N * K
-    # deferred slab sums (ctx.rr_deferred is a list while a network collects the layers of its residual trunk, bf16 operand mode): the
-    # layer keeps its own slabs and all of them are summed by ONE launch behind the trunk (emit_deferred_reduce_rows)
-    deferred = getattr(ctx, "rr_deferred", None) if (pair_with is not None and twins and OPT.tile256) else None
+    # deferred slab sums (ctx.rr_deferred is a list while a network's backward plan is being built): the layer keeps its own slabs and all
+    # of them are summed by ONE launch at the plan's next flush point (emit_deferred_reduce_rows: where a data-parallel bucket is final,
+    # and at the end of the plan)
+    deferred = getattr(ctx, "rr_deferred", None)
     slabs = ctx.zeros(need) if deferred is not None else (slabs_pool.get(need) if slabs_pool is not None else ctx.zeros(need))
     ctx.keep.append(slabs)
     d = L.WgradDesc()
@@ -376,27 +377,34 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     else:
         plan.add("nirgan_wgrad_igemm", C.byref(d))
     if deferred is not None:
-        deferred.append((slabs, nsplit, N, K, imap, grad, spec.row_stride, 1 if accumulate else 0))
+        # the Conv2d weight's own layout: packed column t * Cin + c <-> gradient element c * T + t -- the batch launch then writes whole runs
+        T = taps.n
+        conv_layout = (spec.key[:1] == ("cf",) and taps.run % 64 == 0 and T <= 16 and spec.row_stride == taps.run * T and K == T * taps.run)
+        deferred.append((slabs, nsplit, N, K, imap, grad, spec.row_stride, 1 if accumulate else 0, T if conv_layout else 0))
         return d
     plan.add("nirgan_reduce_rows", slabs.data_ptr(), nsplit, N, K, imap.data_ptr(), grad.data_ptr(), grad.numel(),
              spec.row_stride, 1 if accumulate else 0)
     return d
 
 
-def emit_deferred_reduce_rows(plan: Plan, ctx: Ctx):
-    """ONE nirgan_reduce_rows_batch for the weight gradients collected in ctx.rr_deferred (up to 64 per launch): a single layer's slab sum
-    is 14 us of launch latency for 31 MB; twelve in one grid run at the memory rate."""
-    items, ctx.rr_deferred = (getattr(ctx, "rr_deferred", None) or []), None
+def emit_deferred_reduce_rows(plan: Plan, ctx: Ctx, last: bool = True):
+    """ONE nirgan_reduce_rows_batch for the weight gradients collected in ctx.rr_deferred since the last flush (up to 64 per launch): a
+    single layer's slab sum is 12-14 us of launch latency for up to 31 MB; a dozen in one grid run at the memory rate.  `last` ends the
+    collection (the end of the plan); otherwise the list stays open for the layers behind this flush point."""
+    if getattr(ctx, "rr_deferred", None) is None:
+        return
+    items = ctx.rr_deferred
+    ctx.rr_deferred = None if last else []
     for i0 in range(0, len(items), 64):
         part = items[i0:i0 + 64]
         if len(part) == 1:
-            slabs, nsplit, N, K, imap, grad, stride, acc = part[0]
+            slabs, nsplit, N, K, imap, grad, stride, acc, _ = part[0]
             plan.add("nirgan_reduce_rows", slabs.data_ptr(), nsplit, N, K, imap.data_ptr(), grad.data_ptr(), grad.numel(), stride, acc)
             continue
         rows, first = [], 0
-        for slabs, nsplit, N, K, imap, grad, stride, acc in part:
-            rows.append([slabs.data_ptr(), grad.data_ptr(), imap.data_ptr(), nsplit, N, K, grad.numel(), stride | (acc << 32), first])
-            first += N * ((K + 255) // 256)
+        for slabs, nsplit, N, K, imap, grad, stride, acc, T in part:
+            rows.append([slabs.data_ptr(), grad.data_ptr(), imap.data_ptr(), nsplit, N, K, grad.numel(), stride | (acc << 32), first, T])
+            first += N * ((K // T // 64) if T else ((K + 255) // 256))
         table = torch.tensor(rows, dtype=torch.int64).to(ctx.device)
         ctx.keep.append(table)
         plan.add("nirgan_reduce_rows_batch", table.data_ptr(), len(rows), first)

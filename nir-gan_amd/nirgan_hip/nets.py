@@ -200,6 +200,7 @@ class GeneratorEngine(_Engine):
         def GW(i, what="weight"):
             return gr[f"model.{i}.{what}"]
 
+        ctx.rr_deferred = [] if OPT.batch_reduce else None      # the weight gradients' slab sums are collected and run as one launch per flush point
         self.last.alloc_bwd()
         self.dpred = self.last.dout
         for layer in [self.L1]:
@@ -222,7 +223,6 @@ class GeneratorEngine(_Engine):
         dense = [Halo(ctx, B, H3, W3, c4, 0), Halo(ctx, B, H3, W3, c4, 0)] if self.blocks else []
         flip = 0
         ctx.w6_deferred = []      # collect the blocks' weight-gradient finishes
-        ctx.rr_deferred = []      # ... and, bf16 operand mode, their slab sums
         for j in range(len(self.blocks) - 1, -1, -1):
             i, c1, c2 = self.blocks[j]
             gq = grad_halo(ctx, B, H3, W3, c4, 1)
@@ -237,7 +237,7 @@ class GeneratorEngine(_Engine):
             c1.emit_bwd(b, pk, g=gq, g_fold=True, gw=GW(i, "conv_block.1.weight"), gb=GW(i, "conv_block.1.bias"), dgrad_out=gp)
             g_in, g_fold, g_skip = gp, True, skip_next
         emit_w6_deferred_finishes(b, ctx)         # the blocks' Winograd weight gradients: one inverse-transform launch for all of them
-        emit_deferred_reduce_rows(b, ctx)         # bf16 operand mode: the blocks' slab sums as one launch
+        emit_deferred_reduce_rows(b, ctx, last=False)     # the slab sums of every weight gradient so far (last layer, decoder, blocks) as one launch
         # data parallel: from here on the gradients of [first residual block .. last conv] are final (28 of 31 MB for 6 blocks)
         first_tail = f"model.{lay['blocks'][0]}.conv_block.1.weight" if self.blocks else f"model.{i0}.weight"
         self.bwd_tail = (len(b.ops), first_tail, f"model.{il}.bias")
@@ -251,6 +251,7 @@ class GeneratorEngine(_Engine):
             dz2 = self._emit_inject_bwd(b, g_a2)
             self.L2.emit_bwd(b, pk, g=dz2, gw=GW(4), gb=GW(4, "bias"), dgrad_out=g_a1, act=L.ACT_NONE)
         self.L1.emit_bwd(b, pk, g=g_a1, gw=GW(1), gb=GW(1, "bias"), dgrad_out=None)
+        emit_deferred_reduce_rows(b, ctx)         # the encoder's slab sums (the data-parallel head bucket)
 
     # ------------------------------------------------------------------ run
     def forward(self, rgb: torch.Tensor, embeds: Optional[torch.Tensor] = None, version: int = 0) -> torch.Tensor:
@@ -324,13 +325,17 @@ class DiscriminatorEngine(_Engine):
             if not frozen:   # live biases (first and last conv) accumulate with atomics
                 for k in ("model.0.bias", "model.11.bias"):
                     plan.add("nirgan_fill", gr[k].data_ptr(), gr[k].numel(), 0.0)
+                ctx.rr_deferred = [] if OPT.batch_reduce else None      # the weight gradients' slab sums: one launch per flush point
             self.C5.emit_bwd(plan, pk, GW(11), GW(11, "bias"))
             self.C4.emit_bwd(plan, pk, g=self.C5.gin, g_fold=False, gw=GW(8), gb=GW(8, "bias"), dgrad_out=self.g3p)
             if not frozen:   # data parallel: the two last layers' gradients (8.4 of 11 MB) are final here
+                emit_deferred_reduce_rows(plan, ctx, last=False)
                 self.bwd_tail = (len(plan.ops), "model.8.weight", "model.11.bias")
             self.C3.emit_bwd(plan, pk, g=self.g3p, g_fold=False, gw=GW(5), gb=GW(5, "bias"), dgrad_out=self.g2)
             self.C2.emit_bwd(plan, pk, g=self.g2, gw=GW(2), gb=GW(2, "bias"), dgrad_out=self.g1)
             self.C1.emit_bwd(plan, pk, g=self.g1, gw=GW(0), gb=GW(0, "bias"), dgrad_out=self.gx4 if mode == "input" else None)
+            if not frozen:
+                emit_deferred_reduce_rows(plan, ctx)
             if mode == "pred":
                 d = L.ChanDgradDesc()
                 dy, w = self.C1.dy, self.params["model.0.weight"]

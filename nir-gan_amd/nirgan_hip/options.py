@@ -47,6 +47,8 @@ class Options:
     fold_apply: bool = True
     # bf16 operand mode: the 256 x 256 x 64 eight-phase tiles (csrc/igemm_tile256.h) where they apply; False = the 128-row tiles (A/B)
     tile256: bool = True
+    # the slab sums of a backward plan's weight gradients as one launch per flush point (nirgan_reduce_rows_batch); False = one launch per layer
+    batch_reduce: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
     endconv_direct: bool = True
 

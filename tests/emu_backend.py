@@ -291,15 +291,20 @@ class EmuBackend:
         return 0
 
     def nirgan_reduce_rows_batch(self, jobs, njobs, total_blocks, stream=None):
-        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 9)).from_address(int(jobs))).reshape(njobs, 9)
+        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 10)).from_address(int(jobs))).reshape(njobs, 10)
         blocks = 0
-        for slabs, dst, imap, nsplit, N, K, dst_elems, stride, first in J:
+        for slabs, dst, imap, nsplit, N, K, dst_elems, stride, first, taps in J:
             if first != blocks:
                 return self._fail("reduce_rows_batch: first_block mismatch")
+            if taps:
+                cin = int(K) // int(taps)
+                m = arr(int(imap), int(K), np.int32)
+                if int(K) % int(taps) or cin % 64 or taps > 16 or not np.array_equal(m.reshape(int(taps), cin), np.arange(cin)[None, :] * int(taps) + np.arange(int(taps))[:, None]):
+                    return self._fail("reduce_rows_batch: taps given but the map is not (t, c) -> c * taps + t")
             rc = self.nirgan_reduce_rows(int(slabs), int(nsplit), int(N), int(K), int(imap), int(dst), int(dst_elems), int(stride) & 0xffffffff, int(stride) >> 32)
             if rc:
                 return rc
-            blocks += int(N) * ((int(K) + 255) // 256)
+            blocks += int(N) * ((int(K) // int(taps) // 64) if taps else ((int(K) + 255) // 256))
         return 0 if blocks == total_blocks else self._fail("reduce_rows_batch: total_blocks mismatch")
 
     def nirgan_pack_rows_batch(self, jobs, njobs, total_blocks, stream=None):

@@ -1374,3 +1374,31 @@ def test_wino6_input_transform_forms_agree_for_both_patch_sizes(case):
         res.append((V.cpu(), Yt.cpu()))
     assert torch.isfinite(res[0][0]).all() and torch.isfinite(res[0][1]).all()
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_reduce_rows_batch_equals_the_single_launches():
+    """nirgan_reduce_rows_batch: several weight gradients' slab sums in one launch -- the general form (any index map) and the Conv2d-layout
+    form (taps > 0: whole runs of the [N][Cin][kh][kw] gradient stored contiguously) -- bitwise equal to nirgan_reduce_rows job by job
+    (same split order), with and without accumulation, odd split counts."""
+    g = torch.Generator().manual_seed(13)
+    jobs, keep, refs, outs = [], [], [], []
+    first = 0
+    for (N, Cin, k, nsplit, acc, conv_layout) in ((256, 256, 3, 13, 0, True), (128, 64, 3, 5, 1, True), (64, 128, 4, 7, 0, True), (96, 36, 3, 4, 0, False), (256, 128, 3, 26, 1, False)):
+        spec = G.conv_fwd_pack(N, Cin, k) if conv_layout else G.convT_dgrad_pack(N, Cin, k)
+        K = spec.K
+        slabs = torch.randn(nsplit, N, K, generator=g).to(DEV)
+        imap = torch.from_numpy(spec.index_map).to(DEV)
+        base = torch.randn(N * spec.row_stride, generator=g).to(DEV)
+        ref, out = base.clone(), base.clone()
+        L.call("nirgan_reduce_rows", slabs.data_ptr(), nsplit, N, K, imap.data_ptr(), ref.data_ptr(), ref.numel(), spec.row_stride, acc, None)
+        T = k * k if conv_layout else 0
+        jobs.append([slabs.data_ptr(), out.data_ptr(), imap.data_ptr(), nsplit, N, K, out.numel(), spec.row_stride | (acc << 32), first, T])
+        first += N * ((Cin // 64) if T else ((K + 255) // 256))
+        keep += [slabs, imap]
+        refs.append(ref)
+        outs.append(out)
+    table = torch.tensor(jobs, dtype=torch.int64).to(DEV)
+    L.call("nirgan_reduce_rows_batch", table.data_ptr(), len(jobs), first, None)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(outs, refs)):
+        assert torch.equal(a, b), f"job {i}: batched slab sum differs from nirgan_reduce_rows (max {float((a - b).abs().max()):.3e})"
