@@ -10,8 +10,6 @@ set -o pipefail
 TAG=${1:-r04}
 export TMPDIR=/tmp
 R=$PWD/gpurun_out/refresh; rm -rf $R; mkdir -p $R
-timeout -k 10 400 python3 bench.py > $R/${TAG}_bench_final.json.log 2>&1 || exit 1
-echo bench done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt -- python3 bench.py --no-cpu-baseline --sustain 0 > $R/${TAG}_bench_under_rocprof.json.log 2>&1 || exit 2
 echo kernel trace done
 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/pmc1 -- python3 bench.py --no-cpu-baseline --no-probe --sustain 0 --steps 3 --warmup 1 > $R/pmc1.log 2>&1 || exit 3
@@ -19,6 +17,10 @@ timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/pmc2 -- p
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/pmc3 -- python3 bench.py --no-cpu-baseline --no-probe --sustain 0 --steps 3 --warmup 1 > $R/pmc3.log 2>&1 || exit 5
 echo pmc done
 python3 scripts/pmc_summary.py $R/pmc1 $R/pmc2 $R/pmc3 > $R/${TAG}_pmc_bench_summary.json || exit 6
+# the plain run LAST of the fp32 set, with the summary just recorded in place: its line replays traffic / MFMA busy of THIS build
+cp $R/${TAG}_pmc_bench_summary.json profiles/
+timeout -k 10 400 python3 bench.py > $R/${TAG}_bench_final.json.log 2>&1 || exit 1
+echo bench done
 cp $(find $R/kt -name "*kernel_stats.csv" | head -1) $R/${TAG}_bench_kernel_stats.csv || exit 7
 timeout -k 10 300 python3 scripts/profile_ops.py > $R/${TAG}_per_op_times.txt 2>&1
 # the drop-in API as Lightning drives it, and one rank over RCCL with the data-parallel check (cited by DESIGN.md sections 5 / 6)
