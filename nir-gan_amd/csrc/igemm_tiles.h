@@ -2,6 +2,7 @@
 // kernels and the horizontally fused data-gradient + weight-gradient launch), plus the
 // descriptor -> kernel-parameter translation with validation.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 // In-kernel stamps for the diagnostic build only (scripts/diag/conv_stamp.hip defines NG_DIAG); no stamp
@@ -476,16 +477,21 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
             }
     }
     __syncthreads();
-    {
-        constexpr int LPR = BN / 4;            // lanes per output row (float4 each)
+    // W output channels per lane: 4 (16 bytes of fp32), or 8 for a bf16 output (16 bytes again: the store path is bound by the NUMBER of
+    // store instructions -- the 8-byte stores of a bf16 output cost as many as the fp32 ones for half the bytes)
+    auto write_out = [&](auto wtag) {
+        constexpr int W = decltype(wtag)::value;
+        constexpr int LPR = BN / W;            // lanes per output row
         constexpr int RPP = 256 / LPR;         // rows per pass
+        typedef float fW __attribute__((ext_vector_type(W)));
+        typedef __bf16 bW __attribute__((ext_vector_type(W)));
         const int chunk = tid % LPR, row0 = tid / LPR;
-        const int n = n0 + chunk * 4;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        const int n = n0 + chunk * W;
+        fW bv = {};
         const bool to_ws = p.ksplit > 1;
         if (p.bias != nullptr && !to_ws) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = n + j < p.N ? p.bias[n + j] : 0.f;
+            for (int j = 0; j < W; ++j) bv[j] = n + j < p.N ? p.bias[n + j] : 0.f;
         }
         int m = m0 + row0;
         const int mc = m < p.M ? m : p.M - 1;
@@ -493,46 +499,43 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
         const int r0 = mc - b * p.OHW;
         int oh = r0 / p.OW, ow = r0 - oh * p.OW;
         const int OH = p.OHW / p.OW;
-        // fused first pass of the consumer layer's instance-norm backward: this thread's 4 channels over its rows of the tile (host:
+        // fused first pass of the consumer layer's instance-norm backward: this thread's W channels over its rows of the tile (host:
         // OHW % 128 == 0 -- one sample per tile -- and N % 4 == 0)
         const bool fused = p.f_y != nullptr;
         const int fb = m0 / p.OHW;
-        f32x4 fm = {0.f, 0.f, 0.f, 0.f}, fr = {1.f, 1.f, 1.f, 1.f}, s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        fW fm = {}, fr = {}, s1 = {}, s2 = {};
         if (fused && n < p.N) {
-            fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(fb) * p.N + n);
-            fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(fb) * p.N + n);
+            fm = *reinterpret_cast<const fW*>(p.f_mean + size_t(fb) * p.N + n);
+            fr = *reinterpret_cast<const fW*>(p.f_rstd + size_t(fb) * p.N + n);
         }
         const float fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
 #pragma unroll 4
         for (int row = row0; row < BM; row += RPP) {
             if (m < p.M && n < p.N) {
-                const float* src = reinterpret_cast<const float*>(row < 64 ? st0 : st1) + (row & 63) * BN + chunk * 4;
-                f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                const float* src = reinterpret_cast<const float*>(row < 64 ? st0 : st1) + (row & 63) * BN + chunk * W;
+                fW v = *reinterpret_cast<const fW*>(src);
                 v += bv;
                 const int oidx = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n;
                 float* dst = to_ws ? p.split_ws + ((size_t(ksp) * p.M + m) * p.N + n) : p_out + oidx;
-                if (p.out16) {                        // (host: N % 4 == 0, no split-K) four bf16, rounded to nearest even
-                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<unsigned short*>(p_out) + oidx) = __builtin_convertvector(v, bf16x4_t);
+                if constexpr (W == 8) {               // (host: out16, N % 8 == 0, no split-K) eight bf16, rounded to nearest even
+                    *reinterpret_cast<bW*>(reinterpret_cast<unsigned short*>(p_out) + oidx) = __builtin_convertvector(v, bW);
+                } else if (p.out16) {                 // (host: N % 4 == 0, no split-K) four bf16
+                    *reinterpret_cast<bW*>(reinterpret_cast<unsigned short*>(p_out) + oidx) = __builtin_convertvector(v, bW);
                 } else if (n + 4 <= p.N) {
-                    *reinterpret_cast<f32x4*>(dst) = v;
+                    *reinterpret_cast<fW*>(dst) = v;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < W; ++j)
                         if (n + j < p.N) dst[j] = v[j];
                 }
                 if (fused) {
                     const size_t yidx = size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n;
-                    f32x4 y4;
-                    if (p.f_y16) {
-                        typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-                        y4 = __builtin_convertvector(*reinterpret_cast<const bf16x4_t*>(reinterpret_cast<const unsigned short*>(p.f_y) + yidx), f32x4);
-                    } else {
-                        y4 = *reinterpret_cast<const f32x4*>(p.f_y + yidx);
-                    }
-                    const f32x4 z = (y4 - fm) * fr;
+                    fW y4;
+                    if (p.f_y16) y4 = __builtin_convertvector(*reinterpret_cast<const bW*>(reinterpret_cast<const unsigned short*>(p.f_y) + yidx), fW);
+                    else y4 = *reinterpret_cast<const fW*>(p.f_y + yidx);
+                    const fW z = (y4 - fm) * fr;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < W; ++j) {
                         const float gz = z[j] > 0.f ? v[j] : v[j] * fneg;
                         s1[j] += gz;
                         s2[j] += gz * z[j];
@@ -545,25 +548,29 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
             while (oh >= OH) { oh -= OH; ++b; }
         }
         if (fused) {
-            // the RPP threads of a channel quad join through LDS (the staged tile has been read), fixed order
+            // the RPP threads of a channel group join through LDS (the staged tile has been read), fixed order
             __syncthreads();
-            f32x4* red = reinterpret_cast<f32x4*>(st0);
+            fW* red = reinterpret_cast<fW*>(st0);
             red[tid * 2] = s1;
             red[tid * 2 + 1] = s2;
             __syncthreads();
             if (tid < LPR && n < p.N) {
-                f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+                fW t1 = {}, t2 = {};
 #pragma unroll 4
                 for (int r = 0; r < RPP; ++r) {
                     t1 += red[(r * LPR + tid) * 2];
                     t2 += red[(r * LPR + tid) * 2 + 1];
                 }
                 float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((m0 - fb * p.OHW) >> 7)) * 2 * p.N + n;
-                *reinterpret_cast<f32x4*>(pp) = t1;
-                *reinterpret_cast<f32x4*>(pp + p.N) = t2;
+                *reinterpret_cast<fW*>(pp) = t1;
+                *reinterpret_cast<fW*>(pp + p.N) = t2;
             }
         }
-    }
+    };
+    // eight channels per lane when the output is bf16, the tile's columns are whole (N % BN == 0: no partial channel group), every pixel's
+    // channel group is 16-byte aligned, and the fused sums' staging fits the first stage buffer (256 threads x 2 x 32 B = 16 KB)
+    if (p.out16 && p.N % BN == 0 && p.ksplit <= 1 && ((p.out_cs | p.out_org | p.out_row | p.out_img) & 7) == 0) write_out(std::integral_constant<int, 8>{});
+    else write_out(std::integral_constant<int, 4>{});
     NG_DIAG_STORE(p.dbg, block_id)
 }
 

@@ -40,6 +40,9 @@ int main() {
     d.B = B; d.OH = H; d.OW = H; d.N = N; d.zero_page = zero;
 #ifdef NGD_BF16
     d.precision = 1; d.w_bf16 = 1; d.in_bf16 = 1;
+#ifdef NGD_OUT16
+    d.out_bf16 = 1;                 // the output stored as bf16 (a y in front of an instance norm, a data gradient): same buffer, half used
+#endif
 #endif
     d.algo = NIRGAN_CONV_TILE128;
     ng::ConvParams p;
