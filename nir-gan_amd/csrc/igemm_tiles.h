@@ -15,6 +15,7 @@ __device__ __forceinline__ unsigned long long ng_stamp() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
+#define NG_DIAG_ENTRY const unsigned long long ng_entry = ng_stamp();
 #define NG_DIAG_DECL unsigned long long ng_t0 = ng_stamp(), ng_a = ng_t0, ng_wait = 0, ng_body = 0, ng_b = 0;
 #define NG_WAIT_BEGIN ng_a = ng_stamp();
 #define NG_WAIT_END ng_b = ng_stamp(); ng_wait += ng_b - ng_a; ng_a = ng_b;
@@ -24,9 +25,10 @@ __device__ __forceinline__ unsigned long long ng_stamp() {
         unsigned long long* o = (dbg) + (size_t(blk) * 4 + (threadIdx.x >> 6)) * 6;                         \
         const unsigned long long te = ng_stamp();                                                           \
         o[0] = ng_t0; o[1] = ng_loop_end; o[2] = te; o[3] = ng_wait; o[4] = ng_body;                        \
-        o[5] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                                        \
+        o[5] = ng_t0 - ng_entry;                              /* set-up: kernel entry to the first LDS-DMA issue */ \
     }
 #else
+#define NG_DIAG_ENTRY
 #define NG_DIAG_DECL
 #define NG_WAIT_BEGIN
 #define NG_WAIT_END
@@ -97,6 +99,7 @@ struct ConvParams {
 template <int BN, int PREC, bool WB16 = false, bool AB16 = false>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_id, char* st0, char* st1,
                                           const float* in_base = nullptr, const float* w_base = nullptr, float* out_base = nullptr) {
+    NG_DIAG_ENTRY
     // optional base overrides: a plane-batched launch (csrc/wino6.hip) runs many problems of one geometry from one parameter block
     const float* const p_in = in_base ? in_base : p.in;
     const float* const p_w = w_base ? w_base : p.w;

@@ -27,7 +27,10 @@ class Options:
     epilogue_stats: bool = True
     fuse_inbwd: bool = True
     epilogue_min_pixels: int = 16384
-    epilogue_min_pixels_bf16: int = 4096      # bf16 operand mode: its residual trunk runs on the direct tiles (64 x 64 maps): 1436 -> 1453 tiles/s
+    # bf16 operand mode: its residual trunk runs on the direct tiles (64 x 64 maps: 4096 measured 1436 -> 1453 tiles/s in round 3); 1024
+    # since the tiles' bf16 epilogue moves 16 bytes per lane (round 4: the 32 x 32 maps of the 128-pixel bucket and of the PatchGAN join:
+    # same-box A/B with bf16_store_min_tiles 100: 6-block +0.9 %, configs[4] mixed +2.3 %; 256 / 50 / 0 add nothing)
+    epilogue_min_pixels_bf16: int = 1024
     # the second pass of a residual-block layer's instance-norm backward evaluated inside the dY Winograd transform (lane-spread kernel):
     # dY is neither written nor read (nirgan_wino6_input_dy_norm)
     fuse_dy_norm: bool = True
@@ -40,7 +43,7 @@ class Options:
     bf16_g: bool = True
     # ... both only for launches of at least this many output tiles (below, choose_ksplit divides K and the tiles go through a workspace;
     # the tests set 0 to run small layers through the bf16 stores)
-    bf16_store_min_tiles: int = 400
+    bf16_store_min_tiles: int = 100
     # bf16 operand mode: activations / output gradients that every reader takes from the bf16 twin are stored as bf16 only
     bf16_twin_only: bool = True
     # a ResnetBlock's first InstanceNorm + ReLU + reflect pad evaluated inside the second convolution's input transform

@@ -67,10 +67,10 @@ int main() {
     double s[5] = {};
     for (int i = 0; i < nb * 4; ++i) {
         const unsigned long long* o = &r[i * 6];
-        s[0] += double(o[1] - o[0]); s[1] += double(o[2] - o[1]); s[2] += double(o[3]); s[3] += double(o[4]);
+        s[0] += double(o[1] - o[0]); s[1] += double(o[2] - o[1]); s[2] += double(o[3]); s[3] += double(o[4]); s[4] += double(o[5]);
     }
     const double n = nb * 4.0;
-    printf("per wave, 10 ns ticks: K loop %.0f (waits %.0f, bodies %.0f)  epilogue %.0f\n", s[0] / n, s[2] / n, s[3] / n, s[1] / n);
+    printf("per wave, cycles: set-up %.0f  K loop %.0f (waits %.0f, bodies %.0f)  epilogue %.0f\n", s[4] / n, s[0] / n, s[2] / n, s[3] / n, s[1] / n);
     for (int b : {0, 1, nb / 2}) {
         const unsigned long long* o = &r[size_t(b) * 24];
         printf("block %d wave0: start %llu loop %llu epi %llu wait %llu body %llu\n", b, o[0] - tmin, o[1] - o[0], o[2] - o[1], o[3], o[4]);

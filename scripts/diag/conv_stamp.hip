@@ -43,7 +43,7 @@ int main() {
     int cnt[2] = {};
     for (int i = 0; i < nb * 4; ++i) {
         const unsigned long long* o = &r[i * 6];
-        const int slot = int(o[5] & 15) & 1;
+        const int slot = 0;                 // (o[5] is the set-up time since round 4)
         s[slot][0] += double(o[1] - o[0]); s[slot][1] += double(o[2] - o[1]); s[slot][2] += double(o[3]); s[slot][3] += double(o[4]);
         s[slot][4] += double(o[0] - tmin);
         cnt[slot]++;
@@ -55,7 +55,7 @@ int main() {
     // one block's timeline
     for (int b : {0, 1, 600}) {
         const unsigned long long* o = &r[size_t(b) * 24];
-        printf("block %d wave0: start %llu loop %llu epi %llu wait %llu body %llu slot %llu\n", b, o[0] - tmin, o[1] - o[0], o[2] - o[1], o[3], o[4], o[5] & 15);
+        printf("block %d wave0: start %llu loop %llu epi %llu wait %llu body %llu set-up %llu\n", b, o[0] - tmin, o[1] - o[0], o[2] - o[1], o[3], o[4], o[5]);
     }
     return 0;
 }

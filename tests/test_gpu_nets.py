@@ -33,6 +33,7 @@ import pytest
 import torch
 
 import nirgan_oracle as O
+from nirgan_hip.options import OPT
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -776,7 +777,7 @@ def test_configs4_bf16_mixed_resolution_with_the_spectral_loss():
                 for k in ("loss_D", "loss_G", "loss_G_rs"):
                     close(out[k], o32[k], 1e-3, f"fp32 {k} bucket {i}")
                 continue
-            with O.operand_precision("bf16", y_bf16_min_pixels=4096, y_bf16_min_tiles=400, g_bf16_min_tiles=400):      # the build's storage rule for convolution outputs
+            with O.operand_precision("bf16", y_bf16_min_pixels=OPT.epilogue_min_pixels_bf16, y_bf16_min_tiles=OPT.bf16_store_min_tiles, g_bf16_min_tiles=OPT.bf16_store_min_tiles):      # the build's storage rule for convolution outputs
                 ref = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
                 o = ref.step(rgb, nir)
             assert float(ref.last["pred"].min()) > 0.3          # denominators pred + band stay away from 0
@@ -824,7 +825,7 @@ def test_configs4_bf16_with_the_spectral_loss_at_full_width():
         out = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
         ref32 = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
         ref32.step(rgb, nir)
-        with O.operand_precision("bf16", y_bf16_min_pixels=4096, y_bf16_min_tiles=400, g_bf16_min_tiles=400):      # the build's storage rule for convolution outputs
+        with O.operand_precision("bf16", y_bf16_min_pixels=OPT.epilogue_min_pixels_bf16, y_bf16_min_tiles=OPT.bf16_store_min_tiles, g_bf16_min_tiles=OPT.bf16_store_min_tiles):      # the build's storage rule for convolution outputs
             ref = O.OracleTrainer(sdG, sdD, nb, lr=0.0, lambda_rs=1.0, rs_weights=RS_W)
             o = ref.step(rgb, nir)
         assert float(ref.last["pred"].min()) > 0.3
