@@ -333,7 +333,7 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     assert K == spec.K, (K, spec.K)
     tiles = (-(-N // 128) if N > 64 else 1) * (-(-K // 128))
     M = p.B * OH * OW
-    target = 512         # blocks of a stand-alone launch: ONE round of the 512 slots (256 / 384 / 512 / 1024 / 2048: 765 / 759 / 789 / 782 / 771 tiles/s)
+    target = OPT.wgrad_target         # blocks of a stand-alone launch: ONE round of the 512 slots (256 / 384 / 512 / 1024 / 2048: 765 / 759 / 789 / 782 / 771 tiles/s)
     if pair_with is not None:
         c = pair_with
         conv_blocks = -(-(c.B * c.OH * c.OW) // 128) * (-(-c.N // 128) if c.N > 64 else 1)

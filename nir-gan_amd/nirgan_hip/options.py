@@ -52,6 +52,8 @@ class Options:
     tile256: bool = True
     # the slab sums of a backward plan's weight gradients as one launch per flush point (nirgan_reduce_rows_batch); False = one launch per layer
     batch_reduce: bool = True
+    # wanted workgroups of a stand-alone weight-gradient launch (the pixel range is split to reach it): one round of the 512 slots
+    wgrad_target: int = 512
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
     endconv_direct: bool = True
 
