@@ -1048,6 +1048,56 @@ def test_conv_epilogue_takes_the_instance_norm_backward_first_pass(case):
     close(outs[0], outs[1], 2e-5, "dy with the sums from the epilogue")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 16, 64, 64), (2, 32, 32, 64, 128), (3, 16, 16, 128, 64)])
+def test_conv_epilogue_first_pass_with_bf16_output(case):
+    """The same fused first pass when the launch stores its output as bf16 and reads a bf16 y (bf16 operand mode: nirgan_conv_desc.out_bf16,
+    fuse_y_bf16): the 128-row tile's epilogue then hands a lane EIGHT channels (16-byte stores and y loads).  Against the fp32-output form
+    of the same launch (four channels per lane): the stored gradient is bitwise the rounding of the fp32 store, the partial sums -- taken
+    from the fp32 accumulators either way, by different threads in a different row order -- agree to fp32 rounding."""
+    B, H, W, Cin, N = case
+    gen = torch.Generator().manual_seed(37)
+    ctx = Ctx(DEV, "bf16")
+    k = 3
+    y = (torch.randn(B, H, W, N, generator=gen) * 1.5 + 0.3).to(DEV).to(torch.bfloat16)
+    yf = y.float()
+    mean = yf.mean((1, 2)).contiguous()
+    rstd = (1.0 / torch.sqrt(yf.var((1, 2), unbiased=False) + 1e-5)).contiguous()
+    x = Halo(ctx, B, H, W, Cin, 1, twin=True)
+    xv = torch.randn(x.t.shape, generator=gen).to(DEV)
+    x.t.copy_(xv)
+    x.t16.copy_(xv.to(torch.bfloat16))
+    spec = G.conv_fwd_pack(N, Cin, k)
+    w = (torch.randn(N, Cin, k, k, generator=gen) * 0.05).to(DEV)
+    wp = torch.zeros(spec.N, spec.K, device=DEV, dtype=torch.bfloat16)
+    L.call("nirgan_pack_rows_bf16", w.data_ptr(), w.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), wp.data_ptr(), spec.N, spec.K, None)
+    chunks = H * W // 128
+    res = []
+    for out16 in (True, False):
+        g = Halo(ctx, B, H, W, N, 1, bf16=out16)
+        part = ctx.zeros(B * chunks * 2 * N)
+        d = emit_conv(None, ctx, x, G.conv_fwd_taps(k, Cin), wp, None, g, N=N, OH=H, OW=W, out_oh=1, out_ow=1, allow_split=False)
+        assert d.in_bf16 == 1 and d.w_bf16 == 1 and d.out_bf16 == (1 if out16 else 0)
+        d.algo = L.CONV_TILE128
+        d.fuse_y, d.fuse_y_bf16, d.fuse_mean, d.fuse_rstd = y.data_ptr(), 1, mean.data_ptr(), rstd.data_ptr()
+        d.fuse_h, d.fuse_w, d.fuse_oh, d.fuse_ow = H, W, 0, 0
+        d.fuse_act, d.fuse_slope = L.ACT_RELU, 0.2
+        d.fuse_part, d.fuse_part_elems, d.fuse_chunk0, d.fuse_chunks = part.data_ptr(), part.numel(), 0, chunks
+        L.call("nirgan_conv_igemm", C.byref(d), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res.append((g.t[:, 1:-1, 1:-1].clone(), part.view(B, chunks, 2, N).clone()))
+    (g16, p16), (g32, p32) = res
+    assert g16.dtype == torch.bfloat16 and torch.equal(g16, g32.to(torch.bfloat16)), "the bf16 store is not the rounding of the fp32 store"
+    scale = p32.abs().max().item()
+    assert (p16 - p32).abs().max().item() < 1e-5 * scale, f"partial sums differ by {(p16 - p32).abs().max().item():.3e} at scale {scale:.3e}"
+    # and against torch on the fp32 gradient
+    z = (yf - mean[:, None, None]) * rstd[:, None, None]
+    gz = torch.where(z > 0, g32.double(), torch.zeros((), dtype=torch.float64, device=DEV))
+    tot = p16.double().sum(1)
+    ref_scale = gz.abs().sum((1, 2)).max().item()
+    assert (tot[:, 0] - gz.sum((1, 2))).abs().max().item() < 4e-6 * ref_scale
+    assert (tot[:, 1] - (gz * z.double()).sum((1, 2))).abs().max().item() < 8e-6 * ref_scale
+
+
 def test_wino6_plane_gemm_stage_depths_agree(monkeypatch):
     """The plane GEMM kernels a descriptor can select (nirgan_wino6_desc.algo): persistent workgroups on 32-k stages (default) and on
     16-k stages, one tile per workgroup, the direct convolution tile -- the same products in the same k order: equal to fp32 rounding
