@@ -28,7 +28,7 @@ from model.generator_inject import define_G_inject as ref_define_G_inject  # noq
 from utils.remote_sensing_indices import RemoteSensingIndices as RefRS  # noqa: E402
 import nirgan_oracle as O                                               # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("NIRGAN_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))      # (another directory: regenerate and diff against the committed set)
 os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(4)
 
