@@ -198,6 +198,9 @@ __device__ __forceinline__ void conv_tile256(const ConvParams& p, const int id, 
     const char* const in8 = reinterpret_cast<const char*>(p_in);
     const char* const w8 = reinterpret_cast<const char*>(p_w);
     auto issueA = [&](const int slot, const int h) {
+#ifdef NG_DIAG_SHARE_A          // diagnostic build only (wrong results): the A stage of tap dw = 0 stands for the taps dw = 1, 2 of its kernel row --
+        if (ct % 3 != 0) return; // an upper bound of what one A stage per kernel row would buy the K loop
+#endif
         const int toff = __builtin_amdgcn_readlane(tapv, ct);
         const char* base = ng_uniform_ptr(in8 + (long long)(toff + cc) * ES);
         char* dst = lds + slot * T256_HALF + wave * 2048;
