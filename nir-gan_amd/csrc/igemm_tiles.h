@@ -189,6 +189,9 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, const int block_i
             const char* bb = ng_uniform_ptr(reinterpret_cast<const char*>(p_w) + (long long)(t * p.run + c0) * ESB);
 #pragma unroll
             for (int i = 0; i < AIW; ++i) ng_glds16_so(ab, a_boff[i], sA + (wave * 4 + i) * 1024);
+#ifdef NG_DIAG_SKIP_B            // diagnostic build only (wrong results): the weight tile is staged for the first K-step only -- what do its pieces cost?
+            if (t != 0 || c0 != 0) return;
+#endif
 #pragma unroll
             for (int i = 0; i < BIW; ++i) ng_glds16_so(bb, b_boff[i], sB + (wave * (WB16 ? BIW : BI) + i) * 1024);
             return;
