@@ -116,6 +116,12 @@ typedef struct {
      * eight waves per CU, LDS-DMA in flight across the barriers), everything else on the 128-row tile; NIRGAN_CONV_TILE128 = always the
      * 128-row tile; NIRGAN_CONV_TILE256 = the 256-wide tile also for exact-fp32 problems.  Results differ by fp32 summation order only. */
     int algo;
+    /* precision 3 -- fp32-EQUIVALENT on the bf16 matrix pipe (round 5): every fp32 operand is split into three bf16 terms h + m + l (exact)
+     * and a product is contracted as the six bf16 products down to 2^-16 of the leading one (dropped: <= 2^-24 |a b|), fp32 accumulate;
+     * buffers, results and tolerances are those of precision 0.  The activations are split inside the kernel (fp32 `in` as in every
+     * mode); the packed weights come as three bf16 planes written by nirgan_split3 from `w`: w_x3 = plane h, planes m and l follow
+     * w_x3_plane bf16 elements apart.  Problems the split tile does not cover (run % 32, N % 64, split-K, no w_x3) run as precision 0. */
+    const void* w_x3; int64_t w_x3_plane;
 } nirgan_conv_desc;
 #define NIRGAN_CONV_TILE128 1
 #define NIRGAN_CONV_TILE256 2   /* exact-fp32 problems (N % 256 == 0, run % 32 == 0, >= 128 tiles) on the 256-wide tile too (A/B: within 1 % of the 128-row tile) */
@@ -195,6 +201,11 @@ int nirgan_pack_rows_bf16(const float* src, int64_t src_elems, int src_row_strid
  * {src, dst, map, src_elems, N, K, src_row_stride | (bf16 destination ? 1 << 32 : 0), first_block}; job j owns blocks
  * [first_block_j, first_block_j + N_j * ceil(K_j / 1024)); total_blocks = their sum. */
 int nirgan_pack_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
+
+/* precision 3 (nirgan_conv_desc.w_x3): n fp32 values -> three bf16 planes dst[0..n), dst[plane..), dst[2 plane..) with
+ * src = h + m + l exactly, each term the round-to-nearest-even bf16 of what the previous ones left.  n % 8 == 0, plane >= n, plane % 8 == 0.
+ * Runs once per optimizer step on the packed weights of the layers that take the split tile (model/networks.py:349,360-363,559-574). */
+int nirgan_split3(const float* src, void* dst_bf16, int64_t n, int64_t plane, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * InstanceNorm2d(affine=False, eps) + activation + residual + halo write, forward.

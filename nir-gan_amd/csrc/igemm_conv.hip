@@ -14,6 +14,7 @@
 //   (4096 cycles) of step s.  Out-of-range rows/channels read a zero page.
 #include "igemm_tiles.h"
 #include "igemm_tile256.h"
+#include "igemm_x3.h"
 
 namespace {
 
@@ -29,6 +30,27 @@ template <bool F32>
 __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ng::ConvParams p) {
     __shared__ __attribute__((aligned(16))) char lds[ng::T256_LDS];
     ng::conv_tile256<F32>(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
+}
+
+// precision 3 (igemm_x3.h): fp32 operands as three bf16 terms, six bf16 products -- 256 x BN x 32 tile, one workgroup of eight waves per CU
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_x3_kernel(const ng::ConvParams p) {
+    __shared__ __attribute__((aligned(16))) char sA0[ng::X3_A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sA1[ng::X3_A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sB0[3 * BN * 64];
+    __shared__ __attribute__((aligned(16))) char sB1[3 * BN * 64];
+    ng::conv_tile_x3<BN>(p, ng_xcd_remap(blockIdx.x, gridDim.x), sA0, sA1, sB0, sB1);
+}
+
+// fp32 -> three bf16 planes h, m, l with x = h + m + l exactly (each term the RNE bf16 of what the previous ones left)
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, const long long n, const long long plane) {
+    const long long i = (blockIdx.x * 256ll + threadIdx.x) * 8;
+    if (i >= n) return;
+    ng::bf16x8 H, M, L;
+    ng::x3_split8(*reinterpret_cast<const f32x4*>(src + i), *reinterpret_cast<const f32x4*>(src + i + 4), H, M, L);
+    *reinterpret_cast<ng::bf16x8*>(dst + i) = H;
+    *reinterpret_cast<ng::bf16x8*>(dst + plane + i) = M;
+    *reinterpret_cast<ng::bf16x8*>(dst + 2 * plane + i) = L;
 }
 
 // split-K second stage: out(m, n) = bias[n] + sum_s ws[s][m][n], written with the descriptor's output geometry
@@ -72,13 +94,48 @@ __global__ __launch_bounds__(256, 2) void conv_group_kernel(const ConvGroup g) {
     else ng::conv_tile<BN, PREC, WB16, AB16>(g.p[3], bid - g.first[3], st0, st1);
 }
 
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_group_x3_kernel(const ConvGroup g) {
+    __shared__ __attribute__((aligned(16))) char sA0[ng::X3_A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sA1[ng::X3_A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sB0[3 * BN * 64];
+    __shared__ __attribute__((aligned(16))) char sB1[3 * BN * 64];
+    const int bid = ng_xcd_remap(blockIdx.x, gridDim.x);
+    int k = 0;
+    if (bid >= g.first[1]) k = 1;
+    if (bid >= g.first[2]) k = 2;
+    if (bid >= g.first[3]) k = 3;
+    if (k == 0) ng::conv_tile_x3<BN>(g.p[0], bid, sA0, sA1, sB0, sB1);
+    else if (k == 1) ng::conv_tile_x3<BN>(g.p[1], bid - g.first[1], sA0, sA1, sB0, sB1);
+    else if (k == 2) ng::conv_tile_x3<BN>(g.p[2], bid - g.first[2], sA0, sA1, sB0, sB1);
+    else ng::conv_tile_x3<BN>(g.p[3], bid - g.first[3], sA0, sA1, sB0, sB1);
+}
+
 }  // namespace
+
+extern "C" int nirgan_split3(const float* src, void* dst_bf16, int64_t n, int64_t plane, void* stream) {
+    NG_REQUIRE(src && dst_bf16 && n > 0 && n % 8 == 0 && plane >= n && plane % 8 == 0, "split3: n and plane must be positive multiples of 8, plane >= n");
+    NG_REQUIRE(ng_aligned16(src) && ng_aligned16(dst_bf16), "split3: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       src, static_cast<unsigned short*>(dst_bf16), (long long)n, (long long)plane);
+    return nirgan_check_launch("split3");
+}
 
 extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
     ng::ConvParams p;
     const int rc = ng::build_conv_params(d, p);
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p.prec == 3) {
+        if (ng::conv_x3_ok(p)) {
+            const int bn = ng::conv_x3_bn(p);
+            const dim3 grid(((p.M + 255) >> 8) * (p.N / bn));
+            if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, p);
+            else hipLaunchKernelGGL(conv_x3_kernel<64>, grid, dim3(512), 0, st, p);
+            return nirgan_check_launch("conv_igemm (three-term split tile)");
+        }
+        p.prec = 0;             // what the split tile does not cover runs as exact fp32
+    }
     if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) {
         if (p.prec == 0) hipLaunchKernelGGL(conv_igemm256_kernel<true>, dim3(((p.M + 255) >> 8) * (p.N >> 8)), dim3(512), 0, st, p);
         else hipLaunchKernelGGL(conv_igemm256_kernel<false>, dim3(((p.M + 255) >> 8) * (p.N >> 8)), dim3(512), 0, st, p);
@@ -111,6 +168,10 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
 extern "C" const char* nirgan_conv_kernel_name(const nirgan_conv_desc* d) {
     ng::ConvParams p;
     if (ng::build_conv_params(d, p) != NIRGAN_OK) return nullptr;
+    if (p.prec == 3) {
+        if (ng::conv_x3_ok(p)) return ng::conv_x3_bn(p) == 128 ? "conv_x3_kernel<128>" : "conv_x3_kernel<64>";
+        p.prec = 0;
+    }
     if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) return p.prec == 0 ? "conv_igemm256_kernel<fp32>" : "conv_igemm256_kernel";
     return d->N > 64 ? "conv_igemm_kernel<128>" : "conv_igemm_kernel<64>";
 }
@@ -132,10 +193,27 @@ extern "C" int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int
         g.first[i] = total;
         total += g.p[i].mtiles * g.p[i].ntiles;
     }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g.p[0].prec == 3) {
+        // the three-term split tile for every problem of the group, or exact fp32 for all of them
+        bool ok = true;
+        for (int i = 0; i < n; ++i) ok = ok && ng::conv_x3_ok(g.p[i]) && ng::conv_x3_bn(g.p[i]) == ng::conv_x3_bn(g.p[0]);
+        if (ok) {
+            const int bn = ng::conv_x3_bn(g.p[0]);
+            total = 0;
+            for (int i = 0; i < n; ++i) { g.first[i] = total; total += ((g.p[i].M + 255) >> 8) * (g.p[i].N / bn); }
+            for (int i = n; i < 4; ++i) { g.p[i] = g.p[0]; g.first[i] = 0x7fffffff; }
+            g.first[4] = total;
+            g.n = n;
+            if (bn == 128) hipLaunchKernelGGL(conv_group_x3_kernel<128>, dim3(total), dim3(512), 0, st, g);
+            else hipLaunchKernelGGL(conv_group_x3_kernel<64>, dim3(total), dim3(512), 0, st, g);
+            return nirgan_check_launch("conv_igemm_group (three-term split tile)");
+        }
+        for (int i = 0; i < n; ++i) g.p[i].prec = 0;
+    }
     for (int i = n; i < 4; ++i) { g.p[i] = g.p[0]; g.first[i] = 0x7fffffff; }
     g.first[4] = total;
     g.n = n;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const int prec = g.p[0].prec;
 #define NG_LAUNCH_GROUP(BN, PREC) hipLaunchKernelGGL((conv_group_kernel<BN, PREC>), dim3(total), dim3(256), 0, st, g)
     const bool wb = g.p[0].w_bf16 != 0, ab = g.p[0].in_bf16 != 0;

@@ -78,7 +78,7 @@ struct ConvParams {
     unsigned long long* dbg;   // diagnostic build only
     int w_bf16;                // packed weights stored as bf16 (bf16 operand mode only)
     int in_bf16;               // activations read from a bf16 twin (with w_bf16)
-    int prec;                  // 0 fp32, 1 bf16 operands, 2 bf16x3 split (host-side dispatch only)
+    int prec;                  // 0 fp32, 1 bf16 operands, 2 bf16x3 split, 3 fp32-equivalent three-term split (host-side dispatch only)
     float* stats;              // partial sums for the instance norm that follows: [B][stats_cps][2][N], see nirgan_conv_desc
     int stats_chunk0, stats_cps;
     // first pass of the instance-norm backward of the layer whose output gradient this launch writes (nirgan_conv_desc.fuse_*)
@@ -88,6 +88,8 @@ struct ConvParams {
     int out16, f_y16;          // the output / the fused pass's y are stored as bf16 (nirgan_conv_desc.out_bf16 / fuse_y_bf16)
     int algo;                  // nirgan_conv_desc.algo
     int off32;                 // both operand buffers span < 4 GB: per-lane 32-bit byte offsets from a scalar base (the loader's fast path)
+    const unsigned short* w3;  // precision 3: the packed weights as three bf16 planes h, m, l (nirgan_split3), w3_plane elements apart
+    long long w3_plane;
 };
 
 
@@ -1315,8 +1317,11 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.M = int(M); p.N = d->N;
     p.mtiles = (p.M + 127) / 128;
     p.ntiles = d->N > 64 ? (d->N + 127) / 128 : 1;
-    NG_REQUIRE(d->precision >= 0 && d->precision <= 2, "conv: precision=%d (0 fp32, 1 bf16, 2 bf16x3)", d->precision);
+    NG_REQUIRE(d->precision >= 0 && d->precision <= 3, "conv: precision=%d (0 fp32, 1 bf16, 2 bf16x3, 3 fp32 as three bf16 terms)", d->precision);
     p.prec = d->precision;
+    p.w3 = static_cast<const unsigned short*>(d->w_x3);
+    p.w3_plane = d->w_x3_plane;
+    NG_REQUIRE(p.w3 == nullptr || (ng_aligned16(p.w3) && d->w_x3_plane >= int64_t(d->N) * d->ntaps * d->run && d->w_x3_plane % 8 == 0), "conv: w_x3 misaligned or w_x3_plane too small");
     p.w_bf16 = d->w_bf16 ? 1 : 0;
     NG_REQUIRE(!p.w_bf16 || (d->precision == 1 && d->run % 8 == 0), "conv: bf16-stored weights need precision 1 and run %% 8 == 0 (run=%d)", d->run);
     p.in_bf16 = d->in_bf16 ? 1 : 0;

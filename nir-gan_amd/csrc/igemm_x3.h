@@ -1,0 +1,336 @@
+// fp32-EQUIVALENT contraction on the bf16 matrix pipe (round 5; descriptor precision 3).
+//
+// On gfx950 an fp32 MFMA runs at the vector rate (157 TFLOP/s, 1/16 of bf16).  Here every fp32 operand is split into THREE bf16 terms
+// x = h + m + l (each the round-to-nearest bf16 of what the previous ones left: 24+ significant bits, the split is exact) and a
+// product a * b is contracted as six bf16 products with fp32 accumulation,
+//     al bh + ah bl + am bm + am bh + ah bm + ah bh,
+// i.e. every cross term down to 2^-16 of the leading one; the three dropped terms (am bl, al bm, al bl) are <= 2^-24 |a b| -- below the
+// rounding of the fp32 product itself.  Ceiling 2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-equivalent work against 157.
+// (model/networks.py:349,360-363,559-574 through train.py:29: the reference's arithmetic is fp32.)
+//
+// Tile 256 (M) x BN (N) x 32 (K), ONE workgroup of eight waves per CU (4 x 2, wave tile 64 x BN/2), v_mfma_f32_16x16x32_bf16.
+//   A (activations / gradients, fp32 in HBM as every other kernel reads them -- no twin buffers, no producer changes): each thread
+//     fetches 2 x 8 consecutive k of its two rows into registers one K-tile ahead (global_load_dwordx4), splits them (11 VALU per two
+//     elements: v_cvt_pk_bf16_f32, shift / mask, subtract -- in the shadow of the MFMAs: an MFMA holds the vector issue port for 8 of
+//     its 16 cycles) and writes the three bf16 images with ds_write_b128: every element is converted ONCE per workgroup, the fragment
+//     reads are plain bf16 (no conversion in front of the MFMAs, one read feeds six of them).
+//   B (packed weights): split once per optimizer step by nirgan_split3 into three bf16 planes [3][N][K]; staged by LDS-DMA
+//     (one 1 KB piece per wave and term).
+//   LDS images: per term [rows][32 k] in 64-byte rows, 16-byte chunk c of row r stored at chunk c ^ g((r >> 2) & 3), g = {0, 2, 3, 1}:
+//     conflict-free for ds_read_b128's lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32) with lane = 16 * chunk + row
+//     (MI355X_MICROARCH.md, LDS table) and for the 8-lane groups of ds_write_b128 (two whole rows per group).
+//   Two stages (2 x (48 + 3 BN / 16) KB = 144 KB at BN = 128), ONE barrier per K-tile: 96 MFMAs (1 536 cycles) per wave between barriers.
+#pragma once
+#include "igemm_tiles.h"
+
+namespace ng {
+
+constexpr int X3_A_TERM = 256 * 64;            // bytes of one term image of A (256 rows x 32 k bf16)
+constexpr int X3_A_BYTES = 3 * X3_A_TERM;
+
+__device__ __forceinline__ int x3_key(const int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+__device__ __forceinline__ f32x4 ng_gld16_so(const char* base, unsigned off) {
+    asm volatile("" : "+v"(off));
+    return *reinterpret_cast<const NG_GLOBAL f32x4*>((const NG_GLOBAL char*)base + off);
+}
+
+// x = h + m + l, each term the RNE bf16 of the remainder (exact: the remainders are representable in fp32).  Per PAIR of elements:
+// one v_cvt_pk_bf16_f32 gives both bf16 terms in one dword, a shift and a mask widen them back, two subtractions leave the remainders
+// (5 VALU per level, 11 in all; hipcc's own bf16 -> f32 widening of a vector re-converts every element: 15)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned x3_pk(const float a, const float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void x3_split8(const f32x4 lo, const f32x4 hi, bf16x8& H, bf16x8& M, bf16x8& L) {
+    const f32x8 x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    u32x4 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        h[i] = x3_pk(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, h[i] << 16), r1 = x1 - __builtin_bit_cast(float, h[i] & 0xffff0000u);
+        m[i] = x3_pk(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, m[i] << 16), s1 = r1 - __builtin_bit_cast(float, m[i] & 0xffff0000u);
+        l[i] = x3_pk(s0, s1);
+    }
+    H = __builtin_bit_cast(bf16x8, h);
+    M = __builtin_bit_cast(bf16x8, m);
+    L = __builtin_bit_cast(bf16x8, l);
+}
+
+template <int BN>
+__device__ __forceinline__ void conv_tile_x3(const ConvParams& p, const int id, char* sA0, char* sA1, char* sB0, char* sB1,
+                                             const float* in_base = nullptr, const unsigned short* w3_base = nullptr, float* out_base = nullptr) {
+    static_assert(BN == 128 || BN == 64, "256 x 128 or 256 x 64 block tiles");
+    constexpr int B_TERM = BN * 64;            // bytes of one term image of B
+    constexpr int NT = BN / 32;                // 16-column MFMA tiles per wave (wave tile 64 x BN/2)
+    constexpr int CW = BN / 2;                 // columns per wave
+    constexpr int BPT = BN / 16;               // 1 KB LDS-DMA pieces per term image of B
+    const float* const p_in = in_base ? in_base : p.in;
+    const unsigned short* const p_w3 = w3_base ? w3_base : p.w3;
+    float* const p_out = out_base ? out_base : p.out;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = p.N / BN;
+    const int n0 = (id % ntn) * BN, m0 = (id / ntn) * 256;
+
+    // ---------------- loader state
+    unsigned a_goff[2];
+    int a_wr[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = j * 128 + (tid >> 2), c = tid & 3;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        const int b = m / p.OHW, r = m - b * p.OHW;
+        const int oh = r / p.OW, ow = r - oh * p.OW;
+        a_goff[j] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + c * 8) * 4u;
+        a_wr[j] = row * 64 + ((c ^ x3_key(row)) << 4);
+    }
+    const int b_idx = wave % BPT;               // piece of a term image this wave stages (the same for every term it serves)
+    unsigned b_goff;
+    {
+        const int row = b_idx * 16 + (lane >> 2), c = (lane & 3) ^ x3_key(row);
+        b_goff = unsigned((n0 + row) * p.K + c * 8) * 2u;
+    }
+    const int tapv = p.tap_off[lane & (NIRGAN_MAX_TAPS - 1)];
+    const int nk = p.ntaps * (p.run >> 5);
+    int ct = 0, cc = 0;                         // K-tiles in slice-major order: 32-channel slice cc of the run, all taps
+    auto advance = [&]() {
+        ++ct;
+        if (ct == p.ntaps) { ct = 0; cc += 32; }
+    };
+    const char* const in8 = reinterpret_cast<const char*>(p_in);
+    const char* const w8 = reinterpret_cast<const char*>(p_w3);
+    f32x4 ra[4];
+    auto loadA = [&]() {
+        const int toff = __builtin_amdgcn_readlane(tapv, ct);
+        const char* base = ng_uniform_ptr(in8 + (long long)(toff + cc) * 4);
+        ra[0] = ng_gld16_so(base, a_goff[0]);
+        ra[1] = ng_gld16_so(base, a_goff[0] + 16u);
+        ra[2] = ng_gld16_so(base, a_goff[1]);
+        ra[3] = ng_gld16_so(base, a_goff[1] + 16u);
+    };
+    auto issueB = [&](char* sB) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int piece = wave + 8 * i;     // (uniform) BN = 128: term i, piece `wave` of it
+            if (BN == 128 || piece < 3 * BPT) {
+                const int term = piece / BPT;
+                const char* base = ng_uniform_ptr(w8 + ((long long)term * p.w3_plane + ct * p.run + cc) * 2);
+                ng_glds16_so(base, b_goff, sB + term * B_TERM + b_idx * 1024);
+            }
+        }
+    };
+    auto commitA = [&](char* sA, const int j) {
+        bf16x8 H, M, L;
+        x3_split8(ra[2 * j], ra[2 * j + 1], H, M, L);
+        *reinterpret_cast<bf16x8*>(sA + a_wr[j]) = H;
+        *reinterpret_cast<bf16x8*>(sA + X3_A_TERM + a_wr[j]) = M;
+        *reinterpret_cast<bf16x8*>(sA + 2 * X3_A_TERM + a_wr[j]) = L;
+    };
+
+    // ---------------- compute state
+    const int swz = ((lane >> 4) ^ x3_key(lane & 15)) << 4;
+    const int a_rd = (wr * 64 + (lane & 15)) * 64 + swz;
+    const int b_rd = (wc * CW + (lane & 15)) * 64 + swz;
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one K-tile: B fragments (3 terms), then the two row halves of the wave tile; `mid()` = the conversion + LDS stores of the NEXT
+    // K-tile's A rows
+    auto compute = [&](const char* sA, const char* sB, auto&& mid) {
+        bf16x8 B[NT][3];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) B[nt][t] = *reinterpret_cast<const bf16x8*>(sB + t * B_TERM + b_rd + nt * 1024);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            bf16x8 A[2][3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) A[q][t] = *reinterpret_cast<const bf16x8*>(sA + t * X3_A_TERM + a_rd + (hf * 2 + q) * 1024);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x4 c = acc[hf * 2 + q][nt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][2], B[nt][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][0], B[nt][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][1], B[nt][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][1], B[nt][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][0], B[nt][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][0], B[nt][0], c, 0, 0, 0);
+                    acc[hf * 2 + q][nt] = c;
+                }
+            // the next K-tile's A rows (fetched at the top of this step) are converted and stored BEHIND the first half's MFMAs -- a
+            // fence: scheduled freely, the conversion is hoisted to the head of the step and its vmcnt wait exposes the fetch -- and
+            // interleaved with the second half's (two VALU per MFMA gap: an MFMA holds the vector issue port for 8 of its 16 cycles)
+            if (hf == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+            }
+        }
+    };
+
+    // ---------------- main loop (two distinct stage objects, unrolled by two: the compiler sees that the stores and the LDS-DMA of
+    // stage s + 1 do not alias the fragment reads of stage s)
+    loadA();
+    issueB(sB0);
+    advance();
+    commitA(sA0, 0);
+    commitA(sA0, 1);
+    auto step = [&](const char* cA, const char* cB, char* nA, char* nB, const bool more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (more) {
+            loadA();
+            issueB(nB);
+            advance();
+            compute(cA, cB, [&]() { commitA(nA, 0); commitA(nA, 1); });
+        } else {
+            compute(cA, cB, []() {});
+        }
+    };
+    int k = 0;
+    for (; k + 2 <= nk; k += 2) {
+        step(sA0, sB0, sA1, sB1, true);
+        step(sA1, sB1, sA0, sB0, k + 2 < nk);
+    }
+    if (k < nk) step(sA0, sB0, sA1, sB1, false);
+
+    // ---------------- partial sums for the instance norm that follows (nirgan_conv_desc.stats_ws): a wave's 64 rows leave, per column,
+    // {k = the chunk's first row, sum (v - k), sum (v - k)^2, 64} -- the contract of conv_tile / conv_tile256, chunk = 64 output pixels
+    if (p.stats != nullptr) {
+        const int mrow = m0 + wr * 64;
+        if (mrow < p.M) {                       // (host: OH*OW % 128 == 0, so a 64-row chunk is whole and inside one sample)
+            const int b = mrow / p.OHW;
+            float* sp = p.stats + (size_t(b) * p.stats_cps + p.stats_chunk0 + ((mrow - b * p.OHW) >> 6)) * 4 * p.N;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float k0 = __shfl(acc[0][nt][0], lane & 15, 64);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[mt][nt][r] - k0;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                s1 += __shfl_xor(s1, 16, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                const int col = n0 + wc * CW + nt * 16 + (lane & 15);
+                if (lane < 16) {
+                    sp[col] = k0;
+                    sp[p.N + col] = s1;
+                    sp[2 * p.N + col] = s2;
+                    sp[3 * p.N + col] = 64.f;
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue: each wave transposes its 64 x CW tile through its OWN region of the (now idle) stages and stores whole
+    // row segments, 16 bytes per lane (as conv_tile256)
+    __syncthreads();                            // every wave's fragment reads of the last K-tile are done
+    char* const reg = wave < 3 ? sA0 + wave * 16384 : (wave < 6 ? sA1 + (wave - 3) * 16384 : (wave == 6 ? sB0 : sB1));
+    float* const stg = reinterpret_cast<float*>(reg);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(mt * 16 + (lane >> 4) * 4 + r) * CW + nt * 16 + (lane & 15)] = acc[mt][nt][r];
+    constexpr int LPR = CW / 4, RPP = 64 / LPR;         // lanes per row (4 channels each), rows per pass
+    const int OH = p.OHW / p.OW;
+    const bool fused = p.f_y != nullptr;
+    const float fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
+    const int chunk = lane % LPR, lrow = lane / LPR;
+    const int n = n0 + wc * CW + chunk * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    const int mbase = m0 + wr * 64;
+    int m = mbase + lrow;
+    const int mc = m < p.M ? m : p.M - 1;
+    int b = mc / p.OHW;
+    const int r0 = mc - b * p.OHW;
+    int oh = r0 / p.OW, ow = r0 - oh * p.OW;
+    const int fb = (mbase < p.M ? mbase : p.M - 1) / p.OHW;          // (fused: one sample per 128-row chunk, host: OH*OW % 128 == 0)
+    f32x4 fm = {0.f, 0.f, 0.f, 0.f}, fr = fm, s1 = fm, s2 = fm;
+    if (fused) {
+        fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(fb) * p.N + n);
+        fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(fb) * p.N + n);
+    }
+#pragma unroll 4
+    for (int pass = 0; pass < 64 / RPP; ++pass) {
+        if (m < p.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pass * RPP + lrow) * CW + chunk * 4);
+            v += bv;
+            const int oidx = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n;
+            *reinterpret_cast<f32x4*>(p_out + oidx) = v;
+            if (fused) {
+                const size_t yidx = size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n;
+                const f32x4 y = *reinterpret_cast<const f32x4*>(p.f_y + yidx);
+                const f32x4 z = (y - fm) * fr;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float gz = z[q] > 0.f ? v[q] : v[q] * fneg;
+                    s1[q] += gz;
+                    s2[q] += gz * z[q];
+                }
+            }
+        }
+        m += RPP;
+        ow += RPP;
+        while (ow >= p.OW) { ow -= p.OW; ++oh; }
+        while (oh >= OH) { oh -= OH; ++b; }
+    }
+    if (fused) {
+        // first pass of the consumer layer's instance-norm backward: this wave's 64 rows, then the two waves of a 128-row chunk
+        // (wr = 2 c, 2 c + 1) join through LDS in a fixed order
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                s1[q] += __shfl_xor(s1[q], o, 64);
+                s2[q] += __shfl_xor(s2[q], o, 64);
+            }
+        __syncthreads();                        // (uniform: `fused` is a launch constant) every wave's staging reads are done
+        f32x4* const red = reinterpret_cast<f32x4*>(sA0);          // 8 waves x LPR x 2 sums
+        if (lane < LPR) {
+            red[(wave * LPR + chunk) * 2] = s1;
+            red[(wave * LPR + chunk) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        if ((wr & 1) == 0 && lane < LPR && mbase < p.M) {
+            const f32x4 t1 = s1 + red[((wave + 2) * LPR + chunk) * 2], t2 = s2 + red[((wave + 2) * LPR + chunk) * 2 + 1];
+            float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((mbase - fb * p.OHW) >> 7)) * 2 * p.N + n;
+            *reinterpret_cast<f32x4*>(pp) = t1;
+            *reinterpret_cast<f32x4*>(pp + p.N) = t2;
+        }
+    }
+}
+
+// whether the split tile covers a problem (host): precision 3 with the weight planes present, 32-channel slices, whole 64-column tiles,
+// fp32 tensors on both sides, 32-bit offsets, no split-K
+inline bool conv_x3_ok(const ConvParams& p) {
+    if (!(p.prec == 3 && p.w3 != nullptr && p.off32 && p.ksplit == 1)) return false;
+    if (p.run % 32 != 0 || p.N % 64 != 0 || p.in_bf16 || p.w_bf16 || p.out16 || p.f_y16) return false;
+    if (((p.out_cs | p.out_org | p.out_row | p.out_img) & 3) != 0) return false;
+    return (long long)p.N * p.K * 2 < (1ll << 32);
+}
+inline int conv_x3_bn(const ConvParams& p) { return p.N % 128 == 0 ? 128 : 64; }
+
+}  // namespace ng
