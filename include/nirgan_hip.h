@@ -124,6 +124,7 @@ typedef struct {
     const void* w_x3; int64_t w_x3_plane;
 } nirgan_conv_desc;
 #define NIRGAN_CONV_TILE128 1
+#define NIRGAN_CONV_X3_BN64 3   /* precision 3: the 256 x 64 block tile also where 256 x 128 applies (A/B) */
 #define NIRGAN_CONV_TILE256 2   /* exact-fp32 problems (N % 256 == 0, run % 32 == 0, >= 128 tiles) on the 256-wide tile too (A/B: within 1 % of the 128-row tile) */
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
@@ -197,9 +198,10 @@ int nirgan_pack_rows(const float* src, int64_t src_elems, int src_row_stride, co
 /* nirgan_pack_rows with the destination in bf16 (round to nearest even), K % 8 == 0 */
 int nirgan_pack_rows_bf16(const float* src, int64_t src_elems, int src_row_stride, const int32_t* map,
                           void* dst_bf16, int N, int K, void* stream);
-/* All weight packs of a step in one launch.  jobs_device: njobs x 8 int64 in DEVICE memory:
- * {src, dst, map, src_elems, N, K, src_row_stride | (bf16 destination ? 1 << 32 : 0), first_block}; job j owns blocks
- * [first_block_j, first_block_j + N_j * ceil(K_j / 1024)); total_blocks = their sum. */
+/* All weight packs of a step in one launch.  jobs_device: njobs x 10 int64 in DEVICE memory:
+ * {src, dst, map, src_elems, N, K, src_row_stride | (bf16 destination ? 1 << 32 : 0), first_block, w_x3, w_x3_plane}; job j owns blocks
+ * [first_block_j, first_block_j + N_j * ceil(K_j / 1024)); total_blocks = their sum.  w_x3 != 0 (fp32 destination only): the job also
+ * writes the three bf16 planes of nirgan_split3 for its packed values (plane stride w_x3_plane bf16 elements). */
 int nirgan_pack_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream);
 
 /* precision 3 (nirgan_conv_desc.w_x3): n fp32 values -> three bf16 planes dst[0..n), dst[plane..), dst[2 plane..) with

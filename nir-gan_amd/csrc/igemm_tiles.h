@@ -1404,11 +1404,11 @@ inline int build_wgrad_params(const nirgan_wgrad_desc* d, WgradParams& p) {
     p.rows_per_split = d->rows_per_split; p.nsplit = d->nsplit;
     p.ntiles_k = (K + 127) / 128;
     p.ntiles_n = d->N > 64 ? (d->N + 127) / 128 : 1;
-    NG_REQUIRE(d->precision >= 0 && d->precision <= 2, "wgrad_igemm: precision=%d (0 fp32, 1 bf16, 2 bf16x3)", d->precision);
+    NG_REQUIRE(d->precision >= 0 && d->precision <= 3, "wgrad_igemm: precision=%d (0 fp32, 1 bf16, 2 bf16x3, 3 fp32 as three bf16 terms)", d->precision);
     p.prec = d->precision;
     p.nplanes = d->nplanes > 1 ? d->nplanes : 1;
     p.p_plane = d->p_plane; p.q_plane = d->q_plane;
-    NG_REQUIRE(p.nplanes == 1 || (d->precision == 0 && !d->pq_bf16 && d->p_plane > 0 && d->q_plane > 0), "wgrad_igemm: planes need the fp32 tile and positive plane strides");
+    NG_REQUIRE(p.nplanes == 1 || ((d->precision == 0 || d->precision == 3) && !d->pq_bf16 && d->p_plane > 0 && d->q_plane > 0), "wgrad_igemm: planes need the fp32 tile and positive plane strides");
     NG_REQUIRE(d->slab_elems >= int64_t(p.nplanes) * d->nsplit * d->N * K, "wgrad_igemm: slab_elems too small for %d planes", p.nplanes);
     NG_REQUIRE(d->p_elems >= (p.nplanes - 1) * d->p_plane + int64_t(d->B) * d->p_hp * d->p_wp * d->p_cs && d->q_elems >= (p.nplanes - 1) * d->q_plane + int64_t(d->B) * d->q_hp * d->q_wp * d->q_cs, "wgrad_igemm: p/q too small for the planes");
     p.pq_bf16 = d->pq_bf16 ? 1 : 0;

@@ -12,6 +12,7 @@
 //   order, so gradients are bitwise reproducible run to run.
 #include "igemm_tiles.h"
 #include "igemm_tile256.h"
+#include "igemm_x3.h"
 #include <cstdlib>
 
 namespace {
@@ -87,6 +88,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_pair256_kernel(const ng::Co
             ng::wgrad_tile256<S>(wp, u, lds);
             again = true;
         }
+    }
+}
+
+// precision 3 (igemm_x3.h): the weight gradient with both fp32 operands split into three bf16 terms in the kernel; persistent, one workgroup per CU
+template <int TN>
+__global__ __launch_bounds__(512, 2) void wgrad_x3_kernel(const ng::WgradParams p, const int units) {
+    __shared__ __attribute__((aligned(16))) char sP0[3 * 32 * TN * 2];
+    __shared__ __attribute__((aligned(16))) char sP1[3 * 32 * TN * 2];
+    __shared__ __attribute__((aligned(16))) char sQ0[3 * 32 * 256];
+    __shared__ __attribute__((aligned(16))) char sQ1[3 * 32 * 256];
+    for (int u = ng_xcd_remap(blockIdx.x, gridDim.x); u < units; u += gridDim.x) {
+        ng::wgrad_tile_x3<TN>(p, u, sP0, sP1, sQ0, sQ1);
+        __syncthreads();                // every wave has read its staging back before the next unit's images land
     }
 }
 
@@ -230,13 +244,14 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     pack_store(dst, size_t(n) * K + k4, v, bf16);
 }
 
-// all weight packs of a plan in one launch: jobs live in device memory (8 x int64 each):
-// src, dst, map, src_elems, N, K, src_row_stride | (bf16 destination << 32), first_block
+// all weight packs of a plan in one launch: jobs live in device memory (10 x int64 each):
+// src, dst, map, src_elems, N, K, src_row_stride | (bf16 destination << 32), first_block, w3, w3_plane
+// (w3 != 0: the fp32 pack also leaves its three bf16 terms h, m, l -- nirgan_split3 -- in the planes w3, w3 + w3_plane, w3 + 2 w3_plane)
 __global__ __launch_bounds__(256) void pack_rows_batch_kernel(const long long* __restrict__ jobs, int njobs) {
     int j = 0;
     for (int i = 1; i < njobs; ++i)
-        if (int(blockIdx.x) >= int(jobs[i * 8 + 7])) j = i;
-    const long long* J = jobs + j * 8;
+        if (int(blockIdx.x) >= int(jobs[i * 10 + 7])) j = i;
+    const long long* J = jobs + j * 10;
     const float* src = reinterpret_cast<const float*>(J[0]);
     float* dst = reinterpret_cast<float*>(J[1]);
     const int32_t* map = reinterpret_cast<const int32_t*>(J[2]);
@@ -257,6 +272,23 @@ __global__ __launch_bounds__(256) void pack_rows_batch_kernel(const long long* _
         }
     }
     pack_store(dst, size_t(n) * K + k4, v, bf16);
+    if (J[8] != 0) {
+        unsigned short* w3 = reinterpret_cast<unsigned short*>(J[8]) + size_t(n) * K + k4;
+        const long long plane = J[9];
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 h, m, l;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float x0 = v[2 * i], x1 = v[2 * i + 1];
+            h[i] = ng::x3_pk(x0, x1);
+            const float r0 = x0 - __builtin_bit_cast(float, h[i] << 16), r1 = x1 - __builtin_bit_cast(float, h[i] & 0xffff0000u);
+            m[i] = ng::x3_pk(r0, r1);
+            l[i] = ng::x3_pk(r0 - __builtin_bit_cast(float, m[i] << 16), r1 - __builtin_bit_cast(float, m[i] & 0xffff0000u));
+        }
+        *reinterpret_cast<u32x2*>(w3) = h;
+        *reinterpret_cast<u32x2*>(w3 + plane) = m;
+        *reinterpret_cast<u32x2*>(w3 + 2 * plane) = l;
+    }
 }
 
 }  // namespace
@@ -294,6 +326,16 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     const int rc = ng::build_wgrad_params(d, p);
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p.prec == 3) {
+        if (ng::wgrad_x3_ok(p)) {
+            const int tn = ng::wgrad_x3_tn(p);
+            const int units = (p.N / tn) * ((p.K + 127) >> 7) * p.nsplit, G = ng_cu_count();
+            if (tn == 256) hipLaunchKernelGGL(wgrad_x3_kernel<256>, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
+            else hipLaunchKernelGGL(wgrad_x3_kernel<128>, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
+            return nirgan_check_launch("wgrad_igemm (three-term split tile)");
+        }
+        p.prec = 0;             // what the split tile does not cover runs as exact fp32
+    }
     if (d->algo != NIRGAN_WGRAD_TILE128 && d->algo != NIRGAN_WGRAD_ONE_UNIT && ng::wgrad_tile256_ok(p)) {
         const int units = (p.N >> 8) * (p.K >> 8) * p.nsplit, G = ng_cu_count();
         if (d->algo == NIRGAN_WGRAD_RING10) hipLaunchKernelGGL(wgrad_igemm256_kernel<10>, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
@@ -328,7 +370,7 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
     if (rc != NIRGAN_OK) return rc;
     rc = ng::build_wgrad_params(w, wp);
     if (rc != NIRGAN_OK) return rc;
-    if (c->N <= 64 || w->N <= 64 || c->ksplit > 1 || (wp.pq_bf16 && !cp.in_bf16)) {      // narrow, split-K or mixed-storage variants: two ordinary launches
+    if (c->N <= 64 || w->N <= 64 || c->ksplit > 1 || (wp.pq_bf16 && !cp.in_bf16) || cp.prec == 3 || wp.prec == 3) {      // narrow, split-K, mixed-storage or three-term variants: two ordinary launches
         rc = nirgan_conv_igemm(c, stream);
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
@@ -356,6 +398,10 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
 extern "C" const char* nirgan_wgrad_kernel_name(const nirgan_wgrad_desc* d) {
     ng::WgradParams p;
     if (ng::build_wgrad_params(d, p) != NIRGAN_OK) return nullptr;
+    if (p.prec == 3) {
+        if (ng::wgrad_x3_ok(p)) return ng::wgrad_x3_tn(p) == 256 ? "wgrad_x3_kernel<256>" : "wgrad_x3_kernel<128>";
+        p.prec = 0;
+    }
     if (d->algo != NIRGAN_WGRAD_TILE128 && ng::wgrad_tile256_ok(p)) return "wgrad_igemm256_kernel";
     if (ng::wgrad_persist_ok(p) && ng::wgrad_matrix_form(p) && p.ntiles_n * p.ntiles_k * p.nsplit * p.nplanes > 512 && d->algo != NIRGAN_WGRAD_ONE_UNIT) return "wgrad_persist_kernel";
     if (p.pq_bf16) return "wgrad_igemm16_kernel";
@@ -366,7 +412,7 @@ extern "C" const char* nirgan_conv_wgrad_pair_kernel_name(const nirgan_conv_desc
     ng::ConvParams cp;
     ng::WgradParams wp;
     if (ng::build_conv_params(c, cp) != NIRGAN_OK || ng::build_wgrad_params(w, wp) != NIRGAN_OK) return nullptr;
-    if (c->N <= 64 || w->N <= 64 || c->ksplit > 1 || (wp.pq_bf16 && !cp.in_bf16)) return "(two launches)";
+    if (c->N <= 64 || w->N <= 64 || c->ksplit > 1 || (wp.pq_bf16 && !cp.in_bf16) || cp.prec == 3 || wp.prec == 3) return "(two launches)";
     if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp, true) && ng::wgrad_tile256_ok(wp)) return "conv_wgrad_pair256_kernel";
     return "conv_wgrad_pair_kernel";
 }

@@ -331,6 +331,188 @@ inline bool conv_x3_ok(const ConvParams& p) {
     if (((p.out_cs | p.out_org | p.out_row | p.out_img) & 3) != 0) return false;
     return (long long)p.N * p.K * 2 < (1ll << 32);
 }
-inline int conv_x3_bn(const ConvParams& p) { return p.N % 128 == 0 ? 128 : 64; }
+// 128-column tiles unless N has no such tiles, the caller pins the 64-column tile (NIRGAN_CONV_X3_BN64: A/B), or the problem has fewer
+// 256 x 128 tiles than three quarters of the CUs (one workgroup per CU: twice as many 64-column tiles fill the chip)
+inline int conv_x3_bn(const ConvParams& p, const int cus = 256) {
+    if (p.N % 128 != 0 || p.algo == NIRGAN_CONV_X3_BN64) return 64;
+    const long long tiles = (long long)((p.M + 255) >> 8) * (p.N / 128);
+    return tiles * 4 >= 3ll * cus ? 128 : 64;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The weight gradient in the same arithmetic: slab[split][n][J] = sum over the split's pixels m of P[m][n] * Q[m + tap(J)][c(J)] with
+// both operands fp32 in memory (dY and the layer input as every other kernel reads them), split into three bf16 terms on the way into
+// LDS.  Unit = TN rows n x 128 columns J x one split; a K-tile = 32 consecutive pixels of ONE image row (host: fast32 -- OW, M and the
+// split length multiples of 32 -- so the tile's first pixel walks in scalar registers and every per-lane offset is a constant of the
+// unit).  The reduction index (the pixel) is the ROW of both images, the MFMA wants it contiguous per lane: the images are
+// [pixel][channel] in rows of 2 TN / 256 bytes and the fragments are read with ds_read_b64_tr_b16 (as wgrad_tile256: a 16-lane group
+// reads a 4-row x 16-column block, lane i receives column i; two reads = one 16x16x32 operand); 16-byte chunk c of row r sits at
+// chunk c ^ 2 ((r & 3) | ((r >> 3) & 1) << 2).  Eight waves as 4 (n) x 2 (J): wave tile TN/4 x 64.
+template <int TN>
+__device__ __forceinline__ void wgrad_tile_x3(const WgradParams& p, const int unit, char* sP0, char* sP1, char* sQ0, char* sQ1) {
+    static_assert(TN == 128 || TN == 256, "128 or 256 rows n per unit");
+    constexpr int PRS = TN * 2;                 // bytes of an image row of P (one pixel, TN channels bf16)
+    constexpr int P_TERM = 32 * PRS, Q_TERM = 32 * 256;
+    constexpr int MT = TN / 64;                 // 16-row MFMA tiles per wave (wave tile TN/4 x 64)
+    constexpr int PT = TN / 128;                // loader tasks per thread for P (8 channels of one pixel each)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = p.N / TN, ntj = (p.K + 127) >> 7;
+    const int nt_ = unit % ntn, rest = unit / ntn;
+    const int jt = rest % ntj, split = rest / ntj;
+    const int n0 = nt_ * TN, j0 = jt * 128;
+    const int mstart = split * p.rows_per_split;
+    int mend = mstart + p.rows_per_split;
+    mend = mend < p.M ? mend : p.M;
+    const int nk = mend > mstart ? (mend - mstart) >> 5 : 0;
+
+    // ---------------- loader state: thread -> pixel row tid >> 4 of the K-tile, 8 channels / columns from (tid & 15) * 8
+    const int lrow = tid >> 4, lch = tid & 15;
+    const int lkey = 2 * ((lrow & 3) | (((lrow >> 3) & 1) << 2));
+    unsigned p_goff[PT], q_goff;
+    int p_wr[PT], q_wr;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        p_goff[i] = unsigned(lrow * p.p_cs + i * 128 + lch * 8) * 4u;
+        p_wr[i] = lrow * PRS + (((i * 16 + lch) ^ lkey) << 4);
+    }
+    {
+        int J = j0 + lch * 8;
+        J = J < p.K ? J : 0;                    // (columns past K are never stored and never summed: any valid address does)
+        const int t = J / p.run;
+        q_goff = unsigned(lrow * p.q_stride * p.q_cs + p.tap_off[t] + (J - t * p.run)) * 4u;
+        q_wr = lrow * 256 + ((lch ^ lkey) << 4);
+    }
+    // the K-tile cursor: first pixel (sb, soh, sow) of the tile, advanced by additions in scalar registers
+    int sb = __builtin_amdgcn_readfirstlane(mstart / p.OHW);
+    int soh = __builtin_amdgcn_readfirstlane((mstart - sb * p.OHW) / p.OW);
+    int sow = __builtin_amdgcn_readfirstlane(mstart - sb * p.OHW - soh * p.OW);
+    f32x4 rp[PT][2], rq[2];
+    auto load = [&]() {
+        const char* pb = ng_uniform_ptr(reinterpret_cast<const char*>(p.p + (size_t(sb) * p.p_img + size_t(soh) * p.p_row + sow * p.p_cs + p.p_org + n0)));
+        const char* qb = ng_uniform_ptr(reinterpret_cast<const char*>(p.q + (size_t(sb) * p.q_img + size_t(soh) * p.q_stride * p.q_row + sow * p.q_stride * p.q_cs + p.q_org)));
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            rp[i][0] = ng_gld16_so(pb, p_goff[i]);
+            rp[i][1] = ng_gld16_so(pb, p_goff[i] + 16u);
+        }
+        rq[0] = ng_gld16_so(qb, q_goff);
+        rq[1] = ng_gld16_so(qb, q_goff + 16u);
+        sow += 32;
+        if (sow >= p.OW) { sow = 0; ++soh; }
+        if (soh >= p.OH) { soh = 0; ++sb; }
+    };
+    auto commit = [&](char* sP, char* sQ) {
+        bf16x8 H, M, L;
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+            x3_split8(rp[i][0], rp[i][1], H, M, L);
+            *reinterpret_cast<bf16x8*>(sP + p_wr[i]) = H;
+            *reinterpret_cast<bf16x8*>(sP + P_TERM + p_wr[i]) = M;
+            *reinterpret_cast<bf16x8*>(sP + 2 * P_TERM + p_wr[i]) = L;
+        }
+        x3_split8(rq[0], rq[1], H, M, L);
+        *reinterpret_cast<bf16x8*>(sQ + q_wr) = H;
+        *reinterpret_cast<bf16x8*>(sQ + Q_TERM + q_wr) = M;
+        *reinterpret_cast<bf16x8*>(sQ + 2 * Q_TERM + q_wr) = L;
+    };
+
+    // ---------------- compute state: lane (g, q, pp) reads 8 bytes of row 8 g + q (+ 4) -- see wgrad_tile256
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int fl = 2 * (q | ((g & 1) << 2));
+    int a_ad[MT], b_ad[4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a_ad[mt] = (8 * g + q) * PRS + ((((wr * MT + mt) * 2) | (pp >> 1)) ^ fl) * 16 + 8 * (pp & 1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b_ad[nt] = (8 * g + q) * 256 + ((((wc * 4 + nt) * 2) | (pp >> 1)) ^ fl) * 16 + 8 * (pp & 1);
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto frag = [&](const char* img, const int ad, const int rs) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((NG_LDS s16x4*)(img + ad));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((NG_LDS s16x4*)(img + ad + 4 * rs));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto compute = [&](const char* sP, const char* sQ, auto&& mid) {
+        bf16x8 B[4][3];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) B[nt][t] = frag(sQ + t * Q_TERM, b_ad[nt], 256);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 A[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) A[t] = frag(sP + t * P_TERM, a_ad[mt], PRS);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 c = acc[mt][nt];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[nt][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[nt][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[nt][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[nt][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[nt][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[nt][0], c, 0, 0, 0);
+                acc[mt][nt] = c;
+            }
+            if (mt == MT / 2 - 1) {             // behind the first half of the MFMAs: the next K-tile's operands have arrived
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+            }
+        }
+    };
+    auto step = [&](const char* cP, const char* cQ, char* nP, char* nQ, const bool more) {
+        __syncthreads();
+        if (more) {
+            load();
+            compute(cP, cQ, [&]() { commit(nP, nQ); });
+        } else {
+            compute(cP, cQ, []() {});
+        }
+    };
+    if (nk > 0) {
+        load();
+        commit(sP0, sQ0);
+        int k = 0;
+        for (; k + 2 <= nk; k += 2) {
+            step(sP0, sQ0, sP1, sQ1, true);
+            step(sP1, sQ1, sP0, sQ0, k + 2 < nk);
+        }
+        if (k < nk) step(sP0, sQ0, sP1, sQ1, false);
+    }
+
+    // ---------------- the partial tile to its slab: rows n, 256-byte segments of J, through the wave's own 16 / 8 KB of the idle stages
+    __syncthreads();
+    // (a P stage holds three regions of MT x 4 KB, a Q stage -- 24 KB -- one)
+    char* const reg = wave < 3 ? sP0 + wave * (MT * 4096) : (wave < 6 ? sP1 + (wave - 3) * (MT * 4096) : (wave == 6 ? sQ0 : sQ1));
+    float* const stg = reinterpret_cast<float*>(reg);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(mt * 16 + (lane >> 4) * 4 + r) * 64 + nt * 16 + (lane & 15)] = acc[mt][nt][r];
+    float* const slab = p.slabs + size_t(split) * p.N * p.K;
+    const int chunk = lane & 15, srow = lane >> 4;
+    const int jj = j0 + wc * 64 + chunk * 4;
+    if (jj < p.K) {
+        float* dst = slab + size_t(n0 + wr * (TN / 4) + srow) * p.K + jj;
+#pragma unroll 4
+        for (int pass = 0; pass < MT * 4; ++pass)
+            *reinterpret_cast<f32x4*>(dst + size_t(pass * 4) * p.K) = *reinterpret_cast<const f32x4*>(stg + (pass * 4 + srow) * 64 + chunk * 4);
+    }
+}
+
+// whether wgrad_tile_x3 covers a problem (host)
+inline bool wgrad_x3_ok(const WgradParams& p) {
+    if (!(p.prec == 3 && !p.pq_bf16 && p.nplanes == 1 && p.fast32)) return false;
+    if (p.N % 128 != 0 || p.run % 8 != 0 || p.K % 4 != 0) return false;
+    return true;
+}
+inline int wgrad_x3_tn(const WgradParams& p) { return p.N % 256 == 0 ? 256 : 128; }
 
 }  // namespace ng

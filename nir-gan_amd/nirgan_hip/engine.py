@@ -167,17 +167,21 @@ class Plan:
         self.ops.extend(other.ops)
 
     def fuse_packs(self):
-        """Replace the nirgan_pack_rows ops of this plan by ONE nirgan_pack_rows_batch launch (job table in device memory)."""
+        """Replace the nirgan_pack_rows ops of this plan by ONE nirgan_pack_rows_batch launch (job table in device memory); a pack that is
+        followed by its nirgan_split3 (precision 3: three bf16 planes of the packed weights) carries the planes in its job."""
         packs = [(a, n == "nirgan_pack_rows_bf16") for n, a in self.ops if n in ("nirgan_pack_rows", "nirgan_pack_rows_bf16")]
         if len(packs) < 2 or len(packs) > 256:
             return
+        twins = {a[0]: (a[1], a[3]) for n, a in self.ops if n == "nirgan_split3"}       # packed buffer -> (planes, plane stride)
         rows, first = [], 0
         for (src, src_elems, stride, imap, dst, N, K), bf16 in packs:
-            rows.append([src, dst, imap, src_elems, N, K, stride | ((1 << 32) if bf16 else 0), first])
+            tw, plane = twins.pop(dst, (0, 0))
+            rows.append([src, dst, imap, src_elems, N, K, stride | ((1 << 32) if bf16 else 0), first, tw, plane])
             first += N * ((K + 1023) // 1024)
+        assert not twins, "a nirgan_split3 op without its pack"
         table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
         self.ctx.keep.append(table)
-        self.ops = [(n, a) for n, a in self.ops if n not in ("nirgan_pack_rows", "nirgan_pack_rows_bf16")]
+        self.ops = [(n, a) for n, a in self.ops if n not in ("nirgan_pack_rows", "nirgan_pack_rows_bf16", "nirgan_split3")]
         self.ops.append(("nirgan_pack_rows_batch", (table.data_ptr(), len(rows), first)))
 
     def fuse_wino6_weights(self):
@@ -260,6 +264,15 @@ class Weights:
             buf = self.ctx.zeros(rows, spec.K)
             plan.add("nirgan_pack_rows", param.data_ptr(), param.numel(), spec.row_stride, imap.data_ptr(),
                      buf.data_ptr(), spec.N, spec.K)
+            if self.ctx.precision == 0 and OPT.split3 and spec.run > 0 and spec.run % 32 == 0 and spec.N % 64 == 0 and not fp32:
+                # precision 3 (csrc/igemm_x3.h): the packed weights once more as three bf16 planes h, m, l (w = h + m + l exactly),
+                # refreshed with the pack; emit_conv finds them on the tensor
+                plane = rows * spec.K
+                tw = torch.zeros(3 * plane, dtype=torch.bfloat16, device=self.ctx.device)
+                self.ctx.bytes += tw.numel() * 2
+                self.ctx.keep.append(tw)
+                plan.add("nirgan_split3", buf.data_ptr(), tw.data_ptr(), spec.N * spec.K, plane)
+                buf.x3 = (tw, plane)
         self.ctx.keep.append(buf)
         self.cache[key] = buf
         return buf
@@ -312,6 +325,11 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.zero_page = ctx.zero_page.data_ptr()
     d.precision = ctx.precision
     d.algo = 0 if OPT.tile256 else L.CONV_TILE128
+    x3 = getattr(w, "x3", None)
+    if x3 is not None and ctx.precision == 0 and OPT.split3 and taps.run % 32 == 0 and N % 64 == 0 and not d.out_bf16 and out.C % 4 == 0:
+        # exact-fp32 mode: this contraction on the bf16 pipe as three bf16 terms per operand, six products (fp32-equivalent; no split-K form)
+        d.precision, d.w_x3, d.w_x3_plane = 3, x3[0].data_ptr(), x3[1]
+        allow_split = False
     ctx.keep.append(d)
     if plan is not None:
         M = inp.B * OH * OW
@@ -342,6 +360,12 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     twins = (ctx.precision == 1 and p.t16 is not None and q.t16 is not None and N > 64 and N % 8 == 0 and taps.run % 8 == 0
              and (pair_with is None or pair_with.in_bf16))
     nsplit, rows = G.wgrad_split(M, tiles, target, 64 if twins else 32)
+    # exact-fp32 mode: the three-term split tile (csrc/igemm_x3.h::wgrad_tile_x3: persistent, one workgroup per CU, units of 128 or 256 rows
+    # x 128 columns x one split) where its scalar pixel walk applies -- mirrors wgrad_x3_ok
+    x3 = (ctx.precision == 0 and OPT.split3 and N % 128 == 0 and taps.run % 8 == 0 and OW % 32 == 0 and M % 32 == 0
+          and all(a * q.wp * q.C + b * q.C >= 0 for a, b in zip(taps.dh, taps.dw)))
+    if x3:
+        nsplit, rows = G.wgrad_split(M, (N // (256 if N % 256 == 0 else 128)) * (-(-K // 128)), G.CUS, 32)
     if twins and OPT.tile256 and G.wgrad256_ok(M, OH, OW, N, K, taps.run):
         # the 256-wide persistent tiles (csrc/igemm_tile256.h): splits sized so that the data-gradient and weight-gradient workgroups
         # of the fused launch finish together (the library divides the CUs with the same cost figure)
@@ -367,7 +391,7 @@ def emit_wgrad(plan: Plan, ctx: Ctx, p: Halo, q: Halo, taps: G.Taps, spec: G.Pac
     d.B, d.OH, d.OW, d.N = p.B, OH, OW, N
     d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
     d.zero_page = ctx.zero_page.data_ptr()
-    d.precision = ctx.precision
+    d.precision = 3 if x3 else ctx.precision
     if not OPT.tile256:
         d.algo = L.WGRAD_TILE128
     ctx.keep.append(d)

@@ -54,6 +54,11 @@ class Options:
     batch_reduce: bool = True
     # wanted workgroups of a stand-alone weight-gradient launch (the pixel range is split to reach it): one round of the 512 slots
     wgrad_target: int = 512
+    # exact-fp32 mode: the direct convolutions and weight gradients with 32-channel runs (every stride-2 / transposed layer of both networks)
+    # on the bf16 matrix pipe as THREE bf16 terms per fp32 operand and six products per fp32 product (descriptor precision 3,
+    # csrc/igemm_x3.h): fp32-equivalent results (measured 0.8-1.0 x the exact tile's error against float64) at 1.6-1.8 x its rate; False =
+    # the exact fp32 MFMA tiles everywhere (A/B)
+    split3: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
     endconv_direct: bool = True
 

@@ -37,8 +37,21 @@ def contract(A: np.ndarray, B: np.ndarray, precision: int) -> np.ndarray:
     if precision == 1:
         return ah.astype(np.float64) @ bh.astype(np.float64)
     am, bm = bf16_round(A - ah), bf16_round(B - bh)
+    if precision == 3:        # three bf16 terms per operand, the six products down to 2^-16 of the leading one (csrc/igemm_x3.h)
+        al, bl = bf16_round(A - ah - am), bf16_round(B - bh - bm)
+        ah, bh, am, bm, al, bl = (v.astype(np.float64) for v in (ah, bh, am, bm, al, bl))
+        return al @ bh + ah @ bl + am @ bm + am @ bh + ah @ bm + ah @ bh
     ah, bh, am, bm = (v.astype(np.float64) for v in (ah, bh, am, bm))
     return ah @ bh + ah @ bm + am @ bh
+
+
+def split3_planes(x: np.ndarray):
+    """x = h + m + l, each term the nearest-even bf16 of what the previous ones left (nirgan_split3), as uint16 bit patterns"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    h = bf16_round(x)
+    m = bf16_round(x - h)
+    l = bf16_round(x - h - m)
+    return [(v.view(np.uint32) >> 16).astype(np.uint16) for v in (h, m, l)]
 
 
 def mirror_twin(twin_ptr, buf: np.ndarray) -> None:
@@ -121,6 +134,18 @@ class EmuBackend:
             w = (w16.astype(np.uint32) << 16).view(np.float32).reshape(d.N, K)
         else:
             w = arr(d.w, d.w_elems)[: d.N * K].reshape(d.N, K)
+        prec = d.precision
+        if prec == 3:
+            # the split tile's coverage (csrc/igemm_x3.h::conv_x3_ok); anything else runs as exact fp32
+            if d.w_x3 and d.run % 32 == 0 and d.N % 64 == 0 and d.ksplit <= 1 and not (d.in_bf16 or d.w_bf16 or d.out_bf16 or d.fuse_y_bf16):
+                if d.w_x3_plane < d.N * K or d.w_x3_plane % 8:
+                    return self._fail("conv: w_x3_plane too small")
+                planes = [(arr16(d.w_x3 + 2 * t * d.w_x3_plane, d.N * K).astype(np.uint32) << 16).view(np.float32).astype(np.float64) for t in range(3)]
+                w3 = (planes[0] + planes[1] + planes[2]).reshape(d.N, K)
+                if not np.array_equal(w3, w.astype(np.float64)):
+                    return self._fail("conv: the w_x3 planes are not the three-term split of w (stale planes?)")
+            else:
+                prec = 0
         if d.out_bf16 and (d.N % 4 or d.out_cs % 4 or d.ksplit > 1):
             return self._fail("conv: a bf16 output needs N % 4 == 0, out_cs % 4 == 0 and no split-K")
         out = arr16(d.out, d.out_elems) if d.out_bf16 else arr(d.out, d.out_elems)
@@ -159,7 +184,7 @@ class EmuBackend:
             for t in range(d.ntaps):
                 off = (d.tap_dh[t] * d.in_wp + d.tap_dw[t]) * d.in_cs
                 A = inp[b * in_img + base[..., None] + off + rr]
-                acc += contract(A.reshape(-1, d.run), np.ascontiguousarray(w[:, t * d.run:(t + 1) * d.run].T), d.precision).reshape(d.OH, d.OW, d.N)
+                acc += contract(A.reshape(-1, d.run), np.ascontiguousarray(w[:, t * d.run:(t + 1) * d.run].T), prec).reshape(d.OH, d.OW, d.N)
             if stats is not None:                      # per 64 pixels: {k = first pixel, sum (v - k), sum (v - k)^2, 64}, without the bias
                 ch = acc.reshape(-1, 64, d.N)
                 k = ch[:, 0]
@@ -307,16 +332,30 @@ class EmuBackend:
             blocks += int(N) * ((int(K) // int(taps) // 64) if taps else ((int(K) + 255) // 256))
         return 0 if blocks == total_blocks else self._fail("reduce_rows_batch: total_blocks mismatch")
 
+    def nirgan_split3(self, src, dst, n, plane, stream=None):
+        self.calls.append("split3")
+        if n <= 0 or n % 8 or plane < n or plane % 8:
+            return self._fail("split3: n and plane must be positive multiples of 8, plane >= n")
+        for t, v in enumerate(split3_planes(arr(src, n))):
+            arr16(int(dst) + 2 * t * int(plane), n)[:] = v
+        return 0
+
     def nirgan_pack_rows_batch(self, jobs, njobs, total_blocks, stream=None):
-        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 8)).from_address(int(jobs))).reshape(njobs, 8)
+        J = np.ctypeslib.as_array((C.c_int64 * (njobs * 10)).from_address(int(jobs))).reshape(njobs, 10)
         blocks = 0
-        for src, dst, imap, src_elems, N, K, stride, first in J:
+        for src, dst, imap, src_elems, N, K, stride, first, w3, w3_plane in J:
             if first != blocks:
                 return self._fail("pack_rows_batch: first_block mismatch")
             rc = self.nirgan_pack_rows(int(src), int(src_elems), int(stride) & 0xffffffff, int(imap), int(dst), int(N), int(K),
                                        bf16=bool(int(stride) >> 32))
             if rc:
                 return rc
+            if w3:
+                if int(stride) >> 32:
+                    return self._fail("pack_rows_batch: w_x3 planes come with an fp32 destination")
+                rc = self.nirgan_split3(int(dst), int(w3), int(N) * int(K), int(w3_plane))
+                if rc:
+                    return rc
             blocks += int(N) * ((int(K) + 1023) // 1024)
         return 0 if blocks == total_blocks else self._fail("pack_rows_batch: total_blocks mismatch")
 
