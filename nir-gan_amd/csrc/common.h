@@ -12,6 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define NG_GLOBAL __attribute__((address_space(1)))
 #define NG_LDS __attribute__((address_space(3)))
+#define NG_CONST __attribute__((address_space(4)))      // the kernarg segment: uniform reads are scalar loads, also with a runtime index
 
 void nirgan_set_error(const char* fmt, ...);
 

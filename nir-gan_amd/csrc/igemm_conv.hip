@@ -32,14 +32,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm256_kernel(const ng::ConvPar
     ng::conv_tile256<F32>(p, ng_xcd_remap(blockIdx.x, gridDim.x), lds);
 }
 
-// precision 3 (igemm_x3.h): fp32 operands as three bf16 terms, six bf16 products -- 256 x BN x 32 tile, one workgroup of eight waves per CU
+// precision 3 (igemm_x3.h): fp32 operands as three bf16 terms, six bf16 products -- 256 x BN x 32 tiles walked by persistent workgroups,
+// one of eight waves per CU; up to four problems (sub-pixel phases) or a batch of planes per launch
 template <int BN>
-__global__ __launch_bounds__(512, 2) void conv_x3_kernel(const ng::ConvParams p) {
+__global__ __launch_bounds__(512, 2) void conv_x3_kernel(const ng::X3Work w) {
     __shared__ __attribute__((aligned(16))) char sA0[ng::X3_A_BYTES];
     __shared__ __attribute__((aligned(16))) char sA1[ng::X3_A_BYTES];
     __shared__ __attribute__((aligned(16))) char sB0[3 * BN * 64];
     __shared__ __attribute__((aligned(16))) char sB1[3 * BN * 64];
-    ng::conv_tile_x3<BN>(p, ng_xcd_remap(blockIdx.x, gridDim.x), sA0, sA1, sB0, sB1);
+    __shared__ __attribute__((aligned(16))) char sRed[8 * (BN / 8) * 2 * 16];
+    // (the work list is read through the kernarg segment: a runtime problem index then costs scalar loads, not a scratch copy)
+    ng::conv_x3_persist<BN>((const NG_CONST ng::X3Work*)__builtin_amdgcn_kernarg_segment_ptr(), sA0, sA1, sB0, sB1, sRed);
 }
 
 // fp32 -> three bf16 planes h, m, l with x = h + m + l exactly (each term the RNE bf16 of what the previous ones left)
@@ -94,24 +97,36 @@ __global__ __launch_bounds__(256, 2) void conv_group_kernel(const ConvGroup g) {
     else ng::conv_tile<BN, PREC, WB16, AB16>(g.p[3], bid - g.first[3], st0, st1);
 }
 
-template <int BN>
-__global__ __launch_bounds__(512, 2) void conv_group_x3_kernel(const ConvGroup g) {
-    __shared__ __attribute__((aligned(16))) char sA0[ng::X3_A_BYTES];
-    __shared__ __attribute__((aligned(16))) char sA1[ng::X3_A_BYTES];
-    __shared__ __attribute__((aligned(16))) char sB0[3 * BN * 64];
-    __shared__ __attribute__((aligned(16))) char sB1[3 * BN * 64];
-    const int bid = ng_xcd_remap(blockIdx.x, gridDim.x);
-    int k = 0;
-    if (bid >= g.first[1]) k = 1;
-    if (bid >= g.first[2]) k = 2;
-    if (bid >= g.first[3]) k = 3;
-    if (k == 0) ng::conv_tile_x3<BN>(g.p[0], bid, sA0, sA1, sB0, sB1);
-    else if (k == 1) ng::conv_tile_x3<BN>(g.p[1], bid - g.first[1], sA0, sA1, sB0, sB1);
-    else if (k == 2) ng::conv_tile_x3<BN>(g.p[2], bid - g.first[2], sA0, sA1, sB0, sB1);
-    else ng::conv_tile_x3<BN>(g.p[3], bid - g.first[3], sA0, sA1, sB0, sB1);
+}  // namespace
+
+// CUs of the current device (the persistent launches start one workgroup per CU)
+static int ng_cu_count_conv() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
 }
 
-}  // namespace
+// one persistent launch of the three-term split tile over 1..4 problems of one tile width
+static int launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, hipStream_t st, const char* what) {
+    ng::X3Work w;
+    int total = 0;
+    for (int i = 0; i < n; ++i) { w.p[i] = ps[i]; w.first[i] = total; total += ng::conv_x3_tiles(ps[i], bn); }
+    for (int i = n; i < 4; ++i) { w.p[i] = ps[0]; w.first[i] = 0x7fffffff; }
+    w.first[n] = total;
+    for (int i = n + 1; i < 5; ++i) w.first[i] = 0x7fffffff;
+    w.n = n;
+    w.nplanes = 1;
+    w.in_plane = w.w3_pstride = w.out_plane = 0;
+    const int G = ng_cu_count_conv();
+    const dim3 grid(total < G ? total : G);
+    if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, w);
+    else hipLaunchKernelGGL(conv_x3_kernel<64>, grid, dim3(512), 0, st, w);
+    return nirgan_check_launch(what);
+}
 
 extern "C" int nirgan_split3(const float* src, void* dst_bf16, int64_t n, int64_t plane, void* stream) {
     NG_REQUIRE(src && dst_bf16 && n > 0 && n % 8 == 0 && plane >= n && plane % 8 == 0, "split3: n and plane must be positive multiples of 8, plane >= n");
@@ -127,13 +142,7 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
     if (rc != NIRGAN_OK) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p.prec == 3) {
-        if (ng::conv_x3_ok(p)) {
-            const int bn = ng::conv_x3_bn(p);
-            const dim3 grid(((p.M + 255) >> 8) * (p.N / bn));
-            if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, p);
-            else hipLaunchKernelGGL(conv_x3_kernel<64>, grid, dim3(512), 0, st, p);
-            return nirgan_check_launch("conv_igemm (three-term split tile)");
-        }
+        if (ng::conv_x3_ok(p)) return launch_conv_x3(&p, 1, ng::conv_x3_bn(p, ng_cu_count_conv()), st, "conv_igemm (three-term split tile)");
         p.prec = 0;             // what the split tile does not cover runs as exact fp32
     }
     if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) {
@@ -197,17 +206,13 @@ extern "C" int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int
     if (g.p[0].prec == 3) {
         // the three-term split tile for every problem of the group, or exact fp32 for all of them
         bool ok = true;
-        for (int i = 0; i < n; ++i) ok = ok && ng::conv_x3_ok(g.p[i]) && ng::conv_x3_bn(g.p[i]) == ng::conv_x3_bn(g.p[0]);
+        for (int i = 0; i < n; ++i) ok = ok && ng::conv_x3_ok(g.p[i]) && (g.p[i].N % 128 == 0) == (g.p[0].N % 128 == 0);
         if (ok) {
-            const int bn = ng::conv_x3_bn(g.p[0]);
-            total = 0;
-            for (int i = 0; i < n; ++i) { g.first[i] = total; total += ((g.p[i].M + 255) >> 8) * (g.p[i].N / bn); }
-            for (int i = n; i < 4; ++i) { g.p[i] = g.p[0]; g.first[i] = 0x7fffffff; }
-            g.first[4] = total;
-            g.n = n;
-            if (bn == 128) hipLaunchKernelGGL(conv_group_x3_kernel<128>, dim3(total), dim3(512), 0, st, g);
-            else hipLaunchKernelGGL(conv_group_x3_kernel<64>, dim3(total), dim3(512), 0, st, g);
-            return nirgan_check_launch("conv_igemm_group (three-term split tile)");
+            // (the tile width from the whole group's tile count: the phases of one launch share the chip)
+            long long t128 = 0;
+            for (int i = 0; i < n; ++i) t128 += g.p[i].N % 128 == 0 ? ng::conv_x3_tiles(g.p[i], 128) : 0;
+            const int bn = (g.p[0].N % 128 != 0 || g.p[0].algo == NIRGAN_CONV_X3_BN64 || t128 * 4 < 3ll * ng_cu_count_conv()) ? 64 : 128;
+            return launch_conv_x3(g.p, n, bn, st, "conv_igemm_group (three-term split tile)");
         }
         for (int i = 0; i < n; ++i) g.p[i].prec = 0;
     }

@@ -61,55 +61,110 @@ __device__ __forceinline__ void x3_split8(const f32x4 lo, const f32x4 hi, bf16x8
     L = __builtin_bit_cast(bf16x8, l);
 }
 
+// Work of one persistent launch: up to four problems of one tile width (the sub-pixel phases of a stride-2 layer) or `nplanes`
+// problems of one geometry (the plane GEMMs of a Winograd layer: plane i reads in + i in_plane, the weight planes + i w3_pstride and
+// writes out + i out_plane).  Item i of the launch = tile i - first[k] of problem k.
+struct X3Work {
+    ConvParams p[4];
+    int first[5];              // first item of each problem; first[n] = all items
+    int n;
+    int nplanes;               // > 1: p[0] only; item = plane * tiles + tile
+    long long in_plane, w3_pstride, out_plane;
+};
+
+// PERSISTENT workgroups, one per CU: a workgroup walks items b, b + G, ... (XCD-contiguous through ng_xcd_remap).  What one tile per
+// workgroup left exposed with a single workgroup per CU -- 7-10 us of prologue (index arithmetic, the first fetch's latency) and
+// epilogue per tile, as much as the K loop of a sub-pixel phase with 4-16 K-tiles -- overlaps here: behind the K loop's last barrier
+// the NEXT item's first K-tile is fetched (registers + LDS-DMA into stage 0), then this item's accumulators are stored, then the
+// fetched rows are converted.  The epilogue's transpose goes through stage 1 only (in two halves): stage 0 is the next item's.
+// (Measured and dropped: the MFMA operands swapped so that a lane's four accumulator registers are four consecutive channels of one
+// pixel and leave as one 16-byte store without LDS -- adjacent lanes then hold different pixels, the stores do not coalesce: +8 us per tile.)
 template <int BN>
-__device__ __forceinline__ void conv_tile_x3(const ConvParams& p, const int id, char* sA0, char* sA1, char* sB0, char* sB1,
-                                             const float* in_base = nullptr, const unsigned short* w3_base = nullptr, float* out_base = nullptr) {
+__device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp, char* sA0, char* sA1, char* sB0, char* sB1, char* sRed) {
     static_assert(BN == 128 || BN == 64, "256 x 128 or 256 x 64 block tiles");
     constexpr int B_TERM = BN * 64;            // bytes of one term image of B
     constexpr int NT = BN / 32;                // 16-column MFMA tiles per wave (wave tile 64 x BN/2)
     constexpr int CW = BN / 2;                 // columns per wave
     constexpr int BPT = BN / 16;               // 1 KB LDS-DMA pieces per term image of B
-    const float* const p_in = in_base ? in_base : p.in;
-    const unsigned short* const p_w3 = w3_base ? w3_base : p.w3;
-    float* const p_out = out_base ? out_base : p.out;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int ntn = p.N / BN;
-    const int n0 = (id % ntn) * BN, m0 = (id / ntn) * 256;
+    const int total = wp->first[wp->n];
+    const int G = gridDim.x;
 
-    // ---------------- loader state
-    unsigned a_goff[2];
+    // ---------------- constants of the launch
     int a_wr[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = j * 128 + (tid >> 2), c = tid & 3;
-        int m = m0 + row;
-        m = m < p.M ? m : p.M - 1;
-        const int b = m / p.OHW, r = m - b * p.OHW;
-        const int oh = r / p.OW, ow = r - oh * p.OW;
-        a_goff[j] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + c * 8) * 4u;
         a_wr[j] = row * 64 + ((c ^ x3_key(row)) << 4);
     }
     const int b_idx = wave % BPT;               // piece of a term image this wave stages (the same for every term it serves)
-    unsigned b_goff;
-    {
-        const int row = b_idx * 16 + (lane >> 2), c = (lane & 3) ^ x3_key(row);
-        b_goff = unsigned((n0 + row) * p.K + c * 8) * 2u;
-    }
-    const int tapv = p.tap_off[lane & (NIRGAN_MAX_TAPS - 1)];
-    const int nk = p.ntaps * (p.run >> 5);
-    int ct = 0, cc = 0;                         // K-tiles in slice-major order: 32-channel slice cc of the run, all taps
+    const int b_row = b_idx * 16 + (lane >> 2), b_c = (lane & 3) ^ x3_key(b_row);
+    const int swz = ((lane >> 4) ^ x3_key(lane & 15)) << 4;
+    const int a_rd = (wr * 64 + (lane & 15)) * 64 + swz;
+    const int b_rd = (wc * CW + (lane & 15)) * 64 + swz;
+
+    // ---------------- per-item state: `L` the item whose K-tiles are being fetched, `E` the item whose accumulators are being stored
+    struct Item {
+        const NG_CONST ConvParams* p;
+        const char* in8; const char* w8; float* out;
+        int m0, n0, nk;
+        int ntaps, run;            // (copies: a read through `p` behind a barrier or an asm memory clobber is a scalar load again)
+        long long w3_plane;
+    };
+    auto locate = [&](const int item, Item& t) {
+        const int id0 = ng_xcd_remap(item, total);
+        int k = 0;
+        if (id0 >= wp->first[1]) k = 1;
+        if (id0 >= wp->first[2]) k = 2;
+        if (id0 >= wp->first[3]) k = 3;
+        const NG_CONST ConvParams* p = &wp->p[k];
+        int id = id0 - wp->first[k];
+        int plane = 0;
+        if (wp->nplanes > 1) {
+            const int per = total / wp->nplanes;
+            plane = id / per;
+            id -= plane * per;
+        }
+        const int ntn = p->N / BN;
+        t.p = p;
+        t.n0 = (id % ntn) * BN;
+        t.m0 = (id / ntn) * 256;
+        t.ntaps = p->ntaps;
+        t.run = p->run;
+        t.w3_plane = p->w3_plane;
+        t.nk = t.ntaps * (t.run >> 5);
+        t.in8 = reinterpret_cast<const char*>(p->in + (long long)plane * wp->in_plane);
+        t.w8 = reinterpret_cast<const char*>(p->w3 + (long long)plane * wp->w3_pstride);
+        t.out = p->out + (long long)plane * wp->out_plane;
+    };
+    Item L, E;
+    unsigned a_goff[2], b_goff;
+    int tapv, ct = 0, cc = 0;                  // K-tiles in slice-major order: 32-channel slice cc of the run, all taps
+    auto begin = [&]() {                       // loader state of item L
+        const NG_CONST ConvParams& p = *L.p;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int m = L.m0 + j * 128 + (tid >> 2);
+            m = m < p.M ? m : p.M - 1;
+            const int b = m / p.OHW, r = m - b * p.OHW;
+            const int oh = r / p.OW, ow = r - oh * p.OW;
+            a_goff[j] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + (tid & 3) * 8) * 4u;
+        }
+        b_goff = unsigned((L.n0 + b_row) * p.K + b_c * 8) * 2u;
+        tapv = p.tap_off[lane & (NIRGAN_MAX_TAPS - 1)];
+        ct = 0;
+        cc = 0;
+    };
     auto advance = [&]() {
         ++ct;
-        if (ct == p.ntaps) { ct = 0; cc += 32; }
+        if (ct == L.ntaps) { ct = 0; cc += 32; }
     };
-    const char* const in8 = reinterpret_cast<const char*>(p_in);
-    const char* const w8 = reinterpret_cast<const char*>(p_w3);
     f32x4 ra[4];
     auto loadA = [&]() {
         const int toff = __builtin_amdgcn_readlane(tapv, ct);
-        const char* base = ng_uniform_ptr(in8 + (long long)(toff + cc) * 4);
+        const char* base = ng_uniform_ptr(L.in8 + (long long)(toff + cc) * 4);
         ra[0] = ng_gld16_so(base, a_goff[0]);
         ra[1] = ng_gld16_so(base, a_goff[0] + 16u);
         ra[2] = ng_gld16_so(base, a_goff[1]);
@@ -121,29 +176,27 @@ __device__ __forceinline__ void conv_tile_x3(const ConvParams& p, const int id, 
             const int piece = wave + 8 * i;     // (uniform) BN = 128: term i, piece `wave` of it
             if (BN == 128 || piece < 3 * BPT) {
                 const int term = piece / BPT;
-                const char* base = ng_uniform_ptr(w8 + ((long long)term * p.w3_plane + ct * p.run + cc) * 2);
+                const char* base = ng_uniform_ptr(L.w8 + ((long long)term * L.w3_plane + ct * L.run + cc) * 2);
                 ng_glds16_so(base, b_goff, sB + term * B_TERM + b_idx * 1024);
             }
         }
     };
     auto commitA = [&](char* sA, const int j) {
-        bf16x8 H, M, L;
-        x3_split8(ra[2 * j], ra[2 * j + 1], H, M, L);
+        bf16x8 H, M, Lo;
+        x3_split8(ra[2 * j], ra[2 * j + 1], H, M, Lo);
         *reinterpret_cast<bf16x8*>(sA + a_wr[j]) = H;
         *reinterpret_cast<bf16x8*>(sA + X3_A_TERM + a_wr[j]) = M;
-        *reinterpret_cast<bf16x8*>(sA + 2 * X3_A_TERM + a_wr[j]) = L;
+        *reinterpret_cast<bf16x8*>(sA + 2 * X3_A_TERM + a_wr[j]) = Lo;
     };
 
-    // ---------------- compute state
-    const int swz = ((lane >> 4) ^ x3_key(lane & 15)) << 4;
-    const int a_rd = (wr * 64 + (lane & 15)) * 64 + swz;
-    const int b_rd = (wc * CW + (lane & 15)) * 64 + swz;
+    // ---------------- compute: acc[mt][nt][r] = out[row mt * 16 + 4 (lane >> 4) + r][column nt * 16 + (lane & 15)] of the wave tile
     f32x4 acc[4][NT];
+    auto zero = [&]() {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
     // one K-tile: B fragments (3 terms), then the two row halves of the wave tile; `mid()` = the conversion + LDS stores of the NEXT
     // K-tile's A rows
     auto compute = [&](const char* sA, const char* sB, auto&& mid) {
@@ -181,16 +234,20 @@ __device__ __forceinline__ void conv_tile_x3(const ConvParams& p, const int id, 
             }
         }
     };
-
-    // ---------------- main loop (two distinct stage objects, unrolled by two: the compiler sees that the stores and the LDS-DMA of
-    // stage s + 1 do not alias the fragment reads of stage s)
-    loadA();
-    issueB(sB0);
-    advance();
-    commitA(sA0, 0);
-    commitA(sA0, 1);
-    auto step = [&](const char* cA, const char* cB, char* nA, char* nB, const bool more) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (two distinct stage objects, unrolled by two: the compiler sees that the stores and the LDS-DMA of stage s + 1 do not alias the
+    // fragment reads of stage s)
+    // `behind_stores`: the first step behind a full tile's epilogue.  vmcnt counts in issue order and this item's first LDS-DMA pieces
+    // were issued BEFORE that epilogue's ESTORES output stores, so "all but the ESTORES youngest" covers them and leaves the stores in
+    // flight -- with vmcnt(0) every workgroup would sit out the drain of the 32 MB all 256 of them have just written (measured: +8 us
+    // per tile against one tile per workgroup, where the next workgroup's loop runs under the previous one's stores).
+    constexpr int ESTORES = 2 * (32 / (64 / (CW / 4)));       // store instructions of a full tile's epilogue, per lane
+    auto step = [&](const char* cA, const char* cB, char* nA, char* nB, const bool more, const bool behind_stores = false) {
+        if (behind_stores) {
+            if constexpr (ESTORES == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         if (more) {
             loadA();
@@ -201,20 +258,24 @@ __device__ __forceinline__ void conv_tile_x3(const ConvParams& p, const int id, 
             compute(cA, cB, []() {});
         }
     };
-    int k = 0;
-    for (; k + 2 <= nk; k += 2) {
-        step(sA0, sB0, sA1, sB1, true);
-        step(sA1, sB1, sA0, sB0, k + 2 < nk);
-    }
-    if (k < nk) step(sA0, sB0, sA1, sB1, false);
 
-    // ---------------- partial sums for the instance norm that follows (nirgan_conv_desc.stats_ws): a wave's 64 rows leave, per column,
-    // {k = the chunk's first row, sum (v - k), sum (v - k)^2, 64} -- the contract of conv_tile / conv_tile256, chunk = 64 output pixels
-    if (p.stats != nullptr) {
-        const int mrow = m0 + wr * 64;
-        if (mrow < p.M) {                       // (host: OH*OW % 128 == 0, so a 64-row chunk is whole and inside one sample)
-            const int b = mrow / p.OHW;
-            float* sp = p.stats + (size_t(b) * p.stats_cps + p.stats_chunk0 + ((mrow - b * p.OHW) >> 6)) * 4 * p.N;
+    // ---------------- epilogue of item E.  The accumulators go through the SECOND stage (idle until the next item's second K-tile lands:
+    // the next item's first fetch, into stage 0, is in flight meanwhile) in two halves of 32 rows, each wave through its own 32 x CW
+    // floats, and leave as whole row segments, 16 bytes per lane.
+    auto epilogue = [&]() -> bool {
+        const NG_CONST ConvParams& p = *E.p;
+        // (copies: the stores below make the compiler read every field again through `p`)
+        const int pM = p.M, pN = p.N, OHW = p.OHW, OW = p.OW, OH = p.OHW / p.OW, out_img = p.out_img, out_row = p.out_row * p.out_stride,
+                  out_px = p.out_cs * p.out_stride, out_org = p.out_org, f_img = p.f_img, f_row = p.f_row * p.out_stride, f_px = p.N * p.out_stride,
+                  f_org = p.f_org;
+        const float* const f_y = p.f_y;
+        const int mbase = E.m0 + wr * 64;
+        const bool full = E.m0 + 256 <= pM;
+        // partial sums for the instance norm that follows (nirgan_conv_desc.stats_ws): the wave's 64 rows leave, per column,
+        // {k = the chunk's first row, sum (v - k), sum (v - k)^2, 64} -- the contract of conv_tile / conv_tile256
+        if (p.stats != nullptr && mbase < pM) {                     // (host: OH*OW % 128 == 0: a 64-row chunk is whole and inside one sample)
+            const int b = mbase / OHW;
+            float* sp = p.stats + (size_t(b) * p.stats_cps + p.stats_chunk0 + ((mbase - b * OHW) >> 6)) * 4 * pN;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float k0 = __shfl(acc[0][nt][0], lane & 15, 64);
@@ -231,95 +292,150 @@ __device__ __forceinline__ void conv_tile_x3(const ConvParams& p, const int id, 
                 s2 += __shfl_xor(s2, 16, 64);
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
-                const int col = n0 + wc * CW + nt * 16 + (lane & 15);
+                const int col = E.n0 + wc * CW + nt * 16 + (lane & 15);
                 if (lane < 16) {
                     sp[col] = k0;
-                    sp[p.N + col] = s1;
-                    sp[2 * p.N + col] = s2;
-                    sp[3 * p.N + col] = 64.f;
+                    sp[pN + col] = s1;
+                    sp[2 * pN + col] = s2;
+                    sp[3 * pN + col] = 64.f;
                 }
             }
         }
-    }
+        constexpr int LPR = CW / 4, RPP = 64 / LPR;         // lanes per row (4 channels each), rows per pass
+        float* const stg = reinterpret_cast<float*>(wave < 6 ? sA1 + wave * 8192 : sB1 + (wave - 6) * 8192);
+        const bool fused = f_y != nullptr;
+        const float fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
+        const int chunk = lane % LPR, lrow = lane / LPR;
+        const int n = E.n0 + wc * CW + chunk * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+        int m = mbase + lrow;
+        const int mc = m < pM ? m : pM - 1;
+        int b = mc / OHW;
+        const int r0 = mc - b * OHW;
+        int oh = r0 / OW, ow = r0 - oh * OW;
+        const int fb = (mbase < pM ? mbase : pM - 1) / OHW;           // (fused: one sample per 128-row chunk, host: OH*OW % 128 == 0)
+        f32x4 fm = {0.f, 0.f, 0.f, 0.f}, fr = fm, s1 = fm, s2 = fm;
+        if (fused) {
+            fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(fb) * pN + n);
+            fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(fb) * pN + n);
+        }
+        // (FULL: a tile whose 256 rows all exist issues every store instruction, unrolled and without a predicate -- step() counts them,
+        // and so can the compiler when it waits for the next item's fetched rows in front of their conversion)
+        auto halves = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            constexpr int P = 32 / RPP;                       // passes (store instructions per lane) of a half
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) stg[(q * 16 + (lane >> 4) * 4 + r) * CW + nt * 16 + (lane & 15)] = acc[h * 2 + q][nt][r];
+                // the half's y values (fused first pass) are fetched BEFORE its stores: vmcnt counts loads and stores in one order, so a
+                // load issued behind a store is not "done" before that store is acknowledged -- a y load per pass behind the previous
+                // pass's store sat out a store round trip sixteen times per tile
+                int ooff[P];
+                bool ok[P];
+                f32x4 yv[P];
+#pragma unroll
+                for (int pass = 0; pass < P; ++pass) {
+                    ok[pass] = FULL || m < pM;
+                    ooff[pass] = b * out_img + oh * out_row + ow * out_px + out_org + n;
+                    if (fused && ok[pass]) yv[pass] = *reinterpret_cast<const f32x4*>(f_y + (size_t(b) * f_img + size_t(oh) * f_row + size_t(ow) * f_px + f_org + n));
+                    m += RPP;
+                    ow += RPP;
+                    while (ow >= OW) { ow -= OW; ++oh; }
+                    while (oh >= OH) { oh -= OH; ++b; }
+                }
+#pragma unroll
+                for (int pass = 0; pass < P; ++pass) {
+                    if (ok[pass]) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pass * RPP + lrow) * CW + chunk * 4);
+                        v += bv;
+                        *reinterpret_cast<f32x4*>(E.out + ooff[pass]) = v;
+                        if (fused) {
+                            const f32x4 z = (yv[pass] - fm) * fr;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float gz = z[q] > 0.f ? v[q] : v[q] * fneg;
+                                s1[q] += gz;
+                                s2[q] += gz * z[q];
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        if (full) halves(std::true_type{}); else halves(std::false_type{});
+        if (fused) {
+            // first pass of the consumer layer's instance-norm backward: this wave's 64 rows, then the two waves of a 128-row chunk
+            // (wr = 2 c, 2 c + 1) join through a small LDS array of their own in a fixed order
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) {
+                    s1[q] += __shfl_xor(s1[q], o, 64);
+                    s2[q] += __shfl_xor(s2[q], o, 64);
+                }
+            f32x4* const red = reinterpret_cast<f32x4*>(sRed);        // 8 waves x LPR x 2 sums
+            if (lane < LPR) {
+                red[(wave * LPR + chunk) * 2] = s1;
+                red[(wave * LPR + chunk) * 2 + 1] = s2;
+            }
+            __syncthreads();                    // (uniform: `fused` is a constant of the item's problem, the items of a launch agree)
+            if ((wr & 1) == 0 && lane < LPR && mbase < pM) {
+                const f32x4 t1 = s1 + red[((wave + 2) * LPR + chunk) * 2], t2 = s2 + red[((wave + 2) * LPR + chunk) * 2 + 1];
+                float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((mbase - fb * OHW) >> 7)) * 2 * pN + n;
+                *reinterpret_cast<f32x4*>(pp) = t1;
+                *reinterpret_cast<f32x4*>(pp + pN) = t2;
+            }
+            __syncthreads();                    // the array is free for the next item
+        }
+        return full;
+    };
 
-    // ---------------- epilogue: each wave transposes its 64 x CW tile through its OWN region of the (now idle) stages and stores whole
-    // row segments, 16 bytes per lane (as conv_tile256)
-    __syncthreads();                            // every wave's fragment reads of the last K-tile are done
-    char* const reg = wave < 3 ? sA0 + wave * 16384 : (wave < 6 ? sA1 + (wave - 3) * 16384 : (wave == 6 ? sB0 : sB1));
-    float* const stg = reinterpret_cast<float*>(reg);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) stg[(mt * 16 + (lane >> 4) * 4 + r) * CW + nt * 16 + (lane & 15)] = acc[mt][nt][r];
-    constexpr int LPR = CW / 4, RPP = 64 / LPR;         // lanes per row (4 channels each), rows per pass
-    const int OH = p.OHW / p.OW;
-    const bool fused = p.f_y != nullptr;
-    const float fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
-    const int chunk = lane % LPR, lrow = lane / LPR;
-    const int n = n0 + wc * CW + chunk * 4;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-    const int mbase = m0 + wr * 64;
-    int m = mbase + lrow;
-    const int mc = m < p.M ? m : p.M - 1;
-    int b = mc / p.OHW;
-    const int r0 = mc - b * p.OHW;
-    int oh = r0 / p.OW, ow = r0 - oh * p.OW;
-    const int fb = (mbase < p.M ? mbase : p.M - 1) / p.OHW;          // (fused: one sample per 128-row chunk, host: OH*OW % 128 == 0)
-    f32x4 fm = {0.f, 0.f, 0.f, 0.f}, fr = fm, s1 = fm, s2 = fm;
-    if (fused) {
-        fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(fb) * p.N + n);
-        fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(fb) * p.N + n);
-    }
-#pragma unroll 4
-    for (int pass = 0; pass < 64 / RPP; ++pass) {
-        if (m < p.M) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pass * RPP + lrow) * CW + chunk * 4);
-            v += bv;
-            const int oidx = b * p.out_img + oh * p.out_stride * p.out_row + ow * p.out_stride * p.out_cs + p.out_org + n;
-            *reinterpret_cast<f32x4*>(p_out + oidx) = v;
-            if (fused) {
-                const size_t yidx = size_t(b) * p.f_img + size_t(oh * p.out_stride) * p.f_row + size_t(ow * p.out_stride) * p.N + p.f_org + n;
-                const f32x4 y = *reinterpret_cast<const f32x4*>(p.f_y + yidx);
-                const f32x4 z = (y - fm) * fr;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float gz = z[q] > 0.f ? v[q] : v[q] * fneg;
-                    s1[q] += gz;
-                    s2[q] += gz * z[q];
-                }
-            }
+    // ---------------- the walk
+    int item = blockIdx.x;
+    if (item >= total) return;
+    locate(item, L);
+    begin();
+    loadA();
+    issueB(sB0);
+    advance();
+    commitA(sA0, 0);
+    commitA(sA0, 1);
+    bool behind = false;
+    while (true) {
+        zero();
+        const int nk = L.nk;
+        int k = 0;
+        if (nk >= 2) {
+            if (behind) step(sA0, sB0, sA1, sB1, true, true); else step(sA0, sB0, sA1, sB1, true);
+            step(sA1, sB1, sA0, sB0, 2 < nk);
+            k = 2;
         }
-        m += RPP;
-        ow += RPP;
-        while (ow >= p.OW) { ow -= p.OW; ++oh; }
-        while (oh >= OH) { oh -= OH; ++b; }
-    }
-    if (fused) {
-        // first pass of the consumer layer's instance-norm backward: this wave's 64 rows, then the two waves of a 128-row chunk
-        // (wr = 2 c, 2 c + 1) join through LDS in a fixed order
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int o = LPR; o < 64; o <<= 1) {
-                s1[q] += __shfl_xor(s1[q], o, 64);
-                s2[q] += __shfl_xor(s2[q], o, 64);
-            }
-        __syncthreads();                        // (uniform: `fused` is a launch constant) every wave's staging reads are done
-        f32x4* const red = reinterpret_cast<f32x4*>(sA0);          // 8 waves x LPR x 2 sums
-        if (lane < LPR) {
-            red[(wave * LPR + chunk) * 2] = s1;
-            red[(wave * LPR + chunk) * 2 + 1] = s2;
+        for (; k + 2 <= nk; k += 2) {
+            step(sA0, sB0, sA1, sB1, true);
+            step(sA1, sB1, sA0, sB0, k + 2 < nk);
         }
-        __syncthreads();
-        if ((wr & 1) == 0 && lane < LPR && mbase < p.M) {
-            const f32x4 t1 = s1 + red[((wave + 2) * LPR + chunk) * 2], t2 = s2 + red[((wave + 2) * LPR + chunk) * 2 + 1];
-            float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((mbase - fb * p.OHW) >> 7)) * 2 * p.N + n;
-            *reinterpret_cast<f32x4*>(pp) = t1;
-            *reinterpret_cast<f32x4*>(pp + p.N) = t2;
+        if (k < nk) step(sA0, sB0, sA1, sB1, false);
+        E = L;
+        item += G;
+        const bool more = item < total;
+        __syncthreads();                        // every wave's fragment reads of the last K-tile are done: stage 0 is free
+        if (more) {
+            locate(item, L);
+            begin();
+            loadA();
+            issueB(sB0);
+            advance();
         }
+        behind = epilogue();
+        if (!more) break;
+        commitA(sA0, 0);
+        commitA(sA0, 1);
     }
 }
 
@@ -333,6 +449,7 @@ inline bool conv_x3_ok(const ConvParams& p) {
 }
 // 128-column tiles unless N has no such tiles, the caller pins the 64-column tile (NIRGAN_CONV_X3_BN64: A/B), or the problem has fewer
 // 256 x 128 tiles than three quarters of the CUs (one workgroup per CU: twice as many 64-column tiles fill the chip)
+inline int conv_x3_tiles(const ConvParams& p, const int bn) { return ((p.M + 255) >> 8) * (p.N / bn); }
 inline int conv_x3_bn(const ConvParams& p, const int cus = 256) {
     if (p.N % 128 != 0 || p.algo == NIRGAN_CONV_X3_BN64) return 64;
     const long long tiles = (long long)((p.M + 255) >> 8) * (p.N / 128);

@@ -326,7 +326,10 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.precision = ctx.precision
     d.algo = 0 if OPT.tile256 else L.CONV_TILE128
     x3 = getattr(w, "x3", None)
-    if x3 is not None and ctx.precision == 0 and OPT.split3 and taps.run % 32 == 0 and N % 64 == 0 and not d.out_bf16 and out.C % 4 == 0:
+    # (N = 64: the 256 x 64 tile converts as many activation rows per MFMA as the 128-column tile does for two -- it pays from K = 512 on:
+    # PatchGAN sub-pixel phases 307 -> 247 us, the generator's K = 128 .. 512 phases on the 256 x 256 maps 397 -> 508)
+    if (x3 is not None and ctx.precision == 0 and OPT.split3 and taps.run % 32 == 0 and not d.out_bf16 and out.C % 4 == 0
+            and (N % 128 == 0 or (N % 64 == 0 and taps.n * taps.run >= 512))):
         # exact-fp32 mode: this contraction on the bf16 pipe as three bf16 terms per operand, six products (fp32-equivalent; no split-K form)
         d.precision, d.w_x3, d.w_x3_plane = 3, x3[0].data_ptr(), x3[1]
         allow_split = False
@@ -638,6 +641,10 @@ def emit_conv_group(plan: Plan, ctx: Ctx, descs: list):
     """One launch for up to 4 conv descriptors (sub-pixel phases)."""
     for i in range(0, len(descs), 4):
         grp = descs[i:i + 4]
+        if any(d.precision != grp[0].precision for d in grp):      # the three-term split tile for every phase of a launch, or for none
+            for d in grp:
+                if d.precision == 3:
+                    d.precision = 0
         arr = (C.POINTER(L.ConvDesc) * len(grp))(*[C.pointer(d) for d in grp])
         ctx.keep.append(arr)
         plan.add("nirgan_conv_igemm_group", arr, len(grp))
