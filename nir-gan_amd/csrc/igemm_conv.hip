@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_group_kernel(const ConvGroup g) {
 }  // namespace
 
 // CUs of the current device (the persistent launches start one workgroup per CU)
-static int ng_cu_count_conv() {
+int ng::ng_cu_count_conv() {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0, n = 0;
@@ -109,23 +109,28 @@ static int ng_cu_count_conv() {
     }
     return cus;
 }
+using ng::ng_cu_count_conv;
 
-// one persistent launch of the three-term split tile over 1..4 problems of one tile width
-static int launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, hipStream_t st, const char* what) {
+// one persistent launch of the three-term split tile over 1..4 problems of one tile width, or over nplanes problems of ps[0]'s geometry
+int ng::ng_launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, const int nplanes, const long long in_plane, const long long w3_pstride,
+                          const long long out_plane, hipStream_t st, const char* what) {
     ng::X3Work w;
     int total = 0;
-    for (int i = 0; i < n; ++i) { w.p[i] = ps[i]; w.first[i] = total; total += ng::conv_x3_tiles(ps[i], bn); }
+    for (int i = 0; i < n; ++i) { w.p[i] = ps[i]; w.first[i] = total; total += ng::conv_x3_tiles(ps[i], bn) * (nplanes > 1 ? nplanes : 1); }
     for (int i = n; i < 4; ++i) { w.p[i] = ps[0]; w.first[i] = 0x7fffffff; }
     w.first[n] = total;
     for (int i = n + 1; i < 5; ++i) w.first[i] = 0x7fffffff;
     w.n = n;
-    w.nplanes = 1;
-    w.in_plane = w.w3_pstride = w.out_plane = 0;
+    w.nplanes = nplanes > 1 ? nplanes : 1;
+    w.in_plane = in_plane; w.w3_pstride = w3_pstride; w.out_plane = out_plane;
     const int G = ng_cu_count_conv();
     const dim3 grid(total < G ? total : G);
     if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, w);
     else hipLaunchKernelGGL(conv_x3_kernel<64>, grid, dim3(512), 0, st, w);
     return nirgan_check_launch(what);
+}
+static int launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, hipStream_t st, const char* what) {
+    return ng::ng_launch_conv_x3(ps, n, bn, 1, 0, 0, 0, st, what);
 }
 
 extern "C" int nirgan_split3(const float* src, void* dst_bf16, int64_t n, int64_t plane, void* stream) {

@@ -329,7 +329,7 @@ extern "C" int nirgan_wgrad_igemm(const nirgan_wgrad_desc* d, void* stream) {
     if (p.prec == 3) {
         if (ng::wgrad_x3_ok(p)) {
             const int tn = ng::wgrad_x3_tn(p);
-            const int units = (p.N / tn) * ((p.K + 127) >> 7) * p.nsplit, G = ng_cu_count();
+            const int units = (p.N / tn) * ((p.K + 127) >> 7) * p.nsplit * p.nplanes, G = ng_cu_count();
             if (tn == 256) hipLaunchKernelGGL(wgrad_x3_kernel<256>, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
             else hipLaunchKernelGGL(wgrad_x3_kernel<128>, dim3(units < G ? units : G), dim3(512), 0, st, p, units);
             return nirgan_check_launch("wgrad_igemm (three-term split tile)");

@@ -439,6 +439,11 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
     }
 }
 
+// one persistent launch over 1..4 problems of one tile width, or over nplanes problems of p[0]'s geometry (defined in igemm_conv.hip)
+int ng_launch_conv_x3(const ConvParams* ps, int n, int bn, int nplanes, long long in_plane, long long w3_pstride, long long out_plane,
+                      hipStream_t st, const char* what);
+int ng_cu_count_conv();
+
 // whether the split tile covers a problem (host): precision 3 with the weight planes present, 32-channel slices, whole 64-column tiles,
 // fp32 tensors on both sides, 32-bit offsets, no split-K
 inline bool conv_x3_ok(const ConvParams& p) {
@@ -476,13 +481,17 @@ __device__ __forceinline__ void wgrad_tile_x3(const WgradParams& p, const int un
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int ntn = p.N / TN, ntj = (p.K + 127) >> 7;
-    const int nt_ = unit % ntn, rest = unit / ntn;
+    const int per_plane = ntn * ntj * p.nsplit;
+    const int plane = unit / per_plane, u = unit - plane * per_plane;       // (planes: the transform-domain weight gradient of a Winograd layer)
+    const int nt_ = u % ntn, rest = u / ntn;
     const int jt = rest % ntj, split = rest / ntj;
     const int n0 = nt_ * TN, j0 = jt * 128;
     const int mstart = split * p.rows_per_split;
     int mend = mstart + p.rows_per_split;
     mend = mend < p.M ? mend : p.M;
-    const int nk = mend > mstart ? (mend - mstart) >> 5 : 0;
+    const int nk = mend > mstart ? (mend - mstart + 31) >> 5 : 0;          // (a partly filled last K-tile only in the plane-matrix form)
+    const float* const Pp = p.p + (long long)plane * p.p_plane;
+    const float* const Qp = p.q + (long long)plane * p.q_plane;
 
     // ---------------- loader state: thread -> pixel row tid >> 4 of the K-tile, 8 channels / columns from (tid & 15) * 8
     const int lrow = tid >> 4, lch = tid & 15;
@@ -506,16 +515,36 @@ __device__ __forceinline__ void wgrad_tile_x3(const WgradParams& p, const int un
     int soh = __builtin_amdgcn_readfirstlane((mstart - sb * p.OHW) / p.OW);
     int sow = __builtin_amdgcn_readfirstlane(mstart - sb * p.OHW - soh * p.OW);
     f32x4 rp[PT][2], rq[2];
+    int mcur = mstart;
     auto load = [&]() {
-        const char* pb = ng_uniform_ptr(reinterpret_cast<const char*>(p.p + (size_t(sb) * p.p_img + size_t(soh) * p.p_row + sow * p.p_cs + p.p_org + n0)));
-        const char* qb = ng_uniform_ptr(reinterpret_cast<const char*>(p.q + (size_t(sb) * p.q_img + size_t(soh) * p.q_stride * p.q_row + sow * p.q_stride * p.q_cs + p.q_org)));
+        const char* pb = ng_uniform_ptr(reinterpret_cast<const char*>(Pp + (size_t(sb) * p.p_img + size_t(soh) * p.p_row + sow * p.p_cs + p.p_org + n0)));
+        const char* qb = ng_uniform_ptr(reinterpret_cast<const char*>(Qp + (size_t(sb) * p.q_img + size_t(soh) * p.q_stride * p.q_row + sow * p.q_stride * p.q_cs + p.q_org)));
+        if (mcur + 32 <= mend) {
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            rp[i][0] = ng_gld16_so(pb, p_goff[i]);
-            rp[i][1] = ng_gld16_so(pb, p_goff[i] + 16u);
+            for (int i = 0; i < PT; ++i) {
+                rp[i][0] = ng_gld16_so(pb, p_goff[i]);
+                rp[i][1] = ng_gld16_so(pb, p_goff[i] + 16u);
+            }
+            rq[0] = ng_gld16_so(qb, q_goff);
+            rq[1] = ng_gld16_so(qb, q_goff + 16u);
+        } else {
+            // the split's last, partly filled K-tile (plane-matrix form: one image row of M pixels, M no multiple of 32): rows past the
+            // end read the last valid row and contribute zeros
+            const int last = mend - 1 - mcur, back = lrow > last ? lrow - last : 0;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const unsigned o = p_goff[i] - unsigned(back * p.p_cs) * 4u;
+                rp[i][0] = ng_gld16_so(pb, o);
+                rp[i][1] = ng_gld16_so(pb, o + 16u);
+                if (back) rp[i][0] = rp[i][1] = z4;
+            }
+            const unsigned o = q_goff - unsigned(back * p.q_stride * p.q_cs) * 4u;
+            rq[0] = ng_gld16_so(qb, o);
+            rq[1] = ng_gld16_so(qb, o + 16u);
+            if (back) rq[0] = rq[1] = z4;
         }
-        rq[0] = ng_gld16_so(qb, q_goff);
-        rq[1] = ng_gld16_so(qb, q_goff + 16u);
+        mcur += 32;
         sow += 32;
         if (sow >= p.OW) { sow = 0; ++soh; }
         if (soh >= p.OH) { soh = 0; ++sb; }
@@ -613,7 +642,7 @@ __device__ __forceinline__ void wgrad_tile_x3(const WgradParams& p, const int un
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) stg[(mt * 16 + (lane >> 4) * 4 + r) * 64 + nt * 16 + (lane & 15)] = acc[mt][nt][r];
-    float* const slab = p.slabs + size_t(split) * p.N * p.K;
+    float* const slab = p.slabs + (size_t(plane) * p.nsplit + split) * p.N * p.K;
     const int chunk = lane & 15, srow = lane >> 4;
     const int jj = j0 + wc * 64 + chunk * 4;
     if (jj < p.K) {
@@ -626,7 +655,10 @@ __device__ __forceinline__ void wgrad_tile_x3(const WgradParams& p, const int un
 
 // whether wgrad_tile_x3 covers a problem (host)
 inline bool wgrad_x3_ok(const WgradParams& p) {
-    if (!(p.prec == 3 && !p.pq_bf16 && p.nplanes == 1 && p.fast32)) return false;
+    // the scalar pixel walk: K-tiles of 32 pixels inside one image row (fast32), or the plane-matrix form (one row of M pixels, any M)
+    const bool matrix = p.ntaps == 1 && p.tap_off[0] == 0 && p.q_stride == 1 && p.OH == 1 && p.OW == p.M && p.fast32_bytes;
+    if (!(p.prec == 3 && !p.pq_bf16 && (p.fast32 || matrix))) return false;
+    if (p.nplanes > 1 && !matrix) return false;
     if (p.N % 128 != 0 || p.run % 8 != 0 || p.K % 4 != 0) return false;
     return true;
 }

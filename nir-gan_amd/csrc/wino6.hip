@@ -21,6 +21,7 @@
 //   A^T = [[1,1,1,1,1,0],[0,1,-1,2,-1/2,0],[0,1,1,4,1/4,0],[0,1,-1,8,-1/8,1]]
 #include "igemm_tiles.h"
 #include "igemm_tile256.h"
+#include "igemm_x3.h"
 #include "instnorm_dev.h"
 #include <stdlib.h>
 
@@ -179,7 +180,7 @@ template <int V> struct W6 {
 };
 
 // ------------------------------------------------------------------------------------------------ weights
-struct W6W { const float* w; float* U; int K, C, flip; };
+struct W6W { const float* w; float* U; int K, C, flip; unsigned short* U3; };       // U3: the three bf16 planes of U (precision 3), or NULL
 
 template <int V>
 __device__ __forceinline__ void wino6_weight_one(const W6W& p, const long long i) {
@@ -206,19 +207,34 @@ __device__ __forceinline__ void wino6_weight_one(const W6W& p, const long long i
         W6<V>::g(t[a], o);
 #pragma unroll
         for (int b = 0; b < N; ++b) U[(a * N + b) * plane] = o[b];
+        if (p.U3 != nullptr) {
+            // the same value as three bf16 terms h + m + l (nirgan_split3's rule) for the three-term split plane GEMMs: planes N*N*K*C apart
+            unsigned short* U3 = p.U3 + size_t(k) * p.C + c;
+            const size_t term = size_t(N) * N * plane;
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+                const unsigned h = ng::x3_pk(o[b], 0.f) & 0xffffu;
+                const float r1 = o[b] - __builtin_bit_cast(float, h << 16);
+                const unsigned m = ng::x3_pk(r1, 0.f) & 0xffffu;
+                const unsigned l = ng::x3_pk(r1 - __builtin_bit_cast(float, m << 16), 0.f) & 0xffffu;
+                U3[(a * N + b) * plane] = (unsigned short)h;
+                U3[term + (a * N + b) * plane] = (unsigned short)m;
+                U3[2 * term + (a * N + b) * plane] = (unsigned short)l;
+            }
+        }
     }
 }
 
 template <int V>
 __global__ __launch_bounds__(256) void wino6_weight_kernel(const W6W p) { wino6_weight_one<V>(p, blockIdx.x * 256ll + threadIdx.x); }
 
-// all weight transforms of a step in one launch: 8 x int64 per job {w, U, K, C, flip, first_block, variant, 0}
+// all weight transforms of a step in one launch: 8 x int64 per job {w, U, K, C, flip, first_block, variant, U3 (three bf16 planes of U, or 0)}
 __global__ __launch_bounds__(256) void wino6_weights_batch_kernel(const long long* __restrict__ jobs, int njobs) {
     int j = 0;
     for (int i = 1; i < njobs; ++i)
         if (int(blockIdx.x) >= int(jobs[i * 8 + 5])) j = i;
     const long long* J = jobs + j * 8;
-    W6W p{reinterpret_cast<const float*>(J[0]), reinterpret_cast<float*>(J[1]), int(J[2]), int(J[3]), int(J[4])};
+    W6W p{reinterpret_cast<const float*>(J[0]), reinterpret_cast<float*>(J[1]), int(J[2]), int(J[3]), int(J[4]), reinterpret_cast<unsigned short*>(J[7])};
     const long long i = (long long)(int(blockIdx.x) - int(J[5])) * 256 + threadIdx.x;
     if (J[6] == 4) wino6_weight_one<4>(p, i);
     else if (J[6] == 6) wino6_weight_one<6>(p, i);
@@ -1284,11 +1300,19 @@ extern "C" int64_t nirgan_wino6_tiles_r(int B, int H, int W, int r) {
 
 extern "C" int64_t nirgan_wino6_tiles(int B, int H, int W) { return nirgan_wino6_tiles_r(B, H, W, 3); }
 
+static int w6_weights_impl(const float* w, int K, int C, int r, int transpose_flip, float* U, void* U3, void* stream);
 extern "C" int nirgan_wino6_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream) {
+    return w6_weights_impl(w, K, C, r, transpose_flip, U, nullptr, stream);
+}
+extern "C" int nirgan_wino6_weights_x3(const float* w, int K, int C, int r, int transpose_flip, float* U, void* U3_bf16, void* stream) {
+    NG_REQUIRE(U3_bf16 != nullptr, "wino6_weights_x3: null planes");
+    return w6_weights_impl(w, K, C, r, transpose_flip, U, U3_bf16, stream);
+}
+static int w6_weights_impl(const float* w, int K, int C, int r, int transpose_flip, float* U, void* U3, void* stream) {
     r = w6_r(r);
     NG_REQUIRE(w && U && K > 0 && C > 0, "wino6_weights: bad arguments");
     NG_REQUIRE(w6_known(r), "wino6_weights: variant %d (3, 4 or 6)", r);
-    W6W p{w, U, K, C, transpose_flip ? 1 : 0};
+    W6W p{w, U, K, C, transpose_flip ? 1 : 0, static_cast<unsigned short*>(U3)};
     const long long n = (long long)K * C;
     const dim3 grid(unsigned((n + 255) / 256));
     if (r == 3) hipLaunchKernelGGL(wino6_weight_kernel<3>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), p);
@@ -1462,8 +1486,19 @@ static W6Choice w6_gemm_choice(const nirgan_wino6_desc* d, bool pair) {
     return W6_ONE_TILE16;
 }
 
+// precision 3 for the plane GEMMs: the three bf16 planes of U are there and the split tile's shapes apply
+static bool w6_x3(const nirgan_wino6_desc* d, const W6Gemm& g) {
+    return d->U3 != nullptr && d->C % 32 == 0 && d->K % 64 == 0 && g.p.off32 && (long long)w6_np(w6_r(d->r)) * d->K * d->C * 2 < (1ll << 40);
+}
+static bool w6_x3_desc(const nirgan_wino6_desc* d) {
+    W6Gemm g;
+    long long T;
+    return d && d->U3 != nullptr && w6_gemm_params(d, g, T) == NIRGAN_OK && w6_x3(d, g);
+}
+
 extern "C" const char* nirgan_wino6_gemm_kernel_name(const nirgan_wino6_desc* d) {
     if (!d) return "";
+    if (w6_x3_desc(d)) return d->K % 128 == 0 ? "conv_x3_kernel<128> (planes)" : "conv_x3_kernel<64> (planes)";
     if (d->algo == NIRGAN_W6_TILE256 && d->C % 32 == 0 && d->K % 256 == 0) return "wino6_gemm256_kernel";
     switch (w6_gemm_choice(d, false)) {
         case W6_PERSIST32: return "wino6_gemm32p_kernel";
@@ -1482,7 +1517,7 @@ extern "C" const char* nirgan_wino6_pair_kernel_name(const nirgan_wino6_desc* d,
     if (!d || !w) return "";
     ng::WgradParams wp;
     if (ng::build_wgrad_params(w, wp) != NIRGAN_OK) return "";
-    if (w->N <= 64 || wp.prec != 0 || wp.pq_bf16) return "";                      // two ordinary launches
+    if (w->N <= 64 || wp.prec != 0 || wp.pq_bf16 || w6_x3_desc(d)) return "";                      // two ordinary launches
     if (w6_gemm_choice(d, true) == W6_PERSIST32) return w6_pair_wgrad_persistent(wp, w) ? "wino6_pair16p_kernel" : "wino6_pair16_kernel";
     return "wino6_pair_kernel";
 }
@@ -1495,7 +1530,7 @@ extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const ni
     ng::WgradParams wp;
     rc = ng::build_wgrad_params(w, wp);
     if (rc != NIRGAN_OK) return rc;
-    if (w->N <= 64 || wp.prec != 0 || wp.pq_bf16) {           // not the wide fp32 tile: two ordinary launches
+    if (w->N <= 64 || wp.prec != 0 || wp.pq_bf16 || w6_x3(d, g)) {           // not the wide fp32 tile, or the three-term split tiles: two ordinary launches
         rc = nirgan_wino6_gemm(d, stream);
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
@@ -1522,6 +1557,14 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
     const int rc0 = w6_gemm_params(d, g, T);
     if (rc0 != NIRGAN_OK) return rc0;
     const W6Choice ch = w6_gemm_choice(d, false);
+    if (w6_x3(d, g)) {
+        // precision 3: the plane GEMMs on the bf16 pipe, V split in the kernel, U from its three bf16 planes (nirgan_wino6_weights_x3)
+        g.p.prec = 3;
+        g.p.w3 = static_cast<const unsigned short*>(d->U3);
+        g.p.w3_plane = (long long)w6_np(w6_r(d->r)) * d->K * d->C;
+        return ng::ng_launch_conv_x3(&g.p, 1, d->K % 128 == 0 ? 128 : 64, w6_np(w6_r(d->r)), g.in_plane, g.w_plane, g.out_plane,
+                                     static_cast<hipStream_t>(stream), "wino6_gemm (three-term split tile)");
+    }
     if (d->algo == NIRGAN_W6_TILE256 && d->C % 32 == 0 && d->K % 256 == 0 && g.p.off32) {
         const int per_plane = ((g.p.M + 255) >> 8) * (g.p.N >> 8), total = w6_np(w6_r(d->r)) * per_plane;
         hipLaunchKernelGGL(wino6_gemm256_kernel, dim3(total < 256 ? total : 256), dim3(512), 0, static_cast<hipStream_t>(stream), g, per_plane, total);

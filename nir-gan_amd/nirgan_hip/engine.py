@@ -186,16 +186,17 @@ class Plan:
 
     def fuse_wino6_weights(self):
         """The same for the Winograd weight transforms (csrc/wino6.hip: two per residual-block convolution and step, forward and flipped filter)."""
-        jobs = [a for n, a in self.ops if n == "nirgan_wino6_weights_r"]
+        names = ("nirgan_wino6_weights_r", "nirgan_wino6_weights_x3")
+        jobs = [(a + (0,) if n == names[0] else a) for n, a in self.ops if n in names]
         if len(jobs) < 2 or len(jobs) > 256:
             return
         rows, first = [], 0
-        for w, K, Cc, r, flip, U in jobs:
-            rows.append([w, U, K, Cc, flip, first, r, 0])
+        for w, K, Cc, r, flip, U, U3 in jobs:
+            rows.append([w, U, K, Cc, flip, first, r, U3])
             first += (K * Cc + 255) // 256
         table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
         self.ctx.keep.append(table)
-        self.ops = [(n, a) for n, a in self.ops if n != "nirgan_wino6_weights_r"]
+        self.ops = [(n, a) for n, a in self.ops if n not in names]
         self.ops.append(("nirgan_wino6_weights_batch", (table.data_ptr(), len(rows), first)))
 
     def run(self):
@@ -486,7 +487,15 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     NP = _w6_geo(v)[1]
     U = ctx.zeros(NP * cout * cin)
     ctx.keep.append(U)
-    pack.add("nirgan_wino6_weights_r", weight.data_ptr(), cout, cin, v, 1 if flip else 0, U.data_ptr())
+    U3 = None
+    if ctx.precision == 0 and OPT.split3 and OPT.split3_wino and cin % 32 == 0 and cout % 64 == 0:
+        # precision 3 for the plane GEMMs (csrc/igemm_x3.h): U once more as three bf16 planes, written by the same weight transform
+        U3 = torch.zeros(3 * NP * cout * cin, dtype=torch.bfloat16, device=ctx.device)
+        ctx.bytes += U3.numel() * 2
+        ctx.keep.append(U3)
+        pack.add("nirgan_wino6_weights_x3", weight.data_ptr(), cout, cin, v, 1 if flip else 0, U.data_ptr(), U3.data_ptr())
+    else:
+        pack.add("nirgan_wino6_weights_r", weight.data_ptr(), cout, cin, v, 1 if flip else 0, U.data_ptr())
     for name in ("wino6_pool_v", "wino6_pool_m"):
         if not hasattr(ctx, name):
             setattr(ctx, name, SplitPool(ctx))          # one layer at a time (launches run serially)
@@ -503,6 +512,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
     d.zero_page = ctx.zero_page.data_ptr()
     d.algo = OPT.w6_gemm_algo
+    d.U3 = _ptr(U3)
     if stats_ws is not None:        # the output transform leaves the instance norm's partial sums (one chunk per tile): no statistics pass over y
         assert stats_ws.numel() >= T * 4 * cout
         d.stats_ws, d.stats_ws_elems = stats_ws.data_ptr(), stats_ws.numel()
@@ -558,6 +568,12 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     # the one-tile-per-workgroup launch wants: half the slab traffic, 743 -> 750 tiles/s
     persistent = cout == 256 and OPT.w6_gemm_algo == 0 and OPT.wgrad_algo == 0 and OPT.w6_pair
     nsplit, rows = G.wgrad_split(T, tiles, 512 if persistent else 1024)
+    # precision 3 (the layer's plane GEMMs run on the split tile: dgrad.U3): the transform-domain weight gradient as wgrad_tile_x3 units
+    # (256 or 128 rows x 128 columns x one split per plane), one round of the CUs where the split count allows
+    x3 = bool(dgrad.U3) and cout % 128 == 0 and cin % 8 == 0
+    if x3:
+        units = (cout // (256 if cout % 256 == 0 else 128)) * (-(-cin // 128)) * NP
+        nsplit, rows = G.wgrad_split(T, units, max(G.CUS, units), 32)
     # deferred finish (ctx.w6_deferred is a list while a network collects the layers of one trunk): the layer keeps its own slabs and the
     # inverse transforms of all of them run as ONE launch behind the trunk (emit_w6_deferred_finishes)
     deferred = getattr(ctx, "w6_deferred", None) if persistent else None
@@ -572,7 +588,7 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
     d.B, d.OH, d.OW, d.N = 1, 1, T, cout
     d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
     d.zero_page = ctx.zero_page.data_ptr()
-    d.precision = 0
+    d.precision = 3 if x3 else 0
     d.nplanes, d.p_plane, d.q_plane = NP, T * cout, T * cin
     d.algo = OPT.wgrad_algo
     ctx.keep.extend([vin, ydesc, d, slabs])

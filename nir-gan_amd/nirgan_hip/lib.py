@@ -139,7 +139,7 @@ class Wino6Desc(C.Structure):
     _fields_ = [("x", fp), ("x_hp", i32), ("x_wp", i32), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("K", i32),
                 ("U", fp), ("bias", fp), ("V", fp), ("V_elems", i64), ("M", fp), ("M_elems", i64), ("y", fp), ("zero_page", fp), ("r", i32), ("stats_ws", fp), ("stats_ws_elems", i64),
                 ("fuse_y", fp), ("fuse_mean", fp), ("fuse_rstd", fp), ("fuse_g2", fp), ("fuse_gz", fp), ("fuse_part", fp), ("fuse_part_elems", i64),
-                ("fuse_act", i32), ("fuse_slope", f32), ("algo", i32)]
+                ("fuse_act", i32), ("fuse_slope", f32), ("algo", i32), ("U3", fp)]
 
 
 W6_ONE_TILE, W6_PERSIST16, W6_DIRECT_TILE, W6_TILE256 = 1, 2, 3, 4      # nirgan_wino6_desc.algo
@@ -183,6 +183,7 @@ PROTOTYPES = {
     "nirgan_wino6_tiles_r": (i64, [i32, i32, i32, i32]),
     "nirgan_wino6_weights": (i32, [fp, i32, i32, i32, fp, fp]),
     "nirgan_wino6_weights_r": (i32, [fp, i32, i32, i32, i32, fp, fp]),
+    "nirgan_wino6_weights_x3": (i32, [fp, i32, i32, i32, i32, fp, fp, fp]),
     "nirgan_wino6_weights_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_wino6_input": (i32, [C.POINTER(Wino6Desc), fp]),
     "nirgan_wino6_input_norm": (i32, [C.POINTER(Wino6Desc), fp, fp, fp, i32, f32, fp]),

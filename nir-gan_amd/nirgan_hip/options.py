@@ -59,6 +59,8 @@ class Options:
     # csrc/igemm_x3.h): fp32-equivalent results (measured 0.8-1.0 x the exact tile's error against float64) at 1.6-1.8 x its rate; False =
     # the exact fp32 MFMA tiles everywhere (A/B)
     split3: bool = True
+    # ... and the plane GEMMs / transform-domain weight gradients of the Winograd layers too (A/B)
+    split3_wino: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
     endconv_direct: bool = True
 

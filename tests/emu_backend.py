@@ -446,7 +446,7 @@ class EmuBackend:
     def nirgan_wino6_weights(self, w, K, Cc, flip, U, stream=None):
         return self.nirgan_wino6_weights_r(w, K, Cc, 3, flip, U)
 
-    def nirgan_wino6_weights_r(self, w, K, Cc, r, flip, U, stream=None):
+    def nirgan_wino6_weights_r(self, w, K, Cc, r, flip, U, stream=None, U3=None):
         self.calls.append("wino6_w")
         r = self._r6(r)
         if r not in self._W6:
@@ -459,15 +459,23 @@ class EmuBackend:
             g = arr(w, K * Cc * r * r).reshape(K, Cc, r, r).astype(np.float64)
         u = np.einsum("ai,kcij,bj->abkc", Gm, g, Gm)
         arr(U, n * n * K * Cc)[:] = u.reshape(-1).astype(np.float32)
+        if U3:            # the same values as three bf16 planes (nirgan_split3's rule), for the three-term split plane GEMMs
+            for t, v in enumerate(split3_planes(arr(U, n * n * K * Cc))):
+                arr16(int(U3) + 2 * t * n * n * K * Cc, n * n * K * Cc)[:] = v
         return 0
+
+    def nirgan_wino6_weights_x3(self, w, K, Cc, r, flip, U, U3, stream=None):
+        if not U3:
+            return self._fail("wino6_weights_x3: null planes")
+        return self.nirgan_wino6_weights_r(w, K, Cc, r, flip, U, U3=U3)
 
     def nirgan_wino6_weights_batch(self, jobs, njobs, total_blocks, stream=None):
         J = np.ctypeslib.as_array((C.c_int64 * (njobs * 8)).from_address(int(jobs))).reshape(njobs, 8)
         blocks = 0
-        for w, U, K, Cc, flip, first, r, _ in J:
+        for w, U, K, Cc, flip, first, r, U3 in J:
             if first != blocks:
                 return self._fail("wino6_weights_batch: first_block mismatch")
-            rc = self.nirgan_wino6_weights_r(int(w), int(K), int(Cc), int(r), int(flip), int(U))
+            rc = self.nirgan_wino6_weights_r(int(w), int(K), int(Cc), int(r), int(flip), int(U), U3=int(U3))
             if rc:
                 return rc
             blocks += (int(K) * int(Cc) + 255) // 256
@@ -524,6 +532,15 @@ class EmuBackend:
             return self._fail("wino6_gemm: bad geometry / workspace")
         V = arr(d.V, nplanes * T * d.C).reshape(nplanes, T, d.C).astype(np.float64)
         U = arr(d.U, nplanes * d.K * d.C).reshape(nplanes, d.K, d.C).astype(np.float64)
+        if d.U3 and d.C % 32 == 0 and d.K % 64 == 0:
+            # precision 3 (csrc/igemm_x3.h): the planes must be the three-term split of U; the products follow the six-product rule
+            n = nplanes * d.K * d.C
+            pl = [(arr16(int(d.U3) + 2 * t * n, n).astype(np.uint32) << 16).view(np.float32).astype(np.float64) for t in range(3)]
+            if not np.array_equal((pl[0] + pl[1] + pl[2]).reshape(U.shape), U):
+                return self._fail("wino6_gemm: the U3 planes are not the three-term split of U (stale planes?)")
+            Mo = np.stack([contract(V[f].astype(np.float32), np.ascontiguousarray(U[f].T).astype(np.float32), 3) for f in range(nplanes)])
+            arr(d.M, nplanes * T * d.K)[:] = Mo.reshape(-1).astype(np.float32)
+            return 0
         arr(d.M, nplanes * T * d.K)[:] = np.einsum("ftc,fkc->ftk", V, U).reshape(-1).astype(np.float32)
         return 0
 

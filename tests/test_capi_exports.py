@@ -53,7 +53,7 @@ def test_struct_layouts_match_the_header(tmp_path):
              ("nirgan_inject_bwd_desc", L.InjectBwdDesc, "ws_elems"), ("nirgan_plan_entry", L.PlanEntry, "desc"),
              ("nirgan_metrics_desc", L.MetricsDesc, "means"), ("nirgan_locenc_desc", L.LocEncDesc, "features"),
              ("nirgan_hist_match_desc", L.HistMatchDesc, "out"), ("nirgan_ssim_loss_desc", L.SsimLossDesc, "grad_pred"), ("nirgan_emd_loss_desc", L.EmdLossDesc, "grad_pred"),
-             ("nirgan_wino_dy_desc", L.WinoDyDesc, "r"), ("nirgan_wino6_desc", L.Wino6Desc, "algo")]
+             ("nirgan_wino_dy_desc", L.WinoDyDesc, "r"), ("nirgan_wino6_desc", L.Wino6Desc, "U3")]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "nirgan_hip.h"\nint main(void){\n'
     for cname, _, last in pairs:
         src += f'printf("%zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));\n'
