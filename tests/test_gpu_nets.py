@@ -157,8 +157,12 @@ def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
         close(out[k], o[k], 1e-3, k)
     gD, gG = tr.flatD.grad_views(), tr.flatG.grad_views()
     # unforced fp32-vs-fp32 comparison on a 2 x 64 x 64 batch: a handful of activations within rounding of zero flip; F(6x6,3x3) carries
-    # 5x the rounding noise of F(4x4,3x3) (1.7e-5 against 3.4e-6 of a layer's output range), so more of them do
-    l2 = 4e-3 if variant == "F(6x6,3x3)" else 1e-3
+    # 5x the rounding noise of F(4x4,3x3) (1.7e-5 against 3.4e-6 of a layer's output range), so more of them do.  Which ones is a lottery
+    # of the last ulp: over three seeds and three arithmetic settings (exact fp32 tiles; the three-term split tiles for the direct layers;
+    # for the Winograd layers too) the worst tensor lands anywhere between 1.5e-5 and 8.2e-3 with the prediction at 2-3e-5 every time,
+    # the exact-fp32 setting itself at 5.1e-3 / 6.3e-3 on two of the seeds (scripts/diag_x3_medium.py, profiles/r05_medium_width_kink_noise.txt);
+    # the bound that does not depend on the flips is the forced-kink one of test_fullsize_fused_step_against_oracle (3e-4, unchanged)
+    l2 = 1e-2 if variant == "F(6x6,3x3)" else 1e-3
     for k, v in ref.last["grads_D"].items():
         if k not in O.shadowed_bias_keys("D"):
             grad_close(gD[k], v, "gD " + k, l2=l2, mx=4e-2 if variant == "F(6x6,3x3)" else 1e-2)

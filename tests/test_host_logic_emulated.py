@@ -859,3 +859,54 @@ def test_conv_epilogue_takes_the_instance_norm_backward_first_pass(emu, monkeypa
     for k, v in sub(z, "gG/").items():
         if k not in shadow:
             close(gG[k], v, 2e-4, "gG " + k)
+
+
+def test_three_term_split_planes_follow_the_weights(emu, monkeypatch):
+    """Descriptor precision 3 (csrc/igemm_x3.h) through the engine: in exact-fp32 mode the 32-channel-run convolutions / weight gradients
+    and the Winograd plane GEMMs carry the bf16 planes of their packed / transformed weights.  The emulator refuses a launch whose planes
+    are not the three-term split of the weights it is given, so two optimizer steps at lr > 0 prove the planes are refreshed with the
+    weights; OPT.split3 = False emits none of it; the first step's results stay at the fp32 oracle's."""
+    from emu_backend import obj
+    from model import networks
+    from nirgan_hip.options import OPT
+    from nirgan_hip.trainer import Pix2PixTrainer
+
+    def run(split3, steps):
+        monkeypatch.setattr(OPT, "split3", split3)
+        torch.manual_seed(5)
+        netG = networks.define_G(3, 1, 32, "resnet_6blocks", "instance", False, "normal", 0.02)
+        netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
+        G0 = {k: v.detach().clone() for k, v in netG.state_dict().items()}
+        D0 = {k: v.detach().clone() for k, v in netD.state_dict().items()}
+        g = torch.Generator().manual_seed(6)
+        rgb, nir = torch.rand(2, 3, 32, 32, generator=g), torch.rand(2, 1, 32, 32, generator=g)
+        seen = {"conv": [], "wgrad": [], "gemm": []}
+        for name, key, probe in (("nirgan_conv_igemm", "conv", lambda d: (d.precision, bool(d.w_x3))),
+                                 ("nirgan_wgrad_igemm", "wgrad", lambda d: (d.precision, d.nplanes)),
+                                 ("nirgan_wino6_gemm", "gemm", lambda d: bool(d.U3))):
+            orig = getattr(emu, name)
+
+            def spy(ref, stream=None, _orig=orig, _key=key, _probe=probe):
+                seen[_key].append(_probe(obj(ref)))
+                return _orig(ref, stream)
+            monkeypatch.setattr(emu, name, spy)
+        tr = Pix2PixTrainer(netG, netD, n_blocks=6)
+        outs = [tr.step(rgb, nir).as_dict() for _ in range(steps)]
+        return outs, seen, (G0, D0, rgb, nir), tr
+
+    outs, seen, (G0, D0, rgb, nir), tr = run(True, 2)
+    assert any(p == 3 and has for p, has in seen["conv"]), "no convolution took the split tile"
+    assert all(has for p, has in seen["conv"] if p == 3)
+    assert any(p == 3 and n == 1 for p, n in seen["wgrad"]) and any(p == 3 and n > 1 for p, n in seen["wgrad"]), seen["wgrad"]
+    assert seen["gemm"] and all(seen["gemm"])
+    assert emu.calls.count("split3") >= 2, "the planes are written with every pack"
+    ref = O.OracleTrainer(G0, D0, 6)
+    o = ref.step(rgb, nir)
+    close(outs[0]["loss_G"], o["loss_G"], 1e-5, "loss_G, first step")
+    o2 = ref.step(rgb, nir)
+    close(outs[1]["loss_G"], o2["loss_G"], 2e-3, "loss_G, second step (after both Adam updates)")
+    n_split3 = emu.calls.count("split3")
+    outs_off, seen_off, _, _ = run(False, 1)
+    assert not any(p == 3 for p, _ in seen_off["conv"]) and not any(p == 3 for p, _ in seen_off["wgrad"]) and not any(seen_off["gemm"])
+    assert emu.calls.count("split3") == n_split3, "OPT.split3 = False still writes planes"
+    close(outs_off[0]["loss_G"], outs[0]["loss_G"], 1e-5, "split tiles on / off")
