@@ -28,6 +28,7 @@ Other workloads (not the headline): --blocks 9 --lambda-rs 1 --bs 32 (configs[2]
 (configs[4]: resolution buckets, bf16 MFMA); --precision bf16x3 (split-fp32 on the bf16 pipe).
 """
 import argparse
+import ctypes as C
 import hashlib
 import json
 import os
@@ -45,6 +46,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (v_mfma_f32_32x32x16_bf16); never the 2:1-sparsity headline
 # peak the ALGORITHMIC flops are priced against, per operand precision (bf16x3 issues three bf16 products per product)
 PEAKS = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3.0}
+# the three-term split tiles of the exact-fp32 mode (csrc/igemm_x3.h, descriptor precision 3): six bf16 products per fp32 product on the
+# bf16 pipe -- their fp32-equivalent FLOPs are priced against a sixth of the dense bf16 peak
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def kernel_peak(label: str, precision: str) -> float:
+    return PEAK_X3_TFLOPS if "_x3_kernel" in label else PEAKS[precision]
 
 
 def synth(B, H, W, seed, device):
@@ -100,11 +108,16 @@ def op_mfma_work(name, args):
     if name == "nirgan_conv_igemm_group":
         ds = [args[0][j].contents for j in range(args[1])]
         by = conv_bytes(ds[0]) + sum(d.N * d.ntaps * d.run * (2.0 if d.w_bf16 else 4.0) + d.B * d.OH * d.OW * d.N * 4.0 for d in ds[1:])      # the phases share the input
-        return f"conv_group_kernel<{128 if ds[0].N > 64 else 64}>", sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds), by
+        label = f"conv_group_kernel<{128 if ds[0].N > 64 else 64}>"
+        if all(d.precision == 3 for d in ds) and hasattr(be, "nirgan_conv_kernel_name"):      # the three-term split tile: one persistent launch of conv_x3_kernel over the phases
+            k = be.nirgan_conv_kernel_name(C.byref(ds[0]))
+            if k and k.decode().startswith("conv_x3"):
+                label = f"conv_x3_kernel<{128 if ds[0].N % 128 == 0 else 64}>"
+        return label, sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds), by
     if name == "nirgan_wgrad_igemm":
         w = args[0]._obj
         k = be.nirgan_wgrad_kernel_name(args[0]) if hasattr(be, "nirgan_wgrad_kernel_name") else None
-        label = k.decode() if k and k.decode().endswith("256_kernel") else f"wgrad_igemm_kernel<{128 if w.N > 64 else 64}>" + ("(bf16 twins)" if w.pq_bf16 else "")
+        label = k.decode() if k and (k.decode().endswith("256_kernel") or k.decode().startswith("wgrad_x3")) else f"wgrad_igemm_kernel<{128 if w.N > 64 else 64}>" + ("(bf16 twins)" if w.pq_bf16 else "")
         return label, 2.0 * max(w.nplanes, 1) * w.B * w.OH * w.OW * w.N * w.ntaps * w.run, wgrad_bytes(w)
     if name == "nirgan_conv_wgrad_pair":
         c, w = args[0]._obj, args[1]._obj
@@ -116,6 +129,7 @@ def op_mfma_work(name, args):
         d = args[0]._obj
         T = w6_tiles(d)
         k = be.nirgan_wino6_gemm_kernel_name(args[0]).decode() if hasattr(be, "nirgan_wino6_gemm_kernel_name") else "wino6_gemm"
+        k = k.replace(" (planes)", "")         # (the plane batches of the split tile are launches of conv_x3_kernel: one row of a kernel trace)
         # EXECUTED flops: the plane GEMMs [T x C] x [C x K] (64/324 of the direct layer's multiplies for F(6x6,3x3)); V read once, U once, M written once
         return k, 2.0 * w6_planes(d.r) * T * d.C * d.K, 4.0 * w6_planes(d.r) * (T * d.C + d.K * d.C + T * d.K)
     if name == "nirgan_wino6_gemm_wgrad_pair":
@@ -136,7 +150,8 @@ def op_mfma_work(name, args):
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.3 achievable)
 
 
-def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_igemm256_kernel", "conv_group_kernel<128>", "wgrad_igemm_kernel<128>", "wgrad_igemm256_kernel", "conv_wgrad_pair", "wino6_")):
+def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_igemm256_kernel", "conv_group_kernel<128>", "wgrad_igemm_kernel<128>", "wgrad_igemm256_kernel", "conv_wgrad_pair", "wino6_",
+                                "conv_x3_kernel", "wgrad_x3_kernel")):
     """EXECUTED FLOPs of one step's launches of the big MFMA kernels, and the op indices to bracket with HIP events."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds, algo_bytes, direct = {}, {}, {}
@@ -163,8 +178,65 @@ def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_igemm256_kernel",
 
 
 def plan_executed_flops(plan) -> float:
-    """Executed matrix-pipe FLOPs of every launch of a plan (all tile widths; the Winograd layers at their executed count)."""
+    """Executed matrix-pipe FLOPs of every launch of a plan (all tile widths; the Winograd layers at their executed count; the three-term
+    split tiles at their fp32-EQUIVALENT count, a sixth of the bf16 products they issue)."""
     return sum(w[1] for w in (op_mfma_work(n, a) for n, a in plan.ops if isinstance(n, str)) if w is not None)
+
+
+def plan_pipe_ms_at_peak(plan, precision) -> float:
+    """Time the matrix pipe needs for a plan's launches at each kernel's own peak (fp32 MFMA, or a sixth of the bf16 peak for the split
+    tiles), in ms: divided by the elapsed time it is the share of the elapsed time the pipe would be busy at peak -- the utilisation of a
+    step that mixes the two pipes."""
+    return sum(w[1] / (kernel_peak(w[0], precision) * 1e12) for w in (op_mfma_work(n, a) for n, a in plan.ops if isinstance(n, str)) if w is not None) * 1e3
+
+
+def predict_scaling(tr, ms1: float, tiles_per_rank: int):
+    """What the first N > 1 measurement should be compared with (no multi-GPU node is available to the builder): weak scaling of the
+    data-parallel step from quantities measured on ONE GPU plus an explicit model of the two exposed all-reduces.  Every input is in the
+    block; nothing here is a measurement of N > 1."""
+    def buckets(eng, flat):
+        index, first, last = eng.bwd_tail
+        lo = flat.slices[first][0]
+        o, k, _ = flat.slices[last]
+        hi = min(flat.total, o + -(-k // 4) * 4)
+        return 4 * (hi - lo), 4 * (flat.total - (hi - lo))
+    tailG, headG = buckets(tr.G, tr.flatG)
+    tailD, headD = buckets(tr.D2, tr.flatD)
+    # one rank over RCCL against the plain run, same box (scripts/refresh_profiles.sh: *_bench_rccl_one_rank / *_bench_final): the fixed
+    # cost of going through torch.distributed (stream waits, two async launches per network)
+    fixed_ms, src = 0.18, "profiles/r04_bench_rccl_one_rank.json.log vs r04_bench_final.json.log (19.29 vs 19.11 ms)"
+    try:
+        tags = sorted({f.split("_")[0] for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_rccl_one_rank.json.log")}, reverse=True)
+        for tag in tags:
+            one = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", f"{tag}_bench_rccl_one_rank.json.log")) if l.startswith("{")]
+            fin = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", f"{tag}_bench_final.json.log")) if l.startswith("{")]
+            if one and fin:
+                fixed_ms = max(0.0, one[-1]["ms_per_step"] - fin[-1]["ms_per_step"])
+                src = f"profiles/{tag}_bench_rccl_one_rank.json.log vs {tag}_bench_final.json.log ({one[-1]['ms_per_step']} vs {fin[-1]['ms_per_step']} ms)"
+                break
+    except Exception:
+        pass
+    link_gbps, links = 153.0, 7            # MI355X_MICROARCH.md / task statement: 7 xGMI links x ~153 GB/s per GPU, point to point
+    eff, lat_us = 0.6, 25.0                # ASSUMED: fraction of the link rate a ring step sustains on 1-3 MB messages; latency per ring step
+    res = []
+    for n in (2, 4, 8):
+        def allreduce_ms(nbytes):
+            # ring all-reduce: 2 (n - 1) steps of nbytes / n each; over the fully connected mesh min(n - 1, links) rings run on disjoint links
+            rings = min(n - 1, links)
+            return 2 * (n - 1) * (lat_us * 1e-3 + (nbytes / n / rings) / (link_gbps * eff * 1e9) * 1e3)
+        exposed = allreduce_ms(headG) + allreduce_ms(headD)          # the head buckets start after their backward plans: nothing covers them
+        hidden = allreduce_ms(tailG) + allreduce_ms(tailD)           # the tails run under the rest of the backward plans
+        ms = ms1 + fixed_ms + exposed
+        res.append({"n_gpus": n, "ms_per_step": round(ms, 3), "tiles_per_s": round(n * tiles_per_rank / ms * 1e3, 1),
+                    "weak_scaling_efficiency": round(ms1 / ms, 4), "exposed_allreduce_ms": round(exposed, 4), "tail_allreduce_ms_under_backward": round(hidden, 4)})
+    return {"what": "PREDICTED from one-GPU measurements + a stated all-reduce model; not a measurement of N > 1",
+            "by_n_gpus": res,
+            "inputs": {"ms_per_step_1gpu": round(ms1, 3), "rccl_fixed_ms_per_step": round(fixed_ms, 3), "rccl_fixed_source": src,
+                       "bucket_bytes": {"G_tail": tailG, "G_head": headG, "D_tail": tailD, "D_head": headD},
+                       "xgmi": {"links_per_gpu": links, "gbps_per_link": link_gbps, "assumed_ring_efficiency": eff, "assumed_latency_us_per_ring_step": lat_us}},
+            "model": "ms(N) = ms(1) + fixed RCCL cost + all-reduce(head bucket of G) + all-reduce(head bucket of D); all-reduce(b) = 2 (N - 1) x "
+                     "(latency + b / N / min(N - 1, 7) rings / (153 GB/s x efficiency)); the tail buckets (started inside the backward plans) are "
+                     "assumed hidden: their modelled time is listed next to the backward they run under"}
 
 
 def host_cores() -> int:
@@ -462,11 +534,13 @@ def main():
         data = [synth(b, sz, sz, 1234 + 17 * i + rank, dev) for i, (b, sz) in enumerate(buckets)]
         bucket_ms = [[] for _ in buckets]
         counter = [rank]                   # ranks start on different buckets
+        timed_order = []                   # bucket index of every timed step of this rank, in order
 
         def mixed_step(_r, _n, timed=False):
             i = counter[0] % len(buckets)
             counter[0] += 1
             if timed:
+                timed_order.append(i)
                 e0, e1 = Tick(dev), Tick(dev)
                 e0.record()
             out = _step(data[i][0], data[i][1], None)
@@ -558,6 +632,16 @@ def main():
         rank_ms = [round(float(x[0]), 3) for x in allt]
         comm_ms = [round(float(x[1]), 4) for x in allt]
         dt = max(float(x[0]) for x in allt) * a.steps / 1e3          # MAX over ranks
+    sched_by_rank = None
+    if a.mixed:
+        # configs[4]'s load balance: which bucket every rank's timed steps drew (first one = where the rank started)
+        mine = torch.tensor((timed_order + [-1] * a.steps)[:a.steps], device=dev, dtype=torch.int64)
+        if reducer is not None:
+            alls = [torch.empty_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(alls, mine)
+            sched_by_rank = [[int(v) for v in t.tolist()] for t in alls]
+        else:
+            sched_by_rank = [[int(v) for v in mine.tolist()]]
     # ---- share of the step spent outside the matrix pipe: 3 untimed steps with EVERY matrix-pipe launch bracketed by HIP events
     mfma_share = None
     if not a.no_probe and pl_model is None and a.micro == 1 and dev.type == "cuda":
@@ -635,17 +719,18 @@ def main():
                 ach = per_launch_flop / (avg_ms * 1e-3) / 1e12
                 by = (mfma_probes.algo_bytes[k] / nlaunch) if k in getattr(mfma_probes, "algo_bytes", {}) else None
                 gbps = None if by is None else by / (avg_ms * 1e-3) / 1e9
-                roofs.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAKS[a.precision], 1), "unit": "TFLOP/s",
-                              "frac": round(ach / PEAKS[a.precision], 4),
+                pk = kernel_peak(k, a.precision)
+                roofs.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(pk, 1), "unit": "TFLOP/s",
+                              "frac": round(ach / pk, 4),
                               # the same launches priced by the DIRECT convolution's FLOPs (the Winograd layers execute 64/324 and 49/256 of them)
-                              "algorithmic_over_peak": round(getattr(mfma_probes, "direct", {}).get(k, flops) / nlaunch / (avg_ms * 1e-3) / 1e12 / PEAKS[a.precision], 4),
+                              "algorithmic_over_peak": round(getattr(mfma_probes, "direct", {}).get(k, flops) / nlaunch / (avg_ms * 1e-3) / 1e12 / pk, 4),
                               "traffic": None, "kernel": k,
                               "launches_per_step": nlaunch, "avg_launch_ms": round(avg_ms, 5),
                               "algorithmic_gflop_per_launch": round(per_launch_flop / 1e9, 3),
                               "algorithmic_bytes_per_launch": None if by is None else int(by),
                               # the OTHER bound of the same launch: its algorithmic bytes over the same time against the HBM peak
                               "hbm_bound": None if by is None else {"achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4)},
-                              "binding": None if by is None else ("mfma" if ach / PEAKS[a.precision] >= gbps / PEAK_HBM_GBPS else "hbm"),
+                              "binding": None if by is None else ("mfma" if ach / pk >= gbps / PEAK_HBM_GBPS else "hbm"),
                               "share_of_step_time": round(avg_ms * nlaunch / ms, 3),
                               "measured": "HIP events on the launch stream inside the timed steps" if live else "HIP events on the launch stream, 3 untimed steps before the timed ones"})
             # HBM traffic per launch: NOT measured in this run (PMC needs rocprofv3 passes around the process).  It is replayed from
@@ -680,6 +765,14 @@ def main():
                     r["traffic_source"] = (f"{pmc_file} was recorded for kernel sources {meta.get('kernel_src_sha16')}, this build is {src_now}: "
                                            "stale, not reported (rerun scripts/refresh_profiles.sh)")
             for r in roofs:
+                if "_x3_kernel" in r["kernel"]:
+                    r["arithmetic"] = ("fp32-equivalent on the bf16 matrix pipe: every fp32 operand as three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per "
+                                       "fp32 product, fp32 accumulate (csrc/igemm_x3.h); `achieved` counts fp32-EQUIVALENT FLOPs, `peak` = 2.5 PFLOP/s dense bf16 / 6")
+                    r["executed_bf16_tflops"] = round(6.0 * r["achieved"], 1)
+                    r["flops_counted"] = ("fp32-equivalent flops of every launch of this kernel in a step: direct convolutions / sub-pixel groups / weight gradients "
+                                          "at 2 M N K, the Winograd layers' plane GEMMs and transform-domain weight gradients at their EXECUTED count (64/324 of "
+                                          "the direct layer's multiplies for F(6x6,3x3), 49/256 for F(4x4,4x4))")
+                    continue
                 if r["kernel"].startswith("wino6"):
                     r["flops_counted"] = ("EXECUTED matrix-pipe flops: the Winograd plane GEMMs (and, in the pair launch, the transform-domain weight-gradient "
                                           "planes) perform 64/324 of the direct layer's multiplies for the F(6x6,3x3) residual-block layers (36/144 with "
@@ -695,8 +788,14 @@ def main():
             roof = roofs[0] if roofs else None
             roof_other = roofs[1:] or None
         gflop_tile = {(6, 0): 257.0, (6, 10): 290.5, (9, 0): 344.0, (9, 10): 391.6}.get((a.blocks, a.padding))
+        from nirgan_hip.options import OPT as _OPT
+        x3_on = a.precision == "fp32" and _OPT.split3
         dtype = {"fp32": "f32", "bf16": "bf16 operands, f32 accumulate", "bf16x3": "f32 as 2 bf16 terms (3 products), f32 accumulate"}[a.precision]
         mfma = {"fp32": "fp32 MFMA", "bf16": "bf16 MFMA (fp32 accumulate/master)", "bf16x3": "bf16x3 split-fp32 MFMA"}[a.precision]
+        if x3_on:
+            dtype = ("f32 (3xbf16 split, 6 products, f32 accumulate) for the contractions with 32-channel runs" + (" incl. the Winograd plane GEMMs" if _OPT.split3_wino else "")
+                     + "; exact f32 MFMA for the first / last layers; f32 everywhere else")
+            mfma = "fp32-equivalent MFMA (three bf16 terms, six products)"
         if a.mixed:
             workload = (f"configs[4]: mixed-resolution buckets {[f'{b}@{sz}' for b, sz in buckets]} per GPU (one bucket per rank-step, "
                         f"equal tile area), {a.blocks}-block ResnetGenerator + PatchGAN, GAN+L1"
@@ -729,6 +828,11 @@ def main():
             out["collective_backend"] = None
             out["ms_per_step_by_rank"] = [round(ms, 3)]
             out["comm_exposed_ms_per_step_by_rank"] = [0.0]
+        if pl_model is None and not a.mixed and a.micro == 1 and not a.emulate_cpu:
+            try:
+                out["predicted"] = predict_scaling(tr, ms if world == 1 else min(rank_ms), a.bs)
+            except Exception as exc:              # (never lose the measured line to the model)
+                out["predicted"] = {"error": repr(exc)}
         if reducer is not None:
             out["comm"] = ("two gradient buckets per network (tail started inside the backward plan, head after it); exposed = launch-stream "
                            "time spent waiting for the collectives before each Adam step (HIP events)")
@@ -738,6 +842,12 @@ def main():
             out["config"]["micro_batches"] = a.micro
             if roof:
                 roof["note"] = "kernels of the micro-batches share the chip: per-launch time includes the sharing"
+        if a.mixed and sched_by_rank is not None:
+            per_bucket = [[sum(1 for v in sch if v == i) for i in range(len(buckets))] for sch in sched_by_rank]
+            out["bucket_schedule"] = {"first_bucket_by_rank": [sch[0] for sch in sched_by_rank], "timed_steps_per_bucket_by_rank": per_bucket,
+                                      "timed_steps_per_bucket_all_ranks": [sum(pb[i] for pb in per_bucket) for i in range(len(buckets))],
+                                      "note": "rank r starts on bucket r mod 3 and walks the buckets round-robin: every step all-reduces gradients that come from "
+                                              "different tile sizes; with steps a multiple of 3 every rank spends the same time per bucket"}
         if a.mixed:
             out["buckets_rank0"] = [{"tiles": b, "size": sz, "steps": len(ev),
                                      "raw_tiles_per_s": round(b * len(ev) / (sum(x.elapsed_time(y) for x, y in ev) * 1e-3), 2) if ev else None}
@@ -755,11 +865,12 @@ def main():
             out["gen_fwd"] = {"ms_per_call": round(ms_call, 3), "tflops_algorithmic": round(tf, 2),
                               "algorithmic_over_peak": round(tf / PEAKS[a.precision], 4), "peak": round(PEAKS[a.precision], 1),
                               "executed_gflop_per_call": None if ex is None else round(ex, 2),
-                              "executed_mfma_util": None if ex is None else round(ex / ms_call / PEAKS[a.precision], 4),
+                              "executed_mfma_util": None if ex is None else round(plan_pipe_ms_at_peak(tr.G.fwd, a.precision) / ms_call, 4),
                               "note": "generator forward incl. its instance-norm / transform / layout kernels.  algorithmic_over_peak = direct-"
                                       "convolution FLOPs (SURVEY 8d) / elapsed / dense MFMA peak: NOT a utilisation -- the Winograd layers execute 64/324 "
                                       "of those multiplies, so it can exceed 1.  executed_mfma_util = FLOPs the matrix pipe actually executes (from "
-                                      "the launch descriptors) / elapsed / peak: BASELINE.json's 'gen-fwd MFMA util'"}
+                                      "the launch descriptors) / elapsed / peak, each launch at its own pipe's peak (fp32 MFMA 157.3, or 2500 / 6 for the "
+                                      "three-term split tiles' fp32-equivalent FLOPs): BASELINE.json's 'gen-fwd MFMA util'"}
         if gen_fwd_events and gen_bwd_events:
             # backward = data + weight gradients of every conv except the first layer's data gradient: 2g - g1,
             # g1 = 7x7x3x64 MACs per pixel (SURVEY 8d formula)
@@ -773,13 +884,14 @@ def main():
             out["gen_fwd_bwd"] = {"ms_per_step": round(ms_fb, 3), "tflops_algorithmic": round(tf, 2),
                                   "algorithmic_over_peak": round(tf / PEAKS[a.precision], 4),
                                   "executed_gflop_per_step": None if ex is None else round(ex, 2),
-                                  "executed_mfma_util": None if ex is None else round(ex / ms_fb / PEAKS[a.precision], 4)}
+                                  "executed_mfma_util": None if ex is None else round((plan_pipe_ms_at_peak(tr.G.fwd, a.precision) + plan_pipe_ms_at_peak(tr.G.bwd, a.precision)) / ms_fb, 4)}
         if gflop_tile and not a.mixed and a.size == 256:
             out["step_tflops_algorithmic"] = round(gflop_tile * value / 1e3, 2)
         if pl_model is None and not a.no_probe and not (a.mixed or a.micro > 1):
             exs = sum(plan_executed_flops(pl) for pl in plans) / 1e9
-            out["whole_step"] = {"executed_mfma_gflop": round(exs, 1), "executed_mfma_util": round(exs / ms / PEAKS[a.precision], 4),
-                                 "note": "FLOPs the matrix pipe executes per step (launch descriptors) / ms_per_step / dense peak"}
+            out["whole_step"] = {"executed_mfma_gflop": round(exs, 1), "executed_mfma_util": round(sum(plan_pipe_ms_at_peak(pl, a.precision) for pl in plans) / ms, 4),
+                                 "note": "FLOPs the matrix pipe executes per step (launch descriptors; fp32-equivalent for the three-term split tiles); util = each "
+                                         "launch's FLOPs over its own pipe's dense peak (fp32 MFMA 157.3, split tiles 2500 / 6), summed, over ms_per_step"}
             if mfma_share is not None:
                 out["whole_step"]["matrix_pipe_launch_share"] = round(mfma_share, 4)
                 out["whole_step"]["hbm_bound_share"] = round(1.0 - mfma_share, 4)

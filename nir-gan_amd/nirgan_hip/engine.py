@@ -598,7 +598,7 @@ def emit_wino6_backward(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.T
         plan.add("nirgan_wino6_input_dy", C.byref(dgrad), C.byref(ydesc))      # one read of dY for both transforms
     if vin is not None:
         plan.add("nirgan_wino6_input", C.byref(vin))
-    if OPT.w6_pair:                                # 24.87 -> 24.64 ms per step
+    if OPT.w6_pair and not x3:                     # 24.87 -> 24.64 ms per step
         plan.add("nirgan_wino6_gemm_wgrad_pair", C.byref(dgrad), C.byref(d))      # one grid: weight-gradient blocks first, GEMM blocks behind
     else:
         plan.add("nirgan_wino6_gemm", C.byref(dgrad))

@@ -74,6 +74,23 @@ def test_bench_eight_ranks_mixed_resolution_verified():
     assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 32
     assert len(out["ms_per_step_by_rank"]) == 8 and len(out["comm_exposed_ms_per_step_by_rank"]) == 8
     assert out["collective_backend"] == "gloo" and out["rccl_ranks"] == 0 and out["value"] > 0
+    sch = out["bucket_schedule"]
+    assert len(sch["first_bucket_by_rank"]) == 8 and sorted(set(sch["first_bucket_by_rank"])) == [0, 1, 2], sch        # the ranks start on different buckets
+    assert sch["timed_steps_per_bucket_all_ranks"] in ([3, 3, 2], [3, 2, 3], [2, 3, 3]), sch                            # one timed step: eight draws over three buckets
+
+
+def test_bench_mixed_resolution_load_balance_over_the_buckets():
+    """configs[4]'s load balance: with a multiple of three timed steps every one of four ranks (started on different buckets) finishes the
+    SAME number of steps per bucket, and every step mixes the three tile sizes over the ranks."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--mixed", "--emulate-cpu", "--ngf", "8",
+                        "--size", "64", "--bs", "4", "--steps", "3", "--warmup", "3", "--blocks", "6"],
+                       capture_output=True, text=True, env={**_env(), "OMP_NUM_THREADS": "1"}, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    sch = out["bucket_schedule"]
+    assert len(sch["first_bucket_by_rank"]) == 4 and len(set(sch["first_bucket_by_rank"])) == 3, sch       # four ranks over three buckets: all three from step one
+    assert sch["timed_steps_per_bucket_by_rank"] == [[1, 1, 1]] * 4, sch
+    assert sch["timed_steps_per_bucket_all_ranks"] == [4, 4, 4], sch
 
 
 def test_bench_eight_ranks_verify_dp():

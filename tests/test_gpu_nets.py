@@ -144,7 +144,10 @@ def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     if variant != "direct":      # residual blocks as F(6x6,3x3) / F(4x4,3x3) AND the PatchGAN's 4x4 layer as F(4x4,4x4)
         rcodes = {a[0]._obj.r for pl in (tr.G.fwd, tr.G.bwd) for n, a in pl.ops if n == "nirgan_wino6_gemm"}
         assert rcodes == ({6} if variant == "F(6x6,3x3)" else {3}), rcodes
-        for want in ("nirgan_wino6_input_norm", "nirgan_wino6_input_dy_norm" if variant == "F(6x6,3x3)" else "nirgan_wino6_input_dy", "nirgan_wino6_gemm", "nirgan_wino6_gemm_wgrad_pair", "nirgan_wino6_output",
+        # (with the three-term split tiles -- the default -- a layer's data-gradient GEMMs and its transform-domain weight gradient are two
+        # launches, nirgan_wino6_gemm + nirgan_wgrad_igemm with planes; the exact-fp32 tiles share one grid: nirgan_wino6_gemm_wgrad_pair)
+        for want in ("nirgan_wino6_input_norm", "nirgan_wino6_input_dy_norm" if variant == "F(6x6,3x3)" else "nirgan_wino6_input_dy", "nirgan_wino6_gemm",
+                     "nirgan_wgrad_igemm" if (OPT.split3 and OPT.split3_wino) else "nirgan_wino6_gemm_wgrad_pair", "nirgan_wino6_output",
                      "nirgan_wino6_wgrad_finish_r"):
             assert want in names, want
         assert sum(1 for pl in (tr.D2.fwd, tr.D2.bwd, tr.D1.fwd, tr.D1.bwd_pred) for n, a in pl.ops if n.startswith("nirgan_wino6_gemm")) == 4
