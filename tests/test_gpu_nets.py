@@ -453,6 +453,49 @@ def test_configs2_batch32_properties():
     assert o0 == o1 and torch.equal(p0, p1) and torch.equal(g0, g1) and torch.equal(w0, w1), "two identical bs-32 steps differ"
 
 
+def test_configs3_batch8_at_512_properties():
+    """configs[3] at its per-GPU batch (configs/config_px2px_SatCLIP.yaml:100: batch 8; model/generator_inject.py:105-135): define_G_inject,
+    9 blocks, ngf 64, multiply style with the learned scale, reflect pad 10, eight 512 x 512 tiles -- finite losses, the prediction of
+    tiles 2..3 equal to the same tiles run as a batch of two (per-sample independence: InstanceNorm and the injection have no cross-sample
+    term), and two identical steps bitwise equal.  The arithmetic itself is pinned at B = 1 / 2 by the forced-kink tests above."""
+    from model import networks
+    from model.generator_inject import define_G_inject
+    from nirgan_hip.trainer import Pix2PixTrainer
+    ns = types.SimpleNamespace
+    rgb, nir = synth(8, 512, 512, 9)
+    rgb, nir = rgb.to(DEV), nir.to(DEV)
+    emb = torch.randn(8, 256, generator=torch.Generator().manual_seed(10)).to(DEV)
+    inj = {"style": "multiply", "use_scale": True}
+
+    def nets():
+        torch.manual_seed(0)
+        netG = define_G_inject(ns(base_configs=ns(input_nc=3, output_nc=1, ngf=64, netG="resnet_9blocks", norm="instance", no_dropout=True,
+                                                  init_type="normal", init_gain=0.02),
+                                  satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
+                                             scaling_param=True, scaling_param_init=0.5))).to(DEV)
+        torch.manual_seed(0)
+        return netG, networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+    netG, netD = nets()
+    small = Pix2PixTrainer(netG, netD, n_blocks=9, inject=inj, padding=10, lr=0.0)
+    small.step(rgb[2:4].contiguous(), nir[2:4].contiguous(), emb[2:4].contiguous())
+    p2 = small.pred.clone()
+    del small
+    runs = []
+    for _ in range(2):
+        netG, netD = nets()
+        tr = Pix2PixTrainer(netG, netD, n_blocks=9, inject=inj, padding=10)
+        out = tr.step(rgb, nir, emb).as_dict()
+        assert all(np.isfinite(v) for v in out.values()), out
+        assert tr.pred.shape == (8, 1, 512, 512)
+        if not runs:
+            close(tr.pred[2:4], p2, 3e-4, "sample independence at bs 8, 512 x 512 + pad 10")
+        runs.append((out, tr.pred.clone(), tr.flatG.grad.clone(), tr.flatD.grad.clone(), tr.flatG.flat.clone()))
+        del tr
+        torch.cuda.empty_cache()
+    (o0, p0, g0, d0, w0), (o1, p1, g1, d1, w1) = runs
+    assert o0 == o1 and torch.equal(p0, p1) and torch.equal(g0, g1) and torch.equal(d0, d1) and torch.equal(w0, w1), "two identical configs[3] steps differ"
+
+
 def test_fused_step_is_bitwise_reproducible():
     """bs 16, the benchmark configuration: two runs from the same weights on the same tiles give bitwise-equal losses, gradients,
     Adam moments and parameters after two steps -- every reduction (weight-gradient slabs, instance-norm partials, loss sums, live

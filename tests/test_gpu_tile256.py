@@ -87,6 +87,21 @@ def test_tile256_against_the_128_row_tile_and_float64(case):
         if out16:
             ref = ref.float().to(torch.bfloat16)
         assert _rel(a, ref.float()) <= (2 ** -7 if out16 else 1e-5), f"256-row tile vs float64 conv2d on the rounded operands: {_rel(a, ref.float()):.3e}"
+    else:
+        # the benchmark's own shapes: float64 on a random sample of 8 192 output pixels (every channel) instead of the whole tensor
+        OH, OW = a.shape[1], a.shape[2]
+        g = torch.Generator().manual_seed(17)
+        idx = torch.randint(0, B * OH * OW, (8192,), generator=g).to(DEV)
+        bi, r = idx // (OH * OW), idx % (OH * OW)
+        oh, ow = r // OW, r % OW
+        xp = x.t16.double()                                              # [B][H + 2p][W + 2p][Cin]: the halo is part of the buffer
+        patches = torch.stack([xp[bi, oh + kh, ow + kw, :] for kh in range(k) for kw in range(k)], 1)
+        wk = w.to(torch.bfloat16).double().permute(0, 2, 3, 1).reshape(Cout, k * k, Cin)
+        ref = torch.einsum("ntc,otc->no", patches, wk) + (0.0 if b is None else b.double())
+        if out16:
+            ref = ref.float().to(torch.bfloat16)
+        got = a[bi, oh, ow, :]
+        assert _rel(got, ref.float()) <= (2 ** -7 if out16 else 1e-5), f"256-row tile vs float64 on 8 192 sampled pixels: {_rel(got, ref.float()):.3e}"
 
 
 def test_tile256_repeated_launches_agree_bitwise():
@@ -149,6 +164,13 @@ WCASES = [
 ]
 
 
+def _wgrad_float64(x, dy, OH, OW, k):
+    """dW[co][ci][kh][kw] of a stride-1 convolution from the bf16 twins, in float64: one [Cout x M] x [M x Cin] product per tap"""
+    xd = x.t16.double()
+    dyd = dy.t16.double()[:, dy.pad:dy.pad + OH, dy.pad:dy.pad + OW].reshape(-1, dy.C)
+    return torch.stack([torch.stack([dyd.T @ xd[:, kh:kh + OH, kw:kw + OW, :].reshape(-1, x.C) for kw in range(k)], -1) for kh in range(k)], -2)
+
+
 @pytest.mark.parametrize("case", WCASES)
 def test_wgrad256_against_the_128_row_tile_and_float64(case):
     B, H, W, Cin, Cout, k = case
@@ -163,12 +185,14 @@ def test_wgrad256_against_the_128_row_tile_and_float64(case):
     assert _rel(g256, g128) <= 2e-5, f"256-wide tile vs 128-row tile: {_rel(g256, g128):.3e}"
     if eligible and case == WCASES[0]:
         assert (d256.nsplit, d256.rows_per_split) == G.pair256_plan(B * H * W, 9), "the 256-wide plan chooses its own split"
+    OH, OW, p = geo
     if B * H * W <= 40000:
-        OH, OW, p = geo
         xi = x.t16.double().permute(0, 3, 1, 2)
         gi = dy.t16.double()[:, dy.pad:dy.pad + OH, dy.pad:dy.pad + OW].permute(0, 3, 1, 2)
         ref = torch.nn.grad.conv2d_weight(xi, (Cout, Cin, k, k), gi)
-        assert _rel(g256, ref.float()) <= 1e-5, f"256-wide tile vs float64 on the rounded operands: {_rel(g256, ref.float()):.3e}"
+    else:
+        ref = _wgrad_float64(x, dy, OH, OW, k)                 # the benchmark's shapes too: one float64 GEMM per tap
+    assert _rel(g256, ref.float()) <= 1e-5, f"256-wide tile vs float64 on the rounded operands: {_rel(g256, ref.float()):.3e}"
 
 
 @pytest.mark.parametrize("case", [(16, 64, 64, 256, 256, 3, False), (16, 64, 64, 256, 256, 3, True), (32, 32, 32, 256, 256, 3, True), (5, 64, 128, 256, 256, 3, False)])
@@ -206,6 +230,8 @@ def test_pair256_equals_separate_launches(case):
     if B * H * W <= 45000:
         gi = dy.t16.double()[:, dy.pad:dy.pad + OH, dy.pad:dy.pad + OW].permute(0, 3, 1, 2)
         assert _rel(gw256, torch.nn.grad.conv2d_weight(xi, (Cout, Cin, k, k), gi).float()) <= 1e-5
+    else:
+        assert _rel(gw256, _wgrad_float64(x, dy, OH, OW, k).float()) <= 1e-5, "fused launch's weight gradient vs float64 at the benchmark shape"
 
 
 def test_pair256_repeated_launches_agree_bitwise():
