@@ -204,43 +204,63 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // one K-tile: B fragments (3 terms), then the two row halves of the wave tile; `mid()` = the conversion + LDS stores of the NEXT
-    // K-tile's A rows
-    auto compute = [&](const char* sA, const char* sB, auto&& mid) {
-        bf16x8 B[NT][3];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) B[nt][t] = *reinterpret_cast<const bf16x8*>(sB + t * B_TERM + b_rd + nt * 1024);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            bf16x8 A[2][3];
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) A[q][t] = *reinterpret_cast<const bf16x8*>(sA + t * X3_A_TERM + a_rd + (hf * 2 + q) * 1024);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    f32x4 c = acc[hf * 2 + q][nt];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][2], B[nt][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][0], B[nt][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][1], B[nt][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][1], B[nt][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][0], B[nt][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][0], B[nt][0], c, 0, 0, 0);
-                    acc[hf * 2 + q][nt] = c;
-                }
-            // the next K-tile's A rows (fetched at the top of this step) are converted and stored BEHIND the first half's MFMAs -- a
-            // fence: scheduled freely, the conversion is hoisted to the head of the step and its vmcnt wait exposes the fetch -- and
-            // interleaved with the second half's (two VALU per MFMA gap: an MFMA holds the vector issue port for 8 of its 16 cycles)
-            if (hf == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                mid();
-            }
+    // one K-tile.  The fragment reads are INLINE ASM with counted lgkmcnt waits, ordered by hand against the MFMAs:
+    //   * written as plain loads, hipcc puts s_waitcnt vmcnt(0) in front of the first fragment read of a step once the next stage's LDS-DMA
+    //     has been issued (it cannot tell the read from the DMA's destination): the whole fetch latency at the head of every step;
+    //   * left to the scheduler, all 18 reads of the first half are issued up front and the first MFMA waits for most of them while all
+    //     eight waves read at once (~600 cycles of the LDS pipe with the matrix pipe idle).
+    // Here the first MFMA group needs six reads (A row tile 0, B column tile 0); the next column tile's terms are read under the current
+    // group's MFMAs, the next row tile's under the last group's; no scalar-memory operation is issued inside the loop (lgkmcnt counts
+    // LDS operations in order only while none is outstanding).  `mid()` = the conversion + LDS stores of the NEXT K-tile's A rows: behind
+    // the first half (their fetch has landed by then), interleaved by the scheduler with the second half's MFMAs, whose operands are all
+    // in registers (two VALU per MFMA gap: an MFMA holds the vector issue port for 8 of its 16 cycles).
+    const unsigned a_ad0 = unsigned(size_t((NG_LDS char*)sA0)) + unsigned(a_rd), a_ad1 = unsigned(size_t((NG_LDS char*)sA1)) + unsigned(a_rd);
+    const unsigned b_ad0 = unsigned(size_t((NG_LDS char*)sB0)) + unsigned(b_rd), b_ad1 = unsigned(size_t((NG_LDS char*)sB1)) + unsigned(b_rd);
+#define X3_DSR(dst, ad, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(off) : "memory")
+#define X3_RA(a, ad, MT) { X3_DSR(a[0], ad, (MT) * 1024); X3_DSR(a[1], ad, X3_A_TERM + (MT) * 1024); X3_DSR(a[2], ad, 2 * X3_A_TERM + (MT) * 1024); }
+#define X3_RB(ad, NTI) { X3_DSR(B[NTI][0], ad, (NTI) * 1024); X3_DSR(B[NTI][1], ad, B_TERM + (NTI) * 1024); X3_DSR(B[NTI][2], ad, 2 * B_TERM + (NTI) * 1024); }
+#define X3_WAIT(n) { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    auto compute = [&](const unsigned aad, const unsigned bad, auto&& pre, auto&& mid) {
+        bf16x8 B[NT][3], A[2][3];
+        auto mma = [&](const int mt, const bf16x8 (&a)[3], const int nt) {
+            f32x4 c = acc[mt][nt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], B[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], B[nt][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], B[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], B[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], B[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], B[nt][0], c, 0, 0, 0);
+            acc[mt][nt] = c;
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        X3_RA(A[0], aad, 0)
+        X3_RB(bad, 0)
+        pre();                                    // the next K-tile's fetch (registers + LDS-DMA): issued behind the first reads
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NT == 4) {
+            X3_RB(bad, 1) X3_WAIT(3) mma(0, A[0], 0); __builtin_amdgcn_sched_barrier(0);
+            X3_RB(bad, 2) X3_WAIT(3) mma(0, A[0], 1); __builtin_amdgcn_sched_barrier(0);
+            X3_RB(bad, 3) X3_WAIT(3) mma(0, A[0], 2); __builtin_amdgcn_sched_barrier(0);
+            X3_RA(A[1], aad, 1) X3_WAIT(3) mma(0, A[0], 3); __builtin_amdgcn_sched_barrier(0);
+        } else {
+            X3_RB(bad, 1) X3_WAIT(3) mma(0, A[0], 0); __builtin_amdgcn_sched_barrier(0);
+            X3_RA(A[1], aad, 1) X3_WAIT(3) mma(0, A[0], 1); __builtin_amdgcn_sched_barrier(0);
         }
+        X3_RA(A[0], aad, 2) X3_WAIT(3)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mma(1, A[1], nt);
+        __builtin_amdgcn_sched_barrier(0);
+        X3_RA(A[1], aad, 3) X3_WAIT(0)
+        mid();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mma(2, A[0], nt);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mma(3, A[1], nt);
     };
+#undef X3_WAIT
+#undef X3_RB
+#undef X3_RA
+#undef X3_DSR
     // (two distinct stage objects, unrolled by two: the compiler sees that the stores and the LDS-DMA of stage s + 1 do not alias the
     // fragment reads of stage s)
     // `behind_stores`: the first step behind a full tile's epilogue.  vmcnt counts in issue order and this item's first LDS-DMA pieces
@@ -248,7 +268,7 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
     // flight -- with vmcnt(0) every workgroup would sit out the drain of the 32 MB all 256 of them have just written (measured: +8 us
     // per tile against one tile per workgroup, where the next workgroup's loop runs under the previous one's stores).
     constexpr int ESTORES = 2 * (32 / (64 / (CW / 4)));       // store instructions of a full tile's epilogue, per lane
-    auto step = [&](const char* cA, const char* cB, char* nA, char* nB, const bool more, const bool behind_stores = false) {
+    auto step = [&](const int cur, char* nA, char* nB, const bool more, const bool behind_stores = false) {
         if (behind_stores) {
             if constexpr (ESTORES == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -256,13 +276,11 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        const unsigned aad = cur == 0 ? a_ad0 : a_ad1, bad = cur == 0 ? b_ad0 : b_ad1;
         if (more) {
-            loadA();
-            issueB(nB);
-            advance();
-            compute(cA, cB, [&]() { commitA(nA, 0); commitA(nA, 1); });
+            compute(aad, bad, [&]() { issueB(nB); loadA(); advance(); }, [&]() { commitA(nA, 0); commitA(nA, 1); });
         } else {
-            compute(cA, cB, []() {});
+            compute(aad, bad, []() {}, []() {});
         }
     };
 
@@ -419,15 +437,15 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
         const int nk = L.nk;
         int k = 0;
         if (nk >= 2) {
-            if (behind) step(sA0, sB0, sA1, sB1, true, true); else step(sA0, sB0, sA1, sB1, true);
-            step(sA1, sB1, sA0, sB0, 2 < nk);
+            if (behind) step(0, sA1, sB1, true, true); else step(0, sA1, sB1, true);
+            step(1, sA0, sB0, 2 < nk);
             k = 2;
         }
         for (; k + 2 <= nk; k += 2) {
-            step(sA0, sB0, sA1, sB1, true);
-            step(sA1, sB1, sA0, sB0, k + 2 < nk);
+            step(0, sA1, sB1, true);
+            step(1, sA0, sB0, k + 2 < nk);
         }
-        if (k < nk) step(sA0, sB0, sA1, sB1, false);
+        if (k < nk) step(0, sA1, sB1, false);
         E = L;
         item += G;
         const bool more = item < total;
@@ -590,33 +608,54 @@ __device__ __forceinline__ void wgrad_tile_x3(const WgradParams& p, const int un
         const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     };
+    // (reads ordered against the MFMAs as in conv_x3_persist: the first group needs one row tile and one column tile, the next tile's
+    // terms are read under the current group's MFMAs; this kernel issues no LDS-DMA, the compiler's own lgkmcnt bookkeeping applies)
     auto compute = [&](const char* sP, const char* sQ, auto&& mid) {
-        bf16x8 B[4][3];
+        bf16x8 B[4][3], A[2][3];
+        auto readA = [&](const int mt, bf16x8 (&a)[3]) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int t = 0; t < 3; ++t) a[t] = frag(sP + t * P_TERM, a_ad[mt], PRS);
+        };
+        auto readB = [&](const int nt) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) B[nt][t] = frag(sQ + t * Q_TERM, b_ad[nt], 256);
+        };
+        auto mma = [&](const int mt, const bf16x8 (&a)[3], const int nt) {
+            f32x4 c = acc[mt][nt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], B[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], B[nt][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], B[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], B[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], B[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], B[nt][0], c, 0, 0, 0);
+            acc[mt][nt] = c;
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        readA(0, A[0]);
+        readB(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            bf16x8 A[3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) A[t] = frag(sP + t * P_TERM, a_ad[mt], PRS);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                f32x4 c = acc[mt][nt];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2], B[nt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[nt][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[nt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1], B[nt][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[nt][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], B[nt][0], c, 0, 0, 0);
-                acc[mt][nt] = c;
-            }
-            if (mt == MT / 2 - 1) {             // behind the first half of the MFMAs: the next K-tile's operands have arrived
-                __builtin_amdgcn_sched_barrier(0);
-                mid();
-            }
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt + 1 < 4) readB(nt + 1); else readA(1, A[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, A[0], nt);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (MT == 2) {
+            mid();                                  // behind the first half of the MFMAs: the next K-tile's operands have arrived
+        } else {
+            readA(2, A[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) mma(1, A[1], nt);
+            __builtin_amdgcn_sched_barrier(0);
+            readA(3, A[1]);
+            mid();
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) mma(2, A[0], nt);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) mma(MT - 1, A[1], nt);
     };
     auto step = [&](const char* cP, const char* cQ, char* nP, char* nQ, const bool more) {
         __syncthreads();
