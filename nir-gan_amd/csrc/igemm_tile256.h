@@ -695,6 +695,10 @@ inline bool conv_tile256_ok(const ConvParams& p, const bool pair = false, const 
     const bool b16 = p.prec == 1 && p.in_bf16 && p.w_bf16, f32 = p.prec == 0 && !p.out16 && !p.f_y16 && p.algo == NIRGAN_CONV_TILE256;
     if (!((b16 || f32) && p.off32 && p.ksplit == 1)) return false;
     if (p.run % (b16 ? 64 : 32) != 0 || p.N % 256 != 0) return false;
+    // a bf16 output leaves eight channels per lane (16-byte stores, 32-byte loads of bias / mean / rstd, 16-byte loads of a bf16 y): every
+    // pixel's channel group must then be 16-byte aligned, as the 128-row tile requires for its eight-channel form
+    if (p.out16 && ((p.out_cs | p.out_org | p.out_row | p.out_img) & 7) != 0) return false;
+    if (p.f_y16 && ((p.f_img | p.f_row | p.f_org) & 7) != 0) return false;
     const long long tiles = (long long)((p.M + 255) >> 8) * (p.N >> 8);
     if (pair) return tiles >= cus / 2;
     const long long rounds = (tiles + cus - 1) / cus;

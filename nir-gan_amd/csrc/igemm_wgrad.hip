@@ -375,7 +375,8 @@ extern "C" int nirgan_conv_wgrad_pair(const nirgan_conv_desc* c, const nirgan_wg
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
     NG_REQUIRE(cp.prec == wp.prec, "conv_wgrad_pair: both halves must use the same precision");
-    if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp, true) && ng::wgrad_tile256_ok(wp)) {
+    // (the fused 256-wide launch divides the CUs between the two kinds of item: it needs at least two; a one-CU device takes the 128-row pair)
+    if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng_cu_count() >= 2 && ng::conv_tile256_ok(cp, true, ng_cu_count()) && ng::wgrad_tile256_ok(wp)) {
         const int conv_tiles = ((cp.M + 255) >> 8) * (cp.N >> 8), units = (wp.N >> 8) * (wp.K >> 8) * wp.nsplit, G = ng_cu_count();
         const int conv_wgs = pair256_split(G, conv_tiles, cp.ntaps * (cp.run >> 6), units, wp.rows_per_split >> 6);
         if (w->algo == NIRGAN_WGRAD_RING10) hipLaunchKernelGGL(conv_wgrad_pair256_kernel<10>, dim3(G), dim3(512), 0, static_cast<hipStream_t>(stream), cp, wp, conv_wgs, conv_tiles, units);
@@ -402,7 +403,7 @@ extern "C" const char* nirgan_wgrad_kernel_name(const nirgan_wgrad_desc* d) {
         if (ng::wgrad_x3_ok(p)) return ng::wgrad_x3_tn(p) == 256 ? "wgrad_x3_kernel<256>" : "wgrad_x3_kernel<128>";
         p.prec = 0;
     }
-    if (d->algo != NIRGAN_WGRAD_TILE128 && ng::wgrad_tile256_ok(p)) return "wgrad_igemm256_kernel";
+    if (d->algo != NIRGAN_WGRAD_TILE128 && d->algo != NIRGAN_WGRAD_ONE_UNIT && ng::wgrad_tile256_ok(p)) return "wgrad_igemm256_kernel";      // (the launcher's own predicate)
     if (ng::wgrad_persist_ok(p) && ng::wgrad_matrix_form(p) && p.ntiles_n * p.ntiles_k * p.nsplit * p.nplanes > 512 && d->algo != NIRGAN_WGRAD_ONE_UNIT) return "wgrad_persist_kernel";
     if (p.pq_bf16) return "wgrad_igemm16_kernel";
     return d->N > 64 ? "wgrad_igemm_kernel<128>" : "wgrad_igemm_kernel<64>";
@@ -413,7 +414,7 @@ extern "C" const char* nirgan_conv_wgrad_pair_kernel_name(const nirgan_conv_desc
     ng::WgradParams wp;
     if (ng::build_conv_params(c, cp) != NIRGAN_OK || ng::build_wgrad_params(w, wp) != NIRGAN_OK) return nullptr;
     if (c->N <= 64 || w->N <= 64 || c->ksplit > 1 || (wp.pq_bf16 && !cp.in_bf16) || cp.prec == 3 || wp.prec == 3) return "(two launches)";
-    if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng::conv_tile256_ok(cp, true) && ng::wgrad_tile256_ok(wp)) return "conv_wgrad_pair256_kernel";
+    if (cp.prec == 1 && cp.algo != NIRGAN_CONV_TILE128 && w->algo != NIRGAN_WGRAD_TILE128 && ng_cu_count() >= 2 && ng::conv_tile256_ok(cp, true, ng_cu_count()) && ng::wgrad_tile256_ok(wp)) return "conv_wgrad_pair256_kernel";
     return "conv_wgrad_pair_kernel";
 }
 
