@@ -190,6 +190,12 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
     };
     auto commitA = [&](char* sA, const int j) {
         bf16x8 H, M, Lo;
+#ifdef NG_X3_DIAG              // diagnostic build only: 0x400 = no conversion (raw bits stored), 0x800 = no LDS stores of the converted rows
+        if (L.p->algo & 0x800) return;
+        if (L.p->algo & 0x400) {
+            H = __builtin_bit_cast(bf16x8, ra[2 * j]); M = __builtin_bit_cast(bf16x8, ra[2 * j + 1]); Lo = H;
+        } else
+#endif
         x3_split8(ra[2 * j], ra[2 * j + 1], H, M, Lo);
         *reinterpret_cast<bf16x8*>(sA + a_wr[j]) = H;
         *reinterpret_cast<bf16x8*>(sA + X3_A_TERM + a_wr[j]) = M;
@@ -220,7 +226,8 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
 #define X3_RA(a, ad, MT) { X3_DSR(a[0], ad, (MT) * 1024); X3_DSR(a[1], ad, X3_A_TERM + (MT) * 1024); X3_DSR(a[2], ad, 2 * X3_A_TERM + (MT) * 1024); }
 #define X3_RB(ad, NTI) { X3_DSR(B[NTI][0], ad, (NTI) * 1024); X3_DSR(B[NTI][1], ad, B_TERM + (NTI) * 1024); X3_DSR(B[NTI][2], ad, 2 * B_TERM + (NTI) * 1024); }
 #define X3_WAIT(n) { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-    auto compute = [&](const unsigned aad, const unsigned bad, auto&& pre, auto&& mid) {
+    auto compute = [&](const unsigned aad, const unsigned bad, auto more_tag, auto&& pre, auto&& mid) {
+        constexpr bool MORE = decltype(more_tag)::value;
         bf16x8 B[NT][3], A[2][3];
         auto mma = [&](const int mt, const bf16x8 (&a)[3], const int nt) {
             f32x4 c = acc[mt][nt];
@@ -250,10 +257,17 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) mma(1, A[1], nt);
         __builtin_amdgcn_sched_barrier(0);
-        X3_RA(A[1], aad, 3) X3_WAIT(0)
-        mid();
+        // second half: row tile 3's terms are read into the registers row tile 1 has just left, under row tile 2's MFMAs and the first
+        // half of the conversion; the wait in front of row tile 3 counts the LDS stores issued behind that read (three per converted row
+        // set) instead of draining them
+        X3_RA(A[1], aad, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        mid(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) mma(2, A[0], nt);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE) { X3_WAIT(3) } else { X3_WAIT(0) }
+        mid(1);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) mma(3, A[1], nt);
     };
@@ -278,9 +292,12 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
         __syncthreads();
         const unsigned aad = cur == 0 ? a_ad0 : a_ad1, bad = cur == 0 ? b_ad0 : b_ad1;
         if (more) {
-            compute(aad, bad, [&]() { issueB(nB); loadA(); advance(); }, [&]() { commitA(nA, 0); commitA(nA, 1); });
+#ifdef NG_X3_DIAG              // 0x1000 = no fetch of the next K-tile (the loop runs on stale LDS images); 0x800 changes the store count: drain
+            if (L.p->algo & 0x1800) { compute(aad, bad, std::false_type{}, [&]() { if (!(L.p->algo & 0x1000)) { issueB(nB); loadA(); } advance(); }, [&](const int j) { commitA(nA, j); }); return; }
+#endif
+            compute(aad, bad, std::true_type{}, [&]() { issueB(nB); loadA(); advance(); }, [&](const int j) { commitA(nA, j); });
         } else {
-            compute(aad, bad, []() {}, []() {});
+            compute(aad, bad, std::false_type{}, []() {}, [](const int) {});
         }
     };
 
@@ -289,6 +306,9 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
     // floats, and leave as whole row segments, 16 bytes per lane.
     auto epilogue = [&]() -> bool {
         const NG_CONST ConvParams& p = *E.p;
+#ifdef NG_X3_DIAG              // diagnostic build only (scripts/diag/x3_parts.sh): what do the epilogue / its stores cost a plane GEMM?
+        if (p.algo & 0x200) return E.m0 + 256 <= p.M;
+#endif
         // (copies: the stores below make the compiler read every field again through `p`)
         const int pM = p.M, pN = p.N, OHW = p.OHW, OW = p.OW, OH = p.OHW / p.OW, out_img = p.out_img, out_row = p.out_row * p.out_stride,
                   out_px = p.out_cs * p.out_stride, out_org = p.out_org, f_img = p.f_img, f_row = p.f_row * p.out_stride, f_px = p.N * p.out_stride,
@@ -379,6 +399,9 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
                     if (ok[pass]) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pass * RPP + lrow) * CW + chunk * 4);
                         v += bv;
+#ifdef NG_X3_DIAG
+                        if (!(p.algo & 0x100))
+#endif
                         *reinterpret_cast<f32x4*>(E.out + ooff[pass]) = v;
                         if (fused) {
                             const f32x4 z = (yv[pass] - fm) * fr;

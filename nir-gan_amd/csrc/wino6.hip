@@ -1562,6 +1562,9 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
         g.p.prec = 3;
         g.p.w3 = static_cast<const unsigned short*>(d->U3);
         g.p.w3_plane = (long long)w6_np(w6_r(d->r)) * d->K * d->C;
+#ifdef NG_X3_DIAG
+        g.p.algo = d->algo & 0xf00;          // diagnostic build only: the epilogue switches of igemm_x3.h
+#endif
         return ng::ng_launch_conv_x3(&g.p, 1, d->K % 128 == 0 ? 128 : 64, w6_np(w6_r(d->r)), g.in_plane, g.w_plane, g.out_plane,
                                      static_cast<hipStream_t>(stream), "wino6_gemm (three-term split tile)");
     }
