@@ -259,9 +259,10 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
         __builtin_amdgcn_sched_barrier(0);
         // second half: row tile 3's terms are read into the registers row tile 1 has just left, under row tile 2's MFMAs and the first
         // half of the conversion; the wait in front of row tile 3 counts the LDS stores issued behind that read (three per converted row
-        // set) instead of draining them
-        X3_RA(A[1], aad, 3)
-        __builtin_amdgcn_sched_barrier(0);
+        // set) instead of draining them.  Row tile 2's own terms are waited for HERE (all but the three reads just issued): they were
+        // issued a whole MFMA group ago and have long landed on an idle LDS pipe, but nothing else orders mma(2) behind them -- without
+        // this wait a workgroup whose LDS pipe is contended (two launches on two streams) multiplied a stale low term once in ~10^5 tiles
+        X3_RA(A[1], aad, 3) X3_WAIT(3)
         mid(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) mma(2, A[0], nt);
