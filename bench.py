@@ -77,6 +77,13 @@ def op_direct_flops(name, args):
     """DIRECT-convolution FLOPs of a Winograd launch (SURVEY 8d's count for the layer: 2 * pixels * C * K * taps), None for launches whose
     executed count is the direct count already.  `algorithmic_over_peak` of a roofline entry is built from it: what the launch is worth in
     the reference's arithmetic, next to the executed `frac`."""
+    if name == "nirgan_conv_igemm_group":
+        # paired sub-pixel phases (nirgan_conv_desc.out_span = 2, a 3 x 3 stride-2 kernel): 9 of the 12 tap blocks of the two problems'
+        # weight matrices are non-zero -- the launch EXECUTES 4/3 of the layer's multiplies
+        ds = [args[0][j].contents for j in range(args[1])]
+        if any(d.out_span == 2 for d in ds):
+            return sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run * (0.75 if d.out_span == 2 else 1.0) for d in ds)
+        return None
     if name not in ("nirgan_wino6_gemm", "nirgan_wino6_gemm_wgrad_pair"):
         return None
     d = args[0]._obj

@@ -122,6 +122,15 @@ typedef struct {
      * mode); the packed weights come as three bf16 planes written by nirgan_split3 from `w`: w_x3 = plane h, planes m and l follow
      * w_x3_plane bf16 elements apart.  Problems the split tile does not cover (run % 32, N % 64, split-K, no w_x3) run as precision 0. */
     const void* w_x3; int64_t w_x3_plane;
+    /* out_span = 2 (precision 3 only; 0 / 1 = one pixel per row): a GEMM row writes TWO horizontally adjacent output pixels -- N = 2 C
+     * columns, column n = channel n % C of pixel (oh out_stride + out_oh, ow out_stride + out_ow + n / C); needs out_cs == C (dense pixels)
+     * and out_stride >= 2.  Two sub-pixel phases of one output row of a stride-2 transposed convolution / data gradient with C = 64 become
+     * ONE problem of 128-column tiles over the union of their taps (zero weight rows where a phase has no tap): the staged activation
+     * rows serve both phases and the launch's two problems (output-row parities) balance over the persistent workgroups.  bias holds N
+     * values (the layer's C twice).  The instance-norm partial sums and the fused backward sums keep their per-channel records: a chunk
+     * of rows leaves two records (pixel parity 0, then 1) of C columns -- stats_chunk0 + 2 OH OW / 64 <= stats_chunks, stats_ws and
+     * fuse_part sized with C; fuse_mean / fuse_rstd / fuse_y are those of the C-channel tensor. */
+    int out_span;
 } nirgan_conv_desc;
 #define NIRGAN_CONV_TILE128 1
 #define NIRGAN_CONV_X3_BN64 3   /* precision 3: the 256 x 64 block tile also where 256 x 128 applies (A/B) */

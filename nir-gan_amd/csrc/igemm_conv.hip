@@ -123,6 +123,8 @@ int ng::ng_launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, c
     w.n = n;
     w.nplanes = nplanes > 1 ? nplanes : 1;
     w.in_plane = in_plane; w.w3_pstride = w3_pstride; w.out_plane = out_plane;
+    // two problems of equal tile counts and different K (the two output-row parities of a paired sub-pixel launch): alternate them
+    w.alternate = (n == 2 && w.nplanes == 1 && ng::conv_x3_tiles(ps[0], bn) == ng::conv_x3_tiles(ps[1], bn) && ps[0].K != ps[1].K && ps[0].K < ps[1].K) ? 1 : 0;
     const int G = ng_cu_count_conv();
     const dim3 grid(total < G ? total : G);
     if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, w);
@@ -148,6 +150,7 @@ extern "C" int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p.prec == 3) {
         if (ng::conv_x3_ok(p)) return launch_conv_x3(&p, 1, ng::conv_x3_bn(p, ng_cu_count_conv()), st, "conv_igemm (three-term split tile)");
+        NG_REQUIRE(p.ch == p.N, "conv: out_span = 2 needs a problem the three-term split tile covers (run %% 32 == 0, N %% 64 == 0)");
         p.prec = 0;             // what the split tile does not cover runs as exact fp32
     }
     if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) {
@@ -219,7 +222,10 @@ extern "C" int nirgan_conv_igemm_group(const nirgan_conv_desc* const* descs, int
             const int bn = (g.p[0].N % 128 != 0 || g.p[0].algo == NIRGAN_CONV_X3_BN64 || t128 * 4 < 3ll * ng_cu_count_conv()) ? 64 : 128;
             return launch_conv_x3(g.p, n, bn, st, "conv_igemm_group (three-term split tile)");
         }
-        for (int i = 0; i < n; ++i) g.p[i].prec = 0;
+        for (int i = 0; i < n; ++i) {
+            NG_REQUIRE(g.p[i].ch == g.p[i].N, "conv_igemm_group: out_span = 2 needs problems the three-term split tile covers (run %% 32 == 0, N %% 64 == 0, one tile width)");
+            g.p[i].prec = 0;
+        }
     }
     for (int i = n; i < 4; ++i) { g.p[i] = g.p[0]; g.first[i] = 0x7fffffff; }
     g.first[4] = total;

@@ -90,6 +90,7 @@ struct ConvParams {
     int off32;                 // both operand buffers span < 4 GB: per-lane 32-bit byte offsets from a scalar base (the loader's fast path)
     const unsigned short* w3;  // precision 3: the packed weights as three bf16 planes h, m, l (nirgan_split3), w3_plane elements apart
     long long w3_plane;
+    int ch;                    // channels per output pixel: N, or N / 2 with nirgan_conv_desc.out_span = 2 (conv_x3_persist only)
 };
 
 
@@ -1293,7 +1294,11 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     NG_REQUIRE(d->in_elems >= int64_t(d->B) * d->in_hp * d->in_wp * d->in_cs, "conv: in_elems too small");
     NG_REQUIRE(d->out_elems >= int64_t(d->B) * d->out_hp * d->out_wp * d->out_cs, "conv: out_elems too small");
     NG_REQUIRE(d->w_elems >= int64_t(d->N) * d->ntaps * d->run, "conv: w_elems too small");
-    NG_REQUIRE(d->N <= d->out_cs, "conv: N=%d exceeds out_cs=%d", d->N, d->out_cs);
+    const int span = d->out_span > 1 ? d->out_span : 1;
+    NG_REQUIRE(span == 1 || (span == 2 && d->precision == 3 && d->N % 8 == 0 && d->out_cs == d->N / 2 && d->out_stride >= 2 && !d->out_bf16 && !d->fuse_y_bf16 && d->ksplit <= 1 && d->w_x3 != nullptr),
+               "conv: out_span=%d needs precision 3 with its weight planes, out_cs == N / 2, out_stride >= 2, fp32 tensors and no split-K", d->out_span);
+    const int ch = d->N / span;
+    NG_REQUIRE(ch <= d->out_cs, "conv: %d channels per pixel exceed out_cs=%d", ch, d->out_cs);
     int dh0 = d->tap_dh[0], dh1 = d->tap_dh[0], dw0 = d->tap_dw[0], dw1 = d->tap_dw[0];
     for (int t = 1; t < d->ntaps; ++t) {
         dh0 = d->tap_dh[t] < dh0 ? d->tap_dh[t] : dh0; dh1 = d->tap_dh[t] > dh1 ? d->tap_dh[t] : dh1;
@@ -1301,7 +1306,7 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     }
     NG_REQUIRE(d->in_oh + dh0 >= 0 && (d->OH - 1) * d->in_stride + d->in_oh + dh1 < d->in_hp, "conv: input rows out of range");
     NG_REQUIRE(d->in_ow + dw0 >= 0 && int64_t((d->OW - 1) * d->in_stride + d->in_ow + dw1) * d->in_cs + d->run <= int64_t(d->in_wp) * d->in_cs, "conv: input columns out of range");
-    NG_REQUIRE(d->out_oh >= 0 && (d->OH - 1) * d->out_stride + d->out_oh < d->out_hp && d->out_ow >= 0 && (d->OW - 1) * d->out_stride + d->out_ow < d->out_wp, "conv: output window out of range");
+    NG_REQUIRE(d->out_oh >= 0 && (d->OH - 1) * d->out_stride + d->out_oh < d->out_hp && d->out_ow >= 0 && (d->OW - 1) * d->out_stride + d->out_ow + span - 1 < d->out_wp, "conv: output window out of range");
 
     p.in = d->in; p.w = d->w; p.bias = d->bias; p.out = d->out; p.zero = d->zero_page;
     p.in_cs = d->in_cs; p.in_row = d->in_wp * d->in_cs; p.in_img = d->in_hp * p.in_row;
@@ -1314,7 +1319,7 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.OW = d->OW; p.OHW = d->OH * d->OW;
     const int64_t M = int64_t(d->B) * p.OHW;
     NG_REQUIRE(M < (int64_t(1) << 31), "conv: too many output pixels");
-    p.M = int(M); p.N = d->N;
+    p.M = int(M); p.N = d->N; p.ch = ch;
     p.mtiles = (p.M + 127) / 128;
     p.ntiles = d->N > 64 ? (d->N + 127) / 128 : 1;
     NG_REQUIRE(d->precision >= 0 && d->precision <= 3, "conv: precision=%d (0 fp32, 1 bf16, 2 bf16x3, 3 fp32 as three bf16 terms)", d->precision);
@@ -1337,8 +1342,8 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     p.stats = nullptr; p.stats_chunk0 = 0; p.stats_cps = 0;
     if (d->stats_ws != nullptr) {
         NG_REQUIRE(d->ksplit <= 1 && p.OHW % 128 == 0, "conv: the instance-norm partial sums need OH*OW %% 128 == 0 and no split-K (OH*OW=%d)", p.OHW);
-        NG_REQUIRE(d->stats_chunk0 >= 0 && d->stats_chunk0 + p.OHW / 64 <= d->stats_chunks, "conv: stats_chunk0 + OH*OW/64 exceeds stats_chunks");
-        NG_REQUIRE(d->stats_ws_elems >= int64_t(d->B) * d->stats_chunks * 4 * d->N, "conv: stats_ws too small (B * stats_chunks * 4 * N floats)");
+        NG_REQUIRE(d->stats_chunk0 >= 0 && d->stats_chunk0 + p.OHW / 64 * span <= d->stats_chunks, "conv: stats_chunk0 + OH*OW/64 (x out_span) exceeds stats_chunks");
+        NG_REQUIRE(d->stats_ws_elems >= int64_t(d->B) * d->stats_chunks * 4 * ch, "conv: stats_ws too small (B * stats_chunks * 4 * channels floats)");
         p.stats = d->stats_ws; p.stats_chunk0 = d->stats_chunk0; p.stats_cps = d->stats_chunks;
     }
     p.f_y = nullptr; p.f_mean = nullptr; p.f_rstd = nullptr; p.f_part = nullptr;
@@ -1346,13 +1351,13 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     if (d->fuse_y != nullptr) {
         NG_REQUIRE(d->ksplit <= 1 && p.OHW % 128 == 0 && d->N % 4 == 0 && d->bias == nullptr, "conv: the fused instance-norm backward sums need OH*OW %% 128 == 0, N %% 4 == 0, no split-K and no bias (OH*OW=%d N=%d)", p.OHW, d->N);
         NG_REQUIRE(d->fuse_mean && d->fuse_rstd && d->fuse_part && ng_aligned16(d->fuse_y) && ng_aligned16(d->fuse_mean) && ng_aligned16(d->fuse_rstd) && ng_aligned16(d->fuse_part), "conv: fuse_mean / fuse_rstd / fuse_part missing or misaligned");
-        NG_REQUIRE(d->fuse_oh >= 0 && d->fuse_ow >= 0 && (d->OH - 1) * d->out_stride + d->fuse_oh < d->fuse_h && (d->OW - 1) * d->out_stride + d->fuse_ow < d->fuse_w, "conv: fused window out of y's %d x %d extent", d->fuse_h, d->fuse_w);
-        NG_REQUIRE(int64_t(d->B) * d->fuse_h * d->fuse_w * d->N < (int64_t(1) << 31), "conv: fuse_y must be < 2^31 floats");
-        NG_REQUIRE(d->fuse_chunk0 >= 0 && d->fuse_chunk0 + p.OHW / 128 <= d->fuse_chunks, "conv: fuse_chunk0 + OH*OW/128 exceeds fuse_chunks");
-        NG_REQUIRE(d->fuse_part_elems >= int64_t(d->B) * d->fuse_chunks * 2 * d->N, "conv: fuse_part too small");
+        NG_REQUIRE(d->fuse_oh >= 0 && d->fuse_ow >= 0 && (d->OH - 1) * d->out_stride + d->fuse_oh < d->fuse_h && (d->OW - 1) * d->out_stride + d->fuse_ow + span - 1 < d->fuse_w, "conv: fused window out of y's %d x %d extent", d->fuse_h, d->fuse_w);
+        NG_REQUIRE(int64_t(d->B) * d->fuse_h * d->fuse_w * ch < (int64_t(1) << 31), "conv: fuse_y must be < 2^31 floats");
+        NG_REQUIRE(d->fuse_chunk0 >= 0 && d->fuse_chunk0 + p.OHW / 128 * span <= d->fuse_chunks, "conv: fuse_chunk0 + OH*OW/128 (x out_span) exceeds fuse_chunks");
+        NG_REQUIRE(d->fuse_part_elems >= int64_t(d->B) * d->fuse_chunks * 2 * ch, "conv: fuse_part too small");
         NG_REQUIRE(d->fuse_act == NIRGAN_ACT_NONE || d->fuse_act == NIRGAN_ACT_RELU || d->fuse_act == NIRGAN_ACT_LRELU, "conv: fuse_act=%d", d->fuse_act);
         p.f_y = d->fuse_y; p.f_mean = d->fuse_mean; p.f_rstd = d->fuse_rstd; p.f_part = d->fuse_part;
-        p.f_row = d->fuse_w * d->N; p.f_img = d->fuse_h * p.f_row; p.f_org = d->fuse_oh * p.f_row + d->fuse_ow * d->N;
+        p.f_row = d->fuse_w * ch; p.f_img = d->fuse_h * p.f_row; p.f_org = d->fuse_oh * p.f_row + d->fuse_ow * ch;
         p.f_act = d->fuse_act; p.f_slope = d->fuse_slope; p.f_chunk0 = d->fuse_chunk0; p.f_cps = d->fuse_chunks;
     }
     if (d->ksplit > 1) {

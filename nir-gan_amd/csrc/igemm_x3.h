@@ -77,6 +77,8 @@ struct X3Work {
     int n;
     int nplanes;               // > 1: p[0] only; item = plane * tiles + tile
     long long in_plane, w3_pstride, out_plane;
+    int alternate;             // two problems of equal tile counts and unequal K (the output-row parities of nirgan_conv_desc.out_span = 2):
+                               // rounds of gridDim.x items alternate between them -- every workgroup gets the long and the short K loop
 };
 
 // PERSISTENT workgroups, one per CU: a workgroup walks items b, b + G, ... (XCD-contiguous through ng_xcd_remap).  What one tile per
@@ -121,13 +123,27 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
         long long w3_plane;
     };
     auto locate = [&](const int item, Item& t) {
-        const int id0 = ng_xcd_remap(item, total);
-        int k = 0;
-        if (id0 >= wp->first[1]) k = 1;
-        if (id0 >= wp->first[2]) k = 2;
-        if (id0 >= wp->first[3]) k = 3;
+        int k = 0, id;
+        if (wp->alternate) {
+            // (no XCD walk here: neighbouring row tiles share one input row in four, the weights sit in every L2)
+            const int per = wp->first[1], full = (per / G) * G;           // tiles of each problem; those in whole rounds
+            if (item < 2 * full) {
+                const int j = item / G;
+                k = (j & 1) ^ 1;                                          // problem 1 (the longer K loop) first
+                id = (j >> 1) * G + (item - j * G);
+            } else {
+                const int r = item - 2 * full, left = per - full;
+                k = r < left ? 1 : 0;
+                id = full + (r < left ? r : r - left);
+            }
+        } else {
+            const int id0 = ng_xcd_remap(item, total);
+            if (id0 >= wp->first[1]) k = 1;
+            if (id0 >= wp->first[2]) k = 2;
+            if (id0 >= wp->first[3]) k = 3;
+            id = id0 - wp->first[k];
+        }
         const NG_CONST ConvParams* p = &wp->p[k];
-        int id = id0 - wp->first[k];
         int plane = 0;
         if (wp->nplanes > 1) {
             const int per = total / wp->nplanes;
@@ -312,8 +328,10 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
 #endif
         // (copies: the stores below make the compiler read every field again through `p`)
         const int pM = p.M, pN = p.N, OHW = p.OHW, OW = p.OW, OH = p.OHW / p.OW, out_img = p.out_img, out_row = p.out_row * p.out_stride,
-                  out_px = p.out_cs * p.out_stride, out_org = p.out_org, f_img = p.f_img, f_row = p.f_row * p.out_stride, f_px = p.N * p.out_stride,
-                  f_org = p.f_org;
+                  out_px = p.out_cs * p.out_stride, out_org = p.out_org, f_img = p.f_img, f_row = p.f_row * p.out_stride, f_px = p.ch * p.out_stride,
+                  f_org = p.f_org, pC = p.ch, span = p.N / p.ch;
+        // (pC < pN -- out_span = 2: column n is channel n - pC of the row's SECOND pixel from pC on; the per-channel records of the
+        // statistics / the fused sums then come in pairs per chunk, pixel parity 0 first)
         const float* const f_y = p.f_y;
         const int mbase = E.m0 + wr * 64;
         const bool full = E.m0 + 256 <= pM;
@@ -321,7 +339,7 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
         // {k = the chunk's first row, sum (v - k), sum (v - k)^2, 64} -- the contract of conv_tile / conv_tile256
         if (p.stats != nullptr && mbase < pM) {                     // (host: OH*OW % 128 == 0: a 64-row chunk is whole and inside one sample)
             const int b = mbase / OHW;
-            float* sp = p.stats + (size_t(b) * p.stats_cps + p.stats_chunk0 + ((mbase - b * OHW) >> 6)) * 4 * pN;
+            float* sp = p.stats + (size_t(b) * p.stats_cps + p.stats_chunk0 + ((mbase - b * OHW) >> 6) * span) * 4 * pC;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float k0 = __shfl(acc[0][nt][0], lane & 15, 64);
@@ -338,12 +356,13 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
                 s2 += __shfl_xor(s2, 16, 64);
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
-                const int col = E.n0 + wc * CW + nt * 16 + (lane & 15);
+                int col = E.n0 + wc * CW + nt * 16 + (lane & 15);
+                if (col >= pC) col += 3 * pC;                   // the second pixel's record follows the first one's four rows
                 if (lane < 16) {
                     sp[col] = k0;
-                    sp[pN + col] = s1;
-                    sp[2 * pN + col] = s2;
-                    sp[3 * pN + col] = 64.f;
+                    sp[pC + col] = s1;
+                    sp[2 * pC + col] = s2;
+                    sp[3 * pC + col] = 64.f;
                 }
             }
         }
@@ -362,9 +381,10 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
         int oh = r0 / OW, ow = r0 - oh * OW;
         const int fb = (mbase < pM ? mbase : pM - 1) / OHW;           // (fused: one sample per 128-row chunk, host: OH*OW % 128 == 0)
         f32x4 fm = {0.f, 0.f, 0.f, 0.f}, fr = fm, s1 = fm, s2 = fm;
+        const int nq = n >= pC ? 1 : 0, nc = n - nq * pC;           // pixel of the row and channel of this lane's four columns
         if (fused) {
-            fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(fb) * pN + n);
-            fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(fb) * pN + n);
+            fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(fb) * pC + nc);
+            fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(fb) * pC + nc);
         }
         // (FULL: a tile whose 256 rows all exist issues every store instruction, unrolled and without a predicate -- step() counts them,
         // and so can the compiler when it waits for the next item's fetched rows in front of their conversion)
@@ -436,9 +456,9 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
             __syncthreads();                    // (uniform: `fused` is a constant of the item's problem, the items of a launch agree)
             if ((wr & 1) == 0 && lane < LPR && mbase < pM) {
                 const f32x4 t1 = s1 + red[((wave + 2) * LPR + chunk) * 2], t2 = s2 + red[((wave + 2) * LPR + chunk) * 2 + 1];
-                float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((mbase - fb * OHW) >> 7)) * 2 * pN + n;
+                float* pp = p.f_part + (size_t(fb) * p.f_cps + p.f_chunk0 + ((mbase - fb * OHW) >> 7) * span + nq) * 2 * pC + nc;
                 *reinterpret_cast<f32x4*>(pp) = t1;
-                *reinterpret_cast<f32x4*>(pp + pN) = t2;
+                *reinterpret_cast<f32x4*>(pp + pC) = t2;
             }
             __syncthreads();                    // the array is free for the next item
         }

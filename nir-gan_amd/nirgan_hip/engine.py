@@ -278,6 +278,46 @@ class Weights:
         self.cache[key] = buf
         return buf
 
+    def packed_pair(self, plan: Plan, param: torch.Tensor, specs: list) -> torch.Tensor:
+        """Two pack specs of equal shape stacked into one [2 N][K] matrix with its three bf16 planes (precision 3): the weights of a
+        paired sub-pixel problem (nirgan_conv_desc.out_span = 2) -- rows 0..N-1 the first pixel's, N..2N-1 the second's."""
+        a, b = specs
+        assert (a.N, a.K, a.run) == (b.N, b.K, b.run) and a.run % 32 == 0 and self.ctx.precision == 0
+        key = (param.data_ptr(), "pair", a.key, b.key)
+        if key in self.cache:
+            return self.cache[key]
+        buf = self.ctx.zeros(2 * a.N, a.K)
+        plane = 2 * a.N * a.K
+        tw = torch.zeros(3 * plane, dtype=torch.bfloat16, device=self.ctx.device)
+        self.ctx.bytes += tw.numel() * 2
+        for i, spec in enumerate(specs):
+            imap = self.ctx.i32(spec.index_map)
+            half = buf.data_ptr() + i * a.N * a.K * 4
+            plan.add("nirgan_pack_rows", param.data_ptr(), param.numel(), spec.row_stride, imap.data_ptr(), half, spec.N, spec.K)
+            plan.add("nirgan_split3", half, tw.data_ptr() + i * a.N * a.K * 2, spec.N * spec.K, plane)
+        buf.x3 = (tw, plane)
+        self.ctx.keep += [buf, tw]
+        self.cache[key] = buf
+        return buf
+
+    def doubled(self, plan: Plan, vec: torch.Tensor) -> torch.Tensor:
+        """[v, v]: the bias of a paired sub-pixel problem (one value per GEMM column), refreshed with the packs."""
+        key = (vec.data_ptr(), "doubled")
+        if key in self.cache:
+            return self.cache[key]
+        n = vec.numel()
+        buf = self.ctx.zeros(2 * n)
+        imap = self.ctx.i32(np.concatenate([np.arange(n), np.arange(n)]))
+        plan.add("nirgan_pack_rows", vec.data_ptr(), n, 0, imap.data_ptr(), buf.data_ptr(), 1, 2 * n)
+        self.ctx.keep.append(buf)
+        self.cache[key] = buf
+        return buf
+
+
+def channels_of(d) -> int:
+    """Channels per output pixel of a convolution descriptor (N, or N / 2 with out_span = 2)."""
+    return d.N // max(1, d.out_span)
+
 
 # ---------------------------------------------------------------------------------------------
 # descriptor emitters
@@ -304,7 +344,7 @@ def choose_ksplit(tiles: int, nk: int) -> int:
 
 
 def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bias, out: Halo, *, N, OH, OW,
-              in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None, allow_split=True):
+              in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None, allow_split=True, out_span=1):
     d = L.ConvDesc()
     d.inp, d.in_elems = inp.operand_ptr(d), inp.elems
     if inp.t16 is not None and w.dtype == torch.bfloat16 and taps.run % 8 == 0:
@@ -334,6 +374,10 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
         # exact-fp32 mode: this contraction on the bf16 pipe as three bf16 terms per operand, six products (fp32-equivalent; no split-K form)
         d.precision, d.w_x3, d.w_x3_plane = 3, x3[0].data_ptr(), x3[1]
         allow_split = False
+    if out_span > 1:
+        # two adjacent output pixels per GEMM row (the split tile only): N = 2 C columns into a dense C-channel tensor
+        assert d.precision == 3 and out.C * out_span == N and out_stride >= out_span, "out_span needs the three-term split tile and a dense output"
+        d.out_span = out_span
     ctx.keep.append(d)
     if plan is not None:
         M = inp.B * OH * OW
@@ -641,16 +685,44 @@ def attach_conv_stats(ctx: Ctx, descs: list, bias) -> Optional[tuple]:
     # costs 2-4 us and the layer keeps it (OPT.epilogue_min_pixels: the kernel tests run small layers through it)
     if sum(d.OH * d.OW for d in descs) < (OPT.epilogue_min_pixels if ctx.precision == 0 else min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16)):
         return None
-    B, N = descs[0].B, descs[0].N
-    total = sum(d.OH * d.OW // 64 for d in descs)
+    B, N = descs[0].B, channels_of(descs[0])
+    recs = [d.OH * d.OW // 64 * max(1, d.out_span) for d in descs]       # (a paired problem leaves two records per 64 rows)
+    total = sum(recs)
     if not hasattr(ctx, "conv_pool_stats"):
         ctx.conv_pool_stats = SplitPool(ctx)
     ws = ctx.conv_pool_stats.get(B * total * 4 * N)
     first = 0
-    for d in descs:
+    for d, n in zip(descs, recs):
         d.stats_ws, d.stats_ws_elems, d.stats_chunk0, d.stats_chunks = ws.data_ptr(), ws.numel(), first, total
-        first += d.OH * d.OW // 64
+        first += n
     return total, bias, ws
+
+
+def want_phase_pairs(ctx: Ctx, phases: list, run: int, N: int, out) -> bool:
+    """A 64-channel sub-pixel launch whose four phases would not all take the split tile (taps x run < 512 somewhere: 1 / 2 / 2 / 4 taps of a
+    3 x 3 kernel) runs as two paired problems of 128 columns on it (nirgan_conv_desc.out_span = 2, geometry.pair_row_phases): measured
+    412 / 349 us -> see DESIGN 3.1 for ConvTranspose2d(128, 64, 3, s2) at bs 16 / the data gradient of Conv2d(64, 128, 3, s2)."""
+    return (ctx.precision == 0 and OPT.split3 and OPT.pair_phases and N == 64 and run % 32 == 0 and out.C == N and out.C % 4 == 0
+            and not getattr(out, "is16", False) and len(phases) == 4 and min(len(ph.dh) for ph in phases) * run < 512)
+
+
+def emit_phase_pairs(eng, pack: Plan, ctx: Ctx, inp: Halo, phases: list, spec_fn, weight, bias, out: Halo, *, N, in_off, out_off):
+    """The two paired problems (output-row parities) of a stride-2 gather, or None when the phases do not pair up.  spec_fn(taps_hw) ->
+    PackSpec of one phase; in_off / out_off: what the caller adds to a phase's input / output origin."""
+    pairs = G.pair_row_phases(phases)
+    if pairs is None:
+        return None
+    descs = []
+    for pr in pairs:
+        w = eng.weights.packed_pair(pack, weight, [G.masked_pack(spec_fn, hw) for hw in pr.taps_hw])
+        b2 = eng.weights.doubled(pack, bias) if bias is not None else None
+        d = emit_conv(None, ctx, inp, G.Taps(pr.dh, pr.dw, inp.C), w, b2, out, N=2 * N, OH=pr.n_h, OW=pr.n_w,
+                      in_oh=pr.in_oh + in_off, in_ow=pr.in_ow + in_off, out_stride=2, out_oh=pr.out_oh + out_off, out_ow=pr.out_ow + out_off,
+                      out_span=2)
+        used = sum(hw is not None for hws in pr.taps_hw for hw in hws)
+        d.useful_fraction = used / (2.0 * len(pr.dh))            # (bench.py: the zero blocks are executed, not algorithmic, work)
+        descs.append(d)
+    return descs
 
 
 def emit_conv_group(plan: Plan, ctx: Ctx, descs: list):
@@ -905,8 +977,13 @@ class ConvIN:
                 pre = attach_conv_stats(ctx, [cd], self.bias)
             self._y_fallback(pre, [cd])
         else:  # convT: 4 sub-pixel phases over the zero-halo-1 input, one launch
-            descs = []
-            for ph in G.convT_fwd_phases(inp.H, inp.W, k, p):
+            descs = None
+            phases = G.convT_fwd_phases(inp.H, inp.W, k, p)
+            if want_phase_pairs(ctx, phases, inp.C, self.cout, self.y):
+                descs = emit_phase_pairs(eng, pack, ctx, inp, phases, lambda hw: G.convT_fwd_pack(inp.C, self.cout, k, hw), self.weight,
+                                         self.bias, self.y, N=self.cout, in_off=inp.pad - 1, out_off=0)
+            for ph in (phases if descs is None else []):
+                descs = descs or []
                 taps = G.Taps(ph.dh, ph.dw, inp.C)
                 w = eng.weights.packed(pack, self.weight, G.convT_fwd_pack(inp.C, self.cout, k, ph.taps_hw))
                 descs.append(emit_conv(None, ctx, inp, taps, w, self.bias, self.y, N=self.cout, OH=ph.n_h, OW=ph.n_w,
@@ -987,10 +1064,10 @@ class ConvIN:
         cds = getattr(g, "conv_out_descs", None) if g is not None else None
         if (cds and not pre_sums and self.norm and not g_fold and g2 is None and gsum is None and self.cout % 4 == 0
                 and act in (L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU) and OPT.fuse_inbwd
-                and all(c.ksplit <= 1 and (c.OH * c.OW) % 128 == 0 and c.N == self.cout and not c.bias for c in cds)
-                and sum(c.OH * c.OW for c in cds) == self.OH * self.OW
+                and all(c.ksplit <= 1 and (c.OH * c.OW) % 128 == 0 and channels_of(c) == self.cout and not c.bias for c in cds)
+                and sum(c.OH * c.OW * max(1, c.out_span) for c in cds) == self.OH * self.OW
                 and self.OH * self.OW >= (OPT.epilogue_min_pixels if ctx.precision == 0 else min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16))):
-            chunks = sum(c.OH * c.OW // 128 for c in cds)
+            chunks = sum(c.OH * c.OW // 128 * max(1, c.out_span) for c in cds)
             if not hasattr(ctx, "inbwd_part"):
                 ctx.inbwd_part = SplitPool(ctx)
             ws = ctx.inbwd_part.get(inp.B * chunks * 2 * self.cout + inp.B * 2 * self.cout)
@@ -1002,7 +1079,7 @@ class ConvIN:
                 c.fuse_oh, c.fuse_ow = c.out_oh - g.pad, c.out_ow - g.pad
                 c.fuse_act, c.fuse_slope = act, 0.2
                 c.fuse_part, c.fuse_part_elems, c.fuse_chunk0, c.fuse_chunks = ws.data_ptr(), ws.numel(), first, chunks
-                first += c.OH * c.OW // 128
+                first += c.OH * c.OW // 128 * max(1, c.out_span)
             pre_sums = chunks
         nd = emit_in_bwd(plan, ctx, g=g, g_fold=g_fold, g2=g2, act=act,
                          y=self.y, stats=self.stats, norm=self.norm, dy=self.dy, gsum=gsum,
@@ -1064,8 +1141,13 @@ class ConvIN:
         elif self.kind in ("conv", "rowpacked") and s == 2:
             assert dgrad_out.H == inp.H and dy.pad == 1
             cin_buf = inp.C
-            descs = []
-            for ph in G.conv_dgrad_s2_phases(inp.H, inp.W, k, p):
+            descs = None
+            phases = G.conv_dgrad_s2_phases(inp.H, inp.W, k, p)
+            if self.kind == "conv" and want_phase_pairs(ctx, phases, self.cout, inp.C, dgrad_out):
+                descs = emit_phase_pairs(eng, pack, ctx, dy, phases, lambda hw: G.conv_dgrad_pack(self.cout, inp.C, k, hw), self.weight, None,
+                                         dgrad_out, N=inp.C, in_off=0, out_off=dgrad_out.pad)
+            for ph in (phases if descs is None else []):
+                descs = descs or []
                 if self.kind == "conv":
                     spec = G.conv_dgrad_pack(self.cout, inp.C, k, ph.taps_hw)
                 else:

@@ -149,6 +149,58 @@ def convT_fwd_phases(Hin: int, Win: int, k: int = 3, p: int = 1) -> List[Phase]:
     return out
 
 
+@dataclass
+class PhasePair:
+    """Two sub-pixel phases of ONE output row (pixels 2 ow + out_ow and 2 ow + out_ow + 1) as one problem over the union of their taps:
+    GEMM row (oh, ow) reads input rows in_oh + oh + dh[t], columns in_ow + ow + dw[t]; taps_hw[q][t] = the kernel element pixel q
+    multiplies tap t with, or None (a zero block of the packed weights)."""
+    n_h: int
+    n_w: int
+    out_oh: int
+    out_ow: int
+    in_oh: int
+    in_ow: int
+    dh: List[int]
+    dw: List[int]
+    taps_hw: List[list]
+
+
+def pair_row_phases(phases: List[Phase]):
+    """The four phases of a stride-2 gather as two PhasePairs (one per output-row parity, the shorter tap list first), or None when
+    they do not pair up (odd sizes drop or shrink a phase)."""
+    if len(phases) != 4:
+        return None
+    rows = {}
+    for ph in phases:
+        rows.setdefault(ph.out_oh, []).append(ph)
+    if len(rows) != 2 or any(len(v) != 2 for v in rows.values()):
+        return None
+    out = []
+    for ooh in sorted(rows):
+        a, b = sorted(rows[ooh], key=lambda ph: ph.out_ow)
+        if b.out_ow != a.out_ow + 1 or (a.n_h, a.n_w) != (b.n_h, b.n_w):
+            return None
+        pos = sorted({(ph.in_oh + h, ph.in_ow + w) for ph in (a, b) for h, w in zip(ph.dh, ph.dw)})
+        ioh, iow = min(h for h, _ in pos), min(w for _, w in pos)
+        maps = []
+        for ph in (a, b):
+            own = {(ph.in_oh + h, ph.in_ow + w): hw for h, w, hw in zip(ph.dh, ph.dw, ph.taps_hw)}
+            maps.append([own.get(q) for q in pos])
+        out.append(PhasePair(a.n_h, a.n_w, a.out_oh, a.out_ow, ioh, iow, [h - ioh for h, _ in pos], [w - iow for _, w in pos], maps))
+    out.sort(key=lambda pr: len(pr.dh))
+    return out
+
+
+def masked_pack(spec_fn, taps_hw: list) -> PackSpec:
+    """spec_fn(list of (kh, kw)) -> PackSpec with one run per tap; the taps given as None become zero blocks (index -1)."""
+    spec = spec_fn([hw if hw is not None else (0, 0) for hw in taps_hw])
+    idx = spec.index_map.reshape(len(taps_hw), -1).copy()
+    for t, hw in enumerate(taps_hw):
+        if hw is None:
+            idx[t, :] = -1
+    return PackSpec(spec.N, spec.K, spec.row_stride, idx.reshape(-1), spec.key + ("mask", tuple(hw is not None for hw in taps_hw)), spec.run)
+
+
 def convT_fwd_pack(cin: int, cout: int, k: int, taps_hw: List[Tuple[int, int]]) -> PackSpec:
     """packed[co][t*cin + ci] = W[ci][co][kh_t][kw_t]."""
     idx = np.empty((len(taps_hw), cin), dtype=np.int32)

@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ("stats_ws", fp), ("stats_ws_elems", i64), ("stats_chunk0", i32), ("stats_chunks", i32),
                 ("fuse_y", fp), ("fuse_mean", fp), ("fuse_rstd", fp), ("fuse_h", i32), ("fuse_w", i32), ("fuse_oh", i32), ("fuse_ow", i32),
                 ("fuse_act", i32), ("fuse_slope", f32), ("fuse_part", fp), ("fuse_part_elems", i64), ("fuse_chunk0", i32), ("fuse_chunks", i32),
-                ("out_bf16", i32), ("fuse_y_bf16", i32), ("algo", i32), ("w_x3", fp), ("w_x3_plane", i64)]
+                ("out_bf16", i32), ("fuse_y_bf16", i32), ("algo", i32), ("w_x3", fp), ("w_x3_plane", i64), ("out_span", i32)]
 
 
 class WgradDesc(C.Structure):

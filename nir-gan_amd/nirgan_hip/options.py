@@ -61,6 +61,10 @@ class Options:
     split3: bool = True
     # ... and the plane GEMMs / transform-domain weight gradients of the Winograd layers too (A/B)
     split3_wino: bool = True
+    # ... and the 64-channel sub-pixel launches with short K (ConvTranspose2d(128, 64, 3, s2) and the data gradient of Conv2d(64, 128, 3, s2):
+    # phases of 1 / 2 / 2 / 4 taps) as TWO problems of 128 columns -- the two phases of one output row side by side, over the union of
+    # their taps (nirgan_conv_desc.out_span = 2) -- on the split tile instead of four 64-column problems on the exact fp32 tile (A/B)
+    pair_phases: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
     endconv_direct: bool = True
 

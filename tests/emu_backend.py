@@ -164,20 +164,25 @@ class EmuBackend:
             c1 = (d.OW - 1) * d.in_stride + d.in_ow + d.tap_dw[t]
             if c0 < 0 or c1 * d.in_cs + d.run > d.in_wp * d.in_cs:
                 return self._fail("conv: input cols out of range")
-        if d.N > d.out_cs or (d.OH - 1) * d.out_stride + d.out_oh >= d.out_hp or (d.OW - 1) * d.out_stride + d.out_ow >= d.out_wp:
+        span = d.out_span if d.out_span > 1 else 1
+        ch = d.N // span                                  # channels per output pixel
+        if span > 1 and not (span == 2 and d.precision == 3 and prec == 3 and d.N % 8 == 0 and d.out_cs == ch and d.out_stride >= 2
+                             and not (d.out_bf16 or d.fuse_y_bf16) and d.ksplit <= 1):
+            return self._fail("conv: out_span needs precision 3 with its weight planes on a problem the split tile covers, out_cs == N / 2, out_stride >= 2")
+        if ch > d.out_cs or (d.OH - 1) * d.out_stride + d.out_oh >= d.out_hp or (d.OW - 1) * d.out_stride + d.out_ow + span - 1 >= d.out_wp:
             return self._fail("conv: output out of range")
         if d.fuse_y:
             if (d.ksplit > 1 or (d.OH * d.OW) % 128 or d.N % 4 or d.bias or not (d.fuse_mean and d.fuse_rstd and d.fuse_part)
-                    or (d.OH - 1) * d.out_stride + d.fuse_oh >= d.fuse_h or (d.OW - 1) * d.out_stride + d.fuse_ow >= d.fuse_w
-                    or d.fuse_chunk0 < 0 or d.fuse_chunk0 + d.OH * d.OW // 128 > d.fuse_chunks or d.fuse_part_elems < d.B * d.fuse_chunks * 2 * d.N):
+                    or (d.OH - 1) * d.out_stride + d.fuse_oh >= d.fuse_h or (d.OW - 1) * d.out_stride + d.fuse_ow + span - 1 >= d.fuse_w
+                    or d.fuse_chunk0 < 0 or d.fuse_chunk0 + d.OH * d.OW // 128 * span > d.fuse_chunks or d.fuse_part_elems < d.B * d.fuse_chunks * 2 * ch):
                 return self._fail("conv: the fused instance-norm backward sums need OH*OW % 128 == 0, N % 4 == 0, no split-K, no bias, a window inside y and a large enough fuse_part")
             self.calls.append("conv_inbwd")
         stats = None
         if d.stats_ws:
             ohw = d.OH * d.OW
-            if d.ksplit > 1 or ohw % 128 or d.stats_chunk0 < 0 or d.stats_chunk0 + ohw // 64 > d.stats_chunks or d.stats_ws_elems < d.B * d.stats_chunks * 4 * d.N:
+            if d.ksplit > 1 or ohw % 128 or d.stats_chunk0 < 0 or d.stats_chunk0 + ohw // 64 * span > d.stats_chunks or d.stats_ws_elems < d.B * d.stats_chunks * 4 * ch:
                 return self._fail("conv: the instance-norm partial sums need OH*OW % 128 == 0, no split-K and a large enough stats_ws")
-            stats = arr(d.stats_ws, d.B * d.stats_chunks * 4 * d.N).reshape(d.B, d.stats_chunks, 4, d.N)
+            stats = arr(d.stats_ws, d.B * d.stats_chunks * 4 * ch).reshape(d.B, d.stats_chunks, 4, ch)
             self.calls.append("conv_stats")
         for b in range(d.B):
             acc = np.zeros((d.OH, d.OW, d.N), dtype=np.float64)
@@ -185,13 +190,14 @@ class EmuBackend:
                 off = (d.tap_dh[t] * d.in_wp + d.tap_dw[t]) * d.in_cs
                 A = inp[b * in_img + base[..., None] + off + rr]
                 acc += contract(A.reshape(-1, d.run), np.ascontiguousarray(w[:, t * d.run:(t + 1) * d.run].T), prec).reshape(d.OH, d.OW, d.N)
-            if stats is not None:                      # per 64 pixels: {k = first pixel, sum (v - k), sum (v - k)^2, 64}, without the bias
-                ch = acc.reshape(-1, 64, d.N)
-                k = ch[:, 0]
-                sl = slice(d.stats_chunk0, d.stats_chunk0 + ch.shape[0])
+            if stats is not None:                      # per 64 rows: {k = first row, sum (v - k), sum (v - k)^2, 64}, without the bias
+                # (out_span = 2: a row holds two pixels -- two records of `ch` columns per 64 rows, the first pixel's first)
+                rows = acc.reshape(-1, 64, span, ch).transpose(0, 2, 1, 3).reshape(-1, 64, ch)
+                k = rows[:, 0]
+                sl = slice(d.stats_chunk0, d.stats_chunk0 + rows.shape[0])
                 stats[b, sl, 0] = k
-                stats[b, sl, 1] = (ch - k[:, None]).sum(1)
-                stats[b, sl, 2] = ((ch - k[:, None]) ** 2).sum(1)
+                stats[b, sl, 1] = (rows - k[:, None]).sum(1)
+                stats[b, sl, 2] = ((rows - k[:, None]) ** 2).sum(1)
                 stats[b, sl, 3] = 64.0
             if bias is not None:
                 acc += bias
@@ -201,16 +207,18 @@ class EmuBackend:
             else:
                 out[idx] = acc.astype(np.float32)
             if d.fuse_y:                               # first pass of the consumer layer's instance-norm backward, per 128-pixel tile
-                yv = load_y(d.fuse_y, d.B * d.fuse_h * d.fuse_w * d.N, d.fuse_y_bf16).reshape(d.B, d.fuse_h, d.fuse_w, d.N)
-                ys = yv[b, d.fuse_oh:d.fuse_oh + (d.OH - 1) * d.out_stride + 1:d.out_stride, d.fuse_ow:d.fuse_ow + (d.OW - 1) * d.out_stride + 1:d.out_stride]
-                z = ((ys - arr(d.fuse_mean, d.B * d.N).reshape(d.B, d.N)[b]) * arr(d.fuse_rstd, d.B * d.N).reshape(d.B, d.N)[b]).astype(np.float32)
-                gv = acc.astype(np.float32).astype(np.float64)
+                yv = load_y(d.fuse_y, d.B * d.fuse_h * d.fuse_w * ch, d.fuse_y_bf16).reshape(d.B, d.fuse_h, d.fuse_w, ch)
+                ys = np.stack([yv[b, d.fuse_oh:d.fuse_oh + (d.OH - 1) * d.out_stride + 1:d.out_stride,
+                                  d.fuse_ow + q:d.fuse_ow + q + (d.OW - 1) * d.out_stride + 1:d.out_stride] for q in range(span)], axis=2)     # [OH][OW][span][ch]
+                z = ((ys - arr(d.fuse_mean, d.B * ch).reshape(d.B, ch)[b]) * arr(d.fuse_rstd, d.B * ch).reshape(d.B, ch)[b]).astype(np.float32)
+                gv = acc.astype(np.float32).astype(np.float64).reshape(d.OH, d.OW, span, ch)
                 neg = 0.0 if d.fuse_act == 1 else (d.fuse_slope if d.fuse_act == 2 else 1.0)
                 gz = np.where(z > 0, gv, gv * neg)
-                part = arr(d.fuse_part, d.B * d.fuse_chunks * 2 * d.N).reshape(d.B, d.fuse_chunks, 2, d.N)
+                part = arr(d.fuse_part, d.B * d.fuse_chunks * 2 * ch).reshape(d.B, d.fuse_chunks, 2, ch)
                 nch = d.OH * d.OW // 128
-                part[b, d.fuse_chunk0:d.fuse_chunk0 + nch, 0] = gz.reshape(nch, 128, d.N).sum(1)
-                part[b, d.fuse_chunk0:d.fuse_chunk0 + nch, 1] = (gz * z).reshape(nch, 128, d.N).sum(1)
+                # per 128 rows: one record per pixel of the row (span of them), the first pixel's first
+                part[b, d.fuse_chunk0:d.fuse_chunk0 + nch * span, 0] = gz.reshape(nch, 128, span, ch).sum(1).reshape(nch * span, ch)
+                part[b, d.fuse_chunk0:d.fuse_chunk0 + nch * span, 1] = (gz * z).reshape(nch, 128, span, ch).sum(1).reshape(nch * span, ch)
         return 0
 
     def nirgan_wgrad_igemm(self, ref, stream=None):

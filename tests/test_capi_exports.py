@@ -46,7 +46,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     """ctypes mirrors have exactly the C layout: sizeof and the offset of the last field, computed by gcc."""
     import ctypes as C
     import subprocess
-    pairs = [("nirgan_conv_desc", L.ConvDesc, "w_x3_plane"), ("nirgan_wgrad_desc", L.WgradDesc, "algo"),
+    pairs = [("nirgan_conv_desc", L.ConvDesc, "out_span"), ("nirgan_wgrad_desc", L.WgradDesc, "algo"),
              ("nirgan_in_fwd_desc", L.InFwdDesc, "y_bf16"), ("nirgan_in_bwd_desc", L.InBwdDesc, "g_bf16"),
              ("nirgan_tap_gather_desc", L.TapGatherDesc, "dst"), ("nirgan_tap_scatter_desc", L.TapScatterDesc, "dbias"),
              ("nirgan_pix_loss_desc", L.PixLossDesc, "ws_elems"), ("nirgan_inject_fwd_desc", L.InjectFwdDesc, "o_pad"),

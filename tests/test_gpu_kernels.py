@@ -122,6 +122,55 @@ def test_convT_phases_match_torch():
     close(y.t.permute(0, 3, 1, 2), ref, 1e-5, "convT fwd")
 
 
+@pytest.mark.parametrize("shape", [(2, 7, 6), (3, 32, 32), (1, 40, 24)])
+def test_paired_phases_match_torch_float64(shape):
+    """nirgan_conv_desc.out_span = 2: ConvTranspose2d(128, 64, 3, s2, p1, op1) + bias as the two paired problems of engine.emit_phase_pairs
+    (128 columns = two adjacent output pixels, union of the two phases' taps, zero weight blocks) and the data gradient of
+    Conv2d(64, 128, 3, s2, p1) the same way, against torch in float64 (ragged sizes: partial 256-row tiles, 64-column tile for the small
+    problems)."""
+    from nirgan_hip.engine import Weights, emit_phase_pairs, emit_conv_group, want_phase_pairs
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(31)
+    tw = Twin()
+    ctx = tw.gctx
+
+    class Eng:
+        pass
+    eng = Eng()
+    eng.ctx, eng.weights = ctx, Weights(ctx)
+    # forward of the transposed convolution
+    Cin, Cout, k = 128, 64, 3
+    xg, xc = tw.halo(B, H, W, Cin, 1, gen, fill_halo=False)
+    wg, wc = tw.tensor(Cin, Cout, k, k, gen=gen, scale=0.05)
+    bg, bc = tw.tensor(Cout, gen=gen, scale=1.0)
+    y = Halo(ctx, B, 2 * H, 2 * W, Cout, 0)
+    plan, pack = Plan(ctx), Plan(ctx)
+    phases = G.convT_fwd_phases(H, W, k, 1)
+    assert want_phase_pairs(ctx, phases, Cin, Cout, y)
+    descs = emit_phase_pairs(eng, pack, ctx, xg, phases, lambda hw: G.convT_fwd_pack(Cin, Cout, k, hw), wg, bg, y, N=Cout, in_off=0, out_off=0)
+    assert descs is not None and [d.out_span for d in descs] == [2, 2] and [d.ntaps for d in descs] == [2, 4]
+    emit_conv_group(plan, ctx, descs)
+    pack.run()
+    plan.run()
+    ref = torch.nn.functional.conv_transpose2d(xc.interior().permute(0, 3, 1, 2).double(), wc.double(), bc.double(), stride=2, padding=1, output_padding=1)
+    close(y.t.permute(0, 3, 1, 2), ref.float(), 2e-6, "paired convT forward")
+    # data gradient of the stride-2 convolution (even sizes: the four phases exist and pair up)
+    if H % 2 == 0 and W % 2 == 0:
+        Ci, Co = 64, 128
+        dyg, dyc = tw.halo(B, H // 2, W // 2, Co, 1, gen, fill_halo=False)
+        w2g, w2c = tw.tensor(Co, Ci, k, k, gen=gen, scale=0.05)
+        dx = Halo(ctx, B, H, W, Ci, 0)
+        plan2, pack2 = Plan(ctx), Plan(ctx)
+        ph2 = G.conv_dgrad_s2_phases(H, W, k, 1)
+        d2 = emit_phase_pairs(eng, pack2, ctx, dyg, ph2, lambda hw: G.conv_dgrad_pack(Co, Ci, k, hw), w2g, None, dx, N=Ci, in_off=0, out_off=0)
+        assert d2 is not None
+        emit_conv_group(plan2, ctx, d2)
+        pack2.run()
+        plan2.run()
+        ref2 = torch.nn.grad.conv2d_input((B, Ci, H, W), w2c.double(), dyc.interior().permute(0, 3, 1, 2).double(), stride=2, padding=1)
+        close(dx.t.permute(0, 3, 1, 2), ref2.float(), 2e-6, "paired data gradient")
+
+
 def test_rowpacked_first_conv():
     """7x7, 3 -> 64 over a 4-channel NHWC buffer with one tap per kernel row (run = 28)."""
     gen = torch.Generator().manual_seed(5)

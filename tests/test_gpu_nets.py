@@ -1050,6 +1050,42 @@ def test_two_stream_steps_are_bitwise_reproducible_under_contention():
     assert not bad, f"{len(bad)} of 499 steps differ from the first: {bad[:5]}"
 
 
+def test_paired_sub_pixel_phases_on_the_device():
+    """nirgan_conv_desc.out_span = 2 (ConvTranspose2d(128, 64, 3, s2) forward and the data gradient of Conv2d(64, 128, 3, s2) as two paired
+    problems on the split tile, with the instance-norm partial sums and the fused first backward pass in the epilogue) against the four
+    phases on the exact fp32 tile (OPT.pair_phases = False), ngf 64, bs 2 @128: prediction and losses to fp32 rounding, gradients to the
+    bound the other exact-against-split comparisons use (unforced ReLU kinks)."""
+    from model import networks
+    from nirgan_hip.options import OPT
+    from nirgan_hip.trainer import Pix2PixTrainer
+
+    def run(pair):
+        OPT.reset()
+        OPT.pair_phases = pair
+        try:
+            torch.manual_seed(0)
+            g = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02).to(DEV)
+            d = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(DEV)
+            tr = Pix2PixTrainer(g, d, n_blocks=6, lr=0.0)          # (no Adam step between the passes: it amplifies rounding noise to its step size)
+            rgb, nir = synth(2, 128, 128, 33)
+            o = tr.step(rgb.to(DEV), nir.to(DEV)).as_dict()
+            torch.cuda.synchronize()
+            spans = [[a[0][i].contents.out_span for i in range(a[1])] for pl in (tr.G.fwd, tr.G.bwd) for n_, a in pl.ops if n_ == "nirgan_conv_igemm_group"]
+            return o, tr.flatG.grad.clone(), tr.flatD.grad.clone(), tr.pred.clone(), spans
+        finally:
+            OPT.reset()
+    o1, gG1, gD1, p1, spans1 = run(True)
+    o0, gG0, gD0, p0, spans0 = run(False)
+    assert [2, 2] in spans1 and sum(s == [2, 2] for s in spans1) == 2, spans1
+    assert not any(2 in s for s in spans0), spans0
+    close(p1, p0, 2e-5, "prediction")
+    for k in o0:
+        close(torch.tensor(o1[k]), torch.tensor(o0[k]), 1e-4, k)
+    # (profiles/r05_medium_width_kink_noise.txt: two exact-fp32 tilings of these networks differ by 5e-3 in the gradients at random init)
+    assert ((gD1 - gD0).norm() / gD0.norm()).item() < 5e-3
+    assert ((gG1 - gG0).norm() / gG0.norm()).item() < 1e-2
+
+
 def test_fullsize_inject_generator_forward_against_oracle():
     """configs[3] geometry at one tile: ngf 64, 9 blocks, 256x256 with the YAML's reflect pad 10 -> the SatCLIP map (128x128
     from the 256 -> 16384 fc) is resized to the 138x138 feature map and multiplies it (generator_inject.py:110-127); the

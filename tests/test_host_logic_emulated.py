@@ -910,3 +910,52 @@ def test_three_term_split_planes_follow_the_weights(emu, monkeypatch):
     assert not any(p == 3 for p, _ in seen_off["conv"]) and not any(p == 3 for p, _ in seen_off["wgrad"]) and not any(seen_off["gemm"])
     assert emu.calls.count("split3") == n_split3, "OPT.split3 = False still writes planes"
     close(outs_off[0]["loss_G"], outs[0]["loss_G"], 1e-5, "split tiles on / off")
+
+
+def test_paired_sub_pixel_phases_keep_the_step(emu, monkeypatch):
+    """nirgan_conv_desc.out_span = 2 through the engine (ngf = 64: ConvTranspose2d(128, 64, 3, s2) forward and the data gradient of
+    Conv2d(64, 128, 3, s2) as two problems of 128 columns over the union of two phases' taps, with the instance-norm partial sums and the
+    fused first backward pass in per-channel records): same losses and gradients as the four-phase launches (OPT.pair_phases = False)
+    and as the oracle."""
+    from emu_backend import obj
+    from model import networks
+    from nirgan_hip.options import OPT
+    from nirgan_hip.trainer import Pix2PixTrainer
+
+    def run(pair):
+        monkeypatch.setattr(OPT, "pair_phases", pair)
+        monkeypatch.setattr(OPT, "epilogue_min_pixels", 0)
+        torch.manual_seed(11)
+        netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02)
+        netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
+        G0 = {k: v.detach().clone() for k, v in netG.state_dict().items()}
+        D0 = {k: v.detach().clone() for k, v in netD.state_dict().items()}
+        g = torch.Generator().manual_seed(12)
+        rgb, nir = torch.rand(1, 3, 32, 32, generator=g), torch.rand(1, 1, 32, 32, generator=g)
+        seen = []
+        orig = emu.nirgan_conv_igemm_group
+
+        def spy(descs, n, stream=None):
+            seen.append([(descs[i].contents.out_span, descs[i].contents.N, descs[i].contents.ntaps, bool(descs[i].contents.stats_ws),
+                          bool(descs[i].contents.fuse_y), descs[i].contents.precision) for i in range(n)])
+            return orig(descs, n, stream)
+        monkeypatch.setattr(emu, "nirgan_conv_igemm_group", spy)
+        tr = Pix2PixTrainer(netG, netD, n_blocks=6)
+        out = tr.step(rgb, nir).as_dict()
+        return out, tr.flatG.grad.clone(), tr.flatD.grad.clone(), tr.pred.clone(), seen, (G0, D0, rgb, nir)
+
+    out, gG, gD, pred, seen, (G0, D0, rgb, nir) = run(True)
+    pairs = [grp for grp in seen if any(s == 2 for s, *_ in grp)]
+    assert len(pairs) >= 2, seen
+    for grp in pairs:
+        assert [(s, n, t, p) for s, n, t, _, _, p in grp] == [(2, 128, 2, 3), (2, 128, 4, 3)], grp
+    assert any(all(st for _, _, _, st, _, _ in grp) for grp in pairs), "the forward pair leaves the instance-norm partial sums"
+    assert any(all(fy for _, _, _, _, fy, _ in grp) for grp in pairs), "the data-gradient pair takes the consumer's first backward pass"
+    out4, gG4, gD4, pred4, seen4, _ = run(False)
+    assert not any(s == 2 for grp in seen4 for s, *_ in grp)
+    close(pred, pred4, 1e-5, "prediction, paired against four phases")
+    for k in out:
+        close(out[k], out4[k], 1e-5, k)
+    assert ((gG - gG4).norm() / gG4.norm()).item() < 1e-5 and ((gD - gD4).norm() / gD4.norm()).item() < 1e-5
+    o = O.OracleTrainer(G0, D0, 6).step(rgb, nir)
+    close(out["loss_G"], o["loss_G"], 1e-5, "loss_G against the oracle")
