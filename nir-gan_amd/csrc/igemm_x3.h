@@ -367,6 +367,10 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
             }
         }
         constexpr int LPR = CW / 4, RPP = 64 / LPR;         // lanes per row (4 channels each), rows per pass
+        // staging rows are CW floats = a whole number of bank rounds: the four 16-lane groups of an accumulator store (rows 4 apart,
+        // same columns) would hit the same banks -- 16-column block b of row r is stored at block b ^ ((r >> 2) & SWM)
+        constexpr int SWM = CW / 16 - 1;
+        const int sw_wr = ((lane >> 4) & SWM) << 4;
         float* const stg = reinterpret_cast<float*>(wave < 6 ? sA1 + wave * 8192 : sB1 + (wave - 6) * 8192);
         const bool fused = f_y != nullptr;
         const float fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
@@ -398,7 +402,7 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) stg[(q * 16 + (lane >> 4) * 4 + r) * CW + nt * 16 + (lane & 15)] = acc[h * 2 + q][nt][r];
+                        for (int r = 0; r < 4; ++r) stg[(q * 16 + (lane >> 4) * 4 + r) * CW + ((nt * 16 + (lane & 15)) ^ sw_wr)] = acc[h * 2 + q][nt][r];
                 // the half's y values (fused first pass) are fetched BEFORE its stores: vmcnt counts loads and stores in one order, so a
                 // load issued behind a store is not "done" before that store is acknowledged -- a y load per pass behind the previous
                 // pass's store sat out a store round trip sixteen times per tile
@@ -418,7 +422,7 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
 #pragma unroll
                 for (int pass = 0; pass < P; ++pass) {
                     if (ok[pass]) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pass * RPP + lrow) * CW + chunk * 4);
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pass * RPP + lrow) * CW + ((chunk * 4) ^ ((((pass * RPP + lrow) >> 2) & SWM) << 4)));
                         v += bv;
 #ifdef NG_X3_DIAG
                         if (!(p.algo & 0x100))

@@ -16,14 +16,30 @@ dev = "cuda:0"
 torch.manual_seed(0)
 netG = networks.define_G(3, 1, 64, f"resnet_{nb}blocks", "instance", False, "normal", 0.02).to(dev)
 netD = networks.define_D(4, 64, "basic", 3, "instance", "normal", 0.02).to(dev)
-tr = Pix2PixTrainer(netG, netD, n_blocks=nb, padding=pad, precision=prec)
+infer = len(sys.argv) > 5 and sys.argv[5] == "infer"      # the forward-only engine of netG.eval()(x) instead of a train step
 g = torch.Generator().manual_seed(1)
 rgb = (0.02 + 0.58 * torch.rand(bs, 3, 256, 256, generator=g)).to(dev)
 nir = (0.05 + 0.75 * torch.rand(bs, 1, 256, 256, generator=g)).to(dev)
+if infer:
+    from nirgan_hip.nets import GeneratorEngine
+    from nirgan_hip.flat import FlatParams
+    flat = netG._flat() if hasattr(netG, "_flat") else FlatParams(netG)
+    flat.ensure()
+    eng = GeneratorEngine(flat.param_views(), flat.grad_views(), nb, bs, 256, 256, data_pad=pad, need_backward=False, precision=prec)
+
+    class _Step:
+        def step(self, a, b):
+            eng.forward(a, version=0)
+    tr = _Step()
+    tr.G = eng
+    plans = {"G.fwd": eng.fwd, "G.pack": eng.pack_fwd}
+else:
+    tr = Pix2PixTrainer(netG, netD, n_blocks=nb, padding=pad, precision=prec)
 for _ in range(3):
     tr.step(rgb, nir)
-plans = {"G.fwd": tr.G.fwd, "G.bwd": tr.G.bwd, "D2.fwd": tr.D2.fwd, "D2.bwd": tr.D2.bwd, "D1.fwd": tr.D1.fwd, "D1.bwdP": tr.D1.bwd_pred,
-         "G.pack": tr.G.pack_fwd, "G.packb": tr.G.pack_bwd}
+if not infer:
+    plans = {"G.fwd": tr.G.fwd, "G.bwd": tr.G.bwd, "D2.fwd": tr.D2.fwd, "D2.bwd": tr.D2.bwd, "D1.fwd": tr.D1.fwd, "D1.bwdP": tr.D1.bwd_pred,
+             "G.pack": tr.G.pack_fwd, "G.packb": tr.G.pack_bwd}
 
 
 
@@ -92,7 +108,10 @@ for pl in plans.values():
     pl.probe_idx = {i: i for i in range(len(pl.ops))}
     pl.probe_events = []
 tr.G._packed_version = tr.G._packed_bwd_version = -1   # force the pack plans once
-tr.step(rgb, nir)
+if infer:
+    eng.forward(rgb, version=1)
+else:
+    tr.step(rgb, nir)
 torch.cuda.synchronize()
 rows = []
 for pname, pl in plans.items():
