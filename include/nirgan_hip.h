@@ -564,7 +564,9 @@ typedef struct {
     const void* U3;                       /* optional (precision 3, as nirgan_conv_desc.w_x3): U as three bf16 planes h, m, l, each [planes][K][C],
                                              written by nirgan_wino6_weights_x3 next to U.  With it (and C % 32 == 0, K % 64 == 0) the plane
                                              GEMMs run on the bf16 matrix pipe as six bf16 products per fp32 product, V split inside the
-                                             kernel: fp32-equivalent results.  nirgan_wino6_gemm_wgrad_pair then runs its two halves as two
+                                             kernel: fp32-equivalent results.  U itself may then be NULL (nirgan_wino6_weights_x3 with U = NULL
+                                             writes the planes only: 6 instead of 10 bytes per transformed weight); a launch the split tile
+                                             does not take fails without U.  nirgan_wino6_gemm_wgrad_pair then runs its two halves as two
                                              launches (the weight-gradient planes take nirgan_wgrad_desc.precision = 3 on their own). */
 } nirgan_wino6_desc;
 #define NIRGAN_W6_ONE_TILE 1
@@ -581,7 +583,8 @@ int64_t nirgan_wino6_tiles(int B, int H, int W);                   /* T of the 4
 int64_t nirgan_wino6_tiles_r(int B, int H, int W, int r);          /* T of variant r (0 / 3, 4, 6); 0 for an unknown variant */
 int nirgan_wino6_weights(const float* w, int K, int C, int transpose_flip, float* U, void* stream);   /* transpose_flip = 0: U of the forward filter, w = [K][C][3][3]; 1: U of the DATA GRADIENT's filter g'[k][c][i][j] = w[c][k][2-i][2-j] with w = [C][K][3][3] the forward weight */
 int nirgan_wino6_weights_r(const float* w, int K, int C, int r, int transpose_flip, float* U, void* stream);   /* w = [K][C][r][r], U = [(r+3)^2][K][C] */
-/* nirgan_wino6_weights_r that also leaves U as three bf16 planes (nirgan_split3's rule; U3 = 3 x (r+3)^2 x K x C bf16 elements) */
+/* nirgan_wino6_weights_r that also leaves U as three bf16 planes (nirgan_split3's rule; U3 = 3 x (r+3)^2 x K x C bf16 elements); U may be
+ * NULL: the planes only */
 int nirgan_wino6_weights_x3(const float* w, int K, int C, int r, int transpose_flip, float* U, void* U3_bf16, void* stream);
 /* all weight transforms of a step in one launch: njobs x 8 int64 {w, U, K, C, transpose_flip, first_block, r, U3 (or 0)} in device memory,
  * first_block = running sum of ceil(K*C/256) */

@@ -205,8 +205,10 @@ __device__ __forceinline__ void wino6_weight_one(const W6W& p, const long long i
     for (int a = 0; a < N; ++a) {
         float o[N];
         W6<V>::g(t[a], o);
+        if (p.U != nullptr) {
 #pragma unroll
-        for (int b = 0; b < N; ++b) U[(a * N + b) * plane] = o[b];
+            for (int b = 0; b < N; ++b) U[(a * N + b) * plane] = o[b];
+        }
         if (p.U3 != nullptr) {
             // the same value as three bf16 terms h + m + l (nirgan_split3's rule) for the three-term split plane GEMMs: planes N*N*K*C apart
             unsigned short* U3 = p.U3 + size_t(k) * p.C + c;
@@ -1310,7 +1312,7 @@ extern "C" int nirgan_wino6_weights_x3(const float* w, int K, int C, int r, int 
 }
 static int w6_weights_impl(const float* w, int K, int C, int r, int transpose_flip, float* U, void* U3, void* stream) {
     r = w6_r(r);
-    NG_REQUIRE(w && U && K > 0 && C > 0, "wino6_weights: bad arguments");
+    NG_REQUIRE(w && (U || U3) && K > 0 && C > 0, "wino6_weights: bad arguments");        // (U may be omitted when only the planes are wanted)
     NG_REQUIRE(w6_known(r), "wino6_weights: variant %d (3, 4 or 6)", r);
     W6W p{w, U, K, C, transpose_flip ? 1 : 0, static_cast<unsigned short*>(U3)};
     const long long n = (long long)K * C;
@@ -1435,7 +1437,7 @@ extern "C" int nirgan_wino6_dy(const nirgan_wino_dy_desc* d, void* stream) {
 
 // validation + the 32-k form's parameters (one plane as a 1x1 'convolution' over a [1][T] image of C-channel pixels: the direct tile's descriptor)
 static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
-    NG_REQUIRE(d && d->U && d->V && d->M && d->zero_page, "wino6_gemm: null pointer");
+    NG_REQUIRE(d && (d->U || d->U3) && d->V && d->M && d->zero_page, "wino6_gemm: null pointer");
     const int v = w6_r(d->r), np = w6_np(v);
     NG_REQUIRE(w6_known(v), "wino6_gemm: variant %d (3, 4 or 6)", v);
     NG_REQUIRE(d->B > 0 && d->H > 1 && d->W > 1 && d->C > 0 && d->C % 4 == 0 && d->K > 64 && d->K % 4 == 0, "wino6_gemm: C %% 4 == 0, K > 64, K %% 4 == 0 (C=%d K=%d)", d->C, d->K);
@@ -1445,7 +1447,9 @@ static int w6_gemm_params(const nirgan_wino6_desc* d, W6Gemm& g, long long& T) {
     nirgan_conv_desc c = {};
     c.in = d->V; c.in_elems = T * d->C; c.in_hp = 1; c.in_wp = int(T); c.in_cs = d->C; c.run = d->C; c.in_stride = 1;
     c.ntaps = 1;
-    c.w = d->U; c.w_elems = (long long)d->K * d->C; c.bias = nullptr;
+    // (U may be omitted when its three bf16 planes are given and the split tile takes the launch -- checked by the launchers; the
+    // planes' address stands in for the descriptor check)
+    c.w = d->U ? d->U : static_cast<const float*>(d->U3); c.w_elems = (long long)d->K * d->C; c.bias = nullptr;
     c.out = d->M; c.out_elems = T * d->K; c.out_hp = 1; c.out_wp = int(T); c.out_cs = d->K; c.out_stride = 1;
     c.B = 1; c.OH = 1; c.OW = int(T); c.N = d->K; c.zero_page = d->zero_page;
     const int rc = ng::build_conv_params(&c, g.p);
@@ -1534,6 +1538,7 @@ extern "C" int nirgan_wino6_gemm_wgrad_pair(const nirgan_wino6_desc* d, const ni
         rc = nirgan_wino6_gemm(d, stream);
         return rc != NIRGAN_OK ? rc : nirgan_wgrad_igemm(w, stream);
     }
+    NG_REQUIRE(d->U != nullptr, "wino6_gemm_wgrad_pair: U is required unless the three-term split tile takes the launch");
     const int wgrad_blocks = wp.ntiles_n * wp.ntiles_k * wp.nsplit * wp.nplanes;
     if (w6_gemm_choice(d, true) == W6_PERSIST32) {
         NG_REQUIRE(ng_aligned16(d->U) && ng_aligned16(d->V) && ng_aligned16(d->M) && ng_aligned16(d->zero_page), "wino6_gemm_wgrad_pair: pointers must be 16-byte aligned");
@@ -1568,6 +1573,7 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
         return ng::ng_launch_conv_x3(&g.p, 1, d->K % 128 == 0 ? 128 : 64, w6_np(w6_r(d->r)), g.in_plane, g.w_plane, g.out_plane,
                                      static_cast<hipStream_t>(stream), "wino6_gemm (three-term split tile)");
     }
+    NG_REQUIRE(d->U != nullptr, "wino6_gemm: U is required unless the three-term split tile takes the launch (U3, C %% 32 == 0, K %% 64 == 0)");
     if (d->algo == NIRGAN_W6_TILE256 && d->C % 32 == 0 && d->K % 256 == 0 && g.p.off32) {
         const int per_plane = ((g.p.M + 255) >> 8) * (g.p.N >> 8), total = w6_np(w6_r(d->r)) * per_plane;
         hipLaunchKernelGGL(wino6_gemm256_kernel, dim3(total < 256 ? total : 256), dim3(512), 0, static_cast<hipStream_t>(stream), g, per_plane, total);

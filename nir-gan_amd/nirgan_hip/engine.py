@@ -192,7 +192,7 @@ class Plan:
             return
         rows, first = [], 0
         for w, K, Cc, r, flip, U, U3 in jobs:
-            rows.append([w, U, K, Cc, flip, first, r, U3])
+            rows.append([w, U or 0, K, Cc, flip, first, r, U3])
             first += (K * Cc + 255) // 256
         table = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
         self.ctx.keep.append(table)
@@ -529,16 +529,17 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     v = wino6_variant(r)
     T = _w6_tiles(B, H, W, v)
     NP = _w6_geo(v)[1]
-    U = ctx.zeros(NP * cout * cin)
-    ctx.keep.append(U)
-    U3 = None
+    U = U3 = None
     if ctx.precision == 0 and OPT.split3 and OPT.split3_wino and cin % 32 == 0 and cout % 64 == 0:
-        # precision 3 for the plane GEMMs (csrc/igemm_x3.h): U once more as three bf16 planes, written by the same weight transform
+        # precision 3 for the plane GEMMs (csrc/igemm_x3.h): U as three bf16 planes ONLY -- the split tile reads nothing else and the
+        # transform-domain weight gradient needs no U (6 instead of 10 bytes per transformed weight and step)
         U3 = torch.zeros(3 * NP * cout * cin, dtype=torch.bfloat16, device=ctx.device)
         ctx.bytes += U3.numel() * 2
         ctx.keep.append(U3)
-        pack.add("nirgan_wino6_weights_x3", weight.data_ptr(), cout, cin, v, 1 if flip else 0, U.data_ptr(), U3.data_ptr())
+        pack.add("nirgan_wino6_weights_x3", weight.data_ptr(), cout, cin, v, 1 if flip else 0, None, U3.data_ptr())
     else:
+        U = ctx.zeros(NP * cout * cin)
+        ctx.keep.append(U)
         pack.add("nirgan_wino6_weights_r", weight.data_ptr(), cout, cin, v, 1 if flip else 0, U.data_ptr())
     for name in ("wino6_pool_v", "wino6_pool_m"):
         if not hasattr(ctx, name):
@@ -553,7 +554,7 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     d.r = v
     d.x, d.x_hp, d.x_wp = x.ptr, x.hp, x.wp
     d.B, d.H, d.W, d.C, d.K = B, H, W, cin, cout
-    d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = U.data_ptr(), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
+    d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = _ptr(U), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
     d.zero_page = ctx.zero_page.data_ptr()
     d.algo = OPT.w6_gemm_algo
     d.U3 = _ptr(U3)

@@ -10,9 +10,12 @@ from model import networks
 from nirgan_hip.trainer import Pix2PixTrainer
 from nirgan_hip.options import OPT
 DEV = "cuda:0"
+WINO = sys.argv[1] if len(sys.argv) > 1 else "f6"          # OPT.winograd: f6 | f4 | off
 for seed in (7, 17, 27):
-    for conf in ({"split3": False}, {"split3": True, "split3_wino": False}, {"split3": True, "split3_wino": True}):
+    for conf in ({"split3": False}, {"split3": True, "split3_wino": False, "pair_phases": False}, {"split3": True, "split3_wino": True, "pair_phases": False},
+                 {"split3": True, "split3_wino": True, "pair_phases": True}):
         OPT.reset()
+        OPT.winograd = WINO
         for k, v in conf.items():
             setattr(OPT, k, v)
         torch.manual_seed(seed)
@@ -33,4 +36,4 @@ for seed in (7, 17, 27):
                 errs.append(((gG[k].cpu() - v).norm().item() / max(v.norm().item(), 1e-20), k))
         errs.sort(reverse=True)
         pe = (tr.G.pred.cpu() - ref.last["pred"]).abs().max().item() / ref.last["pred"].abs().max().item()
-        print(f"seed {seed} {conf}: pred err {pe:.2e}; worst rel L2: " + ", ".join(f"{e:.2e} {k}" for e, k in errs[:3]), flush=True)
+        print(f"winograd={WINO} seed {seed} {conf}: pred err {pe:.2e}; worst rel L2: " + ", ".join(f"{e:.2e} {k}" for e, k in errs[:3]), flush=True)

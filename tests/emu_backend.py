@@ -460,16 +460,24 @@ class EmuBackend:
         if r not in self._W6:
             return self._fail("wino6_weights: filter size")
         Gm = self._W6[r][0]
+        variant = r
         r, _, n = self._geo6(r)
         if flip:
             g = arr(w, K * Cc * r * r).reshape(Cc, K, r, r).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1]
         else:
             g = arr(w, K * Cc * r * r).reshape(K, Cc, r, r).astype(np.float64)
-        u = np.einsum("ai,kcij,bj->abkc", Gm, g, Gm)
-        arr(U, n * n * K * Cc)[:] = u.reshape(-1).astype(np.float32)
+        u = np.einsum("ai,kcij,bj->abkc", Gm, g, Gm).reshape(-1).astype(np.float32)
+        if not U and not U3:
+            return self._fail("wino6_weights: neither U nor its planes")
+        if U:
+            arr(U, n * n * K * Cc)[:] = u
         if U3:            # the same values as three bf16 planes (nirgan_split3's rule), for the three-term split plane GEMMs
-            for t, v in enumerate(split3_planes(arr(U, n * n * K * Cc))):
+            for t, v in enumerate(split3_planes(u)):
                 arr16(int(U3) + 2 * t * n * n * K * Cc, n * n * K * Cc)[:] = v
+            # (U may be omitted: the plane GEMM then checks its planes against a fresh transform of THESE weights)
+            if not hasattr(self, "_u3_src"):
+                self._u3_src = {}
+            self._u3_src[int(U3)] = (int(w), K, Cc, variant, int(flip))
         return 0
 
     def nirgan_wino6_weights_x3(self, w, K, Cc, r, flip, U, U3, stream=None):
@@ -539,16 +547,31 @@ class EmuBackend:
         if d.K <= 64 or d.K % 4 or d.C % 4 or d.V_elems < nplanes * T * d.C or d.M_elems < nplanes * T * d.K:
             return self._fail("wino6_gemm: bad geometry / workspace")
         V = arr(d.V, nplanes * T * d.C).reshape(nplanes, T, d.C).astype(np.float64)
-        U = arr(d.U, nplanes * d.K * d.C).reshape(nplanes, d.K, d.C).astype(np.float64)
         if d.U3 and d.C % 32 == 0 and d.K % 64 == 0:
-            # precision 3 (csrc/igemm_x3.h): the planes must be the three-term split of U; the products follow the six-product rule
+            # precision 3 (csrc/igemm_x3.h): the planes must be the three-term split of U -- of the U given, or (U omitted) of a fresh
+            # transform of the weights the planes were written from; the products follow the six-product rule
             n = nplanes * d.K * d.C
             pl = [(arr16(int(d.U3) + 2 * t * n, n).astype(np.uint32) << 16).view(np.float32).astype(np.float64) for t in range(3)]
+            if d.U:
+                U = arr(d.U, n).reshape(nplanes, d.K, d.C).astype(np.float64)
+            else:
+                src = getattr(self, "_u3_src", {}).get(int(d.U3))
+                if src is None:
+                    return self._fail("wino6_gemm: U3 planes nobody wrote")
+                w_, K_, C_, r_, flip_ = src
+                Gm = self._W6[r_][0]
+                rr = self._geo6(r_)[0]
+                gw = arr(w_, K_ * C_ * rr * rr)
+                gw = gw.reshape(C_, K_, rr, rr).astype(np.float64).transpose(1, 0, 2, 3)[:, :, ::-1, ::-1] if flip_ else gw.reshape(K_, C_, rr, rr).astype(np.float64)
+                U = np.einsum("ai,kcij,bj->abkc", Gm, gw, Gm).astype(np.float32).astype(np.float64).reshape(nplanes, d.K, d.C)
             if not np.array_equal((pl[0] + pl[1] + pl[2]).reshape(U.shape), U):
                 return self._fail("wino6_gemm: the U3 planes are not the three-term split of U (stale planes?)")
             Mo = np.stack([contract(V[f].astype(np.float32), np.ascontiguousarray(U[f].T).astype(np.float32), 3) for f in range(nplanes)])
             arr(d.M, nplanes * T * d.K)[:] = Mo.reshape(-1).astype(np.float32)
             return 0
+        if not d.U:
+            return self._fail("wino6_gemm: U is required unless the split tile takes the launch")
+        U = arr(d.U, nplanes * d.K * d.C).reshape(nplanes, d.K, d.C).astype(np.float64)
         arr(d.M, nplanes * T * d.K)[:] = np.einsum("ftc,fkc->ftk", V, U).reshape(-1).astype(np.float32)
         return 0
 

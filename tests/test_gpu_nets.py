@@ -165,8 +165,10 @@ def test_medium_width_nets_take_the_winograd_paths(monkeypatch, variant):
     # for the Winograd layers too) the worst tensor lands anywhere between 1.5e-5 and 8.2e-3 with the prediction at 2-3e-5 every time,
     # the exact-fp32 setting itself at 5.1e-3 / 6.3e-3 on two of the seeds (scripts/diag_x3_medium.py, profiles/r05_medium_width_kink_noise.txt);
     # the bound that does not depend on the flips is the forced-kink one of test_fullsize_fused_step_against_oracle (3e-4, unchanged)
-    l2 = 1e-2 if variant == "F(6x6,3x3)" else 1e-3
-    mx = 1e-1 if variant == "F(6x6,3x3)" else 1e-2          # (one flipped activation is a local error of a few per cent of the tensor's maximum: 4.5e-2 seen)
+    # The same holds for F(4x4,3x3) (profiles/r05_medium_width_kink_noise_f4.txt: seed 17 in exact fp32 3.0e-3, seed 7 with the split tiles
+    # 5.4e-3, seed 27 6e-6 in every setting), so the three variants share the bound; "direct" has no Winograd noise and keeps 1e-3.
+    l2 = 1e-3 if variant == "direct" else 1e-2
+    mx = 1e-2 if variant == "direct" else 1e-1          # (one flipped activation is a local error of a few per cent of the tensor's maximum: 4.5e-2 seen)
     for k, v in ref.last["grads_D"].items():
         if k not in O.shadowed_bias_keys("D"):
             grad_close(gD[k], v, "gD " + k, l2=l2, mx=mx)
@@ -1233,8 +1235,8 @@ def test_instance_norm_backward_first_pass_inside_the_conv_epilogues(monkeypatch
             for name, a in plan.ops:
                 if name == "nirgan_conv_igemm" and a[0]._obj.fuse_y:
                     n += 1
-                if name == "nirgan_conv_igemm_group":
-                    n += sum(1 for i in range(a[1]) if a[0][i].contents.fuse_y)
+                if name == "nirgan_conv_igemm_group":       # (a paired problem -- out_span = 2 -- stands for two sub-pixel phases)
+                    n += sum(max(1, a[0][i].contents.out_span) for i in range(a[1]) if a[0][i].contents.fuse_y)
         return tr.G.pred.clone(), tr.flatG.grad.clone(), tr.flatD.grad.clone(), n
 
     p1, g1, d1, n1 = run(True)
