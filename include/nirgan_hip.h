@@ -129,7 +129,9 @@ typedef struct {
      * rows serve both phases and the launch's two problems (output-row parities) balance over the persistent workgroups.  bias holds N
      * values (the layer's C twice).  The instance-norm partial sums and the fused backward sums keep their per-channel records: a chunk
      * of rows leaves two records (pixel parity 0, then 1) of C columns -- stats_chunk0 + 2 OH OW / 64 <= stats_chunks, stats_ws and
-     * fuse_part sized with C; fuse_mean / fuse_rstd / fuse_y are those of the C-channel tensor. */
+     * fuse_part sized with C; fuse_mean / fuse_rstd / fuse_y are those of the C-channel tensor.
+     * Second form, out_cs == N: the caller already describes the output in pixel pairs (out_wp = W / 2, any out_stride; no fuse_y) --
+     * the generator's first convolution with two adjacent outputs per GEMM row; out_span then only shapes the statistics' records. */
     int out_span;
 } nirgan_conv_desc;
 #define NIRGAN_CONV_TILE128 1

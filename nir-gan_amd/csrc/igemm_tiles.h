@@ -1295,8 +1295,12 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     NG_REQUIRE(d->out_elems >= int64_t(d->B) * d->out_hp * d->out_wp * d->out_cs, "conv: out_elems too small");
     NG_REQUIRE(d->w_elems >= int64_t(d->N) * d->ntaps * d->run, "conv: w_elems too small");
     const int span = d->out_span > 1 ? d->out_span : 1;
-    NG_REQUIRE(span == 1 || (span == 2 && d->precision == 3 && d->N % 8 == 0 && d->out_cs == d->N / 2 && d->out_stride >= 2 && !d->out_bf16 && !d->fuse_y_bf16 && d->ksplit <= 1 && d->w_x3 != nullptr),
-               "conv: out_span=%d needs precision 3 with its weight planes, out_cs == N / 2, out_stride >= 2, fp32 tensors and no split-K", d->out_span);
+    // (out_cs == N with out_span = 2: the caller describes the output in pixel PAIRS already -- one 'pixel' of N channels per GEMM row, any
+    // stride; only the per-channel records of the statistics follow out_span then)
+    const bool span_view = span == 2 && d->out_cs == d->N;
+    NG_REQUIRE(span == 1 || (span == 2 && d->precision == 3 && d->N % 8 == 0 && (span_view ? d->fuse_y == nullptr : (d->out_cs == d->N / 2 && d->out_stride >= 2))
+                             && !d->out_bf16 && !d->fuse_y_bf16 && d->ksplit <= 1 && d->w_x3 != nullptr),
+               "conv: out_span=%d needs precision 3 with its weight planes, out_cs == N / 2 and out_stride >= 2 (or out_cs == N), fp32 tensors and no split-K", d->out_span);
     const int ch = d->N / span;
     NG_REQUIRE(ch <= d->out_cs, "conv: %d channels per pixel exceed out_cs=%d", ch, d->out_cs);
     int dh0 = d->tap_dh[0], dh1 = d->tap_dh[0], dw0 = d->tap_dw[0], dw1 = d->tap_dw[0];
@@ -1306,7 +1310,7 @@ inline int build_conv_params(const nirgan_conv_desc* d, ConvParams& p) {
     }
     NG_REQUIRE(d->in_oh + dh0 >= 0 && (d->OH - 1) * d->in_stride + d->in_oh + dh1 < d->in_hp, "conv: input rows out of range");
     NG_REQUIRE(d->in_ow + dw0 >= 0 && int64_t((d->OW - 1) * d->in_stride + d->in_ow + dw1) * d->in_cs + d->run <= int64_t(d->in_wp) * d->in_cs, "conv: input columns out of range");
-    NG_REQUIRE(d->out_oh >= 0 && (d->OH - 1) * d->out_stride + d->out_oh < d->out_hp && d->out_ow >= 0 && (d->OW - 1) * d->out_stride + d->out_ow + span - 1 < d->out_wp, "conv: output window out of range");
+    NG_REQUIRE(d->out_oh >= 0 && (d->OH - 1) * d->out_stride + d->out_oh < d->out_hp && d->out_ow >= 0 && (d->OW - 1) * d->out_stride + d->out_ow + (span_view ? 0 : span - 1) < d->out_wp, "conv: output window out of range");
 
     p.in = d->in; p.w = d->w; p.bias = d->bias; p.out = d->out; p.zero = d->zero_page;
     p.in_cs = d->in_cs; p.in_row = d->in_wp * d->in_cs; p.in_img = d->in_hp * p.in_row;

@@ -344,12 +344,14 @@ def choose_ksplit(tiles: int, nk: int) -> int:
 
 
 def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bias, out: Halo, *, N, OH, OW,
-              in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None, allow_split=True, out_span=1):
+              in_stride=1, in_oh=0, in_ow=0, out_stride=1, out_oh=0, out_ow=0, in_hw=None, allow_split=True, out_span=1,
+              in_cs=None, out_hw=None, out_cs=None):
+    """in_hw / in_cs, out_hw / out_cs: another VIEW of the same dense buffers (two adjacent pixels as one pixel of twice the channels)."""
     d = L.ConvDesc()
     d.inp, d.in_elems = inp.operand_ptr(d), inp.elems
     if inp.t16 is not None and w.dtype == torch.bfloat16 and taps.run % 8 == 0:
         d.inp, d.in_bf16 = inp.t16.data_ptr(), 1          # both operands as stored (bf16 twin of the producer, bf16 weights)
-    d.in_hp, d.in_wp, d.in_cs = (in_hw or (inp.hp, inp.wp)) + (inp.C,)
+    d.in_hp, d.in_wp, d.in_cs = (in_hw or (inp.hp, inp.wp)) + (in_cs or inp.C,)
     d.run, d.in_stride, d.in_oh, d.in_ow = taps.run, in_stride, in_oh, in_ow
     _set_taps(d, taps.dh, taps.dw)
     d.w, d.w_elems, d.bias = w.data_ptr(), w.numel(), _ptr(bias)
@@ -360,7 +362,7 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
     d.out, d.out_elems = (out.ptr_any() if d.out_bf16 else out.ptr), out.elems
     if d.out_bf16:
         allow_split = False          # a bf16 output is stored by the tile's own epilogue (no split-K workspace pass)
-    d.out_hp, d.out_wp, d.out_cs = out.hp, out.wp, out.C
+    d.out_hp, d.out_wp, d.out_cs = (out_hw or (out.hp, out.wp)) + (out_cs or out.C,)
     d.out_stride, d.out_oh, d.out_ow = out_stride, out_oh, out_ow
     d.B, d.OH, d.OW, d.N = inp.B, OH, OW, N
     d.zero_page = ctx.zero_page.data_ptr()
@@ -376,7 +378,7 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
         allow_split = False
     if out_span > 1:
         # two adjacent output pixels per GEMM row (the split tile only): N = 2 C columns into a dense C-channel tensor
-        assert d.precision == 3 and out.C * out_span == N and out_stride >= out_span, "out_span needs the three-term split tile and a dense output"
+        assert d.precision == 3 and out.C * out_span == N and (out_stride >= out_span or d.out_cs == N), "out_span needs the three-term split tile and a dense output"
         d.out_span = out_span
     ctx.keep.append(d)
     if plan is not None:
@@ -969,6 +971,18 @@ class ConvIN:
             if self.norm:
                 pre = attach_conv_stats(ctx, [cd], self.bias)
             self._y_fallback(pre, [cd])
+        elif (self.kind == "rowpacked" and s == 1 and ctx.precision == 0 and OPT.split3 and OPT.pair_pixels and self.cout == 64
+              and (k + 1) * inp.C == 32 and self.OW % 2 == 0 and inp.wp % 2 == 0 and (inp.pad - p) % 2 == 0 and not self.y.is16):
+            # Conv2d(3, 64, 7) on the split tile: TWO adjacent output pixels per GEMM row -- 128 columns, one tap per kernel row over the
+            # 8 pixels x 4 channels both windows cover (a run of 32), the buffers viewed as pixel pairs (measured: DESIGN 3.1)
+            cs = inp.C
+            w = eng.weights.packed_pair(pack, self.weight, [G.conv_rowpacked_pair_pack(self.cout, self.cin, k, cs, q) for q in (0, 1)])
+            b2 = eng.weights.doubled(pack, self.bias) if self.bias is not None else None
+            cd = emit_conv(plan, ctx, inp, G.Taps(list(range(k)), [0] * k, (k + 1) * cs), w, b2, self.y, N=2 * self.cout, OH=self.OH, OW=self.OW // 2,
+                           in_oh=inp.pad - p, in_ow=(inp.pad - p) // 2, in_hw=(inp.hp, inp.wp // 2), in_cs=2 * cs,
+                           out_hw=(self.y.hp, self.y.wp // 2), out_cs=2 * self.cout, out_span=2)
+            if self.norm:
+                pre = attach_conv_stats(ctx, [cd], self.bias)
         elif self.kind == "rowpacked":
             taps = G.conv_rowpacked_taps(k, inp.C)
             w = eng.weights.packed(pack, self.weight, G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C))

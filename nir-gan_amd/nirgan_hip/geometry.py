@@ -69,6 +69,18 @@ def conv_rowpacked_pack(cout: int, cin: int, k: int, cs: int) -> PackSpec:
     return PackSpec(cout, k * k * cs, cin * k * k, idx.reshape(-1), ("cr", cout, cin, k, cs), k * cs)
 
 
+def conv_rowpacked_pair_pack(cout: int, cin: int, k: int, cs: int, q: int) -> PackSpec:
+    """Row-packed first convolution with TWO adjacent output pixels per GEMM row (stride 1): a tap is one kernel row over the k + 1
+    pixels both windows cover; pixel q of the pair sees W[co][c][kh][kw] at window pixel kw + q.
+    packed[co][kh*((k+1)*cs) + px*cs + c] = W[co][c][kh][px - q] for 0 <= px - q < k and c < cin, else 0."""
+    idx = np.full((k, k + 1, cs), -1, dtype=np.int32)
+    for kh in range(k):
+        for kw in range(k):
+            for c in range(cin):
+                idx[kh, kw + q, c] = c * k * k + kh * k + kw
+    return PackSpec(cout, k * (k + 1) * cs, cin * k * k, idx.reshape(-1), ("crp", cout, cin, k, cs, q), (k + 1) * cs)
+
+
 def conv_dgrad_s1_taps(k: int, cout: int) -> Taps:
     """Full correlation over dY with a zero halo of k-1: dXp[a] = sum_kh Z[a + (k-1-kh)] W[kh]."""
     return Taps([k - 1 - kh for kh in range(k) for _ in range(k)], [k - 1 - kw for _ in range(k) for kw in range(k)], cout)

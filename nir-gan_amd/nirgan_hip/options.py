@@ -65,6 +65,9 @@ class Options:
     # phases of 1 / 2 / 2 / 4 taps) as TWO problems of 128 columns -- the two phases of one output row side by side, over the union of
     # their taps (nirgan_conv_desc.out_span = 2) -- on the split tile instead of four 64-column problems on the exact fp32 tile (A/B)
     pair_phases: bool = True
+    # ... and the generator's first layer, Conv2d(3, 64, 7) over the 4-channel row-packed input, with two adjacent output pixels per GEMM
+    # row (128 columns, runs of 8 pixels x 4 channels = 32) on the split tile instead of 64 columns x runs of 28 on the exact fp32 tile (A/B)
+    pair_pixels: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
     endconv_direct: bool = True
 

@@ -924,6 +924,7 @@ def test_paired_sub_pixel_phases_keep_the_step(emu, monkeypatch):
 
     def run(pair):
         monkeypatch.setattr(OPT, "pair_phases", pair)
+        monkeypatch.setattr(OPT, "pair_pixels", pair)        # (the first convolution with two output pixels per GEMM row: the same descriptor field)
         monkeypatch.setattr(OPT, "epilogue_min_pixels", 0)
         torch.manual_seed(11)
         netG = networks.define_G(3, 1, 64, "resnet_6blocks", "instance", False, "normal", 0.02)
@@ -940,11 +941,22 @@ def test_paired_sub_pixel_phases_keep_the_step(emu, monkeypatch):
                           bool(descs[i].contents.fuse_y), descs[i].contents.precision) for i in range(n)])
             return orig(descs, n, stream)
         monkeypatch.setattr(emu, "nirgan_conv_igemm_group", spy)
+        orig1 = emu.nirgan_conv_igemm
+
+        def spy1(ref, stream=None):
+            d = obj(ref)
+            if d.out_span == 2 and d.out_cs == d.N:          # (the group launches come through here too: theirs have out_cs == N / 2)
+                seen.append([("first", d.N, d.ntaps, d.run, d.in_cs, d.out_cs, bool(d.stats_ws), d.precision)])
+            return orig1(ref, stream)
+        monkeypatch.setattr(emu, "nirgan_conv_igemm", spy1)
         tr = Pix2PixTrainer(netG, netD, n_blocks=6)
         out = tr.step(rgb, nir).as_dict()
         return out, tr.flatG.grad.clone(), tr.flatD.grad.clone(), tr.pred.clone(), seen, (G0, D0, rgb, nir)
 
     out, gG, gD, pred, seen, (G0, D0, rgb, nir) = run(True)
+    firsts = [grp[0] for grp in seen if grp[0][0] == "first"]
+    assert firsts and all(f == ("first", 128, 7, 32, 8, 128, True, 3) for f in firsts), firsts      # Conv2d(3, 64, 7): 128 columns, 7 taps of 32, pixel-pair views, statistics
+    seen[:] = [grp for grp in seen if grp[0][0] != "first"]
     pairs = [grp for grp in seen if any(s == 2 for s, *_ in grp)]
     assert len(pairs) >= 2, seen
     for grp in pairs:
@@ -952,7 +964,7 @@ def test_paired_sub_pixel_phases_keep_the_step(emu, monkeypatch):
     assert any(all(st for _, _, _, st, _, _ in grp) for grp in pairs), "the forward pair leaves the instance-norm partial sums"
     assert any(all(fy for _, _, _, _, fy, _ in grp) for grp in pairs), "the data-gradient pair takes the consumer's first backward pass"
     out4, gG4, gD4, pred4, seen4, _ = run(False)
-    assert not any(s == 2 for grp in seen4 for s, *_ in grp)
+    assert not any(grp[0][0] == "first" or any(s == 2 for s, *_ in grp) for grp in seen4)
     close(pred, pred4, 1e-5, "prediction, paired against four phases")
     for k in out:
         close(out[k], out4[k], 1e-5, k)
