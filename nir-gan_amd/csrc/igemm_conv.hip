@@ -123,9 +123,37 @@ int ng::ng_launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, c
     w.n = n;
     w.nplanes = nplanes > 1 ? nplanes : 1;
     w.in_plane = in_plane; w.w3_pstride = w3_pstride; w.out_plane = out_plane;
-    // two problems of equal tile counts and different K (the two output-row parities of a paired sub-pixel launch): alternate them
-    w.alternate = (n == 2 && w.nplanes == 1 && ng::conv_x3_tiles(ps[0], bn) == ng::conv_x3_tiles(ps[1], bn) && ps[0].K != ps[1].K && ps[0].K < ps[1].K) ? 1 : 0;
+    w.spread = 0;
+    for (int i = 0; i < 4; ++i) w.start[i] = 0;
     const int G = ng_cu_count_conv();
+    // problems of unequal K (sub-pixel phases of a 3 x 3 stride-2 layer: 1 / 2 / 2 / 4 taps) on a full grid: the spread walk of
+    // igemm_x3.h.  Every position gets T / G tiles of a problem anyway; the T % G left over go to consecutive positions from start[k],
+    // chosen longest problem first where the window's load so far is lowest.
+    bool unequal = false;
+    for (int i = 1; i < n; ++i) unequal = unequal || ps[i].K != ps[0].K;
+    if (n >= 2 && w.nplanes == 1 && unequal && total >= G && G <= 1024) {
+        long long load[2 * 1024 + 1];
+        for (int i = 0; i < G; ++i) load[i] = 0;
+        int order[4] = {0, 1, 2, 3};
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j)
+                if (ps[order[j]].K > ps[order[i]].K) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+        for (int oi = 0; oi < n; ++oi) {
+            const int k = order[oi];
+            const int rem = (w.first[k + 1] - w.first[k]) % G;
+            if (rem == 0) continue;
+            const long long cost = ps[k].K / 32 + 3;                 // K-tiles of a tile + its epilogue, in K-tile units
+            long long prefix[2 * 1024 + 1];
+            prefix[0] = 0;
+            for (int i = 0; i < 2 * G; ++i) prefix[i + 1] = prefix[i] + load[i % G];
+            int best = 0;
+            for (int s0 = 1; s0 < G; ++s0)
+                if (prefix[s0 + rem] - prefix[s0] < prefix[best + rem] - prefix[best]) best = s0;
+            for (int t = 0; t < rem; ++t) load[(best + t) % G] += cost;
+            w.start[k] = best;
+        }
+        w.spread = 1;
+    }
     const dim3 grid(total < G ? total : G);
     if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, w);
     else hipLaunchKernelGGL(conv_x3_kernel<64>, grid, dim3(512), 0, st, w);

@@ -77,8 +77,11 @@ struct X3Work {
     int n;
     int nplanes;               // > 1: p[0] only; item = plane * tiles + tile
     long long in_plane, w3_pstride, out_plane;
-    int alternate;             // two problems of equal tile counts and unequal K (the output-row parities of nirgan_conv_desc.out_span = 2):
-                               // rounds of gridDim.x items alternate between them -- every workgroup gets the long and the short K loop
+    int spread;                // problems of UNEQUAL K in one launch (sub-pixel phases with 1 / 2 / 2 / 4 taps): tile t of problem k belongs to
+    int start[4];              // the workgroup at walk position (start[k] + t) mod gridDim.x, so every workgroup gets its share of every
+                               // problem (host: ng_launch_conv_x3 places the problems longest first where the load is lowest).  Without
+                               // it the items are walked problem by problem, XCD-contiguous: the XCDs that got the 4-tap phase ran 295 us
+                               // of a 316 us launch whose balanced time is 177 (ConvTranspose2d(256, 128, 3, s2) at bs 16)
 };
 
 // PERSISTENT workgroups, one per CU: a workgroup walks items b, b + G, ... (XCD-contiguous through ng_xcd_remap).  What one tile per
@@ -123,19 +126,25 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
         long long w3_plane;
     };
     auto locate = [&](const int item, Item& t) {
-        int k = 0, id;
-        if (wp->alternate) {
-            // (no XCD walk here: neighbouring row tiles share one input row in four, the weights sit in every L2)
-            const int per = wp->first[1], full = (per / G) * G;           // tiles of each problem; those in whole rounds
-            if (item < 2 * full) {
-                const int j = item / G;
-                k = (j & 1) ^ 1;                                          // problem 1 (the longer K loop) first
-                id = (j >> 1) * G + (item - j * G);
-            } else {
-                const int r = item - 2 * full, left = per - full;
-                k = r < left ? 1 : 0;
-                id = full + (r < left ? r : r - left);
+        int k = 0, id = 0;
+        if (wp->spread) {
+            // this workgroup's m-th item (item = blockIdx.x + m G): walk the problems, count the tiles of each that sit at this position.
+            // Positions are XCD-contiguous (ng_xcd_remap of the workgroup id): neighbouring row tiles, and ALL phases of one row tile,
+            // are fetched through one L2
+            int m = (item - int(blockIdx.x)) / G;
+            const int pos = ng_xcd_remap(int(blockIdx.x), G);
+            k = -1;
+            for (int q = 0; q < wp->n; ++q) {
+                const int Tq = wp->first[q + 1] - wp->first[q];
+                int t0 = pos - wp->start[q];
+                t0 += t0 < 0 ? G : 0;
+                const int cnt = t0 < Tq ? (Tq - 1 - t0) / G + 1 : 0;
+                if (k < 0) {
+                    if (m < cnt) { k = q; id = t0 + m * G; }
+                    else m -= cnt;
+                }
             }
+            if (k < 0) { t.nk = -1; return; }                             // no such item: this workgroup is done
         } else {
             const int id0 = ng_xcd_remap(item, total);
             if (id0 >= wp->first[1]) k = 1;
@@ -473,6 +482,7 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
     int item = blockIdx.x;
     if (item >= total) return;
     locate(item, L);
+    if (L.nk < 0) return;                       // (spread walk: no tile of any problem sits at this workgroup's position)
     begin();
     loadA();
     issueB(sB0);
@@ -496,10 +506,13 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
         if (k < nk) step(0, sA1, sB1, false);
         E = L;
         item += G;
-        const bool more = item < total;
+        bool more = wp->spread ? true : item < total;      // (spread walk: locate says when this workgroup's items are through)
         __syncthreads();                        // every wave's fragment reads of the last K-tile are done: stage 0 is free
         if (more) {
             locate(item, L);
+            more = L.nk >= 0;
+        }
+        if (more) {
             begin();
             loadA();
             issueB(sB0);

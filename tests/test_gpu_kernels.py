@@ -122,7 +122,46 @@ def test_convT_phases_match_torch():
     close(y.t.permute(0, 3, 1, 2), ref, 1e-5, "convT fwd")
 
 
-@pytest.mark.parametrize("shape", [(2, 7, 6), (3, 32, 32), (1, 40, 24)])
+@pytest.mark.parametrize("shape", [(16, 36, 36), (16, 32, 32), (7, 50, 38)])
+def test_sub_pixel_phases_on_the_split_tile_spread_walk(shape):
+    """ConvTranspose2d(256, 128, 3, s2, p1, op1) as ONE persistent launch of the split tile over its four phases (1 / 2 / 2 / 4 taps):
+    the spread walk of igemm_x3.h (tile t of phase k at walk position (start[k] + t) mod 256; every workgroup gets its share of every
+    phase) with tile counts that are / are not multiples of the grid (81, 64 and 52 tiles per phase), against torch in float64."""
+    from nirgan_hip.engine import Weights, emit_conv_group
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(41)
+    tw = Twin()
+    ctx = tw.gctx
+
+    class Eng:
+        pass
+    eng = Eng()
+    eng.ctx, eng.weights = ctx, Weights(ctx)
+    Cin, Cout, k = 256, 128, 3
+    xg, xc = tw.halo(B, H, W, Cin, 1, gen, fill_halo=False)
+    wg, wc = tw.tensor(Cin, Cout, k, k, gen=gen, scale=0.05)
+    bg, bc = tw.tensor(Cout, gen=gen, scale=1.0)
+    y = Halo(ctx, B, 2 * H, 2 * W, Cout, 0)
+    plan, pack = Plan(ctx), Plan(ctx)
+    descs = []
+    for ph in G.convT_fwd_phases(H, W, k, 1):
+        w = eng.weights.packed(pack, wg, G.convT_fwd_pack(Cin, Cout, k, ph.taps_hw))
+        descs.append(emit_conv(None, ctx, xg, G.Taps(ph.dh, ph.dw, Cin), w, bg, y, N=Cout, OH=ph.n_h, OW=ph.n_w,
+                               in_oh=ph.in_oh, in_ow=ph.in_ow, out_stride=2, out_oh=ph.out_oh, out_ow=ph.out_ow))
+    assert all(d.precision == 3 for d in descs) and sorted(d.ntaps for d in descs) == [1, 2, 2, 4]
+    assert sum(-(-(d.B * d.OH * d.OW) // 256) for d in descs) >= 200
+    emit_conv_group(plan, ctx, descs)
+    pack.run()
+    plan.run()
+    ref = torch.nn.functional.conv_transpose2d(xc.interior().permute(0, 3, 1, 2).double(), wc.double(), bc.double(), stride=2, padding=1, output_padding=1)
+    close(y.t.permute(0, 3, 1, 2), ref.float(), 2e-6, "four phases, spread walk")
+    first = y.t.clone()
+    for _ in range(20):                       # the walk is a fixed assignment: bitwise repeatable
+        plan.run()
+        assert torch.equal(y.t, first)
+
+
+@pytest.mark.parametrize("shape", [(2, 7, 6), (3, 32, 32), (1, 40, 24), (16, 48, 48)])
 def test_paired_phases_match_torch_float64(shape):
     """nirgan_conv_desc.out_span = 2: ConvTranspose2d(128, 64, 3, s2, p1, op1) + bias as the two paired problems of engine.emit_phase_pairs
     (128 columns = two adjacent output pixels, union of the two phases' taps, zero weight blocks) and the data gradient of
