@@ -193,6 +193,12 @@ const char* nirgan_conv_wgrad_pair_kernel_name(const nirgan_conv_desc* c, const 
 /* dst[n*dst_row_stride + map[k]] (= | +=) sum_s slabs[s][n][k]  for map[k] >= 0 */
 int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, const int32_t* map,
                        float* dst, int64_t dst_elems, int dst_row_stride, int accumulate, void* stream);
+/* The same over a BAND of the slabs' rows: dst[n*dst_row_stride + map[k]] (= | +=) sum_s slabs[s][row0 + n][k] for n < rows (slabs of
+ * N rows).  The weight gradient of the generator's first convolution, taken with two adjacent output pixels per GEMM row (its slab rows
+ * are (pixel parity, output channel)), folds its two bands into the one weight tensor with two calls, the second accumulating
+ * (model/networks.py:342 through autograd). */
+int nirgan_reduce_rows_part(const float* slabs, int nsplit, int N, int row0, int rows, int K, const int32_t* map,
+                            float* dst, int64_t dst_elems, int dst_row_stride, int accumulate, void* stream);
 
 /* The slab sums of several weight gradients in one launch (a network's layers: launch latency for up to 31 MB each otherwise).
  * jobs_device: njobs x 10 int64 in DEVICE memory: {slabs, dst, map, nsplit, N, K, dst_elems, dst_row_stride | (accumulate ? 1 << 32 : 0),

@@ -108,15 +108,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_x3_kernel(const ng::WgradParams 
 // splits sp = wave, wave+4, ... (independent loads in flight) and are combined through LDS in a fixed order
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ slabs, int nsplit, int N, int K,
                                                           const int32_t* __restrict__ map, float* __restrict__ dst,
-                                                          int64_t dst_elems, int dst_row_stride, int accumulate) {
+                                                          int64_t dst_elems, int dst_row_stride, int accumulate, int row0) {
     __shared__ f32x4 part[4][64];
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int k4 = (blockIdx.x * 64 + lane) * 4;
-    const int n = blockIdx.y;
+    const int n = blockIdx.y;                   // destination row; slab row row0 + n (nirgan_reduce_rows_part: a band of the slab's rows)
     const size_t total = size_t(N) * K;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (k4 < K) {
-        const float* src = slabs + size_t(n) * K + k4;
+        const float* src = slabs + size_t(row0 + n) * K + k4;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, s3 = {0.f, 0.f, 0.f, 0.f};
         int sp = grp;
         for (; sp + 12 < nsplit; sp += 16) {                 // four slabs in flight per wave (fixed association)
@@ -423,8 +423,18 @@ extern "C" int nirgan_reduce_rows(const float* slabs, int nsplit, int N, int K, 
     NG_REQUIRE(slabs && map && dst && nsplit >= 1 && N > 0 && K > 0 && K % 4 == 0 && N <= 65535, "reduce_rows: bad arguments");
     NG_REQUIRE(ng_aligned16(slabs), "reduce_rows: slabs must be 16-byte aligned");
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((K + 255) / 256, N), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       slabs, nsplit, N, K, map, dst, dst_elems, dst_row_stride, accumulate);
+                       slabs, nsplit, N, K, map, dst, dst_elems, dst_row_stride, accumulate, 0);
     return nirgan_check_launch("reduce_rows");
+}
+
+extern "C" int nirgan_reduce_rows_part(const float* slabs, int nsplit, int N, int row0, int rows, int K, const int32_t* map,
+                                       float* dst, int64_t dst_elems, int dst_row_stride, int accumulate, void* stream) {
+    NG_REQUIRE(slabs && map && dst && nsplit >= 1 && N > 0 && K > 0 && K % 4 == 0 && N <= 65535, "reduce_rows_part: bad arguments");
+    NG_REQUIRE(row0 >= 0 && rows > 0 && row0 + rows <= N, "reduce_rows_part: rows [%d, %d) outside the slab's %d rows", row0, row0 + rows, N);
+    NG_REQUIRE(ng_aligned16(slabs), "reduce_rows_part: slabs must be 16-byte aligned");
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((K + 255) / 256, rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       slabs, nsplit, N, K, map, dst, dst_elems, dst_row_stride, accumulate, row0);
+    return nirgan_check_launch("reduce_rows_part");
 }
 
 extern "C" int nirgan_reduce_rows_batch(const int64_t* jobs_device, int njobs, int total_blocks, void* stream) {

@@ -701,6 +701,41 @@ def attach_conv_stats(ctx: Ctx, descs: list, bias) -> Optional[tuple]:
     return total, bias, ws
 
 
+def emit_wgrad_pixel_pairs(plan: Plan, ctx: Ctx, dy: Halo, inp: Halo, grad: torch.Tensor, *, k, p, cin, cout, OH, OW, accumulate=False) -> bool:
+    """Weight gradient of the row-packed first convolution on the split tile, two adjacent output pixels per GEMM row (as its forward,
+    ConvIN.emit_fwd): P = dY viewed [B][OH][OW/2][2 cout], Q = the 4-channel input viewed in pixel pairs, one tap per kernel row over
+    (k + 1) pixels x cs channels = a run of 32.  Slab rows are (pixel parity q, output channel); column (kh, px, c) of parity q is
+    weight element (c, kh, px - q): two nirgan_reduce_rows_part calls fold the two bands into the gradient.  False: does not apply."""
+    cs = inp.C
+    N, run, K = 2 * cout, (k + 1) * cs, k * (k + 1) * cs
+    OWp = OW // 2
+    M = inp.B * OH * OWp
+    if not (ctx.precision == 0 and OPT.split3 and OPT.pair_pixels and cout == 64 and run == 32 and OW % 2 == 0 and inp.wp % 2 == 0
+            and dy.wp % 2 == 0 and dy.pad % 2 == 0 and (inp.pad - p) % 2 == 0 and dy.t16 is None and OWp % 32 == 0 and M % 32 == 0):
+        return False
+    nsplit, rows = G.wgrad_split(M, (N // 128) * (-(-K // 128)), G.CUS, 32)
+    slabs = ctx.zeros(nsplit * N * K)
+    ctx.keep.append(slabs)
+    d = L.WgradDesc()
+    d.p, d.p_elems, d.p_hp, d.p_wp, d.p_cs, d.p_oh, d.p_ow = dy.operand_ptr(d), dy.elems, dy.hp, dy.wp // 2, N, dy.pad, dy.pad // 2
+    d.q, d.q_elems, d.q_hp, d.q_wp, d.q_cs = inp.operand_ptr(d), inp.elems, inp.hp, inp.wp // 2, 2 * cs
+    d.q_stride, d.q_oh, d.q_ow = 1, inp.pad - p, (inp.pad - p) // 2
+    d.run = run
+    _set_taps(d, list(range(k)), [0] * k)
+    d.B, d.OH, d.OW, d.N = inp.B, OH, OWp, N
+    d.slabs, d.slab_elems, d.nsplit, d.rows_per_split = slabs.data_ptr(), slabs.numel(), nsplit, rows
+    d.zero_page = ctx.zero_page.data_ptr()
+    d.precision = 3
+    ctx.keep.append(d)
+    plan.add("nirgan_wgrad_igemm", C.byref(d))
+    for q in (0, 1):
+        spec = G.conv_rowpacked_pair_pack(cout, cin, k, cs, q)
+        imap = ctx.i32(spec.index_map)
+        plan.add("nirgan_reduce_rows_part", slabs.data_ptr(), nsplit, N, q * cout, cout, K, imap.data_ptr(), grad.data_ptr(), grad.numel(),
+                 spec.row_stride, 1 if (accumulate or q) else 0)
+    return True
+
+
 def want_phase_pairs(ctx: Ctx, phases: list, run: int, N: int, out) -> bool:
     """A 64-channel sub-pixel launch whose four phases would not all take the split tile (taps x run < 512 somewhere: 1 / 2 / 2 / 4 taps of a
     3 x 3 kernel) runs as two paired problems of 128 columns on it (nirgan_conv_desc.out_span = 2, geometry.pair_row_phases): measured
@@ -1130,6 +1165,9 @@ class ConvIN:
             emit_wgrad(plan, ctx, dy, inp, G.conv_fwd_taps(k, inp.C), G.conv_fwd_pack(self.cout, inp.C, k), gw,
                        N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,
                        q_oh=inp.pad - p, q_ow=inp.pad - p, slabs_pool=eng.slabs)
+        elif self.kind == "rowpacked" and s == 1 and emit_wgrad_pixel_pairs(plan, ctx, dy, inp, gw, k=k, p=p, cin=self.cin, cout=self.cout,
+                                                                            OH=self.OH, OW=self.OW):
+            pass
         elif self.kind == "rowpacked":
             emit_wgrad(plan, ctx, dy, inp, G.conv_rowpacked_taps(k, inp.C), G.conv_rowpacked_pack(self.cout, self.cin, k, inp.C), gw,
                        N=self.cout, OH=self.OH, OW=self.OW, p_oh=dy.pad, p_ow=dy.pad, q_stride=s,

@@ -170,6 +170,7 @@ PROTOTYPES = {
     "nirgan_wgrad_kernel_name": (C.c_char_p, [C.POINTER(WgradDesc)]),
     "nirgan_conv_wgrad_pair_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc), C.POINTER(WgradDesc)]),
     "nirgan_reduce_rows": (i32, [fp, i32, i32, i32, fp, fp, i64, i32, i32, fp]),
+    "nirgan_reduce_rows_part": (i32, [fp, i32, i32, i32, i32, i32, fp, fp, i64, i32, i32, fp]),
     "nirgan_reduce_rows_batch": (i32, [fp, i32, i32, fp]),
     "nirgan_pack_rows": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),
     "nirgan_pack_rows_bf16": (i32, [fp, i64, i32, fp, fp, i32, i32, fp]),

@@ -304,6 +304,23 @@ class EmuBackend:
             o[idx] = s[:, ok]
         return 0
 
+    def nirgan_reduce_rows_part(self, slabs, nsplit, N, row0, rows, K, imap, dst, dst_elems, stride, accumulate, stream=None):
+        self.calls.append("reduce_part")
+        if row0 < 0 or rows <= 0 or row0 + rows > N:
+            return self._fail("reduce_rows_part: rows outside the slab")
+        s = arr(slabs, nsplit * N * K).reshape(nsplit, N, K).sum(0)[row0:row0 + rows]
+        m = arr(imap, K, np.int32)
+        o = arr(dst, dst_elems)
+        ok = m >= 0
+        idx = (np.arange(rows)[:, None] * stride + m[None, :])[:, ok]
+        if idx.max() >= dst_elems:
+            return self._fail("reduce_rows_part: index out of range")
+        if accumulate:
+            o[idx] += s[:, ok]
+        else:
+            o[idx] = s[:, ok]
+        return 0
+
     def nirgan_pack_rows_bf16(self, src, src_elems, stride, imap, dst, N, K, stream=None):
         return self.nirgan_pack_rows(src, src_elems, stride, imap, dst, N, K, bf16=True)
 

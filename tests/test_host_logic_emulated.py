@@ -932,7 +932,7 @@ def test_paired_sub_pixel_phases_keep_the_step(emu, monkeypatch):
         G0 = {k: v.detach().clone() for k, v in netG.state_dict().items()}
         D0 = {k: v.detach().clone() for k, v in netD.state_dict().items()}
         g = torch.Generator().manual_seed(12)
-        rgb, nir = torch.rand(1, 3, 32, 32, generator=g), torch.rand(1, 1, 32, 32, generator=g)
+        rgb, nir = torch.rand(1, 3, 64, 64, generator=g), torch.rand(1, 1, 64, 64, generator=g)      # (64 wide: 32 pixel pairs per row, the weight gradient's K-tile)
         seen = []
         orig = emu.nirgan_conv_igemm_group
 
@@ -954,6 +954,7 @@ def test_paired_sub_pixel_phases_keep_the_step(emu, monkeypatch):
         return out, tr.flatG.grad.clone(), tr.flatD.grad.clone(), tr.pred.clone(), seen, (G0, D0, rgb, nir)
 
     out, gG, gD, pred, seen, (G0, D0, rgb, nir) = run(True)
+    assert emu.calls.count("reduce_part") == 2, "the first convolution's weight gradient folds its two pixel-parity bands with two calls"
     firsts = [grp[0] for grp in seen if grp[0][0] == "first"]
     assert firsts and all(f == ("first", 128, 7, 32, 8, 128, True, 3) for f in firsts), firsts      # Conv2d(3, 64, 7): 128 columns, 7 taps of 32, pixel-pair views, statistics
     seen[:] = [grp for grp in seen if grp[0][0] != "first"]
