@@ -436,7 +436,11 @@ __device__ __forceinline__ void conv_x3_persist(const NG_CONST X3Work* const wp,
 #ifdef NG_X3_DIAG
                         if (!(p.algo & 0x100))
 #endif
+#ifdef NG_X3_NT_STORES         // (A/B switch, scripts/diag/ab_build.sh: non-temporal stores -- the consumer's reads then miss: -0.84 % on the step)
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(E.out + ooff[pass]));
+#else
                         *reinterpret_cast<f32x4*>(E.out + ooff[pass]) = v;
+#endif
                         if (fused) {
                             const f32x4 z = (yv[pass] - fm) * fr;
 #pragma unroll
