@@ -759,7 +759,7 @@ def main():
                         and not a.mixed and a.micro == 1 and not a.inject and a.lambda_rs == 0.0 and a.ngf == 64)
             for r in roofs:
                 ent = next((v for k, v in pmc.items() if k != "_meta" and k.split("<")[0] == r["kernel"].split("<")[0]
-                            and ("<" not in r["kernel"] or k.startswith(r["kernel"][:-1] + ","))), None)
+                            and ("<" not in r["kernel"] or k == r["kernel"] or k.startswith(r["kernel"][:-1] + ","))), None)
                 r["traffic_source"] = None
                 if ent and headline and fresh and "hbm_read_bytes_per_launch_corrected" in ent:
                     r["traffic"] = int(ent["hbm_read_bytes_per_launch_corrected"] + ent.get("hbm_write_bytes_per_launch", 0.0))
