@@ -44,7 +44,14 @@ __device__ __forceinline__ float dpp_add(float v) {
 // wave = (image, 4 output rows, 64 output columns)
 __global__ __launch_bounds__(256) void endconv_fwd_kernel(const EndP p, const float* __restrict__ x, const float* __restrict__ wt_, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
+    // (XCD-contiguous walk: a block = the four column segments of one group of 4 output rows and reads 10 input rows, 6 of them shared
+    // with the next group -- dispatched round-robin, neighbouring groups sat on different XCDs and every L2 fetched its own copy:
+    // 742 MB read for a 281 MB input)
+#ifdef NG_END_NOREMAP
     const int wave = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
+#else
+    const int wave = uni(ng_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));
+#endif
     const int segs = (p.W2 + 63) / 64, rgs = (p.H2 + 3) / 4;
     if (wave >= p.B * rgs * segs) return;
     const int seg = wave % segs, rg = (wave / segs) % rgs, b = wave / (segs * rgs);
