@@ -1516,6 +1516,36 @@ def test_wino6_input_transform_forms_agree_for_both_patch_sizes(case):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+def test_reduce_rows_part_folds_the_bands_of_a_slab():
+    """nirgan_reduce_rows_part: a band of the slabs' rows summed over the splits into dst rows 0.. -- bitwise the same sums as
+    nirgan_reduce_rows over a slab that holds only that band; the two pixel-parity bands of the first convolution's weight gradient
+    (geometry.conv_rowpacked_pair_pack: column (kh, px, c) of parity q is weight element (c, kh, px - q)) folded into one tensor equal the
+    float64 fold."""
+    g = torch.Generator().manual_seed(19)
+    cout, cin, k, cs, nsplit = 64, 3, 7, 4, 11
+    specs = [G.conv_rowpacked_pair_pack(cout, cin, k, cs, q) for q in (0, 1)]
+    K = specs[0].K
+    slabs = torch.randn(nsplit, 2 * cout, K, generator=g).to(DEV)
+    out = torch.full((cout * cin * k * k,), float("nan"), device=DEV)
+    for q, spec in enumerate(specs):
+        imap = torch.from_numpy(spec.index_map).to(DEV)
+        L.call("nirgan_reduce_rows_part", slabs.data_ptr(), nsplit, 2 * cout, q * cout, cout, K, imap.data_ptr(), out.data_ptr(), out.numel(), spec.row_stride, q, None)
+        band = slabs[:, q * cout:(q + 1) * cout].contiguous()
+        alone = torch.zeros_like(out)
+        L.call("nirgan_reduce_rows", band.data_ptr(), nsplit, cout, K, imap.data_ptr(), alone.data_ptr(), alone.numel(), spec.row_stride, 0, None)
+        only = torch.zeros_like(out)
+        L.call("nirgan_reduce_rows_part", slabs.data_ptr(), nsplit, 2 * cout, q * cout, cout, K, imap.data_ptr(), only.data_ptr(), only.numel(), spec.row_stride, 0, None)
+        torch.cuda.synchronize()
+        assert torch.equal(only, alone), f"band {q}"
+    ref = np.zeros((cout, cin * k * k))
+    s64 = slabs.double().sum(0).cpu().numpy()
+    for q, spec in enumerate(specs):
+        ok = spec.index_map >= 0
+        np.add.at(ref, (np.arange(cout)[:, None], spec.index_map[ok][None, :]), s64[q * cout:(q + 1) * cout][:, ok])
+    close(out.reshape(cout, -1), torch.from_numpy(ref).float(), 1e-6, "two bands folded into the weight gradient")
+    assert L.backend().nirgan_reduce_rows_part(slabs.data_ptr(), nsplit, 2 * cout, 100, cout, K, imap.data_ptr(), out.data_ptr(), out.numel(), spec.row_stride, 0, None) != 0
+
+
 def test_reduce_rows_batch_equals_the_single_launches():
     """nirgan_reduce_rows_batch: several weight gradients' slab sums in one launch -- the general form (any index map) and the Conv2d-layout
     form (taps > 0: whole runs of the [N][Cin][kh][kw] gradient stored contiguously) -- bitwise equal to nirgan_reduce_rows job by job

@@ -160,6 +160,11 @@ def test_wino6_plane_gemms_and_weight_gradient_x3(case):
     bits = U3.view(torch.int16).cpu().numpy().view(np.uint16).reshape(3, -1)
     back = sum((bits[t].astype(np.uint32) << 16).view(np.float32).astype(np.float64) for t in range(3))
     assert np.array_equal(back, U.cpu().numpy().astype(np.float64)), "U3 is not the three-term split of U"
+    # the planes alone (U = NULL: what the engine asks for when the split tile takes the layer) are the same planes
+    U3_only = torch.zeros_like(U3)
+    L.call("nirgan_wino6_weights_x3", w.data_ptr(), K, Cc, v, 0, None, U3_only.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert torch.equal(U3_only.view(torch.int16), U3.view(torch.int16))
     V = torch.randn(NP * T * Cc, generator=g).to(DEV)
     zero = torch.zeros(64, device=DEV)
     Ms = {}
@@ -174,6 +179,16 @@ def test_wino6_plane_gemms_and_weight_gradient_x3(case):
         L.call("nirgan_wino6_gemm", C.byref(d), None)
         torch.cuda.synchronize()
         Ms[x3] = M
+    # ... and the plane GEMM needs nothing else: the same launch without U is bitwise the one with it; without U AND planes it is refused
+    M2 = torch.full((NP * T * K,), float("nan"), device=DEV)
+    d = L.Wino6Desc()
+    d.r, d.B, d.H, d.W, d.C, d.K = v, B, H, W, Cc, K
+    d.V, d.V_elems, d.M, d.M_elems, d.zero_page, d.U3 = V.data_ptr(), V.numel(), M2.data_ptr(), M2.numel(), zero.data_ptr(), U3.data_ptr()
+    L.call("nirgan_wino6_gemm", C.byref(d), None)
+    torch.cuda.synchronize()
+    assert torch.equal(M2, Ms[True])
+    d.U3 = None
+    assert be.nirgan_wino6_gemm(C.byref(d), None) != 0
     ref = torch.einsum("ftc,fkc->ftk", V.double().reshape(NP, T, Cc), U.double().reshape(NP, K, Cc)).reshape(-1)
     e0, e3 = _err(Ms[False], ref), _err(Ms[True], ref)
     assert torch.isfinite(Ms[True]).all()
