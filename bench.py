@@ -51,8 +51,13 @@ PEAKS = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3":
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
+def _is_x3(label):
+    """launches of the three-term split tiles (csrc/igemm_x3.h, igemm_x3r.h)"""
+    return "_x3_kernel" in label or "_x3r_kernel" in label
+
+
 def kernel_peak(label: str, precision: str) -> float:
-    return PEAK_X3_TFLOPS if "_x3_kernel" in label else PEAKS[precision]
+    return PEAK_X3_TFLOPS if _is_x3(label) else PEAKS[precision]
 
 
 def synth(B, H, W, seed, device):
@@ -119,7 +124,10 @@ def op_mfma_work(name, args):
         if all(d.precision == 3 for d in ds) and hasattr(be, "nirgan_conv_kernel_name"):      # the three-term split tile: one persistent launch of conv_x3_kernel over the phases
             k = be.nirgan_conv_kernel_name(C.byref(ds[0]))
             if k and k.decode().startswith("conv_x3"):
-                label = f"conv_x3_kernel<{128 if ds[0].N % 128 == 0 else 64}>"
+                # (the register-fed four-wave tile takes a group only if it takes every phase: igemm_conv.hip::ng_launch_conv_x3)
+                ks = [be.nirgan_conv_kernel_name(C.byref(d)) for d in ds]
+                r4 = all(kk and kk.decode().startswith("conv_x3r") for kk in ks)
+                label = f"conv_x3r_kernel<128>" if r4 else f"conv_x3_kernel<{128 if ds[0].N % 128 == 0 else 64}>"
         return label, sum(2.0 * d.B * d.OH * d.OW * d.N * d.ntaps * d.run for d in ds), by
     if name == "nirgan_wgrad_igemm":
         w = args[0]._obj
@@ -158,7 +166,7 @@ PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s (about 6.
 
 
 def mfma_probes(trainer, want=("conv_igemm_kernel<128>", "conv_igemm256_kernel", "conv_group_kernel<128>", "wgrad_igemm_kernel<128>", "wgrad_igemm256_kernel", "conv_wgrad_pair", "wino6_",
-                                "conv_x3_kernel", "wgrad_x3_kernel")):
+                                "conv_x3_kernel", "conv_x3r_kernel", "wgrad_x3_kernel")):
     """EXECUTED FLOPs of one step's launches of the big MFMA kernels, and the op indices to bracket with HIP events."""
     plans = [trainer.G.fwd, trainer.G.bwd, trainer.D2.fwd, trainer.D2.bwd, trainer.D1.fwd, trainer.D1.bwd_pred]
     kinds, algo_bytes, direct = {}, {}, {}
@@ -772,7 +780,7 @@ def main():
                     r["traffic_source"] = (f"{pmc_file} was recorded for kernel sources {meta.get('kernel_src_sha16')}, this build is {src_now}: "
                                            "stale, not reported (rerun scripts/refresh_profiles.sh)")
             for r in roofs:
-                if "_x3_kernel" in r["kernel"]:
+                if _is_x3(r["kernel"]):
                     r["arithmetic"] = ("fp32-equivalent on the bf16 matrix pipe: every fp32 operand as three bf16 terms, six v_mfma_f32_16x16x32_bf16 products per "
                                        "fp32 product, fp32 accumulate (csrc/igemm_x3.h); `achieved` counts fp32-EQUIVALENT FLOPs, `peak` = 2.5 PFLOP/s dense bf16 / 6")
                     r["executed_bf16_tflops"] = round(6.0 * r["achieved"], 1)

@@ -136,6 +136,7 @@ typedef struct {
 } nirgan_conv_desc;
 #define NIRGAN_CONV_TILE128 1
 #define NIRGAN_CONV_X3_BN64 3   /* precision 3: the 256 x 64 block tile also where 256 x 128 applies (A/B) */
+#define NIRGAN_CONV_X3_R4 4     /* precision 3, N % 128 == 0: the four-wave register-fed tile of igemm_x3r.h instead of the eight-wave tile (A/B; same bits) */
 #define NIRGAN_CONV_TILE256 2   /* exact-fp32 problems (N % 256 == 0, run % 32 == 0, >= 128 tiles) on the 256-wide tile too (A/B: within 1 % of the 128-row tile) */
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
@@ -581,6 +582,7 @@ typedef struct {
 #define NIRGAN_W6_PERSIST16 2
 #define NIRGAN_W6_DIRECT_TILE 3
 #define NIRGAN_W6_TILE256 4                 /* nirgan_wino6_gemm: the exact-fp32 256 x 256 eight-phase tile as persistent workgroups (A/B; K % 256 == 0, C % 32 == 0) */
+#define NIRGAN_W6_X3_R4 5                   /* nirgan_wino6_gemm with U3, K % 128 == 0: the plane GEMMs on the four-wave register-fed split tile (A/B; same bits) */
 #define NIRGAN_W6_PATCH_PER_THREAD 16      /* nirgan_wino6_input*: F(6x6,3x3) patches one per thread (A/B; default for the plain / dY transforms: a wave per patch x 32 channels) */
 #define NIRGAN_W6_PATCH_PER_LANES 17       /* ... and the lane-spread form also for the normalising variant (default there: one per thread) */
 /* names of the kernels the two launchers above pick for a descriptor (what a profile of the launch shows) */

@@ -15,6 +15,7 @@
 #include "igemm_tiles.h"
 #include "igemm_tile256.h"
 #include "igemm_x3.h"
+#include "igemm_x3r.h"
 
 namespace {
 
@@ -43,6 +44,17 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const ng::X3Work w) {
     __shared__ __attribute__((aligned(16))) char sRed[8 * (BN / 8) * 2 * 16];
     // (the work list is read through the kernarg segment: a runtime problem index then costs scalar loads, not a scratch copy)
     ng::conv_x3_persist<BN>((const NG_CONST ng::X3Work*)__builtin_amdgcn_kernarg_segment_ptr(), sA0, sA1, sB0, sB1, sRed);
+}
+
+// the same arithmetic as ONE wave per SIMD (igemm_x3r.h): four waves, wave tile 64 x BN, the activation operand split in registers and
+// never staged, the weight planes through a four-stage LDS-DMA ring, the epilogue's slices under the item's last K-tile
+template <int BN>
+__global__ __launch_bounds__(256, 1) void conv_x3r_kernel(const ng::X3Work w) {
+    __shared__ __attribute__((aligned(1024))) char ring[ng::X3R<BN>::RING];
+    __shared__ __attribute__((aligned(16))) char stg[4 * ng::X3R<BN>::STG];
+    __shared__ __attribute__((aligned(16))) char sRed[4 * (BN / 4) * 2 * 16];
+    __shared__ __attribute__((aligned(1024))) char trash[4 * 1024];
+    ng::conv_x3r_persist<BN>((const NG_CONST ng::X3Work*)__builtin_amdgcn_kernarg_segment_ptr(), ring, stg, sRed, trash);
 }
 
 // fp32 -> three bf16 planes h, m, l with x = h + m + l exactly (each term the RNE bf16 of what the previous ones left)
@@ -155,13 +167,22 @@ int ng::ng_launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, c
         w.spread = 1;
     }
     const dim3 grid(total < G ? total : G);
-    if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, w);
+    bool reg_fed = true;
+    for (int i = 0; i < n; ++i) reg_fed = reg_fed && ng::conv_x3r_ok(ps[i], bn);
+    if (reg_fed) hipLaunchKernelGGL(conv_x3r_kernel<128>, grid, dim3(256), 0, st, w);
+    else if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, w);
     else hipLaunchKernelGGL(conv_x3_kernel<64>, grid, dim3(512), 0, st, w);
     return nirgan_check_launch(what);
 }
 static int launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, hipStream_t st, const char* what) {
     return ng::ng_launch_conv_x3(ps, n, bn, 1, 0, 0, 0, st, what);
 }
+
+#ifdef NG_X3R_STAMP
+extern "C" int nirgan_x3r_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ng::ng_x3r_stamps), size_t(n) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int nirgan_split3(const float* src, void* dst_bf16, int64_t n, int64_t plane, void* stream) {
     NG_REQUIRE(src && dst_bf16 && n > 0 && n % 8 == 0 && plane >= n && plane % 8 == 0, "split3: n and plane must be positive multiples of 8, plane >= n");
@@ -214,7 +235,10 @@ extern "C" const char* nirgan_conv_kernel_name(const nirgan_conv_desc* d) {
     ng::ConvParams p;
     if (ng::build_conv_params(d, p) != NIRGAN_OK) return nullptr;
     if (p.prec == 3) {
-        if (ng::conv_x3_ok(p)) return ng::conv_x3_bn(p) == 128 ? "conv_x3_kernel<128>" : "conv_x3_kernel<64>";
+        if (ng::conv_x3_ok(p)) {
+            const int bn = ng::conv_x3_bn(p, ng_cu_count_conv());
+            return ng::conv_x3r_ok(p, bn) ? "conv_x3r_kernel<128>" : (bn == 128 ? "conv_x3_kernel<128>" : "conv_x3_kernel<64>");
+        }
         p.prec = 0;
     }
     if (p.algo != NIRGAN_CONV_TILE128 && ng::conv_tile256_ok(p)) return p.prec == 0 ? "conv_igemm256_kernel<fp32>" : "conv_igemm256_kernel";

@@ -1,0 +1,576 @@
+// The three-term split tile of igemm_x3.h as ONE WAVE PER SIMD with the activation operand fed from REGISTERS (round 6).
+//
+// Same arithmetic, same operand order, same accumulation order per output element as conv_x3_persist (the results are bitwise those of
+// the eight-wave tile); what changed is where the operands live and how the stream is scheduled:
+//   * 256 (M) x BN (N) x 32 (K) per K-tile, FOUR waves as 4 x 1: a wave owns 64 rows and ALL BN columns (wave tile 64 x 128 at BN = 128:
+//     128 accumulator registers, the wave has the SIMD's 512 registers to itself).
+//   * A (activations, fp32 in HBM) never touches LDS.  The MFMA A operand of v_mfma_f32_16x16x32_bf16 is "lane (row r, chunk c) holds
+//     k = 8 c .. 8 c + 7 of row r": exactly what two global_load_dwordx4 of that lane fetch from the row's 32-channel slice.  A row of
+//     the block tile is consumed by ONE wave, so that wave fetches it, splits it into the three bf16 terms in registers and multiplies:
+//     no ds_write of converted rows, no fragment reads of A, no barrier between conversion and use.  LDS traffic per K-tile and CU:
+//     96 KB of B fragment reads + 24 KB of LDS-DMA against 192 KB + 72 KB of the eight-wave tile.
+//   * B (the three bf16 planes of the packed weights) goes through a FOUR-stage LDS-DMA ring, three K-tiles ahead; ONE barrier per
+//     K-tile in the MIDDLE of the tile (it publishes tile j + 1 and frees the stage of tile j - 1 for the DMA of tile j + 3), none at
+//     the tile boundaries: the MFMA stream runs from one K-tile into the next -- and from one item into the next -- without a stop.
+//   * mt-outer order with ROLLING operands: a K-tile is four blocks (one 16-row tile mt each) of NT x 6 MFMAs; all NT B fragments of
+//     the tile stay in registers (96 at BN = 128) and are replaced one by one behind their last use in block 3; A[mt] of the next
+//     K-tile is converted behind block mt (one raw buffer, refilled right behind its conversion).
+//   * The epilogue of an item overlaps its own last K-tile: after block mt of the LAST K-tile the 16 x BN accumulators of that row
+//     tile are final -- slice mt goes through a wave-private 8 KB staging block (no barrier) and leaves as whole rows under the MFMAs of
+//     the blocks that follow; only slice 3 runs after the tile.  One accumulator set, no copies.
+// Every vector-memory operation of the loop is issued unconditionally and in a fixed order (a loader past the end of its work re-reads
+// its last tile; the ring's DMA goes to a block of LDS nobody reads), so every s_waitcnt vmcnt(N) below is a constant of the schedule: N counts
+// only operations that are ALWAYS issued behind the one waited for (the epilogue's stores are not counted: more operations in flight
+// than assumed only waits longer, never shorter).
+#pragma once
+#include "igemm_x3.h"
+
+namespace ng {
+
+// x3_split8 with plain subtractions: the scheduler's fences of this kernel let VALU instructions through and keep everything else in
+// place -- an inline-asm v_sub_f32 would be "everything else" (same values: the remainders are exact)
+__device__ __forceinline__ void x3r_split8(const f32x4 lo, const f32x4 hi, bf16x8& H, bf16x8& M, bf16x8& L) {
+    const f32x8 x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    u32x4 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        h[i] = x3_pk(x0, x1);
+        const float r0 = x0 - __builtin_bit_cast(float, h[i] << 16), r1 = x1 - __builtin_bit_cast(float, h[i] & 0xffff0000u);
+        m[i] = x3_pk(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, m[i] << 16), s1 = r1 - __builtin_bit_cast(float, m[i] & 0xffff0000u);
+        l[i] = x3_pk(s0, s1);
+    }
+    H = __builtin_bit_cast(bf16x8, h);
+    M = __builtin_bit_cast(bf16x8, m);
+    L = __builtin_bit_cast(bf16x8, l);
+}
+
+// diagnostic build only (scripts/diag/x3r_stamps.sh, -DNG_X3R_STAMP): per-wave cycle sums of the segments of a K-tile and of the epilogue
+#ifdef NG_X3R_STAMP
+__device__ unsigned long long ng_x3r_stamps[1024 * 4 * 16];
+#define X3R_STAMP(k) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                       __builtin_amdgcn_sched_barrier(0); st_sum[k] += unsigned(t_) - st_last; st_last = unsigned(t_); }
+#else
+#define X3R_STAMP(k)
+#endif
+
+template <int BN>
+struct X3R {
+    static constexpr int NT = BN / 16;                 // 16-column MFMA tiles of the wave tile (64 x BN)
+    static constexpr int B_TERM = BN * 64;             // bytes of one term image of B ([BN rows][32 k] bf16)
+    static constexpr int STAGE = 3 * B_TERM;
+    static constexpr int NSTAGE = 4;
+    static constexpr int RING = NSTAGE * STAGE;        // 96 KB at BN = 128
+    static constexpr int STG = 16 * BN * 4;            // staging of one wave: 16 rows x BN floats
+    static constexpr int BPT = BN / 16;                // 1 KB LDS-DMA pieces per term image
+    static constexpr int PIECES = 3 * BPT / 4;         // pieces per wave and K-tile (6 / 3)
+    static constexpr int LPR = BN / 4;                 // lanes per output row (4 channels each)
+    static constexpr int RPP = 64 / LPR;               // rows per store pass
+    static constexpr int SP = 16 / RPP;                // store passes per slice (8 / 4)
+};
+
+#define X3R_VALU 0x6        // sched_barrier mask: VALU and SALU instructions may cross, MFMAs, memory operations and inline asm may not
+#define X3R_GLD(dst, off, base, imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(off), "s"(base), "n"(imm) : "memory")
+// (the B fragments live in the accumulator half of the register file: ds_read writes AGPRs directly, MFMA reads them as operands --
+// the vector half is left to what VALU instructions touch: the raw rows, the split terms, the epilogue)
+#define X3R_DSR(dst, ad, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(ad), "n"(off) : "memory")
+
+template <int BN>
+__device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp, char* const ring, char* const stg_all, char* const sRed, char* const trash) {
+    static_assert(BN == 128 || BN == 64, "256 x 128 or 256 x 64 block tiles");
+    using T = X3R<BN>;
+    constexpr int NT = T::NT, B_TERM = T::B_TERM, STAGE = T::STAGE, BPT = T::BPT, PIECES = T::PIECES, LPR = T::LPR, RPP = T::RPP, SP = T::SP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = wp->first[wp->n];
+    const int G = gridDim.x;
+#ifdef NG_X3R_STAMP
+    unsigned st_sum[16], st_last = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st_sum[i] = 0;
+#endif
+
+    // ---------------- which tile is item i of this workgroup (as conv_x3_persist::locate)
+    struct Item {
+        const NG_CONST ConvParams* p;
+        const char* in8; const char* w8; float* out;
+        int m0, n0, nk, ntaps, run;
+        long long w3_plane;
+    };
+    auto locate = [&](const int item, Item& t) {
+        int k = 0, id = 0;
+        if (wp->spread) {
+            int m = (item - int(blockIdx.x)) / G;
+            const int pos = ng_xcd_remap(int(blockIdx.x), G);
+            k = -1;
+            for (int q = 0; q < wp->n; ++q) {
+                const int Tq = wp->first[q + 1] - wp->first[q];
+                int t0 = pos - wp->start[q];
+                t0 += t0 < 0 ? G : 0;
+                const int cnt = t0 < Tq ? (Tq - 1 - t0) / G + 1 : 0;
+                if (k < 0) {
+                    if (m < cnt) { k = q; id = t0 + m * G; }
+                    else m -= cnt;
+                }
+            }
+            if (k < 0) { t.nk = -1; return; }
+        } else {
+            if (item >= total) { t.nk = -1; return; }
+            const int id0 = ng_xcd_remap(item, total);
+            if (id0 >= wp->first[1]) k = 1;
+            if (id0 >= wp->first[2]) k = 2;
+            if (id0 >= wp->first[3]) k = 3;
+            id = id0 - wp->first[k];
+        }
+        const NG_CONST ConvParams* p = &wp->p[k];
+        int plane = 0;
+        if (wp->nplanes > 1) {
+            const int per = total / wp->nplanes;
+            plane = id / per;
+            id -= plane * per;
+        }
+        const int ntn = p->N / BN;
+        t.p = p;
+        t.n0 = (id % ntn) * BN;
+        t.m0 = (id / ntn) * 256;
+        t.ntaps = p->ntaps;
+        t.run = p->run;
+        t.w3_plane = p->w3_plane;
+        t.nk = t.ntaps * (t.run >> 5);
+        t.in8 = reinterpret_cast<const char*>(p->in + (long long)plane * wp->in_plane);
+        t.w8 = reinterpret_cast<const char*>(p->w3 + (long long)plane * wp->w3_pstride);
+        t.out = p->out + (long long)plane * wp->out_plane;
+    };
+
+    // ---------------- the loader: a cursor THREE K-tiles ahead of the MFMAs, over the workgroup's items as one stream of K-tiles.
+    // The ring's DMA of K-tile j + 3 is issued from the cursor itself; the rows of K-tile j + 2 (row tiles 0-2) and of K-tile j + 1 (row
+    // tile 3, converted one block later than the rest of its tile) are fetched through SNAPSHOTS of the cursor one and two tiles old
+    // (a scalar base and the lane's row offsets): one raw buffer, refilled right behind its conversion, one K-tile of latency budget.
+    Item L;
+    int itemL = blockIdx.x;
+    bool live = true;                           // the cursor is on a K-tile that exists (past the end it stays on the last one)
+    int left = 0, ct = 0, cc = 0, tapv = 0, pK = 0;
+    unsigned goffB[4], b_goff = 0;              // per lane: byte offsets of its four rows (one per 16-row tile) in the cursor's item / of its B row
+    const int b_c = (lane & 3) ^ x3_key(lane >> 2);
+    auto begin = [&]() {
+        const NG_CONST ConvParams& p = *L.p;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int m = L.m0 + wave * 64 + mt * 16 + (lane & 15);
+            m = m < p.M ? m : p.M - 1;
+            const int b = m / p.OHW, r = m - b * p.OHW;
+            const int oh = r / p.OW, ow = r - oh * p.OW;
+            goffB[mt] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + (lane >> 4) * 8) * 4u;
+        }
+        pK = p.K;
+        b_goff = unsigned((L.n0 + wave * 16 + (lane >> 2)) * pK + b_c * 8) * 2u;
+        tapv = p.tap_off[lane & (NIRGAN_MAX_TAPS - 1)];
+        left = L.nk;
+        ct = 0;
+        cc = 0;
+    };
+    auto a_base = [&]() -> const char* {
+        const int toff = __builtin_amdgcn_readlane(tapv, ct);
+        return ng_uniform_ptr(L.in8 + (long long)(toff + cc) * 4);
+    };
+    auto advance = [&]() {                      // to the next K-tile of the stream; past the end the cursor stays where it is
+        if (left > 1) {
+            --left;
+            ++ct;
+            if (ct == L.ntaps) { ct = 0; cc += 32; }
+            return;
+        }
+        if (!live) return;
+        Item nx;
+        locate(itemL + G, nx);
+        if (nx.nk < 0) { live = false; return; }
+        itemL += G;
+        L = nx;
+        begin();
+    };
+    const char* baseA = nullptr;                // snapshot one tile old: K-tile j + 2 while tile j is multiplied
+    const char* baseP = nullptr;                // two tiles old: K-tile j + 1
+    unsigned goffA[4] = {0u, 0u, 0u, 0u}, goff3P = 0;
+    auto snapshot = [&]() {                     // the cursor moves on: what it stood on becomes the rows' snapshot, that one the older one
+        baseP = baseA;
+        goff3P = goffA[3];
+        baseA = a_base();
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) goffA[mt] = goffB[mt];
+        advance();
+    };
+    f32x4 F[4][2];                              // raw rows: F[mt] = this lane's 8 k of its row of 16-row tile mt
+    u32x4 A[4][3];                              // the three terms of the CURRENT K-tile's rows, two bf16 per dword (rolling: A[mt] is replaced behind block mt)
+    bf16x8 Bf[NT][3];                           // the current K-tile's B fragments (rolling: replaced behind their last use in block 3)
+    // (inline asm with hand-counted waits: left to the compiler, the wait in front of a raw row set that was fetched in the PREVIOUS
+    // iteration of the loop comes out as vmcnt(0) -- every K-tile would sit out the fetches issued half a tile ago.  The destination
+    // registers are tied to the wait ("+v"), so nothing that reads them can be scheduled in front of it; scripts/check_x3r_asm.py
+    // checks in the built code object that no instruction touches them between the load and its wait)
+    auto loadA = [&](f32x4 (&f)[2], const char* base, const unsigned goff) {
+        X3R_GLD(f[0], goff, base, 0);
+        X3R_GLD(f[1], goff, base, 16);
+    };
+    auto wait_raw = [&](f32x4 (&f)[2], auto n_tag) {
+        if constexpr (decltype(n_tag)::value == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
+    };
+    // pair i (k = 2 i, 2 i + 1 of the lane's eight) of a raw row set into dword i of the three terms: 11 VALU (x3_split8's rule)
+    auto convert_pair = [&](const f32x4 (&f)[2], u32x4 (&a)[3], const int i) {
+        const float x0 = f[i >> 1][(2 * i) & 3], x1 = f[i >> 1][(2 * i + 1) & 3];
+        const unsigned h = x3_pk(x0, x1);
+        const float r0 = x3_sub(x0, __builtin_bit_cast(float, h << 16)), r1 = x3_sub(x1, __builtin_bit_cast(float, h & 0xffff0000u));
+        const unsigned m = x3_pk(r0, r1);
+        const float s0 = x3_sub(r0, __builtin_bit_cast(float, m << 16)), s1 = x3_sub(r1, __builtin_bit_cast(float, m & 0xffff0000u));
+        a[0][i] = h;
+        a[1][i] = m;
+        a[2][i] = x3_pk(s0, s1);
+    };
+    // the ring's DMA of the cursor's K-tile: PIECES 1 KB pieces per wave (piece q = wave + 4 i: term q / BPT, 16-row group q % BPT)
+    auto issueB_piece = [&](char* const stage, const int i) {
+        // past the end the cursor stands on its last K-tile: the same pieces are fetched again (the NUMBER of vector-memory operations is
+        // what the counted waits rely on) into a 1 KB block of LDS nobody reads.  (Not plain loads into a scratch register: the
+        // compiler reuses a register it believes dead while the load is still in flight -- the late data then lands in a live value.)
+        const int q = wave + 4 * i, term = q / BPT, idx = q % BPT;
+        const char* base = ng_uniform_ptr(L.w8 + ((long long)term * L.w3_plane + ct * L.run + cc) * 2 + (long long)(idx - wave) * 16 * pK * 2);
+        ng_glds16_so(base, b_goff, live ? stage + term * B_TERM + idx * 1024 : trash + wave * 1024);
+    };
+    auto issueB = [&](char* const stage) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) issueB_piece(stage, i);
+    };
+
+    // ---------------- compute state
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int swz = ((lane >> 4) ^ x3_key(lane & 15)) << 4;
+    const unsigned ring0 = unsigned(size_t((NG_LDS char*)ring));
+    const unsigned b_rd = unsigned((lane & 15) * 64 + swz);
+    int sj = 0;                                 // ring stage of the K-tile being multiplied
+    auto mma = [&](const int mt, const int nt) {
+        f32x4 c = acc[mt][nt];
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, A[mt][0]), am = __builtin_bit_cast(bf16x8, A[mt][1]), al = __builtin_bit_cast(bf16x8, A[mt][2]);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Bf[nt][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Bf[nt][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, Bf[nt][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, Bf[nt][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Bf[nt][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Bf[nt][0], c, 0, 0, 0);
+        acc[mt][nt] = c;
+    };
+#define X3R_RB(NTI, ad) { X3R_DSR(Bf[NTI][0], ad, (NTI) * 1024); X3R_DSR(Bf[NTI][1], ad, B_TERM + (NTI) * 1024); X3R_DSR(Bf[NTI][2], ad, 2 * B_TERM + (NTI) * 1024); }
+
+    // ---------------- epilogue of the item whose K-tiles are being multiplied (`E`), in four slices of 16 rows per wave
+    Item E;
+    char* const stg8 = stg_all + wave * T::STG;
+    float* const stg = reinterpret_cast<float*>(stg8);
+    const int chunk = lane % LPR, lrow = lane / LPR;
+    struct Epi {
+        int pM, OHW, OW, OH, out_img, out_row, out_px, out_org, f_img, f_row, f_px, f_org, pC, span;
+        const float* f_y;
+        bool fused, stats;
+        float fneg;
+        int n, nq, nc, m, b, oh, ow, fb, mbase;
+        f32x4 bv, fm, fr, s1, s2;
+        float k0[NT], t1[NT], t2[NT];
+    };
+    auto epi_begin = [&](Epi& e) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) e.k0[nt] = e.t1[nt] = e.t2[nt] = 0.f;
+        const NG_CONST ConvParams& p = *E.p;
+        e.pM = p.M; e.OHW = p.OHW; e.OW = p.OW; e.OH = p.OHW / p.OW; e.out_img = p.out_img; e.out_row = p.out_row * p.out_stride;
+        e.out_px = p.out_cs * p.out_stride; e.out_org = p.out_org; e.f_img = p.f_img; e.f_row = p.f_row * p.out_stride; e.f_px = p.ch * p.out_stride;
+        e.f_org = p.f_org; e.pC = p.ch; e.span = p.N / p.ch;
+        e.f_y = p.f_y;
+        e.mbase = E.m0 + wave * 64;
+        e.fused = e.f_y != nullptr;
+        e.stats = p.stats != nullptr && e.mbase < e.pM;
+        e.fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
+        e.n = E.n0 + chunk * 4;
+        e.bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) e.bv = *reinterpret_cast<const f32x4*>(p.bias + e.n);
+        e.m = e.mbase + lrow;
+        const int mc = e.m < e.pM ? e.m : e.pM - 1;
+        e.b = mc / e.OHW;
+        const int r0 = mc - e.b * e.OHW;
+        e.oh = r0 / e.OW;
+        e.ow = r0 - e.oh * e.OW;
+        e.fb = (e.mbase < e.pM ? e.mbase : e.pM - 1) / e.OHW;
+        e.nq = e.n >= e.pC ? 1 : 0;
+        e.nc = e.n - e.nq * e.pC;
+        e.fm = e.fr = e.s1 = e.s2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e.fused) {
+            e.fm = *reinterpret_cast<const f32x4*>(p.f_mean + size_t(e.fb) * e.pC + e.nc);
+            e.fr = *reinterpret_cast<const f32x4*>(p.f_rstd + size_t(e.fb) * e.pC + e.nc);
+        }
+    };
+    // slice mt: the wave's rows 16 mt .. 16 mt + 15.  The instance-norm partial sums (nirgan_conv_desc.stats_ws) are taken from the
+    // accumulators as they stand (the contract and the order of conv_x3_persist: per column {k = the chunk's first row, sum (v - k),
+    // sum (v - k)^2, 64} over the wave's 64 rows), the rows then go through the staging block and leave 16 bytes per lane
+    auto slice = [&](Epi& e, auto mt_tag, auto mode_tag) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mt_tag)::value;
+        constexpr bool PLAIN = decltype(mode_tag)::value == 1;          // no statistics, no fused pass: straight-line code (it is interleaved with MFMAs)
+        if (!PLAIN && e.stats) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (mt == 0) {
+                    e.k0[nt] = __shfl(acc[0][nt][0], lane & 15, 64);
+                    e.t1[nt] = 0.f;
+                    e.t2[nt] = 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[mt][nt][r] - e.k0[nt];
+                    e.t1[nt] += v;
+                    e.t2[nt] += v * v;
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[((lane >> 4) * 4 + r) * BN + nt * 16 + (lane & 15)] = acc[mt][nt][r];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};         // the next item's row tile starts from zero
+        int ooff[SP];
+        bool ok[SP];
+        f32x4 yv[SP];
+#pragma unroll
+        for (int pass = 0; pass < SP; ++pass) {
+            ok[pass] = e.m < e.pM;
+            ooff[pass] = e.b * e.out_img + e.oh * e.out_row + e.ow * e.out_px + e.out_org + e.n;
+            if (!PLAIN && e.fused && ok[pass]) yv[pass] = *reinterpret_cast<const f32x4*>(e.f_y + (size_t(e.b) * e.f_img + size_t(e.oh) * e.f_row + size_t(e.ow) * e.f_px + e.f_org + e.n));
+            // (selects, no loops: host -- OW >= RPP, see conv_x3r_ok)
+            e.m += RPP;
+            e.ow += RPP;
+            const bool wrap_w = e.ow >= e.OW;
+            e.ow -= wrap_w ? e.OW : 0;
+            e.oh += wrap_w ? 1 : 0;
+            const bool wrap_h = e.oh >= e.OH;
+            e.oh -= wrap_h ? e.OH : 0;
+            e.b += wrap_h ? 1 : 0;
+        }
+#pragma unroll
+        for (int pass = 0; pass < SP; ++pass) {
+            if (ok[pass]) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(stg + (pass * RPP + lrow) * BN + chunk * 4);
+                v += e.bv;
+                *reinterpret_cast<f32x4*>(E.out + ooff[pass]) = v;
+                if (!PLAIN && e.fused) {
+                    const f32x4 z = (yv[pass] - e.fm) * e.fr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float gz = z[q] > 0.f ? v[q] : v[q] * e.fneg;
+                        e.s1[q] += gz;
+                        e.s2[q] += gz * z[q];
+                    }
+                }
+            }
+        }
+    };
+    auto epi_finish = [&](Epi& e) {
+        const NG_CONST ConvParams& p = *E.p;
+        if (e.stats) {
+            const int b = e.mbase / e.OHW;
+            float* sp = p.stats + (size_t(b) * p.stats_cps + p.stats_chunk0 + ((e.mbase - b * e.OHW) >> 6) * e.span) * 4 * e.pC;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float s1 = e.t1[nt], s2 = e.t2[nt];
+                s1 += __shfl_xor(s1, 16, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                int col = E.n0 + nt * 16 + (lane & 15);
+                if (col >= e.pC) col += 3 * e.pC;
+                if (lane < 16) {
+                    sp[col] = e.k0[nt];
+                    sp[e.pC + col] = s1;
+                    sp[2 * e.pC + col] = s2;
+                    sp[3 * e.pC + col] = 64.f;
+                }
+            }
+        }
+        if (e.fused) {
+            // first pass of the consumer layer's instance-norm backward: this wave's 64 rows, then the two waves of a 128-row chunk
+            // (waves 2 c, 2 c + 1) join through a small LDS array in a fixed order
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) {
+                    e.s1[q] += __shfl_xor(e.s1[q], o, 64);
+                    e.s2[q] += __shfl_xor(e.s2[q], o, 64);
+                }
+            f32x4* const red = reinterpret_cast<f32x4*>(sRed);        // 4 waves x LPR x 2 sums
+            if (lane < LPR) {
+                red[(wave * LPR + chunk) * 2] = e.s1;
+                red[(wave * LPR + chunk) * 2 + 1] = e.s2;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // (uniform: `fused` is a constant of the item's problem, the items of a launch agree)
+            asm volatile("" ::: "memory");
+            if ((wave & 1) == 0 && lane < LPR && e.mbase < e.pM) {
+                const f32x4 t1 = e.s1 + red[((wave + 1) * LPR + chunk) * 2], t2 = e.s2 + red[((wave + 1) * LPR + chunk) * 2 + 1];
+                float* pp = p.f_part + (size_t(e.fb) * p.f_cps + p.f_chunk0 + ((e.mbase - e.fb * e.OHW) >> 7) * e.span + e.nq) * 2 * e.pC + e.nc;
+                *reinterpret_cast<f32x4*>(pp) = t1;
+                *reinterpret_cast<f32x4*>(pp + e.pC) = t2;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // the array is free for the next item
+            asm volatile("" ::: "memory");
+        }
+    };
+
+    // ---------------- one K-tile.  MODE 1 = the item's last K-tile with a plain epilogue: its slices ride in blocks 1-3.
+    // Vector-memory operations of a tile, in order: L3 (2 loads, K-tile j + 1; end of block 0), L0 (2, K-tile j + 2; end of block 1), the
+    // ring's DMA (6 pieces, K-tile j + 3; one per region of block 2), L1 (2), L2 (2) = 14.  A raw row set is waited for one tile after its
+    // loads: 12 operations are behind it (vmcnt(12)) -- 6 for row tile 1, whose wait stands in front of this tile's DMA pieces; the DMA of
+    // K-tile j + 1 was issued two tiles ago: 4 + 14 + 4 behind it (vmcnt(22)).
+    // The schedule is written region by region -- [6 MFMAs of one column tile + one pair of the conversion (11 VALU) + what the block
+    // adds] between full scheduling fences: inside a region hipcc interleaves the VALU with the MFMAs (an MFMA holds the vector issue
+    // port for 8 of its 16 cycles), across regions nothing moves (left to itself it issues every wait of a block up front and lumps the
+    // conversion; its sched_barrier masks let MFMAs through with the VALU class).
+    auto tile = [&]() __attribute__((always_inline)) {
+        const unsigned bnext = ring0 + unsigned(((sj + 1) & 3) * STAGE) + b_rd;
+        char* const stageD = ring + ((sj + 3) & 3) * STAGE;
+        // regions of one block: row tile MT; raw set SRC -> A[DST]; `base / goff` = where SRC is fetched again
+        auto block = [&](auto mt_tag, auto src_tag, auto dst_tag, const char* base, const unsigned goff) __attribute__((always_inline)) {
+            constexpr int MT = decltype(mt_tag)::value, SRC = decltype(src_tag)::value, DST = decltype(dst_tag)::value;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (nt == 0) wait_raw(F[SRC], std::integral_constant<int, MT == 2 ? 6 : 12>{});
+                if (MT == 2 && nt < PIECES) issueB_piece(stageD, nt);       // the ring's DMA of K-tile j + 3, a piece per region
+                if (MT == 0) {
+                    // this fragment's three reads were issued behind the previous tile's block 3, followed by those of the fragments after it
+                    if (3 * (NT - 1 - nt) >= 15) asm volatile("s_waitcnt lgkmcnt(15)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
+                    else if (NT - 1 - nt == 4) asm volatile("s_waitcnt lgkmcnt(12)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
+                    else if (NT - 1 - nt == 3) asm volatile("s_waitcnt lgkmcnt(9)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
+                    else if (NT - 1 - nt == 2) asm volatile("s_waitcnt lgkmcnt(6)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
+                    else if (NT - 1 - nt == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
+                }
+                mma(MT, nt);
+                // the conversion's four pairs in the block's first regions (NT = 8: every other one), the raw set's next fetch in the last
+                constexpr int every = NT / 4;
+                if (nt % every == 0) convert_pair(F[SRC], A[DST], nt / every);
+                if (nt == NT - 1) loadA(F[SRC], base, goff);
+                if (MT == 3 && nt == NT - 1) { sj = (sj + 1) & 3; snapshot(); }       // (the cursor's step among the tile's last MFMAs)
+                if (MT == 3) {
+                    // behind the last use of a B fragment the NEXT tile's fragment takes its registers
+                    if (nt == 0) X3R_RB(0, bnext) else if (nt == 1) X3R_RB(1, bnext) else if (nt == 2) X3R_RB(2, bnext) else if (nt == 3) X3R_RB(3, bnext)
+                    else if (nt == 4) X3R_RB(4 % NT, bnext) else if (nt == 5) X3R_RB(5 % NT, bnext) else if (nt == 6) X3R_RB(6 % NT, bnext) else X3R_RB(7 % NT, bnext)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        X3R_STAMP(5)                                     // (what lies between two tiles: the loop's overhead, an epilogue's tail)
+        block(I0{}, I3{}, I3{}, baseP, goff3P);          // THIS tile's row tile 3 is converted (needed in block 3), refilled from K-tile j + 1
+        X3R_STAMP(0)
+        block(I1{}, I0{}, I0{}, baseA, goffA[0]);        // the NEXT tile's row tile 0 into A[0] (block 0 has issued its last use), K-tile j + 2
+        X3R_STAMP(1)
+        // the tile's barrier: this wave's pieces of K-tile j + 1 have landed (issued two tiles ago); behind it K-tile j + 1 is visible to
+        // every wave and every wave has left K-tile j - 1, whose stage takes the DMA of K-tile j + 3
+        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        X3R_STAMP(2)
+        block(I2{}, I1{}, I1{}, baseA, goffA[1]);
+        X3R_STAMP(3)
+        block(I3{}, I2{}, I2{}, baseA, goffA[2]);
+        X3R_STAMP(4)
+#ifdef NG_X3R_STAMP
+        ++st_sum[15];
+#endif
+    };
+
+    // ---------------- the walk.  In front of K-tile 0 the loader issues what "tile -2" and "tile -1" would have, in their order, so
+    // that the counted waits of the first tiles find the operations they assume
+    locate(itemL, L);
+    if (L.nk < 0) return;
+    begin();
+    issueB(ring);                               // K-tile 0 -> stage 0
+    snapshot();                                 // (baseA, goffA) = K-tile 0, cursor on K-tile 1
+    loadA(F[0], baseA, goffA[0]);
+    issueB(ring + STAGE);                       // K-tile 1 -> stage 1
+    loadA(F[1], baseA, goffA[1]);
+    loadA(F[2], baseA, goffA[2]);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]) :: "memory");       // (and K-tile 0's own pieces of B)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { convert_pair(F[0], A[0], i); convert_pair(F[1], A[1], i); convert_pair(F[2], A[2], i); }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+        const unsigned b0 = ring0 + b_rd;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt == 0) X3R_RB(0, b0) else if (nt == 1) X3R_RB(1, b0) else if (nt == 2) X3R_RB(2, b0) else if (nt == 3) X3R_RB(3, b0)
+            else if (nt == 4) X3R_RB(4 % NT, b0) else if (nt == 5) X3R_RB(5 % NT, b0) else if (nt == 6) X3R_RB(6 % NT, b0) else X3R_RB(7 % NT, b0)
+        }
+    }
+    snapshot();                                 // P = K-tile 0, A = K-tile 1, cursor on K-tile 2
+    loadA(F[3], baseP, goff3P);
+    loadA(F[0], baseA, goffA[0]);
+    issueB(ring + 2 * STAGE);                   // K-tile 2 -> stage 2
+    loadA(F[1], baseA, goffA[1]);
+    loadA(F[2], baseA, goffA[2]);
+    snapshot();                                 // P = K-tile 1, A = K-tile 2, cursor on K-tile 3: the state tile 0 expects
+#ifdef NG_X3R_STAMP
+    { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_last = unsigned(t_); }
+#endif
+    // (the multiplying side knows of its item only the number of K-tiles; the item itself is located again behind its last K-tile, for the
+    // epilogue: nothing of the epilogue's state is live across the K loop)
+    int itemC = blockIdx.x;
+    locate(itemC, E);
+    int kC = 0, nkC = E.nk;
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    while (true) {
+        tile();
+        if (++kC < nkC) continue;
+        X3R_STAMP(5)
+        locate(itemC, E);
+        Epi e;
+        epi_begin(e);
+        X3R_STAMP(6)
+        if (!e.stats && !e.fused) {
+            slice(e, I0{}, I1{});
+            slice(e, I1{}, I1{});
+            slice(e, I2{}, I1{});
+            slice(e, I3{}, I1{});
+        } else {
+            slice(e, I0{}, I2{});
+            slice(e, I1{}, I2{});
+            slice(e, I2{}, I2{});
+            slice(e, I3{}, I2{});
+        }
+        epi_finish(e);
+        X3R_STAMP(7)
+#ifdef NG_X3R_STAMP
+        ++st_sum[14];
+#endif
+        itemC += G;
+        locate(itemC, E);
+        if (E.nk < 0) break;
+        kC = 0;
+        nkC = E.nk;
+    }
+#ifdef NG_X3R_STAMP
+    if (lane == 0 && blockIdx.x < 1024) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ng_x3r_stamps[(blockIdx.x * 4 + wave) * 16 + i] = st_sum[i];
+    }
+#endif
+#undef X3R_RB
+}
+#undef X3R_GLD
+#undef X3R_VALU
+#undef X3R_DSR
+
+// whether the register-fed tile takes a launch the split tile covers (host): 128-column tiles, asked for by the descriptor (A/B switch)
+inline bool conv_x3r_ok(const ConvParams& p, const int bn) { return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 4; }
+
+}  // namespace ng

@@ -1502,7 +1502,7 @@ static bool w6_x3_desc(const nirgan_wino6_desc* d) {
 
 extern "C" const char* nirgan_wino6_gemm_kernel_name(const nirgan_wino6_desc* d) {
     if (!d) return "";
-    if (w6_x3_desc(d)) return d->K % 128 == 0 ? "conv_x3_kernel<128> (planes)" : "conv_x3_kernel<64> (planes)";
+    if (w6_x3_desc(d)) return d->K % 128 == 0 ? (d->algo == NIRGAN_W6_X3_R4 ? "conv_x3r_kernel<128> (planes)" : "conv_x3_kernel<128> (planes)") : "conv_x3_kernel<64> (planes)";
     if (d->algo == NIRGAN_W6_TILE256 && d->C % 32 == 0 && d->K % 256 == 0) return "wino6_gemm256_kernel";
     switch (w6_gemm_choice(d, false)) {
         case W6_PERSIST32: return "wino6_gemm32p_kernel";
@@ -1567,6 +1567,7 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
         g.p.prec = 3;
         g.p.w3 = static_cast<const unsigned short*>(d->U3);
         g.p.w3_plane = (long long)w6_np(w6_r(d->r)) * d->K * d->C;
+        g.p.algo = d->algo == NIRGAN_W6_X3_R4 ? NIRGAN_CONV_X3_R4 : 0;       // (A/B: the four-wave register-fed tile)
 #ifdef NG_X3_DIAG
         g.p.algo = d->algo & 0xf00;          // diagnostic build only: the epilogue switches of igemm_x3.h
 #endif

@@ -142,10 +142,10 @@ class Wino6Desc(C.Structure):
                 ("fuse_act", i32), ("fuse_slope", f32), ("algo", i32), ("U3", fp)]
 
 
-W6_ONE_TILE, W6_PERSIST16, W6_DIRECT_TILE, W6_TILE256 = 1, 2, 3, 4      # nirgan_wino6_desc.algo
+W6_ONE_TILE, W6_PERSIST16, W6_DIRECT_TILE, W6_TILE256, W6_X3_R4 = 1, 2, 3, 4, 5      # nirgan_wino6_desc.algo
 W6_PATCH_PER_THREAD, W6_PATCH_PER_LANES = 16, 17                                 # nirgan_wino6_desc.algo for the input transforms (A/B)
 WGRAD_ONE_UNIT, WGRAD_TILE128, WGRAD_RING10 = 1, 2, 3      # nirgan_wgrad_desc.algo
-CONV_TILE128, CONV_TILE256, CONV_X3_BN64 = 1, 2, 3                        # nirgan_conv_desc.algo
+CONV_TILE128, CONV_TILE256, CONV_X3_BN64, CONV_X3_R4 = 1, 2, 3, 4            # nirgan_conv_desc.algo
 
 
 class EndConvDesc(C.Structure):

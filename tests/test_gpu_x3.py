@@ -80,7 +80,7 @@ def test_conv_x3_against_float64_at_the_fp32_tiles_error(case):
         d.precision = prec
         if prec == 3:
             d.w_x3, d.w_x3_plane = tw.data_ptr(), plane
-            assert L.backend().nirgan_conv_kernel_name(C.byref(d)).startswith(b"conv_x3_kernel"), "the split tile does not cover this case"
+            assert L.backend().nirgan_conv_kernel_name(C.byref(d)).startswith(b"conv_x3"), "the split tile does not cover this case"
         L.call("nirgan_conv_igemm", C.byref(d), None)
         L.call("nirgan_conv_igemm", C.byref(d), None)          # (a second launch over the same buffers: same bits)
         torch.cuda.synchronize()
@@ -175,7 +175,7 @@ def test_wino6_plane_gemms_and_weight_gradient_x3(case):
         d.U, d.V, d.V_elems, d.M, d.M_elems, d.zero_page = U.data_ptr(), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), zero.data_ptr()
         if x3:
             d.U3 = U3.data_ptr()
-            assert be.nirgan_wino6_gemm_kernel_name(C.byref(d)).startswith(b"conv_x3_kernel")
+            assert be.nirgan_wino6_gemm_kernel_name(C.byref(d)).startswith(b"conv_x3")
         L.call("nirgan_wino6_gemm", C.byref(d), None)
         torch.cuda.synchronize()
         Ms[x3] = M
