@@ -658,6 +658,13 @@ int nirgan_inject_bwd(const nirgan_inject_bwd_desc* d, void* stream);
 int nirgan_colsum(const float* x, int64_t rows, int cols, float* out, int accumulate, void* stream);
 
 /* misc stream-ordered helpers */
+/* ResnetGenerator_inject's optional post-correction (model/generator_inject.py:97-100,133-134: `x = x * self.post_correction_param`, a
+ * learnable 0-dim parameter): out[i] = x[i] * (*param); the parameter is read from device memory (it changes with every optimizer step).
+ * Backward: gx[i] = gout[i] * (*param) and *dparam += sum_i gout[i] * x[i] (x = the UNcorrected output; per-block partial sums in ws --
+ * at least min(1024, ceil(n / 256)) floats -- added in block order: bitwise reproducible; the caller zeroes dparam first). */
+int nirgan_param_scale_fwd(const float* x, const float* param, float* out, int64_t n, void* stream);
+int nirgan_param_scale_bwd(const float* gout, const float* x, const float* param, float* gx, float* dparam, float* ws, int64_t ws_elems,
+                           int64_t n, void* stream);
 int nirgan_fill(float* dst, int64_t n, float value, void* stream);
 int nirgan_axpy(float* y, const float* x, int64_t n, float alpha, void* stream);   /* y += alpha*x */
 

@@ -217,6 +217,28 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 }
 
 
+// model/generator_inject.py:133-134: x * post_correction_param (a learnable 0-dim parameter read from device memory)
+__global__ __launch_bounds__(256) void param_scale_fwd_kernel(const float* __restrict__ x, const float* __restrict__ param, float* __restrict__ out, int64_t n) {
+    const float c = *param;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) out[i] = x[i] * c;
+}
+// its backward: gx = gout * c; ws[block] = sum over the block's elements of gout * x (block order fixed: summed by ng_partials_finish)
+__global__ __launch_bounds__(256) void param_scale_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ x, const float* __restrict__ param,
+                                                               float* __restrict__ gx, float* __restrict__ ws, int64_t n) {
+    __shared__ float red[4];
+    const float c = *param;
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+        const float g = gout[i];
+        gx[i] = g * c;
+        acc += g * x[i];
+    }
+    acc = ng_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // per-block partial sums -> dst, fixed association (see common.h::ng_partials_finish)
 __global__ __launch_bounds__(256) void partials_finish_kernel(const float* __restrict__ ws, int rows, int nv, float* dst) {
     __shared__ float part[4][8];
@@ -296,6 +318,22 @@ extern "C" int nirgan_inject_bwd(const nirgan_inject_bwd_desc* d, void* stream) 
     hipLaunchKernelGGL(inject_bwd_kernel, dim3(int(g)), dim3(256), 0, static_cast<hipStream_t>(stream), p, npix);
     if (d->dscale) return ng_partials_finish(d->ws, int(g), 1, d->dscale, static_cast<hipStream_t>(stream));
     return nirgan_check_launch("inject_bwd");
+}
+
+extern "C" int nirgan_param_scale_fwd(const float* x, const float* param, float* out, int64_t n, void* stream) {
+    NG_REQUIRE(x && param && out && n > 0, "param_scale_fwd: bad arguments");
+    hipLaunchKernelGGL(param_scale_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, param, out, n);
+    return nirgan_check_launch("param_scale_fwd");
+}
+
+extern "C" int nirgan_param_scale_bwd(const float* gout, const float* x, const float* param, float* gx, float* dparam, float* ws, int64_t ws_elems,
+                                      int64_t n, void* stream) {
+    NG_REQUIRE(gout && x && param && gx && dparam && ws && n > 0, "param_scale_bwd: bad arguments");
+    int64_t g = (n + 255) / 256;
+    g = g < 1024 ? g : 1024;                        // (a fixed grid for a fixed n: the partial sums' association never changes)
+    NG_REQUIRE(ws_elems >= g, "param_scale_bwd: workspace holds %lld floats, %lld needed", (long long)ws_elems, (long long)g);
+    hipLaunchKernelGGL(param_scale_bwd_kernel, dim3(int(g)), dim3(256), 0, static_cast<hipStream_t>(stream), gout, x, param, gx, ws, n);
+    return ng_partials_finish(ws, int(g), 1, dparam, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int nirgan_colsum(const float* x, int64_t rows, int cols, float* out, int accumulate, void* stream) {

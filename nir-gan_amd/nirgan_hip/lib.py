@@ -228,6 +228,8 @@ PROTOTYPES = {
     "nirgan_bilinear_bwd": (i32, [fp, i32, i32, i32, fp, i32, i32, fp]),
     "nirgan_inject_fwd": (i32, [C.POINTER(InjectFwdDesc), fp]),
     "nirgan_inject_bwd": (i32, [C.POINTER(InjectBwdDesc), fp]),
+    "nirgan_param_scale_fwd": (i32, [fp, fp, fp, i64, fp]),
+    "nirgan_param_scale_bwd": (i32, [fp, fp, fp, fp, fp, fp, i64, i64, fp]),
     "nirgan_colsum": (i32, [fp, i64, i32, fp, i32, fp]),
     "nirgan_fill": (i32, [fp, i64, f32, fp]),
     "nirgan_axpy": (i32, [fp, fp, i64, f32, fp]),

@@ -121,6 +121,11 @@ class GeneratorEngine(_Engine):
         il = lay["last"]
         self.last = TapPlaneConv(self, "last", self.U2.out, P(il, "weight"), P(il, "bias"), k=7, p=3, act=L.ACT_TANH, crop=data_pad)
         self.pred = self.last.dst
+        # generator_inject.py:97-100,133-134: the prediction times a learnable scalar behind the tanh
+        self.post_correction = inject is not None and bool(inject.get("post_correction"))
+        if self.post_correction:
+            self.pred_raw = self.pred
+            self.pred = torch.empty_like(self.pred_raw)
         self.lay = lay
 
         # ---------------- forward plan
@@ -137,8 +142,8 @@ class GeneratorEngine(_Engine):
         self.U1.emit_fwd(f, pk)
         self.U2.emit_fwd(f, pk)
         self.last.emit_fwd(f, pk)
-        if inject is not None and inject.get("post_correction"):
-            raise NotImplementedError("post_correction=True is not on the MI355X path yet")
+        if self.post_correction:
+            f.add("nirgan_param_scale_fwd", self.pred_raw.data_ptr(), self.params["post_correction_param"].data_ptr(), self.pred.data_ptr(), self.pred.numel())
         if need_backward:
             self._build_backward()
         # bf16 operand mode: activations / output gradients that every reader takes from the bf16 twin are stored as bf16 only
@@ -203,6 +208,14 @@ class GeneratorEngine(_Engine):
         ctx.rr_deferred = [] if OPT.batch_reduce else None      # the weight gradients' slab sums are collected and run as one launch per flush point
         self.last.alloc_bwd()
         self.dpred = self.last.dout
+        if self.post_correction:
+            # the loss writes the gradient wrt the CORRECTED prediction; the last layer's backward takes it times the parameter
+            self.dpred = torch.zeros_like(self.last.dout)
+            self.pc_ws = ctx.zeros(1024)
+            gpc = gr["post_correction_param"]
+            b.add("nirgan_fill", gpc.data_ptr(), 1, 0.0)
+            b.add("nirgan_param_scale_bwd", self.dpred.data_ptr(), self.pred_raw.data_ptr(), self.params["post_correction_param"].data_ptr(),
+                  self.last.dout.data_ptr(), gpc.data_ptr(), self.pc_ws.data_ptr(), self.pc_ws.numel(), self.dpred.numel())
         for layer in [self.L1]:
             layer.alloc_bwd(need_dgrad=False)
         for layer in [self.L2, self.L3, self.U1, self.U2] + [c for _, c1, c2 in self.blocks for c in (c1, c2)]:

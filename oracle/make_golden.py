@@ -261,10 +261,11 @@ def ns(**kw):
     return types.SimpleNamespace(**kw)
 
 
-def f_inject(name):
+def f_inject(name, post_correction=False, post_correction_init=1.0):
+    """post_correction=True (generator_inject.py:97-100,133-134: the prediction times a learnable scalar): fixture f1_inject_pc."""
     cfg = ns(base_configs=ns(input_nc=3, output_nc=1, ngf=8, netG="resnet_9blocks", norm="instance",
                              no_dropout=True, init_type="normal", init_gain=0.02),
-             satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
+             satclip=ns(satclip_inject_style="multiply", post_correction=post_correction, post_correction_init=post_correction_init,
                         scaling_param=True, scaling_param_init=0.01))
     torch.manual_seed(0)
     netG = ref_define_G_inject(cfg)
@@ -279,8 +280,8 @@ def f_inject(name):
     pG0, pD0 = sd(netG), sd(netD)
     rgb, nir, emb = synth(2, 40, 40, 100)     # inject map is 20x20 (seed chosen so that no ReLU input is within 1e-6 of 0)
     res = ref_train_batch(netG, netD, rgb, nir, embeds=emb)
-    close(O.generator_inject_forward(pG0, rgb, emb, 9), res["pred"], what="inject forward")
-    check_trainer(pG0, pD0, 9, rgb, nir, res, embeds=emb)
+    close(O.generator_inject_forward(pG0, rgb, emb, 9, post_correction=post_correction), res["pred"], what="inject forward")
+    check_trainer(pG0, pD0, 9, rgb, nir, res, embeds=emb, inject_cfg={"style": "multiply", "use_scale": True, "post_correction": post_correction})
     arrs = {"rgb": rgb.numpy(), "nir": nir.numpy(), "embeds": emb.numpy(), "fc_seed": np.int64(4321),
             "fc_weight_sum": pG0["fc.weight"].double().sum().numpy(),
             "fc_weight_abs": pG0["fc.weight"].double().abs().sum().numpy()}
@@ -476,6 +477,93 @@ def f7(name, L=10):
     print("wrote", name)
 
 
+def _load_ref_by_path(modname, relpath, stubs=()):
+    """A reference source file loaded by path with named modules pre-seeded as EMPTY modules.  Only for imports the code under test
+    never touches: a stub for an unused import is not a stand-in for arithmetic (nothing that computes is replaced)."""
+    import importlib.util
+    saved = {}
+    for name in stubs:
+        saved[name] = sys.modules.get(name)
+        m = types.ModuleType(name)
+        m.__path__ = []                                       # (importable as a package too)
+        sys.modules[name] = m
+    try:
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for name, old in saved.items():
+            if old is None:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = old
+    return mod
+
+
+def f8(name):
+    """utils/losses.py::emd_loss (:64-78) -- pure torch; the file's top-level `import kornia` (used by ssim_loss only, absent here) is
+    satisfied with an empty module.  Values and autograd gradients wrt `pred` in float32 (as the training step would evaluate it) and
+    float64, three shapes."""
+    mod = _load_ref_by_path("ref_losses", os.path.join("utils", "losses.py"), stubs=("kornia",))
+    arrs = {}
+    for i, shape in enumerate(((2, 1, 16, 16), (3, 1, 8, 12), (1, 1, 32, 32))):
+        g = torch.Generator().manual_seed(80 + i)
+        pred = torch.rand(*shape, generator=g, dtype=torch.float64)
+        target = (pred + 0.2 * torch.randn(*shape, generator=g, dtype=torch.float64)).clamp(0, 1)
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            p = pred.to(dt).clone().requires_grad_(True)
+            v = mod.emd_loss(p, target.to(dt))
+            gr, = torch.autograd.grad(v, p)
+            mine = O.emd_loss(pred.to(dt), target.to(dt))
+            close(mine, v.detach(), 1e-12 if dt == torch.float64 else 1e-6, f"emd_loss {shape} {tag}")
+            arrs[f"value_{tag}_{i}"] = v.detach().numpy()
+            arrs[f"grad_{tag}_{i}"] = gr.numpy()
+        arrs[f"pred_{i}"] = pred.numpy()
+        arrs[f"target_{i}"] = target.numpy()
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name)
+
+
+def f9(name):
+    """model/satclip/location_encoder.py::SirenNet (:73-151) -- pure torch + einops; the file's top-level
+    `import model.satclip.positional_encoding as PE` (used by get_positional_encoding only; the package pulls in pytorch_lightning and
+    the missing spherical_harmonics_ylm.py) is satisfied with empty modules.  A seeded SirenNet(100 -> 64 -> 64 -> 32) in float64,
+    eval mode (the reference runs the encoder frozen: model/pix2pix.py builds it through SatClIP_wrapper and never trains it): its
+    state_dict and its outputs on seeded inputs; the oracle's siren_forward is checked against it here."""
+    mod = _load_ref_by_path("ref_location_encoder", os.path.join("model", "satclip", "location_encoder.py"),
+                            stubs=("model.satclip", "model.satclip.positional_encoding"))
+    torch.manual_seed(90)
+    net = mod.SirenNet(dim_in=100, dim_hidden=64, dim_out=32, num_layers=2).double().eval()
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(12, 100, generator=g, dtype=torch.float64) * 0.3
+    with torch.no_grad():
+        y = net(x)
+    p = {"nnet." + k: v.detach().clone() for k, v in net.state_dict().items()}
+    close(O.siren_forward(p, x, 2), y, 1e-13, "SirenNet forward")
+    arrs = {"x": x.numpy(), "y": y.numpy()}
+    # the whole LocationEncoder.forward (:267-274) from reference parts: the reference's closed-form harmonics of fixture f6's
+    # coordinates (f6 holds them as the reference computed them) through this reference SirenNet
+    z6 = np.load(os.path.join(OUT, "f6_locenc.npz"))
+    with torch.no_grad():
+        y6 = net(torch.from_numpy(z6["Y10"]))
+    close(O.location_encoder_forward(p, torch.from_numpy(z6["lonlat"]), 10, 2, "closed-form"), y6, 1e-12, "LocationEncoder forward")
+    arrs["lonlat"] = z6["lonlat"]
+    arrs["y_lonlat"] = y6.numpy()
+    arrs.update({"siren/" + k: v.numpy() for k, v in p.items()})
+    # a wider / deeper one (the SatCLIP encoder's own sizes are 512 x 2 -> 256): 100 -> 3 x 48 -> 16
+    torch.manual_seed(92)
+    net3 = mod.SirenNet(dim_in=100, dim_hidden=48, dim_out=16, num_layers=3).double().eval()
+    with torch.no_grad():
+        y3 = net3(x)
+    p3 = {"nnet." + k: v.detach().clone() for k, v in net3.state_dict().items()}
+    close(O.siren_forward(p3, x, 3), y3, 1e-13, "SirenNet forward (3 layers)")
+    arrs["y3"] = y3.numpy()
+    arrs.update({"siren3/" + k: v.numpy() for k, v in p3.items()})
+    np.savez_compressed(os.path.join(OUT, name), **arrs)
+    print("wrote", name)
+
+
+
 def to_ns(x):
     if isinstance(x, dict):
         return types.SimpleNamespace(**{k: to_ns(v) for k, v in x.items()})
@@ -529,8 +617,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "f0":
         f0("f0_config.json")
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] in ("f1_legacy", "f7"):       # add one fixture without touching the others
-        {"f1_legacy": lambda: f1_legacy("f1_legacy.npz"), "f7": lambda: f7("f7_sh_analytic.npz")}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("f1_legacy", "f7", "f8", "f9", "f1_inject_pc"):       # add one fixture without touching the others
+        {"f1_legacy": lambda: f1_legacy("f1_legacy.npz"), "f7": lambda: f7("f7_sh_analytic.npz"), "f8": lambda: f8("f8_emd.npz"),
+         "f9": lambda: f9("f9_siren.npz"), "f1_inject_pc": lambda: f_inject("f1_inject_pc.npz", True, 0.8)}[sys.argv[1]]()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "f6":       # add the location-encoder fixture without touching the others
         f6("f6_locenc.npz")
@@ -538,9 +627,12 @@ if __name__ == "__main__":
     f1(6, "f1_g6_d.npz")
     f1(9, "f1_g9_rs_pad.npz", lam_rs=1.0, padding=10, H=44)
     f_inject("f1_inject.npz")
+    f_inject("f1_inject_pc.npz", True, 0.8)
     f3("f3_losses.npz")
     f5("f5_fullsize.npz")
     f6("f6_locenc.npz")
     f1_legacy("f1_legacy.npz")
     f7("f7_sh_analytic.npz")
+    f8("f8_emd.npz")
+    f9("f9_siren.npz")
     f0("f0_config.json")

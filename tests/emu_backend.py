@@ -1326,6 +1326,16 @@ class EmuBackend:
         o[:] = o + s if accumulate else s
         return 0
 
+    def nirgan_param_scale_fwd(self, x, param, out, n, stream=None):
+        arr(out, n)[:] = arr(x, n) * arr(param, 1)[0]
+        return 0
+
+    def nirgan_param_scale_bwd(self, gout, x, param, gx, dparam, ws, ws_elems, n, stream=None):
+        g = arr(gout, n)
+        arr(gx, n)[:] = g * arr(param, 1)[0]
+        arr(dparam, 1)[0] += np.float32(np.dot(g.astype(np.float64), arr(x, n).astype(np.float64)))
+        return 0
+
     def nirgan_fill(self, dst, n, value, stream=None):
         arr(dst, n)[:] = value
         return 0

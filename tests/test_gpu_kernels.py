@@ -510,6 +510,21 @@ def test_emd_loss_value_and_gradient(shape):
     assert torch.equal(again, emd_loss(pd, td).cpu())
 
 
+def test_emd_loss_against_the_references_vectors(golden_dir):
+    """nirgan_emd_loss against utils/losses.py::emd_loss of the REFERENCE itself (fixture f8: values and autograd gradients)."""
+    import os
+    from utils.losses import emd_loss
+    z = np.load(os.path.join(golden_dir, "f8_emd.npz"))
+    for i in range(3):
+        pred, target = torch.from_numpy(z[f"pred_{i}"]).float().to(DEV), torch.from_numpy(z[f"target_{i}"]).float().to(DEV)
+        close(emd_loss(pred, target).cpu().reshape(()), torch.from_numpy(z[f"value_f64_{i}"]).float(), 1e-3, "emd value")   # (float32 CDFs: see above)
+        pa = pred.clone().requires_grad_(True)
+        emd_loss(pa, target).backward()
+        ref = torch.from_numpy(z[f"grad_f64_{i}"]).float()
+        e = (pa.grad.cpu() - ref).norm() / ref.norm()
+        assert e < 1e-3, f"emd gradient {i}: rel L2 {e:.3e}"
+
+
 def test_location_encoder_kernel(golden_dir, tmp_path):
     """nirgan_location_encoder (fp64) against the reference's closed-form harmonics (fixture f6) and the oracle's
     Siren restatement; a SatCLIP-sized encoder (L = 10 -> 512 -> 512 -> 256, B = 32) against the oracle."""
@@ -539,6 +554,14 @@ def test_location_encoder_kernel(golden_dir, tmp_path):
     p = {"nnet." + k: v.detach().cpu() for k, v in enc.nnet.state_dict().items()}
     ref = O.location_encoder_forward(p, ll, 10, 2, "analytic")
     assert got.dtype == torch.float64 and (got - ref).abs().max().item() < 1e-11 * max(ref.abs().max().item(), 1.0)
+    # the reference's own SirenNet (fixture f9: its seeded state_dict) behind the reference's closed-form harmonics: the whole
+    # LocationEncoder.forward from reference parts
+    z9 = np.load(os.path.join(golden_dir, "f9_siren.npz"))
+    enc9 = LocationEncoder(get_positional_encoding("sphericalharmonics", 10, "closed-form"), get_neural_network("siren", 100, 32, 64, 2)).double().eval()
+    enc9.nnet.load_state_dict({k[len("siren/nnet."):]: torch.from_numpy(z9[k]) for k in z9.files if k.startswith("siren/nnet.")})
+    got = enc9.to(DEV)(torch.from_numpy(z9["lonlat"]).to(DEV)).cpu()
+    want = torch.from_numpy(z9["y_lonlat"])
+    assert (got - want).abs().max().item() < 1e-11 * max(want.abs().max().item(), 1.0)
 
 
 @pytest.mark.parametrize("shape,ties", [((2, 1, 64, 64), False), ((1, 1, 256, 256), False), ((1, 1, 50, 70), False),

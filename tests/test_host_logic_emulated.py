@@ -156,31 +156,35 @@ def regen_fc(z):
     return torch.randn(16384, 256, generator=g) * 0.02, torch.randn(16384, generator=g) * 0.02
 
 
-def inject_config():
+def inject_config(post_correction=False, post_correction_init=1.0):
     ns = types.SimpleNamespace
     return ns(base_configs=ns(input_nc=3, output_nc=1, ngf=8, netG="resnet_9blocks", norm="instance", no_dropout=True,
                               init_type="normal", init_gain=0.02),
-              satclip=ns(satclip_inject_style="multiply", post_correction=False, post_correction_init=1.0,
+              satclip=ns(satclip_inject_style="multiply", post_correction=post_correction, post_correction_init=post_correction_init,
                          scaling_param=True, scaling_param_init=0.01))
 
 
-def test_inject_generator_trainer(emu, golden_dir, capsys):
+@pytest.mark.parametrize("name,pc", [("f1_inject.npz", False), ("f1_inject_pc.npz", True)])
+def test_inject_generator_trainer(emu, golden_dir, capsys, name, pc):
+    """(f1_inject_pc: post_correction=True, generator_inject.py:97-100,133-134 -- the prediction times a learnable scalar, init 0.8)"""
     from model import networks
     from model.generator_inject import define_G_inject
     from nirgan_hip.trainer import Pix2PixTrainer
-    z = load(golden_dir, "f1_inject.npz")
-    netG = define_G_inject(inject_config())
+    z = load(golden_dir, name)
+    netG = define_G_inject(inject_config(pc, 0.8))
     sd = sub(z, "G0/")
     sd["fc.weight"], sd["fc.bias"] = regen_fc(z)
     netG.load_state_dict(sd)
     netD = networks.define_D(4, 8, "basic", 3, "instance", "normal", 0.02)
     netD.load_state_dict(sub(z, "D0/"))
     rgb, nir, emb = (torch.from_numpy(z[k]) for k in ("rgb", "nir", "embeds"))
-    tr = Pix2PixTrainer(netG, netD, n_blocks=9, inject={"style": "multiply", "use_scale": True})
+    tr = Pix2PixTrainer(netG, netD, n_blocks=9, inject={"style": "multiply", "use_scale": True, "post_correction": pc})
     out = tr.step(rgb, nir, emb).as_dict()
     close(tr.G.pred, z["pred"], 2e-5, "pred")
     close(out["loss_G"], z["loss_G"], 1e-5, "loss_G")
     g = tr.flatG.grad_views()
+    if pc:
+        close(g["post_correction_param"].reshape(()), z["gG/post_correction_param"], 2e-4, "dpost_correction_param")
     close(g["scale_param"], z["g_scale_param"], 2e-4, "dscale")
     close(g["fc.bias"], z["g_fc_bias"], 2e-4, "dfc.bias")
     close(g["fc.weight"][:8], z["g_fc_weight_rows0_8"], 2e-4, "dfc.weight")
