@@ -532,7 +532,16 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     T = _w6_tiles(B, H, W, v)
     NP = _w6_geo(v)[1]
     U = U3 = None
-    if ctx.precision == 0 and OPT.split3 and OPT.split3_wino and cin % 32 == 0 and cout % 64 == 0:
+    want_x3 = ctx.precision == 0 and OPT.split3 and OPT.split3_wino and cin % 32 == 0 and cout % 64 == 0
+    if want_x3 and not L.is_emulated():
+        # the library decides (32-bit offsets, plane sizes: wino6.hip::w6_x3): ask it with the planes pretended present -- where it says
+        # no, U is allocated and the exact-fp32 tile takes the layer instead of a launch failing with "U is required"
+        probe = L.Wino6Desc()
+        probe.r, probe.B, probe.H, probe.W, probe.C, probe.K = v, B, H, W, cin, cout
+        probe.U3, probe.V, probe.V_elems, probe.M, probe.M_elems = ctx.zero_page.data_ptr(), ctx.zero_page.data_ptr(), NP * T * cin, ctx.zero_page.data_ptr(), NP * T * cout
+        probe.zero_page = ctx.zero_page.data_ptr()
+        want_x3 = (L.backend().nirgan_wino6_gemm_kernel_name(C.byref(probe)) or b"").startswith(b"conv_x3")
+    if want_x3:
         # precision 3 for the plane GEMMs (csrc/igemm_x3.h): U as three bf16 planes ONLY -- the split tile reads nothing else and the
         # transform-domain weight gradient needs no U (6 instead of 10 bytes per transformed weight and step)
         U3 = torch.zeros(3 * NP * cout * cin, dtype=torch.bfloat16, device=ctx.device)
@@ -686,7 +695,8 @@ def attach_conv_stats(ctx: Ctx, descs: list, bias) -> Optional[tuple]:
     # worth it from ~16 K pixels per sample in fp32 (the 128x128 and 256x256 layers save 16 / 54 us of statistics pass each; the trunk is
     # Winograd there) and from 4 K in the bf16 operand mode (its 64x64 trunk maps run on the direct tiles: 1436 -> 1453 tiles/s); below, the pass
     # costs 2-4 us and the layer keeps it (OPT.epilogue_min_pixels: the kernel tests run small layers through it)
-    if sum(d.OH * d.OW for d in descs) < (OPT.epilogue_min_pixels if ctx.precision == 0 else min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16)):
+    # (a paired launch -- out_span = 2 -- writes two output pixels per GEMM row: counted as the pixels they are)
+    if sum(d.OH * d.OW * max(1, d.out_span) for d in descs) < (OPT.epilogue_min_pixels if ctx.precision == 0 else min(OPT.epilogue_min_pixels, OPT.epilogue_min_pixels_bf16)):
         return None
     B, N = descs[0].B, channels_of(descs[0])
     recs = [d.OH * d.OW // 64 * max(1, d.out_span) for d in descs]       # (a paired problem leaves two records per 64 rows)
