@@ -210,13 +210,24 @@ def predict_scaling(tr, ms1: float, tiles_per_rank: int):
     data-parallel step from quantities measured on ONE GPU plus an explicit model of the two exposed all-reduces.  Every input is in the
     block; nothing here is a measurement of N > 1."""
     def buckets(eng, flat):
-        index, first, last = eng.bwd_tail
-        lo = flat.slices[first][0]
-        o, k, _ = flat.slices[last]
-        hi = min(flat.total, o + -(-k // 4) * 4)
-        return 4 * (hi - lo), 4 * (flat.total - (hi - lo))
-    tailG, headG = buckets(tr.G, tr.flatG)
-    tailD, headD = buckets(tr.D2, tr.flatD)
+        """bytes of the tail / middle / head bucket (trainer._hook_tail: the head is the first layer's gradient only)"""
+        def span(first, last):
+            lo = flat.slices[first][0]
+            o, k, _ = flat.slices[last]
+            return lo, min(flat.total, o + -(-k // 4) * 4)
+        lo, hi = span(*eng.bwd_tail[1:])
+        head = 0
+        if getattr(eng, "bwd_mid", None) is not None:
+            hlo, hhi = span(*eng.bwd_mid[1:])
+            head = hhi - hlo
+        else:
+            head = flat.total - (hi - lo)
+        return 4 * (hi - lo), 4 * (flat.total - (hi - lo) - head), 4 * head
+    tailG, midG, headG = buckets(tr.G, tr.flatG)
+    tailD, midD, headD = buckets(tr.D2, tr.flatD)
+    # what covers the middle buckets: the first layer's backward (its weight gradient and slab sum), measured per op on one GPU
+    # (profiles/r05_per_op_times.txt: generator 7x7 weight gradient 0.21 ms + reduce; PatchGAN first layer's weight gradient 0.1 ms)
+    cover_mid_G_ms, cover_mid_D_ms = 0.25, 0.12
     # one rank over RCCL against the plain run, same box (scripts/refresh_profiles.sh: *_bench_rccl_one_rank / *_bench_final): the fixed
     # cost of going through torch.distributed (stream waits, two async launches per network)
     fixed_ms, src = 0.18, "profiles/r04_bench_rccl_one_rank.json.log vs r04_bench_final.json.log (19.29 vs 19.11 ms)"
@@ -239,19 +250,23 @@ def predict_scaling(tr, ms1: float, tiles_per_rank: int):
             # ring all-reduce: 2 (n - 1) steps of nbytes / n each; over the fully connected mesh min(n - 1, links) rings run on disjoint links
             rings = min(n - 1, links)
             return 2 * (n - 1) * (lat_us * 1e-3 + (nbytes / n / rings) / (link_gbps * eff * 1e9) * 1e3)
-        exposed = allreduce_ms(headG) + allreduce_ms(headD)          # the head buckets start after their backward plans: nothing covers them
+        # the head buckets (the first layers' gradients) start after their backward plans: nothing covers them; the middle buckets
+        # start in front of the first layer's backward: exposed by what that backward does not cover
+        exposed = (allreduce_ms(headG) + allreduce_ms(headD) + max(0.0, allreduce_ms(midG) - cover_mid_G_ms) + max(0.0, allreduce_ms(midD) - cover_mid_D_ms))
         hidden = allreduce_ms(tailG) + allreduce_ms(tailD)           # the tails run under the rest of the backward plans
         ms = ms1 + fixed_ms + exposed
         res.append({"n_gpus": n, "ms_per_step": round(ms, 3), "tiles_per_s": round(n * tiles_per_rank / ms * 1e3, 1),
                     "weak_scaling_efficiency": round(ms1 / ms, 4), "exposed_allreduce_ms": round(exposed, 4), "tail_allreduce_ms_under_backward": round(hidden, 4)})
-    return {"what": "PREDICTED from one-GPU measurements + a stated all-reduce model; not a measurement of N > 1",
+    return {"what": "PREDICTED from one-GPU measurements + a stated all-reduce model; not a measurement of N > 1 (with more than one rank the "
+                    "line carries `measured_vs_predicted`: this run's own numbers beside the entry for its N)",
             "by_n_gpus": res,
             "inputs": {"ms_per_step_1gpu": round(ms1, 3), "rccl_fixed_ms_per_step": round(fixed_ms, 3), "rccl_fixed_source": src,
-                       "bucket_bytes": {"G_tail": tailG, "G_head": headG, "D_tail": tailD, "D_head": headD},
+                       "bucket_bytes": {"G_tail": tailG, "G_mid": midG, "G_head": headG, "D_tail": tailD, "D_mid": midD, "D_head": headD},
+                       "mid_bucket_cover_ms": {"G": cover_mid_G_ms, "D": cover_mid_D_ms},
                        "xgmi": {"links_per_gpu": links, "gbps_per_link": link_gbps, "assumed_ring_efficiency": eff, "assumed_latency_us_per_ring_step": lat_us}},
-            "model": "ms(N) = ms(1) + fixed RCCL cost + all-reduce(head bucket of G) + all-reduce(head bucket of D); all-reduce(b) = 2 (N - 1) x "
-                     "(latency + b / N / min(N - 1, 7) rings / (153 GB/s x efficiency)); the tail buckets (started inside the backward plans) are "
-                     "assumed hidden: their modelled time is listed next to the backward they run under"}
+            "model": "ms(N) = ms(1) + fixed RCCL cost + sum over G, D of [all-reduce(head bucket) + max(0, all-reduce(middle bucket) - the first "
+                     "layer's backward)]; all-reduce(b) = 2 (N - 1) x (latency + b / N / min(N - 1, 7) rings / (153 GB/s x efficiency)); the tail "
+                     "buckets (started inside the backward plans) are assumed hidden: their modelled time is listed next to the backward they run under"}
 
 
 def host_cores() -> int:
@@ -416,6 +431,9 @@ def main():
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--verify-dp", action="store_true",
                     help="before timing: N-rank averaged gradients == single-process gradients on the concatenated batch")
+    ap.add_argument("--no-verify-dp", action="store_true",
+                    help="with more than one rank the check of --verify-dp runs by default (one extra step before the timing; a failure is "
+                         "REPORTED in the JSON line, `dp_verify.ok`, and only fatal with an explicit --verify-dp): this switches it off")
     ap.add_argument("--verify-tol", type=float, default=1e-4, help="relative L2 bound of --verify-dp (measured values are in the JSON)")
     ap.add_argument("--ngf", type=int, default=64, help="network width (64 = the reference's; smaller only for the CPU launch test)")
     ap.add_argument("--emulate-cpu", action="store_true",
@@ -479,11 +497,20 @@ def main():
                               inject=inject, reducer=red, precision=a.precision, micro_batches=a.micro)
     rgb, nir = synth(a.bs, a.size, a.size, 1234 + rank, dev)
     dp_check = None
-    if a.verify_dp:
+    # the first real multi-GPU run checks itself: with more than one rank the gradient check runs unless switched off (mixed-resolution
+    # ranks hold different shapes: no concatenated batch to compare with)
+    auto_verify = reducer is not None and world > 1 and not a.no_verify_dp and not a.mixed
+    if a.verify_dp or auto_verify:
         if reducer is None:
             sys.exit("bench.py: --verify-dp needs more than one rank (or NIRGAN_FORCE_DIST=1)")
-        dp_check = verify_dp(a, dev, rank, world, reducer, netG, netD, make_trainer, rgb, nir, embeds)
-        if not dp_check["ok"]:
+        try:
+            dp_check = verify_dp(a, dev, rank, world, reducer, netG, netD, make_trainer, rgb, nir, embeds)
+        except Exception as exc:            # (the default check must never cost the measurement)
+            if a.verify_dp:
+                raise
+            dp_check = {"ok": False, "error": repr(exc)}
+        dp_check["requested"] = "--verify-dp" if a.verify_dp else "default with more than one rank"
+        if not dp_check["ok"] and a.verify_dp:
             print(json.dumps({"dp_verify": dp_check}), flush=True)
             sys.exit(f"bench.py: data-parallel gradients differ from the single-process gradients: {dp_check}")
     tr = make_trainer(reducer)          # with a reducer: broadcasts rank 0's weights first (what DDP does at wrap time)
@@ -647,6 +674,31 @@ def main():
         rank_ms = [round(float(x[0]), 3) for x in allt]
         comm_ms = [round(float(x[1]), 4) for x in allt]
         dt = max(float(x[0]) for x in allt) * a.steps / 1e3          # MAX over ranks
+    # ---- the same steps WITHOUT the collectives, in this process on this rank's own shard (a second trainer with no reducer): what the
+    # step costs when nothing is exchanged -- measured here instead of taken from another run, so that `measured - no_comm` is this
+    # node's communication cost and the `predicted` line has its own one-GPU input
+    nocomm_ms = None
+    if reducer is not None and world > 1 and pl_model is None and not a.mixed and a.micro == 1:
+        try:
+            solo = make_trainer(None)
+            for _ in range(2):
+                solo.step(rgb, nir, embeds)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                solo.step(rgb, nir, embeds)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            mine = torch.tensor([(time.perf_counter() - t1) / a.steps * 1e3], device=dev, dtype=torch.float64)
+            alln = [torch.empty_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(alln, mine)
+            nocomm_ms = [round(float(x[0]), 3) for x in alln]
+            del solo
+            # (the solo steps moved each rank's weights apart: put rank 0's back before anything else runs on them)
+            reducer.broadcast_params(netG._flat())
+            reducer.broadcast_params(netD._flat())
+        except Exception as exc:
+            nocomm_ms = {"error": repr(exc)}
     sched_by_rank = None
     if a.mixed:
         # configs[4]'s load balance: which bucket every rank's timed steps drew (first one = where the rank started)
@@ -843,14 +895,30 @@ def main():
             out["collective_backend"] = None
             out["ms_per_step_by_rank"] = [round(ms, 3)]
             out["comm_exposed_ms_per_step_by_rank"] = [0.0]
+        if isinstance(nocomm_ms, list):
+            out["ms_per_step_no_comm_by_rank"] = nocomm_ms
+        elif nocomm_ms is not None:
+            out["ms_per_step_no_comm_by_rank"] = nocomm_ms
         if pl_model is None and not a.mixed and a.micro == 1 and not a.emulate_cpu:
             try:
-                out["predicted"] = predict_scaling(tr, ms if world == 1 else min(rank_ms), a.bs)
+                # (N > 1: the model's one-GPU input is THIS run's no-communication leg, not the N-rank time)
+                ms1 = ms if world == 1 else (min(nocomm_ms) if isinstance(nocomm_ms, list) else min(rank_ms))
+                out["predicted"] = predict_scaling(tr, ms1, a.bs)
+                if world > 1:
+                    mine = [r for r in out["predicted"]["by_n_gpus"] if r["n_gpus"] == world]
+                    # measured beside predicted for THIS N: the record is evidence of the model's error as well as of the speed
+                    out["measured_vs_predicted"] = {
+                        "n_gpus": world, "measured_ms_per_step": round(ms, 3), "measured_no_comm_ms_per_step": ms1,
+                        "measured_comm_cost_ms": round(ms - ms1, 3), "measured_exposed_wait_ms_max_rank": max(comm_ms) if comm_ms else None,
+                        "measured_weak_scaling_efficiency_vs_no_comm": round(ms1 / ms, 4),
+                        "predicted": mine[0] if mine else None,
+                        "note": "efficiency against this run's own no-communication leg (same process, same GPUs); the driver computes the "
+                                "efficiency against the N = 1 run itself"}
             except Exception as exc:              # (never lose the measured line to the model)
                 out["predicted"] = {"error": repr(exc)}
         if reducer is not None:
-            out["comm"] = ("two gradient buckets per network (tail started inside the backward plan, head after it); exposed = launch-stream "
-                           "time spent waiting for the collectives before each Adam step (HIP events)")
+            out["comm"] = ("three gradient buckets per network (tail and middle started inside the backward plan, the first layer's gradient -- "
+                           "16 / 38 KB -- after it); exposed = launch-stream time spent waiting for the collectives before each Adam step (HIP events)")
         if dp_check is not None:
             out["dp_verify"] = dp_check
         if a.micro > 1:

@@ -263,8 +263,12 @@ class GeneratorEngine(_Engine):
         else:
             dz2 = self._emit_inject_bwd(b, g_a2)
             self.L2.emit_bwd(b, pk, g=dz2, gw=GW(4), gb=GW(4, "bias"), dgrad_out=g_a1, act=L.ACT_NONE)
+        # data parallel: everything but the FIRST layer's gradient is final here (the two stride-2 layers, the SatCLIP projection): the
+        # middle bucket goes out under the first layer's backward; only model.1.* (38 KB) is left for after the plan
+        emit_deferred_reduce_rows(b, ctx, last=False)
+        self.bwd_mid = (len(b.ops), "model.1.weight", "model.1.bias")
         self.L1.emit_bwd(b, pk, g=g_a1, gw=GW(1), gb=GW(1, "bias"), dgrad_out=None)
-        emit_deferred_reduce_rows(b, ctx)         # the encoder's slab sums (the data-parallel head bucket)
+        emit_deferred_reduce_rows(b, ctx)         # the first layer's slab sum (the data-parallel head bucket)
 
     # ------------------------------------------------------------------ run
     def forward(self, rgb: torch.Tensor, embeds: Optional[torch.Tensor] = None, version: int = 0) -> torch.Tensor:
@@ -346,6 +350,9 @@ class DiscriminatorEngine(_Engine):
                 self.bwd_tail = (len(plan.ops), "model.8.weight", "model.11.bias")
             self.C3.emit_bwd(plan, pk, g=self.g3p, g_fold=False, gw=GW(5), gb=GW(5, "bias"), dgrad_out=self.g2)
             self.C2.emit_bwd(plan, pk, g=self.g2, gw=GW(2), gb=GW(2, "bias"), dgrad_out=self.g1)
+            if not frozen:   # data parallel: all but the first layer's gradient (16 KB) is final here -- the middle bucket
+                emit_deferred_reduce_rows(plan, ctx, last=False)
+                self.bwd_mid = (len(plan.ops), "model.0.weight", "model.0.bias")
             self.C1.emit_bwd(plan, pk, g=self.g1, gw=GW(0), gb=GW(0, "bias"), dgrad_out=self.gx4 if mode == "input" else None)
             if not frozen:
                 emit_deferred_reduce_rows(plan, ctx)

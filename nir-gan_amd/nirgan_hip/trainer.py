@@ -96,9 +96,9 @@ class _ShapeState:
             self.micros.append(_Micro(tr, i * per, (i + 1) * per, H, W, gG, gD, 1.0 / n))
         dev = tr.flatG.flat.device
         self.streams = [None] + [torch.cuda.Stream(dev) if dev.type == "cuda" else None for _ in range(n - 1)]
-        # data parallel, single part: two gradient buckets per network -- the tail of the flat gradient goes to RCCL from inside
-        # the backward plan, as soon as the launches that complete it are on the stream (parallel.GradReducer.begin); the head
-        # follows after the plan.  With micro-batches the side parts are added after the plans: one bucket, after the join.
+        # data parallel, single part: three gradient buckets per network -- the tail of the flat gradient goes to RCCL from inside
+        # the backward plan, as soon as the launches that complete it are on the stream (parallel.GradReducer.begin), the middle in
+        # front of the first layer's backward; only the first layer's gradient (the head) follows after the plan.  With micro-batches the side parts are added after the plans: one bucket, after the join.
         self.bucketed = tr.reducer is not None and n == 1 and OPT.dp_buckets
         self.headD = self.headG = None
         if self.bucketed:
@@ -108,15 +108,34 @@ class _ShapeState:
 
     @staticmethod
     def _hook_tail(tr, eng, flat):
-        """Insert the tail bucket's ``begin`` into eng.bwd; returns the complementary slices of the flat gradient."""
+        """Insert the ``begin`` of the tail bucket and of the middle bucket into eng.bwd (three buckets per network: the tail as soon as
+        the last layers' gradients are final, the middle -- everything else but the FIRST layer's gradient -- in front of the first
+        layer's backward); returns what is left for after the plan: the first layer's slice of the flat gradient (16 / 38 KB)."""
+        def span(first, last):
+            lo = flat.slices[first][0]
+            o, k, _ = flat.slices[last]
+            hi = min(flat.total, o + -(-k // 4) * 4)
+            assert 0 <= lo < hi <= flat.total
+            return lo, hi
         index, first, last = eng.bwd_tail
-        lo = flat.slices[first][0]
-        o, k, _ = flat.slices[last]
-        hi = min(flat.total, o + -(-k // 4) * 4)
-        assert 0 <= lo < hi <= flat.total
+        lo, hi = span(first, last)
         tail = flat.grad[lo:hi]
         eng.bwd.insert_hook(index, lambda: tr.reducer.begin(tail))
-        return [part for part in (flat.grad[:lo], flat.grad[hi:]) if part.numel()]
+        rest = [(0, lo), (hi, flat.total)]                 # what the tail leaves, as index ranges
+        mid = getattr(eng, "bwd_mid", None)
+        if mid is None:
+            return [flat.grad[a:b] for a, b in rest if b > a]
+        mindex, hfirst, hlast = mid
+        hlo, hhi = span(hfirst, hlast)
+        assert mindex >= index and not (hlo < hi and lo < hhi), "the head bucket lies outside the tail"
+        parts = []
+        for a, b in rest:                                  # the ranges minus the head
+            for c, d in ((a, min(b, hlo)), (max(a, hhi), b)):
+                if d > c:
+                    parts.append(flat.grad[c:d])
+        if parts:
+            eng.bwd.insert_hook(mindex, lambda: [tr.reducer.begin(p_) for p_ in parts])
+        return [flat.grad[hlo:hhi]]
 
 
 class _on_stream:

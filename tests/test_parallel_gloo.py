@@ -65,7 +65,10 @@ def _worker(rank, world, port, out_dir, micro, perturb=False):
         assert not tr._state.bucketed and not any(n == "__hook__" for n, _ in tr.G.bwd.ops)
     elif micro == 1:                   # two buckets per network: the tail went out from inside the backward plans
         assert tr._state.bucketed and any(n == "__hook__" for n, _ in tr.G.bwd.ops) and any(n == "__hook__" for n, _ in tr.D2.bwd.ops)
-        assert sum(p_.numel() for p_ in tr._state.headG) < 0.2 * tr.flatG.total and not red._pending
+        # ... and the middle from in front of the first layer's backward: what is left for after the plan is the first layer's gradient only
+        assert sum(1 for n, _ in tr.G.bwd.ops if n == "__hook__") == 2 and sum(1 for n, _ in tr.D2.bwd.ops if n == "__hook__") == 2
+        assert sum(p_.numel() for p_ in tr._state.headG) == sum(tr.flatG.slices[k][1] for k in ("model.1.weight", "model.1.bias"))
+        assert sum(p_.numel() for p_ in tr._state.headD) == sum(tr.flatD.slices[k][1] for k in ("model.0.weight", "model.0.bias")) and not red._pending
     torch.save({"gD": tr.flatD.grad.clone(), "gG": tr.flatG.grad.clone(), "pD": tr.flatD.flat.clone(),
                 "pG": tr.flatG.flat.clone(), "loss": out}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
