@@ -69,12 +69,16 @@ def test_bucketed_fused_step_over_rccl_matches_the_plain_step(nccl_world1):
     torch.cuda.synchronize()
     st = tr._state
     assert st.bucketed and st.headG is not None and st.headD is not None
-    # the tail buckets were started from INSIDE the backward plans (hooks), the heads after them: 2+ begins per network
+    # the tail and the middle buckets were started from INSIDE the backward plans (hooks), the heads -- the first layers' gradients
+    # only -- after them: 3 begins per network
     nD, nG = tr.flatD.total, tr.flatG.total
     headD, headG = sum(p.numel() for p in st.headD), sum(p.numel() for p in st.headG)
-    assert 0 < headG < 0.2 * nG and 0 < headD < 0.3 * nD, (headG, nG, headD, nD)
-    assert len(begun) >= 4 and sum(n for _, n in begun) == nD + nG, (begun, nD, nG)
-    assert any(n == nG - headG for _, n in begun) and any(n == nD - headD for _, n in begun), "tail buckets missing"
+    assert headG == sum(tr.flatG.slices[k][1] for k in ("model.1.weight", "model.1.bias")) and headD == sum(tr.flatD.slices[k][1] for k in ("model.0.weight", "model.0.bias"))
+    assert len(begun) == 6 and sum(n for _, n in begun) == nD + nG, (begun, nD, nG)
+    tailG = tr.flatG.total - tr.flatG.slices["model.10.conv_block.1.weight"][0]
+    tailD = tr.flatD.total - tr.flatD.slices["model.8.weight"][0]
+    sizes = [n for _, n in begun]
+    assert sizes[:3] == [tailD, nD - tailD - headD, headD] and sizes[3:] == [tailG, nG - tailG - headG, headG], (sizes, tailD, tailG)
     assert len(red.exposed_events) == 2 and all(e0.elapsed_time(e1) >= 0.0 for e0, e1 in red.exposed_events)
     assert not red._pending
     for k in o_plain:
