@@ -9,9 +9,11 @@
 //     the block tile is consumed by ONE wave, so that wave fetches it, splits it into the three bf16 terms in registers and multiplies:
 //     no ds_write of converted rows, no fragment reads of A, no barrier between conversion and use.  LDS traffic per K-tile and CU:
 //     96 KB of B fragment reads + 24 KB of LDS-DMA against 192 KB + 72 KB of the eight-wave tile.
-//   * B (the three bf16 planes of the packed weights) goes through a FOUR-stage LDS-DMA ring, three K-tiles ahead; ONE barrier per
-//     K-tile in the MIDDLE of the tile (it publishes tile j + 1 and frees the stage of tile j - 1 for the DMA of tile j + 3), none at
-//     the tile boundaries: the MFMA stream runs from one K-tile into the next -- and from one item into the next -- without a stop.
+//   * B (the three bf16 planes of the packed weights) is staged through REGISTERS into two LDS stages: six global_load_dwordx4 per wave
+//     and K-tile, one tile ahead, six ds_write_b128 a tile later (an LDS-DMA piece costs the issuing wave ~180 cycles among MFMAs --
+//     measured with in-kernel stamps, scripts/diag/x3r_stamps.* -- and with one wave per SIMD nothing else feeds the matrix pipe
+//     meanwhile).  ONE barrier per K-tile in the MIDDLE of the tile (it publishes K-tile j + 1), none at the tile boundaries: the MFMA
+//     stream runs from one K-tile into the next -- and from one item into the next -- without a stop.
 //   * mt-outer order with ROLLING operands: a K-tile is four blocks (one 16-row tile mt each) of NT x 6 MFMAs; all NT B fragments of
 //     the tile stay in registers (96 at BN = 128) and are replaced one by one behind their last use in block 3; A[mt] of the next
 //     K-tile is converted behind block mt (one raw buffer, refilled right behind its conversion).
@@ -19,7 +21,7 @@
 //     tile are final -- slice mt goes through a wave-private 8 KB staging block (no barrier) and leaves as whole rows under the MFMAs of
 //     the blocks that follow; only slice 3 runs after the tile.  One accumulator set, no copies.
 // Every vector-memory operation of the loop is issued unconditionally and in a fixed order (a loader past the end of its work re-reads
-// its last tile; the ring's DMA goes to a block of LDS nobody reads), so every s_waitcnt vmcnt(N) below is a constant of the schedule: N counts
+// its last tile), so every s_waitcnt vmcnt(N) below is a constant of the schedule: N counts
 // only operations that are ALWAYS issued behind the one waited for (the epilogue's stores are not counted: more operations in flight
 // than assumed only waits longer, never shorter).
 #pragma once
@@ -60,8 +62,8 @@ struct X3R {
     static constexpr int NT = BN / 16;                 // 16-column MFMA tiles of the wave tile (64 x BN)
     static constexpr int B_TERM = BN * 64;             // bytes of one term image of B ([BN rows][32 k] bf16)
     static constexpr int STAGE = 3 * B_TERM;
-    static constexpr int NSTAGE = 4;
-    static constexpr int RING = NSTAGE * STAGE;        // 96 KB at BN = 128
+    static constexpr int NSTAGE = 2;
+    static constexpr int RING = NSTAGE * STAGE;        // 48 KB at BN = 128
     static constexpr int STG = 16 * BN * 4;            // staging of one wave: 16 rows x BN floats
     static constexpr int BPT = BN / 16;                // 1 KB LDS-DMA pieces per term image
     static constexpr int PIECES = 3 * BPT / 4;         // pieces per wave and K-tile (6 / 3)
@@ -76,8 +78,31 @@ struct X3R {
 // the vector half is left to what VALU instructions touch: the raw rows, the split terms, the epilogue)
 #define X3R_DSR(dst, ad, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(ad), "n"(off) : "memory")
 
-template <int BN>
-__device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp, char* const ring, char* const stg_all, char* const sRed, char* const trash) {
+// One REGION of the K loop as ONE asm block: the six MFMAs of a (row tile, column tile) pair in the order of conv_x3_persist::mma
+// (al bh, ah bl, am bm, am bh, ah bm, ah bh), optionally interleaved by hand with the conversion of one pair of raw values into the
+// three bf16 terms (11 VALU, x3_split8's rule: two per MFMA gap), optionally behind a counted lgkmcnt wait, optionally followed by the
+// three fragment reads that replace this column tile's B terms.  The accumulator is "+a": it lives in the accumulator half of the
+// register file for the whole kernel (left to itself hipcc keeps a third of the accumulators in VGPRs and moves them back and forth
+// every K-tile).  Hazards: dependent MFMAs on one accumulator back to back are interlocked by the hardware; an MFMA's A / B operands
+// are read in its first passes (the VALU writes here go to OTHER registers: the next K-tile's terms); what reads an accumulator
+// behind the loop waits out the last MFMA explicitly (X3R_MFMA_DRAIN) -- the compiler does not know these are MFMAs.
+#define X3R_M(a, b) "v_mfma_f32_16x16x32_bf16 %[c], %[" #a "], %[" #b "], %[c]\n\t"
+#define X3R_MFMA6 X3R_M(al, b0) X3R_M(ah, b2) X3R_M(am, b1) X3R_M(am, b0) X3R_M(ah, b1) X3R_M(ah, b0)
+#define X3R_MFMA6_CONV \
+    X3R_M(al, b0) "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n\t" "v_lshlrev_b32 %[t0], 16, %[h]\n\t" \
+    X3R_M(ah, b2) "v_and_b32 %[t1], 0xffff0000, %[h]\n\t" "v_sub_f32 %[r0], %[x0], %[t0]\n\t" \
+    X3R_M(am, b1) "v_sub_f32 %[r1], %[x1], %[t1]\n\t" "v_cvt_pk_bf16_f32 %[m], %[r0], %[r1]\n\t" \
+    X3R_M(am, b0) "v_lshlrev_b32 %[t0], 16, %[m]\n\t" "v_and_b32 %[t1], 0xffff0000, %[m]\n\t" \
+    X3R_M(ah, b1) "v_sub_f32 %[r0], %[r0], %[t0]\n\t" "v_sub_f32 %[r1], %[r1], %[t1]\n\t" \
+    X3R_M(ah, b0) "v_cvt_pk_bf16_f32 %[l], %[r0], %[r1]\n\t"
+#define X3R_WAITL "s_waitcnt lgkmcnt(%[w])\n\t"
+#define X3R_READS "ds_read_b128 %[b0], %[bad] offset:%[o0]\n\t" "ds_read_b128 %[b1], %[bad] offset:%[o1]\n\t" "ds_read_b128 %[b2], %[bad] offset:%[o2]\n\t"
+#define X3R_MFMA_DRAIN asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+
+// GEN: the launch's problems leave instance-norm partial sums or run the fused first backward pass (their epilogue branches and needs
+// the accumulators in VGPRs: a kernel of its own, so that its register pressure is not the plain kernel's)
+template <int BN, bool GEN>
+__device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp, char* const ring, char* const stg_all, char* const sRed) {
     static_assert(BN == 128 || BN == 64, "256 x 128 or 256 x 64 block tiles");
     using T = X3R<BN>;
     constexpr int NT = T::NT, B_TERM = T::B_TERM, STAGE = T::STAGE, BPT = T::BPT, PIECES = T::PIECES, LPR = T::LPR, RPP = T::RPP, SP = T::SP;
@@ -143,64 +168,90 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         t.out = p->out + (long long)plane * wp->out_plane;
     };
 
-    // ---------------- the loader: a cursor THREE K-tiles ahead of the MFMAs, over the workgroup's items as one stream of K-tiles.
-    // The ring's DMA of K-tile j + 3 is issued from the cursor itself; the rows of K-tile j + 2 (row tiles 0-2) and of K-tile j + 1 (row
-    // tile 3, converted one block later than the rest of its tile) are fetched through SNAPSHOTS of the cursor one and two tiles old
-    // (a scalar base and the lane's row offsets): one raw buffer, refilled right behind its conversion, one K-tile of latency budget.
-    Item L;
-    int itemL = blockIdx.x;
-    bool live = true;                           // the cursor is on a K-tile that exists (past the end it stays on the last one)
-    int left = 0, ct = 0, cc = 0, tapv = 0, pK = 0;
-    unsigned goffB[4], b_goff = 0;              // per lane: byte offsets of its four rows (one per 16-row tile) in the cursor's item / of its B row
-    const int b_c = (lane & 3) ^ x3_key(lane >> 2);
-    auto begin = [&]() {
-        const NG_CONST ConvParams& p = *L.p;
+    // ---------------- the loader: a cursor TWO K-tiles ahead of the MFMAs, over the workgroup's items as one stream of K-tiles.  From
+    // the cursor itself: the rows of row tiles 0-2 and the B pieces of K-tile j + 2 (while tile j is multiplied); row tile 3 of K-tile
+    // j + 1 (converted one block later than the rest of its tile) through a SNAPSHOT of the cursor one tile old (a scalar base and the
+    // lane's row offset).  One raw buffer per operand, refilled right behind its last use: one K-tile of latency budget.
+    // The cursor's step is straight-line code: a K-tile further inside the item, or -- on the item's last K-tile -- onto the first
+    // K-tile of the NEXT item, whose state (`N`) was prepared outside the K loop, behind the previous item's epilogue (host: every
+    // problem has at least three K-tiles, so the cursor crosses one item boundary per multiplied item).  Past the end of the
+    // workgroup's items `N` is the last item once more: the fetches go on (their NUMBER is what the counted waits rely on), to valid
+    // addresses, and are never used.
+    struct Cur {
+        const char* in8; const char* w8[3];
+        int ntaps, run2, nk;
+        unsigned goff[4], b0, b1;
+        int tapv;
+    };
+    auto prepare = [&](const Item& t, Cur& c) {
+        const NG_CONST ConvParams& p = *t.p;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            int m = L.m0 + wave * 64 + mt * 16 + (lane & 15);
+            int m = t.m0 + wave * 64 + mt * 16 + (lane & 15);
             m = m < p.M ? m : p.M - 1;
             const int b = m / p.OHW, r = m - b * p.OHW;
             const int oh = r / p.OW, ow = r - oh * p.OW;
-            goffB[mt] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + (lane >> 4) * 8) * 4u;
+            c.goff[mt] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + (lane >> 4) * 8) * 4u;
         }
-        pK = p.K;
-        b_goff = unsigned((L.n0 + wave * 16 + (lane >> 2)) * pK + b_c * 8) * 2u;
-        tapv = p.tap_off[lane & (NIRGAN_MAX_TAPS - 1)];
-        left = L.nk;
-        ct = 0;
-        cc = 0;
-    };
-    auto a_base = [&]() -> const char* {
-        const int toff = __builtin_amdgcn_readlane(tapv, ct);
-        return ng_uniform_ptr(L.in8 + (long long)(toff + cc) * 4);
-    };
-    auto advance = [&]() {                      // to the next K-tile of the stream; past the end the cursor stays where it is
-        if (left > 1) {
-            --left;
-            ++ct;
-            if (ct == L.ntaps) { ct = 0; cc += 32; }
-            return;
-        }
-        if (!live) return;
-        Item nx;
-        locate(itemL + G, nx);
-        if (nx.nk < 0) { live = false; return; }
-        itemL += G;
-        L = nx;
-        begin();
-    };
-    const char* baseA = nullptr;                // snapshot one tile old: K-tile j + 2 while tile j is multiplied
-    const char* baseP = nullptr;                // two tiles old: K-tile j + 1
-    unsigned goffA[4] = {0u, 0u, 0u, 0u}, goff3P = 0;
-    auto snapshot = [&]() {                     // the cursor moves on: what it stood on becomes the rows' snapshot, that one the older one
-        baseP = baseA;
-        goff3P = goffA[3];
-        baseA = a_base();
+        const int pK = p.K;
+        // piece q = wave + 4 i of a K-tile's 3 BPT pieces (term q / BPT, 16-row group q % BPT): the lane's row of group `wave` and, at
+        // BN = 128, of group `wave + 4`
+        const int b_c = (lane & 3) ^ x3_key(lane >> 2);
+        c.b0 = unsigned((t.n0 + wave * 16 + (lane >> 2)) * pK + b_c * 8) * 2u;
+        c.b1 = c.b0 + unsigned(64 * pK) * 2u;
+        // the tap table into a VGPR (lane i holds tap i: the cursor picks with v_readlane) through SCALAR loads and selects
+        c.tapv = 0;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) goffA[mt] = goffB[mt];
-        advance();
+        for (int i = 0; i < NIRGAN_MAX_TAPS; ++i) c.tapv = (lane & (NIRGAN_MAX_TAPS - 1)) == i ? p.tap_off[i] : c.tapv;
+        c.in8 = ng_uniform_ptr(t.in8);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) c.w8[q] = ng_uniform_ptr(t.w8 + (long long)q * t.w3_plane * 2);
+        c.ntaps = t.ntaps;
+        c.run2 = t.run * 2;
+        c.nk = t.nk;
+    };
+    Cur L, N;                                   // the cursor's item / the item behind it
+    int itemN = blockIdx.x;                     // the item `N` stands for
+    int left = 0, ct = 0, cc = 0, kb = 0;       // K-tiles left in the cursor's item (this one included), its tap, its slice, (ct run + cc) 2
+    const char* baseC = nullptr;                // the cursor's K-tile (j + 2 while tile j is multiplied)
+    const char* baseP = nullptr;                // snapshot one tile old: K-tile j + 1
+    const char* baseW[3] = {nullptr, nullptr, nullptr};      // the cursor's K-tile in the three weight planes
+    unsigned goff3P = 0;
+    auto cursor_bases = [&]() {
+        const int toff = __builtin_amdgcn_readlane(L.tapv, ct);
+        baseC = L.in8 + (long long)(toff + cc) * 4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) baseW[q] = L.w8[q] + kb;
+    };
+    auto step_cursor = [&]() {                  // the cursor moves on: what it stood on becomes the snapshot
+        baseP = baseC;
+        goff3P = L.goff[3];
+        const bool cross = left == 1;           // (uniform)
+        // inside the item: the next tap of this slice, or the first tap of the next slice
+        int ct1 = ct + 1, cc1 = cc, kb1 = kb + L.run2;
+        const bool wrap = ct1 == L.ntaps;
+        ct1 = wrap ? 0 : ct1;
+        cc1 = wrap ? cc + 32 : cc1;
+        kb1 = wrap ? cc1 * 2 : kb1;
+        ct = cross ? 0 : ct1;
+        cc = cross ? 0 : cc1;
+        kb = cross ? 0 : kb1;
+        left = cross ? N.nk : left - 1;
+        // onto the next item: every field a select (the K loop keeps one basic block per region)
+        L.in8 = cross ? N.in8 : L.in8;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) L.w8[q] = cross ? N.w8[q] : L.w8[q];
+        L.ntaps = cross ? N.ntaps : L.ntaps;
+        L.run2 = cross ? N.run2 : L.run2;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) L.goff[mt] = cross ? N.goff[mt] : L.goff[mt];
+        L.b0 = cross ? N.b0 : L.b0;
+        L.b1 = cross ? N.b1 : L.b1;
+        L.tapv = cross ? N.tapv : L.tapv;
+        cursor_bases();
     };
     f32x4 F[4][2];                              // raw rows: F[mt] = this lane's 8 k of its row of 16-row tile mt
+    f32x4 Braw[PIECES];                         // raw B pieces (bf16 bits): 16 bytes per lane and piece
     u32x4 A[4][3];                              // the three terms of the CURRENT K-tile's rows, two bf16 per dword (rolling: A[mt] is replaced behind block mt)
     bf16x8 Bf[NT][3];                           // the current K-tile's B fragments (rolling: replaced behind their last use in block 3)
     // (inline asm with hand-counted waits: left to the compiler, the wait in front of a raw row set that was fetched in the PREVIOUS
@@ -226,18 +277,31 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         a[1][i] = m;
         a[2][i] = x3_pk(s0, s1);
     };
-    // the ring's DMA of the cursor's K-tile: PIECES 1 KB pieces per wave (piece q = wave + 4 i: term q / BPT, 16-row group q % BPT)
-    auto issueB_piece = [&](char* const stage, const int i) {
-        // past the end the cursor stands on its last K-tile: the same pieces are fetched again (the NUMBER of vector-memory operations is
-        // what the counted waits rely on) into a 1 KB block of LDS nobody reads.  (Not plain loads into a scratch register: the
-        // compiler reuses a register it believes dead while the load is still in flight -- the late data then lands in a live value.)
-        const int q = wave + 4 * i, term = q / BPT, idx = q % BPT;
-        const char* base = ng_uniform_ptr(L.w8 + ((long long)term * L.w3_plane + ct * L.run + cc) * 2 + (long long)(idx - wave) * 16 * pK * 2);
-        ng_glds16_so(base, b_goff, live ? stage + term * B_TERM + idx * 1024 : trash + wave * 1024);
+    // B piece i of the cursor's K-tile into its raw register set / from there into an LDS stage (image: igemm_x3.h -- 64-byte rows,
+    // 16-byte chunk c of row r at chunk c ^ key(r): the swizzle is applied on the global side, the LDS side is lane-linear)
+    auto loadB = [&](const int i) {              // (i is a constant of the unrolled caller; wave < 4: the term of piece wave + 4 i does not depend on the wave)
+        const int term = i / (BPT / 4);         // BN = 128: 0 0 1 1 2 2; BN = 64: 0 1 2
+        if (term == 0) { if (BPT == 8 && (i & 1)) X3R_GLD(Braw[i], L.b1, baseW[0], 0); else X3R_GLD(Braw[i], L.b0, baseW[0], 0); }
+        else if (term == 1) { if (BPT == 8 && (i & 1)) X3R_GLD(Braw[i], L.b1, baseW[1], 0); else X3R_GLD(Braw[i], L.b0, baseW[1], 0); }
+        else { if (BPT == 8 && (i & 1)) X3R_GLD(Braw[i], L.b1, baseW[2], 0); else X3R_GLD(Braw[i], L.b0, baseW[2], 0); }
     };
-    auto issueB = [&](char* const stage) {
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) issueB_piece(stage, i);
+    const unsigned ring0 = unsigned(size_t((NG_LDS char*)ring));
+    const unsigned b_wr = ring0 + unsigned(wave * 1024 + lane * 16);
+    auto storeB = [&](const unsigned stage_off, const int i) {
+        // piece q = wave + 4 i -> term (q / BPT), group (q % BPT): byte offset term * B_TERM + (q % BPT) * 1024 - wave * 1024 from b_wr
+        const unsigned ad = b_wr + stage_off;
+        if (BPT == 8) {
+            if (i == 0) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[0]), "n"(0) : "memory");
+            else if (i == 1) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[1]), "n"(4096) : "memory");
+            else if (i == 2) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[2]), "n"(B_TERM) : "memory");
+            else if (i == 3) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[3 % PIECES]), "n"(B_TERM + 4096) : "memory");
+            else if (i == 4) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[4 % PIECES]), "n"(2 * B_TERM) : "memory");
+            else asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[5 % PIECES]), "n"(2 * B_TERM + 4096) : "memory");
+        } else {
+            if (i == 0) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[0]), "n"(0) : "memory");
+            else if (i == 1) asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[1]), "n"(B_TERM) : "memory");
+            else asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(ad), "v"(Braw[2]), "n"(2 * B_TERM) : "memory");
+        }
     };
 
     // ---------------- compute state
@@ -247,19 +311,54 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int swz = ((lane >> 4) ^ x3_key(lane & 15)) << 4;
-    const unsigned ring0 = unsigned(size_t((NG_LDS char*)ring));
     const unsigned b_rd = unsigned((lane & 15) * 64 + swz);
-    int sj = 0;                                 // ring stage of the K-tile being multiplied
-    auto mma = [&](const int mt, const int nt) {
-        f32x4 c = acc[mt][nt];
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, A[mt][0]), am = __builtin_bit_cast(bf16x8, A[mt][1]), al = __builtin_bit_cast(bf16x8, A[mt][2]);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, Bf[nt][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Bf[nt][2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, Bf[nt][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, Bf[nt][0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Bf[nt][1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, Bf[nt][0], c, 0, 0, 0);
-        acc[mt][nt] = c;
+    int sj = 0;                                 // LDS stage of the K-tile being multiplied
+    // one region (see X3R_MFMA6 above).  WAIT < 0: no wait; READ: the column tile's fragments of the NEXT K-tile behind its MFMAs
+    auto region = [&](auto mt_tag, auto nt_tag, auto src_tag, auto pair_tag, auto wait_tag, auto read_tag, const unsigned bad) __attribute__((always_inline)) {
+        constexpr int MT = decltype(mt_tag)::value, NTI = decltype(nt_tag)::value, SRC = decltype(src_tag)::value, PAIR = decltype(pair_tag)::value,
+                      WAIT = decltype(wait_tag)::value;
+        constexpr bool READ = decltype(read_tag)::value;
+        f32x4& c = acc[MT][NTI];
+        if constexpr (PAIR >= 0) {
+            const float x0 = F[SRC][PAIR >> 1][(2 * PAIR) & 3], x1 = F[SRC][PAIR >> 1][(2 * PAIR + 1) & 3];
+            unsigned h, m, l;
+            float t0, t1, r0, r1;
+            if constexpr (WAIT >= 0) {
+                asm volatile(X3R_WAITL X3R_MFMA6_CONV
+                             : [c] "+a"(c), [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(r0), [r1] "=&v"(r1),
+                               [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
+                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x0] "v"(x0), [x1] "v"(x1), [w] "n"(WAIT) : "memory");
+            } else if constexpr (READ) {
+                asm volatile(X3R_MFMA6_CONV X3R_READS
+                             : [c] "+a"(c), [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(r0), [r1] "=&v"(r1),
+                               [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
+                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x0] "v"(x0), [x1] "v"(x1), [bad] "v"(bad),
+                               [o0] "n"(NTI * 1024), [o1] "n"(B_TERM + NTI * 1024), [o2] "n"(2 * B_TERM + NTI * 1024) : "memory");
+            } else {
+                asm volatile(X3R_MFMA6_CONV
+                             : [c] "+a"(c), [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(r0), [r1] "=&v"(r1)
+                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x0] "v"(x0), [x1] "v"(x1),
+                               [b0] "a"(Bf[NTI][0]), [b1] "a"(Bf[NTI][1]), [b2] "a"(Bf[NTI][2]) : "memory");
+            }
+            A[SRC][0][PAIR] = h;
+            A[SRC][1][PAIR] = m;
+            A[SRC][2][PAIR] = l;
+        } else {
+            if constexpr (WAIT >= 0) {
+                asm volatile(X3R_WAITL X3R_MFMA6
+                             : [c] "+a"(c), [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
+                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [w] "n"(WAIT) : "memory");
+            } else if constexpr (READ) {
+                asm volatile(X3R_MFMA6 X3R_READS
+                             : [c] "+a"(c), [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
+                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [bad] "v"(bad),
+                               [o0] "n"(NTI * 1024), [o1] "n"(B_TERM + NTI * 1024), [o2] "n"(2 * B_TERM + NTI * 1024) : "memory");
+            } else {
+                asm volatile(X3R_MFMA6
+                             : [c] "+a"(c)
+                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [b0] "a"(Bf[NTI][0]), [b1] "a"(Bf[NTI][1]), [b2] "a"(Bf[NTI][2]) : "memory");
+            }
+        }
     };
 #define X3R_RB(NTI, ad) { X3R_DSR(Bf[NTI][0], ad, (NTI) * 1024); X3R_DSR(Bf[NTI][1], ad, B_TERM + (NTI) * 1024); X3R_DSR(Bf[NTI][2], ad, 2 * B_TERM + (NTI) * 1024); }
 
@@ -267,6 +366,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     Item E;
     char* const stg8 = stg_all + wave * T::STG;
     float* const stg = reinterpret_cast<float*>(stg8);
+    const unsigned stg_lds = unsigned(size_t((NG_LDS char*)stg8));
     const int chunk = lane % LPR, lrow = lane / LPR;
     struct Epi {
         int pM, OHW, OW, OH, out_img, out_row, out_px, out_org, f_img, f_row, f_px, f_org, pC, span;
@@ -291,7 +391,13 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         e.fneg = p.f_act == NIRGAN_ACT_RELU ? 0.f : (p.f_act == NIRGAN_ACT_LRELU ? p.f_slope : 1.f);
         e.n = E.n0 + chunk * 4;
         e.bv = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr) e.bv = *reinterpret_cast<const f32x4*>(p.bias + e.n);
+        if (p.bias != nullptr) {
+            // (inline asm with its own wait: a compiler-visible load inside the loop makes hipcc guard its destination registers with
+            // s_waitcnt vmcnt(0) at the top of EVERY K-tile -- the fetches of the previous tile would be drained each time)
+            const char* bb = ng_uniform_ptr(reinterpret_cast<const char*>(p.bias));
+            const unsigned bo = unsigned(e.n) * 4u;
+            asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(e.bv) : "v"(bo), "s"(bb) : "memory");
+        }
         e.m = e.mbase + lrow;
         const int mc = e.m < e.pM ? e.m : e.pM - 1;
         e.b = mc / e.OHW;
@@ -328,6 +434,63 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                     e.t2[nt] += v * v;
                 }
             }
+        }
+        if constexpr (PLAIN) {
+            // the staging traffic in inline asm with its own waits (compiler-visible LDS accesses next to hand-counted ones get a full
+            // drain in front of them): 32 ds_write_b32 -- rows 4 apart of one column per instruction: two lanes per bank, free on a
+            // store -- then 8 ds_read_b128 of whole row segments
+            const unsigned sw = stg_lds + unsigned(((lane >> 4) * 4 * BN + (lane & 15)) * 4);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // (straight from the accumulator registers: ds_write takes AGPR data; a copy into VGPRs first -- the compiler hoists all
+                    // 128 of an item -- is what pushed loop-carried values into scratch.  Offset (r BN + 16 nt) floats, one case per r:
+                    // the immediate must be a constant of the instruction)
+                    const float v = acc[mt][nt][r];
+                    if (nt == 0) {
+                        if (r == 0) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sw), "a"(v), "n"(0) : "memory");
+                        else if (r == 1) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sw), "a"(v), "n"(BN * 4) : "memory");
+                        else if (r == 2) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sw), "a"(v), "n"(2 * BN * 4) : "memory");
+                        else asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sw), "a"(v), "n"(3 * BN * 4) : "memory");
+                    }
+#define X3R_STW(NTI) else if (nt == NTI) { \
+                        if (r == 0) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sw), "a"(v), "n"(NTI * 64) : "memory"); \
+                        else if (r == 1) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sw), "a"(v), "n"(BN * 4 + NTI * 64) : "memory"); \
+                        else if (r == 2) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sw), "a"(v), "n"(2 * BN * 4 + NTI * 64) : "memory"); \
+                        else asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sw), "a"(v), "n"(3 * BN * 4 + NTI * 64) : "memory"); }
+                    X3R_STW(1) X3R_STW(2) X3R_STW(3) X3R_STW(4) X3R_STW(5) X3R_STW(6) X3R_STW(7)
+#undef X3R_STW
+                }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};         // the next item's row tile starts from zero
+            int ooff[SP];
+            bool ok[SP];
+#pragma unroll
+            for (int pass = 0; pass < SP; ++pass) {
+                ok[pass] = e.m < e.pM;
+                ooff[pass] = e.b * e.out_img + e.oh * e.out_row + e.ow * e.out_px + e.out_org + e.n;
+                // (selects, no loops: host -- OW >= RPP, see conv_x3r_ok)
+                e.m += RPP;
+                e.ow += RPP;
+                const bool wrap_w = e.ow >= e.OW;
+                e.ow -= wrap_w ? e.OW : 0;
+                e.oh += wrap_w ? 1 : 0;
+                const bool wrap_h = e.oh >= e.OH;
+                e.oh -= wrap_h ? e.OH : 0;
+                e.b += wrap_h ? 1 : 0;
+            }
+            f32x4 v[SP];
+            const unsigned sr = stg_lds + unsigned((lrow * BN + chunk * 4) * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int pass = 0; pass < SP; ++pass) asm volatile("ds_read_b128 %0, %1" : "=v"(v[pass]) : "v"(sr + unsigned(pass * RPP * BN * 4)) : "memory");
+            if (SP == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4 % SP]), "+v"(v[5 % SP]), "+v"(v[6 % SP]), "+v"(v[7 % SP]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
+#pragma unroll
+            for (int pass = 0; pass < SP; ++pass)
+                if (ok[pass]) *reinterpret_cast<f32x4*>(E.out + ooff[pass]) = v[pass] + e.bv;
+            return;
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -423,85 +586,97 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         }
     };
 
-    // ---------------- one K-tile.  MODE 1 = the item's last K-tile with a plain epilogue: its slices ride in blocks 1-3.
-    // Vector-memory operations of a tile, in order: L3 (2 loads, K-tile j + 1; end of block 0), L0 (2, K-tile j + 2; end of block 1), the
-    // ring's DMA (6 pieces, K-tile j + 3; one per region of block 2), L1 (2), L2 (2) = 14.  A raw row set is waited for one tile after its
-    // loads: 12 operations are behind it (vmcnt(12)) -- 6 for row tile 1, whose wait stands in front of this tile's DMA pieces; the DMA of
-    // K-tile j + 1 was issued two tiles ago: 4 + 14 + 4 behind it (vmcnt(22)).
-    // The schedule is written region by region -- [6 MFMAs of one column tile + one pair of the conversion (11 VALU) + what the block
-    // adds] between full scheduling fences: inside a region hipcc interleaves the VALU with the MFMAs (an MFMA holds the vector issue
-    // port for 8 of its 16 cycles), across regions nothing moves (left to itself it issues every wait of a block up front and lumps the
-    // conversion; its sched_barrier masks let MFMAs through with the VALU class).
+    // ---------------- one K-tile.
+    // Vector-memory operations of a tile, in order: L3 (2 loads, K-tile j + 1; last region of block 0), the B pieces (6, K-tile j + 2;
+    // one per region of block 1), L0 (2, K-tile j + 2; last region of block 1), L1 (2), L2 (2) = 14.  A raw set is waited for one tile
+    // after its loads: the B pieces in the first region of block 0 (6 behind them: L0, L1, L2), row tile 3 there too (12), row tile 0
+    // in front of this tile's B pieces (6), row tiles 1 and 2 with 12 behind them.
+    // The schedule is written region by region, each region one asm block (X3R_MFMA6...): the loop's instruction stream is what is
+    // written here, in this order (every statement of the loop is a volatile asm; hipcc allocates the registers).
     auto tile = [&]() __attribute__((always_inline)) {
-        const unsigned bnext = ring0 + unsigned(((sj + 1) & 3) * STAGE) + b_rd;
-        char* const stageD = ring + ((sj + 3) & 3) * STAGE;
-        // regions of one block: row tile MT; raw set SRC -> A[DST]; `base / goff` = where SRC is fetched again
-        auto block = [&](auto mt_tag, auto src_tag, auto dst_tag, const char* base, const unsigned goff) __attribute__((always_inline)) {
-            constexpr int MT = decltype(mt_tag)::value, SRC = decltype(src_tag)::value, DST = decltype(dst_tag)::value;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (nt == 0) wait_raw(F[SRC], std::integral_constant<int, MT == 2 ? 6 : 12>{});
-                if (MT == 2 && nt < PIECES) issueB_piece(stageD, nt);       // the ring's DMA of K-tile j + 3, a piece per region
-                if (MT == 0) {
-                    // this fragment's three reads were issued behind the previous tile's block 3, followed by those of the fragments after it
-                    if (3 * (NT - 1 - nt) >= 15) asm volatile("s_waitcnt lgkmcnt(15)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
-                    else if (NT - 1 - nt == 4) asm volatile("s_waitcnt lgkmcnt(12)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
-                    else if (NT - 1 - nt == 3) asm volatile("s_waitcnt lgkmcnt(9)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
-                    else if (NT - 1 - nt == 2) asm volatile("s_waitcnt lgkmcnt(6)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
-                    else if (NT - 1 - nt == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(Bf[nt][0]), "+a"(Bf[nt][1]), "+a"(Bf[nt][2]) :: "memory");
-                }
-                mma(MT, nt);
-                // the conversion's four pairs in the block's first regions (NT = 8: every other one), the raw set's next fetch in the last
-                constexpr int every = NT / 4;
-                if (nt % every == 0) convert_pair(F[SRC], A[DST], nt / every);
-                if (nt == NT - 1) loadA(F[SRC], base, goff);
-                if (MT == 3 && nt == NT - 1) { sj = (sj + 1) & 3; snapshot(); }       // (the cursor's step among the tile's last MFMAs)
-                if (MT == 3) {
-                    // behind the last use of a B fragment the NEXT tile's fragment takes its registers
-                    if (nt == 0) X3R_RB(0, bnext) else if (nt == 1) X3R_RB(1, bnext) else if (nt == 2) X3R_RB(2, bnext) else if (nt == 3) X3R_RB(3, bnext)
-                    else if (nt == 4) X3R_RB(4 % NT, bnext) else if (nt == 5) X3R_RB(5 % NT, bnext) else if (nt == 6) X3R_RB(6 % NT, bnext) else X3R_RB(7 % NT, bnext)
-                }
+        const unsigned bnext = ring0 + unsigned((sj ^ 1) * STAGE) + b_rd;
+        const unsigned stage_next = unsigned((sj ^ 1) * STAGE);
+        // regions of one block: row tile MT; raw set SRC -> A[SRC]; `base / goff` = where SRC is fetched again
+        auto block = [&](auto mt_tag, auto src_tag, const char* base, const unsigned goff) __attribute__((always_inline)) {
+            constexpr int MT = decltype(mt_tag)::value, SRC = decltype(src_tag)::value;
+            constexpr int every = NT / 4;       // the conversion's four pairs in every other region (NT = 8) / in every region (NT = 4)
+            if (MT == 0) {
+                // K-tile j + 1's pieces of B have landed (fetched in block 1 of the previous tile)
+                if (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) :: "memory");
             }
-            __builtin_amdgcn_sched_barrier(0);
+            wait_raw(F[SRC], std::integral_constant<int, MT == 1 ? 6 : 12>{});
+            auto one = [&](auto nt_tag) __attribute__((always_inline)) {
+                constexpr int nt = decltype(nt_tag)::value;
+                if constexpr (nt < NT) {
+                    // block 0: this fragment's three reads were issued behind the previous tile's block 3, followed by those of the
+                    // fragments after it (the B stores of this block, issued behind earlier regions, only make the wait stricter)
+                    constexpr int behind = 3 * (NT - 1 - nt);
+                    using W = std::integral_constant<int, MT == 0 ? (behind > 15 ? 15 : behind) : -1>;
+                    using PR = std::integral_constant<int, nt % every == 0 ? nt / every : -1>;
+                    region(mt_tag, nt_tag, src_tag, PR{}, W{}, std::integral_constant<bool, MT == 3>{}, bnext);
+                    if (nt == NT - 1) loadA(F[SRC], base, goff);
+                    // K-tile j + 1's pieces of B into the other stage (every wave has left it: it held K-tile j - 1, last read in block 3 of
+                    // tile j - 2, in front of tile j - 1's barrier)
+                    if (MT == 0 && nt >= NT - PIECES) storeB(stage_next, nt - (NT - PIECES));
+                    if (MT == 1 && nt < PIECES) loadB(nt);          // K-tile j + 2's pieces, behind the stores that emptied the registers
+                    if (MT == 3 && nt == NT - 1) { sj ^= 1; step_cursor(); }       // (the cursor's step behind the tile's last MFMAs)
+                }
+            };
+            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{}); one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         X3R_STAMP(5)                                     // (what lies between two tiles: the loop's overhead, an epilogue's tail)
-        block(I0{}, I3{}, I3{}, baseP, goff3P);          // THIS tile's row tile 3 is converted (needed in block 3), refilled from K-tile j + 1
+        block(I0{}, I3{}, baseP, goff3P);                // THIS tile's row tile 3 is converted (needed in block 3), refilled from K-tile j + 1
         X3R_STAMP(0)
-        block(I1{}, I0{}, I0{}, baseA, goffA[0]);        // the NEXT tile's row tile 0 into A[0] (block 0 has issued its last use), K-tile j + 2
+        block(I1{}, I0{}, baseC, L.goff[0]);              // the NEXT tile's row tile 0 into A[0] (block 0 has issued its last use), K-tile j + 2
         X3R_STAMP(1)
-        // the tile's barrier: this wave's pieces of K-tile j + 1 have landed (issued two tiles ago); behind it K-tile j + 1 is visible to
-        // every wave and every wave has left K-tile j - 1, whose stage takes the DMA of K-tile j + 3
-        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        // the tile's barrier: every wave's pieces of K-tile j + 1 are in LDS (stored in block 0: long done)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         X3R_STAMP(2)
-        block(I2{}, I1{}, I1{}, baseA, goffA[1]);
+        block(I2{}, I1{}, baseC, L.goff[1]);
         X3R_STAMP(3)
-        block(I3{}, I2{}, I2{}, baseA, goffA[2]);
+        block(I3{}, I2{}, baseC, L.goff[2]);
         X3R_STAMP(4)
 #ifdef NG_X3R_STAMP
         ++st_sum[15];
 #endif
     };
 
-    // ---------------- the walk.  In front of K-tile 0 the loader issues what "tile -2" and "tile -1" would have, in their order, so
-    // that the counted waits of the first tiles find the operations they assume
-    locate(itemL, L);
-    if (L.nk < 0) return;
-    begin();
-    issueB(ring);                               // K-tile 0 -> stage 0
-    snapshot();                                 // (baseA, goffA) = K-tile 0, cursor on K-tile 1
-    loadA(F[0], baseA, goffA[0]);
-    issueB(ring + STAGE);                       // K-tile 1 -> stage 1
-    loadA(F[1], baseA, goffA[1]);
-    loadA(F[2], baseA, goffA[2]);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]) :: "memory");       // (and K-tile 0's own pieces of B)
+    // ---------------- the walk.  In front of K-tile 0 the loader issues what the tile before it would have, in its order, so that the
+    // counted waits of the first tile find the operations they assume
+    locate(itemN, E);
+    if (E.nk < 0) return;
+    prepare(E, N);
+    L = N;
+    left = L.nk;
+    auto prepare_next = [&]() {                 // `N` = the item behind the cursor's (or that one again, past the end)
+        Item t;
+        locate(itemN + G, t);
+        if (t.nk >= 0) {
+            itemN += G;
+            prepare(t, N);
+        }
+    };
+    prepare_next();
+    cursor_bases();                             // the cursor on K-tile 0
+    loadA(F[0], baseC, L.goff[0]);
+    loadA(F[1], baseC, L.goff[1]);
+    loadA(F[2], baseC, L.goff[2]);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) loadB(i);
+    if (PIECES == 6) asm volatile("s_waitcnt vmcnt(0)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]),
+                                  "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]) :: "memory");
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) storeB(0u, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { convert_pair(F[0], A[0], i); convert_pair(F[1], A[1], i); convert_pair(F[2], A[2], i); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     {
@@ -512,31 +687,31 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             else if (nt == 4) X3R_RB(4 % NT, b0) else if (nt == 5) X3R_RB(5 % NT, b0) else if (nt == 6) X3R_RB(6 % NT, b0) else X3R_RB(7 % NT, b0)
         }
     }
-    snapshot();                                 // P = K-tile 0, A = K-tile 1, cursor on K-tile 2
-    loadA(F[3], baseP, goff3P);
-    loadA(F[0], baseA, goffA[0]);
-    issueB(ring + 2 * STAGE);                   // K-tile 2 -> stage 2
-    loadA(F[1], baseA, goffA[1]);
-    loadA(F[2], baseA, goffA[2]);
-    snapshot();                                 // P = K-tile 1, A = K-tile 2, cursor on K-tile 3: the state tile 0 expects
+    loadA(F[3], baseC, L.goff[3]);              // K-tile 0's row tile 3: converted in block 0 of tile 0
+    step_cursor();                              // snapshot = K-tile 0, cursor on K-tile 1
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) loadB(i);
+    loadA(F[0], baseC, L.goff[0]);
+    loadA(F[1], baseC, L.goff[1]);
+    loadA(F[2], baseC, L.goff[2]);
+    step_cursor();                              // snapshot = K-tile 1, cursor on K-tile 2: the state tile 0 expects
 #ifdef NG_X3R_STAMP
     { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_last = unsigned(t_); }
 #endif
     // (the multiplying side knows of its item only the number of K-tiles; the item itself is located again behind its last K-tile, for the
     // epilogue: nothing of the epilogue's state is live across the K loop)
     int itemC = blockIdx.x;
-    locate(itemC, E);
-    int kC = 0, nkC = E.nk;
+    int nkC = E.nk;
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     while (true) {
-        tile();
-        if (++kC < nkC) continue;
+        for (int k = 0; k < nkC; ++k) tile();
         X3R_STAMP(5)
+        X3R_MFMA_DRAIN;                          // the last MFMAs' results are in the accumulators
         locate(itemC, E);
         Epi e;
         epi_begin(e);
         X3R_STAMP(6)
-        if (!e.stats && !e.fused) {
+        if constexpr (!GEN) {
             slice(e, I0{}, I1{});
             slice(e, I1{}, I1{});
             slice(e, I2{}, I1{});
@@ -546,8 +721,8 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             slice(e, I1{}, I2{});
             slice(e, I2{}, I2{});
             slice(e, I3{}, I2{});
+            epi_finish(e);
         }
-        epi_finish(e);
         X3R_STAMP(7)
 #ifdef NG_X3R_STAMP
         ++st_sum[14];
@@ -555,8 +730,10 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         itemC += G;
         locate(itemC, E);
         if (E.nk < 0) break;
-        kC = 0;
         nkC = E.nk;
+        // the cursor crossed into this item while the last one was multiplied (two K-tiles ahead, at least three per item): the item
+        // behind it is prepared here, outside the K loop
+        prepare_next();
     }
 #ifdef NG_X3R_STAMP
     if (lane == 0 && blockIdx.x < 1024) {
@@ -570,7 +747,8 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #undef X3R_VALU
 #undef X3R_DSR
 
+inline bool conv_x3r_generic(const ConvParams& p) { return p.stats != nullptr || p.f_y != nullptr; }
 // whether the register-fed tile takes a launch the split tile covers (host): 128-column tiles, asked for by the descriptor (A/B switch)
-inline bool conv_x3r_ok(const ConvParams& p, const int bn) { return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 4; }
+inline bool conv_x3r_ok(const ConvParams& p, const int bn) { return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 4 && p.ntaps * (p.run >> 5) >= 3; }
 
 }  // namespace ng

@@ -375,6 +375,8 @@ def emit_conv(plan: Plan, ctx: Ctx, inp: Halo, taps: G.Taps, w: torch.Tensor, bi
             and (N % 128 == 0 or (N % 64 == 0 and taps.n * taps.run >= 512))):
         # exact-fp32 mode: this contraction on the bf16 pipe as three bf16 terms per operand, six products (fp32-equivalent; no split-K form)
         d.precision, d.w_x3, d.w_x3_plane = 3, x3[0].data_ptr(), x3[1]
+        if OPT.x3_r4:
+            d.algo = L.CONV_X3_R4        # (the library takes it where the four-wave tile applies: igemm_x3r.h::conv_x3r_ok)
         allow_split = False
     if out_span > 1:
         # two adjacent output pixels per GEMM row (the split tile only): N = 2 C columns into a dense C-channel tensor
@@ -568,6 +570,8 @@ def emit_wino6(plan: Optional[Plan], pack: Plan, ctx: Ctx, x: Halo, weight: torc
     d.U, d.bias, d.V, d.V_elems, d.M, d.M_elems, d.y = _ptr(U), _ptr(bias), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), y.ptr
     d.zero_page = ctx.zero_page.data_ptr()
     d.algo = OPT.w6_gemm_algo
+    if U3 is not None and OPT.x3_r4 and d.algo == 0:
+        d.algo = L.W6_X3_R4
     d.U3 = _ptr(U3)
     if stats_ws is not None:        # the output transform leaves the instance norm's partial sums (one chunk per tile): no statistics pass over y
         assert stats_ws.numel() >= T * 4 * cout

@@ -68,6 +68,9 @@ class Options:
     # ... and the generator's first layer, Conv2d(3, 64, 7) over the 4-channel row-packed input, with two adjacent output pixels per GEMM
     # row (128 columns, runs of 8 pixels x 4 channels = 32) on the split tile instead of 64 columns x runs of 28 on the exact fp32 tile (A/B)
     pair_pixels: bool = True
+    # the split tile as ONE wave per SIMD with the activation operand fed from registers (csrc/igemm_x3r.h: conv_x3r_kernel) where it
+    # applies -- N % 128 == 0, at least three K-tiles -- instead of the eight-wave tile (same bits; A/B)
+    x3_r4: bool = True
     # the generator's Conv2d(64, 1, 7) + tanh as direct kernels (csrc/endconv.hip) instead of tap planes + gather
     endconv_direct: bool = True
 
