@@ -749,6 +749,11 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 
 inline bool conv_x3r_generic(const ConvParams& p) { return p.stats != nullptr || p.f_y != nullptr; }
 // whether the register-fed tile takes a launch the split tile covers (host): 128-column tiles, asked for by the descriptor (A/B switch)
-inline bool conv_x3r_ok(const ConvParams& p, const int bn) { return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 4 && p.ntaps * (p.run >> 5) >= 3; }
+// (problems whose epilogue leaves statistics / runs the fused pass -- the branching epilogue is not overlapped and not tuned -- only from
+// 24 K-tiles on: measured inside the step, profiles/r06_x3r_per_op_ab.txt -- 1.04-1.14 x from 32 K-tiles, 0.68-0.91 x at 7-18)
+inline bool conv_x3r_ok(const ConvParams& p, const int bn) {
+    const int nk = p.ntaps * (p.run >> 5);
+    return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 4 && nk >= (conv_x3r_generic(p) ? 24 : 3);
+}
 
 }  // namespace ng
