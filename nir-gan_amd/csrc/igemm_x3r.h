@@ -95,6 +95,23 @@ struct X3R {
     X3R_M(am, b0) "v_lshlrev_b32 %[t0], 16, %[m]\n\t" "v_and_b32 %[t1], 0xffff0000, %[m]\n\t" \
     X3R_M(ah, b1) "v_sub_f32 %[r0], %[r0], %[t0]\n\t" "v_sub_f32 %[r1], %[r1], %[t1]\n\t" \
     X3R_M(ah, b0) "v_cvt_pk_bf16_f32 %[l], %[r0], %[r1]\n\t"
+// the same conversion over TWO regions (a region with all 11 VALU is issue-bound: 6 x 8 cycles of MFMA issue + 11 x 4 > the 96 cycles its
+// MFMAs take; five or six per region leave room for the region's waits and fragment reads): first h, the remainders and m ...
+#define X3R_MFMA6_CONVA \
+    X3R_M(al, b0) "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n\t" \
+    X3R_M(ah, b2) "v_lshlrev_b32 %[t0], 16, %[h]\n\t" "v_and_b32 %[t1], 0xffff0000, %[h]\n\t" \
+    X3R_M(am, b1) "v_sub_f32 %[r0], %[x0], %[t0]\n\t" \
+    X3R_M(am, b0) "v_sub_f32 %[r1], %[x1], %[t1]\n\t" \
+    X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[m], %[r0], %[r1]\n\t" \
+    X3R_M(ah, b0)
+// ... then the second remainders and l
+#define X3R_MFMA6_CONVB \
+    X3R_M(al, b0) "v_lshlrev_b32 %[t0], 16, %[m]\n\t" \
+    X3R_M(ah, b2) "v_and_b32 %[t1], 0xffff0000, %[m]\n\t" \
+    X3R_M(am, b1) "v_sub_f32 %[t0], %[r0], %[t0]\n\t" \
+    X3R_M(am, b0) "v_sub_f32 %[t1], %[r1], %[t1]\n\t" \
+    X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[l], %[t0], %[t1]\n\t" \
+    X3R_M(ah, b0)
 #define X3R_WAITL "s_waitcnt lgkmcnt(%[w])\n\t"
 #define X3R_READS "ds_read_b128 %[b0], %[bad] offset:%[o0]\n\t" "ds_read_b128 %[b1], %[bad] offset:%[o1]\n\t" "ds_read_b128 %[b2], %[bad] offset:%[o2]\n\t"
 #define X3R_MFMA_DRAIN asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
@@ -313,52 +330,57 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     const int swz = ((lane >> 4) ^ x3_key(lane & 15)) << 4;
     const unsigned b_rd = unsigned((lane & 15) * 64 + swz);
     int sj = 0;                                 // LDS stage of the K-tile being multiplied
-    // one region (see X3R_MFMA6 above).  WAIT < 0: no wait; READ: the column tile's fragments of the NEXT K-tile behind its MFMAs
-    auto region = [&](auto mt_tag, auto nt_tag, auto src_tag, auto pair_tag, auto wait_tag, auto read_tag, const unsigned bad) __attribute__((always_inline)) {
+    // one region (see X3R_MFMA6 above).  HALF: 0 = first half of the conversion of pair PAIR (h, the remainders, m), 1 = its second half
+    // (l), -1 = no conversion; WAIT < 0: no wait; READ: the column tile's fragments of the NEXT K-tile behind its MFMAs
+    float cr0 = 0.f, cr1 = 0.f;                 // the remainders of the pair whose conversion is under way
+    unsigned cm = 0;
+    auto region = [&](auto mt_tag, auto nt_tag, auto src_tag, auto pair_tag, auto half_tag, auto wait_tag, auto read_tag, const unsigned bad) __attribute__((always_inline)) {
         constexpr int MT = decltype(mt_tag)::value, NTI = decltype(nt_tag)::value, SRC = decltype(src_tag)::value, PAIR = decltype(pair_tag)::value,
-                      WAIT = decltype(wait_tag)::value;
+                      HALF = decltype(half_tag)::value, WAIT = decltype(wait_tag)::value;
         constexpr bool READ = decltype(read_tag)::value;
+        static_assert(!(WAIT >= 0 && READ), "a region waits for fragments (block 0) or replaces them (block 3)");
         f32x4& c = acc[MT][NTI];
-        if constexpr (PAIR >= 0) {
+#define X3R_ACC_B_INOUT [c] "+a"(c), [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
+#define X3R_A_IN [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2])
+#define X3R_B_IN [b0] "a"(Bf[NTI][0]), [b1] "a"(Bf[NTI][1]), [b2] "a"(Bf[NTI][2])
+#define X3R_RD_IN [bad] "v"(bad), [o0] "n"(NTI * 1024), [o1] "n"(B_TERM + NTI * 1024), [o2] "n"(2 * B_TERM + NTI * 1024)
+        if constexpr (HALF == 0) {
             const float x0 = F[SRC][PAIR >> 1][(2 * PAIR) & 3], x1 = F[SRC][PAIR >> 1][(2 * PAIR + 1) & 3];
-            unsigned h, m, l;
-            float t0, t1, r0, r1;
-            if constexpr (WAIT >= 0) {
-                asm volatile(X3R_WAITL X3R_MFMA6_CONV
-                             : [c] "+a"(c), [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(r0), [r1] "=&v"(r1),
-                               [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
-                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x0] "v"(x0), [x1] "v"(x1), [w] "n"(WAIT) : "memory");
-            } else if constexpr (READ) {
-                asm volatile(X3R_MFMA6_CONV X3R_READS
-                             : [c] "+a"(c), [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(r0), [r1] "=&v"(r1),
-                               [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
-                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x0] "v"(x0), [x1] "v"(x1), [bad] "v"(bad),
-                               [o0] "n"(NTI * 1024), [o1] "n"(B_TERM + NTI * 1024), [o2] "n"(2 * B_TERM + NTI * 1024) : "memory");
-            } else {
-                asm volatile(X3R_MFMA6_CONV
-                             : [c] "+a"(c), [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(r0), [r1] "=&v"(r1)
-                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x0] "v"(x0), [x1] "v"(x1),
-                               [b0] "a"(Bf[NTI][0]), [b1] "a"(Bf[NTI][1]), [b2] "a"(Bf[NTI][2]) : "memory");
-            }
+            unsigned h;
+            float t0, t1;
+            if constexpr (WAIT >= 0)
+                asm volatile(X3R_WAITL X3R_MFMA6_CONVA : X3R_ACC_B_INOUT, [h] "=&v"(h), [m] "=&v"(cm), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(cr0), [r1] "=&v"(cr1)
+                             : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), [w] "n"(WAIT) : "memory");
+            else if constexpr (READ)
+                asm volatile(X3R_MFMA6_CONVA X3R_READS : X3R_ACC_B_INOUT, [h] "=&v"(h), [m] "=&v"(cm), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(cr0), [r1] "=&v"(cr1)
+                             : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), X3R_RD_IN : "memory");
+            else
+                asm volatile(X3R_MFMA6_CONVA : [c] "+a"(c), [h] "=&v"(h), [m] "=&v"(cm), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(cr0), [r1] "=&v"(cr1)
+                             : X3R_A_IN, X3R_B_IN, [x0] "v"(x0), [x1] "v"(x1) : "memory");
             A[SRC][0][PAIR] = h;
-            A[SRC][1][PAIR] = m;
+            A[SRC][1][PAIR] = cm;
+        } else if constexpr (HALF == 1) {
+            unsigned l;
+            float t0, t1;
+            if constexpr (WAIT >= 0)
+                asm volatile(X3R_WAITL X3R_MFMA6_CONVB : X3R_ACC_B_INOUT, [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                             : X3R_A_IN, [m] "v"(cm), [r0] "v"(cr0), [r1] "v"(cr1), [w] "n"(WAIT) : "memory");
+            else if constexpr (READ)
+                asm volatile(X3R_MFMA6_CONVB X3R_READS : X3R_ACC_B_INOUT, [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                             : X3R_A_IN, [m] "v"(cm), [r0] "v"(cr0), [r1] "v"(cr1), X3R_RD_IN : "memory");
+            else
+                asm volatile(X3R_MFMA6_CONVB : [c] "+a"(c), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                             : X3R_A_IN, X3R_B_IN, [m] "v"(cm), [r0] "v"(cr0), [r1] "v"(cr1) : "memory");
             A[SRC][2][PAIR] = l;
         } else {
-            if constexpr (WAIT >= 0) {
-                asm volatile(X3R_WAITL X3R_MFMA6
-                             : [c] "+a"(c), [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
-                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [w] "n"(WAIT) : "memory");
-            } else if constexpr (READ) {
-                asm volatile(X3R_MFMA6 X3R_READS
-                             : [c] "+a"(c), [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
-                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [bad] "v"(bad),
-                               [o0] "n"(NTI * 1024), [o1] "n"(B_TERM + NTI * 1024), [o2] "n"(2 * B_TERM + NTI * 1024) : "memory");
-            } else {
-                asm volatile(X3R_MFMA6
-                             : [c] "+a"(c)
-                             : [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [b0] "a"(Bf[NTI][0]), [b1] "a"(Bf[NTI][1]), [b2] "a"(Bf[NTI][2]) : "memory");
-            }
+            if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6 : X3R_ACC_B_INOUT : X3R_A_IN, [w] "n"(WAIT) : "memory");
+            else if constexpr (READ) asm volatile(X3R_MFMA6 X3R_READS : X3R_ACC_B_INOUT : X3R_A_IN, X3R_RD_IN : "memory");
+            else asm volatile(X3R_MFMA6 : [c] "+a"(c) : X3R_A_IN, X3R_B_IN : "memory");
         }
+#undef X3R_ACC_B_INOUT
+#undef X3R_A_IN
+#undef X3R_B_IN
+#undef X3R_RD_IN
     };
 #define X3R_RB(NTI, ad) { X3R_DSR(Bf[NTI][0], ad, (NTI) * 1024); X3R_DSR(Bf[NTI][1], ad, B_TERM + (NTI) * 1024); X3R_DSR(Bf[NTI][2], ad, 2 * B_TERM + (NTI) * 1024); }
 
@@ -599,7 +621,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         // regions of one block: row tile MT; raw set SRC -> A[SRC]; `base / goff` = where SRC is fetched again
         auto block = [&](auto mt_tag, auto src_tag, const char* base, const unsigned goff) __attribute__((always_inline)) {
             constexpr int MT = decltype(mt_tag)::value, SRC = decltype(src_tag)::value;
-            constexpr int every = NT / 4;       // the conversion's four pairs in every other region (NT = 8) / in every region (NT = 4)
+            // the conversion's four pairs: NT = 8 -- a half per region (pair nt / 2); NT = 4 -- a pair per region (both halves: two calls)
             if (MT == 0) {
                 // K-tile j + 1's pieces of B have landed (fetched in block 1 of the previous tile)
                 if (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) :: "memory");
@@ -613,8 +635,10 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                     // fragments after it (the B stores of this block, issued behind earlier regions, only make the wait stricter)
                     constexpr int behind = 3 * (NT - 1 - nt);
                     using W = std::integral_constant<int, MT == 0 ? (behind > 15 ? 15 : behind) : -1>;
-                    using PR = std::integral_constant<int, nt % every == 0 ? nt / every : -1>;
-                    region(mt_tag, nt_tag, src_tag, PR{}, W{}, std::integral_constant<bool, MT == 3>{}, bnext);
+                    static_assert(NT == 8, "the 64-column form needs its own region (a whole pair per region)");
+                    using PR = std::integral_constant<int, nt / 2>;
+                    using HF = std::integral_constant<int, nt & 1>;
+                    region(mt_tag, nt_tag, src_tag, PR{}, HF{}, W{}, std::integral_constant<bool, MT == 3>{}, bnext);
                     if (nt == NT - 1) loadA(F[SRC], base, goff);
                     // K-tile j + 1's pieces of B into the other stage (every wave has left it: it held K-tile j - 1, last read in block 3 of
                     // tile j - 2, in front of tile j - 1's barrier)
