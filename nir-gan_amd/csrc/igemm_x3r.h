@@ -131,6 +131,8 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     unsigned st_sum[16], st_last = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) st_sum[i] = 0;
+    unsigned long long st_c0, st_r0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0) :: "memory");
 #endif
 
     // ---------------- which tile is item i of this workgroup (as conv_x3_persist::locate)
@@ -279,9 +281,19 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         X3R_GLD(f[0], goff, base, 0);
         X3R_GLD(f[1], goff, base, 16);
     };
+    // `stores_behind`: the K-tile right behind a full tile's plain epilogue -- its 4 SP = 32 output stores were issued behind every fetch
+    // this tile waits for, and vmcnt counts loads and stores in one order: the waits leave them in flight (without that every item
+    // would sit out the acknowledgement of the 32 KB it has just written: ~18 % of a plane GEMM's item, measured)
+    bool stores_behind = false;
+    constexpr int EST = 4 * SP;
+    static_assert(12 + EST <= 63, "vmcnt is a six-bit counter");
+    // (ONE asm statement per wait, the choice between its two counts a scalar branch INSIDE it: two statements in the arms of a C++ `if`
+    // let the compiler merge the tied registers with copies in front of one of them -- copies of a destination whose load has not landed)
+#define X3R_WAITV2(N) "s_cmp_eq_u32 %[sb], 0\n\ts_cbranch_scc1 .Lx3rw%=\n\ts_waitcnt vmcnt(%[n1])\n\ts_branch .Lx3rv%=\n.Lx3rw%=:\n\ts_waitcnt vmcnt(" #N ")\n.Lx3rv%=:"
     auto wait_raw = [&](f32x4 (&f)[2], auto n_tag) {
-        if constexpr (decltype(n_tag)::value == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
+        const int sb = __builtin_amdgcn_readfirstlane(stores_behind ? 1 : 0);
+        if constexpr (decltype(n_tag)::value == 12) asm volatile(X3R_WAITV2(12) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(12 + EST) : "memory", "scc");
+        else asm volatile(X3R_WAITV2(6) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
     };
     // pair i (k = 2 i, 2 i + 1 of the lane's eight) of a raw row set into dword i of the three terms: 11 VALU (x3_split8's rule)
     auto convert_pair = [&](const f32x4 (&f)[2], u32x4 (&a)[3], const int i) {
@@ -624,8 +636,9 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             // the conversion's four pairs: NT = 8 -- a half per region (pair nt / 2); NT = 4 -- a pair per region (both halves: two calls)
             if (MT == 0) {
                 // K-tile j + 1's pieces of B have landed (fetched in block 1 of the previous tile)
-                if (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) :: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) :: "memory");
+                const int sb = __builtin_amdgcn_readfirstlane(stores_behind ? 1 : 0);
+                if (PIECES == 6) asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
+                else asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
             }
             wait_raw(F[SRC], std::integral_constant<int, MT == 1 ? 6 : 12>{});
             auto one = [&](auto nt_tag) __attribute__((always_inline)) {
@@ -728,7 +741,10 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     int nkC = E.nk;
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     while (true) {
-        for (int k = 0; k < nkC; ++k) tile();
+        for (int k = 0; k < nkC; ++k) {
+            tile();
+            stores_behind = false;
+        }
         X3R_STAMP(5)
         X3R_MFMA_DRAIN;                          // the last MFMAs' results are in the accumulators
         locate(itemC, E);
@@ -740,6 +756,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             slice(e, I1{}, I1{});
             slice(e, I2{}, I1{});
             slice(e, I3{}, I1{});
+            stores_behind = E.m0 + 256 <= e.pM;       // (a full tile: every one of its store instructions was issued)
         } else {
             slice(e, I0{}, I2{});
             slice(e, I1{}, I2{});
@@ -760,6 +777,12 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         prepare_next();
     }
 #ifdef NG_X3R_STAMP
+    {
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1) :: "memory");
+        st_sum[12] = unsigned(c1 - st_c0);      // shader cycles of the whole kernel
+        st_sum[13] = unsigned(r1 - st_r0);      // 100 MHz ticks of the whole kernel
+    }
     if (lane == 0 && blockIdx.x < 1024) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) ng_x3r_stamps[(blockIdx.x * 4 + wave) * 16 + i] = st_sum[i];
@@ -768,6 +791,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #undef X3R_RB
 }
 #undef X3R_GLD
+#undef X3R_WAITV2
 #undef X3R_VALU
 #undef X3R_DSR
 

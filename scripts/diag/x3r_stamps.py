@@ -29,6 +29,8 @@ def report(title):
     v = (a[..., 5] / np.maximum(tiles, 1)).mean(); tot += v
     print(f"   {NAMES[5]:28s} {v:8.0f} cycles per K-tile")
     print(f"   = {tot:.0f} cycles per K-tile (MFMA issue alone: {192 * 16})")
+    clk = (a[..., 12] / np.maximum(a[..., 13], 1)).mean() * 100.0
+    print(f"   whole kernel: {a[..., 12].mean():.0f} cycles per wave, clock {clk:.0f} MHz (s_memtime / s_memrealtime)")
     for k in (6, 7):
         print(f"   {NAMES[k]:28s} {(a[..., k] / np.maximum(items, 1)).mean():8.0f} cycles per item")
 
