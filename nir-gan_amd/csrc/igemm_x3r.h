@@ -202,14 +202,28 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         unsigned goff[4], b0, b1;
         int tapv;
     };
+    // m = (b OH + oh) OW + ow by two float reciprocals and a correction step each (m < 2^24: the estimate is off by at most one) instead
+    // of two integer divisions (~50 VALU) per row: this runs once per item and row tile, with the matrix pipe idle
+    auto split_row = [&](const int m, const int OHW, const int OW, const float r_ohw, const float r_ow, int& b, int& oh, int& ow) {
+        b = int(float(m) * r_ohw);
+        int r = m - b * OHW;
+        b += r < 0 ? -1 : (r >= OHW ? 1 : 0);
+        r = m - b * OHW;
+        oh = int(float(r) * r_ow);
+        ow = r - oh * OW;
+        oh += ow < 0 ? -1 : (ow >= OW ? 1 : 0);
+        ow = r - oh * OW;
+    };
     auto prepare = [&](const Item& t, Cur& c) {
         const NG_CONST ConvParams& p = *t.p;
+        const int OHW = p.OHW, OW = p.OW, pM = p.M;
+        const float r_ohw = 1.0f / float(OHW), r_ow = 1.0f / float(OW);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             int m = t.m0 + wave * 64 + mt * 16 + (lane & 15);
-            m = m < p.M ? m : p.M - 1;
-            const int b = m / p.OHW, r = m - b * p.OHW;
-            const int oh = r / p.OW, ow = r - oh * p.OW;
+            m = m < pM ? m : pM - 1;
+            int b, oh, ow;
+            split_row(m, OHW, OW, r_ohw, r_ow, b, oh, ow);
             c.goff[mt] = unsigned(b * p.in_img + oh * p.in_stride * p.in_row + ow * p.in_stride * p.in_cs + p.in_org + (lane >> 4) * 8) * 4u;
         }
         const int pK = p.K;
@@ -434,10 +448,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         }
         e.m = e.mbase + lrow;
         const int mc = e.m < e.pM ? e.m : e.pM - 1;
-        e.b = mc / e.OHW;
-        const int r0 = mc - e.b * e.OHW;
-        e.oh = r0 / e.OW;
-        e.ow = r0 - e.oh * e.OW;
+        split_row(mc, e.OHW, e.OW, 1.0f / float(e.OHW), 1.0f / float(e.OW), e.b, e.oh, e.ow);
         e.fb = (e.mbase < e.pM ? e.mbase : e.pM - 1) / e.OHW;
         e.nq = e.n >= e.pC ? 1 : 0;
         e.nc = e.n - e.nq * e.pC;
@@ -691,12 +702,14 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     prepare(E, N);
     L = N;
     left = L.nk;
-    auto prepare_next = [&]() {                 // `N` = the item behind the cursor's (or that one again, past the end)
-        Item t;
-        locate(itemN + G, t);
-        if (t.nk >= 0) {
+    // an item is located ONCE: `E` = the item being multiplied, `Q1` = the item behind it, the one `N` stands for (behind E's last
+    // K-tile the cursor has crossed into it: E = Q1, and the item behind that one is located and prepared)
+    Item Q1;
+    auto prepare_next = [&]() {                 // `N` = the item behind the cursor's (past the end: the last state once more, never used)
+        locate(itemN + G, Q1);
+        if (Q1.nk >= 0) {
             itemN += G;
-            prepare(t, N);
+            prepare(Q1, N);
         }
     };
     prepare_next();
@@ -737,7 +750,6 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #endif
     // (the multiplying side knows of its item only the number of K-tiles; the item itself is located again behind its last K-tile, for the
     // epilogue: nothing of the epilogue's state is live across the K loop)
-    int itemC = blockIdx.x;
     int nkC = E.nk;
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     while (true) {
@@ -747,7 +759,6 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         }
         X3R_STAMP(5)
         X3R_MFMA_DRAIN;                          // the last MFMAs' results are in the accumulators
-        locate(itemC, E);
         Epi e;
         epi_begin(e);
         X3R_STAMP(6)
@@ -768,12 +779,11 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #ifdef NG_X3R_STAMP
         ++st_sum[14];
 #endif
-        itemC += G;
-        locate(itemC, E);
+        E = Q1;
         if (E.nk < 0) break;
         nkC = E.nk;
         // the cursor crossed into this item while the last one was multiplied (two K-tiles ahead, at least three per item): the item
-        // behind it is prepared here, outside the K loop
+        // behind it is located and prepared here, outside the K loop
         prepare_next();
     }
 #ifdef NG_X3R_STAMP
