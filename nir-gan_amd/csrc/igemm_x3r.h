@@ -64,7 +64,7 @@ struct X3R {
     static constexpr int STAGE = 3 * B_TERM;
     static constexpr int NSTAGE = 2;
     static constexpr int RING = NSTAGE * STAGE;        // 48 KB at BN = 128
-    static constexpr int STG = 16 * BN * 4;            // staging of one wave: 16 rows x BN floats
+    static constexpr int STG = 2 * 16 * BN * 4;        // staging of one wave: two halves of 16 rows x BN floats (a slice each)
     static constexpr int BPT = BN / 16;                // 1 KB LDS-DMA pieces per term image
     static constexpr int PIECES = 3 * BPT / 4;         // pieces per wave and K-tile (6 / 3)
     static constexpr int LPR = BN / 4;                 // lanes per output row (4 channels each)
@@ -579,6 +579,87 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             }
         }
     };
+    // A FULL tile's plain epilogue, software-pipelined over the four slices through the two staging halves (every statement a volatile
+    // asm or plain VALU: the order below is the order issued):  W0 | R0 W1 walk0 S0 | R1 W2 walk1 S1 | R2 W3 walk2 S2 | R3 walk3 S3.
+    // W = 32 ds_write_b32 straight from the accumulator registers (rows 4 apart of one column per instruction: two lanes per bank,
+    // free on a store) + the slice's accumulators back to zero; R = 8 ds_read_b128 of whole row segments; walk = the byte offsets of
+    // the lane's 8 rows (selects at the row / sample wraps); S = 8 stores, scalar base + 32-bit offset.
+    auto epilogue_full = [&](Epi& e) __attribute__((always_inline)) {
+        const unsigned sw0 = stg_lds + unsigned(((lane >> 4) * 4 * BN + (lane & 15)) * 4);
+        const unsigned sr0 = stg_lds + unsigned((lrow * BN + chunk * 4) * 4);
+        constexpr unsigned HALF = 16 * BN * 4;
+        const char* const obase = ng_uniform_ptr(reinterpret_cast<const char*>(E.out));
+        // byte steps of the row walk: RPP pixels on; a row wrap; a sample wrap
+        const int d0 = RPP * e.out_px * 4, dW = (e.out_row - e.OW * e.out_px) * 4, dH = (e.out_img - e.OH * e.out_row) * 4;
+        int off = (e.b * e.out_img + e.oh * e.out_row + e.ow * e.out_px + e.out_org + e.n) * 4;
+        auto W = [&](auto mt_tag) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mt_tag)::value;
+            const unsigned sw = sw0 + (mt & 1) * HALF;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 c = acc[mt][nt];
+                const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+#define X3R_STW4(NTI) if (nt == NTI) asm volatile("ds_write_b32 %0, %1 offset:%5\n\tds_write_b32 %0, %2 offset:%6\n\tds_write_b32 %0, %3 offset:%7\n\tds_write_b32 %0, %4 offset:%8" \
+                        :: "v"(sw), "a"(c0), "a"(c1), "a"(c2), "a"(c3), "n"(NTI * 64), "n"(BN * 4 + NTI * 64), "n"(2 * BN * 4 + NTI * 64), "n"(3 * BN * 4 + NTI * 64) : "memory");
+                X3R_STW4(0) X3R_STW4(1) X3R_STW4(2) X3R_STW4(3) X3R_STW4(4) X3R_STW4(5) X3R_STW4(6) X3R_STW4(7)
+#undef X3R_STW4
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};         // the next item's row tile starts from zero
+        };
+        f32x4 v0[SP], v1[SP];
+        auto R = [&](auto mt_tag, f32x4 (&vv)[SP]) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mt_tag)::value;
+            const unsigned sr = sr0 + (mt & 1) * HALF;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slice's writes are in LDS
+#pragma unroll
+            for (int pass = 0; pass < SP; ++pass) asm volatile("ds_read_b128 %0, %1" : "=v"(vv[pass]) : "v"(sr + unsigned(pass * RPP * BN * 4)) : "memory");
+        };
+        auto S = [&](auto more_tag, f32x4 (&vv)[SP]) __attribute__((always_inline)) {
+            int ooff[SP];
+#pragma unroll
+            for (int pass = 0; pass < SP; ++pass) {
+                ooff[pass] = off;
+                off += d0;
+                e.ow += RPP;
+                const bool wrap_w = e.ow >= e.OW;
+                e.ow -= wrap_w ? e.OW : 0;
+                off += wrap_w ? dW : 0;
+                e.oh += wrap_w ? 1 : 0;
+                const bool wrap_h = e.oh >= e.OH;
+                e.oh -= wrap_h ? e.OH : 0;
+                off += wrap_h ? dH : 0;
+            }
+            // the slice's reads have landed (behind them at most the 32 stores of the next slice's W: lgkmcnt counts to 15, the LDS
+            // pipe returns in order -- all but the 15 youngest done means every read done)
+            if constexpr (decltype(more_tag)::value) {
+                if (SP == 8) asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4 % SP]), "+v"(vv[5 % SP]), "+v"(vv[6 % SP]), "+v"(vv[7 % SP]) :: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]) :: "memory");
+            } else {
+                if (SP == 8) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4 % SP]), "+v"(vv[5 % SP]), "+v"(vv[6 % SP]), "+v"(vv[7 % SP]) :: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]) :: "memory");
+            }
+            const char* const ob = obase;           // (a local: clang refuses an asm operand that names the enclosing lambda's variable)
+            // the bias on all eight row segments first, then the eight stores back to back from the registers the reads landed in, then
+            // two wait states: a store of more than 8 bytes reads its data registers late -- a VALU write to them within two wait
+            // states of the store corrupts what is stored (seen: the third / fourth dword of every segment whose registers the next
+            // segment's v_pk_add reused), and the compiler's hazard recognizer does not see into the asm
+#pragma unroll
+            for (int pass = 0; pass < SP; ++pass) vv[pass] += e.bv;
+#pragma unroll
+            for (int pass = 0; pass < SP; ++pass) {
+                const unsigned oo = unsigned(ooff[pass]);
+                asm volatile("global_store_dwordx4 %1, %0, %2" : "+v"(vv[pass]) : "v"(oo), "s"(ob) : "memory");
+            }
+            asm volatile("s_nop 1" ::: "memory");
+        };
+        using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+        W(J0{});
+        R(J0{}, v0); W(J1{}); S(std::true_type{}, v0);
+        R(J1{}, v1); W(J2{}); S(std::true_type{}, v1);
+        R(J2{}, v0); W(J3{}); S(std::true_type{}, v0);
+        R(J3{}, v1); S(std::false_type{}, v1);
+    };
     auto epi_finish = [&](Epi& e) {
         const NG_CONST ConvParams& p = *E.p;
         if (e.stats) {
@@ -763,11 +844,15 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         epi_begin(e);
         X3R_STAMP(6)
         if constexpr (!GEN) {
-            slice(e, I0{}, I1{});
-            slice(e, I1{}, I1{});
-            slice(e, I2{}, I1{});
-            slice(e, I3{}, I1{});
-            stores_behind = E.m0 + 256 <= e.pM;       // (a full tile: every one of its store instructions was issued)
+            if (E.m0 + 256 <= e.pM) {                 // a full tile: every one of its 32 store instructions is issued
+                epilogue_full(e);
+                stores_behind = true;
+            } else {
+                slice(e, I0{}, I1{});
+                slice(e, I1{}, I1{});
+                slice(e, I2{}, I1{});
+                slice(e, I3{}, I1{});
+            }
         } else {
             slice(e, I0{}, I2{});
             slice(e, I1{}, I2{});
