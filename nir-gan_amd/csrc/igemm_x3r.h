@@ -838,7 +838,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             tile();
             stores_behind = false;
         }
-        X3R_STAMP(5)
+        X3R_STAMP(9)
         X3R_MFMA_DRAIN;                          // the last MFMAs' results are in the accumulators
         Epi e;
         epi_begin(e);
@@ -870,6 +870,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         // the cursor crossed into this item while the last one was multiplied (two K-tiles ahead, at least three per item): the item
         // behind it is located and prepared here, outside the K loop
         prepare_next();
+        X3R_STAMP(8)
     }
 #ifdef NG_X3R_STAMP
     {

@@ -31,6 +31,7 @@ def report(title):
     print(f"   = {tot:.0f} cycles per K-tile (MFMA issue alone: {192 * 16})")
     clk = (a[..., 12] / np.maximum(a[..., 13], 1)).mean() * 100.0
     print(f"   whole kernel: {a[..., 12].mean():.0f} cycles per wave, clock {clk:.0f} MHz (s_memtime / s_memrealtime)")
+    print(f"   item switch (lookup + prepare)  {(a[..., 8] / np.maximum(items, 1)).mean():8.0f} cycles per item;  behind the last K-tile {(a[..., 9] / np.maximum(items, 1)).mean():8.0f} cycles per item")
     for k in (6, 7):
         print(f"   {NAMES[k]:28s} {(a[..., k] / np.maximum(items, 1)).mean():8.0f} cycles per item")
 
