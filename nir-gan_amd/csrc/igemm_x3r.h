@@ -112,6 +112,22 @@ struct X3R {
     X3R_M(am, b0) "v_sub_f32 %[t1], %[r1], %[t1]\n\t" \
     X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[l], %[t0], %[t1]\n\t" \
     X3R_M(ah, b0)
+// the FIRST K-tile of an item: the first product of every accumulator takes C = 0 (no zeroing of 128 registers per item)
+#define X3R_M0(a, b) "v_mfma_f32_16x16x32_bf16 %[c], %[" #a "], %[" #b "], 0\n\t"
+#define X3R_MFMA6_CONVA0 \
+    X3R_M0(al, b0) "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n\t" \
+    X3R_M(ah, b2) "v_lshlrev_b32 %[t0], 16, %[h]\n\t" "v_and_b32 %[t1], 0xffff0000, %[h]\n\t" \
+    X3R_M(am, b1) "v_sub_f32 %[r0], %[x0], %[t0]\n\t" \
+    X3R_M(am, b0) "v_sub_f32 %[r1], %[x1], %[t1]\n\t" \
+    X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[m], %[r0], %[r1]\n\t" \
+    X3R_M(ah, b0)
+#define X3R_MFMA6_CONVB0 \
+    X3R_M0(al, b0) "v_lshlrev_b32 %[t0], 16, %[m]\n\t" \
+    X3R_M(ah, b2) "v_and_b32 %[t1], 0xffff0000, %[m]\n\t" \
+    X3R_M(am, b1) "v_sub_f32 %[t0], %[r0], %[t0]\n\t" \
+    X3R_M(am, b0) "v_sub_f32 %[t1], %[r1], %[t1]\n\t" \
+    X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[l], %[t0], %[t1]\n\t" \
+    X3R_M(ah, b0)
 #define X3R_WAITL "s_waitcnt lgkmcnt(%[w])\n\t"
 #define X3R_READS "ds_read_b128 %[b0], %[bad] offset:%[o0]\n\t" "ds_read_b128 %[b1], %[bad] offset:%[o1]\n\t" "ds_read_b128 %[b2], %[bad] offset:%[o2]\n\t"
 #define X3R_MFMA_DRAIN asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
@@ -360,10 +376,11 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // (l), -1 = no conversion; WAIT < 0: no wait; READ: the column tile's fragments of the NEXT K-tile behind its MFMAs
     float cr0 = 0.f, cr1 = 0.f;                 // the remainders of the pair whose conversion is under way
     unsigned cm = 0;
-    auto region = [&](auto mt_tag, auto nt_tag, auto src_tag, auto pair_tag, auto half_tag, auto wait_tag, auto read_tag, const unsigned bad) __attribute__((always_inline)) {
+    auto region = [&](auto first_tag, auto mt_tag, auto nt_tag, auto src_tag, auto pair_tag, auto half_tag, auto wait_tag, auto read_tag, const unsigned bad) __attribute__((always_inline)) {
         constexpr int MT = decltype(mt_tag)::value, NTI = decltype(nt_tag)::value, SRC = decltype(src_tag)::value, PAIR = decltype(pair_tag)::value,
                       HALF = decltype(half_tag)::value, WAIT = decltype(wait_tag)::value;
-        constexpr bool READ = decltype(read_tag)::value;
+        constexpr bool READ = decltype(read_tag)::value, FIRST = decltype(first_tag)::value;
+        static_assert(HALF >= 0, "every region of the 128-column form carries half a pair of the conversion");
         static_assert(!(WAIT >= 0 && READ), "a region waits for fragments (block 0) or replaces them (block 3)");
         f32x4& c = acc[MT][NTI];
 #define X3R_ACC_B_INOUT [c] "+a"(c), [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
@@ -374,29 +391,35 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             const float x0 = F[SRC][PAIR >> 1][(2 * PAIR) & 3], x1 = F[SRC][PAIR >> 1][(2 * PAIR + 1) & 3];
             unsigned h;
             float t0, t1;
-            if constexpr (WAIT >= 0)
-                asm volatile(X3R_WAITL X3R_MFMA6_CONVA : X3R_ACC_B_INOUT, [h] "=&v"(h), [m] "=&v"(cm), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(cr0), [r1] "=&v"(cr1)
-                             : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), [w] "n"(WAIT) : "memory");
-            else if constexpr (READ)
-                asm volatile(X3R_MFMA6_CONVA X3R_READS : X3R_ACC_B_INOUT, [h] "=&v"(h), [m] "=&v"(cm), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(cr0), [r1] "=&v"(cr1)
-                             : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), X3R_RD_IN : "memory");
-            else
-                asm volatile(X3R_MFMA6_CONVA : [c] "+a"(c), [h] "=&v"(h), [m] "=&v"(cm), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(cr0), [r1] "=&v"(cr1)
-                             : X3R_A_IN, X3R_B_IN, [x0] "v"(x0), [x1] "v"(x1) : "memory");
+#define X3R_CONVA_OUT [h] "=&v"(h), [m] "=&v"(cm), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(cr0), [r1] "=&v"(cr1)
+            if constexpr (FIRST) {
+                if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6_CONVA0 : X3R_ACC_B_INOUT, X3R_CONVA_OUT : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), [w] "n"(WAIT) : "memory");
+                else if constexpr (READ) asm volatile(X3R_MFMA6_CONVA0 X3R_READS : X3R_ACC_B_INOUT, X3R_CONVA_OUT : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), X3R_RD_IN : "memory");
+                else asm volatile(X3R_MFMA6_CONVA0 : [c] "+a"(c), X3R_CONVA_OUT : X3R_A_IN, X3R_B_IN, [x0] "v"(x0), [x1] "v"(x1) : "memory");
+            } else {
+                if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6_CONVA : X3R_ACC_B_INOUT, X3R_CONVA_OUT : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), [w] "n"(WAIT) : "memory");
+                else if constexpr (READ) asm volatile(X3R_MFMA6_CONVA X3R_READS : X3R_ACC_B_INOUT, X3R_CONVA_OUT : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), X3R_RD_IN : "memory");
+                else asm volatile(X3R_MFMA6_CONVA : [c] "+a"(c), X3R_CONVA_OUT : X3R_A_IN, X3R_B_IN, [x0] "v"(x0), [x1] "v"(x1) : "memory");
+            }
+#undef X3R_CONVA_OUT
             A[SRC][0][PAIR] = h;
             A[SRC][1][PAIR] = cm;
         } else if constexpr (HALF == 1) {
             unsigned l;
             float t0, t1;
-            if constexpr (WAIT >= 0)
-                asm volatile(X3R_WAITL X3R_MFMA6_CONVB : X3R_ACC_B_INOUT, [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1)
-                             : X3R_A_IN, [m] "v"(cm), [r0] "v"(cr0), [r1] "v"(cr1), [w] "n"(WAIT) : "memory");
-            else if constexpr (READ)
-                asm volatile(X3R_MFMA6_CONVB X3R_READS : X3R_ACC_B_INOUT, [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1)
-                             : X3R_A_IN, [m] "v"(cm), [r0] "v"(cr0), [r1] "v"(cr1), X3R_RD_IN : "memory");
-            else
-                asm volatile(X3R_MFMA6_CONVB : [c] "+a"(c), [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1)
-                             : X3R_A_IN, X3R_B_IN, [m] "v"(cm), [r0] "v"(cr0), [r1] "v"(cr1) : "memory");
+#define X3R_CONVB_OUT [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1)
+#define X3R_CONVB_IN [m] "v"(cm), [r0] "v"(cr0), [r1] "v"(cr1)
+            if constexpr (FIRST) {
+                if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6_CONVB0 : X3R_ACC_B_INOUT, X3R_CONVB_OUT : X3R_A_IN, X3R_CONVB_IN, [w] "n"(WAIT) : "memory");
+                else if constexpr (READ) asm volatile(X3R_MFMA6_CONVB0 X3R_READS : X3R_ACC_B_INOUT, X3R_CONVB_OUT : X3R_A_IN, X3R_CONVB_IN, X3R_RD_IN : "memory");
+                else asm volatile(X3R_MFMA6_CONVB0 : [c] "+a"(c), X3R_CONVB_OUT : X3R_A_IN, X3R_B_IN, X3R_CONVB_IN : "memory");
+            } else {
+                if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6_CONVB : X3R_ACC_B_INOUT, X3R_CONVB_OUT : X3R_A_IN, X3R_CONVB_IN, [w] "n"(WAIT) : "memory");
+                else if constexpr (READ) asm volatile(X3R_MFMA6_CONVB X3R_READS : X3R_ACC_B_INOUT, X3R_CONVB_OUT : X3R_A_IN, X3R_CONVB_IN, X3R_RD_IN : "memory");
+                else asm volatile(X3R_MFMA6_CONVB : [c] "+a"(c), X3R_CONVB_OUT : X3R_A_IN, X3R_B_IN, X3R_CONVB_IN : "memory");
+            }
+#undef X3R_CONVB_OUT
+#undef X3R_CONVB_IN
             A[SRC][2][PAIR] = l;
         } else {
             if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6 : X3R_ACC_B_INOUT : X3R_A_IN, [w] "n"(WAIT) : "memory");
@@ -507,8 +530,6 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                     X3R_STW(1) X3R_STW(2) X3R_STW(3) X3R_STW(4) X3R_STW(5) X3R_STW(6) X3R_STW(7)
 #undef X3R_STW
                 }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};         // the next item's row tile starts from zero
             int ooff[SP];
             bool ok[SP];
 #pragma unroll
@@ -541,8 +562,6 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) stg[((lane >> 4) * 4 + r) * BN + nt * 16 + (lane & 15)] = acc[mt][nt][r];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};         // the next item's row tile starts from zero
         int ooff[SP];
         bool ok[SP];
         f32x4 yv[SP];
@@ -579,12 +598,17 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             }
         }
     };
-    // A FULL tile's plain epilogue, software-pipelined over the four slices through the two staging halves (every statement a volatile
-    // asm or plain VALU: the order below is the order issued):  W0 | R0 W1 walk0 S0 | R1 W2 walk1 S1 | R2 W3 walk2 S2 | R3 walk3 S3.
-    // W = 32 ds_write_b32 straight from the accumulator registers (rows 4 apart of one column per instruction: two lanes per bank,
-    // free on a store) + the slice's accumulators back to zero; R = 8 ds_read_b128 of whole row segments; walk = the byte offsets of
-    // the lane's 8 rows (selects at the row / sample wraps); S = 8 stores, scalar base + 32-bit offset.
-    auto epilogue_full = [&](Epi& e) __attribute__((always_inline)) {
+    // A FULL tile's plain epilogue.  It is ISSUE-bound (one wave per SIMD: every instruction of it is exposed), so it is kept short:
+    //   W (per slice): 16 ds_write2_b32 straight from the accumulator registers -- two rows of one column per instruction (rows 4 apart
+    //     per 16-lane group: two lanes per bank, free on a store); the accumulators are NOT zeroed (the next item's first K-tile
+    //     starts them with C = 0);
+    //   R: 8 ds_read_b128 of whole row segments, no wait in front (a wave's LDS operations execute in issue order);
+    //   S: 8 stores, scalar base + 32-bit offset, straight from the registers the reads landed in (+ the bias only where there is one);
+    //   the byte offsets of the lane's rows: ONE add per slice while the slice's 16 rows do not cross an image row (a scalar test);
+    //     the select walk otherwise.
+    // Two staging halves, order  W0 R0 W1 S0 R1 W2 S1 R2 W3 S2 R3 S3.
+    auto epilogue_full = [&](Epi& e, auto bias_tag) __attribute__((always_inline)) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
         const unsigned sw0 = stg_lds + unsigned(((lane >> 4) * 4 * BN + (lane & 15)) * 4);
         const unsigned sr0 = stg_lds + unsigned((lrow * BN + chunk * 4) * 4);
         constexpr unsigned HALF = 16 * BN * 4;
@@ -592,45 +616,72 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         // byte steps of the row walk: RPP pixels on; a row wrap; a sample wrap
         const int d0 = RPP * e.out_px * 4, dW = (e.out_row - e.OW * e.out_px) * 4, dH = (e.out_img - e.OH * e.out_row) * 4;
         int off = (e.b * e.out_img + e.oh * e.out_row + e.ow * e.out_px + e.out_org + e.n) * 4;
+        // (uniform) the column of the slice's first row: the slice wraps iff its 16 rows cross the end of an image row
+        int s_ow = __builtin_amdgcn_readfirstlane(e.ow);       // (lane 0 stands on the slice's first row)
+        const int s_OW = e.OW;
         auto W = [&](auto mt_tag) __attribute__((always_inline)) {
             constexpr int mt = decltype(mt_tag)::value;
-            const unsigned sw = sw0 + (mt & 1) * HALF;
+            const unsigned sw = sw0 + (mt & 1) * HALF, sw2 = sw + 2 * BN * 4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const f32x4 c = acc[mt][nt];
                 const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-#define X3R_STW4(NTI) if (nt == NTI) asm volatile("ds_write_b32 %0, %1 offset:%5\n\tds_write_b32 %0, %2 offset:%6\n\tds_write_b32 %0, %3 offset:%7\n\tds_write_b32 %0, %4 offset:%8" \
-                        :: "v"(sw), "a"(c0), "a"(c1), "a"(c2), "a"(c3), "n"(NTI * 64), "n"(BN * 4 + NTI * 64), "n"(2 * BN * 4 + NTI * 64), "n"(3 * BN * 4 + NTI * 64) : "memory");
+                // (offsets in dwords: column block nt, the second row BN dwords on)
+#define X3R_STW4(NTI) if (nt == NTI) asm volatile("ds_write2_b32 %0, %2, %3 offset0:%6 offset1:%7\n\tds_write2_b32 %1, %4, %5 offset0:%6 offset1:%7" \
+                        :: "v"(sw), "v"(sw2), "a"(c0), "a"(c1), "a"(c2), "a"(c3), "n"(NTI * 16), "n"(NTI * 16 + BN) : "memory");
                 X3R_STW4(0) X3R_STW4(1) X3R_STW4(2) X3R_STW4(3) X3R_STW4(4) X3R_STW4(5) X3R_STW4(6) X3R_STW4(7)
 #undef X3R_STW4
             }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};         // the next item's row tile starts from zero
         };
+        static_assert(7 * 16 + BN <= 255, "ds_write2_b32 offsets are 8-bit dword counts");
         f32x4 v0[SP], v1[SP];
         auto R = [&](auto mt_tag, f32x4 (&vv)[SP]) __attribute__((always_inline)) {
             constexpr int mt = decltype(mt_tag)::value;
             const unsigned sr = sr0 + (mt & 1) * HALF;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slice's writes are in LDS
 #pragma unroll
-            for (int pass = 0; pass < SP; ++pass) asm volatile("ds_read_b128 %0, %1" : "=v"(vv[pass]) : "v"(sr + unsigned(pass * RPP * BN * 4)) : "memory");
+            for (int pass = 0; pass < SP; ++pass) {
+                if (pass == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(vv[0]) : "v"(sr) : "memory");
+#define X3R_RDP(P) else if (pass == P) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vv[P % SP]) : "v"(sr), "n"(P * RPP * BN * 4) : "memory");
+                X3R_RDP(1) X3R_RDP(2) X3R_RDP(3) X3R_RDP(4) X3R_RDP(5) X3R_RDP(6) X3R_RDP(7)
+#undef X3R_RDP
+            }
         };
         auto S = [&](auto more_tag, f32x4 (&vv)[SP]) __attribute__((always_inline)) {
             int ooff[SP];
+            if (s_ow + 16 <= s_OW) {
+                // the slice stays inside one image row: the lane's rows are d0 bytes apart
 #pragma unroll
-            for (int pass = 0; pass < SP; ++pass) {
-                ooff[pass] = off;
-                off += d0;
-                e.ow += RPP;
-                const bool wrap_w = e.ow >= e.OW;
-                e.ow -= wrap_w ? e.OW : 0;
-                off += wrap_w ? dW : 0;
-                e.oh += wrap_w ? 1 : 0;
-                const bool wrap_h = e.oh >= e.OH;
-                e.oh -= wrap_h ? e.OH : 0;
-                off += wrap_h ? dH : 0;
+                for (int pass = 0; pass < SP; ++pass) ooff[pass] = off + pass * d0;
+                off += SP * d0;
+                e.ow += 16;
+                s_ow += 16;
+                if (s_ow == s_OW) {                 // ... and ends exactly at its end: the next slice starts the next image row
+                    s_ow = 0;
+                    e.ow -= s_OW;
+                    off += dW;
+                    e.oh += 1;
+                    const bool wrap_h = e.oh >= e.OH;
+                    e.oh -= wrap_h ? e.OH : 0;
+                    off += wrap_h ? dH : 0;
+                }
+            } else {
+#pragma unroll
+                for (int pass = 0; pass < SP; ++pass) {
+                    ooff[pass] = off;
+                    off += d0;
+                    e.ow += RPP;
+                    const bool wrap_w = e.ow >= e.OW;
+                    e.ow -= wrap_w ? e.OW : 0;
+                    off += wrap_w ? dW : 0;
+                    e.oh += wrap_w ? 1 : 0;
+                    const bool wrap_h = e.oh >= e.OH;
+                    e.oh -= wrap_h ? e.OH : 0;
+                    off += wrap_h ? dH : 0;
+                }
+                s_ow += 16;
+                s_ow -= s_ow >= s_OW ? s_OW : 0;    // (host: OW >= 16 for this kernel's problems, see conv_x3r_ok)
             }
-            // the slice's reads have landed (behind them at most the 32 stores of the next slice's W: lgkmcnt counts to 15, the LDS
+            // the slice's reads have landed (behind them at most the 16 stores of the next slice's W: lgkmcnt counts to 15, the LDS
             // pipe returns in order -- all but the 15 youngest done means every read done)
             if constexpr (decltype(more_tag)::value) {
                 if (SP == 8) asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4 % SP]), "+v"(vv[5 % SP]), "+v"(vv[6 % SP]), "+v"(vv[7 % SP]) :: "memory");
@@ -644,8 +695,10 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             // two wait states: a store of more than 8 bytes reads its data registers late -- a VALU write to them within two wait
             // states of the store corrupts what is stored (seen: the third / fourth dword of every segment whose registers the next
             // segment's v_pk_add reused), and the compiler's hazard recognizer does not see into the asm
+            if constexpr (BIAS) {
 #pragma unroll
-            for (int pass = 0; pass < SP; ++pass) vv[pass] += e.bv;
+                for (int pass = 0; pass < SP; ++pass) vv[pass] += e.bv;
+            }
 #pragma unroll
             for (int pass = 0; pass < SP; ++pass) {
                 const unsigned oo = unsigned(ooff[pass]);
@@ -719,7 +772,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // in front of this tile's B pieces (6), row tiles 1 and 2 with 12 behind them.
     // The schedule is written region by region, each region one asm block (X3R_MFMA6...): the loop's instruction stream is what is
     // written here, in this order (every statement of the loop is a volatile asm; hipcc allocates the registers).
-    auto tile = [&]() __attribute__((always_inline)) {
+    auto tile = [&](auto first_tag) __attribute__((always_inline)) {
         const unsigned bnext = ring0 + unsigned((sj ^ 1) * STAGE) + b_rd;
         const unsigned stage_next = unsigned((sj ^ 1) * STAGE);
         // regions of one block: row tile MT; raw set SRC -> A[SRC]; `base / goff` = where SRC is fetched again
@@ -743,7 +796,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                     static_assert(NT == 8, "the 64-column form needs its own region (a whole pair per region)");
                     using PR = std::integral_constant<int, nt / 2>;
                     using HF = std::integral_constant<int, nt & 1>;
-                    region(mt_tag, nt_tag, src_tag, PR{}, HF{}, W{}, std::integral_constant<bool, MT == 3>{}, bnext);
+                    region(first_tag, mt_tag, nt_tag, src_tag, PR{}, HF{}, W{}, std::integral_constant<bool, MT == 3>{}, bnext);
                     if (nt == NT - 1) loadA(F[SRC], base, goff);
                     // K-tile j + 1's pieces of B into the other stage (every wave has left it: it held K-tile j - 1, last read in block 3 of
                     // tile j - 2, in front of tile j - 1's barrier)
@@ -834,10 +887,10 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     int nkC = E.nk;
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
     while (true) {
-        for (int k = 0; k < nkC; ++k) {
-            tile();
-            stores_behind = false;
-        }
+        // (the item's first K-tile starts its accumulators: C = 0 in the first product of each -- nothing zeroes them in between)
+        tile(std::true_type{});
+        stores_behind = false;
+        for (int k = 1; k < nkC; ++k) tile(std::false_type{});
         X3R_STAMP(9)
         X3R_MFMA_DRAIN;                          // the last MFMAs' results are in the accumulators
         Epi e;
@@ -845,7 +898,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         X3R_STAMP(6)
         if constexpr (!GEN) {
             if (E.m0 + 256 <= e.pM) {                 // a full tile: every one of its 32 store instructions is issued
-                epilogue_full(e);
+                if (E.p->bias != nullptr) epilogue_full(e, std::true_type{}); else epilogue_full(e, std::false_type{});
                 stores_behind = true;
             } else {
                 slice(e, I0{}, I1{});
@@ -897,7 +950,7 @@ inline bool conv_x3r_generic(const ConvParams& p) { return p.stats != nullptr ||
 // 24 K-tiles on: measured inside the step, profiles/r06_x3r_per_op_ab.txt -- 1.04-1.14 x from 32 K-tiles, 0.68-0.91 x at 7-18)
 inline bool conv_x3r_ok(const ConvParams& p, const int bn) {
     const int nk = p.ntaps * (p.run >> 5);
-    return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 4 && nk >= (conv_x3r_generic(p) ? 24 : 3);
+    return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 16 && nk >= (conv_x3r_generic(p) ? 24 : 3);
 }
 
 }  // namespace ng
