@@ -606,7 +606,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     //   S: 8 stores, scalar base + 32-bit offset, straight from the registers the reads landed in (+ the bias only where there is one);
     //   the byte offsets of the lane's rows: ONE add per slice while the slice's 16 rows do not cross an image row (a scalar test);
     //     the select walk otherwise.
-    // Two staging halves, order  W0 R0 W1 S0 R1 W2 S1 R2 W3 S2 R3 S3.
+    // Two staging halves, order  W0 R0 [S0 | W1] R1 [S1 | W2] R2 [S2 | W3] R3 S3  ([S | W]: a store, a column block, a store, ...).
     auto epilogue_full = [&](Epi& e, auto bias_tag) __attribute__((always_inline)) {
         constexpr bool BIAS = decltype(bias_tag)::value;
         const unsigned sw0 = stg_lds + unsigned(((lane >> 4) * 4 * BN + (lane & 15)) * 4);
@@ -619,11 +619,12 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         // (uniform) the column of the slice's first row: the slice wraps iff its 16 rows cross the end of an image row
         int s_ow = __builtin_amdgcn_readfirstlane(e.ow);       // (lane 0 stands on the slice's first row)
         const int s_OW = e.OW;
-        auto W = [&](auto mt_tag) __attribute__((always_inline)) {
+        auto W = [&](auto mt_tag, const int only = -1) __attribute__((always_inline)) {        // (only >= 0: column block `only` alone)
             constexpr int mt = decltype(mt_tag)::value;
             const unsigned sw = sw0 + (mt & 1) * HALF, sw2 = sw + 2 * BN * 4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                if (only >= 0 && nt != only) continue;
                 const f32x4 c = acc[mt][nt];
                 const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
                 // (offsets in dwords: column block nt, the second row BN dwords on)
@@ -646,7 +647,10 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #undef X3R_RDP
             }
         };
-        auto S = [&](auto more_tag, f32x4 (&vv)[SP]) __attribute__((always_inline)) {
+        // S with the NEXT slice's W woven in, a column block behind every store (NEXT < 4): the LDS store path and the global store
+        // path each move 32 KB per wave and slice -- back to back they add up, alternating they overlap
+        auto S = [&](auto next_tag, f32x4 (&vv)[SP]) __attribute__((always_inline)) {
+            constexpr int NEXT = decltype(next_tag)::value;
             int ooff[SP];
             if (s_ow + 16 <= s_OW) {
                 // the slice stays inside one image row: the lane's rows are d0 bytes apart
@@ -683,7 +687,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             }
             // the slice's reads have landed (behind them at most the 16 stores of the next slice's W: lgkmcnt counts to 15, the LDS
             // pipe returns in order -- all but the 15 youngest done means every read done)
-            if constexpr (decltype(more_tag)::value) {
+            if constexpr (false) {
                 if (SP == 8) asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4 % SP]), "+v"(vv[5 % SP]), "+v"(vv[6 % SP]), "+v"(vv[7 % SP]) :: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]) :: "memory");
             } else {
@@ -699,19 +703,22 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #pragma unroll
                 for (int pass = 0; pass < SP; ++pass) vv[pass] += e.bv;
             }
+            static_assert(SP == NT, "one column block of the next slice per store");
 #pragma unroll
             for (int pass = 0; pass < SP; ++pass) {
                 const unsigned oo = unsigned(ooff[pass]);
                 asm volatile("global_store_dwordx4 %1, %0, %2" : "+v"(vv[pass]) : "v"(oo), "s"(ob) : "memory");
+                if constexpr (NEXT < 4) W(next_tag, pass);
             }
             asm volatile("s_nop 1" ::: "memory");
         };
         using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
+        using J4 = std::integral_constant<int, 4>;
         W(J0{});
-        R(J0{}, v0); W(J1{}); S(std::true_type{}, v0);
-        R(J1{}, v1); W(J2{}); S(std::true_type{}, v1);
-        R(J2{}, v0); W(J3{}); S(std::true_type{}, v0);
-        R(J3{}, v1); S(std::false_type{}, v1);
+        R(J0{}, v0); S(J1{}, v0);             // (the reads are waited for with lgkmcnt(0): nothing is behind them yet)
+        R(J1{}, v1); S(J2{}, v1);
+        R(J2{}, v0); S(J3{}, v0);
+        R(J3{}, v1); S(J4{}, v1);
     };
     auto epi_finish = [&](Epi& e) {
         const NG_CONST ConvParams& p = *E.p;
