@@ -658,16 +658,17 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                 for (int pass = 0; pass < SP; ++pass) ooff[pass] = off + pass * d0;
                 off += SP * d0;
                 e.ow += 16;
+                // the lane's first row of the NEXT slice may lie behind the end of this image row (the slice ended at it, or -- odd OW --
+                // one pixel short of it: the second of the lane pair is then already in the next row)
+                const bool wrap_w = e.ow >= e.OW;
+                e.ow -= wrap_w ? e.OW : 0;
+                off += wrap_w ? dW : 0;
+                e.oh += wrap_w ? 1 : 0;
+                const bool wrap_h = e.oh >= e.OH;
+                e.oh -= wrap_h ? e.OH : 0;
+                off += wrap_h ? dH : 0;
                 s_ow += 16;
-                if (s_ow == s_OW) {                 // ... and ends exactly at its end: the next slice starts the next image row
-                    s_ow = 0;
-                    e.ow -= s_OW;
-                    off += dW;
-                    e.oh += 1;
-                    const bool wrap_h = e.oh >= e.OH;
-                    e.oh -= wrap_h ? e.OH : 0;
-                    off += wrap_h ? dH : 0;
-                }
+                s_ow -= s_ow >= s_OW ? s_OW : 0;
             } else {
 #pragma unroll
                 for (int pass = 0; pass < SP; ++pass) {

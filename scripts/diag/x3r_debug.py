@@ -41,3 +41,7 @@ def run(B, H, W, Cc, K):
 
 for case in [(1, 96, 96, 32, 128), (1, 96, 96, 64, 128), (1, 96, 96, 128, 128), (2, 16, 16, 128, 128), (1, 96, 96, 256, 256), (4, 96, 96, 128, 128)]:
     run(*case)
+
+# odd extents (the 532 x 532 maps of configs[3]): T = 529 = two full row tiles + one of 17 rows, two items per workgroup
+for case in [(1, 133, 133, 256, 256), (1, 133, 133, 128, 256), (2, 70, 70, 256, 256)]:
+    run(*case)

@@ -122,7 +122,7 @@ def test_convT_phases_match_torch():
     close(y.t.permute(0, 3, 1, 2), ref, 1e-5, "convT fwd")
 
 
-@pytest.mark.parametrize("shape", [(16, 36, 36), (16, 32, 32), (7, 50, 38)])
+@pytest.mark.parametrize("shape", [(16, 36, 36), (16, 32, 32), (7, 50, 38), (1, 133, 133), (2, 71, 101)])
 def test_sub_pixel_phases_on_the_split_tile_spread_walk(shape):
     """ConvTranspose2d(256, 128, 3, s2, p1, op1) as ONE persistent launch of the split tile over its four phases (1 / 2 / 2 / 4 taps):
     the spread walk of igemm_x3.h (tile t of phase k at walk position (start[k] + t) mod 256; every workgroup gets its share of every
