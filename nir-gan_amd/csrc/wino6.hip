@@ -1577,7 +1577,8 @@ extern "C" int nirgan_wino6_gemm(const nirgan_wino6_desc* d, void* stream) {
     NG_REQUIRE(d->U != nullptr, "wino6_gemm: U is required unless the three-term split tile takes the launch (U3, C %% 32 == 0, K %% 64 == 0)");
     if (d->algo == NIRGAN_W6_TILE256 && d->C % 32 == 0 && d->K % 256 == 0 && g.p.off32) {
         const int per_plane = ((g.p.M + 255) >> 8) * (g.p.N >> 8), total = w6_np(w6_r(d->r)) * per_plane;
-        hipLaunchKernelGGL(wino6_gemm256_kernel, dim3(total < 256 ? total : 256), dim3(512), 0, static_cast<hipStream_t>(stream), g, per_plane, total);
+        const int cus = ng::ng_cu_count_conv();
+        hipLaunchKernelGGL(wino6_gemm256_kernel, dim3(total < cus ? total : cus), dim3(512), 0, static_cast<hipStream_t>(stream), g, per_plane, total);
         return nirgan_check_launch("wino6_gemm (256-wide tile)");
     }
     if (ch == W6_DIRECT) {

@@ -51,6 +51,8 @@ class Ctx:
         self.precision = precision_code(precision)
         if self.device.type != "cuda" and not L.is_emulated():
             raise RuntimeError("nirgan_hip runs on MI355X (cuda device) only; there is no CPU path")
+        if self.device.type == "cuda":
+            G.CUS = torch.cuda.get_device_properties(self.device).multi_processor_count     # the split plans balance against the CUs that exist
         self.zero_page = torch.zeros(64, dtype=torch.float32, device=self.device)
         self.keep: list = []
         self.bytes = 0

@@ -262,7 +262,8 @@ def wgrad_split(M: int, tiles: int, target_blocks: int = 1024, row_mult: int = 3
     return nsplit, rows
 
 
-CUS = 256          # MI355X: the persistent 256-wide launches start one workgroup per CU (csrc/igemm_wgrad.hip::ng_cu_count)
+CUS = 256          # MI355X; engine.Ctx overwrites it with the device's own count: the persistent launches start one workgroup per CU
+                   # (csrc/igemm_wgrad.hip::ng_cu_count, csrc/igemm_conv.hip::ng_cu_count_conv read the same property)
 # cost figures of the 256-wide items in tenths of a convolution K-tile (csrc/igemm_wgrad.hip::pair256_split uses the same ones; measured,
 # profiles/r04_tile256_stamps.txt): convolution K-tile 10 (2 500 cycles) + 65 per tile, weight-gradient K-tile 12 (3 010 cycles) + 40 per unit
 T256_CONV_KT, T256_CONV_FIXED, T256_WGRAD_KT, T256_WGRAD_FIXED = 10, 65, 12, 40
@@ -274,12 +275,13 @@ def wgrad256_ok(M: int, OH: int, OW: int, N: int, K: int, run: int) -> bool:
             and (OH * OW) % 64 == 0 and M % 64 == 0)
 
 
-def pair256_plan(M: int, units_per_split: int, conv_tiles: int = 0, conv_nk: int = 0, cus: int = CUS) -> Tuple[int, int]:
+def pair256_plan(M: int, units_per_split: int, conv_tiles: int = 0, conv_nk: int = 0, cus: int = 0) -> Tuple[int, int]:
     """(nsplit, rows_per_split) of a weight gradient on the 256-wide persistent tiles, alone (conv_tiles = 0) or fused with the data
     gradient's conv_tiles tiles of conv_nk K-tiles each: the split count that minimises the longer walk -- data-gradient workgroups
     ceil(conv_tiles / x) items, weight-gradient workgroups ceil(units / (cus - x)) units of M / 64 / nsplit K-tiles, at the measured cost
     figures above -- and, among equals, the fewest slabs."""
     kt = M // 64
+    cus = cus or CUS
     best = None
     for ns in range(1, min(kt, 64) + 1):
         per = -(-kt // ns)

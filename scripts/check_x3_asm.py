@@ -81,11 +81,21 @@ def parse(path):
     return bodies, meta
 
 
-def loop_span(body):
-    """index range [lo, hi] of the innermost loop that holds the MFMAs (label .. the backward branch to it)"""
+def loop_span(body, whole=True):
+    """index range [lo, hi] (label .. the backward branch to it) of the innermost loop that holds ALL the MFMAs -- the walk over a
+    workgroup's items: first K-tile, K loop, epilogue -- or, whole=False, of the innermost loop that holds any: the K loop itself"""
     mf = [i for i, (c, _) in enumerate(body) if c.startswith("v_mfma")]
     if not mf:
         return None
+    if not whole:
+        labels = {c[:-1]: i for i, (c, _) in enumerate(body) if c.endswith(":")}
+        best = None
+        for i, (c, _) in enumerate(body):
+            m = re.match(r"s_cbranch_\w+\s+(\S+)|s_branch\s+(\S+)", c)
+            tgt = labels.get(m.group(1) or m.group(2)) if m else None
+            if tgt is not None and tgt < i and any(tgt <= k <= i for k in mf) and (best is None or (i - tgt) < (best[1] - best[0])):
+                best = (tgt, i)
+        return best
     labels = {c[:-1]: i for i, (c, _) in enumerate(body) if c.endswith(":")}
     best = None
     for i, (c, _) in enumerate(body):
@@ -178,7 +188,7 @@ def main():
         if not spills_ok and (md.get("vgpr_spill_count", 1) != 0 or md.get("private_segment_fixed_size", 1) != 0):
             problems.append(label + ": spills to scratch")
         scratch_in_loop = 0
-        span = loop_span(bodies[key])
+        span = loop_span(bodies[key], whole=False)
         if span:
             scratch_in_loop = sum(1 for c, _ in bodies[key][span[0]:span[1] + 1] if c.startswith("scratch_"))
             if scratch_in_loop and key.startswith("conv_x3r"):
