@@ -15,6 +15,7 @@
 #include "igemm_tiles.h"
 #include "igemm_tile256.h"
 #include "igemm_x3.h"
+#include <cstdlib>
 #include "igemm_x3r.h"
 
 namespace {
@@ -117,6 +118,9 @@ int ng::ng_cu_count_conv() {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         cus = n;
+#ifdef NG_X3R_STAMP
+        if (const char* e = getenv("NG_X3R_CUS")) cus = atoi(e);        // (diagnostic build: a grid smaller than the chip)
+#endif
     }
     return cus;
 }

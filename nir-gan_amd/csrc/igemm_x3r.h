@@ -78,58 +78,76 @@ struct X3R {
 // the vector half is left to what VALU instructions touch: the raw rows, the split terms, the epilogue)
 #define X3R_DSR(dst, ad, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(ad), "n"(off) : "memory")
 
-// One REGION of the K loop as ONE asm block: the six MFMAs of a (row tile, column tile) pair in the order of conv_x3_persist::mma
-// (al bh, ah bl, am bm, am bh, ah bm, ah bh), optionally interleaved by hand with the conversion of one pair of raw values into the
-// three bf16 terms (11 VALU, x3_split8's rule: two per MFMA gap), optionally behind a counted lgkmcnt wait, optionally followed by the
-// three fragment reads that replace this column tile's B terms.  The accumulator is "+a": it lives in the accumulator half of the
-// register file for the whole kernel (left to itself hipcc keeps a third of the accumulators in VGPRs and moves them back and forth
-// every K-tile).  Hazards: dependent MFMAs on one accumulator back to back are interlocked by the hardware; an MFMA's A / B operands
-// are read in its first passes (the VALU writes here go to OTHER registers: the next K-tile's terms); what reads an accumulator
-// behind the loop waits out the last MFMA explicitly (X3R_MFMA_DRAIN) -- the compiler does not know these are MFMAs.
-#define X3R_M(a, b) "v_mfma_f32_16x16x32_bf16 %[c], %[" #a "], %[" #b "], %[c]\n\t"
-#define X3R_MFMA6 X3R_M(al, b0) X3R_M(ah, b2) X3R_M(am, b1) X3R_M(am, b0) X3R_M(ah, b1) X3R_M(ah, b0)
-#define X3R_MFMA6_CONV \
-    X3R_M(al, b0) "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n\t" "v_lshlrev_b32 %[t0], 16, %[h]\n\t" \
-    X3R_M(ah, b2) "v_and_b32 %[t1], 0xffff0000, %[h]\n\t" "v_sub_f32 %[r0], %[x0], %[t0]\n\t" \
-    X3R_M(am, b1) "v_sub_f32 %[r1], %[x1], %[t1]\n\t" "v_cvt_pk_bf16_f32 %[m], %[r0], %[r1]\n\t" \
-    X3R_M(am, b0) "v_lshlrev_b32 %[t0], 16, %[m]\n\t" "v_and_b32 %[t1], 0xffff0000, %[m]\n\t" \
-    X3R_M(ah, b1) "v_sub_f32 %[r0], %[r0], %[t0]\n\t" "v_sub_f32 %[r1], %[r1], %[t1]\n\t" \
-    X3R_M(ah, b0) "v_cvt_pk_bf16_f32 %[l], %[r0], %[r1]\n\t"
-// the same conversion over TWO regions (a region with all 11 VALU is issue-bound: 6 x 8 cycles of MFMA issue + 11 x 4 > the 96 cycles its
-// MFMAs take; five or six per region leave room for the region's waits and fragment reads): first h, the remainders and m ...
-#define X3R_MFMA6_CONVA \
-    X3R_M(al, b0) "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n\t" \
-    X3R_M(ah, b2) "v_lshlrev_b32 %[t0], 16, %[h]\n\t" "v_and_b32 %[t1], 0xffff0000, %[h]\n\t" \
-    X3R_M(am, b1) "v_sub_f32 %[r0], %[x0], %[t0]\n\t" \
-    X3R_M(am, b0) "v_sub_f32 %[r1], %[x1], %[t1]\n\t" \
-    X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[m], %[r0], %[r1]\n\t" \
-    X3R_M(ah, b0)
-// ... then the second remainders and l
-#define X3R_MFMA6_CONVB \
-    X3R_M(al, b0) "v_lshlrev_b32 %[t0], 16, %[m]\n\t" \
-    X3R_M(ah, b2) "v_and_b32 %[t1], 0xffff0000, %[m]\n\t" \
-    X3R_M(am, b1) "v_sub_f32 %[t0], %[r0], %[t0]\n\t" \
-    X3R_M(am, b0) "v_sub_f32 %[t1], %[r1], %[t1]\n\t" \
-    X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[l], %[t0], %[t1]\n\t" \
-    X3R_M(ah, b0)
-// the FIRST K-tile of an item: the first product of every accumulator takes C = 0 (no zeroing of 128 registers per item)
-#define X3R_M0(a, b) "v_mfma_f32_16x16x32_bf16 %[c], %[" #a "], %[" #b "], 0\n\t"
-#define X3R_MFMA6_CONVA0 \
-    X3R_M0(al, b0) "v_cvt_pk_bf16_f32 %[h], %[x0], %[x1]\n\t" \
-    X3R_M(ah, b2) "v_lshlrev_b32 %[t0], 16, %[h]\n\t" "v_and_b32 %[t1], 0xffff0000, %[h]\n\t" \
-    X3R_M(am, b1) "v_sub_f32 %[r0], %[x0], %[t0]\n\t" \
-    X3R_M(am, b0) "v_sub_f32 %[r1], %[x1], %[t1]\n\t" \
-    X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[m], %[r0], %[r1]\n\t" \
-    X3R_M(ah, b0)
-#define X3R_MFMA6_CONVB0 \
-    X3R_M0(al, b0) "v_lshlrev_b32 %[t0], 16, %[m]\n\t" \
-    X3R_M(ah, b2) "v_and_b32 %[t1], 0xffff0000, %[m]\n\t" \
-    X3R_M(am, b1) "v_sub_f32 %[t0], %[r0], %[t0]\n\t" \
-    X3R_M(am, b0) "v_sub_f32 %[t1], %[r1], %[t1]\n\t" \
-    X3R_M(ah, b1) "v_cvt_pk_bf16_f32 %[l], %[t0], %[t1]\n\t" \
-    X3R_M(ah, b0)
+// One REGION of the K loop as ONE asm block: the twelve MFMAs of a row tile against TWO column tiles -- per accumulator in the order of
+// conv_x3_persist::mma (al bh, ah bl, am bm, am bh, ah bm, ah bh) -- interleaved by hand with the conversion of one pair of raw values into
+// the three bf16 terms (11 VALU: x3_split8's rule), optionally behind a counted lgkmcnt wait, optionally with the six fragment reads that replace the two column tiles' B terms.
+// With ONE wave per SIMD every instruction costs its issue cycles (4 per VALU / SALU / memory instruction, 8 per MFMA; an MFMA occupies
+// the pipe for 16): what does not fit the two free slots behind each MFMA adds its full cost to the tile (measured with knock-out builds,
+// scripts/diag/x3r_knockout.sh).  Hence regions of
+// twelve: hipcc puts an `s_nop 0` between two inline asm statements that share any register operand (a hazard it cannot rule out), and
+// consecutive six-MFMA regions shared the conversion's temporaries -- 36 of them per K-tile.  The temporaries here are FIXED registers
+// (clobbers), two sets used alternately, so consecutive regions name no common register.
+// The accumulators are "+a": they live in the accumulator half of the register file for the whole kernel (left to itself hipcc keeps a
+// third of them in VGPRs and moves them back and forth every K-tile).  Hazards: dependent MFMAs on one accumulator back to back are
+// interlocked by the hardware; an MFMA's A / B operands are read in its first passes (the VALU writes here go to OTHER registers: the
+// next K-tile's terms); what reads an accumulator behind the loop waits out the last MFMA explicitly (X3R_MFMA_DRAIN) -- the compiler
+// does not know these are MFMAs.
+#define X3R_MC(c, a, b) "v_mfma_f32_16x16x32_bf16 %[" #c "], %[" #a "], %[" #b "], %[" #c "]\n\t"
+#define X3R_MZ(c, a, b) "v_mfma_f32_16x16x32_bf16 %[" #c "], %[" #a "], %[" #b "], 0\n\t"
+// (diagnostic builds only, scripts/diag/x3r_knockout.sh: NG_X3R_KO is a bit mask of parts of the K loop left out -- wrong results, timing
+// of what remains: 1 the conversion's VALU, 2 its v_cvt_pk replaced by v_and, 4 the raw rows' fetches, 8 the B pieces' fetches and
+// stores, 16 the fragment reads of block 3, 32 the full epilogue's staging writes and reads, 64 its global stores)
+#ifndef NG_X3R_KO
+#define NG_X3R_KO 0
+#endif
+#if NG_X3R_KO & 1
+#define X3R_V(s)
+#else
+#define X3R_V(s) s
+#endif
+#if NG_X3R_KO & 2
+#define X3R_CVT "v_and_b32 "
+#else
+#define X3R_CVT "v_cvt_pk_bf16_f32 "
+#endif
+#if NG_X3R_KO & 16
+#define X3R_RD(s)
+#else
+#define X3R_RD(s) s
+#endif
+// (v_pk_add_f32 for the two subtractions of a step -- 9 instead of 11 VALU per pair -- is SLOWER: + 100 cycles per block of 48 MFMAs,
+// stamps: the packed add costs about three plain ones here)
+#ifndef NG_X3R_PK
+#define NG_X3R_PK 0
+#endif
+#if NG_X3R_PK
+#define X3R_SUB2(RP, R0, R1, XP, X0, X1, TP, T0, T1) X3R_V("v_pk_add_f32 " RP ", " XP ", " TP " neg_lo:[0,1] neg_hi:[0,1]\n\t")
+#else
+#define X3R_SUB2(RP, R0, R1, XP, X0, X1, TP, T0, T1) X3R_V("v_sub_f32 " R0 ", " X0 ", " T0 "\n\t") X3R_V("v_sub_f32 " R1 ", " X1 ", " T1 "\n\t")
+#endif
+// MA / MB: the first product of each accumulator (X3R_MC, or X3R_MZ in an item's first K-tile: C = 0, nothing zeroes 128 registers per
+// item); T0 T1 TP / R0 R1 RP: the temporaries (a register pair each, by halves and whole); RDA / RDB: the reads replacing the first /
+// second column tile's fragments (block 3), behind the last MFMA that names them
+#define X3R_PAIR(MA, MB, T0, T1, TP, R0, R1, RP, RDA, RDB) \
+    MA(c0, al, b0) X3R_V(X3R_CVT "%[h], %[x0], %[x1]\n\t") \
+    X3R_MC(c0, ah, b2) X3R_V("v_lshlrev_b32 " T0 ", 16, %[h]\n\t") X3R_V("v_and_b32 " T1 ", 0xffff0000, %[h]\n\t") \
+    X3R_MC(c0, am, b1) X3R_SUB2(RP, R0, R1, "%[x]", "%[x0]", "%[x1]", TP, T0, T1) \
+    X3R_MC(c0, am, b0) X3R_V(X3R_CVT "%[m], " R0 ", " R1 "\n\t") \
+    X3R_MC(c0, ah, b1) X3R_V("v_lshlrev_b32 " T0 ", 16, %[m]\n\t") X3R_V("v_and_b32 " T1 ", 0xffff0000, %[m]\n\t") \
+    X3R_MC(c0, ah, b0) X3R_SUB2(RP, R0, R1, RP, R0, R1, TP, T0, T1) \
+    MB(c1, al, d0) X3R_V(X3R_CVT "%[l], " R0 ", " R1 "\n\t") \
+    X3R_MC(c1, ah, d2) RDA \
+    X3R_MC(c1, am, d1) \
+    X3R_MC(c1, am, d0) \
+    X3R_MC(c1, ah, d1) \
+    X3R_MC(c1, ah, d0) RDB
+#define X3R_TA "v248", "v249", "v[248:249]", "v250", "v251", "v[250:251]"
+#define X3R_TB "v252", "v253", "v[252:253]", "v254", "v255", "v[254:255]"
+#define X3R_CLOB_A "memory", "v248", "v249", "v250", "v251"
+#define X3R_CLOB_B "memory", "v252", "v253", "v254", "v255"
 #define X3R_WAITL "s_waitcnt lgkmcnt(%[w])\n\t"
-#define X3R_READS "ds_read_b128 %[b0], %[bad] offset:%[o0]\n\t" "ds_read_b128 %[b1], %[bad] offset:%[o1]\n\t" "ds_read_b128 %[b2], %[bad] offset:%[o2]\n\t"
+#define X3R_READS_A X3R_RD("ds_read_b128 %[b0], %[bad] offset:%[o0]\n\t" "ds_read_b128 %[b1], %[bad] offset:%[o1]\n\t" "ds_read_b128 %[b2], %[bad] offset:%[o2]\n\t")
+#define X3R_READS_B X3R_RD("ds_read_b128 %[d0], %[bad] offset:%[o3]\n\t" "ds_read_b128 %[d1], %[bad] offset:%[o4]\n\t" "ds_read_b128 %[d2], %[bad] offset:%[o5]\n\t")
 #define X3R_MFMA_DRAIN asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 // GEN: the launch's problems leave instance-norm partial sums or run the fused first backward pass (their epilogue branches and needs
@@ -155,9 +173,22 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     struct Item {
         const NG_CONST ConvParams* p;
         const char* in8; const char* w8; float* out;
-        int m0, n0, nk, ntaps, run;
+        int m0, n0, nk, ntaps, run, k;
         long long w3_plane;
     };
+    // the tap tables of the launch's (at most four) problems, lane i of tapq[k] = tap i of problem k: fetched ONCE, here -- per item they
+    // cost sixteen scalar loads that hipcc issues one behind the other through one SGPR, each with its own wait: 1 400 of the 2 060 cycles
+    // between two items, measured (scripts/diag/x3r_knockout.sh)
+    int tapq[4];
+    {
+        const unsigned to = unsigned(lane & (NIRGAN_MAX_TAPS - 1)) * 4u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char* tb = ng_uniform_ptr(reinterpret_cast<const char*>((const int*)wp->p[q].tap_off));
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(tapq[q]) : "v"(to), "s"(tb) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(tapq[0]), "+v"(tapq[1]), "+v"(tapq[2]), "+v"(tapq[3]) :: "memory");
+    }
     auto locate = [&](const int item, Item& t) {
         int k = 0, id = 0;
         if (wp->spread) {
@@ -192,6 +223,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         }
         const int ntn = p->N / BN;
         t.p = p;
+        t.k = k;
         t.n0 = (id % ntn) * BN;
         t.m0 = (id / ntn) * 256;
         t.ntaps = p->ntaps;
@@ -248,10 +280,8 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         const int b_c = (lane & 3) ^ x3_key(lane >> 2);
         c.b0 = unsigned((t.n0 + wave * 16 + (lane >> 2)) * pK + b_c * 8) * 2u;
         c.b1 = c.b0 + unsigned(64 * pK) * 2u;
-        // the tap table into a VGPR (lane i holds tap i: the cursor picks with v_readlane) through SCALAR loads and selects
-        c.tapv = 0;
-#pragma unroll
-        for (int i = 0; i < NIRGAN_MAX_TAPS; ++i) c.tapv = (lane & (NIRGAN_MAX_TAPS - 1)) == i ? p.tap_off[i] : c.tapv;
+        // the tap table in a VGPR (lane i holds tap i: the cursor picks with v_readlane)
+        c.tapv = t.k == 0 ? tapq[0] : (t.k == 1 ? tapq[1] : (t.k == 2 ? tapq[2] : tapq[3]));
         c.in8 = ng_uniform_ptr(t.in8);
 #pragma unroll
         for (int q = 0; q < 3; ++q) c.w8[q] = ng_uniform_ptr(t.w8 + (long long)q * t.w3_plane * 2);
@@ -272,32 +302,43 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #pragma unroll
         for (int q = 0; q < 3; ++q) baseW[q] = L.w8[q] + kb;
     };
-    auto step_cursor = [&]() {                  // the cursor moves on: what it stood on becomes the snapshot
-        baseP = baseC;
-        goff3P = L.goff[3];
-        const bool cross = left == 1;           // (uniform)
-        // inside the item: the next tap of this slice, or the first tap of the next slice
-        int ct1 = ct + 1, cc1 = cc, kb1 = kb + L.run2;
-        const bool wrap = ct1 == L.ntaps;
-        ct1 = wrap ? 0 : ct1;
-        cc1 = wrap ? cc + 32 : cc1;
-        kb1 = wrap ? cc1 * 2 : kb1;
-        ct = cross ? 0 : ct1;
-        cc = cross ? 0 : cc1;
-        kb = cross ? 0 : kb1;
-        left = cross ? N.nk : left - 1;
+    // the cursor moves on: what it stood on becomes the snapshot.  (Issued in pieces behind regions of block 0 instead of between two
+    // tiles, the same ~60 scalar and vector selects cost MORE: block 0 + 400 cycles against 130 saved between the tiles, stamps -- the
+    // PIECE argument is what is left of that experiment)
+    bool crossS = false;
+    auto step_cursor = [&](auto piece_tag) __attribute__((always_inline)) {
+        constexpr int PIECE = decltype(piece_tag)::value;
+        if constexpr (PIECE < 0 || PIECE == 0) {
+            baseP = baseC;
+            goff3P = L.goff[3];
+            crossS = left == 1;                 // (uniform)
+            // inside the item: the next tap of this slice, or the first tap of the next slice
+            int ct1 = ct + 1, cc1 = cc, kb1 = kb + L.run2;
+            const bool wrap = ct1 == L.ntaps;
+            ct1 = wrap ? 0 : ct1;
+            cc1 = wrap ? cc + 32 : cc1;
+            kb1 = wrap ? cc1 * 2 : kb1;
+            ct = crossS ? 0 : ct1;
+            cc = crossS ? 0 : cc1;
+            kb = crossS ? 0 : kb1;
+            left = crossS ? N.nk : left - 1;
+        }
         // onto the next item: every field a select (the K loop keeps one basic block per region)
-        L.in8 = cross ? N.in8 : L.in8;
+        if constexpr (PIECE < 0 || PIECE == 1) {
+            L.in8 = crossS ? N.in8 : L.in8;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) L.w8[q] = cross ? N.w8[q] : L.w8[q];
-        L.ntaps = cross ? N.ntaps : L.ntaps;
-        L.run2 = cross ? N.run2 : L.run2;
+            for (int q = 0; q < 3; ++q) L.w8[q] = crossS ? N.w8[q] : L.w8[q];
+            L.ntaps = crossS ? N.ntaps : L.ntaps;
+            L.run2 = crossS ? N.run2 : L.run2;
+        }
+        if constexpr (PIECE < 0 || PIECE == 2) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) L.goff[mt] = cross ? N.goff[mt] : L.goff[mt];
-        L.b0 = cross ? N.b0 : L.b0;
-        L.b1 = cross ? N.b1 : L.b1;
-        L.tapv = cross ? N.tapv : L.tapv;
-        cursor_bases();
+            for (int mt = 0; mt < 4; ++mt) L.goff[mt] = crossS ? N.goff[mt] : L.goff[mt];
+            L.b0 = crossS ? N.b0 : L.b0;
+            L.b1 = crossS ? N.b1 : L.b1;
+            L.tapv = crossS ? N.tapv : L.tapv;
+        }
+        if constexpr (PIECE < 0 || PIECE == 3) cursor_bases();
     };
     f32x4 F[4][2];                              // raw rows: F[mt] = this lane's 8 k of its row of 16-row tile mt
     f32x4 Braw[PIECES];                         // raw B pieces (bf16 bits): 16 bytes per lane and piece
@@ -320,10 +361,18 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // (ONE asm statement per wait, the choice between its two counts a scalar branch INSIDE it: two statements in the arms of a C++ `if`
     // let the compiler merge the tied registers with copies in front of one of them -- copies of a destination whose load has not landed)
 #define X3R_WAITV2(N) "s_cmp_eq_u32 %[sb], 0\n\ts_cbranch_scc1 .Lx3rw%=\n\ts_waitcnt vmcnt(%[n1])\n\ts_branch .Lx3rv%=\n.Lx3rw%=:\n\ts_waitcnt vmcnt(" #N ")\n.Lx3rv%=:"
-    auto wait_raw = [&](f32x4 (&f)[2], auto n_tag) {
-        const int sb = __builtin_amdgcn_readfirstlane(stores_behind ? 1 : 0);
-        if constexpr (decltype(n_tag)::value == 12) asm volatile(X3R_WAITV2(12) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(12 + EST) : "memory", "scc");
-        else asm volatile(X3R_WAITV2(6) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
+    // (only an item's FIRST K-tile can have stores behind its fetches: the steady tile's waits are plain counts, no compare and branch --
+    // five waits per tile, four instructions each, every one of them paid in full with one wave per SIMD)
+    auto wait_raw = [&](f32x4 (&f)[2], auto n_tag, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if constexpr (FIRST) {
+            const int sb = __builtin_amdgcn_readfirstlane(stores_behind ? 1 : 0);
+            if constexpr (decltype(n_tag)::value == 12) asm volatile(X3R_WAITV2(12) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(12 + EST) : "memory", "scc");
+            else asm volatile(X3R_WAITV2(6) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
+        } else {
+            if constexpr (decltype(n_tag)::value == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
+        }
     };
     // pair i (k = 2 i, 2 i + 1 of the lane's eight) of a raw row set into dword i of the three terms: 11 VALU (x3_split8's rule)
     auto convert_pair = [&](const f32x4 (&f)[2], u32x4 (&a)[3], const int i) {
@@ -372,64 +421,45 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     const int swz = ((lane >> 4) ^ x3_key(lane & 15)) << 4;
     const unsigned b_rd = unsigned((lane & 15) * 64 + swz);
     int sj = 0;                                 // LDS stage of the K-tile being multiplied
-    // one region (see X3R_MFMA6 above).  HALF: 0 = first half of the conversion of pair PAIR (h, the remainders, m), 1 = its second half
-    // (l), -1 = no conversion; WAIT < 0: no wait; READ: the column tile's fragments of the NEXT K-tile behind its MFMAs
-    float cr0 = 0.f, cr1 = 0.f;                 // the remainders of the pair whose conversion is under way
-    unsigned cm = 0;
-    auto region = [&](auto first_tag, auto mt_tag, auto nt_tag, auto src_tag, auto pair_tag, auto half_tag, auto wait_tag, auto read_tag, const unsigned bad) __attribute__((always_inline)) {
-        constexpr int MT = decltype(mt_tag)::value, NTI = decltype(nt_tag)::value, SRC = decltype(src_tag)::value, PAIR = decltype(pair_tag)::value,
-                      HALF = decltype(half_tag)::value, WAIT = decltype(wait_tag)::value;
+    // one region (see X3R_PAIR above): row tile MT against column tiles 2 P and 2 P + 1; pair P of raw set SRC becomes dword P of A[SRC]'s
+    // three terms; WAIT >= 0: behind a counted lgkmcnt wait (block 0); READ: both column tiles' fragments of the NEXT K-tile behind their
+    // last MFMAs (block 3)
+    auto region = [&](auto first_tag, auto mt_tag, auto p_tag, auto src_tag, auto wait_tag, auto read_tag, const unsigned bad) __attribute__((always_inline)) {
+        constexpr int MT = decltype(mt_tag)::value, P = decltype(p_tag)::value, SRC = decltype(src_tag)::value, WAIT = decltype(wait_tag)::value;
+        constexpr int N0 = 2 * P, N1 = 2 * P + 1;
         constexpr bool READ = decltype(read_tag)::value, FIRST = decltype(first_tag)::value;
-        static_assert(HALF >= 0, "every region of the 128-column form carries half a pair of the conversion");
         static_assert(!(WAIT >= 0 && READ), "a region waits for fragments (block 0) or replaces them (block 3)");
-        f32x4& c = acc[MT][NTI];
-#define X3R_ACC_B_INOUT [c] "+a"(c), [b0] "+a"(Bf[NTI][0]), [b1] "+a"(Bf[NTI][1]), [b2] "+a"(Bf[NTI][2])
-#define X3R_A_IN [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2])
-#define X3R_B_IN [b0] "a"(Bf[NTI][0]), [b1] "a"(Bf[NTI][1]), [b2] "a"(Bf[NTI][2])
-#define X3R_RD_IN [bad] "v"(bad), [o0] "n"(NTI * 1024), [o1] "n"(B_TERM + NTI * 1024), [o2] "n"(2 * B_TERM + NTI * 1024)
-        if constexpr (HALF == 0) {
-            const float x0 = F[SRC][PAIR >> 1][(2 * PAIR) & 3], x1 = F[SRC][PAIR >> 1][(2 * PAIR + 1) & 3];
-            unsigned h;
-            float t0, t1;
-#define X3R_CONVA_OUT [h] "=&v"(h), [m] "=&v"(cm), [t0] "=&v"(t0), [t1] "=&v"(t1), [r0] "=&v"(cr0), [r1] "=&v"(cr1)
-            if constexpr (FIRST) {
-                if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6_CONVA0 : X3R_ACC_B_INOUT, X3R_CONVA_OUT : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), [w] "n"(WAIT) : "memory");
-                else if constexpr (READ) asm volatile(X3R_MFMA6_CONVA0 X3R_READS : X3R_ACC_B_INOUT, X3R_CONVA_OUT : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), X3R_RD_IN : "memory");
-                else asm volatile(X3R_MFMA6_CONVA0 : [c] "+a"(c), X3R_CONVA_OUT : X3R_A_IN, X3R_B_IN, [x0] "v"(x0), [x1] "v"(x1) : "memory");
-            } else {
-                if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6_CONVA : X3R_ACC_B_INOUT, X3R_CONVA_OUT : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), [w] "n"(WAIT) : "memory");
-                else if constexpr (READ) asm volatile(X3R_MFMA6_CONVA X3R_READS : X3R_ACC_B_INOUT, X3R_CONVA_OUT : X3R_A_IN, [x0] "v"(x0), [x1] "v"(x1), X3R_RD_IN : "memory");
-                else asm volatile(X3R_MFMA6_CONVA : [c] "+a"(c), X3R_CONVA_OUT : X3R_A_IN, X3R_B_IN, [x0] "v"(x0), [x1] "v"(x1) : "memory");
-            }
-#undef X3R_CONVA_OUT
-            A[SRC][0][PAIR] = h;
-            A[SRC][1][PAIR] = cm;
-        } else if constexpr (HALF == 1) {
-            unsigned l;
-            float t0, t1;
-#define X3R_CONVB_OUT [l] "=&v"(l), [t0] "=&v"(t0), [t1] "=&v"(t1)
-#define X3R_CONVB_IN [m] "v"(cm), [r0] "v"(cr0), [r1] "v"(cr1)
-            if constexpr (FIRST) {
-                if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6_CONVB0 : X3R_ACC_B_INOUT, X3R_CONVB_OUT : X3R_A_IN, X3R_CONVB_IN, [w] "n"(WAIT) : "memory");
-                else if constexpr (READ) asm volatile(X3R_MFMA6_CONVB0 X3R_READS : X3R_ACC_B_INOUT, X3R_CONVB_OUT : X3R_A_IN, X3R_CONVB_IN, X3R_RD_IN : "memory");
-                else asm volatile(X3R_MFMA6_CONVB0 : [c] "+a"(c), X3R_CONVB_OUT : X3R_A_IN, X3R_B_IN, X3R_CONVB_IN : "memory");
-            } else {
-                if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6_CONVB : X3R_ACC_B_INOUT, X3R_CONVB_OUT : X3R_A_IN, X3R_CONVB_IN, [w] "n"(WAIT) : "memory");
-                else if constexpr (READ) asm volatile(X3R_MFMA6_CONVB X3R_READS : X3R_ACC_B_INOUT, X3R_CONVB_OUT : X3R_A_IN, X3R_CONVB_IN, X3R_RD_IN : "memory");
-                else asm volatile(X3R_MFMA6_CONVB : [c] "+a"(c), X3R_CONVB_OUT : X3R_A_IN, X3R_B_IN, X3R_CONVB_IN : "memory");
-            }
-#undef X3R_CONVB_OUT
-#undef X3R_CONVB_IN
-            A[SRC][2][PAIR] = l;
+        f32x4& c0 = acc[MT][N0];
+        f32x4& c1 = acc[MT][N1];
+        const float x0 = F[SRC][P >> 1][(2 * P) & 3], x1 = F[SRC][P >> 1][(2 * P + 1) & 3];
+        const f32x2 x = {x0, x1};
+        unsigned h, m, l;
+#define X3R_ACC [c0] "+a"(c0), [c1] "+a"(c1)
+#define X3R_B_INOUT [b0] "+a"(Bf[N0][0]), [b1] "+a"(Bf[N0][1]), [b2] "+a"(Bf[N0][2]), [d0] "+a"(Bf[N1][0]), [d1] "+a"(Bf[N1][1]), [d2] "+a"(Bf[N1][2])
+#define X3R_B_IN [b0] "a"(Bf[N0][0]), [b1] "a"(Bf[N0][1]), [b2] "a"(Bf[N0][2]), [d0] "a"(Bf[N1][0]), [d1] "a"(Bf[N1][1]), [d2] "a"(Bf[N1][2])
+#define X3R_TERMS [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l)
+#define X3R_A_IN [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x] "v"(x), [x0] "v"(x0), [x1] "v"(x1)
+#define X3R_RD_IN [bad] "v"(bad), [o0] "n"(N0 * 1024), [o1] "n"(B_TERM + N0 * 1024), [o2] "n"(2 * B_TERM + N0 * 1024), \
+                  [o3] "n"(N1 * 1024), [o4] "n"(B_TERM + N1 * 1024), [o5] "n"(2 * B_TERM + N1 * 1024)
+#define X3R_EMIT(MA, T, CLOB) \
+        if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_PAIR(MA, MA, T, "", "") : X3R_ACC, X3R_B_INOUT, X3R_TERMS : X3R_A_IN, [w] "n"(WAIT) : CLOB); \
+        else if constexpr (READ) asm volatile(X3R_PAIR(MA, MA, T, X3R_READS_A, X3R_READS_B) : X3R_ACC, X3R_B_INOUT, X3R_TERMS : X3R_A_IN, X3R_RD_IN : CLOB); \
+        else asm volatile(X3R_PAIR(MA, MA, T, "", "") : X3R_ACC, X3R_TERMS : X3R_A_IN, X3R_B_IN : CLOB);
+        if constexpr (P & 1) {
+            if constexpr (FIRST) { X3R_EMIT(X3R_MZ, X3R_TB, X3R_CLOB_B) } else { X3R_EMIT(X3R_MC, X3R_TB, X3R_CLOB_B) }
         } else {
-            if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_MFMA6 : X3R_ACC_B_INOUT : X3R_A_IN, [w] "n"(WAIT) : "memory");
-            else if constexpr (READ) asm volatile(X3R_MFMA6 X3R_READS : X3R_ACC_B_INOUT : X3R_A_IN, X3R_RD_IN : "memory");
-            else asm volatile(X3R_MFMA6 : [c] "+a"(c) : X3R_A_IN, X3R_B_IN : "memory");
+            if constexpr (FIRST) { X3R_EMIT(X3R_MZ, X3R_TA, X3R_CLOB_A) } else { X3R_EMIT(X3R_MC, X3R_TA, X3R_CLOB_A) }
         }
-#undef X3R_ACC_B_INOUT
-#undef X3R_A_IN
+#undef X3R_EMIT
+#undef X3R_ACC
+#undef X3R_B_INOUT
 #undef X3R_B_IN
+#undef X3R_TERMS
+#undef X3R_A_IN
 #undef X3R_RD_IN
+        A[SRC][0][P] = h;
+        A[SRC][1][P] = m;
+        A[SRC][2][P] = l;
     };
 #define X3R_RB(NTI, ad) { X3R_DSR(Bf[NTI][0], ad, (NTI) * 1024); X3R_DSR(Bf[NTI][1], ad, B_TERM + (NTI) * 1024); X3R_DSR(Bf[NTI][2], ad, 2 * B_TERM + (NTI) * 1024); }
 
@@ -624,7 +654,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             const unsigned sw = sw0 + (mt & 1) * HALF, sw2 = sw + 2 * BN * 4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (only >= 0 && nt != only) continue;
+                if ((only >= 0 && nt != only) || (NG_X3R_KO & 32)) continue;
                 const f32x4 c = acc[mt][nt];
                 const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
                 // (offsets in dwords: column block nt, the second row BN dwords on)
@@ -641,6 +671,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             const unsigned sr = sr0 + (mt & 1) * HALF;
 #pragma unroll
             for (int pass = 0; pass < SP; ++pass) {
+                if (NG_X3R_KO & 32) { asm volatile("" : "=v"(vv[pass]) :: "memory"); continue; }
                 if (pass == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(vv[0]) : "v"(sr) : "memory");
 #define X3R_RDP(P) else if (pass == P) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vv[P % SP]) : "v"(sr), "n"(P * RPP * BN * 4) : "memory");
                 X3R_RDP(1) X3R_RDP(2) X3R_RDP(3) X3R_RDP(4) X3R_RDP(5) X3R_RDP(6) X3R_RDP(7)
@@ -708,7 +739,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #pragma unroll
             for (int pass = 0; pass < SP; ++pass) {
                 const unsigned oo = unsigned(ooff[pass]);
-                asm volatile("global_store_dwordx4 %1, %0, %2" : "+v"(vv[pass]) : "v"(oo), "s"(ob) : "memory");
+                if (!(NG_X3R_KO & 64)) asm volatile("global_store_dwordx4 %1, %0, %2" : "+v"(vv[pass]) : "v"(oo), "s"(ob) : "memory");
                 if constexpr (NEXT < 4) W(next_tag, pass);
             }
             asm volatile("s_nop 1" ::: "memory");
@@ -778,7 +809,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // one per region of block 1), L0 (2, K-tile j + 2; last region of block 1), L1 (2), L2 (2) = 14.  A raw set is waited for one tile
     // after its loads: the B pieces in the first region of block 0 (6 behind them: L0, L1, L2), row tile 3 there too (12), row tile 0
     // in front of this tile's B pieces (6), row tiles 1 and 2 with 12 behind them.
-    // The schedule is written region by region, each region one asm block (X3R_MFMA6...): the loop's instruction stream is what is
+    // The schedule is written region by region, each region one asm block (X3R_PAIR): the loop's instruction stream is what is
     // written here, in this order (every statement of the loop is a volatile asm; hipcc allocates the registers).
     auto tile = [&](auto first_tag) __attribute__((always_inline)) {
         const unsigned bnext = ring0 + unsigned((sj ^ 1) * STAGE) + b_rd;
@@ -789,32 +820,35 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             // the conversion's four pairs: NT = 8 -- a half per region (pair nt / 2); NT = 4 -- a pair per region (both halves: two calls)
             if (MT == 0) {
                 // K-tile j + 1's pieces of B have landed (fetched in block 1 of the previous tile)
-                const int sb = __builtin_amdgcn_readfirstlane(stores_behind ? 1 : 0);
-                if (PIECES == 6) asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
-                else asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
-            }
-            wait_raw(F[SRC], std::integral_constant<int, MT == 1 ? 6 : 12>{});
-            auto one = [&](auto nt_tag) __attribute__((always_inline)) {
-                constexpr int nt = decltype(nt_tag)::value;
-                if constexpr (nt < NT) {
-                    // block 0: this fragment's three reads were issued behind the previous tile's block 3, followed by those of the
-                    // fragments after it (the B stores of this block, issued behind earlier regions, only make the wait stricter)
-                    constexpr int behind = 3 * (NT - 1 - nt);
-                    using W = std::integral_constant<int, MT == 0 ? (behind > 15 ? 15 : behind) : -1>;
-                    static_assert(NT == 8, "the 64-column form needs its own region (a whole pair per region)");
-                    using PR = std::integral_constant<int, nt / 2>;
-                    using HF = std::integral_constant<int, nt & 1>;
-                    region(first_tag, mt_tag, nt_tag, src_tag, PR{}, HF{}, W{}, std::integral_constant<bool, MT == 3>{}, bnext);
-                    if (nt == NT - 1) loadA(F[SRC], base, goff);
-                    // K-tile j + 1's pieces of B into the other stage (every wave has left it: it held K-tile j - 1, last read in block 3 of
-                    // tile j - 2, in front of tile j - 1's barrier)
-                    if (MT == 0 && nt >= NT - PIECES) storeB(stage_next, nt - (NT - PIECES));
-                    if (MT == 1 && nt < PIECES) loadB(nt);          // K-tile j + 2's pieces, behind the stores that emptied the registers
-                    if (MT == 3 && nt == NT - 1) { sj ^= 1; step_cursor(); }       // (the cursor's step behind the tile's last MFMAs)
+                if constexpr (decltype(first_tag)::value) {
+                    const int sb = __builtin_amdgcn_readfirstlane(stores_behind ? 1 : 0);
+                    if (PIECES == 6) asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
+                    else asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
+                } else {
+                    if (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) :: "memory");
                 }
+            }
+            wait_raw(F[SRC], std::integral_constant<int, MT == 1 ? 6 : 12>{}, first_tag);
+            auto one = [&](auto p_tag) __attribute__((always_inline)) {
+                constexpr int P = decltype(p_tag)::value, nt = 2 * P + 1;       // (nt: the second column tile of the region)
+                static_assert(NT == 8, "the 64-column form needs its own region");
+                // block 0: the second column tile's three reads were issued behind the previous tile's block 3, followed by those of
+                // the fragments after it (the B stores of this block, issued behind earlier regions, only make the wait stricter)
+                constexpr int behind = 3 * (NT - 1 - nt);
+                using W = std::integral_constant<int, MT == 0 ? (behind > 15 ? 15 : behind) : -1>;
+                region(first_tag, mt_tag, p_tag, src_tag, W{}, std::integral_constant<bool, MT == 3>{}, bnext);
+                if (P == 3 && !(NG_X3R_KO & 4)) {
+                    loadA(F[SRC], base, goff);
+                }
+                // K-tile j + 1's pieces of B into the other stage (every wave has left it: it held K-tile j - 1, last read in block 3 of
+                // tile j - 2, in front of tile j - 1's barrier)
+                if (MT == 0 && P >= 1 && !(NG_X3R_KO & 8)) { storeB(stage_next, 2 * (P - 1)); storeB(stage_next, 2 * (P - 1) + 1); }
+                if (MT == 1 && P < 3 && !(NG_X3R_KO & 8)) { loadB(2 * P); loadB(2 * P + 1); }      // K-tile j + 2's pieces, behind the stores that emptied the registers
+                if (MT == 3 && P == 3) { sj ^= 1; step_cursor(std::integral_constant<int, -1>{}); }     // (the cursor's step behind the tile's last MFMAs)
             };
+            static_assert(PIECES == 6, "six B pieces per wave and K-tile: two behind each of three regions");
             one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
-            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{}); one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         X3R_STAMP(5)                                     // (what lies between two tiles: the loop's overhead, an epilogue's tail)
@@ -880,13 +914,13 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         }
     }
     loadA(F[3], baseC, L.goff[3]);              // K-tile 0's row tile 3: converted in block 0 of tile 0
-    step_cursor();                              // snapshot = K-tile 0, cursor on K-tile 1
+    step_cursor(std::integral_constant<int, -1>{});      // snapshot = K-tile 0, cursor on K-tile 1
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) loadB(i);
     loadA(F[0], baseC, L.goff[0]);
     loadA(F[1], baseC, L.goff[1]);
     loadA(F[2], baseC, L.goff[2]);
-    step_cursor();                              // snapshot = K-tile 1, cursor on K-tile 2: the state tile 0 expects
+    step_cursor(std::integral_constant<int, -1>{});      // snapshot = K-tile 1, cursor on K-tile 2: the state tile 0 expects
 #ifdef NG_X3R_STAMP
     { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_last = unsigned(t_); }
 #endif

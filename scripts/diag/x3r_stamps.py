@@ -7,7 +7,9 @@ sys.path.insert(0, os.path.join(ROOT, "nir-gan_amd"))
 import numpy as np
 import torch
 from nirgan_hip import lib as L
-L.set_backend(L._CLib(os.path.join(ROOT, "scripts", "diag", "libnirgan_x3rstamp.so")))
+LIB = os.environ.get("X3R_LIB", os.path.join(ROOT, "scripts", "diag", "libnirgan_x3rstamp.so"))
+print("library:", LIB)
+L.set_backend(L._CLib(os.path.abspath(LIB)))
 be = L.backend()
 fn = be._dll.nirgan_x3r_stamps
 fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]
@@ -20,6 +22,7 @@ def report(title):
     buf = (C.c_ulonglong * (256 * 4 * 16))()
     assert fn(buf, 256 * 4 * 16) == 0
     a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 4, 16).astype(np.float64)
+    a = a[a[:, 0, 15] > 0]                                  # (NG_X3R_CUS: a grid smaller than the chip)
     tiles, items = a[..., 15], a[..., 14]
     print(title, f"  tiles per wave {tiles.mean():.1f}, items per wave {items.mean():.1f}")
     tot = 0.0
