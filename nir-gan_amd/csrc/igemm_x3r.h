@@ -464,7 +464,13 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #define X3R_RB(NTI, ad) { X3R_DSR(Bf[NTI][0], ad, (NTI) * 1024); X3R_DSR(Bf[NTI][1], ad, B_TERM + (NTI) * 1024); X3R_DSR(Bf[NTI][2], ad, 2 * B_TERM + (NTI) * 1024); }
 
     // ---------------- epilogue of the item whose K-tiles are being multiplied (`E`), in four slices of 16 rows per wave
-    Item E;
+    // (what outlives an item's lookup: the epilogue's view of it -- seven scalar registers per slot, three slots)
+    struct Slot {
+        const NG_CONST ConvParams* p;
+        float* out;
+        int m0, n0, nk;
+    };
+    Slot E;
     char* const stg8 = stg_all + wave * T::STG;
     float* const stg = reinterpret_cast<float*>(stg8);
     const unsigned stg_lds = unsigned(size_t((NG_LDS char*)stg8));
@@ -637,9 +643,24 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     //   the byte offsets of the lane's rows: ONE add per slice while the slice's 16 rows do not cross an image row (a scalar test);
     //     the select walk otherwise.
     // Two staging halves, order  W0 R0 [S0 | W1] R1 [S1 | W2] R2 [S2 | W3] R3 S3  ([S | W]: a store, a column block, a store, ...).
-    auto epilogue_full = [&](Epi& e, auto bias_tag) __attribute__((always_inline)) {
+    // column blocks of slice mt from the accumulators into the staging half (mt & 1) (only >= 0: column block `only` alone)
+    auto stage_w = [&](auto mt_tag, const int only = -1) __attribute__((always_inline)) {        // (only >= 0: column block `only` alone)
+        constexpr int mt = decltype(mt_tag)::value;
+        const unsigned sw = stg_lds + unsigned(((lane >> 4) * 4 * BN + (lane & 15)) * 4) + (mt & 1) * (16 * BN * 4), sw2 = sw + 2 * BN * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if ((only >= 0 && nt != only) || (NG_X3R_KO & 32)) continue;
+            const f32x4 c = acc[mt][nt];
+            const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            // (offsets in dwords: column block nt, the second row BN dwords on)
+#define X3R_STW4(NTI) if (nt == NTI) asm volatile("ds_write2_b32 %0, %2, %3 offset0:%6 offset1:%7\n\tds_write2_b32 %1, %4, %5 offset0:%6 offset1:%7" \
+                    :: "v"(sw), "v"(sw2), "a"(c0), "a"(c1), "a"(c2), "a"(c3), "n"(NTI * 16), "n"(NTI * 16 + BN) : "memory");
+            X3R_STW4(0) X3R_STW4(1) X3R_STW4(2) X3R_STW4(3) X3R_STW4(4) X3R_STW4(5) X3R_STW4(6) X3R_STW4(7)
+#undef X3R_STW4
+        }
+    };
+    auto epilogue_full = [&](Epi& e, auto bias_tag, auto&& mid) __attribute__((always_inline)) {
         constexpr bool BIAS = decltype(bias_tag)::value;
-        const unsigned sw0 = stg_lds + unsigned(((lane >> 4) * 4 * BN + (lane & 15)) * 4);
         const unsigned sr0 = stg_lds + unsigned((lrow * BN + chunk * 4) * 4);
         constexpr unsigned HALF = 16 * BN * 4;
         const char* const obase = ng_uniform_ptr(reinterpret_cast<const char*>(E.out));
@@ -649,21 +670,6 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         // (uniform) the column of the slice's first row: the slice wraps iff its 16 rows cross the end of an image row
         int s_ow = __builtin_amdgcn_readfirstlane(e.ow);       // (lane 0 stands on the slice's first row)
         const int s_OW = e.OW;
-        auto W = [&](auto mt_tag, const int only = -1) __attribute__((always_inline)) {        // (only >= 0: column block `only` alone)
-            constexpr int mt = decltype(mt_tag)::value;
-            const unsigned sw = sw0 + (mt & 1) * HALF, sw2 = sw + 2 * BN * 4;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if ((only >= 0 && nt != only) || (NG_X3R_KO & 32)) continue;
-                const f32x4 c = acc[mt][nt];
-                const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-                // (offsets in dwords: column block nt, the second row BN dwords on)
-#define X3R_STW4(NTI) if (nt == NTI) asm volatile("ds_write2_b32 %0, %2, %3 offset0:%6 offset1:%7\n\tds_write2_b32 %1, %4, %5 offset0:%6 offset1:%7" \
-                        :: "v"(sw), "v"(sw2), "a"(c0), "a"(c1), "a"(c2), "a"(c3), "n"(NTI * 16), "n"(NTI * 16 + BN) : "memory");
-                X3R_STW4(0) X3R_STW4(1) X3R_STW4(2) X3R_STW4(3) X3R_STW4(4) X3R_STW4(5) X3R_STW4(6) X3R_STW4(7)
-#undef X3R_STW4
-            }
-        };
         static_assert(7 * 16 + BN <= 255, "ds_write2_b32 offsets are 8-bit dword counts");
         f32x4 v0[SP], v1[SP];
         auto R = [&](auto mt_tag, f32x4 (&vv)[SP]) __attribute__((always_inline)) {
@@ -740,15 +746,20 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             for (int pass = 0; pass < SP; ++pass) {
                 const unsigned oo = unsigned(ooff[pass]);
                 if (!(NG_X3R_KO & 64)) asm volatile("global_store_dwordx4 %1, %0, %2" : "+v"(vv[pass]) : "v"(oo), "s"(ob) : "memory");
-                if constexpr (NEXT < 4) W(next_tag, pass);
+                if constexpr (NEXT < 4) stage_w(next_tag, pass);
             }
             asm volatile("s_nop 1" ::: "memory");
         };
         using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
         using J4 = std::integral_constant<int, 4>;
-        W(J0{});
+        // (slice 0 is in the staging block already: written in front of the epilogue's set-up, whose ~400 cycles of address arithmetic and
+        // scalar loads then run beside the LDS writes)
         R(J0{}, v0); S(J1{}, v0);             // (the reads are waited for with lgkmcnt(0): nothing is behind them yet)
         R(J1{}, v1); S(J2{}, v1);
+        // the item behind the next one is looked up and its loader state prepared HERE: ~1 100 cycles, most of them latency of dependent
+        // scalar loads, while the store path works off the 16 stores just issued (a CU takes 33 B per cycle, scripts/diag/x3r_knockout.sh:
+        // the epilogue's time is that of its 128 KB of stores)
+        mid();
         R(J2{}, v0); S(J3{}, v0);
         R(J3{}, v1); S(J4{}, v1);
     };
@@ -873,22 +884,31 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 
     // ---------------- the walk.  In front of K-tile 0 the loader issues what the tile before it would have, in its order, so that the
     // counted waits of the first tile find the operations they assume
-    locate(itemN, E);
-    if (E.nk < 0) return;
-    prepare(E, N);
+    auto keep = [&](const Item& t, Slot& q) { q.p = t.p; q.out = t.out; q.m0 = t.m0; q.n0 = t.n0; q.nk = t.nk; };
+    {
+        Item t;
+        locate(itemN, t);
+        if (t.nk < 0) return;
+        prepare(t, N);
+        keep(t, E);
+    }
     L = N;
     left = L.nk;
-    // an item is located ONCE: `E` = the item being multiplied, `Q1` = the item behind it, the one `N` stands for (behind E's last
-    // K-tile the cursor has crossed into it: E = Q1, and the item behind that one is located and prepared)
-    Item Q1;
+    // an item is located ONCE: `E` = the item being multiplied, `Q1` = the item behind it, `Q2` = the one behind that, located and prepared
+    // (`N`) during E's epilogue
+    Slot Q1, Q2;
     auto prepare_next = [&]() {                 // `N` = the item behind the cursor's (past the end: the last state once more, never used)
-        locate(itemN + G, Q1);
-        if (Q1.nk >= 0) {
+        Item t;
+        locate(itemN + G, t);
+        Q2.nk = t.nk;
+        if (t.nk >= 0) {
             itemN += G;
-            prepare(Q1, N);
+            prepare(t, N);
+            keep(t, Q2);
         }
     };
     prepare_next();
+    Q1 = Q2;
     cursor_bases();                             // the cursor on K-tile 0
     loadA(F[0], baseC, L.goff[0]);
     loadA(F[1], baseC, L.goff[1]);
@@ -936,17 +956,23 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         X3R_STAMP(9)
         X3R_MFMA_DRAIN;                          // the last MFMAs' results are in the accumulators
         Epi e;
+        bool full = false;
+        if constexpr (!GEN) {
+            full = E.m0 + 256 <= E.p->M;             // a full tile: every one of its 32 store instructions is issued
+            if (full) stage_w(I0{});
+        }
         epi_begin(e);
         X3R_STAMP(6)
         if constexpr (!GEN) {
-            if (E.m0 + 256 <= e.pM) {                 // a full tile: every one of its 32 store instructions is issued
-                if (E.p->bias != nullptr) epilogue_full(e, std::true_type{}); else epilogue_full(e, std::false_type{});
+            if (full) {                 // a full tile: every one of its 32 store instructions is issued
+                if (E.p->bias != nullptr) epilogue_full(e, std::true_type{}, prepare_next); else epilogue_full(e, std::false_type{}, prepare_next);
                 stores_behind = true;
             } else {
                 slice(e, I0{}, I1{});
                 slice(e, I1{}, I1{});
                 slice(e, I2{}, I1{});
                 slice(e, I3{}, I1{});
+                prepare_next();
             }
         } else {
             slice(e, I0{}, I2{});
@@ -954,17 +980,18 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             slice(e, I2{}, I2{});
             slice(e, I3{}, I2{});
             epi_finish(e);
+            prepare_next();
         }
         X3R_STAMP(7)
 #ifdef NG_X3R_STAMP
         ++st_sum[14];
 #endif
+        // the cursor crossed into Q1 while E was multiplied (two K-tiles ahead, at least three per item), which freed `N`: the item behind
+        // Q1 was located and prepared above (inside the full epilogue, otherwise behind it)
         E = Q1;
+        Q1 = Q2;
         if (E.nk < 0) break;
         nkC = E.nk;
-        // the cursor crossed into this item while the last one was multiplied (two K-tiles ahead, at least three per item): the item
-        // behind it is located and prepared here, outside the K loop
-        prepare_next();
         X3R_STAMP(8)
     }
 #ifdef NG_X3R_STAMP
@@ -990,9 +1017,12 @@ inline bool conv_x3r_generic(const ConvParams& p) { return p.stats != nullptr ||
 // whether the register-fed tile takes a launch the split tile covers (host): 128-column tiles, asked for by the descriptor (A/B switch)
 // (problems whose epilogue leaves statistics / runs the fused pass -- the branching epilogue is not overlapped and not tuned -- only from
 // 24 K-tiles on: measured inside the step, profiles/r06_x3r_per_op_ab.txt -- 1.04-1.14 x from 32 K-tiles, 0.68-0.91 x at 7-18)
+#ifndef NG_X3R_GEN_MIN_NK
+#define NG_X3R_GEN_MIN_NK 24
+#endif
 inline bool conv_x3r_ok(const ConvParams& p, const int bn) {
     const int nk = p.ntaps * (p.run >> 5);
-    return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 16 && nk >= (conv_x3r_generic(p) ? 24 : 3);
+    return bn == 128 && p.algo == NIRGAN_CONV_X3_R4 && p.OW >= 16 && nk >= (conv_x3r_generic(p) ? NG_X3R_GEN_MIN_NK : 3);
 }
 
 }  // namespace ng

@@ -7,6 +7,10 @@ sys.path.insert(0, os.path.join(ROOT, "nir-gan_amd"))
 import torch
 from model import networks
 from nirgan_hip.trainer import Pix2PixTrainer
+if os.environ.get("NIRGAN_DIAG_LIB"):      # a diagnostic build of the library (A/B of a compile-time switch), e.g. scripts/diag/*.so
+    from nirgan_hip import lib as _L
+    _L.set_backend(_L._CLib(os.path.abspath(os.environ["NIRGAN_DIAG_LIB"])))
+    print("library:", os.environ["NIRGAN_DIAG_LIB"])
 
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 6
