@@ -116,38 +116,54 @@ struct X3R {
 #define X3R_RD(s) s
 #endif
 // (v_pk_add_f32 for the two subtractions of a step -- 9 instead of 11 VALU per pair -- is SLOWER: + 100 cycles per block of 48 MFMAs,
-// stamps: the packed add costs about three plain ones here)
-#ifndef NG_X3R_PK
-#define NG_X3R_PK 0
-#endif
-#if NG_X3R_PK
-#define X3R_SUB2(RP, R0, R1, XP, X0, X1, TP, T0, T1) X3R_V("v_pk_add_f32 " RP ", " XP ", " TP " neg_lo:[0,1] neg_hi:[0,1]\n\t")
-#else
-#define X3R_SUB2(RP, R0, R1, XP, X0, X1, TP, T0, T1) X3R_V("v_sub_f32 " R0 ", " X0 ", " T0 "\n\t") X3R_V("v_sub_f32 " R1 ", " X1 ", " T1 "\n\t")
-#endif
+// stamps, profiles/r06_x3r_knockout.txt: the packed add costs about three plain ones here)
+#define X3R_SUB2(R0, R1, X0, X1, T0, T1) X3R_V("v_sub_f32 " R0 ", " X0 ", " T0 "\n\t") X3R_V("v_sub_f32 " R1 ", " X1 ", " T1 "\n\t")
 // MA / MB: the first product of each accumulator (X3R_MC, or X3R_MZ in an item's first K-tile: C = 0, nothing zeroes 128 registers per
 // item); T0 T1 TP / R0 R1 RP: the temporaries (a register pair each, by halves and whole); RDA / RDB: the reads replacing the first /
 // second column tile's fragments (block 3), behind the last MFMA that names them
-#define X3R_PAIR(MA, MB, T0, T1, TP, R0, R1, RP, RDA, RDB) \
+// G8 .. G12: what else is issued in the gaps behind MFMAs 8 .. 12, which carry no conversion VALU: the fragment reads of block 3 (those
+// of the PREVIOUS region's column tiles: its own are still MFMA operands), the B pieces' LDS stores of block 0, the fetches of blocks
+// 0-2 -- two instructions per gap at most (an MFMA leaves two issue slots free): as statements of their own between two regions
+// every one of them was paid in full
+#define X3R_PAIR(MA, MB, T0, T1, TP, R0, R1, RP, G8, G9, G10, G11, G12) \
     MA(c0, al, b0) X3R_V(X3R_CVT "%[h], %[x0], %[x1]\n\t") \
     X3R_MC(c0, ah, b2) X3R_V("v_lshlrev_b32 " T0 ", 16, %[h]\n\t") X3R_V("v_and_b32 " T1 ", 0xffff0000, %[h]\n\t") \
-    X3R_MC(c0, am, b1) X3R_SUB2(RP, R0, R1, "%[x]", "%[x0]", "%[x1]", TP, T0, T1) \
+    X3R_MC(c0, am, b1) X3R_SUB2(R0, R1, "%[x0]", "%[x1]", T0, T1) \
     X3R_MC(c0, am, b0) X3R_V(X3R_CVT "%[m], " R0 ", " R1 "\n\t") \
     X3R_MC(c0, ah, b1) X3R_V("v_lshlrev_b32 " T0 ", 16, %[m]\n\t") X3R_V("v_and_b32 " T1 ", 0xffff0000, %[m]\n\t") \
-    X3R_MC(c0, ah, b0) X3R_SUB2(RP, R0, R1, RP, R0, R1, TP, T0, T1) \
+    X3R_MC(c0, ah, b0) X3R_SUB2(R0, R1, R0, R1, T0, T1) \
     MB(c1, al, d0) X3R_V(X3R_CVT "%[l], " R0 ", " R1 "\n\t") \
-    X3R_MC(c1, ah, d2) RDA \
-    X3R_MC(c1, am, d1) \
-    X3R_MC(c1, am, d0) \
-    X3R_MC(c1, ah, d1) \
-    X3R_MC(c1, ah, d0) RDB
+    X3R_MC(c1, ah, d2) G8 \
+    X3R_MC(c1, am, d1) G9 \
+    X3R_MC(c1, am, d0) G10 \
+    X3R_MC(c1, ah, d1) G11 \
+    X3R_MC(c1, ah, d0) G12
 #define X3R_TA "v248", "v249", "v[248:249]", "v250", "v251", "v[250:251]"
 #define X3R_TB "v252", "v253", "v[252:253]", "v254", "v255", "v[254:255]"
 #define X3R_CLOB_A "memory", "v248", "v249", "v250", "v251"
 #define X3R_CLOB_B "memory", "v252", "v253", "v254", "v255"
 #define X3R_WAITL "s_waitcnt lgkmcnt(%[w])\n\t"
-#define X3R_READS_A X3R_RD("ds_read_b128 %[b0], %[bad] offset:%[o0]\n\t" "ds_read_b128 %[b1], %[bad] offset:%[o1]\n\t" "ds_read_b128 %[b2], %[bad] offset:%[o2]\n\t")
-#define X3R_READS_B X3R_RD("ds_read_b128 %[d0], %[bad] offset:%[o3]\n\t" "ds_read_b128 %[d1], %[bad] offset:%[o4]\n\t" "ds_read_b128 %[d2], %[bad] offset:%[o5]\n\t")
+#if NG_X3R_KO & 4
+#define X3R_KA(s) ""
+#else
+#define X3R_KA(s) s
+#endif
+#if NG_X3R_KO & 8
+#define X3R_KB(s) ""
+#else
+#define X3R_KB(s) s
+#endif
+// the previous region's six fragment reads (block 3), two per gap
+#define X3R_PR0 X3R_RD("ds_read_b128 %[q0], %[bad] offset:%[o0]\n\t" "ds_read_b128 %[q1], %[bad] offset:%[o1]\n\t")
+#define X3R_PR1 X3R_RD("ds_read_b128 %[q2], %[bad] offset:%[o2]\n\t" "ds_read_b128 %[q3], %[bad] offset:%[o3]\n\t")
+#define X3R_PR2 X3R_RD("ds_read_b128 %[q4], %[bad] offset:%[o4]\n\t" "ds_read_b128 %[q5], %[bad] offset:%[o5]\n\t")
+// two B pieces into the other LDS stage / two B pieces fetched / a raw row set fetched
+#define X3R_ST0 X3R_KB("ds_write_b128 %[sa], %[sd0] offset:%[so0]\n\t")
+#define X3R_ST1 X3R_KB("ds_write_b128 %[sa], %[sd1] offset:%[so1]\n\t")
+#define X3R_LB0 X3R_KB("global_load_dwordx4 %[ld0], %[lo0], %[lb]\n\t")
+#define X3R_LB1 X3R_KB("global_load_dwordx4 %[ld1], %[lo1], %[lb]\n\t")
+#define X3R_LA0 X3R_KA("global_load_dwordx4 %[ld0], %[lo0], %[lb]\n\t")
+#define X3R_LA1 X3R_KA("global_load_dwordx4 %[ld1], %[lo0], %[lb] offset:16\n\t")
 #define X3R_MFMA_DRAIN asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
 // GEN: the launch's problems leave instance-norm partial sums or run the fused first backward pass (their epilogue branches and needs
@@ -424,27 +440,59 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // one region (see X3R_PAIR above): row tile MT against column tiles 2 P and 2 P + 1; pair P of raw set SRC becomes dword P of A[SRC]'s
     // three terms; WAIT >= 0: behind a counted lgkmcnt wait (block 0); READ: both column tiles' fragments of the NEXT K-tile behind their
     // last MFMAs (block 3)
-    auto region = [&](auto first_tag, auto mt_tag, auto p_tag, auto src_tag, auto wait_tag, auto read_tag, const unsigned bad) __attribute__((always_inline)) {
+    auto region = [&](auto first_tag, auto mt_tag, auto p_tag, auto src_tag, auto wait_tag, const unsigned bad, const unsigned st_ad, const char* base, const unsigned goff) __attribute__((always_inline)) {
         constexpr int MT = decltype(mt_tag)::value, P = decltype(p_tag)::value, SRC = decltype(src_tag)::value, WAIT = decltype(wait_tag)::value;
         constexpr int N0 = 2 * P, N1 = 2 * P + 1;
-        constexpr bool READ = decltype(read_tag)::value, FIRST = decltype(first_tag)::value;
-        static_assert(!(WAIT >= 0 && READ), "a region waits for fragments (block 0) or replaces them (block 3)");
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // what rides in the region's free gaps (see X3R_PAIR): ST -- B pieces 2 (P - 1), 2 (P - 1) + 1 of K-tile j + 1 into the other LDS stage
+        // (block 0, regions 1-3); LB -- pieces 2 P, 2 P + 1 of K-tile j + 2 fetched (block 1, regions 0-2: behind the stores that emptied
+        // their registers); LA -- the block's raw row set fetched again (last region of blocks 0-2; block 3's follows its region: the
+        // operand list is full); PR -- the fragments of the PREVIOUS region's column tiles read for the next K-tile (block 3)
+        constexpr bool ST = MT == 0 && P >= 1, LB = MT == 1 && P < 3, LA = P == 3 && MT < 3, PR = MT == 3 && P >= 1;
+        static_assert((WAIT >= 0) == (MT == 0), "block 0's regions wait for their fragments");
+        static_assert(PIECES == 6 && BPT == 8, "B pieces: two per term");
         f32x4& c0 = acc[MT][N0];
         f32x4& c1 = acc[MT][N1];
         const float x0 = F[SRC][P >> 1][(2 * P) & 3], x1 = F[SRC][P >> 1][(2 * P + 1) & 3];
-        const f32x2 x = {x0, x1};
         unsigned h, m, l;
+        constexpr int I0 = ST ? 2 * (P - 1) : (LB ? 2 * P : 0), I1 = I0 + 1;       // the region's two B pieces
+        constexpr int SO0 = (I0 / 2) * B_TERM, SO1 = SO0 + 4096;                   // piece i in its stage: term i / 2, row group i % 2
+        constexpr int NP0 = PR ? N0 - 2 : 0, NP1 = PR ? N1 - 2 : 1;
 #define X3R_ACC [c0] "+a"(c0), [c1] "+a"(c1)
 #define X3R_B_INOUT [b0] "+a"(Bf[N0][0]), [b1] "+a"(Bf[N0][1]), [b2] "+a"(Bf[N0][2]), [d0] "+a"(Bf[N1][0]), [d1] "+a"(Bf[N1][1]), [d2] "+a"(Bf[N1][2])
 #define X3R_B_IN [b0] "a"(Bf[N0][0]), [b1] "a"(Bf[N0][1]), [b2] "a"(Bf[N0][2]), [d0] "a"(Bf[N1][0]), [d1] "a"(Bf[N1][1]), [d2] "a"(Bf[N1][2])
 #define X3R_TERMS [h] "=&v"(h), [m] "=&v"(m), [l] "=&v"(l)
-#define X3R_A_IN [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x] "v"(x), [x0] "v"(x0), [x1] "v"(x1)
-#define X3R_RD_IN [bad] "v"(bad), [o0] "n"(N0 * 1024), [o1] "n"(B_TERM + N0 * 1024), [o2] "n"(2 * B_TERM + N0 * 1024), \
-                  [o3] "n"(N1 * 1024), [o4] "n"(B_TERM + N1 * 1024), [o5] "n"(2 * B_TERM + N1 * 1024)
+#define X3R_A_IN [ah] "v"(A[MT][0]), [am] "v"(A[MT][1]), [al] "v"(A[MT][2]), [x0] "v"(x0), [x1] "v"(x1)
+#define X3R_PR_OUT [q0] "+a"(Bf[NP0][0]), [q1] "+a"(Bf[NP0][1]), [q2] "+a"(Bf[NP0][2]), [q3] "+a"(Bf[NP1][0]), [q4] "+a"(Bf[NP1][1]), [q5] "+a"(Bf[NP1][2])
+#define X3R_PR_IN [bad] "v"(bad), [o0] "n"(NP0 * 1024), [o1] "n"(B_TERM + NP0 * 1024), [o2] "n"(2 * B_TERM + NP0 * 1024), \
+                  [o3] "n"(NP1 * 1024), [o4] "n"(B_TERM + NP1 * 1024), [o5] "n"(2 * B_TERM + NP1 * 1024)
+#define X3R_ST_IN [sa] "v"(st_ad), [sd0] "v"(Braw[I0]), [sd1] "v"(Braw[I1]), [so0] "n"(SO0), [so1] "n"(SO1)
+// (NOT early-clobber: the row set's old value is an INPUT of the same statement -- x0, x1 are two of its elements, read by the
+// conversion long before the fetch is issued -- and with "=&v" the new value had to live in other registers than the old one: hipcc
+// then copied it back at the loop's end, in front of the wait that covers the fetch (scripts/check_x3_asm.py))
+#define X3R_LB_OUT [ld0] "=v"(Braw[I0]), [ld1] "=v"(Braw[I1])
+#define X3R_LA_OUT [ld0] "=v"(F[SRC][0]), [ld1] "=v"(F[SRC][1])
 #define X3R_EMIT(MA, T, CLOB) \
-        if constexpr (WAIT >= 0) asm volatile(X3R_WAITL X3R_PAIR(MA, MA, T, "", "") : X3R_ACC, X3R_B_INOUT, X3R_TERMS : X3R_A_IN, [w] "n"(WAIT) : CLOB); \
-        else if constexpr (READ) asm volatile(X3R_PAIR(MA, MA, T, X3R_READS_A, X3R_READS_B) : X3R_ACC, X3R_B_INOUT, X3R_TERMS : X3R_A_IN, X3R_RD_IN : CLOB); \
-        else asm volatile(X3R_PAIR(MA, MA, T, "", "") : X3R_ACC, X3R_TERMS : X3R_A_IN, X3R_B_IN : CLOB);
+        if constexpr (ST && LA) { \
+            const char* const lb = base; \
+            asm volatile(X3R_WAITL X3R_PAIR(MA, MA, T, "", X3R_ST0, X3R_ST1, X3R_LA0, X3R_LA1) : X3R_ACC, X3R_B_INOUT, X3R_TERMS, X3R_LA_OUT \
+                         : X3R_A_IN, [w] "n"(WAIT), X3R_ST_IN, [lo0] "v"(goff), [lb] "s"(lb) : CLOB); \
+        } else if constexpr (ST) { \
+            asm volatile(X3R_WAITL X3R_PAIR(MA, MA, T, "", "", X3R_ST0, X3R_ST1, "") : X3R_ACC, X3R_B_INOUT, X3R_TERMS : X3R_A_IN, [w] "n"(WAIT), X3R_ST_IN : CLOB); \
+        } else if constexpr (WAIT >= 0) { \
+            asm volatile(X3R_WAITL X3R_PAIR(MA, MA, T, "", "", "", "", "") : X3R_ACC, X3R_B_INOUT, X3R_TERMS : X3R_A_IN, [w] "n"(WAIT) : CLOB); \
+        } else if constexpr (LB) { \
+            const char* const lb = P == 0 ? baseW[0] : (P == 1 ? baseW[1] : baseW[2]); \
+            const unsigned lo0 = L.b0, lo1 = L.b1; \
+            asm volatile(X3R_PAIR(MA, MA, T, "", "", X3R_LB0, X3R_LB1, "") : X3R_ACC, X3R_TERMS, X3R_LB_OUT : X3R_A_IN, X3R_B_IN, [lo0] "v"(lo0), [lo1] "v"(lo1), [lb] "s"(lb) : CLOB); \
+        } else if constexpr (LA) { \
+            const char* const lb = base; \
+            asm volatile(X3R_PAIR(MA, MA, T, "", "", X3R_LA0, X3R_LA1, "") : X3R_ACC, X3R_TERMS, X3R_LA_OUT : X3R_A_IN, X3R_B_IN, [lo0] "v"(goff), [lb] "s"(lb) : CLOB); \
+        } else if constexpr (PR) { \
+            asm volatile(X3R_PAIR(MA, MA, T, X3R_PR0, X3R_PR1, X3R_PR2, "", "") : X3R_ACC, X3R_TERMS, X3R_PR_OUT : X3R_A_IN, X3R_B_IN, X3R_PR_IN : CLOB); \
+        } else { \
+            asm volatile(X3R_PAIR(MA, MA, T, "", "", "", "", "") : X3R_ACC, X3R_TERMS : X3R_A_IN, X3R_B_IN : CLOB); \
+        }
         if constexpr (P & 1) {
             if constexpr (FIRST) { X3R_EMIT(X3R_MZ, X3R_TB, X3R_CLOB_B) } else { X3R_EMIT(X3R_MC, X3R_TB, X3R_CLOB_B) }
         } else {
@@ -456,7 +504,11 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #undef X3R_B_IN
 #undef X3R_TERMS
 #undef X3R_A_IN
-#undef X3R_RD_IN
+#undef X3R_PR_OUT
+#undef X3R_PR_IN
+#undef X3R_ST_IN
+#undef X3R_LB_OUT
+#undef X3R_LA_OUT
         A[SRC][0][P] = h;
         A[SRC][1][P] = m;
         A[SRC][2][P] = l;
@@ -848,14 +900,13 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                 // the fragments after it (the B stores of this block, issued behind earlier regions, only make the wait stricter)
                 constexpr int behind = 3 * (NT - 1 - nt);
                 using W = std::integral_constant<int, MT == 0 ? (behind > 15 ? 15 : behind) : -1>;
-                region(first_tag, mt_tag, p_tag, src_tag, W{}, std::integral_constant<bool, MT == 3>{}, bnext);
-                if (P == 3 && !(NG_X3R_KO & 4)) {
-                    loadA(F[SRC], base, goff);
+                region(first_tag, mt_tag, p_tag, src_tag, W{}, bnext, b_wr + stage_next, base, goff);
+                if constexpr (MT == 3 && P == 3) {
+                    // the last region's own column tiles: their fragments of the next K-tile, then the block's fetch
+                    X3R_RB(6, bnext)
+                    X3R_RB(7, bnext)
+                    if (!(NG_X3R_KO & 4)) loadA(F[SRC], base, goff);
                 }
-                // K-tile j + 1's pieces of B into the other stage (every wave has left it: it held K-tile j - 1, last read in block 3 of
-                // tile j - 2, in front of tile j - 1's barrier)
-                if (MT == 0 && P >= 1 && !(NG_X3R_KO & 8)) { storeB(stage_next, 2 * (P - 1)); storeB(stage_next, 2 * (P - 1) + 1); }
-                if (MT == 1 && P < 3 && !(NG_X3R_KO & 8)) { loadB(2 * P); loadB(2 * P + 1); }      // K-tile j + 2's pieces, behind the stores that emptied the registers
                 if (MT == 3 && P == 3) { sj ^= 1; step_cursor(std::integral_constant<int, -1>{}); }     // (the cursor's step behind the tile's last MFMAs)
             };
             static_assert(PIECES == 6, "six B pieces per wave and K-tile: two behind each of three regions");
