@@ -323,38 +323,37 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // PIECE argument is what is left of that experiment)
     bool crossS = false;
     auto step_cursor = [&](auto piece_tag) __attribute__((always_inline)) {
-        constexpr int PIECE = decltype(piece_tag)::value;
-        if constexpr (PIECE < 0 || PIECE == 0) {
-            baseP = baseC;
-            goff3P = L.goff[3];
-            crossS = left == 1;                 // (uniform)
+        (void)piece_tag;
+        baseP = baseC;
+        goff3P = L.goff[3];
+        crossS = left == 1;                     // (uniform)
+        if (__builtin_expect(crossS, 0)) {
+            // onto the next item (once per item: a real branch -- as selects these were ~20 instructions of every K-tile, each paid in
+            // full with one wave per SIMD; the empty asm keeps hipcc from turning the branch back into selects)
+            asm volatile("" ::: "memory");
+            ct = 0; cc = 0; kb = 0;
+            left = N.nk;
+            L.in8 = N.in8;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) L.w8[q] = N.w8[q];
+            L.ntaps = N.ntaps;
+            L.run2 = N.run2;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) L.goff[mt] = N.goff[mt];
+            L.b0 = N.b0;
+            L.b1 = N.b1;
+            L.tapv = N.tapv;
+        } else {
             // inside the item: the next tap of this slice, or the first tap of the next slice
-            int ct1 = ct + 1, cc1 = cc, kb1 = kb + L.run2;
+            const int ct1 = ct + 1;
             const bool wrap = ct1 == L.ntaps;
-            ct1 = wrap ? 0 : ct1;
-            cc1 = wrap ? cc + 32 : cc1;
-            kb1 = wrap ? cc1 * 2 : kb1;
-            ct = crossS ? 0 : ct1;
-            cc = crossS ? 0 : cc1;
-            kb = crossS ? 0 : kb1;
-            left = crossS ? N.nk : left - 1;
+            const int cc1 = wrap ? cc + 32 : cc;
+            kb = wrap ? cc1 * 2 : kb + L.run2;
+            ct = wrap ? 0 : ct1;
+            cc = cc1;
+            left = left - 1;
         }
-        // onto the next item: every field a select (the K loop keeps one basic block per region)
-        if constexpr (PIECE < 0 || PIECE == 1) {
-            L.in8 = crossS ? N.in8 : L.in8;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) L.w8[q] = crossS ? N.w8[q] : L.w8[q];
-            L.ntaps = crossS ? N.ntaps : L.ntaps;
-            L.run2 = crossS ? N.run2 : L.run2;
-        }
-        if constexpr (PIECE < 0 || PIECE == 2) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) L.goff[mt] = crossS ? N.goff[mt] : L.goff[mt];
-            L.b0 = crossS ? N.b0 : L.b0;
-            L.b1 = crossS ? N.b1 : L.b1;
-            L.tapv = crossS ? N.tapv : L.tapv;
-        }
-        if constexpr (PIECE < 0 || PIECE == 3) cursor_bases();
+        cursor_bases();
     };
     f32x4 F[4][2];                              // raw rows: F[mt] = this lane's 8 k of its row of 16-row tile mt
     f32x4 Braw[PIECES];                         // raw B pieces (bf16 bits): 16 bytes per lane and piece
