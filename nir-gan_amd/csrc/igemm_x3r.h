@@ -322,14 +322,50 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // tiles, the same ~60 scalar and vector selects cost MORE: block 0 + 400 cycles against 130 saved between the tiles, stamps -- the
     // PIECE argument is what is left of that experiment)
     bool crossS = false;
+    // The cursor moves on: what it stood on becomes the snapshot.  In the K loop the step is taken in two parts: step_early() computes where
+    // the cursor goes INSIDE its item (the common case) into shadow variables, in the middle of the tile -- hipcc spreads those ~25 scalar
+    // instructions through the gaps between the regions behind it -- and step_cursor() at the tile's end commits them, or, on the item's
+    // last K-tile (once per item: a real branch; as selects these were ~20 instructions of every K-tile, each paid in full with one
+    // wave per SIMD; the empty asm keeps hipcc from turning the branch back into selects), puts the cursor on the next item's first K-tile.
+    int n_ct = 0, n_cc = 0, n_kb = 0;
+    const char* n_baseC = nullptr;
+    const char* n_baseW[3] = {nullptr, nullptr, nullptr};
+    bool n_valid = false;
+    // (four pieces, each pinned where it is called by an empty volatile asm on what it computed: without the pins hipcc sinks all of it
+    // to the commit at the tile's end)
+    auto step_early = [&](auto piece_tag) __attribute__((always_inline)) {
+        constexpr int PIECE = decltype(piece_tag)::value;
+        if constexpr (PIECE < 0 || PIECE == 0) {
+            // the next tap of this slice, or the first tap of the next slice
+            const int ct1 = ct + 1;
+            const bool wrap = ct1 == L.ntaps;
+            n_cc = wrap ? cc + 32 : cc;
+            n_kb = wrap ? n_cc * 2 : kb + L.run2;
+            n_ct = wrap ? 0 : ct1;
+            if constexpr (PIECE == 0) asm volatile("" : "+s"(n_cc), "+s"(n_kb), "+s"(n_ct));
+        }
+        if constexpr (PIECE < 0 || PIECE == 1) {
+            const int toff = __builtin_amdgcn_readlane(L.tapv, n_ct);
+            n_baseC = L.in8 + (long long)(toff + n_cc) * 4;
+            if constexpr (PIECE == 1) asm volatile("" : "+s"(n_baseC));
+        }
+        if constexpr (PIECE < 0 || PIECE == 2) {
+            n_baseW[0] = L.w8[0] + n_kb;
+            n_baseW[1] = L.w8[1] + n_kb;
+            if constexpr (PIECE == 2) asm volatile("" : "+s"(n_baseW[0]), "+s"(n_baseW[1]));
+        }
+        if constexpr (PIECE < 0 || PIECE == 3) {
+            n_baseW[2] = L.w8[2] + n_kb;
+            if constexpr (PIECE == 3) asm volatile("" : "+s"(n_baseW[2]));
+            n_valid = true;
+        }
+    };
     auto step_cursor = [&](auto piece_tag) __attribute__((always_inline)) {
         (void)piece_tag;
         baseP = baseC;
         goff3P = L.goff[3];
         crossS = left == 1;                     // (uniform)
         if (__builtin_expect(crossS, 0)) {
-            // onto the next item (once per item: a real branch -- as selects these were ~20 instructions of every K-tile, each paid in
-            // full with one wave per SIMD; the empty asm keeps hipcc from turning the branch back into selects)
             asm volatile("" ::: "memory");
             ct = 0; cc = 0; kb = 0;
             left = N.nk;
@@ -343,17 +379,16 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             L.b0 = N.b0;
             L.b1 = N.b1;
             L.tapv = N.tapv;
+            cursor_bases();
         } else {
-            // inside the item: the next tap of this slice, or the first tap of the next slice
-            const int ct1 = ct + 1;
-            const bool wrap = ct1 == L.ntaps;
-            const int cc1 = wrap ? cc + 32 : cc;
-            kb = wrap ? cc1 * 2 : kb + L.run2;
-            ct = wrap ? 0 : ct1;
-            cc = cc1;
+            if (!n_valid) step_early(std::integral_constant<int, -1>{});         // (the prologue's steps: nothing was computed ahead)
+            ct = n_ct; cc = n_cc; kb = n_kb;
             left = left - 1;
+            baseC = n_baseC;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) baseW[q] = n_baseW[q];
         }
-        cursor_bases();
+        n_valid = false;
     };
     f32x4 F[4][2];                              // raw rows: F[mt] = this lane's 8 k of its row of 16-row tile mt
     f32x4 Braw[PIECES];                         // raw B pieces (bf16 bits): 16 bytes per lane and piece
@@ -900,6 +935,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                 constexpr int behind = 3 * (NT - 1 - nt);
                 using W = std::integral_constant<int, MT == 0 ? (behind > 15 ? 15 : behind) : -1>;
                 region(first_tag, mt_tag, p_tag, src_tag, W{}, bnext, b_wr + stage_next, base, goff);
+                if constexpr (MT == 2 && P < 3) step_early(std::integral_constant<int, P + 1>{});      // (the cursor's next position, a piece per gap)
                 if constexpr (MT == 3 && P == 3) {
                     // the last region's own column tiles: their fragments of the next K-tile, then the block's fetch
                     X3R_RB(6, bnext)
@@ -917,6 +953,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         X3R_STAMP(0)
         block(I1{}, I0{}, baseC, L.goff[0]);              // the NEXT tile's row tile 0 into A[0] (block 0 has issued its last use), K-tile j + 2
         X3R_STAMP(1)
+        step_early(std::integral_constant<int, 0>{});
         // the tile's barrier: every wave's pieces of K-tile j + 1 are in LDS (stored in block 0: long done)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
