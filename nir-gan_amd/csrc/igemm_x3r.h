@@ -8,45 +8,28 @@
 //     k = 8 c .. 8 c + 7 of row r": exactly what two global_load_dwordx4 of that lane fetch from the row's 32-channel slice.  A row of
 //     the block tile is consumed by ONE wave, so that wave fetches it, splits it into the three bf16 terms in registers and multiplies:
 //     no ds_write of converted rows, no fragment reads of A, no barrier between conversion and use.  LDS traffic per K-tile and CU:
-//     96 KB of B fragment reads + 24 KB of LDS-DMA against 192 KB + 72 KB of the eight-wave tile.
+//     96 KB of B fragment reads + 24 KB of B stores against 192 KB + 72 KB of the eight-wave tile.
 //   * B (the three bf16 planes of the packed weights) is staged through REGISTERS into two LDS stages: six global_load_dwordx4 per wave
 //     and K-tile, one tile ahead, six ds_write_b128 a tile later (an LDS-DMA piece costs the issuing wave ~180 cycles among MFMAs --
 //     measured with in-kernel stamps, scripts/diag/x3r_stamps.* -- and with one wave per SIMD nothing else feeds the matrix pipe
 //     meanwhile).  ONE barrier per K-tile in the MIDDLE of the tile (it publishes K-tile j + 1), none at the tile boundaries: the MFMA
-//     stream runs from one K-tile into the next -- and from one item into the next -- without a stop.
+//     stream runs from one K-tile into the next without a stop.
 //   * mt-outer order with ROLLING operands: a K-tile is four blocks (one 16-row tile mt each) of NT x 6 MFMAs; all NT B fragments of
 //     the tile stay in registers (96 at BN = 128) and are replaced one by one behind their last use in block 3; A[mt] of the next
 //     K-tile is converted behind block mt (one raw buffer, refilled right behind its conversion).
-//   * The epilogue of an item overlaps its own last K-tile: after block mt of the LAST K-tile the 16 x BN accumulators of that row
-//     tile are final -- slice mt goes through a wave-private 8 KB staging block (no barrier) and leaves as whole rows under the MFMAs of
-//     the blocks that follow; only slice 3 runs after the tile.  One accumulator set, no copies.
+//   * The hot loop is written as asm REGIONS of twelve MFMAs (X3R_PAIR): the conversion's VALU and the tile's memory instructions sit
+//     in the gaps behind the MFMAs, by hand -- with one wave per SIMD an instruction that does not fit a gap is paid in full
+//     (scripts/diag/x3r_knockout.sh measures what each part costs).
+//   * The loader is a cursor TWO K-tiles ahead of the MFMAs over the workgroup's items as one stream (it is in the next item while the
+//     current one is multiplied); the epilogue follows the item's last K-tile: four slices of 16 rows per wave through wave-private
+//     staging halves, LDS writes and global stores alternating (full plain tiles: asm; partial tiles, statistics, fused pass: C++).
 // Every vector-memory operation of the loop is issued unconditionally and in a fixed order (a loader past the end of its work re-reads
-// its last tile), so every s_waitcnt vmcnt(N) below is a constant of the schedule: N counts
-// only operations that are ALWAYS issued behind the one waited for (the epilogue's stores are not counted: more operations in flight
-// than assumed only waits longer, never shorter).
+// its last tile), so every s_waitcnt vmcnt(N) below is a constant of the schedule; an item's first K-tile adds the stores its
+// epilogue issued behind the fetches it waits for.
 #pragma once
 #include "igemm_x3.h"
 
 namespace ng {
-
-// x3_split8 with plain subtractions: the scheduler's fences of this kernel let VALU instructions through and keep everything else in
-// place -- an inline-asm v_sub_f32 would be "everything else" (same values: the remainders are exact)
-__device__ __forceinline__ void x3r_split8(const f32x4 lo, const f32x4 hi, bf16x8& H, bf16x8& M, bf16x8& L) {
-    const f32x8 x = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    u32x4 h, m, l;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float x0 = x[2 * i], x1 = x[2 * i + 1];
-        h[i] = x3_pk(x0, x1);
-        const float r0 = x0 - __builtin_bit_cast(float, h[i] << 16), r1 = x1 - __builtin_bit_cast(float, h[i] & 0xffff0000u);
-        m[i] = x3_pk(r0, r1);
-        const float s0 = r0 - __builtin_bit_cast(float, m[i] << 16), s1 = r1 - __builtin_bit_cast(float, m[i] & 0xffff0000u);
-        l[i] = x3_pk(s0, s1);
-    }
-    H = __builtin_bit_cast(bf16x8, h);
-    M = __builtin_bit_cast(bf16x8, m);
-    L = __builtin_bit_cast(bf16x8, l);
-}
 
 // diagnostic build only (scripts/diag/x3r_stamps.sh, -DNG_X3R_STAMP): per-wave cycle sums of the segments of a K-tile and of the epilogue
 #ifdef NG_X3R_STAMP
@@ -65,7 +48,7 @@ struct X3R {
     static constexpr int NSTAGE = 2;
     static constexpr int RING = NSTAGE * STAGE;        // 48 KB at BN = 128
     static constexpr int STG = 2 * 16 * BN * 4;        // staging of one wave: two halves of 16 rows x BN floats (a slice each)
-    static constexpr int BPT = BN / 16;                // 1 KB LDS-DMA pieces per term image
+    static constexpr int BPT = BN / 16;                // 1 KB pieces (one wave instruction) per term image
     static constexpr int PIECES = 3 * BPT / 4;         // pieces per wave and K-tile (6 / 3)
     static constexpr int LPR = BN / 4;                 // lanes per output row (4 channels each)
     static constexpr int RPP = 64 / LPR;               // rows per store pass
@@ -255,7 +238,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // the cursor itself: the rows of row tiles 0-2 and the B pieces of K-tile j + 2 (while tile j is multiplied); row tile 3 of K-tile
     // j + 1 (converted one block later than the rest of its tile) through a SNAPSHOT of the cursor one tile old (a scalar base and the
     // lane's row offset).  One raw buffer per operand, refilled right behind its last use: one K-tile of latency budget.
-    // The cursor's step is straight-line code: a K-tile further inside the item, or -- on the item's last K-tile -- onto the first
+    // The cursor's step (step_early / step_cursor below): a K-tile further inside the item, or -- on the item's last K-tile -- onto the first
     // K-tile of the NEXT item, whose state (`N`) was prepared outside the K loop, behind the previous item's epilogue (host: every
     // problem has at least three K-tiles, so the cursor crosses one item boundary per multiplied item).  Past the end of the
     // workgroup's items `N` is the last item once more: the fetches go on (their NUMBER is what the counted waits rely on), to valid
@@ -318,9 +301,6 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #pragma unroll
         for (int q = 0; q < 3; ++q) baseW[q] = L.w8[q] + kb;
     };
-    // the cursor moves on: what it stood on becomes the snapshot.  (Issued in pieces behind regions of block 0 instead of between two
-    // tiles, the same ~60 scalar and vector selects cost MORE: block 0 + 400 cycles against 130 saved between the tiles, stamps -- the
-    // PIECE argument is what is left of that experiment)
     bool crossS = false;
     // The cursor moves on: what it stood on becomes the snapshot.  In the K loop the step is taken in two parts: step_early() computes where
     // the cursor goes INSIDE its item (the common case) into shadow variables, in the middle of the tile -- hipcc spreads those ~25 scalar
@@ -360,8 +340,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             n_valid = true;
         }
     };
-    auto step_cursor = [&](auto piece_tag) __attribute__((always_inline)) {
-        (void)piece_tag;
+    auto step_cursor = [&]() __attribute__((always_inline)) {
         baseP = baseC;
         goff3P = L.goff[3];
         crossS = left == 1;                     // (uniform)
@@ -942,7 +921,7 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                     X3R_RB(7, bnext)
                     if (!(NG_X3R_KO & 4)) loadA(F[SRC], base, goff);
                 }
-                if (MT == 3 && P == 3) { sj ^= 1; step_cursor(std::integral_constant<int, -1>{}); }     // (the cursor's step behind the tile's last MFMAs)
+                if (MT == 3 && P == 3) { sj ^= 1; step_cursor(); }     // (the cursor's step behind the tile's last MFMAs)
             };
             static_assert(PIECES == 6, "six B pieces per wave and K-tile: two behind each of three regions");
             one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
@@ -1021,13 +1000,13 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         }
     }
     loadA(F[3], baseC, L.goff[3]);              // K-tile 0's row tile 3: converted in block 0 of tile 0
-    step_cursor(std::integral_constant<int, -1>{});      // snapshot = K-tile 0, cursor on K-tile 1
+    step_cursor();      // snapshot = K-tile 0, cursor on K-tile 1
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) loadB(i);
     loadA(F[0], baseC, L.goff[0]);
     loadA(F[1], baseC, L.goff[1]);
     loadA(F[2], baseC, L.goff[2]);
-    step_cursor(std::integral_constant<int, -1>{});      // snapshot = K-tile 1, cursor on K-tile 2: the state tile 0 expects
+    step_cursor();      // snapshot = K-tile 1, cursor on K-tile 2: the state tile 0 expects
 #ifdef NG_X3R_STAMP
     { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_last = unsigned(t_); }
 #endif

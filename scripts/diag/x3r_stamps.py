@@ -15,7 +15,7 @@ fn = be._dll.nirgan_x3r_stamps
 fn.restype, fn.argtypes = C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
-NAMES = ["block 0", "block 1", "wait + barrier", "block 2 (+DMA)", "block 3 (+B reads, cursor)", "between tiles", "epilogue set-up", "epilogue slices"]
+NAMES = ["block 0", "block 1", "wait + barrier", "block 2", "block 3 (+B reads, cursor)", "between tiles", "epilogue set-up", "epilogue slices"]
 
 def report(title):
     torch.cuda.synchronize()
