@@ -247,3 +247,82 @@ def test_x3_launches_are_bitwise_reproducible_over_many_launches():
         L.call("nirgan_conv_igemm", C.byref(d), None)
         torch.cuda.synchronize()
         assert torch.equal(y.t, first), f"launch {i} differs"
+
+
+R4_CONVS = [  # B, H, W, cin, cout, k, stride, pad, bias   (>= 192 tiles of 128 columns each: below that the library takes 64-column tiles)
+    (16, 128, 128, 64, 128, 3, 2, 1, True),    # 256 full tiles, bias
+    (6, 95, 93, 128, 256, 3, 1, 1, False),     # odd extents: a ragged last tile, two column tiles, the row walk wraps inside a lane pair
+    (13, 64, 64, 96, 128, 1, 1, 0, False),     # THREE K-tiles per item: the least the cursor supports, an item crossing in every third tile
+    (12, 64, 68, 128, 128, 1, 1, 0, True),     # four K-tiles, bias
+    (16, 192, 192, 64, 128, 3, 2, 1, False),   # 576 tiles: two or three items per workgroup, an epilogue's stores behind the next item's fetches
+    (4, 133, 101, 64, 128, 3, 1, 1, False),    # odd width and height
+]
+
+
+@pytest.mark.parametrize("case", R4_CONVS)
+def test_four_wave_split_tile_is_bitwise_the_eight_wave_tile(case):
+    """csrc/igemm_x3r.h (descriptor algo NIRGAN_CONV_X3_R4): same operands, same products, same accumulation order per output element as
+    conv_x3_persist -- the outputs are compared BITWISE, over three launches each (the persistent walk keeps fetches in flight across items)"""
+    B, H, W, cin, cout, k, s, pad, with_bias = case
+    g = torch.Generator().manual_seed(21)
+    ctx = Ctx(DEV)
+    OH, OW = G.conv_out(H, k, s, pad), G.conv_out(W, k, s, pad)
+    x = Halo(ctx, B, H, W, cin, pad)
+    x.interior().copy_(torch.randn(B, H, W, cin, generator=g).to(DEV))
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(cout, generator=g).to(DEV) if with_bias else None
+    spec = G.conv_fwd_pack(cout, cin, k)
+    wp = ctx.zeros(spec.N, spec.K)
+    ctx.keep.append(wp)
+    L.call("nirgan_pack_rows", w.data_ptr(), w.numel(), spec.row_stride, ctx.i32(spec.index_map).data_ptr(), wp.data_ptr(), spec.N, spec.K, None)
+    tw, plane = _split3(ctx, wp)
+    outs = {}
+    for algo in (0, L.CONV_X3_R4):
+        y = Halo(ctx, B, OH, OW, cout, 0)
+        d = emit_conv(None, ctx, x, G.conv_fwd_taps(k, cin), wp, bias, y, N=cout, OH=OH, OW=OW, in_stride=s, allow_split=False)
+        d.precision, d.w_x3, d.w_x3_plane, d.algo = 3, tw.data_ptr(), plane, algo
+        name = L.backend().nirgan_conv_kernel_name(C.byref(d))
+        assert name.startswith(b"conv_x3r_kernel" if algo else b"conv_x3_kernel"), name
+        for _ in range(3):
+            y.t.fill_(float("nan"))
+            L.call("nirgan_conv_igemm", C.byref(d), None)
+            torch.cuda.synchronize()
+            if algo in outs:
+                assert torch.equal(outs[algo], y.t), "a launch differs from the first one"
+            outs[algo] = y.t.clone()
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[L.CONV_X3_R4])
+    ref = torch.nn.functional.conv2d(x.t.double().permute(0, 3, 1, 2), w.double(), None if bias is None else bias.double(), stride=s).permute(0, 2, 3, 1)
+    assert _err(outs[L.CONV_X3_R4], ref)[0] < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 128, 128), (16, 64, 64, 256, 256), (3, 40, 28, 96, 256)])
+def test_four_wave_plane_gemm_is_bitwise_the_eight_wave_plane_gemm(shape):
+    """the Winograd plane batches (nirgan_wino6_desc.algo NIRGAN_W6_X3_R4): 64 planes of [T x C] x [C x K]; T = 18 leaves one partly filled
+    tile per plane, C = 96 is three K-tiles per item"""
+    B, H, W, Cc, K = shape
+    g = torch.Generator().manual_seed(22)
+    T = B * ((H + 5) // 6) * ((W + 5) // 6)
+    V = torch.randn(64 * T * Cc, generator=g).to(DEV)
+    U = (torch.randn(64 * K * Cc, generator=g) * 0.05).to(DEV)
+    zero = torch.zeros(64, device=DEV)
+    plane = 64 * K * Cc
+    U3 = torch.zeros(3 * plane, dtype=torch.bfloat16, device=DEV)
+    L.call("nirgan_split3", U.data_ptr(), U3.data_ptr(), plane, plane, None)
+    outs = {}
+    for algo in (0, L.W6_X3_R4):
+        M = torch.full((64 * T * K,), float("nan"), device=DEV)
+        d = L.Wino6Desc()
+        d.r, d.B, d.H, d.W, d.C, d.K = 6, B, H, W, Cc, K
+        d.U3, d.V, d.V_elems, d.M, d.M_elems, d.zero_page = U3.data_ptr(), V.data_ptr(), V.numel(), M.data_ptr(), M.numel(), zero.data_ptr()
+        d.algo = algo
+        name = L.backend().nirgan_wino6_gemm_kernel_name(C.byref(d))
+        assert name.startswith(b"conv_x3r_kernel" if algo else b"conv_x3_kernel"), name
+        for _ in range(2):
+            L.call("nirgan_wino6_gemm", C.byref(d), None)
+        torch.cuda.synchronize()
+        outs[algo] = M
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[L.W6_X3_R4])
+    ref = torch.bmm(V.view(64, T, Cc).double(), U.view(64, K, Cc).double().transpose(1, 2)).reshape(-1)
+    assert _err(outs[L.W6_X3_R4], ref)[0] < 2e-6
