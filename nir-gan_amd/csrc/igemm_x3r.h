@@ -325,16 +325,19 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             if constexpr (PIECE == 0) asm volatile("" : "+s"(n_cc), "+s"(n_kb), "+s"(n_ct));
         }
         if constexpr (PIECE < 0 || PIECE == 1) {
+            if constexpr (PIECE == 1) asm volatile("" : "+s"(n_ct), "+s"(n_cc));      // (... and not earlier than here: hipcc hoisted pieces 1-3 to the tile's barrier)
             const int toff = __builtin_amdgcn_readlane(L.tapv, n_ct);
             n_baseC = L.in8 + (long long)(toff + n_cc) * 4;
             if constexpr (PIECE == 1) asm volatile("" : "+s"(n_baseC));
         }
         if constexpr (PIECE < 0 || PIECE == 2) {
+            if constexpr (PIECE == 2) asm volatile("" : "+s"(n_kb));
             n_baseW[0] = L.w8[0] + n_kb;
             n_baseW[1] = L.w8[1] + n_kb;
             if constexpr (PIECE == 2) asm volatile("" : "+s"(n_baseW[0]), "+s"(n_baseW[1]));
         }
         if constexpr (PIECE < 0 || PIECE == 3) {
+            if constexpr (PIECE == 3) asm volatile("" : "+s"(n_kb));
             n_baseW[2] = L.w8[2] + n_kb;
             if constexpr (PIECE == 3) asm volatile("" : "+s"(n_baseW[2]));
             n_valid = true;
