@@ -49,12 +49,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_kernel(const ng::X3Work w) {
 
 // the same arithmetic as ONE wave per SIMD (igemm_x3r.h): four waves, wave tile 64 x BN, the activation operand split in registers and
 // never staged, the weight planes through a four-stage LDS-DMA ring, the epilogue's slices under the item's last K-tile
-template <int BN, bool GEN>
+template <int BN, int KIND>
 __global__ __launch_bounds__(256, 1) void conv_x3r_kernel(const ng::X3Work w) {
     __shared__ __attribute__((aligned(1024))) char ring[ng::X3R<BN>::RING];
     __shared__ __attribute__((aligned(16))) char stg[4 * ng::X3R<BN>::STG];
     __shared__ __attribute__((aligned(16))) char sRed[4 * (BN / 4) * 2 * 16];
-    ng::conv_x3r_persist<BN, GEN>((const NG_CONST ng::X3Work*)__builtin_amdgcn_kernarg_segment_ptr(), ring, stg, sRed);
+    ng::conv_x3r_persist<BN, KIND>((const NG_CONST ng::X3Work*)__builtin_amdgcn_kernarg_segment_ptr(), ring, stg, sRed);
 }
 
 // fp32 -> three bf16 planes h, m, l with x = h + m + l exactly (each term the RNE bf16 of what the previous ones left)
@@ -170,10 +170,15 @@ int ng::ng_launch_conv_x3(const ng::ConvParams* ps, const int n, const int bn, c
         w.spread = 1;
     }
     const dim3 grid(total < G ? total : G);
-    bool reg_fed = true, gen = false;
-    for (int i = 0; i < n; ++i) { reg_fed = reg_fed && ng::conv_x3r_ok(ps[i], bn); gen = gen || ng::conv_x3r_generic(ps[i]); }
-    if (reg_fed && gen) hipLaunchKernelGGL((conv_x3r_kernel<128, true>), grid, dim3(256), 0, st, w);
-    else if (reg_fed) hipLaunchKernelGGL((conv_x3r_kernel<128, false>), grid, dim3(256), 0, st, w);
+    bool reg_fed = true, gen = false, stats = false;
+    for (int i = 0; i < n; ++i) {
+        reg_fed = reg_fed && ng::conv_x3r_ok(ps[i], bn);
+        gen = gen || ng::conv_x3r_generic(ps[i]);
+        stats = stats || ng::conv_x3r_stats(ps[i]);
+    }
+    if (reg_fed && gen) hipLaunchKernelGGL((conv_x3r_kernel<128, 2>), grid, dim3(256), 0, st, w);
+    else if (reg_fed && stats) hipLaunchKernelGGL((conv_x3r_kernel<128, 1>), grid, dim3(256), 0, st, w);
+    else if (reg_fed) hipLaunchKernelGGL((conv_x3r_kernel<128, 0>), grid, dim3(256), 0, st, w);
     else if (bn == 128) hipLaunchKernelGGL(conv_x3_kernel<128>, grid, dim3(512), 0, st, w);
     else hipLaunchKernelGGL(conv_x3_kernel<64>, grid, dim3(512), 0, st, w);
     return nirgan_check_launch(what);

@@ -149,11 +149,14 @@ struct X3R {
 #define X3R_LA1 X3R_KA("global_load_dwordx4 %[ld1], %[lo0], %[lb] offset:16\n\t")
 #define X3R_MFMA_DRAIN asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
 
-// GEN: the launch's problems leave instance-norm partial sums or run the fused first backward pass (their epilogue branches and needs
+// KIND 2 (GEN): the launch's problems run the fused first backward pass (their epilogue branches and needs
 // the accumulators in VGPRs: a kernel of its own, so that its register pressure is not the plain kernel's)
-template <int BN, bool GEN>
+template <int BN, int KIND>
 __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp, char* const ring, char* const stg_all, char* const sRed) {
     static_assert(BN == 128 || BN == 64, "256 x 128 or 256 x 64 block tiles");
+    // KIND 0: plain problems; 1: problems that leave instance-norm partial sums (the plain kernel + the sums from the accumulators and NT
+    // stores per item); 2: the fused first backward pass (its epilogue branches per element: the C++ path)
+    constexpr bool GEN = KIND == 2, STATS = KIND == 1;
     using T = X3R<BN>;
     constexpr int NT = T::NT, B_TERM = T::B_TERM, STAGE = T::STAGE, BPT = T::BPT, PIECES = T::PIECES, LPR = T::LPR, RPP = T::RPP, SP = T::SP;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -387,20 +390,21 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // `stores_behind`: the K-tile right behind a full tile's plain epilogue -- its 4 SP = 32 output stores were issued behind every fetch
     // this tile waits for, and vmcnt counts loads and stores in one order: the waits leave them in flight (without that every item
     // would sit out the acknowledgement of the 32 KB it has just written: ~18 % of a plane GEMM's item, measured)
-    bool stores_behind = false;
+    int stores_behind = 0;                      // 0: none; 1: EST (a plain epilogue); 2: EST + NT (... and the NT stores of a statistics record)
     constexpr int EST = 4 * SP;
-    static_assert(12 + EST <= 63, "vmcnt is a six-bit counter");
+    static_assert(12 + EST + NT <= 63, "vmcnt is a six-bit counter");
     // (ONE asm statement per wait, the choice between its two counts a scalar branch INSIDE it: two statements in the arms of a C++ `if`
     // let the compiler merge the tied registers with copies in front of one of them -- copies of a destination whose load has not landed)
-#define X3R_WAITV2(N) "s_cmp_eq_u32 %[sb], 0\n\ts_cbranch_scc1 .Lx3rw%=\n\ts_waitcnt vmcnt(%[n1])\n\ts_branch .Lx3rv%=\n.Lx3rw%=:\n\ts_waitcnt vmcnt(" #N ")\n.Lx3rv%=:"
+#define X3R_WAITV2(N) "s_cmp_eq_u32 %[sb], 0\n\ts_cbranch_scc1 .Lx3rw%=\n\ts_cmp_eq_u32 %[sb], 1\n\ts_cbranch_scc1 .Lx3ru%=\n\ts_waitcnt vmcnt(%[n2])\n\ts_branch .Lx3rv%=\n" \
+                      ".Lx3ru%=:\n\ts_waitcnt vmcnt(%[n1])\n\ts_branch .Lx3rv%=\n.Lx3rw%=:\n\ts_waitcnt vmcnt(" #N ")\n.Lx3rv%=:"
     // (only an item's FIRST K-tile can have stores behind its fetches: the steady tile's waits are plain counts, no compare and branch --
     // five waits per tile, four instructions each, every one of them paid in full with one wave per SIMD)
     auto wait_raw = [&](f32x4 (&f)[2], auto n_tag, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         if constexpr (FIRST) {
-            const int sb = __builtin_amdgcn_readfirstlane(stores_behind ? 1 : 0);
-            if constexpr (decltype(n_tag)::value == 12) asm volatile(X3R_WAITV2(12) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(12 + EST) : "memory", "scc");
-            else asm volatile(X3R_WAITV2(6) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
+            const int sb = __builtin_amdgcn_readfirstlane(stores_behind);
+            if constexpr (decltype(n_tag)::value == 12) asm volatile(X3R_WAITV2(12) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(12 + EST), [n2] "n"(12 + EST + NT) : "memory", "scc");
+            else asm volatile(X3R_WAITV2(6) : "+v"(f[0]), "+v"(f[1]) : [sb] "s"(sb), [n1] "n"(6 + EST), [n2] "n"(6 + EST + NT) : "memory", "scc");
         } else {
             if constexpr (decltype(n_tag)::value == 12) asm volatile("s_waitcnt vmcnt(12)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
@@ -588,25 +592,33 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     // slice mt: the wave's rows 16 mt .. 16 mt + 15.  The instance-norm partial sums (nirgan_conv_desc.stats_ws) are taken from the
     // accumulators as they stand (the contract and the order of conv_x3_persist: per column {k = the chunk's first row, sum (v - k),
     // sum (v - k)^2, 64} over the wave's 64 rows), the rows then go through the staging block and leave 16 bytes per lane
+    // the instance-norm partial sums of slice mt from the accumulators as they stand: per column sum (v - k), sum (v - k)^2 over the lane's
+    // four rows, rows in order (the contract and the order of conv_x3_persist).  ONE asm statement per column tile, straight from the
+    // accumulator registers: written in C++ hipcc reads all 128 accumulators of an item into VGPRs up front -- loop-carried values went
+    // to scratch, and every reload behind the epilogue's stores is a `s_waitcnt vmcnt(0)` that sits out their acknowledgement
+    auto stats_acc = [&](Epi& e, auto mt_tag) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mt_tag)::value;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (mt == 0) {
+                e.k0[nt] = __shfl(acc[0][nt][0], lane & 15, 64);
+                e.t1[nt] = 0.f;
+                e.t2[nt] = 0.f;
+            }
+            const f32x4 c = acc[mt][nt];
+            const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+            float tmp;
+            asm volatile("v_accvgpr_read_b32 %[t], %[c0]\n\tv_sub_f32 %[t], %[t], %[k]\n\tv_add_f32 %[s1], %[s1], %[t]\n\tv_fmac_f32 %[s2], %[t], %[t]\n\t"
+                         "v_accvgpr_read_b32 %[t], %[c1]\n\tv_sub_f32 %[t], %[t], %[k]\n\tv_add_f32 %[s1], %[s1], %[t]\n\tv_fmac_f32 %[s2], %[t], %[t]\n\t"
+                         "v_accvgpr_read_b32 %[t], %[c2]\n\tv_sub_f32 %[t], %[t], %[k]\n\tv_add_f32 %[s1], %[s1], %[t]\n\tv_fmac_f32 %[s2], %[t], %[t]\n\t"
+                         "v_accvgpr_read_b32 %[t], %[c3]\n\tv_sub_f32 %[t], %[t], %[k]\n\tv_add_f32 %[s1], %[s1], %[t]\n\tv_fmac_f32 %[s2], %[t], %[t]"
+                         : [t] "=&v"(tmp), [s1] "+v"(e.t1[nt]), [s2] "+v"(e.t2[nt]) : [c0] "a"(c0), [c1] "a"(c1), [c2] "a"(c2), [c3] "a"(c3), [k] "v"(e.k0[nt]));
+        }
+    };
     auto slice = [&](Epi& e, auto mt_tag, auto mode_tag) __attribute__((always_inline)) {
         constexpr int mt = decltype(mt_tag)::value;
         constexpr bool PLAIN = decltype(mode_tag)::value == 1;          // no statistics, no fused pass: straight-line code (it is interleaved with MFMAs)
-        if (!PLAIN && e.stats) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if constexpr (mt == 0) {
-                    e.k0[nt] = __shfl(acc[0][nt][0], lane & 15, 64);
-                    e.t1[nt] = 0.f;
-                    e.t2[nt] = 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = acc[mt][nt][r] - e.k0[nt];
-                    e.t1[nt] += v;
-                    e.t2[nt] += v * v;
-                }
-            }
-        }
+        if (!PLAIN && e.stats) stats_acc(e, mt_tag);
         if constexpr (PLAIN) {
             // the staging traffic in inline asm with its own waits (compiler-visible LDS accesses next to hand-counted ones get a full
             // drain in front of them): 32 ds_write_b32 -- rows 4 apart of one column per instruction: two lanes per bank, free on a
@@ -754,9 +766,9 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         };
         // S with the NEXT slice's W woven in, a column block behind every store (NEXT < 4): the LDS store path and the global store
         // path each move 32 KB per wave and slice -- back to back they add up, alternating they overlap
-        auto S = [&](auto next_tag, f32x4 (&vv)[SP]) __attribute__((always_inline)) {
-            constexpr int NEXT = decltype(next_tag)::value;
-            int ooff[SP];
+        // the byte offsets of a slice's eight row segments (in front of the slice's reads: nothing but the wait stands between the reads
+        // and the stores -- and no branch, which scripts/check_x3_asm.py's linear walk could not follow)
+        auto Aoff = [&](int (&ooff)[SP]) __attribute__((always_inline)) {
             if (s_ow + 16 <= s_OW) {
                 // the slice stays inside one image row: the lane's rows are d0 bytes apart
 #pragma unroll
@@ -791,6 +803,9 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                 s_ow += 16;
                 s_ow -= s_ow >= s_OW ? s_OW : 0;    // (host: OW >= 16 for this kernel's problems, see conv_x3r_ok)
             }
+        };
+        auto S = [&](auto next_tag, f32x4 (&vv)[SP], const int (&ooff)[SP]) __attribute__((always_inline)) {
+            constexpr int NEXT = decltype(next_tag)::value;
             // the slice's reads have landed (behind them at most the 16 stores of the next slice's W: lgkmcnt counts to 15, the LDS
             // pipe returns in order -- all but the 15 youngest done means every read done)
             if constexpr (false) {
@@ -816,20 +831,46 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
                 if (!(NG_X3R_KO & 64)) asm volatile("global_store_dwordx4 %1, %0, %2" : "+v"(vv[pass]) : "v"(oo), "s"(ob) : "memory");
                 if constexpr (NEXT < 4) stage_w(next_tag, pass);
             }
-            asm volatile("s_nop 1" ::: "memory");
+            // (the segments stay LIVE up to here: "+v" alone lets hipcc hand a store's data register to the next value at once -- seen under
+            // register pressure: a v_or_b32 of an address one wait state behind the store that still had to read the register)
+            asm volatile("s_nop 1" :: "v"(vv[0]), "v"(vv[1]), "v"(vv[2]), "v"(vv[3]), "v"(vv[4 % SP]), "v"(vv[5 % SP]), "v"(vv[6 % SP]), "v"(vv[7 % SP]) : "memory");
         };
         using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>; using J3 = std::integral_constant<int, 3>;
         using J4 = std::integral_constant<int, 4>;
         // (slice 0 is in the staging block already: written in front of the epilogue's set-up, whose ~400 cycles of address arithmetic and
         // scalar loads then run beside the LDS writes)
-        R(J0{}, v0); S(J1{}, v0);             // (the reads are waited for with lgkmcnt(0): nothing is behind them yet)
-        R(J1{}, v1); S(J2{}, v1);
+        int oo[SP];
+        Aoff(oo); R(J0{}, v0); S(J1{}, v0, oo);             // (the reads are waited for with lgkmcnt(0): nothing is behind them yet)
+        Aoff(oo); R(J1{}, v1); S(J2{}, v1, oo);
         // the item behind the next one is looked up and its loader state prepared HERE: ~1 100 cycles, most of them latency of dependent
         // scalar loads, while the store path works off the 16 stores just issued (a CU takes 33 B per cycle, scripts/diag/x3r_knockout.sh:
         // the epilogue's time is that of its 128 KB of stores)
         mid();
-        R(J2{}, v0); S(J3{}, v0);
-        R(J3{}, v1); S(J4{}, v1);
+        Aoff(oo); R(J2{}, v0); S(J3{}, v0, oo);
+        Aoff(oo); R(J3{}, v1); S(J4{}, v1, oo);
+    };
+    // the wave's statistics record of its 64 rows as NT store instructions: lane (field = lane >> 4, column = lane & 15) writes field
+    // {k, sum (v - k), sum (v - k)^2, 64} of its column (the four fields are pC floats apart; every lane holds every sum after the two
+    // shuffles).  (The full tiles' fast path: their number is part of the next item's counted waits)
+    auto stats_flush = [&](Epi& e) __attribute__((always_inline)) {
+        const NG_CONST ConvParams& p = *E.p;
+        const int b = e.mbase / e.OHW;
+        float* sp = p.stats + (size_t(b) * p.stats_cps + p.stats_chunk0 + ((e.mbase - b * e.OHW) >> 6) * e.span) * 4 * e.pC;
+        const char* const sb8 = ng_uniform_ptr(reinterpret_cast<const char*>(sp));
+        const int field = lane >> 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s1 = e.t1[nt], s2 = e.t2[nt];
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            int col = E.n0 + nt * 16 + (lane & 15);
+            if (col >= e.pC) col += 3 * e.pC;
+            const float val = field == 0 ? e.k0[nt] : (field == 1 ? s1 : (field == 2 ? s2 : 64.f));
+            const unsigned so = unsigned(field * e.pC + col) * 4u;
+            asm volatile("global_store_dword %0, %1, %2" :: "v"(so), "v"(val), "s"(sb8) : "memory");
+        }
     };
     auto epi_finish = [&](Epi& e) {
         const NG_CONST ConvParams& p = *E.p;
@@ -900,9 +941,9 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
             if (MT == 0) {
                 // K-tile j + 1's pieces of B have landed (fetched in block 1 of the previous tile)
                 if constexpr (decltype(first_tag)::value) {
-                    const int sb = __builtin_amdgcn_readfirstlane(stores_behind ? 1 : 0);
-                    if (PIECES == 6) asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
-                    else asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) : [sb] "s"(sb), [n1] "n"(6 + EST) : "memory", "scc");
+                    const int sb = __builtin_amdgcn_readfirstlane(stores_behind);
+                    if (PIECES == 6) asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) : [sb] "s"(sb), [n1] "n"(6 + EST), [n2] "n"(6 + EST + NT) : "memory", "scc");
+                    else asm volatile(X3R_WAITV2(6) : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) : [sb] "s"(sb), [n1] "n"(6 + EST), [n2] "n"(6 + EST + NT) : "memory", "scc");
                 } else {
                     if (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) :: "memory");
                     else asm volatile("s_waitcnt vmcnt(6)" : "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]) :: "memory");
@@ -1020,22 +1061,33 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
     while (true) {
         // (the item's first K-tile starts its accumulators: C = 0 in the first product of each -- nothing zeroes them in between)
         tile(std::true_type{});
-        stores_behind = false;
+        stores_behind = 0;
         for (int k = 1; k < nkC; ++k) tile(std::false_type{});
         X3R_STAMP(9)
         X3R_MFMA_DRAIN;                          // the last MFMAs' results are in the accumulators
         Epi e;
         bool full = false;
-        if constexpr (!GEN) {
+        if constexpr (KIND == 0) {
             full = E.m0 + 256 <= E.p->M;             // a full tile: every one of its 32 store instructions is issued
             if (full) stage_w(I0{});
         }
         epi_begin(e);
         X3R_STAMP(6)
         if constexpr (!GEN) {
-            if (full) {                 // a full tile: every one of its 32 store instructions is issued
+            bool st = false;
+            if constexpr (STATS) {
+                // the wave's statistics record from the accumulators as they stand -- arithmetic, then NT stores -- in front of the
+                // plain epilogue.  (Through the branching C++ path of KIND 2 every slice's stores were followed by reloads of spilled
+                // registers, each behind a `s_waitcnt vmcnt(0)` that sat out the stores' acknowledgement: ~30 000 cycles per item
+                // against the plain epilogue's 6 000 -- short-K launches with statistics lost on it)
+                full = E.m0 + 256 <= e.pM;
+                st = e.stats;
+                if (st) { stats_acc(e, I0{}); stats_acc(e, I1{}); stats_acc(e, I2{}); stats_acc(e, I3{}); stats_flush(e); }
+                if (full) stage_w(I0{});
+            }
+            if (full) {
                 if (E.p->bias != nullptr) epilogue_full(e, std::true_type{}, prepare_next); else epilogue_full(e, std::false_type{}, prepare_next);
-                stores_behind = true;
+                stores_behind = st ? 2 : 1;
             } else {
                 slice(e, I0{}, I1{});
                 slice(e, I1{}, I1{});
@@ -1082,7 +1134,8 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
 #undef X3R_VALU
 #undef X3R_DSR
 
-inline bool conv_x3r_generic(const ConvParams& p) { return p.stats != nullptr || p.f_y != nullptr; }
+inline bool conv_x3r_generic(const ConvParams& p) { return p.f_y != nullptr; }
+inline bool conv_x3r_stats(const ConvParams& p) { return p.stats != nullptr; }
 // whether the register-fed tile takes a launch the split tile covers (host): 128-column tiles, asked for by the descriptor (A/B switch)
 // (problems whose epilogue leaves statistics / runs the fused pass -- the branching epilogue is not overlapped and not tuned -- only from
 // 24 K-tiles on: measured inside the step, profiles/r06_x3r_per_op_ab.txt -- 1.04-1.14 x from 32 K-tiles, 0.68-0.91 x at 7-18)

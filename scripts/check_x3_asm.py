@@ -25,8 +25,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "nir-gan_amd", "csrc", "igemm_conv.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 KERNELS = {                                     # substring of the mangled name -> (label, spills allowed)
-    "conv_x3r_kernelILi128ELb0": ("conv_x3r_kernel<128, plain>", False),
-    "conv_x3r_kernelILi128ELb1": ("conv_x3r_kernel<128, statistics / fused pass>", True),
+    "conv_x3r_kernelILi128ELi0E": ("conv_x3r_kernel<128, plain>", False),
+    "conv_x3r_kernelILi128ELi1E": ("conv_x3r_kernel<128, statistics>", False),
+    "conv_x3r_kernelILi128ELi2E": ("conv_x3r_kernel<128, fused pass>", True),
     "conv_x3_kernelILi128": ("conv_x3_kernel<128>", True),
     "conv_x3_kernelILi64": ("conv_x3_kernel<64>", True),
 }
