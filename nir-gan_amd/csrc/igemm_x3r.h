@@ -1065,6 +1065,14 @@ __device__ __forceinline__ void conv_x3r_persist(const NG_CONST X3Work* const wp
         for (int k = 1; k < nkC; ++k) tile(std::false_type{});
         X3R_STAMP(9)
         X3R_MFMA_DRAIN;                          // the last MFMAs' results are in the accumulators
+        if constexpr (GEN) {
+            // KIND 2's epilogue is C++ under register pressure: hipcc spills and reloads what it likes, and it believes the raw row sets
+            // and B pieces -- the next item's fetches, in flight -- valid.  One drain per item makes them so before it touches anything
+            // (the other kinds' epilogues keep no value in scratch; scripts/check_x3_asm.py)
+            static_assert(PIECES == 6, "six raw B pieces per wave");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[2][0]), "+v"(F[2][1]), "+v"(F[3][0]), "+v"(F[3][1]),
+                         "+v"(Braw[0]), "+v"(Braw[1]), "+v"(Braw[2]), "+v"(Braw[3 % PIECES]), "+v"(Braw[4 % PIECES]), "+v"(Braw[5 % PIECES]) :: "memory");
+        }
         Epi e;
         bool full = false;
         if constexpr (KIND == 0) {
