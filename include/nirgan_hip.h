@@ -137,7 +137,7 @@ typedef struct {
 } nirgan_conv_desc;
 #define NIRGAN_CONV_TILE128 1
 #define NIRGAN_CONV_X3_BN64 3   /* precision 3: the 256 x 64 block tile also where 256 x 128 applies (A/B) */
-#define NIRGAN_CONV_X3_R4 4     /* precision 3, N % 128 == 0: the four-wave register-fed tile of igemm_x3r.h instead of the eight-wave tile (A/B; same bits) */
+#define NIRGAN_CONV_X3_R4 4     /* precision 3, N % 128 == 0: the four-wave register-fed tile of igemm_x3r.h instead of the eight-wave tile (A/B; same output bits) */
 #define NIRGAN_CONV_TILE256 2   /* exact-fp32 problems (N % 256 == 0, run % 32 == 0, >= 128 tiles) on the 256-wide tile too (A/B: within 1 % of the 128-row tile) */
 
 int nirgan_conv_igemm(const nirgan_conv_desc* d, void* stream);
